@@ -1,0 +1,204 @@
+/*
+ * orbhip.h -- C ABI of the MI355X-native ORB front-end + local-BA solver.
+ *
+ * This is the drop-in boundary: plain pointers and sizes,
+ * no C++ / torch / OpenCV types.  Every entry point cites the reference interface
+ * it replaces (paths relative to the reference repo root).  Status codes: 0 = ok,
+ * negative = error (never throws; see ORBHIP_E_*).  All entry points are thread-safe
+ * across distinct contexts; one context = one HIP stream + its own device scratch
+ * (mirrors "one ORBextractor instance per thread", src/Frame.cc:109-110).
+ *
+ * The library REQUIRES a gfx950 device: there is no CPU fallback.  orbhip_ctx_create
+ * fails with ORBHIP_E_NODEVICE when no HIP device is present.
+ */
+#ifndef ORBHIP_H
+#define ORBHIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBHIP_OK 0
+#define ORBHIP_E_BADARG (-1)
+#define ORBHIP_E_NODEVICE (-2)
+#define ORBHIP_E_HIP (-3)        /* a HIP runtime call failed; see orbhip_last_error() */
+#define ORBHIP_E_CAPACITY (-4)   /* a device-side list overflowed its reserved capacity */
+#define ORBHIP_E_ABORTED (-5)    /* BA: stop flag raised (Optimizer.cc:2041-2043) */
+#define ORBHIP_E_NOTSPD (-6)     /* BA: reduced system not SPD on every LM trial */
+#define ORBHIP_E_EMPTY (-7)      /* extractor: empty image (ORBextractor.cc:1072-1073 returns -1) */
+
+/* cv::KeyPoint layout (28 B): what ORBextractor::operator() fills (ORBextractor.cc:1100). */
+typedef struct {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} orbhip_keypoint;
+
+typedef struct orbhip_ctx orbhip_ctx;
+typedef struct orbhip_extractor orbhip_extractor;
+
+const char *orbhip_version(void);
+const char *orbhip_last_error(void);
+
+/* Device context.  `stream` may be NULL (the library creates its own non-blocking
+ * stream) or an existing hipStream_t (e.g. torch's current stream) which is borrowed. */
+int orbhip_ctx_create(int device, void *stream, orbhip_ctx **out);
+void orbhip_ctx_destroy(orbhip_ctx *ctx);
+int orbhip_ctx_synchronize(orbhip_ctx *ctx);
+void *orbhip_ctx_stream(orbhip_ctx *ctx);
+
+/* ------------------------------------------------------------------ ORB extractor */
+/* Replaces ORBextractor::ORBextractor(int nfeatures, float scaleFactor, int nlevels,
+ *   int iniThFAST, int minThFAST)            include/ORBextractor.h:54, src/ORBextractor.cc:408 */
+int orbhip_extractor_create(orbhip_ctx *ctx, int nfeatures, float scale_factor, int nlevels,
+                            int ini_th_fast, int min_th_fast, orbhip_extractor **out);
+void orbhip_extractor_destroy(orbhip_extractor *ext);
+
+/* GetLevels / GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
+ * GetInverseScaleSigmaSquares                 include/ORBextractor.h:61-79
+ * which: 0 scale, 1 inv scale, 2 sigma2, 3 inv sigma2.  out[nlevels]. */
+int orbhip_extractor_levels(const orbhip_extractor *ext);
+int orbhip_extractor_table(const orbhip_extractor *ext, int which, float *out);
+/* mnFeaturesPerLevel (ORBextractor.cc:434-445) and umax (ORBextractor.cc:453-468). */
+int orbhip_extractor_features_per_level(const orbhip_extractor *ext, int *out);
+int orbhip_extractor_umax(const orbhip_extractor *ext, int *out16);
+
+/* Reserve device memory for batches of up to max_batch frames of width x height.
+ * Called implicitly by the extract calls; explicit call keeps allocation out of timed code. */
+int orbhip_extractor_reserve(orbhip_extractor *ext, int width, int height, int max_batch);
+/* Upper bound of keypoints per frame (row capacity of the output arrays). */
+int orbhip_extractor_max_keypoints(const orbhip_extractor *ext);
+
+/* Batched ORBextractor::operator()           include/ORBextractor.h:57-59, ORBextractor.cc:1068
+ * d_images: DEVICE pointer, u8, frame f at d_images + f*frame_stride, rows at row_stride.
+ * Results stay on the device (see orbhip_extractor_results).  lap0/lap1 = vLappingArea.
+ * Asynchronous on the context's stream. */
+int orbhip_extract_batch_device(orbhip_extractor *ext, const uint8_t *d_images, int width,
+                                int height, size_t row_stride, size_t frame_stride, int batch,
+                                int lap0, int lap1);
+/* Device result arrays of the last batch: kp[batch][max_kp], desc[batch][max_kp][32],
+ * count[batch] (nkeypoints), mono_index[batch] (operator()'s return value). */
+int orbhip_extractor_results(orbhip_extractor *ext, orbhip_keypoint **d_kp, uint8_t **d_desc,
+                             int32_t **d_count, int32_t **d_mono_index);
+/* Host convenience == one ORBextractor::operator() call per frame: H2D, extract, D2H, sync.
+ * kp_out[batch][cap], desc_out[batch][cap][32], count_out[batch], mono_out[batch].
+ * Returns ORBHIP_E_EMPTY for an empty image, ORBHIP_E_CAPACITY if cap < keypoints. */
+int orbhip_extract_batch_host(orbhip_extractor *ext, const uint8_t *h_images, int width, int height,
+                              size_t row_stride, size_t frame_stride, int batch, int lap0, int lap1,
+                              orbhip_keypoint *kp_out, uint8_t *desc_out, int cap,
+                              int32_t *count_out, int32_t *mono_out);
+
+/* mvImagePyramid[level] of frame `frame` (include/ORBextractor.h:83; read by
+ * src/Frame.cc:809,899,913,918).  padded != 0 -> the (w+38)x(h+38) reflect-101 parent
+ * buffer, else the w x h ROI.  Synchronous D2H. */
+int orbhip_extractor_level_dims(const orbhip_extractor *ext, int level, int *w, int *h);
+int orbhip_extractor_get_pyramid_level(orbhip_extractor *ext, int frame, int level, int padded,
+                                       uint8_t *h_out, size_t out_stride);
+/* Parity taps (test hooks; synchronous D2H of intermediate stages of the last batch). */
+int orbhip_extractor_get_blurred_level(orbhip_extractor *ext, int frame, int level,
+                                       uint8_t *h_out, size_t out_stride);
+/* Pre-octree FAST candidates in reference emission order; x,y relative to (16,16). */
+int orbhip_extractor_get_fast_candidates(orbhip_extractor *ext, int frame, int level,
+                                         int32_t *xs, int32_t *ys, int32_t *scores, int cap,
+                                         int32_t *n_out);
+/* Post-octree keypoints of one level (level coords, angle set, not scaled), list order. */
+int orbhip_extractor_get_level_keypoints(orbhip_extractor *ext, int frame, int level,
+                                         orbhip_keypoint *out, int cap, int32_t *n_out);
+
+/* Per-stage device time (ms) of the last extract call, measured with hipEvents recorded on
+ * the context's stream when profiling is enabled.  Stage ids: ORBHIP_STAGE_*. */
+#define ORBHIP_STAGE_PYRAMID 0
+#define ORBHIP_STAGE_FAST 1
+#define ORBHIP_STAGE_OCTREE 2
+#define ORBHIP_STAGE_BLUR 3
+#define ORBHIP_STAGE_DESC 4
+#define ORBHIP_STAGE_ASSEMBLE 5
+#define ORBHIP_STAGE_COUNT 6
+int orbhip_extractor_set_profiling(orbhip_extractor *ext, int enable);
+int orbhip_extractor_stage_ms(orbhip_extractor *ext, float *ms_out /*[ORBHIP_STAGE_COUNT]*/);
+
+/* ------------------------------------------------------------------ ORB matcher */
+/* ORBmatcher::DescriptorDistance(const cv::Mat&, const cv::Mat&)
+ *                                            include/ORBmatcher.h:45, src/ORBmatcher.cc:2353
+ * Host-callable scalar (two 32-byte descriptors). */
+int orbhip_descriptor_distance(const uint8_t *a32, const uint8_t *b32);
+
+/* Batched all-pairs 2-NN == cv::BFMatcher(NORM_HAMMING).knnMatch(k=2) as used by
+ * Frame::ComputeStereoFishEyeMatches          src/Frame.cc:43,1146-1153
+ * For pair p: queries d_descA + p*strideA (nA[p] rows), train d_descB + p*strideB (nB[p] rows).
+ * Outputs per query row: idx[2], dist[2] (ascending; strict <, lowest index wins ties;
+ * idx -1 / dist INT_MAX when fewer than k train rows) and ratio-test flag
+ * (float)d0 < (float)d1*ratio evaluated in double as in Frame.cc:1153 (ratio there: 0.7).
+ * Row q of pair p lands at [p*max_n + q].  All pointers DEVICE. */
+int orbhip_match_bf2nn_device(orbhip_ctx *ctx, const uint8_t *d_descA, const int32_t *d_nA,
+                              size_t strideA, const uint8_t *d_descB, const int32_t *d_nB,
+                              size_t strideB, int pairs, int max_n, double ratio,
+                              int32_t *d_idx2, int32_t *d_dist2, uint8_t *d_accept);
+
+/* Batched ORBmatcher::SearchForInitialization(F1,F2,vbPrevMatched,vnMatches12,windowSize)
+ *                                            include/ORBmatcher.h:66, src/ORBmatcher.cc:710-825
+ * including Frame::AssignFeaturesToGrid / GetFeaturesInArea semantics
+ *                                            src/Frame.cc:377-408,645-726
+ * Pair p matches frame A_p against frame B_p.  kp arrays are the extractor's device
+ * outputs (row capacity max_n).  d_prev_matched[pairs][max_n][2] (float x,y) is in/out
+ * (vbPrevMatched); d_matches12[pairs][max_n] out; d_nmatches[pairs] out (return value).
+ * Grid bounds = image bounds (mnMinX..mnMaxX of an undistorted-free camera). */
+int orbhip_search_for_initialization_device(orbhip_ctx *ctx,
+        const orbhip_keypoint *d_kpA, const uint8_t *d_descA, const int32_t *d_nA,
+        const orbhip_keypoint *d_kpB, const uint8_t *d_descB, const int32_t *d_nB,
+        int pairs, int max_n, size_t frame_stride_kp /*entries*/, float min_x, float min_y,
+        float max_x, float max_y, int window_size, float nn_ratio, int check_orientation,
+        float *d_prev_matched, int32_t *d_matches12, int32_t *d_nmatches);
+
+/* ------------------------------------------------------------------ local BA */
+/* One keyframe-window graph in SoA form: what Optimizer::LocalBundleAdjustment builds
+ * between src/Optimizer.cc:1850 and :2034.  Poses world->camera as (qx,qy,qz,qw,tx,ty,tz)
+ * doubles (g2o::SE3Quat, Thirdparty/g2o/g2o/types/se3quat.h:41); points xyz doubles.
+ * Edges are sorted by point (insertion order of Optimizer.cc:1940-2034 == point-major). */
+typedef struct {
+    int32_t n_poses;            /* free + fixed keyframes */
+    int32_t n_points;
+    int32_t n_edges;
+    const uint8_t *pose_fixed;  /* [n_poses] 1 = fixed (lFixedCameras, Optimizer.cc:1877-1903) */
+    const int32_t *edge_pose;   /* [n_edges] */
+    const int32_t *edge_point;  /* [n_edges] non-decreasing */
+    const double *edge_obs;     /* [n_edges][3]  u,v,(ur; unused for mono) */
+    const double *edge_inv_sigma2; /* [n_edges]  mvInvLevelSigma2[octave] */
+    const uint8_t *edge_stereo; /* [n_edges] 0 = EdgeSE3ProjectXYZ, 1 = EdgeStereoSE3ProjectXYZ */
+    double fx, fy, cx, cy, bf;  /* Pinhole intrinsics (Pinhole.cpp:41-47) + stereo baseline*fx */
+} orbhip_ba_graph;
+
+typedef struct {
+    int32_t iters1, iters2;     /* optimize(5) then optimize(10): Optimizer.cc:2048,2122 */
+    double huber_mono2, huber_stereo2;   /* 5.991, 7.815 (Optimizer.cc:1910-1911) */
+    double user_lambda_init;    /* 0 -> tau*max diag (levenberg.cpp:171-185); 100 if inertial */
+    double tau;                 /* 1e-50 (levenberg.cpp:47) */
+    int32_t max_trials;         /* 100 (levenberg.cpp:51) */
+} orbhip_ba_params;
+
+typedef struct {
+    int32_t iterations_run[2];  /* outer iterations executed in pass 1 / pass 2 */
+    int32_t lm_trials;          /* total inner trials */
+    int32_t n_outliers;         /* chi2 > gate or depth <= 0 (Optimizer.cc:2126-2173) */
+    int32_t discarded;          /* 1 if >= 50 % outliers (Optimizer.cc:2177-2181): no write-back */
+    double chi2_initial, chi2_final;
+} orbhip_ba_stats;
+
+void orbhip_ba_default_params(orbhip_ba_params *p);
+
+/* The numerical core of Optimizer::LocalBundleAdjustment(KeyFrame*, bool* pbStopFlag, Map*, int&)
+ *                                            include/Optimizer.h:58, src/Optimizer.cc:1699-2344
+ * i.e. initializeOptimization + optimize(5) + initializeOptimization(0) + optimize(10) +
+ * outlier classification, on `n_graphs` independent graphs at once.  Host pointers in the
+ * graph structs; poses_inout[g] = double[n_poses*7], points_inout[g] = double[n_points*3]
+ * (updated in place unless discarded), edge_outlier_out[g] = uint8[n_edges] (may be NULL),
+ * abort = LocalMapping::mbAbortBA (polled between iterations and LM trials; may be NULL). */
+int orbhip_ba_solve_batch(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_graphs,
+                          const orbhip_ba_params *params, volatile const uint8_t *abort,
+                          double *const *poses_inout, double *const *points_inout,
+                          uint8_t *const *edge_outlier_out, orbhip_ba_stats *stats_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,77 @@
+// Internal structures shared by the ORB kernels and the C-ABI implementation.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/orbhip.h"
+
+#define ORB_MAX_LEVELS 16
+#define ORB_EDGE 19           // EDGE_THRESHOLD  (ORBextractor.cc:72)
+#define ORB_MINB 16           // minBorder = EDGE_THRESHOLD-3 (ORBextractor.cc:771)
+#define ORB_HALF_PATCH 15
+
+// One pyramid level, batched: frame f lives at img + f*frame_stride, rows at pitch.
+struct OrbLevel {
+    uint8_t *img;             // un-padded level image (level 0 may alias the caller's input)
+    uint8_t *blur;            // 7x7 sigma-2 blurred level
+    size_t img_frame_stride;
+    size_t blur_frame_stride;
+    int w, h, img_pitch, blur_pitch;
+    // FAST cell grid (ORBextractor.cc:774-781)
+    int ncols, nrows, wcell, hcell;
+    int cell_base;            // first cell of this level in the per-frame cell array
+    int cell_cap;             // entries per cell list
+    // octree
+    int quota;                // mnFeaturesPerLevel[level]
+    int key_base, key_cap;    // ordered-candidate scratch slice (per frame)
+    int kp_base, kp_cap;      // per-level keypoint staging slice (per frame)
+    int n_ini;                // nIni (ORBextractor.cc:541)
+    float hx;                 // hX   (ORBextractor.cc:543)
+    float scale;              // mvScaleFactor[level]
+    float size;               // (int)(PATCH_SIZE*scale) as float (ORBextractor.cc:862)
+    // resize tables (device): xofs[w], xalpha[2w], yofs[h], ybeta[2h]  (level>0)
+    const int16_t *xofs; const int16_t *xalpha; const int16_t *yofs; const int16_t *ybeta;
+};
+
+struct OrbParams {
+    OrbLevel lv[ORB_MAX_LEVELS];
+    int nlevels, batch;
+    int ini_th, min_th;
+    int cells_per_frame;      // sum over levels of ncols*nrows
+    int keys_per_frame;       // sum of key_cap
+    int kps_per_frame;        // sum of kp_cap  (== staging slots per frame)
+    int max_kp;               // output row capacity per frame
+    int lap0, lap1;
+    // per-frame scratch
+    uint32_t *cell_count;     // [batch][cells_per_frame]
+    uint32_t *cell_list;      // [batch][sum(cells*cell_cap)]  packed x | y<<12 | score<<24
+    size_t cell_list_frame_stride;
+    uint32_t *keys;           // [batch][keys_per_frame] ordered candidates (packed)
+    uint16_t *node_of;        // [batch][keys_per_frame]
+    uint32_t *lvl_kp;         // [batch][kps_per_frame] selected keypoints (packed)
+    float *lvl_angle;         // [batch][kps_per_frame]
+    uint8_t *lvl_desc;        // [batch][kps_per_frame][32]
+    int32_t *lvl_count;       // [batch][nlevels]   post-octree count
+    int32_t *lvl_ncand;       // [batch][nlevels]   pre-octree count
+    int32_t *status;          // [1] sticky error flag (capacity overflow)
+    // outputs
+    orbhip_keypoint *out_kp;  // [batch][max_kp]
+    uint8_t *out_desc;        // [batch][max_kp][32]
+    int32_t *out_count;       // [batch]
+    int32_t *out_mono;        // [batch]
+    int umax[ORB_HALF_PATCH + 1];
+    int gauss_q8[7];
+};
+
+#define ORB_PACK_KEY(x, y, s) ((uint32_t)(x) | ((uint32_t)(y) << 12) | ((uint32_t)(s) << 24))
+#define ORB_KEY_X(k) ((int)((k) & 0xFFFu))
+#define ORB_KEY_Y(k) ((int)(((k) >> 12) & 0xFFFu))
+#define ORB_KEY_S(k) ((int)((k) >> 24))
+
+// kernel launchers (orb_kernels.hip)
+void orb_launch_resize(const OrbParams &P, int level, hipStream_t s);
+void orb_launch_fast(const OrbParams &P, hipStream_t s);
+void orb_launch_octree(const OrbParams &P, hipStream_t s);
+void orb_launch_blur(const OrbParams &P, hipStream_t s);
+void orb_launch_orient_desc(const OrbParams &P, hipStream_t s);
+void orb_launch_assemble(const OrbParams &P, hipStream_t s);
+size_t orb_octree_lds_bytes(int max_quota);

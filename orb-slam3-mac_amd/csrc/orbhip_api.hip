@@ -1,0 +1,516 @@
+// orbhip_api.hip -- C-ABI implementation: context + ORB extractor (include/orbhip.h).
+// Host logic mirrors ORBextractor's constructor / ComputePyramid bookkeeping
+// (reference src/ORBextractor.cc:408-468, 1152-1177) and owns all device memory.
+#include "orb_internal.h"
+#include <cmath>
+#include <cfloat>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <mutex>
+
+static thread_local std::string g_last_error;
+extern "C" const char *orbhip_last_error(void) { return g_last_error.c_str(); }
+extern "C" const char *orbhip_version(void) { return "orbhip 0.1 (gfx950)"; }
+
+#define HIP_TRY(expr)                                                                   \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            g_last_error = std::string(#expr) + ": " + hipGetErrorString(_e);           \
+            return ORBHIP_E_HIP;                                                        \
+        }                                                                               \
+    } while (0)
+
+struct orbhip_ctx {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+};
+
+extern "C" int orbhip_ctx_create(int device, void *stream, orbhip_ctx **out)
+{
+    if (!out) return ORBHIP_E_BADARG;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0 || device < 0 || device >= n) {
+        g_last_error = "no HIP device (this library has no CPU fallback)";
+        return ORBHIP_E_NODEVICE;
+    }
+    HIP_TRY(hipSetDevice(device));
+    orbhip_ctx *c = new orbhip_ctx();
+    c->device = device;
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else {
+        hipError_t e2 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e2 != hipSuccess) { delete c; g_last_error = hipGetErrorString(e2); return ORBHIP_E_HIP; }
+        c->own_stream = true;
+    }
+    *out = c;
+    return ORBHIP_OK;
+}
+extern "C" void orbhip_ctx_destroy(orbhip_ctx *c)
+{
+    if (!c) return;
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+extern "C" int orbhip_ctx_synchronize(orbhip_ctx *c)
+{
+    if (!c) return ORBHIP_E_BADARG;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ORBHIP_OK;
+}
+extern "C" void *orbhip_ctx_stream(orbhip_ctx *c) { return c ? (void *)c->stream : nullptr; }
+hipStream_t orbhip_ctx_stream_internal(orbhip_ctx *c) { return c->stream; }
+int orbhip_ctx_device_internal(orbhip_ctx *c) { return c->device; }
+
+// ------------------------------------------------------------------------------------
+static inline int cv_round_f(float v) { return (int)lrintf(v); }   // round-half-even
+static inline int cv_round_d(double v) { return (int)lrint(v); }
+static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+struct orbhip_extractor {
+    orbhip_ctx *ctx;
+    int nfeatures, nlevels, ini_th, min_th;
+    float scale_factor;
+    float scale[ORB_MAX_LEVELS], inv_scale[ORB_MAX_LEVELS], sigma2[ORB_MAX_LEVELS], inv_sigma2[ORB_MAX_LEVELS];
+    int per_level[ORB_MAX_LEVELS];
+    int umax[ORB_HALF_PATCH + 1];
+    int gauss_q8[7];
+    // reserved geometry
+    int width, height, max_batch;
+    bool level0_owned;          // level-0 buffer allocated (host path / stride mismatch)
+    OrbParams P;
+    std::vector<void *> allocs;
+    size_t bytes_reserved;
+    int last_batch;
+    bool profiling;
+    hipEvent_t ev[ORBHIP_STAGE_COUNT + 1];
+    bool ev_created;
+    float stage_ms[ORBHIP_STAGE_COUNT];
+    uint8_t *d_level0;          // owned level-0 storage
+    size_t level0_frame_stride; int level0_pitch;
+};
+
+extern "C" int orbhip_extractor_create(orbhip_ctx *ctx, int nfeatures, float scale_factor, int nlevels,
+                                       int ini_th, int min_th, orbhip_extractor **out)
+{
+    if (!ctx || !out || nlevels < 1 || nlevels > ORB_MAX_LEVELS || nfeatures < 1 || !(scale_factor > 1.0f))
+        return ORBHIP_E_BADARG;
+    orbhip_extractor *e = new orbhip_extractor();
+    e->ctx = ctx; e->nfeatures = nfeatures; e->nlevels = nlevels; e->ini_th = ini_th; e->min_th = min_th;
+    e->scale_factor = scale_factor;
+    e->width = e->height = e->max_batch = 0; e->bytes_reserved = 0; e->last_batch = 0;
+    e->profiling = false; e->ev_created = false; e->d_level0 = nullptr; e->level0_owned = false;
+    memset(&e->P, 0, sizeof(e->P));
+    memset(e->stage_ms, 0, sizeof(e->stage_ms));
+    // scale tables, ORBextractor.cc:413-429
+    e->scale[0] = 1.0f; e->sigma2[0] = 1.0f;
+    for (int i = 1; i < nlevels; i++) { e->scale[i] = e->scale[i - 1] * scale_factor; e->sigma2[i] = e->scale[i] * e->scale[i]; }
+    for (int i = 0; i < nlevels; i++) { e->inv_scale[i] = 1.0f / e->scale[i]; e->inv_sigma2[i] = 1.0f / e->sigma2[i]; }
+    // per-level quota, ORBextractor.cc:433-445
+    float factor = 1.0f / scale_factor;
+    float desired = nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nlevels));
+    int sum = 0;
+    for (int l = 0; l < nlevels - 1; l++) { e->per_level[l] = cv_round_f(desired); sum += e->per_level[l]; desired *= factor; }
+    e->per_level[nlevels - 1] = std::max(nfeatures - sum, 0);
+    // umax, ORBextractor.cc:453-468
+    int v, v0, vmax = (int)floor(ORB_HALF_PATCH * sqrtf(2.f) / 2 + 1), vmin = (int)ceil(ORB_HALF_PATCH * sqrtf(2.f) / 2);
+    const double hp2 = ORB_HALF_PATCH * ORB_HALF_PATCH;
+    for (v = 0; v <= vmax; ++v) e->umax[v] = cv_round_d(sqrt(hp2 - v * v));
+    for (v = ORB_HALF_PATCH, v0 = 0; v >= vmin; --v) { while (e->umax[v0] == e->umax[v0 + 1]) ++v0; e->umax[v] = v0; ++v0; }
+    // cv::getGaussianKernel(7, 2, CV_32F) -> q8
+    {
+        float cf[7]; double s = 0;
+        for (int i = 0; i < 7; i++) { double x = i - 3.0; cf[i] = (float)exp(-0.5 / 4.0 * x * x); s += cf[i]; }
+        s = 1. / s;
+        for (int i = 0; i < 7; i++) { cf[i] = (float)(cf[i] * s); e->gauss_q8[i] = cv_round_f(cf[i] * 256.f); }
+    }
+    *out = e;
+    return ORBHIP_OK;
+}
+
+static void ext_free_all(orbhip_extractor *e)
+{
+    for (void *p : e->allocs) (void)hipFree(p);
+    e->allocs.clear();
+    e->bytes_reserved = 0; e->width = e->height = e->max_batch = 0; e->d_level0 = nullptr;
+}
+
+extern "C" void orbhip_extractor_destroy(orbhip_extractor *e)
+{
+    if (!e) return;
+    (void)hipStreamSynchronize(e->ctx->stream);
+    ext_free_all(e);
+    if (e->ev_created) for (auto &ev : e->ev) (void)hipEventDestroy(ev);
+    delete e;
+}
+
+extern "C" int orbhip_extractor_levels(const orbhip_extractor *e) { return e ? e->nlevels : ORBHIP_E_BADARG; }
+extern "C" int orbhip_extractor_table(const orbhip_extractor *e, int which, float *out)
+{
+    if (!e || !out || which < 0 || which > 3) return ORBHIP_E_BADARG;
+    const float *t = which == 0 ? e->scale : which == 1 ? e->inv_scale : which == 2 ? e->sigma2 : e->inv_sigma2;
+    memcpy(out, t, sizeof(float) * e->nlevels);
+    return ORBHIP_OK;
+}
+extern "C" int orbhip_extractor_features_per_level(const orbhip_extractor *e, int *out)
+{
+    if (!e || !out) return ORBHIP_E_BADARG;
+    memcpy(out, e->per_level, sizeof(int) * e->nlevels);
+    return ORBHIP_OK;
+}
+extern "C" int orbhip_extractor_umax(const orbhip_extractor *e, int *out16)
+{
+    if (!e || !out16) return ORBHIP_E_BADARG;
+    memcpy(out16, e->umax, sizeof(int) * 16);
+    return ORBHIP_OK;
+}
+extern "C" int orbhip_extractor_max_keypoints(const orbhip_extractor *e) { return e ? e->P.max_kp : ORBHIP_E_BADARG; }
+
+template <typename T>
+static int dev_alloc(orbhip_extractor *e, T **p, size_t count)
+{
+    void *q = nullptr;
+    size_t bytes = std::max<size_t>(count * sizeof(T), 256);
+    hipError_t err = hipMalloc(&q, bytes);
+    if (err != hipSuccess) { g_last_error = std::string("hipMalloc: ") + hipGetErrorString(err); return ORBHIP_E_HIP; }
+    e->allocs.push_back(q);
+    e->bytes_reserved += bytes;
+    *p = (T *)q;
+    return ORBHIP_OK;
+}
+
+// cv::resize INTER_LINEAR coefficient tables, host float math as OpenCV's.
+static void resize_tables(int sn, int dn, bool horizontal, std::vector<int16_t> &ofs, std::vector<int16_t> &coef)
+{
+    double scale = 1. / ((double)dn / sn);
+    ofs.resize(dn); coef.resize(2 * dn);
+    for (int d = 0; d < dn; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)floorf(f);
+        f -= s;
+        if (horizontal) {
+            if (s < 0) { f = 0; s = 0; }
+            if (s >= sn - 1) { f = 0; s = sn - 1; }
+        }
+        int c0 = cv_round_f((1.f - f) * 2048), c1 = cv_round_f(f * 2048);
+        ofs[d] = (int16_t)std::min(std::max(s, -32768), 32767);
+        coef[2 * d] = (int16_t)std::min(std::max(c0, -32768), 32767);
+        coef[2 * d + 1] = (int16_t)std::min(std::max(c1, -32768), 32767);
+    }
+}
+
+extern "C" int orbhip_extractor_reserve(orbhip_extractor *e, int width, int height, int max_batch)
+{
+    if (!e || width <= 0 || height <= 0 || max_batch <= 0) return ORBHIP_E_BADARG;
+    if (e->width == width && e->height == height && e->max_batch >= max_batch) return ORBHIP_OK;
+    if (width > 4096 + 2 * ORB_MINB || height > 4096 + 2 * ORB_MINB) { g_last_error = "image larger than 12-bit key packing"; return ORBHIP_E_BADARG; }
+    HIP_TRY(hipSetDevice(e->ctx->device));
+    HIP_TRY(hipStreamSynchronize(e->ctx->stream));
+    ext_free_all(e);
+    OrbParams &P = e->P;
+    memset(&P, 0, sizeof(P));
+    P.nlevels = e->nlevels; P.ini_th = e->ini_th; P.min_th = e->min_th;
+    memcpy(P.umax, e->umax, sizeof(P.umax));
+    memcpy(P.gauss_q8, e->gauss_q8, sizeof(P.gauss_q8));
+    int cells = 0, keys = 0, kps = 0, max_cell_cap = 0;
+    for (int l = 0; l < e->nlevels; l++) {
+        OrbLevel &L = P.lv[l];
+        // ComputePyramid sizes, ORBextractor.cc:1156-1157
+        L.w = cv_round_f((float)width * e->inv_scale[l]);
+        L.h = cv_round_f((float)height * e->inv_scale[l]);
+        // cell grid, ORBextractor.cc:771-781
+        const float w_ = (float)((L.w - ORB_EDGE + 3) - ORB_MINB), h_ = (float)((L.h - ORB_EDGE + 3) - ORB_MINB);
+        if (w_ < 30.f || h_ < 30.f) { g_last_error = "pyramid level smaller than one FAST cell"; return ORBHIP_E_BADARG; }
+        L.ncols = (int)(w_ / 30.f); L.nrows = (int)(h_ / 30.f);
+        L.wcell = (int)ceilf(w_ / L.ncols); L.hcell = (int)ceilf(h_ / L.nrows);
+        if (L.wcell + 6 > 64 || L.hcell + 6 > 64) { g_last_error = "FAST cell exceeds the 64x64 LDS tile"; return ORBHIP_E_BADARG; }
+        max_cell_cap = std::max(max_cell_cap, ((L.wcell + 1) / 2) * ((L.hcell + 1) / 2));
+        L.cell_base = cells; cells += L.ncols * L.nrows;
+        L.quota = e->per_level[l];
+        // DistributeOctTree roots, ORBextractor.cc:541-543
+        const int maxx = L.w - ORB_MINB, maxy = L.h - ORB_MINB;
+        L.n_ini = (int)roundf((float)(maxx - ORB_MINB) / (maxy - ORB_MINB));
+        if (L.n_ini < 1) { g_last_error = "nIni == 0 (image taller than 2x its width): undefined in the reference"; return ORBHIP_E_BADARG; }
+        L.hx = (float)(maxx - ORB_MINB) / L.n_ini;
+        L.scale = e->scale[l];
+        L.size = (float)(int)(31 * e->scale[l]);              // ORBextractor.cc:862
+        L.kp_base = kps; L.kp_cap = std::max(L.quota + 8, 4 * L.n_ini + 4); kps += L.kp_cap;
+    }
+    // cell list capacity: 3x3 strict-greater NMS admits at most one keypoint per 2x2 block
+    for (int l = 0; l < e->nlevels; l++) {
+        OrbLevel &L = P.lv[l];
+        L.cell_cap = max_cell_cap;
+        L.key_base = keys;
+        // candidates per level: bounded by the same 2x2 argument over the whole detection area
+        L.key_cap = std::min(L.ncols * L.nrows * max_cell_cap, ((L.w - 2 * ORB_MINB + 1) / 2 + L.ncols) * ((L.h - 2 * ORB_MINB + 1) / 2 + L.nrows));
+        L.key_cap = std::min(L.key_cap, 0xFFFFF);
+        keys += align_up(L.key_cap, 4);
+    }
+    P.cells_per_frame = cells; P.keys_per_frame = keys; P.kps_per_frame = kps; P.max_kp = align_up(kps, 8);
+    P.cell_list_frame_stride = (size_t)cells * max_cell_cap;
+    int rc;
+    const size_t B = (size_t)max_batch;
+    for (int l = 0; l < e->nlevels; l++) {
+        OrbLevel &L = P.lv[l];
+        L.img_pitch = align_up(L.w, 64); L.blur_pitch = L.img_pitch;
+        L.img_frame_stride = (size_t)L.img_pitch * L.h; L.blur_frame_stride = L.img_frame_stride;
+        if ((rc = dev_alloc(e, &L.img, B * L.img_frame_stride + 64))) return rc;
+        if ((rc = dev_alloc(e, &L.blur, B * L.blur_frame_stride + 64))) return rc;
+        if (l > 0) {
+            std::vector<int16_t> xo, xa, yo, yb;
+            resize_tables(P.lv[l - 1].w, L.w, true, xo, xa);
+            resize_tables(P.lv[l - 1].h, L.h, false, yo, yb);
+            int16_t *dxo, *dxa, *dyo, *dyb;
+            if ((rc = dev_alloc(e, &dxo, xo.size()))) return rc;
+            if ((rc = dev_alloc(e, &dxa, xa.size()))) return rc;
+            if ((rc = dev_alloc(e, &dyo, yo.size()))) return rc;
+            if ((rc = dev_alloc(e, &dyb, yb.size()))) return rc;
+            HIP_TRY(hipMemcpy(dxo, xo.data(), xo.size() * 2, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(dxa, xa.data(), xa.size() * 2, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(dyo, yo.data(), yo.size() * 2, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(dyb, yb.data(), yb.size() * 2, hipMemcpyHostToDevice));
+            L.xofs = dxo; L.xalpha = dxa; L.yofs = dyo; L.ybeta = dyb;
+        }
+    }
+    e->d_level0 = P.lv[0].img; e->level0_pitch = P.lv[0].img_pitch; e->level0_frame_stride = P.lv[0].img_frame_stride;
+    if ((rc = dev_alloc(e, &P.cell_count, B * cells))) return rc;
+    if ((rc = dev_alloc(e, &P.cell_list, B * P.cell_list_frame_stride))) return rc;
+    if ((rc = dev_alloc(e, &P.keys, B * keys))) return rc;
+    if ((rc = dev_alloc(e, &P.node_of, B * keys))) return rc;
+    if ((rc = dev_alloc(e, &P.lvl_kp, B * kps))) return rc;
+    if ((rc = dev_alloc(e, &P.lvl_angle, B * kps))) return rc;
+    if ((rc = dev_alloc(e, &P.lvl_desc, B * kps * 32))) return rc;
+    if ((rc = dev_alloc(e, &P.lvl_count, B * e->nlevels))) return rc;
+    if ((rc = dev_alloc(e, &P.lvl_ncand, B * e->nlevels))) return rc;
+    if ((rc = dev_alloc(e, &P.status, 1))) return rc;
+    if ((rc = dev_alloc(e, &P.out_kp, B * P.max_kp))) return rc;
+    if ((rc = dev_alloc(e, &P.out_desc, B * P.max_kp * 32))) return rc;
+    if ((rc = dev_alloc(e, &P.out_count, B))) return rc;
+    if ((rc = dev_alloc(e, &P.out_mono, B))) return rc;
+    HIP_TRY(hipMemset(P.status, 0, sizeof(int32_t)));
+    // the octree kernel's dynamic LDS may exceed the 64 KB default for large quotas
+    int mq = 0;
+    for (int l = 0; l < e->nlevels; l++) mq = std::max(mq, P.lv[l].quota);
+    if (orb_octree_lds_bytes(mq) > 150 * 1024) { g_last_error = "per-level quota too large for the LDS-resident octree"; return ORBHIP_E_BADARG; }
+    e->width = width; e->height = height; e->max_batch = max_batch;
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_extractor_set_profiling(orbhip_extractor *e, int enable)
+{
+    if (!e) return ORBHIP_E_BADARG;
+    if (enable && !e->ev_created) {
+        for (auto &ev : e->ev) HIP_TRY(hipEventCreate(&ev));
+        e->ev_created = true;
+    }
+    e->profiling = enable != 0;
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_extractor_stage_ms(orbhip_extractor *e, float *ms_out)
+{
+    if (!e || !ms_out || !e->ev_created) return ORBHIP_E_BADARG;
+    HIP_TRY(hipEventSynchronize(e->ev[ORBHIP_STAGE_COUNT]));
+    for (int i = 0; i < ORBHIP_STAGE_COUNT; i++) HIP_TRY(hipEventElapsedTime(&ms_out[i], e->ev[i], e->ev[i + 1]));
+    return ORBHIP_OK;
+}
+
+static int run_pipeline(orbhip_extractor *e, int batch, int lap0, int lap1)
+{
+    OrbParams &P = e->P;
+    P.batch = batch; P.lap0 = lap0; P.lap1 = lap1;
+    hipStream_t s = e->ctx->stream;
+    const bool prof = e->profiling;
+#define STAGE_MARK(i) do { if (prof) HIP_TRY(hipEventRecord(e->ev[i], s)); } while (0)
+    STAGE_MARK(ORBHIP_STAGE_PYRAMID);
+    for (int l = 1; l < e->nlevels; l++) orb_launch_resize(P, l, s);
+    STAGE_MARK(ORBHIP_STAGE_FAST);
+    orb_launch_fast(P, s);
+    STAGE_MARK(ORBHIP_STAGE_OCTREE);
+    orb_launch_octree(P, s);
+    STAGE_MARK(ORBHIP_STAGE_BLUR);
+    orb_launch_blur(P, s);
+    STAGE_MARK(ORBHIP_STAGE_DESC);
+    orb_launch_orient_desc(P, s);
+    STAGE_MARK(ORBHIP_STAGE_ASSEMBLE);
+    orb_launch_assemble(P, s);
+    STAGE_MARK(ORBHIP_STAGE_COUNT);
+#undef STAGE_MARK
+    HIP_TRY(hipGetLastError());
+    e->last_batch = batch;
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_extract_batch_device(orbhip_extractor *e, const uint8_t *d_images, int width, int height,
+                                           size_t row_stride, size_t frame_stride, int batch, int lap0, int lap1)
+{
+    if (!e || batch <= 0 || row_stride < (size_t)width) return ORBHIP_E_BADARG;
+    if (!d_images || width <= 0 || height <= 0) return ORBHIP_E_EMPTY;
+    HIP_TRY(hipSetDevice(e->ctx->device));
+    int rc = orbhip_extractor_reserve(e, width, height, batch);
+    if (rc) return rc;
+    // level 0 of the pyramid is the input itself (the reference copies it into a padded
+    // buffer, ORBextractor.cc:1172; the bytes are identical): alias, do not copy.
+    OrbLevel &L0 = e->P.lv[0];
+    L0.img = const_cast<uint8_t *>(d_images);
+    L0.img_pitch = (int)row_stride;
+    L0.img_frame_stride = frame_stride;
+    return run_pipeline(e, batch, lap0, lap1);
+}
+
+extern "C" int orbhip_extractor_results(orbhip_extractor *e, orbhip_keypoint **d_kp, uint8_t **d_desc,
+                                        int32_t **d_count, int32_t **d_mono)
+{
+    if (!e || !e->max_batch) return ORBHIP_E_BADARG;
+    if (d_kp) *d_kp = e->P.out_kp;
+    if (d_desc) *d_desc = e->P.out_desc;
+    if (d_count) *d_count = e->P.out_count;
+    if (d_mono) *d_mono = e->P.out_mono;
+    return ORBHIP_OK;
+}
+
+static int check_status(orbhip_extractor *e)
+{
+    int32_t st = 0;
+    HIP_TRY(hipMemcpyAsync(&st, e->P.status, sizeof(st), hipMemcpyDeviceToHost, e->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(e->ctx->stream));
+    if (st) {
+        g_last_error = "device-side list capacity exceeded";
+        (void)hipMemsetAsync(e->P.status, 0, sizeof(int32_t), e->ctx->stream);
+    }
+    return st;
+}
+
+extern "C" int orbhip_extract_batch_host(orbhip_extractor *e, const uint8_t *h_images, int width, int height,
+                                         size_t row_stride, size_t frame_stride, int batch, int lap0, int lap1,
+                                         orbhip_keypoint *kp_out, uint8_t *desc_out, int cap,
+                                         int32_t *count_out, int32_t *mono_out)
+{
+    if (!e || batch <= 0) return ORBHIP_E_BADARG;
+    if (!h_images || width <= 0 || height <= 0) return ORBHIP_E_EMPTY;      // ORBextractor.cc:1072-1073
+    if (row_stride < (size_t)width || !kp_out || !desc_out || !count_out || !mono_out) return ORBHIP_E_BADARG;
+    HIP_TRY(hipSetDevice(e->ctx->device));
+    int rc = orbhip_extractor_reserve(e, width, height, batch);
+    if (rc) return rc;
+    hipStream_t s = e->ctx->stream;
+    OrbLevel &L0 = e->P.lv[0];
+    L0.img = e->d_level0; L0.img_pitch = e->level0_pitch; L0.img_frame_stride = e->level0_frame_stride;
+    for (int f = 0; f < batch; f++)
+        HIP_TRY(hipMemcpy2DAsync(L0.img + (size_t)f * L0.img_frame_stride, L0.img_pitch, h_images + (size_t)f * frame_stride,
+                                 row_stride, width, height, hipMemcpyHostToDevice, s));
+    rc = run_pipeline(e, batch, lap0, lap1);
+    if (rc) return rc;
+    std::vector<int32_t> cnt(batch);
+    HIP_TRY(hipMemcpyAsync(cnt.data(), e->P.out_count, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(mono_out, e->P.out_mono, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
+    if ((rc = check_status(e))) return rc;
+    for (int f = 0; f < batch; f++) {
+        count_out[f] = cnt[f];
+        if (cnt[f] > cap) return ORBHIP_E_CAPACITY;
+        if (cnt[f] == 0) continue;
+        HIP_TRY(hipMemcpyAsync(kp_out + (size_t)f * cap, e->P.out_kp + (size_t)f * e->P.max_kp, sizeof(orbhip_keypoint) * cnt[f], hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(desc_out + (size_t)f * cap * 32, e->P.out_desc + (size_t)f * e->P.max_kp * 32, (size_t)32 * cnt[f], hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    return ORBHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------ taps
+extern "C" int orbhip_extractor_level_dims(const orbhip_extractor *e, int level, int *w, int *h)
+{
+    if (!e || level < 0 || level >= e->nlevels || !e->max_batch) return ORBHIP_E_BADARG;
+    *w = e->P.lv[level].w; *h = e->P.lv[level].h;
+    return ORBHIP_OK;
+}
+
+static inline int reflect101_host(int p, int n)
+{
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) { if (p < 0) p = -p; else p = 2 * n - 2 - p; }
+    return p;
+}
+
+extern "C" int orbhip_extractor_get_pyramid_level(orbhip_extractor *e, int frame, int level, int padded,
+                                                  uint8_t *h_out, size_t out_stride)
+{
+    if (!e || !h_out || level < 0 || level >= e->nlevels || frame < 0 || frame >= e->last_batch) return ORBHIP_E_BADARG;
+    const OrbLevel &L = e->P.lv[level];
+    HIP_TRY(hipSetDevice(e->ctx->device));
+    HIP_TRY(hipStreamSynchronize(e->ctx->stream));
+    if (!padded) {
+        HIP_TRY(hipMemcpy2D(h_out, out_stride, L.img + (size_t)frame * L.img_frame_stride, L.img_pitch, L.w, L.h, hipMemcpyDeviceToHost));
+        return ORBHIP_OK;
+    }
+    // mvImagePyramid's parent buffer: ROI + 19-px BORDER_REFLECT_101 (ORBextractor.cc:1167,1172),
+    // synthesised lazily on copy-out; the extraction itself never reads the border.
+    std::vector<uint8_t> tmp((size_t)L.w * L.h);
+    HIP_TRY(hipMemcpy2D(tmp.data(), L.w, L.img + (size_t)frame * L.img_frame_stride, L.img_pitch, L.w, L.h, hipMemcpyDeviceToHost));
+    const int pw = L.w + 2 * ORB_EDGE, ph = L.h + 2 * ORB_EDGE;
+    for (int y = 0; y < ph; y++) {
+        const uint8_t *srow = tmp.data() + (size_t)reflect101_host(y - ORB_EDGE, L.h) * L.w;
+        uint8_t *drow = h_out + (size_t)y * out_stride;
+        for (int x = 0; x < pw; x++) drow[x] = srow[reflect101_host(x - ORB_EDGE, L.w)];
+    }
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_extractor_get_blurred_level(orbhip_extractor *e, int frame, int level, uint8_t *h_out, size_t out_stride)
+{
+    if (!e || !h_out || level < 0 || level >= e->nlevels || frame < 0 || frame >= e->last_batch) return ORBHIP_E_BADARG;
+    const OrbLevel &L = e->P.lv[level];
+    HIP_TRY(hipSetDevice(e->ctx->device));
+    HIP_TRY(hipStreamSynchronize(e->ctx->stream));
+    HIP_TRY(hipMemcpy2D(h_out, out_stride, L.blur + (size_t)frame * L.blur_frame_stride, L.blur_pitch, L.w, L.h, hipMemcpyDeviceToHost));
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_extractor_get_fast_candidates(orbhip_extractor *e, int frame, int level, int32_t *xs, int32_t *ys,
+                                                    int32_t *scores, int cap, int32_t *n_out)
+{
+    if (!e || level < 0 || level >= e->nlevels || frame < 0 || frame >= e->last_batch || !n_out) return ORBHIP_E_BADARG;
+    const OrbParams &P = e->P;
+    const OrbLevel &L = P.lv[level];
+    HIP_TRY(hipSetDevice(e->ctx->device));
+    HIP_TRY(hipStreamSynchronize(e->ctx->stream));
+    int32_t n = 0;
+    HIP_TRY(hipMemcpy(&n, P.lvl_ncand + frame * P.nlevels + level, sizeof(n), hipMemcpyDeviceToHost));
+    *n_out = n;
+    int m = std::min(n, cap);
+    if (m > 0 && xs && ys && scores) {
+        std::vector<uint32_t> k(m);
+        HIP_TRY(hipMemcpy(k.data(), P.keys + (size_t)frame * P.keys_per_frame + L.key_base, sizeof(uint32_t) * m, hipMemcpyDeviceToHost));
+        for (int i = 0; i < m; i++) { xs[i] = ORB_KEY_X(k[i]); ys[i] = ORB_KEY_Y(k[i]); scores[i] = ORB_KEY_S(k[i]); }
+    }
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_extractor_get_level_keypoints(orbhip_extractor *e, int frame, int level, orbhip_keypoint *out,
+                                                    int cap, int32_t *n_out)
+{
+    if (!e || level < 0 || level >= e->nlevels || frame < 0 || frame >= e->last_batch || !n_out) return ORBHIP_E_BADARG;
+    const OrbParams &P = e->P;
+    const OrbLevel &L = P.lv[level];
+    HIP_TRY(hipSetDevice(e->ctx->device));
+    HIP_TRY(hipStreamSynchronize(e->ctx->stream));
+    int32_t n = 0;
+    HIP_TRY(hipMemcpy(&n, P.lvl_count + frame * P.nlevels + level, sizeof(n), hipMemcpyDeviceToHost));
+    *n_out = n;
+    int m = std::min(n, cap);
+    if (m > 0 && out) {
+        std::vector<uint32_t> k(m); std::vector<float> a(m);
+        const size_t off = (size_t)frame * P.kps_per_frame + L.kp_base;
+        HIP_TRY(hipMemcpy(k.data(), P.lvl_kp + off, sizeof(uint32_t) * m, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(a.data(), P.lvl_angle + off, sizeof(float) * m, hipMemcpyDeviceToHost));
+        for (int i = 0; i < m; i++) {
+            out[i].x = (float)(ORB_KEY_X(k[i]) + ORB_MINB); out[i].y = (float)(ORB_KEY_Y(k[i]) + ORB_MINB);
+            out[i].size = L.size; out[i].angle = a[i]; out[i].response = (float)ORB_KEY_S(k[i]);
+            out[i].octave = level; out[i].class_id = -1;
+        }
+    }
+    return ORBHIP_OK;
+}

@@ -1,0 +1,228 @@
+"""ctypes binding of the orbhip C ABI (include/orbhip.h) for tests and bench.py.
+
+Plumbing only: every call goes straight to liborbhip.so (HIP kernels).  There is no
+Python or CPU implementation behind these wrappers; if the shared library is missing the
+import fails loudly.
+
+torch is imported BEFORE the library is loaded so that one HIP runtime (torch's bundled
+libamdhip64.so.7) serves both torch tensors and our kernels in the same process.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+try:  # one HIP runtime per process: let torch load its copy first when torch is present
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(os.path.dirname(_HERE), "lib")
+LIB_PATH = os.path.join(LIB_DIR, "liborbhip.so")
+SYNTH_PATH = os.path.join(LIB_DIR, "libsynth.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "liborbhip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(there is no CPU fallback for the HIP path)")
+
+lib = C.CDLL(LIB_PATH)
+
+OK, E_BADARG, E_NODEVICE, E_HIP, E_CAPACITY, E_ABORTED, E_NOTSPD, E_EMPTY = 0, -1, -2, -3, -4, -5, -6, -7
+STAGES = ["pyramid", "fast", "octree", "blur", "desc", "assemble"]
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+vp, ci, cf, cd, sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
+lib.orbhip_version.restype = C.c_char_p
+lib.orbhip_last_error.restype = C.c_char_p
+lib.orbhip_ctx_create.argtypes = [ci, vp, C.POINTER(vp)]
+lib.orbhip_ctx_destroy.argtypes = [vp]
+lib.orbhip_ctx_synchronize.argtypes = [vp]
+lib.orbhip_ctx_stream.argtypes = [vp]
+lib.orbhip_ctx_stream.restype = vp
+lib.orbhip_extractor_create.argtypes = [vp, ci, cf, ci, ci, ci, C.POINTER(vp)]
+lib.orbhip_extractor_destroy.argtypes = [vp]
+lib.orbhip_extractor_levels.argtypes = [vp]
+lib.orbhip_extractor_table.argtypes = [vp, ci, vp]
+lib.orbhip_extractor_features_per_level.argtypes = [vp, vp]
+lib.orbhip_extractor_umax.argtypes = [vp, vp]
+lib.orbhip_extractor_reserve.argtypes = [vp, ci, ci, ci]
+lib.orbhip_extractor_max_keypoints.argtypes = [vp]
+lib.orbhip_extract_batch_device.argtypes = [vp, vp, ci, ci, sz, sz, ci, ci, ci]
+lib.orbhip_extractor_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+lib.orbhip_extract_batch_host.argtypes = [vp, vp, ci, ci, sz, sz, ci, ci, ci, vp, vp, ci, vp, vp]
+lib.orbhip_extractor_level_dims.argtypes = [vp, ci, C.POINTER(ci), C.POINTER(ci)]
+lib.orbhip_extractor_get_pyramid_level.argtypes = [vp, ci, ci, ci, vp, sz]
+lib.orbhip_extractor_get_blurred_level.argtypes = [vp, ci, ci, vp, sz]
+lib.orbhip_extractor_get_fast_candidates.argtypes = [vp, ci, ci, vp, vp, vp, ci, C.POINTER(C.c_int32)]
+lib.orbhip_extractor_get_level_keypoints.argtypes = [vp, ci, ci, vp, ci, C.POINTER(C.c_int32)]
+lib.orbhip_extractor_set_profiling.argtypes = [vp, ci]
+lib.orbhip_extractor_stage_ms.argtypes = [vp, vp]
+lib.orbhip_descriptor_distance.argtypes = [vp, vp]
+
+
+class OrbHipError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        super().__init__("%s failed: %d (%s)" % (where, code, lib.orbhip_last_error().decode()))
+
+
+def _chk(rc, where):
+    if rc != OK:
+        raise OrbHipError(rc, where)
+
+
+class Context:
+    def __init__(self, device=0, stream=None):
+        h = vp()
+        _chk(lib.orbhip_ctx_create(device, stream, C.byref(h)), "orbhip_ctx_create")
+        self.h = h
+
+    def synchronize(self):
+        _chk(lib.orbhip_ctx_synchronize(self.h), "orbhip_ctx_synchronize")
+
+    @property
+    def stream(self):
+        return lib.orbhip_ctx_stream(self.h)
+
+    def close(self):
+        if self.h:
+            lib.orbhip_ctx_destroy(self.h)
+            self.h = None
+
+
+class Extractor:
+    """Mirror of ORB_SLAM3::ORBextractor (reference include/ORBextractor.h:49-81)."""
+
+    def __init__(self, ctx, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        h = vp()
+        _chk(lib.orbhip_extractor_create(ctx.h, nfeatures, scale_factor, nlevels, ini_th, min_th, C.byref(h)),
+             "orbhip_extractor_create")
+        self.h, self.ctx, self.nlevels = h, ctx, nlevels
+
+    def close(self):
+        if self.h:
+            lib.orbhip_extractor_destroy(self.h)
+            self.h = None
+
+    # -- tables (GetScaleFactors etc.)
+    def table(self, which):
+        out = np.zeros(self.nlevels, np.float32)
+        _chk(lib.orbhip_extractor_table(self.h, which, out.ctypes.data), "orbhip_extractor_table")
+        return out
+
+    def features_per_level(self):
+        out = np.zeros(self.nlevels, np.int32)
+        _chk(lib.orbhip_extractor_features_per_level(self.h, out.ctypes.data), "features_per_level")
+        return out
+
+    def umax(self):
+        out = np.zeros(16, np.int32)
+        _chk(lib.orbhip_extractor_umax(self.h, out.ctypes.data), "umax")
+        return out
+
+    def reserve(self, w, h, batch):
+        _chk(lib.orbhip_extractor_reserve(self.h, w, h, batch), "orbhip_extractor_reserve")
+
+    @property
+    def max_keypoints(self):
+        return lib.orbhip_extractor_max_keypoints(self.h)
+
+    def set_profiling(self, on):
+        _chk(lib.orbhip_extractor_set_profiling(self.h, 1 if on else 0), "set_profiling")
+
+    def stage_ms(self):
+        out = np.zeros(len(STAGES), np.float32)
+        _chk(lib.orbhip_extractor_stage_ms(self.h, out.ctypes.data), "stage_ms")
+        return dict(zip(STAGES, out.tolist()))
+
+    # -- operator()
+    def extract_host(self, images, lap=(0, 1000)):
+        """images: uint8 [B,H,W] (or [H,W]).  Returns list of (kp structured array, desc [n,32], mono_index)."""
+        img = np.ascontiguousarray(images, np.uint8)
+        if img.ndim == 2:
+            img = img[None]
+        B, H, W = img.shape
+        self.reserve(W, H, B)
+        cap = self.max_keypoints
+        kp = np.zeros((B, cap), KP_DTYPE)
+        desc = np.zeros((B, cap, 32), np.uint8)
+        cnt = np.zeros(B, np.int32)
+        mono = np.zeros(B, np.int32)
+        _chk(lib.orbhip_extract_batch_host(self.h, img.ctypes.data, W, H, W, W * H, B, lap[0], lap[1],
+                                           kp.ctypes.data, desc.ctypes.data, cap, cnt.ctypes.data, mono.ctypes.data),
+             "orbhip_extract_batch_host")
+        return [(kp[f, :cnt[f]].copy(), desc[f, :cnt[f]].copy(), int(mono[f])) for f in range(B)]
+
+    def extract_device(self, d_ptr, w, h, row_stride, frame_stride, batch, lap=(0, 1000)):
+        _chk(lib.orbhip_extract_batch_device(self.h, d_ptr, w, h, row_stride, frame_stride, batch, lap[0], lap[1]),
+             "orbhip_extract_batch_device")
+
+    def results_device(self):
+        a, b, c, d = vp(), vp(), vp(), vp()
+        _chk(lib.orbhip_extractor_results(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "results")
+        return a.value, b.value, c.value, d.value
+
+    # -- taps
+    def level_dims(self, level):
+        w, h = ci(), ci()
+        _chk(lib.orbhip_extractor_level_dims(self.h, level, C.byref(w), C.byref(h)), "level_dims")
+        return w.value, h.value
+
+    def pyramid_level(self, frame, level, padded=False):
+        w, h = self.level_dims(level)
+        if padded:
+            w, h = w + 38, h + 38
+        out = np.zeros((h, w), np.uint8)
+        _chk(lib.orbhip_extractor_get_pyramid_level(self.h, frame, level, 1 if padded else 0, out.ctypes.data, w),
+             "get_pyramid_level")
+        return out
+
+    def blurred_level(self, frame, level):
+        w, h = self.level_dims(level)
+        out = np.zeros((h, w), np.uint8)
+        _chk(lib.orbhip_extractor_get_blurred_level(self.h, frame, level, out.ctypes.data, w), "get_blurred_level")
+        return out
+
+    def fast_candidates(self, frame, level, cap=1 << 17):
+        xs, ys, ss = (np.zeros(cap, np.int32) for _ in range(3))
+        n = C.c_int32()
+        _chk(lib.orbhip_extractor_get_fast_candidates(self.h, frame, level, xs.ctypes.data, ys.ctypes.data,
+                                                      ss.ctypes.data, cap, C.byref(n)), "get_fast_candidates")
+        return xs[:n.value].copy(), ys[:n.value].copy(), ss[:n.value].copy()
+
+    def level_keypoints(self, frame, level, cap=8192):
+        out = np.zeros(cap, KP_DTYPE)
+        n = C.c_int32()
+        _chk(lib.orbhip_extractor_get_level_keypoints(self.h, frame, level, out.ctypes.data, cap, C.byref(n)),
+             "get_level_keypoints")
+        return out[:n.value].copy()
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return lib.orbhip_descriptor_distance(a.ctypes.data, b.ctypes.data)
+
+
+# ---------------------------------------------------------------- synthetic inputs (host C)
+_synth = None
+
+
+def synth_lib():
+    global _synth
+    if _synth is None:
+        _synth = C.CDLL(SYNTH_PATH)
+        _synth.synth_frame.argtypes = [vp, ci, ci, ci, C.c_uint64, ci]
+        _synth.synth_batch.argtypes = [vp, ci, ci, ci, C.c_uint64, ci]
+        _synth.synth_frame_transform.argtypes = [C.c_uint64, ci, C.POINTER(cf), C.POINTER(cf), C.POINTER(cf)]
+    return _synth
+
+
+def synth_frames(w, h, n, seed=20241004, first=0):
+    out = np.zeros((n, h, w), np.uint8)
+    synth_lib().synth_batch(out.ctypes.data, w, h, n, seed, first)
+    return out

@@ -1,0 +1,125 @@
+"""HIP-vs-oracle parity of the ORB front-end, stage by stage, through the C ABI.
+Bar: bit-exact (SURVEY.md 8c "Definition of bit-exact": candidates, octree set, angles,
+descriptors, output order incl. lapping split, return value)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(gpu_ctx, nfeat=1000, nlev=8, ini=20, mn=7, scale=1.2):
+    import orbhip
+    import oracle_bind as ob
+    return orbhip.Extractor(gpu_ctx, nfeat, scale, nlev, ini, mn), ob.OracleExtractor(nfeat, scale, nlev, ini, mn)
+
+
+def _compare_frame(ext, ora, imgs, f, lap, got):
+    kp, desc, mono = ora.extract(imgs[f], lap)
+    for l in range(ext.nlevels):
+        np.testing.assert_array_equal(ext.pyramid_level(f, l), ora.pyramid_level(l), err_msg="pyramid L%d" % l)
+    for l in range(ext.nlevels):
+        gx, gy, gs = ext.fast_candidates(f, l)
+        ox, oy, os_ = ora.fast_candidates(l)
+        assert len(gx) == len(ox), "FAST candidate count L%d: %d vs %d" % (l, len(gx), len(ox))
+        np.testing.assert_array_equal(gx, ox, err_msg="cand x L%d" % l)
+        np.testing.assert_array_equal(gy, oy, err_msg="cand y L%d" % l)
+        np.testing.assert_array_equal(gs, os_, err_msg="cand score L%d" % l)
+    for l in range(ext.nlevels):
+        gk = ext.level_keypoints(f, l)
+        ok = ora.level_keypoints(l)
+        assert len(gk) == len(ok), "octree count L%d: %d vs %d" % (l, len(gk), len(ok))
+        np.testing.assert_array_equal(gk["x"], ok["x"], err_msg="octree x L%d" % l)
+        np.testing.assert_array_equal(gk["y"], ok["y"], err_msg="octree y L%d" % l)
+        assert gk["angle"].tobytes() == ok["angle"].tobytes(), "angle bits L%d" % l
+        assert gk.tobytes() == ok.tobytes(), "level keypoints L%d" % l
+    for l in range(ext.nlevels):
+        ob_ = ora.blurred_level(l)
+        if ob_ is not None:
+            np.testing.assert_array_equal(ext.blurred_level(f, l), ob_, err_msg="blur L%d" % l)
+    gk, gd, gm = got[f]
+    assert gm == mono
+    assert len(gk) == len(kp)
+    assert gk.tobytes() == kp.tobytes(), "final keypoints"
+    assert gd.tobytes() == desc.tobytes(), "final descriptors"
+    return len(kp)
+
+
+@pytest.mark.parametrize("w,h,nfeat,lap", [
+    (640, 480, 1000, (0, 1000)),     # monocular ctor lapping: everything 'stereo', reversed
+    (640, 480, 1000, (0, 0)),        # stereo ctor lapping: everything 'mono'
+    (640, 480, 1000, (200, 420)),    # genuine split
+    (752, 480, 1000, (0, 1000)),     # EuRoC native size
+    (512, 512, 1500, (0, 511)),      # TUM-VI fisheye (Frame.cc:1056)
+    (333, 277, 300, (100, 150)),     # ragged sizes, few features
+])
+def test_extract_parity_stages(gpu_ctx, w, h, nfeat, lap):
+    import orbhip
+    ext, ora = _mk(gpu_ctx, nfeat)
+    imgs = orbhip.synth_frames(w, h, 3, seed=1000 + w + nfeat)
+    got = ext.extract_host(imgs, lap)
+    total = 0
+    for f in range(3):
+        total += _compare_frame(ext, ora, imgs, f, lap, got)
+    assert total > 0.8 * nfeat * 3
+    ext.close()
+
+
+def test_extract_padded_pyramid(gpu_ctx):
+    import orbhip
+    ext, ora = _mk(gpu_ctx)
+    imgs = orbhip.synth_frames(640, 480, 1, seed=5)
+    ext.extract_host(imgs)
+    ora.extract(imgs[0])
+    for l in (0, 3, 7):
+        np.testing.assert_array_equal(ext.pyramid_level(0, l, padded=True), ora.pyramid_level(l, padded=True))
+    ext.close()
+
+
+def test_extract_edge_inputs(gpu_ctx):
+    """Flat image (no corners at either threshold), pure noise, and a min-threshold-only image."""
+    import orbhip
+    ext, ora = _mk(gpu_ctx)
+    rng = np.random.default_rng(3)
+    flat = np.full((480, 640), 77, np.uint8)
+    noise = rng.integers(0, 256, (480, 640), dtype=np.uint8)
+    low = (128 + 6 * (rng.integers(0, 2, (60, 80)).repeat(8, 0).repeat(8, 1)) + rng.integers(0, 3, (480, 640))).astype(np.uint8)
+    imgs = np.stack([flat, noise, low])
+    got = ext.extract_host(imgs)
+    assert len(got[0][0]) == 0 and got[0][2] == 0
+    for f in range(3):
+        _compare_frame(ext, ora, imgs, f, (0, 1000), got)
+    ext.close()
+
+
+def test_extract_other_params(gpu_ctx):
+    import orbhip
+    ext, ora = _mk(gpu_ctx, nfeat=2000, nlev=5, ini=12, mn=5, scale=1.3)
+    imgs = orbhip.synth_frames(800, 600, 2, seed=99)
+    got = ext.extract_host(imgs, (0, 400))
+    for f in range(2):
+        _compare_frame(ext, ora, imgs, f, (0, 400), got)
+    ext.close()
+
+
+def test_extract_batch_consistency(gpu_ctx):
+    """A frame's result must not depend on its batch neighbours (no cross-frame leakage)."""
+    import orbhip
+    ext, _ = _mk(gpu_ctx)
+    imgs = orbhip.synth_frames(640, 480, 24, seed=11)
+    a = ext.extract_host(imgs)
+    b = ext.extract_host(imgs[5:6])
+    assert a[5][0].tobytes() == b[0][0].tobytes() and a[5][1].tobytes() == b[0][1].tobytes()
+    c = ext.extract_host(imgs[::-1].copy())
+    for f in range(24):
+        assert a[f][1].tobytes() == c[23 - f][1].tobytes()
+    ext.close()
+
+
+def test_empty_image_and_bad_args(gpu_ctx):
+    import orbhip
+    ext, _ = _mk(gpu_ctx)
+    rc = orbhip.lib.orbhip_extract_batch_host(ext.h, None, 0, 0, 0, 0, 1, 0, 1000, None, None, 0, None, None)
+    assert rc == orbhip.E_EMPTY          # ORBextractor.cc:1072-1073 returns -1 on empty
+    with pytest.raises(orbhip.OrbHipError):
+        ext.reserve(64, 48, 1)           # smaller than one FAST cell: rejected loudly
+    ext.close()
