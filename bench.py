@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- ORB extract+match throughput on synthetic VGA batches (BASELINE.json configs[1]).
+
+One "step" = one pass of the hot path over one batch already resident in HBM:
+  ORBextractor::operator() on `batch` frames (pyramid, FAST+NMS, octree, blur, IC-angle,
+  rBRIEF, lapping assembly) + Hamming 2-NN match of every frame against its successor.
+Prints ONE JSON line (rank 0).  N>1: one process per GPU, frames sharded, no data-path
+collective -> "scaling": "weak".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "orb-slam3-mac_amd", "python"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec" (6.29 TB/s measured copy)
+
+
+def level_dims(w, h, nlevels=8, scale=1.2):
+    import numpy as np
+    sf = np.float32(1.0)
+    dims = []
+    for l in range(nlevels):
+        inv = np.float32(1.0) / sf
+        dims.append((int(np.rint(np.float32(w) * inv)), int(np.rint(np.float32(h) * inv))))
+        sf = np.float32(sf * np.float32(scale))
+    return dims
+
+
+def algorithmic_bytes(w, h, n_kp, nlevels=8):
+    """per-frame algorithmic bytes of each stage."""
+    dims = level_dims(w, h, nlevels)
+    S = sum(a * b for a, b in dims)
+    S_lo = S - dims[-1][0] * dims[-1][1]
+    S_hi = S - dims[0][0] * dims[0][1]
+    return {"pyramid": S_lo + S_hi, "fast": S, "blur": 2 * S, "desc": n_kp * (749 + 512) + n_kp * 36,
+            "octree": 0, "assemble": n_kp * 60 * 2, "total": S_lo + S_hi + S + 2 * S + n_kp * (749 + 512) + n_kp * 60}
+
+
+def cpu_baseline(w, h, nfeat, seconds_budget=20.0):
+    """Oracle (CPU restatement of the reference path) timed on this host's cores: kind 'port'."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    import orbhip
+    import oracle_bind as ob
+    import oracle_match_bind as om
+    cores = min(os.cpu_count() or 1, 16)
+    # single-thread probe: 4 frames
+    imgs = orbhip.synth_frames(w, h, 5, seed=4242)
+    e = ob.OracleExtractor(nfeat, 1.2, 8, 20, 7)
+    t0 = time.time()
+    res = [e.extract(imgs[i]) for i in range(5)]
+    for i in range(4):
+        om.bf2nn(res[i][1], res[i + 1][1], 0.7)
+    t1 = (time.time() - t0) / 4.0
+    per_thread = max(4, int(seconds_budget / max(t1, 1e-3) / 1.0 / 1) // cores)
+    per_thread = min(per_thread, 48)
+
+    def work(tid):
+        ee = ob.OracleExtractor(nfeat, 1.2, 8, 20, 7)
+        fr = orbhip.synth_frames(w, h, per_thread + 1, seed=777, first=tid * 64)
+        prev = ee.extract(fr[0])
+        for i in range(1, per_thread + 1):
+            cur = ee.extract(fr[i])
+            om.bf2nn(prev[1], cur[1], 0.7)
+            prev = cur
+        return per_thread
+
+    t0 = time.time()
+    with ThreadPoolExecutor(cores) as ex:
+        done = sum(ex.map(work, range(cores)))
+    dt = time.time() - t0
+    return {"value": round(done / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d threads x %d frames %dx%d, %d feats, extract + BF 2-NN match vs successor; "
+                      "single-thread %.2f frames/s" % (cores, per_thread, w, h, nfeat, 1.0 / t1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--nfeatures", type=int, default=1000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import orbhip
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    B, W, H = args.batch, args.width, args.height
+    # synthetic frames: generated on the host, then resident in HBM before the timed region
+    imgs = orbhip.synth_frames(W, H, B, seed=20241004, first=rank * B)
+    d_imgs = torch.from_numpy(imgs).cuda()
+    ctx = orbhip.Context(local_rank)
+    ext = orbhip.Extractor(ctx, args.nfeatures, 1.2, 8, 20, 7)
+    ext.reserve(W, H, B)
+    max_kp = ext.max_keypoints
+    d_idx2 = torch.empty((B, max_kp, 2), dtype=torch.int32, device="cuda")
+    d_dist2 = torch.empty((B, max_kp, 2), dtype=torch.int32, device="cuda")
+    d_acc = torch.empty((B, max_kp), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    kp_p, desc_p, cnt_p, mono_p = ext.results_device()
+    dstride = max_kp * 32
+
+    def step():
+        ext.extract_device(d_imgs.data_ptr(), W, H, W, W * H, B, (0, 1000))
+        # frame i vs frame i+1 (B-1 pairs) + wrap-around pair (B-1 vs 0): every frame matched once
+        if B > 1:
+            orbhip.match_bf2nn_device(ctx, desc_p, cnt_p, dstride, desc_p + dstride, cnt_p + 4, dstride, B - 1, max_kp,
+                                      0.7, d_idx2.data_ptr(), d_dist2.data_ptr(), d_acc.data_ptr())
+        orbhip.match_bf2nn_device(ctx, desc_p + (B - 1) * dstride, cnt_p + 4 * (B - 1), dstride, desc_p, cnt_p, dstride, 1,
+                                  max_kp, 0.7, d_idx2.data_ptr() + (B - 1) * max_kp * 8,
+                                  d_dist2.data_ptr() + (B - 1) * max_kp * 8, d_acc.data_ptr() + (B - 1) * max_kp)
+
+    def sync():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    ext.set_profiling(True)
+    if world > 1:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    stage = ext.stage_ms()
+    ext.set_profiling(False)
+    # loud failure if any device-side list overflowed
+    res = ext.extract_host(imgs[:2])   # also re-validates the host path; raises on capacity errors
+    n_kp_avg = float(np.mean([len(r[0]) for r in res]))
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        fps = world * B * args.steps / dt
+        ab = algorithmic_bytes(W, H, n_kp_avg)
+        dom = max(("pyramid", "fast", "blur", "desc", "octree", "assemble"), key=lambda k: stage[k])
+        launches = {"pyramid": 7, "fast": 1, "octree": 1, "blur": 8, "desc": 1, "assemble": 1}[dom]
+        dom_bytes = ab[dom] * B
+        achieved = dom_bytes / (stage[dom] * 1e-3) / 1e9 if stage[dom] > 0 else 0.0
+        out = {
+            "metric": "ORB extract+match frames/sec", "value": round(fps, 1), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": "synthetic %dx%d batch=%d per GPU, 8-level pyramid, %d feats/frame, "
+                                   "ORB extract + Hamming 2-NN match vs successor frame" % (W, H, B, args.nfeatures),
+                       "keypoints_per_frame": round(n_kp_avg, 1),
+                       "stage_ms": {k: round(v, 4) for k, v in stage.items()},
+                       "end_to_end_algorithmic_GBps": round(ab["total"] * B * args.steps / dt / 1e9, 2)},
+            "roofline": {"bound": "hbm", "kernel": dom, "launches_per_step": launches,
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "algorithmic_bytes_per_step": int(dom_bytes)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(W, H, args.nfeatures)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

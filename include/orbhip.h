@@ -105,8 +105,9 @@ int orbhip_extractor_get_fast_candidates(orbhip_extractor *ext, int frame, int l
 int orbhip_extractor_get_level_keypoints(orbhip_extractor *ext, int frame, int level,
                                          orbhip_keypoint *out, int cap, int32_t *n_out);
 
-/* Per-stage device time (ms) of the last extract call, measured with hipEvents recorded on
- * the context's stream when profiling is enabled.  Stage ids: ORBHIP_STAGE_*. */
+/* Per-stage device time (ms), averaged over the extract calls made since the previous query
+ * (at most the 32 most recent), measured with hipEvents recorded on the context's stream
+ * around each stage's launches while profiling is enabled.  Stage ids: ORBHIP_STAGE_*. */
 #define ORBHIP_STAGE_PYRAMID 0
 #define ORBHIP_STAGE_FAST 1
 #define ORBHIP_STAGE_OCTREE 2

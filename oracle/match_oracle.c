@@ -1,0 +1,189 @@
+/*
+ * match_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).  See match_oracle.h.
+ * "ORBm" = /root/reference/src/ORBmatcher.cc, "Frame" = /root/reference/src/Frame.cc.
+ */
+#include "match_oracle.h"
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <limits.h>
+
+#define GRID_COLS 64   /* FRAME_GRID_COLS, include/Frame.h:38 */
+#define GRID_ROWS 48   /* FRAME_GRID_ROWS, include/Frame.h:39 */
+#define TH_LOW 50      /* ORBm:41 */
+#define HISTO_LENGTH 30 /* ORBm:42 */
+
+/* ORBm:2353-2369 */
+int orc_descriptor_distance(const uint8_t *a, const uint8_t *b)
+{
+    int dist = 0;
+    for (int i = 0; i < 8; i++) {
+        uint32_t pa, pb;
+        memcpy(&pa, a + 4 * i, 4); memcpy(&pb, b + 4 * i, 4);
+        unsigned int v = pa ^ pb;
+        v = v - ((v >> 1) & 0x55555555);
+        v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+        dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+    }
+    return dist;
+}
+
+/* Frame.cc:1146-1153 */
+void orc_bf2nn(const uint8_t *A, int na, const uint8_t *B, int nb, double ratio,
+               int32_t *idx2, int32_t *dist2, uint8_t *accept)
+{
+    for (int q = 0; q < na; q++) {
+        int best = INT_MAX, second = INT_MAX, bi = -1, si = -1;
+        for (int j = 0; j < nb; j++) {
+            int d = orc_descriptor_distance(A + 32 * (size_t)q, B + 32 * (size_t)j);
+            if (d < best) { second = best; si = bi; best = d; bi = j; }
+            else if (d < second) { second = d; si = j; }
+        }
+        idx2[2 * q] = bi; idx2[2 * q + 1] = si; dist2[2 * q] = best; dist2[2 * q + 1] = second;
+        accept[q] = (si >= 0 && (float)best < (float)second * ratio) ? 1 : 0;
+    }
+}
+
+/* Frame grid: vectors of indices per cell, insertion order (Frame.cc:377-408, PosInGrid :716-726). */
+struct grid {
+    int *cell_start;   /* [GRID_COLS*GRID_ROWS+1], cell id = ix*GRID_ROWS+iy */
+    int *items;
+    float min_x, min_y, inv_w, inv_h;
+};
+
+static void grid_build(struct grid *g, const orc_keypoint *kp, int n, float min_x, float min_y, float max_x, float max_y)
+{
+    const int nc = GRID_COLS * GRID_ROWS;
+    g->min_x = min_x; g->min_y = min_y;
+    g->inv_w = (float)GRID_COLS / (max_x - min_x);       /* Frame.cc:334-335 */
+    g->inv_h = (float)GRID_ROWS / (max_y - min_y);
+    g->cell_start = (int *)calloc(nc + 1, sizeof(int));
+    g->items = (int *)malloc(sizeof(int) * (n ? n : 1));
+    int *cell = (int *)malloc(sizeof(int) * (n ? n : 1));
+    for (int i = 0; i < n; i++) {
+        int px = (int)roundf((kp[i].x - min_x) * g->inv_w);   /* Frame.cc:718-719: round, not floor */
+        int py = (int)roundf((kp[i].y - min_y) * g->inv_h);
+        if (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) cell[i] = -1;
+        else { cell[i] = px * GRID_ROWS + py; g->cell_start[cell[i] + 1]++; }
+    }
+    for (int c = 0; c < nc; c++) g->cell_start[c + 1] += g->cell_start[c];
+    int *fill = (int *)calloc(nc, sizeof(int));
+    for (int i = 0; i < n; i++) if (cell[i] >= 0) g->items[g->cell_start[cell[i]] + fill[cell[i]]++] = i;
+    free(fill); free(cell);
+}
+static void grid_free(struct grid *g) { free(g->cell_start); free(g->items); }
+
+/* Frame::GetFeaturesInArea, Frame.cc:645-714 */
+static int grid_query(const struct grid *g, const orc_keypoint *kp, float x, float y, float r,
+                      int min_level, int max_level, int32_t *out, int cap)
+{
+    int n = 0;
+    const float fx = r, fy = r;
+    int c0 = (int)floorf((x - g->min_x - fx) * g->inv_w); if (c0 < 0) c0 = 0;
+    if (c0 >= GRID_COLS) return 0;
+    int c1 = (int)ceilf((x - g->min_x + fx) * g->inv_w); if (c1 > GRID_COLS - 1) c1 = GRID_COLS - 1;
+    if (c1 < 0) return 0;
+    int r0 = (int)floorf((y - g->min_y - fy) * g->inv_h); if (r0 < 0) r0 = 0;
+    if (r0 >= GRID_ROWS) return 0;
+    int r1 = (int)ceilf((y - g->min_y + fy) * g->inv_h); if (r1 > GRID_ROWS - 1) r1 = GRID_ROWS - 1;
+    if (r1 < 0) return 0;
+    const int check = (min_level > 0) || (max_level >= 0);
+    for (int ix = c0; ix <= c1; ix++)
+        for (int iy = r0; iy <= r1; iy++) {
+            const int c = ix * GRID_ROWS + iy;
+            for (int j = g->cell_start[c]; j < g->cell_start[c + 1]; j++) {
+                const orc_keypoint *k = &kp[g->items[j]];
+                if (check) {
+                    if (k->octave < min_level) continue;
+                    if (max_level >= 0 && k->octave > max_level) continue;
+                }
+                const float dx = k->x - x, dy = k->y - y;
+                if (fabsf(dx) < fx && fabsf(dy) < fy) { if (n < cap) out[n] = g->items[j]; n++; }
+            }
+        }
+    return n;
+}
+
+int orc_features_in_area(const orc_keypoint *kp, int n, float min_x, float min_y, float max_x, float max_y,
+                         float x, float y, float r, int min_level, int max_level, int32_t *out, int cap)
+{
+    struct grid g;
+    grid_build(&g, kp, n, min_x, min_y, max_x, max_y);
+    int m = grid_query(&g, kp, x, y, r, min_level, max_level, out, cap);
+    grid_free(&g);
+    return m;
+}
+
+/* ORBm:2307-2348 */
+static void three_maxima(const int *hist, int L, int *ind1, int *ind2, int *ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = hist[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; *ind3 = *ind2; *ind2 = *ind1; *ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; *ind3 = *ind2; *ind2 = i; }
+        else if (s > max3) { max3 = s; *ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { *ind2 = -1; *ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { *ind3 = -1; }
+}
+
+/* ORBm:710-825 */
+int orc_search_for_initialization(const orc_keypoint *kpA, const uint8_t *descA, int na,
+                                  const orc_keypoint *kpB, const uint8_t *descB, int nb,
+                                  float min_x, float min_y, float max_x, float max_y,
+                                  int window_size, float nn_ratio, int check_orientation,
+                                  float *prev, int32_t *m12)
+{
+    int nmatches = 0;
+    struct grid g;
+    grid_build(&g, kpB, nb, min_x, min_y, max_x, max_y);
+    int hist[HISTO_LENGTH]; memset(hist, 0, sizeof(hist));
+    int *bin_of = (int *)malloc(sizeof(int) * (na ? na : 1));
+    int *matched_dist = (int *)malloc(sizeof(int) * (nb ? nb : 1));
+    int *m21 = (int *)malloc(sizeof(int) * (nb ? nb : 1));
+    int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * (nb ? nb : 1));
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int i = 0; i < na; i++) { m12[i] = -1; bin_of[i] = -1; }
+    for (int i = 0; i < nb; i++) { matched_dist[i] = INT_MAX; m21[i] = -1; }
+    for (int i1 = 0; i1 < na; i1++) {
+        const int level1 = kpA[i1].octave;
+        if (level1 > 0) continue;
+        int nc = grid_query(&g, kpB, prev[2 * i1], prev[2 * i1 + 1], (float)window_size, level1, level1, cand, nb);
+        if (nc == 0) continue;
+        int best = INT_MAX, best2 = INT_MAX, best_idx = -1;
+        for (int c = 0; c < nc; c++) {
+            const int i2 = cand[c];
+            const int dist = orc_descriptor_distance(descA + 32 * (size_t)i1, descB + 32 * (size_t)i2);
+            if (matched_dist[i2] <= dist) continue;
+            if (dist < best) { best2 = best; best = dist; best_idx = i2; }
+            else if (dist < best2) best2 = dist;
+        }
+        if (best <= TH_LOW) {
+            if (best < (float)best2 * nn_ratio) {
+                if (m21[best_idx] >= 0) { m12[m21[best_idx]] = -1; nmatches--; }
+                m12[i1] = best_idx; m21[best_idx] = i1; matched_dist[best_idx] = best; nmatches++;
+                if (check_orientation) {
+                    float rot = kpA[i1].angle - kpB[best_idx].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)roundf(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    hist[bin]++; bin_of[i1] = bin;
+                }
+            }
+        }
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(hist, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i1 = 0; i1 < na; i1++) {
+            const int b = bin_of[i1];
+            if (b < 0 || b == ind1 || b == ind2 || b == ind3) continue;
+            if (m12[i1] >= 0) { m12[i1] = -1; nmatches--; }
+        }
+    }
+    for (int i1 = 0; i1 < na; i1++)
+        if (m12[i1] >= 0) { prev[2 * i1] = kpB[m12[i1]].x; prev[2 * i1 + 1] = kpB[m12[i1]].y; }
+    grid_free(&g); free(bin_of); free(matched_dist); free(m21); free(cand);
+    return nmatches;
+}

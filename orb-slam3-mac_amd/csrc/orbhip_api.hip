@@ -72,6 +72,7 @@ static inline int cv_round_f(float v) { return (int)lrintf(v); }   // round-half
 static inline int cv_round_d(double v) { return (int)lrint(v); }
 static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 
+#define ORBHIP_PROF_SLOTS 32
 struct orbhip_extractor {
     orbhip_ctx *ctx;
     int nfeatures, nlevels, ini_th, min_th;
@@ -88,7 +89,8 @@ struct orbhip_extractor {
     size_t bytes_reserved;
     int last_batch;
     bool profiling;
-    hipEvent_t ev[ORBHIP_STAGE_COUNT + 1];
+    hipEvent_t ev[ORBHIP_PROF_SLOTS][ORBHIP_STAGE_COUNT + 1];   // ring of per-call stage marks
+    int ev_calls;               // extract calls recorded since the last stage_ms() query
     bool ev_created;
     float stage_ms[ORBHIP_STAGE_COUNT];
     uint8_t *d_level0;          // owned level-0 storage
@@ -104,7 +106,7 @@ extern "C" int orbhip_extractor_create(orbhip_ctx *ctx, int nfeatures, float sca
     e->ctx = ctx; e->nfeatures = nfeatures; e->nlevels = nlevels; e->ini_th = ini_th; e->min_th = min_th;
     e->scale_factor = scale_factor;
     e->width = e->height = e->max_batch = 0; e->bytes_reserved = 0; e->last_batch = 0;
-    e->profiling = false; e->ev_created = false; e->d_level0 = nullptr; e->level0_owned = false;
+    e->profiling = false; e->ev_created = false; e->ev_calls = 0; e->d_level0 = nullptr; e->level0_owned = false;
     memset(&e->P, 0, sizeof(e->P));
     memset(e->stage_ms, 0, sizeof(e->stage_ms));
     // scale tables, ORBextractor.cc:413-429
@@ -145,7 +147,7 @@ extern "C" void orbhip_extractor_destroy(orbhip_extractor *e)
     if (!e) return;
     (void)hipStreamSynchronize(e->ctx->stream);
     ext_free_all(e);
-    if (e->ev_created) for (auto &ev : e->ev) (void)hipEventDestroy(ev);
+    if (e->ev_created) for (auto &slot : e->ev) for (auto &ev : slot) (void)hipEventDestroy(ev);
     delete e;
 }
 
@@ -305,18 +307,30 @@ extern "C" int orbhip_extractor_set_profiling(orbhip_extractor *e, int enable)
 {
     if (!e) return ORBHIP_E_BADARG;
     if (enable && !e->ev_created) {
-        for (auto &ev : e->ev) HIP_TRY(hipEventCreate(&ev));
+        for (auto &slot : e->ev) for (auto &ev : slot) HIP_TRY(hipEventCreate(&ev));
         e->ev_created = true;
     }
     e->profiling = enable != 0;
+    e->ev_calls = 0;
     return ORBHIP_OK;
 }
 
 extern "C" int orbhip_extractor_stage_ms(orbhip_extractor *e, float *ms_out)
 {
-    if (!e || !ms_out || !e->ev_created) return ORBHIP_E_BADARG;
-    HIP_TRY(hipEventSynchronize(e->ev[ORBHIP_STAGE_COUNT]));
-    for (int i = 0; i < ORBHIP_STAGE_COUNT; i++) HIP_TRY(hipEventElapsedTime(&ms_out[i], e->ev[i], e->ev[i + 1]));
+    if (!e || !ms_out || !e->ev_created || e->ev_calls <= 0) return ORBHIP_E_BADARG;
+    // average over the (up to ORBHIP_PROF_SLOTS) most recent extract calls since the last query
+    const int n = std::min(e->ev_calls, ORBHIP_PROF_SLOTS);
+    for (int i = 0; i < ORBHIP_STAGE_COUNT; i++) ms_out[i] = 0.f;
+    for (int c = 0; c < n; c++) {
+        const int slot = (e->ev_calls - 1 - c) % ORBHIP_PROF_SLOTS;
+        HIP_TRY(hipEventSynchronize(e->ev[slot][ORBHIP_STAGE_COUNT]));
+        for (int i = 0; i < ORBHIP_STAGE_COUNT; i++) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, e->ev[slot][i], e->ev[slot][i + 1]));
+            ms_out[i] += ms / n;
+        }
+    }
+    e->ev_calls = 0;
     return ORBHIP_OK;
 }
 
@@ -326,7 +340,8 @@ static int run_pipeline(orbhip_extractor *e, int batch, int lap0, int lap1)
     P.batch = batch; P.lap0 = lap0; P.lap1 = lap1;
     hipStream_t s = e->ctx->stream;
     const bool prof = e->profiling;
-#define STAGE_MARK(i) do { if (prof) HIP_TRY(hipEventRecord(e->ev[i], s)); } while (0)
+    const int slot = e->ev_calls % ORBHIP_PROF_SLOTS;
+#define STAGE_MARK(i) do { if (prof) HIP_TRY(hipEventRecord(e->ev[slot][i], s)); } while (0)
     STAGE_MARK(ORBHIP_STAGE_PYRAMID);
     for (int l = 1; l < e->nlevels; l++) orb_launch_resize(P, l, s);
     STAGE_MARK(ORBHIP_STAGE_FAST);
@@ -341,6 +356,7 @@ static int run_pipeline(orbhip_extractor *e, int batch, int lap0, int lap1)
     orb_launch_assemble(P, s);
     STAGE_MARK(ORBHIP_STAGE_COUNT);
 #undef STAGE_MARK
+    if (prof) e->ev_calls++;
     HIP_TRY(hipGetLastError());
     e->last_batch = batch;
     return ORBHIP_OK;

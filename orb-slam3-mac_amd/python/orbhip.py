@@ -62,6 +62,7 @@ lib.orbhip_extractor_get_level_keypoints.argtypes = [vp, ci, ci, vp, ci, C.POINT
 lib.orbhip_extractor_set_profiling.argtypes = [vp, ci]
 lib.orbhip_extractor_stage_ms.argtypes = [vp, vp]
 lib.orbhip_descriptor_distance.argtypes = [vp, vp]
+lib.orbhip_match_bf2nn_device.argtypes = [vp, vp, vp, sz, vp, vp, sz, ci, ci, cd, vp, vp, vp]
 
 
 class OrbHipError(RuntimeError):
@@ -200,6 +201,13 @@ class Extractor:
         _chk(lib.orbhip_extractor_get_level_keypoints(self.h, frame, level, out.ctypes.data, cap, C.byref(n)),
              "get_level_keypoints")
         return out[:n.value].copy()
+
+
+def match_bf2nn_device(ctx, d_descA, d_nA, strideA, d_descB, d_nB, strideB, pairs, max_n, ratio, d_idx2, d_dist2,
+                       d_accept):
+    """Frame.cc:1146-1153 semantics, batched; all pointers are device addresses (ints)."""
+    _chk(lib.orbhip_match_bf2nn_device(ctx.h, d_descA, d_nA, strideA, d_descB, d_nB, strideB, pairs, max_n, ratio,
+                                       d_idx2, d_dist2, d_accept), "orbhip_match_bf2nn_device")
 
 
 def descriptor_distance(a, b):

@@ -1,0 +1,48 @@
+"""ctypes binding of the matching ORACLE (oracle/match_oracle.c).  TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+import numpy as np
+from oracle_bind import lib, KP_DTYPE
+
+vp, ci, cf, cd = C.c_void_p, C.c_int, C.c_float, C.c_double
+lib.orc_descriptor_distance.argtypes = [vp, vp]
+lib.orc_bf2nn.argtypes = [vp, ci, vp, ci, cd, vp, vp, vp]
+lib.orc_search_for_initialization.argtypes = [vp, vp, ci, vp, vp, ci, cf, cf, cf, cf, ci, cf, ci, vp, vp]
+lib.orc_features_in_area.argtypes = [vp, ci, cf, cf, cf, cf, cf, cf, cf, ci, ci, vp, ci]
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return lib.orc_descriptor_distance(a.ctypes.data, b.ctypes.data)
+
+
+def bf2nn(A, B, ratio=0.7):
+    A = np.ascontiguousarray(A, np.uint8)
+    B = np.ascontiguousarray(B, np.uint8)
+    na, nb = len(A), len(B)
+    idx = np.zeros((max(na, 1), 2), np.int32)
+    dist = np.zeros((max(na, 1), 2), np.int32)
+    acc = np.zeros(max(na, 1), np.uint8)
+    lib.orc_bf2nn(A.ctypes.data, na, B.ctypes.data, nb, ratio, idx.ctypes.data, dist.ctypes.data, acc.ctypes.data)
+    return idx[:na], dist[:na], acc[:na]
+
+
+def search_for_initialization(kpA, dA, kpB, dB, bounds, prev, window=100, ratio=0.9, check_ori=True):
+    kpA = np.ascontiguousarray(kpA, KP_DTYPE)
+    kpB = np.ascontiguousarray(kpB, KP_DTYPE)
+    dA = np.ascontiguousarray(dA, np.uint8)
+    dB = np.ascontiguousarray(dB, np.uint8)
+    prev = np.ascontiguousarray(prev, np.float32).copy()
+    m12 = np.zeros(max(len(kpA), 1), np.int32)
+    n = lib.orc_search_for_initialization(kpA.ctypes.data, dA.ctypes.data, len(kpA), kpB.ctypes.data, dB.ctypes.data,
+                                          len(kpB), bounds[0], bounds[1], bounds[2], bounds[3], window, ratio,
+                                          1 if check_ori else 0, prev.ctypes.data, m12.ctypes.data)
+    return n, m12[:len(kpA)], prev
+
+
+def features_in_area(kp, bounds, x, y, r, min_level, max_level):
+    kp = np.ascontiguousarray(kp, KP_DTYPE)
+    out = np.zeros(max(len(kp), 1), np.int32)
+    n = lib.orc_features_in_area(kp.ctypes.data, len(kp), bounds[0], bounds[1], bounds[2], bounds[3], x, y, r,
+                                 min_level, max_level, out.ctypes.data, len(out))
+    return out[:n]
