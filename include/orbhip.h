@@ -199,6 +199,20 @@ int orbhip_ba_solve_batch(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
                           double *const *poses_inout, double *const *points_inout,
                           uint8_t *const *edge_outlier_out, orbhip_ba_stats *stats_out);
 
+
+/* Two-phase form of the same solver for callers that keep graphs resident in HBM (bench,
+ * map-merge BA): create uploads topology + initial estimates; solve runs both LM passes and
+ * the outlier gates entirely on the device (restarting from the initial estimates each call);
+ * download copies estimates / outlier flags / stats back. */
+typedef struct orbhip_ba_batch orbhip_ba_batch;
+int orbhip_ba_batch_create(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_graphs,
+                           double *const *poses, double *const *points, orbhip_ba_batch **out);
+int orbhip_ba_batch_solve(orbhip_ba_batch *b, const orbhip_ba_params *params, volatile const uint8_t *abort);
+int orbhip_ba_batch_download(orbhip_ba_batch *b, double *const *poses_out, double *const *points_out,
+                             uint8_t *const *edge_outlier_out, orbhip_ba_stats *stats_out);
+int orbhip_ba_batch_ticks(const orbhip_ba_batch *b);   /* LM trials of the slowest graph, last solve */
+void orbhip_ba_batch_destroy(orbhip_ba_batch *b);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,1006 @@
+// ba_kernels.hip -- batched local bundle adjustment on gfx950: the numerical core of
+// Optimizer::LocalBundleAdjustment (reference src/Optimizer.cc:1699-2344), i.e. g2o's
+// Levenberg-Marquardt + Schur complement (BlockSolver_6_3), for G independent graphs at once.
+//
+//   B1  SE3Quat exp / oplus                  Thirdparty/g2o/g2o/types/se3quat.h:104-110,223-257
+//   B2  residuals + chi2                     include/OptimizableTypes.h:99-110, types_six_dof_expmap.cpp:190-197
+//   B3  Jacobians                            src/OptimizableTypes.cpp:139-160, types_six_dof_expmap.cpp:228-274
+//   B4  Huber-weighted quadratic form        g2o/core/base_binary_edge.hpp:55-120, robust_kernel_impl.cpp:65-91
+//   B5  system layout, lambda on diagonals   g2o/core/block_solver.hpp:502-604
+//   B6  Schur complement + reduced solve     g2o/core/block_solver.hpp:354-486, solvers/linear_solver_eigen.h:94-125
+//   B7  LM control                           g2o/core/optimization_algorithm_levenberg.cpp:61-194, sparse_optimizer.cpp:354-419
+//   B8  two-pass schedule + outlier gates    src/Optimizer.cc:2041-2181
+//
+// Design: everything FP64.  The LM state machine of every graph lives on the device
+// (BaState); the host only "ticks" a fixed kernel sequence (one LM trial per tick per
+// graph) and polls one integer.  Edges arrive point-major (the reference's insertion
+// order), so per-point assembly needs no atomics; pose blocks use a host-built pose-major
+// edge list (deterministic reductions).  The only dense contraction, S -= (W D^-1) W^T, runs
+// on the FP64 matrix cores (v_mfma_f64_16x16x4_f64) over a K-padded dense W panel.
+#include "orb_internal.h"
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <algorithm>
+
+struct orbhip_ctx;
+hipStream_t orbhip_ctx_stream_internal(orbhip_ctx *c);
+int orbhip_ctx_device_internal(orbhip_ctx *c);
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------ device structures
+struct BaGraphDev {
+    int n_poses, n_points, n_edges, nf, n, ld;      // n = 6*nf, ld = n rounded up to 48
+    int pose_off, point_off, edge_off, free_off;     // offsets into the concatenated arrays
+    int ptstart_off, posestart_off;                  // into pt_start / pose_start (+g extra entries)
+    size_t wd_off, s_off, spart_off, xl_off;         // element offsets
+    int ks;                                          // split-K factor of the Schur GEMM
+    int ksteps;                                      // K steps (points) per split
+    double fx, fy, cx, cy, bf;
+};
+
+struct BaState {
+    double lambda, ni, current_chi, ini_chi, chi_first, chi_last;
+    int pass, iter, qmax, nbad;
+    int need_build, need_lambda_init, active, cur;   // cur: which pose/point buffer is current
+    int ok;                                          // last LDLT status
+    int iters_run[2], lm_trials, n_outliers;
+    double rho_dbg;
+};
+
+struct BaBatch {      // kernel argument (by value)
+    int G, max_edges, max_points, max_nf, max_ld;
+    const BaGraphDev *gd;
+    BaState *st;
+    // graph topology
+    const int *hidx;            // [sumP]
+    const int *edge_pose, *edge_point;   // [sumE] local indices
+    const double *edge_obs, *edge_is2;   // [sumE*3], [sumE]
+    const uint8_t *edge_stereo;
+    const int *pt_start;        // per graph n_points+1
+    const int *pose_start;      // per graph nf+1  (free poses only, by hessian index)
+    const int *pose_edges;      // [sumE'] edge ids (graph-local) grouped by free pose
+    // estimates, double buffered: buffer b at poses + b*sumP*7
+    double *poses, *points;
+    int sumP, sumL, sumE, sumF;
+    // per-edge
+    double *err, *chi2, *rho0;
+    // system
+    double *Hll, *bl, *Dinv, *db;        // [sumL*6] [sumL*3] [sumL*6] [sumL*3]
+    double *Hpp, *bp, *bs;               // [sumF*36] [sumF*6] [sumF*6]
+    double *Wd;                          // per graph [4*L][ld]
+    double *S, *Spart;                   // per graph [ld*ld], [ks][ld*ld]
+    double *xp, *xl;                     // [sumF*6], [sumL*3]
+    double *scale_pt, *scale_pose;       // partial sums of computeScale
+    double *chi, *scale, *maxdiag;       // [G]
+    int *n_active;                       // [1]
+    uint8_t *outlier;                    // [sumE]
+    // params
+    double delta_m, dsqr_m, delta_s, dsqr_s, gate_m, gate_s, user_lambda, tau;
+    int iters[2], max_trials;
+};
+
+// ------------------------------------------------------------------ SE3 helpers (B1)
+__device__ __forceinline__ void quat_to_R(const double *q, double *R)
+{
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w;
+    const double txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+    R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+__device__ __forceinline__ void quat_rot(const double *q, const double *v, double *o)
+{
+    double u0 = q[1] * v[2] - q[2] * v[1], u1 = q[2] * v[0] - q[0] * v[2], u2 = q[0] * v[1] - q[1] * v[0];
+    u0 += u0; u1 += u1; u2 += u2;
+    o[0] = v[0] + q[3] * u0 + (q[1] * u2 - q[2] * u1);
+    o[1] = v[1] + q[3] * u1 + (q[2] * u0 - q[0] * u2);
+    o[2] = v[2] + q[3] * u2 + (q[0] * u1 - q[1] * u0);
+}
+__device__ __forceinline__ void quat_norm_rot(double *q)
+{
+    if (q[3] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+__device__ void R_to_quat(const double *R, double *q)
+{
+    double t = R[0] + R[4] + R[8];
+    if (t > 0) {
+        t = sqrt(t + 1.0);
+        q[3] = 0.5 * t; t = 0.5 / t;
+        q[0] = (R[7] - R[5]) * t; q[1] = (R[2] - R[6]) * t; q[2] = (R[3] - R[1]) * t;
+    } else {
+        int i = 0;
+        if (R[4] > R[0]) i = 1;
+        if (R[8] > R[4 * i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
+        double qq[4];
+        qq[i] = 0.5 * t; t = 0.5 / t;
+        qq[3] = (R[3 * k + j] - R[3 * j + k]) * t;
+        qq[j] = (R[3 * j + i] + R[3 * i + j]) * t;
+        qq[k] = (R[3 * k + i] + R[3 * i + k]) * t;
+        q[0] = qq[0]; q[1] = qq[1]; q[2] = qq[2]; q[3] = qq[3];
+    }
+}
+// T_new = exp(u) * T  (VertexSE3Expmap::oplusImpl)
+__device__ void se3_oplus(const double *u, const double *pose, double *out)
+{
+    const double om0 = u[0], om1 = u[1], om2 = u[2];
+    const double theta = sqrt(om0 * om0 + om1 * om1 + om2 * om2);
+    const double O[9] = {0, -om2, om1, om2, 0, -om0, -om1, om0, 0};
+    double O2[9], R[9], V[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        double s = 0; for (int k = 0; k < 3; k++) s += O[3 * i + k] * O[3 * k + j];
+        O2[3 * i + j] = s;
+    }
+    if (theta < 0.00001) {
+        for (int i = 0; i < 9; i++) { R[i] = (i % 4 == 0 ? 1.0 : 0.0) + O[i] + O2[i]; V[i] = R[i]; }
+    } else {
+        const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta);
+        const double c = (theta - sin(theta)) / (theta * theta * theta);
+        for (int i = 0; i < 9; i++) {
+            const double I = (i % 4 == 0 ? 1.0 : 0.0);
+            R[i] = I + a * O[i] + b * O2[i];
+            V[i] = I + b * O[i] + c * O2[i];
+        }
+    }
+    double qe[4], te[3], rt[3], qn[4];
+    R_to_quat(R, qe);
+    for (int i = 0; i < 3; i++) te[i] = V[3 * i] * u[3] + V[3 * i + 1] * u[4] + V[3 * i + 2] * u[5];
+    quat_norm_rot(qe);
+    quat_rot(qe, pose + 4, rt);
+    const double *b = pose;
+    qn[3] = qe[3] * b[3] - qe[0] * b[0] - qe[1] * b[1] - qe[2] * b[2];
+    qn[0] = qe[3] * b[0] + qe[0] * b[3] + qe[1] * b[2] - qe[2] * b[1];
+    qn[1] = qe[3] * b[1] + qe[1] * b[3] + qe[2] * b[0] - qe[0] * b[2];
+    qn[2] = qe[3] * b[2] + qe[2] * b[3] + qe[0] * b[1] - qe[1] * b[0];
+    quat_norm_rot(qn);
+    out[0] = qn[0]; out[1] = qn[1]; out[2] = qn[2]; out[3] = qn[3];
+    out[4] = te[0] + rt[0]; out[5] = te[1] + rt[1]; out[6] = te[2] + rt[2];
+}
+
+// ------------------------------------------------------------------ edge math (B2, B3)
+__device__ __forceinline__ void edge_error(const BaGraphDev &g, const double *pose, const double *X, const double *obs,
+                                           int stereo, double *P, double *err)
+{
+    quat_rot(pose, X, P);
+    P[0] += pose[4]; P[1] += pose[5]; P[2] += pose[6];
+    if (!stereo) {
+        err[0] = obs[0] - (g.fx * P[0] / P[2] + g.cx);
+        err[1] = obs[1] - (g.fy * P[1] / P[2] + g.cy);
+        err[2] = 0;
+    } else {   // float invz / float bf, types_six_dof_expmap.cpp:190-197
+        const float invz = (float)(1.0 / P[2]);
+        const float bff = (float)g.bf;
+        const double r0 = P[0] * invz * g.fx + g.cx;
+        err[0] = obs[0] - r0;
+        err[1] = obs[1] - (P[1] * invz * g.fy + g.cy);
+        err[2] = obs[2] - (r0 - (double)__fmul_rn(bff, invz));
+    }
+}
+
+// Jacobians at camera-frame point P with rotation R.  Jx: D x 3, Jt: D x 6 (row-major)
+__device__ __forceinline__ void edge_jacobians(const BaGraphDev &g, const double *P, const double *R, int stereo, double *Jx, double *Jt)
+{
+    const double x = P[0], y = P[1], z = P[2];
+    if (!stereo) {
+        const double iz = 1.0 / z;
+        const double p00 = -(g.fx / z), p02 = g.fx * x / (z * z), p11 = -(g.fy / z), p12 = g.fy * y / (z * z);
+        (void)iz;
+        for (int c = 0; c < 3; c++) {
+            Jx[c] = p00 * R[c] + p02 * R[6 + c];
+            Jx[3 + c] = p11 * R[3 + c] + p12 * R[6 + c];
+        }
+        // SE3deriv = [0 z -y 1 0 0; -z 0 x 0 1 0; y -x 0 0 0 1]
+        Jt[0] = p02 * y;            Jt[1] = p00 * z - p02 * x;  Jt[2] = -p00 * y;  Jt[3] = p00; Jt[4] = 0;   Jt[5] = p02;
+        Jt[6] = -p11 * z + p12 * y; Jt[7] = -p12 * x;           Jt[8] = p11 * x;   Jt[9] = 0;   Jt[10] = p11; Jt[11] = p12;
+    } else {
+        const double z2 = z * z, fx = g.fx, fy = g.fy, bf = g.bf;
+        for (int c = 0; c < 3; c++) {
+            Jx[c] = -fx * R[c] / z + fx * x * R[6 + c] / z2;
+            Jx[3 + c] = -fy * R[3 + c] / z + fy * y * R[6 + c] / z2;
+            Jx[6 + c] = Jx[c] - bf * R[6 + c] / z2;
+        }
+        Jt[0] = x * y / z2 * fx; Jt[1] = -(1 + (x * x / z2)) * fx; Jt[2] = y / z * fx;
+        Jt[3] = -1. / z * fx; Jt[4] = 0; Jt[5] = x / z2 * fx;
+        Jt[6] = (1 + y * y / z2) * fy; Jt[7] = -x * y / z2 * fy; Jt[8] = -x / z * fy;
+        Jt[9] = 0; Jt[10] = -1. / z * fy; Jt[11] = y / z2 * fy;
+        Jt[12] = Jt[0] - bf * y / z2; Jt[13] = Jt[1] + bf * x / z2; Jt[14] = Jt[2];
+        Jt[15] = Jt[3]; Jt[16] = 0; Jt[17] = Jt[5] - bf / z2;
+    }
+}
+
+__device__ __forceinline__ void huber(double e, double delta, double dsqr, double *rho0, double *rho1)
+{
+    if (e <= dsqr) { *rho0 = e; *rho1 = 1.; }
+    else { const double s = sqrt(e); *rho0 = 2 * s * delta - dsqr; *rho1 = delta / s; }
+}
+
+// ------------------------------------------------------------------ kernels
+// which: 0 -> evaluate at the CURRENT estimate for graphs that need a (re)build;
+//        1 -> evaluate at the TRIAL estimate for every active graph.
+__global__ __launch_bounds__(256) void k_ba_errors(BaBatch B, int which)
+{
+    const int g = blockIdx.y;
+    const BaState &st = B.st[g];
+    if (!st.active || (which == 0 && !st.need_build)) return;
+    const BaGraphDev &G = B.gd[g];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= G.n_edges) return;
+    const int buf = which == 0 ? st.cur : (st.cur ^ 1);
+    const int ge = G.edge_off + e;
+    const double *pose = B.poses + ((size_t)buf * B.sumP + G.pose_off + B.edge_pose[ge]) * 7;
+    const double *X = B.points + ((size_t)buf * B.sumL + G.point_off + B.edge_point[ge]) * 3;
+    double P[3], er[3];
+    const int stereo = B.edge_stereo[ge];
+    edge_error(G, pose, X, B.edge_obs + 3 * (size_t)ge, stereo, P, er);
+    const double chi2 = (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * B.edge_is2[ge];
+    double r0, r1;
+    if (stereo) huber(chi2, B.delta_s, B.dsqr_s, &r0, &r1); else huber(chi2, B.delta_m, B.dsqr_m, &r0, &r1);
+    B.err[3 * (size_t)ge] = er[0]; B.err[3 * (size_t)ge + 1] = er[1]; B.err[3 * (size_t)ge + 2] = er[2];
+    B.chi2[ge] = chi2;
+    B.rho0[ge] = r0;
+}
+
+// Deterministic per-graph sums: chi = sum rho0 over edges (activeRobustChi2, sparse_optimizer.cpp:100-114);
+// mode 1 additionally sums computeScale partials (levenberg.cpp:187-194).
+__global__ __launch_bounds__(256) void k_ba_reduce(BaBatch B, int which)
+{
+    __shared__ double red[256];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const BaState &st = B.st[g];
+    if (!st.active || (which == 0 && !st.need_build)) return;
+    const BaGraphDev &G = B.gd[g];
+    double s = 0;
+    for (int e = tid; e < G.n_edges; e += 256) s += B.rho0[G.edge_off + e];
+    red[tid] = s;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) { if (tid < d) red[tid] += red[tid + d]; __syncthreads(); }
+    if (tid == 0) B.chi[g] = red[0];
+    if (which == 1) {
+        __syncthreads();
+        double t = 0;
+        for (int l = tid; l < G.n_points; l += 256) t += B.scale_pt[G.point_off + l];
+        for (int h = tid; h < G.nf; h += 256) t += B.scale_pose[G.free_off + h];
+        red[tid] = t;
+        __syncthreads();
+        for (int d = 128; d > 0; d >>= 1) { if (tid < d) red[tid] += red[tid + d]; __syncthreads(); }
+        if (tid == 0) B.scale[g] = red[0];
+    }
+}
+
+// buildSystem, landmark side: one thread per point walks its (contiguous) edges.
+// Hll (sym 6), bl, and the point's column of Hpl written into the dense K-padded panel
+// Wd[4*l + b][6*h + a] = (J_T^T w Omega J_X)[a][b].
+__global__ __launch_bounds__(128) void k_ba_build_points(BaBatch B)
+{
+    const int g = blockIdx.y;
+    const BaState &st = B.st[g];
+    if (!st.active || !st.need_build) return;
+    const BaGraphDev &G = B.gd[g];
+    const int l = blockIdx.x * 128 + threadIdx.x;
+    if (l >= G.n_points) return;
+    const int *ps = B.pt_start + G.ptstart_off;
+    const int e0 = ps[l], e1 = ps[l + 1];
+    const double *X = B.points + ((size_t)st.cur * B.sumL + G.point_off + l) * 3;
+    double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+    double *Wd = B.Wd + G.wd_off + (size_t)(4 * l) * G.ld;
+    for (int e = e0; e < e1; e++) {
+        const int ge = G.edge_off + e;
+        const int pi = B.edge_pose[ge];
+        const int hi = B.hidx[G.pose_off + pi];
+        const double *pose = B.poses + ((size_t)st.cur * B.sumP + G.pose_off + pi) * 7;
+        const int stereo = B.edge_stereo[ge];
+        const int D = stereo ? 3 : 2;
+        double P[3], R[9], Jx[9], Jt[18];
+        quat_rot(pose, X, P);
+        P[0] += pose[4]; P[1] += pose[5]; P[2] += pose[6];
+        quat_to_R(pose, R);
+        edge_jacobians(G, P, R, stereo, Jx, Jt);
+        const double chi2 = B.chi2[ge];
+        double r0, r1;
+        if (stereo) huber(chi2, B.delta_s, B.dsqr_s, &r0, &r1); else huber(chi2, B.delta_m, B.dsqr_m, &r0, &r1);
+        const double w = r1 * B.edge_is2[ge];
+        const double *es = B.err + 3 * (size_t)ge;
+        for (int d = 0; d < D; d++) {
+            const double j0 = Jx[3 * d], j1 = Jx[3 * d + 1], j2 = Jx[3 * d + 2];
+            const double we = -w * es[d];
+            b[0] += j0 * we; b[1] += j1 * we; b[2] += j2 * we;
+            H[0] += j0 * w * j0; H[1] += j0 * w * j1; H[2] += j0 * w * j2;
+            H[3] += j1 * w * j1; H[4] += j1 * w * j2; H[5] += j2 * w * j2;
+        }
+        if (hi >= 0) {
+            for (int bb = 0; bb < 3; bb++)
+                for (int a = 0; a < 6; a++) {
+                    double h = 0;
+                    for (int d = 0; d < D; d++) h += Jt[6 * d + a] * w * Jx[3 * d + bb];
+                    Wd[(size_t)bb * G.ld + 6 * hi + a] = h;
+                }
+        }
+    }
+    double *Ho = B.Hll + (size_t)(G.point_off + l) * 6, *bo = B.bl + (size_t)(G.point_off + l) * 3;
+    for (int i = 0; i < 6; i++) Ho[i] = H[i];
+    bo[0] = b[0]; bo[1] = b[1]; bo[2] = b[2];
+}
+
+// buildSystem, pose side: one wave per free pose over its edges (pose-major list).
+__global__ __launch_bounds__(64) void k_ba_build_poses(BaBatch B)
+{
+    const int g = blockIdx.y;
+    const BaState &st = B.st[g];
+    if (!st.active || !st.need_build) return;
+    const BaGraphDev &G = B.gd[g];
+    const int h = blockIdx.x;
+    if (h >= G.nf) return;
+    const int lane = threadIdx.x;
+    const int *qs = B.pose_start + G.posestart_off;
+    const int *pe = B.pose_edges + G.edge_off;
+    double acc[27];
+    for (int i = 0; i < 27; i++) acc[i] = 0;
+    for (int k = qs[h] + lane; k < qs[h + 1]; k += 64) {
+        const int e = pe[k];
+        const int ge = G.edge_off + e;
+        const double *pose = B.poses + ((size_t)st.cur * B.sumP + G.pose_off + B.edge_pose[ge]) * 7;
+        const double *X = B.points + ((size_t)st.cur * B.sumL + G.point_off + B.edge_point[ge]) * 3;
+        const int stereo = B.edge_stereo[ge];
+        const int D = stereo ? 3 : 2;
+        double P[3], R[9], Jx[9], Jt[18];
+        quat_rot(pose, X, P);
+        P[0] += pose[4]; P[1] += pose[5]; P[2] += pose[6];
+        quat_to_R(pose, R);
+        edge_jacobians(G, P, R, stereo, Jx, Jt);
+        double r0, r1;
+        const double chi2 = B.chi2[ge];
+        if (stereo) huber(chi2, B.delta_s, B.dsqr_s, &r0, &r1); else huber(chi2, B.delta_m, B.dsqr_m, &r0, &r1);
+        const double w = r1 * B.edge_is2[ge];
+        const double *es = B.err + 3 * (size_t)ge;
+        for (int d = 0; d < D; d++) {
+            const double we = -w * es[d];
+            int idx = 0;
+            for (int a = 0; a < 6; a++) {
+                const double ja = Jt[6 * d + a];
+                acc[21 + a] += ja * we;
+                for (int bb = a; bb < 6; bb++) acc[idx++] += ja * w * Jt[6 * d + bb];
+            }
+        }
+    }
+    for (int i = 0; i < 27; i++) {
+        double v = acc[i];
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        acc[i] = v;
+    }
+    if (lane == 0) {
+        double *Hp = B.Hpp + (size_t)(G.free_off + h) * 36;
+        int idx = 0;
+        for (int a = 0; a < 6; a++)
+            for (int bb = a; bb < 6; bb++) { Hp[6 * a + bb] = acc[idx]; Hp[6 * bb + a] = acc[idx]; idx++; }
+        for (int a = 0; a < 6; a++) B.bp[(size_t)(G.free_off + h) * 6 + a] = acc[21 + a];
+    }
+}
+
+// computeLambdaInit (levenberg.cpp:171-185): max |diag| over pose and landmark blocks
+__global__ __launch_bounds__(256) void k_ba_maxdiag(BaBatch B)
+{
+    __shared__ double red[256];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const BaState &st = B.st[g];
+    if (!st.active || !st.need_build || !st.need_lambda_init) return;
+    const BaGraphDev &G = B.gd[g];
+    const int *ps = B.pt_start + G.ptstart_off;
+    double m = 0;
+    for (int h = tid; h < G.nf; h += 256)
+        for (int a = 0; a < 6; a++) m = fmax(m, fabs(B.Hpp[(size_t)(G.free_off + h) * 36 + 7 * a]));
+    for (int l = tid; l < G.n_points; l += 256)
+        if (ps[l + 1] > ps[l]) {
+            const double *H = B.Hll + (size_t)(G.point_off + l) * 6;
+            m = fmax(m, fmax(fabs(H[0]), fmax(fabs(H[3]), fabs(H[5]))));
+        }
+    red[tid] = m;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) { if (tid < d) red[tid] = fmax(red[tid], red[tid + d]); __syncthreads(); }
+    if (tid == 0) B.maxdiag[g] = red[0];
+}
+
+// start of an outer LM iteration (levenberg.cpp:71-92) for graphs that just (re)built
+__global__ void k_ba_pretrial(BaBatch B)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= B.G) return;
+    BaState &st = B.st[g];
+    if (!st.active || !st.need_build) return;
+    st.current_chi = B.chi[g];
+    st.ini_chi = st.current_chi;
+    if (st.chi_first < 0) st.chi_first = st.current_chi;
+    if (st.need_lambda_init) {
+        st.lambda = B.user_lambda > 0 ? B.user_lambda : B.tau * B.maxdiag[g];
+        st.ni = 2; st.nbad = 0;
+        st.need_lambda_init = 0;
+    }
+    st.qmax = 0;
+    st.need_build = 0;
+}
+
+// per trial: D = Hll + lambda I, D^-1 (symmetric), db = D^-1 bl   (block_solver.hpp:395-404)
+__global__ __launch_bounds__(256) void k_ba_point_prep(BaBatch B)
+{
+    const int g = blockIdx.y;
+    const BaState &st = B.st[g];
+    if (!st.active) return;
+    const BaGraphDev &G = B.gd[g];
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= G.n_points) return;
+    const int *ps = B.pt_start + G.ptstart_off;
+    double *Di = B.Dinv + (size_t)(G.point_off + l) * 6, *db = B.db + (size_t)(G.point_off + l) * 3;
+    if (ps[l + 1] == ps[l]) { for (int i = 0; i < 6; i++) Di[i] = 0; db[0] = db[1] = db[2] = 0; return; }
+    const double *H = B.Hll + (size_t)(G.point_off + l) * 6;
+    const double a00 = H[0] + st.lambda, a01 = H[1], a02 = H[2], a11 = H[3] + st.lambda, a12 = H[4], a22 = H[5] + st.lambda;
+    const double c0 = a11 * a22 - a12 * a12, c1 = a12 * a02 - a01 * a22, c2 = a01 * a12 - a11 * a02;
+    const double id = 1.0 / (a00 * c0 + a01 * c1 + a02 * c2);
+    const double i00 = c0 * id, i01 = c1 * id, i02 = c2 * id;
+    const double i11 = (a00 * a22 - a02 * a02) * id, i12 = (a02 * a01 - a00 * a12) * id, i22 = (a00 * a11 - a01 * a01) * id;
+    Di[0] = i00; Di[1] = i01; Di[2] = i02; Di[3] = i11; Di[4] = i12; Di[5] = i22;
+    const double *b = B.bl + (size_t)(G.point_off + l) * 3;
+    db[0] = i00 * b[0] + i01 * b[1] + i02 * b[2];
+    db[1] = i01 * b[0] + i11 * b[1] + i12 * b[2];
+    db[2] = i02 * b[0] + i12 * b[1] + i22 * b[2];
+}
+
+// Schur GEMM on the FP64 matrix cores:  Spart[ks] (upper 48x48 wave tiles) =
+//   sum over points l in the split of  (D_l^-1 Wd_l)^T(rows r0..) x Wd_l(cols c0..)
+// v_mfma_f64_16x16x4_f64: A[i][k] (lane i=l&15,k=l>>4), B[k][j] (lane j=l&15,k=l>>4),
+// C/D: 4 regs, col = l&15, row = (l>>4) + 4*reg.  K = 4 per point (3 + zero pad).
+// One wave per (tile_r <= tile_c, split) work item; D^-1 is applied to the A fragment in
+// registers, so no second dense panel is materialised.
+__global__ __launch_bounds__(256) void k_ba_schur_gemm(BaBatch B)
+{
+    const int g = blockIdx.y;
+    const BaState &st = B.st[g];
+    if (!st.active) return;
+    const BaGraphDev &G = B.gd[g];
+    const int nt = G.ld / 48;
+    const int ntiles = nt * (nt + 1) / 2;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= ntiles * G.ks) return;
+    const int lane = threadIdx.x & 63;
+    const int ksi = item / ntiles;
+    int t = item - ksi * ntiles, tr = 0;
+    while (t >= nt - tr) { t -= nt - tr; tr++; }
+    const int tc = tr + t;
+    const int r0 = tr * 48, c0 = tc * 48;
+    const int l0 = ksi * G.ksteps, l1 = min(G.n_points, l0 + G.ksteps);
+    const int li = lane & 15, lk = lane >> 4;
+    v4d acc[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) acc[i][j] = (v4d){0, 0, 0, 0};
+    const double *Wd = B.Wd + G.wd_off;
+    const double *Dv = B.Dinv + (size_t)G.point_off * 6;
+    for (int l = l0; l < l1; l++) {
+        const double *row = Wd + (size_t)(4 * l) * G.ld;
+        const double *Di = Dv + (size_t)l * 6;
+        // row lk of the symmetric D^-1 (row 3 = zero padding)
+        double d0 = 0, d1 = 0, d2 = 0;
+        if (lk == 0) { d0 = Di[0]; d1 = Di[1]; d2 = Di[2]; }
+        else if (lk == 1) { d0 = Di[1]; d1 = Di[3]; d2 = Di[4]; }
+        else if (lk == 2) { d0 = Di[2]; d1 = Di[4]; d2 = Di[5]; }
+        double a[3], b[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const double *p = row + r0 + 16 * i + li;
+            a[i] = d0 * p[0] + d1 * p[G.ld] + d2 * p[2 * (size_t)G.ld];
+            b[i] = row[(size_t)lk * G.ld + c0 + 16 * i + li];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    double *Sp = B.Spart + G.spart_off + (size_t)ksi * G.ld * G.ld;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                Sp[(size_t)(r0 + 16 * i + lk + 4 * r) * G.ld + c0 + 16 * j + li] = acc[i][j][r];
+}
+
+// S = blockdiag(Hpp + lambda I) - sum_ks Spart (mirrored from the upper tiles); padding rows -> identity
+__global__ __launch_bounds__(256) void k_ba_schur_finish(BaBatch B)
+{
+    const int g = blockIdx.y;
+    const BaState &st = B.st[g];
+    if (!st.active) return;
+    const BaGraphDev &G = B.gd[g];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= G.ld * G.ld) return;
+    const int r = idx / G.ld, c = idx - r * G.ld;
+    double v = 0;
+    if (r >= G.n || c >= G.n) v = (r == c) ? 1.0 : 0.0;
+    else {
+        if (r / 6 == c / 6) v = B.Hpp[(size_t)(G.free_off + r / 6) * 36 + (r % 6) * 6 + (c % 6)] + (r == c ? st.lambda : 0.0);
+        const int ur = (r / 48 <= c / 48) ? r : c, uc = (r / 48 <= c / 48) ? c : r;   // upper-tile source
+        const double *Sp = B.Spart + G.spart_off + (size_t)ur * G.ld + uc;
+        double s = 0;
+        for (int k = 0; k < G.ks; k++) s += Sp[(size_t)k * G.ld * G.ld];
+        v -= s;
+    }
+    B.S[G.s_off + idx] = v;
+}
+
+// bs = bp - sum_{edges of pose} W_e * db_point   (block_solver.hpp:409-416,435-438), one wave per free pose
+__global__ __launch_bounds__(64) void k_ba_bschur(BaBatch B)
+{
+    const int g = blockIdx.y;
+    const BaState &st = B.st[g];
+    if (!st.active) return;
+    const BaGraphDev &G = B.gd[g];
+    const int h = blockIdx.x;
+    if (h >= G.nf) return;
+    const int lane = threadIdx.x;
+    const int *qs = B.pose_start + G.posestart_off;
+    const int *pe = B.pose_edges + G.edge_off;
+    const double *Wd = B.Wd + G.wd_off;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int k = qs[h] + lane; k < qs[h + 1]; k += 64) {
+        const int l = B.edge_point[G.edge_off + pe[k]];
+        const double *db = B.db + (size_t)(G.point_off + l) * 3;
+        const double *w = Wd + (size_t)(4 * l) * G.ld + 6 * h;
+        for (int a = 0; a < 6; a++) acc[a] += w[a] * db[0] + w[G.ld + a] * db[1] + w[2 * (size_t)G.ld + a] * db[2];
+    }
+    for (int a = 0; a < 6; a++) {
+        double v = acc[a];
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        acc[a] = v;
+    }
+    if (lane == 0)
+        for (int a = 0; a < 6; a++) B.bs[(size_t)(G.free_off + h) * 6 + a] = B.bp[(size_t)(G.free_off + h) * 6 + a] - acc[a];
+}
+
+// Reduced pose system: dense LDL^T without pivoting + solve, one workgroup per graph
+// (stands in for Eigen::SimplicialLDLT, linear_solver_eigen.h:94-125; fails on a zero /
+// non-finite pivot).  Right-looking, lower triangle of S in global memory (L2-resident),
+// current column and right-hand side in LDS; the forward substitution rides along as an
+// extra row of the elimination.
+#define BA_LDLT_MAXN 768
+__global__ __launch_bounds__(1024) void k_ba_ldlt(BaBatch B)
+{
+    __shared__ double col[BA_LDLT_MAXN];     // unscaled column j below the diagonal
+    __shared__ double y[BA_LDLT_MAXN];       // right-hand side being eliminated
+    __shared__ double s_d;
+    __shared__ int s_ok;
+    const int g = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
+    BaState &st = B.st[g];
+    if (!st.active) return;
+    const BaGraphDev &G = B.gd[g];
+    const int n = G.n, ld = G.ld;
+    double *S = B.S + G.s_off;
+    for (int i = tid; i < n; i += nth) y[i] = B.bs[(size_t)G.free_off * 6 + i];
+    if (tid == 0) s_ok = 1;
+    __syncthreads();
+    for (int j = 0; j < n; j++) {
+        if (tid == 0) {
+            const double d = S[(size_t)j * ld + j];
+            s_d = d;
+            if (d == 0.0 || !isfinite(d)) s_ok = 0;
+        }
+        for (int i = j + 1 + tid; i < n; i += nth) col[i] = S[(size_t)i * ld + j];
+        __syncthreads();
+        if (!s_ok) break;
+        const double d = s_d, yj = y[j];
+        const int m = n - j - 1;
+        // trailing update of the lower triangle: S[i][k] -= (col[i]/d) * col[k],  j < k <= i < n
+        for (int t = tid; t < m * m; t += nth) {
+            const int i = j + 1 + t / m, k = j + 1 + t % m;
+            if (k <= i) S[(size_t)i * ld + k] -= (col[i] / d) * col[k];
+        }
+        for (int i = j + 1 + tid; i < n; i += nth) {
+            S[(size_t)i * ld + j] = col[i] / d;          // L
+            y[i] -= (col[i] / d) * yj;                   // forward substitution
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (!s_ok) { if (tid == 0) st.ok = 0; return; }      // x untouched (as the reference on failure)
+    // y <- D^-1 y ; back substitution with rows of L (contiguous)
+    for (int i = tid; i < n; i += nth) y[i] /= S[(size_t)i * ld + i];
+    __syncthreads();
+    for (int i = n - 1; i >= 0; i--) {
+        const double xi = y[i];
+        for (int k = tid; k < i; k += nth) y[k] -= S[(size_t)i * ld + k] * xi;
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += nth) B.xp[(size_t)G.free_off * 6 + i] = y[i];
+    if (tid == 0) st.ok = 1;
+}
+
+// landmark back-substitution (block_solver.hpp:461-481) + trial update of every vertex
+// (sparse_optimizer.cpp:422-435) + computeScale partials (levenberg.cpp:187-194)
+__global__ __launch_bounds__(128) void k_ba_backsub_points(BaBatch B)
+{
+    const int g = blockIdx.y;
+    const BaState &st = B.st[g];
+    if (!st.active) return;
+    const BaGraphDev &G = B.gd[g];
+    const int l = blockIdx.x * 128 + threadIdx.x;
+    if (l >= G.n_points) return;
+    const int *ps = B.pt_start + G.ptstart_off;
+    const size_t gl = (size_t)G.point_off + l;
+    double *xl = B.xl + gl * 3;
+    const double *Xc = B.points + ((size_t)st.cur * B.sumL + gl) * 3;
+    double *Xn = B.points + ((size_t)(st.cur ^ 1) * B.sumL + gl) * 3;
+    if (ps[l + 1] == ps[l]) { Xn[0] = Xc[0]; Xn[1] = Xc[1]; Xn[2] = Xc[2]; B.scale_pt[gl] = 0; return; }
+    const double *bl = B.bl + gl * 3;
+    if (st.ok) {
+        double c0 = bl[0], c1 = bl[1], c2 = bl[2];
+        const double *Wd = B.Wd + G.wd_off + (size_t)(4 * l) * G.ld;
+        for (int e = ps[l]; e < ps[l + 1]; e++) {
+            const int h = B.hidx[G.pose_off + B.edge_pose[G.edge_off + e]];
+            if (h < 0) continue;
+            const double *xp = B.xp + (size_t)(G.free_off + h) * 6;
+            const double *w = Wd + 6 * h;
+            for (int a = 0; a < 6; a++) { c0 -= w[a] * xp[a]; c1 -= w[G.ld + a] * xp[a]; c2 -= w[2 * (size_t)G.ld + a] * xp[a]; }
+        }
+        const double *Di = B.Dinv + gl * 6;
+        xl[0] = Di[0] * c0 + Di[1] * c1 + Di[2] * c2;
+        xl[1] = Di[1] * c0 + Di[3] * c1 + Di[4] * c2;
+        xl[2] = Di[2] * c0 + Di[4] * c1 + Di[5] * c2;
+    }
+    Xn[0] = Xc[0] + xl[0]; Xn[1] = Xc[1] + xl[1]; Xn[2] = Xc[2] + xl[2];
+    B.scale_pt[gl] = xl[0] * (st.lambda * xl[0] + bl[0]) + xl[1] * (st.lambda * xl[1] + bl[1]) + xl[2] * (st.lambda * xl[2] + bl[2]);
+}
+
+__global__ __launch_bounds__(64) void k_ba_update_poses(BaBatch B)
+{
+    const int g = blockIdx.y;
+    const BaState &st = B.st[g];
+    if (!st.active) return;
+    const BaGraphDev &G = B.gd[g];
+    const int p = blockIdx.x * 64 + threadIdx.x;
+    if (p >= G.n_poses) return;
+    const double *pc = B.poses + ((size_t)st.cur * B.sumP + G.pose_off + p) * 7;
+    double *pn = B.poses + ((size_t)(st.cur ^ 1) * B.sumP + G.pose_off + p) * 7;
+    const int h = B.hidx[G.pose_off + p];
+    if (h < 0) { for (int i = 0; i < 7; i++) pn[i] = pc[i]; return; }
+    const double *x = B.xp + (size_t)(G.free_off + h) * 6;
+    se3_oplus(x, pc, pn);
+    const double *bp = B.bp + (size_t)(G.free_off + h) * 6;
+    double s = 0;
+    for (int a = 0; a < 6; a++) s += x[a] * (st.lambda * x[a] + bp[a]);
+    B.scale_pose[G.free_off + h] = s;
+}
+
+// LM accept/reject + iteration bookkeeping: levenberg.cpp:121-169, sparse_optimizer.cpp:372-418,
+// Optimizer.cc:2048-2122 (two passes).  One thread per graph.
+__global__ void k_ba_control(BaBatch B, int abort_flag)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= B.G) return;
+    BaState &st = B.st[g];
+    if (!st.active) return;
+    double temp_chi = B.chi[g];
+    if (!st.ok) temp_chi = DBL_MAX;
+    double rho = st.current_chi - temp_chi;
+    const double scale = B.scale[g] + 1e-3;
+    rho /= scale;
+    if (rho > 0 && isfinite(temp_chi)) {
+        double alpha = 1. - pow((2 * rho - 1), 3);
+        alpha = fmin(alpha, 2. / 3.);
+        const double sf = fmax(1. / 3., alpha);
+        st.lambda *= sf; st.ni = 2; st.current_chi = temp_chi;
+        st.cur ^= 1;                                   // discardTop: the trial becomes the estimate
+    } else {
+        st.lambda *= st.ni; st.ni *= 2;                // pop: keep the old estimate
+    }
+    st.qmax++; st.lm_trials++;
+    st.rho_dbg = rho;
+    if (rho < 0 && st.qmax < B.max_trials && !abort_flag) return;      // retry with the larger lambda
+    // outer iteration finished
+    st.iters_run[st.pass]++;
+    st.chi_last = st.current_chi;
+    int ok = 1;
+    if (st.qmax == B.max_trials || rho == 0) ok = 0;
+    else {
+        if ((st.ini_chi - st.current_chi) * 1e3 < st.ini_chi) st.nbad++; else st.nbad = 0;
+        if (st.nbad >= 3) ok = 0;
+    }
+    st.iter++;
+    st.need_build = 1;
+    if (!ok || st.iter >= B.iters[st.pass] || abort_flag) {
+        if (st.pass == 0 && !abort_flag && B.iters[1] > 0) { st.pass = 1; st.iter = 0; st.need_lambda_init = 1; }
+        else { st.active = 0; atomicSub(B.n_active, 1); }
+    }
+}
+
+// outlier gates, Optimizer.cc:2126-2173: stored chi2 of the last evaluation; depth at the final estimate
+__global__ __launch_bounds__(256) void k_ba_finalize(BaBatch B)
+{
+    const int g = blockIdx.y;
+    const BaState &st = B.st[g];
+    const BaGraphDev &G = B.gd[g];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= G.n_edges) return;
+    const int ge = G.edge_off + e;
+    const double *pose = B.poses + ((size_t)st.cur * B.sumP + G.pose_off + B.edge_pose[ge]) * 7;
+    const double *X = B.points + ((size_t)st.cur * B.sumL + G.point_off + B.edge_point[ge]) * 3;
+    double P[3];
+    quat_rot(pose, X, P);
+    const double z = P[2] + pose[6];
+    const double gate = B.edge_stereo[ge] ? B.gate_s : B.gate_m;
+    const int out = (B.chi2[ge] > gate) || !(z > 0.0);
+    B.outlier[ge] = (uint8_t)out;
+    if (out) atomicAdd(&B.st[g].n_outliers, 1);
+}
+
+// ------------------------------------------------------------------ host side
+static thread_local std::string g_ba_error;
+
+struct orbhip_ba_batch {
+    orbhip_ctx *ctx;
+    BaBatch B;
+    std::vector<BaGraphDev> gd;
+    std::vector<void *> allocs;
+    std::vector<double> poses0, points0;     // normalised initial estimates (host copy)
+    int *h_n_active;                         // pinned
+    size_t wd_total, s_total, spart_total;
+    int ticks_last;
+};
+
+template <typename T>
+static T *ba_alloc(orbhip_ba_batch *b, size_t count)
+{
+    void *p = nullptr;
+    if (hipMalloc(&p, std::max<size_t>(count * sizeof(T), 256)) != hipSuccess) return nullptr;
+    b->allocs.push_back(p);
+    return (T *)p;
+}
+template <typename T>
+static T *ba_upload(orbhip_ba_batch *b, const std::vector<T> &v)
+{
+    T *d = ba_alloc<T>(b, v.size());
+    if (d && !v.empty() && hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    return d;
+}
+
+extern "C" void orbhip_ba_default_params(orbhip_ba_params *p)
+{
+    p->iters1 = 5; p->iters2 = 10; p->huber_mono2 = 5.991; p->huber_stereo2 = 7.815;
+    p->user_lambda_init = 0.0; p->tau = 1e-50; p->max_trials = 100;
+}
+
+extern "C" void orbhip_ba_batch_destroy(orbhip_ba_batch *b)
+{
+    if (!b) return;
+    (void)hipStreamSynchronize(orbhip_ctx_stream_internal(b->ctx));
+    for (void *p : b->allocs) (void)hipFree(p);
+    if (b->h_n_active) (void)hipHostFree(b->h_n_active);
+    delete b;
+}
+
+extern "C" int orbhip_ba_batch_create(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_graphs,
+                                      double *const *poses, double *const *points, orbhip_ba_batch **out)
+{
+    if (!ctx || !graphs || n_graphs <= 0 || !poses || !points || !out) return ORBHIP_E_BADARG;
+    if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
+    orbhip_ba_batch *b = new orbhip_ba_batch();
+    b->ctx = ctx; b->h_n_active = nullptr; b->ticks_last = 0;
+    BaBatch &B = b->B;
+    memset(&B, 0, sizeof(B));
+    B.G = n_graphs;
+    std::vector<int> hidx, epose, epoint, ptstart, posestart, poseedges;
+    std::vector<double> eobs, eis2;
+    std::vector<uint8_t> est;
+    int sumP = 0, sumL = 0, sumE = 0, sumF = 0;
+    size_t wd = 0, s = 0, sp = 0;
+    // split-K so that the Schur GEMM launches >= ~4096 waves
+    for (int g = 0; g < n_graphs; g++) {
+        const orbhip_ba_graph &H = graphs[g];
+        if (H.n_poses <= 0 || H.n_points <= 0 || H.n_edges < 0) { delete b; return ORBHIP_E_BADARG; }
+        BaGraphDev D;
+        memset(&D, 0, sizeof(D));
+        D.n_poses = H.n_poses; D.n_points = H.n_points; D.n_edges = H.n_edges;
+        D.pose_off = sumP; D.point_off = sumL; D.edge_off = sumE; D.free_off = sumF;
+        D.fx = H.fx; D.fy = H.fy; D.cx = H.cx; D.cy = H.cy; D.bf = H.bf;
+        std::vector<int> has(H.n_poses, 0), local_h(H.n_poses, -1);
+        for (int e = 0; e < H.n_edges; e++) {
+            if (H.edge_pose[e] < 0 || H.edge_pose[e] >= H.n_poses || H.edge_point[e] < 0 || H.edge_point[e] >= H.n_points ||
+                (e > 0 && H.edge_point[e] < H.edge_point[e - 1])) { delete b; g_ba_error = "edges must be point-major with valid ids"; return ORBHIP_E_BADARG; }
+            has[H.edge_pose[e]] = 1;
+        }
+        int nf = 0;
+        for (int i = 0; i < H.n_poses; i++) { local_h[i] = (!H.pose_fixed[i] && has[i]) ? nf++ : -1; hidx.push_back(local_h[i]); }
+        D.nf = nf; D.n = 6 * nf; D.ld = std::max(48, (D.n + 47) / 48 * 48);
+        if (D.n > BA_LDLT_MAXN) { delete b; g_ba_error = "too many free keyframes for the single-workgroup LDLT (max 128)"; return ORBHIP_E_BADARG; }
+        D.ptstart_off = (int)ptstart.size();
+        std::vector<int> cnt(H.n_points + 1, 0);
+        for (int e = 0; e < H.n_edges; e++) cnt[H.edge_point[e] + 1]++;
+        for (int l = 0; l < H.n_points; l++) cnt[l + 1] += cnt[l];
+        ptstart.insert(ptstart.end(), cnt.begin(), cnt.end());
+        D.posestart_off = (int)posestart.size();
+        std::vector<int> pc(nf + 1, 0);
+        for (int e = 0; e < H.n_edges; e++) if (local_h[H.edge_pose[e]] >= 0) pc[local_h[H.edge_pose[e]] + 1]++;
+        for (int h = 0; h < nf; h++) pc[h + 1] += pc[h];
+        std::vector<int> fill(pc.begin(), pc.end() - 1), pel(H.n_edges, 0);
+        for (int e = 0; e < H.n_edges; e++) { const int h = local_h[H.edge_pose[e]]; if (h >= 0) pel[fill[h]++] = e; }
+        posestart.insert(posestart.end(), pc.begin(), pc.end());
+        poseedges.insert(poseedges.end(), pel.begin(), pel.end());
+        for (int e = 0; e < H.n_edges; e++) {
+            epose.push_back(H.edge_pose[e]); epoint.push_back(H.edge_point[e]);
+            eobs.push_back(H.edge_obs[3 * e]); eobs.push_back(H.edge_obs[3 * e + 1]); eobs.push_back(H.edge_obs[3 * e + 2]);
+            eis2.push_back(H.edge_inv_sigma2[e]); est.push_back(H.edge_stereo ? H.edge_stereo[e] : 0);
+        }
+        const int nt = D.ld / 48, ntiles = nt * (nt + 1) / 2;
+        int ks = (4096 + n_graphs * ntiles - 1) / (n_graphs * ntiles);
+        ks = std::max(1, std::min(ks, 64));
+        ks = std::min(ks, std::max(1, H.n_points / 8));
+        D.ks = ks; D.ksteps = (H.n_points + ks - 1) / ks;
+        D.wd_off = wd; wd += (size_t)4 * H.n_points * D.ld;
+        D.s_off = s; s += (size_t)D.ld * D.ld;
+        D.spart_off = sp; sp += (size_t)ks * D.ld * D.ld;
+        B.max_edges = std::max(B.max_edges, H.n_edges); B.max_points = std::max(B.max_points, H.n_points);
+        B.max_nf = std::max(B.max_nf, nf); B.max_ld = std::max(B.max_ld, D.ld);
+        // initial estimates: SE3Quat ctor normalises the rotation (se3quat.h:58-64)
+        for (int i = 0; i < H.n_poses; i++) {
+            double q[7];
+            memcpy(q, poses[g] + 7 * i, sizeof(q));
+            if (q[3] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+            const double nn = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+            for (int k = 0; k < 4; k++) q[k] /= nn;
+            b->poses0.insert(b->poses0.end(), q, q + 7);
+        }
+        b->points0.insert(b->points0.end(), points[g], points[g] + 3 * (size_t)H.n_points);
+        sumP += H.n_poses; sumL += H.n_points; sumE += H.n_edges; sumF += nf;
+        b->gd.push_back(D);
+    }
+    B.sumP = sumP; B.sumL = sumL; B.sumE = sumE; B.sumF = sumF;
+    b->wd_total = wd; b->s_total = s; b->spart_total = sp;
+    bool ok = true;
+#define UP(dst, vec) do { auto *_p = ba_upload(b, vec); ok = ok && _p; dst = _p; } while (0)
+#define AL(dst, T, n) do { auto *_p = ba_alloc<T>(b, n); ok = ok && _p; dst = _p; } while (0)
+    UP(B.gd, b->gd); UP(B.hidx, hidx); UP(B.edge_pose, epose); UP(B.edge_point, epoint); UP(B.edge_obs, eobs);
+    UP(B.edge_is2, eis2); UP(B.edge_stereo, est); UP(B.pt_start, ptstart); UP(B.pose_start, posestart); UP(B.pose_edges, poseedges);
+    AL(B.st, BaState, n_graphs);
+    AL(B.poses, double, (size_t)2 * sumP * 7); AL(B.points, double, (size_t)2 * sumL * 3);
+    AL(B.err, double, (size_t)sumE * 3); AL(B.chi2, double, sumE); AL(B.rho0, double, sumE);
+    AL(B.Hll, double, (size_t)sumL * 6); AL(B.bl, double, (size_t)sumL * 3); AL(B.Dinv, double, (size_t)sumL * 6); AL(B.db, double, (size_t)sumL * 3);
+    AL(B.Hpp, double, (size_t)sumF * 36); AL(B.bp, double, (size_t)sumF * 6); AL(B.bs, double, (size_t)sumF * 6);
+    AL(B.Wd, double, wd); AL(B.S, double, s); AL(B.Spart, double, sp);
+    AL(B.xp, double, (size_t)sumF * 6); AL(B.xl, double, (size_t)sumL * 3);
+    AL(B.scale_pt, double, sumL); AL(B.scale_pose, double, sumF);
+    AL(B.chi, double, n_graphs); AL(B.scale, double, n_graphs); AL(B.maxdiag, double, n_graphs);
+    AL(B.n_active, int, 1); AL(B.outlier, uint8_t, sumE);
+#undef UP
+#undef AL
+    if (!ok || hipHostMalloc((void **)&b->h_n_active, sizeof(int)) != hipSuccess) { orbhip_ba_batch_destroy(b); g_ba_error = "device allocation failed"; return ORBHIP_E_HIP; }
+    // the dense W panel keeps its zero pattern for the life of the batch: clear once
+    if (hipMemset(B.Wd, 0, wd * sizeof(double)) != hipSuccess) { orbhip_ba_batch_destroy(b); return ORBHIP_E_HIP; }
+    *out = b;
+    return ORBHIP_OK;
+}
+
+// Runs optimize(iters1) + optimize(iters2) + outlier classification for every graph of the batch,
+// starting from the initial estimates given at creation.  Device-resident; returns after completion.
+extern "C" int orbhip_ba_batch_solve(orbhip_ba_batch *b, const orbhip_ba_params *params, volatile const uint8_t *abort_flag)
+{
+    if (!b || !params) return ORBHIP_E_BADARG;
+    if (hipSetDevice(orbhip_ctx_device_internal(b->ctx)) != hipSuccess) return ORBHIP_E_HIP;
+    if (abort_flag && *abort_flag) return ORBHIP_E_ABORTED;                    // Optimizer.cc:2041-2043
+    hipStream_t s = orbhip_ctx_stream_internal(b->ctx);
+    BaBatch &B = b->B;
+    B.delta_m = (double)(float)sqrt(params->huber_mono2); B.dsqr_m = (double)(float)(B.delta_m * B.delta_m);
+    B.delta_s = (double)(float)sqrt(params->huber_stereo2); B.dsqr_s = (double)(float)(B.delta_s * B.delta_s);
+    B.gate_m = params->huber_mono2; B.gate_s = params->huber_stereo2;
+    B.user_lambda = params->user_lambda_init; B.tau = params->tau;
+    B.iters[0] = params->iters1; B.iters[1] = params->iters2; B.max_trials = params->max_trials;
+    // reset state + estimates
+    std::vector<BaState> st(B.G);
+    for (auto &x : st) {
+        memset(&x, 0, sizeof(x));
+        x.need_build = 1; x.need_lambda_init = 1; x.active = 1; x.ok = 1; x.chi_first = -1.0;
+    }
+    if (params->iters1 <= 0) for (auto &x : st) { x.pass = 1; }
+    int n_active = B.G;
+    if (params->iters1 <= 0 && params->iters2 <= 0) { for (auto &x : st) x.active = 0; n_active = 0; }
+#define TRY(e) do { if ((e) != hipSuccess) { g_ba_error = #e; return ORBHIP_E_HIP; } } while (0)
+    TRY(hipMemcpyAsync(B.st, st.data(), sizeof(BaState) * B.G, hipMemcpyHostToDevice, s));
+    TRY(hipMemcpyAsync(B.poses, b->poses0.data(), sizeof(double) * b->poses0.size(), hipMemcpyHostToDevice, s));
+    TRY(hipMemcpyAsync(B.points, b->points0.data(), sizeof(double) * b->points0.size(), hipMemcpyHostToDevice, s));
+    TRY(hipMemcpyAsync(B.n_active, &n_active, sizeof(int), hipMemcpyHostToDevice, s));
+    TRY(hipMemsetAsync(B.xp, 0, sizeof(double) * (size_t)B.sumF * 6, s));
+    TRY(hipMemsetAsync(B.xl, 0, sizeof(double) * (size_t)B.sumL * 3, s));
+    TRY(hipStreamSynchronize(s));     // st / n_active host buffers must outlive the copies
+    const int G = B.G;
+    const dim3 ge((B.max_edges + 255) / 256, G), gp128((B.max_points + 127) / 128, G), gp256((B.max_points + 255) / 256, G);
+    const dim3 gf(std::max(B.max_nf, 1), G);
+    int max_items = 0, max_poses = 0;
+    for (auto &D : b->gd) { const int nt = D.ld / 48; max_items = std::max(max_items, nt * (nt + 1) / 2 * D.ks); max_poses = std::max(max_poses, D.n_poses); }
+    const int max_ticks = (params->iters1 + params->iters2) * params->max_trials + 4;
+    int tick = 0;
+    for (; tick < max_ticks && n_active > 0; tick++) {
+        const int ab = (abort_flag && *abort_flag) ? 1 : 0;
+        hipLaunchKernelGGL(k_ba_errors, ge, dim3(256), 0, s, B, 0);
+        hipLaunchKernelGGL(k_ba_reduce, dim3(G), dim3(256), 0, s, B, 0);
+        hipLaunchKernelGGL(k_ba_build_points, gp128, dim3(128), 0, s, B);
+        hipLaunchKernelGGL(k_ba_build_poses, gf, dim3(64), 0, s, B);
+        hipLaunchKernelGGL(k_ba_maxdiag, dim3(G), dim3(256), 0, s, B);
+        hipLaunchKernelGGL(k_ba_pretrial, dim3((G + 63) / 64), dim3(64), 0, s, B);
+        hipLaunchKernelGGL(k_ba_point_prep, gp256, dim3(256), 0, s, B);
+        hipLaunchKernelGGL(k_ba_schur_gemm, dim3((max_items + 3) / 4, G), dim3(256), 0, s, B);
+        hipLaunchKernelGGL(k_ba_schur_finish, dim3((B.max_ld * B.max_ld + 255) / 256, G), dim3(256), 0, s, B);
+        hipLaunchKernelGGL(k_ba_bschur, gf, dim3(64), 0, s, B);
+        hipLaunchKernelGGL(k_ba_ldlt, dim3(G), dim3(1024), 0, s, B);
+        hipLaunchKernelGGL(k_ba_backsub_points, gp128, dim3(128), 0, s, B);
+        hipLaunchKernelGGL(k_ba_update_poses, dim3((max_poses + 63) / 64, G), dim3(64), 0, s, B);
+        hipLaunchKernelGGL(k_ba_errors, ge, dim3(256), 0, s, B, 1);
+        hipLaunchKernelGGL(k_ba_reduce, dim3(G), dim3(256), 0, s, B, 1);
+        hipLaunchKernelGGL(k_ba_control, dim3((G + 63) / 64), dim3(64), 0, s, B, ab);
+        TRY(hipMemcpyAsync(b->h_n_active, B.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
+        TRY(hipStreamSynchronize(s));
+        n_active = *b->h_n_active;
+    }
+    b->ticks_last = tick;
+    hipLaunchKernelGGL(k_ba_finalize, ge, dim3(256), 0, s, B);
+    TRY(hipStreamSynchronize(s));
+    TRY(hipGetLastError());
+#undef TRY
+    return ORBHIP_OK;
+}
+
+// D2H of the results of the last solve.  poses_out[g]/points_out[g] are written unless the graph
+// was discarded (>= 50 % outliers, Optimizer.cc:2177-2181); outlier/stats may be NULL.
+extern "C" int orbhip_ba_batch_download(orbhip_ba_batch *b, double *const *poses_out, double *const *points_out,
+                                        uint8_t *const *edge_outlier_out, orbhip_ba_stats *stats_out)
+{
+    if (!b) return ORBHIP_E_BADARG;
+    if (hipSetDevice(orbhip_ctx_device_internal(b->ctx)) != hipSuccess) return ORBHIP_E_HIP;
+    BaBatch &B = b->B;
+    std::vector<BaState> st(B.G);
+    std::vector<double> poses((size_t)2 * B.sumP * 7), points((size_t)2 * B.sumL * 3);
+    std::vector<uint8_t> outl(B.sumE ? B.sumE : 1);
+    if (hipMemcpy(st.data(), B.st, sizeof(BaState) * B.G, hipMemcpyDeviceToHost) != hipSuccess) return ORBHIP_E_HIP;
+    if (hipMemcpy(poses.data(), B.poses, poses.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return ORBHIP_E_HIP;
+    if (hipMemcpy(points.data(), B.points, points.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return ORBHIP_E_HIP;
+    if (B.sumE && hipMemcpy(outl.data(), B.outlier, B.sumE, hipMemcpyDeviceToHost) != hipSuccess) return ORBHIP_E_HIP;
+    for (int g = 0; g < B.G; g++) {
+        const BaGraphDev &D = b->gd[g];
+        const int discarded = (D.n_edges > 0 && st[g].n_outliers >= D.n_edges * 0.5) ? 1 : 0;
+        if (!discarded) {
+            if (poses_out && poses_out[g]) memcpy(poses_out[g], poses.data() + ((size_t)st[g].cur * B.sumP + D.pose_off) * 7, sizeof(double) * 7 * D.n_poses);
+            if (points_out && points_out[g]) memcpy(points_out[g], points.data() + ((size_t)st[g].cur * B.sumL + D.point_off) * 3, sizeof(double) * 3 * D.n_points);
+        }
+        if (edge_outlier_out && edge_outlier_out[g]) memcpy(edge_outlier_out[g], outl.data() + D.edge_off, D.n_edges);
+        if (stats_out) {
+            orbhip_ba_stats &o = stats_out[g];
+            o.iterations_run[0] = st[g].iters_run[0]; o.iterations_run[1] = st[g].iters_run[1];
+            o.lm_trials = st[g].lm_trials; o.n_outliers = st[g].n_outliers; o.discarded = discarded;
+            o.chi2_initial = st[g].chi_first; o.chi2_final = st[g].chi_last;
+        }
+    }
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_ba_batch_ticks(const orbhip_ba_batch *b) { return b ? b->ticks_last : ORBHIP_E_BADARG; }
+
+extern "C" int orbhip_ba_solve_batch(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_graphs,
+                                     const orbhip_ba_params *params, volatile const uint8_t *abort_flag,
+                                     double *const *poses_inout, double *const *points_inout,
+                                     uint8_t *const *edge_outlier_out, orbhip_ba_stats *stats_out)
+{
+    if (abort_flag && *abort_flag) return ORBHIP_E_ABORTED;
+    orbhip_ba_batch *b = nullptr;
+    int rc = orbhip_ba_batch_create(ctx, graphs, n_graphs, poses_inout, points_inout, &b);
+    if (rc) return rc;
+    rc = orbhip_ba_batch_solve(b, params, abort_flag);
+    if (rc == ORBHIP_OK) rc = orbhip_ba_batch_download(b, poses_inout, points_inout, edge_outlier_out, stats_out);
+    orbhip_ba_batch_destroy(b);
+    return rc;
+}

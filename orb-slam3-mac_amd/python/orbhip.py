@@ -234,3 +234,96 @@ def synth_frames(w, h, n, seed=20241004, first=0):
     out = np.zeros((n, h, w), np.uint8)
     synth_lib().synth_batch(out.ctypes.data, w, h, n, seed, first)
     return out
+
+
+# ---------------------------------------------------------------- local BA (Optimizer::LocalBundleAdjustment core)
+class BaGraph(C.Structure):
+    _fields_ = [("n_poses", C.c_int32), ("n_points", C.c_int32), ("n_edges", C.c_int32),
+                ("pose_fixed", vp), ("edge_pose", vp), ("edge_point", vp), ("edge_obs", vp),
+                ("edge_inv_sigma2", vp), ("edge_stereo", vp),
+                ("fx", cd), ("fy", cd), ("cx", cd), ("cy", cd), ("bf", cd)]
+
+
+class BaParams(C.Structure):
+    _fields_ = [("iters1", C.c_int32), ("iters2", C.c_int32), ("huber_mono2", cd), ("huber_stereo2", cd),
+                ("user_lambda_init", cd), ("tau", cd), ("max_trials", C.c_int32)]
+
+
+class BaStats(C.Structure):
+    _fields_ = [("iterations_run", C.c_int32 * 2), ("lm_trials", C.c_int32), ("n_outliers", C.c_int32),
+                ("discarded", C.c_int32), ("chi2_initial", cd), ("chi2_final", cd)]
+
+    def as_dict(self):
+        return dict(iterations_run=list(self.iterations_run), lm_trials=self.lm_trials, n_outliers=self.n_outliers,
+                    discarded=self.discarded, chi2_initial=self.chi2_initial, chi2_final=self.chi2_final)
+
+
+lib.orbhip_ba_default_params.argtypes = [C.POINTER(BaParams)]
+lib.orbhip_ba_batch_create.argtypes = [vp, vp, ci, vp, vp, C.POINTER(vp)]
+lib.orbhip_ba_batch_solve.argtypes = [vp, C.POINTER(BaParams), vp]
+lib.orbhip_ba_batch_download.argtypes = [vp, vp, vp, vp, vp]
+lib.orbhip_ba_batch_ticks.argtypes = [vp]
+lib.orbhip_ba_batch_destroy.argtypes = [vp]
+lib.orbhip_ba_solve_batch.argtypes = [vp, vp, ci, C.POINTER(BaParams), vp, vp, vp, vp, vp]
+
+
+def ba_default_params():
+    p = BaParams()
+    lib.orbhip_ba_default_params(C.byref(p))
+    return p
+
+
+class BaBatch:
+    """Device-resident batch of keyframe-window graphs (dicts as produced by synth_ba.make_graph:
+    n_poses, n_points, n_edges, pose_fixed, edge_pose, edge_point, edge_obs, edge_inv_sigma2,
+    edge_stereo, fx, fy, cx, cy, bf, poses0, points0)."""
+
+    def __init__(self, ctx, graphs):
+        self.ctx, self.n = ctx, len(graphs)
+        self._keep = []
+        arr = (BaGraph * self.n)()
+        self.sizes = []
+        for i, g in enumerate(graphs):
+            k = [np.ascontiguousarray(g["pose_fixed"], np.uint8), np.ascontiguousarray(g["edge_pose"], np.int32),
+                 np.ascontiguousarray(g["edge_point"], np.int32), np.ascontiguousarray(g["edge_obs"], np.float64),
+                 np.ascontiguousarray(g["edge_inv_sigma2"], np.float64), np.ascontiguousarray(g["edge_stereo"], np.uint8)]
+            self._keep.append(k)
+            arr[i] = BaGraph(g["n_poses"], g["n_points"], g["n_edges"], *[a.ctypes.data for a in k],
+                             g["fx"], g["fy"], g["cx"], g["cy"], g["bf"])
+            self.sizes.append((g["n_poses"], g["n_points"], g["n_edges"]))
+        self.poses = [np.ascontiguousarray(g["poses0"], np.float64).copy() for g in graphs]
+        self.points = [np.ascontiguousarray(g["points0"], np.float64).copy() for g in graphs]
+        pp = (vp * self.n)(*[a.ctypes.data for a in self.poses])
+        pq = (vp * self.n)(*[a.ctypes.data for a in self.points])
+        h = vp()
+        _chk(lib.orbhip_ba_batch_create(ctx.h, C.cast(arr, vp), self.n, C.cast(pp, vp), C.cast(pq, vp), C.byref(h)),
+             "orbhip_ba_batch_create")
+        self.h = h
+
+    def solve(self, params=None, abort=None):
+        p = params or ba_default_params()
+        rc = lib.orbhip_ba_batch_solve(self.h, C.byref(p), abort.ctypes.data if abort is not None else None)
+        if rc not in (OK, E_ABORTED):
+            raise OrbHipError(rc, "orbhip_ba_batch_solve")
+        return rc
+
+    @property
+    def ticks(self):
+        return lib.orbhip_ba_batch_ticks(self.h)
+
+    def download(self):
+        poses = [a.copy() for a in self.poses]
+        points = [a.copy() for a in self.points]
+        outl = [np.zeros(max(s[2], 1), np.uint8) for s in self.sizes]
+        stats = (BaStats * self.n)()
+        pp = (vp * self.n)(*[a.ctypes.data for a in poses])
+        pq = (vp * self.n)(*[a.ctypes.data for a in points])
+        po = (vp * self.n)(*[a.ctypes.data for a in outl])
+        _chk(lib.orbhip_ba_batch_download(self.h, C.cast(pp, vp), C.cast(pq, vp), C.cast(po, vp), C.cast(stats, vp)),
+             "orbhip_ba_batch_download")
+        return poses, points, [o[:s[2]] for o, s in zip(outl, self.sizes)], [st.as_dict() for st in stats]
+
+    def close(self):
+        if self.h:
+            lib.orbhip_ba_batch_destroy(self.h)
+            self.h = None

@@ -1,0 +1,114 @@
+"""Seeded synthetic local-BA graphs (BASELINE config #4).  Host-side input
+generator only (numpy); not part of the oracle and not part of the measured path.
+
+P keyframes on a noisy circle (radius 5 m) looking at the centroid, Pinhole fx=fy=458,
+cx=320, cy=240; KFs 0,1 fixed; L points uniform in a 4 m cube; each point observed by `obs`
+keyframes that see it in-image with positive depth; octave ~ U{0..7} -> invSigma2 =
+(float)1.2^-2oct; pixel noise N(0, 1.2^oct); 5 % gross outliers (+-30 px); initial poses
+perturbed by exp(N(0,[0.01 rad, 0.05 m])), points by N(0, 0.05 m); everything rounded through
+float32 at the boundary.
+"""
+import numpy as np
+
+
+def _quat_from_R(R):
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0)
+        w = 0.5 * s
+        s = 0.5 / s
+        q = [(R[2, 1] - R[1, 2]) * s, (R[0, 2] - R[2, 0]) * s, (R[1, 0] - R[0, 1]) * s, w]
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0)
+        q = [0, 0, 0, 0]
+        q[i] = 0.5 * s
+        s = 0.5 / s
+        q[3] = (R[k, j] - R[j, k]) * s
+        q[j] = (R[j, i] + R[i, j]) * s
+        q[k] = (R[k, i] + R[i, k]) * s
+    q = np.array(q)
+    if q[3] < 0:
+        q = -q
+    return q / np.linalg.norm(q)
+
+
+def _R_from_quat(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def _exp_so3(w):
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    if th < 1e-12:
+        return np.eye(3) + K
+    return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * (K @ K)
+
+
+def make_graph(n_kf=50, n_pts=2000, obs=10, seed=0, n_fixed=2, outlier_frac=0.05, stereo_frac=0.0,
+               pose_noise=(0.01, 0.05), point_noise=0.05, pixel_noise=1.0):
+    rng = np.random.default_rng(seed)
+    fx = fy = 458.0
+    cx, cy, W, H = 320.0, 240.0, 640, 480
+    bf = 458.0 * 0.11
+    # ground-truth poses (world -> camera)
+    Rs, ts = [], []
+    for i in range(n_kf):
+        ang = 2 * np.pi * i / n_kf + rng.normal(0, 0.02)
+        C = np.array([5 * np.cos(ang), rng.normal(0, 0.2), 5 * np.sin(ang)]) + rng.normal(0, 0.05, 3)
+        z = -C / np.linalg.norm(C)
+        up = np.array([0.0, -1.0, 0.0])
+        x = np.cross(up, z); x /= np.linalg.norm(x)
+        y = np.cross(z, x)
+        R = np.stack([x, y, z])                   # rows = camera axes in world
+        Rs.append(R); ts.append(-R @ C)
+    Rs, ts = np.array(Rs), np.array(ts)
+    X = rng.uniform(-2, 2, (n_pts, 3))
+    e_pose, e_point, e_obs, e_is2, e_st = [], [], [], [], []
+    sig2 = np.cumprod(np.concatenate([[np.float32(1.0)], np.full(7, np.float32(1.2))]).astype(np.float32)) ** 2
+    inv_sig2 = (np.float32(1.0) / sig2.astype(np.float32)).astype(np.float32)
+    for l in range(n_pts):
+        Pc = Rs @ X[l] + ts
+        u = fx * Pc[:, 0] / Pc[:, 2] + cx
+        v = fy * Pc[:, 1] / Pc[:, 2] + cy
+        vis = np.nonzero((Pc[:, 2] > 0.1) & (u > 0) & (u < W) & (v > 0) & (v < H))[0]
+        if len(vis) == 0:
+            vis = np.arange(n_kf)
+        sel = np.sort(rng.choice(vis, size=min(obs, len(vis)), replace=False))
+        for k in sel:
+            octv = int(rng.integers(0, 8))
+            sd = pixel_noise * 1.2 ** octv
+            uu = u[k] + rng.normal(0, sd)
+            vv = v[k] + rng.normal(0, sd)
+            if rng.random() < outlier_frac:
+                uu += rng.choice([-30.0, 30.0]); vv += rng.choice([-30.0, 30.0])
+            st = rng.random() < stereo_frac
+            ur = uu - bf / Pc[k, 2] + (rng.normal(0, sd) if st else 0.0)
+            e_pose.append(k); e_point.append(l); e_st.append(1 if st else 0)
+            e_obs.append([np.float32(uu), np.float32(vv), np.float32(ur) if st else 0.0])
+            e_is2.append(float(inv_sig2[octv]))
+    # perturbed initial estimates, float32-rounded
+    poses0 = np.zeros((n_kf, 7))
+    poses_gt = np.zeros((n_kf, 7))
+    for i in range(n_kf):
+        poses_gt[i, :4] = _quat_from_R(Rs[i]); poses_gt[i, 4:] = ts[i]
+        if i < n_fixed:
+            R0, t0 = Rs[i], ts[i]
+        else:
+            dR = _exp_so3(rng.normal(0, pose_noise[0], 3))
+            R0 = dR @ Rs[i]
+            t0 = dR @ ts[i] + rng.normal(0, pose_noise[1], 3)
+        R0 = R0.astype(np.float32).astype(np.float64)
+        t0 = t0.astype(np.float32).astype(np.float64)
+        poses0[i, :4] = _quat_from_R(R0); poses0[i, 4:] = t0
+    pts0 = (X + rng.normal(0, point_noise, X.shape)).astype(np.float32).astype(np.float64)
+    fixed = np.zeros(n_kf, np.uint8); fixed[:n_fixed] = 1
+    return dict(n_poses=n_kf, n_points=n_pts, n_edges=len(e_pose), pose_fixed=fixed,
+                edge_pose=np.array(e_pose, np.int32), edge_point=np.array(e_point, np.int32),
+                edge_obs=np.array(e_obs, np.float64).reshape(-1, 3), edge_inv_sigma2=np.array(e_is2, np.float64),
+                edge_stereo=np.array(e_st, np.uint8), fx=fx, fy=fy, cx=cx, cy=cy, bf=bf,
+                poses0=poses0, points0=pts0, poses_gt=poses_gt, points_gt=X.copy())

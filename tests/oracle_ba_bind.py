@@ -1,0 +1,62 @@
+"""ctypes binding of the BA ORACLE (oracle/ba_oracle.c).  TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+import numpy as np
+from oracle_bind import lib
+
+vp, ci, cd = C.c_void_p, C.c_int, C.c_double
+
+
+class Graph(C.Structure):
+    _fields_ = [("n_poses", C.c_int32), ("n_points", C.c_int32), ("n_edges", C.c_int32),
+                ("pose_fixed", vp), ("edge_pose", vp), ("edge_point", vp), ("edge_obs", vp),
+                ("edge_inv_sigma2", vp), ("edge_stereo", vp),
+                ("fx", cd), ("fy", cd), ("cx", cd), ("cy", cd), ("bf", cd)]
+
+
+class Params(C.Structure):
+    _fields_ = [("iters1", C.c_int32), ("iters2", C.c_int32), ("huber_mono2", cd), ("huber_stereo2", cd),
+                ("user_lambda_init", cd), ("tau", cd), ("max_trials", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("iterations_run", C.c_int32 * 2), ("lm_trials", C.c_int32), ("n_outliers", C.c_int32),
+                ("discarded", C.c_int32), ("chi2_initial", cd), ("chi2_final", cd)]
+
+    def as_dict(self):
+        return dict(iterations_run=list(self.iterations_run), lm_trials=self.lm_trials, n_outliers=self.n_outliers,
+                    discarded=self.discarded, chi2_initial=self.chi2_initial, chi2_final=self.chi2_final)
+
+
+lib.orc_ba_default_params.argtypes = [C.POINTER(Params)]
+lib.orc_ba_solve.argtypes = [C.POINTER(Graph), C.POINTER(Params), vp, vp, vp, vp, C.POINTER(Stats)]
+lib.orc_se3_exp.argtypes = [vp, vp, vp]
+lib.orc_se3_oplus.argtypes = [vp, vp]
+lib.orc_ba_edge.argtypes = [vp, vp, vp, ci, cd, cd, cd, cd, cd, vp, vp, vp]
+
+
+def default_params():
+    p = Params()
+    lib.orc_ba_default_params(C.byref(p))
+    return p
+
+
+def make_cgraph(g, cls=Graph):
+    """g: dict from synth_ba.make_graph.  Returns (struct, keepalive list)."""
+    keep = [np.ascontiguousarray(g["pose_fixed"], np.uint8), np.ascontiguousarray(g["edge_pose"], np.int32),
+            np.ascontiguousarray(g["edge_point"], np.int32), np.ascontiguousarray(g["edge_obs"], np.float64),
+            np.ascontiguousarray(g["edge_inv_sigma2"], np.float64), np.ascontiguousarray(g["edge_stereo"], np.uint8)]
+    s = cls(g["n_poses"], g["n_points"], g["n_edges"], *[k.ctypes.data for k in keep],
+            g["fx"], g["fy"], g["cx"], g["cy"], g["bf"])
+    return s, keep
+
+
+def solve(g, params=None, abort=None):
+    p = params or default_params()
+    cg, keep = make_cgraph(g)
+    poses = np.ascontiguousarray(g["poses0"], np.float64).copy()
+    pts = np.ascontiguousarray(g["points0"], np.float64).copy()
+    out = np.zeros(max(g["n_edges"], 1), np.uint8)
+    st = Stats()
+    ab = abort.ctypes.data if abort is not None else None
+    rc = lib.orc_ba_solve(C.byref(cg), C.byref(p), ab, poses.ctypes.data, pts.ctypes.data, out.ctypes.data, C.byref(st))
+    return rc, poses, pts, out[:g["n_edges"]], st.as_dict()

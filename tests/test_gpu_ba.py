@@ -1,0 +1,129 @@
+"""HIP-vs-oracle parity of the local-BA solver (rows B1-B8) through the C ABI.
+Tolerance (BASELINE.json north_star): RMSE <= 1e-4 on poses and points vs the CPU path."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _rmse(a, b):
+    return float(np.sqrt(np.mean((np.asarray(a) - np.asarray(b)) ** 2)))
+
+
+def _check(gpu_ctx, graphs, params=None, tol=TOL):
+    import orbhip
+    import oracle_ba_bind as ob
+    bb = orbhip.BaBatch(gpu_ctx, graphs)
+    bb.solve(params)
+    poses, points, outl, stats = bb.download()
+    bb.close()
+    op = None
+    if params is not None:
+        op = ob.default_params()
+        for f, _ in ob.Params._fields_:
+            setattr(op, f, getattr(params, f))
+    for i, g in enumerate(graphs):
+        rc, o_poses, o_pts, o_out, o_st = ob.solve(g, op)
+        assert stats[i]["discarded"] == o_st["discarded"]
+        if o_st["discarded"]:
+            np.testing.assert_array_equal(poses[i], g["poses0"])
+            continue
+        assert _rmse(poses[i][:, 4:], o_poses[:, 4:]) <= tol, ("pose t", i, stats[i], o_st)
+        assert _rmse(poses[i][:, :4], o_poses[:, :4]) <= tol, ("pose q", i)
+        assert _rmse(points[i], o_pts) <= tol, ("points", i)
+        assert stats[i]["iterations_run"] == o_st["iterations_run"], (stats[i], o_st)
+        assert stats[i]["lm_trials"] == o_st["lm_trials"], (stats[i], o_st)
+        assert abs(stats[i]["chi2_initial"] - o_st["chi2_initial"]) <= 1e-6 * abs(o_st["chi2_initial"])
+        assert abs(stats[i]["chi2_final"] - o_st["chi2_final"]) <= 1e-6 * abs(o_st["chi2_final"])
+        # outlier flags may differ only for edges whose chi2 sits numerically on the gate
+        assert int(np.sum(outl[i] != o_out)) <= max(2, len(o_out) // 2000), "outlier flags"
+    return stats
+
+
+def test_ba_small_mono(gpu_ctx):
+    import synth_ba
+    graphs = [synth_ba.make_graph(n_kf=6, n_pts=40, obs=4, seed=s) for s in range(4)]
+    _check(gpu_ctx, graphs)
+
+
+def test_ba_full_size_mono(gpu_ctx):
+    """BASELINE config #4: 50 KF x 2000 points x 10 obs, 2 fixed KFs, 5 % outliers."""
+    import synth_ba
+    graphs = [synth_ba.make_graph(seed=s) for s in (1, 2)]
+    st = _check(gpu_ctx, graphs)
+    assert all(s["iterations_run"][0] == 5 for s in st)
+
+
+def test_ba_stereo_and_mixed(gpu_ctx):
+    import synth_ba
+    graphs = [synth_ba.make_graph(n_kf=12, n_pts=300, obs=6, seed=7, stereo_frac=1.0),
+              synth_ba.make_graph(n_kf=12, n_pts=300, obs=6, seed=8, stereo_frac=0.4)]
+    _check(gpu_ctx, graphs)
+
+
+def test_ba_ragged_batch(gpu_ctx):
+    """Graphs of different sizes in one batch, incl. a point seen only by fixed KFs."""
+    import synth_ba
+    graphs = [synth_ba.make_graph(n_kf=5, n_pts=30, obs=3, seed=11),
+              synth_ba.make_graph(n_kf=20, n_pts=500, obs=8, seed=12),
+              synth_ba.make_graph(n_kf=9, n_pts=77, obs=5, seed=13, n_fixed=3)]
+    g = graphs[2]
+    keep = ~((g["edge_point"] == 5) & (g["pose_fixed"][g["edge_pose"]] == 0))     # point 5: fixed-KF edges only
+    for k in ("edge_pose", "edge_point", "edge_obs", "edge_inv_sigma2", "edge_stereo"):
+        g[k] = g[k][keep]
+    g["n_edges"] = int(keep.sum())
+    _check(gpu_ctx, graphs)
+
+
+def test_ba_discards_when_mostly_outliers(gpu_ctx):
+    import synth_ba
+    g = synth_ba.make_graph(n_kf=8, n_pts=120, obs=5, seed=21, outlier_frac=0.9)
+    st = _check(gpu_ctx, [g])
+    assert st[0]["discarded"] == 1
+
+
+def test_ba_inertial_lambda_and_short_schedule(gpu_ctx):
+    """user lambda init = 100 (pMap->IsInertial(), Optimizer.cc:1837-1838) and a 2+3 schedule."""
+    import orbhip
+    import synth_ba
+    p = orbhip.ba_default_params()
+    p.user_lambda_init = 100.0
+    p.iters1, p.iters2 = 2, 3
+    _check(gpu_ctx, [synth_ba.make_graph(n_kf=10, n_pts=200, obs=6, seed=31)], p)
+
+
+def test_ba_abort_flag(gpu_ctx):
+    import orbhip
+    import synth_ba
+    g = synth_ba.make_graph(n_kf=6, n_pts=40, obs=4, seed=3)
+    bb = orbhip.BaBatch(gpu_ctx, [g])
+    flag = np.ones(1, np.uint8)
+    assert bb.solve(abort=flag) == orbhip.E_ABORTED       # Optimizer.cc:2041-2043: return before optimizing
+    bb.close()
+
+
+def test_ba_convenience_entry_point(gpu_ctx):
+    """orbhip_ba_solve_batch == create + solve + download."""
+    import ctypes as C
+    import orbhip
+    import synth_ba
+    g = synth_ba.make_graph(n_kf=6, n_pts=40, obs=4, seed=5)
+    bb = orbhip.BaBatch(gpu_ctx, [g])
+    bb.solve()
+    poses, points, outl, stats = bb.download()
+    bb.close()
+    bb2 = orbhip.BaBatch(gpu_ctx, [g])          # only to reuse the struct packing
+    arr = (orbhip.BaGraph * 1)()
+    k = bb2._keep[0]
+    arr[0] = orbhip.BaGraph(g["n_poses"], g["n_points"], g["n_edges"], *[a.ctypes.data for a in k],
+                            g["fx"], g["fy"], g["cx"], g["cy"], g["bf"])
+    P = g["poses0"].copy(); X = g["points0"].copy()
+    pp = (C.c_void_p * 1)(P.ctypes.data); px = (C.c_void_p * 1)(X.ctypes.data)
+    prm = orbhip.ba_default_params()
+    rc = orbhip.lib.orbhip_ba_solve_batch(gpu_ctx.h, C.cast(arr, C.c_void_p), 1, C.byref(prm), None,
+                                          C.cast(pp, C.c_void_p), C.cast(px, C.c_void_p), None, None)
+    assert rc == 0
+    np.testing.assert_array_equal(P, poses[0])
+    np.testing.assert_array_equal(X, points[0])
+    bb2.close()
