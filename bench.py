@@ -53,9 +53,13 @@ def cpu_baseline(w, h, nfeat, seconds_budget=20.0):
     imgs = orbhip.synth_frames(w, h, 5, seed=4242)
     e = ob.OracleExtractor(nfeat, 1.2, 8, 20, 7)
     t0 = time.time()
-    res = [e.extract(imgs[i]) for i in range(5)]
+    res = [e.extract(imgs[i], (0, 0)) for i in range(5)]
+    def match(a, b):
+        om.bf2nn(a[1], b[1], 0.7)
+        om.search_for_initialization(a[0], a[1], b[0], b[1], (0.0, 0.0, float(w), float(h)),
+                                     np.stack([a[0]["x"], a[0]["y"]], 1), 100, 0.9, True)
     for i in range(4):
-        om.bf2nn(res[i][1], res[i + 1][1], 0.7)
+        match(res[i], res[i + 1])
     t1 = (time.time() - t0) / 4.0
     per_thread = max(4, int(seconds_budget / max(t1, 1e-3) / 1.0 / 1) // cores)
     per_thread = min(per_thread, 48)
@@ -63,10 +67,10 @@ def cpu_baseline(w, h, nfeat, seconds_budget=20.0):
     def work(tid):
         ee = ob.OracleExtractor(nfeat, 1.2, 8, 20, 7)
         fr = orbhip.synth_frames(w, h, per_thread + 1, seed=777, first=tid * 64)
-        prev = ee.extract(fr[0])
+        prev = ee.extract(fr[0], (0, 0))
         for i in range(1, per_thread + 1):
-            cur = ee.extract(fr[i])
-            om.bf2nn(prev[1], cur[1], 0.7)
+            cur = ee.extract(fr[i], (0, 0))
+            match(prev, cur)
             prev = cur
         return per_thread
 
@@ -75,8 +79,31 @@ def cpu_baseline(w, h, nfeat, seconds_budget=20.0):
         done = sum(ex.map(work, range(cores)))
     dt = time.time() - t0
     return {"value": round(done / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d threads x %d frames %dx%d, %d feats, extract + BF 2-NN match vs successor; "
+            "sample": "%d threads x %d frames %dx%d, %d feats, extract + BF 2-NN + SearchForInitialization vs successor; "
                       "single-thread %.2f frames/s" % (cores, per_thread, w, h, nfeat, 1.0 / t1)}
+
+
+def ba_cpu_baseline(graphs, seconds_budget=12.0):
+    """BA oracle (CPU restatement of g2o LM+Schur) on this host's cores: kind 'port'."""
+    from concurrent.futures import ThreadPoolExecutor
+    import oracle_ba_bind as obb
+    cores = min(os.cpu_count() or 1, 16)
+    t0 = time.time()
+    obb.solve(graphs[0])
+    t1 = time.time() - t0
+    per_thread = max(1, min(8, int(seconds_budget / max(t1, 1e-3))))
+
+    def work(tid):
+        for i in range(per_thread):
+            obb.solve(graphs[(tid + i) % len(graphs)])
+        return per_thread
+    t0 = time.time()
+    with ThreadPoolExecutor(cores) as ex:
+        done = sum(ex.map(work, range(cores)))
+    dt = time.time() - t0
+    return {"value": round(done / dt, 2), "unit": "solves/s", "cores": cores, "kind": "port",
+            "sample": "%d threads x %d solves of the 50KFx2000ptx10obs graph; single-thread %.2f solves/s"
+                      % (cores, per_thread, 1.0 / t1)}
 
 
 def main():
@@ -88,6 +115,8 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--nfeatures", type=int, default=1000)
+    ap.add_argument("--ba-graphs", type=int, default=64, help="local-BA graphs solved concurrently per GPU (0 = skip BA leg)")
+    ap.add_argument("--ba-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -115,13 +144,17 @@ def main():
     max_kp = ext.max_keypoints
     d_idx2 = torch.empty((B, max_kp, 2), dtype=torch.int32, device="cuda")
     d_dist2 = torch.empty((B, max_kp, 2), dtype=torch.int32, device="cuda")
-    d_acc = torch.empty((B, max_kp), dtype=torch.uint8, device="cuda")
+    d_acc = torch.zeros((B, max_kp), dtype=torch.uint8, device="cuda")
+    d_prev = torch.zeros((B, max_kp, 2), dtype=torch.float32, device="cuda")
+    d_m12 = torch.empty((B, max_kp), dtype=torch.int32, device="cuda")
+    d_nm = torch.empty((B,), dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
     kp_p, desc_p, cnt_p, mono_p = ext.results_device()
     dstride = max_kp * 32
 
     def step():
-        ext.extract_device(d_imgs.data_ptr(), W, H, W, W * H, B, (0, 1000))
+        # lap (0,0): keypoints come out in level order (the stereo constructors' lapping, Frame.cc:109-110)
+        ext.extract_device(d_imgs.data_ptr(), W, H, W, W * H, B, (0, 0))
         # frame i vs frame i+1 (B-1 pairs) + wrap-around pair (B-1 vs 0): every frame matched once
         if B > 1:
             orbhip.match_bf2nn_device(ctx, desc_p, cnt_p, dstride, desc_p + dstride, cnt_p + 4, dstride, B - 1, max_kp,
@@ -129,6 +162,16 @@ def main():
         orbhip.match_bf2nn_device(ctx, desc_p + (B - 1) * dstride, cnt_p + 4 * (B - 1), dstride, desc_p, cnt_p, dstride, 1,
                                   max_kp, 0.7, d_idx2.data_ptr() + (B - 1) * max_kp * 8,
                                   d_dist2.data_ptr() + (B - 1) * max_kp * 8, d_acc.data_ptr() + (B - 1) * max_kp)
+        if B > 1:
+            windowed()
+
+    def windowed():
+        # ORBmatcher::SearchForInitialization(frame i, frame i+1) (Tracking.cc:1506-1507: ORBmatcher(0.9,true),
+        # windowSize 100) with vbPrevMatched = frame i's keypoint positions (Tracking.cc:1497-1499); B-1 pairs.
+        orbhip.prev_matched_init_device(ctx, kp_p, max_kp, B - 1, max_kp, d_prev.data_ptr())
+        orbhip.search_for_initialization_device(ctx, kp_p, desc_p, cnt_p, kp_p + max_kp * 28, desc_p + dstride, cnt_p + 4,
+                                                B - 1, max_kp, max_kp, (0.0, 0.0, float(W), float(H)), 100, 0.9, True,
+                                                d_prev.data_ptr(), d_m12.data_ptr(), d_nm.data_ptr())
 
     def sync():
         ctx.synchronize()
@@ -150,14 +193,59 @@ def main():
     dt = time.perf_counter() - t0
     stage = ext.stage_ms()
     ext.set_profiling(False)
-    # loud failure if any device-side list overflowed
-    res = ext.extract_host(imgs[:2])   # also re-validates the host path; raises on capacity errors
-    n_kp_avg = float(np.mean([len(r[0]) for r in res]))
+
+    ctx.check_status()                                   # loud failure on any device-side capacity overflow
+    res_chk = ext.extract_host(imgs[:min(B, 4)], (0, 0))  # host entry point re-check (raises on capacity errors)
+    n_kp_avg = float(np.mean([len(r[0]) for r in res_chk]))
+    win_matches = float(d_nm[:max(B - 1, 1)].float().mean().item()) if B > 1 else 0.0
+    bf_accept = float(d_acc.float().sum().item()) / B
 
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    # ---- local-BA leg: G graphs per GPU solved concurrently (replicas) ----------
+    ba = None
+    graphs = None
+    if args.ba_graphs > 0:
+        import synth_ba
+        distinct = min(args.ba_graphs, 8)
+        graphs = [synth_ba.make_graph(seed=1000 * rank + i) for i in range(distinct)]
+        glist = [graphs[i % distinct] for i in range(args.ba_graphs)]
+        bb = orbhip.BaBatch(ctx, glist)
+        bb.solve()                                   # warm-up
+        bb.set_profiling(True)
+        if world > 1:
+            dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.ba_steps):
+            bb.solve()
+        sync()
+        if world > 1:
+            dist.barrier()
+        dt_ba = time.perf_counter() - t0
+        gemm_ms, gemm_n, gemm_fl = bb.gemm_profile()
+        ticks = bb.ticks
+        _, _, _, stats = bb.download()
+        bb.close()
+        if world > 1:
+            t = torch.tensor([dt_ba], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_ba = float(t.item())
+        peak64 = orbhip.mfma_f64_peak_tflops(ctx)
+        tfl = gemm_fl * gemm_n / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        ba = {"metric": "local-BA solves/sec", "value": round(world * args.ba_graphs * args.ba_steps / dt_ba, 2),
+              "unit": "solves/s", "graphs_per_gpu": args.ba_graphs, "ms_per_batch": round(dt_ba / args.ba_steps * 1e3, 2),
+              "lm_ticks": ticks, "workload": "50 KF (2 fixed) x 2000 points x 10 obs, 5+10 LM iterations, Huber, Schur",
+              "lm_trials_graph0": stats[0]["lm_trials"], "dtype": "f64",
+              "roofline": {"bound": "mfma", "kernel": "k_ba_schur_gemm", "achieved": round(tfl, 2),
+                           "peak": round(peak64, 2), "unit": "TFLOP/s", "frac": round(tfl / peak64, 4) if peak64 else None,
+                           "traffic": None, "peak_source": "measured v_mfma_f64_16x16x4_f64 micro-benchmark on this device",
+                           "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),
+                           "flops_per_launch_dense_padded": gemm_fl}}
+
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         fps = world * B * args.steps / dt
@@ -172,8 +260,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
             "config": {"workload": "synthetic %dx%d batch=%d per GPU, 8-level pyramid, %d feats/frame, "
-                                   "ORB extract + Hamming 2-NN match vs successor frame" % (W, H, B, args.nfeatures),
+                                   "ORB extract + Hamming 2-NN match (Frame.cc:1146) + SearchForInitialization "
+                                   "(ORBmatcher.cc:710) vs successor frame" % (W, H, B, args.nfeatures),
                        "keypoints_per_frame": round(n_kp_avg, 1),
+                       "bf_ratio_matches_per_frame": round(bf_accept, 1),
+                       "windowed_matches_per_pair": round(win_matches, 1),
                        "stage_ms": {k: round(v, 4) for k, v in stage.items()},
                        "end_to_end_algorithmic_GBps": round(ab["total"] * B * args.steps / dt / 1e9, 2)},
             "roofline": {"bound": "hbm", "kernel": dom, "launches_per_step": launches,
@@ -181,8 +272,12 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "algorithmic_bytes_per_step": int(dom_bytes)},
         }
+        if ba is not None:
+            out["ba"] = ba
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, H, args.nfeatures)
+            if graphs is not None:
+                out["ba"]["cpu_baseline"] = ba_cpu_baseline(graphs)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

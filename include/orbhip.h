@@ -45,6 +45,9 @@ const char *orbhip_last_error(void);
 int orbhip_ctx_create(int device, void *stream, orbhip_ctx **out);
 void orbhip_ctx_destroy(orbhip_ctx *ctx);
 int orbhip_ctx_synchronize(orbhip_ctx *ctx);
+/* Synchronises, then returns and clears the context's sticky device-side error word
+ * (ORBHIP_E_CAPACITY when a matcher kernel met more keypoints than it can hold). */
+int orbhip_ctx_check_status(orbhip_ctx *ctx);
 void *orbhip_ctx_stream(orbhip_ctx *ctx);
 
 /* ------------------------------------------------------------------ ORB extractor */
@@ -143,13 +146,19 @@ int orbhip_match_bf2nn_device(orbhip_ctx *ctx, const uint8_t *d_descA, const int
  * Pair p matches frame A_p against frame B_p.  kp arrays are the extractor's device
  * outputs (row capacity max_n).  d_prev_matched[pairs][max_n][2] (float x,y) is in/out
  * (vbPrevMatched); d_matches12[pairs][max_n] out; d_nmatches[pairs] out (return value).
- * Grid bounds = image bounds (mnMinX..mnMaxX of an undistorted-free camera). */
+ * Grid bounds = image bounds (mnMinX..mnMaxX of a distortion-free camera).  At most 2048
+ * keypoints per frame (else the context's status word is set: orbhip_ctx_check_status). */
 int orbhip_search_for_initialization_device(orbhip_ctx *ctx,
         const orbhip_keypoint *d_kpA, const uint8_t *d_descA, const int32_t *d_nA,
         const orbhip_keypoint *d_kpB, const uint8_t *d_descB, const int32_t *d_nB,
         int pairs, int max_n, size_t frame_stride_kp /*entries*/, float min_x, float min_y,
         float max_x, float max_y, int window_size, float nn_ratio, int check_orientation,
         float *d_prev_matched, int32_t *d_matches12, int32_t *d_nmatches);
+
+/* vbPrevMatched[i] = mvKeysUn[i].pt for `frames` frames (src/Tracking.cc:1497-1499), on the device:
+ * d_prev_matched[f][i] = (kp[f][i].x, kp[f][i].y), rows of max_n entries. */
+int orbhip_prev_matched_init_device(orbhip_ctx *ctx, const orbhip_keypoint *d_kp, size_t frame_stride_kp,
+                                    int frames, int max_n, float *d_prev_matched);
 
 /* ------------------------------------------------------------------ local BA */
 /* One keyframe-window graph in SoA form: what Optimizer::LocalBundleAdjustment builds
@@ -212,6 +221,11 @@ int orbhip_ba_batch_download(orbhip_ba_batch *b, double *const *poses_out, doubl
                              uint8_t *const *edge_outlier_out, orbhip_ba_stats *stats_out);
 int orbhip_ba_batch_ticks(const orbhip_ba_batch *b);   /* LM trials of the slowest graph, last solve */
 void orbhip_ba_batch_destroy(orbhip_ba_batch *b);
+/* Measurement hooks: hipEvent timing of the Schur GEMM launches (on the context's stream), the
+ * MFMA flops one launch issues, and a measured FP64 matrix-core peak for this device. */
+int orbhip_ba_batch_set_profiling(orbhip_ba_batch *b, int enable);
+int orbhip_ba_batch_gemm_profile(const orbhip_ba_batch *b, float *total_ms, int *launches, double *flops_per_launch);
+int orbhip_mfma_f64_peak_tflops(orbhip_ctx *ctx, double *tflops_out);
 
 #ifdef __cplusplus
 }

@@ -753,6 +753,10 @@ struct orbhip_ba_batch {
     int *h_n_active;                         // pinned
     size_t wd_total, s_total, spart_total;
     int ticks_last;
+    bool profile;                            // time the Schur GEMM launches with hipEvents
+    hipEvent_t ev0, ev1;
+    float gemm_ms_total; int gemm_launches;
+    double gemm_flops_per_launch;            // MFMA flops actually issued by one launch (all graphs)
 };
 
 template <typename T>
@@ -783,6 +787,7 @@ extern "C" void orbhip_ba_batch_destroy(orbhip_ba_batch *b)
     (void)hipStreamSynchronize(orbhip_ctx_stream_internal(b->ctx));
     for (void *p : b->allocs) (void)hipFree(p);
     if (b->h_n_active) (void)hipHostFree(b->h_n_active);
+    if (b->ev0) { (void)hipEventDestroy(b->ev0); (void)hipEventDestroy(b->ev1); }
     delete b;
 }
 
@@ -793,6 +798,7 @@ extern "C" int orbhip_ba_batch_create(orbhip_ctx *ctx, const orbhip_ba_graph *gr
     if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
     orbhip_ba_batch *b = new orbhip_ba_batch();
     b->ctx = ctx; b->h_n_active = nullptr; b->ticks_last = 0;
+    b->profile = false; b->ev0 = b->ev1 = nullptr; b->gemm_ms_total = 0; b->gemm_launches = 0; b->gemm_flops_per_launch = 0;
     BaBatch &B = b->B;
     memset(&B, 0, sizeof(B));
     B.G = n_graphs;
@@ -843,6 +849,7 @@ extern "C" int orbhip_ba_batch_create(orbhip_ctx *ctx, const orbhip_ba_graph *gr
         ks = std::max(1, std::min(ks, 64));
         ks = std::min(ks, std::max(1, H.n_points / 8));
         D.ks = ks; D.ksteps = (H.n_points + ks - 1) / ks;
+        b->gemm_flops_per_launch += (double)ntiles * 9.0 * 2048.0 * (double)H.n_points;   // 9 MFMA 16x16x4 per tile per point
         D.wd_off = wd; wd += (size_t)4 * H.n_points * D.ld;
         D.s_off = s; s += (size_t)D.ld * D.ld;
         D.spart_off = sp; sp += (size_t)ks * D.ld * D.ld;
@@ -934,7 +941,9 @@ extern "C" int orbhip_ba_batch_solve(orbhip_ba_batch *b, const orbhip_ba_params 
         hipLaunchKernelGGL(k_ba_maxdiag, dim3(G), dim3(256), 0, s, B);
         hipLaunchKernelGGL(k_ba_pretrial, dim3((G + 63) / 64), dim3(64), 0, s, B);
         hipLaunchKernelGGL(k_ba_point_prep, gp256, dim3(256), 0, s, B);
+        if (b->profile) TRY(hipEventRecord(b->ev0, s));
         hipLaunchKernelGGL(k_ba_schur_gemm, dim3((max_items + 3) / 4, G), dim3(256), 0, s, B);
+        if (b->profile) TRY(hipEventRecord(b->ev1, s));
         hipLaunchKernelGGL(k_ba_schur_finish, dim3((B.max_ld * B.max_ld + 255) / 256, G), dim3(256), 0, s, B);
         hipLaunchKernelGGL(k_ba_bschur, gf, dim3(64), 0, s, B);
         hipLaunchKernelGGL(k_ba_ldlt, dim3(G), dim3(1024), 0, s, B);
@@ -946,6 +955,11 @@ extern "C" int orbhip_ba_batch_solve(orbhip_ba_batch *b, const orbhip_ba_params 
         TRY(hipMemcpyAsync(b->h_n_active, B.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
         TRY(hipStreamSynchronize(s));
         n_active = *b->h_n_active;
+        if (b->profile) {
+            float ms = 0;
+            TRY(hipEventElapsedTime(&ms, b->ev0, b->ev1));
+            b->gemm_ms_total += ms; b->gemm_launches++;
+        }
     }
     b->ticks_last = tick;
     hipLaunchKernelGGL(k_ba_finalize, ge, dim3(256), 0, s, B);
@@ -989,6 +1003,63 @@ extern "C" int orbhip_ba_batch_download(orbhip_ba_batch *b, double *const *poses
 }
 
 extern "C" int orbhip_ba_batch_ticks(const orbhip_ba_batch *b) { return b ? b->ticks_last : ORBHIP_E_BADARG; }
+
+extern "C" int orbhip_ba_batch_set_profiling(orbhip_ba_batch *b, int enable)
+{
+    if (!b) return ORBHIP_E_BADARG;
+    if (enable && !b->ev0) {
+        if (hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess) return ORBHIP_E_HIP;
+    }
+    b->profile = enable != 0; b->gemm_ms_total = 0; b->gemm_launches = 0;
+    return ORBHIP_OK;
+}
+
+// Accumulated device time / launch count of the Schur GEMM kernel since profiling was enabled,
+// and the MFMA flops one launch issues (dense K-padded form, upper tiles only).
+extern "C" int orbhip_ba_batch_gemm_profile(const orbhip_ba_batch *b, float *total_ms, int *launches, double *flops_per_launch)
+{
+    if (!b || !total_ms || !launches || !flops_per_launch) return ORBHIP_E_BADARG;
+    *total_ms = b->gemm_ms_total; *launches = b->gemm_launches; *flops_per_launch = b->gemm_flops_per_launch;
+    return ORBHIP_OK;
+}
+
+// FP64 matrix-core peak of this device, measured: every wave issues independent
+// v_mfma_f64_16x16x4_f64 chains (the local micro-architecture guide lists no FP64 MFMA peak).
+__global__ __launch_bounds__(256) void k_mfma_f64_peak(double *sink, int iters)
+{
+    v4d acc[8];
+    for (int i = 0; i < 8; i++) acc[i] = (v4d){0, 0, 0, 0};
+    const double a = 1.0 + threadIdx.x * 1e-9, bb = 1.0 - threadIdx.x * 1e-9;
+    for (int it = 0; it < iters; it++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[i], 0, 0, 0);
+    double s = 0;
+    for (int i = 0; i < 8; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 12345.678) sink[0] = s;
+}
+
+extern "C" int orbhip_mfma_f64_peak_tflops(orbhip_ctx *ctx, double *tflops_out)
+{
+    if (!ctx || !tflops_out) return ORBHIP_E_BADARG;
+    if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
+    hipStream_t s = orbhip_ctx_stream_internal(ctx);
+    double *sink = nullptr;
+    if (hipMalloc((void **)&sink, 8) != hipSuccess) return ORBHIP_E_HIP;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    const int blocks = 256 * 8, iters = 4096;
+    hipLaunchKernelGGL(k_mfma_f64_peak, dim3(blocks), dim3(256), 0, s, sink, 64);          // warm-up
+    (void)hipEventRecord(e0, s);
+    hipLaunchKernelGGL(k_mfma_f64_peak, dim3(blocks), dim3(256), 0, s, sink, iters);
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(sink);
+    const double flops = (double)blocks * 4.0 * iters * 8.0 * 2048.0;
+    *tflops_out = flops / (ms * 1e-3) / 1e12;
+    return ORBHIP_OK;
+}
 
 extern "C" int orbhip_ba_solve_batch(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_graphs,
                                      const orbhip_ba_params *params, volatile const uint8_t *abort_flag,

@@ -13,6 +13,7 @@
 struct orbhip_ctx;
 hipStream_t orbhip_ctx_stream_internal(orbhip_ctx *c);
 int orbhip_ctx_device_internal(orbhip_ctx *c);
+int32_t *orbhip_ctx_status_internal(orbhip_ctx *c);
 
 // M1: host-callable scalar; same SWAR sequence as the reference (== sum of popcount32).
 extern "C" int orbhip_descriptor_distance(const uint8_t *a32, const uint8_t *b32)
@@ -81,5 +82,208 @@ extern "C" int orbhip_match_bf2nn_device(orbhip_ctx *ctx, const uint8_t *d_descA
     dim3 grid((max_n + 255) / 256, pairs);
     hipLaunchKernelGGL(k_bf2nn, grid, dim3(256), 0, orbhip_ctx_stream_internal(ctx), d_descA, d_nA, strideA, d_descB, d_nB,
                        strideB, max_n, ratio, d_idx2, d_dist2, d_accept);
+    return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
+}
+
+// ---------------------------------------------------------------------------- M3 + M4
+// ORBmatcher::SearchForInitialization (ORBmatcher.cc:710-825) over the Frame grid
+// (Frame.cc:377-408 AssignFeaturesToGrid, :716-726 PosInGrid, :645-714 GetFeaturesInArea).
+// One wave per frame pair.  The F1 loop is inherently sequential (vMatchedDistance feeds
+// later iterations, ORBmatcher.cc:749), but each iteration's best / second-best search over
+// the window's grid cells is order-free except for the tie-break "first candidate in
+// GetFeaturesInArea order wins" -- so the 64 lanes scan cells in parallel carrying
+// (dist << 23 | visit order) keys and the wave reduces them.
+#define SI_COLS 64            // FRAME_GRID_COLS (include/Frame.h:38)
+#define SI_ROWS 48            // FRAME_GRID_ROWS (include/Frame.h:39)
+#define SI_MAXN 2048
+#define SI_TH_LOW 50          // ORBmatcher::TH_LOW  (ORBmatcher.cc:41)
+#define SI_HISTO 30           // ORBmatcher::HISTO_LENGTH (ORBmatcher.cc:42)
+
+__global__ __launch_bounds__(64) void k_search_init(const orbhip_keypoint *kpA_, const uint8_t *descA_, const int32_t *nA,
+                                                    const orbhip_keypoint *kpB_, const uint8_t *descB_, const int32_t *nB,
+                                                    int max_n, size_t kp_stride, float min_x, float min_y, float max_x, float max_y,
+                                                    int window, float nn_ratio, int check_ori,
+                                                    float *prev_, int32_t *m12_, int32_t *nmatches_, int32_t *status)
+{
+    __shared__ uint16_t cell_of[SI_MAXN];
+    __shared__ uint16_t items[SI_MAXN];
+    __shared__ int cell_start[SI_COLS * SI_ROWS + 1];
+    __shared__ int matched_dist[SI_MAXN];
+    __shared__ int16_t m21[SI_MAXN];
+    __shared__ int8_t bin_of[SI_MAXN];
+    __shared__ int hist[SI_HISTO];
+    __shared__ int s_keep[3];
+    const int pair = blockIdx.x, lane = threadIdx.x;
+    const int n1 = nA[pair], n2 = nB[pair];
+    const orbhip_keypoint *kpA = kpA_ + (size_t)pair * kp_stride, *kpB = kpB_ + (size_t)pair * kp_stride;
+    const uint4 *dA = reinterpret_cast<const uint4 *>(descA_ + (size_t)pair * kp_stride * 32);
+    const uint4 *dB = reinterpret_cast<const uint4 *>(descB_ + (size_t)pair * kp_stride * 32);
+    float *prev = prev_ + (size_t)pair * max_n * 2;
+    int32_t *m12 = m12_ + (size_t)pair * max_n;
+    if (n1 > SI_MAXN || n2 > SI_MAXN) { if (lane == 0) { atomicExch(status, ORBHIP_E_CAPACITY); nmatches_[pair] = 0; } return; }
+    const float inv_w = __fdiv_rn((float)SI_COLS, __fsub_rn(max_x, min_x));       // Frame.cc:334-335
+    const float inv_h = __fdiv_rn((float)SI_ROWS, __fsub_rn(max_y, min_y));
+    const int NC = SI_COLS * SI_ROWS;
+    // ---- AssignFeaturesToGrid: cell = posX*ROWS + posY (mGrid[posX][posY]), insertion order kept
+    for (int c = lane; c <= NC; c += 64) cell_start[c] = 0;
+    for (int i = lane; i < SI_HISTO; i += 64) hist[i] = 0;
+    __syncthreads();
+    for (int i = lane; i < n2; i += 64) {
+        const int px = (int)roundf(__fmul_rn(__fsub_rn(kpB[i].x, min_x), inv_w));     // round(), Frame.cc:718-719
+        const int py = (int)roundf(__fmul_rn(__fsub_rn(kpB[i].y, min_y), inv_h));
+        int c = 0xFFFF;
+        if (px >= 0 && px < SI_COLS && py >= 0 && py < SI_ROWS) { c = px * SI_ROWS + py; atomicAdd(&cell_start[c + 1], 1); }
+        cell_of[i] = (uint16_t)c;
+        matched_dist[i] = INT_MAX;
+        m21[i] = -1;
+    }
+    for (int i = lane; i < n1; i += 64) { m12[i] = -1; bin_of[i] = -1; }
+    __syncthreads();
+    {   // exclusive scan over the cells: 48 cells per lane, then a wave scan
+        const int per = NC / 64;
+        int s = 0;
+        for (int k = 0; k < per; k++) s += cell_start[1 + lane * per + k];
+        int inc = s;
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+        int run = inc - s;
+        for (int k = 0; k < per; k++) { const int c = cell_start[1 + lane * per + k]; cell_start[1 + lane * per + k] = run + c; run += c; }
+    }
+    __syncthreads();
+    for (int i = lane; i < n2; i += 64) {
+        const int c = cell_of[i];
+        if (c == 0xFFFF) continue;
+        int rank = 0;
+        for (int j = 0; j < i; j++) rank += (cell_of[j] == c);
+        items[cell_start[c] + rank] = (uint16_t)i;
+    }
+    __syncthreads();
+    // ---- sequential F1 loop
+    int nmatches = 0;
+    const float r = (float)window;
+    const float factor = 1.0f / SI_HISTO;
+    for (int i1 = 0; i1 < n1; i1++) {
+        if (kpA[i1].octave > 0) continue;                                   // ORBmatcher.cc:726-728
+        const float x = prev[2 * i1], y = prev[2 * i1 + 1];
+        int c0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, min_x), r), inv_w)); if (c0 < 0) c0 = 0;
+        if (c0 >= SI_COLS) continue;
+        int c1 = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, min_x), r), inv_w)); if (c1 > SI_COLS - 1) c1 = SI_COLS - 1;
+        if (c1 < 0) continue;
+        int r0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, min_y), r), inv_h)); if (r0 < 0) r0 = 0;
+        if (r0 >= SI_ROWS) continue;
+        int r1 = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, min_y), r), inv_h)); if (r1 > SI_ROWS - 1) r1 = SI_ROWS - 1;
+        if (r1 < 0) continue;
+        const int ncy = r1 - r0 + 1, wc = (c1 - c0 + 1) * ncy;
+        const uint4 a0 = dA[2 * i1], a1 = dA[2 * i1 + 1];
+        uint32_t lk1 = 0xFFFFFFFFu; int d2 = INT_MAX, best_i2 = -1, any = 0;
+        for (int v = lane; v < wc; v += 64) {
+            const int ix = c0 + v / ncy, iy = r0 + v % ncy;
+            const int c = ix * SI_ROWS + iy;
+            for (int j = cell_start[c]; j < cell_start[c + 1]; j++) {
+                const int i2 = items[j];
+                const orbhip_keypoint kb = kpB[i2];
+                if (kb.octave != 0) continue;                               // minLevel = maxLevel = 0, Frame.cc:695-702
+                if (!(fabsf(__fsub_rn(kb.x, x)) < r && fabsf(__fsub_rn(kb.y, y)) < r)) continue;
+                any = 1;
+                const int dist = hamming256(a0, a1, dB[2 * i2], dB[2 * i2 + 1]);
+                if (matched_dist[i2] <= dist) continue;                     // ORBmatcher.cc:749
+                const uint32_t key = ((uint32_t)dist << 23) | (uint32_t)(v * 2048 + (j - cell_start[c]));
+                if (key < lk1) { if (lk1 != 0xFFFFFFFFu) d2 = min(d2, (int)(lk1 >> 23)); lk1 = key; best_i2 = i2; }
+                else d2 = min(d2, dist);
+            }
+        }
+        if (!__any(any)) continue;                                          // vIndices2.empty(), ORBmatcher.cc:732-733
+        uint32_t k1 = lk1;
+        for (int d = 32; d >= 1; d >>= 1) {
+            const uint32_t ok1 = __shfl_xor(k1, d, 64);
+            const int od2 = __shfl_xor(d2, d, 64);
+            const uint32_t lose = max(k1, ok1);
+            d2 = min(min(d2, od2), lose == 0xFFFFFFFFu ? INT_MAX : (int)(lose >> 23));
+            k1 = min(k1, ok1);
+        }
+        if (k1 == 0xFFFFFFFFu) continue;                                    // bestDist stays INT_MAX > TH_LOW
+        const int best = (int)(k1 >> 23);
+        if (!(best <= SI_TH_LOW && (float)best < __fmul_rn((float)d2, nn_ratio))) continue;   // ORBmatcher.cc:764-766
+        const unsigned long long owner = __ballot(lk1 == k1);              // keys are unique: exactly one lane
+        const int best_idx = __shfl(best_i2, __ffsll((long long)owner) - 1, 64);
+        if (lane == 0) {
+            const int old = m21[best_idx];
+            if (old >= 0) { m12[old] = -1; nmatches--; }                    // ORBmatcher.cc:768-772
+            m12[i1] = best_idx; m21[best_idx] = (int16_t)i1; matched_dist[best_idx] = best; nmatches++;
+            if (check_ori) {                                                // ORBmatcher.cc:778-789
+                float rot = __fsub_rn(kpA[i1].angle, kpB[best_idx].angle);
+                if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                int bin = (int)roundf(__fmul_rn(rot, factor));
+                if (bin == SI_HISTO) bin = 0;
+                hist[bin]++; bin_of[i1] = (int8_t)bin;
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    // ---- rotation consistency: keep the three most populated bins (ORBmatcher.cc:792-815, 2307-2348)
+    if (check_ori) {
+        if (lane == 0) {
+            int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+            for (int i = 0; i < SI_HISTO; i++) {
+                const int sz = hist[i];
+                if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+                else if (sz > max3) { max3 = sz; ind3 = i; }
+            }
+            if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+            else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) ind3 = -1;
+            s_keep[0] = ind1; s_keep[1] = ind2; s_keep[2] = ind3;
+        }
+        __syncthreads();
+        int removed = 0;
+        for (int i1 = lane; i1 < n1; i1 += 64) {
+            const int b = bin_of[i1];
+            if (b < 0 || b == s_keep[0] || b == s_keep[1] || b == s_keep[2]) continue;
+            if (m12[i1] >= 0) { m12[i1] = -1; removed++; }
+        }
+        for (int d = 32; d >= 1; d >>= 1) removed += __shfl_xor(removed, d, 64);
+        nmatches -= removed;                                                // lane 0's copy is the one written out
+    }
+    __syncthreads();
+    for (int i1 = lane; i1 < n1; i1 += 64)                                  // ORBmatcher.cc:818-822
+        if (m12[i1] >= 0) { prev[2 * i1] = kpB[m12[i1]].x; prev[2 * i1 + 1] = kpB[m12[i1]].y; }
+    if (lane == 0) nmatches_[pair] = nmatches;
+}
+
+extern "C" int orbhip_search_for_initialization_device(orbhip_ctx *ctx,
+        const orbhip_keypoint *d_kpA, const uint8_t *d_descA, const int32_t *d_nA,
+        const orbhip_keypoint *d_kpB, const uint8_t *d_descB, const int32_t *d_nB,
+        int pairs, int max_n, size_t frame_stride_kp, float min_x, float min_y, float max_x, float max_y,
+        int window_size, float nn_ratio, int check_orientation,
+        float *d_prev_matched, int32_t *d_matches12, int32_t *d_nmatches)
+{
+    if (!ctx || !d_kpA || !d_descA || !d_nA || !d_kpB || !d_descB || !d_nB || pairs <= 0 || max_n <= 0 ||
+        !d_prev_matched || !d_matches12 || !d_nmatches || !(max_x > min_x) || !(max_y > min_y))
+        return ORBHIP_E_BADARG;
+    if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
+    int32_t *d_status = orbhip_ctx_status_internal(ctx);    // frames with > 2048 keypoints set ORBHIP_E_CAPACITY
+    hipLaunchKernelGGL(k_search_init, dim3(pairs), dim3(64), 0, orbhip_ctx_stream_internal(ctx), d_kpA, d_descA, d_nA,
+                       d_kpB, d_descB, d_nB, max_n, frame_stride_kp, min_x, min_y, max_x, max_y, window_size, nn_ratio,
+                       check_orientation, d_prev_matched, d_matches12, d_nmatches, d_status);
+    return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
+}
+
+// vbPrevMatched initialisation (Tracking.cc:1497-1499: mvbPrevMatched[i] = mvKeysUn[i].pt), batched.
+__global__ void k_prev_matched_init(const orbhip_keypoint *kp, size_t kp_stride, int frames, int max_n, float *xy)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
+    if (i >= max_n || f >= frames) return;
+    const orbhip_keypoint k = kp[(size_t)f * kp_stride + i];
+    xy[((size_t)f * max_n + i) * 2] = k.x;
+    xy[((size_t)f * max_n + i) * 2 + 1] = k.y;
+}
+
+extern "C" int orbhip_prev_matched_init_device(orbhip_ctx *ctx, const orbhip_keypoint *d_kp, size_t frame_stride_kp,
+                                               int frames, int max_n, float *d_prev_matched)
+{
+    if (!ctx || !d_kp || !d_prev_matched || frames <= 0 || max_n <= 0) return ORBHIP_E_BADARG;
+    if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
+    hipLaunchKernelGGL(k_prev_matched_init, dim3((max_n + 255) / 256, frames), dim3(256), 0, orbhip_ctx_stream_internal(ctx),
+                       d_kp, frame_stride_kp, frames, max_n, d_prev_matched);
     return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
 }

@@ -28,6 +28,7 @@ struct orbhip_ctx {
     int device;
     hipStream_t stream;
     bool own_stream;
+    int32_t *d_status;      // sticky device-side error word (capacity overflows in matcher kernels)
 };
 
 extern "C" int orbhip_ctx_create(int device, void *stream, orbhip_ctx **out)
@@ -48,12 +49,27 @@ extern "C" int orbhip_ctx_create(int device, void *stream, orbhip_ctx **out)
         if (e2 != hipSuccess) { delete c; g_last_error = hipGetErrorString(e2); return ORBHIP_E_HIP; }
         c->own_stream = true;
     }
+    if (hipMalloc((void **)&c->d_status, sizeof(int32_t)) != hipSuccess || hipMemset(c->d_status, 0, sizeof(int32_t)) != hipSuccess) {
+        if (c->own_stream) (void)hipStreamDestroy(c->stream);
+        delete c; g_last_error = "hipMalloc(status)"; return ORBHIP_E_HIP;
+    }
     *out = c;
     return ORBHIP_OK;
 }
+extern "C" int orbhip_ctx_check_status(orbhip_ctx *c)
+{
+    if (!c) return ORBHIP_E_BADARG;
+    int32_t st = 0;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(&st, c->d_status, sizeof(st), hipMemcpyDeviceToHost));
+    if (st) { HIP_TRY(hipMemset(c->d_status, 0, sizeof(int32_t))); g_last_error = "device-side capacity exceeded in a matcher kernel"; }
+    return st;
+}
+int32_t *orbhip_ctx_status_internal(orbhip_ctx *c) { return c->d_status; }
 extern "C" void orbhip_ctx_destroy(orbhip_ctx *c)
 {
     if (!c) return;
+    (void)hipFree(c->d_status);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

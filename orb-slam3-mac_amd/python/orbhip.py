@@ -63,6 +63,10 @@ lib.orbhip_extractor_set_profiling.argtypes = [vp, ci]
 lib.orbhip_extractor_stage_ms.argtypes = [vp, vp]
 lib.orbhip_descriptor_distance.argtypes = [vp, vp]
 lib.orbhip_match_bf2nn_device.argtypes = [vp, vp, vp, sz, vp, vp, sz, ci, ci, cd, vp, vp, vp]
+lib.orbhip_search_for_initialization_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, sz, cf, cf, cf, cf, ci, cf, ci,
+                                                        vp, vp, vp]
+lib.orbhip_ctx_check_status.argtypes = [vp]
+lib.orbhip_prev_matched_init_device.argtypes = [vp, vp, sz, ci, ci, vp]
 
 
 class OrbHipError(RuntimeError):
@@ -84,6 +88,9 @@ class Context:
 
     def synchronize(self):
         _chk(lib.orbhip_ctx_synchronize(self.h), "orbhip_ctx_synchronize")
+
+    def check_status(self):
+        _chk(lib.orbhip_ctx_check_status(self.h), "orbhip_ctx_check_status")
 
     @property
     def stream(self):
@@ -210,6 +217,19 @@ def match_bf2nn_device(ctx, d_descA, d_nA, strideA, d_descB, d_nB, strideB, pair
                                        d_idx2, d_dist2, d_accept), "orbhip_match_bf2nn_device")
 
 
+def search_for_initialization_device(ctx, d_kpA, d_descA, d_nA, d_kpB, d_descB, d_nB, pairs, max_n, kp_stride, bounds,
+                                     window, nn_ratio, check_ori, d_prev, d_m12, d_nmatches):
+    """ORBmatcher::SearchForInitialization, batched; all pointers are device addresses (ints)."""
+    _chk(lib.orbhip_search_for_initialization_device(ctx.h, d_kpA, d_descA, d_nA, d_kpB, d_descB, d_nB, pairs, max_n,
+                                                     kp_stride, bounds[0], bounds[1], bounds[2], bounds[3], window,
+                                                     nn_ratio, 1 if check_ori else 0, d_prev, d_m12, d_nmatches),
+         "orbhip_search_for_initialization_device")
+
+
+def prev_matched_init_device(ctx, d_kp, kp_stride, frames, max_n, d_prev):
+    _chk(lib.orbhip_prev_matched_init_device(ctx.h, d_kp, kp_stride, frames, max_n, d_prev), "orbhip_prev_matched_init_device")
+
+
 def descriptor_distance(a, b):
     a = np.ascontiguousarray(a, np.uint8)
     b = np.ascontiguousarray(b, np.uint8)
@@ -265,6 +285,15 @@ lib.orbhip_ba_batch_download.argtypes = [vp, vp, vp, vp, vp]
 lib.orbhip_ba_batch_ticks.argtypes = [vp]
 lib.orbhip_ba_batch_destroy.argtypes = [vp]
 lib.orbhip_ba_solve_batch.argtypes = [vp, vp, ci, C.POINTER(BaParams), vp, vp, vp, vp, vp]
+lib.orbhip_ba_batch_set_profiling.argtypes = [vp, ci]
+lib.orbhip_ba_batch_gemm_profile.argtypes = [vp, C.POINTER(cf), C.POINTER(ci), C.POINTER(cd)]
+lib.orbhip_mfma_f64_peak_tflops.argtypes = [vp, C.POINTER(cd)]
+
+
+def mfma_f64_peak_tflops(ctx):
+    v = cd()
+    _chk(lib.orbhip_mfma_f64_peak_tflops(ctx.h, C.byref(v)), "orbhip_mfma_f64_peak_tflops")
+    return v.value
 
 
 def ba_default_params():
@@ -310,6 +339,14 @@ class BaBatch:
     @property
     def ticks(self):
         return lib.orbhip_ba_batch_ticks(self.h)
+
+    def set_profiling(self, on):
+        _chk(lib.orbhip_ba_batch_set_profiling(self.h, 1 if on else 0), "ba set_profiling")
+
+    def gemm_profile(self):
+        ms, n, fl = cf(), ci(), cd()
+        _chk(lib.orbhip_ba_batch_gemm_profile(self.h, C.byref(ms), C.byref(n), C.byref(fl)), "ba gemm_profile")
+        return ms.value, n.value, fl.value
 
     def download(self):
         poses = [a.copy() for a in self.poses]

@@ -96,3 +96,81 @@ def test_bf2nn_on_extracted_frames(gpu_ctx):
         n_acc += int(oa.sum())
     assert n_acc > 100          # consecutive synthetic frames really do match
     ext.close()
+
+
+# ------------------------------------------------------------------ M3 + M4: SearchForInitialization
+def _search_init(gpu_ctx, frames_a, frames_b, bounds, prevs, max_n, window=100, ratio=0.9, check_ori=True):
+    """frames_*: list of (kp structured array, desc [n,32]).  Returns per pair (nmatches, m12, prev)."""
+    import torch
+    import orbhip
+    P = len(frames_a)
+    kpA = np.zeros((P, max_n), orbhip.KP_DTYPE); kpB = np.zeros((P, max_n), orbhip.KP_DTYPE)
+    dA = np.zeros((P, max_n, 32), np.uint8); dB = np.zeros((P, max_n, 32), np.uint8)
+    nA = np.array([len(f[0]) for f in frames_a], np.int32); nB = np.array([len(f[0]) for f in frames_b], np.int32)
+    prev = np.zeros((P, max_n, 2), np.float32)
+    for p in range(P):
+        kpA[p, :nA[p]] = frames_a[p][0]; dA[p, :nA[p]] = frames_a[p][1]
+        kpB[p, :nB[p]] = frames_b[p][0]; dB[p, :nB[p]] = frames_b[p][1]
+        prev[p, :nA[p]] = prevs[p]
+    t = [torch.from_numpy(a.view(np.uint8) if a.dtype == orbhip.KP_DTYPE else a).cuda() for a in (kpA, dA, nA, kpB, dB, nB, prev)]
+    m12 = torch.full((P, max_n), -9, dtype=torch.int32, device="cuda")
+    nm = torch.full((P,), -9, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    orbhip.search_for_initialization_device(gpu_ctx, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(),
+                                            t[4].data_ptr(), t[5].data_ptr(), P, max_n, max_n, bounds, window, ratio,
+                                            check_ori, t[6].data_ptr(), m12.data_ptr(), nm.data_ptr())
+    gpu_ctx.check_status()
+    m12 = m12.cpu().numpy(); nm = nm.cpu().numpy(); pv = t[6].cpu().numpy()
+    return [(int(nm[p]), m12[p, :nA[p]], pv[p, :nA[p]]) for p in range(P)]
+
+
+@pytest.mark.parametrize("check_ori,window,ratio", [(True, 100, 0.9), (False, 100, 0.9), (True, 30, 0.6), (True, 400, 0.95)])
+def test_search_for_initialization_parity(gpu_ctx, check_ori, window, ratio):
+    import orbhip
+    import oracle_match_bind as om
+    ext = orbhip.Extractor(gpu_ctx, 1000, 1.2, 8, 20, 7)
+    imgs = orbhip.synth_frames(640, 480, 6, seed=77)
+    res = ext.extract_host(imgs, lap=(0, 0))
+    fa = [(res[i][0], res[i][1]) for i in (0, 1, 2, 3, 4)]
+    fb = [(res[i][0], res[i][1]) for i in (1, 2, 3, 5, 4)]        # incl. a 2-frame jump and a self-match
+    bounds = (0.0, 0.0, 640.0, 480.0)
+    prevs = [np.stack([f[0]["x"], f[0]["y"]], 1) for f in fa]     # Tracking.cc:1497-1499
+    got = _search_init(gpu_ctx, fa, fb, bounds, prevs, ext.max_keypoints, window, ratio, check_ori)
+    total = 0
+    for p in range(len(fa)):
+        n, m12, prev = om.search_for_initialization(fa[p][0], fa[p][1], fb[p][0], fb[p][1], bounds, prevs[p], window, ratio, check_ori)
+        assert got[p][0] == n, (p, got[p][0], n)
+        np.testing.assert_array_equal(got[p][1], m12)
+        assert got[p][2].tobytes() == prev.tobytes()
+        total += n
+    assert total > 50
+    ext.close()
+
+
+def test_search_for_initialization_edge_cases(gpu_ctx):
+    """Empty frames, keypoints outside the grid, duplicated descriptors (ties), prev far off-image."""
+    import orbhip
+    import oracle_match_bind as om
+    rng = np.random.default_rng(5)
+
+    def mk(n, spread=1.0):
+        kp = np.zeros(n, orbhip.KP_DTYPE)
+        kp["x"] = rng.uniform(-20, 660, n).astype(np.float32) * spread
+        kp["y"] = rng.uniform(-20, 500, n).astype(np.float32) * spread
+        kp["angle"] = rng.uniform(0, 360, n).astype(np.float32)
+        kp["octave"] = rng.integers(0, 3, n)
+        d = rng.integers(0, 256, (max(n // 8, 1), 32), dtype=np.uint8)[rng.integers(0, max(n // 8, 1), n)]   # many duplicates
+        d[:, 0] ^= rng.integers(0, 4, n).astype(np.uint8)
+        return kp, d
+    fa = [mk(0), mk(50), mk(300), mk(200), mk(700)]
+    fb = [mk(10), mk(0), mk(300), mk(200), mk(650)]
+    fb[2] = (fa[2][0].copy(), fa[2][1].copy())                     # identical frame: every level-0 point has an exact twin
+    bounds = (0.0, 0.0, 640.0, 480.0)
+    prevs = [np.stack([f[0]["x"], f[0]["y"]], 1) for f in fa]
+    prevs[3] = prevs[3] + 5000.0                                    # windows entirely outside the grid
+    got = _search_init(gpu_ctx, fa, fb, bounds, prevs, 800, 100, 0.9, True)
+    for p in range(len(fa)):
+        n, m12, prev = om.search_for_initialization(fa[p][0], fa[p][1], fb[p][0], fb[p][1], bounds, prevs[p], 100, 0.9, True)
+        assert got[p][0] == n, (p, got[p][0], n)
+        np.testing.assert_array_equal(got[p][1], m12)
+        assert got[p][2].tobytes() == prev.tobytes()
