@@ -56,7 +56,7 @@ class OracleExtractor:
         self.nfeatures = nfeatures
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:
             lib.orc_extractor_destroy(self.h)
             self.h = None
 

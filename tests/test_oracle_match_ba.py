@@ -1,0 +1,199 @@
+"""CPU tests pinning the matching and BA oracles (no GPU)."""
+import numpy as np
+import pytest
+
+import oracle_bind as ob
+import oracle_match_bind as om
+import oracle_ba_bind as obb
+
+
+# ------------------------------------------------------------------ matching
+def test_swar_hamming_equals_popcount():
+    rng = np.random.default_rng(0)
+    for _ in range(500):
+        a = rng.integers(0, 256, 32, dtype=np.uint8)
+        b = rng.integers(0, 256, 32, dtype=np.uint8)
+        assert om.descriptor_distance(a, b) == int(np.unpackbits(a ^ b).sum())
+    assert om.descriptor_distance(np.zeros(32, np.uint8), np.full(32, 255, np.uint8)) == 256
+
+
+def test_bf2nn_against_numpy():
+    rng = np.random.default_rng(1)
+    A = rng.integers(0, 256, (60, 32), dtype=np.uint8)
+    B = rng.integers(0, 256, (75, 32), dtype=np.uint8)
+    B[10] = B[3]                                              # tie: lower index must win
+    idx, dist, acc = om.bf2nn(A, B, 0.7)
+    D = np.unpackbits(A[:, None, :] ^ B[None, :, :], axis=2).sum(2)
+    order = np.argsort(D, axis=1, kind="stable")
+    np.testing.assert_array_equal(idx, order[:, :2])
+    np.testing.assert_array_equal(dist, np.take_along_axis(D, order[:, :2], 1))
+    np.testing.assert_array_equal(acc, (dist[:, 0].astype(np.float32) < dist[:, 1].astype(np.float32) * 0.7).astype(np.uint8))
+    idx1, dist1, acc1 = om.bf2nn(A[:3], B[:1], 0.7)           # fewer than k train rows -> never accepted
+    assert (idx1[:, 1] == -1).all() and (acc1 == 0).all()
+
+
+def _kps(n, rng, w=640, h=480):
+    kp = np.zeros(n, ob.KP_DTYPE)
+    kp["x"] = rng.uniform(0, w, n).astype(np.float32)
+    kp["y"] = rng.uniform(0, h, n).astype(np.float32)
+    kp["octave"] = rng.integers(0, 8, n)
+    kp["angle"] = rng.uniform(0, 360, n).astype(np.float32)
+    return kp
+
+
+def test_features_in_area_against_bruteforce_and_grid_rounding():
+    """GetFeaturesInArea: cell index uses round() (Frame.cc:718), the window uses floor/ceil and a
+    strict |d| < r test; the result equals a brute-force scan re-ordered cell-major."""
+    rng = np.random.default_rng(2)
+    kp = _kps(800, rng)
+    b = (0.0, 0.0, 640.0, 480.0)
+    inv_w, inv_h = np.float32(64) / np.float32(640), np.float32(48) / np.float32(480)
+    cx = np.floor(np.float32(kp["x"] * inv_w) + np.float32(0.5)).astype(int)      # round half away (x >= 0)
+    cy = np.floor(np.float32(kp["y"] * inv_h) + np.float32(0.5)).astype(int)
+    ingrid = (cx < 64) & (cy < 48)
+    for (x, y, r, lo, hi) in [(320, 240, 100, 0, 0), (5, 5, 50, -1, -1), (630, 470, 40, 2, 5), (100, 400, 15, 0, 7),
+                              (-200, 50, 100, 0, 0), (320, 240, 1000, -1, -1)]:
+        got = om.features_in_area(kp, b, x, y, r, lo, hi)
+        sel = ingrid & (np.abs(kp["x"] - np.float32(x)) < r) & (np.abs(kp["y"] - np.float32(y)) < r)
+        if lo > 0 or hi >= 0:
+            sel &= kp["octave"] >= lo
+            if hi >= 0:
+                sel &= kp["octave"] <= hi
+        # window cell range
+        c0 = max(0, int(np.floor((np.float32(x) - np.float32(r)) * inv_w))); c1 = min(63, int(np.ceil((np.float32(x) + np.float32(r)) * inv_w)))
+        r0 = max(0, int(np.floor((np.float32(y) - np.float32(r)) * inv_h))); r1 = min(47, int(np.ceil((np.float32(y) + np.float32(r)) * inv_h)))
+        sel &= (cx >= c0) & (cx <= c1) & (cy >= r0) & (cy <= r1)
+        want = sorted(np.nonzero(sel)[0].tolist(), key=lambda i: (cx[i], cy[i], i))
+        assert got.tolist() == want
+
+
+def test_search_for_initialization_identity_and_properties():
+    import orbhip
+    img = orbhip.synth_frames(640, 480, 2, seed=9)
+    e = ob.OracleExtractor()
+    k0, d0, _ = e.extract(img[0], (0, 0))
+    k1, d1, _ = e.extract(img[1], (0, 0))
+    b = (0.0, 0.0, 640.0, 480.0)
+    prev = np.stack([k0["x"], k0["y"]], 1)
+    n, m12, pv = om.search_for_initialization(k0, d0, k0, d0, b, prev, 100, 0.9, True)
+    lvl0 = np.nonzero(k0["octave"] == 0)[0]
+    assert n == int((m12 >= 0).sum())
+    assert (m12[k0["octave"] > 0] == -1).all()                    # only level-0 keypoints are matched
+    assert (m12[lvl0][m12[lvl0] >= 0] == lvl0[m12[lvl0] >= 0]).all()   # a frame matches itself point for point
+    n2, m2, pv2 = om.search_for_initialization(k0, d0, k1, d1, b, prev, 100, 0.9, True)
+    good = np.nonzero(m2 >= 0)[0]
+    assert n2 == len(good) and len(set(m2[good].tolist())) == len(good)       # one-to-one
+    assert (k1["octave"][m2[good]] == 0).all()
+    np.testing.assert_array_equal(pv2[good], np.stack([k1["x"][m2[good]], k1["y"][m2[good]]], 1))
+    n3, _, _ = om.search_for_initialization(k0, d0, k1, d1, b, prev, 100, 0.9, False)
+    assert n3 >= n2                                                  # rotation check only removes matches
+
+
+# ------------------------------------------------------------------ BA
+def test_se3_exp_matches_rodrigues_and_small_angle_branch():
+    rng = np.random.default_rng(3)
+    for scale in (1.0, 1e-3, 1e-7):
+        u = rng.normal(0, scale, 6)
+        q = np.zeros(4); t = np.zeros(3)
+        ob.lib.orc_se3_exp(u.ctypes.data, q.ctypes.data, t.ctypes.data)
+        w = u[:3]; th = np.linalg.norm(w)
+        K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+        if th < 1e-5:
+            R = np.eye(3) + K + K @ K; V = R                        # se3quat.h:240-246 (sic)
+        else:
+            R = np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * K @ K
+            V = np.eye(3) + (1 - np.cos(th)) / th ** 2 * K + (th - np.sin(th)) / th ** 3 * K @ K
+        x, y, z, w_ = q
+        Rq = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w_), 2 * (x * z + y * w_)],
+                       [2 * (x * y + z * w_), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w_)],
+                       [2 * (x * z - y * w_), 2 * (y * z + x * w_), 1 - 2 * (x * x + y * y)]])
+        np.testing.assert_allclose(Rq, R / np.cbrt(np.linalg.det(R)) if th < 1e-5 else R, atol=1e-9)
+        np.testing.assert_allclose(t, V @ u[3:], atol=1e-12)
+        assert q[3] >= 0 and abs(np.linalg.norm(q) - 1) < 1e-12
+
+
+@pytest.mark.parametrize("stereo", [0, 1])
+def test_edge_jacobians_against_finite_differences(stereo):
+    rng = np.random.default_rng(4 + stereo)
+    q = rng.normal(0, 1, 4); q /= np.linalg.norm(q); q *= np.sign(q[3])
+    pose = np.concatenate([q, rng.normal(0, 1, 3)])
+    Xc = np.array([0.3, -0.2, 4.0])
+    # choose X so that the camera-frame point is Xc
+    e0 = np.zeros(3); Jx = np.zeros(9); Jt = np.zeros(18)
+    R = np.zeros(9)
+    x, y, z, w = q
+    Rm = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                   [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                   [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    X = Rm.T @ (Xc - pose[4:])
+    obs = np.array([300.0, 200.0, 290.0])
+    fx, fy, cx, cy, bf = 458.0, 457.0, 320.0, 240.0, 50.0
+
+    def err(p, Xw):
+        e = np.zeros(3)
+        ob.lib.orc_ba_edge(np.ascontiguousarray(p).ctypes.data, np.ascontiguousarray(Xw).ctypes.data, obs.ctypes.data,
+                           stereo, fx, fy, cx, cy, bf, e.ctypes.data, Jx.ctypes.data, Jt.ctypes.data)
+        return e.copy()
+    e0 = err(pose, X)
+    D = 3 if stereo else 2
+    JxA = Jx[:3 * D].reshape(D, 3).copy(); JtA = Jt[:6 * D].reshape(D, 6).copy()
+    h = 1e-3 if stereo else 1e-6      # stereo residual quantises 1/z to float32: FD needs a coarse step
+    Jx_num = np.zeros((D, 3)); Jt_num = np.zeros((D, 6))
+    for k in range(3):
+        d = np.zeros(3); d[k] = h
+        Jx_num[:, k] = (err(pose, X + d)[:D] - err(pose, X - d)[:D]) / (2 * h)
+    for k in range(6):
+        d = np.zeros(6); d[k] = h
+        pp = pose.copy(); pm = pose.copy()
+        ob.lib.orc_se3_oplus(d.ctypes.data, pp.ctypes.data)
+        ob.lib.orc_se3_oplus((-d).ctypes.data, pm.ctypes.data)
+        Jt_num[:, k] = (err(pp, X)[:D] - err(pm, X)[:D]) / (2 * h)
+    tol = 5e-2 if stereo else 1e-5        # stereo error uses a float32 1/z (types_six_dof_expmap.cpp:191)
+    np.testing.assert_allclose(JxA, Jx_num, atol=tol, rtol=1e-4)
+    np.testing.assert_allclose(JtA, Jt_num, atol=tol, rtol=1e-4)
+
+
+def test_ba_recovers_noise_free_structure():
+    import synth_ba
+    g = synth_ba.make_graph(n_kf=8, n_pts=150, obs=5, seed=5, outlier_frac=0.0, pixel_noise=0.0)
+    rc, poses, pts, out, st = obb.solve(g)
+    assert rc == 0 and st["discarded"] == 0
+    assert st["chi2_final"] < 1e-3 * st["chi2_initial"]
+    # gauge is fixed by the two fixed keyframes: the optimum is the ground truth (up to float32 obs rounding)
+    assert np.sqrt(np.mean((pts - g["points_gt"]) ** 2)) < 2e-3
+    assert np.sqrt(np.mean((poses[:, 4:] - g["poses_gt"][:, 4:]) ** 2)) < 2e-3
+    np.testing.assert_array_equal(poses[:2], g["poses0"][:2])      # fixed keyframes untouched
+    assert out.sum() == 0
+
+
+def test_ba_schedule_abort_and_discard():
+    import synth_ba
+    g = synth_ba.make_graph(n_kf=8, n_pts=120, obs=5, seed=6)
+    rc, poses, pts, out, st = obb.solve(g)
+    assert st["iterations_run"][0] <= 5 and st["iterations_run"][1] <= 10 and st["lm_trials"] >= sum(st["iterations_run"])
+    assert st["chi2_final"] <= st["chi2_initial"]
+    rc2, p2, x2, _, st2 = obb.solve(g, abort=np.ones(1, np.uint8))
+    assert rc2 == -5                                               # Optimizer.cc:2041-2043
+    np.testing.assert_array_equal(p2, g["poses0"])
+    gbad = synth_ba.make_graph(n_kf=8, n_pts=120, obs=5, seed=7, outlier_frac=0.9)
+    rc3, p3, x3, out3, st3 = obb.solve(gbad)
+    assert st3["discarded"] == 1 and out3.sum() >= 0.5 * len(out3)   # Optimizer.cc:2177-2181
+    np.testing.assert_array_equal(p3, gbad["poses0"])
+    np.testing.assert_array_equal(x3, gbad["points0"])
+
+
+def test_ba_golden_regression():
+    import os
+    import synth_ba
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gold = np.load(os.path.join(root, "tests", "golden", "ba_golden.npz"))
+    g = {k[2:]: gold[k] for k in gold.files if k.startswith("g_")}
+    for k in ("n_poses", "n_points", "n_edges"):
+        g[k] = int(g[k])
+    for k in ("fx", "fy", "cx", "cy", "bf"):
+        g[k] = float(g[k])
+    rc, poses, pts, out, st = obb.solve(g)
+    np.testing.assert_allclose(poses, gold["poses"], atol=1e-9)
+    np.testing.assert_allclose(pts, gold["points"], atol=1e-9)
+    np.testing.assert_array_equal(out, gold["outlier"])
+    assert st["iterations_run"] == gold["iterations_run"].tolist() and st["lm_trials"] == int(gold["lm_trials"])
