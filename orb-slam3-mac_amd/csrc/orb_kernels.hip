@@ -54,43 +54,90 @@ __device__ __forceinline__ int wave_sum(int v)
 // Each thread produces 4 horizontally adjacent output pixels and stores one dword.
 // Coefficient tables are computed on the host in float exactly like OpenCV does.
 // ----------------------------------------------------------------------------------
+#define RS_TW 64              // output tile
+#define RS_TH 32
+#define RS_MAXC 144           // staged source columns (scale factor <= 2: 64*2 + apron, dword aligned)
+#define RS_MAXR 68            // staged source rows
+// Separable inside LDS: (A) stage the source footprint of a 64x32 output tile with aligned dword
+// loads (vertical clamping of cv::resize baked into the staged rows), (B) horizontal pass for every
+// staged row -> (S[sx]*a0 + S[sx+1]*a1) >> 4 as u16 (<= 32640), (C) vertical pass + rounding,
+// 4 pixels per thread, one dword store.  Bit-identical to the scalar formula of Appendix A.3.
 __global__ __launch_bounds__(256) void k_resize(OrbParams P, int level)
 {
+    __shared__ uint32_t in[RS_MAXR * (RS_MAXC / 4)];
+    __shared__ uint16_t hz[RS_MAXR * RS_TW];
     const OrbLevel &D = P.lv[level];
     const OrbLevel &S = P.lv[level - 1];
-    const int frame = blockIdx.z;
-    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int dx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    if (dy >= D.h || dx0 >= D.w) return;
-    const int sy = D.yofs[dy];
-    const int b0 = D.ybeta[2 * dy], b1 = D.ybeta[2 * dy + 1];
-    const int y0 = sy < 0 ? 0 : (sy < S.h ? sy : S.h - 1);
-    const int y1 = sy + 1 < 0 ? 0 : (sy + 1 < S.h ? sy + 1 : S.h - 1);
+    const int tid = threadIdx.x, frame = blockIdx.z;
+    const int dx0 = blockIdx.x * RS_TW, dy0 = blockIdx.y * RS_TH;
+    const int dx_last = min(dx0 + RS_TW, D.w) - 1, dy_last = min(dy0 + RS_TH, D.h) - 1;
+    const int ybase = D.yofs[dy0];                                   // may be -1
+    const int nrows = min(D.yofs[dy_last] + 1 - ybase + 1, RS_MAXR);
+    const int xbase = D.xofs[dx0] & ~3;
+    const int ncd = min((D.xofs[dx_last] + 1 - xbase) / 4 + 1, RS_MAXC / 4);
     const uint8_t *src = S.img + (size_t)frame * S.img_frame_stride;
-    const uint8_t *S0 = src + (size_t)y0 * S.img_pitch;
-    const uint8_t *S1 = src + (size_t)y1 * S.img_pitch;
-    uint32_t packed = 0;
+    // ---- A
+    for (int i = tid; i < nrows * ncd; i += 256) {
+        const int r = i / ncd, cd = i - r * ncd;
+        const int y = min(max(ybase + r, 0), S.h - 1);               // clip(sy, 0, ssize.height)
+        const int x = xbase + 4 * cd;
+        const uint8_t *row = src + (size_t)y * S.img_pitch;
+        uint32_t v;
+        if (x + 3 < S.w) v = *reinterpret_cast<const uint32_t *>(row + x);
+        else {
+            v = 0;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int dx = dx0 + i;
+            for (int j = 0; j < 4; j++) v |= (uint32_t)row[min(x + j, S.w - 1)] << (8 * j);
+        }
+        in[r * (RS_MAXC / 4) + cd] = v;
+    }
+    __syncthreads();
+    // ---- B
+    {
+        const int dxl = tid & 63, dx = dx0 + dxl;
         if (dx < D.w) {
-            const int sx = D.xofs[dx];
-            const int sx1 = sx + 1 < S.w ? sx + 1 : sx;
+            const int sx = D.xofs[dx] - xbase;
             const int a0 = D.xalpha[2 * dx], a1 = D.xalpha[2 * dx + 1];
-            const int t0 = S0[sx] * a0 + S0[sx1] * a1;
-            const int t1 = S1[sx] * a0 + S1[sx1] * a1;
-            const int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
-            packed |= (uint32_t)(v & 255) << (8 * i);
+            const uint8_t *inb = reinterpret_cast<const uint8_t *>(in);
+            for (int r = tid >> 6; r < nrows; r += 4) {
+                const uint8_t *q = inb + r * RS_MAXC + sx;
+                hz[r * RS_TW + dxl] = (uint16_t)((q[0] * a0 + q[1] * a1) >> 4);
+            }
         }
     }
-    uint8_t *dst = D.img + (size_t)frame * D.img_frame_stride + (size_t)dy * D.img_pitch + dx0;
-    *reinterpret_cast<uint32_t *>(dst) = packed;   // pitch is a multiple of 64: pad bytes are scratch
+    __syncthreads();
+    // ---- C
+    {
+        const int c4 = tid & 15, rg = tid >> 4;
+        const int dx = dx0 + 4 * c4;
+        if (dx < D.w) {
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) {
+                const int dy = dy0 + 2 * rg + rr;
+                if (dy < D.h) {
+                    const int r0 = D.yofs[dy] - ybase;
+                    const int b0 = D.ybeta[2 * dy], b1 = D.ybeta[2 * dy + 1];
+                    const uint2 t0 = *reinterpret_cast<const uint2 *>(&hz[r0 * RS_TW + 4 * c4]);
+                    const uint2 t1 = *reinterpret_cast<const uint2 *>(&hz[(r0 + 1) * RS_TW + 4 * c4]);
+                    const int u0[4] = {(int)(t0.x & 0xFFFF), (int)(t0.x >> 16), (int)(t0.y & 0xFFFF), (int)(t0.y >> 16)};
+                    const int u1[4] = {(int)(t1.x & 0xFFFF), (int)(t1.x >> 16), (int)(t1.y & 0xFFFF), (int)(t1.y >> 16)};
+                    uint32_t packed = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int v = (((b0 * u0[j]) >> 16) + ((b1 * u1[j]) >> 16) + 2) >> 2;
+                        packed |= (uint32_t)(v & 255) << (8 * j);
+                    }
+                    *reinterpret_cast<uint32_t *>(D.img + (size_t)frame * D.img_frame_stride + (size_t)dy * D.img_pitch + dx) = packed;
+                }
+            }
+        }
+    }
 }
 
 void orb_launch_resize(const OrbParams &P, int level, hipStream_t s)
 {
     const OrbLevel &D = P.lv[level];
-    dim3 grid((D.w + 255) / 256, (D.h + 3) / 4, P.batch);
+    dim3 grid((D.w + RS_TW - 1) / RS_TW, (D.h + RS_TH - 1) / RS_TH, P.batch);
     hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, P, level);
 }
 
@@ -105,41 +152,62 @@ void orb_launch_resize(const OrbParams &P, int level, hipStream_t s)
 // from it.  One 256-thread workgroup per cell, the cell's (wCell+6)x(hCell+6) sub-image
 // staged in LDS.  Keypoints are emitted in cv::FAST order (row-major) via a block scan.
 // ----------------------------------------------------------------------------------
-#define FAST_TP 64            // LDS tile pitch (bytes); cells up to 64x64 incl. the 6-px apron
-#define FAST_MAX_PPT 16       // pixels per thread upper bound: 58*58/256 < 16
+#define FAST_TP 72            // LDS pitch (bytes): cells up to 64 wide + up to 3 bytes of dword alignment
+typedef short s16x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ int fast_arc_score(const uint8_t *c)
+__device__ __forceinline__ s16x2 as_s16x2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
+__device__ __forceinline__ s16x2 pkmin(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ s16x2 pkmax(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
+
+// Two horizontally adjacent pixels (window byte i and i+1 of a 12-byte row window w0|w1|w2) as
+// packed u16x2, one v_perm_b32.  I is a compile-time constant in [0,10].
+template <int I>
+__device__ __forceinline__ uint32_t pair_at(uint32_t w0, uint32_t w1, uint32_t w2)
 {
-    // Bresenham circle r=3 in cv::makeOffsets order.
-    const int v = c[0];
-    int d[16];
-    d[0] = v - c[3 * FAST_TP + 0];   d[1] = v - c[3 * FAST_TP + 1];
-    d[2] = v - c[2 * FAST_TP + 2];   d[3] = v - c[1 * FAST_TP + 3];
-    d[4] = v - c[3];                 d[5] = v - c[-1 * FAST_TP + 3];
-    d[6] = v - c[-2 * FAST_TP + 2];  d[7] = v - c[-3 * FAST_TP + 1];
-    d[8] = v - c[-3 * FAST_TP + 0];  d[9] = v - c[-3 * FAST_TP - 1];
-    d[10] = v - c[-2 * FAST_TP - 2]; d[11] = v - c[-1 * FAST_TP - 3];
-    d[12] = v - c[-3];               d[13] = v - c[1 * FAST_TP - 3];
-    d[14] = v - c[2 * FAST_TP - 2];  d[15] = v - c[3 * FAST_TP - 1];
-    int lo2[16], hi2[16], lo4[16], hi4[16];
+    if (I <= 6) return __builtin_amdgcn_perm(w1, w0, 0x0c000c00u | (uint32_t)I | ((uint32_t)(I + 1) << 16));
+    return __builtin_amdgcn_perm(w2, w1, 0x0c000c00u | (uint32_t)(I - 4) | ((uint32_t)(I - 3) << 16));
+}
+
+// Arc score of the pixel pair whose left pixel sits at window byte 4+J (J = 0 or 2) of the centre row.
+// rows[r][0..2] = the three dwords of tile row (y-3+r).  Returns packed S (threshold independent).
+// Bresenham circle r=3 in cv::makeOffsets order: (dx,dy) k=0..15 =
+// (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
+template <int J>
+__device__ __forceinline__ bool fast_pair_score(const uint32_t (&rows)[7][3], int th, s16x2 *S_out)
+{
+#define PX(DX, DY) as_s16x2(pair_at<4 + J + (DX)>(rows[3 + (DY)][0], rows[3 + (DY)][1], rows[3 + (DY)][2]))
+    const s16x2 v = PX(0, 0);
+    s16x2 d[16];
+    // compass points first: a 9-arc contains at least one pixel of every diametral pair
+    d[0] = v - PX(0, 3); d[8] = v - PX(0, -3); d[4] = v - PX(3, 0); d[12] = v - PX(-3, 0);
+    d[2] = v - PX(2, 2); d[10] = v - PX(-2, -2); d[6] = v - PX(2, -2); d[14] = v - PX(-2, 2);
+    {
+        const s16x2 dark = pkmin(pkmin(pkmax(d[0], d[8]), pkmax(d[4], d[12])), pkmin(pkmax(d[2], d[10]), pkmax(d[6], d[14])));
+        const s16x2 brig = pkmax(pkmax(pkmin(d[0], d[8]), pkmin(d[4], d[12])), pkmax(pkmin(d[2], d[10]), pkmin(d[6], d[14])));
+        const bool pass = dark.x > th || dark.y > th || brig.x < -th || brig.y < -th;
+        if (!__any(pass)) return false;           // whole wave rejects: S <= th for every lane
+    }
+    d[1] = v - PX(1, 3); d[3] = v - PX(3, 1); d[5] = v - PX(3, -1); d[7] = v - PX(1, -3);
+    d[9] = v - PX(-1, -3); d[11] = v - PX(-3, -1); d[13] = v - PX(-3, 1); d[15] = v - PX(-1, 3);
+#undef PX
+    s16x2 lo2[16], hi2[16], lo4[16], hi4[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) { lo2[i] = min(d[i], d[(i + 1) & 15]); hi2[i] = max(d[i], d[(i + 1) & 15]); }
+    for (int i = 0; i < 16; i++) { lo2[i] = pkmin(d[i], d[(i + 1) & 15]); hi2[i] = pkmax(d[i], d[(i + 1) & 15]); }
 #pragma unroll
-    for (int i = 0; i < 16; i++) { lo4[i] = min(lo2[i], lo2[(i + 2) & 15]); hi4[i] = max(hi2[i], hi2[(i + 2) & 15]); }
-    int A = -256, B = 256;
+    for (int i = 0; i < 16; i++) { lo4[i] = pkmin(lo2[i], lo2[(i + 2) & 15]); hi4[i] = pkmax(hi2[i], hi2[(i + 2) & 15]); }
+    s16x2 A = (s16x2){-256, -256}, B = (s16x2){256, 256};
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        int lo9 = min(min(lo4[i], lo4[(i + 4) & 15]), d[(i + 8) & 15]);
-        int hi9 = max(max(hi4[i], hi4[(i + 4) & 15]), d[(i + 8) & 15]);
-        A = max(A, lo9);
-        B = min(B, hi9);
+        A = pkmax(A, pkmin(pkmin(lo4[i], lo4[(i + 4) & 15]), d[(i + 8) & 15]));
+        B = pkmin(B, pkmax(pkmax(hi4[i], hi4[(i + 4) & 15]), d[(i + 8) & 15]));
     }
-    return max(A, -B);
+    *S_out = pkmax(A, (s16x2){0, 0} - B);
+    return true;
 }
 
 __global__ __launch_bounds__(256) void k_fast_cells(OrbParams P)
 {
-    __shared__ uint8_t tile[64 * FAST_TP];
+    __shared__ uint32_t tile[64 * (FAST_TP / 4)];
     __shared__ uint8_t sc[66 * FAST_TP];      // score map, +1 row apron top/bottom
     __shared__ int wsum[8];
     __shared__ int s_cnt;
@@ -167,24 +235,49 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbParams P)
         if (tid == 0) *cnt_out = 0;
         return;
     }
-    // stage sub-image, clear score map
-    const uint8_t *img = L.img + (size_t)frame * L.img_frame_stride + (size_t)ini_y * L.img_pitch + ini_x;
-    for (int i = tid; i < cw * ch; i += 256) {
-        const int y = i / cw, x = i - y * cw;
-        tile[y * FAST_TP + x] = img[(size_t)y * L.img_pitch + x];
+    // stage the sub-image with aligned dword loads; LDS column lx = image x - xb, xb = ini_x & ~3
+    const int xb = ini_x & ~3, off = ini_x - xb;
+    const int ncd = (cw + off + 3) >> 2;                      // dwords per staged row (<= 17)
+    const uint8_t *img = L.img + (size_t)frame * L.img_frame_stride + (size_t)ini_y * L.img_pitch + xb;
+    for (int i = tid; i < ncd * ch; i += 256) {
+        const int y = i / ncd, cd = i - y * ncd;
+        tile[y * (FAST_TP / 4) + cd] = *reinterpret_cast<const uint32_t *>(img + (size_t)y * L.img_pitch + 4 * cd);
     }
     for (int i = tid; i < 66 * FAST_TP / 4; i += 256) reinterpret_cast<uint32_t *>(sc)[i] = 0;
     if (tid == 0) s_cnt = 0;
     __syncthreads();
-    // score map over the detection band; sc index (y+1, x) so the apron rows exist
-    const int npix = dw * dh;
-    for (int i = tid; i < npix; i += 256) {
-        const int y = 3 + i / dw, x = 3 + i % dw;
-        const int S = fast_arc_score(&tile[y * FAST_TP + x]);
-        sc[(y + 1) * FAST_TP + x] = (uint8_t)(S > P.min_th ? S - 1 : 0);
+    // score map: groups of 4 pixels (lx = 4g .. 4g+3), packed 16-bit arithmetic on pixel pairs
+    const int g0 = (3 + off) >> 2, g1 = (cw - 4 + off) >> 2;  // first / last group touching the band
+    const int ng = g1 - g0 + 1;
+    const int lx_lo = 3 + off, lx_hi = cw - 4 + off;
+    const int ngroups = ng * dh;
+    for (int i0 = 0; i0 < ngroups; i0 += 256) {
+        const int i = i0 + tid;
+        const bool valid = i < ngroups;
+        const int gy = valid ? i / ng : 0, gx = valid ? i - gy * ng : 0;
+        const int y = 3 + gy, g = g0 + gx;
+        uint32_t rows[7][3];
+#pragma unroll
+        for (int r = 0; r < 7; r++) {
+            const uint32_t *q = &tile[(y - 3 + r) * (FAST_TP / 4) + g];
+            rows[r][0] = g > 0 ? q[-1] : 0u; rows[r][1] = q[0]; rows[r][2] = q[1];
+        }
+        s16x2 S01 = (s16x2){0, 0}, S23 = (s16x2){0, 0};
+        const bool h01 = fast_pair_score<0>(rows, P.min_th, &S01);
+        const bool h23 = fast_pair_score<2>(rows, P.min_th, &S23);
+        if (valid && (h01 || h23)) {
+            const int lx = 4 * g;
+            uint32_t out = 0;
+            const int Sv[4] = {S01.x, S01.y, S23.x, S23.y};
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (Sv[j] > P.min_th && lx + j >= lx_lo && lx + j <= lx_hi) out |= (uint32_t)(Sv[j] - 1) << (8 * j);
+            if (out) *reinterpret_cast<uint32_t *>(&sc[(y + 1) * FAST_TP + lx]) = out;
+        }
     }
     __syncthreads();
     // NMS, thread owns a contiguous run of pixels (row-major) -> ordered emission
+    const int npix = dw * dh;
     const int ppt = (npix + 255) / 256;
     const int p0 = tid * ppt;
     uint32_t keep = 0;
@@ -194,7 +287,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbParams P)
         for (int k = 0; k < ppt; k++) {
             const int i = p0 + k;
             if (i < npix) {
-                const int y = 3 + i / dw, x = 3 + i % dw;
+                const int y = 3 + i / dw, x = 3 + i % dw + off;
                 const uint8_t *q = &sc[(y + 1) * FAST_TP + x];
                 // v(th) = score if score >= th (i.e. S > th) else 0
                 const int v = q[0] >= th ? q[0] : 0;
@@ -217,16 +310,16 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbParams P)
         }
     }
     int total;
-    int off = block_excl_scan256(__popc(keep), wsum, &total);
+    int offs = block_excl_scan256(__popc(keep), wsum, &total);
     uint32_t *list = P.cell_list + (size_t)frame * P.cell_list_frame_stride + (size_t)cell * L.cell_cap;
     if (total > L.cell_cap) { if (tid == 0) atomicExch(P.status, ORBHIP_E_CAPACITY); total = L.cell_cap; }
     for (int k = 0; k < ppt; k++) {
         if (keep & (1u << k)) {
             const int i = p0 + k;
             const int y = 3 + i / dw, x = 3 + i % dw;
-            if (off < L.cell_cap)
-                list[off] = ORB_PACK_KEY(x + cj * L.wcell, y + ci * L.hcell, sc[(y + 1) * FAST_TP + x]);
-            off++;
+            if (offs < L.cell_cap)
+                list[offs] = ORB_PACK_KEY(x + cj * L.wcell, y + ci * L.hcell, sc[(y + 1) * FAST_TP + x + off]);
+            offs++;
         }
     }
     if (tid == 0) *cnt_out = (uint32_t)total;
@@ -533,6 +626,7 @@ void orb_launch_octree(const OrbParams &P, hipStream_t s)
 // ----------------------------------------------------------------------------------
 #define BL_TW 64
 #define BL_TH 32
+#define BL_IP 72              // input tile pitch (bytes): 4 left apron + 64 + 4 right apron
 __device__ __forceinline__ int reflect101(int p, int n)
 {
     if (p < 0) p = -p;
@@ -540,43 +634,91 @@ __device__ __forceinline__ int reflect101(int p, int n)
     return p;
 }
 
+// Tile 64x32 outputs per 256-thread workgroup.
+//  A  stage rows y0-3..y0+34, cols x0-4..x0+67 as aligned dwords (byte path only at image borders)
+//  B  row pass: 4 outputs per thread-task from 3 LDS dwords, v_alignbyte_b32 + v_dot4_u32_u8
+//  C  column pass: 4 columns x 2 rows per thread, dword store
 __global__ __launch_bounds__(256) void k_blur(OrbParams P, int level)
 {
-    __shared__ uint8_t in[(BL_TH + 6) * (BL_TW + 8)];
+    __shared__ uint32_t in[(BL_TH + 6) * (BL_IP / 4)];
     __shared__ uint16_t hz[(BL_TH + 6) * BL_TW];
     const OrbLevel &L = P.lv[level];
     const int tid = threadIdx.x, frame = blockIdx.z;
     const int x0 = blockIdx.x * BL_TW, y0 = blockIdx.y * BL_TH;
     const uint8_t *src = L.img + (size_t)frame * L.img_frame_stride;
-    for (int i = tid; i < (BL_TH + 6) * (BL_TW + 6); i += 256) {
-        const int r = i / (BL_TW + 6), c = i - r * (BL_TW + 6);
-        const int y = reflect101(y0 + r - 3, L.h), x = reflect101(x0 + c - 3, L.w);
-        // tiles past the right/bottom edge reflect twice at most for w,h >= 7; clamp defensively
-        const int yy = min(max(y, 0), L.h - 1), xx = min(max(x, 0), L.w - 1);
-        in[r * (BL_TW + 8) + c] = src[(size_t)yy * L.img_pitch + xx];
-    }
-    __syncthreads();
-    const int k0 = P.gauss_q8[0], k1 = P.gauss_q8[1], k2 = P.gauss_q8[2], k3 = P.gauss_q8[3];
-    for (int i = tid; i < (BL_TH + 6) * BL_TW; i += 256) {
-        const int r = i / BL_TW, c = i - r * BL_TW;
-        const uint8_t *q = &in[r * (BL_TW + 8) + c];
-        hz[i] = (uint16_t)(k0 * (q[0] + q[6]) + k1 * (q[1] + q[5]) + k2 * (q[2] + q[4]) + k3 * q[3]);
-    }
-    __syncthreads();
-    uint8_t *dst = L.blur + (size_t)frame * L.blur_frame_stride;
-    for (int i = tid; i < BL_TH * BL_TW / 4; i += 256) {
-        const int r = i / (BL_TW / 4), c4 = (i - r * (BL_TW / 4)) * 4;
-        const int y = y0 + r, x = x0 + c4;
-        if (y >= L.h || x >= L.w) continue;
-        uint32_t packed = 0;
+    const int w = L.w, h = L.h;
+    // ---- A
+    for (int i = tid; i < (BL_TH + 6) * (BL_IP / 4); i += 256) {
+        const int r = i / (BL_IP / 4), cd = i - r * (BL_IP / 4);
+        int y = reflect101(y0 + r - 3, h);
+        y = min(max(y, 0), h - 1);
+        const int x = x0 - 4 + 4 * cd;
+        const uint8_t *row = src + (size_t)y * L.img_pitch;
+        uint32_t v;
+        if (x >= 0 && x + 3 < w) v = *reinterpret_cast<const uint32_t *>(row + x);      // pitch%64==0, x%4==0
+        else {
+            v = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint16_t *q = &hz[r * BL_TW + c4 + j];
-            int s = k0 * (q[0] + q[6 * BL_TW]) + k1 * (q[BL_TW] + q[5 * BL_TW]) + k2 * (q[2 * BL_TW] + q[4 * BL_TW]) + k3 * q[3 * BL_TW];
-            s = (s + 32768) >> 16;
-            packed |= (uint32_t)min(s, 255) << (8 * j);
+            for (int j = 0; j < 4; j++) {
+                int xx = reflect101(x + j, w);
+                xx = min(max(xx, 0), w - 1);
+                v |= (uint32_t)row[xx] << (8 * j);
+            }
         }
-        *reinterpret_cast<uint32_t *>(dst + (size_t)y * L.blur_pitch + x) = packed;   // pitch % 64 == 0
+        in[i] = v;
+    }
+    __syncthreads();
+    // ---- B: q8 kernel {k0,k1,k2,k3,k2,k1,k0} packed for v_dot4_u32_u8
+    const uint32_t klo = (uint32_t)P.gauss_q8[0] | ((uint32_t)P.gauss_q8[1] << 8) | ((uint32_t)P.gauss_q8[2] << 16) | ((uint32_t)P.gauss_q8[3] << 24);
+    const uint32_t khi = (uint32_t)P.gauss_q8[4] | ((uint32_t)P.gauss_q8[5] << 8) | ((uint32_t)P.gauss_q8[6] << 16);
+    for (int i = tid; i < (BL_TH + 6) * (BL_TW / 4); i += 256) {
+        const int r = i / (BL_TW / 4), c4 = i - r * (BL_TW / 4);
+        // outputs c..c+3 (c = 4*c4) read input bytes c+1 .. c+10 of the tile row (tile col = out col + 4)
+        const uint32_t *q = &in[r * (BL_IP / 4) + c4];
+        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+        uint32_t o[4];
+        // output j: bytes (c+1+j .. c+4+j) . klo + bytes (c+5+j .. c+7+j) . khi
+        o[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), klo, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), khi, 0u, false), false);
+        o[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), klo, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), khi, 0u, false), false);
+        o[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), klo, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), khi, 0u, false), false);
+        o[3] = __builtin_amdgcn_udot4(d1, klo, __builtin_amdgcn_udot4(d2, khi, 0u, false), false);
+        uint2 pk;
+        pk.x = o[0] | (o[1] << 16);
+        pk.y = o[2] | (o[3] << 16);
+        *reinterpret_cast<uint2 *>(&hz[r * BL_TW + 4 * c4]) = pk;
+    }
+    __syncthreads();
+    // ---- C
+    const int k0 = P.gauss_q8[0], k1 = P.gauss_q8[1], k2 = P.gauss_q8[2], k3 = P.gauss_q8[3];
+    uint8_t *dst = L.blur + (size_t)frame * L.blur_frame_stride;
+    {
+        const int c4 = tid & 15, rg = tid >> 4;          // 16 column groups x 16 row groups (2 rows each)
+        const int x = x0 + 4 * c4;
+        if (x < w) {
+            uint2 rows[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) rows[k] = *reinterpret_cast<const uint2 *>(&hz[(2 * rg + k) * BL_TW + 4 * c4]);
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) {
+                const int y = y0 + 2 * rg + rr;
+                if (y < h) {
+                    uint32_t packed = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        int v[7];
+#pragma unroll
+                        for (int k = 0; k < 7; k++) {
+                            const uint32_t wv = (j < 2) ? rows[rr + k].x : rows[rr + k].y;
+                            v[k] = (j & 1) ? (int)(wv >> 16) : (int)(wv & 0xFFFF);
+                        }
+                        int sacc = k0 * (v[0] + v[6]) + k1 * (v[1] + v[5]) + k2 * (v[2] + v[4]) + k3 * v[3];
+                        sacc = (sacc + 32768) >> 16;
+                        packed |= (uint32_t)min(sacc, 255) << (8 * j);
+                    }
+                    *reinterpret_cast<uint32_t *>(dst + (size_t)y * L.blur_pitch + x) = packed;   // pitch % 64 == 0
+                }
+            }
+        }
     }
 }
 
@@ -649,68 +791,83 @@ __device__ __forceinline__ void sincos_det(double x, double *s_out, double *c_ou
     }
 }
 
+// Persistent waves: each wave walks the (frame, staging slot) space with a grid stride, keeping its
+// 4 rBRIEF test pairs and its circular-patch row mask in registers (no LDS, no barriers).
 __global__ __launch_bounds__(256) void k_orient_desc(OrbParams P)
 {
-    __shared__ int8_t pat[1024];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    reinterpret_cast<uint32_t *>(pat)[tid] = reinterpret_cast<const uint32_t *>(c_pattern)[tid];
-    __syncthreads();
-    const int frame = blockIdx.y;
-    const int slot = blockIdx.x * 4 + wid;
-    if (slot >= P.kps_per_frame) return;
-    int lvl = 0;
-    for (int l = 1; l < P.nlevels; l++) if (slot >= P.lv[l].kp_base) lvl = l;
-    const OrbLevel &L = P.lv[lvl];
-    const int idx = slot - L.kp_base;
-    if (idx >= P.lvl_count[frame * P.nlevels + lvl]) return;
-    const uint32_t key = P.lvl_kp[(size_t)frame * P.kps_per_frame + slot];
-    const int x = ORB_KEY_X(key) + ORB_MINB, y = ORB_KEY_Y(key) + ORB_MINB;     // ORBextractor.cc:868-869
-    // ---- IC_Angle
-    const uint8_t *c = L.img + (size_t)frame * L.img_frame_stride + (size_t)y * L.img_pitch + x;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
+    // lane-constant state
+    float px0[4], py0[4], px1[4], py1[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int8_t *pp = &c_pattern[4 * (lane + 64 * j)];
+        px0[j] = (float)pp[0]; py0[j] = (float)pp[1]; px1[j] = (float)pp[2]; py1[j] = (float)pp[3];
+    }
     const int half = lane >> 5, u = (lane & 31) - ORB_HALF_PATCH;
-    int m10 = 0, m01 = 0;
-#pragma unroll 4
+    uint32_t rowmask = 0;                       // bit it: this lane contributes in step it of IC_Angle
     for (int it = 0; it < 16; it++) {
-        const int v = it - ORB_HALF_PATCH + half * 16;       // half0: -15..0, half1: 1..16
+        const int v = it - ORB_HALF_PATCH + half * 16;
         const int av = v < 0 ? -v : v;
         if (av <= ORB_HALF_PATCH && (lane & 31) < 31) {
             const int d = P.umax[av];
-            if (u >= -d && u <= d) {
+            if (u >= -d && u <= d) rowmask |= 1u << it;
+        }
+    }
+    const float factor_pi = (float)(3.1415926535897932384626433832795 / 180.f);
+    const long total = (long)P.batch * P.kps_per_frame;
+    for (long gs = wave; gs < total; gs += nwaves) {
+        const int frame = (int)(gs / P.kps_per_frame);
+        const int slot = (int)(gs - (long)frame * P.kps_per_frame);
+        int lvl = 0;
+        for (int l = 1; l < P.nlevels; l++) if (slot >= P.lv[l].kp_base) lvl = l;
+        const OrbLevel &L = P.lv[lvl];
+        const int idx = slot - L.kp_base;
+        if (idx >= P.lvl_count[frame * P.nlevels + lvl]) continue;
+        const uint32_t key = P.lvl_kp[(size_t)frame * P.kps_per_frame + slot];
+        const int x = ORB_KEY_X(key) + ORB_MINB, y = ORB_KEY_Y(key) + ORB_MINB;     // ORBextractor.cc:868-869
+        // ---- IC_Angle (ORBextractor.cc:75-102): two patch rows per step (lanes 0-30 / 32-62)
+        const uint8_t *c = L.img + (size_t)frame * L.img_frame_stride + (size_t)y * L.img_pitch + x;
+        int m10 = 0, m01 = 0;
+#pragma unroll
+        for (int it = 0; it < 16; it++) {
+            if (rowmask & (1u << it)) {
+                const int v = it - ORB_HALF_PATCH + half * 16;
                 const int val = c[v * L.img_pitch + u];
                 m10 += u * val;
                 m01 += v * val;
             }
         }
-    }
-    m10 = wave_sum(m10);
-    m01 = wave_sum(m01);
-    const float angle = fast_atan2_deg((float)m01, (float)m10);
-    // ---- steered BRIEF on the blurred level
-    const float factor_pi = (float)(3.1415926535897932384626433832795 / 180.f);
-    double sd, cd;
-    sincos_det((double)__fmul_rn(angle, factor_pi), &sd, &cd);
-    const float a = (float)cd, b = (float)sd;
-    const uint8_t *bc = L.blur + (size_t)frame * L.blur_frame_stride + (size_t)y * L.blur_pitch + x;
-    uint8_t *desc = P.lvl_desc + ((size_t)frame * P.kps_per_frame + slot) * 32;
+        m10 = wave_sum(m10);
+        m01 = wave_sum(m01);
+        const float angle = fast_atan2_deg((float)m01, (float)m10);
+        // ---- steered BRIEF on the blurred level (ORBextractor.cc:106-145)
+        double sd, cd;
+        sincos_det((double)__fmul_rn(angle, factor_pi), &sd, &cd);
+        const float a = (float)cd, b = (float)sd;
+        const uint8_t *bc = L.blur + (size_t)frame * L.blur_frame_stride + (size_t)y * L.blur_pitch + x;
+        uint8_t *desc = P.lvl_desc + ((size_t)frame * P.kps_per_frame + slot) * 32;
+        unsigned long long m[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int8_t *pp = &pat[4 * (lane + 64 * j)];
-        const float px0 = (float)pp[0], py0 = (float)pp[1], px1 = (float)pp[2], py1 = (float)pp[3];
-        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(px0, b), __fmul_rn(py0, a)));
-        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(px0, a), __fmul_rn(py0, b)));
-        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1, b), __fmul_rn(py1, a)));
-        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(px1, a), __fmul_rn(py1, b)));
-        const int t0 = bc[r0 * L.blur_pitch + c0], t1 = bc[r1 * L.blur_pitch + c1];
-        const unsigned long long m = __ballot(t0 < t1);
-        if (lane == 0) reinterpret_cast<unsigned long long *>(desc)[j] = m;
+        for (int j = 0; j < 4; j++) {
+            const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(px0[j], b), __fmul_rn(py0[j], a)));
+            const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(px0[j], a), __fmul_rn(py0[j], b)));
+            const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1[j], b), __fmul_rn(py1[j], a)));
+            const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(px1[j], a), __fmul_rn(py1[j], b)));
+            const int t0 = bc[r0 * L.blur_pitch + c0], t1 = bc[r1 * L.blur_pitch + c1];
+            m[j] = __ballot(t0 < t1);
+        }
+        if (lane < 4) reinterpret_cast<unsigned long long *>(desc)[lane] = lane == 0 ? m[0] : lane == 1 ? m[1] : lane == 2 ? m[2] : m[3];
+        if (lane == 0) P.lvl_angle[(size_t)frame * P.kps_per_frame + slot] = angle;
     }
-    if (lane == 0) P.lvl_angle[(size_t)frame * P.kps_per_frame + slot] = angle;
 }
 
 void orb_launch_orient_desc(const OrbParams &P, hipStream_t s)
 {
-    dim3 grid((P.kps_per_frame + 3) / 4, P.batch);
-    hipLaunchKernelGGL(k_orient_desc, grid, dim3(256), 0, s, P);
+    const long total = (long)P.batch * P.kps_per_frame;
+    long blocks = (total + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;           // 8 blocks (32 waves) per CU, grid-stride beyond
+    hipLaunchKernelGGL(k_orient_desc, dim3((unsigned)blocks), dim3(256), 0, s, P);
 }
 
 // ----------------------------------------------------------------------------------

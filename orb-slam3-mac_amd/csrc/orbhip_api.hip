@@ -116,8 +116,8 @@ struct orbhip_extractor {
 extern "C" int orbhip_extractor_create(orbhip_ctx *ctx, int nfeatures, float scale_factor, int nlevels,
                                        int ini_th, int min_th, orbhip_extractor **out)
 {
-    if (!ctx || !out || nlevels < 1 || nlevels > ORB_MAX_LEVELS || nfeatures < 1 || !(scale_factor > 1.0f))
-        return ORBHIP_E_BADARG;
+    if (!ctx || !out || nlevels < 1 || nlevels > ORB_MAX_LEVELS || nfeatures < 1 || !(scale_factor > 1.0f) || scale_factor > 2.0f)
+        return ORBHIP_E_BADARG;     // k_resize stages the footprint of a 64x32 tile in LDS: scale factors up to 2
     orbhip_extractor *e = new orbhip_extractor();
     e->ctx = ctx; e->nfeatures = nfeatures; e->nlevels = nlevels; e->ini_th = ini_th; e->min_th = min_th;
     e->scale_factor = scale_factor;
