@@ -147,7 +147,8 @@ int orbhip_match_bf2nn_device(orbhip_ctx *ctx, const uint8_t *d_descA, const int
  * outputs (row capacity max_n).  d_prev_matched[pairs][max_n][2] (float x,y) is in/out
  * (vbPrevMatched); d_matches12[pairs][max_n] out; d_nmatches[pairs] out (return value).
  * Grid bounds = image bounds (mnMinX..mnMaxX of a distortion-free camera).  At most 2048
- * keypoints per frame (else the context's status word is set: orbhip_ctx_check_status). */
+ * keypoints and 1024 octave-0 keypoints per frame (else the context's status word is set:
+ * orbhip_ctx_check_status). */
 int orbhip_search_for_initialization_device(orbhip_ctx *ctx,
         const orbhip_keypoint *d_kpA, const uint8_t *d_descA, const int32_t *d_nA,
         const orbhip_keypoint *d_kpB, const uint8_t *d_descB, const int32_t *d_nB,

@@ -95,25 +95,38 @@ extern "C" int orbhip_match_bf2nn_device(orbhip_ctx *ctx, const uint8_t *d_descA
 // (dist << 23 | visit order) keys and the wave reduces them.
 #define SI_COLS 64            // FRAME_GRID_COLS (include/Frame.h:38)
 #define SI_ROWS 48            // FRAME_GRID_ROWS (include/Frame.h:39)
-#define SI_MAXN 2048
+#define SI_MAXN 2048          // keypoints per frame
+#define SI_CAP0 1024          // octave-0 keypoints per frame held in LDS
 #define SI_TH_LOW 50          // ORBmatcher::TH_LOW  (ORBmatcher.cc:41)
 #define SI_HISTO 30           // ORBmatcher::HISTO_LENGTH (ORBmatcher.cc:42)
 
+// Only octave-0 keypoints take part (F1: ORBmatcher.cc:726-728; F2: GetFeaturesInArea(...,level1,level1)
+// with level1 == 0), so both frames are first compacted to their octave-0 subsets in LDS.  The grid
+// (Frame.cc:377-408) is kept implicitly: each F2 entry carries its cell (round(), Frame.cc:718-719) and
+// its rank inside the cell; a keypoint that passes the |dx|<r,|dy|<r test always lies inside the
+// floor/ceil cell range of Frame.cc:656-674 (round(a) is within [floor(b), ceil(c)] for b < a < c), so
+// scanning the subset and ordering candidates by (cell visit index, rank) reproduces
+// GetFeaturesInArea's list exactly.  The F1 loop stays sequential (vMatchedDistance, ORBmatcher.cc:749);
+// per F1 point the lanes first collect candidates (LDS only), then evaluate one candidate per lane
+// so all descriptor loads are in flight together.
 __global__ __launch_bounds__(64) void k_search_init(const orbhip_keypoint *kpA_, const uint8_t *descA_, const int32_t *nA,
                                                     const orbhip_keypoint *kpB_, const uint8_t *descB_, const int32_t *nB,
                                                     int max_n, size_t kp_stride, float min_x, float min_y, float max_x, float max_y,
                                                     int window, float nn_ratio, int check_ori,
                                                     float *prev_, int32_t *m12_, int32_t *nmatches_, int32_t *status)
 {
-    __shared__ uint16_t cell_of[SI_MAXN];
-    __shared__ uint16_t items[SI_MAXN];
-    __shared__ int cell_start[SI_COLS * SI_ROWS + 1];
-    __shared__ int matched_dist[SI_MAXN];
-    __shared__ int16_t m21[SI_MAXN];
+    __shared__ float kx[SI_CAP0], ky[SI_CAP0];
+    __shared__ uint16_t cellx[SI_CAP0], celly[SI_CAP0], cpos[SI_CAP0], gidx[SI_CAP0];
+    __shared__ int matched_dist[SI_CAP0];
+    __shared__ int16_t m21[SI_CAP0];
+    __shared__ uint16_t aidx[SI_CAP0];
+    __shared__ uint16_t cand_li[SI_CAP0];
+    __shared__ uint32_t cand_key[SI_CAP0];
     __shared__ int8_t bin_of[SI_MAXN];
     __shared__ int hist[SI_HISTO];
     __shared__ int s_keep[3];
     const int pair = blockIdx.x, lane = threadIdx.x;
+    const unsigned long long lt_mask = (1ull << lane) - 1;
     const int n1 = nA[pair], n2 = nB[pair];
     const orbhip_keypoint *kpA = kpA_ + (size_t)pair * kp_stride, *kpB = kpB_ + (size_t)pair * kp_stride;
     const uint4 *dA = reinterpret_cast<const uint4 *>(descA_ + (size_t)pair * kp_stride * 32);
@@ -123,48 +136,55 @@ __global__ __launch_bounds__(64) void k_search_init(const orbhip_keypoint *kpA_,
     if (n1 > SI_MAXN || n2 > SI_MAXN) { if (lane == 0) { atomicExch(status, ORBHIP_E_CAPACITY); nmatches_[pair] = 0; } return; }
     const float inv_w = __fdiv_rn((float)SI_COLS, __fsub_rn(max_x, min_x));       // Frame.cc:334-335
     const float inv_h = __fdiv_rn((float)SI_ROWS, __fsub_rn(max_y, min_y));
-    const int NC = SI_COLS * SI_ROWS;
-    // ---- AssignFeaturesToGrid: cell = posX*ROWS + posY (mGrid[posX][posY]), insertion order kept
-    for (int c = lane; c <= NC; c += 64) cell_start[c] = 0;
     for (int i = lane; i < SI_HISTO; i += 64) hist[i] = 0;
-    __syncthreads();
-    for (int i = lane; i < n2; i += 64) {
-        const int px = (int)roundf(__fmul_rn(__fsub_rn(kpB[i].x, min_x), inv_w));     // round(), Frame.cc:718-719
-        const int py = (int)roundf(__fmul_rn(__fsub_rn(kpB[i].y, min_y), inv_h));
-        int c = 0xFFFF;
-        if (px >= 0 && px < SI_COLS && py >= 0 && py < SI_ROWS) { c = px * SI_ROWS + py; atomicAdd(&cell_start[c + 1], 1); }
-        cell_of[i] = (uint16_t)c;
-        matched_dist[i] = INT_MAX;
-        m21[i] = -1;
+    // ---- octave-0 subset of F2 that PosInGrid accepts, index order kept (= insertion order of the grid)
+    int n0 = 0;
+    for (int i0 = 0; i0 < n2; i0 += 64) {
+        const int i = i0 + lane;
+        bool in = false; int px = 0, py = 0; float fx = 0, fy = 0;
+        if (i < n2) {
+            const orbhip_keypoint k = kpB[i];
+            fx = k.x; fy = k.y;
+            px = (int)roundf(__fmul_rn(__fsub_rn(fx, min_x), inv_w));             // round(), Frame.cc:718-719
+            py = (int)roundf(__fmul_rn(__fsub_rn(fy, min_y), inv_h));
+            in = k.octave == 0 && px >= 0 && px < SI_COLS && py >= 0 && py < SI_ROWS;
+        }
+        const unsigned long long bal = __ballot(in);
+        const int li = n0 + __popcll(bal & lt_mask);
+        if (in && li < SI_CAP0) {
+            kx[li] = fx; ky[li] = fy; cellx[li] = (uint16_t)px; celly[li] = (uint16_t)py; gidx[li] = (uint16_t)i;
+            matched_dist[li] = INT_MAX; m21[li] = -1;
+        }
+        n0 += __popcll(bal);
     }
-    for (int i = lane; i < n1; i += 64) { m12[i] = -1; bin_of[i] = -1; }
-    __syncthreads();
-    {   // exclusive scan over the cells: 48 cells per lane, then a wave scan
-        const int per = NC / 64;
-        int s = 0;
-        for (int k = 0; k < per; k++) s += cell_start[1 + lane * per + k];
-        int inc = s;
-        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
-        int run = inc - s;
-        for (int k = 0; k < per; k++) { const int c = cell_start[1 + lane * per + k]; cell_start[1 + lane * per + k] = run + c; run += c; }
+    // ---- octave-0 subset of F1 (ORBmatcher.cc:726-728)
+    int na0 = 0;
+    for (int i0 = 0; i0 < n1; i0 += 64) {
+        const int i = i0 + lane;
+        const bool in = i < n1 && kpA[i].octave == 0;
+        const unsigned long long bal = __ballot(in);
+        const int li = na0 + __popcll(bal & lt_mask);
+        if (in && li < SI_CAP0) aidx[li] = (uint16_t)i;
+        na0 += __popcll(bal);
+        if (i < n1) { m12[i] = -1; bin_of[i] = -1; }
     }
+    if (n0 > SI_CAP0 || na0 > SI_CAP0) { if (lane == 0) { atomicExch(status, ORBHIP_E_CAPACITY); nmatches_[pair] = 0; } return; }
     __syncthreads();
-    for (int i = lane; i < n2; i += 64) {
-        const int c = cell_of[i];
-        if (c == 0xFFFF) continue;
+    for (int li = lane; li < n0; li += 64) {                                    // rank inside the grid cell
+        const int cx = cellx[li], cy = celly[li];
         int rank = 0;
-        for (int j = 0; j < i; j++) rank += (cell_of[j] == c);
-        items[cell_start[c] + rank] = (uint16_t)i;
+        for (int j = 0; j < li; j++) rank += (cellx[j] == cx && celly[j] == cy);
+        cpos[li] = (uint16_t)rank;
     }
     __syncthreads();
     // ---- sequential F1 loop
     int nmatches = 0;
     const float r = (float)window;
     const float factor = 1.0f / SI_HISTO;
-    for (int i1 = 0; i1 < n1; i1++) {
-        if (kpA[i1].octave > 0) continue;                                   // ORBmatcher.cc:726-728
+    for (int t = 0; t < na0; t++) {
+        const int i1 = aidx[t];
         const float x = prev[2 * i1], y = prev[2 * i1 + 1];
-        int c0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, min_x), r), inv_w)); if (c0 < 0) c0 = 0;
+        int c0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, min_x), r), inv_w)); if (c0 < 0) c0 = 0;   // Frame.cc:656-674
         if (c0 >= SI_COLS) continue;
         int c1 = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, min_x), r), inv_w)); if (c1 > SI_COLS - 1) c1 = SI_COLS - 1;
         if (c1 < 0) continue;
@@ -172,26 +192,40 @@ __global__ __launch_bounds__(64) void k_search_init(const orbhip_keypoint *kpA_,
         if (r0 >= SI_ROWS) continue;
         int r1 = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, min_y), r), inv_h)); if (r1 > SI_ROWS - 1) r1 = SI_ROWS - 1;
         if (r1 < 0) continue;
-        const int ncy = r1 - r0 + 1, wc = (c1 - c0 + 1) * ncy;
+        const int ncy = r1 - r0 + 1;
+        // phase A: collect candidates (GetFeaturesInArea's result set, any order, with their visit-order key)
+        int ncand = 0;
+        for (int l0 = 0; l0 < n0; l0 += 64) {
+            const int li = l0 + lane;
+            bool c = false; uint32_t key = 0;
+            if (li < n0) {
+                const int cx = cellx[li], cy = celly[li];
+                c = cx >= c0 && cx <= c1 && cy >= r0 && cy <= r1 &&
+                    fabsf(__fsub_rn(kx[li], x)) < r && fabsf(__fsub_rn(ky[li], y)) < r;
+                key = (uint32_t)(((cx - c0) * ncy + (cy - r0)) * 2048 + cpos[li]);
+            }
+            const unsigned long long bal = __ballot(c);
+            if (c) { const int o = ncand + __popcll(bal & lt_mask); cand_li[o] = (uint16_t)li; cand_key[o] = key; }
+            ncand += __popcll(bal);
+        }
+        if (ncand == 0) continue;                                           // vIndices2.empty(), ORBmatcher.cc:732-733
+        __syncthreads();
+        // phase B: one candidate per lane
         const uint4 a0 = dA[2 * i1], a1 = dA[2 * i1 + 1];
-        uint32_t lk1 = 0xFFFFFFFFu; int d2 = INT_MAX, best_i2 = -1, any = 0;
-        for (int v = lane; v < wc; v += 64) {
-            const int ix = c0 + v / ncy, iy = r0 + v % ncy;
-            const int c = ix * SI_ROWS + iy;
-            for (int j = cell_start[c]; j < cell_start[c + 1]; j++) {
-                const int i2 = items[j];
-                const orbhip_keypoint kb = kpB[i2];
-                if (kb.octave != 0) continue;                               // minLevel = maxLevel = 0, Frame.cc:695-702
-                if (!(fabsf(__fsub_rn(kb.x, x)) < r && fabsf(__fsub_rn(kb.y, y)) < r)) continue;
-                any = 1;
+        uint32_t lk1 = 0xFFFFFFFFu; int d2 = INT_MAX, best_li = -1;
+        for (int q0 = 0; q0 < ncand; q0 += 64) {
+            const int q = q0 + lane;
+            if (q < ncand) {
+                const int li = cand_li[q];
+                const int i2 = gidx[li];
                 const int dist = hamming256(a0, a1, dB[2 * i2], dB[2 * i2 + 1]);
-                if (matched_dist[i2] <= dist) continue;                     // ORBmatcher.cc:749
-                const uint32_t key = ((uint32_t)dist << 23) | (uint32_t)(v * 2048 + (j - cell_start[c]));
-                if (key < lk1) { if (lk1 != 0xFFFFFFFFu) d2 = min(d2, (int)(lk1 >> 23)); lk1 = key; best_i2 = i2; }
-                else d2 = min(d2, dist);
+                if (!(matched_dist[li] <= dist)) {                          // ORBmatcher.cc:749
+                    const uint32_t key = ((uint32_t)dist << 23) | cand_key[q];
+                    if (key < lk1) { if (lk1 != 0xFFFFFFFFu) d2 = min(d2, (int)(lk1 >> 23)); lk1 = key; best_li = li; }
+                    else d2 = min(d2, dist);
+                }
             }
         }
-        if (!__any(any)) continue;                                          // vIndices2.empty(), ORBmatcher.cc:732-733
         uint32_t k1 = lk1;
         for (int d = 32; d >= 1; d >>= 1) {
             const uint32_t ok1 = __shfl_xor(k1, d, 64);
@@ -200,15 +234,17 @@ __global__ __launch_bounds__(64) void k_search_init(const orbhip_keypoint *kpA_,
             d2 = min(min(d2, od2), lose == 0xFFFFFFFFu ? INT_MAX : (int)(lose >> 23));
             k1 = min(k1, ok1);
         }
+        __syncthreads();                                                    // cand_* reused by the next F1 point
         if (k1 == 0xFFFFFFFFu) continue;                                    // bestDist stays INT_MAX > TH_LOW
         const int best = (int)(k1 >> 23);
         if (!(best <= SI_TH_LOW && (float)best < __fmul_rn((float)d2, nn_ratio))) continue;   // ORBmatcher.cc:764-766
         const unsigned long long owner = __ballot(lk1 == k1);              // keys are unique: exactly one lane
-        const int best_idx = __shfl(best_i2, __ffsll((long long)owner) - 1, 64);
+        const int bli = __shfl(best_li, __ffsll((long long)owner) - 1, 64);
         if (lane == 0) {
-            const int old = m21[best_idx];
+            const int best_idx = gidx[bli];
+            const int old = m21[bli];
             if (old >= 0) { m12[old] = -1; nmatches--; }                    // ORBmatcher.cc:768-772
-            m12[i1] = best_idx; m21[best_idx] = (int16_t)i1; matched_dist[best_idx] = best; nmatches++;
+            m12[i1] = best_idx; m21[bli] = (int16_t)i1; matched_dist[bli] = best; nmatches++;
             if (check_ori) {                                                // ORBmatcher.cc:778-789
                 float rot = __fsub_rn(kpA[i1].angle, kpB[best_idx].angle);
                 if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);

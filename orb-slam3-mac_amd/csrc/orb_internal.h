@@ -13,6 +13,8 @@
 struct OrbLevel {
     uint8_t *img;             // un-padded level image (level 0 may alias the caller's input)
     uint8_t *blur;            // 7x7 sigma-2 blurred level
+    uint8_t *score;           // FAST score map (S-1 where S > minThFAST, else 0)
+    size_t score_frame_stride; int score_pitch;
     size_t img_frame_stride;
     size_t blur_frame_stride;
     int w, h, img_pitch, blur_pitch;

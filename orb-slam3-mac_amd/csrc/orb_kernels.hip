@@ -172,7 +172,7 @@ __device__ __forceinline__ uint32_t pair_at(uint32_t w0, uint32_t w1, uint32_t w
 // rows[r][0..2] = the three dwords of tile row (y-3+r).  Returns packed S (threshold independent).
 // Bresenham circle r=3 in cv::makeOffsets order: (dx,dy) k=0..15 =
 // (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
-template <int J>
+template <int J, bool REJECT = false>
 __device__ __forceinline__ bool fast_pair_score(const uint32_t (&rows)[7][3], int th, s16x2 *S_out)
 {
 #define PX(DX, DY) as_s16x2(pair_at<4 + J + (DX)>(rows[3 + (DY)][0], rows[3 + (DY)][1], rows[3 + (DY)][2]))
@@ -181,7 +181,7 @@ __device__ __forceinline__ bool fast_pair_score(const uint32_t (&rows)[7][3], in
     // compass points first: a 9-arc contains at least one pixel of every diametral pair
     d[0] = v - PX(0, 3); d[8] = v - PX(0, -3); d[4] = v - PX(3, 0); d[12] = v - PX(-3, 0);
     d[2] = v - PX(2, 2); d[10] = v - PX(-2, -2); d[6] = v - PX(2, -2); d[14] = v - PX(-2, 2);
-    {
+    if (REJECT) {
         const s16x2 dark = pkmin(pkmin(pkmax(d[0], d[8]), pkmax(d[4], d[12])), pkmin(pkmax(d[2], d[10]), pkmax(d[6], d[14])));
         const s16x2 brig = pkmax(pkmax(pkmin(d[0], d[8]), pkmin(d[4], d[12])), pkmax(pkmin(d[2], d[10]), pkmin(d[6], d[14])));
         const bool pass = dark.x > th || dark.y > th || brig.x < -th || brig.y < -th;
@@ -205,15 +205,130 @@ __device__ __forceinline__ bool fast_pair_score(const uint32_t (&rows)[7][3], in
     return true;
 }
 
+// Pass 1: threshold-independent score map of a whole level (regular stencil, no cell structure).
+// score = S-1 where S > minThFAST, else 0.  Tile 64x32 per 256-thread workgroup staged with aligned
+// dword loads.  Two phases, because only ~10 % of the pixels survive the cheap necessary test
+// ("a 9-arc contains one pixel of every diametral pair", 4 compass pairs) but almost every wave
+// holds a survivor:  (1) every pixel pair runs the compass test, survivors are compacted into an
+// LDS queue;  (2) queue entries are scored densely, one pair per lane.  Scores land in an LDS tile
+// that is written out with coalesced dword stores.
+#define FS_TW 64
+#define FS_TH 32
+#define FS_IP 72
+// window of pair `pc` (pixels 2pc, 2pc+1 of the tile row): dwords m..m+2 of the staged row, realigned
+// so that the left pixel always sits at window byte 4 (v_alignbit_b32 by 0 or 16 bits).
+__device__ __forceinline__ void fs_window(const uint32_t *in, int row, int pc, uint32_t (&rows)[7][3])
+{
+    const int m = pc >> 1;
+    const uint32_t sh = (pc & 1) * 16;
+#pragma unroll
+    for (int r = 0; r < 7; r++) {
+        const uint32_t *q = &in[(row + r) * (FS_IP / 4) + m];
+        const uint32_t w0 = q[0], w1 = q[1], w2 = q[2];
+        rows[r][0] = __builtin_amdgcn_alignbit(w1, w0, sh);
+        rows[r][1] = __builtin_amdgcn_alignbit(w2, w1, sh);
+        rows[r][2] = w2 >> sh;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fast_score(OrbParams P, int level)
+{
+    __shared__ uint32_t in[(FS_TH + 6) * (FS_IP / 4)];
+    __shared__ uint32_t outt[FS_TH * FS_TW / 4];
+    __shared__ uint16_t queue[FS_TH * FS_TW / 2];
+    __shared__ int qn;
+    const OrbLevel &L = P.lv[level];
+    const int tid = threadIdx.x, lane = tid & 63, frame = blockIdx.z;
+    const int x0 = blockIdx.x * FS_TW, y0 = blockIdx.y * FS_TH;
+    const uint8_t *src = L.img + (size_t)frame * L.img_frame_stride;
+    const int w = L.w, h = L.h, th = P.min_th;
+    for (int i = tid; i < (FS_TH + 6) * (FS_IP / 4); i += 256) {
+        const int r = i / (FS_IP / 4), cd = i - r * (FS_IP / 4);
+        const int y = min(max(y0 + r - 3, 0), h - 1);
+        const int x = x0 - 4 + 4 * cd;
+        uint32_t v = 0;
+        if (x >= 0 && x + 3 < w) v = *reinterpret_cast<const uint32_t *>(src + (size_t)y * L.img_pitch + x);
+        else if (x + 3 >= 0 && x < w) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) v |= (uint32_t)src[(size_t)y * L.img_pitch + min(max(x + j, 0), w - 1)] << (8 * j);
+        }
+        in[i] = v;
+    }
+    outt[tid] = 0; outt[tid + 256] = 0;
+    if (tid == 0) qn = 0;
+    __syncthreads();
+    // ---- phase 1: compass test on 4 pairs per thread (pairs p = tid + 256k, 32 pairs per row)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int p = tid + 256 * k;
+        const int row = p >> 5, pc = p & 31;
+        const int m = pc >> 1;
+        const uint32_t sh = (pc & 1) * 16;
+        // rows -3,-2,0,+2,+3 only
+        uint32_t rw[5][3];
+        const int rsel[5] = {0, 1, 3, 5, 6};
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+            const uint32_t *q = &in[(row + rsel[r]) * (FS_IP / 4) + m];
+            const uint32_t w0 = q[0], w1 = q[1], w2 = q[2];
+            rw[r][0] = __builtin_amdgcn_alignbit(w1, w0, sh);
+            rw[r][1] = __builtin_amdgcn_alignbit(w2, w1, sh);
+            rw[r][2] = w2 >> sh;
+        }
+#define PXR(R, DX) as_s16x2(pair_at<4 + (DX)>(rw[R][0], rw[R][1], rw[R][2]))
+        const s16x2 v = PXR(2, 0);
+        const s16x2 d0 = v - PXR(4, 0), d8 = v - PXR(0, 0), d4 = v - PXR(2, 3), d12 = v - PXR(2, -3);
+        const s16x2 d2 = v - PXR(3, 2), d10 = v - PXR(1, -2), d6 = v - PXR(1, 2), d14 = v - PXR(3, -2);
+#undef PXR
+        const s16x2 dark = pkmin(pkmin(pkmax(d0, d8), pkmax(d4, d12)), pkmin(pkmax(d2, d10), pkmax(d6, d14)));
+        const s16x2 brig = pkmax(pkmax(pkmin(d0, d8), pkmin(d4, d12)), pkmax(pkmin(d2, d10), pkmin(d6, d14)));
+        const bool pass = dark.x > th || dark.y > th || brig.x < -th || brig.y < -th;
+        const unsigned long long bal = __ballot(pass);
+        int base = 0;
+        if (lane == 0 && bal) base = atomicAdd(&qn, __popcll(bal));
+        base = __shfl(base, 0, 64);
+        if (pass) queue[base + __popcll(bal & ((1ull << lane) - 1))] = (uint16_t)p;
+    }
+    __syncthreads();
+    // ---- phase 2: full arc score of the surviving pairs
+    const int nq = qn;
+    uint16_t *out16 = reinterpret_cast<uint16_t *>(outt);
+    for (int q0 = 0; q0 < nq; q0 += 256) {
+        const int qi = q0 + tid;
+        const int p = qi < nq ? queue[qi] : queue[0];
+        const int row = p >> 5, pc = p & 31;
+        uint32_t rows[7][3];
+        fs_window(in, row, pc, rows);
+        s16x2 S = (s16x2){0, 0};
+        fast_pair_score<0>(rows, th, &S);
+        if (qi < nq) {
+            const uint32_t lo = S.x > th ? (uint32_t)(S.x - 1) : 0u, hi = S.y > th ? (uint32_t)(S.y - 1) : 0u;
+            out16[row * (FS_TW / 2) + pc] = (uint16_t)(lo | (hi << 8));
+        }
+    }
+    __syncthreads();
+    uint8_t *dst = L.score + (size_t)frame * L.score_frame_stride;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int i = tid + 256 * k;
+        const int row = i >> 4, g = i & 15;
+        const int x = x0 + 4 * g, y = y0 + row;
+        if (x < w && y < h) *reinterpret_cast<uint32_t *>(dst + (size_t)y * L.score_pitch + x) = outt[i];   // pitch % 64 == 0
+    }
+}
+
+// Pass 2: per cell (ORBextractor.cc:783-854): 3x3 strict NMS inside the cell's detection band only
+// (cv::FAST never looks across the sub-image border), iniThFAST first, minThFAST iff nothing
+// survives, emission in cv::FAST order.  One wave per cell, four cells per workgroup, no barriers.
+#define FC_TP 72
+#define FC_ROWS 62
 __global__ __launch_bounds__(256) void k_fast_cells(OrbParams P)
 {
-    __shared__ uint32_t tile[64 * (FAST_TP / 4)];
-    __shared__ uint8_t sc[66 * FAST_TP];      // score map, +1 row apron top/bottom
-    __shared__ int wsum[8];
-    __shared__ int s_cnt;
-    const int tid = threadIdx.x;
+    __shared__ uint32_t sc_all[4][FC_ROWS * (FC_TP / 4)];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int frame = blockIdx.y;
-    const int cell = blockIdx.x;
+    const int cell = blockIdx.x * 4 + wv;
+    if (cell >= P.cells_per_frame) return;
     int lvl = 0;
     for (int l = 1; l < P.nlevels; l++) if (cell >= P.lv[l].cell_base) lvl = l;
     const OrbLevel &L = P.lv[lvl];
@@ -224,110 +339,106 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbParams P)
     const int ini_y = ORB_MINB + ci * L.hcell, ini_x = ORB_MINB + cj * L.wcell;
     int max_y = ini_y + L.hcell + 6, max_x = ini_x + L.wcell + 6;
     if (ini_y >= max_by - 3 || ini_x >= max_bx - 6) {       // ORBextractor.cc:788,797
-        if (tid == 0) *cnt_out = 0;
+        if (lane == 0) *cnt_out = 0;
         return;
     }
     if (max_y > max_by) max_y = max_by;
     if (max_x > max_bx) max_x = max_bx;
-    const int cw = max_x - ini_x, ch = max_y - ini_y;
-    const int dw = cw - 6, dh = ch - 6;                       // detection band of cv::FAST
+    const int dw = max_x - ini_x - 6, dh = max_y - ini_y - 6;  // detection band of cv::FAST
     if (dw <= 0 || dh <= 0) {
-        if (tid == 0) *cnt_out = 0;
+        if (lane == 0) *cnt_out = 0;
         return;
     }
-    // stage the sub-image with aligned dword loads; LDS column lx = image x - xb, xb = ini_x & ~3
-    const int xb = ini_x & ~3, off = ini_x - xb;
-    const int ncd = (cw + off + 3) >> 2;                      // dwords per staged row (<= 17)
-    const uint8_t *img = L.img + (size_t)frame * L.img_frame_stride + (size_t)ini_y * L.img_pitch + xb;
-    for (int i = tid; i < ncd * ch; i += 256) {
-        const int y = i / ncd, cd = i - y * ncd;
-        tile[y * (FAST_TP / 4) + cd] = *reinterpret_cast<const uint32_t *>(img + (size_t)y * L.img_pitch + 4 * cd);
-    }
-    for (int i = tid; i < 66 * FAST_TP / 4; i += 256) reinterpret_cast<uint32_t *>(sc)[i] = 0;
-    if (tid == 0) s_cnt = 0;
-    __syncthreads();
-    // score map: groups of 4 pixels (lx = 4g .. 4g+3), packed 16-bit arithmetic on pixel pairs
-    const int g0 = (3 + off) >> 2, g1 = (cw - 4 + off) >> 2;  // first / last group touching the band
-    const int ng = g1 - g0 + 1;
-    const int lx_lo = 3 + off, lx_hi = cw - 4 + off;
-    const int ngroups = ng * dh;
-    for (int i0 = 0; i0 < ngroups; i0 += 256) {
-        const int i = i0 + tid;
-        const bool valid = i < ngroups;
-        const int gy = valid ? i / ng : 0, gx = valid ? i - gy * ng : 0;
-        const int y = 3 + gy, g = g0 + gx;
-        uint32_t rows[7][3];
+    // stage the band's scores: LDS (row yy+1, byte xx+4) <- score(bx+xx, by+yy); everything else zero
+    uint32_t *sc32 = sc_all[wv];
+    uint8_t *sc = reinterpret_cast<uint8_t *>(sc32);
+    const int bx = ini_x + 3, by = ini_y + 3;
+    const uint8_t *smap = L.score + (size_t)frame * L.score_frame_stride;
+    const int ndw = ((dw + 4) >> 2) + 1;                      // LDS dwords per row covering bytes [0, dw+4] (band + aprons)
+    const int gx0 = bx - 4;                                   // image x of LDS byte 0 (>= 15)
+    const int ax = gx0 & ~3, sh = gx0 & 3;
+    // lanes = (row sub-index, dword): rows_per_trip rows are staged per trip, no integer division
+    {
+        const int rpt = 64 / ndw;                                  // rows per trip (ndw <= 16)
+        const int r0 = lane / ndw, d = lane - r0 * ndw;
+        uint32_t mask = 0;
 #pragma unroll
-        for (int r = 0; r < 7; r++) {
-            const uint32_t *q = &tile[(y - 3 + r) * (FAST_TP / 4) + g];
-            rows[r][0] = g > 0 ? q[-1] : 0u; rows[r][1] = q[0]; rows[r][2] = q[1];
-        }
-        s16x2 S01 = (s16x2){0, 0}, S23 = (s16x2){0, 0};
-        const bool h01 = fast_pair_score<0>(rows, P.min_th, &S01);
-        const bool h23 = fast_pair_score<2>(rows, P.min_th, &S23);
-        if (valid && (h01 || h23)) {
-            const int lx = 4 * g;
-            uint32_t out = 0;
-            const int Sv[4] = {S01.x, S01.y, S23.x, S23.y};
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (Sv[j] > P.min_th && lx + j >= lx_lo && lx + j <= lx_hi) out |= (uint32_t)(Sv[j] - 1) << (8 * j);
-            if (out) *reinterpret_cast<uint32_t *>(&sc[(y + 1) * FAST_TP + lx]) = out;
+        for (int j = 0; j < 4; j++) { const int xx = 4 * d - 4 + j; if (xx >= 0 && xx < dw) mask |= 0xFFu << (8 * j); }
+        if (r0 < rpt) {
+            for (int yy = r0; yy < dh; yy += rpt) {
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(smap + (size_t)(by + yy) * L.score_pitch + ax + 4 * d);
+                const uint32_t lo = q[0], hi = q[1];               // within the row pitch (pad bytes are masked off)
+                const uint32_t v = __builtin_amdgcn_alignbit(hi, lo, 8 * sh);
+                sc32[(yy + 1) * (FC_TP / 4) + d] = v & mask;
+            }
         }
     }
-    __syncthreads();
-    // NMS, thread owns a contiguous run of pixels (row-major) -> ordered emission
+    for (int d = lane; d < ndw; d += 64) { sc32[d] = 0; sc32[(dh + 1) * (FC_TP / 4) + d] = 0; }
+    // the staging buffer is private to this wave: order its own LDS writes before its reads (no workgroup barrier:
+    // sibling waves may already have returned)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // NMS: lane owns a contiguous run of band pixels (row-major) -> ordered emission
     const int npix = dw * dh;
-    const int ppt = (npix + 255) / 256;
-    const int p0 = tid * ppt;
-    uint32_t keep = 0;
+    const int ppt = (npix + 63) >> 6;
+    const int p0 = lane * ppt;
+    unsigned long long keep = 0;
     int th = P.ini_th;
+    const int yy0 = p0 / dw, xx0 = p0 - yy0 * dw;          // one division per lane; the run is walked incrementally
     for (int pass = 0; pass < 2; pass++) {
         keep = 0;
+        int yy = yy0, xx = xx0;
         for (int k = 0; k < ppt; k++) {
-            const int i = p0 + k;
-            if (i < npix) {
-                const int y = 3 + i / dw, x = 3 + i % dw + off;
-                const uint8_t *q = &sc[(y + 1) * FAST_TP + x];
-                // v(th) = score if score >= th (i.e. S > th) else 0
-                const int v = q[0] >= th ? q[0] : 0;
+            if (p0 + k < npix) {
+                const uint8_t *q = &sc[(yy + 1) * FC_TP + xx + 4];
+                const int v = q[0] >= th ? q[0] : 0;          // v(th) = score if S > th else 0
                 if (v) {
                     int m = 0;
 #pragma unroll
                     for (int dy = -1; dy <= 1; dy++)
 #pragma unroll
                         for (int dx = -1; dx <= 1; dx++)
-                            if (dx | dy) { const int nb = q[dy * FAST_TP + dx]; m = max(m, nb >= th ? nb : 0); }
-                    if (v > m) keep |= 1u << k;
+                            if (dx | dy) { const int nb = q[dy * FC_TP + dx]; m = max(m, nb >= th ? nb : 0); }
+                    if (v > m) keep |= 1ull << k;
                 }
             }
+            if (++xx == dw) { xx = 0; yy++; }
         }
         if (pass == 0) {
-            if (keep) atomicAdd(&s_cnt, 1);
-            __syncthreads();
-            if (s_cnt > 0) break;                          // vKeysCell non-empty at iniThFAST
-            th = P.min_th;                                 // ORBextractor.cc:825-828 retry
+            if (__any(keep != 0)) break;                      // vKeysCell non-empty at iniThFAST
+            th = P.min_th;                                    // ORBextractor.cc:825-828 retry
         }
     }
-    int total;
-    int offs = block_excl_scan256(__popc(keep), wsum, &total);
+    const int mine = __popcll(keep);
+    const int inc = wave_incl_scan(mine);
+    int total = __shfl(inc, 63, 64);
+    int offs = inc - mine;
     uint32_t *list = P.cell_list + (size_t)frame * P.cell_list_frame_stride + (size_t)cell * L.cell_cap;
-    if (total > L.cell_cap) { if (tid == 0) atomicExch(P.status, ORBHIP_E_CAPACITY); total = L.cell_cap; }
-    for (int k = 0; k < ppt; k++) {
-        if (keep & (1u << k)) {
-            const int i = p0 + k;
-            const int y = 3 + i / dw, x = 3 + i % dw;
-            if (offs < L.cell_cap)
-                list[offs] = ORB_PACK_KEY(x + cj * L.wcell, y + ci * L.hcell, sc[(y + 1) * FAST_TP + x + off]);
-            offs++;
+    if (total > L.cell_cap) { if (lane == 0) atomicExch(P.status, ORBHIP_E_CAPACITY); total = L.cell_cap; }
+    {
+        int yy = yy0, xx = xx0;
+        for (int k = 0; k < ppt; k++) {
+            if (keep & (1ull << k)) {
+                if (offs < L.cell_cap)
+                    list[offs] = ORB_PACK_KEY(xx + 3 + cj * L.wcell, yy + 3 + ci * L.hcell, sc[(yy + 1) * FC_TP + xx + 4]);
+                offs++;
+            }
+            if (++xx == dw) { xx = 0; yy++; }
         }
     }
-    if (tid == 0) *cnt_out = (uint32_t)total;
+    if (lane == 0) *cnt_out = (uint32_t)total;
 }
 
 void orb_launch_fast(const OrbParams &P, hipStream_t s)
 {
-    dim3 grid(P.cells_per_frame, P.batch);
+    for (int l = 0; l < P.nlevels; l++) {
+        const OrbLevel &L = P.lv[l];
+        dim3 grid((L.w + FS_TW - 1) / FS_TW, (L.h + FS_TH - 1) / FS_TH, P.batch);
+        hipLaunchKernelGGL(k_fast_score, grid, dim3(256), 0, s, P, l);
+    }
+    dim3 grid((P.cells_per_frame + 3) / 4, P.batch);
     hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, s, P);
 }
 
@@ -792,11 +903,28 @@ __device__ __forceinline__ void sincos_det(double x, double *s_out, double *c_ou
 }
 
 // Persistent waves: each wave walks the (frame, staging slot) space with a grid stride, keeping its
-// 4 rBRIEF test pairs and its circular-patch row mask in registers (no LDS, no barriers).
+// 4 rBRIEF test pairs and its circular-patch row mask in registers.  Per keypoint the wave stages the
+// 31x31 un-blurred patch and the 39x39 blurred patch into its private LDS slice with coalesced dword
+// loads (a few cache lines per instruction) and does the 749-pixel moment sums and the 512 steered
+// samples from LDS -- the direct per-lane byte gathers touched up to ~40 cache lines per instruction.
+#define OD_UP 36              // un-blurred patch pitch (31 + up to 3 alignment bytes, dword multiple)
+#define OD_BP 44              // blurred patch pitch (39 + up to 3)
+__device__ __forceinline__ uint32_t od_load_dword(const uint8_t *row, int x, int w)
+{
+    if (x + 3 < w) return *reinterpret_cast<const uint32_t *>(row + x);
+    uint32_t v = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) v |= (uint32_t)row[min(x + j, w - 1)] << (8 * j);   // never read past the row
+    return v;
+}
+
 __global__ __launch_bounds__(256) void k_orient_desc(OrbParams P)
 {
-    const int lane = threadIdx.x & 63;
+    __shared__ uint32_t lds_all[4][(31 * OD_UP + 39 * OD_BP) / 4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
+    uint32_t *up32 = lds_all[wv], *bp32 = lds_all[wv] + 31 * OD_UP / 4;
+    const uint8_t *up = reinterpret_cast<const uint8_t *>(up32), *bp = reinterpret_cast<const uint8_t *>(bp32);
     // lane-constant state
     float px0[4], py0[4], px1[4], py1[4];
 #pragma unroll
@@ -814,6 +942,9 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrbParams P)
             if (u >= -d && u <= d) rowmask |= 1u << it;
         }
     }
+    // staging lane maps: un-blurred 31 rows x 9 dwords (7 rows per trip), blurred 39 rows x 11 dwords (5 rows per trip)
+    const int ur = lane / 9, ud = lane - ur * 9;
+    const int br = lane / 11, bd = lane - br * 11;
     const float factor_pi = (float)(3.1415926535897932384626433832795 / 180.f);
     const long total = (long)P.batch * P.kps_per_frame;
     for (long gs = wave; gs < total; gs += nwaves) {
@@ -826,14 +957,28 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrbParams P)
         if (idx >= P.lvl_count[frame * P.nlevels + lvl]) continue;
         const uint32_t key = P.lvl_kp[(size_t)frame * P.kps_per_frame + slot];
         const int x = ORB_KEY_X(key) + ORB_MINB, y = ORB_KEY_Y(key) + ORB_MINB;     // ORBextractor.cc:868-869
+        // ---- stage both patches
+        const int uxs = (x - 15) & ~3, uoff = (x - 15) - uxs;        // un-blurred: cols x-15..x+15
+        const int bxs = (x - 19) & ~3, boff = (x - 19) - bxs;        // blurred:    cols x-19..x+19
+        const uint8_t *ubase = L.img + (size_t)frame * L.img_frame_stride + (size_t)(y - 15) * L.img_pitch;
+        const uint8_t *bbase = L.blur + (size_t)frame * L.blur_frame_stride + (size_t)(y - 19) * L.blur_pitch;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // previous keypoint's LDS reads are done
+        if (ur < 7)
+            for (int r = ur; r < 31; r += 7) up32[r * (OD_UP / 4) + ud] = od_load_dword(ubase + (size_t)r * L.img_pitch, uxs + 4 * ud, L.w);
+        if (br < 5)
+            for (int r = br; r < 39; r += 5) bp32[r * (OD_BP / 4) + bd] = od_load_dword(bbase + (size_t)r * L.blur_pitch, bxs + 4 * bd, L.w);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // ---- IC_Angle (ORBextractor.cc:75-102): two patch rows per step (lanes 0-30 / 32-62)
-        const uint8_t *c = L.img + (size_t)frame * L.img_frame_stride + (size_t)y * L.img_pitch + x;
+        const uint8_t *c = up + 15 * OD_UP + uoff + 15;
         int m10 = 0, m01 = 0;
 #pragma unroll
         for (int it = 0; it < 16; it++) {
             if (rowmask & (1u << it)) {
                 const int v = it - ORB_HALF_PATCH + half * 16;
-                const int val = c[v * L.img_pitch + u];
+                const int val = c[v * OD_UP + u];
                 m10 += u * val;
                 m01 += v * val;
             }
@@ -845,7 +990,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrbParams P)
         double sd, cd;
         sincos_det((double)__fmul_rn(angle, factor_pi), &sd, &cd);
         const float a = (float)cd, b = (float)sd;
-        const uint8_t *bc = L.blur + (size_t)frame * L.blur_frame_stride + (size_t)y * L.blur_pitch + x;
+        const uint8_t *bc = bp + 19 * OD_BP + boff + 19;
         uint8_t *desc = P.lvl_desc + ((size_t)frame * P.kps_per_frame + slot) * 32;
         unsigned long long m[4];
 #pragma unroll
@@ -854,7 +999,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrbParams P)
             const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(px0[j], a), __fmul_rn(py0[j], b)));
             const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1[j], b), __fmul_rn(py1[j], a)));
             const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(px1[j], a), __fmul_rn(py1[j], b)));
-            const int t0 = bc[r0 * L.blur_pitch + c0], t1 = bc[r1 * L.blur_pitch + c1];
+            const int t0 = bc[r0 * OD_BP + c0], t1 = bc[r1 * OD_BP + c1];
             m[j] = __ballot(t0 < t1);
         }
         if (lane < 4) reinterpret_cast<unsigned long long *>(desc)[lane] = lane == 0 ? m[0] : lane == 1 ? m[1] : lane == 2 ? m[2] : m[3];

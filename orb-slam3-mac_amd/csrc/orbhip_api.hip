@@ -279,6 +279,8 @@ extern "C" int orbhip_extractor_reserve(orbhip_extractor *e, int width, int heig
         L.img_frame_stride = (size_t)L.img_pitch * L.h; L.blur_frame_stride = L.img_frame_stride;
         if ((rc = dev_alloc(e, &L.img, B * L.img_frame_stride + 64))) return rc;
         if ((rc = dev_alloc(e, &L.blur, B * L.blur_frame_stride + 64))) return rc;
+        L.score_pitch = L.blur_pitch; L.score_frame_stride = L.blur_frame_stride;
+        if ((rc = dev_alloc(e, &L.score, B * L.score_frame_stride + 64))) return rc;
         if (l > 0) {
             std::vector<int16_t> xo, xa, yo, yb;
             resize_tables(P.lv[l - 1].w, L.w, true, xo, xa);
