@@ -76,20 +76,31 @@ __global__ __launch_bounds__(256) void k_resize(OrbParams P, int level)
     const int xbase = D.xofs[dx0] & ~3;
     const int ncd = min((D.xofs[dx_last] + 1 - xbase) / 4 + 1, RS_MAXC / 4);
     const uint8_t *src = S.img + (size_t)frame * S.img_frame_stride;
-    // ---- A
-    for (int i = tid; i < nrows * ncd; i += 256) {
-        const int r = i / ncd, cd = i - r * ncd;
-        const int y = min(max(ybase + r, 0), S.h - 1);               // clip(sy, 0, ssize.height)
-        const int x = xbase + 4 * cd;
-        const uint8_t *row = src + (size_t)y * S.img_pitch;
-        uint32_t v;
-        if (x + 3 < S.w) v = *reinterpret_cast<const uint32_t *>(row + x);
-        else {
-            v = 0;
+    // ---- A: loads in batches of 4 per thread before their LDS stores
+    for (int i0 = 0; i0 < nrows * ncd; i0 += 1024) {
+        uint32_t reg[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) v |= (uint32_t)row[min(x + j, S.w - 1)] << (8 * j);
+        for (int k = 0; k < 4; k++) {
+            const int i = i0 + tid + 256 * k;
+            uint32_t v = 0;
+            if (i < nrows * ncd) {
+                const int r = i / ncd, cd = i - r * ncd;
+                const int y = min(max(ybase + r, 0), S.h - 1);               // clip(sy, 0, ssize.height)
+                const int x = xbase + 4 * cd;
+                const uint8_t *row = src + (size_t)y * S.img_pitch;
+                if (x + 3 < S.w) v = *reinterpret_cast<const uint32_t *>(row + x);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) v |= (uint32_t)row[min(x + j, S.w - 1)] << (8 * j);
+                }
+            }
+            reg[k] = v;
         }
-        in[r * (RS_MAXC / 4) + cd] = v;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = i0 + tid + 256 * k;
+            if (i < nrows * ncd) { const int r = i / ncd, cd = i - r * ncd; in[r * (RS_MAXC / 4) + cd] = reg[k]; }
+        }
     }
     __syncthreads();
     // ---- B
@@ -242,17 +253,27 @@ __global__ __launch_bounds__(256) void k_fast_score(OrbParams P, int level)
     const int x0 = blockIdx.x * FS_TW, y0 = blockIdx.y * FS_TH;
     const uint8_t *src = L.img + (size_t)frame * L.img_frame_stride;
     const int w = L.w, h = L.h, th = P.min_th;
-    for (int i = tid; i < (FS_TH + 6) * (FS_IP / 4); i += 256) {
-        const int r = i / (FS_IP / 4), cd = i - r * (FS_IP / 4);
-        const int y = min(max(y0 + r - 3, 0), h - 1);
-        const int x = x0 - 4 + 4 * cd;
-        uint32_t v = 0;
-        if (x >= 0 && x + 3 < w) v = *reinterpret_cast<const uint32_t *>(src + (size_t)y * L.img_pitch + x);
-        else if (x + 3 >= 0 && x < w) {
+    {   // 684 dwords = 3 per thread: issue all loads, then all LDS stores
+        uint32_t reg[3];
 #pragma unroll
-            for (int j = 0; j < 4; j++) v |= (uint32_t)src[(size_t)y * L.img_pitch + min(max(x + j, 0), w - 1)] << (8 * j);
+        for (int k = 0; k < 3; k++) {
+            const int i = tid + 256 * k;
+            const int r = i / (FS_IP / 4), cd = i - r * (FS_IP / 4);
+            const int y = min(max(y0 + r - 3, 0), h - 1);
+            const int x = x0 - 4 + 4 * cd;
+            const uint8_t *row = src + (size_t)y * L.img_pitch;
+            uint32_t v = 0;
+            if (i < (FS_TH + 6) * (FS_IP / 4)) {
+                if (x >= 0 && x + 3 < w) v = *reinterpret_cast<const uint32_t *>(row + x);
+                else if (x + 3 >= 0 && x < w) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) v |= (uint32_t)row[min(max(x + j, 0), w - 1)] << (8 * j);
+                }
+            }
+            reg[k] = v;
         }
-        in[i] = v;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const int i = tid + 256 * k; if (i < (FS_TH + 6) * (FS_IP / 4)) in[i] = reg[k]; }
     }
     outt[tid] = 0; outt[tid + 256] = 0;
     if (tid == 0) qn = 0;
@@ -758,25 +779,33 @@ __global__ __launch_bounds__(256) void k_blur(OrbParams P, int level)
     const int x0 = blockIdx.x * BL_TW, y0 = blockIdx.y * BL_TH;
     const uint8_t *src = L.img + (size_t)frame * L.img_frame_stride;
     const int w = L.w, h = L.h;
-    // ---- A
-    for (int i = tid; i < (BL_TH + 6) * (BL_IP / 4); i += 256) {
-        const int r = i / (BL_IP / 4), cd = i - r * (BL_IP / 4);
-        int y = reflect101(y0 + r - 3, h);
-        y = min(max(y, 0), h - 1);
-        const int x = x0 - 4 + 4 * cd;
-        const uint8_t *row = src + (size_t)y * L.img_pitch;
-        uint32_t v;
-        if (x >= 0 && x + 3 < w) v = *reinterpret_cast<const uint32_t *>(row + x);      // pitch%64==0, x%4==0
-        else {
-            v = 0;
+    // ---- A: 684 dwords = 3 per thread: issue all loads, then all LDS stores
+    {
+        uint32_t reg[3];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                int xx = reflect101(x + j, w);
-                xx = min(max(xx, 0), w - 1);
-                v |= (uint32_t)row[xx] << (8 * j);
+        for (int k = 0; k < 3; k++) {
+            const int i = tid + 256 * k;
+            const int r = i / (BL_IP / 4), cd = i - r * (BL_IP / 4);
+            int y = reflect101(y0 + r - 3, h);
+            y = min(max(y, 0), h - 1);
+            const int x = x0 - 4 + 4 * cd;
+            const uint8_t *row = src + (size_t)y * L.img_pitch;
+            uint32_t v = 0;
+            if (i < (BL_TH + 6) * (BL_IP / 4)) {
+                if (x >= 0 && x + 3 < w) v = *reinterpret_cast<const uint32_t *>(row + x);      // pitch%64==0, x%4==0
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        int xx = reflect101(x + j, w);
+                        xx = min(max(xx, 0), w - 1);
+                        v |= (uint32_t)row[xx] << (8 * j);
+                    }
+                }
             }
+            reg[k] = v;
         }
-        in[i] = v;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const int i = tid + 256 * k; if (i < (BL_TH + 6) * (BL_IP / 4)) in[i] = reg[k]; }
     }
     __syncthreads();
     // ---- B: q8 kernel {k0,k1,k2,k3,k2,k1,k0} packed for v_dot4_u32_u8
@@ -902,116 +931,158 @@ __device__ __forceinline__ void sincos_det(double x, double *s_out, double *c_ou
     }
 }
 
-// Persistent waves: each wave walks the (frame, staging slot) space with a grid stride, keeping its
-// 4 rBRIEF test pairs and its circular-patch row mask in registers.  Per keypoint the wave stages the
-// 31x31 un-blurred patch and the 39x39 blurred patch into its private LDS slice with coalesced dword
-// loads (a few cache lines per instruction) and does the 749-pixel moment sums and the 512 steered
-// samples from LDS -- the direct per-lane byte gathers touched up to ~40 cache lines per instruction.
+// Sixteen lanes per keypoint (four keypoints per wave), persistent waves with a grid stride.
+// Per keypoint the 16 lanes stage the 31x31 un-blurred patch and the 39x39 blurred patch into LDS
+// with coalesced dword loads, accumulate the 749-pixel moments from LDS (two patch columns per
+// lane, reduced over the 16 lanes), evaluate cv::fastAtan2 / orb_sincos once per keypoint (the four
+// keypoints of a wave share those instructions), and each lane produces 16 of the 256 rBRIEF bits
+// = two consecutive descriptor bytes.
 #define OD_UP 36              // un-blurred patch pitch (31 + up to 3 alignment bytes, dword multiple)
 #define OD_BP 44              // blurred patch pitch (39 + up to 3)
+#define OD_KP_LDS ((31 * OD_UP + 39 * OD_BP) / 4)       // dwords per keypoint
+// Branch-free dword fetch that never reads past the row: the load address is clamped to w-4 (unaligned
+// global loads are legal on gfx950) and the wanted bytes are shifted down; bytes beyond the row come
+// out as zero and are never sampled (patches lie inside the image).
 __device__ __forceinline__ uint32_t od_load_dword(const uint8_t *row, int x, int w)
 {
-    if (x + 3 < w) return *reinterpret_cast<const uint32_t *>(row + x);
-    uint32_t v = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) v |= (uint32_t)row[min(x + j, w - 1)] << (8 * j);   // never read past the row
-    return v;
+    const int xs = min(x, w - 4);
+    uint32_t v;
+    __builtin_memcpy(&v, row + xs, 4);
+    return v >> (8 * min(x - xs, 3));
 }
 
-__global__ __launch_bounds__(256) void k_orient_desc(OrbParams P)
+__global__ __launch_bounds__(256, 3) void k_orient_desc(OrbParams P)
 {
-    __shared__ uint32_t lds_all[4][(31 * OD_UP + 39 * OD_BP) / 4];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
-    uint32_t *up32 = lds_all[wv], *bp32 = lds_all[wv] + 31 * OD_UP / 4;
+    __shared__ uint32_t lds_all[16][OD_KP_LDS];
+    __shared__ uint32_t pat_t[16 * 16];          // pat_t[t][l] = tests 16*l + t, packed x0,y0,x1,y1 (int8)
+    const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, sub = lane >> 4;
+    {
+        const int l = tid & 15, t = tid >> 4;     // 256 threads = 16 x 16 entries
+        pat_t[t * 16 + l] = reinterpret_cast<const uint32_t *>(c_pattern)[16 * l + t];
+    }
+    __syncthreads();
+    // XCD-aware work split (speed only): workgroups with equal blockIdx.x % 8 share an XCD and its L2, so
+    // frame f is handled by the workgroups of XCD (f % 8): every 128-byte line of a frame's pyramid is then
+    // fetched from HBM by one L2 instead of eight.
+    const int xcd = blockIdx.x & 7, nblk_x = gridDim.x >> 3;             // gridDim.x is a multiple of 8
+    const long wave_x = (long)(blockIdx.x >> 3) * 4 + (tid >> 6), nwaves_x = (long)nblk_x * 4;
+    const int gpf = (P.kps_per_frame + 3) >> 2;                          // groups of 4 slots per frame
+    const int nframes_x = (P.batch - xcd + 7) >> 3;                      // frames xcd, xcd+8, ...
+    uint32_t *up32 = lds_all[(tid >> 4)], *bp32 = up32 + 31 * OD_UP / 4;
     const uint8_t *up = reinterpret_cast<const uint8_t *>(up32), *bp = reinterpret_cast<const uint8_t *>(bp32);
-    // lane-constant state
-    float px0[4], py0[4], px1[4], py1[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int8_t *pp = &c_pattern[4 * (lane + 64 * j)];
-        px0[j] = (float)pp[0]; py0[j] = (float)pp[1]; px1[j] = (float)pp[2]; py1[j] = (float)pp[3];
-    }
-    const int half = lane >> 5, u = (lane & 31) - ORB_HALF_PATCH;
-    uint32_t rowmask = 0;                       // bit it: this lane contributes in step it of IC_Angle
-    for (int it = 0; it < 16; it++) {
-        const int v = it - ORB_HALF_PATCH + half * 16;
-        const int av = v < 0 ? -v : v;
-        if (av <= ORB_HALF_PATCH && (lane & 31) < 31) {
-            const int d = P.umax[av];
-            if (u >= -d && u <= d) rowmask |= 1u << it;
-        }
-    }
-    // staging lane maps: un-blurred 31 rows x 9 dwords (7 rows per trip), blurred 39 rows x 11 dwords (5 rows per trip)
-    const int ur = lane / 9, ud = lane - ur * 9;
-    const int br = lane / 11, bd = lane - br * 11;
     const float factor_pi = (float)(3.1415926535897932384626433832795 / 180.f);
-    const long total = (long)P.batch * P.kps_per_frame;
-    for (long gs = wave; gs < total; gs += nwaves) {
-        const int frame = (int)(gs / P.kps_per_frame);
-        const int slot = (int)(gs - (long)frame * P.kps_per_frame);
+    const long ngroups = (long)nframes_x * gpf;
+    const int u0 = l16 - ORB_HALF_PATCH, u1 = l16 + 1;             // this lane's two patch columns (u1 == 16 unused)
+    for (long q = wave_x; q < ngroups; q += nwaves_x) {
+        // every per-level staging slice is a multiple of 4 slots (orbhip_extractor_reserve), so the 4 keypoints
+        // of a wave share frame and level: level parameters stay in scalar registers
+        const int fk = __builtin_amdgcn_readfirstlane((int)(q / gpf));
+        const int frame = xcd + 8 * fk;
+        const int slot0 = __builtin_amdgcn_readfirstlane(4 * (int)(q - (long)fk * gpf));
         int lvl = 0;
-        for (int l = 1; l < P.nlevels; l++) if (slot >= P.lv[l].kp_base) lvl = l;
+        for (int l = 1; l < P.nlevels; l++) if (slot0 >= P.lv[l].kp_base) lvl = l;
+        lvl = __builtin_amdgcn_readfirstlane(lvl);
         const OrbLevel &L = P.lv[lvl];
-        const int idx = slot - L.kp_base;
-        if (idx >= P.lvl_count[frame * P.nlevels + lvl]) continue;
-        const uint32_t key = P.lvl_kp[(size_t)frame * P.kps_per_frame + slot];
-        const int x = ORB_KEY_X(key) + ORB_MINB, y = ORB_KEY_Y(key) + ORB_MINB;     // ORBextractor.cc:868-869
-        // ---- stage both patches
+        const int slot = slot0 + sub;
+        const int nk = P.lvl_count[frame * P.nlevels + lvl];
+        const bool valid = (slot - L.kp_base) < nk;
+        if (slot0 - L.kp_base >= nk) continue;
+        int x = 19, y = 19;
+        if (valid) {
+            const uint32_t key = P.lvl_kp[(size_t)frame * P.kps_per_frame + slot];
+            x = ORB_KEY_X(key) + ORB_MINB; y = ORB_KEY_Y(key) + ORB_MINB;           // ORBextractor.cc:868-869
+        }
+        // ---- stage both patches (16 lanes per keypoint)
         const int uxs = (x - 15) & ~3, uoff = (x - 15) - uxs;        // un-blurred: cols x-15..x+15
         const int bxs = (x - 19) & ~3, boff = (x - 19) - bxs;        // blurred:    cols x-19..x+19
-        const uint8_t *ubase = L.img + (size_t)frame * L.img_frame_stride + (size_t)(y - 15) * L.img_pitch;
-        const uint8_t *bbase = L.blur + (size_t)frame * L.blur_frame_stride + (size_t)(y - 19) * L.blur_pitch;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // previous keypoint's LDS reads are done
-        if (ur < 7)
-            for (int r = ur; r < 31; r += 7) up32[r * (OD_UP / 4) + ud] = od_load_dword(ubase + (size_t)r * L.img_pitch, uxs + 4 * ud, L.w);
-        if (br < 5)
-            for (int r = br; r < 39; r += 5) bp32[r * (OD_BP / 4) + bd] = od_load_dword(bbase + (size_t)r * L.blur_pitch, bxs + 4 * bd, L.w);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // previous keypoints' LDS reads are done
+        if (valid) {
+            const uint8_t *ubase = L.img + (size_t)frame * L.img_frame_stride + (size_t)(y - 15) * L.img_pitch;
+            const uint8_t *bbase = L.blur + (size_t)frame * L.blur_frame_stride + (size_t)(y - 19) * L.blur_pitch;
+            // the 16 lanes sweep the flattened patch (18 + 27 dword loads per lane); loads are issued in
+            // batches of 9 before their LDS stores so that each batch is in flight together
+#pragma unroll
+            for (int k0 = 0; k0 < 18; k0 += 9) {
+                uint32_t reg[9];
+#pragma unroll
+                for (int k = 0; k < 9; k++) {
+                    const int i = l16 + 16 * (k0 + k);
+                    const int r = i / 9, d = i - r * 9;
+                    reg[k] = i < 31 * 9 ? od_load_dword(ubase + (size_t)r * L.img_pitch, uxs + 4 * d, L.w) : 0u;
+                }
+#pragma unroll
+                for (int k = 0; k < 9; k++) {
+                    const int i = l16 + 16 * (k0 + k);
+                    const int r = i / 9, d = i - r * 9;
+                    if (i < 31 * 9) up32[r * (OD_UP / 4) + d] = reg[k];
+                }
+            }
+#pragma unroll
+            for (int k0 = 0; k0 < 27; k0 += 9) {
+                uint32_t reg[9];
+#pragma unroll
+                for (int k = 0; k < 9; k++) {
+                    const int i = l16 + 16 * (k0 + k);
+                    const int r = i / 11, d = i - r * 11;
+                    reg[k] = i < 39 * 11 ? od_load_dword(bbase + (size_t)r * L.blur_pitch, bxs + 4 * d, L.w) : 0u;
+                }
+#pragma unroll
+                for (int k = 0; k < 9; k++) {
+                    const int i = l16 + 16 * (k0 + k);
+                    const int r = i / 11, d = i - r * 11;
+                    if (i < 39 * 11) bp32[r * (OD_BP / 4) + d] = reg[k];
+                }
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // ---- IC_Angle (ORBextractor.cc:75-102): two patch rows per step (lanes 0-30 / 32-62)
+        // ---- IC_Angle (ORBextractor.cc:75-102)
         const uint8_t *c = up + 15 * OD_UP + uoff + 15;
         int m10 = 0, m01 = 0;
-#pragma unroll
-        for (int it = 0; it < 16; it++) {
-            if (rowmask & (1u << it)) {
-                const int v = it - ORB_HALF_PATCH + half * 16;
-                const int val = c[v * OD_UP + u];
-                m10 += u * val;
-                m01 += v * val;
-            }
+#pragma unroll 1
+        for (int v = -ORB_HALF_PATCH; v <= ORB_HALF_PATCH; v++) {
+            const int d = P.umax[v < 0 ? -v : v];
+            const int a0 = (u0 >= -d) ? c[v * OD_UP + u0] : 0;       // u0 <= 0 <= d always
+            const int a1 = (u1 <= d) ? c[v * OD_UP + u1] : 0;        // u1 >= 1 > -d always
+            m10 += u0 * a0 + u1 * a1;
+            m01 += v * (a0 + a1);
         }
-        m10 = wave_sum(m10);
-        m01 = wave_sum(m01);
+#pragma unroll
+        for (int dd = 8; dd >= 1; dd >>= 1) { m10 += __shfl_xor(m10, dd, 16); m01 += __shfl_xor(m01, dd, 16); }
         const float angle = fast_atan2_deg((float)m01, (float)m10);
         // ---- steered BRIEF on the blurred level (ORBextractor.cc:106-145)
         double sd, cd;
         sincos_det((double)__fmul_rn(angle, factor_pi), &sd, &cd);
         const float a = (float)cd, b = (float)sd;
         const uint8_t *bc = bp + 19 * OD_BP + boff + 19;
-        uint8_t *desc = P.lvl_desc + ((size_t)frame * P.kps_per_frame + slot) * 32;
-        unsigned long long m[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(px0[j], b), __fmul_rn(py0[j], a)));
-            const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(px0[j], a), __fmul_rn(py0[j], b)));
-            const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1[j], b), __fmul_rn(py1[j], a)));
-            const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(px1[j], a), __fmul_rn(py1[j], b)));
+        uint32_t bits = 0;
+#pragma unroll 4
+        for (int t = 0; t < 16; t++) {
+            const uint32_t pk = pat_t[t * 16 + l16];
+            const float px0 = (float)(int8_t)(pk & 255), py0 = (float)(int8_t)((pk >> 8) & 255);
+            const float px1 = (float)(int8_t)((pk >> 16) & 255), py1 = (float)(int8_t)(pk >> 24);
+            const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(px0, b), __fmul_rn(py0, a)));
+            const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(px0, a), __fmul_rn(py0, b)));
+            const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1, b), __fmul_rn(py1, a)));
+            const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(px1, a), __fmul_rn(py1, b)));
             const int t0 = bc[r0 * OD_BP + c0], t1 = bc[r1 * OD_BP + c1];
-            m[j] = __ballot(t0 < t1);
+            bits |= (uint32_t)(t0 < t1) << t;
         }
-        if (lane < 4) reinterpret_cast<unsigned long long *>(desc)[lane] = lane == 0 ? m[0] : lane == 1 ? m[1] : lane == 2 ? m[2] : m[3];
-        if (lane == 0) P.lvl_angle[(size_t)frame * P.kps_per_frame + slot] = angle;
+        if (valid) {
+            uint8_t *desc = P.lvl_desc + ((size_t)frame * P.kps_per_frame + slot) * 32;
+            reinterpret_cast<uint16_t *>(desc)[l16] = (uint16_t)bits;              // tests 16*l16 .. 16*l16+15 = bytes 2*l16, 2*l16+1
+            if (l16 == 0) P.lvl_angle[(size_t)frame * P.kps_per_frame + slot] = angle;
+        }
     }
 }
 
 void orb_launch_orient_desc(const OrbParams &P, hipStream_t s)
 {
     const long total = (long)P.batch * P.kps_per_frame;
-    long blocks = (total + 3) / 4;
-    if (blocks > 256 * 8) blocks = 256 * 8;           // 8 blocks (32 waves) per CU, grid-stride beyond
+    (void)total;
+    const long blocks = 256 * 3;                       // LDS: 46 KB per workgroup -> 3 per CU; multiple of 8 (XCD split)
     hipLaunchKernelGGL(k_orient_desc, dim3((unsigned)blocks), dim3(256), 0, s, P);
 }
 

@@ -257,7 +257,7 @@ extern "C" int orbhip_extractor_reserve(orbhip_extractor *e, int width, int heig
         L.hx = (float)(maxx - ORB_MINB) / L.n_ini;
         L.scale = e->scale[l];
         L.size = (float)(int)(31 * e->scale[l]);              // ORBextractor.cc:862
-        L.kp_base = kps; L.kp_cap = std::max(L.quota + 8, 4 * L.n_ini + 4); kps += L.kp_cap;
+        L.kp_base = kps; L.kp_cap = align_up(std::max(L.quota + 8, 4 * L.n_ini + 4), 4); kps += L.kp_cap;   // multiple of 4: k_orient_desc
     }
     // cell list capacity: 3x3 strict-greater NMS admits at most one keypoint per 2x2 block
     for (int l = 0; l < e->nlevels; l++) {
