@@ -37,7 +37,7 @@ def algorithmic_bytes(w, h, n_kp, nlevels=8):
     S = sum(a * b for a, b in dims)
     S_lo = S - dims[-1][0] * dims[-1][1]
     S_hi = S - dims[0][0] * dims[0][1]
-    return {"pyramid": S_lo + S_hi, "fast": S, "blur": 2 * S, "desc": n_kp * (749 + 512) + n_kp * 36,
+    return {"pyramid": S_lo + S_hi, "blur_score": 3 * S, "fast_cells": 0, "desc": n_kp * (749 + 512) + n_kp * 36,
             "octree": 0, "assemble": n_kp * 60 * 2, "total": S_lo + S_hi + S + 2 * S + n_kp * (749 + 512) + n_kp * 60}
 
 
@@ -250,8 +250,11 @@ def main():
         ms_step = dt / args.steps * 1e3
         fps = world * B * args.steps / dt
         ab = algorithmic_bytes(W, H, n_kp_avg)
-        dom = max(("pyramid", "fast", "blur", "desc", "octree", "assemble"), key=lambda k: stage[k])
-        launches = {"pyramid": 7, "fast": 1, "octree": 1, "blur": 8, "desc": 1, "assemble": 1}[dom]
+        # dominant kernel among those with an algorithmic byte count: one stage == one kernel
+        # (k_blur_score = SURVEY's "FAST read S" + "blur read+write 2S" done from one staged tile)
+        kern = {"pyramid": "k_resize", "blur_score": "k_blur_score", "desc": "k_orient_desc"}
+        dom = max(kern, key=lambda k: stage[k])
+        launches = {"pyramid": 7, "blur_score": 8, "desc": 1}[dom]
         dom_bytes = ab[dom] * B
         achieved = dom_bytes / (stage[dom] * 1e-3) / 1e9 if stage[dom] > 0 else 0.0
         out = {
@@ -267,7 +270,7 @@ def main():
                        "windowed_matches_per_pair": round(win_matches, 1),
                        "stage_ms": {k: round(v, 4) for k, v in stage.items()},
                        "end_to_end_algorithmic_GBps": round(ab["total"] * B * args.steps / dt / 1e9, 2)},
-            "roofline": {"bound": "hbm", "kernel": dom, "launches_per_step": launches,
+            "roofline": {"bound": "hbm", "kernel": kern[dom], "stage": dom, "launches_per_step": launches,
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "algorithmic_bytes_per_step": int(dom_bytes)},

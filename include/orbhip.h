@@ -111,12 +111,12 @@ int orbhip_extractor_get_level_keypoints(orbhip_extractor *ext, int frame, int l
 /* Per-stage device time (ms), averaged over the extract calls made since the previous query
  * (at most the 32 most recent), measured with hipEvents recorded on the context's stream
  * around each stage's launches while profiling is enabled.  Stage ids: ORBHIP_STAGE_*. */
-#define ORBHIP_STAGE_PYRAMID 0
-#define ORBHIP_STAGE_FAST 1
-#define ORBHIP_STAGE_OCTREE 2
-#define ORBHIP_STAGE_BLUR 3
-#define ORBHIP_STAGE_DESC 4
-#define ORBHIP_STAGE_ASSEMBLE 5
+#define ORBHIP_STAGE_PYRAMID 0      /* k_resize, nlevels-1 launches */
+#define ORBHIP_STAGE_BLUR_SCORE 1   /* k_blur_score (7x7 blur + FAST score map, one staged tile), nlevels launches */
+#define ORBHIP_STAGE_FAST_CELLS 2   /* k_fast_cells, 1 launch */
+#define ORBHIP_STAGE_OCTREE 3       /* k_octree, 1 launch */
+#define ORBHIP_STAGE_DESC 4         /* k_orient_desc, 1 launch */
+#define ORBHIP_STAGE_ASSEMBLE 5     /* k_assemble, 1 launch */
 #define ORBHIP_STAGE_COUNT 6
 int orbhip_extractor_set_profiling(orbhip_extractor *ext, int enable);
 int orbhip_extractor_stage_ms(orbhip_extractor *ext, float *ms_out /*[ORBHIP_STAGE_COUNT]*/);

@@ -71,9 +71,9 @@ struct OrbParams {
 
 // kernel launchers (orb_kernels.hip)
 void orb_launch_resize(const OrbParams &P, int level, hipStream_t s);
-void orb_launch_fast(const OrbParams &P, hipStream_t s);
+void orb_launch_fast_cells(const OrbParams &P, hipStream_t s);
+void orb_launch_blur_score(const OrbParams &P, hipStream_t s);
 void orb_launch_octree(const OrbParams &P, hipStream_t s);
-void orb_launch_blur(const OrbParams &P, hipStream_t s);
 void orb_launch_orient_desc(const OrbParams &P, hipStream_t s);
 void orb_launch_assemble(const OrbParams &P, hipStream_t s);
 size_t orb_octree_lds_bytes(int max_quota);

@@ -226,6 +226,21 @@ __device__ __forceinline__ bool fast_pair_score(const uint32_t (&rows)[7][3], in
 #define FS_TW 64
 #define FS_TH 32
 #define FS_IP 72
+// Necessary test for S > th on the pixel pair at window byte 4+J: a 9-arc contains at least one pixel
+// of every diametral pair, here checked on the 4 compass pairs.  rw = tile rows -3,-2,0,+2,+3.
+template <int J>
+__device__ __forceinline__ bool fast_compass(const uint32_t (&rw)[5][3], int th)
+{
+#define PXR(R, DX) as_s16x2(pair_at<4 + J + (DX)>(rw[R][0], rw[R][1], rw[R][2]))
+    const s16x2 v = PXR(2, 0);
+    const s16x2 d0 = v - PXR(4, 0), d8 = v - PXR(0, 0), d4 = v - PXR(2, 3), d12 = v - PXR(2, -3);
+    const s16x2 d2 = v - PXR(3, 2), d10 = v - PXR(1, -2), d6 = v - PXR(1, 2), d14 = v - PXR(3, -2);
+#undef PXR
+    const s16x2 dark = pkmin(pkmin(pkmax(d0, d8), pkmax(d4, d12)), pkmin(pkmax(d2, d10), pkmax(d6, d14)));
+    const s16x2 brig = pkmax(pkmax(pkmin(d0, d8), pkmin(d4, d12)), pkmax(pkmin(d2, d10), pkmin(d6, d14)));
+    return dark.x > th || dark.y > th || brig.x < -th || brig.y < -th;
+}
+
 // window of pair `pc` (pixels 2pc, 2pc+1 of the tile row): dwords m..m+2 of the staged row, realigned
 // so that the left pixel always sits at window byte 4 (v_alignbit_b32 by 0 or 16 bits).
 __device__ __forceinline__ void fs_window(const uint32_t *in, int row, int pc, uint32_t (&rows)[7][3])
@@ -239,102 +254,6 @@ __device__ __forceinline__ void fs_window(const uint32_t *in, int row, int pc, u
         rows[r][0] = __builtin_amdgcn_alignbit(w1, w0, sh);
         rows[r][1] = __builtin_amdgcn_alignbit(w2, w1, sh);
         rows[r][2] = w2 >> sh;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_fast_score(OrbParams P, int level)
-{
-    __shared__ uint32_t in[(FS_TH + 6) * (FS_IP / 4)];
-    __shared__ uint32_t outt[FS_TH * FS_TW / 4];
-    __shared__ uint16_t queue[FS_TH * FS_TW / 2];
-    __shared__ int qn;
-    const OrbLevel &L = P.lv[level];
-    const int tid = threadIdx.x, lane = tid & 63, frame = blockIdx.z;
-    const int x0 = blockIdx.x * FS_TW, y0 = blockIdx.y * FS_TH;
-    const uint8_t *src = L.img + (size_t)frame * L.img_frame_stride;
-    const int w = L.w, h = L.h, th = P.min_th;
-    {   // 684 dwords = 3 per thread: issue all loads, then all LDS stores
-        uint32_t reg[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const int i = tid + 256 * k;
-            const int r = i / (FS_IP / 4), cd = i - r * (FS_IP / 4);
-            const int y = min(max(y0 + r - 3, 0), h - 1);
-            const int x = x0 - 4 + 4 * cd;
-            const uint8_t *row = src + (size_t)y * L.img_pitch;
-            uint32_t v = 0;
-            if (i < (FS_TH + 6) * (FS_IP / 4)) {
-                if (x >= 0 && x + 3 < w) v = *reinterpret_cast<const uint32_t *>(row + x);
-                else if (x + 3 >= 0 && x < w) {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) v |= (uint32_t)row[min(max(x + j, 0), w - 1)] << (8 * j);
-                }
-            }
-            reg[k] = v;
-        }
-#pragma unroll
-        for (int k = 0; k < 3; k++) { const int i = tid + 256 * k; if (i < (FS_TH + 6) * (FS_IP / 4)) in[i] = reg[k]; }
-    }
-    outt[tid] = 0; outt[tid + 256] = 0;
-    if (tid == 0) qn = 0;
-    __syncthreads();
-    // ---- phase 1: compass test on 4 pairs per thread (pairs p = tid + 256k, 32 pairs per row)
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int p = tid + 256 * k;
-        const int row = p >> 5, pc = p & 31;
-        const int m = pc >> 1;
-        const uint32_t sh = (pc & 1) * 16;
-        // rows -3,-2,0,+2,+3 only
-        uint32_t rw[5][3];
-        const int rsel[5] = {0, 1, 3, 5, 6};
-#pragma unroll
-        for (int r = 0; r < 5; r++) {
-            const uint32_t *q = &in[(row + rsel[r]) * (FS_IP / 4) + m];
-            const uint32_t w0 = q[0], w1 = q[1], w2 = q[2];
-            rw[r][0] = __builtin_amdgcn_alignbit(w1, w0, sh);
-            rw[r][1] = __builtin_amdgcn_alignbit(w2, w1, sh);
-            rw[r][2] = w2 >> sh;
-        }
-#define PXR(R, DX) as_s16x2(pair_at<4 + (DX)>(rw[R][0], rw[R][1], rw[R][2]))
-        const s16x2 v = PXR(2, 0);
-        const s16x2 d0 = v - PXR(4, 0), d8 = v - PXR(0, 0), d4 = v - PXR(2, 3), d12 = v - PXR(2, -3);
-        const s16x2 d2 = v - PXR(3, 2), d10 = v - PXR(1, -2), d6 = v - PXR(1, 2), d14 = v - PXR(3, -2);
-#undef PXR
-        const s16x2 dark = pkmin(pkmin(pkmax(d0, d8), pkmax(d4, d12)), pkmin(pkmax(d2, d10), pkmax(d6, d14)));
-        const s16x2 brig = pkmax(pkmax(pkmin(d0, d8), pkmin(d4, d12)), pkmax(pkmin(d2, d10), pkmin(d6, d14)));
-        const bool pass = dark.x > th || dark.y > th || brig.x < -th || brig.y < -th;
-        const unsigned long long bal = __ballot(pass);
-        int base = 0;
-        if (lane == 0 && bal) base = atomicAdd(&qn, __popcll(bal));
-        base = __shfl(base, 0, 64);
-        if (pass) queue[base + __popcll(bal & ((1ull << lane) - 1))] = (uint16_t)p;
-    }
-    __syncthreads();
-    // ---- phase 2: full arc score of the surviving pairs
-    const int nq = qn;
-    uint16_t *out16 = reinterpret_cast<uint16_t *>(outt);
-    for (int q0 = 0; q0 < nq; q0 += 256) {
-        const int qi = q0 + tid;
-        const int p = qi < nq ? queue[qi] : queue[0];
-        const int row = p >> 5, pc = p & 31;
-        uint32_t rows[7][3];
-        fs_window(in, row, pc, rows);
-        s16x2 S = (s16x2){0, 0};
-        fast_pair_score<0>(rows, th, &S);
-        if (qi < nq) {
-            const uint32_t lo = S.x > th ? (uint32_t)(S.x - 1) : 0u, hi = S.y > th ? (uint32_t)(S.y - 1) : 0u;
-            out16[row * (FS_TW / 2) + pc] = (uint16_t)(lo | (hi << 8));
-        }
-    }
-    __syncthreads();
-    uint8_t *dst = L.score + (size_t)frame * L.score_frame_stride;
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const int i = tid + 256 * k;
-        const int row = i >> 4, g = i & 15;
-        const int x = x0 + 4 * g, y = y0 + row;
-        if (x < w && y < h) *reinterpret_cast<uint32_t *>(dst + (size_t)y * L.score_pitch + x) = outt[i];   // pitch % 64 == 0
     }
 }
 
@@ -452,13 +371,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbParams P)
     if (lane == 0) *cnt_out = (uint32_t)total;
 }
 
-void orb_launch_fast(const OrbParams &P, hipStream_t s)
+void orb_launch_fast_cells(const OrbParams &P, hipStream_t s)
 {
-    for (int l = 0; l < P.nlevels; l++) {
-        const OrbLevel &L = P.lv[l];
-        dim3 grid((L.w + FS_TW - 1) / FS_TW, (L.h + FS_TH - 1) / FS_TH, P.batch);
-        hipLaunchKernelGGL(k_fast_score, grid, dim3(256), 0, s, P, l);
-    }
     dim3 grid((P.cells_per_frame + 3) / 4, P.batch);
     hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, s, P);
 }
@@ -766,20 +680,26 @@ __device__ __forceinline__ int reflect101(int p, int n)
     return p;
 }
 
-// Tile 64x32 outputs per 256-thread workgroup.
-//  A  stage rows y0-3..y0+34, cols x0-4..x0+67 as aligned dwords (byte path only at image borders)
-//  B  row pass: 4 outputs per thread-task from 3 LDS dwords, v_alignbyte_b32 + v_dot4_u32_u8
-//  C  column pass: 4 columns x 2 rows per thread, dword store
-__global__ __launch_bounds__(256) void k_blur(OrbParams P, int level)
+// ----------------------------------------------------------------------------------
+// Fused A7 + A4 pass over one pyramid level: the 64x32 tile (+3 rows / +4 columns of apron) is
+// staged ONCE and feeds both the 7x7 Gaussian (blurred level, for rBRIEF) and the FAST score map.
+// Staging uses BORDER_REFLECT_101 (needed by the blur); FAST scores within 19 px of the border are
+// never consumed (cells cover [19, w-19) x [19, h-19)), so the reflected apron is harmless there.
+// Algorithmic bytes: S read + S blurred write (+ S score write, an internal product).
+// ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_blur_score(OrbParams P, int level)
 {
     __shared__ uint32_t in[(BL_TH + 6) * (BL_IP / 4)];
     __shared__ uint16_t hz[(BL_TH + 6) * BL_TW];
+    __shared__ uint32_t outt[FS_TH * FS_TW / 4];
+    __shared__ uint16_t queue[FS_TH * FS_TW / 2];
+    __shared__ int qn;
     const OrbLevel &L = P.lv[level];
-    const int tid = threadIdx.x, frame = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, frame = blockIdx.z;
     const int x0 = blockIdx.x * BL_TW, y0 = blockIdx.y * BL_TH;
     const uint8_t *src = L.img + (size_t)frame * L.img_frame_stride;
-    const int w = L.w, h = L.h;
-    // ---- A: 684 dwords = 3 per thread: issue all loads, then all LDS stores
+    const int w = L.w, h = L.h, th = P.min_th;
+    // ---- stage: 684 dwords = 3 per thread, all loads before the LDS stores
     {
         uint32_t reg[3];
 #pragma unroll
@@ -807,17 +727,17 @@ __global__ __launch_bounds__(256) void k_blur(OrbParams P, int level)
 #pragma unroll
         for (int k = 0; k < 3; k++) { const int i = tid + 256 * k; if (i < (BL_TH + 6) * (BL_IP / 4)) in[i] = reg[k]; }
     }
+    outt[tid] = 0; outt[tid + 256] = 0;
+    if (tid == 0) qn = 0;
     __syncthreads();
-    // ---- B: q8 kernel {k0,k1,k2,k3,k2,k1,k0} packed for v_dot4_u32_u8
+    // ---- blur row pass (B of k_blur)
     const uint32_t klo = (uint32_t)P.gauss_q8[0] | ((uint32_t)P.gauss_q8[1] << 8) | ((uint32_t)P.gauss_q8[2] << 16) | ((uint32_t)P.gauss_q8[3] << 24);
     const uint32_t khi = (uint32_t)P.gauss_q8[4] | ((uint32_t)P.gauss_q8[5] << 8) | ((uint32_t)P.gauss_q8[6] << 16);
     for (int i = tid; i < (BL_TH + 6) * (BL_TW / 4); i += 256) {
         const int r = i / (BL_TW / 4), c4 = i - r * (BL_TW / 4);
-        // outputs c..c+3 (c = 4*c4) read input bytes c+1 .. c+10 of the tile row (tile col = out col + 4)
         const uint32_t *q = &in[r * (BL_IP / 4) + c4];
         const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
         uint32_t o[4];
-        // output j: bytes (c+1+j .. c+4+j) . klo + bytes (c+5+j .. c+7+j) . khi
         o[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), klo, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), khi, 0u, false), false);
         o[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), klo, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), khi, 0u, false), false);
         o[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), klo, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), khi, 0u, false), false);
@@ -827,12 +747,34 @@ __global__ __launch_bounds__(256) void k_blur(OrbParams P, int level)
         pk.y = o[2] | (o[3] << 16);
         *reinterpret_cast<uint2 *>(&hz[r * BL_TW + 4 * c4]) = pk;
     }
+    // ---- FAST phase 1: compass test, one group of 4 pixels (two pairs, one 3-dword window) per task
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int gi = tid + 256 * k;
+        const int row = gi >> 4, g = gi & 15;
+        uint32_t rw[5][3];
+        const int rsel[5] = {0, 1, 3, 5, 6};            // rows -3,-2,0,+2,+3
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+            const uint32_t *q = &in[(row + rsel[r]) * (FS_IP / 4) + g];
+            rw[r][0] = q[0]; rw[r][1] = q[1]; rw[r][2] = q[2];
+        }
+        const bool pass[2] = {fast_compass<0>(rw, th), fast_compass<2>(rw, th)};
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const unsigned long long bal = __ballot(pass[j]);
+            int base = 0;
+            if (lane == 0 && bal) base = atomicAdd(&qn, __popcll(bal));
+            base = __shfl(base, 0, 64);
+            if (pass[j]) queue[base + __popcll(bal & ((1ull << lane) - 1))] = (uint16_t)(row * 32 + 2 * g + j);
+        }
+    }
     __syncthreads();
-    // ---- C
+    // ---- blur column pass (C of k_blur)
     const int k0 = P.gauss_q8[0], k1 = P.gauss_q8[1], k2 = P.gauss_q8[2], k3 = P.gauss_q8[3];
-    uint8_t *dst = L.blur + (size_t)frame * L.blur_frame_stride;
+    uint8_t *bdst = L.blur + (size_t)frame * L.blur_frame_stride;
     {
-        const int c4 = tid & 15, rg = tid >> 4;          // 16 column groups x 16 row groups (2 rows each)
+        const int c4 = tid & 15, rg = tid >> 4;
         const int x = x0 + 4 * c4;
         if (x < w) {
             uint2 rows[8];
@@ -855,19 +797,44 @@ __global__ __launch_bounds__(256) void k_blur(OrbParams P, int level)
                         sacc = (sacc + 32768) >> 16;
                         packed |= (uint32_t)min(sacc, 255) << (8 * j);
                     }
-                    *reinterpret_cast<uint32_t *>(dst + (size_t)y * L.blur_pitch + x) = packed;   // pitch % 64 == 0
+                    *reinterpret_cast<uint32_t *>(bdst + (size_t)y * L.blur_pitch + x) = packed;
                 }
             }
         }
     }
+    // ---- FAST phase 2: full arc score of the surviving pairs, one pair per lane
+    const int nq = qn;
+    uint16_t *out16 = reinterpret_cast<uint16_t *>(outt);
+    for (int q0 = 0; q0 < nq; q0 += 256) {
+        const int qi = q0 + tid;
+        const int p = qi < nq ? queue[qi] : queue[0];
+        const int row = p >> 5, pc = p & 31;
+        uint32_t rows[7][3];
+        fs_window(in, row, pc, rows);
+        s16x2 S = (s16x2){0, 0};
+        fast_pair_score<0>(rows, th, &S);
+        if (qi < nq) {
+            const uint32_t lo = S.x > th ? (uint32_t)(S.x - 1) : 0u, hi = S.y > th ? (uint32_t)(S.y - 1) : 0u;
+            out16[row * (FS_TW / 2) + pc] = (uint16_t)(lo | (hi << 8));
+        }
+    }
+    __syncthreads();
+    uint8_t *sdst = L.score + (size_t)frame * L.score_frame_stride;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int i = tid + 256 * k;
+        const int row = i >> 4, g = i & 15;
+        const int x = x0 + 4 * g, y = y0 + row;
+        if (x < w && y < h) *reinterpret_cast<uint32_t *>(sdst + (size_t)y * L.score_pitch + x) = outt[i];
+    }
 }
 
-void orb_launch_blur(const OrbParams &P, hipStream_t s)
+void orb_launch_blur_score(const OrbParams &P, hipStream_t s)
 {
     for (int l = 0; l < P.nlevels; l++) {
         const OrbLevel &L = P.lv[l];
         dim3 grid((L.w + BL_TW - 1) / BL_TW, (L.h + BL_TH - 1) / BL_TH, P.batch);
-        hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, s, P, l);
+        hipLaunchKernelGGL(k_blur_score, grid, dim3(256), 0, s, P, l);
     }
 }
 

@@ -362,12 +362,12 @@ static int run_pipeline(orbhip_extractor *e, int batch, int lap0, int lap1)
 #define STAGE_MARK(i) do { if (prof) HIP_TRY(hipEventRecord(e->ev[slot][i], s)); } while (0)
     STAGE_MARK(ORBHIP_STAGE_PYRAMID);
     for (int l = 1; l < e->nlevels; l++) orb_launch_resize(P, l, s);
-    STAGE_MARK(ORBHIP_STAGE_FAST);
-    orb_launch_fast(P, s);
+    STAGE_MARK(ORBHIP_STAGE_BLUR_SCORE);
+    orb_launch_blur_score(P, s);
+    STAGE_MARK(ORBHIP_STAGE_FAST_CELLS);
+    orb_launch_fast_cells(P, s);
     STAGE_MARK(ORBHIP_STAGE_OCTREE);
     orb_launch_octree(P, s);
-    STAGE_MARK(ORBHIP_STAGE_BLUR);
-    orb_launch_blur(P, s);
     STAGE_MARK(ORBHIP_STAGE_DESC);
     orb_launch_orient_desc(P, s);
     STAGE_MARK(ORBHIP_STAGE_ASSEMBLE);
