@@ -257,6 +257,16 @@ def main():
         launches = {"pyramid": 7, "blur_score": 8, "desc": 1}[dom]
         dom_bytes = ab[dom] * B
         achieved = dom_bytes / (stage[dom] * 1e-3) / 1e9 if stage[dom] > 0 else 0.0
+        # HBM traffic of the dominant kernel: PMC counters are collected in separate rocprofv3 passes (they cannot be
+        # read from inside this process); the per-step sums of the committed pass are reported when the workload matches.
+        traffic, traffic_src = None, None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if (W, H, B, args.nfeatures) == (640, 480, 1024, 1000) and kern[dom] in pmc["kernels"]:
+                traffic = pmc["kernels"][kern[dom]]["hbm_bytes_per_step"]
+                traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per step)"
+        except Exception:
+            pass
         out = {
             "metric": "ORB extract+match frames/sec", "value": round(fps, 1), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
@@ -272,7 +282,7 @@ def main():
                        "end_to_end_algorithmic_GBps": round(ab["total"] * B * args.steps / dt / 1e9, 2)},
             "roofline": {"bound": "hbm", "kernel": kern[dom], "stage": dom, "launches_per_step": launches,
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_step": int(dom_bytes)},
         }
         if ba is not None:

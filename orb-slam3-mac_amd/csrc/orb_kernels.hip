@@ -41,6 +41,16 @@ __device__ __forceinline__ int block_excl_scan256(int v, int *wsum, int *total)
     return base + inc - v;
 }
 
+// XCD-aware workgroup order (speed only, never correctness): workgroups are dealt round-robin over the
+// 8 XCDs, so raw neighbours b, b+1 sit on different L2s.  This bijection gives every XCD one contiguous
+// range of logical ids, so that tiles sharing 128-byte lines (horizontal neighbours, vertical aprons,
+// consecutive frames) are fetched from HBM by one L2 instead of up to eight.
+__device__ __forceinline__ unsigned xcd_logical_id(unsigned bid, unsigned nblocks)
+{
+    const unsigned q = nblocks >> 3, r = nblocks & 7, k = bid & 7, j = bid >> 3;
+    return k * q + min(k, r) + j;
+}
+
 __device__ __forceinline__ int wave_sum(int v)
 {
 #pragma unroll
@@ -68,8 +78,11 @@ __global__ __launch_bounds__(256) void k_resize(OrbParams P, int level)
     __shared__ uint16_t hz[RS_MAXR * RS_TW];
     const OrbLevel &D = P.lv[level];
     const OrbLevel &S = P.lv[level - 1];
-    const int tid = threadIdx.x, frame = blockIdx.z;
-    const int dx0 = blockIdx.x * RS_TW, dy0 = blockIdx.y * RS_TH;
+    const int tid = threadIdx.x;
+    const int ntx = (D.w + RS_TW - 1) / RS_TW, nty = (D.h + RS_TH - 1) / RS_TH;
+    const unsigned lid = xcd_logical_id(blockIdx.x, gridDim.x);
+    const int frame = lid / (ntx * nty), trem = lid - frame * (ntx * nty);
+    const int dx0 = (trem % ntx) * RS_TW, dy0 = (trem / ntx) * RS_TH;
     const int dx_last = min(dx0 + RS_TW, D.w) - 1, dy_last = min(dy0 + RS_TH, D.h) - 1;
     const int ybase = D.yofs[dy0];                                   // may be -1
     const int nrows = min(D.yofs[dy_last] + 1 - ybase + 1, RS_MAXR);
@@ -148,8 +161,8 @@ __global__ __launch_bounds__(256) void k_resize(OrbParams P, int level)
 void orb_launch_resize(const OrbParams &P, int level, hipStream_t s)
 {
     const OrbLevel &D = P.lv[level];
-    dim3 grid((D.w + RS_TW - 1) / RS_TW, (D.h + RS_TH - 1) / RS_TH, P.batch);
-    hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, P, level);
+    const unsigned nblocks = (unsigned)(((D.w + RS_TW - 1) / RS_TW) * ((D.h + RS_TH - 1) / RS_TH)) * (unsigned)P.batch;
+    hipLaunchKernelGGL(k_resize, dim3(nblocks), dim3(256), 0, s, P, level);
 }
 
 // ----------------------------------------------------------------------------------
@@ -266,8 +279,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbParams P)
 {
     __shared__ uint32_t sc_all[4][FC_ROWS * (FC_TP / 4)];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int frame = blockIdx.y;
-    const int cell = blockIdx.x * 4 + wv;
+    const int bpf = (P.cells_per_frame + 3) >> 2;              // workgroups per frame
+    const unsigned lid = xcd_logical_id(blockIdx.x, gridDim.x);
+    const int frame = lid / bpf;
+    const int cell = (lid - frame * bpf) * 4 + wv;
     if (cell >= P.cells_per_frame) return;
     int lvl = 0;
     for (int l = 1; l < P.nlevels; l++) if (cell >= P.lv[l].cell_base) lvl = l;
@@ -373,8 +388,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbParams P)
 
 void orb_launch_fast_cells(const OrbParams &P, hipStream_t s)
 {
-    dim3 grid((P.cells_per_frame + 3) / 4, P.batch);
-    hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, s, P);
+    const unsigned nblocks = (unsigned)((P.cells_per_frame + 3) / 4) * (unsigned)P.batch;
+    hipLaunchKernelGGL(k_fast_cells, dim3(nblocks), dim3(256), 0, s, P);
 }
 
 // ----------------------------------------------------------------------------------
@@ -695,10 +710,13 @@ __global__ __launch_bounds__(256) void k_blur_score(OrbParams P, int level)
     __shared__ uint16_t queue[FS_TH * FS_TW / 2];
     __shared__ int qn;
     const OrbLevel &L = P.lv[level];
-    const int tid = threadIdx.x, lane = tid & 63, frame = blockIdx.z;
-    const int x0 = blockIdx.x * BL_TW, y0 = blockIdx.y * BL_TH;
-    const uint8_t *src = L.img + (size_t)frame * L.img_frame_stride;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int w = L.w, h = L.h, th = P.min_th;
+    const int ntx = (w + BL_TW - 1) / BL_TW, nty = (h + BL_TH - 1) / BL_TH;
+    const unsigned lid = xcd_logical_id(blockIdx.x, gridDim.x);
+    const int frame = lid / (ntx * nty), trem = lid - frame * (ntx * nty);
+    const int x0 = (trem % ntx) * BL_TW, y0 = (trem / ntx) * BL_TH;
+    const uint8_t *src = L.img + (size_t)frame * L.img_frame_stride;
     // ---- stage: 684 dwords = 3 per thread, all loads before the LDS stores
     {
         uint32_t reg[3];
@@ -833,8 +851,8 @@ void orb_launch_blur_score(const OrbParams &P, hipStream_t s)
 {
     for (int l = 0; l < P.nlevels; l++) {
         const OrbLevel &L = P.lv[l];
-        dim3 grid((L.w + BL_TW - 1) / BL_TW, (L.h + BL_TH - 1) / BL_TH, P.batch);
-        hipLaunchKernelGGL(k_blur_score, grid, dim3(256), 0, s, P, l);
+        const unsigned nblocks = (unsigned)(((L.w + BL_TW - 1) / BL_TW) * ((L.h + BL_TH - 1) / BL_TH)) * (unsigned)P.batch;
+        hipLaunchKernelGGL(k_blur_score, dim3(nblocks), dim3(256), 0, s, P, l);
     }
 }
 
