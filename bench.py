@@ -227,6 +227,7 @@ def main():
             dist.barrier()
         dt_ba = time.perf_counter() - t0
         gemm_ms, gemm_n, gemm_fl = bb.gemm_profile()
+        gemm_dense = bb.gemm_dense_flops()
         ticks = bb.ticks
         _, _, _, stats = bb.download()
         bb.close()
@@ -244,7 +245,7 @@ def main():
                            "peak": round(peak64, 2), "unit": "TFLOP/s", "frac": round(tfl / peak64, 4) if peak64 else None,
                            "traffic": None, "peak_source": "measured v_mfma_f64_16x16x4_f64 micro-benchmark on this device",
                            "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),
-                           "flops_per_launch_dense_padded": gemm_fl}}
+                           "mfma_flops_issued_per_launch": gemm_fl, "flops_per_launch_without_sparsity_skipping": gemm_dense}}
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3

@@ -226,6 +226,7 @@ void orbhip_ba_batch_destroy(orbhip_ba_batch *b);
  * MFMA flops one launch issues, and a measured FP64 matrix-core peak for this device. */
 int orbhip_ba_batch_set_profiling(orbhip_ba_batch *b, int enable);
 int orbhip_ba_batch_gemm_profile(const orbhip_ba_batch *b, float *total_ms, int *launches, double *flops_per_launch);
+double orbhip_ba_batch_gemm_dense_flops(const orbhip_ba_batch *b);   /* same tiles without block-sparsity skipping */
 int orbhip_mfma_f64_peak_tflops(orbhip_ctx *ctx, double *tflops_out);
 
 #ifdef __cplusplus

@@ -33,12 +33,13 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------ device structures
 struct BaGraphDev {
-    int n_poses, n_points, n_edges, nf, n, ld;      // n = 6*nf, ld = n rounded up to 48
+    int n_poses, n_points, n_edges, nf, n, ld;      // n = 6*nf, ld = n rounded up to 96
     int pose_off, point_off, edge_off, free_off;     // offsets into the concatenated arrays
     int ptstart_off, posestart_off;                  // into pt_start / pose_start (+g extra entries)
     size_t wd_off, s_off, spart_off, xl_off;         // element offsets
-    int ks;                                          // split-K factor of the Schur GEMM
-    int ksteps;                                      // K steps (points) per split
+    int ks;                                          // split-K factor of the Schur GEMM (point chunks)
+    int nt16;                                        // 16-column tiles per side (ld / 16)
+    int ngrp;                                        // tile groups (each workgroup keeps <= GEMM_WAVES*GEMM_TPW tiles in registers)
     double fx, fy, cx, cy, bf;
 };
 
@@ -72,6 +73,7 @@ struct BaBatch {      // kernel argument (by value)
     double *Hll, *bl, *Dinv, *db;        // [sumL*6] [sumL*3] [sumL*6] [sumL*3]
     double *Hpp, *bp, *bs;               // [sumF*36] [sumF*6] [sumF*6]
     double *Wd;                          // per graph [4*L][ld]
+    const uint32_t *ptmask;              // [sumL] bit t: the point's Hpl column is non-zero inside columns [16t, 16t+16) (static)
     double *S, *Spart;                   // per graph [ld*ld], [ks][ld*ld]
     double *xp, *xl;                     // [sumF*6], [sumL*3]
     double *scale_pt, *scale_pose;       // partial sums of computeScale
@@ -452,66 +454,113 @@ __global__ __launch_bounds__(256) void k_ba_point_prep(BaBatch B)
     db[2] = i02 * b[0] + i12 * b[1] + i22 * b[2];
 }
 
-// Schur GEMM on the FP64 matrix cores:  Spart[ks] (upper 48x48 wave tiles) =
-//   sum over points l in the split of  (D_l^-1 Wd_l)^T(rows r0..) x Wd_l(cols c0..)
-// v_mfma_f64_16x16x4_f64: A[i][k] (lane i=l&15,k=l>>4), B[k][j] (lane j=l&15,k=l>>4),
-// C/D: 4 regs, col = l&15, row = (l>>4) + 4*reg.  K = 4 per point (3 + zero pad).
-// One wave per (tile_r <= tile_c, split) work item; D^-1 is applied to the A fragment in
-// registers, so no second dense panel is materialised.
-__global__ __launch_bounds__(256) void k_ba_schur_gemm(BaBatch B)
+// Schur GEMM on the FP64 matrix cores:  S_sub = (D^-1 Wd)^T Wd  over the K-padded dense panel
+// Wd[4l+b][c] (K = 4 per point: 3 + zero pad), v_mfma_f64_16x16x4_f64:
+//   A[i][k] (lane i=l&15,k=l>>4), B[k][j] (lane j=l&15,k=l>>4), C/D 4 regs: col = l&15, row = (l>>4) + 4*reg.
+// One 512-thread workgroup (8 waves, up to 256 VGPRs each) owns a chunk of points of one graph.  The chunk's three Wd rows per point
+// are streamed through LDS ONCE (GEMM_PS points per stage) and every wave keeps its share of the upper
+// 16x16 output tiles (<= GEMM_TPW consecutive tiles per wave) in accumulator registers, so HBM/L2
+// sees each Wd byte once per launch instead of once per output tile.  Block sparsity: a point is seen
+// by ~10 of ~48 free keyframes; its static 16-column occupancy mask turns ~79 % of the (point, tile)
+// MFMAs into a wave-uniform scalar branch.  D^-1 is applied to the A fragment in registers.
+#define GEMM_PS 8
+#define GEMM_TPW 22
+#define GEMM_WAVES 8
+__global__ __launch_bounds__(64 * GEMM_WAVES) void k_ba_schur_gemm(BaBatch B)
 {
+    extern __shared__ double glds[];               // [2][GEMM_PS][4][ld] staged Wd rows (row 3 = zero pad), double buffered
+    __shared__ double s_dinv[2][GEMM_PS][6];
+    __shared__ uint32_t s_mask[2][GEMM_PS];
     const int g = blockIdx.y;
     const BaState &st = B.st[g];
     if (!st.active) return;
     const BaGraphDev &G = B.gd[g];
-    const int nt = G.ld / 48;
-    const int ntiles = nt * (nt + 1) / 2;
-    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= ntiles * G.ks) return;
-    const int lane = threadIdx.x & 63;
-    const int ksi = item / ntiles;
-    int t = item - ksi * ntiles, tr = 0;
-    while (t >= nt - tr) { t -= nt - tr; tr++; }
-    const int tc = tr + t;
-    const int r0 = tr * 48, c0 = tc * 48;
-    const int l0 = ksi * G.ksteps, l1 = min(G.n_points, l0 + G.ksteps);
+    const int nt = G.nt16, ntiles = nt * (nt + 1) / 2;
+    if ((int)blockIdx.x >= G.ks * G.ngrp) return;
+    const int ksi = blockIdx.x / G.ngrp, grp = blockIdx.x - ksi * G.ngrp;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lk = lane >> 4;
-    v4d acc[3][3];
+    const int ld = G.ld;
+    // this wave's tiles: GEMM_TPW CONSECUTIVE tiles of the row-major upper-triangle enumeration, so they span
+    // at most a few row strips and the A fragment (which depends on the row tile only) is reused along a strip.
+    // tr/tc/need are wave-uniform -> scalar registers.
+    int trs[GEMM_TPW], tcs[GEMM_TPW];
+    uint32_t need[GEMM_TPW];
+    v4d acc[GEMM_TPW];
+    uint32_t rowbits = 0;                              // row tiles this wave touches
 #pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++) acc[i][j] = (v4d){0, 0, 0, 0};
+    for (int s = 0; s < GEMM_TPW; s++) {
+        acc[s] = (v4d){0, 0, 0, 0};
+        int t = (grp * GEMM_WAVES + wv) * GEMM_TPW + s, tr = 0;
+        if (t < ntiles) {
+            while (t >= nt - tr) { t -= nt - tr; tr++; }
+            trs[s] = tr; tcs[s] = tr + t; need[s] = (1u << tr) | (1u << (tr + t)); rowbits |= 1u << tr;
+        } else { trs[s] = -1; tcs[s] = -1; need[s] = 0xFFFFFFFFu; }
+    }
+    const int per = (G.n_points + G.ks - 1) / G.ks;
+    const int l0 = ksi * per, l1 = min(G.n_points, l0 + per);
     const double *Wd = B.Wd + G.wd_off;
     const double *Dv = B.Dinv + (size_t)G.point_off * 6;
-    for (int l = l0; l < l1; l++) {
-        const double *row = Wd + (size_t)(4 * l) * G.ld;
-        const double *Di = Dv + (size_t)l * 6;
-        // row lk of the symmetric D^-1 (row 3 = zero padding)
-        double d0 = 0, d1 = 0, d2 = 0;
-        if (lk == 0) { d0 = Di[0]; d1 = Di[1]; d2 = Di[2]; }
-        else if (lk == 1) { d0 = Di[1]; d1 = Di[3]; d2 = Di[4]; }
-        else if (lk == 2) { d0 = Di[2]; d1 = Di[4]; d2 = Di[5]; }
-        double a[3], b[3];
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-            const double *p = row + r0 + 16 * i + li;
-            a[i] = d0 * p[0] + d1 * p[G.ld] + d2 * p[2 * (size_t)G.ld];
-            b[i] = row[(size_t)lk * G.ld + c0 + 16 * i + li];
+    const uint32_t *pm = B.ptmask + G.point_off;
+    const int s0 = lk == 0 ? 0 : lk == 1 ? 1 : 2, s1 = lk == 0 ? 1 : lk == 1 ? 3 : 4, s2 = lk == 0 ? 2 : lk == 1 ? 4 : 5;
+    const double live = lk < 3 ? 1.0 : 0.0;
+    // double-buffered stages: the LDS-DMA of stage k+1 is in flight while stage k is multiplied
+    const size_t stage_doubles = (size_t)GEMM_PS * 4 * ld;
+    auto issue_stage = [&](int lb, int buf) {
+        const int np = min(GEMM_PS, l1 - lb);
+        // ordinary loads first: hipcc waits vmcnt(0) at the first use of an ordinary load while an LDS-DMA is in
+        // flight, which would drain the prefetch -- so nothing but LDS-DMA is outstanding after this point
+        if (tid < np * 6) s_dinv[buf][tid / 6][tid % 6] = Dv[(size_t)(lb + tid / 6) * 6 + tid % 6];
+        if (tid < np) s_mask[buf][tid] = pm[lb + tid];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // asynchronous global -> LDS copy (global_load_lds_dwordx4): a point's four K-rows are one contiguous
+        // block of 4*ld doubles = ld/32 pieces of 1 KiB; no staging registers, all pieces in flight at once
+        const int ppp = ld >> 5;                            // 1-KiB pieces per point (ld is a multiple of 32)
+        for (int piece = wv; piece < np * ppp; piece += GEMM_WAVES) {
+            const int p = piece / ppp, k = piece - p * ppp;
+            const char *gsrc = reinterpret_cast<const char *>(Wd + (size_t)(4 * (lb + p)) * ld) + k * 1024 + lane * 16;
+            char *ldst = reinterpret_cast<char *>(glds + buf * stage_doubles) + ((size_t)p * 4 * ld * 8) + k * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                             (__attribute__((address_space(3))) void *)ldst, 16, 0, 0);
         }
+    };
+    if (l0 < l1) issue_stage(l0, 0);
+    int cur = 0;
+    for (int lb = l0; lb < l1; lb += GEMM_PS, cur ^= 1) {
+        const int np = min(GEMM_PS, l1 - lb);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of the current stage have landed
+        __syncthreads();                                    // ... everyone's have, and stage k-1 is fully consumed
+        if (lb + GEMM_PS < l1) issue_stage(lb + GEMM_PS, cur ^ 1);
+        const double *stage = glds + cur * stage_doubles;
+        for (int p = 0; p < np; p++) {
+            const uint32_t mask = __builtin_amdgcn_readfirstlane(s_mask[cur][p]);
+            if ((mask & rowbits) == 0) continue;            // the point touches none of this wave's row strips
+            const double *rows = stage + (size_t)p * 4 * ld;
+            const double d0 = s_dinv[cur][p][s0], d1 = s_dinv[cur][p][s1], d2 = s_dinv[cur][p][s2];
+            double a = 0.0;
 #pragma unroll
-        for (int i = 0; i < 3; i++)
-#pragma unroll
-            for (int j = 0; j < 3; j++)
-                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+            for (int s = 0; s < GEMM_TPW; s++) {
+                if (s == 0 || trs[s] != trs[s - 1]) {       // new row strip: (re)build the A fragment if the strip is hit
+                    if (trs[s] >= 0 && ((mask >> trs[s]) & 1u)) {
+                        const double *q = rows + 16 * trs[s] + li;
+                        a = live * (d0 * q[0] + d1 * q[ld] + d2 * q[2 * ld]);
+                    }
+                }
+                if ((mask & need[s]) == need[s]) {
+                    const double b = rows[lk * ld + 16 * tcs[s] + li];          // K-row 3 is the zero pad
+                    acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[s], 0, 0, 0);
+                }
+            }
+        }
     }
-    double *Sp = B.Spart + G.spart_off + (size_t)ksi * G.ld * G.ld;
+    double *Sp = B.Spart + G.spart_off + (size_t)ksi * ld * ld;
 #pragma unroll
-    for (int i = 0; i < 3; i++)
+    for (int s = 0; s < GEMM_TPW; s++) {
+        if (trs[s] >= 0) {
 #pragma unroll
-        for (int j = 0; j < 3; j++)
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-                Sp[(size_t)(r0 + 16 * i + lk + 4 * r) * G.ld + c0 + 16 * j + li] = acc[i][j][r];
+            for (int r = 0; r < 4; r++) Sp[(size_t)(16 * trs[s] + lk + 4 * r) * ld + 16 * tcs[s] + li] = acc[s][r];
+        }
+    }
 }
 
 // S = blockdiag(Hpp + lambda I) - sum_ks Spart (mirrored from the upper tiles); padding rows -> identity
@@ -528,7 +577,7 @@ __global__ __launch_bounds__(256) void k_ba_schur_finish(BaBatch B)
     if (r >= G.n || c >= G.n) v = (r == c) ? 1.0 : 0.0;
     else {
         if (r / 6 == c / 6) v = B.Hpp[(size_t)(G.free_off + r / 6) * 36 + (r % 6) * 6 + (c % 6)] + (r == c ? st.lambda : 0.0);
-        const int ur = (r / 48 <= c / 48) ? r : c, uc = (r / 48 <= c / 48) ? c : r;   // upper-tile source
+        const int ur = (r / 16 <= c / 16) ? r : c, uc = (r / 16 <= c / 16) ? c : r;   // upper-tile source
         const double *Sp = B.Spart + G.spart_off + (size_t)ur * G.ld + uc;
         double s = 0;
         for (int k = 0; k < G.ks; k++) s += Sp[(size_t)k * G.ld * G.ld];
@@ -566,17 +615,21 @@ __global__ __launch_bounds__(64) void k_ba_bschur(BaBatch B)
         for (int a = 0; a < 6; a++) B.bs[(size_t)(G.free_off + h) * 6 + a] = B.bp[(size_t)(G.free_off + h) * 6 + a] - acc[a];
 }
 
-// Reduced pose system: dense LDL^T without pivoting + solve, one workgroup per graph
-// (stands in for Eigen::SimplicialLDLT, linear_solver_eigen.h:94-125; fails on a zero /
-// non-finite pivot).  Right-looking, lower triangle of S in global memory (L2-resident),
-// current column and right-hand side in LDS; the forward substitution rides along as an
-// extra row of the elimination.
-#define BA_LDLT_MAXN 768
+// Reduced pose system: dense LDL^T without pivoting + solve, one workgroup per graph (stands in for
+// Eigen::SimplicialLDLT, linear_solver_eigen.h:94-125; fails on a zero / non-finite pivot, in which case
+// x is left untouched exactly as the reference does).
+// Blocked right-looking factorisation: a 32-column panel (all rows below the diagonal block) lives in
+// LDS, is factored there (32 steps of LDS-only updates, the right-hand side rides along), is written
+// back once, and the trailing matrix gets ONE rank-32 update per panel from LDS (4x4 register tiles).
+// The trailing matrix therefore makes 9 instead of 288 round trips through L2 for n = 288.
+#define BA_LDLT_MAXN 480
+#define LD_NB 32
+#define LD_PP 33
+size_t ba_ldlt_lds_bytes(int max_n) { return sizeof(double) * ((size_t)max_n * LD_PP + 2 * (size_t)max_n + LD_NB + 32 * 32); }
+
 __global__ __launch_bounds__(1024) void k_ba_ldlt(BaBatch B)
 {
-    __shared__ double col[BA_LDLT_MAXN];     // unscaled column j below the diagonal
-    __shared__ double y[BA_LDLT_MAXN];       // right-hand side being eliminated
-    __shared__ double s_d;
+    extern __shared__ double lds[];
     __shared__ int s_ok;
     const int g = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
     BaState &st = B.st[g];
@@ -584,39 +637,121 @@ __global__ __launch_bounds__(1024) void k_ba_ldlt(BaBatch B)
     const BaGraphDev &G = B.gd[g];
     const int n = G.n, ld = G.ld;
     double *S = B.S + G.s_off;
+    double *P = lds;                              // panel [rows][LD_PP]
+    double *y = P + (size_t)B.max_ld * LD_PP;     // right-hand side / solution
+    double *dval = y + B.max_ld;                  // pivots d_c of every column
+    double *lcol = dval + B.max_ld;               // scaled current column (max n entries) -- aliases red below
+    double *red = lcol;                           // [32][32] partial sums of the back substitution
+    // NB: lcol needs n entries, red needs 1024: both fit in max(n,1024) doubles reserved by the host
     for (int i = tid; i < n; i += nth) y[i] = B.bs[(size_t)G.free_off * 6 + i];
     if (tid == 0) s_ok = 1;
     __syncthreads();
-    for (int j = 0; j < n; j++) {
-        if (tid == 0) {
-            const double d = S[(size_t)j * ld + j];
-            s_d = d;
-            if (d == 0.0 || !isfinite(d)) s_ok = 0;
+    for (int p0 = 0; p0 < n; p0 += LD_NB) {
+        const int nb = min(LD_NB, n - p0), m = n - p0;
+        for (int idx = tid; idx < m * LD_NB; idx += nth) {
+            const int r = idx >> 5, c = idx & 31;
+            if (c < nb) P[r * LD_PP + c] = S[(size_t)(p0 + r) * ld + p0 + c];
         }
-        for (int i = j + 1 + tid; i < n; i += nth) col[i] = S[(size_t)i * ld + j];
+        __syncthreads();
+        for (int jj = 0; jj < nb; jj++) {
+            const double d = P[jj * LD_PP + jj];
+            if (d == 0.0 || !isfinite(d)) { if (tid == 0) s_ok = 0; break; }      // uniform: every thread reads the same d
+            for (int r = jj + 1 + tid; r < m; r += nth) lcol[r] = P[r * LD_PP + jj] / d;
+            if (tid == 0) dval[p0 + jj] = d;
+            __syncthreads();
+            const int cnt = nb - jj - 1, rows = m - jj - 1;
+            // P[r][kk] -= (col[r]/d) * col[kk]  for jj < kk < nb, r >= kk   (lower triangle only)
+            for (int idx = tid; idx < rows * cnt; idx += nth) {
+                const int r = jj + 1 + idx / cnt, kk = jj + 1 + idx % cnt;
+                if (r >= kk) P[r * LD_PP + kk] -= lcol[r] * P[kk * LD_PP + jj];
+            }
+            const double yj = y[p0 + jj];
+            for (int r = jj + 1 + tid; r < m; r += nth) y[p0 + r] -= lcol[r] * yj;   // forward substitution rides along
+            __syncthreads();
+            for (int r = jj + 1 + tid; r < m; r += nth) P[r * LD_PP + jj] = lcol[r];  // column jj now holds L
+            // (column jj is not read again inside this panel; the barrier at the top of the next step orders lcol reuse)
+            __syncthreads();
+        }
         __syncthreads();
         if (!s_ok) break;
-        const double d = s_d, yj = y[j];
-        const int m = n - j - 1;
-        // trailing update of the lower triangle: S[i][k] -= (col[i]/d) * col[k],  j < k <= i < n
-        for (int t = tid; t < m * m; t += nth) {
-            const int i = j + 1 + t / m, k = j + 1 + t % m;
-            if (k <= i) S[(size_t)i * ld + k] -= (col[i] / d) * col[k];
+        // write the factored panel back: L below the diagonal, d on it
+        for (int idx = tid; idx < m * LD_NB; idx += nth) {
+            const int r = idx >> 5, c = idx & 31;
+            if (c < nb && r >= c) S[(size_t)(p0 + r) * ld + p0 + c] = (r == c) ? dval[p0 + c] : P[r * LD_PP + c];
         }
-        for (int i = j + 1 + tid; i < n; i += nth) {
-            S[(size_t)i * ld + j] = col[i] / d;          // L
-            y[i] -= (col[i] / d) * yj;                   // forward substitution
+        // trailing update S[i][k] -= sum_c L[i][c] d_c L[k][c]  (i >= k >= p0+nb), 4x4 register tiles
+        const int m2 = m - nb;
+        if (m2 > 0) {
+            const int T = (m2 + 3) >> 2;
+            for (int t = tid; t < T * T; t += nth) {
+                const int ti = t / T, tk = t - ti * T;
+                if (ti < tk) continue;
+                const int i0 = nb + 4 * ti, k0 = nb + 4 * tk;
+                double acc[4][4];
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+#pragma unroll
+                    for (int b2 = 0; b2 < 4; b2++) acc[a][b2] = 0.0;
+                for (int c = 0; c < nb; c++) {
+                    const double dc = dval[p0 + c];
+                    double av[4], bv[4];
+#pragma unroll
+                    for (int a = 0; a < 4; a++) {
+                        av[a] = (i0 + a < m) ? P[(i0 + a) * LD_PP + c] * dc : 0.0;
+                        bv[a] = (k0 + a < m) ? P[(k0 + a) * LD_PP + c] : 0.0;
+                    }
+#pragma unroll
+                    for (int a = 0; a < 4; a++)
+#pragma unroll
+                        for (int b2 = 0; b2 < 4; b2++) acc[a][b2] += av[a] * bv[b2];
+                }
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+#pragma unroll
+                    for (int b2 = 0; b2 < 4; b2++)
+                        if (i0 + a < m && k0 + b2 < m && i0 + a >= k0 + b2)
+                            S[(size_t)(p0 + i0 + a) * ld + p0 + k0 + b2] -= acc[a][b2];
+            }
         }
         __syncthreads();
     }
     __syncthreads();
     if (!s_ok) { if (tid == 0) st.ok = 0; return; }      // x untouched (as the reference on failure)
-    // y <- D^-1 y ; back substitution with rows of L (contiguous)
-    for (int i = tid; i < n; i += nth) y[i] /= S[(size_t)i * ld + i];
+    // y <- D^-1 y, then L^T x = y panel by panel from the bottom
+    for (int i = tid; i < n; i += nth) y[i] /= dval[i];
     __syncthreads();
-    for (int i = n - 1; i >= 0; i--) {
-        const double xi = y[i];
-        for (int k = tid; k < i; k += nth) y[k] -= S[(size_t)i * ld + k] * xi;
+    const int last_p0 = ((n - 1) / LD_NB) * LD_NB;
+    for (int p0 = last_p0; p0 >= 0; p0 -= LD_NB) {
+        const int nb = min(LD_NB, n - p0), m = n - p0;
+        // contributions of the rows below the diagonal block: t_c = sum_{r >= nb} L[p0+r][p0+c] x[p0+r]
+        {
+            const int c = tid & 31, rg = tid >> 5;          // 1024 threads = 32 columns x 32 row groups
+            double part = 0.0;
+            if (c < nb)
+                for (int r = nb + rg; r < m; r += 32) part += S[(size_t)(p0 + r) * ld + p0 + c] * y[p0 + r];
+            red[rg * 32 + c] = part;
+        }
+        for (int idx = tid; idx < nb * LD_NB; idx += nth) {   // diagonal block of L into LDS
+            const int r = idx >> 5, c = idx & 31;
+            if (c < nb) P[r * LD_PP + c] = S[(size_t)(p0 + r) * ld + p0 + c];
+        }
+        __syncthreads();
+        if (tid < nb) {
+            double t = 0.0;
+            for (int rg = 0; rg < 32; rg++) t += red[rg * 32 + tid];
+            y[p0 + tid] -= t;
+        }
+        __syncthreads();
+        if (tid < 64) {                                       // 32x32 triangular solve inside one wave
+            for (int jj = nb - 1; jj >= 0; jj--) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const double xj = y[p0 + jj];
+                if (tid < jj) y[p0 + tid] -= P[jj * LD_PP + tid] * xj;
+            }
+        }
         __syncthreads();
     }
     for (int i = tid; i < n; i += nth) B.xp[(size_t)G.free_off * 6 + i] = y[i];
@@ -757,6 +892,7 @@ struct orbhip_ba_batch {
     hipEvent_t ev0, ev1;
     float gemm_ms_total; int gemm_launches;
     double gemm_flops_per_launch;            // MFMA flops actually issued by one launch (all graphs)
+    double gemm_flops_dense;                 // what the same upper tiles would cost without block-sparsity skipping
 };
 
 template <typename T>
@@ -798,11 +934,12 @@ extern "C" int orbhip_ba_batch_create(orbhip_ctx *ctx, const orbhip_ba_graph *gr
     if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
     orbhip_ba_batch *b = new orbhip_ba_batch();
     b->ctx = ctx; b->h_n_active = nullptr; b->ticks_last = 0;
-    b->profile = false; b->ev0 = b->ev1 = nullptr; b->gemm_ms_total = 0; b->gemm_launches = 0; b->gemm_flops_per_launch = 0;
+    b->profile = false; b->ev0 = b->ev1 = nullptr; b->gemm_ms_total = 0; b->gemm_launches = 0; b->gemm_flops_per_launch = 0; b->gemm_flops_dense = 0;
     BaBatch &B = b->B;
     memset(&B, 0, sizeof(B));
     B.G = n_graphs;
     std::vector<int> hidx, epose, epoint, ptstart, posestart, poseedges;
+    std::vector<uint32_t> ptmask;
     std::vector<double> eobs, eis2;
     std::vector<uint8_t> est;
     int sumP = 0, sumL = 0, sumE = 0, sumF = 0;
@@ -824,8 +961,8 @@ extern "C" int orbhip_ba_batch_create(orbhip_ctx *ctx, const orbhip_ba_graph *gr
         }
         int nf = 0;
         for (int i = 0; i < H.n_poses; i++) { local_h[i] = (!H.pose_fixed[i] && has[i]) ? nf++ : -1; hidx.push_back(local_h[i]); }
-        D.nf = nf; D.n = 6 * nf; D.ld = std::max(48, (D.n + 47) / 48 * 48);
-        if (D.n > BA_LDLT_MAXN) { delete b; g_ba_error = "too many free keyframes for the single-workgroup LDLT (max 128)"; return ORBHIP_E_BADARG; }
+        D.nf = nf; D.n = 6 * nf; D.ld = std::max(96, (D.n + 95) / 96 * 96);   // multiple of 16 (MFMA tiles) and of 32 (1-KiB LDS-DMA pieces)
+        if (D.n > BA_LDLT_MAXN) { delete b; g_ba_error = "too many free keyframes for the LDS-panel LDLT (max 80)"; return ORBHIP_E_BADARG; }
         D.ptstart_off = (int)ptstart.size();
         std::vector<int> cnt(H.n_points + 1, 0);
         for (int e = 0; e < H.n_edges; e++) cnt[H.edge_point[e] + 1]++;
@@ -844,12 +981,24 @@ extern "C" int orbhip_ba_batch_create(orbhip_ctx *ctx, const orbhip_ba_graph *gr
             eobs.push_back(H.edge_obs[3 * e]); eobs.push_back(H.edge_obs[3 * e + 1]); eobs.push_back(H.edge_obs[3 * e + 2]);
             eis2.push_back(H.edge_inv_sigma2[e]); est.push_back(H.edge_stereo ? H.edge_stereo[e] : 0);
         }
-        const int nt = D.ld / 48, ntiles = nt * (nt + 1) / 2;
-        int ks = (4096 + n_graphs * ntiles - 1) / (n_graphs * ntiles);
-        ks = std::max(1, std::min(ks, 64));
-        ks = std::min(ks, std::max(1, H.n_points / 8));
-        D.ks = ks; D.ksteps = (H.n_points + ks - 1) / ks;
-        b->gemm_flops_per_launch += (double)ntiles * 9.0 * 2048.0 * (double)H.n_points;   // 9 MFMA 16x16x4 per tile per point
+        const int nt = D.ld / 16, ntiles = nt * (nt + 1) / 2;
+        D.nt16 = nt; D.ngrp = (ntiles + GEMM_WAVES * GEMM_TPW - 1) / (GEMM_WAVES * GEMM_TPW);
+        // split the points so that ~2 workgroups per CU are in flight (each streams its chunk of Wd once)
+        int ks = (512 + n_graphs * D.ngrp - 1) / (n_graphs * D.ngrp);
+        ks = std::max(1, std::min(ks, std::max(1, H.n_points / (4 * GEMM_PS))));
+        D.ks = ks;
+        {   // static block-sparsity masks: 16-column tiles of the point's Hpl column that hold a non-zero block
+            double issued = 0;
+            for (int l = 0; l < H.n_points; l++) ptmask.push_back(0u);
+            uint32_t *pmv = ptmask.data() + (ptmask.size() - H.n_points);
+            for (int e = 0; e < H.n_edges; e++) {
+                const int h = local_h[H.edge_pose[e]];
+                if (h >= 0) pmv[H.edge_point[e]] |= (1u << ((6 * h) >> 4)) | (1u << ((6 * h + 5) >> 4));
+            }
+            for (int l = 0; l < H.n_points; l++) { const double k = __builtin_popcount(pmv[l]); issued += k * (k + 1) / 2; }
+            b->gemm_flops_per_launch += issued * 2048.0;                               // one 16x16x4 f64 MFMA (2048 flop) per (point, upper tile) hit
+            b->gemm_flops_dense += (double)ntiles * 2048.0 * (double)H.n_points;        // same tiles without the masks
+        }
         D.wd_off = wd; wd += (size_t)4 * H.n_points * D.ld;
         D.s_off = s; s += (size_t)D.ld * D.ld;
         D.spart_off = sp; sp += (size_t)ks * D.ld * D.ld;
@@ -875,6 +1024,7 @@ extern "C" int orbhip_ba_batch_create(orbhip_ctx *ctx, const orbhip_ba_graph *gr
 #define AL(dst, T, n) do { auto *_p = ba_alloc<T>(b, n); ok = ok && _p; dst = _p; } while (0)
     UP(B.gd, b->gd); UP(B.hidx, hidx); UP(B.edge_pose, epose); UP(B.edge_point, epoint); UP(B.edge_obs, eobs);
     UP(B.edge_is2, eis2); UP(B.edge_stereo, est); UP(B.pt_start, ptstart); UP(B.pose_start, posestart); UP(B.pose_edges, poseedges);
+    UP(B.ptmask, ptmask);
     AL(B.st, BaState, n_graphs);
     AL(B.poses, double, (size_t)2 * sumP * 7); AL(B.points, double, (size_t)2 * sumL * 3);
     AL(B.err, double, (size_t)sumE * 3); AL(B.chi2, double, sumE); AL(B.rho0, double, sumE);
@@ -929,7 +1079,11 @@ extern "C" int orbhip_ba_batch_solve(orbhip_ba_batch *b, const orbhip_ba_params 
     const dim3 ge((B.max_edges + 255) / 256, G), gp128((B.max_points + 127) / 128, G), gp256((B.max_points + 255) / 256, G);
     const dim3 gf(std::max(B.max_nf, 1), G);
     int max_items = 0, max_poses = 0;
-    for (auto &D : b->gd) { const int nt = D.ld / 48; max_items = std::max(max_items, nt * (nt + 1) / 2 * D.ks); max_poses = std::max(max_poses, D.n_poses); }
+    for (auto &D : b->gd) { max_items = std::max(max_items, D.ks * D.ngrp); max_poses = std::max(max_poses, D.n_poses); }
+    const size_t gemm_lds = sizeof(double) * 2 * GEMM_PS * 4 * (size_t)B.max_ld;
+    TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_schur_gemm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds));
+    const size_t ldlt_lds = ba_ldlt_lds_bytes(B.max_ld);
+    TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_ldlt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldlt_lds));
     const int max_ticks = (params->iters1 + params->iters2) * params->max_trials + 4;
     int tick = 0;
     for (; tick < max_ticks && n_active > 0; tick++) {
@@ -942,11 +1096,11 @@ extern "C" int orbhip_ba_batch_solve(orbhip_ba_batch *b, const orbhip_ba_params 
         hipLaunchKernelGGL(k_ba_pretrial, dim3((G + 63) / 64), dim3(64), 0, s, B);
         hipLaunchKernelGGL(k_ba_point_prep, gp256, dim3(256), 0, s, B);
         if (b->profile) TRY(hipEventRecord(b->ev0, s));
-        hipLaunchKernelGGL(k_ba_schur_gemm, dim3((max_items + 3) / 4, G), dim3(256), 0, s, B);
+        hipLaunchKernelGGL(k_ba_schur_gemm, dim3(max_items, G), dim3(64 * GEMM_WAVES), gemm_lds, s, B);
         if (b->profile) TRY(hipEventRecord(b->ev1, s));
         hipLaunchKernelGGL(k_ba_schur_finish, dim3((B.max_ld * B.max_ld + 255) / 256, G), dim3(256), 0, s, B);
         hipLaunchKernelGGL(k_ba_bschur, gf, dim3(64), 0, s, B);
-        hipLaunchKernelGGL(k_ba_ldlt, dim3(G), dim3(1024), 0, s, B);
+        hipLaunchKernelGGL(k_ba_ldlt, dim3(G), dim3(1024), ldlt_lds, s, B);
         hipLaunchKernelGGL(k_ba_backsub_points, gp128, dim3(128), 0, s, B);
         hipLaunchKernelGGL(k_ba_update_poses, dim3((max_poses + 63) / 64, G), dim3(64), 0, s, B);
         hipLaunchKernelGGL(k_ba_errors, ge, dim3(256), 0, s, B, 1);
@@ -1015,13 +1169,14 @@ extern "C" int orbhip_ba_batch_set_profiling(orbhip_ba_batch *b, int enable)
 }
 
 // Accumulated device time / launch count of the Schur GEMM kernel since profiling was enabled,
-// and the MFMA flops one launch issues (dense K-padded form, upper tiles only).
+// and the MFMA flops one launch really issues (upper 16x16 tiles, static block-sparsity masks).
 extern "C" int orbhip_ba_batch_gemm_profile(const orbhip_ba_batch *b, float *total_ms, int *launches, double *flops_per_launch)
 {
     if (!b || !total_ms || !launches || !flops_per_launch) return ORBHIP_E_BADARG;
     *total_ms = b->gemm_ms_total; *launches = b->gemm_launches; *flops_per_launch = b->gemm_flops_per_launch;
     return ORBHIP_OK;
 }
+extern "C" double orbhip_ba_batch_gemm_dense_flops(const orbhip_ba_batch *b) { return b ? b->gemm_flops_dense : 0.0; }
 
 // FP64 matrix-core peak of this device, measured: every wave issues independent
 // v_mfma_f64_16x16x4_f64 chains (the local micro-architecture guide lists no FP64 MFMA peak).

@@ -288,6 +288,8 @@ lib.orbhip_ba_solve_batch.argtypes = [vp, vp, ci, C.POINTER(BaParams), vp, vp, v
 lib.orbhip_ba_batch_set_profiling.argtypes = [vp, ci]
 lib.orbhip_ba_batch_gemm_profile.argtypes = [vp, C.POINTER(cf), C.POINTER(ci), C.POINTER(cd)]
 lib.orbhip_mfma_f64_peak_tflops.argtypes = [vp, C.POINTER(cd)]
+lib.orbhip_ba_batch_gemm_dense_flops.argtypes = [vp]
+lib.orbhip_ba_batch_gemm_dense_flops.restype = cd
 
 
 def mfma_f64_peak_tflops(ctx):
@@ -347,6 +349,9 @@ class BaBatch:
         ms, n, fl = cf(), ci(), cd()
         _chk(lib.orbhip_ba_batch_gemm_profile(self.h, C.byref(ms), C.byref(n), C.byref(fl)), "ba gemm_profile")
         return ms.value, n.value, fl.value
+
+    def gemm_dense_flops(self):
+        return lib.orbhip_ba_batch_gemm_dense_flops(self.h)
 
     def download(self):
         poses = [a.copy() for a in self.poses]
