@@ -389,11 +389,20 @@ extern "C" int orbhip_extract_batch_device(orbhip_extractor *e, const uint8_t *d
     int rc = orbhip_extractor_reserve(e, width, height, batch);
     if (rc) return rc;
     // level 0 of the pyramid is the input itself (the reference copies it into a padded
-    // buffer, ORBextractor.cc:1172; the bytes are identical): alias, do not copy.
+    // buffer, ORBextractor.cc:1172; the bytes are identical): alias, do not copy -- unless the caller's
+    // layout would break the kernels' aligned dword row accesses, then stage it once on the device.
     OrbLevel &L0 = e->P.lv[0];
-    L0.img = const_cast<uint8_t *>(d_images);
-    L0.img_pitch = (int)row_stride;
-    L0.img_frame_stride = frame_stride;
+    const bool aligned = ((uintptr_t)d_images % 4 == 0) && (row_stride % 4 == 0) && (frame_stride % 4 == 0);
+    if (aligned) {
+        L0.img = const_cast<uint8_t *>(d_images);
+        L0.img_pitch = (int)row_stride;
+        L0.img_frame_stride = frame_stride;
+    } else {
+        L0.img = e->d_level0; L0.img_pitch = e->level0_pitch; L0.img_frame_stride = e->level0_frame_stride;
+        for (int f = 0; f < batch; f++)
+            HIP_TRY(hipMemcpy2DAsync(L0.img + (size_t)f * L0.img_frame_stride, L0.img_pitch, d_images + (size_t)f * frame_stride,
+                                     row_stride, width, height, hipMemcpyDeviceToDevice, e->ctx->stream));
+    }
     return run_pipeline(e, batch, lap0, lap1);
 }
 

@@ -123,3 +123,84 @@ def test_empty_image_and_bad_args(gpu_ctx):
     with pytest.raises(orbhip.OrbHipError):
         ext.reserve(64, 48, 1)           # smaller than one FAST cell: rejected loudly
     ext.close()
+
+
+def _dev_extract(gpu_ctx, ext, imgs, lap, row_stride=None):
+    """Device entry point (orbhip_extract_batch_device): images resident in HBM, results fetched from the
+    device result arrays."""
+    import ctypes as C
+    import torch
+    import orbhip
+    B, H, W = imgs.shape
+    rs = row_stride or W
+    buf = np.zeros((B, H, rs), np.uint8)
+    buf[:, :, :W] = imgs
+    d = torch.from_numpy(buf).cuda()
+    torch.cuda.synchronize()
+    ext.extract_device(d.data_ptr(), W, H, rs, rs * H, B, lap)
+    gpu_ctx.synchronize()
+    kp_p, desc_p, cnt_p, mono_p = ext.results_device()
+    mk = ext.max_keypoints
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    kp = np.zeros((B, mk), orbhip.KP_DTYPE); desc = np.zeros((B, mk, 32), np.uint8)
+    cnt = np.zeros(B, np.int32); mono = np.zeros(B, np.int32)
+    for dst, src in ((kp, kp_p), (desc, desc_p), (cnt, cnt_p), (mono, mono_p)):
+        assert hip.hipMemcpy(dst.ctypes.data, src, dst.nbytes, 2) == 0
+    return [(kp[f, :cnt[f]], desc[f, :cnt[f]], int(mono[f])) for f in range(B)]
+
+
+@pytest.mark.parametrize("w,h,stride", [(640, 480, None), (333, 277, 333), (333, 277, 336)])
+def test_device_entry_point_matches_host_entry_point(gpu_ctx, w, h, stride):
+    """orbhip_extract_batch_device (level 0 aliases the caller's buffer; odd strides are staged) == host path."""
+    import orbhip
+    ext, _ = _mk(gpu_ctx, 500)
+    imgs = orbhip.synth_frames(w, h, 5, seed=4)
+    a = ext.extract_host(imgs, (0, 300))
+    b = _dev_extract(gpu_ctx, ext, imgs, (0, 300), stride)
+    for f in range(5):
+        assert a[f][2] == b[f][2]
+        assert a[f][0].tobytes() == b[f][0].tobytes() and a[f][1].tobytes() == b[f][1].tobytes()
+    ext.close()
+
+
+@pytest.mark.parametrize("w,h,nfeat", [(1920, 1080, 2000), (3840, 2160, 2000)])
+def test_extract_parity_hd_and_4k(gpu_ctx, w, h, nfeat):
+    """BASELINE configs #3 sizes: HD / 4K frames, 2000 features, bit-exact vs the oracle (final outputs +
+    pre-octree candidates of the largest level)."""
+    import orbhip
+    ext, ora = _mk(gpu_ctx, nfeat)
+    imgs = orbhip.synth_frames(w, h, 1, seed=w)
+    got = ext.extract_host(imgs, (0, 1000))
+    kp, desc, mono = ora.extract(imgs[0], (0, 1000))
+    gx, gy, gs = ext.fast_candidates(0, 0)
+    ox, oy, os_ = ora.fast_candidates(0)
+    np.testing.assert_array_equal(gx, ox); np.testing.assert_array_equal(gy, oy); np.testing.assert_array_equal(gs, os_)
+    assert got[0][2] == mono and len(got[0][0]) == len(kp) > 0.9 * nfeat
+    assert got[0][0].tobytes() == kp.tobytes()
+    assert got[0][1].tobytes() == desc.tobytes()
+    ext.close()
+
+
+def test_full_batch_1024_properties(gpu_ctx):
+    """BASELINE config #2 at full size (1024 VGA frames): sampled frames bit-exact vs the oracle, run-to-run
+    determinism of the whole batch (checksum of checksums), and structural invariants of every frame."""
+    import hashlib
+    import orbhip
+    ext, ora = _mk(gpu_ctx, 1000)
+    imgs = orbhip.synth_frames(640, 480, 1024, seed=20241004)
+    r1 = _dev_extract(gpu_ctx, ext, imgs, (0, 0))
+    digest1 = hashlib.sha256(b"".join(hashlib.sha256(k.tobytes() + d.tobytes()).digest() for k, d, _ in r1)).hexdigest()
+    for f in (0, 1, 511, 1023):
+        kp, desc, mono = ora.extract(imgs[f], (0, 0))
+        assert r1[f][2] == mono and r1[f][0].tobytes() == kp.tobytes() and r1[f][1].tobytes() == desc.tobytes(), f
+    quota = ext.features_per_level()
+    for k, d, m in r1:
+        assert 800 < len(k) <= ext.max_keypoints and m == len(k)
+        assert (np.diff(k["octave"]) >= 0).all()                               # level order when nothing is 'stereo'
+        assert (np.bincount(k["octave"], minlength=8) <= quota + 2).all()      # octree never overshoots by more than 2
+        assert (k["x"] >= 19).all() and (k["y"] >= 19).all()
+    r2 = _dev_extract(gpu_ctx, ext, imgs, (0, 0))
+    digest2 = hashlib.sha256(b"".join(hashlib.sha256(k.tobytes() + d.tobytes()).digest() for k, d, _ in r2)).hexdigest()
+    assert digest1 == digest2
+    ext.close()
