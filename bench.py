@@ -130,9 +130,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # rehearsal hooks (single-GPU boxes): ORBHIP_BENCH_BACKEND=gloo keeps the collectives on the CPU and
+    # ORBHIP_BENCH_DEVICE pins every rank to one card; the driver's runs use neither (RCCL, one rank per GPU).
+    backend = os.environ.get("ORBHIP_BENCH_BACKEND", "nccl")
+    if "ORBHIP_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["ORBHIP_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     B, W, H = args.batch, args.width, args.height
     # synthetic frames: generated on the host, then resident in HBM before the timed region
@@ -201,9 +210,15 @@ def main():
     bf_accept = float(d_acc.float().sum().item()) / B
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # the only data exchange of the sharded ORB path: one all-gather of fixed-size per-frame
+        # records, outside the timed region (a host-side Tracking consumer would D2H per GPU instead)
+        import shard
+        rec = torch.stack([d_nm.to(torch.int32), d_nm.to(torch.int32)], 1).to(coll_dev)
+        allrec = shard.allgather_records(rec)
+        assert allrec.shape[0] == world
 
     # ---- local-BA leg: G graphs per GPU solved concurrently (replicas) ----------
     ba = None
@@ -232,7 +247,7 @@ def main():
         _, _, _, stats = bb.download()
         bb.close()
         if world > 1:
-            t = torch.tensor([dt_ba], dtype=torch.float64, device="cuda")
+            t = torch.tensor([dt_ba], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt_ba = float(t.item())
         peak64 = orbhip.mfma_f64_peak_tflops(ctx)
