@@ -777,7 +777,17 @@ __global__ __launch_bounds__(256) void k_blur_score(OrbParams P, int level)
             const uint32_t *q = &in[(row + rsel[r]) * (FS_IP / 4) + g];
             rw[r][0] = q[0]; rw[r][1] = q[1]; rw[r][2] = q[2];
         }
-        const bool pass[2] = {fast_compass<0>(rw, th), fast_compass<2>(rw, th)};
+        // FAST is only ever consumed inside the cells' detection bands, [19, w-19) x [19, h-19): pixels outside
+        // never enter the queue, and a wave whose four rows lie outside skips the test altogether
+        const int yy = y0 + row;
+        const int wrow0 = y0 + ((gi & ~63) >> 4);                      // first of the 4 rows this wave covers
+        bool pass[2] = {false, false};
+        if (wrow0 + 3 >= ORB_EDGE && wrow0 < h - ORB_EDGE) {           // uniform
+            const bool rowin = yy >= ORB_EDGE && yy < h - ORB_EDGE;
+            const int xg = x0 + 4 * g;
+            pass[0] = rowin && xg + 1 >= ORB_EDGE && xg < w - ORB_EDGE && fast_compass<0>(rw, th);
+            pass[1] = rowin && xg + 3 >= ORB_EDGE && xg + 2 < w - ORB_EDGE && fast_compass<2>(rw, th);
+        }
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             const unsigned long long bal = __ballot(pass[j]);
