@@ -932,27 +932,34 @@ __device__ __forceinline__ void sincos_det(double x, double *s_out, double *c_ou
 // lane, reduced over the 16 lanes), evaluate cv::fastAtan2 / orb_sincos once per keypoint (the four
 // keypoints of a wave share those instructions), and each lane produces 16 of the 256 rBRIEF bits
 // = two consecutive descriptor bytes.
-#define OD_UP 36              // un-blurred patch pitch (31 + up to 3 alignment bytes, dword multiple)
-#define OD_BP 44              // blurred patch pitch (39 + up to 3)
+#define OD_UP 48              // un-blurred patch pitch: 31 + up to 3 alignment bytes, staged as three 16-byte chunks
+#define OD_BP 48              // blurred patch pitch: 39 + up to 3, three 16-byte chunks
 #define OD_KP_LDS ((31 * OD_UP + 39 * OD_BP) / 4)       // dwords per keypoint
-// Branch-free dword fetch that never reads past the row: the load address is clamped to w-4 (unaligned
-// global loads are legal on gfx950) and the wanted bytes are shifted down; bytes beyond the row come
-// out as zero and are never sampled (patches lie inside the image).
-__device__ __forceinline__ uint32_t od_load_dword(const uint8_t *row, int x, int w)
+#define OD_THREADS 128        // 8 keypoints per workgroup: 27 KB of LDS -> 5 workgroups per CU
+// Branch-free 16-byte fetch that never reads past the row pitch: the address is clamped to pitch-16
+// and the wanted dwords are shifted down (x and pitch are multiples of 4); dwords beyond the pitch come
+// out as zero and are never sampled (patches lie inside the image).  One dwordx4 per lane instead of
+// four dword loads: the kernel's time follows the number of load wave-instructions.
+__device__ __forceinline__ uint4 od_load16(const uint8_t *row, int x, int pitch)
 {
-    const int xs = min(x, w - 4);
-    uint32_t v;
-    __builtin_memcpy(&v, row + xs, 4);
-    return v >> (8 * min(x - xs, 3));
+    const int xs = min(x, pitch - 16);
+    const uint4 v = *reinterpret_cast<const uint4 *>(row + xs);
+    const int d = (x - xs) >> 2;
+    uint4 o;
+    o.x = d == 0 ? v.x : d == 1 ? v.y : d == 2 ? v.z : v.w;
+    o.y = d == 0 ? v.y : d == 1 ? v.z : d == 2 ? v.w : 0u;
+    o.z = d == 0 ? v.z : d == 1 ? v.w : 0u;
+    o.w = d == 0 ? v.w : 0u;
+    return o;
 }
 
-__global__ __launch_bounds__(256, 3) void k_orient_desc(OrbParams P)
+__global__ __launch_bounds__(OD_THREADS) void k_orient_desc(OrbParams P)
 {
-    __shared__ uint32_t lds_all[16][OD_KP_LDS];
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[OD_THREADS / 16][OD_KP_LDS];
     __shared__ uint32_t pat_t[16 * 16];          // pat_t[t][l] = tests 16*l + t, packed x0,y0,x1,y1 (int8)
     const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, sub = lane >> 4;
-    {
-        const int l = tid & 15, t = tid >> 4;     // 256 threads = 16 x 16 entries
+    for (int e = tid; e < 256; e += OD_THREADS) {
+        const int l = e & 15, t = e >> 4;         // 16 x 16 entries
         pat_t[t * 16 + l] = reinterpret_cast<const uint32_t *>(c_pattern)[16 * l + t];
     }
     __syncthreads();
@@ -960,7 +967,7 @@ __global__ __launch_bounds__(256, 3) void k_orient_desc(OrbParams P)
     // frame f is handled by the workgroups of XCD (f % 8): every 128-byte line of a frame's pyramid is then
     // fetched from HBM by one L2 instead of eight.
     const int xcd = blockIdx.x & 7, nblk_x = gridDim.x >> 3;             // gridDim.x is a multiple of 8
-    const long wave_x = (long)(blockIdx.x >> 3) * 4 + (tid >> 6), nwaves_x = (long)nblk_x * 4;
+    const long wave_x = (long)(blockIdx.x >> 3) * (OD_THREADS / 64) + (tid >> 6), nwaves_x = (long)nblk_x * (OD_THREADS / 64);
     const int gpf = (P.kps_per_frame + 3) >> 2;                          // groups of 4 slots per frame
     const int nframes_x = (P.batch - xcd + 7) >> 3;                      // frames xcd, xcd+8, ...
     uint32_t *up32 = lds_all[(tid >> 4)], *bp32 = up32 + 31 * OD_UP / 4;
@@ -994,39 +1001,28 @@ __global__ __launch_bounds__(256, 3) void k_orient_desc(OrbParams P)
         if (valid) {
             const uint8_t *ubase = L.img + (size_t)frame * L.img_frame_stride + (size_t)(y - 15) * L.img_pitch;
             const uint8_t *bbase = L.blur + (size_t)frame * L.blur_frame_stride + (size_t)(y - 19) * L.blur_pitch;
-            // the 16 lanes sweep the flattened patch (18 + 27 dword loads per lane); loads are issued in
-            // batches of 9 before their LDS stores so that each batch is in flight together
+            // the 16 lanes sweep the patch rows in 16-byte chunks (3 per row): 6 + 8 dwordx4 loads per lane, all
+            // issued before the first LDS store so that they are in flight together
+            uint4 ur[6], br[8];
 #pragma unroll
-            for (int k0 = 0; k0 < 18; k0 += 9) {
-                uint32_t reg[9];
-#pragma unroll
-                for (int k = 0; k < 9; k++) {
-                    const int i = l16 + 16 * (k0 + k);
-                    const int r = i / 9, d = i - r * 9;
-                    reg[k] = i < 31 * 9 ? od_load_dword(ubase + (size_t)r * L.img_pitch, uxs + 4 * d, L.w) : 0u;
-                }
-#pragma unroll
-                for (int k = 0; k < 9; k++) {
-                    const int i = l16 + 16 * (k0 + k);
-                    const int r = i / 9, d = i - r * 9;
-                    if (i < 31 * 9) up32[r * (OD_UP / 4) + d] = reg[k];
-                }
+            for (int k = 0; k < 6; k++) {
+                const int i = l16 + 16 * k, r = i / 3, c3 = i - r * 3;
+                ur[k] = i < 31 * 3 ? od_load16(ubase + (size_t)r * L.img_pitch, uxs + 16 * c3, L.img_pitch) : make_uint4(0, 0, 0, 0);
             }
 #pragma unroll
-            for (int k0 = 0; k0 < 27; k0 += 9) {
-                uint32_t reg[9];
+            for (int k = 0; k < 8; k++) {
+                const int i = l16 + 16 * k, r = i / 3, c3 = i - r * 3;
+                br[k] = i < 39 * 3 ? od_load16(bbase + (size_t)r * L.blur_pitch, bxs + 16 * c3, L.blur_pitch) : make_uint4(0, 0, 0, 0);
+            }
 #pragma unroll
-                for (int k = 0; k < 9; k++) {
-                    const int i = l16 + 16 * (k0 + k);
-                    const int r = i / 11, d = i - r * 11;
-                    reg[k] = i < 39 * 11 ? od_load_dword(bbase + (size_t)r * L.blur_pitch, bxs + 4 * d, L.w) : 0u;
-                }
+            for (int k = 0; k < 6; k++) {
+                const int i = l16 + 16 * k, r = i / 3, c3 = i - r * 3;
+                if (i < 31 * 3) *reinterpret_cast<uint4 *>(&up32[r * (OD_UP / 4) + 4 * c3]) = ur[k];
+            }
 #pragma unroll
-                for (int k = 0; k < 9; k++) {
-                    const int i = l16 + 16 * (k0 + k);
-                    const int r = i / 11, d = i - r * 11;
-                    if (i < 39 * 11) bp32[r * (OD_BP / 4) + d] = reg[k];
-                }
+            for (int k = 0; k < 8; k++) {
+                const int i = l16 + 16 * k, r = i / 3, c3 = i - r * 3;
+                if (i < 39 * 3) *reinterpret_cast<uint4 *>(&bp32[r * (OD_BP / 4) + 4 * c3]) = br[k];
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1077,8 +1073,8 @@ void orb_launch_orient_desc(const OrbParams &P, hipStream_t s)
 {
     const long total = (long)P.batch * P.kps_per_frame;
     (void)total;
-    const long blocks = 256 * 3;                       // LDS: 46 KB per workgroup -> 3 per CU; multiple of 8 (XCD split)
-    hipLaunchKernelGGL(k_orient_desc, dim3((unsigned)blocks), dim3(256), 0, s, P);
+    const long blocks = 256 * 5;                       // LDS: 27 KB per workgroup -> 5 per CU; multiple of 8 (XCD split)
+    hipLaunchKernelGGL(k_orient_desc, dim3((unsigned)blocks), dim3(OD_THREADS), 0, s, P);
 }
 
 // ----------------------------------------------------------------------------------
