@@ -278,6 +278,7 @@ __device__ __forceinline__ void fs_window(const uint32_t *in, int row, int pc, u
 __global__ __launch_bounds__(256) void k_fast_cells(OrbParams P)
 {
     __shared__ uint32_t sc_all[4][FC_ROWS * (FC_TP / 4)];
+    __shared__ uint16_t lst_all[4][FC_ROWS * (FC_TP / 4)];         // non-zero 4-pixel groups of the band, row-major
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int bpf = (P.cells_per_frame + 3) >> 2;              // workgroups per frame
     const unsigned lid = xcd_logical_id(blockIdx.x, gridDim.x);
@@ -335,54 +336,78 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbParams P)
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // NMS: lane owns a contiguous run of band pixels (row-major) -> ordered emission
-    const int npix = dw * dh;
-    const int ppt = (npix + 63) >> 6;
-    const int p0 = lane * ppt;
-    unsigned long long keep = 0;
-    int th = P.ini_th;
-    const int yy0 = p0 / dw, xx0 = p0 - yy0 * dw;          // one division per lane; the run is walked incrementally
+    // NMS.  ~97 % of the band's scores are zero and almost every wave holds a non-zero one, so the non-zero
+    // 4-pixel groups (LDS dwords) are first compacted, in row-major order, into a per-wave list; the 3x3 test then
+    // runs densely, one listed group per lane.  Emission order (cv::FAST: row-major) follows from the list order.
+    uint16_t *lst = lst_all[wv];
+    const unsigned long long lt = (1ull << lane) - 1;
+    const int ngx = (dw + 3) >> 2, ngroups = ngx * dh;             // group gx = band x 4gx..4gx+3 = LDS dword 1+gx
+    int nl = 0;
+    for (int g0 = 0; g0 < ngroups; g0 += 64) {
+        const int g = g0 + lane;
+        bool nz = false;
+        if (g < ngroups) { const int yy = g / ngx, gx = g - yy * ngx; nz = sc32[(yy + 1) * (FC_TP / 4) + 1 + gx] != 0; }
+        const unsigned long long bal = __ballot(nz);
+        if (nz) lst[nl + __popcll(bal & lt)] = (uint16_t)g;
+        nl += __popcll(bal);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint32_t *list = P.cell_list + (size_t)frame * P.cell_list_frame_stride + (size_t)cell * L.cell_cap;
+    int th = P.ini_th, total = 0;
     for (int pass = 0; pass < 2; pass++) {
-        keep = 0;
-        int yy = yy0, xx = xx0;
-        for (int k = 0; k < ppt; k++) {
-            if (p0 + k < npix) {
-                const uint8_t *q = &sc[(yy + 1) * FC_TP + xx + 4];
-                const int v = q[0] >= th ? q[0] : 0;          // v(th) = score if S > th else 0
-                if (v) {
-                    int m = 0;
+        total = 0;
+        for (int i0 = 0; i0 < nl; i0 += 64) {
+            const int i = i0 + lane;
+            uint32_t keep = 0, cbytes = 0;
+            int yy = 0, gx = 0;
+            if (i < nl) {
+                const int g = lst[i];
+                yy = g / ngx; gx = g - yy * ngx;
+                const uint32_t *q = &sc32[(yy + 1) * (FC_TP / 4) + 1 + gx];       // centre dword; rows +-1, dwords +-1 around it
+                // 6-byte windows (positions 0..5 = band x 4gx-1 .. 4gx+4) of the three rows
+                unsigned long long wr[3];
 #pragma unroll
-                    for (int dy = -1; dy <= 1; dy++)
+                for (int r = 0; r < 3; r++) {
+                    const uint32_t *qq = q + (r - 1) * (FC_TP / 4);
+                    wr[r] = (unsigned long long)(qq[-1] >> 24) | ((unsigned long long)qq[0] << 8) | ((unsigned long long)(qq[1] & 0xFFu) << 40);
+                }
+                cbytes = q[0];
 #pragma unroll
-                        for (int dx = -1; dx <= 1; dx++)
-                            if (dx | dy) { const int nb = q[dy * FC_TP + dx]; m = max(m, nb >= th ? nb : 0); }
-                    if (v > m) keep |= 1ull << k;
+                for (int j = 0; j < 4; j++) {
+                    const int c = (int)((cbytes >> (8 * j)) & 0xFFu);
+                    const int v = c >= th ? c : 0;                                 // v(th) = score if S > th else 0
+                    if (v) {
+                        int m = 0;
+#pragma unroll
+                        for (int r = 0; r < 3; r++)
+#pragma unroll
+                            for (int dx = 0; dx < 3; dx++)
+                                if (!(r == 1 && dx == 1)) { const int nb = (int)((wr[r] >> (8 * (j + dx))) & 0xFFu); m = max(m, nb >= th ? nb : 0); }
+                        if (v > m) keep |= 1u << j;
+                    }
                 }
             }
-            if (++xx == dw) { xx = 0; yy++; }
+            const int mine = __popc(keep);
+            if (pass == 0) { total += __popcll(__ballot(keep != 0)); continue; }
+            const int inc = wave_incl_scan(mine);
+            int offs = total + inc - mine;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (keep & (1u << j)) {
+                    if (offs < L.cell_cap)
+                        list[offs] = ORB_PACK_KEY(4 * gx + j + 3 + cj * L.wcell, yy + 3 + ci * L.hcell, (cbytes >> (8 * j)) & 0xFFu);
+                    offs++;
+                }
+            total += __shfl(inc, 63, 64);
         }
         if (pass == 0) {
-            if (__any(keep != 0)) break;                      // vKeysCell non-empty at iniThFAST
-            th = P.min_th;                                    // ORBextractor.cc:825-828 retry
+            if (total == 0) th = P.min_th;                    // vKeysCell empty at iniThFAST: retry (ORBextractor.cc:825-828)
         }
     }
-    const int mine = __popcll(keep);
-    const int inc = wave_incl_scan(mine);
-    int total = __shfl(inc, 63, 64);
-    int offs = inc - mine;
-    uint32_t *list = P.cell_list + (size_t)frame * P.cell_list_frame_stride + (size_t)cell * L.cell_cap;
     if (total > L.cell_cap) { if (lane == 0) atomicExch(P.status, ORBHIP_E_CAPACITY); total = L.cell_cap; }
-    {
-        int yy = yy0, xx = xx0;
-        for (int k = 0; k < ppt; k++) {
-            if (keep & (1ull << k)) {
-                if (offs < L.cell_cap)
-                    list[offs] = ORB_PACK_KEY(xx + 3 + cj * L.wcell, yy + 3 + ci * L.hcell, sc[(yy + 1) * FC_TP + xx + 4]);
-                offs++;
-            }
-            if (++xx == dw) { xx = 0; yy++; }
-        }
-    }
     if (lane == 0) *cnt_out = (uint32_t)total;
 }
 
