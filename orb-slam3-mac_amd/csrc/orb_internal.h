@@ -42,6 +42,7 @@ struct OrbParams {
     int keys_per_frame;       // sum of key_cap
     int kps_per_frame;        // sum of kp_cap  (== staging slots per frame)
     int max_kp;               // output row capacity per frame
+    int fc_pd, fc_rows;       // k_fast_cells per-wave LDS geometry: dword pitch and rows of the score band (+ aprons)
     int lap0, lap1;
     // per-frame scratch
     uint32_t *cell_count;     // [batch][cells_per_frame]

@@ -273,12 +273,13 @@ __device__ __forceinline__ void fs_window(const uint32_t *in, int row, int pc, u
 // Pass 2: per cell (ORBextractor.cc:783-854): 3x3 strict NMS inside the cell's detection band only
 // (cv::FAST never looks across the sub-image border), iniThFAST first, minThFAST iff nothing
 // survives, emission in cv::FAST order.  One wave per cell, four cells per workgroup, no barriers.
-#define FC_TP 72
-#define FC_ROWS 62
 __global__ __launch_bounds__(256) void k_fast_cells(OrbParams P)
 {
-    __shared__ uint32_t sc_all[4][FC_ROWS * (FC_TP / 4)];
-    __shared__ uint16_t lst_all[4][FC_ROWS * (FC_TP / 4)];         // non-zero 4-pixel groups of the band, row-major
+    // per-wave LDS: score band [fc_rows][fc_pd dwords] + list of non-zero 4-pixel groups; sized by the host from
+    // the largest cell of this extractor so that small cells do not pay for the 64x64 worst case (occupancy)
+    extern __shared__ uint32_t fc_lds[];
+    const int fc_pd = P.fc_pd, fc_rows = P.fc_rows;
+    const int fc_wave_dw = fc_rows * fc_pd + (fc_rows * fc_pd + 1) / 2;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int bpf = (P.cells_per_frame + 3) >> 2;              // workgroups per frame
     const unsigned lid = xcd_logical_id(blockIdx.x, gridDim.x);
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbParams P)
         return;
     }
     // stage the band's scores: LDS (row yy+1, byte xx+4) <- score(bx+xx, by+yy); everything else zero
-    uint32_t *sc32 = sc_all[wv];
+    uint32_t *sc32 = fc_lds + (size_t)wv * fc_wave_dw;
     uint8_t *sc = reinterpret_cast<uint8_t *>(sc32);
     const int bx = ini_x + 3, by = ini_y + 3;
     const uint8_t *smap = L.score + (size_t)frame * L.score_frame_stride;
@@ -325,11 +326,11 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbParams P)
                 const uint32_t *q = reinterpret_cast<const uint32_t *>(smap + (size_t)(by + yy) * L.score_pitch + ax + 4 * d);
                 const uint32_t lo = q[0], hi = q[1];               // within the row pitch (pad bytes are masked off)
                 const uint32_t v = __builtin_amdgcn_alignbit(hi, lo, 8 * sh);
-                sc32[(yy + 1) * (FC_TP / 4) + d] = v & mask;
+                sc32[(yy + 1) * fc_pd + d] = v & mask;
             }
         }
     }
-    for (int d = lane; d < ndw; d += 64) { sc32[d] = 0; sc32[(dh + 1) * (FC_TP / 4) + d] = 0; }
+    for (int d = lane; d < ndw; d += 64) { sc32[d] = 0; sc32[(dh + 1) * fc_pd + d] = 0; }
     // the staging buffer is private to this wave: order its own LDS writes before its reads (no workgroup barrier:
     // sibling waves may already have returned)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -339,14 +340,14 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbParams P)
     // NMS.  ~97 % of the band's scores are zero and almost every wave holds a non-zero one, so the non-zero
     // 4-pixel groups (LDS dwords) are first compacted, in row-major order, into a per-wave list; the 3x3 test then
     // runs densely, one listed group per lane.  Emission order (cv::FAST: row-major) follows from the list order.
-    uint16_t *lst = lst_all[wv];
+    uint16_t *lst = reinterpret_cast<uint16_t *>(sc32 + fc_rows * fc_pd);
     const unsigned long long lt = (1ull << lane) - 1;
     const int ngx = (dw + 3) >> 2, ngroups = ngx * dh;             // group gx = band x 4gx..4gx+3 = LDS dword 1+gx
     int nl = 0;
     for (int g0 = 0; g0 < ngroups; g0 += 64) {
         const int g = g0 + lane;
         bool nz = false;
-        if (g < ngroups) { const int yy = g / ngx, gx = g - yy * ngx; nz = sc32[(yy + 1) * (FC_TP / 4) + 1 + gx] != 0; }
+        if (g < ngroups) { const int yy = g / ngx, gx = g - yy * ngx; nz = sc32[(yy + 1) * fc_pd + 1 + gx] != 0; }
         const unsigned long long bal = __ballot(nz);
         if (nz) lst[nl + __popcll(bal & lt)] = (uint16_t)g;
         nl += __popcll(bal);
@@ -366,12 +367,12 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbParams P)
             if (i < nl) {
                 const int g = lst[i];
                 yy = g / ngx; gx = g - yy * ngx;
-                const uint32_t *q = &sc32[(yy + 1) * (FC_TP / 4) + 1 + gx];       // centre dword; rows +-1, dwords +-1 around it
+                const uint32_t *q = &sc32[(yy + 1) * fc_pd + 1 + gx];       // centre dword; rows +-1, dwords +-1 around it
                 // 6-byte windows (positions 0..5 = band x 4gx-1 .. 4gx+4) of the three rows
                 unsigned long long wr[3];
 #pragma unroll
                 for (int r = 0; r < 3; r++) {
-                    const uint32_t *qq = q + (r - 1) * (FC_TP / 4);
+                    const uint32_t *qq = q + (r - 1) * fc_pd;
                     wr[r] = (unsigned long long)(qq[-1] >> 24) | ((unsigned long long)qq[0] << 8) | ((unsigned long long)(qq[1] & 0xFFu) << 40);
                 }
                 cbytes = q[0];
@@ -414,7 +415,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbParams P)
 void orb_launch_fast_cells(const OrbParams &P, hipStream_t s)
 {
     const unsigned nblocks = (unsigned)((P.cells_per_frame + 3) / 4) * (unsigned)P.batch;
-    hipLaunchKernelGGL(k_fast_cells, dim3(nblocks), dim3(256), 0, s, P);
+    const int wave_dw = P.fc_rows * P.fc_pd + (P.fc_rows * P.fc_pd + 1) / 2;
+    hipLaunchKernelGGL(k_fast_cells, dim3(nblocks), dim3(256), sizeof(uint32_t) * 4 * (size_t)wave_dw, s, P);
 }
 
 // ----------------------------------------------------------------------------------

@@ -270,6 +270,12 @@ extern "C" int orbhip_extractor_reserve(orbhip_extractor *e, int width, int heig
         keys += align_up(L.key_cap, 4);
     }
     P.cells_per_frame = cells; P.keys_per_frame = keys; P.kps_per_frame = kps; P.max_kp = align_up(kps, 8);
+    {   // k_fast_cells LDS geometry from the largest detection band (wcell x hcell) of this extractor
+        int mw = 0, mh = 0;
+        for (int l = 0; l < e->nlevels; l++) { mw = std::max(mw, P.lv[l].wcell); mh = std::max(mh, P.lv[l].hcell); }
+        P.fc_pd = ((mw + 4) >> 2) + 2;          // bytes [0, dw+4] (band + 4-byte aprons) + one dword of slack for the 16-byte window reads
+        P.fc_rows = mh + 2;
+    }
     P.cell_list_frame_stride = (size_t)cells * max_cell_cap;
     int rc;
     const size_t B = (size_t)max_batch;
