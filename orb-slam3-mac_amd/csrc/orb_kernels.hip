@@ -196,37 +196,33 @@ __device__ __forceinline__ uint32_t pair_at(uint32_t w0, uint32_t w1, uint32_t w
 // rows[r][0..2] = the three dwords of tile row (y-3+r).  Returns packed S (threshold independent).
 // Bresenham circle r=3 in cv::makeOffsets order: (dx,dy) k=0..15 =
 // (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
-template <int J, bool REJECT = false>
-__device__ __forceinline__ bool fast_pair_score(const uint32_t (&rows)[7][3], int th, s16x2 *S_out)
+template <int J>
+__device__ __forceinline__ s16x2 fast_pair_score(const uint32_t (&rows)[7][3])
 {
 #define PX(DX, DY) as_s16x2(pair_at<4 + J + (DX)>(rows[3 + (DY)][0], rows[3 + (DY)][1], rows[3 + (DY)][2]))
     const s16x2 v = PX(0, 0);
     s16x2 d[16];
-    // compass points first: a 9-arc contains at least one pixel of every diametral pair
     d[0] = v - PX(0, 3); d[8] = v - PX(0, -3); d[4] = v - PX(3, 0); d[12] = v - PX(-3, 0);
     d[2] = v - PX(2, 2); d[10] = v - PX(-2, -2); d[6] = v - PX(2, -2); d[14] = v - PX(-2, 2);
-    if (REJECT) {
-        const s16x2 dark = pkmin(pkmin(pkmax(d[0], d[8]), pkmax(d[4], d[12])), pkmin(pkmax(d[2], d[10]), pkmax(d[6], d[14])));
-        const s16x2 brig = pkmax(pkmax(pkmin(d[0], d[8]), pkmin(d[4], d[12])), pkmax(pkmin(d[2], d[10]), pkmin(d[6], d[14])));
-        const bool pass = dark.x > th || dark.y > th || brig.x < -th || brig.y < -th;
-        if (!__any(pass)) return false;           // whole wave rejects: S <= th for every lane
-    }
     d[1] = v - PX(1, 3); d[3] = v - PX(3, 1); d[5] = v - PX(3, -1); d[7] = v - PX(1, -3);
     d[9] = v - PX(-1, -3); d[11] = v - PX(-3, -1); d[13] = v - PX(-3, 1); d[15] = v - PX(-1, 3);
 #undef PX
-    s16x2 lo2[16], hi2[16], lo4[16], hi4[16];
+    // The two 9-arcs starting at j-1 and at j (j odd) share the 8 pixels j..j+7:
+    //   max(min(arc_{j-1}), min(arc_j)) = min(min(d[j..j+7]), max(d[j-1], d[j+8]))
+    // so only the 8 odd-start 8-runs are needed (index m <-> j = 2m+1), built by doubling.
+    s16x2 lo2[8], hi2[8], lo4[8], hi4[8];
 #pragma unroll
-    for (int i = 0; i < 16; i++) { lo2[i] = pkmin(d[i], d[(i + 1) & 15]); hi2[i] = pkmax(d[i], d[(i + 1) & 15]); }
+    for (int m = 0; m < 8; m++) { lo2[m] = pkmin(d[2 * m + 1], d[(2 * m + 2) & 15]); hi2[m] = pkmax(d[2 * m + 1], d[(2 * m + 2) & 15]); }
 #pragma unroll
-    for (int i = 0; i < 16; i++) { lo4[i] = pkmin(lo2[i], lo2[(i + 2) & 15]); hi4[i] = pkmax(hi2[i], hi2[(i + 2) & 15]); }
+    for (int m = 0; m < 8; m++) { lo4[m] = pkmin(lo2[m], lo2[(m + 1) & 7]); hi4[m] = pkmax(hi2[m], hi2[(m + 1) & 7]); }
     s16x2 A = (s16x2){-256, -256}, B = (s16x2){256, 256};
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        A = pkmax(A, pkmin(pkmin(lo4[i], lo4[(i + 4) & 15]), d[(i + 8) & 15]));
-        B = pkmin(B, pkmax(pkmax(hi4[i], hi4[(i + 4) & 15]), d[(i + 8) & 15]));
+    for (int m = 0; m < 8; m++) {
+        const s16x2 e0 = d[2 * m], e1 = d[(2 * m + 9) & 15];
+        A = pkmax(A, pkmin(pkmin(lo4[m], lo4[(m + 2) & 7]), pkmax(e0, e1)));
+        B = pkmin(B, pkmax(pkmax(hi4[m], hi4[(m + 2) & 7]), pkmin(e0, e1)));
     }
-    *S_out = pkmax(A, (s16x2){0, 0} - B);
-    return true;
+    return pkmax(A, (s16x2){0, 0} - B);
 }
 
 // Pass 1: threshold-independent score map of a whole level (regular stencil, no cell structure).
@@ -236,13 +232,10 @@ __device__ __forceinline__ bool fast_pair_score(const uint32_t (&rows)[7][3], in
 // holds a survivor:  (1) every pixel pair runs the compass test, survivors are compacted into an
 // LDS queue;  (2) queue entries are scored densely, one pair per lane.  Scores land in an LDS tile
 // that is written out with coalesced dword stores.
-#define FS_TW 64
-#define FS_TH 32
-#define FS_IP 72
 // Necessary test for S > th on the pixel pair at window byte 4+J: a 9-arc contains at least one pixel
 // of every diametral pair, here checked on the 4 compass pairs.  rw = tile rows -3,-2,0,+2,+3.
 template <int J>
-__device__ __forceinline__ bool fast_compass(const uint32_t (&rw)[5][3], int th)
+__device__ __forceinline__ bool fast_compass(const uint32_t (&rw)[5][3], s16x2 th1)
 {
 #define PXR(R, DX) as_s16x2(pair_at<4 + J + (DX)>(rw[R][0], rw[R][1], rw[R][2]))
     const s16x2 v = PXR(2, 0);
@@ -251,23 +244,9 @@ __device__ __forceinline__ bool fast_compass(const uint32_t (&rw)[5][3], int th)
 #undef PXR
     const s16x2 dark = pkmin(pkmin(pkmax(d0, d8), pkmax(d4, d12)), pkmin(pkmax(d2, d10), pkmax(d6, d14)));
     const s16x2 brig = pkmax(pkmax(pkmin(d0, d8), pkmin(d4, d12)), pkmax(pkmin(d2, d10), pkmin(d6, d14)));
-    return dark.x > th || dark.y > th || brig.x < -th || brig.y < -th;
-}
-
-// window of pair `pc` (pixels 2pc, 2pc+1 of the tile row): dwords m..m+2 of the staged row, realigned
-// so that the left pixel always sits at window byte 4 (v_alignbit_b32 by 0 or 16 bits).
-__device__ __forceinline__ void fs_window(const uint32_t *in, int row, int pc, uint32_t (&rows)[7][3])
-{
-    const int m = pc >> 1;
-    const uint32_t sh = (pc & 1) * 16;
-#pragma unroll
-    for (int r = 0; r < 7; r++) {
-        const uint32_t *q = &in[(row + r) * (FS_IP / 4) + m];
-        const uint32_t w0 = q[0], w1 = q[1], w2 = q[2];
-        rows[r][0] = __builtin_amdgcn_alignbit(w1, w0, sh);
-        rows[r][1] = __builtin_amdgcn_alignbit(w2, w1, sh);
-        rows[r][2] = w2 >> sh;
-    }
+    // either half > th  <=>  a sign bit of max(dark, -brig) - (th+1) is clear
+    const s16x2 M = pkmax(dark, (s16x2){0, 0} - brig) - th1;
+    return (__builtin_bit_cast(uint32_t, M) & 0x80008000u) != 0x80008000u;
 }
 
 // Pass 2: per cell (ORBextractor.cc:783-854): 3x3 strict NMS inside the cell's detection band only
@@ -714,7 +693,8 @@ void orb_launch_octree(const OrbParams &P, hipStream_t s)
 // ----------------------------------------------------------------------------------
 #define BL_TW 64
 #define BL_TH 32
-#define BL_IP 72              // input tile pitch (bytes): 4 left apron + 64 + 4 right apron
+#define BL_ROWS (BL_TH + 6)
+#define BL_IPD 20             // staged-row pitch (dwords): 3 pad | left apron | 16 tile dwords; the right apron is dword 0 of the next row
 __device__ __forceinline__ int reflect101(int p, int n)
 {
     if (p < 0) p = -p;
@@ -722,20 +702,75 @@ __device__ __forceinline__ int reflect101(int p, int n)
     return p;
 }
 
+// four pixels x..x+3 of an image row with BORDER_REFLECT_101 outside [0, w)  (x % 4 == 0)
+__device__ __forceinline__ uint32_t bl_load4(const uint8_t *row, int x, int w)
+{
+    if (x >= 0 && x + 3 < w) return *reinterpret_cast<const uint32_t *>(row + x);
+    uint32_t v = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int xx = reflect101(x + j, w);
+        xx = min(max(xx, 0), w - 1);
+        v |= (uint32_t)row[xx] << (8 * j);
+    }
+    return v;
+}
+
+// horizontal 7-tap of four neighbouring pixels from the 12-byte window d0|d1|d2 (pixel 0 = byte 4), u16 each
+__device__ __forceinline__ void bl_row4(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t klo, uint32_t khi, uint32_t (&o)[4])
+{
+    o[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), klo, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), khi, 0u, false), false);
+    o[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), klo, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), khi, 0u, false), false);
+    o[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), klo, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), khi, 0u, false), false);
+    o[3] = __builtin_amdgcn_udot4(d1, klo, __builtin_amdgcn_udot4(d2, khi, 0u, false), false);
+}
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t bl_dot2(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b), c, false);
+}
+
+// FAST phase 2 for the pairs of one parity (J = 0: pixels 4g,4g+1; J = 2: pixels 4g+2,4g+3): full arc
+// score, one pair per lane; waves beyond the queue's end skip.
+template <int J>
+__device__ __forceinline__ void bl_score_queue(const uint32_t *in, const uint16_t *queue, int nq, int th, uint16_t *out16, int tid)
+{
+    const int lane = tid & 63;
+    for (int q0 = tid & ~63; q0 < nq; q0 += 256) {
+        const int qi = q0 + lane;
+        const int p = queue[min(qi, nq - 1)];
+        const int row = p >> 4, g = p & 15;
+        const uint32_t *q = &in[row * BL_IPD + 3 + g];
+        uint32_t rows[7][3];
+#pragma unroll
+        for (int r = 0; r < 7; r++) { rows[r][0] = q[r * BL_IPD]; rows[r][1] = q[r * BL_IPD + 1]; rows[r][2] = q[r * BL_IPD + 2]; }
+        const s16x2 S = fast_pair_score<J>(rows);
+        if (qi < nq) {
+            const uint32_t lo = S.x > th ? (uint32_t)(S.x - 1) : 0u, hi = S.y > th ? (uint32_t)(S.y - 1) : 0u;
+            out16[row * (BL_TW / 2) + 2 * g + J / 2] = (uint16_t)(lo | (hi << 8));
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------------
 // Fused A7 + A4 pass over one pyramid level: the 64x32 tile (+3 rows / +4 columns of apron) is
 // staged ONCE and feeds both the 7x7 Gaussian (blurred level, for rBRIEF) and the FAST score map.
 // Staging uses BORDER_REFLECT_101 (needed by the blur); FAST scores within 19 px of the border are
 // never consumed (cells cover [19, w-19) x [19, h-19)), so the reflected apron is harmless there.
+// The kernel is bound by vector-instruction issue (~100 lane-ops per pixel), not by HBM: staging is
+// one 16-byte load per lane, the Gaussian's column pass runs on v_dot2_u32_u16 over vertically
+// paired u16 row sums, and FAST is two-phase (compass test on every pixel pair, dense arc score on
+// the ~15 % that survive, queued per parity so no realignment is needed).
 // Algorithmic bytes: S read + S blurred write (+ S score write, an internal product).
 // ----------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_blur_score(OrbParams P, int level)
 {
-    __shared__ uint32_t in[(BL_TH + 6) * (BL_IP / 4)];
-    __shared__ uint16_t hz[(BL_TH + 6) * BL_TW];
-    __shared__ uint32_t outt[FS_TH * FS_TW / 4];
-    __shared__ uint16_t queue[FS_TH * FS_TW / 2];
-    __shared__ int qn;
+    __shared__ __attribute__((aligned(16))) uint32_t in[BL_ROWS * BL_IPD + 4];
+    __shared__ __attribute__((aligned(16))) uint32_t hz2[(BL_ROWS / 2) * BL_TW];     // [row pair][x]: row 2m | row 2m+1 << 16
+    __shared__ uint32_t outt[BL_TH * BL_TW / 4];
+    __shared__ uint16_t queue[2][BL_TH * BL_TW / 4];
+    __shared__ int qn[2];
     const OrbLevel &L = P.lv[level];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = L.w, h = L.h, th = P.min_th;
@@ -744,135 +779,113 @@ __global__ __launch_bounds__(256) void k_blur_score(OrbParams P, int level)
     const int frame = lid / (ntx * nty), trem = lid - frame * (ntx * nty);
     const int x0 = (trem % ntx) * BL_TW, y0 = (trem / ntx) * BL_TH;
     const uint8_t *src = L.img + (size_t)frame * L.img_frame_stride;
-    // ---- stage: 684 dwords = 3 per thread, all loads before the LDS stores
+    // ---- stage: lanes 0..151 one 16-byte chunk each (38 rows x 4), lanes 152..227 one apron dword each
     {
-        uint32_t reg[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const int i = tid + 256 * k;
-            const int r = i / (BL_IP / 4), cd = i - r * (BL_IP / 4);
-            int y = reflect101(y0 + r - 3, h);
-            y = min(max(y, 0), h - 1);
-            const int x = x0 - 4 + 4 * cd;
-            const uint8_t *row = src + (size_t)y * L.img_pitch;
-            uint32_t v = 0;
-            if (i < (BL_TH + 6) * (BL_IP / 4)) {
-                if (x >= 0 && x + 3 < w) v = *reinterpret_cast<const uint32_t *>(row + x);      // pitch%64==0, x%4==0
-                else {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        int xx = reflect101(x + j, w);
-                        xx = min(max(xx, 0), w - 1);
-                        v |= (uint32_t)row[xx] << (8 * j);
-                    }
-                }
-            }
-            reg[k] = v;
+        const bool chunk = tid < 4 * BL_ROWS;
+        const int a = tid - 4 * BL_ROWS;
+        const int r = chunk ? tid >> 2 : a >> 1;
+        int y = reflect101(y0 + r - 3, h);
+        y = min(max(y, 0), h - 1);
+        const uint8_t *row = src + (size_t)y * L.img_pitch;
+        if (chunk) {
+            const int c = tid & 3, x = x0 + 16 * c;
+            uint4 v;
+            if (x + 15 < w) v = *reinterpret_cast<const uint4 *>(row + x);
+            else { v.x = bl_load4(row, x, w); v.y = bl_load4(row, x + 4, w); v.z = bl_load4(row, x + 8, w); v.w = bl_load4(row, x + 12, w); }
+            *reinterpret_cast<uint4 *>(&in[r * BL_IPD + 4 + 4 * c]) = v;
+        } else if (a < 2 * BL_ROWS) {
+            const int side = a & 1;
+            in[r * BL_IPD + (side ? BL_IPD : 3)] = bl_load4(row, side ? x0 + BL_TW : x0 - 4, w);
         }
-#pragma unroll
-        for (int k = 0; k < 3; k++) { const int i = tid + 256 * k; if (i < (BL_TH + 6) * (BL_IP / 4)) in[i] = reg[k]; }
     }
     outt[tid] = 0; outt[tid + 256] = 0;
-    if (tid == 0) qn = 0;
+    if (tid < 2) qn[tid] = 0;
     __syncthreads();
-    // ---- blur row pass (B of k_blur)
+    // ---- blur row pass: two rows x four pixels per task, u16 sums (q8 kernel, sum 257 -> 255*257 fits)
     const uint32_t klo = (uint32_t)P.gauss_q8[0] | ((uint32_t)P.gauss_q8[1] << 8) | ((uint32_t)P.gauss_q8[2] << 16) | ((uint32_t)P.gauss_q8[3] << 24);
     const uint32_t khi = (uint32_t)P.gauss_q8[4] | ((uint32_t)P.gauss_q8[5] << 8) | ((uint32_t)P.gauss_q8[6] << 16);
-    for (int i = tid; i < (BL_TH + 6) * (BL_TW / 4); i += 256) {
-        const int r = i / (BL_TW / 4), c4 = i - r * (BL_TW / 4);
-        const uint32_t *q = &in[r * (BL_IP / 4) + c4];
-        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
-        uint32_t o[4];
-        o[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), klo, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), khi, 0u, false), false);
-        o[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), klo, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), khi, 0u, false), false);
-        o[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), klo, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), khi, 0u, false), false);
-        o[3] = __builtin_amdgcn_udot4(d1, klo, __builtin_amdgcn_udot4(d2, khi, 0u, false), false);
-        uint2 pk;
-        pk.x = o[0] | (o[1] << 16);
-        pk.y = o[2] | (o[3] << 16);
-        *reinterpret_cast<uint2 *>(&hz[r * BL_TW + 4 * c4]) = pk;
+    for (int i = tid; i < (BL_ROWS / 2) * (BL_TW / 4); i += 256) {
+        const int rp = i >> 4, c4 = i & 15;
+        const uint32_t *q = &in[2 * rp * BL_IPD + 3 + c4];
+        uint32_t oa[4], ob[4];
+        bl_row4(q[0], q[1], q[2], klo, khi, oa);
+        bl_row4(q[BL_IPD], q[BL_IPD + 1], q[BL_IPD + 2], klo, khi, ob);
+        uint4 pk;
+        pk.x = oa[0] | (ob[0] << 16); pk.y = oa[1] | (ob[1] << 16); pk.z = oa[2] | (ob[2] << 16); pk.w = oa[3] | (ob[3] << 16);
+        *reinterpret_cast<uint4 *>(&hz2[rp * BL_TW + 4 * c4]) = pk;
     }
     // ---- FAST phase 1: compass test, one group of 4 pixels (two pairs, one 3-dword window) per task
+    const s16x2 th1 = (s16x2){(short)(th + 1), (short)(th + 1)};
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         const int gi = tid + 256 * k;
         const int row = gi >> 4, g = gi & 15;
-        uint32_t rw[5][3];
-        const int rsel[5] = {0, 1, 3, 5, 6};            // rows -3,-2,0,+2,+3
-#pragma unroll
-        for (int r = 0; r < 5; r++) {
-            const uint32_t *q = &in[(row + rsel[r]) * (FS_IP / 4) + g];
-            rw[r][0] = q[0]; rw[r][1] = q[1]; rw[r][2] = q[2];
-        }
         // FAST is only ever consumed inside the cells' detection bands, [19, w-19) x [19, h-19): pixels outside
         // never enter the queue, and a wave whose four rows lie outside skips the test altogether
         const int yy = y0 + row;
         const int wrow0 = y0 + ((gi & ~63) >> 4);                      // first of the 4 rows this wave covers
         bool pass[2] = {false, false};
         if (wrow0 + 3 >= ORB_EDGE && wrow0 < h - ORB_EDGE) {           // uniform
+            uint32_t rw[5][3];
+            const int rsel[5] = {0, 1, 3, 5, 6};                        // rows -3,-2,0,+2,+3
+#pragma unroll
+            for (int r = 0; r < 5; r++) {
+                const uint32_t *q = &in[(row + rsel[r]) * BL_IPD + 3 + g];
+                rw[r][0] = q[0]; rw[r][1] = q[1]; rw[r][2] = q[2];
+            }
             const bool rowin = yy >= ORB_EDGE && yy < h - ORB_EDGE;
             const int xg = x0 + 4 * g;
-            pass[0] = rowin && xg + 1 >= ORB_EDGE && xg < w - ORB_EDGE && fast_compass<0>(rw, th);
-            pass[1] = rowin && xg + 3 >= ORB_EDGE && xg + 2 < w - ORB_EDGE && fast_compass<2>(rw, th);
+            pass[0] = rowin && xg + 1 >= ORB_EDGE && xg < w - ORB_EDGE && fast_compass<0>(rw, th1);
+            pass[1] = rowin && xg + 3 >= ORB_EDGE && xg + 2 < w - ORB_EDGE && fast_compass<2>(rw, th1);
         }
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             const unsigned long long bal = __ballot(pass[j]);
             int base = 0;
-            if (lane == 0 && bal) base = atomicAdd(&qn, __popcll(bal));
+            if (lane == 0 && bal) base = atomicAdd(&qn[j], __popcll(bal));
             base = __shfl(base, 0, 64);
-            if (pass[j]) queue[base + __popcll(bal & ((1ull << lane) - 1))] = (uint16_t)(row * 32 + 2 * g + j);
+            if (pass[j]) queue[j][base + __popcll(bal & ((1ull << lane) - 1))] = (uint16_t)gi;
         }
     }
     __syncthreads();
-    // ---- blur column pass (C of k_blur)
-    const int k0 = P.gauss_q8[0], k1 = P.gauss_q8[1], k2 = P.gauss_q8[2], k3 = P.gauss_q8[3];
+    // ---- blur column pass: rows come vertically paired, so a 7-tap column is four v_dot2_u32_u16
     uint8_t *bdst = L.blur + (size_t)frame * L.blur_frame_stride;
     {
         const int c4 = tid & 15, rg = tid >> 4;
         const int x = x0 + 4 * c4;
         if (x < w) {
-            uint2 rows[8];
+            const uint32_t k0 = P.gauss_q8[0], k1 = P.gauss_q8[1], k2 = P.gauss_q8[2], k3 = P.gauss_q8[3];
+            const uint32_t wt[2][4] = {{k0 | (k1 << 16), k2 | (k3 << 16), k2 | (k1 << 16), k0},
+                                       {k0 << 16, k1 | (k2 << 16), k3 | (k2 << 16), k1 | (k0 << 16)}};
+            uint4 pr[4];
 #pragma unroll
-            for (int k = 0; k < 8; k++) rows[k] = *reinterpret_cast<const uint2 *>(&hz[(2 * rg + k) * BL_TW + 4 * c4]);
+            for (int k = 0; k < 4; k++) pr[k] = *reinterpret_cast<const uint4 *>(&hz2[(rg + k) * BL_TW + 4 * c4]);
 #pragma unroll
             for (int rr = 0; rr < 2; rr++) {
                 const int y = y0 + 2 * rg + rr;
                 if (y < h) {
-                    uint32_t packed = 0;
+                    uint32_t acc[4];
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        int v[7];
+                        uint32_t a = 32768u;
 #pragma unroll
-                        for (int k = 0; k < 7; k++) {
-                            const uint32_t wv = (j < 2) ? rows[rr + k].x : rows[rr + k].y;
-                            v[k] = (j & 1) ? (int)(wv >> 16) : (int)(wv & 0xFFFF);
+                        for (int k = 0; k < 4; k++) {
+                            const uint32_t pv = j == 0 ? pr[k].x : j == 1 ? pr[k].y : j == 2 ? pr[k].z : pr[k].w;
+                            a = bl_dot2(pv, wt[rr][k], a);
                         }
-                        int sacc = k0 * (v[0] + v[6]) + k1 * (v[1] + v[5]) + k2 * (v[2] + v[4]) + k3 * v[3];
-                        sacc = (sacc + 32768) >> 16;
-                        packed |= (uint32_t)min(sacc, 255) << (8 * j);
+                        acc[j] = min(a, 0x00FFFFFFu);                  // byte 2 = min((sum + 2^15) >> 16, 255)
                     }
-                    *reinterpret_cast<uint32_t *>(bdst + (size_t)y * L.blur_pitch + x) = packed;
+                    const uint32_t p01 = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u);
+                    const uint32_t p23 = __builtin_amdgcn_perm(acc[3], acc[2], 0x0c0c0602u);
+                    *reinterpret_cast<uint32_t *>(bdst + (size_t)y * L.blur_pitch + x) = p01 | (p23 << 16);
                 }
             }
         }
     }
-    // ---- FAST phase 2: full arc score of the surviving pairs, one pair per lane
-    const int nq = qn;
+    // ---- FAST phase 2
     uint16_t *out16 = reinterpret_cast<uint16_t *>(outt);
-    for (int q0 = 0; q0 < nq; q0 += 256) {
-        const int qi = q0 + tid;
-        const int p = qi < nq ? queue[qi] : queue[0];
-        const int row = p >> 5, pc = p & 31;
-        uint32_t rows[7][3];
-        fs_window(in, row, pc, rows);
-        s16x2 S = (s16x2){0, 0};
-        fast_pair_score<0>(rows, th, &S);
-        if (qi < nq) {
-            const uint32_t lo = S.x > th ? (uint32_t)(S.x - 1) : 0u, hi = S.y > th ? (uint32_t)(S.y - 1) : 0u;
-            out16[row * (FS_TW / 2) + pc] = (uint16_t)(lo | (hi << 8));
-        }
-    }
+    bl_score_queue<0>(in, queue[0], qn[0], th, out16, tid);
+    bl_score_queue<2>(in, queue[1], qn[1], th, out16, tid);
     __syncthreads();
     uint8_t *sdst = L.score + (size_t)frame * L.score_frame_stride;
 #pragma unroll
