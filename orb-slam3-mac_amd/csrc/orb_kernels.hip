@@ -996,11 +996,19 @@ __device__ __forceinline__ uint4 od_load16(const uint8_t *row, int x, int pitch)
 __global__ __launch_bounds__(OD_THREADS) void k_orient_desc(OrbParams P)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[OD_THREADS / 16][OD_KP_LDS];
-    __shared__ uint32_t pat_t[16 * 16];          // pat_t[t][l] = tests 16*l + t, packed x0,y0,x1,y1 (int8)
+    __shared__ float4 pat_t[16 * 16];            // pat_t[t][l] = test 16*l + t as floats x0,y0,x1,y1
+    __shared__ uint32_t od_msk[16 * 8];          // od_msk[|v|][j]: bytes of columns -15+4j..-12+4j inside the circular patch
     const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, sub = lane >> 4;
     for (int e = tid; e < 256; e += OD_THREADS) {
         const int l = e & 15, t = e >> 4;         // 16 x 16 entries
-        pat_t[t * 16 + l] = reinterpret_cast<const uint32_t *>(c_pattern)[16 * l + t];
+        const int8_t *pp = &c_pattern[4 * (16 * l + t)];
+        pat_t[t * 16 + l] = make_float4((float)pp[0], (float)pp[1], (float)pp[2], (float)pp[3]);
+    }
+    if (tid < 16 * 8) {
+        const int d = P.umax[tid >> 3], j = tid & 7;
+        uint32_t m = 0;
+        for (int k = 0; k < 4; k++) { const int u = -ORB_HALF_PATCH + 4 * j + k; if (u >= -d && u <= d) m |= 0xFFu << (8 * k); }
+        od_msk[tid] = m;
     }
     __syncthreads();
     // XCD-aware work split (speed only): workgroups with equal blockIdx.x % 8 share an XCD and its L2, so
@@ -1011,10 +1019,9 @@ __global__ __launch_bounds__(OD_THREADS) void k_orient_desc(OrbParams P)
     const int gpf = (P.kps_per_frame + 3) >> 2;                          // groups of 4 slots per frame
     const int nframes_x = (P.batch - xcd + 7) >> 3;                      // frames xcd, xcd+8, ...
     uint32_t *up32 = lds_all[(tid >> 4)], *bp32 = up32 + 31 * OD_UP / 4;
-    const uint8_t *up = reinterpret_cast<const uint8_t *>(up32), *bp = reinterpret_cast<const uint8_t *>(bp32);
+    const uint8_t *bp = reinterpret_cast<const uint8_t *>(bp32);
     const float factor_pi = (float)(3.1415926535897932384626433832795 / 180.f);
     const long ngroups = (long)nframes_x * gpf;
-    const int u0 = l16 - ORB_HALF_PATCH, u1 = l16 + 1;             // this lane's two patch columns (u1 == 16 unused)
     for (long q = wave_x; q < ngroups; q += nwaves_x) {
         // every per-level staging slice is a multiple of 4 slots (orbhip_extractor_reserve), so the 4 keypoints
         // of a wave share frame and level: level parameters stay in scalar registers
@@ -1070,15 +1077,25 @@ __global__ __launch_bounds__(OD_THREADS) void k_orient_desc(OrbParams P)
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // ---- IC_Angle (ORBextractor.cc:75-102)
-        const uint8_t *c = up + 15 * OD_UP + uoff + 15;
-        int m10 = 0, m01 = 0;
-#pragma unroll 1
-        for (int v = -ORB_HALF_PATCH; v <= ORB_HALF_PATCH; v++) {
-            const int d = P.umax[v < 0 ? -v : v];
-            const int a0 = (u0 >= -d) ? c[v * OD_UP + u0] : 0;       // u0 <= 0 <= d always
-            const int a1 = (u1 <= d) ? c[v * OD_UP + u1] : 0;        // u1 >= 1 > -d always
-            m10 += u0 * a0 + u1 * a1;
-            m01 += v * (a0 + a1);
+        // lane (j = l16 & 7, parity = l16 >> 3) sweeps patch columns -15+4j .. -12+4j of every second row:
+        // m10 = sum (u+16) I - 16 sum I and m01 = sum v * rowsum, both on v_dot4_u32_u8 (exact integers)
+        int m10, m01 = 0;
+        {
+            const int j = l16 & 7, par = l16 >> 3;
+            const uint32_t wts = 0x04030201u + 0x04040404u * (uint32_t)j;
+            uint32_t accP = 0, accS = 0;
+#pragma unroll 4
+            for (int i = 0; i < 16; i++) {
+                const int v = -ORB_HALF_PATCH + 2 * i + par, vc = min(v, ORB_HALF_PATCH);
+                const uint32_t *rq = up32 + (vc + ORB_HALF_PATCH) * (OD_UP / 4) + j;
+                uint32_t wv = __builtin_amdgcn_alignbyte(rq[1], rq[0], (uint32_t)uoff) & od_msk[(vc < 0 ? -vc : vc) * 8 + j];
+                if (v > ORB_HALF_PATCH) wv = 0;
+                const uint32_t sr = __builtin_amdgcn_udot4(wv, 0x01010101u, 0u, false);
+                accP = __builtin_amdgcn_udot4(wv, wts, accP, false);
+                accS += sr;
+                m01 += v * (int)sr;
+            }
+            m10 = (int)accP - 16 * (int)accS;
         }
 #pragma unroll
         for (int dd = 8; dd >= 1; dd >>= 1) { m10 += __shfl_xor(m10, dd, 16); m01 += __shfl_xor(m01, dd, 16); }
@@ -1087,19 +1104,22 @@ __global__ __launch_bounds__(OD_THREADS) void k_orient_desc(OrbParams P)
         double sd, cd;
         sincos_det((double)__fmul_rn(angle, factor_pi), &sd, &cd);
         const float a = (float)cd, b = (float)sd;
-        const uint8_t *bc = bp + 19 * OD_BP + boff + 19;
+        // cvRound by the 1.5*2^23 trick: fl(r + M) holds round-half-even(r) in its low mantissa bits, i.e.
+        // as_int = K + n with K = 0x4B400000; row*48 + col is then shifts and adds on the raw bits with the
+        // 49*K excess folded into the patch-centre offset.  Bits are shifted in MSB-first, so t runs down.
+        const float MAGIC = 12582912.0f;
+        const uint32_t offk = (uint32_t)(19 * OD_BP + boff + 19) - 49u * 0x4B400000u;
         uint32_t bits = 0;
 #pragma unroll 4
-        for (int t = 0; t < 16; t++) {
-            const uint32_t pk = pat_t[t * 16 + l16];
-            const float px0 = (float)(int8_t)(pk & 255), py0 = (float)(int8_t)((pk >> 8) & 255);
-            const float px1 = (float)(int8_t)((pk >> 16) & 255), py1 = (float)(int8_t)(pk >> 24);
-            const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(px0, b), __fmul_rn(py0, a)));
-            const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(px0, a), __fmul_rn(py0, b)));
-            const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1, b), __fmul_rn(py1, a)));
-            const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(px1, a), __fmul_rn(py1, b)));
-            const int t0 = bc[r0 * OD_BP + c0], t1 = bc[r1 * OD_BP + c1];
-            bits |= (uint32_t)(t0 < t1) << t;
+        for (int t = 15; t >= 0; t--) {
+            const float4 pk = pat_t[t * 16 + l16];
+            const uint32_t r0 = __float_as_uint(__fadd_rn(__fadd_rn(__fmul_rn(pk.x, b), __fmul_rn(pk.y, a)), MAGIC));
+            const uint32_t c0 = __float_as_uint(__fadd_rn(__fsub_rn(__fmul_rn(pk.x, a), __fmul_rn(pk.y, b)), MAGIC));
+            const uint32_t r1 = __float_as_uint(__fadd_rn(__fadd_rn(__fmul_rn(pk.z, b), __fmul_rn(pk.w, a)), MAGIC));
+            const uint32_t c1 = __float_as_uint(__fadd_rn(__fsub_rn(__fmul_rn(pk.z, a), __fmul_rn(pk.w, b)), MAGIC));
+            const uint32_t i0 = (r0 << 5) + (r0 << 4) + c0 + offk, i1 = (r1 << 5) + (r1 << 4) + c1 + offk;
+            const uint32_t t0 = bp[i0], t1 = bp[i1];
+            bits = __builtin_amdgcn_alignbit(bits, t0 - t1, 31);        // bits << 1 | (t0 < t1)
         }
         if (valid) {
             uint8_t *desc = P.lvl_desc + ((size_t)frame * P.kps_per_frame + slot) * 32;
