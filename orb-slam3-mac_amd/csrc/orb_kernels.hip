@@ -74,7 +74,7 @@ __device__ __forceinline__ int wave_sum(int v)
 // 4 pixels per thread, one dword store.  Bit-identical to the scalar formula of Appendix A.3.
 __global__ __launch_bounds__(256) void k_resize(OrbParams P, int level)
 {
-    __shared__ uint32_t in[RS_MAXR * (RS_MAXC / 4)];
+    __shared__ __attribute__((aligned(16))) uint32_t in[RS_MAXR * (RS_MAXC / 4)];
     __shared__ uint16_t hz[RS_MAXR * RS_TW];
     const OrbLevel &D = P.lv[level];
     const OrbLevel &S = P.lv[level - 1];
@@ -86,42 +86,56 @@ __global__ __launch_bounds__(256) void k_resize(OrbParams P, int level)
     const int dx_last = min(dx0 + RS_TW, D.w) - 1, dy_last = min(dy0 + RS_TH, D.h) - 1;
     const int ybase = D.yofs[dy0];                                   // may be -1
     const int nrows = min(D.yofs[dy_last] + 1 - ybase + 1, RS_MAXR);
-    const int xbase = D.xofs[dx0] & ~3;
-    const int ncd = min((D.xofs[dx_last] + 1 - xbase) / 4 + 1, RS_MAXC / 4);
+    const int xbase = D.xofs[dx0] & ~15;
+    const int nc16 = min((D.xofs[dx_last] + 1 - xbase) / 16 + 1, RS_MAXC / 16);
     const uint8_t *src = S.img + (size_t)frame * S.img_frame_stride;
-    // ---- A: loads in batches of 4 per thread before their LDS stores
-    for (int i0 = 0; i0 < nrows * ncd; i0 += 1024) {
-        uint32_t reg[4];
+    // coefficient tables of passes B and C: fetched now so that their latency hides behind the staging loads
+    const int dxl = tid & 63, dxB = min(dx0 + dxl, D.w - 1);
+    const int sxB = D.xofs[dxB], a0 = D.xalpha[2 * dxB], a1 = D.xalpha[2 * dxB + 1];
+    int r0C[2], b0C[2], b1C[2];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int i = i0 + tid + 256 * k;
-            uint32_t v = 0;
-            if (i < nrows * ncd) {
-                const int r = i / ncd, cd = i - r * ncd;
-                const int y = min(max(ybase + r, 0), S.h - 1);               // clip(sy, 0, ssize.height)
-                const int x = xbase + 4 * cd;
+    for (int rr = 0; rr < 2; rr++) {
+        const int dy = min(dy0 + 2 * (tid >> 4) + rr, D.h - 1);
+        r0C[rr] = D.yofs[dy]; b0C[rr] = D.ybeta[2 * dy]; b1C[rr] = D.ybeta[2 * dy + 1];
+    }
+    // ---- A: 16-byte chunks, 8 chunk slots x 32 rows per sweep (index math is shifts only); the loads of a
+    // sweep are issued before its LDS stores
+    for (int c = tid & 7; c < nc16; c += 8) {
+        const int x = xbase + 16 * c;
+        for (int r0 = tid >> 3; r0 < nrows; r0 += 64) {
+            uint4 reg[2];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int r = r0 + 32 * k;
+                const int y = min(max(ybase + r, 0), S.h - 1);                   // clip(sy, 0, ssize.height)
                 const uint8_t *row = src + (size_t)y * S.img_pitch;
-                if (x + 3 < S.w) v = *reinterpret_cast<const uint32_t *>(row + x);
-                else {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (r < nrows) {
+                    if (x + 15 < S.w) v = *reinterpret_cast<const uint4 *>(row + x);
+                    else {
+                        uint32_t d[4] = {0, 0, 0, 0};
+#pragma unroll 1
+                        for (int j = 0; j < 4; j++) {                             // right image edge only: keep it small
 #pragma unroll
-                    for (int j = 0; j < 4; j++) v |= (uint32_t)row[min(x + j, S.w - 1)] << (8 * j);
+                            for (int m = 0; m < 4; m++) d[m] |= (uint32_t)row[min(x + 4 * m + j, S.w - 1)] << (8 * j);
+                        }
+                        v = make_uint4(d[0], d[1], d[2], d[3]);
+                    }
                 }
+                reg[k] = v;
             }
-            reg[k] = v;
-        }
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int i = i0 + tid + 256 * k;
-            if (i < nrows * ncd) { const int r = i / ncd, cd = i - r * ncd; in[r * (RS_MAXC / 4) + cd] = reg[k]; }
+            for (int k = 0; k < 2; k++) {
+                const int r = r0 + 32 * k;
+                if (r < nrows) *reinterpret_cast<uint4 *>(&in[r * (RS_MAXC / 4) + 4 * c]) = reg[k];
+            }
         }
     }
     __syncthreads();
     // ---- B
     {
-        const int dxl = tid & 63, dx = dx0 + dxl;
-        if (dx < D.w) {
-            const int sx = D.xofs[dx] - xbase;
-            const int a0 = D.xalpha[2 * dx], a1 = D.xalpha[2 * dx + 1];
+        if (dx0 + dxl < D.w) {
+            const int sx = sxB - xbase;
             const uint8_t *inb = reinterpret_cast<const uint8_t *>(in);
             for (int r = tid >> 6; r < nrows; r += 4) {
                 const uint8_t *q = inb + r * RS_MAXC + sx;
@@ -139,8 +153,7 @@ __global__ __launch_bounds__(256) void k_resize(OrbParams P, int level)
             for (int rr = 0; rr < 2; rr++) {
                 const int dy = dy0 + 2 * rg + rr;
                 if (dy < D.h) {
-                    const int r0 = D.yofs[dy] - ybase;
-                    const int b0 = D.ybeta[2 * dy], b1 = D.ybeta[2 * dy + 1];
+                    const int r0 = r0C[rr] - ybase, b0 = b0C[rr], b1 = b1C[rr];
                     const uint2 t0 = *reinterpret_cast<const uint2 *>(&hz[r0 * RS_TW + 4 * c4]);
                     const uint2 t1 = *reinterpret_cast<const uint2 *>(&hz[(r0 + 1) * RS_TW + 4 * c4]);
                     const int u0[4] = {(int)(t0.x & 0xFFFF), (int)(t0.x >> 16), (int)(t0.y & 0xFFFF), (int)(t0.y >> 16)};
