@@ -306,20 +306,34 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbParams P)
     const int ndw = ((dw + 4) >> 2) + 1;                      // LDS dwords per row covering bytes [0, dw+4] (band + aprons)
     const int gx0 = bx - 4;                                   // image x of LDS byte 0 (>= 15)
     const int ax = gx0 & ~3, sh = gx0 & 3;
-    // lanes = (row sub-index, dword): rows_per_trip rows are staged per trip, no integer division
+    // lanes = (row sub-index, dword): rpt rows are staged per trip (no integer division in the loop).  ~97 % of
+    // the band's scores are zero and almost every wave holds a non-zero one, so while staging, the non-zero
+    // 4-pixel groups (group gx = band x 4gx..4gx+3 = LDS dword 1+gx) are compacted into a per-wave list
+    // (yy << 4 | gx); lane order within a trip and trip order are both row-major = cv::FAST's emission order.
+    uint16_t *lst = reinterpret_cast<uint16_t *>(sc32 + fc_rows * fc_pd);
+    const unsigned long long lt = (1ull << lane) - 1;
+    const int ngx = (dw + 3) >> 2;
+    int nl = 0;
     {
         const int rpt = 64 / ndw;                                  // rows per trip (ndw <= 16)
         const int r0 = lane / ndw, d = lane - r0 * ndw;
         uint32_t mask = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) { const int xx = 4 * d - 4 + j; if (xx >= 0 && xx < dw) mask |= 0xFFu << (8 * j); }
-        if (r0 < rpt) {
-            for (int yy = r0; yy < dh; yy += rpt) {
+        const bool isgrp = r0 < rpt && d >= 1 && d <= ngx;
+        for (int y0 = 0; y0 < dh; y0 += rpt) {
+            const int yy = y0 + r0;
+            uint32_t v = 0;
+            if (r0 < rpt && yy < dh) {
                 const uint32_t *q = reinterpret_cast<const uint32_t *>(smap + (size_t)(by + yy) * L.score_pitch + ax + 4 * d);
                 const uint32_t lo = q[0], hi = q[1];               // within the row pitch (pad bytes are masked off)
-                const uint32_t v = __builtin_amdgcn_alignbit(hi, lo, 8 * sh);
-                sc32[(yy + 1) * fc_pd + d] = v & mask;
+                v = __builtin_amdgcn_alignbit(hi, lo, 8 * sh) & mask;
+                sc32[(yy + 1) * fc_pd + d] = v;
             }
+            const bool nz = isgrp && v != 0;
+            const unsigned long long bal = __ballot(nz);
+            if (nz) lst[nl + __popcll(bal & lt)] = (uint16_t)((yy << 4) | (d - 1));
+            nl += __popcll(bal);
         }
     }
     for (int d = lane; d < ndw; d += 64) { sc32[d] = 0; sc32[(dh + 1) * fc_pd + d] = 0; }
@@ -329,76 +343,61 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbParams P)
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // NMS.  ~97 % of the band's scores are zero and almost every wave holds a non-zero one, so the non-zero
-    // 4-pixel groups (LDS dwords) are first compacted, in row-major order, into a per-wave list; the 3x3 test then
-    // runs densely, one listed group per lane.  Emission order (cv::FAST: row-major) follows from the list order.
-    uint16_t *lst = reinterpret_cast<uint16_t *>(sc32 + fc_rows * fc_pd);
-    const unsigned long long lt = (1ull << lane) - 1;
-    const int ngx = (dw + 3) >> 2, ngroups = ngx * dh;             // group gx = band x 4gx..4gx+3 = LDS dword 1+gx
-    int nl = 0;
-    for (int g0 = 0; g0 < ngroups; g0 += 64) {
-        const int g = g0 + lane;
-        bool nz = false;
-        if (g < ngroups) { const int yy = g / ngx, gx = g - yy * ngx; nz = sc32[(yy + 1) * fc_pd + 1 + gx] != 0; }
-        const unsigned long long bal = __ballot(nz);
-        if (nz) lst[nl + __popcll(bal & lt)] = (uint16_t)g;
-        nl += __popcll(bal);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    uint32_t *list = P.cell_list + (size_t)frame * P.cell_list_frame_stride + (size_t)cell * L.cell_cap;
-    int th = P.ini_th, total = 0;
-    for (int pass = 0; pass < 2; pass++) {
-        total = 0;
-        for (int i0 = 0; i0 < nl; i0 += 64) {
-            const int i = i0 + lane;
-            uint32_t keep = 0, cbytes = 0;
-            int yy = 0, gx = 0;
-            if (i < nl) {
-                const int g = lst[i];
-                yy = g / ngx; gx = g - yy * ngx;
-                const uint32_t *q = &sc32[(yy + 1) * fc_pd + 1 + gx];       // centre dword; rows +-1, dwords +-1 around it
-                // 6-byte windows (positions 0..5 = band x 4gx-1 .. 4gx+4) of the three rows
-                unsigned long long wr[3];
+    // NMS, threshold independent: with v(th) = score if score >= th else 0, "v(th) > every neighbour's v(th)"
+    // is (score >= th) && (score > raw neighbour maximum), so the strict 3x3 peaks are found once (one listed
+    // group per lane, column maxima shared by the four pixels) and both thresholds only gate the centre.
+    bool any_ini = false;
+    for (int i0 = 0; i0 < nl; i0 += 64) {
+        const int i = i0 + lane;
+        if (i < nl) {
+            const uint32_t e = lst[i];
+            const uint32_t *q = &sc32[((e >> 4) + 1) * fc_pd + 1 + (e & 15)];   // centre dword; rows +-1, dwords +-1 around it
+            uint32_t b[3][6];                                                   // bytes = band x 4gx-1 .. 4gx+4 of the three rows
 #pragma unroll
-                for (int r = 0; r < 3; r++) {
-                    const uint32_t *qq = q + (r - 1) * fc_pd;
-                    wr[r] = (unsigned long long)(qq[-1] >> 24) | ((unsigned long long)qq[0] << 8) | ((unsigned long long)(qq[1] & 0xFFu) << 40);
-                }
-                cbytes = q[0];
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int c = (int)((cbytes >> (8 * j)) & 0xFFu);
-                    const int v = c >= th ? c : 0;                                 // v(th) = score if S > th else 0
-                    if (v) {
-                        int m = 0;
-#pragma unroll
-                        for (int r = 0; r < 3; r++)
-#pragma unroll
-                            for (int dx = 0; dx < 3; dx++)
-                                if (!(r == 1 && dx == 1)) { const int nb = (int)((wr[r] >> (8 * (j + dx))) & 0xFFu); m = max(m, nb >= th ? nb : 0); }
-                        if (v > m) keep |= 1u << j;
-                    }
-                }
+            for (int r = 0; r < 3; r++) {
+                const uint32_t *qq = q + (r - 1) * fc_pd;
+                const uint32_t w0 = qq[-1], w1 = qq[0], w2 = qq[1];
+                b[r][0] = w0 >> 24; b[r][1] = w1 & 0xFFu; b[r][2] = (w1 >> 8) & 0xFFu; b[r][3] = (w1 >> 16) & 0xFFu; b[r][4] = w1 >> 24; b[r][5] = w2 & 0xFFu;
             }
-            const int mine = __popc(keep);
-            if (pass == 0) { total += __popcll(__ballot(keep != 0)); continue; }
-            const int inc = wave_incl_scan(mine);
-            int offs = total + inc - mine;
+            uint32_t cm[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) cm[k] = max(max(b[0][k], b[1][k]), b[2][k]);
+            uint32_t pk = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t m = max(max(cm[j], cm[j + 2]), max(b[0][j + 1], b[2][j + 1]));
+                const uint32_t c = b[1][j + 1];
+                if (c > m) { pk |= 1u << j; any_ini |= (int)c >= P.ini_th; }
+            }
+            lst[i] = (uint16_t)(e | (pk << 12));
+        }
+    }
+    const int th = __ballot(any_ini) ? P.ini_th : P.min_th;       // vKeysCell empty at iniThFAST: retry (ORBextractor.cc:825-828)
+    uint32_t *list = P.cell_list + (size_t)frame * P.cell_list_frame_stride + (size_t)cell * L.cell_cap;
+    int total = 0;
+    for (int i0 = 0; i0 < nl; i0 += 64) {
+        const int i = i0 + lane;
+        uint32_t keep = 0, cbytes = 0;
+        int yy = 0, gx = 0;
+        if (i < nl) {
+            const uint32_t e = lst[i];
+            yy = (e >> 4) & 63; gx = e & 15;
+            cbytes = sc32[(yy + 1) * fc_pd + 1 + gx];
 #pragma unroll
             for (int j = 0; j < 4; j++)
-                if (keep & (1u << j)) {
-                    if (offs < L.cell_cap)
-                        list[offs] = ORB_PACK_KEY(4 * gx + j + 3 + cj * L.wcell, yy + 3 + ci * L.hcell, (cbytes >> (8 * j)) & 0xFFu);
-                    offs++;
-                }
-            total += __shfl(inc, 63, 64);
+                if ((e >> (12 + j)) & 1u) { if ((int)((cbytes >> (8 * j)) & 0xFFu) >= th) keep |= 1u << j; }
         }
-        if (pass == 0) {
-            if (total == 0) th = P.min_th;                    // vKeysCell empty at iniThFAST: retry (ORBextractor.cc:825-828)
-        }
+        const int mine = __popc(keep);
+        const int inc = wave_incl_scan(mine);
+        int offs = total + inc - mine;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (keep & (1u << j)) {
+                if (offs < L.cell_cap)
+                    list[offs] = ORB_PACK_KEY(4 * gx + j + 3 + cj * L.wcell, yy + 3 + ci * L.hcell, (cbytes >> (8 * j)) & 0xFFu);
+                offs++;
+            }
+        total += __shfl(inc, 63, 64);
     }
     if (total > L.cell_cap) { if (lane == 0) atomicExch(P.status, ORBHIP_E_CAPACITY); total = L.cell_cap; }
     if (lane == 0) *cnt_out = (uint32_t)total;
