@@ -321,19 +321,29 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbParams P)
 #pragma unroll
         for (int j = 0; j < 4; j++) { const int xx = 4 * d - 4 + j; if (xx >= 0 && xx < dw) mask |= 0xFFu << (8 * j); }
         const bool isgrp = r0 < rpt && d >= 1 && d <= ngx;
-        for (int y0 = 0; y0 < dh; y0 += rpt) {
-            const int yy = y0 + r0;
-            uint32_t v = 0;
-            if (r0 < rpt && yy < dh) {
-                const uint32_t *q = reinterpret_cast<const uint32_t *>(smap + (size_t)(by + yy) * L.score_pitch + ax + 4 * d);
-                const uint32_t lo = q[0], hi = q[1];               // within the row pitch (pad bytes are masked off)
-                v = __builtin_amdgcn_alignbit(hi, lo, 8 * sh) & mask;
-                sc32[(yy + 1) * fc_pd + d] = v;
+        // four trips per batch: their eight loads are issued together (the ballots below would otherwise
+        // serialise every trip on its own load latency)
+        for (int y0 = 0; y0 < dh; y0 += 4 * rpt) {
+            uint32_t lo[4], hi[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int yy = y0 + k * rpt + r0;
+                lo[k] = 0; hi[k] = 0;
+                if (r0 < rpt && yy < dh) {
+                    const uint32_t *q = reinterpret_cast<const uint32_t *>(smap + (size_t)(by + yy) * L.score_pitch + ax + 4 * d);
+                    lo[k] = q[0]; hi[k] = q[1];                    // within the row pitch (pad bytes are masked off)
+                }
             }
-            const bool nz = isgrp && v != 0;
-            const unsigned long long bal = __ballot(nz);
-            if (nz) lst[nl + __popcll(bal & lt)] = (uint16_t)((yy << 4) | (d - 1));
-            nl += __popcll(bal);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int yy = y0 + k * rpt + r0;
+                const uint32_t v = __builtin_amdgcn_alignbit(hi[k], lo[k], 8 * sh) & mask;
+                if (r0 < rpt && yy < dh) sc32[(yy + 1) * fc_pd + d] = v;
+                const bool nz = isgrp && v != 0;
+                const unsigned long long bal = __ballot(nz);
+                if (nz) lst[nl + __popcll(bal & lt)] = (uint16_t)((yy << 4) | (d - 1));
+                nl += __popcll(bal);
+            }
         }
     }
     for (int d = lane; d < ndw; d += 64) { sc32[d] = 0; sc32[(dh + 1) * fc_pd + d] = 0; }
