@@ -191,6 +191,7 @@ void orb_launch_resize(const OrbParams &P, int level, hipStream_t s)
 // ----------------------------------------------------------------------------------
 #define FAST_TP 72            // LDS pitch (bytes): cells up to 64 wide + up to 3 bytes of dword alignment
 typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
 
 __device__ __forceinline__ s16x2 as_s16x2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
 __device__ __forceinline__ s16x2 pkmin(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
@@ -272,7 +273,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbParams P)
     extern __shared__ uint32_t fc_lds[];
     const int fc_pd = P.fc_pd, fc_rows = P.fc_rows;
     const int fc_wave_dw = fc_rows * fc_pd + (fc_rows * fc_pd + 1) / 2;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform: cell geometry stays in scalar registers
     const int bpf = (P.cells_per_frame + 3) >> 2;              // workgroups per frame
     const unsigned lid = xcd_logical_id(blockIdx.x, gridDim.x);
     const int frame = lid / bpf;
@@ -305,7 +307,6 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbParams P)
     const uint8_t *smap = L.score + (size_t)frame * L.score_frame_stride;
     const int ndw = ((dw + 4) >> 2) + 1;                      // LDS dwords per row covering bytes [0, dw+4] (band + aprons)
     const int gx0 = bx - 4;                                   // image x of LDS byte 0 (>= 15)
-    const int ax = gx0 & ~3, sh = gx0 & 3;
     // lanes = (row sub-index, dword): rpt rows are staged per trip (no integer division in the loop).  ~97 % of
     // the band's scores are zero and almost every wave holds a non-zero one, so while staging, the non-zero
     // 4-pixel groups (group gx = band x 4gx..4gx+3 = LDS dword 1+gx) are compacted into a per-wave list
@@ -321,23 +322,21 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbParams P)
 #pragma unroll
         for (int j = 0; j < 4; j++) { const int xx = 4 * d - 4 + j; if (xx >= 0 && xx < dw) mask |= 0xFFu << (8 * j); }
         const bool isgrp = r0 < rpt && d >= 1 && d <= ngx;
-        // four trips per batch: their eight loads are issued together (the ballots below would otherwise
-        // serialise every trip on its own load latency)
-        for (int y0 = 0; y0 < dh; y0 += 4 * rpt) {
-            uint32_t lo[4], hi[4];
+        // eight trips per batch (a whole VGA cell), one unaligned dword load each, all issued together: the
+        // ballots below would otherwise serialise every trip on its own load latency
+        for (int y0 = 0; y0 < dh; y0 += 8 * rpt) {
+            uint32_t ld[8];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < 8; k++) {
                 const int yy = y0 + k * rpt + r0;
-                lo[k] = 0; hi[k] = 0;
-                if (r0 < rpt && yy < dh) {
-                    const uint32_t *q = reinterpret_cast<const uint32_t *>(smap + (size_t)(by + yy) * L.score_pitch + ax + 4 * d);
-                    lo[k] = q[0]; hi[k] = q[1];                    // within the row pitch (pad bytes are masked off)
-                }
+                ld[k] = 0;
+                if (r0 < rpt && yy < dh)                           // within the row pitch (pad bytes are masked off)
+                    ld[k] = *reinterpret_cast<const u32_unaligned *>(smap + (size_t)(by + yy) * L.score_pitch + gx0 + 4 * d);
             }
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < 8; k++) {
                 const int yy = y0 + k * rpt + r0;
-                const uint32_t v = __builtin_amdgcn_alignbit(hi[k], lo[k], 8 * sh) & mask;
+                const uint32_t v = ld[k] & mask;
                 if (r0 < rpt && yy < dh) sc32[(yy + 1) * fc_pd + d] = v;
                 const bool nz = isgrp && v != 0;
                 const unsigned long long bal = __ballot(nz);
