@@ -995,23 +995,16 @@ __device__ __forceinline__ void sincos_det(double x, double *s_out, double *c_ou
 // = two consecutive descriptor bytes.
 #define OD_UP 48              // un-blurred patch pitch: 31 + up to 3 alignment bytes, staged as three 16-byte chunks
 #define OD_BP 48              // blurred patch pitch: 39 + up to 3, three 16-byte chunks
-#define OD_KP_LDS ((31 * OD_UP + 39 * OD_BP) / 4)       // dwords per keypoint
-#define OD_THREADS 128        // 8 keypoints per workgroup: 27 KB of LDS -> 5 workgroups per CU
-// Branch-free 16-byte fetch that never reads past the row pitch: the address is clamped to pitch-16
-// and the wanted dwords are shifted down (x and pitch are multiples of 4); dwords beyond the pitch come
-// out as zero and are never sampled (patches lie inside the image).  One dwordx4 per lane instead of
-// four dword loads: the kernel's time follows the number of load wave-instructions.
-__device__ __forceinline__ uint4 od_load16(const uint8_t *row, int x, int pitch)
+#define OD_KP_LDS ((39 * OD_BP) / 4)                     // dwords per keypoint: the un-blurred patch (moments) and then the blurred one (rBRIEF) share it
+#define OD_THREADS 128        // 8 keypoints per workgroup: 19.6 KB of LDS -> 8 workgroups (16 waves) per CU
+// 16-byte fetch at a dword-aligned x: one dwordx4 per lane instead of four dword loads (the kernel's time
+// follows the number of load wave-instructions).  A chunk may run up to 16 bytes past the end of its row:
+// those bytes are never sampled (patches lie inside the image) and the read stays inside the buffer -- the
+// un-blurred patch ends at image row <= h-5 (so the overrun lands in a later row, also when level 0 aliases
+// the caller's frames), the blurred levels are allocated with 64 bytes of slack (orbhip_extractor_reserve).
+__device__ __forceinline__ uint4 od_load16(const uint8_t *img, uint32_t row_off, int x)
 {
-    const int xs = min(x, pitch - 16);
-    const uint4 v = *reinterpret_cast<const uint4 *>(row + xs);
-    const int d = (x - xs) >> 2;
-    uint4 o;
-    o.x = d == 0 ? v.x : d == 1 ? v.y : d == 2 ? v.z : v.w;
-    o.y = d == 0 ? v.y : d == 1 ? v.z : d == 2 ? v.w : 0u;
-    o.z = d == 0 ? v.z : d == 1 ? v.w : 0u;
-    o.w = d == 0 ? v.w : 0u;
-    return o;
+    return *reinterpret_cast<const uint4 *>(img + (row_off + (uint32_t)x));      // uniform base + 32-bit lane offset
 }
 
 __global__ __launch_bounds__(OD_THREADS) void k_orient_desc(OrbParams P)
@@ -1039,7 +1032,7 @@ __global__ __launch_bounds__(OD_THREADS) void k_orient_desc(OrbParams P)
     const long wave_x = (long)(blockIdx.x >> 3) * (OD_THREADS / 64) + (tid >> 6), nwaves_x = (long)nblk_x * (OD_THREADS / 64);
     const int gpf = (P.kps_per_frame + 3) >> 2;                          // groups of 4 slots per frame
     const int nframes_x = (P.batch - xcd + 7) >> 3;                      // frames xcd, xcd+8, ...
-    uint32_t *up32 = lds_all[(tid >> 4)], *bp32 = up32 + 31 * OD_UP / 4;
+    uint32_t *up32 = lds_all[(tid >> 4)], *bp32 = up32;
     const uint8_t *bp = reinterpret_cast<const uint8_t *>(bp32);
     const float factor_pi = (float)(3.1415926535897932384626433832795 / 180.f);
     const long ngroups = (long)nframes_x * gpf;
@@ -1066,31 +1059,30 @@ __global__ __launch_bounds__(OD_THREADS) void k_orient_desc(OrbParams P)
         const int uxs = (x - 15) & ~3, uoff = (x - 15) - uxs;        // un-blurred: cols x-15..x+15
         const int bxs = (x - 19) & ~3, boff = (x - 19) - bxs;        // blurred:    cols x-19..x+19
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // previous keypoints' LDS reads are done
+        // the 16 lanes sweep the patch rows in 16-byte chunks (3 per row): 6 + 8 dwordx4 loads per lane, all issued
+        // before the first LDS store so that they are in flight together; the blurred chunks wait in registers
+        // until the moments are done with the shared LDS region
+        uint4 br[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) br[k] = make_uint4(0, 0, 0, 0);
         if (valid) {
-            const uint8_t *ubase = L.img + (size_t)frame * L.img_frame_stride + (size_t)(y - 15) * L.img_pitch;
-            const uint8_t *bbase = L.blur + (size_t)frame * L.blur_frame_stride + (size_t)(y - 19) * L.blur_pitch;
-            // the 16 lanes sweep the patch rows in 16-byte chunks (3 per row): 6 + 8 dwordx4 loads per lane, all
-            // issued before the first LDS store so that they are in flight together
-            uint4 ur[6], br[8];
+            const uint8_t *uimg = L.img + (size_t)frame * L.img_frame_stride, *bimg = L.blur + (size_t)frame * L.blur_frame_stride;
+            const uint32_t urow = (uint32_t)((y - 15) * L.img_pitch), brow = (uint32_t)((y - 19) * L.blur_pitch);
+            uint4 ur[6];
 #pragma unroll
             for (int k = 0; k < 6; k++) {
                 const int i = l16 + 16 * k, r = i / 3, c3 = i - r * 3;
-                ur[k] = i < 31 * 3 ? od_load16(ubase + (size_t)r * L.img_pitch, uxs + 16 * c3, L.img_pitch) : make_uint4(0, 0, 0, 0);
+                ur[k] = i < 31 * 3 ? od_load16(uimg, urow + (uint32_t)(r * L.img_pitch), uxs + 16 * c3) : make_uint4(0, 0, 0, 0);
             }
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const int i = l16 + 16 * k, r = i / 3, c3 = i - r * 3;
-                br[k] = i < 39 * 3 ? od_load16(bbase + (size_t)r * L.blur_pitch, bxs + 16 * c3, L.blur_pitch) : make_uint4(0, 0, 0, 0);
+                if (i < 39 * 3) br[k] = od_load16(bimg, brow + (uint32_t)(r * L.blur_pitch), bxs + 16 * c3);
             }
 #pragma unroll
             for (int k = 0; k < 6; k++) {
                 const int i = l16 + 16 * k, r = i / 3, c3 = i - r * 3;
                 if (i < 31 * 3) *reinterpret_cast<uint4 *>(&up32[r * (OD_UP / 4) + 4 * c3]) = ur[k];
-            }
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int i = l16 + 16 * k, r = i / 3, c3 = i - r * 3;
-                if (i < 39 * 3) *reinterpret_cast<uint4 *>(&bp32[r * (OD_BP / 4) + 4 * c3]) = br[k];
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1118,6 +1110,16 @@ __global__ __launch_bounds__(OD_THREADS) void k_orient_desc(OrbParams P)
             }
             m10 = (int)accP - 16 * (int)accS;
         }
+        // the moments' LDS reads are done: the blurred patch takes the region over
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (valid) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int i = l16 + 16 * k, r = i / 3, c3 = i - r * 3;
+                if (i < 39 * 3) *reinterpret_cast<uint4 *>(&bp32[r * (OD_BP / 4) + 4 * c3]) = br[k];
+            }
+        }
 #pragma unroll
         for (int dd = 8; dd >= 1; dd >>= 1) { m10 += __shfl_xor(m10, dd, 16); m01 += __shfl_xor(m01, dd, 16); }
         const float angle = fast_atan2_deg((float)m01, (float)m10);
@@ -1128,6 +1130,10 @@ __global__ __launch_bounds__(OD_THREADS) void k_orient_desc(OrbParams P)
         // cvRound by the 1.5*2^23 trick: fl(r + M) holds round-half-even(r) in its low mantissa bits, i.e.
         // as_int = K + n with K = 0x4B400000; row*48 + col is then shifts and adds on the raw bits with the
         // 49*K excess folded into the patch-centre offset.  Bits are shifted in MSB-first, so t runs down.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const float MAGIC = 12582912.0f;
         const uint32_t offk = (uint32_t)(19 * OD_BP + boff + 19) - 49u * 0x4B400000u;
         uint32_t bits = 0;
@@ -1154,7 +1160,7 @@ void orb_launch_orient_desc(const OrbParams &P, hipStream_t s)
 {
     const long total = (long)P.batch * P.kps_per_frame;
     (void)total;
-    const long blocks = 256 * 5;                       // LDS: 27 KB per workgroup -> 5 per CU; multiple of 8 (XCD split)
+    const long blocks = 256 * 8;                       // LDS: 19.6 KB per workgroup -> 8 per CU; multiple of 8 (XCD split)
     hipLaunchKernelGGL(k_orient_desc, dim3((unsigned)blocks), dim3(OD_THREADS), 0, s, P);
 }
 
