@@ -305,6 +305,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbParams P)
     uint8_t *sc = reinterpret_cast<uint8_t *>(sc32);
     const int bx = ini_x + 3, by = ini_y + 3;
     const uint8_t *smap = L.score + (size_t)frame * L.score_frame_stride;
+    const int spitch = L.score_pitch & 0xFFFF;                // known-small operands: v_mul_u32_u24 instead of the quarter-rate v_mul_lo_u32
     const int ndw = ((dw + 4) >> 2) + 1;                      // LDS dwords per row covering bytes [0, dw+4] (band + aprons)
     const int gx0 = bx - 4;                                   // image x of LDS byte 0 (>= 15)
     // lanes = (row sub-index, dword): rpt rows are staged per trip (no integer division in the loop).  ~97 % of
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbParams P)
                 const int yy = y0 + k * rpt + r0;
                 ld[k] = 0;
                 if (r0 < rpt && yy < dh)                           // within the row pitch (pad bytes are masked off)
-                    ld[k] = *reinterpret_cast<const u32_unaligned *>(smap + (size_t)(by + yy) * L.score_pitch + gx0 + 4 * d);
+                    ld[k] = *reinterpret_cast<const u32_unaligned *>(smap + (uint32_t)(((by + yy) & 0xFFFF) * spitch + gx0 + 4 * d));
             }
 #pragma unroll
             for (int k = 0; k < 8; k++) {
@@ -1067,21 +1068,22 @@ __global__ __launch_bounds__(OD_THREADS) void k_orient_desc(OrbParams P)
         for (int k = 0; k < 8; k++) br[k] = make_uint4(0, 0, 0, 0);
         if (valid) {
             const uint8_t *uimg = L.img + (size_t)frame * L.img_frame_stride, *bimg = L.blur + (size_t)frame * L.blur_frame_stride;
-            const uint32_t urow = (uint32_t)((y - 15) * L.img_pitch), brow = (uint32_t)((y - 19) * L.blur_pitch);
+            const int upitch = L.img_pitch & 0xFFFF, bpitch = L.blur_pitch & 0xFFFF;     // known-small operands: 24-bit multiplies
+            const uint32_t urow = (uint32_t)(((y - 15) & 0xFFFF) * upitch), brow = (uint32_t)(((y - 19) & 0xFFFF) * bpitch);
             uint4 ur[6];
 #pragma unroll
             for (int k = 0; k < 6; k++) {
-                const int i = l16 + 16 * k, r = i / 3, c3 = i - r * 3;
-                ur[k] = i < 31 * 3 ? od_load16(uimg, urow + (uint32_t)(r * L.img_pitch), uxs + 16 * c3) : make_uint4(0, 0, 0, 0);
+                const int i = l16 + 16 * k, r = (i * 43) >> 7, c3 = i - r * 3;      // i / 3 for i < 128
+                ur[k] = i < 31 * 3 ? od_load16(uimg, urow + (uint32_t)(r * upitch), uxs + 16 * c3) : make_uint4(0, 0, 0, 0);
             }
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const int i = l16 + 16 * k, r = i / 3, c3 = i - r * 3;
-                if (i < 39 * 3) br[k] = od_load16(bimg, brow + (uint32_t)(r * L.blur_pitch), bxs + 16 * c3);
+                const int i = l16 + 16 * k, r = (i * 43) >> 7, c3 = i - r * 3;      // i / 3 for i < 128
+                if (i < 39 * 3) br[k] = od_load16(bimg, brow + (uint32_t)(r * bpitch), bxs + 16 * c3);
             }
 #pragma unroll
             for (int k = 0; k < 6; k++) {
-                const int i = l16 + 16 * k, r = i / 3, c3 = i - r * 3;
+                const int i = l16 + 16 * k, r = (i * 43) >> 7, c3 = i - r * 3;      // i / 3 for i < 128
                 if (i < 31 * 3) *reinterpret_cast<uint4 *>(&up32[r * (OD_UP / 4) + 4 * c3]) = ur[k];
             }
         }
@@ -1116,7 +1118,7 @@ __global__ __launch_bounds__(OD_THREADS) void k_orient_desc(OrbParams P)
         if (valid) {
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const int i = l16 + 16 * k, r = i / 3, c3 = i - r * 3;
+                const int i = l16 + 16 * k, r = (i * 43) >> 7, c3 = i - r * 3;      // i / 3 for i < 128
                 if (i < 39 * 3) *reinterpret_cast<uint4 *>(&bp32[r * (OD_BP / 4) + 4 * c3]) = br[k];
             }
         }
