@@ -133,7 +133,7 @@ int orbhip_descriptor_distance(const uint8_t *a32, const uint8_t *b32);
  * Outputs per query row: idx[2], dist[2] (ascending; strict <, lowest index wins ties;
  * idx -1 / dist INT_MAX when fewer than k train rows) and ratio-test flag
  * (float)d0 < (float)d1*ratio evaluated in double as in Frame.cc:1153 (ratio there: 0.7).
- * Row q of pair p lands at [p*max_n + q].  All pointers DEVICE. */
+ * Row q of pair p lands at [p*max_n + q].  All pointers DEVICE.  max_n <= 65535 (else ORBHIP_E_BADARG). */
 int orbhip_match_bf2nn_device(orbhip_ctx *ctx, const uint8_t *d_descA, const int32_t *d_nA,
                               size_t strideA, const uint8_t *d_descB, const int32_t *d_nB,
                               size_t strideB, int pairs, int max_n, double ratio,

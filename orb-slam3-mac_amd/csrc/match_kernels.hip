@@ -52,19 +52,25 @@ __global__ __launch_bounds__(256) void k_bf2nn(const uint8_t *descA, const int32
     const uint4 *B = reinterpret_cast<const uint4 *>(descB + (size_t)pair * strideB);
     uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
     if (q < na) { a0 = A[2 * q]; a1 = A[2 * q + 1]; }
-    int best = INT_MAX, second = INT_MAX, bi = -1, si = -1;
+    // best / second-best as keys (distance << 16 | train index): "first candidate wins on equal distance"
+    // (strict < in the reference loop) is exactly the lexicographic order of the keys, so the running pair is
+    // the two smallest keys -- three min/max per candidate instead of a compare-and-swap ladder
+    uint32_t kb = 0xFFFFFFFFu, ks = 0xFFFFFFFFu;
     for (int t0 = 0; t0 < nb; t0 += BF_TILE) {
         const int tn = min(BF_TILE, nb - t0);
         __syncthreads();
         for (int i = tid; i < tn * 2; i += 256) tile[i] = B[2 * t0 + i];
         __syncthreads();
+#pragma unroll 4
         for (int j = 0; j < tn; j++) {
-            const int d = hamming256(a0, a1, tile[2 * j], tile[2 * j + 1]);
-            if (d < best) { second = best; si = bi; best = d; bi = t0 + j; }
-            else if (d < second) { second = d; si = t0 + j; }
+            const uint32_t key = ((uint32_t)hamming256(a0, a1, tile[2 * j], tile[2 * j + 1]) << 16) | (uint32_t)(t0 + j);
+            ks = min(ks, max(kb, key));
+            kb = min(kb, key);
         }
     }
     if (q < na) {
+        const int best = kb == 0xFFFFFFFFu ? INT_MAX : (int)(kb >> 16), second = ks == 0xFFFFFFFFu ? INT_MAX : (int)(ks >> 16);
+        const int bi = kb == 0xFFFFFFFFu ? -1 : (int)(kb & 0xFFFFu), si = ks == 0xFFFFFFFFu ? -1 : (int)(ks & 0xFFFFu);
         const size_t o = ((size_t)pair * max_n + q) * 2;
         idx2[o] = bi; idx2[o + 1] = si; dist2[o] = best; dist2[o + 1] = second;
         // Frame.cc:1153: (*it).size() >= 2 && (*it)[0].distance < (*it)[1].distance * 0.7  (float < float*double)
@@ -76,8 +82,8 @@ extern "C" int orbhip_match_bf2nn_device(orbhip_ctx *ctx, const uint8_t *d_descA
                                          const uint8_t *d_descB, const int32_t *d_nB, size_t strideB, int pairs,
                                          int max_n, double ratio, int32_t *d_idx2, int32_t *d_dist2, uint8_t *d_accept)
 {
-    if (!ctx || !d_descA || !d_descB || !d_nA || !d_nB || pairs <= 0 || max_n <= 0 || !d_idx2 || !d_dist2 || !d_accept)
-        return ORBHIP_E_BADARG;
+    if (!ctx || !d_descA || !d_descB || !d_nA || !d_nB || pairs <= 0 || max_n <= 0 || max_n > 65535 || !d_idx2 || !d_dist2 || !d_accept)
+        return ORBHIP_E_BADARG;              // train indices ride in 16 bits of the 2-NN keys
     if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
     dim3 grid((max_n + 255) / 256, pairs);
     hipLaunchKernelGGL(k_bf2nn, grid, dim3(256), 0, orbhip_ctx_stream_internal(ctx), d_descA, d_nA, strideA, d_descB, d_nB,
