@@ -161,6 +161,37 @@ int orbhip_search_for_initialization_device(orbhip_ctx *ctx,
 int orbhip_prev_matched_init_device(orbhip_ctx *ctx, const orbhip_keypoint *d_kp, size_t frame_stride_kp,
                                     int frames, int max_n, float *d_prev_matched);
 
+/* ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono)
+ * (src/ORBmatcher.cc:1965-2181, CurrentFrame.Nleft == -1: monocular / rectified stereo) -- the matcher of
+ * Tracking::TrackWithMotionModel (src/Tracking.cc:2683-2694).  The projection of the last frame's map
+ * points (ORBmatcher.cc:1992-2008) stays host geometry; each surviving point arrives as one query:
+ *   u, v       uv = CurrentFrame.mpCamera->project(x3Dc)                       (ORBmatcher.cc:2003)
+ *   radius     th * CurrentFrame.mvScaleFactors[nLastOctave]                   (:2014)
+ *   ur         uv.x - CurrentFrame.mbf * invzc                                 (:2043)
+ *   angle      angle of the last frame's (undistorted) keypoint                (:2067-2073)
+ *   min_level, max_level   level arguments of the GetFeaturesInArea call picked by bForward / bBackward
+ *              (:2018-2023): (oct,-1) | (0,oct) | (oct-1,oct+1); -1 = open end (src/Frame.cc:676)
+ *   has_obs    pMP->Observations() > 0: a keypoint claimed by such a point is no candidate for later
+ *              queries (:2037-2039)
+ * Train side = CurrentFrame: mvKeysUn (x, y, octave, angle of orbhip_keypoint), descriptors, optional
+ * mvuRight (NULL = monocular, all -1), image bounds mnMinX..mnMaxY for the 64x48 grid (src/Frame.cc:377-408,
+ * 645-726).  d_train_match [pairs][max_n] is CurrentFrame.mvpMapPoints, in/out: entry -1 = free, anything else
+ * = already holds a map point with observations (returned as -2, never matched); on return a value >= 0 is the
+ * index of the query that owns the keypoint.  d_nmatches[pair] = the function's return value (rotation
+ * consistency, :2156-2178, applied when check_orientation).  th_high = ORBmatcher::TH_HIGH = 100 (:40).
+ * At most 2048 queries and 2048 keypoints per pair (else the context status becomes ORBHIP_E_CAPACITY).
+ * Pair p reads queries at d_q + p*max_q, keypoints at d_kp + p*frame_stride_kp.  All pointers DEVICE. */
+typedef struct orbhip_proj_query {
+    float u, v, radius, ur, angle;
+    int32_t min_level, max_level, has_obs;
+} orbhip_proj_query;
+int orbhip_search_by_projection_device(orbhip_ctx *ctx, const orbhip_proj_query *d_q, const uint8_t *d_desc_q,
+                                       const int32_t *d_nq, int max_q, const orbhip_keypoint *d_kp,
+                                       const uint8_t *d_desc, const float *d_u_right, const int32_t *d_n, int max_n,
+                                       size_t frame_stride_kp, int pairs, float min_x, float min_y, float max_x,
+                                       float max_y, int th_high, int check_orientation, int32_t *d_train_match,
+                                       int32_t *d_nmatches);
+
 /* ------------------------------------------------------------------ local BA */
 /* One keyframe-window graph in SoA form: what Optimizer::LocalBundleAdjustment builds
  * between src/Optimizer.cc:1850 and :2034.  Poses world->camera as (qx,qy,qz,qw,tx,ty,tz)

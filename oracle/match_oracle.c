@@ -187,3 +187,57 @@ int orc_search_for_initialization(const orc_keypoint *kpA, const uint8_t *descA,
     grid_free(&g); free(bin_of); free(matched_dist); free(m21); free(cand);
     return nmatches;
 }
+
+/* ORBm:1965-2181, CurrentFrame.Nleft == -1 (monocular / rectified stereo) */
+int orc_search_by_projection(const orc_proj_query *q, const uint8_t *desc_q, int nq,
+                             const orc_keypoint *kp, const uint8_t *desc, const float *u_right, int n,
+                             float min_x, float min_y, float max_x, float max_y,
+                             int th_high, int check_orientation, int32_t *train_match)
+{
+    int nmatches = 0;
+    struct grid g;
+    grid_build(&g, kp, n, min_x, min_y, max_x, max_y);
+    /* rotHist[bin] = list of bestIdx2 (duplicates possible), ORBm:1970-1973, 2083 */
+    int *hist_n = (int *)calloc(HISTO_LENGTH, sizeof(int));
+    int *hist_items = (int *)malloc(sizeof(int) * (size_t)HISTO_LENGTH * (nq ? nq : 1));
+    int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * (n ? n : 1));
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int i = 0; i < n; i++) if (train_match[i] != -1) train_match[i] = -2;
+    for (int t = 0; t < nq; t++) {
+        const float radius = q[t].radius;
+        const int nc = grid_query(&g, kp, q[t].u, q[t].v, radius, q[t].min_level, q[t].max_level, cand, n);
+        if (nc == 0) continue;                                             /* ORBm:2025-2026 */
+        int best_dist = 256, best_idx = -1;                                /* ORBm:2030-2031 */
+        for (int c = 0; c < nc; c++) {
+            const int i2 = cand[c];
+            const int h = train_match[i2];
+            if (h <= -2 || (h >= 0 && q[h].has_obs)) continue;             /* ORBm:2037-2039 */
+            if (u_right && u_right[i2] > 0) {                              /* ORBm:2041-2047 */
+                const float er = fabsf(q[t].ur - u_right[i2]);
+                if (er > radius) continue;
+            }
+            const int dist = orc_descriptor_distance(desc_q + 32 * (size_t)t, desc + 32 * (size_t)i2);
+            if (dist < best_dist) { best_dist = dist; best_idx = i2; }
+        }
+        if (best_dist <= th_high) {                                        /* ORBm:2058-2086 */
+            train_match[best_idx] = t;
+            nmatches++;
+            if (check_orientation) {
+                float rot = q[t].angle - kp[best_idx].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                hist_items[(size_t)bin * nq + hist_n[bin]++] = best_idx;
+            }
+        }
+    }
+    if (check_orientation) {                                               /* ORBm:2156-2178 */
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(hist_n, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int j = 0; j < hist_n[i]; j++) { train_match[hist_items[(size_t)i * nq + j]] = -1; nmatches--; }
+    }
+    free(cand); free(hist_items); free(hist_n); grid_free(&g);
+    return nmatches;
+}

@@ -30,6 +30,19 @@ int orc_search_for_initialization(const orc_keypoint *kpA, const uint8_t *descA,
 int orc_features_in_area(const orc_keypoint *kp, int n, float min_x, float min_y, float max_x,
                          float max_y, float x, float y, float r, int min_level, int max_level,
                          int32_t *out, int cap);
+/* One projected map point of ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono)
+ * (ORBmatcher.cc:1965-2181, Nleft == -1 path).  The projection itself (ORBm:1992-2008) is host geometry:
+ * the caller supplies uv, radius = th * mvScaleFactors[nLastOctave] (ORBm:2014), the level range of the
+ * GetFeaturesInArea call chosen by bForward/bBackward (ORBm:2018-2023; -1 = open), ur = uv.x - mbf*invzc
+ * (ORBm:2043), the last-frame keypoint's angle (ORBm:2067-2073) and whether pMP->Observations() > 0. */
+typedef struct { float u, v, radius, ur, angle; int32_t min_level, max_level, has_obs; } orc_proj_query;
+/* train_match [n] in/out = CurrentFrame.mvpMapPoints: -1 free, <= -2 held by a map point with observations
+ * (never a candidate, ORBm:2037-2039); on return >= 0 is the index of the query that claimed the keypoint.
+ * u_right may be NULL (monocular: mvuRight == -1).  Returns nmatches (ORBm:2061, 2171). */
+int orc_search_by_projection(const orc_proj_query *q, const uint8_t *desc_q, int nq,
+                             const orc_keypoint *kp, const uint8_t *desc, const float *u_right, int n,
+                             float min_x, float min_y, float max_x, float max_y,
+                             int th_high, int check_orientation, int32_t *train_match);
 #ifdef __cplusplus
 }
 #endif

@@ -36,6 +36,13 @@ __device__ __forceinline__ int hamming256(const uint4 &a0, const uint4 &a1, cons
            __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
 }
 
+__device__ __forceinline__ int wave_incl_scan_i(int v)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(v, d, 64); if ((int)(threadIdx.x & 63) >= d) v += o; }
+    return v;
+}
+
 // ---------------------------------------------------------------------------- M2
 // grid = (ceil(max_n/256), pairs); one query per thread; train tile of 256 descriptors in LDS.
 #define BF_TILE 256
@@ -327,5 +334,205 @@ extern "C" int orbhip_prev_matched_init_device(orbhip_ctx *ctx, const orbhip_key
     if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
     hipLaunchKernelGGL(k_prev_matched_init, dim3((max_n + 255) / 256, frames), dim3(256), 0, orbhip_ctx_stream_internal(ctx),
                        d_kp, frame_stride_kp, frames, max_n, d_prev_matched);
+    return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
+}
+
+// ---------------------------------------------------------------------------- M3 + M4 (tracking)
+// ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono), ORBmatcher.cc:1965-2181, Nleft == -1.
+// One wave per frame pair.  The Frame grid (Frame.cc:377-408) is built in LDS as a CSR: cells are numbered
+// ix*48+iy, so the cells (ix, r0..r1) that GetFeaturesInArea visits for one column are one contiguous run of
+// the item list, and concatenating the runs of columns c0..c1 IS the function's visiting order (Frame.cc:
+// 676-711).  Per query the lanes own one grid column each, a wave scan places the runs, and the candidates
+// are then evaluated one per lane with key = distance << 12 | position ("first candidate wins", :2051-2055).
+// The query loop is sequential: a keypoint claimed by a map point with observations drops out of later
+// queries (:2037-2039).
+#define SBP_CAP 2048
+#define SBP_CELLS (SI_COLS * SI_ROWS)
+__global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_query *q_, const uint8_t *descq_, const int32_t *nq_, int max_q,
+                                                             const orbhip_keypoint *kp_, const uint8_t *desc_, const float *uright_,
+                                                             const int32_t *n_, int max_n, size_t kp_stride,
+                                                             float min_x, float min_y, float max_x, float max_y,
+                                                             int th_high, int check_ori, int32_t *tm_, int32_t *nmatches_, int32_t *status)
+{
+    __shared__ float kx[SBP_CAP], ky[SBP_CAP];
+    __shared__ uint8_t oct[SBP_CAP];
+    __shared__ int16_t holder[SBP_CAP];           // -1 free, -2 pre-held, else (query << 1 | has_obs)
+    __shared__ uint32_t cell_start[SBP_CELLS + 1];
+    __shared__ uint16_t items[SBP_CAP], cand[SBP_CAP], cell_of[SBP_CAP], rank_of[SBP_CAP];
+    __shared__ int16_t qm[SBP_CAP];               // query -> claimed keypoint
+    __shared__ int8_t qbin[SBP_CAP];
+    __shared__ int hist[SI_HISTO];
+    __shared__ int s_keep[3];
+    const int pair = blockIdx.x, lane = threadIdx.x;
+    const unsigned long long lt_mask = (1ull << lane) - 1;
+    const int n = n_[pair], nq = nq_[pair];
+    const orbhip_proj_query *Q = q_ + (size_t)pair * max_q;
+    const uint4 *dQ = reinterpret_cast<const uint4 *>(descq_ + (size_t)pair * max_q * 32);
+    const orbhip_keypoint *kp = kp_ + (size_t)pair * kp_stride;
+    const uint4 *dT = reinterpret_cast<const uint4 *>(desc_ + (size_t)pair * kp_stride * 32);
+    const float *uright = uright_ ? uright_ + (size_t)pair * kp_stride : nullptr;
+    int32_t *tm = tm_ + (size_t)pair * max_n;
+    if (n > SBP_CAP || nq > SBP_CAP || n > max_n || nq > max_q) {
+        if (lane == 0) { atomicExch(status, ORBHIP_E_CAPACITY); nmatches_[pair] = 0; }
+        return;
+    }
+    const float inv_w = __fdiv_rn((float)SI_COLS, __fsub_rn(max_x, min_x));       // Frame.cc:334-335
+    const float inv_h = __fdiv_rn((float)SI_ROWS, __fsub_rn(max_y, min_y));
+    for (int i = lane; i < SI_HISTO; i += 64) hist[i] = 0;
+    for (int c = lane; c <= SBP_CELLS; c += 64) cell_start[c] = 0;
+    for (int t = lane; t < nq; t += 64) { qm[t] = -1; qbin[t] = -1; }
+    __syncthreads();
+    // ---- AssignFeaturesToGrid (Frame.cc:377-408): cell by round() (PosInGrid, :716-726), insertion order = index
+    // order.  rank = number of earlier keypoints in the same cell: cell counter before this trip + earlier
+    // lanes of the trip with the same cell.
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        int c = 0xFFFF;
+        if (i < n) {
+            const orbhip_keypoint k = kp[i];
+            kx[i] = k.x; ky[i] = k.y; oct[i] = (uint8_t)k.octave;
+            holder[i] = tm[i] == -1 ? (int16_t)-1 : (int16_t)-2;
+            const int px = (int)roundf(__fmul_rn(__fsub_rn(k.x, min_x), inv_w));
+            const int py = (int)roundf(__fmul_rn(__fsub_rn(k.y, min_y), inv_h));
+            if (px >= 0 && px < SI_COLS && py >= 0 && py < SI_ROWS) c = px * SI_ROWS + py;
+        }
+        int intra = 0;
+        for (int l = 0; l < 64; l++) {
+            const int cl = __builtin_amdgcn_readlane(c, l);
+            intra += (cl == c && l < lane);
+        }
+        if (i < n) {
+            cell_of[i] = (uint16_t)c;
+            if (c != 0xFFFF) rank_of[i] = (uint16_t)(cell_start[c + 1] + intra);
+        }
+        __syncthreads();                                          // every lane has read its counter
+        if (i < n && c != 0xFFFF) atomicAdd(&cell_start[c + 1], 1u);
+        __syncthreads();
+    }
+    // exclusive prefix over the cell counts (cell_start[c+1] holds count(c))
+    {
+        uint32_t carry = 0;
+        for (int c0 = 1; c0 <= SBP_CELLS; c0 += 64) {
+            const int c = c0 + lane;
+            const int v = c <= SBP_CELLS ? (int)cell_start[c] : 0;
+            const int inc = wave_incl_scan_i(v);
+            if (c <= SBP_CELLS) cell_start[c] = carry + (uint32_t)inc;
+            carry += (uint32_t)__shfl(inc, 63, 64);
+        }
+    }
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) { const int c = cell_of[i]; if (c != 0xFFFF) items[cell_start[c] + rank_of[i]] = (uint16_t)i; }
+    __syncthreads();
+    // ---- sequential query loop (ORBmatcher.cc:1987-2088)
+    int nmatches = 0;
+    const float factor = 1.0f / SI_HISTO;
+    for (int t = 0; t < nq; t++) {
+        const orbhip_proj_query qq = Q[t];
+        const float x = qq.u, y = qq.v, r = qq.radius;
+        int c0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, min_x), r), inv_w)); if (c0 < 0) c0 = 0;   // Frame.cc:656-674
+        if (c0 >= SI_COLS) continue;
+        int c1 = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, min_x), r), inv_w)); if (c1 > SI_COLS - 1) c1 = SI_COLS - 1;
+        if (c1 < 0) continue;
+        int r0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, min_y), r), inv_h)); if (r0 < 0) r0 = 0;
+        if (r0 >= SI_ROWS) continue;
+        int r1 = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, min_y), r), inv_h)); if (r1 > SI_ROWS - 1) r1 = SI_ROWS - 1;
+        if (r1 < 0) continue;
+        // lane = grid column c0+lane: its cells r0..r1 are one run of `items`
+        int start = 0, len = 0;
+        if (c0 + lane <= c1) {
+            start = (int)cell_start[(c0 + lane) * SI_ROWS + r0];
+            len = (int)cell_start[(c0 + lane) * SI_ROWS + r1 + 1] - start;
+        }
+        const int inc = wave_incl_scan_i(len);
+        const int off = inc - len, total = __shfl(inc, 63, 64);
+        if (total == 0) continue;
+        int maxlen = len;
+        for (int d = 32; d >= 1; d >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, d, 64));
+        for (int j = 0; j < maxlen; j++) if (j < len) cand[off + j] = items[start + j];
+        __syncthreads();
+        const bool check_lv = qq.min_level > 0 || qq.max_level >= 0;            // Frame.cc:676
+        const uint4 a0 = dQ[2 * t], a1 = dQ[2 * t + 1];
+        uint32_t key = 0xFFFFFFFFu;
+        for (int k0 = 0; k0 < total; k0 += 64) {
+            const int k = k0 + lane;
+            if (k < total) {
+                const int i2 = cand[k];
+                const int o = oct[i2], h = holder[i2];
+                bool ok = !(check_lv && (o < qq.min_level || (qq.max_level >= 0 && o > qq.max_level)));   // Frame.cc:693-701
+                ok = ok && fabsf(__fsub_rn(kx[i2], x)) < r && fabsf(__fsub_rn(ky[i2], y)) < r;           // Frame.cc:704-708
+                ok = ok && !(h <= -2 || (h >= 0 && (h & 1)));                                              // ORBmatcher.cc:2037-2039
+                if (ok && uright) {
+                    const float ur2 = uright[i2];
+                    if (ur2 > 0 && fabsf(__fsub_rn(qq.ur, ur2)) > r) ok = false;                           // ORBmatcher.cc:2041-2047
+                }
+                if (ok) {
+                    const int dist = hamming256(a0, a1, dT[2 * i2], dT[2 * i2 + 1]);
+                    key = min(key, ((uint32_t)dist << 12) | (uint32_t)k);
+                }
+            }
+        }
+        for (int d = 32; d >= 1; d >>= 1) key = min(key, (uint32_t)__shfl_xor((int)key, d, 64));
+        if (key != 0xFFFFFFFFu && (int)(key >> 12) <= th_high && (int)(key >> 12) < 256) {                 // ORBmatcher.cc:2030, 2058
+            if (lane == 0) {
+                const int best = cand[key & 0xFFFu];
+                holder[best] = (int16_t)((t << 1) | (qq.has_obs ? 1 : 0));
+                qm[t] = (int16_t)best;
+                if (check_ori) {                                                                           // ORBmatcher.cc:2064-2084
+                    float rot = __fsub_rn(qq.angle, kp[best].angle);
+                    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                    int bin = (int)roundf(__fmul_rn(rot, factor));
+                    if (bin == SI_HISTO) bin = 0;
+                    hist[bin]++; qbin[t] = (int8_t)bin;
+                }
+            }
+            nmatches++;
+        }
+        __syncthreads();                                                        // cand / holder reused by the next query
+    }
+    __syncthreads();
+    // ---- rotation consistency (ORBmatcher.cc:2156-2178): every histogram entry of a dropped bin clears its
+    // keypoint (also when a later query re-claimed it) and counts once
+    if (check_ori) {
+        if (lane == 0) {
+            int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+            for (int i = 0; i < SI_HISTO; i++) {
+                const int sz = hist[i];
+                if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+                else if (sz > max3) { max3 = sz; ind3 = i; }
+            }
+            if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+            else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) ind3 = -1;
+            s_keep[0] = ind1; s_keep[1] = ind2; s_keep[2] = ind3;
+        }
+        __syncthreads();
+        int removed = 0;
+        for (int t = lane; t < nq; t += 64) {
+            const int b = qbin[t];
+            if (b < 0 || b == s_keep[0] || b == s_keep[1] || b == s_keep[2]) continue;
+            holder[qm[t]] = -1; removed++;
+        }
+        for (int d = 32; d >= 1; d >>= 1) removed += __shfl_xor(removed, d, 64);
+        nmatches -= removed;
+    }
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) { const int h = holder[i]; tm[i] = h >= 0 ? (h >> 1) : h; }
+    if (lane == 0) nmatches_[pair] = nmatches;
+}
+
+extern "C" int orbhip_search_by_projection_device(orbhip_ctx *ctx, const orbhip_proj_query *d_q, const uint8_t *d_desc_q,
+                                                  const int32_t *d_nq, int max_q, const orbhip_keypoint *d_kp,
+                                                  const uint8_t *d_desc, const float *d_u_right, const int32_t *d_n, int max_n,
+                                                  size_t frame_stride_kp, int pairs, float min_x, float min_y, float max_x,
+                                                  float max_y, int th_high, int check_orientation, int32_t *d_train_match,
+                                                  int32_t *d_nmatches)
+{
+    if (!ctx || !d_q || !d_desc_q || !d_nq || !d_kp || !d_desc || !d_n || pairs <= 0 || max_n <= 0 || max_q <= 0 ||
+        !d_train_match || !d_nmatches || !(max_x > min_x) || !(max_y > min_y))
+        return ORBHIP_E_BADARG;
+    if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
+    hipLaunchKernelGGL(k_search_by_projection, dim3(pairs), dim3(64), 0, orbhip_ctx_stream_internal(ctx), d_q, d_desc_q, d_nq,
+                       max_q, d_kp, d_desc, d_u_right, d_n, max_n, frame_stride_kp, min_x, min_y, max_x, max_y, th_high,
+                       check_orientation, d_train_match, d_nmatches, orbhip_ctx_status_internal(ctx));
     return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
 }

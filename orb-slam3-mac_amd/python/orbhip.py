@@ -67,6 +67,7 @@ lib.orbhip_search_for_initialization_device.argtypes = [vp, vp, vp, vp, vp, vp, 
                                                         vp, vp, vp]
 lib.orbhip_ctx_check_status.argtypes = [vp]
 lib.orbhip_prev_matched_init_device.argtypes = [vp, vp, sz, ci, ci, vp]
+lib.orbhip_search_by_projection_device.argtypes = [vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, sz, ci, cf, cf, cf, cf, ci, ci, vp, vp]
 
 
 class OrbHipError(RuntimeError):
@@ -224,6 +225,20 @@ def search_for_initialization_device(ctx, d_kpA, d_descA, d_nA, d_kpB, d_descB, 
                                                      kp_stride, bounds[0], bounds[1], bounds[2], bounds[3], window,
                                                      nn_ratio, 1 if check_ori else 0, d_prev, d_m12, d_nmatches),
          "orbhip_search_for_initialization_device")
+
+
+# one projected map point of ORBmatcher::SearchByProjection (include/orbhip.h: orbhip_proj_query)
+PROJ_QUERY_DTYPE = np.dtype([("u", np.float32), ("v", np.float32), ("radius", np.float32), ("ur", np.float32),
+                             ("angle", np.float32), ("min_level", np.int32), ("max_level", np.int32), ("has_obs", np.int32)])
+
+
+def search_by_projection_device(ctx, d_q, d_desc_q, d_nq, max_q, d_kp, d_desc, d_u_right, d_n, max_n, kp_stride, pairs,
+                                bounds, th_high, check_ori, d_train_match, d_nmatches):
+    """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono), batched; device addresses (ints)."""
+    _chk(lib.orbhip_search_by_projection_device(ctx.h, d_q, d_desc_q, d_nq, max_q, d_kp, d_desc, d_u_right, d_n, max_n,
+                                                kp_stride, pairs, bounds[0], bounds[1], bounds[2], bounds[3], th_high,
+                                                1 if check_ori else 0, d_train_match, d_nmatches),
+         "orbhip_search_by_projection_device")
 
 
 def prev_matched_init_device(ctx, d_kp, kp_stride, frames, max_n, d_prev):

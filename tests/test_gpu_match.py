@@ -174,3 +174,86 @@ def test_search_for_initialization_edge_cases(gpu_ctx):
         assert got[p][0] == n, (p, got[p][0], n)
         np.testing.assert_array_equal(got[p][1], m12)
         assert got[p][2].tobytes() == prev.tobytes()
+
+
+# ------------------------------------------------------------------ M3 + M4: SearchByProjection (tracking)
+def _sbp(gpu_ctx, cases, max_q, max_n, bounds, th_high=100, check_ori=True, stereo=False):
+    """cases: list of (q, dq, kp, d, u_right|None, train_match).  Returns per pair (nmatches, train_match)."""
+    import torch
+    import orbhip
+    P = len(cases)
+    Q = np.zeros((P, max_q), orbhip.PROJ_QUERY_DTYPE); DQ = np.zeros((P, max_q, 32), np.uint8)
+    KP = np.zeros((P, max_n), orbhip.KP_DTYPE); D = np.zeros((P, max_n, 32), np.uint8)
+    UR = np.full((P, max_n), -1, np.float32); TM = np.full((P, max_n), -1, np.int32)
+    nq = np.array([len(c[0]) for c in cases], np.int32); n = np.array([len(c[2]) for c in cases], np.int32)
+    for p, (q, dq, kp, d, ur, tm) in enumerate(cases):
+        Q[p, :nq[p]] = q; DQ[p, :nq[p]] = dq; KP[p, :n[p]] = kp; D[p, :n[p]] = d; TM[p, :n[p]] = tm
+        if ur is not None:
+            UR[p, :n[p]] = ur
+    t = [torch.from_numpy(a.view(np.uint8) if a.dtype in (orbhip.KP_DTYPE, orbhip.PROJ_QUERY_DTYPE) else a).cuda()
+         for a in (Q, DQ, nq, KP, D, UR, n, TM)]
+    nm = torch.full((P,), -9, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    orbhip.search_by_projection_device(gpu_ctx, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), max_q, t[3].data_ptr(),
+                                       t[4].data_ptr(), t[5].data_ptr() if stereo else None, t[6].data_ptr(), max_n, max_n, P,
+                                       bounds, th_high, check_ori, t[7].data_ptr(), nm.data_ptr())
+    gpu_ctx.check_status()
+    tm = t[7].cpu().numpy(); nm = nm.cpu().numpy()
+    return [(int(nm[p]), tm[p, :n[p]]) for p in range(P)]
+
+
+@pytest.mark.parametrize("stereo,check_ori", [(False, True), (True, True), (False, False)])
+def test_search_by_projection_synthetic_parity(gpu_ctx, stereo, check_ori):
+    """Ragged batch incl. empty sides, out-of-grid keypoints, duplicated descriptors (ties), pre-held keypoints,
+    re-claims by points without observations, all three level-range modes."""
+    import oracle_match_bind as om
+    from test_oracle_match_ba import make_sbp_case
+    rng = np.random.default_rng(21 + stereo)
+    bounds = (0.0, 0.0, 640.0, 480.0)
+    cases = [make_sbp_case(rng, n, nq, stereo) for n, nq in ((0, 10), (60, 0), (300, 300), (1000, 900), (2048, 2048), (700, 1500))]
+    got = _sbp(gpu_ctx, cases, 2048, 2048, bounds, 100, check_ori, stereo)
+    tot = 0
+    for p, (q, dq, kp, d, ur, tm) in enumerate(cases):
+        n_ref, tm_ref = om.search_by_projection(q, dq, kp, d, ur if stereo else None, bounds, tm, 100, check_ori)
+        assert got[p][0] == n_ref, (p, got[p][0], n_ref)
+        np.testing.assert_array_equal(got[p][1], tm_ref)
+        tot += n_ref
+    assert tot > 500
+
+
+def test_search_by_projection_on_extracted_frames(gpu_ctx):
+    """TrackWithMotionModel shape: last frame's keypoints projected with the synthetic inter-frame motion."""
+    import orbhip
+    import oracle_match_bind as om
+    ext = orbhip.Extractor(gpu_ctx, 1000, 1.2, 8, 20, 7)
+    imgs = orbhip.synth_frames(640, 480, 5, seed=99)
+    res = ext.extract_host(imgs, lap=(0, 0))
+    sf = ext.table(0)
+    bounds = (0.0, 0.0, 640.0, 480.0)
+    cases = []
+    for a, b in ((0, 1), (1, 2), (2, 3), (3, 4)):
+        kpa, da = res[a][0], res[a][1]
+        q = np.zeros(len(kpa), orbhip.PROJ_QUERY_DTYPE)
+        q["u"] = kpa["x"]; q["v"] = kpa["y"]; q["angle"] = kpa["angle"]
+        q["radius"] = (np.float32(15.0) * sf[kpa["octave"]]).astype(np.float32)       # th = 15 (Tracking.cc:2685), ORBmatcher.cc:2014
+        q["min_level"] = kpa["octave"] - 1; q["max_level"] = kpa["octave"] + 1          # neither forward nor backward
+        q["has_obs"] = 1; q["ur"] = -1
+        inside = (q["u"] >= 0) & (q["u"] <= 640) & (q["v"] >= 0) & (q["v"] <= 480)   # ORBmatcher.cc:2005-2008
+        cases.append((q[inside], da[inside], res[b][0], res[b][1], None, np.full(len(res[b][0]), -1, np.int32)))
+    got = _sbp(gpu_ctx, cases, ext.max_keypoints, ext.max_keypoints, bounds)
+    for p, (q, dq, kp, d, ur, tm) in enumerate(cases):
+        n_ref, tm_ref = om.search_by_projection(q, dq, kp, d, None, bounds, tm, 100, True)
+        assert got[p][0] == n_ref
+        np.testing.assert_array_equal(got[p][1], tm_ref)
+        assert n_ref > 100
+    ext.close()
+
+
+def test_search_by_projection_capacity(gpu_ctx):
+    import orbhip
+    from test_oracle_match_ba import make_sbp_case
+    rng = np.random.default_rng(3)
+    c = make_sbp_case(rng, 2100, 10, False)
+    with pytest.raises(orbhip.OrbHipError):
+        _sbp(gpu_ctx, [c], 16, 2100, (0.0, 0.0, 640.0, 480.0))
+    gpu_ctx.check_status()          # sticky flag was cleared by the raising check

@@ -197,3 +197,94 @@ def test_ba_golden_regression():
     np.testing.assert_allclose(pts, gold["points"], atol=1e-9)
     np.testing.assert_array_equal(out, gold["outlier"])
     assert st["iterations_run"] == gold["iterations_run"].tolist() and st["lm_trials"] == int(gold["lm_trials"])
+
+
+def _sbp_python(q, dq, kp, d, u_right, bounds, tm, th_high, check_ori):
+    """Independent restatement of ORBmatcher.cc:1965-2181 (Nleft == -1) on top of the GetFeaturesInArea oracle."""
+    import oracle_match_bind as om
+    tm = tm.copy(); tm[tm != -1] = -2
+    nm = 0
+    hist = [[] for _ in range(30)]
+    for t in range(len(q)):
+        cand = om.features_in_area(kp, bounds, float(q["u"][t]), float(q["v"][t]), float(q["radius"][t]),
+                                   int(q["min_level"][t]), int(q["max_level"][t]))
+        best, bi = 256, -1
+        for i2 in cand:
+            h = tm[i2]
+            if h <= -2 or (h >= 0 and q["has_obs"][h]):
+                continue
+            if u_right is not None and u_right[i2] > 0 and abs(np.float32(q["ur"][t]) - np.float32(u_right[i2])) > q["radius"][t]:
+                continue
+            dist = int(np.unpackbits(dq[t] ^ d[i2]).sum())
+            if dist < best:
+                best, bi = dist, i2
+        if best <= th_high:
+            tm[bi] = t; nm += 1
+            if check_ori:
+                rot = np.float32(q["angle"][t]) - np.float32(kp["angle"][bi])
+                if rot < 0:
+                    rot = np.float32(rot + np.float32(360.0))
+                b = int(np.floor(np.float32(rot * np.float32(1.0 / 30)) + 0.5))    # roundf for non-negative values
+                hist[0 if b == 30 else b].append(bi)
+    if check_ori:
+        sizes = [len(h) for h in hist]
+        m1 = m2 = m3 = 0; i1 = i2_ = i3 = -1
+        for i, s in enumerate(sizes):
+            if s > m1: m3, m2, m1, i3, i2_, i1 = m2, m1, s, i2_, i1, i
+            elif s > m2: m3, m2, i3, i2_ = m2, s, i2_, i
+            elif s > m3: m3, i3 = s, i
+        if m2 < np.float32(0.1) * np.float32(m1): i2_ = i3 = -1
+        elif m3 < np.float32(0.1) * np.float32(m1): i3 = -1
+        for i in range(30):
+            if i not in (i1, i2_, i3):
+                for bi in hist[i]:
+                    tm[bi] = -1; nm -= 1
+    return nm, tm
+
+
+def make_sbp_case(rng, n, nq, with_stereo, dup=True):
+    """Synthetic SearchByProjection case: keypoints, queries near them, duplicated descriptors (ties)."""
+    import oracle_match_bind as om
+    from oracle_bind import KP_DTYPE
+    kp = np.zeros(n, KP_DTYPE)
+    kp["x"] = rng.uniform(-10, 650, n).astype(np.float32); kp["y"] = rng.uniform(-10, 490, n).astype(np.float32)
+    kp["angle"] = rng.uniform(0, 360, n).astype(np.float32); kp["octave"] = rng.integers(0, 8, n)
+    base = rng.integers(0, 256, (max(n // 6, 1), 32), dtype=np.uint8)
+    d = base[rng.integers(0, len(base), n)].copy() if dup else rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    d[:, 1] ^= rng.integers(0, 8, n).astype(np.uint8)
+    q = np.zeros(nq, om.PROJ_QUERY_DTYPE)
+    src = rng.integers(0, max(n, 1), nq) if n else np.zeros(nq, np.int64)
+    if n:
+        q["u"] = kp["x"][src] + rng.normal(0, 4, nq).astype(np.float32); q["v"] = kp["y"][src] + rng.normal(0, 4, nq).astype(np.float32)
+        octv = kp["octave"][src]
+        dq = d[src].copy(); dq[:, 2] ^= rng.integers(0, 4, nq).astype(np.uint8)
+        q["angle"] = (kp["angle"][src] + rng.choice([0, 0, 0, 90, 200], nq) + rng.normal(0, 3, nq)).astype(np.float32) % np.float32(360)
+    else:
+        q["u"] = rng.uniform(0, 640, nq); q["v"] = rng.uniform(0, 480, nq); octv = rng.integers(0, 8, nq)
+        dq = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+    q["radius"] = (np.float32(15.0) * np.float32(1.2) ** octv.astype(np.float32)).astype(np.float32)
+    mode = rng.integers(0, 3, nq)
+    q["min_level"] = np.where(mode == 0, octv, np.where(mode == 1, 0, octv - 1))
+    q["max_level"] = np.where(mode == 0, -1, np.where(mode == 1, octv, octv + 1))
+    q["has_obs"] = rng.integers(0, 2, nq)
+    q["ur"] = q["u"] - rng.uniform(0, 40, nq).astype(np.float32)
+    ur = None
+    if with_stereo:
+        ur = np.where(rng.random(n) < 0.6, kp["x"] - rng.uniform(0, 40, n), -1).astype(np.float32)
+    tm = np.where(rng.random(n) < 0.1, 7, -1).astype(np.int32)        # some keypoints already hold a map point
+    return q, dq, kp, d, ur, tm
+
+
+@pytest.mark.parametrize("with_stereo,check_ori", [(False, True), (True, True), (True, False)])
+def test_search_by_projection_oracle_against_python(with_stereo, check_ori):
+    import oracle_match_bind as om
+    rng = np.random.default_rng(11 + with_stereo)
+    bounds = (0.0, 0.0, 640.0, 480.0)
+    for n, nq in ((0, 5), (40, 0), (300, 250), (500, 400)):
+        q, dq, kp, d, ur, tm = make_sbp_case(rng, n, nq, with_stereo)
+        n1, tm1 = om.search_by_projection(q, dq, kp, d, ur, bounds, tm, 100, check_ori)
+        n2, tm2 = _sbp_python(q, dq, kp, d, ur, bounds, tm, 100, check_ori)
+        assert n1 == n2
+        np.testing.assert_array_equal(tm1, tm2)
+        if n >= 300:
+            assert (tm1 >= 0).sum() > 20
