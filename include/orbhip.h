@@ -260,6 +260,26 @@ int orbhip_ba_batch_gemm_profile(const orbhip_ba_batch *b, float *total_ms, int 
 double orbhip_ba_batch_gemm_dense_flops(const orbhip_ba_batch *b);   /* same tiles without block-sparsity skipping */
 int orbhip_mfma_f64_peak_tflops(orbhip_ctx *ctx, double *tflops_out);
 
+/* ------------------------------------------------------------------ pose-only BA
+ * Optimizer::PoseOptimization (src/Optimizer.cc:854-1168), batched over frames: per frame one free
+ * VertexSE3Expmap and n unary edges -- EdgeSE3ProjectXYZOnlyPose (include/OptimizableTypes.h:31-57) when
+ * uRight < 0, g2o::EdgeStereoSE3ProjectXYZOnlyPose (Thirdparty/g2o/g2o/types/types_six_dof_expmap.h:204-236)
+ * otherwise -- solved by the same Levenberg-Marquardt as local BA with a dense 6x6 LDL^T
+ * (LinearSolverDense, Thirdparty/g2o/g2o/solvers/linear_solver_dense.h:65-117): 4 rounds x 10 iterations, each
+ * from the frame's initial pose, outliers (float chi2 > 5.991f / 7.815f) dropped from the next round and
+ * re-tested after it, Huber kernel removed for the last round (:1043-1149).  Called by Tracking after every
+ * matcher (src/Tracking.cc:1775,1934,1996-2002).  The fisheye right-camera edge (mpCamera2) is not covered.
+ * Frame f reads Xw at d_Xw + f*max_edges*3 (map points, float values widened to double, :913-916),
+ * d_obs [f][max_edges][3] = (kpUn.pt.x, kpUn.pt.y, mvuRight), d_inv_sigma2 [f][max_edges]
+ * (mvInvLevelSigma2[octave]), d_n_edges [f].  d_pose [f][7] = (qx,qy,qz,qw,tx,ty,tz) of Tcw, in/out
+ * (untouched when n < 3, :1040-1041).  d_outlier [f][max_edges] = pFrame->mvbOutlier.  d_n_inliers [f] = the
+ * return value nInitialCorrespondences - nBad.  d_stats may be NULL, else [f][4] = rounds, LM iterations,
+ * LM trials, nBad.  max_edges <= 8192.  All pointers DEVICE; asynchronous on the context's stream. */
+int orbhip_pose_optimization_device(orbhip_ctx *ctx, const double *d_Xw, const double *d_obs,
+                                    const double *d_inv_sigma2, const int32_t *d_n_edges, int frames, int max_edges,
+                                    double fx, double fy, double cx, double cy, double bf, double *d_pose,
+                                    uint8_t *d_outlier, int32_t *d_n_inliers, int32_t *d_stats);
+
 #ifdef __cplusplus
 }
 #endif

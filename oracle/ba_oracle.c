@@ -508,3 +508,193 @@ int orc_ba_solve(const orc_ba_graph *g, const orc_ba_params *p, const volatile u
     free(B.bs); free(B.x); free(B.Dinv);
     return 0;
 }
+
+
+/* ================================================================= PoseOptimization (Optimizer.cc:854-1168) */
+struct po {
+    const orc_pose_problem *P;
+    double pose[7], pose_bk[7];
+    double *err, *chi2;        /* stored _error / chi2() of every edge (last computeError) */
+    uint8_t *level;            /* 1 = outlier, not optimised (setLevel(1), Optimizer.cc:1081) */
+    int robust;
+    double delta_m, dsqr_m, delta_s, dsqr_s;
+    double H[36], b[6], x[6], lambda, ni; int nbad, lm_trials;
+};
+
+/* computeError of the two unary edges */
+static void po_edge_error(const orc_pose_problem *P, const double pose[7], int e, double er[3])
+{
+    double Xc[3];
+    const double *obs = P->obs + 3 * e;
+    map_point(pose, P->Xw + 3 * e, Xc);
+    if (obs[2] < 0) {                                      /* OptimizableTypes.h:41-45, Pinhole.cpp:41-47 */
+        er[0] = obs[0] - (P->fx * Xc[0] / Xc[2] + P->cx);
+        er[1] = obs[1] - (P->fy * Xc[1] / Xc[2] + P->cy);
+        er[2] = 0;
+    } else {                                               /* types_six_dof_expmap.cpp:339-346: float invz, DOUBLE bf */
+        const float invz = (float)(1.0f / Xc[2]);
+        const double r0 = Xc[0] * invz * P->fx + P->cx;
+        er[0] = obs[0] - r0;
+        er[1] = obs[1] - (Xc[1] * invz * P->fy + P->cy);
+        er[2] = obs[2] - (r0 - P->bf * invz);
+    }
+}
+static void po_compute_errors(struct po *S)                /* computeActiveErrors: level-0 edges only */
+{
+    for (int e = 0; e < S->P->n_edges; e++) {
+        if (S->level[e]) continue;
+        double *er = S->err + 3 * e;
+        po_edge_error(S->P, S->pose, e, er);
+        S->chi2[e] = (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * S->P->inv_sigma2[e];
+    }
+}
+static void po_rho(const struct po *S, int e, double rho[2])
+{
+    if (!S->robust) { rho[0] = S->chi2[e]; rho[1] = 1.; return; }
+    if (S->P->obs[3 * e + 2] < 0) huber(S->chi2[e], S->delta_m, S->dsqr_m, rho);
+    else huber(S->chi2[e], S->delta_s, S->dsqr_s, rho);
+}
+static double po_robust_chi2(const struct po *S)
+{
+    double chi = 0, rho[2];
+    for (int e = 0; e < S->P->n_edges; e++) if (!S->level[e]) { po_rho(S, e, rho); chi += rho[0]; }
+    return chi;
+}
+/* linearizeOplus + BaseUnaryEdge::constructQuadraticForm (base_unary_edge.hpp:56-86) */
+static void po_build(struct po *S)
+{
+    const orc_pose_problem *P = S->P;
+    memset(S->H, 0, sizeof(S->H)); memset(S->b, 0, sizeof(S->b));
+    for (int e = 0; e < P->n_edges; e++) {
+        if (S->level[e]) continue;
+        const int stereo = !(P->obs[3 * e + 2] < 0), D = stereo ? 3 : 2;
+        double er[3], Jx[9], Jt[18], rho[2];
+        orc_ba_edge(S->pose, P->Xw + 3 * e, P->obs + 3 * e, stereo, P->fx, P->fy, P->cx, P->cy, P->bf, er, Jx, Jt);
+        const double *es = S->err + 3 * e;
+        po_rho(S, e, rho);
+        const double w = rho[1] * P->inv_sigma2[e];
+        for (int a = 0; a < 6; a++) {
+            double s = 0;
+            for (int d = 0; d < D; d++) s += Jt[6 * d + a] * (-w * es[d]);
+            S->b[a] += s;
+            for (int c = 0; c < 6; c++) {
+                double h = 0;
+                for (int d = 0; d < D; d++) h += Jt[6 * d + a] * w * Jt[6 * d + c];
+                S->H[6 * a + c] += h;
+            }
+        }
+    }
+}
+/* LinearSolverDense: Eigen::LDLT + isPositive() (stand-in: unpivoted LDL^T, fails on a non-positive pivot) */
+static int po_solve(struct po *S)
+{
+    double A[36];
+    memcpy(A, S->H, sizeof(A));
+    for (int i = 0; i < 6; i++) A[7 * i] += S->lambda;
+    for (int j = 0; j < 6; j++) {
+        double d = A[7 * j];
+        for (int k = 0; k < j; k++) d -= A[6 * j + k] * A[6 * j + k] * A[7 * k];
+        if (!(d > 0.0) || !isfinite(d)) return 0;
+        A[7 * j] = d;
+        for (int i = j + 1; i < 6; i++) {
+            double s = A[6 * i + j];
+            for (int k = 0; k < j; k++) s -= A[6 * i + k] * A[6 * j + k] * A[7 * k];
+            A[6 * i + j] = s / d;
+        }
+    }
+    double x[6];
+    for (int i = 0; i < 6; i++) { double s = S->b[i]; for (int k = 0; k < i; k++) s -= A[6 * i + k] * x[k]; x[i] = s; }
+    for (int i = 0; i < 6; i++) x[i] /= A[7 * i];
+    for (int i = 5; i >= 0; i--) { double s = x[i]; for (int k = i + 1; k < 6; k++) s -= A[6 * k + i] * x[k]; x[i] = s; }
+    memcpy(S->x, x, sizeof(x));
+    return 1;
+}
+static int po_lm_iteration(struct po *S, int iteration)        /* LM:61-169, as lm_iteration above */
+{
+    po_compute_errors(S);
+    double current_chi = po_robust_chi2(S), temp_chi = current_chi;
+    const double ini_chi = current_chi;
+    po_build(S);
+    if (iteration == 0) {
+        double md = 0;
+        for (int a = 0; a < 6; a++) md = fmax(fabs(S->H[7 * a]), md);
+        S->lambda = 1e-50 * md; S->ni = 2; S->nbad = 0;           /* LM:47,171-185 */
+    }
+    double rho = 0; int qmax = 0;
+    do {
+        memcpy(S->pose_bk, S->pose, sizeof(S->pose));
+        const int ok2 = po_solve(S);
+        orc_se3_oplus(S->x, S->pose);
+        po_compute_errors(S);
+        temp_chi = po_robust_chi2(S);
+        if (!ok2) temp_chi = DBL_MAX;
+        rho = current_chi - temp_chi;
+        double scale = 0;
+        for (int j = 0; j < 6; j++) scale += S->x[j] * (S->lambda * S->x[j] + S->b[j]);
+        scale += 1e-3;
+        rho /= scale;
+        if (rho > 0 && isfinite(temp_chi)) {
+            double alpha = 1. - pow((2 * rho - 1), 3);
+            alpha = fmin(alpha, 2. / 3.);
+            S->lambda *= fmax(1. / 3., alpha); S->ni = 2; current_chi = temp_chi;
+        } else {
+            S->lambda *= S->ni; S->ni *= 2;
+            memcpy(S->pose, S->pose_bk, sizeof(S->pose));
+        }
+        qmax++; S->lm_trials++;
+    } while (rho < 0 && qmax < 100);
+    if (qmax == 100 || rho == 0) return 0;
+    if ((ini_chi - current_chi) * 1e3 < ini_chi) S->nbad++; else S->nbad = 0;
+    if (S->nbad >= 3) return 0;
+    return 1;
+}
+
+int orc_pose_optimization(const orc_pose_problem *P, double pose7[7], uint8_t *outlier, orc_pose_stats *stats)
+{
+    orc_pose_stats st; memset(&st, 0, sizeof(st));
+    const int n = P->n_edges;
+    if (outlier) memset(outlier, 0, (size_t)(n > 0 ? n : 0));           /* Optimizer.cc:896 */
+    if (n < 3) { if (stats) *stats = st; return 0; }                    /* Optimizer.cc:1040-1041 */
+    struct po S; memset(&S, 0, sizeof(S));
+    S.P = P;
+    S.err = (double *)calloc(3 * (size_t)n, sizeof(double));
+    S.chi2 = (double *)calloc((size_t)n, sizeof(double));
+    S.level = (uint8_t *)calloc((size_t)n, 1);
+    S.delta_m = (double)(float)sqrt(5.991); S.dsqr_m = (double)(float)(S.delta_m * S.delta_m);     /* Optimizer.cc:887-888 */
+    S.delta_s = (double)(float)sqrt(7.815); S.dsqr_s = (double)(float)(S.delta_s * S.delta_s);
+    S.robust = 1;
+    double pose0[7];
+    memcpy(pose0, pose7, sizeof(pose0));
+    quat_normalize_rot(pose0);
+    memcpy(S.pose, pose0, sizeof(pose0));
+    int nbad = 0;
+    for (int it = 0; it < 4; it++) {
+        memcpy(S.pose, pose0, sizeof(pose0));                           /* Optimizer.cc:1053 */
+        int nact = 0;
+        for (int e = 0; e < n; e++) nact += !S.level[e];
+        if (nact > 0) {                                                 /* optimize(10), SO:354-419 */
+            int ok = 1;
+            for (int i = 0; i < 10 && ok; i++) { ok = po_lm_iteration(&S, i); st.iterations[it]++; }
+        }
+        nbad = 0;
+        for (int e = 0; e < n; e++) {                                   /* Optimizer.cc:1058-1145 */
+            if (S.level[e]) {                                           /* e->computeError() at the current estimate */
+                double *er = S.err + 3 * e;
+                po_edge_error(P, S.pose, e, er);
+                S.chi2[e] = (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * P->inv_sigma2[e];
+            }
+            const float chi2 = (float)S.chi2[e];
+            const float gate = P->obs[3 * e + 2] < 0 ? 5.991f : 7.815f;
+            if (chi2 > gate) { S.level[e] = 1; nbad++; } else S.level[e] = 0;
+        }
+        if (it == 2) S.robust = 0;                                      /* setRobustKernel(0), Optimizer.cc:1084 */
+        st.rounds++;
+        if (n < 10) break;                                              /* Optimizer.cc:1147-1148 */
+    }
+    memcpy(pose7, S.pose, sizeof(S.pose));
+    if (outlier) memcpy(outlier, S.level, (size_t)n);
+    st.lm_trials = S.lm_trials; st.n_bad = nbad;
+    if (stats) *stats = st;
+    free(S.err); free(S.chi2); free(S.level);
+    return n - nbad;
+}

@@ -55,6 +55,25 @@ void orc_se3_oplus(const double upd6[6], double pose7[7]);                      
 void orc_ba_edge(const double pose7[7], const double X[3], const double obs[3], int stereo,
                  double fx, double fy, double cx, double cy, double bf,
                  double *err, double *Jx, double *Jt);
+
+/* ---------------------------------------------------------------------------------------------
+ * Optimizer::PoseOptimization (/root/reference/src/Optimizer.cc:854-1168), SURVEY 8f N1: motion-only BA of
+ * one frame.  Unary edges EdgeSE3ProjectXYZOnlyPose (include/OptimizableTypes.h:31-57, src/OptimizableTypes.cpp:
+ * 49-63) and g2o::EdgeStereoSE3ProjectXYZOnlyPose (Thirdparty/g2o/g2o/types/types_six_dof_expmap.{h:204-236,
+ * cpp:339-404}); BlockSolver_6_3 + LinearSolverDense (Eigen::LDLT, linear_solver_dense.h:65-117) + the same
+ * Levenberg-Marquardt as local BA; 4 rounds x 10 iterations from the SAME initial pose with outlier
+ * re-classification (chi2 as float against 5.991f / 7.815f), Huber kernel dropped for the last round.
+ * The fisheye right-camera edge (EdgeSE3ProjectXYZOnlyPoseToBody, mpCamera2 != 0) is not covered.
+ * obs [n][3] = (u, v, uRight); uRight < 0 selects the monocular edge (Optimizer.cc:893).  Xw [n][3] are the
+ * float map-point coordinates widened to double (Optimizer.cc:913-916).
+ * Returns nInitialCorrespondences - nBad (0 if n < 3, pose untouched).  outlier [n] = pFrame->mvbOutlier. */
+typedef struct {
+    int32_t n_edges;
+    const double *Xw, *obs, *inv_sigma2;
+    double fx, fy, cx, cy, bf;
+} orc_pose_problem;
+typedef struct { int32_t rounds, iterations[4], lm_trials, n_bad; } orc_pose_stats;
+int orc_pose_optimization(const orc_pose_problem *P, double pose7[7], uint8_t *outlier, orc_pose_stats *stats);
 #ifdef __cplusplus
 }
 #endif

@@ -1230,3 +1230,253 @@ extern "C" int orbhip_ba_solve_batch(orbhip_ctx *ctx, const orbhip_ba_graph *gra
     orbhip_ba_batch_destroy(b);
     return rc;
 }
+
+
+// ====================================================================== pose-only BA
+// Optimizer::PoseOptimization (Optimizer.cc:854-1168).  One 256-thread workgroup per frame; thread t owns
+// edges t, t+256, ... (outlier level = one bit per owned edge).  The 6x6 system is tiny, so every thread keeps
+// the whole LM state (pose, lambda, ...) in registers and runs the scalar control flow redundantly on the
+// block-reduced sums: no broadcasts, two barriers per reduction, fixed summation order (run-to-run identical).
+#define PO_THREADS 256
+#define PO_NRED 28            // robust chi2 + 21 upper-triangle entries of H + 6 of b
+struct PoArgs {
+    const double *Xw, *obs, *inv_s2;
+    const int32_t *n;
+    int max_edges;
+    double fx, fy, cx, cy, bf;
+    double *pose;
+    uint8_t *outlier;
+    int32_t *n_inliers, *stats;
+};
+
+template <int N>
+__device__ __forceinline__ void po_block_sum(double (&v)[N], double (*red)[PO_NRED])
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        double x = v[k];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+        v[k] = x;
+    }
+    __syncthreads();                                   // previous readers of red are done
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < N; k++) red[wv][k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; k++) v[k] = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+}
+
+// computeError of the two unary edges; returns chi2 = e^T (inv_sigma2 I) e
+__device__ __forceinline__ double po_edge_chi2(const PoArgs &A, const double *pose, const double *X, const double *ob, double is2,
+                                               double *P, double *er)
+{
+    quat_rot(pose, X, P);
+    P[0] += pose[4]; P[1] += pose[5]; P[2] += pose[6];
+    if (ob[2] < 0) {                                   // OptimizableTypes.h:41-45, Pinhole.cpp:41-47
+        er[0] = ob[0] - (A.fx * P[0] / P[2] + A.cx);
+        er[1] = ob[1] - (A.fy * P[1] / P[2] + A.cy);
+        er[2] = 0;
+    } else {                                           // types_six_dof_expmap.cpp:339-346: float invz, double bf
+        const float invz = (float)(1.0 / P[2]);
+        const double r0 = P[0] * invz * A.fx + A.cx;
+        er[0] = ob[0] - r0;
+        er[1] = ob[1] - (P[1] * invz * A.fy + A.cy);
+        er[2] = ob[2] - (r0 - A.bf * invz);
+    }
+    return (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * is2;
+}
+
+__global__ __launch_bounds__(PO_THREADS) void k_pose_opt(PoArgs A)
+{
+    __shared__ double red[4][PO_NRED];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int n = A.n[f];
+    const double *Xw = A.Xw + (size_t)f * A.max_edges * 3, *obs = A.obs + (size_t)f * A.max_edges * 3;
+    const double *is2 = A.inv_s2 + (size_t)f * A.max_edges;
+    uint8_t *outl = A.outlier + (size_t)f * A.max_edges;
+    for (int e = tid; e < n; e += PO_THREADS) outl[e] = 0;                       // Optimizer.cc:896
+    if (n < 3 || n > A.max_edges) {                                             // Optimizer.cc:1040-1041
+        if (tid == 0) { A.n_inliers[f] = 0; if (A.stats) { for (int k = 0; k < 4; k++) A.stats[4 * f + k] = 0; } }
+        return;
+    }
+    BaGraphDev cam; cam.fx = A.fx; cam.fy = A.fy; cam.cx = A.cx; cam.cy = A.cy; cam.bf = A.bf;
+    double pose0[7], pose[7], pose_ev[7], x[6] = {0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < 7; k++) pose0[k] = A.pose[7 * f + k];
+    quat_norm_rot(pose0);                                                       // SE3Quat ctor
+    for (int k = 0; k < 7; k++) { pose[k] = pose0[k]; pose_ev[k] = pose0[k]; }
+    const double delta_m = (double)(float)sqrt(5.991), dsqr_m = (double)(float)(delta_m * delta_m);   // Optimizer.cc:887-888
+    const double delta_s = (double)(float)sqrt(7.815), dsqr_s = (double)(float)(delta_s * delta_s);
+    uint32_t level = 0;                                                          // bit k: edge tid + 256*k is an outlier
+    int robust = 1, nbad = 0, lm_trials = 0, lm_iters = 0, rounds = 0;
+    for (int it = 0; it < 4; it++) {
+        for (int k = 0; k < 7; k++) pose[k] = pose0[k];                          // Optimizer.cc:1053
+        double cnt[1] = {0};
+        for (int e = tid, k = 0; e < n; e += PO_THREADS, k++) cnt[0] += !((level >> k) & 1u);
+        po_block_sum<1>(cnt, red);
+        if (cnt[0] > 0) {
+            double lambda = 0, ni = 2;
+            int nb = 0, ok = 1;
+            for (int iter = 0; iter < 10 && ok; iter++) {                        // SparseOptimizer::optimize(10)
+                // ---- computeActiveErrors + activeRobustChi2 + buildSystem at the current estimate (LM:69-87)
+                double acc[PO_NRED];
+#pragma unroll
+                for (int k = 0; k < PO_NRED; k++) acc[k] = 0;
+                double R[9];
+                quat_to_R(pose, R);
+                for (int e = tid, k = 0; e < n; e += PO_THREADS, k++) {
+                    if ((level >> k) & 1u) continue;
+                    const double *ob = obs + 3 * e;
+                    const int stereo = !(ob[2] < 0), D = stereo ? 3 : 2;
+                    double P[3], er[3], Jx[9], Jt[18], r0, r1;
+                    const double w0 = is2[e];
+                    const double chi2 = po_edge_chi2(A, pose, Xw + 3 * e, ob, w0, P, er);
+                    if (robust) huber(chi2, stereo ? delta_s : delta_m, stereo ? dsqr_s : dsqr_m, &r0, &r1);
+                    else { r0 = chi2; r1 = 1.; }
+                    edge_jacobians(cam, P, R, stereo, Jx, Jt);
+                    const double w = r1 * w0;
+                    acc[0] += r0;
+                    int h = 1;
+#pragma unroll
+                    for (int a = 0; a < 6; a++) {
+#pragma unroll
+                        for (int c = a; c < 6; c++) {
+                            double s = 0;
+                            for (int d = 0; d < D; d++) s += Jt[6 * d + a] * w * Jt[6 * d + c];
+                            acc[h++] += s;
+                        }
+                    }
+#pragma unroll
+                    for (int a = 0; a < 6; a++) {
+                        double s = 0;
+                        for (int d = 0; d < D; d++) s += Jt[6 * d + a] * (-w * er[d]);
+                        acc[22 + a] += s;
+                    }
+                }
+                po_block_sum<PO_NRED>(acc, red);
+                for (int k = 0; k < 7; k++) pose_ev[k] = pose[k];
+                double current_chi = acc[0];
+                const double ini_chi = current_chi;
+                double H[36], b[6];
+                {
+                    int h = 1;
+                    for (int a = 0; a < 6; a++) for (int c = a; c < 6; c++) { H[6 * a + c] = acc[h]; H[6 * c + a] = acc[h]; h++; }
+                    for (int a = 0; a < 6; a++) b[a] = acc[22 + a];
+                }
+                if (iter == 0) {                                                 // computeLambdaInit, LM:171-185 (_tau = 1e-50)
+                    double md = 0;
+                    for (int a = 0; a < 6; a++) md = fmax(fabs(H[7 * a]), md);
+                    lambda = 1e-50 * md; ni = 2; nb = 0;
+                }
+                double rho = 0;
+                int qmax = 0;
+                do {
+                    double pose_bk[7];
+                    for (int k = 0; k < 7; k++) pose_bk[k] = pose[k];            // push
+                    // LinearSolverDense: LDL^T of H + lambda I; a non-positive pivot fails the solve (x keeps its old value)
+                    double L[36];
+                    for (int k = 0; k < 36; k++) L[k] = H[k];
+                    for (int a = 0; a < 6; a++) L[7 * a] += lambda;
+                    int ok2 = 1;
+                    for (int j = 0; j < 6 && ok2; j++) {
+                        double d = L[7 * j];
+                        for (int k = 0; k < j; k++) d -= L[6 * j + k] * L[6 * j + k] * L[7 * k];
+                        if (!(d > 0.0) || !isfinite(d)) { ok2 = 0; break; }
+                        L[7 * j] = d;
+                        for (int i = j + 1; i < 6; i++) {
+                            double s = L[6 * i + j];
+                            for (int k = 0; k < j; k++) s -= L[6 * i + k] * L[6 * j + k] * L[7 * k];
+                            L[6 * i + j] = s / d;
+                        }
+                    }
+                    if (ok2) {
+                        double y[6];
+                        for (int i = 0; i < 6; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= L[6 * i + k] * y[k]; y[i] = s; }
+                        for (int i = 0; i < 6; i++) y[i] /= L[7 * i];
+                        for (int i = 5; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < 6; k++) s -= L[6 * k + i] * y[k]; y[i] = s; }
+                        for (int i = 0; i < 6; i++) x[i] = y[i];
+                    }
+                    double pn[7];
+                    se3_oplus(x, pose, pn);                                      // update, SO:422-435
+                    for (int k = 0; k < 7; k++) pose[k] = pn[k];
+                    double tc[1] = {0};                                          // computeActiveErrors + activeRobustChi2 at the trial
+                    for (int e = tid, k = 0; e < n; e += PO_THREADS, k++) {
+                        if ((level >> k) & 1u) continue;
+                        const double *ob = obs + 3 * e;
+                        const int stereo = !(ob[2] < 0);
+                        double P[3], er[3], r0, r1;
+                        const double chi2 = po_edge_chi2(A, pose, Xw + 3 * e, ob, is2[e], P, er);
+                        if (robust) huber(chi2, stereo ? delta_s : delta_m, stereo ? dsqr_s : dsqr_m, &r0, &r1);
+                        else r0 = chi2;
+                        tc[0] += r0;
+                    }
+                    po_block_sum<1>(tc, red);
+                    for (int k = 0; k < 7; k++) pose_ev[k] = pose[k];
+                    double temp_chi = ok2 ? tc[0] : DBL_MAX;
+                    rho = current_chi - temp_chi;
+                    double scale = 0;                                            // computeScale, LM:187-194
+                    for (int j = 0; j < 6; j++) scale += x[j] * (lambda * x[j] + b[j]);
+                    scale += 1e-3;
+                    rho /= scale;
+                    if (rho > 0 && isfinite(temp_chi)) {
+                        const double t3 = 2 * rho - 1;
+                        double alpha = 1. - t3 * t3 * t3;
+                        alpha = fmin(alpha, 2. / 3.);
+                        lambda *= fmax(1. / 3., alpha); ni = 2; current_chi = temp_chi;
+                    } else {
+                        lambda *= ni; ni *= 2;
+                        for (int k = 0; k < 7; k++) pose[k] = pose_bk[k];        // pop
+                    }
+                    qmax++; lm_trials++;
+                } while (rho < 0 && qmax < 100);
+                lm_iters++;
+                if (qmax == 100 || rho == 0) ok = 0;                             // LM:151-152
+                else {
+                    if ((ini_chi - current_chi) * 1e3 < ini_chi) nb++; else nb = 0;   // LM:157-166
+                    if (nb >= 3) ok = 0;
+                }
+            }
+        }
+        // ---- re-classification (Optimizer.cc:1058-1145): inliers keep the error of the last evaluation (possibly a
+        // rejected trial), outliers are re-evaluated at the current estimate; the comparison is in float
+        double bad[1] = {0};
+        for (int e = tid, k = 0; e < n; e += PO_THREADS, k++) {
+            const double *ob = obs + 3 * e;
+            double P[3], er[3];
+            const double chi2d = po_edge_chi2(A, ((level >> k) & 1u) ? pose : pose_ev, Xw + 3 * e, ob, is2[e], P, er);
+            const float chi2 = (float)chi2d;
+            const float gate = ob[2] < 0 ? 5.991f : 7.815f;
+            if (chi2 > gate) { level |= 1u << k; bad[0] += 1; } else level &= ~(1u << k);
+        }
+        po_block_sum<1>(bad, red);
+        nbad = (int)bad[0];
+        if (it == 2) robust = 0;                                                 // setRobustKernel(0)
+        rounds++;
+        if (n < 10) break;                                                       // Optimizer.cc:1147-1148
+    }
+    for (int e = tid, k = 0; e < n; e += PO_THREADS, k++) outl[e] = (uint8_t)((level >> k) & 1u);
+    if (tid == 0) {
+        for (int k = 0; k < 7; k++) A.pose[7 * f + k] = pose[k];
+        A.n_inliers[f] = n - nbad;
+        if (A.stats) { A.stats[4 * f] = rounds; A.stats[4 * f + 1] = lm_iters; A.stats[4 * f + 2] = lm_trials; A.stats[4 * f + 3] = nbad; }
+    }
+}
+
+extern "C" int orbhip_pose_optimization_device(orbhip_ctx *ctx, const double *d_Xw, const double *d_obs,
+                                               const double *d_inv_sigma2, const int32_t *d_n_edges, int frames, int max_edges,
+                                               double fx, double fy, double cx, double cy, double bf, double *d_pose,
+                                               uint8_t *d_outlier, int32_t *d_n_inliers, int32_t *d_stats)
+{
+    if (!ctx || !d_Xw || !d_obs || !d_inv_sigma2 || !d_n_edges || frames <= 0 || max_edges <= 0 || max_edges > 8192 ||
+        !d_pose || !d_outlier || !d_n_inliers) { g_ba_error = "bad argument"; return ORBHIP_E_BADARG; }
+    if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
+    PoArgs A;
+    A.Xw = d_Xw; A.obs = d_obs; A.inv_s2 = d_inv_sigma2; A.n = d_n_edges; A.max_edges = max_edges;
+    A.fx = fx; A.fy = fy; A.cx = cx; A.cy = cy; A.bf = bf; A.pose = d_pose; A.outlier = d_outlier; A.n_inliers = d_n_inliers;
+    A.stats = d_stats;
+    hipLaunchKernelGGL(k_pose_opt, dim3(frames), dim3(PO_THREADS), 0, orbhip_ctx_stream_internal(ctx), A);
+    return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
+}

@@ -384,3 +384,14 @@ class BaBatch:
         if self.h:
             lib.orbhip_ba_batch_destroy(self.h)
             self.h = None
+
+
+lib.orbhip_pose_optimization_device.argtypes = [vp, vp, vp, vp, vp, ci, ci, cd, cd, cd, cd, cd, vp, vp, vp, vp]
+
+
+def pose_optimization_device(ctx, d_Xw, d_obs, d_inv_sigma2, d_n_edges, frames, max_edges, cam, d_pose, d_outlier,
+                             d_n_inliers, d_stats=None):
+    """Optimizer::PoseOptimization, batched over frames; device addresses (ints); cam = (fx, fy, cx, cy, bf)."""
+    _chk(lib.orbhip_pose_optimization_device(ctx.h, d_Xw, d_obs, d_inv_sigma2, d_n_edges, frames, max_edges,
+                                             float(cam[0]), float(cam[1]), float(cam[2]), float(cam[3]), float(cam[4]),
+                                             d_pose, d_outlier, d_n_inliers, d_stats), "orbhip_pose_optimization_device")

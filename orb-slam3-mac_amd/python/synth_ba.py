@@ -112,3 +112,45 @@ def make_graph(n_kf=50, n_pts=2000, obs=10, seed=0, n_fixed=2, outlier_frac=0.05
                 edge_obs=np.array(e_obs, np.float64).reshape(-1, 3), edge_inv_sigma2=np.array(e_is2, np.float64),
                 edge_stereo=np.array(e_st, np.uint8), fx=fx, fy=fy, cx=cx, cy=cy, bf=bf,
                 poses0=poses0, points0=pts0, poses_gt=poses_gt, points_gt=X.copy())
+
+
+def make_pose_problem(seed, n=800, stereo_frac=0.0, outlier_frac=0.1, noise=True, perturb=(0.02, 0.08)):
+    """Seeded synthetic Optimizer::PoseOptimization input (host-side generator, numpy only).
+
+    Camera at a random pose looking at a cloud of n map points (float32-rounded, as Xw.at<float>), Pinhole
+    fx=fy=458, cx=320, cy=240, bf=40; observations = projections + N(0, 1.2^octave) px, octave ~ U{0..7},
+    invSigma2 = (float)1.2^-2oct; a fraction are gross outliers (+-40 px); a fraction carry a right-image
+    coordinate (stereo edge).  Returns dict(Xw, obs [n,3], inv_sigma2, cam, pose0 (perturbed), pose_true)."""
+    rng = np.random.default_rng(seed)
+    fx = fy = 458.0; cx, cy, bf = 320.0, 240.0, 40.0
+    ang = rng.normal(0, 0.3, 3)
+    th = np.linalg.norm(ang)
+    K = np.array([[0, -ang[2], ang[1]], [ang[2], 0, -ang[0]], [-ang[1], ang[0], 0]])
+    R = np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * K @ K
+    t = rng.normal(0, 1.0, 3)
+    # points in the camera frustum, then to world
+    z = rng.uniform(2.0, 12.0, n)
+    u = rng.uniform(20, 620, n); v = rng.uniform(20, 460, n)
+    Xc = np.stack([(u - cx) / fx * z, (v - cy) / fy * z, z], 1)
+    Xw = ((Xc - t) @ R).astype(np.float32).astype(np.float64)            # Xw = R^T (Xc - t)
+    Xc = Xw @ R.T + t
+    octv = rng.integers(0, 8, n)
+    sig = 1.2 ** octv
+    uu = fx * Xc[:, 0] / Xc[:, 2] + cx; vv = fy * Xc[:, 1] / Xc[:, 2] + cy
+    ur = uu - bf / Xc[:, 2]
+    if noise:
+        uu = uu + rng.normal(0, 1, n) * sig; vv = vv + rng.normal(0, 1, n) * sig; ur = ur + rng.normal(0, 1, n) * sig
+    bad = rng.random(n) < outlier_frac
+    uu = np.where(bad, uu + rng.choice([-40, 40], n), uu); vv = np.where(bad, vv + rng.choice([-40, 40], n), vv)
+    is_st = rng.random(n) < stereo_frac
+    obs = np.stack([uu, vv, np.where(is_st, np.maximum(ur, 0.5), -1.0)], 1).astype(np.float32).astype(np.float64)
+    inv_s2 = (1.0 / (np.float32(1.2) ** octv.astype(np.float32)) ** 2).astype(np.float32).astype(np.float64)
+    q_true = _quat_from_R(R)
+    d = np.concatenate([rng.normal(0, perturb[0], 3), rng.normal(0, perturb[1], 3)])
+    th = np.linalg.norm(d[:3])
+    Kd = np.array([[0, -d[2], d[1]], [d[2], 0, -d[0]], [-d[1], d[0], 0]])
+    Rd = np.eye(3) + (np.sin(th) / th * Kd + (1 - np.cos(th)) / th ** 2 * Kd @ Kd if th > 0 else 0)
+    R0 = (Rd @ R).astype(np.float32).astype(np.float64); t0 = (Rd @ t + d[3:]).astype(np.float32).astype(np.float64)
+    U, _, Vt = np.linalg.svd(R0); R0 = U @ Vt                               # Converter::toSE3Quat gets a float Tcw
+    return dict(Xw=Xw, obs=obs, inv_sigma2=inv_s2, cam=(fx, fy, cx, cy, bf), pose0=np.concatenate([_quat_from_R(R0), t0]),
+                pose_true=np.concatenate([q_true, t]), outlier_true=bad)

@@ -60,3 +60,31 @@ def solve(g, params=None, abort=None):
     ab = abort.ctypes.data if abort is not None else None
     rc = lib.orc_ba_solve(C.byref(cg), C.byref(p), ab, poses.ctypes.data, pts.ctypes.data, out.ctypes.data, C.byref(st))
     return rc, poses, pts, out[:g["n_edges"]], st.as_dict()
+
+
+# ------------------------------------------------------------------ PoseOptimization oracle
+class PoseProblem(C.Structure):
+    _fields_ = [("n_edges", C.c_int32), ("Xw", vp), ("obs", vp), ("inv_sigma2", vp),
+                ("fx", cd), ("fy", cd), ("cx", cd), ("cy", cd), ("bf", cd)]
+
+
+class PoseStats(C.Structure):
+    _fields_ = [("rounds", C.c_int32), ("iterations", C.c_int32 * 4), ("lm_trials", C.c_int32), ("n_bad", C.c_int32)]
+
+
+lib.orc_pose_optimization.argtypes = [C.POINTER(PoseProblem), vp, vp, C.POINTER(PoseStats)]
+lib.orc_pose_optimization.restype = ci
+
+
+def pose_optimization(Xw, obs, inv_sigma2, cam, pose0):
+    """Optimizer::PoseOptimization restated.  Returns (n_inliers, pose7, outlier[n], stats dict)."""
+    Xw = np.ascontiguousarray(Xw, np.float64).reshape(-1, 3)
+    obs = np.ascontiguousarray(obs, np.float64).reshape(-1, 3)
+    w = np.ascontiguousarray(inv_sigma2, np.float64)
+    n = len(Xw)
+    P = PoseProblem(n, Xw.ctypes.data, obs.ctypes.data, w.ctypes.data, *[float(c) for c in cam])
+    pose = np.ascontiguousarray(pose0, np.float64).copy()
+    out = np.zeros(max(n, 1), np.uint8)
+    st = PoseStats()
+    r = lib.orc_pose_optimization(C.byref(P), pose.ctypes.data, out.ctypes.data, C.byref(st))
+    return r, pose, out[:n], dict(rounds=st.rounds, iterations=sum(st.iterations), lm_trials=st.lm_trials, n_bad=st.n_bad)

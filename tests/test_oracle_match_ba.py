@@ -288,3 +288,48 @@ def test_search_by_projection_oracle_against_python(with_stereo, check_ori):
         np.testing.assert_array_equal(tm1, tm2)
         if n >= 300:
             assert (tm1 >= 0).sum() > 20
+
+
+# ------------------------------------------------------------------ PoseOptimization oracle (8f N1)
+def _pose_err(a, b):
+    qa, qb = a[:4], b[:4]
+    return min(np.linalg.norm(qa - qb), np.linalg.norm(qa + qb)) + np.linalg.norm(a[4:] - b[4:])
+
+
+@pytest.mark.parametrize("stereo_frac", [0.0, 0.5, 1.0])
+def test_pose_optimization_recovers_noise_free_pose(stereo_frac):
+    import oracle_ba_bind as ob
+    import synth_ba
+    p = synth_ba.make_pose_problem(5, n=300, stereo_frac=stereo_frac, outlier_frac=0.0, noise=False)
+    r, pose, out, st = ob.pose_optimization(p["Xw"], p["obs"], p["inv_sigma2"], p["cam"], p["pose0"])
+    assert r == 300 and out.sum() == 0 and st["rounds"] == 4
+    assert _pose_err(pose, p["pose_true"]) < 2e-5          # observations are float32-rounded pixels
+
+
+def test_pose_optimization_flags_gross_outliers_and_small_cases():
+    import oracle_ba_bind as ob
+    import synth_ba
+    p = synth_ba.make_pose_problem(7, n=600, stereo_frac=0.3, outlier_frac=0.15)
+    r, pose, out, st = ob.pose_optimization(p["Xw"], p["obs"], p["inv_sigma2"], p["cam"], p["pose0"])
+    assert out[p["outlier_true"]].mean() > 0.98             # +-40 px never survives chi2 < 5.991
+    assert out[~p["outlier_true"]].mean() < 0.15
+    assert r == 600 - out.sum() == 600 - st["n_bad"]
+    assert _pose_err(pose, p["pose_true"]) < 0.02
+    # fewer than 3 correspondences: untouched, returns 0 (Optimizer.cc:1040-1041)
+    r2, pose2, out2, st2 = ob.pose_optimization(p["Xw"][:2], p["obs"][:2], p["inv_sigma2"][:2], p["cam"], p["pose0"])
+    assert r2 == 0 and st2["rounds"] == 0 and np.array_equal(pose2, p["pose0"])
+    # fewer than 10 edges: one round only (Optimizer.cc:1147-1148)
+    r3, pose3, out3, st3 = ob.pose_optimization(p["Xw"][:8], p["obs"][:8], p["inv_sigma2"][:8], p["cam"], p["pose0"])
+    assert st3["rounds"] == 1 and 0 <= r3 <= 8
+
+
+def test_pose_optimization_golden_regression():
+    """Committed fixture (tests/golden/pose_golden.npz, made by tools/gen_golden.py): guards the oracle itself."""
+    import os
+    import oracle_ba_bind as ob
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "pose_golden.npz"))
+    for k in range(int(g["count"])):
+        r, pose, out, st = ob.pose_optimization(g[f"Xw{k}"], g[f"obs{k}"], g[f"w{k}"], g[f"cam{k}"], g[f"pose0_{k}"])
+        assert r == int(g[f"r{k}"])
+        np.testing.assert_array_equal(out, g[f"out{k}"])
+        np.testing.assert_allclose(pose, g[f"pose{k}"], rtol=0, atol=1e-9)

@@ -31,6 +31,24 @@ def main():
         print(name, len(kp), mono)
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "orb_golden.npz"), **out)
+    pose_goldens()
+
+
+def pose_goldens():
+    """PoseOptimization known-answer vectors from the CPU oracle on seeded synthetic frames."""
+    import oracle_ba_bind as oba
+    import synth_ba
+    out = {}
+    cases = [dict(seed=31, n=200, stereo_frac=0.0), dict(seed=32, n=350, stereo_frac=0.5, outlier_frac=0.2),
+             dict(seed=33, n=9, stereo_frac=1.0, outlier_frac=0.0)]
+    for k, c in enumerate(cases):
+        p = synth_ba.make_pose_problem(**c)
+        r, pose, o, st = oba.pose_optimization(p["Xw"], p["obs"], p["inv_sigma2"], p["cam"], p["pose0"])
+        out.update({f"Xw{k}": p["Xw"], f"obs{k}": p["obs"], f"w{k}": p["inv_sigma2"], f"cam{k}": np.array(p["cam"]),
+                    f"pose0_{k}": p["pose0"], f"r{k}": np.int32(r), f"pose{k}": pose, f"out{k}": o})
+        print("pose", k, r, st)
+    out["count"] = np.int32(len(cases))
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "pose_golden.npz"), **out)
 
 
 if __name__ == "__main__":
