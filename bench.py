@@ -83,6 +83,30 @@ def cpu_baseline(w, h, nfeat, seconds_budget=20.0):
                       "single-thread %.2f frames/s" % (cores, per_thread, w, h, nfeat, 1.0 / t1)}
 
 
+def pose_cpu_baseline(probs, seconds_budget=6.0):
+    """PoseOptimization oracle on this host's cores: kind 'port'."""
+    from concurrent.futures import ThreadPoolExecutor
+    import oracle_ba_bind as obb
+    cores = min(os.cpu_count() or 1, 16)
+    p = probs[0]
+    t0 = time.time()
+    obb.pose_optimization(p["Xw"], p["obs"], p["inv_sigma2"], p["cam"], p["pose0"])
+    t1 = time.time() - t0
+    per_thread = max(4, min(400, int(seconds_budget / max(t1, 1e-4))))
+
+    def work(tid):
+        for i in range(per_thread):
+            q = probs[(tid + i) % len(probs)]
+            obb.pose_optimization(q["Xw"], q["obs"], q["inv_sigma2"], q["cam"], q["pose0"])
+        return per_thread
+    t0 = time.time()
+    with ThreadPoolExecutor(cores) as ex:
+        done = sum(ex.map(work, range(cores)))
+    dt = time.time() - t0
+    return {"value": round(done / dt, 1), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d threads x %d frames of 1000 unary edges; single-thread %.1f frames/s" % (cores, per_thread, 1.0 / t1)}
+
+
 def ba_cpu_baseline(graphs, seconds_budget=12.0):
     """BA oracle (CPU restatement of g2o LM+Schur) on this host's cores: kind 'port'."""
     from concurrent.futures import ThreadPoolExecutor
@@ -117,6 +141,7 @@ def main():
     ap.add_argument("--nfeatures", type=int, default=1000)
     ap.add_argument("--ba-graphs", type=int, default=64, help="local-BA graphs solved concurrently per GPU (0 = skip BA leg)")
     ap.add_argument("--ba-steps", type=int, default=3)
+    ap.add_argument("--pose-frames", type=int, default=1024, help="frames of pose-only BA solved per launch (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -262,6 +287,43 @@ def main():
                            "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),
                            "mfma_flops_issued_per_launch": gemm_fl, "flops_per_launch_without_sparsity_skipping": gemm_dense}}
 
+    pose = None
+    pose_probs = None
+    if args.pose_frames > 0:
+        import numpy as np
+        import synth_ba
+        pose_probs = [synth_ba.make_pose_problem(7000 + 16 * rank + k, n=1000, stereo_frac=0.25 * (k % 4), outlier_frac=0.1)
+                      for k in range(16)]
+        F, M = args.pose_frames, 1000
+        hx = np.stack([pose_probs[k % 16]["Xw"] for k in range(F)]); ho = np.stack([pose_probs[k % 16]["obs"] for k in range(F)])
+        hw = np.stack([pose_probs[k % 16]["inv_sigma2"] for k in range(F)]); hp = np.stack([pose_probs[k % 16]["pose0"] for k in range(F)])
+        dx, do_, dw = (torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (hx, ho, hw))
+        dn = torch.full((F,), M, dtype=torch.int32, device="cuda")
+        dps = [torch.from_numpy(hp).cuda() for _ in range(args.ba_steps + 1)]     # initial poses (in/out), one set per launch
+        dout = torch.zeros((F, M), dtype=torch.uint8, device="cuda"); dni = torch.zeros((F,), dtype=torch.int32, device="cuda")
+
+        def pose_step(dp):
+            orbhip.pose_optimization_device(ctx, dx.data_ptr(), do_.data_ptr(), dw.data_ptr(), dn.data_ptr(), F, M,
+                                            pose_probs[0]["cam"], dp.data_ptr(), dout.data_ptr(), dni.data_ptr())
+        sync(); pose_step(dps[-1]); sync()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(args.ba_steps):
+            pose_step(dps[i])
+        sync()
+        if world > 1:
+            dist.barrier()
+        dt_po = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt_po], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_po = float(t.item())
+        pose = {"metric": "pose-only BA frames/sec", "value": round(world * F * args.ba_steps / dt_po, 1), "unit": "frames/s",
+                "frames_per_gpu": F, "ms_per_batch": round(dt_po / args.ba_steps * 1e3, 3), "dtype": "f64",
+                "workload": "Optimizer::PoseOptimization: 1000 unary edges/frame (0-75 % stereo), 10 % gross outliers, 4 rounds x 10 LM its",
+                "mean_inliers": round(float(dni.float().mean().item()), 1)}
+
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         fps = world * B * args.steps / dt
@@ -303,10 +365,14 @@ def main():
         }
         if ba is not None:
             out["ba"] = ba
+        if pose is not None:
+            out["pose_opt"] = pose
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, H, args.nfeatures)
             if graphs is not None:
                 out["ba"]["cpu_baseline"] = ba_cpu_baseline(graphs)
+            if pose_probs is not None:
+                out["pose_opt"]["cpu_baseline"] = pose_cpu_baseline(pose_probs)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -110,8 +110,10 @@ __device__ __forceinline__ void quat_norm_rot(double *q)
     const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
     q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
 }
-__device__ void R_to_quat(const double *R, double *q)
+__device__ __forceinline__ void R_to_quat(const double *R, double *q)
 {
+    // Eigen::Quaterniond(Matrix3d): trace branch, else the largest diagonal element picks (i,j,k); written out
+    // per case so that every index is a compile-time constant (no scratch memory)
     double t = R[0] + R[4] + R[8];
     if (t > 0) {
         t = sqrt(t + 1.0);
@@ -120,33 +122,46 @@ __device__ void R_to_quat(const double *R, double *q)
     } else {
         int i = 0;
         if (R[4] > R[0]) i = 1;
-        if (R[8] > R[4 * i]) i = 2;
-        const int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
-        double qq[4];
-        qq[i] = 0.5 * t; t = 0.5 / t;
-        qq[3] = (R[3 * k + j] - R[3 * j + k]) * t;
-        qq[j] = (R[3 * j + i] + R[3 * i + j]) * t;
-        qq[k] = (R[3 * k + i] + R[3 * i + k]) * t;
-        q[0] = qq[0]; q[1] = qq[1]; q[2] = qq[2]; q[3] = qq[3];
+        if (R[8] > (i == 0 ? R[0] : R[4])) i = 2;
+        if (i == 0) {          // j = 1, k = 2
+            t = sqrt(R[0] - R[4] - R[8] + 1.0);
+            q[0] = 0.5 * t; t = 0.5 / t;
+            q[3] = (R[7] - R[5]) * t; q[1] = (R[3] + R[1]) * t; q[2] = (R[6] + R[2]) * t;
+        } else if (i == 1) {   // j = 2, k = 0
+            t = sqrt(R[4] - R[8] - R[0] + 1.0);
+            q[1] = 0.5 * t; t = 0.5 / t;
+            q[3] = (R[2] - R[6]) * t; q[2] = (R[7] + R[5]) * t; q[0] = (R[1] + R[3]) * t;
+        } else {               // j = 0, k = 1
+            t = sqrt(R[8] - R[0] - R[4] + 1.0);
+            q[2] = 0.5 * t; t = 0.5 / t;
+            q[3] = (R[3] - R[1]) * t; q[0] = (R[2] + R[6]) * t; q[1] = (R[5] + R[7]) * t;
+        }
     }
 }
 // T_new = exp(u) * T  (VertexSE3Expmap::oplusImpl)
-__device__ void se3_oplus(const double *u, const double *pose, double *out)
+__device__ __forceinline__ void se3_oplus(const double *u, const double *pose, double *out)
 {
     const double om0 = u[0], om1 = u[1], om2 = u[2];
     const double theta = sqrt(om0 * om0 + om1 * om1 + om2 * om2);
     const double O[9] = {0, -om2, om1, om2, 0, -om0, -om1, om0, 0};
     double O2[9], R[9], V[9];
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
-        double s = 0; for (int k = 0; k < 3; k++) s += O[3 * i + k] * O[3 * k + j];
-        O2[3 * i + j] = s;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) s += O[3 * i + k] * O[3 * k + j];
+            O2[3 * i + j] = s;
+        }
     }
     if (theta < 0.00001) {
+#pragma unroll
         for (int i = 0; i < 9; i++) { R[i] = (i % 4 == 0 ? 1.0 : 0.0) + O[i] + O2[i]; V[i] = R[i]; }
     } else {
         const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta);
         const double c = (theta - sin(theta)) / (theta * theta * theta);
+#pragma unroll
         for (int i = 0; i < 9; i++) {
             const double I = (i % 4 == 0 ? 1.0 : 0.0);
             R[i] = I + a * O[i] + b * O2[i];
@@ -155,6 +170,7 @@ __device__ void se3_oplus(const double *u, const double *pose, double *out)
     }
     double qe[4], te[3], rt[3], qn[4];
     R_to_quat(R, qe);
+#pragma unroll
     for (int i = 0; i < 3; i++) te[i] = V[3 * i] * u[3] + V[3 * i + 1] * u[4] + V[3 * i + 2] * u[5];
     quat_norm_rot(qe);
     quat_rot(qe, pose + 4, rt);
@@ -1239,6 +1255,7 @@ extern "C" int orbhip_ba_solve_batch(orbhip_ctx *ctx, const orbhip_ba_graph *gra
 // block-reduced sums: no broadcasts, two barriers per reduction, fixed summation order (run-to-run identical).
 #define PO_THREADS 256
 #define PO_NRED 28            // robust chi2 + 21 upper-triangle entries of H + 6 of b
+#define PO_IDX(a, c) ((a) * 6 - (a) * ((a) - 1) / 2 + ((c) - (a)))      // packed upper triangle, a <= c
 struct PoArgs {
     const double *Xw, *obs, *inv_s2;
     const int32_t *n;
@@ -1290,7 +1307,7 @@ __device__ __forceinline__ double po_edge_chi2(const PoArgs &A, const double *po
     return (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * is2;
 }
 
-__global__ __launch_bounds__(PO_THREADS) void k_pose_opt(PoArgs A)
+__global__ __launch_bounds__(PO_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pose_opt(PoArgs A)
 {
     __shared__ double red[4][PO_NRED];
     const int f = blockIdx.x, tid = threadIdx.x;
@@ -1330,8 +1347,10 @@ __global__ __launch_bounds__(PO_THREADS) void k_pose_opt(PoArgs A)
                 for (int e = tid, k = 0; e < n; e += PO_THREADS, k++) {
                     if ((level >> k) & 1u) continue;
                     const double *ob = obs + 3 * e;
-                    const int stereo = !(ob[2] < 0), D = stereo ? 3 : 2;
+                    const int stereo = !(ob[2] < 0);
                     double P[3], er[3], Jx[9], Jt[18], r0, r1;
+#pragma unroll
+                    for (int k = 12; k < 18; k++) Jt[k] = 0;                     // monocular edge: third row empty (er[2] == 0)
                     const double w0 = is2[e];
                     const double chi2 = po_edge_chi2(A, pose, Xw + 3 * e, ob, w0, P, er);
                     if (robust) huber(chi2, stereo ? delta_s : delta_m, stereo ? dsqr_s : dsqr_m, &r0, &r1);
@@ -1345,14 +1364,16 @@ __global__ __launch_bounds__(PO_THREADS) void k_pose_opt(PoArgs A)
 #pragma unroll
                         for (int c = a; c < 6; c++) {
                             double s = 0;
-                            for (int d = 0; d < D; d++) s += Jt[6 * d + a] * w * Jt[6 * d + c];
+#pragma unroll
+                            for (int d = 0; d < 3; d++) s += Jt[6 * d + a] * w * Jt[6 * d + c];
                             acc[h++] += s;
                         }
                     }
 #pragma unroll
                     for (int a = 0; a < 6; a++) {
                         double s = 0;
-                        for (int d = 0; d < D; d++) s += Jt[6 * d + a] * (-w * er[d]);
+#pragma unroll
+                        for (int d = 0; d < 3; d++) s += Jt[6 * d + a] * (-w * er[d]);
                         acc[22 + a] += s;
                     }
                 }
@@ -1360,15 +1381,16 @@ __global__ __launch_bounds__(PO_THREADS) void k_pose_opt(PoArgs A)
                 for (int k = 0; k < 7; k++) pose_ev[k] = pose[k];
                 double current_chi = acc[0];
                 const double ini_chi = current_chi;
-                double H[36], b[6];
-                {
-                    int h = 1;
-                    for (int a = 0; a < 6; a++) for (int c = a; c < 6; c++) { H[6 * a + c] = acc[h]; H[6 * c + a] = acc[h]; h++; }
-                    for (int a = 0; a < 6; a++) b[a] = acc[22 + a];
-                }
+                // H (symmetric) stays packed as its 21 upper-triangle entries, row-major: Hp[PO_IDX(a, c)], a <= c
+                double Hp[21], b[6];
+#pragma unroll
+                for (int k = 0; k < 21; k++) Hp[k] = acc[1 + k];
+#pragma unroll
+                for (int a = 0; a < 6; a++) b[a] = acc[22 + a];
                 if (iter == 0) {                                                 // computeLambdaInit, LM:171-185 (_tau = 1e-50)
                     double md = 0;
-                    for (int a = 0; a < 6; a++) md = fmax(fabs(H[7 * a]), md);
+#pragma unroll
+                    for (int a = 0; a < 6; a++) md = fmax(fabs(Hp[PO_IDX(a, a)]), md);
                     lambda = 1e-50 * md; ni = 2; nb = 0;
                 }
                 double rho = 0;
@@ -1377,26 +1399,47 @@ __global__ __launch_bounds__(PO_THREADS) void k_pose_opt(PoArgs A)
                     double pose_bk[7];
                     for (int k = 0; k < 7; k++) pose_bk[k] = pose[k];            // push
                     // LinearSolverDense: LDL^T of H + lambda I; a non-positive pivot fails the solve (x keeps its old value)
-                    double L[36];
-                    for (int k = 0; k < 36; k++) L[k] = H[k];
-                    for (int a = 0; a < 6; a++) L[7 * a] += lambda;
-                    int ok2 = 1;
-                    for (int j = 0; j < 6 && ok2; j++) {
-                        double d = L[7 * j];
-                        for (int k = 0; k < j; k++) d -= L[6 * j + k] * L[6 * j + k] * L[7 * k];
-                        if (!(d > 0.0) || !isfinite(d)) { ok2 = 0; break; }
-                        L[7 * j] = d;
+                    // Lp[PO_IDX(j, i)] (j <= i) holds L(i, j) below the diagonal and D(j) on it
+                    double Lp[21];
+#pragma unroll
+                    for (int k = 0; k < 21; k++) Lp[k] = Hp[k];
+#pragma unroll
+                    for (int a = 0; a < 6; a++) Lp[PO_IDX(a, a)] += lambda;
+                    bool ok2 = true;
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
+                        double d = Lp[PO_IDX(j, j)];
+#pragma unroll
+                        for (int k = 0; k < j; k++) d -= Lp[PO_IDX(k, j)] * Lp[PO_IDX(k, j)] * Lp[PO_IDX(k, k)];
+                        ok2 = ok2 && (d > 0.0) && isfinite(d);
+                        Lp[PO_IDX(j, j)] = d;
+#pragma unroll
                         for (int i = j + 1; i < 6; i++) {
-                            double s = L[6 * i + j];
-                            for (int k = 0; k < j; k++) s -= L[6 * i + k] * L[6 * j + k] * L[7 * k];
-                            L[6 * i + j] = s / d;
+                            double sacc = Lp[PO_IDX(j, i)];
+#pragma unroll
+                            for (int k = 0; k < j; k++) sacc -= Lp[PO_IDX(k, i)] * Lp[PO_IDX(k, j)] * Lp[PO_IDX(k, k)];
+                            Lp[PO_IDX(j, i)] = sacc / d;
                         }
                     }
                     if (ok2) {
                         double y[6];
-                        for (int i = 0; i < 6; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= L[6 * i + k] * y[k]; y[i] = s; }
-                        for (int i = 0; i < 6; i++) y[i] /= L[7 * i];
-                        for (int i = 5; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < 6; k++) s -= L[6 * k + i] * y[k]; y[i] = s; }
+#pragma unroll
+                        for (int i = 0; i < 6; i++) {
+                            double sacc = b[i];
+#pragma unroll
+                            for (int k = 0; k < i; k++) sacc -= Lp[PO_IDX(k, i)] * y[k];
+                            y[i] = sacc;
+                        }
+#pragma unroll
+                        for (int i = 0; i < 6; i++) y[i] /= Lp[PO_IDX(i, i)];
+#pragma unroll
+                        for (int i = 5; i >= 0; i--) {
+                            double sacc = y[i];
+#pragma unroll
+                            for (int k = i + 1; k < 6; k++) sacc -= Lp[PO_IDX(i, k)] * y[k];
+                            y[i] = sacc;
+                        }
+#pragma unroll
                         for (int i = 0; i < 6; i++) x[i] = y[i];
                     }
                     double pn[7];
