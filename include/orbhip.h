@@ -146,9 +146,10 @@ int orbhip_match_bf2nn_device(orbhip_ctx *ctx, const uint8_t *d_descA, const int
  * Pair p matches frame A_p against frame B_p.  kp arrays are the extractor's device
  * outputs (row capacity max_n).  d_prev_matched[pairs][max_n][2] (float x,y) is in/out
  * (vbPrevMatched); d_matches12[pairs][max_n] out; d_nmatches[pairs] out (return value).
- * Grid bounds = image bounds (mnMinX..mnMaxX of a distortion-free camera).  At most 2048
- * keypoints and 1024 octave-0 keypoints per frame (else the context's status word is set:
- * orbhip_ctx_check_status). */
+ * Grid bounds = image bounds (mnMinX..mnMaxX of a distortion-free camera).  At most 8192
+ * keypoints and 4096 octave-0 keypoints per frame -- the monocular-initialisation extractor runs
+ * 5 x nFeatures (src/Tracking.cc:210) -- else the context's status word is set
+ * (orbhip_ctx_check_status).  Scratch (LDS) is sized from max_n. */
 int orbhip_search_for_initialization_device(orbhip_ctx *ctx,
         const orbhip_keypoint *d_kpA, const uint8_t *d_descA, const int32_t *d_nA,
         const orbhip_keypoint *d_kpB, const uint8_t *d_descB, const int32_t *d_nB,

@@ -108,8 +108,9 @@ extern "C" int orbhip_match_bf2nn_device(orbhip_ctx *ctx, const uint8_t *d_descA
 // (dist << 23 | visit order) keys and the wave reduces them.
 #define SI_COLS 64            // FRAME_GRID_COLS (include/Frame.h:38)
 #define SI_ROWS 48            // FRAME_GRID_ROWS (include/Frame.h:39)
-#define SI_MAXN 2048          // keypoints per frame
-#define SI_CAP0 1024          // octave-0 keypoints per frame held in LDS
+#define SI_MAXN 8192          // keypoints per frame (the monocular-initialisation extractor runs 5 x nFeatures, Tracking.cc:210)
+#define SI_CAP0 4096          // octave-0 keypoints per frame held in LDS
+#define SI_RANKS 2048         // visit-order key: (cell visit index) * SI_RANKS + rank inside the cell  (3072 cells * 2048 < 2^23)
 #define SI_TH_LOW 50          // ORBmatcher::TH_LOW  (ORBmatcher.cc:41)
 #define SI_HISTO 30           // ORBmatcher::HISTO_LENGTH (ORBmatcher.cc:42)
 
@@ -125,17 +126,18 @@ extern "C" int orbhip_match_bf2nn_device(orbhip_ctx *ctx, const uint8_t *d_descA
 __global__ __launch_bounds__(64) void k_search_init(const orbhip_keypoint *kpA_, const uint8_t *descA_, const int32_t *nA,
                                                     const orbhip_keypoint *kpB_, const uint8_t *descB_, const int32_t *nB,
                                                     int max_n, size_t kp_stride, float min_x, float min_y, float max_x, float max_y,
-                                                    int window, float nn_ratio, int check_ori,
+                                                    int window, float nn_ratio, int check_ori, int cap0, int maxn,
                                                     float *prev_, int32_t *m12_, int32_t *nmatches_, int32_t *status)
 {
-    __shared__ float kx[SI_CAP0], ky[SI_CAP0];
-    __shared__ uint16_t cellx[SI_CAP0], celly[SI_CAP0], cpos[SI_CAP0], gidx[SI_CAP0];
-    __shared__ int matched_dist[SI_CAP0];
-    __shared__ int16_t m21[SI_CAP0];
-    __shared__ uint16_t aidx[SI_CAP0];
-    __shared__ uint16_t cand_li[SI_CAP0];
-    __shared__ uint32_t cand_key[SI_CAP0];
-    __shared__ int8_t bin_of[SI_MAXN];
+    // dynamic LDS, carved by the launcher's capacities: cap0 octave-0 entries per frame, maxn keypoints per frame
+    extern __shared__ __attribute__((aligned(16))) uint8_t si_lds[];
+    float *kx = reinterpret_cast<float *>(si_lds), *ky = kx + cap0;
+    int *matched_dist = reinterpret_cast<int *>(ky + cap0);
+    uint32_t *cand_key = reinterpret_cast<uint32_t *>(matched_dist + cap0);
+    uint16_t *cellx = reinterpret_cast<uint16_t *>(cand_key + cap0), *celly = cellx + cap0, *cpos = celly + cap0, *gidx = cpos + cap0;
+    int16_t *m21 = reinterpret_cast<int16_t *>(gidx + cap0);
+    uint16_t *aidx = reinterpret_cast<uint16_t *>(m21 + cap0), *cand_li = aidx + cap0;
+    int8_t *bin_of = reinterpret_cast<int8_t *>(cand_li + cap0);
     __shared__ int hist[SI_HISTO];
     __shared__ int s_keep[3];
     const int pair = blockIdx.x, lane = threadIdx.x;
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(64) void k_search_init(const orbhip_keypoint *kpA_,
     const uint4 *dB = reinterpret_cast<const uint4 *>(descB_ + (size_t)pair * kp_stride * 32);
     float *prev = prev_ + (size_t)pair * max_n * 2;
     int32_t *m12 = m12_ + (size_t)pair * max_n;
-    if (n1 > SI_MAXN || n2 > SI_MAXN) { if (lane == 0) { atomicExch(status, ORBHIP_E_CAPACITY); nmatches_[pair] = 0; } return; }
+    if (n1 > maxn || n2 > maxn) { if (lane == 0) { atomicExch(status, ORBHIP_E_CAPACITY); nmatches_[pair] = 0; } return; }
     const float inv_w = __fdiv_rn((float)SI_COLS, __fsub_rn(max_x, min_x));       // Frame.cc:334-335
     const float inv_h = __fdiv_rn((float)SI_ROWS, __fsub_rn(max_y, min_y));
     for (int i = lane; i < SI_HISTO; i += 64) hist[i] = 0;
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(64) void k_search_init(const orbhip_keypoint *kpA_,
         }
         const unsigned long long bal = __ballot(in);
         const int li = n0 + __popcll(bal & lt_mask);
-        if (in && li < SI_CAP0) {
+        if (in && li < cap0) {
             kx[li] = fx; ky[li] = fy; cellx[li] = (uint16_t)px; celly[li] = (uint16_t)py; gidx[li] = (uint16_t)i;
             matched_dist[li] = INT_MAX; m21[li] = -1;
         }
@@ -177,11 +179,11 @@ __global__ __launch_bounds__(64) void k_search_init(const orbhip_keypoint *kpA_,
         const bool in = i < n1 && kpA[i].octave == 0;
         const unsigned long long bal = __ballot(in);
         const int li = na0 + __popcll(bal & lt_mask);
-        if (in && li < SI_CAP0) aidx[li] = (uint16_t)i;
+        if (in && li < cap0) aidx[li] = (uint16_t)i;
         na0 += __popcll(bal);
         if (i < n1) { m12[i] = -1; bin_of[i] = -1; }
     }
-    if (n0 > SI_CAP0 || na0 > SI_CAP0) { if (lane == 0) { atomicExch(status, ORBHIP_E_CAPACITY); nmatches_[pair] = 0; } return; }
+    if (n0 > cap0 || na0 > cap0) { if (lane == 0) { atomicExch(status, ORBHIP_E_CAPACITY); nmatches_[pair] = 0; } return; }
     __syncthreads();
     for (int li = lane; li < n0; li += 64) {                                    // rank inside the grid cell
         const int cx = cellx[li], cy = celly[li];
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(64) void k_search_init(const orbhip_keypoint *kpA_,
                 const int cx = cellx[li], cy = celly[li];
                 c = cx >= c0 && cx <= c1 && cy >= r0 && cy <= r1 &&
                     fabsf(__fsub_rn(kx[li], x)) < r && fabsf(__fsub_rn(ky[li], y)) < r;
-                key = (uint32_t)(((cx - c0) * ncy + (cy - r0)) * 2048 + cpos[li]);
+                key = (uint32_t)(((cx - c0) * ncy + (cy - r0)) * SI_RANKS + min((int)cpos[li], SI_RANKS - 1));
             }
             const unsigned long long bal = __ballot(c);
             if (c) { const int o = ncand + __popcll(bal & lt_mask); cand_li[o] = (uint16_t)li; cand_key[o] = key; }
@@ -310,10 +312,19 @@ extern "C" int orbhip_search_for_initialization_device(orbhip_ctx *ctx,
         !d_prev_matched || !d_matches12 || !d_nmatches || !(max_x > min_x) || !(max_y > min_y))
         return ORBHIP_E_BADARG;
     if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
-    int32_t *d_status = orbhip_ctx_status_internal(ctx);    // frames with > 2048 keypoints set ORBHIP_E_CAPACITY
-    hipLaunchKernelGGL(k_search_init, dim3(pairs), dim3(64), 0, orbhip_ctx_stream_internal(ctx), d_kpA, d_descA, d_nA,
+    int32_t *d_status = orbhip_ctx_status_internal(ctx);    // frames over capacity set ORBHIP_E_CAPACITY
+    // LDS is sized from the caller's row capacity: every keypoint of a frame may be octave 0
+    const int maxn = max_n < SI_MAXN ? max_n : SI_MAXN, cap0 = max_n < SI_CAP0 ? max_n : SI_CAP0;
+    const size_t lds = (size_t)cap0 * (4 * 4 + 7 * 2) + (size_t)maxn;
+    static thread_local size_t lds_set = 0;
+    if (lds > lds_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_init), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return ORBHIP_E_HIP;
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(k_search_init, dim3(pairs), dim3(64), lds, orbhip_ctx_stream_internal(ctx), d_kpA, d_descA, d_nA,
                        d_kpB, d_descB, d_nB, max_n, frame_stride_kp, min_x, min_y, max_x, max_y, window_size, nn_ratio,
-                       check_orientation, d_prev_matched, d_matches12, d_nmatches, d_status);
+                       check_orientation, cap0, maxn, d_prev_matched, d_matches12, d_nmatches, d_status);
     return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
 }
 

@@ -257,3 +257,24 @@ def test_search_by_projection_capacity(gpu_ctx):
     with pytest.raises(orbhip.OrbHipError):
         _sbp(gpu_ctx, [c], 16, 2100, (0.0, 0.0, 640.0, 480.0))
     gpu_ctx.check_status()          # sticky flag was cleared by the raising check
+
+
+def test_search_for_initialization_5x_features(gpu_ctx):
+    """The monocular-initialisation extractor runs 5 x nFeatures (Tracking.cc:210): 5000 keypoints, > 1024 at octave 0."""
+    import orbhip
+    import oracle_match_bind as om
+    ext = orbhip.Extractor(gpu_ctx, 5000, 1.2, 8, 20, 7)
+    imgs = orbhip.synth_frames(1280, 960, 3, seed=5)
+    res = ext.extract_host(imgs, lap=(0, 0))
+    assert len(res[0][0]) > 4000 and (res[0][0]["octave"] == 0).sum() > 1024
+    fa = [(res[i][0], res[i][1]) for i in (0, 1)]
+    fb = [(res[i][0], res[i][1]) for i in (1, 2)]
+    bounds = (0.0, 0.0, 1280.0, 960.0)
+    prevs = [np.stack([f[0]["x"], f[0]["y"]], 1) for f in fa]
+    got = _search_init(gpu_ctx, fa, fb, bounds, prevs, ext.max_keypoints, 100, 0.9, True)
+    for p in range(2):
+        n, m12, prev = om.search_for_initialization(fa[p][0], fa[p][1], fb[p][0], fb[p][1], bounds, prevs[p], 100, 0.9, True)
+        assert got[p][0] == n and n > 100
+        np.testing.assert_array_equal(got[p][1], m12)
+        assert got[p][2].tobytes() == prev.tobytes()
+    ext.close()
