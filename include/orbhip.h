@@ -193,6 +193,20 @@ int orbhip_search_by_projection_device(orbhip_ctx *ctx, const orbhip_proj_query 
                                        float max_y, int th_high, int check_orientation, int32_t *d_train_match,
                                        int32_t *d_nmatches);
 
+/* Frame::ComputeStereoMatches (src/Frame.cc:802-980), batched: rectified-stereo association
+ * of the keypoints the LEFT and RIGHT extractor produced in their latest extract call (frame f with frame f;
+ * both called with lapping {0,0} as the stereo constructor does, src/Frame.cc:109-110).  Per left keypoint:
+ * best right keypoint by descriptor distance among those whose row band (+-2*scale[octave]) covers its row,
+ * octave within +-1, disparity in [0, mbf/mb] (:833-887); if better than (TH_HIGH+TH_LOW)/2: 11x11 SAD over
+ * +-5 px on the left keypoint's pyramid level (both extractors' device pyramids; columns left of the image
+ * are the reflect-101 padding of mvImagePyramid), parabola fit, disparity gates (:890-963); finally matches
+ * with SAD >= 1.5*1.4*median are dropped (:966-980).
+ * d_u_right / d_depth [batch][max_keypoints] = mvuRight / mvDepth (-1 = no match); d_n_matches [batch] (may be
+ * NULL) = matches kept.  The extractors must share image size, levels, scale factor and feature budget and may
+ * live on different contexts (the right one's stream is waited for).  Runs on the LEFT context's stream. */
+int orbhip_compute_stereo_matches_device(orbhip_extractor *left, orbhip_extractor *right, float mb, float mbf,
+                                         float *d_u_right, float *d_depth, int32_t *d_n_matches);
+
 /* ------------------------------------------------------------------ local BA */
 /* One keyframe-window graph in SoA form: what Optimizer::LocalBundleAdjustment builds
  * between src/Optimizer.cc:1850 and :2034.  Poses world->camera as (qx,qy,qz,qw,tx,ty,tz)

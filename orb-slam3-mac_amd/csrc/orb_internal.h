@@ -70,6 +70,25 @@ struct OrbParams {
 #define ORB_KEY_Y(k) ((int)(((k) >> 12) & 0xFFFu))
 #define ORB_KEY_S(k) ((int)((k) >> 24))
 
+// Frame::ComputeStereoMatches (stereo_kernels.hip): the two extractors' pyramids and device outputs
+struct StereoLevel {
+    const uint8_t *imgL, *imgR;
+    size_t fsL, fsR;              // frame strides
+    int pitchL, pitchR, wR, pad_;
+    float scale, inv_scale;       // mvScaleFactors / mvInvScaleFactors of the LEFT extractor
+};
+struct StereoArgs {
+    StereoLevel lv[ORB_MAX_LEVELS];
+    int nlevels, batch, max_kp, rows0;
+    const orbhip_keypoint *kpL, *kpR;
+    const uint8_t *descL, *descR;
+    const int32_t *nL, *nR;
+    float mb, mbf;
+    float *u_right, *depth;
+    int32_t *sad, *n_kept;
+};
+void orb_launch_stereo(const StereoArgs &A, hipStream_t s);
+
 // kernel launchers (orb_kernels.hip)
 void orb_launch_resize(const OrbParams &P, int level, hipStream_t s);
 void orb_launch_fast_cells(const OrbParams &P, hipStream_t s);

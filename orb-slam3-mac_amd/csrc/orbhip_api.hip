@@ -110,6 +110,7 @@ struct orbhip_extractor {
     bool ev_created;
     float stage_ms[ORBHIP_STAGE_COUNT];
     uint8_t *d_level0;          // owned level-0 storage
+    int32_t *d_stereo_sad;      // [max_batch][max_kp] scratch of orbhip_compute_stereo_matches_device (lazy)
     size_t level0_frame_stride; int level0_pitch;
 };
 
@@ -123,6 +124,7 @@ extern "C" int orbhip_extractor_create(orbhip_ctx *ctx, int nfeatures, float sca
     e->scale_factor = scale_factor;
     e->width = e->height = e->max_batch = 0; e->bytes_reserved = 0; e->last_batch = 0;
     e->profiling = false; e->ev_created = false; e->ev_calls = 0; e->d_level0 = nullptr; e->level0_owned = false;
+    e->d_stereo_sad = nullptr;
     memset(&e->P, 0, sizeof(e->P));
     memset(e->stage_ms, 0, sizeof(e->stage_ms));
     // scale tables, ORBextractor.cc:413-429
@@ -155,7 +157,7 @@ static void ext_free_all(orbhip_extractor *e)
 {
     for (void *p : e->allocs) (void)hipFree(p);
     e->allocs.clear();
-    e->bytes_reserved = 0; e->width = e->height = e->max_batch = 0; e->d_level0 = nullptr;
+    e->bytes_reserved = 0; e->width = e->height = e->max_batch = 0; e->d_level0 = nullptr; e->d_stereo_sad = nullptr;
 }
 
 extern "C" void orbhip_extractor_destroy(orbhip_extractor *e)
@@ -324,6 +326,47 @@ extern "C" int orbhip_extractor_reserve(orbhip_extractor *e, int width, int heig
     for (int l = 0; l < e->nlevels; l++) mq = std::max(mq, P.lv[l].quota);
     if (orb_octree_lds_bytes(mq) > 150 * 1024) { g_last_error = "per-level quota too large for the LDS-resident octree"; return ORBHIP_E_BADARG; }
     e->width = width; e->height = height; e->max_batch = max_batch;
+    return ORBHIP_OK;
+}
+
+// Frame::ComputeStereoMatches (reference src/Frame.cc:802-980) on the results of the latest extract call of a
+// left and a right extractor (same geometry, same batch); frame f of `left` pairs with frame f of `right`.
+extern "C" int orbhip_compute_stereo_matches_device(orbhip_extractor *left, orbhip_extractor *right, float mb, float mbf,
+                                                    float *d_u_right, float *d_depth, int32_t *d_n_matches)
+{
+    if (!left || !right || !d_u_right || !d_depth || !(mb > 0) || !(mbf > 0)) return ORBHIP_E_BADARG;
+    if (!left->max_batch || !right->max_batch || left->last_batch <= 0 || left->last_batch != right->last_batch ||
+        left->width != right->width || left->height != right->height || left->nlevels != right->nlevels ||
+        left->scale_factor != right->scale_factor || left->P.max_kp != right->P.max_kp || left->P.max_kp > 65535) {
+        g_last_error = "stereo: extractors must share geometry, feature budget and batch, and have extracted";
+        return ORBHIP_E_BADARG;
+    }
+    HIP_TRY(hipSetDevice(left->ctx->device));
+    if (!left->d_stereo_sad) {
+        int rc = dev_alloc(left, &left->d_stereo_sad, (size_t)left->max_batch * left->P.max_kp);
+        if (rc) return rc;
+    }
+    if (right->ctx->stream != left->ctx->stream) {          // the right extractor's kernels must have finished
+        hipEvent_t ev;
+        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ev, right->ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(left->ctx->stream, ev, 0));
+        HIP_TRY(hipEventDestroy(ev));
+    }
+    StereoArgs A;
+    memset(&A, 0, sizeof(A));
+    for (int l = 0; l < left->nlevels; l++) {
+        const OrbLevel &a = left->P.lv[l], &b = right->P.lv[l];
+        A.lv[l].imgL = a.img; A.lv[l].imgR = b.img; A.lv[l].fsL = a.img_frame_stride; A.lv[l].fsR = b.img_frame_stride;
+        A.lv[l].pitchL = a.img_pitch; A.lv[l].pitchR = b.img_pitch; A.lv[l].wR = b.w;
+        A.lv[l].scale = left->scale[l]; A.lv[l].inv_scale = left->inv_scale[l];
+    }
+    A.nlevels = left->nlevels; A.batch = left->last_batch; A.max_kp = left->P.max_kp; A.rows0 = left->height;
+    A.kpL = left->P.out_kp; A.kpR = right->P.out_kp; A.descL = left->P.out_desc; A.descR = right->P.out_desc;
+    A.nL = left->P.out_count; A.nR = right->P.out_count;
+    A.mb = mb; A.mbf = mbf; A.u_right = d_u_right; A.depth = d_depth; A.sad = left->d_stereo_sad; A.n_kept = d_n_matches;
+    orb_launch_stereo(A, left->ctx->stream);
+    HIP_TRY(hipGetLastError());
     return ORBHIP_OK;
 }
 

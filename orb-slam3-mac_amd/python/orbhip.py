@@ -395,3 +395,12 @@ def pose_optimization_device(ctx, d_Xw, d_obs, d_inv_sigma2, d_n_edges, frames, 
     _chk(lib.orbhip_pose_optimization_device(ctx.h, d_Xw, d_obs, d_inv_sigma2, d_n_edges, frames, max_edges,
                                              float(cam[0]), float(cam[1]), float(cam[2]), float(cam[3]), float(cam[4]),
                                              d_pose, d_outlier, d_n_inliers, d_stats), "orbhip_pose_optimization_device")
+
+
+lib.orbhip_compute_stereo_matches_device.argtypes = [vp, vp, cf, cf, vp, vp, vp]
+
+
+def compute_stereo_matches_device(ext_left, ext_right, mb, mbf, d_u_right, d_depth, d_n_matches=None):
+    """Frame::ComputeStereoMatches on the latest results of two extractors; device addresses (ints)."""
+    _chk(lib.orbhip_compute_stereo_matches_device(ext_left.h, ext_right.h, mb, mbf, d_u_right, d_depth, d_n_matches),
+         "orbhip_compute_stereo_matches_device")

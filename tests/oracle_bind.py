@@ -156,3 +156,20 @@ def octree(xs, ys, ss, min_x, max_x, min_y, max_y, n_features):
     n = lib.orc_octree(xs.ctypes.data, ys.ctypes.data, ss.ctypes.data, len(xs), min_x, max_x, min_y, max_y,
                        n_features, keep.ctypes.data, len(keep))
     return keep[:n]
+
+
+# ------------------------------------------------------------------ Frame::ComputeStereoMatches oracle
+lib.orc_compute_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, ci, C.c_void_p, C.c_void_p, ci,
+                                           C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+lib.orc_compute_stereo_matches.restype = ci
+
+
+def compute_stereo_matches(eL, eR, kpL, dL, kpR, dR, mb, mbf):
+    """eL/eR: OracleExtractor objects that have just extracted the left/right image.  Returns (kept, uRight, depth, sad)."""
+    kpL = np.ascontiguousarray(kpL, KP_DTYPE); kpR = np.ascontiguousarray(kpR, KP_DTYPE)
+    dL = np.ascontiguousarray(dL, np.uint8); dR = np.ascontiguousarray(dR, np.uint8)
+    n = len(kpL)
+    ur = np.zeros(max(n, 1), np.float32); dp = np.zeros(max(n, 1), np.float32); sad = np.zeros(max(n, 1), np.int32)
+    k = lib.orc_compute_stereo_matches(eL.h, eR.h, kpL.ctypes.data, dL.ctypes.data, n, kpR.ctypes.data, dR.ctypes.data, len(kpR),
+                                       mb, mbf, ur.ctypes.data, dp.ctypes.data, sad.ctypes.data)
+    return k, ur[:n], dp[:n], sad[:n]
