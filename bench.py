@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--ba-graphs", type=int, default=64, help="local-BA graphs solved concurrently per GPU (0 = skip BA leg)")
     ap.add_argument("--ba-steps", type=int, default=3)
     ap.add_argument("--pose-frames", type=int, default=1024, help="frames of pose-only BA solved per launch (0 = skip)")
+    ap.add_argument("--stereo-pairs", type=int, default=256, help="rectified stereo pairs for the ComputeStereoMatches leg (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -324,6 +325,53 @@ def main():
                 "workload": "Optimizer::PoseOptimization: 1000 unary edges/frame (0-75 % stereo), 10 % gross outliers, 4 rounds x 10 LM its",
                 "mean_inliers": round(float(dni.float().mean().item()), 1)}
 
+    stereo = None
+    if args.stereo_pairs > 0:
+        import numpy as np
+        S = args.stereo_pairs
+        big = orbhip.synth_frames(W + 64, H, S, seed=777 + 100000 * rank)
+        disp = [4 + (7 * k) % 40 for k in range(S)]
+        lefts = np.ascontiguousarray(big[:, :, 0:W])
+        rights = np.stack([big[k, :, disp[k]:disp[k] + W] for k in range(S)])
+        ctx_r = orbhip.Context(local_rank)
+        ext_l = orbhip.Extractor(ctx, args.nfeatures, 1.2, 8, 20, 7); ext_r = orbhip.Extractor(ctx_r, args.nfeatures, 1.2, 8, 20, 7)
+        ext_l.reserve(W, H, S); ext_r.reserve(W, H, S)
+        d_l = torch.from_numpy(lefts).cuda(); d_r = torch.from_numpy(np.ascontiguousarray(rights)).cuda()
+        mk = ext_l.max_keypoints
+        d_ur = torch.empty((S, mk), dtype=torch.float32, device="cuda"); d_dp = torch.empty((S, mk), dtype=torch.float32, device="cuda")
+        d_nk = torch.zeros((S,), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+
+        def stereo_step():
+            # the two extractors run on their own streams (the stereo constructor's two threads, Frame.cc:109-110)
+            ext_l.extract_device(d_l.data_ptr(), W, H, W, W * H, S, (0, 0))
+            ext_r.extract_device(d_r.data_ptr(), W, H, W, W * H, S, (0, 0))
+            orbhip.compute_stereo_matches_device(ext_l, ext_r, 40.0 / 458.0, 40.0, d_ur.data_ptr(), d_dp.data_ptr(), d_nk.data_ptr())
+        stereo_step(); ctx_r.synchronize(); sync()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.ba_steps):
+            stereo_step()
+        ctx_r.synchronize(); sync()
+        t_all = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for _ in range(args.ba_steps):
+            orbhip.compute_stereo_matches_device(ext_l, ext_r, 40.0 / 458.0, 40.0, d_ur.data_ptr(), d_dp.data_ptr(), d_nk.data_ptr())
+        sync()
+        t_match = time.perf_counter() - t0
+        if world > 1:
+            dist.barrier()
+            t = torch.tensor([t_all, t_match], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t_all, t_match = float(t[0].item()), float(t[1].item())
+        stereo = {"metric": "stereo frame pairs/sec (2 x ORB extract + ComputeStereoMatches)", "value": round(world * S * args.ba_steps / t_all, 1),
+                  "unit": "pairs/s", "pairs_per_gpu": S, "ms_per_batch": round(t_all / args.ba_steps * 1e3, 3),
+                  "compute_stereo_matches_ms_per_batch": round(t_match / args.ba_steps * 1e3, 3),
+                  "mean_stereo_matches_per_pair": round(float(d_nk.float().mean().item()), 1),
+                  "workload": "synthetic rectified %dx%d pairs, disparity 4..43 px, %d feats" % (W, H, args.nfeatures)}
+        ext_l.close(); ext_r.close(); ctx_r.close()
+
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         fps = world * B * args.steps / dt
@@ -367,6 +415,8 @@ def main():
             out["ba"] = ba
         if pose is not None:
             out["pose_opt"] = pose
+        if stereo is not None:
+            out["stereo"] = stereo
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, H, args.nfeatures)
             if graphs is not None:
