@@ -139,7 +139,7 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--nfeatures", type=int, default=1000)
-    ap.add_argument("--ba-graphs", type=int, default=64, help="local-BA graphs solved concurrently per GPU (0 = skip BA leg)")
+    ap.add_argument("--ba-graphs", type=int, default=256, help="local-BA graphs solved concurrently per GPU (0 = skip BA leg)")
     ap.add_argument("--ba-steps", type=int, default=3)
     ap.add_argument("--pose-frames", type=int, default=1024, help="frames of pose-only BA solved per launch (0 = skip)")
     ap.add_argument("--stereo-pairs", type=int, default=256, help="rectified stereo pairs for the ComputeStereoMatches leg (0 = skip)")
