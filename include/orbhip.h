@@ -231,6 +231,14 @@ typedef struct {
     double user_lambda_init;    /* 0 -> tau*max diag (levenberg.cpp:171-185); 100 if inertial */
     double tau;                 /* 1e-50 (levenberg.cpp:47) */
     int32_t max_trials;         /* 100 (levenberg.cpp:51) */
+    /* Variant switches for the map-merge local BA, Optimizer::LocalBundleAdjustment(pMainKF, vpAdjustKF, vpFixedKF,
+     * pbStopFlag) (src/Optimizer.cc:6255-6800) -- all 0 in orbhip_ba_default_params: */
+    int32_t stage2_exclude_outliers;  /* after optimize(5): edges with chi2 > gate or depth <= 0 get level 1 and do not
+                                         take part in optimize(10) (:6554-6556, :6571-6573) */
+    int32_t stage2_drop_robust;       /* after optimize(5): setRobustKernel(0) on every edge (:6560, :6577) */
+    int32_t no_discard;               /* no ">= 50 % outliers" bail-out (the merge variant has none) */
+    double gate_mono2, gate_stereo2;  /* outlier gates when they differ from the Huber deltas (merge: Huber sqrt(5.99),
+                                         gate 5.991, :6395,6554); 0 = use huber_mono2 / huber_stereo2 */
 } orbhip_ba_params;
 
 typedef struct {
@@ -242,6 +250,9 @@ typedef struct {
 } orbhip_ba_stats;
 
 void orbhip_ba_default_params(orbhip_ba_params *p);
+/* The parameters of the map-merge variant (src/Optimizer.cc:6255): Huber 5.99 / 7.815, gates 5.991 / 7.815, outliers of
+ * the first pass excluded and the robust kernel dropped for the second pass, no bail-out. */
+void orbhip_ba_merge_params(orbhip_ba_params *p);
 
 /* The numerical core of Optimizer::LocalBundleAdjustment(KeyFrame*, bool* pbStopFlag, Map*, int&)
  *                                            include/Optimizer.h:58, src/Optimizer.cc:1699-2344

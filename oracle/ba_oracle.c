@@ -26,6 +26,17 @@ void orc_ba_default_params(orc_ba_params *p)
     p->huber_mono2 = 5.991; p->huber_stereo2 = 7.815;   /* LBA:1910-1911 */
     p->user_lambda_init = 0.0; p->tau = 1e-50;    /* LM:47 */
     p->max_trials = 100;                          /* LM:51 */
+    p->stage2_exclude_outliers = 0; p->stage2_drop_robust = 0; p->no_discard = 0;
+    p->gate_mono2 = 0; p->gate_stereo2 = 0;
+}
+
+/* Optimizer.cc:6255-6800: thHuber2D = sqrt(5.99) (:6395), gates 5.991 / 7.815 (:6554,6571), setLevel(1) +
+ * setRobustKernel(0) between the passes (:6554-6577), no bail-out */
+void orc_ba_merge_params(orc_ba_params *p)
+{
+    orc_ba_default_params(p);
+    p->huber_mono2 = 5.99; p->gate_mono2 = 5.991; p->gate_stereo2 = 7.815;
+    p->stage2_exclude_outliers = 1; p->stage2_drop_robust = 1; p->no_discard = 1;
 }
 
 /* ---------------------------------------------------------------- quaternion / SE3 (B1) */
@@ -193,6 +204,8 @@ struct ba {
     double lambda, ni; int nbad;
     const volatile uint8_t *abort_flag;
     int lm_trials;
+    uint8_t *level;             /* 1 = excluded from the optimisation (setLevel(1)) */
+    int robust;                 /* 0 after setRobustKernel(0) */
 };
 
 static int terminate(const struct ba *B) { return B->abort_flag ? *B->abort_flag != 0 : 0; }   /* sparse_optimizer.h:188 */
@@ -202,6 +215,7 @@ static void compute_errors(struct ba *B)
 {
     const orc_ba_graph *g = B->g;
     for (int e = 0; e < B->E; e++) {
+        if (B->level[e]) continue;                      /* not an active edge: _error stays as last computed */
         double *er = B->err + 3 * e;
         edge_error(B->poses + 7 * g->edge_pose[e], B->points + 3 * g->edge_point[e], g->edge_obs + 3 * e,
                    g->edge_stereo[e], g->fx, g->fy, g->cx, g->cy, g->bf, er);
@@ -221,6 +235,8 @@ static double robust_chi2(const struct ba *B)
 {
     double chi = 0, rho[2];
     for (int e = 0; e < B->E; e++) {
+        if (B->level[e]) continue;
+        if (!B->robust) { chi += B->chi2[e]; continue; }
         if (B->g->edge_stereo[e]) huber(B->chi2[e], B->delta_s, B->dsqr_s, rho);
         else huber(B->chi2[e], B->delta_m, B->dsqr_m, rho);
         chi += rho[0];
@@ -238,6 +254,7 @@ static void build_system(struct ba *B)
     memset(B->bl, 0, sizeof(double) * 3 * B->L);
     memset(B->W, 0, sizeof(double) * 18 * B->E);
     for (int e = 0; e < B->E; e++) {
+        if (B->level[e]) continue;
         const int D = g->edge_stereo[e] ? 3 : 2;
         const int pi = g->edge_pose[e], li = g->edge_point[e], hi = B->hidx[pi];
         double er[3], Jx[9], Jt[18], rho[2];
@@ -246,7 +263,8 @@ static void build_system(struct ba *B)
         /* NB: constructQuadraticForm uses the edge's stored _error / chi2() of the last
          * computeActiveErrors, which LM:71 ran at this same state. */
         const double *es = B->err + 3 * e;
-        if (g->edge_stereo[e]) huber(B->chi2[e], B->delta_s, B->dsqr_s, rho);
+        if (!B->robust) { rho[0] = B->chi2[e]; rho[1] = 1.; }
+        else if (g->edge_stereo[e]) huber(B->chi2[e], B->delta_s, B->dsqr_s, rho);
         else huber(B->chi2[e], B->delta_m, B->dsqr_m, rho);
         const double w = rho[1] * g->edge_inv_sigma2[e];          /* robustInformation, base_edge.h:96-102 */
         /* point (vertex 0, "from") */
@@ -471,6 +489,7 @@ int orc_ba_solve(const orc_ba_graph *g, const orc_ba_params *p, const volatile u
     B.points_bk = (double *)malloc(sizeof(double) * 3 * (B.L ? B.L : 1));
     B.err = (double *)calloc(3 * (B.E ? B.E : 1), sizeof(double));
     B.chi2 = (double *)calloc(B.E ? B.E : 1, sizeof(double));
+    B.level = (uint8_t *)calloc(B.E ? B.E : 1, 1); B.robust = 1;
     B.Hpp = (double *)calloc(36 * (B.nf ? B.nf : 1), sizeof(double));
     B.bp = (double *)calloc(B.n ? B.n : 1, sizeof(double));
     B.Hll = (double *)calloc(9 * (B.L ? B.L : 1), sizeof(double));
@@ -486,25 +505,34 @@ int orc_ba_solve(const orc_ba_graph *g, const orc_ba_params *p, const volatile u
 
     st.iterations_run[0] = optimize(&B, p->iters1, &st.chi2_initial, &st.chi2_final);      /* LBA:2048 */
     int do_more = !(abort_flag && *abort_flag);                                              /* LBA:2056-2060 */
+    const double gate_m = p->gate_mono2 > 0 ? p->gate_mono2 : p->huber_mono2, gate_s = p->gate_stereo2 > 0 ? p->gate_stereo2 : p->huber_stereo2;
+    if (do_more && (p->stage2_exclude_outliers || p->stage2_drop_robust)) {                  /* merge variant, Optimizer.cc:6546-6579 */
+        for (int e = 0; e < B.E; e++) {
+            double Pc[3];
+            map_point(B.poses + 7 * g->edge_pose[e], B.points + 3 * g->edge_point[e], Pc);
+            if (p->stage2_exclude_outliers && (B.chi2[e] > (g->edge_stereo[e] ? gate_s : gate_m) || !(Pc[2] > 0.0))) B.level[e] = 1;
+        }
+        if (p->stage2_drop_robust) B.robust = 0;
+    }
     if (do_more) st.iterations_run[1] = optimize(&B, p->iters2, NULL, &st.chi2_final);       /* LBA:2121-2122 */
     st.lm_trials = B.lm_trials;
     /* outliers, LBA:2126-2173: chi2 from the stored (last evaluated) error; depth from current estimates */
     for (int e = 0; e < B.E; e++) {
         double Pc[3];
         map_point(B.poses + 7 * g->edge_pose[e], B.points + 3 * g->edge_point[e], Pc);
-        const double gate = g->edge_stereo[e] ? p->huber_stereo2 : p->huber_mono2;
+        const double gate = g->edge_stereo[e] ? gate_s : gate_m;
         const int out = (B.chi2[e] > gate) || !(Pc[2] > 0.0);
         if (edge_outlier) edge_outlier[e] = (uint8_t)out;
         st.n_outliers += out;
     }
-    if (st.n_outliers >= B.E * 0.5 && B.E > 0) st.discarded = 1;                            /* LBA:2177-2181 */
+    if (!p->no_discard && st.n_outliers >= B.E * 0.5 && B.E > 0) st.discarded = 1;           /* LBA:2177-2181 */
     else {
         memcpy(poses, B.poses, sizeof(double) * 7 * g->n_poses);
         memcpy(points, B.points, sizeof(double) * 3 * B.L);
     }
     if (stats) *stats = st;
     free(B.hidx); free(B.pt_start); free(B.poses); free(B.points); free(B.poses_bk); free(B.points_bk);
-    free(B.err); free(B.chi2); free(B.Hpp); free(B.bp); free(B.Hll); free(B.bl); free(B.W); free(B.S);
+    free(B.level); free(B.err); free(B.chi2); free(B.Hpp); free(B.bp); free(B.Hll); free(B.bl); free(B.W); free(B.S);
     free(B.bs); free(B.x); free(B.Dinv);
     return 0;
 }

@@ -33,6 +33,8 @@ typedef struct {
     double user_lambda_init;
     double tau;
     int32_t max_trials;
+    int32_t stage2_exclude_outliers, stage2_drop_robust, no_discard;   /* merge-LBA variant, Optimizer.cc:6255-6800 */
+    double gate_mono2, gate_stereo2;                                   /* 0 = same as the Huber deltas */
 } orc_ba_params;
 
 typedef struct {
@@ -44,6 +46,7 @@ typedef struct {
 } orc_ba_stats;
 
 void orc_ba_default_params(orc_ba_params *p);
+void orc_ba_merge_params(orc_ba_params *p);   /* Optimizer::LocalBundleAdjustment(pMainKF, vpAdjustKF, vpFixedKF, pbStopFlag) */
 /* Returns 0 ok, -5 aborted before start.  poses [n_poses*7] (qx,qy,qz,qw,tx,ty,tz), points [n_points*3]. */
 int orc_ba_solve(const orc_ba_graph *g, const orc_ba_params *p, const volatile uint8_t *abort_flag,
                  double *poses, double *points, uint8_t *edge_outlier, orc_ba_stats *stats);

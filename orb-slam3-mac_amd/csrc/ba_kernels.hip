@@ -49,6 +49,8 @@ struct BaState {
     int need_build, need_lambda_init, active, cur;   // cur: which pose/point buffer is current
     int ok;                                          // last LDLT status
     int iters_run[2], lm_trials, n_outliers;
+    int robust;                                      // 0 after setRobustKernel(0) (merge variant, second pass)
+    int apply_levels;                                // set when pass 1 starts: k_ba_levels classifies the edges once
     double rho_dbg;
 };
 
@@ -80,9 +82,11 @@ struct BaBatch {      // kernel argument (by value)
     double *chi, *scale, *maxdiag;       // [G]
     int *n_active;                       // [1]
     uint8_t *outlier;                    // [sumE]
+    uint8_t *level;                      // [sumE] 1 = excluded from the optimisation (setLevel(1), merge variant)
     // params
     double delta_m, dsqr_m, delta_s, dsqr_s, gate_m, gate_s, user_lambda, tau;
     int iters[2], max_trials;
+    int ex2, nr2;                        // merge variant: exclude first-pass outliers / drop the robust kernel in pass 2
 };
 
 // ------------------------------------------------------------------ SE3 helpers (B1)
@@ -254,6 +258,7 @@ __global__ __launch_bounds__(256) void k_ba_errors(BaBatch B, int which)
     if (e >= G.n_edges) return;
     const int buf = which == 0 ? st.cur : (st.cur ^ 1);
     const int ge = G.edge_off + e;
+    if (B.level[ge]) { B.rho0[ge] = 0; return; }      // not an active edge: its stored error / chi2 stay as last computed
     const double *pose = B.poses + ((size_t)buf * B.sumP + G.pose_off + B.edge_pose[ge]) * 7;
     const double *X = B.points + ((size_t)buf * B.sumL + G.point_off + B.edge_point[ge]) * 3;
     double P[3], er[3];
@@ -261,7 +266,8 @@ __global__ __launch_bounds__(256) void k_ba_errors(BaBatch B, int which)
     edge_error(G, pose, X, B.edge_obs + 3 * (size_t)ge, stereo, P, er);
     const double chi2 = (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * B.edge_is2[ge];
     double r0, r1;
-    if (stereo) huber(chi2, B.delta_s, B.dsqr_s, &r0, &r1); else huber(chi2, B.delta_m, B.dsqr_m, &r0, &r1);
+    if (!st.robust) { r0 = chi2; r1 = 1.; }
+    else if (stereo) huber(chi2, B.delta_s, B.dsqr_s, &r0, &r1); else huber(chi2, B.delta_m, B.dsqr_m, &r0, &r1);
     B.err[3 * (size_t)ge] = er[0]; B.err[3 * (size_t)ge + 1] = er[1]; B.err[3 * (size_t)ge + 2] = er[2];
     B.chi2[ge] = chi2;
     B.rho0[ge] = r0;
@@ -282,6 +288,7 @@ __global__ __launch_bounds__(256) void k_ba_reduce(BaBatch B, int which)
     __syncthreads();
     for (int d = 128; d > 0; d >>= 1) { if (tid < d) red[tid] += red[tid + d]; __syncthreads(); }
     if (tid == 0) B.chi[g] = red[0];
+    if (which == 0 && tid == 0) B.st[g].apply_levels = 0;      // k_ba_levels (earlier in this tick) has consumed it
     if (which == 1) {
         __syncthreads();
         double t = 0;
@@ -324,8 +331,9 @@ __global__ __launch_bounds__(128) void k_ba_build_points(BaBatch B)
         edge_jacobians(G, P, R, stereo, Jx, Jt);
         const double chi2 = B.chi2[ge];
         double r0, r1;
-        if (stereo) huber(chi2, B.delta_s, B.dsqr_s, &r0, &r1); else huber(chi2, B.delta_m, B.dsqr_m, &r0, &r1);
-        const double w = r1 * B.edge_is2[ge];
+        if (!st.robust) r1 = 1.;
+        else if (stereo) huber(chi2, B.delta_s, B.dsqr_s, &r0, &r1); else huber(chi2, B.delta_m, B.dsqr_m, &r0, &r1);
+        const double w = B.level[ge] ? 0.0 : r1 * B.edge_is2[ge];          // level-1 edge: contributes nothing (its Hpl block is zeroed)
         const double *es = B.err + 3 * (size_t)ge;
         for (int d = 0; d < D; d++) {
             const double j0 = Jx[3 * d], j1 = Jx[3 * d + 1], j2 = Jx[3 * d + 2];
@@ -376,8 +384,9 @@ __global__ __launch_bounds__(64) void k_ba_build_poses(BaBatch B)
         edge_jacobians(G, P, R, stereo, Jx, Jt);
         double r0, r1;
         const double chi2 = B.chi2[ge];
-        if (stereo) huber(chi2, B.delta_s, B.dsqr_s, &r0, &r1); else huber(chi2, B.delta_m, B.dsqr_m, &r0, &r1);
-        const double w = r1 * B.edge_is2[ge];
+        if (!st.robust) r1 = 1.;
+        else if (stereo) huber(chi2, B.delta_s, B.dsqr_s, &r0, &r1); else huber(chi2, B.delta_m, B.dsqr_m, &r0, &r1);
+        const double w = B.level[ge] ? 0.0 : r1 * B.edge_is2[ge];
         const double *es = B.err + 3 * (size_t)ge;
         for (int d = 0; d < D; d++) {
             const double we = -w * es[d];
@@ -867,9 +876,33 @@ __global__ void k_ba_control(BaBatch B, int abort_flag)
     st.iter++;
     st.need_build = 1;
     if (!ok || st.iter >= B.iters[st.pass] || abort_flag) {
-        if (st.pass == 0 && !abort_flag && B.iters[1] > 0) { st.pass = 1; st.iter = 0; st.need_lambda_init = 1; }
+        if (st.pass == 0 && !abort_flag && B.iters[1] > 0) {
+            st.pass = 1; st.iter = 0; st.need_lambda_init = 1;
+            if (B.ex2) st.apply_levels = 1;                // Optimizer.cc:6546-6579 (merge variant)
+            if (B.nr2) st.robust = 0;
+        }
         else { st.active = 0; atomicSub(B.n_active, 1); }
     }
+}
+
+// Merge variant, between the passes (Optimizer.cc:6546-6579): chi2 of the last evaluation > gate or depth <= 0 at the
+// current estimate => setLevel(1).  Runs at the start of the tick after the pass switch (apply_levels).
+__global__ __launch_bounds__(256) void k_ba_levels(BaBatch B)
+{
+    const int g = blockIdx.y;
+    const BaState &st = B.st[g];
+    if (!st.active || !st.apply_levels) return;
+    const BaGraphDev &G = B.gd[g];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= G.n_edges) return;
+    const int ge = G.edge_off + e;
+    const double *pose = B.poses + ((size_t)st.cur * B.sumP + G.pose_off + B.edge_pose[ge]) * 7;
+    const double *X = B.points + ((size_t)st.cur * B.sumL + G.point_off + B.edge_point[ge]) * 3;
+    double P[3];
+    quat_rot(pose, X, P);
+    const double z = P[2] + pose[6];
+    const double gate = B.edge_stereo[ge] ? B.gate_s : B.gate_m;
+    if ((B.chi2[ge] > gate) || !(z > 0.0)) B.level[ge] = 1;
 }
 
 // outlier gates, Optimizer.cc:2126-2173: stored chi2 of the last evaluation; depth at the final estimate
@@ -904,6 +937,7 @@ struct orbhip_ba_batch {
     int *h_n_active;                         // pinned
     size_t wd_total, s_total, spart_total;
     int ticks_last;
+    bool no_discard;                         // merge variant: no >= 50 % outlier bail-out
     bool profile;                            // time the Schur GEMM launches with hipEvents
     hipEvent_t ev0, ev1;
     float gemm_ms_total; int gemm_launches;
@@ -931,6 +965,15 @@ extern "C" void orbhip_ba_default_params(orbhip_ba_params *p)
 {
     p->iters1 = 5; p->iters2 = 10; p->huber_mono2 = 5.991; p->huber_stereo2 = 7.815;
     p->user_lambda_init = 0.0; p->tau = 1e-50; p->max_trials = 100;
+    p->stage2_exclude_outliers = 0; p->stage2_drop_robust = 0; p->no_discard = 0; p->gate_mono2 = 0; p->gate_stereo2 = 0;
+}
+
+// Optimizer::LocalBundleAdjustment(pMainKF, vpAdjustKF, vpFixedKF, pbStopFlag), Optimizer.cc:6255-6800
+extern "C" void orbhip_ba_merge_params(orbhip_ba_params *p)
+{
+    orbhip_ba_default_params(p);
+    p->huber_mono2 = 5.99; p->gate_mono2 = 5.991; p->gate_stereo2 = 7.815;       // :6395, :6554, :6571
+    p->stage2_exclude_outliers = 1; p->stage2_drop_robust = 1; p->no_discard = 1;
 }
 
 extern "C" void orbhip_ba_batch_destroy(orbhip_ba_batch *b)
@@ -1050,7 +1093,7 @@ extern "C" int orbhip_ba_batch_create(orbhip_ctx *ctx, const orbhip_ba_graph *gr
     AL(B.xp, double, (size_t)sumF * 6); AL(B.xl, double, (size_t)sumL * 3);
     AL(B.scale_pt, double, sumL); AL(B.scale_pose, double, sumF);
     AL(B.chi, double, n_graphs); AL(B.scale, double, n_graphs); AL(B.maxdiag, double, n_graphs);
-    AL(B.n_active, int, 1); AL(B.outlier, uint8_t, sumE);
+    AL(B.n_active, int, 1); AL(B.outlier, uint8_t, sumE); AL(B.level, uint8_t, sumE);
 #undef UP
 #undef AL
     if (!ok || hipHostMalloc((void **)&b->h_n_active, sizeof(int)) != hipSuccess) { orbhip_ba_batch_destroy(b); g_ba_error = "device allocation failed"; return ORBHIP_E_HIP; }
@@ -1071,14 +1114,16 @@ extern "C" int orbhip_ba_batch_solve(orbhip_ba_batch *b, const orbhip_ba_params 
     BaBatch &B = b->B;
     B.delta_m = (double)(float)sqrt(params->huber_mono2); B.dsqr_m = (double)(float)(B.delta_m * B.delta_m);
     B.delta_s = (double)(float)sqrt(params->huber_stereo2); B.dsqr_s = (double)(float)(B.delta_s * B.delta_s);
-    B.gate_m = params->huber_mono2; B.gate_s = params->huber_stereo2;
+    B.gate_m = params->gate_mono2 > 0 ? params->gate_mono2 : params->huber_mono2;
+    B.gate_s = params->gate_stereo2 > 0 ? params->gate_stereo2 : params->huber_stereo2;
+    B.ex2 = params->stage2_exclude_outliers; B.nr2 = params->stage2_drop_robust; b->no_discard = params->no_discard != 0;
     B.user_lambda = params->user_lambda_init; B.tau = params->tau;
     B.iters[0] = params->iters1; B.iters[1] = params->iters2; B.max_trials = params->max_trials;
     // reset state + estimates
     std::vector<BaState> st(B.G);
     for (auto &x : st) {
         memset(&x, 0, sizeof(x));
-        x.need_build = 1; x.need_lambda_init = 1; x.active = 1; x.ok = 1; x.chi_first = -1.0;
+        x.need_build = 1; x.need_lambda_init = 1; x.active = 1; x.ok = 1; x.chi_first = -1.0; x.robust = 1;
     }
     if (params->iters1 <= 0) for (auto &x : st) { x.pass = 1; }
     int n_active = B.G;
@@ -1090,6 +1135,7 @@ extern "C" int orbhip_ba_batch_solve(orbhip_ba_batch *b, const orbhip_ba_params 
     TRY(hipMemcpyAsync(B.n_active, &n_active, sizeof(int), hipMemcpyHostToDevice, s));
     TRY(hipMemsetAsync(B.xp, 0, sizeof(double) * (size_t)B.sumF * 6, s));
     TRY(hipMemsetAsync(B.xl, 0, sizeof(double) * (size_t)B.sumL * 3, s));
+    TRY(hipMemsetAsync(B.level, 0, (size_t)std::max(B.sumE, 1), s));
     TRY(hipStreamSynchronize(s));     // st / n_active host buffers must outlive the copies
     const int G = B.G;
     const dim3 ge((B.max_edges + 255) / 256, G), gp128((B.max_points + 127) / 128, G), gp256((B.max_points + 255) / 256, G);
@@ -1104,6 +1150,7 @@ extern "C" int orbhip_ba_batch_solve(orbhip_ba_batch *b, const orbhip_ba_params 
     int tick = 0;
     for (; tick < max_ticks && n_active > 0; tick++) {
         const int ab = (abort_flag && *abort_flag) ? 1 : 0;
+        if (B.ex2) hipLaunchKernelGGL(k_ba_levels, ge, dim3(256), 0, s, B);
         hipLaunchKernelGGL(k_ba_errors, ge, dim3(256), 0, s, B, 0);
         hipLaunchKernelGGL(k_ba_reduce, dim3(G), dim3(256), 0, s, B, 0);
         hipLaunchKernelGGL(k_ba_build_points, gp128, dim3(128), 0, s, B);
@@ -1156,7 +1203,7 @@ extern "C" int orbhip_ba_batch_download(orbhip_ba_batch *b, double *const *poses
     if (B.sumE && hipMemcpy(outl.data(), B.outlier, B.sumE, hipMemcpyDeviceToHost) != hipSuccess) return ORBHIP_E_HIP;
     for (int g = 0; g < B.G; g++) {
         const BaGraphDev &D = b->gd[g];
-        const int discarded = (D.n_edges > 0 && st[g].n_outliers >= D.n_edges * 0.5) ? 1 : 0;
+        const int discarded = (!b->no_discard && D.n_edges > 0 && st[g].n_outliers >= D.n_edges * 0.5) ? 1 : 0;
         if (!discarded) {
             if (poses_out && poses_out[g]) memcpy(poses_out[g], poses.data() + ((size_t)st[g].cur * B.sumP + D.pose_off) * 7, sizeof(double) * 7 * D.n_poses);
             if (points_out && points_out[g]) memcpy(points_out[g], points.data() + ((size_t)st[g].cur * B.sumL + D.point_off) * 3, sizeof(double) * 3 * D.n_points);

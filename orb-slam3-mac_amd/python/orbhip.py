@@ -281,7 +281,9 @@ class BaGraph(C.Structure):
 
 class BaParams(C.Structure):
     _fields_ = [("iters1", C.c_int32), ("iters2", C.c_int32), ("huber_mono2", cd), ("huber_stereo2", cd),
-                ("user_lambda_init", cd), ("tau", cd), ("max_trials", C.c_int32)]
+                ("user_lambda_init", cd), ("tau", cd), ("max_trials", C.c_int32),
+                ("stage2_exclude_outliers", C.c_int32), ("stage2_drop_robust", C.c_int32), ("no_discard", C.c_int32),
+                ("gate_mono2", cd), ("gate_stereo2", cd)]
 
 
 class BaStats(C.Structure):
@@ -294,6 +296,7 @@ class BaStats(C.Structure):
 
 
 lib.orbhip_ba_default_params.argtypes = [C.POINTER(BaParams)]
+lib.orbhip_ba_merge_params.argtypes = [C.POINTER(BaParams)]
 lib.orbhip_ba_batch_create.argtypes = [vp, vp, ci, vp, vp, C.POINTER(vp)]
 lib.orbhip_ba_batch_solve.argtypes = [vp, C.POINTER(BaParams), vp]
 lib.orbhip_ba_batch_download.argtypes = [vp, vp, vp, vp, vp]
@@ -311,6 +314,13 @@ def mfma_f64_peak_tflops(ctx):
     v = cd()
     _chk(lib.orbhip_mfma_f64_peak_tflops(ctx.h, C.byref(v)), "orbhip_mfma_f64_peak_tflops")
     return v.value
+
+
+def ba_merge_params():
+    """Parameters of the map-merge local BA (Optimizer.cc:6255)."""
+    p = BaParams()
+    lib.orbhip_ba_merge_params(C.byref(p))
+    return p
 
 
 def ba_default_params():

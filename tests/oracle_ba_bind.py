@@ -15,7 +15,9 @@ class Graph(C.Structure):
 
 class Params(C.Structure):
     _fields_ = [("iters1", C.c_int32), ("iters2", C.c_int32), ("huber_mono2", cd), ("huber_stereo2", cd),
-                ("user_lambda_init", cd), ("tau", cd), ("max_trials", C.c_int32)]
+                ("user_lambda_init", cd), ("tau", cd), ("max_trials", C.c_int32),
+                ("stage2_exclude_outliers", C.c_int32), ("stage2_drop_robust", C.c_int32), ("no_discard", C.c_int32),
+                ("gate_mono2", cd), ("gate_stereo2", cd)]
 
 
 class Stats(C.Structure):
@@ -28,6 +30,7 @@ class Stats(C.Structure):
 
 
 lib.orc_ba_default_params.argtypes = [C.POINTER(Params)]
+lib.orc_ba_merge_params.argtypes = [C.POINTER(Params)]
 lib.orc_ba_solve.argtypes = [C.POINTER(Graph), C.POINTER(Params), vp, vp, vp, vp, C.POINTER(Stats)]
 lib.orc_se3_exp.argtypes = [vp, vp, vp]
 lib.orc_se3_oplus.argtypes = [vp, vp]
@@ -37,6 +40,12 @@ lib.orc_ba_edge.argtypes = [vp, vp, vp, ci, cd, cd, cd, cd, cd, vp, vp, vp]
 def default_params():
     p = Params()
     lib.orc_ba_default_params(C.byref(p))
+    return p
+
+
+def merge_params():
+    p = Params()
+    lib.orc_ba_merge_params(C.byref(p))
     return p
 
 

@@ -333,3 +333,18 @@ def test_pose_optimization_golden_regression():
         assert r == int(g[f"r{k}"])
         np.testing.assert_array_equal(out, g[f"out{k}"])
         np.testing.assert_allclose(pose, g[f"pose{k}"], rtol=0, atol=1e-9)
+
+
+def test_ba_merge_variant_oracle():
+    """Merge-LBA switches (Optimizer.cc:6255-6800): pass 2 minimises the plain chi2 of the kept edges only, nothing is
+    discarded; the default schedule on the same graph keeps every edge and the Huber kernel."""
+    import oracle_ba_bind as ob
+    import synth_ba
+    g = synth_ba.make_graph(n_kf=20, n_pts=300, obs=10, seed=41, outlier_frac=0.03)
+    rc_d, poses_d, pts_d, out_d, st_d = ob.solve(g)
+    rc_m, poses_m, pts_m, out_m, st_m = ob.solve(g, ob.merge_params())
+    assert rc_d == 0 and rc_m == 0 and st_m["discarded"] == 0
+    assert np.isfinite(st_m["chi2_final"]) and st_m["chi2_final"] < st_d["chi2_final"]
+    assert out_m.sum() >= 0.03 * len(out_m)
+    gbad = synth_ba.make_graph(n_kf=8, n_pts=120, obs=5, seed=43, outlier_frac=0.9)
+    assert ob.solve(gbad)[4]["discarded"] == 1 and ob.solve(gbad, ob.merge_params())[4]["discarded"] == 0
