@@ -108,6 +108,13 @@ int orbhip_extractor_get_fast_candidates(orbhip_extractor *ext, int frame, int l
 int orbhip_extractor_get_level_keypoints(orbhip_extractor *ext, int frame, int level,
                                          orbhip_keypoint *out, int cap, int32_t *n_out);
 
+/* Small batches (the per-frame real-time case, BASELINE config #1) are launch bound: 19 kernel launches per
+ * extract call.  With graph mode on, the launches of one orbhip_extract_batch_device / _host call are captured once
+ * per (image size, batch, lapping) and replayed as ONE hipGraph; the input is then always staged into the
+ * extractor's own level-0 buffer so the captured kernels see fixed addresses.  Results are identical.
+ * Ignored while stage profiling is on. */
+int orbhip_extractor_set_graph_mode(orbhip_extractor *ext, int enable);
+
 /* Per-stage device time (ms), averaged over the extract calls made since the previous query
  * (at most the 32 most recent), measured with hipEvents recorded on the context's stream
  * around each stage's launches while profiling is enabled.  Stage ids: ORBHIP_STAGE_*. */

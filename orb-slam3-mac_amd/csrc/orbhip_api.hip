@@ -111,6 +111,10 @@ struct orbhip_extractor {
     float stage_ms[ORBHIP_STAGE_COUNT];
     uint8_t *d_level0;          // owned level-0 storage
     int32_t *d_stereo_sad;      // [max_batch][max_kp] scratch of orbhip_compute_stereo_matches_device (lazy)
+    // graph mode (small batches are launch bound): the 19 launches of one extract call replayed as one hipGraph
+    bool graph_mode, graph_valid;
+    hipGraphExec_t graph_exec;
+    int g_w, g_h, g_batch, g_lap0, g_lap1;
     size_t level0_frame_stride; int level0_pitch;
 };
 
@@ -125,6 +129,7 @@ extern "C" int orbhip_extractor_create(orbhip_ctx *ctx, int nfeatures, float sca
     e->width = e->height = e->max_batch = 0; e->bytes_reserved = 0; e->last_batch = 0;
     e->profiling = false; e->ev_created = false; e->ev_calls = 0; e->d_level0 = nullptr; e->level0_owned = false;
     e->d_stereo_sad = nullptr;
+    e->graph_mode = false; e->graph_valid = false; e->graph_exec = nullptr;
     memset(&e->P, 0, sizeof(e->P));
     memset(e->stage_ms, 0, sizeof(e->stage_ms));
     // scale tables, ORBextractor.cc:413-429
@@ -158,6 +163,7 @@ static void ext_free_all(orbhip_extractor *e)
     for (void *p : e->allocs) (void)hipFree(p);
     e->allocs.clear();
     e->bytes_reserved = 0; e->width = e->height = e->max_batch = 0; e->d_level0 = nullptr; e->d_stereo_sad = nullptr;
+    if (e->graph_valid) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_valid = false; }
 }
 
 extern "C" void orbhip_extractor_destroy(orbhip_extractor *e)
@@ -429,6 +435,28 @@ static int run_pipeline(orbhip_extractor *e, int batch, int lap0, int lap1)
     return ORBHIP_OK;
 }
 
+// Graph mode: capture the launches of run_pipeline once per (size, batch, lapping), then replay.  The caller has
+// staged the input into the extractor's own level-0 buffer (fixed addresses).
+static int run_pipeline_graph(orbhip_extractor *e, int width, int height, int batch, int lap0, int lap1)
+{
+    if (!(e->graph_valid && e->g_w == width && e->g_h == height && e->g_batch == batch && e->g_lap0 == lap0 && e->g_lap1 == lap1)) {
+        if (e->graph_valid) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_valid = false; }
+        hipGraph_t graph = nullptr;
+        HIP_TRY(hipStreamBeginCapture(e->ctx->stream, hipStreamCaptureModeThreadLocal));
+        const int rc = run_pipeline(e, batch, lap0, lap1);
+        hipError_t ce = hipStreamEndCapture(e->ctx->stream, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (ce != hipSuccess) { g_last_error = std::string("hipStreamEndCapture: ") + hipGetErrorString(ce); return ORBHIP_E_HIP; }
+        hipError_t ie = hipGraphInstantiate(&e->graph_exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ie != hipSuccess) { g_last_error = std::string("hipGraphInstantiate: ") + hipGetErrorString(ie); return ORBHIP_E_HIP; }
+        e->graph_valid = true; e->g_w = width; e->g_h = height; e->g_batch = batch; e->g_lap0 = lap0; e->g_lap1 = lap1;
+    }
+    HIP_TRY(hipGraphLaunch(e->graph_exec, e->ctx->stream));
+    e->last_batch = batch;
+    return ORBHIP_OK;
+}
+
 extern "C" int orbhip_extract_batch_device(orbhip_extractor *e, const uint8_t *d_images, int width, int height,
                                            size_t row_stride, size_t frame_stride, int batch, int lap0, int lap1)
 {
@@ -442,17 +470,29 @@ extern "C" int orbhip_extract_batch_device(orbhip_extractor *e, const uint8_t *d
     // layout would break the kernels' aligned dword row accesses, then stage it once on the device.
     OrbLevel &L0 = e->P.lv[0];
     const bool aligned = ((uintptr_t)d_images % 4 == 0) && (row_stride % 4 == 0) && (frame_stride % 4 == 0);
-    if (aligned) {
+    const bool use_graph = e->graph_mode && !e->profiling;
+    if (aligned && !use_graph) {
         L0.img = const_cast<uint8_t *>(d_images);
         L0.img_pitch = (int)row_stride;
         L0.img_frame_stride = frame_stride;
-    } else {
+    } else {                    // graph mode always stages: the captured kernels must see fixed addresses
         L0.img = e->d_level0; L0.img_pitch = e->level0_pitch; L0.img_frame_stride = e->level0_frame_stride;
         for (int f = 0; f < batch; f++)
             HIP_TRY(hipMemcpy2DAsync(L0.img + (size_t)f * L0.img_frame_stride, L0.img_pitch, d_images + (size_t)f * frame_stride,
                                      row_stride, width, height, hipMemcpyDeviceToDevice, e->ctx->stream));
     }
-    return run_pipeline(e, batch, lap0, lap1);
+    return use_graph ? run_pipeline_graph(e, width, height, batch, lap0, lap1) : run_pipeline(e, batch, lap0, lap1);
+}
+
+// Small batches are launch bound (19 kernels per extract call): with graph mode on, the launches of one call are
+// captured once per (size, batch, lapping) and replayed as a single hipGraph; the input is then always staged into
+// the extractor's own level-0 buffer (one D2D copy) so that the captured kernels see fixed addresses.
+extern "C" int orbhip_extractor_set_graph_mode(orbhip_extractor *e, int enable)
+{
+    if (!e) return ORBHIP_E_BADARG;
+    e->graph_mode = enable != 0;
+    if (!e->graph_mode && e->graph_valid) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_valid = false; }
+    return ORBHIP_OK;
 }
 
 extern "C" int orbhip_extractor_results(orbhip_extractor *e, orbhip_keypoint **d_kp, uint8_t **d_desc,
@@ -495,7 +535,7 @@ extern "C" int orbhip_extract_batch_host(orbhip_extractor *e, const uint8_t *h_i
     for (int f = 0; f < batch; f++)
         HIP_TRY(hipMemcpy2DAsync(L0.img + (size_t)f * L0.img_frame_stride, L0.img_pitch, h_images + (size_t)f * frame_stride,
                                  row_stride, width, height, hipMemcpyHostToDevice, s));
-    rc = run_pipeline(e, batch, lap0, lap1);
+    rc = (e->graph_mode && !e->profiling) ? run_pipeline_graph(e, width, height, batch, lap0, lap1) : run_pipeline(e, batch, lap0, lap1);
     if (rc) return rc;
     std::vector<int32_t> cnt(batch);
     HIP_TRY(hipMemcpyAsync(cnt.data(), e->P.out_count, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));

@@ -60,6 +60,7 @@ lib.orbhip_extractor_get_blurred_level.argtypes = [vp, ci, ci, vp, sz]
 lib.orbhip_extractor_get_fast_candidates.argtypes = [vp, ci, ci, vp, vp, vp, ci, C.POINTER(C.c_int32)]
 lib.orbhip_extractor_get_level_keypoints.argtypes = [vp, ci, ci, vp, ci, C.POINTER(C.c_int32)]
 lib.orbhip_extractor_set_profiling.argtypes = [vp, ci]
+lib.orbhip_extractor_set_graph_mode.argtypes = [vp, ci]
 lib.orbhip_extractor_stage_ms.argtypes = [vp, vp]
 lib.orbhip_descriptor_distance.argtypes = [vp, vp]
 lib.orbhip_match_bf2nn_device.argtypes = [vp, vp, vp, sz, vp, vp, sz, ci, ci, cd, vp, vp, vp]
@@ -139,6 +140,9 @@ class Extractor:
     @property
     def max_keypoints(self):
         return lib.orbhip_extractor_max_keypoints(self.h)
+
+    def set_graph_mode(self, on):
+        _chk(lib.orbhip_extractor_set_graph_mode(self.h, 1 if on else 0), "orbhip_extractor_set_graph_mode")
 
     def set_profiling(self, on):
         _chk(lib.orbhip_extractor_set_profiling(self.h, 1 if on else 0), "set_profiling")
@@ -366,6 +370,9 @@ class BaBatch:
     @property
     def ticks(self):
         return lib.orbhip_ba_batch_ticks(self.h)
+
+    def set_graph_mode(self, on):
+        _chk(lib.orbhip_extractor_set_graph_mode(self.h, 1 if on else 0), "orbhip_extractor_set_graph_mode")
 
     def set_profiling(self, on):
         _chk(lib.orbhip_ba_batch_set_profiling(self.h, 1 if on else 0), "ba set_profiling")
