@@ -380,7 +380,7 @@ def main():
         # (k_blur_score = SURVEY's "FAST read S" + "blur read+write 2S" done from one staged tile)
         kern = {"pyramid": "k_resize", "blur_score": "k_blur_score", "desc": "k_orient_desc"}
         dom = max(kern, key=lambda k: stage[k])
-        launches = {"pyramid": 7, "blur_score": 8, "desc": 1}[dom]
+        launches = {"pyramid": 7, "blur_score": 1, "desc": 1}[dom]
         dom_bytes = ab[dom] * B
         achieved = dom_bytes / (stage[dom] * 1e-3) / 1e9 if stage[dom] > 0 else 0.0
         # HBM traffic of the dominant kernel: PMC counters are collected in separate rocprofv3 passes (they cannot be

@@ -43,6 +43,7 @@ struct OrbParams {
     int kps_per_frame;        // sum of kp_cap  (== staging slots per frame)
     int max_kp;               // output row capacity per frame
     int fc_pd, fc_rows;       // k_fast_cells per-wave LDS geometry: dword pitch and rows of the score band (+ aprons)
+    int bs_tiles[ORB_MAX_LEVELS + 1];   // k_blur_score: prefix of 64x32 tiles per frame over the levels (one launch for all levels)
     int lap0, lap1;
     // per-frame scratch
     uint32_t *cell_count;     // [batch][cells_per_frame]

@@ -786,19 +786,24 @@ __device__ __forceinline__ void bl_score_queue(const uint32_t *in, const uint16_
 // the ~15 % that survive, queued per parity so no realignment is needed).
 // Algorithmic bytes: S read + S blurred write (+ S score write, an internal product).
 // ----------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_blur_score(OrbParams P, int level)
+__global__ __launch_bounds__(256) void k_blur_score(OrbParams P)
 {
     __shared__ __attribute__((aligned(16))) uint32_t in[BL_ROWS * BL_IPD + 4];
     __shared__ __attribute__((aligned(16))) uint32_t hz2[(BL_ROWS / 2) * BL_TW];     // [row pair][x]: row 2m | row 2m+1 << 16
     __shared__ uint32_t outt[BL_TH * BL_TW / 4];
     __shared__ uint16_t queue[2][BL_TH * BL_TW / 4];
     __shared__ int qn[2];
-    const OrbLevel &L = P.lv[level];
     const int tid = threadIdx.x, lane = tid & 63;
+    // one launch covers every level: logical block id -> (level, frame, tile), level-major so that each XCD's
+    // contiguous range of logical ids stays inside few frames of one level
+    const unsigned lid = xcd_logical_id(blockIdx.x, gridDim.x);
+    int level = 0;
+    for (int l = 1; l < P.nlevels; l++) if (lid >= (unsigned)P.bs_tiles[l] * (unsigned)P.batch) level = l;
+    const OrbLevel &L = P.lv[level];
     const int w = L.w, h = L.h, th = P.min_th;
     const int ntx = (w + BL_TW - 1) / BL_TW, nty = (h + BL_TH - 1) / BL_TH;
-    const unsigned lid = xcd_logical_id(blockIdx.x, gridDim.x);
-    const int frame = lid / (ntx * nty), trem = lid - frame * (ntx * nty);
+    const unsigned lrel = lid - (unsigned)P.bs_tiles[level] * (unsigned)P.batch;
+    const int frame = lrel / (ntx * nty), trem = lrel - frame * (ntx * nty);
     const int x0 = (trem % ntx) * BL_TW, y0 = (trem / ntx) * BL_TH;
     const uint8_t *src = L.img + (size_t)frame * L.img_frame_stride;
     // ---- stage: lanes 0..151 one 16-byte chunk each (38 rows x 4), lanes 152..227 one apron dword each
@@ -921,11 +926,8 @@ __global__ __launch_bounds__(256) void k_blur_score(OrbParams P, int level)
 
 void orb_launch_blur_score(const OrbParams &P, hipStream_t s)
 {
-    for (int l = 0; l < P.nlevels; l++) {
-        const OrbLevel &L = P.lv[l];
-        const unsigned nblocks = (unsigned)(((L.w + BL_TW - 1) / BL_TW) * ((L.h + BL_TH - 1) / BL_TH)) * (unsigned)P.batch;
-        hipLaunchKernelGGL(k_blur_score, dim3(nblocks), dim3(256), 0, s, P, l);
-    }
+    const unsigned nblocks = (unsigned)P.bs_tiles[P.nlevels] * (unsigned)P.batch;
+    hipLaunchKernelGGL(k_blur_score, dim3(nblocks), dim3(256), 0, s, P);
 }
 
 // ----------------------------------------------------------------------------------

@@ -284,6 +284,8 @@ extern "C" int orbhip_extractor_reserve(orbhip_extractor *e, int width, int heig
         P.fc_pd = ((mw + 4) >> 2) + 2;          // bytes [0, dw+4] (band + 4-byte aprons) + one dword of slack for the 16-byte window reads
         P.fc_rows = mh + 2;
     }
+    P.bs_tiles[0] = 0;
+    for (int l = 0; l < e->nlevels; l++) P.bs_tiles[l + 1] = P.bs_tiles[l] + ((P.lv[l].w + 63) / 64) * ((P.lv[l].h + 31) / 32);
     P.cell_list_frame_stride = (size_t)cells * max_cell_cap;
     int rc;
     const size_t B = (size_t)max_batch;
