@@ -200,6 +200,20 @@ int orbhip_search_by_projection_device(orbhip_ctx *ctx, const orbhip_proj_query 
                                        float max_y, int th_high, int check_orientation, int32_t *d_train_match,
                                        int32_t *d_nmatches);
 
+/* ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th, bFarPoints, thFarPoints)
+ * (src/ORBmatcher.cc:48-218, F.Nleft == -1) -- the matcher of Tracking::SearchLocalPoints (src/Tracking.cc:3096).
+ * Same layout and claim rule as orbhip_search_by_projection_device; one query per map point that passes :57-67:
+ * u, v = mTrackProjX/Y; radius = RadiusByViewingCos(mTrackViewCos) [* th] * F.mvScaleFactors[nPredictedLevel]
+ * (:72-79); (min_level, max_level) = (nPredictedLevel-1, nPredictedLevel); ur = mTrackProjXR; angle unused.
+ * A match needs best <= th_high and, when best and second best lie in the same octave, best <= nn_ratio * second
+ * (mfNNratio, :131-137).  No rotation histogram. */
+int orbhip_search_local_map_device(orbhip_ctx *ctx, const orbhip_proj_query *d_q, const uint8_t *d_desc_q,
+                                   const int32_t *d_nq, int max_q, const orbhip_keypoint *d_kp,
+                                   const uint8_t *d_desc, const float *d_u_right, const int32_t *d_n, int max_n,
+                                   size_t frame_stride_kp, int pairs, float min_x, float min_y, float max_x,
+                                   float max_y, int th_high, float nn_ratio, int32_t *d_train_match,
+                                   int32_t *d_nmatches);
+
 /* Frame::ComputeStereoMatches (src/Frame.cc:802-980), batched: rectified-stereo association
  * of the keypoints the LEFT and RIGHT extractor produced in their latest extract call (frame f with frame f;
  * both called with lapping {0,0} as the stereo constructor does, src/Frame.cc:109-110).  Per left keypoint:

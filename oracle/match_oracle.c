@@ -241,3 +241,41 @@ int orc_search_by_projection(const orc_proj_query *q, const uint8_t *desc_q, int
     free(cand); free(hist_items); free(hist_n); grid_free(&g);
     return nmatches;
 }
+
+/* ORBm:48-218, F.Nleft == -1 */
+int orc_search_by_projection_map(const orc_proj_query *q, const uint8_t *desc_q, int nq,
+                                 const orc_keypoint *kp, const uint8_t *desc, const float *u_right, int n,
+                                 float min_x, float min_y, float max_x, float max_y,
+                                 int th_high, float nn_ratio, int32_t *train_match)
+{
+    int nmatches = 0;
+    struct grid g;
+    grid_build(&g, kp, n, min_x, min_y, max_x, max_y);
+    int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * (n ? n : 1));
+    for (int i = 0; i < n; i++) if (train_match[i] != -1) train_match[i] = -2;
+    for (int t = 0; t < nq; t++) {
+        const float radius = q[t].radius;
+        const int nc = grid_query(&g, kp, q[t].u, q[t].v, radius, q[t].min_level, q[t].max_level, cand, n);   /* ORBm:78-79 */
+        if (nc == 0) continue;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;                    /* ORBm:85-89 */
+        for (int c = 0; c < nc; c++) {
+            const int idx = cand[c];
+            const int h = train_match[idx];
+            if (h <= -2 || (h >= 0 && q[h].has_obs)) continue;                                                 /* ORBm:96-98 */
+            if (u_right && u_right[idx] > 0) {                                                                 /* ORBm:100-105 */
+                const float er = fabsf(q[t].ur - u_right[idx]);
+                if (er > radius) continue;
+            }
+            const int dist = orc_descriptor_distance(desc_q + 32 * (size_t)t, desc + 32 * (size_t)idx);
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = kp[idx].octave; bestIdx = idx; }
+            else if (dist < bestDist2) { bestLevel2 = kp[idx].octave; bestDist2 = dist; }
+        }
+        if (bestDist <= th_high) {                                                                             /* ORBm:131-150 */
+            if (bestLevel == bestLevel2 && bestDist > nn_ratio * bestDist2) continue;
+            train_match[bestIdx] = t;
+            nmatches++;
+        }
+    }
+    free(cand); grid_free(&g);
+    return nmatches;
+}

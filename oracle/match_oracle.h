@@ -43,6 +43,16 @@ int orc_search_by_projection(const orc_proj_query *q, const uint8_t *desc_q, int
                              const orc_keypoint *kp, const uint8_t *desc, const float *u_right, int n,
                              float min_x, float min_y, float max_x, float max_y,
                              int th_high, int check_orientation, int32_t *train_match);
+/* ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th, ...) (ORBmatcher.cc:48-218,
+ * F.Nleft == -1), the TrackLocalMap matcher.  One query per map point with mbTrackInView that survives :57-65:
+ * u,v = mTrackProjX/Y, radius = r * F.mvScaleFactors[nPredictedLevel] with r = RadiusByViewingCos(...) [* th] (:72-79),
+ * (min_level, max_level) = (nPredictedLevel-1, nPredictedLevel), ur = mTrackProjXR, has_obs as above; angle unused.
+ * Best and second-best distance with their octaves; accepted iff best <= th_high and not (same octave and
+ * best > nn_ratio * second) (:131-137).  train_match as in orc_search_by_projection.  Returns nmatches. */
+int orc_search_by_projection_map(const orc_proj_query *q, const uint8_t *desc_q, int nq,
+                                 const orc_keypoint *kp, const uint8_t *desc, const float *u_right, int n,
+                                 float min_x, float min_y, float max_x, float max_y,
+                                 int th_high, float nn_ratio, int32_t *train_match);
 #ifdef __cplusplus
 }
 #endif

@@ -363,7 +363,8 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
                                                              const orbhip_keypoint *kp_, const uint8_t *desc_, const float *uright_,
                                                              const int32_t *n_, int max_n, size_t kp_stride,
                                                              float min_x, float min_y, float max_x, float max_y,
-                                                             int th_high, int check_ori, int32_t *tm_, int32_t *nmatches_, int32_t *status)
+                                                             int th_high, int check_ori, int mode, float nn_ratio,
+                                                             int32_t *tm_, int32_t *nmatches_, int32_t *status)
 {
     __shared__ float kx[SBP_CAP], ky[SBP_CAP];
     __shared__ uint8_t oct[SBP_CAP];
@@ -463,7 +464,7 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
         __syncthreads();
         const bool check_lv = qq.min_level > 0 || qq.max_level >= 0;            // Frame.cc:676
         const uint4 a0 = dQ[2 * t], a1 = dQ[2 * t + 1];
-        uint32_t key = 0xFFFFFFFFu;
+        uint32_t key = 0xFFFFFFFFu, key2 = 0xFFFFFFFFu;                         // the two smallest (distance << 12 | position)
         for (int k0 = 0; k0 < total; k0 += 64) {
             const int k = k0 + lane;
             if (k < total) {
@@ -471,19 +472,34 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
                 const int o = oct[i2], h = holder[i2];
                 bool ok = !(check_lv && (o < qq.min_level || (qq.max_level >= 0 && o > qq.max_level)));   // Frame.cc:693-701
                 ok = ok && fabsf(__fsub_rn(kx[i2], x)) < r && fabsf(__fsub_rn(ky[i2], y)) < r;           // Frame.cc:704-708
-                ok = ok && !(h <= -2 || (h >= 0 && (h & 1)));                                              // ORBmatcher.cc:2037-2039
+                ok = ok && !(h <= -2 || (h >= 0 && (h & 1)));                                              // ORBmatcher.cc:2037-2039 / 96-98
                 if (ok && uright) {
                     const float ur2 = uright[i2];
-                    if (ur2 > 0 && fabsf(__fsub_rn(qq.ur, ur2)) > r) ok = false;                           // ORBmatcher.cc:2041-2047
+                    if (ur2 > 0 && fabsf(__fsub_rn(qq.ur, ur2)) > r) ok = false;                           // ORBmatcher.cc:2041-2047 / 100-105
                 }
                 if (ok) {
                     const int dist = hamming256(a0, a1, dT[2 * i2], dT[2 * i2 + 1]);
-                    key = min(key, ((uint32_t)dist << 12) | (uint32_t)k);
+                    const uint32_t kk = ((uint32_t)dist << 12) | (uint32_t)k;
+                    key2 = min(key2, max(key, kk));
+                    key = min(key, kk);
                 }
             }
         }
-        for (int d = 32; d >= 1; d >>= 1) key = min(key, (uint32_t)__shfl_xor((int)key, d, 64));
-        if (key != 0xFFFFFFFFu && (int)(key >> 12) <= th_high && (int)(key >> 12) < 256) {                 // ORBmatcher.cc:2030, 2058
+        for (int d = 32; d >= 1; d >>= 1) {
+            const uint32_t o1 = (uint32_t)__shfl_xor((int)key, d, 64), o2 = (uint32_t)__shfl_xor((int)key2, d, 64);
+            key2 = min(max(key, o1), min(key2, o2));
+            key = min(key, o1);
+        }
+        bool accept = key != 0xFFFFFFFFu && (int)(key >> 12) <= th_high && (int)(key >> 12) < 256;       // ORBmatcher.cc:2030,2058 / 85,131
+        if (accept && mode == 1) {
+            // local-map variant (ORBmatcher.cc:131-137): ratio test against the second best of the same octave.
+            // "second best" of the reference's scan == second smallest key (strict <, first candidate wins ties)
+            const int best_lv = oct[cand[key & 0xFFFu]];
+            int d2 = 256, lv2 = -1;
+            if (key2 != 0xFFFFFFFFu && (int)(key2 >> 12) < 256) { d2 = (int)(key2 >> 12); lv2 = oct[cand[key2 & 0xFFFu]]; }
+            if (best_lv == lv2 && (float)(int)(key >> 12) > __fmul_rn(nn_ratio, (float)d2)) accept = false;
+        }
+        if (accept) {
             if (lane == 0) {
                 const int best = cand[key & 0xFFFu];
                 holder[best] = (int16_t)((t << 1) | (qq.has_obs ? 1 : 0));
@@ -544,6 +560,24 @@ extern "C" int orbhip_search_by_projection_device(orbhip_ctx *ctx, const orbhip_
     if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
     hipLaunchKernelGGL(k_search_by_projection, dim3(pairs), dim3(64), 0, orbhip_ctx_stream_internal(ctx), d_q, d_desc_q, d_nq,
                        max_q, d_kp, d_desc, d_u_right, d_n, max_n, frame_stride_kp, min_x, min_y, max_x, max_y, th_high,
-                       check_orientation, d_train_match, d_nmatches, orbhip_ctx_status_internal(ctx));
+                       check_orientation, 0, 0.0f, d_train_match, d_nmatches, orbhip_ctx_status_internal(ctx));
+    return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
+}
+
+// ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th, ...), ORBmatcher.cc:48-218 (Nleft == -1)
+extern "C" int orbhip_search_local_map_device(orbhip_ctx *ctx, const orbhip_proj_query *d_q, const uint8_t *d_desc_q,
+                                              const int32_t *d_nq, int max_q, const orbhip_keypoint *d_kp,
+                                              const uint8_t *d_desc, const float *d_u_right, const int32_t *d_n, int max_n,
+                                              size_t frame_stride_kp, int pairs, float min_x, float min_y, float max_x,
+                                              float max_y, int th_high, float nn_ratio, int32_t *d_train_match,
+                                              int32_t *d_nmatches)
+{
+    if (!ctx || !d_q || !d_desc_q || !d_nq || !d_kp || !d_desc || !d_n || pairs <= 0 || max_n <= 0 || max_q <= 0 ||
+        !d_train_match || !d_nmatches || !(max_x > min_x) || !(max_y > min_y))
+        return ORBHIP_E_BADARG;
+    if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
+    hipLaunchKernelGGL(k_search_by_projection, dim3(pairs), dim3(64), 0, orbhip_ctx_stream_internal(ctx), d_q, d_desc_q, d_nq,
+                       max_q, d_kp, d_desc, d_u_right, d_n, max_n, frame_stride_kp, min_x, min_y, max_x, max_y, th_high,
+                       0, 1, nn_ratio, d_train_match, d_nmatches, orbhip_ctx_status_internal(ctx));
     return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
 }

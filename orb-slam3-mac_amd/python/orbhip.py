@@ -69,6 +69,7 @@ lib.orbhip_search_for_initialization_device.argtypes = [vp, vp, vp, vp, vp, vp, 
 lib.orbhip_ctx_check_status.argtypes = [vp]
 lib.orbhip_prev_matched_init_device.argtypes = [vp, vp, sz, ci, ci, vp]
 lib.orbhip_search_by_projection_device.argtypes = [vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, sz, ci, cf, cf, cf, cf, ci, ci, vp, vp]
+lib.orbhip_search_local_map_device.argtypes = [vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, sz, ci, cf, cf, cf, cf, ci, cf, vp, vp]
 
 
 class OrbHipError(RuntimeError):
@@ -243,6 +244,14 @@ def search_by_projection_device(ctx, d_q, d_desc_q, d_nq, max_q, d_kp, d_desc, d
                                                 kp_stride, pairs, bounds[0], bounds[1], bounds[2], bounds[3], th_high,
                                                 1 if check_ori else 0, d_train_match, d_nmatches),
          "orbhip_search_by_projection_device")
+
+
+def search_local_map_device(ctx, d_q, d_desc_q, d_nq, max_q, d_kp, d_desc, d_u_right, d_n, max_n, kp_stride, pairs,
+                            bounds, th_high, nn_ratio, d_train_match, d_nmatches):
+    """ORBmatcher::SearchByProjection(F, vpMapPoints, th) (TrackLocalMap), batched; device addresses (ints)."""
+    _chk(lib.orbhip_search_local_map_device(ctx.h, d_q, d_desc_q, d_nq, max_q, d_kp, d_desc, d_u_right, d_n, max_n,
+                                            kp_stride, pairs, bounds[0], bounds[1], bounds[2], bounds[3], th_high,
+                                            nn_ratio, d_train_match, d_nmatches), "orbhip_search_local_map_device")
 
 
 def prev_matched_init_device(ctx, d_kp, kp_stride, frames, max_n, d_prev):

@@ -10,6 +10,8 @@ lib.orc_search_for_initialization.argtypes = [vp, vp, ci, vp, vp, ci, cf, cf, cf
 lib.orc_features_in_area.argtypes = [vp, ci, cf, cf, cf, cf, cf, cf, cf, ci, ci, vp, ci]
 lib.orc_search_by_projection.argtypes = [vp, vp, ci, vp, vp, vp, ci, cf, cf, cf, cf, ci, ci, vp]
 lib.orc_search_by_projection.restype = ci
+lib.orc_search_by_projection_map.argtypes = [vp, vp, ci, vp, vp, vp, ci, cf, cf, cf, cf, ci, cf, vp]
+lib.orc_search_by_projection_map.restype = ci
 
 PROJ_QUERY_DTYPE = np.dtype([("u", np.float32), ("v", np.float32), ("radius", np.float32), ("ur", np.float32),
                              ("angle", np.float32), ("min_level", np.int32), ("max_level", np.int32), ("has_obs", np.int32)])
@@ -66,4 +68,20 @@ def search_by_projection(q, dq, kp, d, u_right, bounds, train_match, th_high=100
     n = lib.orc_search_by_projection(q.ctypes.data, dq.ctypes.data, len(q), kp.ctypes.data, d.ctypes.data,
                                      None if ur is None else ur.ctypes.data, len(kp), bounds[0], bounds[1], bounds[2],
                                      bounds[3], th_high, 1 if check_ori else 0, tm.ctypes.data)
+    return n, tm[:len(kp)]
+
+
+def search_by_projection_map(q, dq, kp, d, u_right, bounds, train_match, th_high=100, nn_ratio=0.8):
+    """ORBmatcher::SearchByProjection(F, vpMapPoints, th) restated; returns (nmatches, train_match)."""
+    q = np.ascontiguousarray(q, PROJ_QUERY_DTYPE)
+    dq = np.ascontiguousarray(dq, np.uint8)
+    kp = np.ascontiguousarray(kp, KP_DTYPE)
+    d = np.ascontiguousarray(d, np.uint8)
+    tm = np.ascontiguousarray(train_match, np.int32).copy()
+    if len(tm) == 0:
+        tm = np.zeros(1, np.int32)
+    ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    n = lib.orc_search_by_projection_map(q.ctypes.data, dq.ctypes.data, len(q), kp.ctypes.data, d.ctypes.data,
+                                         None if ur is None else ur.ctypes.data, len(kp), bounds[0], bounds[1], bounds[2],
+                                         bounds[3], th_high, nn_ratio, tm.ctypes.data)
     return n, tm[:len(kp)]

@@ -177,7 +177,7 @@ def test_search_for_initialization_edge_cases(gpu_ctx):
 
 
 # ------------------------------------------------------------------ M3 + M4: SearchByProjection (tracking)
-def _sbp(gpu_ctx, cases, max_q, max_n, bounds, th_high=100, check_ori=True, stereo=False):
+def _sbp(gpu_ctx, cases, max_q, max_n, bounds, th_high=100, check_ori=True, stereo=False, map_ratio=None):
     """cases: list of (q, dq, kp, d, u_right|None, train_match).  Returns per pair (nmatches, train_match)."""
     import torch
     import orbhip
@@ -194,9 +194,14 @@ def _sbp(gpu_ctx, cases, max_q, max_n, bounds, th_high=100, check_ori=True, ster
          for a in (Q, DQ, nq, KP, D, UR, n, TM)]
     nm = torch.full((P,), -9, dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
-    orbhip.search_by_projection_device(gpu_ctx, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), max_q, t[3].data_ptr(),
+    if map_ratio is None:
+        orbhip.search_by_projection_device(gpu_ctx, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), max_q, t[3].data_ptr(),
+                                           t[4].data_ptr(), t[5].data_ptr() if stereo else None, t[6].data_ptr(), max_n, max_n, P,
+                                           bounds, th_high, check_ori, t[7].data_ptr(), nm.data_ptr())
+    else:
+        orbhip.search_local_map_device(gpu_ctx, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), max_q, t[3].data_ptr(),
                                        t[4].data_ptr(), t[5].data_ptr() if stereo else None, t[6].data_ptr(), max_n, max_n, P,
-                                       bounds, th_high, check_ori, t[7].data_ptr(), nm.data_ptr())
+                                       bounds, th_high, map_ratio, t[7].data_ptr(), nm.data_ptr())
     gpu_ctx.check_status()
     tm = t[7].cpu().numpy(); nm = nm.cpu().numpy()
     return [(int(nm[p]), tm[p, :n[p]]) for p in range(P)]
@@ -278,3 +283,23 @@ def test_search_for_initialization_5x_features(gpu_ctx):
         np.testing.assert_array_equal(got[p][1], m12)
         assert got[p][2].tobytes() == prev.tobytes()
     ext.close()
+
+
+@pytest.mark.parametrize("stereo,ratio", [(False, 0.8), (True, 0.8), (False, 0.6)])
+def test_search_local_map_parity(gpu_ctx, stereo, ratio):
+    """TrackLocalMap matcher (ORBmatcher.cc:48-218): best / second best with the same-octave ratio rule, claim rule."""
+    import oracle_match_bind as om
+    from test_oracle_match_ba import make_sbp_case
+    rng = np.random.default_rng(41 + stereo)
+    bounds = (0.0, 0.0, 640.0, 480.0)
+    cases = [make_sbp_case(rng, n, nq, stereo) for n, nq in ((0, 10), (60, 0), (300, 300), (1000, 900), (2048, 2048), (700, 1500))]
+    for c in cases:
+        c[0]["min_level"] = np.maximum(c[0]["max_level"], 0) - 1; c[0]["max_level"] = c[0]["min_level"] + 1
+    got = _sbp(gpu_ctx, cases, 2048, 2048, bounds, 100, False, stereo, map_ratio=ratio)
+    tot = 0
+    for p, (q, dq, kp, d, ur, tm) in enumerate(cases):
+        n_ref, tm_ref = om.search_by_projection_map(q, dq, kp, d, ur if stereo else None, bounds, tm, 100, ratio)
+        assert got[p][0] == n_ref, (p, got[p][0], n_ref)
+        np.testing.assert_array_equal(got[p][1], tm_ref)
+        tot += n_ref
+    assert tot > 300

@@ -290,6 +290,50 @@ def test_search_by_projection_oracle_against_python(with_stereo, check_ori):
             assert (tm1 >= 0).sum() > 20
 
 
+def _sbp_map_python(q, dq, kp, d, u_right, bounds, tm, th_high, ratio):
+    """Independent restatement of ORBmatcher.cc:48-218 (Nleft == -1)."""
+    import oracle_match_bind as om
+    tm = tm.copy(); tm[tm != -1] = -2
+    nm = 0
+    for t in range(len(q)):
+        cand = om.features_in_area(kp, bounds, float(q["u"][t]), float(q["v"][t]), float(q["radius"][t]),
+                                   int(q["min_level"][t]), int(q["max_level"][t]))
+        b1, l1, b2, l2, bi = 256, -1, 256, -1, -1
+        for idx in cand:
+            h = tm[idx]
+            if h <= -2 or (h >= 0 and q["has_obs"][h]):
+                continue
+            if u_right is not None and u_right[idx] > 0 and abs(np.float32(q["ur"][t]) - np.float32(u_right[idx])) > q["radius"][t]:
+                continue
+            dist = int(np.unpackbits(dq[t] ^ d[idx]).sum())
+            if dist < b1:
+                b2, l2, b1, l1, bi = b1, l1, dist, int(kp["octave"][idx]), idx
+            elif dist < b2:
+                b2, l2 = dist, int(kp["octave"][idx])
+        if b1 <= th_high:
+            if l1 == l2 and np.float32(b1) > np.float32(ratio) * np.float32(b2):
+                continue
+            tm[bi] = t; nm += 1
+    return nm, tm
+
+
+@pytest.mark.parametrize("with_stereo", [False, True])
+def test_search_by_projection_map_oracle_against_python(with_stereo):
+    import oracle_match_bind as om
+    rng = np.random.default_rng(31 + with_stereo)
+    bounds = (0.0, 0.0, 640.0, 480.0)
+    for n, nq in ((0, 5), (40, 0), (300, 250), (500, 400)):
+        q, dq, kp, d, ur, tm = make_sbp_case(rng, n, nq, with_stereo)
+        q["min_level"] = np.maximum(q["max_level"], 0) - 1; q["max_level"] = q["min_level"] + 1      # (level-1, level)
+        for ratio in (0.8, 0.6):
+            n1, tm1 = om.search_by_projection_map(q, dq, kp, d, ur, bounds, tm, 100, ratio)
+            n2, tm2 = _sbp_map_python(q, dq, kp, d, ur, bounds, tm, 100, ratio)
+            assert n1 == n2
+            np.testing.assert_array_equal(tm1, tm2)
+        if n >= 300:
+            assert (tm1 >= 0).sum() > 20
+
+
 # ------------------------------------------------------------------ PoseOptimization oracle (8f N1)
 def _pose_err(a, b):
     qa, qb = a[:4], b[:4]
