@@ -51,12 +51,6 @@ __device__ __forceinline__ unsigned xcd_logical_id(unsigned bid, unsigned nblock
     return k * q + min(k, r) + j;
 }
 
-__device__ __forceinline__ int wave_sum(int v)
-{
-#pragma unroll
-    for (int d = WAVE / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d, WAVE);
-    return v;
-}
 
 // ----------------------------------------------------------------------------------
 // A2/A3  pyramid: level l from level l-1, cv::resize INTER_LINEAR 8UC1 fixed point
@@ -185,11 +179,10 @@ void orb_launch_resize(const OrbParams &P, int level, hipStream_t s)
 // Identity used (tests/test_oracle_orb.py::test_fast_arc_score_identity):
 //   S = max over the 16 contiguous 9-arcs of min(v-p) and of min(p-v);
 //   corner at threshold t  <=>  S > t ;  cornerScore == S-1.
-// So one pass computes a threshold-independent score map; both thresholds are decided
-// from it.  One 256-thread workgroup per cell, the cell's (wCell+6)x(hCell+6) sub-image
-// staged in LDS.  Keypoints are emitted in cv::FAST order (row-major) via a block scan.
+// So one pass (k_blur_score, fused with the blur) computes a threshold-independent score map of the whole
+// level; k_fast_cells then applies the reference's per-cell semantics to it (3x3 NMS inside the cell's
+// detection band only, iniThFAST with minThFAST retry, cv::FAST emission order).
 // ----------------------------------------------------------------------------------
-#define FAST_TP 72            // LDS pitch (bytes): cells up to 64 wide + up to 3 bytes of dword alignment
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32_unaligned __attribute__((aligned(1)));
 
