@@ -363,16 +363,19 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
                                                              const orbhip_keypoint *kp_, const uint8_t *desc_, const float *uright_,
                                                              const int32_t *n_, int max_n, size_t kp_stride,
                                                              float min_x, float min_y, float max_x, float max_y,
-                                                             int th_high, int check_ori, int mode, float nn_ratio,
+                                                             int th_high, int check_ori, int mode, float nn_ratio, int cap_n, int cap_q,
                                                              int32_t *tm_, int32_t *nmatches_, int32_t *status)
 {
-    __shared__ float kx[SBP_CAP], ky[SBP_CAP];
-    __shared__ uint8_t oct[SBP_CAP];
-    __shared__ int16_t holder[SBP_CAP];           // -1 free, -2 pre-held, else (query << 1 | has_obs)
-    __shared__ uint32_t cell_start[SBP_CELLS + 1];
-    __shared__ uint16_t items[SBP_CAP], cand[SBP_CAP], cell_of[SBP_CAP], rank_of[SBP_CAP];
-    __shared__ int16_t qm[SBP_CAP];               // query -> claimed keypoint
-    __shared__ int8_t qbin[SBP_CAP];
+    // dynamic LDS carved by the launcher's capacities (cap_n keypoints, cap_q queries per pair): small frames keep
+    // four pairs per CU resident
+    extern __shared__ __attribute__((aligned(16))) uint8_t sbp_lds[];
+    uint32_t *cell_start = reinterpret_cast<uint32_t *>(sbp_lds);                   // [SBP_CELLS + 1]
+    float *kx = reinterpret_cast<float *>(cell_start + SBP_CELLS + 1), *ky = kx + cap_n;
+    int16_t *holder = reinterpret_cast<int16_t *>(ky + cap_n);                       // -1 free, -2 pre-held, else (query << 1 | has_obs)
+    uint16_t *items = reinterpret_cast<uint16_t *>(holder + cap_n), *cand = items + cap_n, *cell_of = cand + cap_n, *rank_of = cell_of + cap_n;
+    int16_t *qm = reinterpret_cast<int16_t *>(rank_of + cap_n);                      // query -> claimed keypoint
+    int8_t *qbin = reinterpret_cast<int8_t *>(qm + cap_q);
+    uint8_t *oct = reinterpret_cast<uint8_t *>(qbin + cap_q);
     __shared__ int hist[SI_HISTO];
     __shared__ int s_keep[3];
     const int pair = blockIdx.x, lane = threadIdx.x;
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
     const uint4 *dT = reinterpret_cast<const uint4 *>(desc_ + (size_t)pair * kp_stride * 32);
     const float *uright = uright_ ? uright_ + (size_t)pair * kp_stride : nullptr;
     int32_t *tm = tm_ + (size_t)pair * max_n;
-    if (n > SBP_CAP || nq > SBP_CAP || n > max_n || nq > max_q) {
+    if (n > cap_n || nq > cap_q || n > max_n || nq > max_q) {
         if (lane == 0) { atomicExch(status, ORBHIP_E_CAPACITY); nmatches_[pair] = 0; }
         return;
     }
@@ -438,8 +441,13 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
     // ---- sequential query loop (ORBmatcher.cc:1987-2088)
     int nmatches = 0;
     const float factor = 1.0f / SI_HISTO;
+    // the next query's record and descriptor are fetched one iteration ahead (their latency overlaps this query's work)
+    orbhip_proj_query qn = Q[0];
+    uint4 n0 = dQ[0], n1 = dQ[1];
     for (int t = 0; t < nq; t++) {
-        const orbhip_proj_query qq = Q[t];
+        const orbhip_proj_query qq = qn;
+        const uint4 a0 = n0, a1 = n1;
+        if (t + 1 < nq) { qn = Q[t + 1]; n0 = dQ[2 * t + 2]; n1 = dQ[2 * t + 3]; }
         const float x = qq.u, y = qq.v, r = qq.radius;
         int c0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, min_x), r), inv_w)); if (c0 < 0) c0 = 0;   // Frame.cc:656-674
         if (c0 >= SI_COLS) continue;
@@ -463,7 +471,6 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
         for (int j = 0; j < maxlen; j++) if (j < len) cand[off + j] = items[start + j];
         __syncthreads();
         const bool check_lv = qq.min_level > 0 || qq.max_level >= 0;            // Frame.cc:676
-        const uint4 a0 = dQ[2 * t], a1 = dQ[2 * t + 1];
         uint32_t key = 0xFFFFFFFFu, key2 = 0xFFFFFFFFu;                         // the two smallest (distance << 12 | position)
         for (int k0 = 0; k0 < total; k0 += 64) {
             const int k = k0 + lane;
@@ -504,13 +511,6 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
                 const int best = cand[key & 0xFFFu];
                 holder[best] = (int16_t)((t << 1) | (qq.has_obs ? 1 : 0));
                 qm[t] = (int16_t)best;
-                if (check_ori) {                                                                           // ORBmatcher.cc:2064-2084
-                    float rot = __fsub_rn(qq.angle, kp[best].angle);
-                    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
-                    int bin = (int)roundf(__fmul_rn(rot, factor));
-                    if (bin == SI_HISTO) bin = 0;
-                    hist[bin]++; qbin[t] = (int8_t)bin;
-                }
             }
             nmatches++;
         }
@@ -518,8 +518,19 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
     }
     __syncthreads();
     // ---- rotation consistency (ORBmatcher.cc:2156-2178): every histogram entry of a dropped bin clears its
-    // keypoint (also when a later query re-claimed it) and counts once
+    // keypoint (also when a later query re-claimed it) and counts once.  Bins (ORBmatcher.cc:2064-2084) are computed
+    // here in parallel for all matches instead of inside the sequential loop (one dependent global read less per query).
     if (check_ori) {
+        for (int t = lane; t < nq; t += 64) {
+            const int best = qm[t];
+            if (best < 0) continue;
+            float rot = __fsub_rn(Q[t].angle, kp[best].angle);
+            if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+            int bin = (int)roundf(__fmul_rn(rot, factor));
+            if (bin == SI_HISTO) bin = 0;
+            atomicAdd(&hist[bin], 1); qbin[t] = (int8_t)bin;
+        }
+        __syncthreads();
         if (lane == 0) {
             int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
             for (int i = 0; i < SI_HISTO; i++) {
@@ -547,6 +558,30 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
     if (lane == 0) nmatches_[pair] = nmatches;
 }
 
+// LDS of k_search_by_projection for the given row capacities (keypoints / queries per pair)
+static size_t sbp_lds_bytes(int cap_n, int cap_q)
+{
+    return sizeof(uint32_t) * (SBP_CELLS + 1) + (size_t)cap_n * (4 + 4 + 2 + 2 + 2 + 2 + 2 + 1) + (size_t)cap_q * (2 + 1) + 16;
+}
+static int sbp_launch(orbhip_ctx *ctx, const orbhip_proj_query *d_q, const uint8_t *d_desc_q, const int32_t *d_nq, int max_q,
+                      const orbhip_keypoint *d_kp, const uint8_t *d_desc, const float *d_u_right, const int32_t *d_n, int max_n,
+                      size_t frame_stride_kp, int pairs, float min_x, float min_y, float max_x, float max_y, int th_high,
+                      int check_orientation, int mode, float nn_ratio, int32_t *d_train_match, int32_t *d_nmatches)
+{
+    const int cap_n = ((max_n < SBP_CAP ? max_n : SBP_CAP) + 7) & ~7, cap_q = ((max_q < SBP_CAP ? max_q : SBP_CAP) + 7) & ~7;
+    const size_t lds = sbp_lds_bytes(cap_n, cap_q);
+    static thread_local size_t lds_set = 0;
+    if (lds > lds_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_by_projection), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return ORBHIP_E_HIP;
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(k_search_by_projection, dim3(pairs), dim3(64), lds, orbhip_ctx_stream_internal(ctx), d_q, d_desc_q, d_nq,
+                       max_q, d_kp, d_desc, d_u_right, d_n, max_n, frame_stride_kp, min_x, min_y, max_x, max_y, th_high,
+                       check_orientation, mode, nn_ratio, cap_n, cap_q, d_train_match, d_nmatches, orbhip_ctx_status_internal(ctx));
+    return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
+}
+
 extern "C" int orbhip_search_by_projection_device(orbhip_ctx *ctx, const orbhip_proj_query *d_q, const uint8_t *d_desc_q,
                                                   const int32_t *d_nq, int max_q, const orbhip_keypoint *d_kp,
                                                   const uint8_t *d_desc, const float *d_u_right, const int32_t *d_n, int max_n,
@@ -558,10 +593,8 @@ extern "C" int orbhip_search_by_projection_device(orbhip_ctx *ctx, const orbhip_
         !d_train_match || !d_nmatches || !(max_x > min_x) || !(max_y > min_y))
         return ORBHIP_E_BADARG;
     if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
-    hipLaunchKernelGGL(k_search_by_projection, dim3(pairs), dim3(64), 0, orbhip_ctx_stream_internal(ctx), d_q, d_desc_q, d_nq,
-                       max_q, d_kp, d_desc, d_u_right, d_n, max_n, frame_stride_kp, min_x, min_y, max_x, max_y, th_high,
-                       check_orientation, 0, 0.0f, d_train_match, d_nmatches, orbhip_ctx_status_internal(ctx));
-    return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
+    return sbp_launch(ctx, d_q, d_desc_q, d_nq, max_q, d_kp, d_desc, d_u_right, d_n, max_n, frame_stride_kp, pairs, min_x, min_y,
+                      max_x, max_y, th_high, check_orientation, 0, 0.0f, d_train_match, d_nmatches);
 }
 
 // ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th, ...), ORBmatcher.cc:48-218 (Nleft == -1)
@@ -576,8 +609,6 @@ extern "C" int orbhip_search_local_map_device(orbhip_ctx *ctx, const orbhip_proj
         !d_train_match || !d_nmatches || !(max_x > min_x) || !(max_y > min_y))
         return ORBHIP_E_BADARG;
     if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
-    hipLaunchKernelGGL(k_search_by_projection, dim3(pairs), dim3(64), 0, orbhip_ctx_stream_internal(ctx), d_q, d_desc_q, d_nq,
-                       max_q, d_kp, d_desc, d_u_right, d_n, max_n, frame_stride_kp, min_x, min_y, max_x, max_y, th_high,
-                       0, 1, nn_ratio, d_train_match, d_nmatches, orbhip_ctx_status_internal(ctx));
-    return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
+    return sbp_launch(ctx, d_q, d_desc_q, d_nq, max_q, d_kp, d_desc, d_u_right, d_n, max_n, frame_stride_kp, pairs, min_x, min_y,
+                      max_x, max_y, th_high, 0, 1, nn_ratio, d_train_match, d_nmatches);
 }
