@@ -359,6 +359,7 @@ extern "C" int orbhip_prev_matched_init_device(orbhip_ctx *ctx, const orbhip_key
 // queries (:2037-2039).
 #define SBP_CAP 2048
 #define SBP_CELLS (SI_COLS * SI_ROWS)
+template <bool DESC_LDS>
 __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_query *q_, const uint8_t *descq_, const int32_t *nq_, int max_q,
                                                              const orbhip_keypoint *kp_, const uint8_t *desc_, const float *uright_,
                                                              const int32_t *n_, int max_n, size_t kp_stride,
@@ -376,6 +377,9 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
     int16_t *qm = reinterpret_cast<int16_t *>(rank_of + cap_n);                      // query -> claimed keypoint
     int8_t *qbin = reinterpret_cast<int8_t *>(qm + cap_q);
     uint8_t *oct = reinterpret_cast<uint8_t *>(qbin + cap_q);
+    // optional: the train descriptors too (32 B each) -- removes the one global round trip left in every query; used when
+    // the launch is small enough that fewer resident pairs per CU do not matter
+    uint4 *dlds = reinterpret_cast<uint4 *>(sbp_lds + ((sizeof(uint32_t) * (SBP_CELLS + 1) + (size_t)cap_n * 19 + (size_t)cap_q * 3 + 15) & ~(size_t)15));
     __shared__ int hist[SI_HISTO];
     __shared__ int s_keep[3];
     const int pair = blockIdx.x, lane = threadIdx.x;
@@ -407,6 +411,7 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
             const orbhip_keypoint k = kp[i];
             kx[i] = k.x; ky[i] = k.y; oct[i] = (uint8_t)k.octave;
             holder[i] = tm[i] == -1 ? (int16_t)-1 : (int16_t)-2;
+            if (DESC_LDS) { dlds[2 * i] = dT[2 * i]; dlds[2 * i + 1] = dT[2 * i + 1]; }
             const int px = (int)roundf(__fmul_rn(__fsub_rn(k.x, min_x), inv_w));
             const int py = (int)roundf(__fmul_rn(__fsub_rn(k.y, min_y), inv_h));
             if (px >= 0 && px < SI_COLS && py >= 0 && py < SI_ROWS) c = px * SI_ROWS + py;
@@ -485,7 +490,7 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
                     if (ur2 > 0 && fabsf(__fsub_rn(qq.ur, ur2)) > r) ok = false;                           // ORBmatcher.cc:2041-2047 / 100-105
                 }
                 if (ok) {
-                    const int dist = hamming256(a0, a1, dT[2 * i2], dT[2 * i2 + 1]);
+                    const int dist = DESC_LDS ? hamming256(a0, a1, dlds[2 * i2], dlds[2 * i2 + 1]) : hamming256(a0, a1, dT[2 * i2], dT[2 * i2 + 1]);
                     const uint32_t kk = ((uint32_t)dist << 12) | (uint32_t)k;
                     key2 = min(key2, max(key, kk));
                     key = min(key, kk);
@@ -569,14 +574,21 @@ static int sbp_launch(orbhip_ctx *ctx, const orbhip_proj_query *d_q, const uint8
                       int check_orientation, int mode, float nn_ratio, int32_t *d_train_match, int32_t *d_nmatches)
 {
     const int cap_n = ((max_n < SBP_CAP ? max_n : SBP_CAP) + 7) & ~7, cap_q = ((max_q < SBP_CAP ? max_q : SBP_CAP) + 7) & ~7;
-    const size_t lds = sbp_lds_bytes(cap_n, cap_q);
-    static thread_local size_t lds_set = 0;
-    if (lds > lds_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_by_projection), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    const size_t base = sbp_lds_bytes(cap_n, cap_q), with_desc = base + (size_t)cap_n * 32;
+    // descriptors in LDS when at most two rounds of workgroups are needed anyway (<= 2 pairs per CU resident is enough)
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const bool desc_lds = with_desc <= 150 * 1024 && (size_t)pairs * with_desc <= (size_t)cus * 150 * 1024;
+    const size_t lds = desc_lds ? with_desc : base;
+    static thread_local size_t lds_set[2] = {0, 0};
+    auto kern = desc_lds ? k_search_by_projection<true> : k_search_by_projection<false>;
+    if (lds > lds_set[desc_lds]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return ORBHIP_E_HIP;
-        lds_set = lds;
+        lds_set[desc_lds] = lds;
     }
-    hipLaunchKernelGGL(k_search_by_projection, dim3(pairs), dim3(64), lds, orbhip_ctx_stream_internal(ctx), d_q, d_desc_q, d_nq,
+    hipLaunchKernelGGL(kern, dim3(pairs), dim3(64), lds, orbhip_ctx_stream_internal(ctx), d_q, d_desc_q, d_nq,
                        max_q, d_kp, d_desc, d_u_right, d_n, max_n, frame_stride_kp, min_x, min_y, max_x, max_y, th_high,
                        check_orientation, mode, nn_ratio, cap_n, cap_q, d_train_match, d_nmatches, orbhip_ctx_status_internal(ctx));
     return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;

@@ -27,14 +27,14 @@ q = np.zeros((B, M), orbhip.PROJ_QUERY_DTYPE)
 q["u"] = kp["x"]; q["v"] = kp["y"]; q["angle"] = kp["angle"]; q["radius"] = np.float32(15.0) * sf[np.clip(kp["octave"], 0, 7)]
 q["min_level"] = kp["octave"] - 1; q["max_level"] = kp["octave"] + 1; q["has_obs"] = 1; q["ur"] = -1
 d_q = torch.from_numpy(q.view(np.uint8)).cuda()
-P = B - 1
-tm = torch.full((P, M), -1, dtype=torch.int32, device="cuda"); nm = torch.zeros((P,), dtype=torch.int32, device="cuda")
-torch.cuda.synchronize()
 out = {}
-for name, fn in (("search_by_projection", lambda: orbhip.search_by_projection_device(ctx, d_q.data_ptr(), desc_p, cnt_p, M, kp_p + M * 28, desc_p + M * 32, None, cnt_p + 4, M, M, P, (0.0, 0.0, float(W), float(H)), 100, True, tm.data_ptr(), nm.data_ptr())),
+tm = torch.full((B, M), -1, dtype=torch.int32, device="cuda"); nm = torch.zeros((B,), dtype=torch.int32, device="cuda")
+torch.cuda.synchronize()
+for P in (B - 1, 256, 1):
+  for name, fn in (("search_by_projection", lambda: orbhip.search_by_projection_device(ctx, d_q.data_ptr(), desc_p, cnt_p, M, kp_p + M * 28, desc_p + M * 32, None, cnt_p + 4, M, M, P, (0.0, 0.0, float(W), float(H)), 100, True, tm.data_ptr(), nm.data_ptr())),
                  ("search_local_map", lambda: orbhip.search_local_map_device(ctx, d_q.data_ptr(), desc_p, cnt_p, M, kp_p + M * 28, desc_p + M * 32, None, cnt_p + 4, M, M, P, (0.0, 0.0, float(W), float(H)), 100, 0.8, tm.data_ptr(), nm.data_ptr()))):
     for it in range(4):
         tm.fill_(-1); torch.cuda.synchronize()
         t0 = time.perf_counter(); fn(); ctx.synchronize(); dt = time.perf_counter() - t0
-    out[name + "_ms"] = round(dt * 1e3, 3); out[name + "_matches_per_pair"] = round(float(nm.float().mean().item()), 1)
+    out["%s_%dpairs_ms" % (name, P)] = round(dt * 1e3, 3); out[name + "_matches_per_pair"] = round(float(nm[:P].float().mean().item()), 1)
 print(json.dumps(out))
