@@ -137,7 +137,8 @@ __global__ __launch_bounds__(64) void k_search_init(const orbhip_keypoint *kpA_,
     uint16_t *cellx = reinterpret_cast<uint16_t *>(cand_key + cap0), *celly = cellx + cap0, *cpos = celly + cap0, *gidx = cpos + cap0;
     int16_t *m21 = reinterpret_cast<int16_t *>(gidx + cap0);
     uint16_t *aidx = reinterpret_cast<uint16_t *>(m21 + cap0), *cand_li = aidx + cap0;
-    int8_t *bin_of = reinterpret_cast<int8_t *>(cand_li + cap0);
+    uint16_t *bm = cand_li + cap0;                                  // [maxn] F2 index an F1 keypoint was matched to (0xFFFF = never)
+    int8_t *bin_of = reinterpret_cast<int8_t *>(bm + maxn);
     __shared__ int hist[SI_HISTO];
     __shared__ int s_keep[3];
     const int pair = blockIdx.x, lane = threadIdx.x;
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(64) void k_search_init(const orbhip_keypoint *kpA_,
         const int li = na0 + __popcll(bal & lt_mask);
         if (in && li < cap0) aidx[li] = (uint16_t)i;
         na0 += __popcll(bal);
-        if (i < n1) { m12[i] = -1; bin_of[i] = -1; }
+        if (i < n1) { m12[i] = -1; bin_of[i] = -1; bm[i] = 0xFFFFu; }
     }
     if (n0 > cap0 || na0 > cap0) { if (lane == 0) { atomicExch(status, ORBHIP_E_CAPACITY); nmatches_[pair] = 0; } return; }
     __syncthreads();
@@ -196,9 +197,15 @@ __global__ __launch_bounds__(64) void k_search_init(const orbhip_keypoint *kpA_,
     int nmatches = 0;
     const float r = (float)window;
     const float factor = 1.0f / SI_HISTO;
+    // the next F1 point's window centre and descriptor are fetched one iteration ahead
+    int i1n = na0 > 0 ? (int)aidx[0] : 0;
+    float xn = 0, yn = 0; uint4 pd0 = make_uint4(0, 0, 0, 0), pd1 = pd0;
+    if (na0 > 0) { xn = prev[2 * i1n]; yn = prev[2 * i1n + 1]; pd0 = dA[2 * i1n]; pd1 = dA[2 * i1n + 1]; }
     for (int t = 0; t < na0; t++) {
-        const int i1 = aidx[t];
-        const float x = prev[2 * i1], y = prev[2 * i1 + 1];
+        const int i1 = i1n;
+        const float x = xn, y = yn;
+        const uint4 a0 = pd0, a1 = pd1;
+        if (t + 1 < na0) { i1n = aidx[t + 1]; xn = prev[2 * i1n]; yn = prev[2 * i1n + 1]; pd0 = dA[2 * i1n]; pd1 = dA[2 * i1n + 1]; }
         int c0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, min_x), r), inv_w)); if (c0 < 0) c0 = 0;   // Frame.cc:656-674
         if (c0 >= SI_COLS) continue;
         int c1 = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, min_x), r), inv_w)); if (c1 > SI_COLS - 1) c1 = SI_COLS - 1;
@@ -226,7 +233,6 @@ __global__ __launch_bounds__(64) void k_search_init(const orbhip_keypoint *kpA_,
         if (ncand == 0) continue;                                           // vIndices2.empty(), ORBmatcher.cc:732-733
         __syncthreads();
         // phase B: one candidate per lane
-        const uint4 a0 = dA[2 * i1], a1 = dA[2 * i1 + 1];
         uint32_t lk1 = 0xFFFFFFFFu; int d2 = INT_MAX, best_li = -1;
         for (int q0 = 0; q0 < ncand; q0 += 64) {
             const int q = q0 + lane;
@@ -260,19 +266,24 @@ __global__ __launch_bounds__(64) void k_search_init(const orbhip_keypoint *kpA_,
             const int old = m21[bli];
             if (old >= 0) { m12[old] = -1; nmatches--; }                    // ORBmatcher.cc:768-772
             m12[i1] = best_idx; m21[bli] = (int16_t)i1; matched_dist[bli] = best; nmatches++;
-            if (check_ori) {                                                // ORBmatcher.cc:778-789
-                float rot = __fsub_rn(kpA[i1].angle, kpB[best_idx].angle);
-                if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
-                int bin = (int)roundf(__fmul_rn(rot, factor));
-                if (bin == SI_HISTO) bin = 0;
-                hist[bin]++; bin_of[i1] = (int8_t)bin;
-            }
+            bm[i1] = (uint16_t)best_idx;                                    // its rotation-histogram entry is made after the loop
         }
         __syncthreads();
     }
     __syncthreads();
-    // ---- rotation consistency: keep the three most populated bins (ORBmatcher.cc:792-815, 2307-2348)
+    // ---- rotation consistency: keep the three most populated bins (ORBmatcher.cc:792-815, 2307-2348).  Every F1 point
+    // that was matched at some time has one histogram entry (ORBmatcher.cc:778-789), also when it was displaced later.
     if (check_ori) {
+        for (int i1 = lane; i1 < n1; i1 += 64) {
+            const int b = bm[i1];
+            if (b == 0xFFFF) continue;
+            float rot = __fsub_rn(kpA[i1].angle, kpB[b].angle);
+            if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+            int bin = (int)roundf(__fmul_rn(rot, factor));
+            if (bin == SI_HISTO) bin = 0;
+            atomicAdd(&hist[bin], 1); bin_of[i1] = (int8_t)bin;
+        }
+        __syncthreads();
         if (lane == 0) {
             int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
             for (int i = 0; i < SI_HISTO; i++) {
@@ -315,7 +326,7 @@ extern "C" int orbhip_search_for_initialization_device(orbhip_ctx *ctx,
     int32_t *d_status = orbhip_ctx_status_internal(ctx);    // frames over capacity set ORBHIP_E_CAPACITY
     // LDS is sized from the caller's row capacity: every keypoint of a frame may be octave 0
     const int maxn = max_n < SI_MAXN ? max_n : SI_MAXN, cap0 = max_n < SI_CAP0 ? max_n : SI_CAP0;
-    const size_t lds = (size_t)cap0 * (4 * 4 + 7 * 2) + (size_t)maxn;
+    const size_t lds = (size_t)cap0 * (4 * 4 + 7 * 2) + (size_t)maxn * 3;
     static thread_local size_t lds_set = 0;
     if (lds > lds_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_init), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
