@@ -301,30 +301,36 @@ __global__ __launch_bounds__(256) void k_ba_reduce(BaBatch B, int which)
     }
 }
 
-// buildSystem, landmark side: one thread per point walks its (contiguous) edges.
+// buildSystem, landmark side: 16 lanes per point share its (contiguous) edges -- one edge per lane and trip, so the
+// Jacobians of a point's ~10 observations are evaluated side by side and their scattered Hpl writes are in flight
+// together; Hll / bl are reduced over the 16 lanes in a fixed (butterfly) order.
 // Hll (sym 6), bl, and the point's column of Hpl written into the dense K-padded panel
 // Wd[4*l + b][6*h + a] = (J_T^T w Omega J_X)[a][b].
-__global__ __launch_bounds__(128) void k_ba_build_points(BaBatch B)
+__global__ __launch_bounds__(256) void k_ba_build_points(BaBatch B)
 {
     const int g = blockIdx.y;
     const BaState &st = B.st[g];
     if (!st.active || !st.need_build) return;
     const BaGraphDev &G = B.gd[g];
-    const int l = blockIdx.x * 128 + threadIdx.x;
-    if (l >= G.n_points) return;
+    const int sub = threadIdx.x & 15;
+    const int l = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (l >= G.n_points) return;                      // whole 16-lane groups leave together
     const int *ps = B.pt_start + G.ptstart_off;
     const int e0 = ps[l], e1 = ps[l + 1];
     const double *X = B.points + ((size_t)st.cur * B.sumL + G.point_off + l) * 3;
-    double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // H (6, upper) then b (3)
     double *Wd = B.Wd + G.wd_off + (size_t)(4 * l) * G.ld;
-    for (int e = e0; e < e1; e++) {
+    for (int e = e0 + sub; e < e1; e += 16) {
         const int ge = G.edge_off + e;
         const int pi = B.edge_pose[ge];
         const int hi = B.hidx[G.pose_off + pi];
         const double *pose = B.poses + ((size_t)st.cur * B.sumP + G.pose_off + pi) * 7;
         const int stereo = B.edge_stereo[ge];
-        const int D = stereo ? 3 : 2;
         double P[3], R[9], Jx[9], Jt[18];
+#pragma unroll
+        for (int k = 6; k < 9; k++) Jx[k] = 0;
+#pragma unroll
+        for (int k = 12; k < 18; k++) Jt[k] = 0;                                     // monocular edge: third row empty
         quat_rot(pose, X, P);
         P[0] += pose[4]; P[1] += pose[5]; P[2] += pose[6];
         quat_to_R(pose, R);
@@ -334,26 +340,40 @@ __global__ __launch_bounds__(128) void k_ba_build_points(BaBatch B)
         if (!st.robust) r1 = 1.;
         else if (stereo) huber(chi2, B.delta_s, B.dsqr_s, &r0, &r1); else huber(chi2, B.delta_m, B.dsqr_m, &r0, &r1);
         const double w = B.level[ge] ? 0.0 : r1 * B.edge_is2[ge];          // level-1 edge: contributes nothing (its Hpl block is zeroed)
-        const double *es = B.err + 3 * (size_t)ge;
-        for (int d = 0; d < D; d++) {
+        const double es[3] = {B.err[3 * (size_t)ge], B.err[3 * (size_t)ge + 1], stereo ? B.err[3 * (size_t)ge + 2] : 0.0};
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
             const double j0 = Jx[3 * d], j1 = Jx[3 * d + 1], j2 = Jx[3 * d + 2];
             const double we = -w * es[d];
-            b[0] += j0 * we; b[1] += j1 * we; b[2] += j2 * we;
-            H[0] += j0 * w * j0; H[1] += j0 * w * j1; H[2] += j0 * w * j2;
-            H[3] += j1 * w * j1; H[4] += j1 * w * j2; H[5] += j2 * w * j2;
+            acc[6] += j0 * we; acc[7] += j1 * we; acc[8] += j2 * we;
+            acc[0] += j0 * w * j0; acc[1] += j0 * w * j1; acc[2] += j0 * w * j2;
+            acc[3] += j1 * w * j1; acc[4] += j1 * w * j2; acc[5] += j2 * w * j2;
         }
         if (hi >= 0) {
+#pragma unroll
             for (int bb = 0; bb < 3; bb++)
+#pragma unroll
                 for (int a = 0; a < 6; a++) {
                     double h = 0;
-                    for (int d = 0; d < D; d++) h += Jt[6 * d + a] * w * Jx[3 * d + bb];
+#pragma unroll
+                    for (int d = 0; d < 3; d++) h += Jt[6 * d + a] * w * Jx[3 * d + bb];
                     Wd[(size_t)bb * G.ld + 6 * hi + a] = h;
                 }
         }
     }
-    double *Ho = B.Hll + (size_t)(G.point_off + l) * 6, *bo = B.bl + (size_t)(G.point_off + l) * 3;
-    for (int i = 0; i < 6; i++) Ho[i] = H[i];
-    bo[0] = b[0]; bo[1] = b[1]; bo[2] = b[2];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        double v = acc[k];
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) v += __shfl_xor(v, d, 16);
+        acc[k] = v;
+    }
+    if (sub == 0) {
+        double *Ho = B.Hll + (size_t)(G.point_off + l) * 6, *bo = B.bl + (size_t)(G.point_off + l) * 3;
+#pragma unroll
+        for (int i = 0; i < 6; i++) Ho[i] = acc[i];
+        bo[0] = acc[6]; bo[1] = acc[7]; bo[2] = acc[8];
+    }
 }
 
 // buildSystem, pose side: one wave per free pose over its edges (pose-major list).
@@ -1153,7 +1173,7 @@ extern "C" int orbhip_ba_batch_solve(orbhip_ba_batch *b, const orbhip_ba_params 
         if (B.ex2) hipLaunchKernelGGL(k_ba_levels, ge, dim3(256), 0, s, B);
         hipLaunchKernelGGL(k_ba_errors, ge, dim3(256), 0, s, B, 0);
         hipLaunchKernelGGL(k_ba_reduce, dim3(G), dim3(256), 0, s, B, 0);
-        hipLaunchKernelGGL(k_ba_build_points, gp128, dim3(128), 0, s, B);
+        hipLaunchKernelGGL(k_ba_build_points, dim3((B.max_points + 15) / 16, G), dim3(256), 0, s, B);
         hipLaunchKernelGGL(k_ba_build_poses, gf, dim3(64), 0, s, B);
         hipLaunchKernelGGL(k_ba_maxdiag, dim3(G), dim3(256), 0, s, B);
         hipLaunchKernelGGL(k_ba_pretrial, dim3((G + 63) / 64), dim3(64), 0, s, B);
