@@ -805,38 +805,48 @@ __global__ __launch_bounds__(1024) void k_ba_ldlt(BaBatch B)
 
 // landmark back-substitution (block_solver.hpp:461-481) + trial update of every vertex
 // (sparse_optimizer.cpp:422-435) + computeScale partials (levenberg.cpp:187-194)
-__global__ __launch_bounds__(128) void k_ba_backsub_points(BaBatch B)
+__global__ __launch_bounds__(256) void k_ba_backsub_points(BaBatch B)
 {
+    // 16 lanes per point: one observing pose per lane and trip (the point's Hpl blocks are scattered 48-byte runs of Wd)
     const int g = blockIdx.y;
     const BaState &st = B.st[g];
     if (!st.active) return;
     const BaGraphDev &G = B.gd[g];
-    const int l = blockIdx.x * 128 + threadIdx.x;
+    const int sub = threadIdx.x & 15;
+    const int l = blockIdx.x * 16 + (threadIdx.x >> 4);
     if (l >= G.n_points) return;
     const int *ps = B.pt_start + G.ptstart_off;
     const size_t gl = (size_t)G.point_off + l;
     double *xl = B.xl + gl * 3;
     const double *Xc = B.points + ((size_t)st.cur * B.sumL + gl) * 3;
     double *Xn = B.points + ((size_t)(st.cur ^ 1) * B.sumL + gl) * 3;
-    if (ps[l + 1] == ps[l]) { Xn[0] = Xc[0]; Xn[1] = Xc[1]; Xn[2] = Xc[2]; B.scale_pt[gl] = 0; return; }
+    if (ps[l + 1] == ps[l]) { if (sub == 0) { Xn[0] = Xc[0]; Xn[1] = Xc[1]; Xn[2] = Xc[2]; B.scale_pt[gl] = 0; } return; }
     const double *bl = B.bl + gl * 3;
+    double x0 = xl[0], x1 = xl[1], x2 = xl[2];                     // a failed solve keeps the previous increment
     if (st.ok) {
-        double c0 = bl[0], c1 = bl[1], c2 = bl[2];
+        double c0 = 0, c1 = 0, c2 = 0;
         const double *Wd = B.Wd + G.wd_off + (size_t)(4 * l) * G.ld;
-        for (int e = ps[l]; e < ps[l + 1]; e++) {
+        for (int e = ps[l] + sub; e < ps[l + 1]; e += 16) {
             const int h = B.hidx[G.pose_off + B.edge_pose[G.edge_off + e]];
             if (h < 0) continue;
             const double *xp = B.xp + (size_t)(G.free_off + h) * 6;
             const double *w = Wd + 6 * h;
+#pragma unroll
             for (int a = 0; a < 6; a++) { c0 -= w[a] * xp[a]; c1 -= w[G.ld + a] * xp[a]; c2 -= w[2 * (size_t)G.ld + a] * xp[a]; }
         }
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) { c0 += __shfl_xor(c0, d, 16); c1 += __shfl_xor(c1, d, 16); c2 += __shfl_xor(c2, d, 16); }
+        c0 += bl[0]; c1 += bl[1]; c2 += bl[2];
         const double *Di = B.Dinv + gl * 6;
-        xl[0] = Di[0] * c0 + Di[1] * c1 + Di[2] * c2;
-        xl[1] = Di[1] * c0 + Di[3] * c1 + Di[4] * c2;
-        xl[2] = Di[2] * c0 + Di[4] * c1 + Di[5] * c2;
+        x0 = Di[0] * c0 + Di[1] * c1 + Di[2] * c2;
+        x1 = Di[1] * c0 + Di[3] * c1 + Di[4] * c2;
+        x2 = Di[2] * c0 + Di[4] * c1 + Di[5] * c2;
     }
-    Xn[0] = Xc[0] + xl[0]; Xn[1] = Xc[1] + xl[1]; Xn[2] = Xc[2] + xl[2];
-    B.scale_pt[gl] = xl[0] * (st.lambda * xl[0] + bl[0]) + xl[1] * (st.lambda * xl[1] + bl[1]) + xl[2] * (st.lambda * xl[2] + bl[2]);
+    if (sub == 0) {
+        xl[0] = x0; xl[1] = x1; xl[2] = x2;
+        Xn[0] = Xc[0] + x0; Xn[1] = Xc[1] + x1; Xn[2] = Xc[2] + x2;
+        B.scale_pt[gl] = x0 * (st.lambda * x0 + bl[0]) + x1 * (st.lambda * x1 + bl[1]) + x2 * (st.lambda * x2 + bl[2]);
+    }
 }
 
 __global__ __launch_bounds__(64) void k_ba_update_poses(BaBatch B)
@@ -1184,7 +1194,7 @@ extern "C" int orbhip_ba_batch_solve(orbhip_ba_batch *b, const orbhip_ba_params 
         hipLaunchKernelGGL(k_ba_schur_finish, dim3((B.max_ld * B.max_ld + 255) / 256, G), dim3(256), 0, s, B);
         hipLaunchKernelGGL(k_ba_bschur, gf, dim3(64), 0, s, B);
         hipLaunchKernelGGL(k_ba_ldlt, dim3(G), dim3(1024), ldlt_lds, s, B);
-        hipLaunchKernelGGL(k_ba_backsub_points, gp128, dim3(128), 0, s, B);
+        hipLaunchKernelGGL(k_ba_backsub_points, dim3((B.max_points + 15) / 16, G), dim3(256), 0, s, B);
         hipLaunchKernelGGL(k_ba_update_poses, dim3((max_poses + 63) / 64, G), dim3(64), 0, s, B);
         hipLaunchKernelGGL(k_ba_errors, ge, dim3(256), 0, s, B, 1);
         hipLaunchKernelGGL(k_ba_reduce, dim3(G), dim3(256), 0, s, B, 1);
