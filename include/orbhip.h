@@ -214,6 +214,14 @@ int orbhip_search_local_map_device(orbhip_ctx *ctx, const orbhip_proj_query *d_q
                                    float max_y, int th_high, float nn_ratio, int32_t *d_train_match,
                                    int32_t *d_nmatches);
 
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:327-403), batched over map points: point p
+ * has d_n[p] observing descriptors at d_desc + p*max_n*32 (the loop of :347-361 packs them, left then right index);
+ * d_best_idx[p] = BestIdx: the descriptor with the least median Hamming distance to all of them (median = sorted
+ * row [int(0.5*(n-1))], first minimum wins).  d_best_desc (may be NULL) receives mDescriptor, [points][32].
+ * max_n <= 256.  All pointers DEVICE. */
+int orbhip_distinctive_descriptors_device(orbhip_ctx *ctx, const uint8_t *d_desc, const int32_t *d_n, int points, int max_n,
+                                          int32_t *d_best_idx, uint8_t *d_best_desc);
+
 /* Frame::ComputeStereoMatches (src/Frame.cc:802-980), batched: rectified-stereo association
  * of the keypoints the LEFT and RIGHT extractor produced in their latest extract call (frame f with frame f;
  * both called with lapping {0,0} as the stereo constructor does, src/Frame.cc:109-110).  Per left keypoint:

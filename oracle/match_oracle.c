@@ -279,3 +279,20 @@ int orc_search_by_projection_map(const orc_proj_query *q, const uint8_t *desc_q,
     free(cand); grid_free(&g);
     return nmatches;
 }
+
+static int cmp_int(const void *a, const void *b) { return *(const int *)a - *(const int *)b; }
+/* MapPoint.cc:366-397 */
+int orc_distinctive_descriptor(const uint8_t *desc, int n)
+{
+    if (n <= 0) return 0;
+    int *row = (int *)malloc(sizeof(int) * (size_t)n);
+    int best_median = INT_MAX, best_idx = 0;
+    for (int i = 0; i < n; i++) {
+        for (int j = 0; j < n; j++) row[j] = i == j ? 0 : orc_descriptor_distance(desc + 32 * (size_t)i, desc + 32 * (size_t)j);
+        qsort(row, (size_t)n, sizeof(int), cmp_int);
+        const int median = row[(int)(0.5 * (n - 1))];
+        if (median < best_median) { best_median = median; best_idx = i; }
+    }
+    free(row);
+    return best_idx;
+}

@@ -53,6 +53,10 @@ int orc_search_by_projection_map(const orc_proj_query *q, const uint8_t *desc_q,
                                  const orc_keypoint *kp, const uint8_t *desc, const float *u_right, int n,
                                  float min_x, float min_y, float max_x, float max_y,
                                  int th_high, float nn_ratio, int32_t *train_match);
+/* MapPoint::ComputeDistinctiveDescriptors (/root/reference/src/MapPoint.cc:327-403): among the n
+ * descriptors that observe a map point, the one with the least median Hamming distance to all of them
+ * (median = sorted row [int(0.5*(n-1))], self distance 0 included; first minimum wins).  Returns BestIdx (0 if n<=0). */
+int orc_distinctive_descriptor(const uint8_t *desc, int n);
 #ifdef __cplusplus
 }
 #endif

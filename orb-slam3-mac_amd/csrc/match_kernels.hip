@@ -635,3 +635,58 @@ extern "C" int orbhip_search_local_map_device(orbhip_ctx *ctx, const orbhip_proj
     return sbp_launch(ctx, d_q, d_desc_q, d_nq, max_q, d_kp, d_desc, d_u_right, d_n, max_n, frame_stride_kp, pairs, min_x, min_y,
                       max_x, max_y, th_high, 0, 1, nn_ratio, d_train_match, d_nmatches);
 }
+
+// ---------------------------------------------------------------------------- N3: distinctive descriptor
+// MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:327-403), batched over map points: one wave per point.
+// The n x n distance matrix lives in LDS (u16); row i's median = sorted row [int(0.5*(n-1))] is found without
+// sorting as the smallest v with #{j : D[i][j] <= v} >= k+1 (binary search over the 257 possible distances).
+__global__ __launch_bounds__(64) void k_distinctive(const uint8_t *desc_, const int32_t *n_, int max_n, int32_t *best_idx, uint8_t *best_desc)
+{
+    extern __shared__ uint16_t dd[];               // [n][n]
+    __shared__ uint32_t s_best;
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int n = min(n_[p], max_n);
+    const uint4 *D = reinterpret_cast<const uint4 *>(desc_ + (size_t)p * max_n * 32);
+    if (lane == 0) s_best = 0xFFFFFFFFu;
+    if (n <= 0) { if (lane == 0) best_idx[p] = 0; return; }
+    for (int i = lane; i < n; i += 64) {
+        const uint4 a0 = D[2 * i], a1 = D[2 * i + 1];
+        for (int j = i + 1; j < n; j++) {                                   // MapPoint.cc:369-378
+            const int d = hamming256(a0, a1, D[2 * j], D[2 * j + 1]);
+            dd[i * n + j] = (uint16_t)d; dd[j * n + i] = (uint16_t)d;
+        }
+        dd[i * n + i] = 0;
+    }
+    __syncthreads();
+    const int k = (int)(0.5 * (n - 1));                                     // MapPoint.cc:387
+    for (int i = lane; i < n; i += 64) {
+        int lo = 0, hi = 256;                                               // smallest v with count(<= v) >= k+1
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            int c = 0;
+            for (int j = 0; j < n; j++) c += dd[i * n + j] <= mid;
+            if (c >= k + 1) hi = mid; else lo = mid + 1;
+        }
+        atomicMin(&s_best, ((uint32_t)lo << 16) | (uint32_t)i);            // least median, first index on ties (:389-393)
+    }
+    __syncthreads();
+    const int bi = (int)(s_best & 0xFFFFu);
+    if (lane == 0) best_idx[p] = bi;
+    if (best_desc && lane < 8) reinterpret_cast<uint32_t *>(best_desc + (size_t)p * 32)[lane] = reinterpret_cast<const uint32_t *>(D + 2 * bi)[lane];
+}
+
+extern "C" int orbhip_distinctive_descriptors_device(orbhip_ctx *ctx, const uint8_t *d_desc, const int32_t *d_n, int points, int max_n,
+                                                     int32_t *d_best_idx, uint8_t *d_best_desc)
+{
+    if (!ctx || !d_desc || !d_n || points <= 0 || max_n <= 0 || max_n > 256 || !d_best_idx) return ORBHIP_E_BADARG;
+    if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
+    const size_t lds = sizeof(uint16_t) * (size_t)max_n * max_n;
+    static thread_local size_t lds_set = 0;
+    if (lds > lds_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_distinctive), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return ORBHIP_E_HIP;
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(k_distinctive, dim3(points), dim3(64), lds, orbhip_ctx_stream_internal(ctx), d_desc, d_n, max_n, d_best_idx, d_best_desc);
+    return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
+}

@@ -430,3 +430,12 @@ def compute_stereo_matches_device(ext_left, ext_right, mb, mbf, d_u_right, d_dep
     """Frame::ComputeStereoMatches on the latest results of two extractors; device addresses (ints)."""
     _chk(lib.orbhip_compute_stereo_matches_device(ext_left.h, ext_right.h, mb, mbf, d_u_right, d_depth, d_n_matches),
          "orbhip_compute_stereo_matches_device")
+
+
+lib.orbhip_distinctive_descriptors_device.argtypes = [vp, vp, vp, ci, ci, vp, vp]
+
+
+def distinctive_descriptors_device(ctx, d_desc, d_n, points, max_n, d_best_idx, d_best_desc=None):
+    """MapPoint::ComputeDistinctiveDescriptors, batched over map points; device addresses (ints)."""
+    _chk(lib.orbhip_distinctive_descriptors_device(ctx.h, d_desc, d_n, points, max_n, d_best_idx, d_best_desc),
+         "orbhip_distinctive_descriptors_device")

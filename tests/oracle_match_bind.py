@@ -12,6 +12,8 @@ lib.orc_search_by_projection.argtypes = [vp, vp, ci, vp, vp, vp, ci, cf, cf, cf,
 lib.orc_search_by_projection.restype = ci
 lib.orc_search_by_projection_map.argtypes = [vp, vp, ci, vp, vp, vp, ci, cf, cf, cf, cf, ci, cf, vp]
 lib.orc_search_by_projection_map.restype = ci
+lib.orc_distinctive_descriptor.argtypes = [vp, ci]
+lib.orc_distinctive_descriptor.restype = ci
 
 PROJ_QUERY_DTYPE = np.dtype([("u", np.float32), ("v", np.float32), ("radius", np.float32), ("ur", np.float32),
                              ("angle", np.float32), ("min_level", np.int32), ("max_level", np.int32), ("has_obs", np.int32)])
@@ -85,3 +87,8 @@ def search_by_projection_map(q, dq, kp, d, u_right, bounds, train_match, th_high
                                          None if ur is None else ur.ctypes.data, len(kp), bounds[0], bounds[1], bounds[2],
                                          bounds[3], th_high, nn_ratio, tm.ctypes.data)
     return n, tm[:len(kp)]
+
+
+def distinctive_descriptor(desc):
+    desc = np.ascontiguousarray(desc, np.uint8)
+    return lib.orc_distinctive_descriptor(desc.ctypes.data, len(desc))

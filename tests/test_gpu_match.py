@@ -303,3 +303,33 @@ def test_search_local_map_parity(gpu_ctx, stereo, ratio):
         np.testing.assert_array_equal(got[p][1], tm_ref)
         tot += n_ref
     assert tot > 300
+
+
+def test_distinctive_descriptors_parity(gpu_ctx):
+    """MapPoint::ComputeDistinctiveDescriptors batched: ragged observation counts incl. 0, 1, 2, duplicates, 256."""
+    import torch
+    import orbhip
+    import oracle_match_bind as om
+    rng = np.random.default_rng(17)
+    counts = [0, 1, 2, 3, 5, 10, 33, 64, 65, 100, 200, 256] + list(rng.integers(1, 40, 200))
+    P, M = len(counts), 256
+    desc = np.zeros((P, M, 32), np.uint8)
+    for p, n in enumerate(counts):
+        if n == 0:
+            continue
+        base = rng.integers(0, 256, (1, 32), dtype=np.uint8)
+        d = np.repeat(base, n, 0) ^ (rng.integers(0, 256, (n, 32), dtype=np.uint8) & rng.integers(0, 256, (n, 32), dtype=np.uint8) & rng.integers(0, 256, (n, 32), dtype=np.uint8))
+        if n > 3:
+            d[n - 1] = d[0]
+        desc[p, :n] = d
+    d_desc = torch.from_numpy(desc).cuda(); d_n = torch.tensor(counts, dtype=torch.int32, device="cuda")
+    bi = torch.full((P,), -9, dtype=torch.int32, device="cuda"); bd = torch.zeros((P, 32), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    orbhip.distinctive_descriptors_device(gpu_ctx, d_desc.data_ptr(), d_n.data_ptr(), P, M, bi.data_ptr(), bd.data_ptr())
+    gpu_ctx.synchronize()
+    bi = bi.cpu().numpy(); bd = bd.cpu().numpy()
+    for p, n in enumerate(counts):
+        ref = om.distinctive_descriptor(desc[p, :n])
+        assert bi[p] == ref, (p, n, bi[p], ref)
+        if n > 0:
+            assert bd[p].tobytes() == desc[p, ref].tobytes()

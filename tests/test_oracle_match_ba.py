@@ -392,3 +392,19 @@ def test_ba_merge_variant_oracle():
     assert out_m.sum() >= 0.03 * len(out_m)
     gbad = synth_ba.make_graph(n_kf=8, n_pts=120, obs=5, seed=43, outlier_frac=0.9)
     assert ob.solve(gbad)[4]["discarded"] == 1 and ob.solve(gbad, ob.merge_params())[4]["discarded"] == 0
+
+
+def test_distinctive_descriptor_oracle_against_numpy():
+    import oracle_match_bind as om
+    rng = np.random.default_rng(9)
+    for n in (1, 2, 3, 7, 20, 64, 130):
+        base = rng.integers(0, 256, (1, 32), dtype=np.uint8)
+        d = np.repeat(base, n, 0)
+        flips = rng.integers(0, 256, (n, 32), dtype=np.uint8) & rng.integers(0, 256, (n, 32), dtype=np.uint8) & rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        d ^= flips
+        if n > 3:
+            d[n // 2] = d[1]                                       # duplicates: ties between medians
+        D = np.unpackbits(d[:, None, :] ^ d[None, :, :], axis=2).sum(2)
+        med = np.sort(D, axis=1)[:, int(0.5 * (n - 1))]
+        assert om.distinctive_descriptor(d) == int(np.argmin(med))
+    assert om.distinctive_descriptor(np.zeros((0, 32), np.uint8)) == 0
