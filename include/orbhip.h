@@ -222,6 +222,20 @@ int orbhip_search_local_map_device(orbhip_ctx *ctx, const orbhip_proj_query *d_q
 int orbhip_distinctive_descriptors_device(orbhip_ctx *ctx, const uint8_t *d_desc, const int32_t *d_n, int points, int max_n,
                                           int32_t *d_best_idx, uint8_t *d_best_desc);
 
+/* The per-feature half of Frame::ComputeBoW / KeyFrame::ComputeBoW (src/Frame.cc:729-736 -> DBoW2
+ * TemplatedVocabulary::transform, Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1139-1260): for every
+ * descriptor the tree descent of :1218-1260 -- at each level the child with the smallest Hamming distance, first minimum
+ * wins, until a leaf -- giving its word id, the leaf's weight and the node passed at level L - levelsup (0 = root when
+ * that level is <= 0; ORB-SLAM3 uses levelsup = 4).  Building BowVector (addWeight in feature order + L1 normalise,
+ * :1165-1210) and FeatureVector from these triples stays on the host (std::map containers).
+ * Vocabulary, resident on the device as a flat tree: node i has children d_child_ids[d_child_start[i] ..
+ * d_child_start[i+1]) (none = leaf; node 0 = root), 32-byte descriptors d_node_desc[i], d_node_word[i], d_node_weight[i].
+ * Frame f reads d_n[f] descriptors at d_desc + f*frame_stride*32; outputs are [frames][max_n].  All pointers DEVICE. */
+int orbhip_bow_transform_device(orbhip_ctx *ctx, const uint8_t *d_desc, const int32_t *d_n, int frames, int max_n,
+                                size_t frame_stride, const uint8_t *d_node_desc, const int32_t *d_child_start,
+                                const int32_t *d_child_ids, const int32_t *d_node_word, const double *d_node_weight,
+                                int L, int levelsup, int32_t *d_word_id, double *d_weight, int32_t *d_nid);
+
 /* Frame::ComputeStereoMatches (src/Frame.cc:802-980), batched: rectified-stereo association
  * of the keypoints the LEFT and RIGHT extractor produced in their latest extract call (frame f with frame f;
  * both called with lapping {0,0} as the stereo constructor does, src/Frame.cc:109-110).  Per left keypoint:

@@ -296,3 +296,27 @@ int orc_distinctive_descriptor(const uint8_t *desc, int n)
     free(row);
     return best_idx;
 }
+
+/* TemplatedVocabulary.h:1218-1260 */
+void orc_bow_transform(const uint8_t *f, const uint8_t *node_desc, const int32_t *child_start, const int32_t *child_ids,
+                       const int32_t *node_word, const double *node_weight, int L, int levelsup,
+                       int32_t *word_id, double *weight, int32_t *nid)
+{
+    const int nid_level = L - levelsup;
+    if (nid_level <= 0 && nid) *nid = 0;
+    int final_id = 0, current_level = 0;
+    do {
+        ++current_level;
+        const int c0 = child_start[final_id], c1 = child_start[final_id + 1];
+        final_id = child_ids[c0];
+        double best_d = orc_descriptor_distance(f, node_desc + 32 * (size_t)final_id);
+        for (int c = c0 + 1; c < c1; c++) {
+            const int id = child_ids[c];
+            const double d = orc_descriptor_distance(f, node_desc + 32 * (size_t)id);
+            if (d < best_d) { best_d = d; final_id = id; }
+        }
+        if (nid && current_level == nid_level) *nid = final_id;
+    } while (child_start[final_id + 1] > child_start[final_id]);
+    *word_id = node_word[final_id];
+    *weight = node_weight[final_id];
+}

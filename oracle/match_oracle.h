@@ -57,6 +57,16 @@ int orc_search_by_projection_map(const orc_proj_query *q, const uint8_t *desc_q,
  * descriptors that observe a map point, the one with the least median Hamming distance to all of them
  * (median = sorted row [int(0.5*(n-1))], self distance 0 included; first minimum wins).  Returns BestIdx (0 if n<=0). */
 int orc_distinctive_descriptor(const uint8_t *desc, int n);
+/* DBoW2 TemplatedVocabulary<FORB::TDescriptor, FORB>::transform(feature, word_id, weight, nid, levelsup)
+ * (/root/reference/Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1218-1260; called per feature by Frame::ComputeBoW,
+ * /root/reference/src/Frame.cc:729-736, with levelsup = 4): descend the vocabulary tree from the root, at every level
+ * to the child with the smallest Hamming distance (first minimum wins), until a leaf; nid = the node passed at level
+ * L - levelsup (0 = root when that level is <= 0).  The tree is given flat: node i has children
+ * child_ids[child_start[i] .. child_start[i+1]) (none = leaf), 32-byte descriptors, word_id and weight per node.
+ * The reference's ORBvoc file is absent from its tree (.MISSING_LARGE_BLOBS): tests use synthetic vocabularies. */
+void orc_bow_transform(const uint8_t *feature32, const uint8_t *node_desc, const int32_t *child_start, const int32_t *child_ids,
+                       const int32_t *node_word, const double *node_weight, int L, int levelsup,
+                       int32_t *word_id, double *weight, int32_t *nid);
 #ifdef __cplusplus
 }
 #endif

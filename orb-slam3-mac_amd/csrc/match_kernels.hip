@@ -690,3 +690,49 @@ extern "C" int orbhip_distinctive_descriptors_device(orbhip_ctx *ctx, const uint
     hipLaunchKernelGGL(k_distinctive, dim3(points), dim3(64), lds, orbhip_ctx_stream_internal(ctx), d_desc, d_n, max_n, d_best_idx, d_best_desc);
     return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
 }
+
+// ---------------------------------------------------------------------------- N3: BoW tree descent
+// DBoW2 TemplatedVocabulary::transform(feature, word_id, weight, nid, levelsup) (TemplatedVocabulary.h:1218-1260),
+// one thread per feature; the vocabulary is a flat CSR tree resident in HBM (node descriptors 32 B each).
+__global__ __launch_bounds__(256) void k_bow_transform(const uint8_t *desc, const int32_t *n_, int frames, int max_n, size_t frame_stride,
+                                                       const uint8_t *node_desc, const int32_t *child_start, const int32_t *child_ids,
+                                                       const int32_t *node_word, const double *node_weight, int L, int levelsup,
+                                                       int32_t *word_id, double *weight, int32_t *nid)
+{
+    const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_[f] || i >= max_n) return;
+    const uint4 *a = reinterpret_cast<const uint4 *>(desc + ((size_t)f * frame_stride + i) * 32);
+    const uint4 a0 = a[0], a1 = a[1];
+    const uint4 *nd = reinterpret_cast<const uint4 *>(node_desc);
+    const int nid_level = L - levelsup;
+    int out_nid = 0, final_id = 0, level = 0;
+    int c0 = child_start[0], c1 = child_start[1];
+    do {
+        ++level;
+        final_id = child_ids[c0];
+        int best = hamming256(a0, a1, nd[2 * final_id], nd[2 * final_id + 1]);
+        for (int c = c0 + 1; c < c1; c++) {
+            const int id = child_ids[c];
+            const int d = hamming256(a0, a1, nd[2 * id], nd[2 * id + 1]);
+            if (d < best) { best = d; final_id = id; }
+        }
+        if (level == nid_level) out_nid = final_id;
+        c0 = child_start[final_id]; c1 = child_start[final_id + 1];
+    } while (c1 > c0);
+    const size_t o = (size_t)f * max_n + i;
+    word_id[o] = node_word[final_id]; weight[o] = node_weight[final_id]; nid[o] = out_nid;
+}
+
+extern "C" int orbhip_bow_transform_device(orbhip_ctx *ctx, const uint8_t *d_desc, const int32_t *d_n, int frames, int max_n,
+                                           size_t frame_stride, const uint8_t *d_node_desc, const int32_t *d_child_start,
+                                           const int32_t *d_child_ids, const int32_t *d_node_word, const double *d_node_weight,
+                                           int L, int levelsup, int32_t *d_word_id, double *d_weight, int32_t *d_nid)
+{
+    if (!ctx || !d_desc || !d_n || frames <= 0 || max_n <= 0 || !d_node_desc || !d_child_start || !d_child_ids || !d_node_word ||
+        !d_node_weight || L <= 0 || !d_word_id || !d_weight || !d_nid) return ORBHIP_E_BADARG;
+    if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
+    hipLaunchKernelGGL(k_bow_transform, dim3((max_n + 255) / 256, frames), dim3(256), 0, orbhip_ctx_stream_internal(ctx), d_desc, d_n,
+                       frames, max_n, frame_stride, d_node_desc, d_child_start, d_child_ids, d_node_word, d_node_weight, L, levelsup,
+                       d_word_id, d_weight, d_nid);
+    return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
+}

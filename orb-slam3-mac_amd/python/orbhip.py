@@ -439,3 +439,12 @@ def distinctive_descriptors_device(ctx, d_desc, d_n, points, max_n, d_best_idx, 
     """MapPoint::ComputeDistinctiveDescriptors, batched over map points; device addresses (ints)."""
     _chk(lib.orbhip_distinctive_descriptors_device(ctx.h, d_desc, d_n, points, max_n, d_best_idx, d_best_desc),
          "orbhip_distinctive_descriptors_device")
+
+
+lib.orbhip_bow_transform_device.argtypes = [vp, vp, vp, ci, ci, sz, vp, vp, vp, vp, vp, ci, ci, vp, vp, vp]
+
+
+def bow_transform_device(ctx, d_desc, d_n, frames, max_n, frame_stride, voc, L, levelsup, d_word_id, d_weight, d_nid):
+    """DBoW2 per-feature tree descent; voc = (d_node_desc, d_child_start, d_child_ids, d_node_word, d_node_weight)."""
+    _chk(lib.orbhip_bow_transform_device(ctx.h, d_desc, d_n, frames, max_n, frame_stride, voc[0], voc[1], voc[2], voc[3], voc[4],
+                                         L, levelsup, d_word_id, d_weight, d_nid), "orbhip_bow_transform_device")

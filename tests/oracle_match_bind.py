@@ -14,6 +14,8 @@ lib.orc_search_by_projection_map.argtypes = [vp, vp, ci, vp, vp, vp, ci, cf, cf,
 lib.orc_search_by_projection_map.restype = ci
 lib.orc_distinctive_descriptor.argtypes = [vp, ci]
 lib.orc_distinctive_descriptor.restype = ci
+lib.orc_bow_transform.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, vp, vp, vp]
+lib.orc_bow_transform.restype = None
 
 PROJ_QUERY_DTYPE = np.dtype([("u", np.float32), ("v", np.float32), ("radius", np.float32), ("ur", np.float32),
                              ("angle", np.float32), ("min_level", np.int32), ("max_level", np.int32), ("has_obs", np.int32)])
@@ -92,3 +94,42 @@ def search_by_projection_map(q, dq, kp, d, u_right, bounds, train_match, th_high
 def distinctive_descriptor(desc):
     desc = np.ascontiguousarray(desc, np.uint8)
     return lib.orc_distinctive_descriptor(desc.ctypes.data, len(desc))
+
+
+def make_vocabulary(rng, k, L, ragged=False):
+    """Synthetic DBoW2-style tree (flat CSR): k children per node, L levels below the root; ragged = some inner nodes
+    get fewer children and some branches end early (leaves at different depths)."""
+    desc = [np.zeros(32, np.uint8)]; children = [[]]; depth = [0]
+    frontier = [0]
+    for lev in range(1, L + 1):
+        nxt = []
+        for parent in frontier:
+            nk = k if not ragged else int(rng.integers(2, k + 1))
+            if ragged and lev > 1 and rng.random() < 0.15:
+                continue                                          # this node stays a leaf
+            for _ in range(nk):
+                nid = len(desc)
+                d = desc[parent] ^ rng.integers(0, 256, 32, dtype=np.uint8) if lev == 1 else desc[parent] ^ (rng.integers(0, 256, 32, dtype=np.uint8) & rng.integers(0, 256, 32, dtype=np.uint8) & rng.integers(0, 256, 32, dtype=np.uint8))
+                desc.append(d.astype(np.uint8)); children.append([]); depth.append(lev)
+                children[parent].append(nid); nxt.append(nid)
+        frontier = nxt
+    n = len(desc)
+    child_start = np.zeros(n + 1, np.int32); child_ids = []
+    for i in range(n):
+        child_ids += children[i]; child_start[i + 1] = len(child_ids)
+    word = np.full(n, -1, np.int32); w = np.zeros(n, np.float64); nw = 0
+    for i in range(n):
+        if not children[i]:
+            word[i] = nw; nw += 1; w[i] = float(rng.uniform(0.1, 9.0))
+    return dict(node_desc=np.stack(desc), child_start=child_start, child_ids=np.array(child_ids, np.int32), node_word=word,
+                node_weight=w, L=L, n_words=nw)
+
+
+def bow_transform(feature, voc, levelsup):
+    f = np.ascontiguousarray(feature, np.uint8)
+    wid, nid = C.c_int32(), C.c_int32(); w = C.c_double()
+    nd = np.ascontiguousarray(voc["node_desc"], np.uint8)
+    lib.orc_bow_transform(f.ctypes.data, nd.ctypes.data, voc["child_start"].ctypes.data, voc["child_ids"].ctypes.data,
+                          voc["node_word"].ctypes.data, voc["node_weight"].ctypes.data, voc["L"], levelsup,
+                          C.byref(wid), C.byref(w), C.byref(nid))
+    return wid.value, w.value, nid.value

@@ -333,3 +333,32 @@ def test_distinctive_descriptors_parity(gpu_ctx):
         assert bi[p] == ref, (p, n, bi[p], ref)
         if n > 0:
             assert bd[p].tobytes() == desc[p, ref].tobytes()
+
+
+def test_bow_transform_parity(gpu_ctx):
+    """Per-feature DBoW2 tree descent on synthetic vocabularies (k=10/L=4 regular; ragged tree), ragged frame sizes."""
+    import torch
+    import orbhip
+    import oracle_match_bind as om
+    rng = np.random.default_rng(29)
+    for k, L, ragged, levelsup in ((10, 4, False, 2), (5, 5, True, 4), (10, 3, False, 4)):
+        voc = om.make_vocabulary(rng, k, L, ragged)
+        counts = [0, 1, 300, 777]
+        F, M = len(counts), 800
+        desc = np.zeros((F, M, 32), np.uint8)
+        for f, n in enumerate(counts):
+            leaves = rng.integers(1, len(voc["node_desc"]), n)
+            desc[f, :n] = voc["node_desc"][leaves] ^ (rng.integers(0, 256, (n, 32), dtype=np.uint8) & rng.integers(0, 256, (n, 32), dtype=np.uint8))
+        dv = [torch.from_numpy(np.ascontiguousarray(voc[key])).cuda() for key in ("node_desc", "child_start", "child_ids", "node_word", "node_weight")]
+        d_desc = torch.from_numpy(desc).cuda(); d_n = torch.tensor(counts, dtype=torch.int32, device="cuda")
+        wid = torch.full((F, M), -9, dtype=torch.int32, device="cuda"); w = torch.zeros((F, M), dtype=torch.float64, device="cuda")
+        nid = torch.full((F, M), -9, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        orbhip.bow_transform_device(gpu_ctx, d_desc.data_ptr(), d_n.data_ptr(), F, M, M, [t.data_ptr() for t in dv], L, levelsup,
+                                    wid.data_ptr(), w.data_ptr(), nid.data_ptr())
+        gpu_ctx.synchronize()
+        wid, w, nid = wid.cpu().numpy(), w.cpu().numpy(), nid.cpu().numpy()
+        for f, n in enumerate(counts):
+            for i in range(0, n, 7):
+                assert (int(wid[f, i]), float(w[f, i]), int(nid[f, i])) == om.bow_transform(desc[f, i], voc, levelsup)
+            assert (wid[f, n:] == -9).all()

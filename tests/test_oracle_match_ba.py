@@ -408,3 +408,26 @@ def test_distinctive_descriptor_oracle_against_numpy():
         med = np.sort(D, axis=1)[:, int(0.5 * (n - 1))]
         assert om.distinctive_descriptor(d) == int(np.argmin(med))
     assert om.distinctive_descriptor(np.zeros((0, 32), np.uint8)) == 0
+
+
+def test_bow_transform_oracle_against_python():
+    """DBoW2 tree descent restated: greedy nearest child per level, first minimum wins, nid at level L - levelsup."""
+    import oracle_match_bind as om
+    rng = np.random.default_rng(23)
+    for k, L, ragged in ((10, 3, False), (4, 5, True), (3, 2, False)):
+        voc = om.make_vocabulary(rng, k, L, ragged)
+        for levelsup in (0, 1, L - 1, L, L + 2):
+            for _ in range(40):
+                leaf = int(rng.integers(1, len(voc["node_desc"])))
+                f = voc["node_desc"][leaf] ^ (rng.integers(0, 256, 32, dtype=np.uint8) & rng.integers(0, 256, 32, dtype=np.uint8))
+                node, level, nid = 0, 0, 0
+                nid_level = L - levelsup
+                while voc["child_start"][node + 1] > voc["child_start"][node]:
+                    level += 1
+                    ch = voc["child_ids"][voc["child_start"][node]:voc["child_start"][node + 1]]
+                    dist = [int(np.unpackbits(f ^ voc["node_desc"][c]).sum()) for c in ch]
+                    node = int(ch[int(np.argmin(dist))])
+                    if level == nid_level:
+                        nid = node
+                got = om.bow_transform(f, voc, levelsup)
+                assert got == (int(voc["node_word"][node]), float(voc["node_weight"][node]), nid)
