@@ -265,7 +265,10 @@ typedef struct {
     const double *edge_obs;     /* [n_edges][3]  u,v,(ur; unused for mono) */
     const double *edge_inv_sigma2; /* [n_edges]  mvInvLevelSigma2[octave] */
     const uint8_t *edge_stereo; /* [n_edges] 0 = EdgeSE3ProjectXYZ, 1 = EdgeStereoSE3ProjectXYZ */
-    double fx, fy, cx, cy, bf;  /* Pinhole intrinsics (Pinhole.cpp:41-47) + stereo baseline*fx */
+    double fx, fy, cx, cy, bf;  /* intrinsics (Pinhole.cpp:41-47) + stereo baseline*fx */
+    int32_t camera_model;       /* 0 = Pinhole; 1 = KannalaBrandt8 for the monocular edges (src/CameraModels/
+                                   KannalaBrandt8.cpp:52-69 project, :166-195 projectJac) */
+    double kb[4];               /* k1..k4 (mvParameters[4..7]) when camera_model == 1 */
 } orbhip_ba_graph;
 
 typedef struct {
@@ -343,11 +346,13 @@ int orbhip_mfma_f64_peak_tflops(orbhip_ctx *ctx, double *tflops_out);
  * (mvInvLevelSigma2[octave]), d_n_edges [f].  d_pose [f][7] = (qx,qy,qz,qw,tx,ty,tz) of Tcw, in/out
  * (untouched when n < 3, :1040-1041).  d_outlier [f][max_edges] = pFrame->mvbOutlier.  d_n_inliers [f] = the
  * return value nInitialCorrespondences - nBad.  d_stats may be NULL, else [f][4] = rounds, LM iterations,
- * LM trials, nBad.  max_edges <= 8192.  All pointers DEVICE; asynchronous on the context's stream. */
+ * LM trials, nBad.  max_edges <= 8192.  kb8_k: HOST pointer to k1..k4 when pFrame->mpCamera is a KannalaBrandt8
+ * (monocular edges then project through src/CameraModels/KannalaBrandt8.cpp:52-69,166-195), NULL = Pinhole.
+ * All other pointers DEVICE; asynchronous on the context's stream. */
 int orbhip_pose_optimization_device(orbhip_ctx *ctx, const double *d_Xw, const double *d_obs,
                                     const double *d_inv_sigma2, const int32_t *d_n_edges, int frames, int max_edges,
-                                    double fx, double fy, double cx, double cy, double bf, double *d_pose,
-                                    uint8_t *d_outlier, int32_t *d_n_inliers, int32_t *d_stats);
+                                    double fx, double fy, double cx, double cy, double bf, const double *kb8_k,
+                                    double *d_pose, uint8_t *d_outlier, int32_t *d_n_inliers, int32_t *d_stats);
 
 #ifdef __cplusplus
 }

@@ -137,11 +137,46 @@ static void map_point(const double pose[7], const double X[3], double Xc[3])   /
     Xc[0] += pose[4]; Xc[1] += pose[5]; Xc[2] += pose[6];
 }
 
-static void edge_error(const double pose[7], const double X[3], const double obs[3], int stereo,
-                       double fx, double fy, double cx, double cy, double bf, double err[3])
+/* KannalaBrandt8::project(Eigen::Vector3d), KannalaBrandt8.cpp:52-69: float atan2f / sqrtf, double cos / sin */
+static void kb8_project(const double P[3], double fx, double fy, double cx, double cy, const double k[4], double uv[2])
+{
+    const double x2_plus_y2 = P[0] * P[0] + P[1] * P[1];
+    const double theta = atan2f(sqrtf(x2_plus_y2), P[2]);
+    const double psi = atan2f(P[1], P[0]);
+    const double theta2 = theta * theta, theta3 = theta * theta2, theta5 = theta3 * theta2, theta7 = theta5 * theta2, theta9 = theta7 * theta2;
+    const double r = theta + k[0] * theta3 + k[1] * theta5 + k[2] * theta7 + k[3] * theta9;
+    uv[0] = fx * r * cos(psi) + cx;
+    uv[1] = fy * r * sin(psi) + cy;
+}
+/* KannalaBrandt8::projectJac(Eigen::Vector3d), KannalaBrandt8.cpp:166-195; J row-major 2x3 */
+static void kb8_project_jac(const double v[3], double fx, double fy, const double k[4], double J[6])
+{
+    const double x2 = v[0] * v[0], y2 = v[1] * v[1], z2 = v[2] * v[2];
+    const double r2 = x2 + y2, r = sqrt(r2), r3 = r2 * r;
+    const double theta = atan2(r, v[2]);
+    const double theta2 = theta * theta, theta3 = theta2 * theta, theta4 = theta2 * theta2, theta5 = theta4 * theta;
+    const double theta6 = theta2 * theta4, theta7 = theta6 * theta, theta8 = theta4 * theta4, theta9 = theta8 * theta;
+    const double f = theta + theta3 * k[0] + theta5 * k[1] + theta7 * k[2] + theta9 * k[3];
+    const double fd = 1 + 3 * k[0] * theta2 + 5 * k[1] * theta4 + 7 * k[2] * theta6 + 9 * k[3] * theta8;
+    J[0] = fx * (fd * v[2] * x2 / (r2 * (r2 + z2)) + f * y2 / r3);
+    J[3] = fy * (fd * v[2] * v[1] * v[0] / (r2 * (r2 + z2)) - f * v[1] * v[0] / r3);
+    J[1] = fx * (fd * v[2] * v[1] * v[0] / (r2 * (r2 + z2)) - f * v[1] * v[0] / r3);
+    J[4] = fy * (fd * v[2] * y2 / (r2 * (r2 + z2)) + f * x2 / r3);
+    J[2] = -fx * fd * v[0] / (r2 + z2);
+    J[5] = -fy * fd * v[1] / (r2 + z2);
+}
+
+static void edge_error_cam(const double pose[7], const double X[3], const double obs[3], int stereo,
+                           double fx, double fy, double cx, double cy, double bf, const double *kb, double err[3])
 {
     double P[3];
     map_point(pose, X, P);
+    if (!stereo && kb) {                              /* OptimizableTypes.h:99-104 with pCamera = KannalaBrandt8 */
+        double uv[2];
+        kb8_project(P, fx, fy, cx, cy, kb, uv);
+        err[0] = obs[0] - uv[0]; err[1] = obs[1] - uv[1]; err[2] = 0;
+        return;
+    }
     if (!stereo) {                                    /* OptimizableTypes.h:99-104, Pinhole.cpp:41-47 */
         err[0] = obs[0] - (fx * P[0] / P[2] + cx);
         err[1] = obs[1] - (fy * P[1] / P[2] + cy);
@@ -154,6 +189,31 @@ static void edge_error(const double pose[7], const double X[3], const double obs
         err[1] = obs[1] - (P[1] * invz * fy + cy);
         err[2] = obs[2] - (r0 - (double)(bff * invz));
     }
+}
+
+static void edge_error(const double pose[7], const double X[3], const double obs[3], int stereo,
+                       double fx, double fy, double cx, double cy, double bf, double err[3])
+{
+    edge_error_cam(pose, X, obs, stereo, fx, fy, cx, cy, bf, NULL, err);
+}
+
+/* monocular edge through KannalaBrandt8: Jx = -projectJac * R (OptimizableTypes.cpp:139-160), Jt = -projectJac * SE3deriv */
+void orc_ba_edge_kb8(const double pose[7], const double X[3], const double obs[3],
+                     double fx, double fy, double cx, double cy, const double k[4], double *err, double *Jx, double *Jt)
+{
+    double P[3], R[9], J[6];
+    edge_error_cam(pose, X, obs, 0, fx, fy, cx, cy, 0.0, k, err);
+    map_point(pose, X, P);
+    quat_to_R(pose, R);
+    kb8_project_jac(P, fx, fy, k, J);
+    const double x = P[0], y = P[1], z = P[2];
+    for (int r = 0; r < 2; r++)
+        for (int c = 0; c < 3; c++)
+            Jx[3 * r + c] = -(J[3 * r] * R[c] + J[3 * r + 1] * R[3 + c] + J[3 * r + 2] * R[6 + c]);
+    const double D[18] = {0, z, -y, 1, 0, 0, -z, 0, x, 0, 1, 0, y, -x, 0, 0, 0, 1};
+    for (int r = 0; r < 2; r++)
+        for (int c = 0; c < 6; c++)
+            Jt[6 * r + c] = -(J[3 * r] * D[c] + J[3 * r + 1] * D[6 + c] + J[3 * r + 2] * D[12 + c]);
 }
 
 void orc_ba_edge(const double pose[7], const double X[3], const double obs[3], int stereo,
@@ -217,8 +277,8 @@ static void compute_errors(struct ba *B)
     for (int e = 0; e < B->E; e++) {
         if (B->level[e]) continue;                      /* not an active edge: _error stays as last computed */
         double *er = B->err + 3 * e;
-        edge_error(B->poses + 7 * g->edge_pose[e], B->points + 3 * g->edge_point[e], g->edge_obs + 3 * e,
-                   g->edge_stereo[e], g->fx, g->fy, g->cx, g->cy, g->bf, er);
+        edge_error_cam(B->poses + 7 * g->edge_pose[e], B->points + 3 * g->edge_point[e], g->edge_obs + 3 * e,
+                       g->edge_stereo[e], g->fx, g->fy, g->cx, g->cy, g->bf, g->camera_model == 1 ? g->kb : NULL, er);
         B->chi2[e] = (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * g->edge_inv_sigma2[e];
     }
 }
@@ -258,8 +318,11 @@ static void build_system(struct ba *B)
         const int D = g->edge_stereo[e] ? 3 : 2;
         const int pi = g->edge_pose[e], li = g->edge_point[e], hi = B->hidx[pi];
         double er[3], Jx[9], Jt[18], rho[2];
-        orc_ba_edge(B->poses + 7 * pi, B->points + 3 * li, g->edge_obs + 3 * e, g->edge_stereo[e],
-                    g->fx, g->fy, g->cx, g->cy, g->bf, er, Jx, Jt);
+        if (g->camera_model == 1 && !g->edge_stereo[e])
+            orc_ba_edge_kb8(B->poses + 7 * pi, B->points + 3 * li, g->edge_obs + 3 * e, g->fx, g->fy, g->cx, g->cy, g->kb, er, Jx, Jt);
+        else
+            orc_ba_edge(B->poses + 7 * pi, B->points + 3 * li, g->edge_obs + 3 * e, g->edge_stereo[e],
+                        g->fx, g->fy, g->cx, g->cy, g->bf, er, Jx, Jt);
         /* NB: constructQuadraticForm uses the edge's stored _error / chi2() of the last
          * computeActiveErrors, which LM:71 ran at this same state. */
         const double *es = B->err + 3 * e;
@@ -555,7 +618,11 @@ static void po_edge_error(const orc_pose_problem *P, const double pose[7], int e
     double Xc[3];
     const double *obs = P->obs + 3 * e;
     map_point(pose, P->Xw + 3 * e, Xc);
-    if (obs[2] < 0) {                                      /* OptimizableTypes.h:41-45, Pinhole.cpp:41-47 */
+    if (obs[2] < 0 && P->camera_model == 1) {              /* OptimizableTypes.h:41-45 with pCamera = KannalaBrandt8 */
+        double uv[2];
+        kb8_project(Xc, P->fx, P->fy, P->cx, P->cy, P->kb, uv);
+        er[0] = obs[0] - uv[0]; er[1] = obs[1] - uv[1]; er[2] = 0;
+    } else if (obs[2] < 0) {                               /* OptimizableTypes.h:41-45, Pinhole.cpp:41-47 */
         er[0] = obs[0] - (P->fx * Xc[0] / Xc[2] + P->cx);
         er[1] = obs[1] - (P->fy * Xc[1] / Xc[2] + P->cy);
         er[2] = 0;
@@ -597,7 +664,8 @@ static void po_build(struct po *S)
         if (S->level[e]) continue;
         const int stereo = !(P->obs[3 * e + 2] < 0), D = stereo ? 3 : 2;
         double er[3], Jx[9], Jt[18], rho[2];
-        orc_ba_edge(S->pose, P->Xw + 3 * e, P->obs + 3 * e, stereo, P->fx, P->fy, P->cx, P->cy, P->bf, er, Jx, Jt);
+        if (P->camera_model == 1 && !stereo) orc_ba_edge_kb8(S->pose, P->Xw + 3 * e, P->obs + 3 * e, P->fx, P->fy, P->cx, P->cy, P->kb, er, Jx, Jt);
+        else orc_ba_edge(S->pose, P->Xw + 3 * e, P->obs + 3 * e, stereo, P->fx, P->fy, P->cx, P->cy, P->bf, er, Jx, Jt);
         const double *es = S->err + 3 * e;
         po_rho(S, e, rho);
         const double w = rho[1] * P->inv_sigma2[e];

@@ -25,6 +25,8 @@ typedef struct {
     const double *edge_inv_sigma2;
     const uint8_t *edge_stereo;
     double fx, fy, cx, cy, bf;
+    int32_t camera_model;       /* 0 = Pinhole, 1 = KannalaBrandt8 (monocular edges; CameraModels/KannalaBrandt8.cpp:52-69,166-195) */
+    double kb[4];               /* k1..k4 = mvParameters[4..7] */
 } orc_ba_graph;
 
 typedef struct {
@@ -58,6 +60,10 @@ void orc_se3_oplus(const double upd6[6], double pose7[7]);                      
 void orc_ba_edge(const double pose7[7], const double X[3], const double obs[3], int stereo,
                  double fx, double fy, double cx, double cy, double bf,
                  double *err, double *Jx, double *Jt);
+/* same for the monocular edge seen through a KannalaBrandt8 camera (k = k1..k4) */
+void orc_ba_edge_kb8(const double pose7[7], const double X[3], const double obs[3],
+                     double fx, double fy, double cx, double cy, const double k[4],
+                     double *err, double *Jx, double *Jt);
 
 /* ---------------------------------------------------------------------------------------------
  * Optimizer::PoseOptimization (/root/reference/src/Optimizer.cc:854-1168), SURVEY 8f N1: motion-only BA of
@@ -74,6 +80,8 @@ typedef struct {
     int32_t n_edges;
     const double *Xw, *obs, *inv_sigma2;
     double fx, fy, cx, cy, bf;
+    int32_t camera_model;       /* as in orc_ba_graph (pFrame->mpCamera) */
+    double kb[4];
 } orc_pose_problem;
 typedef struct { int32_t rounds, iterations[4], lm_trials, n_bad; } orc_pose_stats;
 int orc_pose_optimization(const orc_pose_problem *P, double pose7[7], uint8_t *outlier, orc_pose_stats *stats);

@@ -41,6 +41,8 @@ struct BaGraphDev {
     int nt16;                                        // 16-column tiles per side (ld / 16)
     int ngrp;                                        // tile groups (each workgroup keeps <= GEMM_WAVES*GEMM_TPW tiles in registers)
     double fx, fy, cx, cy, bf;
+    int cam_model;                                   // 0 Pinhole, 1 KannalaBrandt8 (monocular edges)
+    double kb[4];
 };
 
 struct BaState {
@@ -194,6 +196,17 @@ __device__ __forceinline__ void edge_error(const BaGraphDev &g, const double *po
 {
     quat_rot(pose, X, P);
     P[0] += pose[4]; P[1] += pose[5]; P[2] += pose[6];
+    if (!stereo && g.cam_model == 1) {   // KannalaBrandt8::project, KannalaBrandt8.cpp:52-69 (float atan2f / sqrtf)
+        const double x2y2 = P[0] * P[0] + P[1] * P[1];
+        const double theta = (double)atan2f(sqrtf((float)x2y2), (float)P[2]);
+        const double psi = (double)atan2f((float)P[1], (float)P[0]);
+        const double t2 = theta * theta, t3 = theta * t2, t5 = t3 * t2, t7 = t5 * t2, t9 = t7 * t2;
+        const double r = theta + g.kb[0] * t3 + g.kb[1] * t5 + g.kb[2] * t7 + g.kb[3] * t9;
+        err[0] = obs[0] - (g.fx * r * cos(psi) + g.cx);
+        err[1] = obs[1] - (g.fy * r * sin(psi) + g.cy);
+        err[2] = 0;
+        return;
+    }
     if (!stereo) {
         err[0] = obs[0] - (g.fx * P[0] / P[2] + g.cx);
         err[1] = obs[1] - (g.fy * P[1] / P[2] + g.cy);
@@ -212,6 +225,26 @@ __device__ __forceinline__ void edge_error(const BaGraphDev &g, const double *po
 __device__ __forceinline__ void edge_jacobians(const BaGraphDev &g, const double *P, const double *R, int stereo, double *Jx, double *Jt)
 {
     const double x = P[0], y = P[1], z = P[2];
+    if (!stereo && g.cam_model == 1) {   // KannalaBrandt8::projectJac, KannalaBrandt8.cpp:166-195
+        const double x2 = x * x, y2 = y * y, z2 = z * z, r2 = x2 + y2, r = sqrt(r2), r3 = r2 * r;
+        const double theta = atan2(r, z);
+        const double t2 = theta * theta, t3 = t2 * theta, t4 = t2 * t2, t5 = t4 * theta, t6 = t2 * t4, t7 = t6 * theta, t8 = t4 * t4, t9 = t8 * theta;
+        const double f = theta + t3 * g.kb[0] + t5 * g.kb[1] + t7 * g.kb[2] + t9 * g.kb[3];
+        const double fd = 1 + 3 * g.kb[0] * t2 + 5 * g.kb[1] * t4 + 7 * g.kb[2] * t6 + 9 * g.kb[3] * t8;
+        const double J00 = g.fx * (fd * z * x2 / (r2 * (r2 + z2)) + f * y2 / r3);
+        const double J10 = g.fy * (fd * z * y * x / (r2 * (r2 + z2)) - f * y * x / r3);
+        const double J01 = g.fx * (fd * z * y * x / (r2 * (r2 + z2)) - f * y * x / r3);
+        const double J11 = g.fy * (fd * z * y2 / (r2 * (r2 + z2)) + f * x2 / r3);
+        const double J02 = -g.fx * fd * x / (r2 + z2), J12 = -g.fy * fd * y / (r2 + z2);
+        for (int c = 0; c < 3; c++) {                // Jx = -projectJac * R  (OptimizableTypes.cpp:139-160)
+            Jx[c] = -(J00 * R[c] + J01 * R[3 + c] + J02 * R[6 + c]);
+            Jx[3 + c] = -(J10 * R[c] + J11 * R[3 + c] + J12 * R[6 + c]);
+        }
+        // Jt = -projectJac * [0 z -y 1 0 0; -z 0 x 0 1 0; y -x 0 0 0 1]
+        Jt[0] = -(-J01 * z + J02 * y); Jt[1] = -(J00 * z - J02 * x); Jt[2] = -(-J00 * y + J01 * x); Jt[3] = -J00; Jt[4] = -J01; Jt[5] = -J02;
+        Jt[6] = -(-J11 * z + J12 * y); Jt[7] = -(J10 * z - J12 * x); Jt[8] = -(-J10 * y + J11 * x); Jt[9] = -J10; Jt[10] = -J11; Jt[11] = -J12;
+        return;
+    }
     if (!stereo) {
         const double iz = 1.0 / z;
         const double p00 = -(g.fx / z), p02 = g.fx * x / (z * z), p11 = -(g.fy / z), p12 = g.fy * y / (z * z);
@@ -1042,6 +1075,7 @@ extern "C" int orbhip_ba_batch_create(orbhip_ctx *ctx, const orbhip_ba_graph *gr
         D.n_poses = H.n_poses; D.n_points = H.n_points; D.n_edges = H.n_edges;
         D.pose_off = sumP; D.point_off = sumL; D.edge_off = sumE; D.free_off = sumF;
         D.fx = H.fx; D.fy = H.fy; D.cx = H.cx; D.cy = H.cy; D.bf = H.bf;
+        D.cam_model = H.camera_model; for (int k = 0; k < 4; k++) D.kb[k] = H.kb[k];
         std::vector<int> has(H.n_poses, 0), local_h(H.n_poses, -1);
         for (int e = 0; e < H.n_edges; e++) {
             if (H.edge_pose[e] < 0 || H.edge_pose[e] >= H.n_poses || H.edge_point[e] < 0 || H.edge_point[e] >= H.n_points ||
@@ -1338,6 +1372,7 @@ struct PoArgs {
     const int32_t *n;
     int max_edges;
     double fx, fy, cx, cy, bf;
+    int cam_model; double kb[4];
     double *pose;
     uint8_t *outlier;
     int32_t *n_inliers, *stats;
@@ -1370,7 +1405,16 @@ __device__ __forceinline__ double po_edge_chi2(const PoArgs &A, const double *po
 {
     quat_rot(pose, X, P);
     P[0] += pose[4]; P[1] += pose[5]; P[2] += pose[6];
-    if (ob[2] < 0) {                                   // OptimizableTypes.h:41-45, Pinhole.cpp:41-47
+    if (ob[2] < 0 && A.cam_model == 1) {               // OptimizableTypes.h:41-45 with pCamera = KannalaBrandt8 (:52-69)
+        const double x2y2 = P[0] * P[0] + P[1] * P[1];
+        const double theta = (double)atan2f(sqrtf((float)x2y2), (float)P[2]);
+        const double psi = (double)atan2f((float)P[1], (float)P[0]);
+        const double t2 = theta * theta, t3 = theta * t2, t5 = t3 * t2, t7 = t5 * t2, t9 = t7 * t2;
+        const double r = theta + A.kb[0] * t3 + A.kb[1] * t5 + A.kb[2] * t7 + A.kb[3] * t9;
+        er[0] = ob[0] - (A.fx * r * cos(psi) + A.cx);
+        er[1] = ob[1] - (A.fy * r * sin(psi) + A.cy);
+        er[2] = 0;
+    } else if (ob[2] < 0) {                            // OptimizableTypes.h:41-45, Pinhole.cpp:41-47
         er[0] = ob[0] - (A.fx * P[0] / P[2] + A.cx);
         er[1] = ob[1] - (A.fy * P[1] / P[2] + A.cy);
         er[2] = 0;
@@ -1398,6 +1442,7 @@ __global__ __launch_bounds__(PO_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         return;
     }
     BaGraphDev cam; cam.fx = A.fx; cam.fy = A.fy; cam.cx = A.cx; cam.cy = A.cy; cam.bf = A.bf;
+    cam.cam_model = A.cam_model; for (int k = 0; k < 4; k++) cam.kb[k] = A.kb[k];
     double pose0[7], pose[7], pose_ev[7], x[6] = {0, 0, 0, 0, 0, 0};
     for (int k = 0; k < 7; k++) pose0[k] = A.pose[7 * f + k];
     quat_norm_rot(pose0);                                                       // SE3Quat ctor
@@ -1587,8 +1632,8 @@ __global__ __launch_bounds__(PO_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 
 extern "C" int orbhip_pose_optimization_device(orbhip_ctx *ctx, const double *d_Xw, const double *d_obs,
                                                const double *d_inv_sigma2, const int32_t *d_n_edges, int frames, int max_edges,
-                                               double fx, double fy, double cx, double cy, double bf, double *d_pose,
-                                               uint8_t *d_outlier, int32_t *d_n_inliers, int32_t *d_stats)
+                                               double fx, double fy, double cx, double cy, double bf, const double *kb8_k,
+                                               double *d_pose, uint8_t *d_outlier, int32_t *d_n_inliers, int32_t *d_stats)
 {
     if (!ctx || !d_Xw || !d_obs || !d_inv_sigma2 || !d_n_edges || frames <= 0 || max_edges <= 0 || max_edges > 8192 ||
         !d_pose || !d_outlier || !d_n_inliers) { g_ba_error = "bad argument"; return ORBHIP_E_BADARG; }
@@ -1596,6 +1641,7 @@ extern "C" int orbhip_pose_optimization_device(orbhip_ctx *ctx, const double *d_
     PoArgs A;
     A.Xw = d_Xw; A.obs = d_obs; A.inv_s2 = d_inv_sigma2; A.n = d_n_edges; A.max_edges = max_edges;
     A.fx = fx; A.fy = fy; A.cx = cx; A.cy = cy; A.bf = bf; A.pose = d_pose; A.outlier = d_outlier; A.n_inliers = d_n_inliers;
+    A.cam_model = kb8_k ? 1 : 0; for (int k = 0; k < 4; k++) A.kb[k] = kb8_k ? kb8_k[k] : 0.0;
     A.stats = d_stats;
     hipLaunchKernelGGL(k_pose_opt, dim3(frames), dim3(PO_THREADS), 0, orbhip_ctx_stream_internal(ctx), A);
     return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;

@@ -289,7 +289,8 @@ class BaGraph(C.Structure):
     _fields_ = [("n_poses", C.c_int32), ("n_points", C.c_int32), ("n_edges", C.c_int32),
                 ("pose_fixed", vp), ("edge_pose", vp), ("edge_point", vp), ("edge_obs", vp),
                 ("edge_inv_sigma2", vp), ("edge_stereo", vp),
-                ("fx", cd), ("fy", cd), ("cx", cd), ("cy", cd), ("bf", cd)]
+                ("fx", cd), ("fy", cd), ("cx", cd), ("cy", cd), ("bf", cd),
+                ("camera_model", C.c_int32), ("kb", cd * 4)]
 
 
 class BaParams(C.Structure):
@@ -357,8 +358,10 @@ class BaBatch:
                  np.ascontiguousarray(g["edge_point"], np.int32), np.ascontiguousarray(g["edge_obs"], np.float64),
                  np.ascontiguousarray(g["edge_inv_sigma2"], np.float64), np.ascontiguousarray(g["edge_stereo"], np.uint8)]
             self._keep.append(k)
+            kb = g.get("kb")                      # KannalaBrandt8 k1..k4 for the monocular edges, None = Pinhole
             arr[i] = BaGraph(g["n_poses"], g["n_points"], g["n_edges"], *[a.ctypes.data for a in k],
-                             g["fx"], g["fy"], g["cx"], g["cy"], g["bf"])
+                             g["fx"], g["fy"], g["cx"], g["cy"], g["bf"], 1 if kb is not None else 0,
+                             (cd * 4)(*(kb if kb is not None else (0, 0, 0, 0))))
             self.sizes.append((g["n_poses"], g["n_points"], g["n_edges"]))
         self.poses = [np.ascontiguousarray(g["poses0"], np.float64).copy() for g in graphs]
         self.points = [np.ascontiguousarray(g["points0"], np.float64).copy() for g in graphs]
@@ -412,15 +415,17 @@ class BaBatch:
             self.h = None
 
 
-lib.orbhip_pose_optimization_device.argtypes = [vp, vp, vp, vp, vp, ci, ci, cd, cd, cd, cd, cd, vp, vp, vp, vp]
+lib.orbhip_pose_optimization_device.argtypes = [vp, vp, vp, vp, vp, ci, ci, cd, cd, cd, cd, cd, vp, vp, vp, vp, vp]
 
 
 def pose_optimization_device(ctx, d_Xw, d_obs, d_inv_sigma2, d_n_edges, frames, max_edges, cam, d_pose, d_outlier,
-                             d_n_inliers, d_stats=None):
-    """Optimizer::PoseOptimization, batched over frames; device addresses (ints); cam = (fx, fy, cx, cy, bf)."""
+                             d_n_inliers, d_stats=None, kb8=None):
+    """Optimizer::PoseOptimization, batched over frames; device addresses (ints); cam = (fx, fy, cx, cy, bf);
+    kb8 = (k1..k4) for a KannalaBrandt8 camera (host values), None = Pinhole."""
+    kb = (cd * 4)(*kb8) if kb8 is not None else None
     _chk(lib.orbhip_pose_optimization_device(ctx.h, d_Xw, d_obs, d_inv_sigma2, d_n_edges, frames, max_edges,
                                              float(cam[0]), float(cam[1]), float(cam[2]), float(cam[3]), float(cam[4]),
-                                             d_pose, d_outlier, d_n_inliers, d_stats), "orbhip_pose_optimization_device")
+                                             kb, d_pose, d_outlier, d_n_inliers, d_stats), "orbhip_pose_optimization_device")
 
 
 lib.orbhip_compute_stereo_matches_device.argtypes = [vp, vp, cf, cf, vp, vp, vp]

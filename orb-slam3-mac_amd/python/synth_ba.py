@@ -11,6 +11,14 @@ float32 at the boundary.
 import numpy as np
 
 
+def kb8_project(P, fx, fy, cx, cy, k):
+    """KannalaBrandt8 projection of camera-frame points P [n,3] (generator side, float64)."""
+    r_xy = np.sqrt(P[:, 0] ** 2 + P[:, 1] ** 2)
+    th = np.arctan2(r_xy, P[:, 2]); psi = np.arctan2(P[:, 1], P[:, 0])
+    r = th + k[0] * th ** 3 + k[1] * th ** 5 + k[2] * th ** 7 + k[3] * th ** 9
+    return fx * r * np.cos(psi) + cx, fy * r * np.sin(psi) + cy
+
+
 def _quat_from_R(R):
     t = np.trace(R)
     if t > 0:
@@ -50,7 +58,8 @@ def _exp_so3(w):
 
 
 def make_graph(n_kf=50, n_pts=2000, obs=10, seed=0, n_fixed=2, outlier_frac=0.05, stereo_frac=0.0,
-               pose_noise=(0.01, 0.05), point_noise=0.05, pixel_noise=1.0):
+               pose_noise=(0.01, 0.05), point_noise=0.05, pixel_noise=1.0, kb8=None):
+    """kb8 = (k1..k4): the monocular observations come from a KannalaBrandt8 camera (fisheye), else Pinhole."""
     rng = np.random.default_rng(seed)
     fx = fy = 458.0
     cx, cy, W, H = 320.0, 240.0, 640, 480
@@ -73,8 +82,11 @@ def make_graph(n_kf=50, n_pts=2000, obs=10, seed=0, n_fixed=2, outlier_frac=0.05
     inv_sig2 = (np.float32(1.0) / sig2.astype(np.float32)).astype(np.float32)
     for l in range(n_pts):
         Pc = Rs @ X[l] + ts
-        u = fx * Pc[:, 0] / Pc[:, 2] + cx
-        v = fy * Pc[:, 1] / Pc[:, 2] + cy
+        if kb8 is not None:
+            u, v = kb8_project(Pc, fx, fy, cx, cy, kb8)
+        else:
+            u = fx * Pc[:, 0] / Pc[:, 2] + cx
+            v = fy * Pc[:, 1] / Pc[:, 2] + cy
         vis = np.nonzero((Pc[:, 2] > 0.1) & (u > 0) & (u < W) & (v > 0) & (v < H))[0]
         if len(vis) == 0:
             vis = np.arange(n_kf)
@@ -110,11 +122,11 @@ def make_graph(n_kf=50, n_pts=2000, obs=10, seed=0, n_fixed=2, outlier_frac=0.05
     return dict(n_poses=n_kf, n_points=n_pts, n_edges=len(e_pose), pose_fixed=fixed,
                 edge_pose=np.array(e_pose, np.int32), edge_point=np.array(e_point, np.int32),
                 edge_obs=np.array(e_obs, np.float64).reshape(-1, 3), edge_inv_sigma2=np.array(e_is2, np.float64),
-                edge_stereo=np.array(e_st, np.uint8), fx=fx, fy=fy, cx=cx, cy=cy, bf=bf,
+                edge_stereo=np.array(e_st, np.uint8), fx=fx, fy=fy, cx=cx, cy=cy, bf=bf, kb=kb8,
                 poses0=poses0, points0=pts0, poses_gt=poses_gt, points_gt=X.copy())
 
 
-def make_pose_problem(seed, n=800, stereo_frac=0.0, outlier_frac=0.1, noise=True, perturb=(0.02, 0.08)):
+def make_pose_problem(seed, n=800, stereo_frac=0.0, outlier_frac=0.1, noise=True, perturb=(0.02, 0.08), kb8=None):
     """Seeded synthetic Optimizer::PoseOptimization input (host-side generator, numpy only).
 
     Camera at a random pose looking at a cloud of n map points (float32-rounded, as Xw.at<float>), Pinhole
@@ -137,6 +149,8 @@ def make_pose_problem(seed, n=800, stereo_frac=0.0, outlier_frac=0.1, noise=True
     octv = rng.integers(0, 8, n)
     sig = 1.2 ** octv
     uu = fx * Xc[:, 0] / Xc[:, 2] + cx; vv = fy * Xc[:, 1] / Xc[:, 2] + cy
+    if kb8 is not None:
+        uu, vv = kb8_project(Xc, fx, fy, cx, cy, kb8)
     ur = uu - bf / Xc[:, 2]
     if noise:
         uu = uu + rng.normal(0, 1, n) * sig; vv = vv + rng.normal(0, 1, n) * sig; ur = ur + rng.normal(0, 1, n) * sig
@@ -152,5 +166,5 @@ def make_pose_problem(seed, n=800, stereo_frac=0.0, outlier_frac=0.1, noise=True
     Rd = np.eye(3) + (np.sin(th) / th * Kd + (1 - np.cos(th)) / th ** 2 * Kd @ Kd if th > 0 else 0)
     R0 = (Rd @ R).astype(np.float32).astype(np.float64); t0 = (Rd @ t + d[3:]).astype(np.float32).astype(np.float64)
     U, _, Vt = np.linalg.svd(R0); R0 = U @ Vt                               # Converter::toSE3Quat gets a float Tcw
-    return dict(Xw=Xw, obs=obs, inv_sigma2=inv_s2, cam=(fx, fy, cx, cy, bf), pose0=np.concatenate([_quat_from_R(R0), t0]),
+    return dict(Xw=Xw, obs=obs, inv_sigma2=inv_s2, cam=(fx, fy, cx, cy, bf), kb8=kb8, pose0=np.concatenate([_quat_from_R(R0), t0]),
                 pose_true=np.concatenate([q_true, t]), outlier_true=bad)

@@ -10,7 +10,8 @@ class Graph(C.Structure):
     _fields_ = [("n_poses", C.c_int32), ("n_points", C.c_int32), ("n_edges", C.c_int32),
                 ("pose_fixed", vp), ("edge_pose", vp), ("edge_point", vp), ("edge_obs", vp),
                 ("edge_inv_sigma2", vp), ("edge_stereo", vp),
-                ("fx", cd), ("fy", cd), ("cx", cd), ("cy", cd), ("bf", cd)]
+                ("fx", cd), ("fy", cd), ("cx", cd), ("cy", cd), ("bf", cd),
+                ("camera_model", C.c_int32), ("kb", cd * 4)]
 
 
 class Params(C.Structure):
@@ -35,6 +36,7 @@ lib.orc_ba_solve.argtypes = [C.POINTER(Graph), C.POINTER(Params), vp, vp, vp, vp
 lib.orc_se3_exp.argtypes = [vp, vp, vp]
 lib.orc_se3_oplus.argtypes = [vp, vp]
 lib.orc_ba_edge.argtypes = [vp, vp, vp, ci, cd, cd, cd, cd, cd, vp, vp, vp]
+lib.orc_ba_edge_kb8.argtypes = [vp, vp, vp, cd, cd, cd, cd, vp, vp, vp, vp]
 
 
 def default_params():
@@ -54,8 +56,9 @@ def make_cgraph(g, cls=Graph):
     keep = [np.ascontiguousarray(g["pose_fixed"], np.uint8), np.ascontiguousarray(g["edge_pose"], np.int32),
             np.ascontiguousarray(g["edge_point"], np.int32), np.ascontiguousarray(g["edge_obs"], np.float64),
             np.ascontiguousarray(g["edge_inv_sigma2"], np.float64), np.ascontiguousarray(g["edge_stereo"], np.uint8)]
+    kb = g.get("kb")
     s = cls(g["n_poses"], g["n_points"], g["n_edges"], *[k.ctypes.data for k in keep],
-            g["fx"], g["fy"], g["cx"], g["cy"], g["bf"])
+            g["fx"], g["fy"], g["cx"], g["cy"], g["bf"], 1 if kb is not None else 0, (cd * 4)(*(kb if kb is not None else (0, 0, 0, 0))))
     return s, keep
 
 
@@ -74,7 +77,7 @@ def solve(g, params=None, abort=None):
 # ------------------------------------------------------------------ PoseOptimization oracle
 class PoseProblem(C.Structure):
     _fields_ = [("n_edges", C.c_int32), ("Xw", vp), ("obs", vp), ("inv_sigma2", vp),
-                ("fx", cd), ("fy", cd), ("cx", cd), ("cy", cd), ("bf", cd)]
+                ("fx", cd), ("fy", cd), ("cx", cd), ("cy", cd), ("bf", cd), ("camera_model", C.c_int32), ("kb", cd * 4)]
 
 
 class PoseStats(C.Structure):
@@ -85,13 +88,14 @@ lib.orc_pose_optimization.argtypes = [C.POINTER(PoseProblem), vp, vp, C.POINTER(
 lib.orc_pose_optimization.restype = ci
 
 
-def pose_optimization(Xw, obs, inv_sigma2, cam, pose0):
+def pose_optimization(Xw, obs, inv_sigma2, cam, pose0, kb8=None):
     """Optimizer::PoseOptimization restated.  Returns (n_inliers, pose7, outlier[n], stats dict)."""
     Xw = np.ascontiguousarray(Xw, np.float64).reshape(-1, 3)
     obs = np.ascontiguousarray(obs, np.float64).reshape(-1, 3)
     w = np.ascontiguousarray(inv_sigma2, np.float64)
     n = len(Xw)
-    P = PoseProblem(n, Xw.ctypes.data, obs.ctypes.data, w.ctypes.data, *[float(c) for c in cam])
+    P = PoseProblem(n, Xw.ctypes.data, obs.ctypes.data, w.ctypes.data, *[float(c) for c in cam], 1 if kb8 is not None else 0,
+                    (cd * 4)(*(kb8 if kb8 is not None else (0, 0, 0, 0))))
     pose = np.ascontiguousarray(pose0, np.float64).copy()
     out = np.zeros(max(n, 1), np.uint8)
     st = PoseStats()

@@ -155,3 +155,12 @@ def test_ba_merge_variant(gpu_ctx):
     _, _, outl, stats = bb.download()
     bb.close()
     assert stats[0]["discarded"] == 0 and outl[0].sum() > 0.5 * len(outl[0])
+
+
+def test_ba_kannala_brandt_camera(gpu_ctx):
+    """Monocular edges through KannalaBrandt8 (rows B2 / B3: KannalaBrandt8.cpp:52-69 project, :166-195 projectJac)."""
+    import synth_ba
+    kb = (-0.0034, 0.0007, -0.0021, 0.0002)
+    graphs = [synth_ba.make_graph(n_kf=12, n_pts=300, obs=6, seed=71, kb8=kb),
+              synth_ba.make_graph(n_kf=10, n_pts=200, obs=5, seed=72, kb8=kb, stereo_frac=0.3)]   # stereo edges stay pinhole (types_six_dof_expmap)
+    _check(gpu_ctx, graphs)

@@ -431,3 +431,56 @@ def test_bow_transform_oracle_against_python():
                         nid = node
                 got = om.bow_transform(f, voc, levelsup)
                 assert got == (int(voc["node_word"][node]), float(voc["node_weight"][node]), nid)
+
+
+# ------------------------------------------------------------------ KannalaBrandt8 camera (rows B2 / B3)
+KB8 = (-0.0034, 0.0007, -0.0021, 0.0002)          # k1..k4 of the order of the TUM-VI calibrations (Examples/*/TUM_512.yaml)
+
+
+def test_kb8_edge_jacobians_against_finite_differences():
+    import ctypes as C
+    import oracle_ba_bind as ob
+    rng = np.random.default_rng(3)
+    fx, fy, cx, cy = 190.9, 190.9, 254.9, 256.8
+    k = np.array(KB8)
+    for _ in range(20):
+        q = rng.normal(0, 1, 4); q /= np.linalg.norm(q)
+        if q[3] < 0: q = -q
+        pose = np.concatenate([q, rng.normal(0, 1, 3)])
+        Xc = np.array([rng.uniform(-2, 2), rng.uniform(-2, 2), rng.uniform(1.5, 6)])
+        # world point that maps to Xc under pose: X = R^T (Xc - t)
+        x, y, z, w = q
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        X = R.T @ (Xc - pose[4:])
+        obs = np.array([250.0, 260.0, 0.0])
+        e = np.zeros(3); Jx = np.zeros(9); Jt = np.zeros(18)
+        ob.lib.orc_ba_edge_kb8(pose.ctypes.data, X.ctypes.data, obs.ctypes.data, fx, fy, cx, cy, k.ctypes.data, e.ctypes.data, Jx.ctypes.data, Jt.ctypes.data)
+        h = 1e-4                                       # the projection runs through float atan2f: coarse steps, loose tolerance
+        for a in range(3):
+            Xp, Xm = X.copy(), X.copy(); Xp[a] += h; Xm[a] -= h
+            ep, em = np.zeros(3), np.zeros(3)
+            ob.lib.orc_ba_edge_kb8(pose.ctypes.data, Xp.ctypes.data, obs.ctypes.data, fx, fy, cx, cy, k.ctypes.data, ep.ctypes.data, Jx.copy().ctypes.data, Jt.copy().ctypes.data)
+            ob.lib.orc_ba_edge_kb8(pose.ctypes.data, Xm.ctypes.data, obs.ctypes.data, fx, fy, cx, cy, k.ctypes.data, em.ctypes.data, Jx.copy().ctypes.data, Jt.copy().ctypes.data)
+            np.testing.assert_allclose((ep[:2] - em[:2]) / (2 * h), Jx.reshape(3, 3)[:2, a], atol=0.15, rtol=5e-3)
+        for a in range(6):
+            d = np.zeros(6); d[a] = h
+            pp, pm = pose.copy(), pose.copy()
+            ob.lib.orc_se3_oplus(d.ctypes.data, pp.ctypes.data); ob.lib.orc_se3_oplus((-d).ctypes.data, pm.ctypes.data)
+            ep, em = np.zeros(3), np.zeros(3)
+            ob.lib.orc_ba_edge_kb8(pp.ctypes.data, X.ctypes.data, obs.ctypes.data, fx, fy, cx, cy, k.ctypes.data, ep.ctypes.data, Jx.copy().ctypes.data, Jt.copy().ctypes.data)
+            ob.lib.orc_ba_edge_kb8(pm.ctypes.data, X.ctypes.data, obs.ctypes.data, fx, fy, cx, cy, k.ctypes.data, em.ctypes.data, Jx.copy().ctypes.data, Jt.copy().ctypes.data)
+            np.testing.assert_allclose((ep[:2] - em[:2]) / (2 * h), Jt.reshape(3, 6)[:2, a], atol=0.15, rtol=5e-3)
+
+
+def test_kb8_ba_and_pose_recover_noise_free_solution():
+    import oracle_ba_bind as ob
+    import synth_ba
+    g = synth_ba.make_graph(n_kf=8, n_pts=150, obs=6, seed=61, outlier_frac=0.0, pixel_noise=0.0, kb8=KB8)
+    rc, poses, pts, out, st = ob.solve(g)
+    assert rc == 0 and st["discarded"] == 0 and out.sum() == 0
+    assert np.abs(poses[:, 4:] - g["poses_gt"][:, 4:]).max() < 5e-4 and np.abs(pts - g["points_gt"]).max() < 2e-3
+    p = synth_ba.make_pose_problem(62, n=300, outlier_frac=0.0, noise=False, kb8=KB8)
+    r, pose, o, _ = ob.pose_optimization(p["Xw"], p["obs"], p["inv_sigma2"], p["cam"], p["pose0"], kb8=KB8)
+    assert r == 300 and _pose_err(pose, p["pose_true"]) < 5e-5
