@@ -264,11 +264,18 @@ typedef struct {
     const int32_t *edge_point;  /* [n_edges] non-decreasing */
     const double *edge_obs;     /* [n_edges][3]  u,v,(ur; unused for mono) */
     const double *edge_inv_sigma2; /* [n_edges]  mvInvLevelSigma2[octave] */
-    const uint8_t *edge_stereo; /* [n_edges] 0 = EdgeSE3ProjectXYZ, 1 = EdgeStereoSE3ProjectXYZ */
+    const uint8_t *edge_stereo; /* [n_edges] 0 = EdgeSE3ProjectXYZ, 1 = EdgeStereoSE3ProjectXYZ,
+                                   2 = EdgeSE3ProjectXYZToBody (observation in the second camera, see Trl below) */
     double fx, fy, cx, cy, bf;  /* intrinsics (Pinhole.cpp:41-47) + stereo baseline*fx */
     int32_t camera_model;       /* 0 = Pinhole; 1 = KannalaBrandt8 for the monocular edges (src/CameraModels/
                                    KannalaBrandt8.cpp:52-69 project, :166-195 projectJac) */
     double kb[4];               /* k1..k4 (mvParameters[4..7]) when camera_model == 1 */
+    /* second, rigidly attached camera for the edges of type 2 (pKFi->mpCamera2 / mTrl, src/Optimizer.cc:2001-2032;
+     * include/OptimizableTypes.h:112-141, src/OptimizableTypes.cpp:192-213): */
+    double Trl[7];              /* mTrl as (qx,qy,qz,qw,tx,ty,tz): left-camera frame -> right-camera frame */
+    double fx2, fy2, cx2, cy2;
+    int32_t camera2_model;      /* as camera_model */
+    double kb2[4];
 } orbhip_ba_graph;
 
 typedef struct {

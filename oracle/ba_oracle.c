@@ -141,8 +141,11 @@ static void map_point(const double pose[7], const double X[3], double Xc[3])   /
 static void kb8_project(const double P[3], double fx, double fy, double cx, double cy, const double k[4], double uv[2])
 {
     const double x2_plus_y2 = P[0] * P[0] + P[1] * P[1];
-    const double theta = atan2f(sqrtf(x2_plus_y2), P[2]);
-    const double psi = atan2f(P[1], P[0]);
+    /* the reference calls libm atan2f / sqrtf on floats; libm's atan2f differs between platforms in the last float ulp
+     * (host glibc vs the device's), which is enough to flip an LM accept/reject decision, so oracle and kernel both take
+     * the float rounding of the DOUBLE atan2 -- within one float ulp of any libm, identical on both sides */
+    const double theta = (float)atan2((double)sqrtf((float)x2_plus_y2), (double)(float)P[2]);
+    const double psi = (float)atan2((double)(float)P[1], (double)(float)P[0]);
     const double theta2 = theta * theta, theta3 = theta * theta2, theta5 = theta3 * theta2, theta7 = theta5 * theta2, theta9 = theta7 * theta2;
     const double r = theta + k[0] * theta3 + k[1] * theta5 + k[2] * theta7 + k[3] * theta9;
     uv[0] = fx * r * cos(psi) + cx;
@@ -249,6 +252,71 @@ void orc_ba_edge(const double pose[7], const double X[3], const double obs[3], i
     }
 }
 
+/* ---- EdgeSE3ProjectXYZToBody (second camera of a rigid pair) */
+/* SE3Quat::operator*, SE3:104-110: result = a * b */
+static void se3_mul(const double a[7], const double b[7], double o[7])
+{
+    double rt[3], q[4];
+    quat_rot(a, b + 4, rt);
+    quat_mul(a, b, q);
+    quat_normalize_rot(q);
+    o[0] = q[0]; o[1] = q[1]; o[2] = q[2]; o[3] = q[3];
+    o[4] = a[4] + rt[0]; o[5] = a[5] + rt[1]; o[6] = a[6] + rt[2];
+}
+static void cam2_project(const orc_ba_graph *g, const double P[3], double uv[2])
+{
+    if (g->camera2_model == 1) kb8_project(P, g->fx2, g->fy2, g->cx2, g->cy2, g->kb2, uv);
+    else { uv[0] = g->fx2 * P[0] / P[2] + g->cx2; uv[1] = g->fy2 * P[1] / P[2] + g->cy2; }      /* Pinhole.cpp:41-47 */
+}
+static void cam2_project_jac(const orc_ba_graph *g, const double P[3], double J[6])
+{
+    if (g->camera2_model == 1) kb8_project_jac(P, g->fx2, g->fy2, g->kb2, J);
+    else {                                                                                   /* Pinhole.cpp:81-91 */
+        J[0] = g->fx2 / P[2]; J[1] = 0; J[2] = -g->fx2 * P[0] / (P[2] * P[2]);
+        J[3] = 0; J[4] = g->fy2 / P[2]; J[5] = -g->fy2 * P[1] / (P[2] * P[2]);
+    }
+}
+/* computeError, OptimizableTypes.h:121-126: obs - pCamera->project((mTrl * T_lw).map(X)) ; returns X_r in Pr */
+static void tobody_error(const orc_ba_graph *g, const double pose[7], const double X[3], const double obs[3], double err[3], double Pr[3])
+{
+    double Trw[7], uv[2];
+    se3_mul(g->Trl, pose, Trw);
+    map_point(Trw, X, Pr);
+    cam2_project(g, Pr, uv);
+    err[0] = obs[0] - uv[0]; err[1] = obs[1] - uv[1]; err[2] = 0;
+}
+/* linearizeOplus, OptimizableTypes.cpp:192-213 */
+void orc_ba_edge_tobody(const orc_ba_graph *g, const double pose[7], const double X[3], const double obs[3],
+                        double *err, double *Jx, double *Jt)
+{
+    double Pr[3], Trw[7], Xl[3], Xr[3], J[6], Rrw[9], Rrl[9];
+    tobody_error(g, pose, X, obs, err, Pr);
+    se3_mul(g->Trl, pose, Trw);
+    map_point(pose, X, Xl);
+    map_point(g->Trl, Xl, Xr);
+    cam2_project_jac(g, Xr, J);
+    quat_to_R(Trw, Rrw); quat_to_R(g->Trl, Rrl);
+    for (int r = 0; r < 2; r++)
+        for (int c = 0; c < 3; c++)
+            Jx[3 * r + c] = -(J[3 * r] * Rrw[c] + J[3 * r + 1] * Rrw[3 + c] + J[3 * r + 2] * Rrw[6 + c]);
+    const double x = Xl[0], y = Xl[1], z = Xl[2];
+    const double D[18] = {0, z, -y, 1, 0, 0, -z, 0, x, 0, 1, 0, y, -x, 0, 0, 0, 1};
+    double M[6];                                                     /* projectJac * R_rl, 2x3 */
+    for (int r = 0; r < 2; r++)
+        for (int c = 0; c < 3; c++) M[3 * r + c] = J[3 * r] * Rrl[c] + J[3 * r + 1] * Rrl[3 + c] + J[3 * r + 2] * Rrl[6 + c];
+    for (int r = 0; r < 2; r++)
+        for (int c = 0; c < 6; c++)
+            Jt[6 * r + c] = -(M[3 * r] * D[c] + M[3 * r + 1] * D[6 + c] + M[3 * r + 2] * D[12 + c]);
+}
+/* depth of the edge's camera-frame point (isDepthPositive of the three edge types) */
+static double edge_depth(const orc_ba_graph *g, const double pose[7], const double X[3], int type)
+{
+    double P[3];
+    if (type == 2) { double Trw[7]; se3_mul(g->Trl, pose, Trw); map_point(Trw, X, P); }
+    else map_point(pose, X, P);
+    return P[2];
+}
+
 /* ---------------------------------------------------------------- solver state */
 struct ba {
     const orc_ba_graph *g; const orc_ba_params *p;
@@ -277,8 +345,10 @@ static void compute_errors(struct ba *B)
     for (int e = 0; e < B->E; e++) {
         if (B->level[e]) continue;                      /* not an active edge: _error stays as last computed */
         double *er = B->err + 3 * e;
-        edge_error_cam(B->poses + 7 * g->edge_pose[e], B->points + 3 * g->edge_point[e], g->edge_obs + 3 * e,
-                       g->edge_stereo[e], g->fx, g->fy, g->cx, g->cy, g->bf, g->camera_model == 1 ? g->kb : NULL, er);
+        if (g->edge_stereo[e] == 2) { double Pr[3]; tobody_error(g, B->poses + 7 * g->edge_pose[e], B->points + 3 * g->edge_point[e], g->edge_obs + 3 * e, er, Pr); }
+        else
+            edge_error_cam(B->poses + 7 * g->edge_pose[e], B->points + 3 * g->edge_point[e], g->edge_obs + 3 * e,
+                           g->edge_stereo[e], g->fx, g->fy, g->cx, g->cy, g->bf, g->camera_model == 1 ? g->kb : NULL, er);
         B->chi2[e] = (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * g->edge_inv_sigma2[e];
     }
 }
@@ -297,7 +367,7 @@ static double robust_chi2(const struct ba *B)
     for (int e = 0; e < B->E; e++) {
         if (B->level[e]) continue;
         if (!B->robust) { chi += B->chi2[e]; continue; }
-        if (B->g->edge_stereo[e]) huber(B->chi2[e], B->delta_s, B->dsqr_s, rho);
+        if (B->g->edge_stereo[e] == 1) huber(B->chi2[e], B->delta_s, B->dsqr_s, rho);
         else huber(B->chi2[e], B->delta_m, B->dsqr_m, rho);
         chi += rho[0];
     }
@@ -315,10 +385,12 @@ static void build_system(struct ba *B)
     memset(B->W, 0, sizeof(double) * 18 * B->E);
     for (int e = 0; e < B->E; e++) {
         if (B->level[e]) continue;
-        const int D = g->edge_stereo[e] ? 3 : 2;
+        const int D = g->edge_stereo[e] == 1 ? 3 : 2;
         const int pi = g->edge_pose[e], li = g->edge_point[e], hi = B->hidx[pi];
         double er[3], Jx[9], Jt[18], rho[2];
-        if (g->camera_model == 1 && !g->edge_stereo[e])
+        if (g->edge_stereo[e] == 2)
+            orc_ba_edge_tobody(g, B->poses + 7 * pi, B->points + 3 * li, g->edge_obs + 3 * e, er, Jx, Jt);
+        else if (g->camera_model == 1 && !g->edge_stereo[e])
             orc_ba_edge_kb8(B->poses + 7 * pi, B->points + 3 * li, g->edge_obs + 3 * e, g->fx, g->fy, g->cx, g->cy, g->kb, er, Jx, Jt);
         else
             orc_ba_edge(B->poses + 7 * pi, B->points + 3 * li, g->edge_obs + 3 * e, g->edge_stereo[e],
@@ -327,7 +399,7 @@ static void build_system(struct ba *B)
          * computeActiveErrors, which LM:71 ran at this same state. */
         const double *es = B->err + 3 * e;
         if (!B->robust) { rho[0] = B->chi2[e]; rho[1] = 1.; }
-        else if (g->edge_stereo[e]) huber(B->chi2[e], B->delta_s, B->dsqr_s, rho);
+        else if (g->edge_stereo[e] == 1) huber(B->chi2[e], B->delta_s, B->dsqr_s, rho);
         else huber(B->chi2[e], B->delta_m, B->dsqr_m, rho);
         const double w = rho[1] * g->edge_inv_sigma2[e];          /* robustInformation, base_edge.h:96-102 */
         /* point (vertex 0, "from") */
@@ -571,9 +643,8 @@ int orc_ba_solve(const orc_ba_graph *g, const orc_ba_params *p, const volatile u
     const double gate_m = p->gate_mono2 > 0 ? p->gate_mono2 : p->huber_mono2, gate_s = p->gate_stereo2 > 0 ? p->gate_stereo2 : p->huber_stereo2;
     if (do_more && (p->stage2_exclude_outliers || p->stage2_drop_robust)) {                  /* merge variant, Optimizer.cc:6546-6579 */
         for (int e = 0; e < B.E; e++) {
-            double Pc[3];
-            map_point(B.poses + 7 * g->edge_pose[e], B.points + 3 * g->edge_point[e], Pc);
-            if (p->stage2_exclude_outliers && (B.chi2[e] > (g->edge_stereo[e] ? gate_s : gate_m) || !(Pc[2] > 0.0))) B.level[e] = 1;
+            const double zc = edge_depth(g, B.poses + 7 * g->edge_pose[e], B.points + 3 * g->edge_point[e], g->edge_stereo[e]);
+            if (p->stage2_exclude_outliers && (B.chi2[e] > (g->edge_stereo[e] == 1 ? gate_s : gate_m) || !(zc > 0.0))) B.level[e] = 1;
         }
         if (p->stage2_drop_robust) B.robust = 0;
     }
@@ -581,10 +652,9 @@ int orc_ba_solve(const orc_ba_graph *g, const orc_ba_params *p, const volatile u
     st.lm_trials = B.lm_trials;
     /* outliers, LBA:2126-2173: chi2 from the stored (last evaluated) error; depth from current estimates */
     for (int e = 0; e < B.E; e++) {
-        double Pc[3];
-        map_point(B.poses + 7 * g->edge_pose[e], B.points + 3 * g->edge_point[e], Pc);
-        const double gate = g->edge_stereo[e] ? gate_s : gate_m;
-        const int out = (B.chi2[e] > gate) || !(Pc[2] > 0.0);
+        const double zc = edge_depth(g, B.poses + 7 * g->edge_pose[e], B.points + 3 * g->edge_point[e], g->edge_stereo[e]);
+        const double gate = g->edge_stereo[e] == 1 ? gate_s : gate_m;
+        const int out = (B.chi2[e] > gate) || !(zc > 0.0);
         if (edge_outlier) edge_outlier[e] = (uint8_t)out;
         st.n_outliers += out;
     }

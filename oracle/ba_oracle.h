@@ -27,6 +27,12 @@ typedef struct {
     double fx, fy, cx, cy, bf;
     int32_t camera_model;       /* 0 = Pinhole, 1 = KannalaBrandt8 (monocular edges; CameraModels/KannalaBrandt8.cpp:52-69,166-195) */
     double kb[4];               /* k1..k4 = mvParameters[4..7] */
+    /* second, rigidly attached camera (pKFi->mpCamera2, mTrl): edges with edge_stereo[e] == 2 are
+     * EdgeSE3ProjectXYZToBody (OptimizableTypes.h:112-141, OptimizableTypes.cpp:192-213; Optimizer.cc:2001-2032) */
+    double Trl[7];              /* mTrl as (qx,qy,qz,qw,tx,ty,tz) */
+    double fx2, fy2, cx2, cy2;
+    int32_t camera2_model;
+    double kb2[4];
 } orc_ba_graph;
 
 typedef struct {
@@ -61,6 +67,9 @@ void orc_ba_edge(const double pose7[7], const double X[3], const double obs[3], 
                  double fx, double fy, double cx, double cy, double bf,
                  double *err, double *Jx, double *Jt);
 /* same for the monocular edge seen through a KannalaBrandt8 camera (k = k1..k4) */
+/* EdgeSE3ProjectXYZToBody through camera 2 of the graph g: residual 2, Jx 2x3, Jt 2x6 */
+void orc_ba_edge_tobody(const orc_ba_graph *g, const double pose7[7], const double X[3], const double obs[3],
+                        double *err, double *Jx, double *Jt);
 void orc_ba_edge_kb8(const double pose7[7], const double X[3], const double obs[3],
                      double fx, double fy, double cx, double cy, const double k[4],
                      double *err, double *Jx, double *Jt);

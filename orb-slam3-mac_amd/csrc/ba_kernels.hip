@@ -43,6 +43,8 @@ struct BaGraphDev {
     double fx, fy, cx, cy, bf;
     int cam_model;                                   // 0 Pinhole, 1 KannalaBrandt8 (monocular edges)
     double kb[4];
+    double Trl[7], fx2, fy2, cx2, cy2, kb2[4];       // second camera of a rigid pair (edge type 2, EdgeSE3ProjectXYZToBody)
+    int cam2_model;
 };
 
 struct BaState {
@@ -65,6 +67,11 @@ struct BaBatch {      // kernel argument (by value)
     const int *edge_pose, *edge_point;   // [sumE] local indices
     const double *edge_obs, *edge_is2;   // [sumE*3], [sumE]
     const uint8_t *edge_stereo;
+    // a point seen by the same keyframe in both cameras of a rig has TWO edges to one pose; g2o maps both onto the same
+    // Hpl block (they accumulate).  edge_dup[e] = 1: an earlier edge of the same point has the same pose (its Hpl share is
+    // added by that first edge); edge_next[e] = the next such edge of the chain or -1.
+    const uint8_t *edge_dup;
+    const int *edge_next;
     const int *pt_start;        // per graph n_points+1
     const int *pose_start;      // per graph nf+1  (free poses only, by hessian index)
     const int *pose_edges;      // [sumE'] edge ids (graph-local) grouped by free pose
@@ -190,16 +197,108 @@ __device__ __forceinline__ void se3_oplus(const double *u, const double *pose, d
     out[4] = te[0] + rt[0]; out[5] = te[1] + rt[1]; out[6] = te[2] + rt[2];
 }
 
+// ------------------------------------------------------------------ second camera (EdgeSE3ProjectXYZToBody)
+// SE3Quat::operator* (se3quat.h:104-110): o = a * b
+__device__ __forceinline__ void se3_mul(const double *a, const double *b, double *o)
+{
+    double rt[3], q[4];
+    quat_rot(a, b + 4, rt);
+    q[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+    q[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    q[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+    q[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+    quat_norm_rot(q);
+    o[0] = q[0]; o[1] = q[1]; o[2] = q[2]; o[3] = q[3];
+    o[4] = a[4] + rt[0]; o[5] = a[5] + rt[1]; o[6] = a[6] + rt[2];
+}
+// GeometricCamera::project / projectJac of camera (fx,fy,cx,cy,model,k): Pinhole.cpp:41-47,81-91; KannalaBrandt8.cpp:52-69,166-195
+__device__ __forceinline__ void cam_project(double fx, double fy, double cx, double cy, int model, const double *k, const double *P, double *uv)
+{
+    if (model == 1) {
+        const double x2y2 = P[0] * P[0] + P[1] * P[1];
+        const double theta = (double)(float)atan2((double)sqrtf((float)x2y2), (double)(float)P[2]);
+        const double psi = (double)(float)atan2((double)(float)P[1], (double)(float)P[0]);
+        const double t2 = theta * theta, t3 = theta * t2, t5 = t3 * t2, t7 = t5 * t2, t9 = t7 * t2;
+        const double r = theta + k[0] * t3 + k[1] * t5 + k[2] * t7 + k[3] * t9;
+        uv[0] = fx * r * cos(psi) + cx; uv[1] = fy * r * sin(psi) + cy;
+    } else { uv[0] = fx * P[0] / P[2] + cx; uv[1] = fy * P[1] / P[2] + cy; }
+}
+__device__ __forceinline__ void cam_project_jac(double fx, double fy, int model, const double *k, const double *P, double *J)
+{
+    const double x = P[0], y = P[1], z = P[2];
+    if (model == 1) {
+        const double x2 = x * x, y2 = y * y, z2 = z * z, r2 = x2 + y2, r = sqrt(r2), r3 = r2 * r;
+        const double theta = atan2(r, z);
+        const double t2 = theta * theta, t3 = t2 * theta, t4 = t2 * t2, t5 = t4 * theta, t6 = t2 * t4, t7 = t6 * theta, t8 = t4 * t4, t9 = t8 * theta;
+        const double f = theta + t3 * k[0] + t5 * k[1] + t7 * k[2] + t9 * k[3];
+        const double fd = 1 + 3 * k[0] * t2 + 5 * k[1] * t4 + 7 * k[2] * t6 + 9 * k[3] * t8;
+        J[0] = fx * (fd * z * x2 / (r2 * (r2 + z2)) + f * y2 / r3);
+        J[3] = fy * (fd * z * y * x / (r2 * (r2 + z2)) - f * y * x / r3);
+        J[1] = fx * (fd * z * y * x / (r2 * (r2 + z2)) - f * y * x / r3);
+        J[4] = fy * (fd * z * y2 / (r2 * (r2 + z2)) + f * x2 / r3);
+        J[2] = -fx * fd * x / (r2 + z2); J[5] = -fy * fd * y / (r2 + z2);
+    } else {
+        J[0] = fx / z; J[1] = 0; J[2] = -fx * x / (z * z);
+        J[3] = 0; J[4] = fy / z; J[5] = -fy * y / (z * z);
+    }
+}
+// EdgeSE3ProjectXYZToBody::computeError (OptimizableTypes.h:121-126): obs - cam2.project((mTrl * T_lw).map(X)); P = that point
+__device__ __forceinline__ void tobody_error(const BaGraphDev &g, const double *pose, const double *X, const double *obs, double *P, double *err)
+{
+    double Trw[7], uv[2];
+    se3_mul(g.Trl, pose, Trw);
+    quat_rot(Trw, X, P);
+    P[0] += Trw[4]; P[1] += Trw[5]; P[2] += Trw[6];
+    cam_project(g.fx2, g.fy2, g.cx2, g.cy2, g.cam2_model, g.kb2, P, uv);
+    err[0] = obs[0] - uv[0]; err[1] = obs[1] - uv[1]; err[2] = 0;
+}
+// EdgeSE3ProjectXYZToBody::linearizeOplus (OptimizableTypes.cpp:192-213); rows 2 of Jx / Jt zeroed
+__device__ __forceinline__ void tobody_jacobians(const BaGraphDev &g, const double *pose, const double *X, double *Jx, double *Jt)
+{
+    double Trw[7], Xl[3], Xr[3], J[6], Rrw[9], Rrl[9], M[6];
+    se3_mul(g.Trl, pose, Trw);
+    quat_rot(pose, X, Xl); Xl[0] += pose[4]; Xl[1] += pose[5]; Xl[2] += pose[6];
+    quat_rot(g.Trl, Xl, Xr); Xr[0] += g.Trl[4]; Xr[1] += g.Trl[5]; Xr[2] += g.Trl[6];
+    cam_project_jac(g.fx2, g.fy2, g.cam2_model, g.kb2, Xr, J);
+    quat_to_R(Trw, Rrw); quat_to_R(g.Trl, Rrl);
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            Jx[3 * r + c] = -(J[3 * r] * Rrw[c] + J[3 * r + 1] * Rrw[3 + c] + J[3 * r + 2] * Rrw[6 + c]);
+            M[3 * r + c] = J[3 * r] * Rrl[c] + J[3 * r + 1] * Rrl[3 + c] + J[3 * r + 2] * Rrl[6 + c];
+        }
+    const double x = Xl[0], y = Xl[1], z = Xl[2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const double m0 = M[3 * r], m1 = M[3 * r + 1], m2 = M[3 * r + 2];
+        Jt[6 * r + 0] = -(-m1 * z + m2 * y); Jt[6 * r + 1] = -(m0 * z - m2 * x); Jt[6 * r + 2] = -(-m0 * y + m1 * x);
+        Jt[6 * r + 3] = -m0; Jt[6 * r + 4] = -m1; Jt[6 * r + 5] = -m2;
+    }
+#pragma unroll
+    for (int k = 6; k < 9; k++) Jx[k] = 0;
+#pragma unroll
+    for (int k = 12; k < 18; k++) Jt[k] = 0;
+}
+// z of the edge's camera-frame point (isDepthPositive of the three edge types)
+__device__ __forceinline__ double edge_depth(const BaGraphDev &g, const double *pose, const double *X, int type)
+{
+    double P[3];
+    if (type == 2) { double Trw[7]; se3_mul(g.Trl, pose, Trw); quat_rot(Trw, X, P); return P[2] + Trw[6]; }
+    quat_rot(pose, X, P);
+    return P[2] + pose[6];
+}
+
 // ------------------------------------------------------------------ edge math (B2, B3)
 __device__ __forceinline__ void edge_error(const BaGraphDev &g, const double *pose, const double *X, const double *obs,
                                            int stereo, double *P, double *err)
 {
     quat_rot(pose, X, P);
     P[0] += pose[4]; P[1] += pose[5]; P[2] += pose[6];
-    if (!stereo && g.cam_model == 1) {   // KannalaBrandt8::project, KannalaBrandt8.cpp:52-69 (float atan2f / sqrtf)
+    if (!stereo && g.cam_model == 1) {   // KannalaBrandt8::project, KannalaBrandt8.cpp:52-69; atan2f as the float rounding of the double atan2 (see oracle/ba_oracle.c)
         const double x2y2 = P[0] * P[0] + P[1] * P[1];
-        const double theta = (double)atan2f(sqrtf((float)x2y2), (float)P[2]);
-        const double psi = (double)atan2f((float)P[1], (float)P[0]);
+        const double theta = (double)(float)atan2((double)sqrtf((float)x2y2), (double)(float)P[2]);
+        const double psi = (double)(float)atan2((double)(float)P[1], (double)(float)P[0]);
         const double t2 = theta * theta, t3 = theta * t2, t5 = t3 * t2, t7 = t5 * t2, t9 = t7 * t2;
         const double r = theta + g.kb[0] * t3 + g.kb[1] * t5 + g.kb[2] * t7 + g.kb[3] * t9;
         err[0] = obs[0] - (g.fx * r * cos(psi) + g.cx);
@@ -295,8 +394,9 @@ __global__ __launch_bounds__(256) void k_ba_errors(BaBatch B, int which)
     const double *pose = B.poses + ((size_t)buf * B.sumP + G.pose_off + B.edge_pose[ge]) * 7;
     const double *X = B.points + ((size_t)buf * B.sumL + G.point_off + B.edge_point[ge]) * 3;
     double P[3], er[3];
-    const int stereo = B.edge_stereo[ge];
-    edge_error(G, pose, X, B.edge_obs + 3 * (size_t)ge, stereo, P, er);
+    const int type = B.edge_stereo[ge], stereo = type == 1;          // 0 mono, 1 stereo, 2 second camera (ToBody)
+    if (type == 2) tobody_error(G, pose, X, B.edge_obs + 3 * (size_t)ge, P, er);
+    else edge_error(G, pose, X, B.edge_obs + 3 * (size_t)ge, stereo, P, er);
     const double chi2 = (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * B.edge_is2[ge];
     double r0, r1;
     if (!st.robust) { r0 = chi2; r1 = 1.; }
@@ -358,16 +458,19 @@ __global__ __launch_bounds__(256) void k_ba_build_points(BaBatch B)
         const int pi = B.edge_pose[ge];
         const int hi = B.hidx[G.pose_off + pi];
         const double *pose = B.poses + ((size_t)st.cur * B.sumP + G.pose_off + pi) * 7;
-        const int stereo = B.edge_stereo[ge];
+        const int type = B.edge_stereo[ge], stereo = type == 1;
         double P[3], R[9], Jx[9], Jt[18];
 #pragma unroll
         for (int k = 6; k < 9; k++) Jx[k] = 0;
 #pragma unroll
         for (int k = 12; k < 18; k++) Jt[k] = 0;                                     // monocular edge: third row empty
-        quat_rot(pose, X, P);
-        P[0] += pose[4]; P[1] += pose[5]; P[2] += pose[6];
-        quat_to_R(pose, R);
-        edge_jacobians(G, P, R, stereo, Jx, Jt);
+        if (type == 2) tobody_jacobians(G, pose, X, Jx, Jt);
+        else {
+            quat_rot(pose, X, P);
+            P[0] += pose[4]; P[1] += pose[5]; P[2] += pose[6];
+            quat_to_R(pose, R);
+            edge_jacobians(G, P, R, stereo, Jx, Jt);
+        }
         const double chi2 = B.chi2[ge];
         double r0, r1;
         if (!st.robust) r1 = 1.;
@@ -382,7 +485,8 @@ __global__ __launch_bounds__(256) void k_ba_build_points(BaBatch B)
             acc[0] += j0 * w * j0; acc[1] += j0 * w * j1; acc[2] += j0 * w * j2;
             acc[3] += j1 * w * j1; acc[4] += j1 * w * j2; acc[5] += j2 * w * j2;
         }
-        if (hi >= 0) {
+        if (hi >= 0 && !B.edge_dup[ge]) {
+            double Wb[18];
 #pragma unroll
             for (int bb = 0; bb < 3; bb++)
 #pragma unroll
@@ -390,8 +494,36 @@ __global__ __launch_bounds__(256) void k_ba_build_points(BaBatch B)
                     double h = 0;
 #pragma unroll
                     for (int d = 0; d < 3; d++) h += Jt[6 * d + a] * w * Jx[3 * d + bb];
-                    Wd[(size_t)bb * G.ld + 6 * hi + a] = h;
+                    Wb[6 * bb + a] = h;
                 }
+            for (int e2 = B.edge_next[ge]; e2 >= 0; e2 = B.edge_next[G.edge_off + e2]) {      // the same keyframe's other camera (rare)
+                const int g2 = G.edge_off + e2;
+                const int type2 = B.edge_stereo[g2], st2 = type2 == 1;
+                double P2[3], R2[9], Jx2[9], Jt2[18];
+                for (int k = 6; k < 9; k++) Jx2[k] = 0;
+                for (int k = 12; k < 18; k++) Jt2[k] = 0;
+                if (type2 == 2) tobody_jacobians(G, pose, X, Jx2, Jt2);
+                else {
+                    quat_rot(pose, X, P2);
+                    P2[0] += pose[4]; P2[1] += pose[5]; P2[2] += pose[6];
+                    quat_to_R(pose, R2);
+                    edge_jacobians(G, P2, R2, st2, Jx2, Jt2);
+                }
+                double q0, q1;
+                if (!st.robust) q1 = 1.;
+                else if (st2) huber(B.chi2[g2], B.delta_s, B.dsqr_s, &q0, &q1); else huber(B.chi2[g2], B.delta_m, B.dsqr_m, &q0, &q1);
+                const double w2 = B.level[g2] ? 0.0 : q1 * B.edge_is2[g2];
+                for (int bb = 0; bb < 3; bb++)
+                    for (int a = 0; a < 6; a++) {
+                        double h = 0;
+                        for (int d = 0; d < 3; d++) h += Jt2[6 * d + a] * w2 * Jx2[3 * d + bb];
+                        Wb[6 * bb + a] += h;
+                    }
+            }
+#pragma unroll
+            for (int bb = 0; bb < 3; bb++)
+#pragma unroll
+                for (int a = 0; a < 6; a++) Wd[(size_t)bb * G.ld + 6 * hi + a] = Wb[6 * bb + a];
         }
     }
 #pragma unroll
@@ -428,13 +560,16 @@ __global__ __launch_bounds__(64) void k_ba_build_poses(BaBatch B)
         const int ge = G.edge_off + e;
         const double *pose = B.poses + ((size_t)st.cur * B.sumP + G.pose_off + B.edge_pose[ge]) * 7;
         const double *X = B.points + ((size_t)st.cur * B.sumL + G.point_off + B.edge_point[ge]) * 3;
-        const int stereo = B.edge_stereo[ge];
+        const int type = B.edge_stereo[ge], stereo = type == 1;
         const int D = stereo ? 3 : 2;
         double P[3], R[9], Jx[9], Jt[18];
-        quat_rot(pose, X, P);
-        P[0] += pose[4]; P[1] += pose[5]; P[2] += pose[6];
-        quat_to_R(pose, R);
-        edge_jacobians(G, P, R, stereo, Jx, Jt);
+        if (type == 2) tobody_jacobians(G, pose, X, Jx, Jt);
+        else {
+            quat_rot(pose, X, P);
+            P[0] += pose[4]; P[1] += pose[5]; P[2] += pose[6];
+            quat_to_R(pose, R);
+            edge_jacobians(G, P, R, stereo, Jx, Jt);
+        }
         double r0, r1;
         const double chi2 = B.chi2[ge];
         if (!st.robust) r1 = 1.;
@@ -679,6 +814,7 @@ __global__ __launch_bounds__(64) void k_ba_bschur(BaBatch B)
     const double *Wd = B.Wd + G.wd_off;
     double acc[6] = {0, 0, 0, 0, 0, 0};
     for (int k = qs[h] + lane; k < qs[h + 1]; k += 64) {
+        if (B.edge_dup[G.edge_off + pe[k]]) continue;                      // one Hpl block per (point, pose)
         const int l = B.edge_point[G.edge_off + pe[k]];
         const double *db = B.db + (size_t)(G.point_off + l) * 3;
         const double *w = Wd + (size_t)(4 * l) * G.ld + 6 * h;
@@ -861,7 +997,7 @@ __global__ __launch_bounds__(256) void k_ba_backsub_points(BaBatch B)
         const double *Wd = B.Wd + G.wd_off + (size_t)(4 * l) * G.ld;
         for (int e = ps[l] + sub; e < ps[l + 1]; e += 16) {
             const int h = B.hidx[G.pose_off + B.edge_pose[G.edge_off + e]];
-            if (h < 0) continue;
+            if (h < 0 || B.edge_dup[G.edge_off + e]) continue;              // one Hpl block per (point, pose)
             const double *xp = B.xp + (size_t)(G.free_off + h) * 6;
             const double *w = Wd + 6 * h;
 #pragma unroll
@@ -961,10 +1097,8 @@ __global__ __launch_bounds__(256) void k_ba_levels(BaBatch B)
     const int ge = G.edge_off + e;
     const double *pose = B.poses + ((size_t)st.cur * B.sumP + G.pose_off + B.edge_pose[ge]) * 7;
     const double *X = B.points + ((size_t)st.cur * B.sumL + G.point_off + B.edge_point[ge]) * 3;
-    double P[3];
-    quat_rot(pose, X, P);
-    const double z = P[2] + pose[6];
-    const double gate = B.edge_stereo[ge] ? B.gate_s : B.gate_m;
+    const double z = edge_depth(G, pose, X, B.edge_stereo[ge]);
+    const double gate = B.edge_stereo[ge] == 1 ? B.gate_s : B.gate_m;
     if ((B.chi2[ge] > gate) || !(z > 0.0)) B.level[ge] = 1;
 }
 
@@ -979,10 +1113,8 @@ __global__ __launch_bounds__(256) void k_ba_finalize(BaBatch B)
     const int ge = G.edge_off + e;
     const double *pose = B.poses + ((size_t)st.cur * B.sumP + G.pose_off + B.edge_pose[ge]) * 7;
     const double *X = B.points + ((size_t)st.cur * B.sumL + G.point_off + B.edge_point[ge]) * 3;
-    double P[3];
-    quat_rot(pose, X, P);
-    const double z = P[2] + pose[6];
-    const double gate = B.edge_stereo[ge] ? B.gate_s : B.gate_m;
+    const double z = edge_depth(G, pose, X, B.edge_stereo[ge]);
+    const double gate = B.edge_stereo[ge] == 1 ? B.gate_s : B.gate_m;
     const int out = (B.chi2[ge] > gate) || !(z > 0.0);
     B.outlier[ge] = (uint8_t)out;
     if (out) atomicAdd(&B.st[g].n_outliers, 1);
@@ -1063,7 +1195,8 @@ extern "C" int orbhip_ba_batch_create(orbhip_ctx *ctx, const orbhip_ba_graph *gr
     std::vector<int> hidx, epose, epoint, ptstart, posestart, poseedges;
     std::vector<uint32_t> ptmask;
     std::vector<double> eobs, eis2;
-    std::vector<uint8_t> est;
+    std::vector<uint8_t> est, edup;
+    std::vector<int> enext;
     int sumP = 0, sumL = 0, sumE = 0, sumF = 0;
     size_t wd = 0, s = 0, sp = 0;
     // split-K so that the Schur GEMM launches >= ~4096 waves
@@ -1076,6 +1209,8 @@ extern "C" int orbhip_ba_batch_create(orbhip_ctx *ctx, const orbhip_ba_graph *gr
         D.pose_off = sumP; D.point_off = sumL; D.edge_off = sumE; D.free_off = sumF;
         D.fx = H.fx; D.fy = H.fy; D.cx = H.cx; D.cy = H.cy; D.bf = H.bf;
         D.cam_model = H.camera_model; for (int k = 0; k < 4; k++) D.kb[k] = H.kb[k];
+        for (int k = 0; k < 7; k++) D.Trl[k] = H.Trl[k];
+        D.fx2 = H.fx2; D.fy2 = H.fy2; D.cx2 = H.cx2; D.cy2 = H.cy2; D.cam2_model = H.camera2_model; for (int k = 0; k < 4; k++) D.kb2[k] = H.kb2[k];
         std::vector<int> has(H.n_poses, 0), local_h(H.n_poses, -1);
         for (int e = 0; e < H.n_edges; e++) {
             if (H.edge_pose[e] < 0 || H.edge_pose[e] >= H.n_poses || H.edge_point[e] < 0 || H.edge_point[e] >= H.n_points ||
@@ -1099,6 +1234,27 @@ extern "C" int orbhip_ba_batch_create(orbhip_ctx *ctx, const orbhip_ba_graph *gr
         for (int e = 0; e < H.n_edges; e++) { const int h = local_h[H.edge_pose[e]]; if (h >= 0) pel[fill[h]++] = e; }
         posestart.insert(posestart.end(), pc.begin(), pc.end());
         poseedges.insert(poseedges.end(), pel.begin(), pel.end());
+        {   // edge types: 0 mono, 1 stereo, 2 second camera (needs a rigid transform mTrl with a non-zero quaternion)
+            bool any2 = false;
+            for (int e = 0; e < H.n_edges && H.edge_stereo; e++) {
+                if (H.edge_stereo[e] > 2) { delete b; g_ba_error = "edge_stereo must be 0, 1 or 2"; return ORBHIP_E_BADARG; }
+                any2 = any2 || H.edge_stereo[e] == 2;
+            }
+            const double qn = H.Trl[0] * H.Trl[0] + H.Trl[1] * H.Trl[1] + H.Trl[2] * H.Trl[2] + H.Trl[3] * H.Trl[3];
+            if (any2 && !(qn > 0.0)) { delete b; g_ba_error = "edges of type 2 need Trl (mTrl) and the second camera"; return ORBHIP_E_BADARG; }
+        }
+        {   // chains of edges that share (point, pose): edges are point-major, so only a point's own edges are compared
+            std::vector<int> nxt(H.n_edges, -1); std::vector<uint8_t> dup(H.n_edges, 0);
+            for (int e0 = 0; e0 < H.n_edges;) {
+                int e1 = e0;
+                while (e1 < H.n_edges && H.edge_point[e1] == H.edge_point[e0]) e1++;
+                for (int a = e0; a < e1; a++)
+                    for (int c = a + 1; c < e1; c++)
+                        if (H.edge_pose[c] == H.edge_pose[a]) { if (nxt[a] < 0) nxt[a] = c; dup[c] = 1; break; }
+                e0 = e1;
+            }
+            edup.insert(edup.end(), dup.begin(), dup.end()); enext.insert(enext.end(), nxt.begin(), nxt.end());
+        }
         for (int e = 0; e < H.n_edges; e++) {
             epose.push_back(H.edge_pose[e]); epoint.push_back(H.edge_point[e]);
             eobs.push_back(H.edge_obs[3 * e]); eobs.push_back(H.edge_obs[3 * e + 1]); eobs.push_back(H.edge_obs[3 * e + 2]);
@@ -1146,7 +1302,7 @@ extern "C" int orbhip_ba_batch_create(orbhip_ctx *ctx, const orbhip_ba_graph *gr
 #define UP(dst, vec) do { auto *_p = ba_upload(b, vec); ok = ok && _p; dst = _p; } while (0)
 #define AL(dst, T, n) do { auto *_p = ba_alloc<T>(b, n); ok = ok && _p; dst = _p; } while (0)
     UP(B.gd, b->gd); UP(B.hidx, hidx); UP(B.edge_pose, epose); UP(B.edge_point, epoint); UP(B.edge_obs, eobs);
-    UP(B.edge_is2, eis2); UP(B.edge_stereo, est); UP(B.pt_start, ptstart); UP(B.pose_start, posestart); UP(B.pose_edges, poseedges);
+    UP(B.edge_is2, eis2); UP(B.edge_stereo, est); UP(B.edge_dup, edup); UP(B.edge_next, enext); UP(B.pt_start, ptstart); UP(B.pose_start, posestart); UP(B.pose_edges, poseedges);
     UP(B.ptmask, ptmask);
     AL(B.st, BaState, n_graphs);
     AL(B.poses, double, (size_t)2 * sumP * 7); AL(B.points, double, (size_t)2 * sumL * 3);
@@ -1407,8 +1563,8 @@ __device__ __forceinline__ double po_edge_chi2(const PoArgs &A, const double *po
     P[0] += pose[4]; P[1] += pose[5]; P[2] += pose[6];
     if (ob[2] < 0 && A.cam_model == 1) {               // OptimizableTypes.h:41-45 with pCamera = KannalaBrandt8 (:52-69)
         const double x2y2 = P[0] * P[0] + P[1] * P[1];
-        const double theta = (double)atan2f(sqrtf((float)x2y2), (float)P[2]);
-        const double psi = (double)atan2f((float)P[1], (float)P[0]);
+        const double theta = (double)(float)atan2((double)sqrtf((float)x2y2), (double)(float)P[2]);
+        const double psi = (double)(float)atan2((double)(float)P[1], (double)(float)P[0]);
         const double t2 = theta * theta, t3 = theta * t2, t5 = t3 * t2, t7 = t5 * t2, t9 = t7 * t2;
         const double r = theta + A.kb[0] * t3 + A.kb[1] * t5 + A.kb[2] * t7 + A.kb[3] * t9;
         er[0] = ob[0] - (A.fx * r * cos(psi) + A.cx);

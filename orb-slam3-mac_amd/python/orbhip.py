@@ -285,12 +285,22 @@ def synth_frames(w, h, n, seed=20241004, first=0):
 
 
 # ---------------------------------------------------------------- local BA (Optimizer::LocalBundleAdjustment core)
+def rig2_fields(g):
+    """Trl, fx2, fy2, cx2, cy2, camera2_model, kb2 of a graph dict (g.get('rig2') = dict(Trl, cam=(fx,fy,cx,cy), kb or None))."""
+    r = g.get("rig2")
+    if r is None:
+        return ((cd * 7)(0, 0, 0, 0, 0, 0, 0), 0.0, 0.0, 0.0, 0.0, 0, (cd * 4)(0, 0, 0, 0))
+    kb2 = r.get("kb")
+    return ((cd * 7)(*r["Trl"]), *[float(c) for c in r["cam"]], 1 if kb2 is not None else 0, (cd * 4)(*(kb2 if kb2 is not None else (0, 0, 0, 0))))
+
+
 class BaGraph(C.Structure):
     _fields_ = [("n_poses", C.c_int32), ("n_points", C.c_int32), ("n_edges", C.c_int32),
                 ("pose_fixed", vp), ("edge_pose", vp), ("edge_point", vp), ("edge_obs", vp),
                 ("edge_inv_sigma2", vp), ("edge_stereo", vp),
                 ("fx", cd), ("fy", cd), ("cx", cd), ("cy", cd), ("bf", cd),
-                ("camera_model", C.c_int32), ("kb", cd * 4)]
+                ("camera_model", C.c_int32), ("kb", cd * 4),
+                ("Trl", cd * 7), ("fx2", cd), ("fy2", cd), ("cx2", cd), ("cy2", cd), ("camera2_model", C.c_int32), ("kb2", cd * 4)]
 
 
 class BaParams(C.Structure):
@@ -361,7 +371,7 @@ class BaBatch:
             kb = g.get("kb")                      # KannalaBrandt8 k1..k4 for the monocular edges, None = Pinhole
             arr[i] = BaGraph(g["n_poses"], g["n_points"], g["n_edges"], *[a.ctypes.data for a in k],
                              g["fx"], g["fy"], g["cx"], g["cy"], g["bf"], 1 if kb is not None else 0,
-                             (cd * 4)(*(kb if kb is not None else (0, 0, 0, 0))))
+                             (cd * 4)(*(kb if kb is not None else (0, 0, 0, 0))), *rig2_fields(g))
             self.sizes.append((g["n_poses"], g["n_points"], g["n_edges"]))
         self.poses = [np.ascontiguousarray(g["poses0"], np.float64).copy() for g in graphs]
         self.points = [np.ascontiguousarray(g["points0"], np.float64).copy() for g in graphs]

@@ -58,8 +58,10 @@ def _exp_so3(w):
 
 
 def make_graph(n_kf=50, n_pts=2000, obs=10, seed=0, n_fixed=2, outlier_frac=0.05, stereo_frac=0.0,
-               pose_noise=(0.01, 0.05), point_noise=0.05, pixel_noise=1.0, kb8=None):
-    """kb8 = (k1..k4): the monocular observations come from a KannalaBrandt8 camera (fisheye), else Pinhole."""
+               pose_noise=(0.01, 0.05), point_noise=0.05, pixel_noise=1.0, kb8=None, rig2=None, right_frac=0.5):
+    """kb8 = (k1..k4): the monocular observations come from a KannalaBrandt8 camera (fisheye), else Pinhole.
+    rig2 = dict(Trl=(qx,qy,qz,qw,tx,ty,tz), cam=(fx,fy,cx,cy), kb=(k1..k4)|None): a second, rigidly attached camera; a
+    fraction right_frac of the observations is also seen there (edge type 2, EdgeSE3ProjectXYZToBody)."""
     rng = np.random.default_rng(seed)
     fx = fy = 458.0
     cx, cy, W, H = 320.0, 240.0, 640, 480
@@ -103,6 +105,20 @@ def make_graph(n_kf=50, n_pts=2000, obs=10, seed=0, n_fixed=2, outlier_frac=0.05
             e_pose.append(k); e_point.append(l); e_st.append(1 if st else 0)
             e_obs.append([np.float32(uu), np.float32(vv), np.float32(ur) if st else 0.0])
             e_is2.append(float(inv_sig2[octv]))
+            if rig2 is not None and rng.random() < right_frac:
+                Rrl = _R_from_quat(np.array(rig2["Trl"][:4])); trl = np.array(rig2["Trl"][4:])
+                Xr = Rrl @ Pc[k] + trl
+                f2x, f2y, c2x, c2y = rig2["cam"]
+                if rig2.get("kb") is not None:
+                    u2, v2 = kb8_project(Xr[None, :], f2x, f2y, c2x, c2y, rig2["kb"]); u2, v2 = float(u2[0]), float(v2[0])
+                else:
+                    u2, v2 = f2x * Xr[0] / Xr[2] + c2x, f2y * Xr[1] / Xr[2] + c2y
+                o2 = int(rng.integers(0, 8)); s2 = pixel_noise * 1.2 ** o2
+                u2 += rng.normal(0, s2); v2 += rng.normal(0, s2)
+                if rng.random() < outlier_frac:
+                    u2 += rng.choice([-30.0, 30.0])
+                e_pose.append(k); e_point.append(l); e_st.append(2)
+                e_obs.append([np.float32(u2), np.float32(v2), 0.0]); e_is2.append(float(inv_sig2[o2]))
     # perturbed initial estimates, float32-rounded
     poses0 = np.zeros((n_kf, 7))
     poses_gt = np.zeros((n_kf, 7))
@@ -122,7 +138,7 @@ def make_graph(n_kf=50, n_pts=2000, obs=10, seed=0, n_fixed=2, outlier_frac=0.05
     return dict(n_poses=n_kf, n_points=n_pts, n_edges=len(e_pose), pose_fixed=fixed,
                 edge_pose=np.array(e_pose, np.int32), edge_point=np.array(e_point, np.int32),
                 edge_obs=np.array(e_obs, np.float64).reshape(-1, 3), edge_inv_sigma2=np.array(e_is2, np.float64),
-                edge_stereo=np.array(e_st, np.uint8), fx=fx, fy=fy, cx=cx, cy=cy, bf=bf, kb=kb8,
+                edge_stereo=np.array(e_st, np.uint8), fx=fx, fy=fy, cx=cx, cy=cy, bf=bf, kb=kb8, rig2=rig2,
                 poses0=poses0, points0=pts0, poses_gt=poses_gt, points_gt=X.copy())
 
 

@@ -11,7 +11,8 @@ class Graph(C.Structure):
                 ("pose_fixed", vp), ("edge_pose", vp), ("edge_point", vp), ("edge_obs", vp),
                 ("edge_inv_sigma2", vp), ("edge_stereo", vp),
                 ("fx", cd), ("fy", cd), ("cx", cd), ("cy", cd), ("bf", cd),
-                ("camera_model", C.c_int32), ("kb", cd * 4)]
+                ("camera_model", C.c_int32), ("kb", cd * 4),
+                ("Trl", cd * 7), ("fx2", cd), ("fy2", cd), ("cx2", cd), ("cy2", cd), ("camera2_model", C.c_int32), ("kb2", cd * 4)]
 
 
 class Params(C.Structure):
@@ -37,12 +38,21 @@ lib.orc_se3_exp.argtypes = [vp, vp, vp]
 lib.orc_se3_oplus.argtypes = [vp, vp]
 lib.orc_ba_edge.argtypes = [vp, vp, vp, ci, cd, cd, cd, cd, cd, vp, vp, vp]
 lib.orc_ba_edge_kb8.argtypes = [vp, vp, vp, cd, cd, cd, cd, vp, vp, vp, vp]
+lib.orc_ba_edge_tobody.argtypes = [C.POINTER(Graph), vp, vp, vp, vp, vp, vp]
 
 
 def default_params():
     p = Params()
     lib.orc_ba_default_params(C.byref(p))
     return p
+
+
+def rig2_fields(g):
+    r = g.get("rig2")
+    if r is None:
+        return ((cd * 7)(0, 0, 0, 0, 0, 0, 0), 0.0, 0.0, 0.0, 0.0, 0, (cd * 4)(0, 0, 0, 0))
+    kb2 = r.get("kb")
+    return ((cd * 7)(*r["Trl"]), *[float(c) for c in r["cam"]], 1 if kb2 is not None else 0, (cd * 4)(*(kb2 if kb2 is not None else (0, 0, 0, 0))))
 
 
 def merge_params():
@@ -58,7 +68,8 @@ def make_cgraph(g, cls=Graph):
             np.ascontiguousarray(g["edge_inv_sigma2"], np.float64), np.ascontiguousarray(g["edge_stereo"], np.uint8)]
     kb = g.get("kb")
     s = cls(g["n_poses"], g["n_points"], g["n_edges"], *[k.ctypes.data for k in keep],
-            g["fx"], g["fy"], g["cx"], g["cy"], g["bf"], 1 if kb is not None else 0, (cd * 4)(*(kb if kb is not None else (0, 0, 0, 0))))
+            g["fx"], g["fy"], g["cx"], g["cy"], g["bf"], 1 if kb is not None else 0, (cd * 4)(*(kb if kb is not None else (0, 0, 0, 0))),
+            *rig2_fields(g))
     return s, keep
 
 

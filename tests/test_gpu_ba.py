@@ -164,3 +164,22 @@ def test_ba_kannala_brandt_camera(gpu_ctx):
     graphs = [synth_ba.make_graph(n_kf=12, n_pts=300, obs=6, seed=71, kb8=kb),
               synth_ba.make_graph(n_kf=10, n_pts=200, obs=5, seed=72, kb8=kb, stereo_frac=0.3)]   # stereo edges stay pinhole (types_six_dof_expmap)
     _check(gpu_ctx, graphs)
+
+
+def test_ba_second_camera_tobody_edges(gpu_ctx):
+    """EdgeSE3ProjectXYZToBody (rows B2 / B3): observations in the second camera of a rigid fisheye pair (mTrl, mpCamera2),
+    mixed with left-camera KannalaBrandt8 edges; plus a pinhole second camera."""
+    import orbhip
+    import synth_ba
+    kb = (-0.0034, 0.0007, -0.0021, 0.0002)
+    rig = dict(Trl=(0.004, -0.012, 0.002, 0.99991, -0.101, 0.0007, 0.0012), cam=(190.4, 190.6, 252.7, 255.0), kb=(0.0031, 0.0007, -0.0019, 0.0003))
+    rig_pin = dict(Trl=(0.0, 0.01, 0.0, 0.99995, -0.11, 0.0, 0.0), cam=(458.0, 458.0, 320.0, 240.0), kb=None)
+    graphs = [synth_ba.make_graph(n_kf=12, n_pts=300, obs=6, seed=91, kb8=kb, rig2=rig),
+              synth_ba.make_graph(n_kf=10, n_pts=200, obs=5, seed=92, rig2=rig_pin, right_frac=0.8)]
+    assert all((g["edge_stereo"] == 2).sum() > 300 for g in graphs)
+    _check(gpu_ctx, graphs)
+    _check(gpu_ctx, graphs[:1], orbhip.ba_merge_params())         # depth gate of the level-1 classification uses the right camera's z
+    # type-2 edges without a rig are rejected
+    bad = dict(graphs[0]); bad["rig2"] = None
+    with pytest.raises(orbhip.OrbHipError):
+        orbhip.BaBatch(gpu_ctx, [bad])

@@ -484,3 +484,57 @@ def test_kb8_ba_and_pose_recover_noise_free_solution():
     p = synth_ba.make_pose_problem(62, n=300, outlier_frac=0.0, noise=False, kb8=KB8)
     r, pose, o, _ = ob.pose_optimization(p["Xw"], p["obs"], p["inv_sigma2"], p["cam"], p["pose0"], kb8=KB8)
     assert r == 300 and _pose_err(pose, p["pose_true"]) < 5e-5
+
+
+RIG2 = dict(Trl=(0.004, -0.012, 0.002, 0.99991, -0.101, 0.0007, 0.0012), cam=(190.4, 190.6, 252.7, 255.0), kb=(0.0031, 0.0007, -0.0019, 0.0003))
+
+
+def _rig_graph_struct():
+    import oracle_ba_bind as ob
+    g = dict(n_poses=0, n_points=0, n_edges=0, pose_fixed=np.zeros(1, np.uint8), edge_pose=np.zeros(1, np.int32), edge_point=np.zeros(1, np.int32),
+             edge_obs=np.zeros(3), edge_inv_sigma2=np.zeros(1), edge_stereo=np.zeros(1, np.uint8), fx=190.9, fy=190.9, cx=254.9, cy=256.8, bf=0.0,
+             kb=KB8, rig2=RIG2)
+    return ob.make_cgraph(g)
+
+
+def test_tobody_edge_jacobians_against_finite_differences():
+    """EdgeSE3ProjectXYZToBody (OptimizableTypes.h:112-141, .cpp:192-213): observation in the second camera of a rigid pair."""
+    import ctypes as C
+    import oracle_ba_bind as ob
+    cg, keep = _rig_graph_struct()
+    rng = np.random.default_rng(8)
+    for _ in range(15):
+        q = rng.normal(0, 1, 4); q /= np.linalg.norm(q)
+        if q[3] < 0: q = -q
+        pose = np.concatenate([q, rng.normal(0, 1, 3)])
+        x, y, z, w = q
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        Xc = np.array([rng.uniform(-2, 2), rng.uniform(-2, 2), rng.uniform(1.5, 6)])
+        X = R.T @ (Xc - pose[4:])
+        obs = np.array([250.0, 260.0, 0.0])
+        e = np.zeros(3); Jx = np.zeros(9); Jt = np.zeros(18)
+        f = lambda P, XX, out: ob.lib.orc_ba_edge_tobody(C.byref(cg), P.ctypes.data, XX.ctypes.data, obs.ctypes.data, out.ctypes.data, np.zeros(9).ctypes.data, np.zeros(18).ctypes.data)
+        ob.lib.orc_ba_edge_tobody(C.byref(cg), pose.ctypes.data, X.ctypes.data, obs.ctypes.data, e.ctypes.data, Jx.ctypes.data, Jt.ctypes.data)
+        h = 1e-4
+        for a in range(3):
+            Xp, Xm = X.copy(), X.copy(); Xp[a] += h; Xm[a] -= h
+            ep, em = np.zeros(3), np.zeros(3); f(pose, Xp, ep); f(pose, Xm, em)
+            np.testing.assert_allclose((ep[:2] - em[:2]) / (2 * h), Jx.reshape(3, 3)[:2, a], atol=0.15, rtol=5e-3)
+        for a in range(6):
+            d = np.zeros(6); d[a] = h
+            pp, pm = pose.copy(), pose.copy()
+            ob.lib.orc_se3_oplus(d.ctypes.data, pp.ctypes.data); ob.lib.orc_se3_oplus((-d).ctypes.data, pm.ctypes.data)
+            ep, em = np.zeros(3), np.zeros(3); f(pp, X, ep); f(pm, X, em)
+            np.testing.assert_allclose((ep[:2] - em[:2]) / (2 * h), Jt.reshape(3, 6)[:2, a], atol=0.15, rtol=5e-3)
+
+
+def test_rig_ba_recovers_noise_free_solution():
+    import oracle_ba_bind as ob
+    import synth_ba
+    g = synth_ba.make_graph(n_kf=8, n_pts=150, obs=6, seed=81, outlier_frac=0.0, pixel_noise=0.0, kb8=KB8, rig2=RIG2)
+    assert (g["edge_stereo"] == 2).sum() > 200
+    rc, poses, pts, out, st = ob.solve(g)
+    assert rc == 0 and st["discarded"] == 0 and out.sum() == 0
+    assert np.abs(poses[:, 4:] - g["poses_gt"][:, 4:]).max() < 5e-4 and np.abs(pts - g["points_gt"]).max() < 2e-3
