@@ -355,10 +355,21 @@ int orbhip_mfma_f64_peak_tflops(orbhip_ctx *ctx, double *tflops_out);
  * return value nInitialCorrespondences - nBad.  d_stats may be NULL, else [f][4] = rounds, LM iterations,
  * LM trials, nBad.  max_edges <= 8192.  kb8_k: HOST pointer to k1..k4 when pFrame->mpCamera is a KannalaBrandt8
  * (monocular edges then project through src/CameraModels/KannalaBrandt8.cpp:52-69,166-195), NULL = Pinhole.
- * All other pointers DEVICE; asynchronous on the context's stream. */
+ * cam2 (HOST pointer, may be NULL) + d_right [f][max_edges] (DEVICE, may be NULL): when pFrame->mpCamera2 exists
+ * (:960-1037), d_right[e] = 1 marks an observation made in the second camera -- EdgeSE3ProjectXYZOnlyPoseToBody
+ * (include/OptimizableTypes.h:59-87, src/OptimizableTypes.cpp:82-106); such rows carry uRight < 0 (2-D residual,
+ * monocular gate).  All other pointers DEVICE; asynchronous on the context's stream. */
+/* second camera of a rigid pair for orbhip_pose_optimization_device (pFrame->mpCamera2, pFrame->mTrl) */
+typedef struct {
+    double Trl[7];              /* mTrl as (qx,qy,qz,qw,tx,ty,tz) */
+    double fx, fy, cx, cy;
+    int32_t camera_model;       /* 0 Pinhole, 1 KannalaBrandt8 */
+    double kb[4];
+} orbhip_camera2;
 int orbhip_pose_optimization_device(orbhip_ctx *ctx, const double *d_Xw, const double *d_obs,
                                     const double *d_inv_sigma2, const int32_t *d_n_edges, int frames, int max_edges,
                                     double fx, double fy, double cx, double cy, double bf, const double *kb8_k,
+                                    const orbhip_camera2 *cam2, const uint8_t *d_right,
                                     double *d_pose, uint8_t *d_outlier, int32_t *d_n_inliers, int32_t *d_stats);
 
 #ifdef __cplusplus

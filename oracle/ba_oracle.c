@@ -683,8 +683,22 @@ struct po {
 };
 
 /* computeError of the two unary edges */
+/* camera-2 parameters of a pose problem as a graph struct (what the ToBody helpers read) */
+static void po_rig(const orc_pose_problem *P, orc_ba_graph *g)
+{
+    memset(g, 0, sizeof(*g));
+    memcpy(g->Trl, P->Trl, sizeof(g->Trl));
+    g->fx2 = P->fx2; g->fy2 = P->fy2; g->cx2 = P->cx2; g->cy2 = P->cy2; g->camera2_model = P->camera2_model;
+    memcpy(g->kb2, P->kb2, sizeof(g->kb2));
+}
 static void po_edge_error(const orc_pose_problem *P, const double pose[7], int e, double er[3])
 {
+    if (P->right && P->right[e]) {                         /* OptimizableTypes.h:69-73 */
+        orc_ba_graph g; double Pr[3];
+        po_rig(P, &g);
+        tobody_error(&g, pose, P->Xw + 3 * e, P->obs + 3 * e, er, Pr);
+        return;
+    }
     double Xc[3];
     const double *obs = P->obs + 3 * e;
     map_point(pose, P->Xw + 3 * e, Xc);
@@ -734,7 +748,8 @@ static void po_build(struct po *S)
         if (S->level[e]) continue;
         const int stereo = !(P->obs[3 * e + 2] < 0), D = stereo ? 3 : 2;
         double er[3], Jx[9], Jt[18], rho[2];
-        if (P->camera_model == 1 && !stereo) orc_ba_edge_kb8(S->pose, P->Xw + 3 * e, P->obs + 3 * e, P->fx, P->fy, P->cx, P->cy, P->kb, er, Jx, Jt);
+        if (P->right && P->right[e]) { orc_ba_graph g; po_rig(P, &g); orc_ba_edge_tobody(&g, S->pose, P->Xw + 3 * e, P->obs + 3 * e, er, Jx, Jt); }
+        else if (P->camera_model == 1 && !stereo) orc_ba_edge_kb8(S->pose, P->Xw + 3 * e, P->obs + 3 * e, P->fx, P->fy, P->cx, P->cy, P->kb, er, Jx, Jt);
         else orc_ba_edge(S->pose, P->Xw + 3 * e, P->obs + 3 * e, stereo, P->fx, P->fy, P->cx, P->cy, P->bf, er, Jx, Jt);
         const double *es = S->err + 3 * e;
         po_rho(S, e, rho);

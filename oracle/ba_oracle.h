@@ -91,6 +91,12 @@ typedef struct {
     double fx, fy, cx, cy, bf;
     int32_t camera_model;       /* as in orc_ba_graph (pFrame->mpCamera) */
     double kb[4];
+    /* pFrame->mpCamera2 != 0 (Optimizer.cc:960-1037): right[e] = 1 marks an observation in the second camera
+     * (EdgeSE3ProjectXYZOnlyPoseToBody, OptimizableTypes.h:59-87, OptimizableTypes.cpp:82-106); may be NULL */
+    const uint8_t *right;
+    double Trl[7], fx2, fy2, cx2, cy2;
+    int32_t camera2_model;
+    double kb2[4];
 } orc_pose_problem;
 typedef struct { int32_t rounds, iterations[4], lm_trials, n_bad; } orc_pose_stats;
 int orc_pose_optimization(const orc_pose_problem *P, double pose7[7], uint8_t *outlier, orc_pose_stats *stats);

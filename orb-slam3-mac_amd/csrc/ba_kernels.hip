@@ -1529,6 +1529,8 @@ struct PoArgs {
     int max_edges;
     double fx, fy, cx, cy, bf;
     int cam_model; double kb[4];
+    const uint8_t *right;               // [frames][max_edges] 1 = observation in the second camera (may be NULL)
+    double Trl[7], fx2, fy2, cx2, cy2, kb2[4]; int cam2_model;
     double *pose;
     uint8_t *outlier;
     int32_t *n_inliers, *stats;
@@ -1556,9 +1558,13 @@ __device__ __forceinline__ void po_block_sum(double (&v)[N], double (*red)[PO_NR
 }
 
 // computeError of the two unary edges; returns chi2 = e^T (inv_sigma2 I) e
-__device__ __forceinline__ double po_edge_chi2(const PoArgs &A, const double *pose, const double *X, const double *ob, double is2,
-                                               double *P, double *er)
+__device__ __forceinline__ double po_edge_chi2(const PoArgs &A, const BaGraphDev &cam, const double *pose, const double *X, const double *ob,
+                                               double is2, int right, double *P, double *er)
 {
+    if (right) {                                       // EdgeSE3ProjectXYZOnlyPoseToBody::computeError, OptimizableTypes.h:69-73
+        tobody_error(cam, pose, X, ob, P, er);
+        return (er[0] * er[0] + er[1] * er[1]) * is2;
+    }
     quat_rot(pose, X, P);
     P[0] += pose[4]; P[1] += pose[5]; P[2] += pose[6];
     if (ob[2] < 0 && A.cam_model == 1) {               // OptimizableTypes.h:41-45 with pCamera = KannalaBrandt8 (:52-69)
@@ -1599,6 +1605,9 @@ __global__ __launch_bounds__(PO_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     }
     BaGraphDev cam; cam.fx = A.fx; cam.fy = A.fy; cam.cx = A.cx; cam.cy = A.cy; cam.bf = A.bf;
     cam.cam_model = A.cam_model; for (int k = 0; k < 4; k++) cam.kb[k] = A.kb[k];
+    for (int k = 0; k < 7; k++) cam.Trl[k] = A.Trl[k];
+    cam.fx2 = A.fx2; cam.fy2 = A.fy2; cam.cx2 = A.cx2; cam.cy2 = A.cy2; cam.cam2_model = A.cam2_model; for (int k = 0; k < 4; k++) cam.kb2[k] = A.kb2[k];
+    const uint8_t *right = A.right ? A.right + (size_t)f * A.max_edges : nullptr;
     double pose0[7], pose[7], pose_ev[7], x[6] = {0, 0, 0, 0, 0, 0};
     for (int k = 0; k < 7; k++) pose0[k] = A.pose[7 * f + k];
     quat_norm_rot(pose0);                                                       // SE3Quat ctor
@@ -1630,10 +1639,12 @@ __global__ __launch_bounds__(PO_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
                     for (int k = 12; k < 18; k++) Jt[k] = 0;                     // monocular edge: third row empty (er[2] == 0)
                     const double w0 = is2[e];
-                    const double chi2 = po_edge_chi2(A, pose, Xw + 3 * e, ob, w0, P, er);
+                    const int rt = right ? right[e] : 0;
+                    const double chi2 = po_edge_chi2(A, cam, pose, Xw + 3 * e, ob, w0, rt, P, er);
                     if (robust) huber(chi2, stereo ? delta_s : delta_m, stereo ? dsqr_s : dsqr_m, &r0, &r1);
                     else { r0 = chi2; r1 = 1.; }
-                    edge_jacobians(cam, P, R, stereo, Jx, Jt);
+                    if (rt) tobody_jacobians(cam, pose, Xw + 3 * e, Jx, Jt);           // OptimizableTypes.cpp:82-106 (the pose block of the binary edge)
+                    else edge_jacobians(cam, P, R, stereo, Jx, Jt);
                     const double w = r1 * w0;
                     acc[0] += r0;
                     int h = 1;
@@ -1729,7 +1740,7 @@ __global__ __launch_bounds__(PO_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                         const double *ob = obs + 3 * e;
                         const int stereo = !(ob[2] < 0);
                         double P[3], er[3], r0, r1;
-                        const double chi2 = po_edge_chi2(A, pose, Xw + 3 * e, ob, is2[e], P, er);
+                        const double chi2 = po_edge_chi2(A, cam, pose, Xw + 3 * e, ob, is2[e], right ? right[e] : 0, P, er);
                         if (robust) huber(chi2, stereo ? delta_s : delta_m, stereo ? dsqr_s : dsqr_m, &r0, &r1);
                         else r0 = chi2;
                         tc[0] += r0;
@@ -1767,7 +1778,7 @@ __global__ __launch_bounds__(PO_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         for (int e = tid, k = 0; e < n; e += PO_THREADS, k++) {
             const double *ob = obs + 3 * e;
             double P[3], er[3];
-            const double chi2d = po_edge_chi2(A, ((level >> k) & 1u) ? pose : pose_ev, Xw + 3 * e, ob, is2[e], P, er);
+            const double chi2d = po_edge_chi2(A, cam, ((level >> k) & 1u) ? pose : pose_ev, Xw + 3 * e, ob, is2[e], right ? right[e] : 0, P, er);
             const float chi2 = (float)chi2d;
             const float gate = ob[2] < 0 ? 5.991f : 7.815f;
             if (chi2 > gate) { level |= 1u << k; bad[0] += 1; } else level &= ~(1u << k);
@@ -1789,6 +1800,7 @@ __global__ __launch_bounds__(PO_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 extern "C" int orbhip_pose_optimization_device(orbhip_ctx *ctx, const double *d_Xw, const double *d_obs,
                                                const double *d_inv_sigma2, const int32_t *d_n_edges, int frames, int max_edges,
                                                double fx, double fy, double cx, double cy, double bf, const double *kb8_k,
+                                               const orbhip_camera2 *cam2, const uint8_t *d_right,
                                                double *d_pose, uint8_t *d_outlier, int32_t *d_n_inliers, int32_t *d_stats)
 {
     if (!ctx || !d_Xw || !d_obs || !d_inv_sigma2 || !d_n_edges || frames <= 0 || max_edges <= 0 || max_edges > 8192 ||
@@ -1798,6 +1810,11 @@ extern "C" int orbhip_pose_optimization_device(orbhip_ctx *ctx, const double *d_
     A.Xw = d_Xw; A.obs = d_obs; A.inv_s2 = d_inv_sigma2; A.n = d_n_edges; A.max_edges = max_edges;
     A.fx = fx; A.fy = fy; A.cx = cx; A.cy = cy; A.bf = bf; A.pose = d_pose; A.outlier = d_outlier; A.n_inliers = d_n_inliers;
     A.cam_model = kb8_k ? 1 : 0; for (int k = 0; k < 4; k++) A.kb[k] = kb8_k ? kb8_k[k] : 0.0;
+    if ((d_right != nullptr) != (cam2 != nullptr)) { g_ba_error = "cam2 and d_right go together"; return ORBHIP_E_BADARG; }
+    A.right = d_right;
+    for (int k = 0; k < 7; k++) A.Trl[k] = cam2 ? cam2->Trl[k] : (k == 3 ? 1.0 : 0.0);
+    A.fx2 = cam2 ? cam2->fx : 0; A.fy2 = cam2 ? cam2->fy : 0; A.cx2 = cam2 ? cam2->cx : 0; A.cy2 = cam2 ? cam2->cy : 0;
+    A.cam2_model = cam2 ? cam2->camera_model : 0; for (int k = 0; k < 4; k++) A.kb2[k] = cam2 ? cam2->kb[k] : 0.0;
     A.stats = d_stats;
     hipLaunchKernelGGL(k_pose_opt, dim3(frames), dim3(PO_THREADS), 0, orbhip_ctx_stream_internal(ctx), A);
     return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;

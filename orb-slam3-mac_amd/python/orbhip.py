@@ -425,17 +425,27 @@ class BaBatch:
             self.h = None
 
 
-lib.orbhip_pose_optimization_device.argtypes = [vp, vp, vp, vp, vp, ci, ci, cd, cd, cd, cd, cd, vp, vp, vp, vp, vp]
+class Camera2(C.Structure):
+    _fields_ = [("Trl", cd * 7), ("fx", cd), ("fy", cd), ("cx", cd), ("cy", cd), ("camera_model", C.c_int32), ("kb", cd * 4)]
+
+
+lib.orbhip_pose_optimization_device.argtypes = [vp, vp, vp, vp, vp, ci, ci, cd, cd, cd, cd, cd, vp, vp, vp, vp, vp, vp, vp]
 
 
 def pose_optimization_device(ctx, d_Xw, d_obs, d_inv_sigma2, d_n_edges, frames, max_edges, cam, d_pose, d_outlier,
-                             d_n_inliers, d_stats=None, kb8=None):
+                             d_n_inliers, d_stats=None, kb8=None, rig2=None, d_right=None):
     """Optimizer::PoseOptimization, batched over frames; device addresses (ints); cam = (fx, fy, cx, cy, bf);
-    kb8 = (k1..k4) for a KannalaBrandt8 camera (host values), None = Pinhole."""
+    kb8 = (k1..k4) for a KannalaBrandt8 camera (host values), None = Pinhole; rig2 = dict(Trl, cam, kb) + d_right
+    (device address of per-edge flags) when some observations were made in a second, rigidly attached camera."""
     kb = (cd * 4)(*kb8) if kb8 is not None else None
+    c2 = None
+    if rig2 is not None:
+        k2 = rig2.get("kb")
+        c2 = C.byref(Camera2((cd * 7)(*rig2["Trl"]), *[float(c) for c in rig2["cam"]], 1 if k2 is not None else 0,
+                             (cd * 4)(*(k2 if k2 is not None else (0, 0, 0, 0)))))
     _chk(lib.orbhip_pose_optimization_device(ctx.h, d_Xw, d_obs, d_inv_sigma2, d_n_edges, frames, max_edges,
                                              float(cam[0]), float(cam[1]), float(cam[2]), float(cam[3]), float(cam[4]),
-                                             kb, d_pose, d_outlier, d_n_inliers, d_stats), "orbhip_pose_optimization_device")
+                                             kb, c2, d_right, d_pose, d_outlier, d_n_inliers, d_stats), "orbhip_pose_optimization_device")
 
 
 lib.orbhip_compute_stereo_matches_device.argtypes = [vp, vp, cf, cf, vp, vp, vp]

@@ -142,7 +142,7 @@ def make_graph(n_kf=50, n_pts=2000, obs=10, seed=0, n_fixed=2, outlier_frac=0.05
                 poses0=poses0, points0=pts0, poses_gt=poses_gt, points_gt=X.copy())
 
 
-def make_pose_problem(seed, n=800, stereo_frac=0.0, outlier_frac=0.1, noise=True, perturb=(0.02, 0.08), kb8=None):
+def make_pose_problem(seed, n=800, stereo_frac=0.0, outlier_frac=0.1, noise=True, perturb=(0.02, 0.08), kb8=None, rig2=None, right_frac=0.4):
     """Seeded synthetic Optimizer::PoseOptimization input (host-side generator, numpy only).
 
     Camera at a random pose looking at a cloud of n map points (float32-rounded, as Xw.at<float>), Pinhole
@@ -173,6 +173,20 @@ def make_pose_problem(seed, n=800, stereo_frac=0.0, outlier_frac=0.1, noise=True
     bad = rng.random(n) < outlier_frac
     uu = np.where(bad, uu + rng.choice([-40, 40], n), uu); vv = np.where(bad, vv + rng.choice([-40, 40], n), vv)
     is_st = rng.random(n) < stereo_frac
+    right = np.zeros(n, np.uint8)
+    if rig2 is not None:                                             # a fraction of the points is observed in the second camera instead
+        right = (rng.random(n) < right_frac).astype(np.uint8)
+        Rrl = _R_from_quat(np.array(rig2["Trl"][:4])); Xr = Xc @ Rrl.T + np.array(rig2["Trl"][4:])
+        f2x, f2y, c2x, c2y = rig2["cam"]
+        if rig2.get("kb") is not None:
+            u2, v2 = kb8_project(Xr, f2x, f2y, c2x, c2y, rig2["kb"])
+        else:
+            u2, v2 = f2x * Xr[:, 0] / Xr[:, 2] + c2x, f2y * Xr[:, 1] / Xr[:, 2] + c2y
+        if noise:
+            u2 = u2 + rng.normal(0, 1, n) * sig; v2 = v2 + rng.normal(0, 1, n) * sig
+        u2 = np.where(bad, u2 + 40.0, u2)
+        uu = np.where(right == 1, u2, uu); vv = np.where(right == 1, v2, vv)
+        is_st = is_st & (right == 0)
     obs = np.stack([uu, vv, np.where(is_st, np.maximum(ur, 0.5), -1.0)], 1).astype(np.float32).astype(np.float64)
     inv_s2 = (1.0 / (np.float32(1.2) ** octv.astype(np.float32)) ** 2).astype(np.float32).astype(np.float64)
     q_true = _quat_from_R(R)
@@ -182,5 +196,5 @@ def make_pose_problem(seed, n=800, stereo_frac=0.0, outlier_frac=0.1, noise=True
     Rd = np.eye(3) + (np.sin(th) / th * Kd + (1 - np.cos(th)) / th ** 2 * Kd @ Kd if th > 0 else 0)
     R0 = (Rd @ R).astype(np.float32).astype(np.float64); t0 = (Rd @ t + d[3:]).astype(np.float32).astype(np.float64)
     U, _, Vt = np.linalg.svd(R0); R0 = U @ Vt                               # Converter::toSE3Quat gets a float Tcw
-    return dict(Xw=Xw, obs=obs, inv_sigma2=inv_s2, cam=(fx, fy, cx, cy, bf), kb8=kb8, pose0=np.concatenate([_quat_from_R(R0), t0]),
+    return dict(Xw=Xw, obs=obs, inv_sigma2=inv_s2, cam=(fx, fy, cx, cy, bf), kb8=kb8, rig2=rig2, right=right if rig2 is not None else None, pose0=np.concatenate([_quat_from_R(R0), t0]),
                 pose_true=np.concatenate([q_true, t]), outlier_true=bad)

@@ -19,8 +19,16 @@ def _built():
     need = [os.path.join(ROOT, "orb-slam3-mac_amd", "lib", "liborbhip.so"),
             os.path.join(ROOT, "orb-slam3-mac_amd", "lib", "libsynth.so"),
             os.path.join(ROOT, "oracle", "liborb_oracle.so")]
-    if not all(os.path.exists(p) for p in need):
-        g.build()
+    import glob
+
+    def stale(lib, patterns):
+        if not os.path.exists(lib):
+            return True
+        t = os.path.getmtime(lib)
+        return any(os.path.getmtime(f) > t for pat in patterns for f in glob.glob(os.path.join(ROOT, pat)))
+    if (stale(need[0], ["orb-slam3-mac_amd/csrc/*", "include/*.h"]) or stale(need[1], ["orb-slam3-mac_amd/synth/*"]) or
+            stale(need[2], ["oracle/*.c", "oracle/*.h", "oracle/*.inc"])):
+        g.build()                      # incremental (make): only what is out of date
     yield
 
 

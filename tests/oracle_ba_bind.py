@@ -88,7 +88,8 @@ def solve(g, params=None, abort=None):
 # ------------------------------------------------------------------ PoseOptimization oracle
 class PoseProblem(C.Structure):
     _fields_ = [("n_edges", C.c_int32), ("Xw", vp), ("obs", vp), ("inv_sigma2", vp),
-                ("fx", cd), ("fy", cd), ("cx", cd), ("cy", cd), ("bf", cd), ("camera_model", C.c_int32), ("kb", cd * 4)]
+                ("fx", cd), ("fy", cd), ("cx", cd), ("cy", cd), ("bf", cd), ("camera_model", C.c_int32), ("kb", cd * 4),
+                ("right", vp), ("Trl", cd * 7), ("fx2", cd), ("fy2", cd), ("cx2", cd), ("cy2", cd), ("camera2_model", C.c_int32), ("kb2", cd * 4)]
 
 
 class PoseStats(C.Structure):
@@ -99,14 +100,16 @@ lib.orc_pose_optimization.argtypes = [C.POINTER(PoseProblem), vp, vp, C.POINTER(
 lib.orc_pose_optimization.restype = ci
 
 
-def pose_optimization(Xw, obs, inv_sigma2, cam, pose0, kb8=None):
+def pose_optimization(Xw, obs, inv_sigma2, cam, pose0, kb8=None, rig2=None, right=None):
     """Optimizer::PoseOptimization restated.  Returns (n_inliers, pose7, outlier[n], stats dict)."""
     Xw = np.ascontiguousarray(Xw, np.float64).reshape(-1, 3)
     obs = np.ascontiguousarray(obs, np.float64).reshape(-1, 3)
     w = np.ascontiguousarray(inv_sigma2, np.float64)
     n = len(Xw)
+    rt = None if right is None else np.ascontiguousarray(right, np.uint8)
     P = PoseProblem(n, Xw.ctypes.data, obs.ctypes.data, w.ctypes.data, *[float(c) for c in cam], 1 if kb8 is not None else 0,
-                    (cd * 4)(*(kb8 if kb8 is not None else (0, 0, 0, 0))))
+                    (cd * 4)(*(kb8 if kb8 is not None else (0, 0, 0, 0))), None if rt is None else rt.ctypes.data,
+                    *rig2_fields(dict(rig2=rig2)))
     pose = np.ascontiguousarray(pose0, np.float64).copy()
     out = np.zeros(max(n, 1), np.uint8)
     st = PoseStats()

@@ -17,13 +17,20 @@ def _run(gpu_ctx, probs, max_edges):
     for f, p in enumerate(probs):
         Xw[f, :n[f]] = p["Xw"]; obs[f, :n[f]] = p["obs"]; w[f, :n[f]] = p["inv_sigma2"]
     t = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (Xw, obs, w, n, pose)]
+    rig2 = probs[0].get("rig2")
+    d_right = None
+    if rig2 is not None:
+        rt = np.zeros((F, max_edges), np.uint8)
+        for f, p in enumerate(probs):
+            rt[f, :n[f]] = p["right"]
+        d_right = torch.from_numpy(rt).cuda()
     out = torch.full((F, max_edges), 9, dtype=torch.uint8, device="cuda")
     ninl = torch.full((F,), -9, dtype=torch.int32, device="cuda")
     stats = torch.full((F, 4), -9, dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
     orbhip.pose_optimization_device(gpu_ctx, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), F, max_edges,
                                     probs[0]["cam"], t[4].data_ptr(), out.data_ptr(), ninl.data_ptr(), stats.data_ptr(),
-                                    kb8=probs[0].get("kb8"))
+                                    kb8=probs[0].get("kb8"), rig2=rig2, d_right=None if d_right is None else d_right.data_ptr())
     gpu_ctx.synchronize()
     return t[4].cpu().numpy(), out.cpu().numpy(), ninl.cpu().numpy(), stats.cpu().numpy()
 
@@ -32,7 +39,8 @@ def _check(gpu_ctx, probs, max_edges):
     import oracle_ba_bind as ob
     pose, out, ninl, stats = _run(gpu_ctx, probs, max_edges)
     for f, p in enumerate(probs):
-        r, pose_ref, out_ref, st = ob.pose_optimization(p["Xw"], p["obs"], p["inv_sigma2"], p["cam"], p["pose0"], kb8=p.get("kb8"))
+        r, pose_ref, out_ref, st = ob.pose_optimization(p["Xw"], p["obs"], p["inv_sigma2"], p["cam"], p["pose0"], kb8=p.get("kb8"),
+                                                        rig2=p.get("rig2"), right=p.get("right"))
         n = len(p["Xw"])
         assert ninl[f] == r, (f, ninl[f], r)
         np.testing.assert_array_equal(out[f, :n], out_ref)
@@ -104,3 +112,14 @@ def test_pose_optimization_kannala_brandt_camera(gpu_ctx):
         n = len(p["Xw"])
         np.testing.assert_allclose(pose[f], pose_ref, rtol=0, atol=1e-5)
         assert int(np.sum(out[f, :n] != out_ref)) <= 2 and abs(int(ninl[f]) - r) <= 2
+
+
+def test_pose_optimization_second_camera(gpu_ctx):
+    """pFrame->mpCamera2 (Optimizer.cc:960-1037): left-camera edges through KannalaBrandt8 + EdgeSE3ProjectXYZOnlyPoseToBody
+    for the observations made in the second camera."""
+    import synth_ba
+    kb = (-0.0034, 0.0007, -0.0021, 0.0002)
+    rig = dict(Trl=(0.004, -0.012, 0.002, 0.99991, -0.101, 0.0007, 0.0012), cam=(458.0, 457.0, 322.0, 238.0), kb=(0.0031, 0.0007, -0.0019, 0.0003))
+    probs = [synth_ba.make_pose_problem(950 + k, n=n, outlier_frac=of, kb8=kb, rig2=rig) for k, (n, of) in enumerate([(700, 0.1), (900, 0.0), (50, 0.2)])]
+    assert all(p["right"].sum() > 10 for p in probs)
+    _check(gpu_ctx, probs, 1024)

@@ -538,3 +538,16 @@ def test_rig_ba_recovers_noise_free_solution():
     rc, poses, pts, out, st = ob.solve(g)
     assert rc == 0 and st["discarded"] == 0 and out.sum() == 0
     assert np.abs(poses[:, 4:] - g["poses_gt"][:, 4:]).max() < 5e-4 and np.abs(pts - g["points_gt"]).max() < 2e-3
+
+
+def test_pose_optimization_second_camera_oracle():
+    import oracle_ba_bind as ob
+    import synth_ba
+    rig = dict(Trl=(0.004, -0.012, 0.002, 0.99991, -0.101, 0.0007, 0.0012), cam=(458.0, 457.0, 322.0, 238.0), kb=(0.0031, 0.0007, -0.0019, 0.0003))
+    p = synth_ba.make_pose_problem(63, n=400, outlier_frac=0.0, noise=False, kb8=KB8, rig2=rig)
+    assert 100 < p["right"].sum() < 300
+    r, pose, o, _ = ob.pose_optimization(p["Xw"], p["obs"], p["inv_sigma2"], p["cam"], p["pose0"], kb8=KB8, rig2=rig, right=p["right"])
+    assert r == 400 and _pose_err(pose, p["pose_true"]) < 5e-5
+    # the same observations WITHOUT the rig information (treated as left-camera) cannot be explained
+    r2, pose2, o2, _ = ob.pose_optimization(p["Xw"], p["obs"], p["inv_sigma2"], p["cam"], p["pose0"], kb8=KB8)
+    assert r2 < 350
