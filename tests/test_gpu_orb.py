@@ -226,3 +226,32 @@ def test_graph_mode_is_identical_and_tracks_new_input(gpu_ctx):
         for f in range(4):
             assert a[f][0].tobytes() == c[f][0].tobytes() and a[f][1].tobytes() == c[f][1].tobytes() and a[f][2] == c[f][2]
     eager.close(); graph.close()
+
+
+def test_extract_random_geometries(gpu_ctx):
+    """Seeded sweep over image sizes, level counts, scale factors (up to the 2.0 limit), thresholds and feature budgets:
+    bit-exact final output for every combination (catches tile / apron / table-size assumptions)."""
+    import orbhip
+    import oracle_bind as ob
+    rng = np.random.default_rng(2024)
+    done = 0
+    while done < 10:
+        nlev = int(rng.integers(1, 9)); scale = float(np.round(rng.uniform(1.1, 2.0), 2))
+        if done == 0:
+            nlev, scale = 3, 2.0
+        smin = 75 * scale ** (nlev - 1)
+        w = int(rng.integers(int(smin), int(smin) + 500)); h = int(rng.integers(int(smin * 0.8) + 1, int(smin * 0.8) + 400))
+        wl, hl = w / scale ** (nlev - 1), h / scale ** (nlev - 1)
+        if (wl - 33) < 0.6 * (hl - 31) or w > 1400 or h > 1100:      # nIni = round(W/H) must be >= 1 on every level (ORBextractor.cc:541)
+            continue
+        nfeat = int(rng.integers(50, 1500)); ini = int(rng.integers(8, 40)); mn = int(rng.integers(2, ini))
+        lap = (int(rng.integers(0, w // 2)), int(rng.integers(w // 2, w + 50)))
+        ext = orbhip.Extractor(gpu_ctx, nfeat, scale, nlev, ini, mn)
+        ora = ob.OracleExtractor(nfeat, scale, nlev, ini, mn)
+        imgs = orbhip.synth_frames(w, h, 2, seed=int(rng.integers(1, 1 << 30)))
+        got = ext.extract_host(imgs, lap)
+        for f in range(2):
+            kp, desc, mono = ora.extract(imgs[f], lap)
+            assert got[f][2] == mono and got[f][0].tobytes() == kp.tobytes() and got[f][1].tobytes() == desc.tobytes(), (w, h, nlev, scale, nfeat, ini, mn, lap)
+        ext.close()
+        done += 1
