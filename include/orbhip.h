@@ -214,6 +214,23 @@ int orbhip_search_local_map_device(orbhip_ctx *ctx, const orbhip_proj_query *d_q
                                    float max_y, int th_high, float nn_ratio, int32_t *d_train_match,
                                    int32_t *d_nmatches);
 
+/* The search part of ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, th, bRight)
+ * (src/ORBmatcher.cc:1403-1613, NLeft == -1; LocalMapping::SearchInNeighbors, src/LocalMapping.cc:781-860), batched over
+ * (keyframe, point set) pairs.  The per-point geometry of :1430-1497 stays with the caller; each surviving point is one
+ * query: u, v = uv; radius = th * pKF->mvScaleFactors[nPredictedLevel]; ur = uv.x - bf*invz; min_level / max_level =
+ * nPredictedLevel-1 / nPredictedLevel (angle, has_obs unused).  Per query: the keypoint inside the window, at an allowed
+ * octave, whose reprojection error passes e2 * mvInvLevelSigma2[octave] <= 5.99 (7.8 with a right coordinate,
+ * mvuRight >= 0) and whose descriptor distance is smallest (first minimum in GetFeaturesInArea order, :1527-1568).
+ * d_best_idx / d_best_dist [pairs][max_q] = bestIdx (-1 = none) / bestDist (256 = none); the caller applies
+ * bestDist <= TH_LOW and the Replace / AddObservation bookkeeping (:1572-1595) in order.  inv_level_sigma2: HOST array
+ * of nlevels floats.  At most 2900 keypoints per keyframe (they and their descriptors are LDS-resident; more sets the
+ * context status to ORBHIP_E_CAPACITY).  All other pointers DEVICE. */
+int orbhip_fuse_search_device(orbhip_ctx *ctx, const orbhip_proj_query *d_q, const uint8_t *d_desc_q, const int32_t *d_nq,
+                              int max_q, const orbhip_keypoint *d_kp, const uint8_t *d_desc, const float *d_u_right,
+                              const int32_t *d_n, int max_n, size_t frame_stride_kp, int pairs,
+                              const float *inv_level_sigma2, int nlevels, float min_x, float min_y, float max_x, float max_y,
+                              int32_t *d_best_idx, int32_t *d_best_dist);
+
 /* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:327-403), batched over map points: point p
  * has d_n[p] observing descriptors at d_desc + p*max_n*32 (the loop of :347-361 packs them, left then right index);
  * d_best_idx[p] = BestIdx: the descriptor with the least median Hamming distance to all of them (median = sorted

@@ -320,3 +320,36 @@ void orc_bow_transform(const uint8_t *f, const uint8_t *node_desc, const int32_t
     *word_id = node_word[final_id];
     *weight = node_weight[final_id];
 }
+
+/* ORBm:1499-1570 (NLeft == -1) */
+void orc_fuse_search(const orc_proj_query *q, const uint8_t *desc_q, int nq,
+                     const orc_keypoint *kp, const uint8_t *desc, const float *u_right, int n,
+                     const float *inv_level_sigma2, float min_x, float min_y, float max_x, float max_y,
+                     int32_t *best_idx, int32_t *best_dist)
+{
+    struct grid g;
+    grid_build(&g, kp, n, min_x, min_y, max_x, max_y);
+    int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * (n ? n : 1));
+    for (int t = 0; t < nq; t++) {
+        const int nc = grid_query(&g, kp, q[t].u, q[t].v, q[t].radius, -1, -1, cand, n);     /* ORBm:1503 */
+        int bestDist = 256, bestIdx = -1;
+        for (int c = 0; c < nc; c++) {
+            const int idx = cand[c];
+            const int kpLevel = kp[idx].octave;
+            if (kpLevel < q[t].min_level || kpLevel > q[t].max_level) continue;              /* ORBm:1527-1528 */
+            if (u_right && u_right[idx] >= 0) {                                              /* ORBm:1530-1545 */
+                const float ex = q[t].u - kp[idx].x, ey = q[t].v - kp[idx].y, er = q[t].ur - u_right[idx];
+                const float e2 = ex * ex + ey * ey + er * er;
+                if (e2 * inv_level_sigma2[kpLevel] > 7.8) continue;
+            } else {                                                                         /* ORBm:1546-1556 */
+                const float ex = q[t].u - kp[idx].x, ey = q[t].v - kp[idx].y;
+                const float e2 = ex * ex + ey * ey;
+                if (e2 * inv_level_sigma2[kpLevel] > 5.99) continue;
+            }
+            const int dist = orc_descriptor_distance(desc_q + 32 * (size_t)t, desc + 32 * (size_t)idx);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        best_idx[t] = bestIdx; best_dist[t] = bestDist;
+    }
+    free(cand); grid_free(&g);
+}

@@ -53,6 +53,18 @@ int orc_search_by_projection_map(const orc_proj_query *q, const uint8_t *desc_q,
                                  const orc_keypoint *kp, const uint8_t *desc, const float *u_right, int n,
                                  float min_x, float min_y, float max_x, float max_y,
                                  int th_high, float nn_ratio, int32_t *train_match);
+/* The search part of ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, th, bRight)
+ * (ORBmatcher.cc:1403-1613, NLeft == -1): per projected map point (the geometry of :1430-1497 stays with the caller) the
+ * keypoint of pKF inside the window with the smallest descriptor distance, among those at octave nPredictedLevel-1 or
+ * nPredictedLevel (:1527-1528) whose reprojection error passes e2 * invLevelSigma2 <= 5.99 (monocular keypoint) or
+ * <= 7.8 with the right coordinate (mvuRight >= 0) (:1530-1560); first minimum in GetFeaturesInArea order wins.
+ * q[t]: u, v = uv; radius = th * mvScaleFactors[nPredictedLevel]; ur = uv.x - bf*invz; min_level / max_level =
+ * nPredictedLevel-1 / nPredictedLevel.  best_idx[t] = bestIdx or -1, best_dist[t] = bestDist (256 if none); the caller
+ * applies bestDist <= TH_LOW and the Replace / AddObservation logic (:1572-1595) in order. */
+void orc_fuse_search(const orc_proj_query *q, const uint8_t *desc_q, int nq,
+                     const orc_keypoint *kp, const uint8_t *desc, const float *u_right, int n,
+                     const float *inv_level_sigma2, float min_x, float min_y, float max_x, float max_y,
+                     int32_t *best_idx, int32_t *best_dist);
 /* MapPoint::ComputeDistinctiveDescriptors (/root/reference/src/MapPoint.cc:327-403): among the n
  * descriptors that observe a map point, the one with the least median Hamming distance to all of them
  * (median = sorted row [int(0.5*(n-1))], self distance 0 included; first minimum wins).  Returns BestIdx (0 if n<=0). */

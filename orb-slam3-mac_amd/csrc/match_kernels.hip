@@ -369,7 +369,53 @@ extern "C" int orbhip_prev_matched_init_device(orbhip_ctx *ctx, const orbhip_key
 // The query loop is sequential: a keypoint claimed by a map point with observations drops out of later
 // queries (:2037-2039).
 #define SBP_CAP 2048
+struct OrbLevelSigma { float inv_sigma2[16]; };       // mvInvLevelSigma2, passed by value
 #define SBP_CELLS (SI_COLS * SI_ROWS)
+// Frame::AssignFeaturesToGrid (Frame.cc:377-408) as a CSR in LDS, built by one wave: cell by round() (PosInGrid, :716-726),
+// insertion order = index order.  rank = number of earlier keypoints in the same cell = the cell's counter before this trip +
+// the earlier lanes of the trip with the same cell.  cell_start must be zeroed by the caller; on return cell_start[c] is the
+// first slot of cell c = ix*48+iy in items[], and kx / ky / oct hold the keypoints' coordinates and octaves.
+__device__ void sbp_build_grid(uint32_t *cell_start, float *kx, float *ky, uint8_t *oct, uint16_t *items, uint16_t *cell_of,
+                               uint16_t *rank_of, const orbhip_keypoint *kp, int n, float min_x, float min_y, float inv_w, float inv_h, int lane)
+{
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        int c = 0xFFFF;
+        if (i < n) {
+            const orbhip_keypoint k = kp[i];
+            kx[i] = k.x; ky[i] = k.y; oct[i] = (uint8_t)k.octave;
+            const int px = (int)roundf(__fmul_rn(__fsub_rn(k.x, min_x), inv_w));
+            const int py = (int)roundf(__fmul_rn(__fsub_rn(k.y, min_y), inv_h));
+            if (px >= 0 && px < SI_COLS && py >= 0 && py < SI_ROWS) c = px * SI_ROWS + py;
+        }
+        int intra = 0;
+        for (int l = 0; l < 64; l++) {
+            const int cl = __builtin_amdgcn_readlane(c, l);
+            intra += (cl == c && l < lane);
+        }
+        if (i < n) {
+            cell_of[i] = (uint16_t)c;
+            if (c != 0xFFFF) rank_of[i] = (uint16_t)(cell_start[c + 1] + intra);
+        }
+        __syncthreads();                                          // every lane has read its counter
+        if (i < n && c != 0xFFFF) atomicAdd(&cell_start[c + 1], 1u);
+        __syncthreads();
+    }
+    {   // exclusive prefix over the cell counts (cell_start[c+1] holds count(c))
+        uint32_t carry = 0;
+        for (int c0 = 1; c0 <= SBP_CELLS; c0 += 64) {
+            const int c = c0 + lane;
+            const int v = c <= SBP_CELLS ? (int)cell_start[c] : 0;
+            const int inc = wave_incl_scan_i(v);
+            if (c <= SBP_CELLS) cell_start[c] = carry + (uint32_t)inc;
+            carry += (uint32_t)__shfl(inc, 63, 64);
+        }
+    }
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) { const int c = cell_of[i]; if (c != 0xFFFF) items[cell_start[c] + rank_of[i]] = (uint16_t)i; }
+    __syncthreads();
+}
+
 template <bool DESC_LDS>
 __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_query *q_, const uint8_t *descq_, const int32_t *nq_, int max_q,
                                                              const orbhip_keypoint *kp_, const uint8_t *desc_, const float *uright_,
@@ -412,48 +458,11 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
     for (int c = lane; c <= SBP_CELLS; c += 64) cell_start[c] = 0;
     for (int t = lane; t < nq; t += 64) { qm[t] = -1; qbin[t] = -1; }
     __syncthreads();
-    // ---- AssignFeaturesToGrid (Frame.cc:377-408): cell by round() (PosInGrid, :716-726), insertion order = index
-    // order.  rank = number of earlier keypoints in the same cell: cell counter before this trip + earlier
-    // lanes of the trip with the same cell.
-    for (int i0 = 0; i0 < n; i0 += 64) {
-        const int i = i0 + lane;
-        int c = 0xFFFF;
-        if (i < n) {
-            const orbhip_keypoint k = kp[i];
-            kx[i] = k.x; ky[i] = k.y; oct[i] = (uint8_t)k.octave;
-            holder[i] = tm[i] == -1 ? (int16_t)-1 : (int16_t)-2;
-            if (DESC_LDS) { dlds[2 * i] = dT[2 * i]; dlds[2 * i + 1] = dT[2 * i + 1]; }
-            const int px = (int)roundf(__fmul_rn(__fsub_rn(k.x, min_x), inv_w));
-            const int py = (int)roundf(__fmul_rn(__fsub_rn(k.y, min_y), inv_h));
-            if (px >= 0 && px < SI_COLS && py >= 0 && py < SI_ROWS) c = px * SI_ROWS + py;
-        }
-        int intra = 0;
-        for (int l = 0; l < 64; l++) {
-            const int cl = __builtin_amdgcn_readlane(c, l);
-            intra += (cl == c && l < lane);
-        }
-        if (i < n) {
-            cell_of[i] = (uint16_t)c;
-            if (c != 0xFFFF) rank_of[i] = (uint16_t)(cell_start[c + 1] + intra);
-        }
-        __syncthreads();                                          // every lane has read its counter
-        if (i < n && c != 0xFFFF) atomicAdd(&cell_start[c + 1], 1u);
-        __syncthreads();
+    for (int i = lane; i < n; i += 64) {
+        holder[i] = tm[i] == -1 ? (int16_t)-1 : (int16_t)-2;
+        if (DESC_LDS) { dlds[2 * i] = dT[2 * i]; dlds[2 * i + 1] = dT[2 * i + 1]; }
     }
-    // exclusive prefix over the cell counts (cell_start[c+1] holds count(c))
-    {
-        uint32_t carry = 0;
-        for (int c0 = 1; c0 <= SBP_CELLS; c0 += 64) {
-            const int c = c0 + lane;
-            const int v = c <= SBP_CELLS ? (int)cell_start[c] : 0;
-            const int inc = wave_incl_scan_i(v);
-            if (c <= SBP_CELLS) cell_start[c] = carry + (uint32_t)inc;
-            carry += (uint32_t)__shfl(inc, 63, 64);
-        }
-    }
-    __syncthreads();
-    for (int i = lane; i < n; i += 64) { const int c = cell_of[i]; if (c != 0xFFFF) items[cell_start[c] + rank_of[i]] = (uint16_t)i; }
-    __syncthreads();
+    sbp_build_grid(cell_start, kx, ky, oct, items, cell_of, rank_of, kp, n, min_x, min_y, inv_w, inv_h, lane);
     // ---- sequential query loop (ORBmatcher.cc:1987-2088)
     int nmatches = 0;
     const float factor = 1.0f / SI_HISTO;
@@ -734,5 +743,106 @@ extern "C" int orbhip_bow_transform_device(orbhip_ctx *ctx, const uint8_t *d_des
     hipLaunchKernelGGL(k_bow_transform, dim3((max_n + 255) / 256, frames), dim3(256), 0, orbhip_ctx_stream_internal(ctx), d_desc, d_n,
                        frames, max_n, frame_stride, d_node_desc, d_child_start, d_child_ids, d_node_word, d_node_weight, L, levelsup,
                        d_word_id, d_weight, d_nid);
+    return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
+}
+
+// ---------------------------------------------------------------------------- Fuse (search part)
+// ORBmatcher::Fuse(pKF, vpMapPoints, th, bRight) (ORBmatcher.cc:1403-1613, NLeft == -1): the window search of :1499-1570 for
+// every projected map point.  The queries do not depend on each other (the Replace / AddObservation bookkeeping of :1572-1595
+// is the caller's), so one lane owns one query: it walks the grid columns of its window in GetFeaturesInArea order against
+// LDS-resident keypoints AND descriptors (no dependent global gathers inside the lane-serial loop).
+__global__ __launch_bounds__(64) void k_fuse_search(const orbhip_proj_query *q_, const uint8_t *descq_, const int32_t *nq_, int max_q,
+                                                    const orbhip_keypoint *kp_, const uint8_t *desc_, const float *uright_,
+                                                    const int32_t *n_, int max_n, size_t kp_stride, OrbLevelSigma sig,
+                                                    float min_x, float min_y, float max_x, float max_y, int cap_n,
+                                                    int32_t *best_idx_, int32_t *best_dist_, int32_t *status)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t sbp_lds[];
+    uint4 *dlds = reinterpret_cast<uint4 *>(sbp_lds);                                 // [cap_n][2]
+    uint32_t *cell_start = reinterpret_cast<uint32_t *>(dlds + 2 * (size_t)cap_n);   // [SBP_CELLS + 1]
+    float *kx = reinterpret_cast<float *>(cell_start + SBP_CELLS + 1), *ky = kx + cap_n, *ur = ky + cap_n;
+    uint16_t *items = reinterpret_cast<uint16_t *>(ur + cap_n), *cell_of = items + cap_n, *rank_of = cell_of + cap_n;
+    uint8_t *oct = reinterpret_cast<uint8_t *>(rank_of + cap_n);
+    const int pair = blockIdx.x, lane = threadIdx.x;
+    const int n = n_[pair], nq = nq_[pair];
+    const orbhip_proj_query *Q = q_ + (size_t)pair * max_q;
+    const uint4 *dQ = reinterpret_cast<const uint4 *>(descq_ + (size_t)pair * max_q * 32);
+    const orbhip_keypoint *kp = kp_ + (size_t)pair * kp_stride;
+    const uint4 *dT = reinterpret_cast<const uint4 *>(desc_ + (size_t)pair * kp_stride * 32);
+    const float *uright = uright_ ? uright_ + (size_t)pair * kp_stride : nullptr;
+    int32_t *bi = best_idx_ + (size_t)pair * max_q, *bd = best_dist_ + (size_t)pair * max_q;
+    if (n > cap_n || n > max_n || nq > max_q) {
+        if (lane == 0) atomicExch(status, ORBHIP_E_CAPACITY);
+        for (int t = lane; t < min(nq, max_q); t += 64) { bi[t] = -1; bd[t] = 256; }
+        return;
+    }
+    const float inv_w = __fdiv_rn((float)SI_COLS, __fsub_rn(max_x, min_x));       // Frame.cc:334-335
+    const float inv_h = __fdiv_rn((float)SI_ROWS, __fsub_rn(max_y, min_y));
+    for (int c = lane; c <= SBP_CELLS; c += 64) cell_start[c] = 0;
+    for (int i = lane; i < n; i += 64) { dlds[2 * i] = dT[2 * i]; dlds[2 * i + 1] = dT[2 * i + 1]; ur[i] = uright ? uright[i] : -1.0f; }
+    __syncthreads();
+    sbp_build_grid(cell_start, kx, ky, oct, items, cell_of, rank_of, kp, n, min_x, min_y, inv_w, inv_h, lane);
+    for (int T = 0; T < nq; T += 64) {
+        const int t = T + lane;
+        if (t >= nq) continue;
+        const orbhip_proj_query qq = Q[t];
+        const float x = qq.u, y = qq.v, r = qq.radius;
+        int best = 256, besti = -1;
+        int c0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, min_x), r), inv_w)); if (c0 < 0) c0 = 0;   // Frame.cc:656-674
+        int c1 = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, min_x), r), inv_w)); if (c1 > SI_COLS - 1) c1 = SI_COLS - 1;
+        int r0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, min_y), r), inv_h)); if (r0 < 0) r0 = 0;
+        int r1 = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, min_y), r), inv_h)); if (r1 > SI_ROWS - 1) r1 = SI_ROWS - 1;
+        if (c0 < SI_COLS && c1 >= 0 && r0 < SI_ROWS && r1 >= 0) {
+            const uint4 a0 = dQ[2 * t], a1 = dQ[2 * t + 1];
+            for (int cx = c0; cx <= c1; cx++) {
+                const int k1 = (int)cell_start[cx * SI_ROWS + r1 + 1];
+                for (int k = (int)cell_start[cx * SI_ROWS + r0]; k < k1; k++) {
+                    const int idx = items[k];
+                    const float dx = __fsub_rn(kx[idx], x), dy = __fsub_rn(ky[idx], y);
+                    if (!(fabsf(dx) < r && fabsf(dy) < r)) continue;                                   // Frame.cc:704-708
+                    const int lv = oct[idx];
+                    if (lv < qq.min_level || lv > qq.max_level) continue;                              // ORBmatcher.cc:1527-1528
+                    const float ex = __fsub_rn(x, kx[idx]), ey = __fsub_rn(y, ky[idx]);
+                    const float kr = ur[idx];
+                    if (kr >= 0) {                                                                      // ORBmatcher.cc:1530-1545
+                        const float er = __fsub_rn(qq.ur, kr);
+                        const float e2 = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(er, er));
+                        if ((double)__fmul_rn(e2, sig.inv_sigma2[lv]) > 7.8) continue;
+                    } else {                                                                            // ORBmatcher.cc:1546-1556
+                        const float e2 = __fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey));
+                        if ((double)__fmul_rn(e2, sig.inv_sigma2[lv]) > 5.99) continue;
+                    }
+                    const int dist = hamming256(a0, a1, dlds[2 * idx], dlds[2 * idx + 1]);
+                    if (dist < best) { best = dist; besti = idx; }                                     // ORBmatcher.cc:1564-1568
+                }
+            }
+        }
+        bi[t] = besti; bd[t] = best;
+    }
+}
+
+extern "C" int orbhip_fuse_search_device(orbhip_ctx *ctx, const orbhip_proj_query *d_q, const uint8_t *d_desc_q, const int32_t *d_nq,
+                                         int max_q, const orbhip_keypoint *d_kp, const uint8_t *d_desc, const float *d_u_right,
+                                         const int32_t *d_n, int max_n, size_t frame_stride_kp, int pairs,
+                                         const float *inv_level_sigma2, int nlevels, float min_x, float min_y, float max_x, float max_y,
+                                         int32_t *d_best_idx, int32_t *d_best_dist)
+{
+    if (!ctx || !d_q || !d_desc_q || !d_nq || !d_kp || !d_desc || !d_n || pairs <= 0 || max_n <= 0 || max_q <= 0 || !inv_level_sigma2 ||
+        nlevels < 1 || nlevels > 16 || !d_best_idx || !d_best_dist || !(max_x > min_x) || !(max_y > min_y)) return ORBHIP_E_BADARG;
+    if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
+    OrbLevelSigma sig;
+    for (int l = 0; l < 16; l++) sig.inv_sigma2[l] = l < nlevels ? inv_level_sigma2[l] : 0.0f;
+    const int cap_n = ((max_n < 2900 ? max_n : 2900) + 7) & ~7;        // keypoints AND descriptors of a keyframe live in LDS (160 KB)
+    const size_t lds = (size_t)cap_n * (32 + 4 + 4 + 4 + 2 + 2 + 2 + 1) + sizeof(uint32_t) * (SBP_CELLS + 1) + 16;
+    if (lds > 160 * 1024 - 512) return ORBHIP_E_BADARG;
+    static thread_local size_t lds_set = 0;
+    if (lds > lds_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fuse_search), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return ORBHIP_E_HIP;
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(k_fuse_search, dim3(pairs), dim3(64), lds, orbhip_ctx_stream_internal(ctx), d_q, d_desc_q, d_nq, max_q, d_kp, d_desc,
+                       d_u_right, d_n, max_n, frame_stride_kp, sig, min_x, min_y, max_x, max_y, cap_n, d_best_idx, d_best_dist,
+                       orbhip_ctx_status_internal(ctx));
     return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
 }

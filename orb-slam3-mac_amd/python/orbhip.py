@@ -473,3 +473,15 @@ def bow_transform_device(ctx, d_desc, d_n, frames, max_n, frame_stride, voc, L, 
     """DBoW2 per-feature tree descent; voc = (d_node_desc, d_child_start, d_child_ids, d_node_word, d_node_weight)."""
     _chk(lib.orbhip_bow_transform_device(ctx.h, d_desc, d_n, frames, max_n, frame_stride, voc[0], voc[1], voc[2], voc[3], voc[4],
                                          L, levelsup, d_word_id, d_weight, d_nid), "orbhip_bow_transform_device")
+
+
+lib.orbhip_fuse_search_device.argtypes = [vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, sz, ci, vp, ci, cf, cf, cf, cf, vp, vp]
+
+
+def fuse_search_device(ctx, d_q, d_desc_q, d_nq, max_q, d_kp, d_desc, d_u_right, d_n, max_n, kp_stride, pairs, inv_level_sigma2,
+                       bounds, d_best_idx, d_best_dist):
+    """Search part of ORBmatcher::Fuse, batched; device addresses (ints); inv_level_sigma2 = host float array."""
+    sig = np.ascontiguousarray(inv_level_sigma2, np.float32)
+    _chk(lib.orbhip_fuse_search_device(ctx.h, d_q, d_desc_q, d_nq, max_q, d_kp, d_desc, d_u_right, d_n, max_n, kp_stride, pairs,
+                                       sig.ctypes.data, len(sig), bounds[0], bounds[1], bounds[2], bounds[3], d_best_idx, d_best_dist),
+         "orbhip_fuse_search_device")

@@ -12,6 +12,8 @@ lib.orc_search_by_projection.argtypes = [vp, vp, ci, vp, vp, vp, ci, cf, cf, cf,
 lib.orc_search_by_projection.restype = ci
 lib.orc_search_by_projection_map.argtypes = [vp, vp, ci, vp, vp, vp, ci, cf, cf, cf, cf, ci, cf, vp]
 lib.orc_search_by_projection_map.restype = ci
+lib.orc_fuse_search.argtypes = [vp, vp, ci, vp, vp, vp, ci, vp, cf, cf, cf, cf, vp, vp]
+lib.orc_fuse_search.restype = None
 lib.orc_distinctive_descriptor.argtypes = [vp, ci]
 lib.orc_distinctive_descriptor.restype = ci
 lib.orc_bow_transform.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, vp, vp, vp]
@@ -133,3 +135,15 @@ def bow_transform(feature, voc, levelsup):
                           voc["node_word"].ctypes.data, voc["node_weight"].ctypes.data, voc["L"], levelsup,
                           C.byref(wid), C.byref(w), C.byref(nid))
     return wid.value, w.value, nid.value
+
+
+def fuse_search(q, dq, kp, d, u_right, inv_level_sigma2, bounds):
+    """Search part of ORBmatcher::Fuse restated; returns (best_idx [nq], best_dist [nq])."""
+    q = np.ascontiguousarray(q, PROJ_QUERY_DTYPE); dq = np.ascontiguousarray(dq, np.uint8)
+    kp = np.ascontiguousarray(kp, KP_DTYPE); d = np.ascontiguousarray(d, np.uint8)
+    sig = np.ascontiguousarray(inv_level_sigma2, np.float32)
+    ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    bi = np.zeros(max(len(q), 1), np.int32); bd = np.zeros(max(len(q), 1), np.int32)
+    lib.orc_fuse_search(q.ctypes.data, dq.ctypes.data, len(q), kp.ctypes.data, d.ctypes.data, None if ur is None else ur.ctypes.data,
+                        len(kp), sig.ctypes.data, bounds[0], bounds[1], bounds[2], bounds[3], bi.ctypes.data, bd.ctypes.data)
+    return bi[:len(q)], bd[:len(q)]

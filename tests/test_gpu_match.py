@@ -362,3 +362,39 @@ def test_bow_transform_parity(gpu_ctx):
             for i in range(0, n, 7):
                 assert (int(wid[f, i]), float(w[f, i]), int(nid[f, i])) == om.bow_transform(desc[f, i], voc, levelsup)
             assert (wid[f, n:] == -9).all()
+
+
+@pytest.mark.parametrize("stereo", [False, True])
+def test_fuse_search_parity(gpu_ctx, stereo):
+    import torch
+    import orbhip
+    import oracle_match_bind as om
+    from test_oracle_match_ba import make_sbp_case
+    rng = np.random.default_rng(51 + stereo)
+    bounds = (0.0, 0.0, 640.0, 480.0)
+    sig = (np.float32(1.0) / (np.float32(1.2) ** np.arange(8, dtype=np.float32)) ** 2).astype(np.float32)
+    cases = [make_sbp_case(rng, n, nq, stereo) for n, nq in ((0, 10), (60, 0), (300, 500), (1000, 900), (2000, 2048))]
+    for c in cases:
+        c[0]["min_level"] = np.maximum(c[0]["max_level"], 0) - 1; c[0]["max_level"] = c[0]["min_level"] + 1
+        c[0]["radius"] = np.float32(3.0) * np.float32(1.2) ** c[0]["max_level"].astype(np.float32)
+    P, MQ, MN = len(cases), 2048, 2048
+    Q = np.zeros((P, MQ), orbhip.PROJ_QUERY_DTYPE); DQ = np.zeros((P, MQ, 32), np.uint8)
+    KP = np.zeros((P, MN), orbhip.KP_DTYPE); D = np.zeros((P, MN, 32), np.uint8); UR = np.full((P, MN), -1, np.float32)
+    nq = np.array([len(c[0]) for c in cases], np.int32); n = np.array([len(c[2]) for c in cases], np.int32)
+    for p, (q, dq, kp, d, ur, _) in enumerate(cases):
+        Q[p, :nq[p]] = q; DQ[p, :nq[p]] = dq; KP[p, :n[p]] = kp; D[p, :n[p]] = d
+        if ur is not None:
+            UR[p, :n[p]] = ur
+    t = [torch.from_numpy(a.view(np.uint8) if a.dtype in (orbhip.KP_DTYPE, orbhip.PROJ_QUERY_DTYPE) else a).cuda() for a in (Q, DQ, nq, KP, D, UR, n)]
+    bi = torch.full((P, MQ), -9, dtype=torch.int32, device="cuda"); bd = torch.full((P, MQ), -9, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    orbhip.fuse_search_device(gpu_ctx, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), MQ, t[3].data_ptr(), t[4].data_ptr(),
+                              t[5].data_ptr() if stereo else None, t[6].data_ptr(), MN, MN, P, sig, bounds, bi.data_ptr(), bd.data_ptr())
+    gpu_ctx.check_status()
+    bi, bd = bi.cpu().numpy(), bd.cpu().numpy()
+    hits = 0
+    for p, (q, dq, kp, d, ur, _) in enumerate(cases):
+        ri, rd = om.fuse_search(q, dq, kp, d, ur if stereo else None, sig, bounds)
+        np.testing.assert_array_equal(bi[p, :nq[p]], ri); np.testing.assert_array_equal(bd[p, :nq[p]], rd)
+        hits += int((ri >= 0).sum())
+    assert hits > 200

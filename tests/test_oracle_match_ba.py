@@ -551,3 +551,40 @@ def test_pose_optimization_second_camera_oracle():
     # the same observations WITHOUT the rig information (treated as left-camera) cannot be explained
     r2, pose2, o2, _ = ob.pose_optimization(p["Xw"], p["obs"], p["inv_sigma2"], p["cam"], p["pose0"], kb8=KB8)
     assert r2 < 350
+
+
+def test_fuse_search_oracle_against_python():
+    """Search part of ORBmatcher::Fuse: window + octave gate + chi2 reprojection gate + nearest descriptor."""
+    import oracle_match_bind as om
+    rng = np.random.default_rng(77)
+    bounds = (0.0, 0.0, 640.0, 480.0)
+    sig = (np.float32(1.0) / (np.float32(1.2) ** np.arange(8, dtype=np.float32)) ** 2).astype(np.float32)
+    for with_stereo in (False, True):
+        for n, nq in ((0, 4), (50, 0), (250, 120)):
+            q, dq, kp, d, ur, _ = make_sbp_case(rng, n, nq, with_stereo)
+            q["min_level"] = np.maximum(q["max_level"], 0) - 1; q["max_level"] = q["min_level"] + 1
+            q["radius"] = np.float32(3.0) * np.float32(1.2) ** q["max_level"].astype(np.float32)
+            bi, bd = om.fuse_search(q, dq, kp, d, ur, sig, bounds)
+            for t in range(nq):
+                cand = om.features_in_area(kp, bounds, float(q["u"][t]), float(q["v"][t]), float(q["radius"][t]), -1, -1)
+                best, besti = 256, -1
+                for idx in cand:
+                    lv = int(kp["octave"][idx])
+                    if lv < q["min_level"][t] or lv > q["max_level"][t]:
+                        continue
+                    ex = np.float32(q["u"][t]) - np.float32(kp["x"][idx]); ey = np.float32(q["v"][t]) - np.float32(kp["y"][idx])
+                    if ur is not None and ur[idx] >= 0:
+                        er = np.float32(q["ur"][t]) - np.float32(ur[idx])
+                        e2 = np.float32(np.float32(ex * ex + ey * ey) + er * er)
+                        if float(np.float32(e2 * sig[lv])) > 7.8:
+                            continue
+                    else:
+                        e2 = np.float32(ex * ex + ey * ey)
+                        if float(np.float32(e2 * sig[lv])) > 5.99:
+                            continue
+                    dist = int(np.unpackbits(dq[t] ^ d[idx]).sum())
+                    if dist < best:
+                        best, besti = dist, idx
+                assert (bi[t], bd[t]) == (besti, best), (t, bi[t], bd[t], besti, best)
+            if n == 250:
+                assert (bi >= 0).sum() > 8
