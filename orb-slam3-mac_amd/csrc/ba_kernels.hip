@@ -1558,16 +1558,17 @@ __device__ __forceinline__ void po_block_sum(double (&v)[N], double (*red)[PO_NR
 }
 
 // computeError of the two unary edges; returns chi2 = e^T (inv_sigma2 I) e
+template <bool GENERAL>
 __device__ __forceinline__ double po_edge_chi2(const PoArgs &A, const BaGraphDev &cam, const double *pose, const double *X, const double *ob,
                                                double is2, int right, double *P, double *er)
 {
-    if (right) {                                       // EdgeSE3ProjectXYZOnlyPoseToBody::computeError, OptimizableTypes.h:69-73
+    if (GENERAL && right) {                                       // EdgeSE3ProjectXYZOnlyPoseToBody::computeError, OptimizableTypes.h:69-73
         tobody_error(cam, pose, X, ob, P, er);
         return (er[0] * er[0] + er[1] * er[1]) * is2;
     }
     quat_rot(pose, X, P);
     P[0] += pose[4]; P[1] += pose[5]; P[2] += pose[6];
-    if (ob[2] < 0 && A.cam_model == 1) {               // OptimizableTypes.h:41-45 with pCamera = KannalaBrandt8 (:52-69)
+    if (GENERAL && ob[2] < 0 && A.cam_model == 1) {    // OptimizableTypes.h:41-45 with pCamera = KannalaBrandt8 (:52-69)
         const double x2y2 = P[0] * P[0] + P[1] * P[1];
         const double theta = (double)(float)atan2((double)sqrtf((float)x2y2), (double)(float)P[2]);
         const double psi = (double)(float)atan2((double)(float)P[1], (double)(float)P[0]);
@@ -1590,6 +1591,9 @@ __device__ __forceinline__ double po_edge_chi2(const PoArgs &A, const BaGraphDev
     return (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * is2;
 }
 
+// GENERAL = false: Pinhole camera, no second camera (the common case keeps its registers); true: KannalaBrandt8 and / or
+// observations in a second, rigidly attached camera.
+template <bool GENERAL>
 __global__ __launch_bounds__(PO_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pose_opt(PoArgs A)
 {
     __shared__ double red[4][PO_NRED];
@@ -1607,7 +1611,8 @@ __global__ __launch_bounds__(PO_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     cam.cam_model = A.cam_model; for (int k = 0; k < 4; k++) cam.kb[k] = A.kb[k];
     for (int k = 0; k < 7; k++) cam.Trl[k] = A.Trl[k];
     cam.fx2 = A.fx2; cam.fy2 = A.fy2; cam.cx2 = A.cx2; cam.cy2 = A.cy2; cam.cam2_model = A.cam2_model; for (int k = 0; k < 4; k++) cam.kb2[k] = A.kb2[k];
-    const uint8_t *right = A.right ? A.right + (size_t)f * A.max_edges : nullptr;
+    const uint8_t *right = (GENERAL && A.right) ? A.right + (size_t)f * A.max_edges : nullptr;
+    if (!GENERAL) cam.cam_model = 0;
     double pose0[7], pose[7], pose_ev[7], x[6] = {0, 0, 0, 0, 0, 0};
     for (int k = 0; k < 7; k++) pose0[k] = A.pose[7 * f + k];
     quat_norm_rot(pose0);                                                       // SE3Quat ctor
@@ -1639,11 +1644,11 @@ __global__ __launch_bounds__(PO_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
                     for (int k = 12; k < 18; k++) Jt[k] = 0;                     // monocular edge: third row empty (er[2] == 0)
                     const double w0 = is2[e];
-                    const int rt = right ? right[e] : 0;
-                    const double chi2 = po_edge_chi2(A, cam, pose, Xw + 3 * e, ob, w0, rt, P, er);
+                    const int rt = (GENERAL && right) ? right[e] : 0;
+                    const double chi2 = po_edge_chi2<GENERAL>(A, cam, pose, Xw + 3 * e, ob, w0, rt, P, er);
                     if (robust) huber(chi2, stereo ? delta_s : delta_m, stereo ? dsqr_s : dsqr_m, &r0, &r1);
                     else { r0 = chi2; r1 = 1.; }
-                    if (rt) tobody_jacobians(cam, pose, Xw + 3 * e, Jx, Jt);           // OptimizableTypes.cpp:82-106 (the pose block of the binary edge)
+                    if (GENERAL && rt) tobody_jacobians(cam, pose, Xw + 3 * e, Jx, Jt);   // OptimizableTypes.cpp:82-106 (the pose block of the binary edge)
                     else edge_jacobians(cam, P, R, stereo, Jx, Jt);
                     const double w = r1 * w0;
                     acc[0] += r0;
@@ -1740,7 +1745,7 @@ __global__ __launch_bounds__(PO_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                         const double *ob = obs + 3 * e;
                         const int stereo = !(ob[2] < 0);
                         double P[3], er[3], r0, r1;
-                        const double chi2 = po_edge_chi2(A, cam, pose, Xw + 3 * e, ob, is2[e], right ? right[e] : 0, P, er);
+                        const double chi2 = po_edge_chi2<GENERAL>(A, cam, pose, Xw + 3 * e, ob, is2[e], (GENERAL && right) ? right[e] : 0, P, er);
                         if (robust) huber(chi2, stereo ? delta_s : delta_m, stereo ? dsqr_s : dsqr_m, &r0, &r1);
                         else r0 = chi2;
                         tc[0] += r0;
@@ -1778,7 +1783,7 @@ __global__ __launch_bounds__(PO_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         for (int e = tid, k = 0; e < n; e += PO_THREADS, k++) {
             const double *ob = obs + 3 * e;
             double P[3], er[3];
-            const double chi2d = po_edge_chi2(A, cam, ((level >> k) & 1u) ? pose : pose_ev, Xw + 3 * e, ob, is2[e], right ? right[e] : 0, P, er);
+            const double chi2d = po_edge_chi2<GENERAL>(A, cam, ((level >> k) & 1u) ? pose : pose_ev, Xw + 3 * e, ob, is2[e], (GENERAL && right) ? right[e] : 0, P, er);
             const float chi2 = (float)chi2d;
             const float gate = ob[2] < 0 ? 5.991f : 7.815f;
             if (chi2 > gate) { level |= 1u << k; bad[0] += 1; } else level &= ~(1u << k);
@@ -1816,6 +1821,7 @@ extern "C" int orbhip_pose_optimization_device(orbhip_ctx *ctx, const double *d_
     A.fx2 = cam2 ? cam2->fx : 0; A.fy2 = cam2 ? cam2->fy : 0; A.cx2 = cam2 ? cam2->cx : 0; A.cy2 = cam2 ? cam2->cy : 0;
     A.cam2_model = cam2 ? cam2->camera_model : 0; for (int k = 0; k < 4; k++) A.kb2[k] = cam2 ? cam2->kb[k] : 0.0;
     A.stats = d_stats;
-    hipLaunchKernelGGL(k_pose_opt, dim3(frames), dim3(PO_THREADS), 0, orbhip_ctx_stream_internal(ctx), A);
+    if (A.cam_model || A.right) hipLaunchKernelGGL(k_pose_opt<true>, dim3(frames), dim3(PO_THREADS), 0, orbhip_ctx_stream_internal(ctx), A);
+    else hipLaunchKernelGGL(k_pose_opt<false>, dim3(frames), dim3(PO_THREADS), 0, orbhip_ctx_stream_internal(ctx), A);
     return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
 }
