@@ -231,6 +231,25 @@ int orbhip_fuse_search_device(orbhip_ctx *ctx, const orbhip_proj_query *d_q, con
                               const float *inv_level_sigma2, int nlevels, float min_x, float min_y, float max_x, float max_y,
                               int32_t *d_best_idx, int32_t *d_best_dist);
 
+/* ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches) (src/ORBmatcher.cc:273-475,
+ * F.Nleft == -1) -- the matcher of Tracking::TrackReferenceKeyFrame (src/Tracking.cc:1757) and Relocalization
+ * (:3290-3300), batched over (keyframe, frame) pairs.  The DBoW2 FeatureVectors (map<NodeId, vector<feature index>>,
+ * pKF->mFeatVec / F.mFeatVec) arrive flattened per pair: node ids ascending [pairs][max_nodes], node_start
+ * [pairs][max_nodes+1] into feat [pairs][max_n], number of nodes [pairs] (orbhip_bow_transform_device yields the node of
+ * every feature).  d_kf_valid [pairs][max_n]: the keyframe's map point at that feature exists and is not bad (:297-302).
+ * Inside a shared node every valid keyframe feature, in order, takes the best still unmatched frame feature if
+ * best <= TH_LOW and best < nn_ratio * second (:304-366); rotation consistency (:445-470) when check_orientation.
+ * d_match_f [pairs][max_n]: per frame feature the keyframe feature whose map point it receives, or -1
+ * (vpMapPointMatches[j] = vpMapPointsKF[d_match_f[j]]); d_nmatches [pairs] = the return value.  At most 4096 features per
+ * frame (their descriptors are LDS-resident).  All pointers DEVICE. */
+int orbhip_search_by_bow_device(orbhip_ctx *ctx,
+        const int32_t *d_kf_node_ids, const int32_t *d_kf_node_start, const int32_t *d_kf_feat, const int32_t *d_kf_nnodes,
+        const uint8_t *d_kf_valid, const orbhip_keypoint *d_kf_kp, const uint8_t *d_kf_desc,
+        const int32_t *d_f_node_ids, const int32_t *d_f_node_start, const int32_t *d_f_feat, const int32_t *d_f_nnodes,
+        const orbhip_keypoint *d_f_kp, const uint8_t *d_f_desc, const int32_t *d_nF,
+        int pairs, int max_nodes, int max_n, size_t frame_stride_kp, float nn_ratio, int check_orientation,
+        int32_t *d_match_f, int32_t *d_nmatches);
+
 /* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:327-403), batched over map points: point p
  * has d_n[p] observing descriptors at d_desc + p*max_n*32 (the loop of :347-361 packs them, left then right index);
  * d_best_idx[p] = BestIdx: the descriptor with the least median Hamming distance to all of them (median = sorted

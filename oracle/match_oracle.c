@@ -353,3 +353,56 @@ void orc_fuse_search(const orc_proj_query *q, const uint8_t *desc_q, int nq,
     }
     free(cand); grid_free(&g);
 }
+
+/* ORBm:273-475, F.Nleft == -1 */
+int orc_search_by_bow(const int32_t *kf_node_ids, const int32_t *kf_node_start, const int32_t *kf_feat, int kf_nnodes,
+                      const uint8_t *kf_valid, const orc_keypoint *kf_kp, const uint8_t *kf_desc,
+                      const int32_t *f_node_ids, const int32_t *f_node_start, const int32_t *f_feat, int f_nnodes,
+                      const orc_keypoint *f_kp, const uint8_t *f_desc, int nF,
+                      float nn_ratio, int check_orientation, int32_t *match_f)
+{
+    int nmatches = 0;
+    int *hist_n = (int *)calloc(HISTO_LENGTH, sizeof(int));
+    int *hist_items = (int *)malloc(sizeof(int) * (size_t)HISTO_LENGTH * (nF ? nF : 1));
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int j = 0; j < nF; j++) match_f[j] = -1;
+    int a = 0, b = 0;
+    while (a < kf_nnodes && b < f_nnodes) {                                   /* ORBm:291-443 */
+        if (kf_node_ids[a] == f_node_ids[b]) {
+            for (int ik = kf_node_start[a]; ik < kf_node_start[a + 1]; ik++) {
+                const int realIdxKF = kf_feat[ik];
+                if (!kf_valid[realIdxKF]) continue;
+                int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+                for (int jf = f_node_start[b]; jf < f_node_start[b + 1]; jf++) {
+                    const int realIdxF = f_feat[jf];
+                    if (match_f[realIdxF] >= 0) continue;                     /* ORBm:321-322 */
+                    const int dist = orc_descriptor_distance(kf_desc + 32 * (size_t)realIdxKF, f_desc + 32 * (size_t)realIdxF);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 <= TH_LOW && (float)bestDist1 < nn_ratio * (float)bestDist2) {
+                    match_f[bestIdxF] = realIdxKF;
+                    if (check_orientation) {
+                        float rot = kf_kp[realIdxKF].angle - f_kp[bestIdxF].angle;
+                        if (rot < 0.0) rot += 360.0f;
+                        int bin = (int)roundf(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        hist_items[(size_t)bin * nF + hist_n[bin]++] = bestIdxF;
+                    }
+                    nmatches++;
+                }
+            }
+            a++; b++;
+        } else if (kf_node_ids[a] < f_node_ids[b]) { while (a < kf_nnodes && kf_node_ids[a] < f_node_ids[b]) a++; }   /* lower_bound */
+        else { while (b < f_nnodes && f_node_ids[b] < kf_node_ids[a]) b++; }
+    }
+    if (check_orientation) {                                                  /* ORBm:445-470 */
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(hist_n, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int j = 0; j < hist_n[i]; j++) { match_f[hist_items[(size_t)i * nF + j]] = -1; nmatches--; }
+    }
+    free(hist_items); free(hist_n);
+    return nmatches;
+}

@@ -65,6 +65,18 @@ void orc_fuse_search(const orc_proj_query *q, const uint8_t *desc_q, int nq,
                      const orc_keypoint *kp, const uint8_t *desc, const float *u_right, int n,
                      const float *inv_level_sigma2, float min_x, float min_y, float max_x, float max_y,
                      int32_t *best_idx, int32_t *best_dist);
+/* ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches) (ORBmatcher.cc:273-475,
+ * F.Nleft == -1): the matcher of Tracking::TrackReferenceKeyFrame / Relocalization.  Feature vectors (DBoW2 FeatureVector =
+ * map<NodeId, vector<feature index>>) arrive flattened: node ids ascending, node_start[k]..node_start[k+1] into feat[].
+ * kf_valid[i] = pKF's map point at feature i exists and is not bad (:297-302).  Within a shared node, every valid KF feature
+ * takes the best unmatched F feature of that node if best <= TH_LOW and best < nn_ratio * second (:304-360); rotation
+ * consistency (:445-470) when check_orientation.  match_f [nF] out: KF feature index whose map point F's feature got, or -1.
+ * Returns nmatches. */
+int orc_search_by_bow(const int32_t *kf_node_ids, const int32_t *kf_node_start, const int32_t *kf_feat, int kf_nnodes,
+                      const uint8_t *kf_valid, const orc_keypoint *kf_kp, const uint8_t *kf_desc,
+                      const int32_t *f_node_ids, const int32_t *f_node_start, const int32_t *f_feat, int f_nnodes,
+                      const orc_keypoint *f_kp, const uint8_t *f_desc, int nF,
+                      float nn_ratio, int check_orientation, int32_t *match_f);
 /* MapPoint::ComputeDistinctiveDescriptors (/root/reference/src/MapPoint.cc:327-403): among the n
  * descriptors that observe a map point, the one with the least median Hamming distance to all of them
  * (median = sorted row [int(0.5*(n-1))], self distance 0 included; first minimum wins).  Returns BestIdx (0 if n<=0). */

@@ -846,3 +846,126 @@ extern "C" int orbhip_fuse_search_device(orbhip_ctx *ctx, const orbhip_proj_quer
                        orbhip_ctx_status_internal(ctx));
     return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
 }
+
+// ---------------------------------------------------------------------------- SearchByBoW (KeyFrame, Frame)
+// ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) (ORBmatcher.cc:273-475, F.Nleft == -1).  A Frame feature belongs to exactly
+// one vocabulary node, so the "already matched" rule (:321-322) only couples KF features of the SAME node: nodes are
+// independent.  One wave per (keyframe, frame) pair, one lane per shared node (binary search of the frame's sorted node list),
+// the node's KF features in order, the frame's descriptors and match slots LDS-resident.
+struct BowSide { const int32_t *node_ids, *node_start, *feat, *nnodes; const orbhip_keypoint *kp; const uint8_t *desc; };
+__global__ __launch_bounds__(64) void k_search_by_bow(BowSide K, const uint8_t *kf_valid_, BowSide F, const int32_t *nF_, int max_nodes, int max_n,
+                                                      size_t kp_stride, float nn_ratio, int check_ori, int cap_n,
+                                                      int32_t *match_f_, int32_t *nmatches_, int32_t *status)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t bow_lds[];
+    uint4 *dlds = reinterpret_cast<uint4 *>(bow_lds);                       // [cap_n][2] frame descriptors
+    int16_t *mf = reinterpret_cast<int16_t *>(dlds + 2 * (size_t)cap_n);    // [cap_n] KF feature matched to frame feature j, or -1
+    int8_t *fbin = reinterpret_cast<int8_t *>(mf + cap_n);                  // [cap_n] rotation bin of that match
+    __shared__ int hist[SI_HISTO];
+    __shared__ int s_keep[3];
+    const int pair = blockIdx.x, lane = threadIdx.x;
+    const int nF = nF_[pair], nk = K.nnodes[pair], nf = F.nnodes[pair];
+    int32_t *match_f = match_f_ + (size_t)pair * max_n;
+    if (nF > cap_n || nF > max_n || nk > max_nodes || nf > max_nodes) {
+        if (lane == 0) { atomicExch(status, ORBHIP_E_CAPACITY); nmatches_[pair] = 0; }
+        return;
+    }
+    const int32_t *kids = K.node_ids + (size_t)pair * max_nodes, *kst = K.node_start + (size_t)pair * (max_nodes + 1), *kfe = K.feat + (size_t)pair * max_n;
+    const int32_t *fids = F.node_ids + (size_t)pair * max_nodes, *fst = F.node_start + (size_t)pair * (max_nodes + 1), *ffe = F.feat + (size_t)pair * max_n;
+    const uint8_t *kvalid = kf_valid_ + (size_t)pair * max_n;
+    const orbhip_keypoint *kkp = K.kp + (size_t)pair * kp_stride, *fkp = F.kp + (size_t)pair * kp_stride;
+    const uint4 *dK = reinterpret_cast<const uint4 *>(K.desc + (size_t)pair * kp_stride * 32);
+    const uint4 *dF = reinterpret_cast<const uint4 *>(F.desc + (size_t)pair * kp_stride * 32);
+    for (int i = lane; i < SI_HISTO; i += 64) hist[i] = 0;
+    for (int j = lane; j < nF; j += 64) { dlds[2 * j] = dF[2 * j]; dlds[2 * j + 1] = dF[2 * j + 1]; mf[j] = -1; fbin[j] = -1; }
+    __syncthreads();
+    const float factor = 1.0f / SI_HISTO;
+    int mine = 0;
+    for (int a0 = 0; a0 < nk; a0 += 64) {
+        const int a = a0 + lane;
+        if (a >= nk) continue;
+        const int nid = kids[a];
+        int lo = 0, hi = nf;                                                 // lower_bound of nid in the frame's node list (:435-442)
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (fids[mid] < nid) lo = mid + 1; else hi = mid; }
+        if (lo >= nf || fids[lo] != nid) continue;
+        const int f0 = fst[lo], f1 = fst[lo + 1];
+        for (int ik = kst[a]; ik < kst[a + 1]; ik++) {
+            const int ri = kfe[ik];
+            if (!kvalid[ri]) continue;                                       // :297-302
+            const uint4 a0v = dK[2 * ri], a1v = dK[2 * ri + 1];
+            int b1 = 256, b2 = 256, bi = -1;
+            for (int jf = f0; jf < f1; jf++) {                               // :317-336
+                const int rj = ffe[jf];
+                if (mf[rj] >= 0) continue;
+                const int dist = hamming256(a0v, a1v, dlds[2 * rj], dlds[2 * rj + 1]);
+                if (dist < b1) { b2 = b1; b1 = dist; bi = rj; }
+                else if (dist < b2) b2 = dist;
+            }
+            if (b1 <= SI_TH_LOW && (float)b1 < __fmul_rn(nn_ratio, (float)b2)) {   // :362-366
+                mf[bi] = (int16_t)ri;
+                mine++;
+                if (check_ori) {                                             // :376-388
+                    float rot = __fsub_rn(kkp[ri].angle, fkp[bi].angle);
+                    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                    int bin = (int)roundf(__fmul_rn(rot, factor));
+                    if (bin == SI_HISTO) bin = 0;
+                    atomicAdd(&hist[bin], 1); fbin[bi] = (int8_t)bin;
+                }
+            }
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d, 64);
+    __syncthreads();
+    int removed = 0;
+    if (check_ori) {                                                         // :445-470
+        if (lane == 0) {
+            int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+            for (int i = 0; i < SI_HISTO; i++) {
+                const int sz = hist[i];
+                if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+                else if (sz > max3) { max3 = sz; ind3 = i; }
+            }
+            if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+            else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) ind3 = -1;
+            s_keep[0] = ind1; s_keep[1] = ind2; s_keep[2] = ind3;
+        }
+        __syncthreads();
+        for (int j = lane; j < nF; j += 64) {
+            const int b = fbin[j];
+            if (b < 0 || b == s_keep[0] || b == s_keep[1] || b == s_keep[2]) continue;
+            mf[j] = -1; removed++;
+        }
+        for (int d = 32; d >= 1; d >>= 1) removed += __shfl_xor(removed, d, 64);
+    }
+    __syncthreads();
+    for (int j = lane; j < nF; j += 64) match_f[j] = mf[j];
+    if (lane == 0) nmatches_[pair] = mine - removed;
+}
+
+extern "C" int orbhip_search_by_bow_device(orbhip_ctx *ctx,
+        const int32_t *d_kf_node_ids, const int32_t *d_kf_node_start, const int32_t *d_kf_feat, const int32_t *d_kf_nnodes,
+        const uint8_t *d_kf_valid, const orbhip_keypoint *d_kf_kp, const uint8_t *d_kf_desc,
+        const int32_t *d_f_node_ids, const int32_t *d_f_node_start, const int32_t *d_f_feat, const int32_t *d_f_nnodes,
+        const orbhip_keypoint *d_f_kp, const uint8_t *d_f_desc, const int32_t *d_nF,
+        int pairs, int max_nodes, int max_n, size_t frame_stride_kp, float nn_ratio, int check_orientation,
+        int32_t *d_match_f, int32_t *d_nmatches)
+{
+    if (!ctx || !d_kf_node_ids || !d_kf_node_start || !d_kf_feat || !d_kf_nnodes || !d_kf_valid || !d_kf_kp || !d_kf_desc || !d_f_node_ids ||
+        !d_f_node_start || !d_f_feat || !d_f_nnodes || !d_f_kp || !d_f_desc || !d_nF || pairs <= 0 || max_nodes <= 0 || max_n <= 0 ||
+        !d_match_f || !d_nmatches) return ORBHIP_E_BADARG;
+    if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
+    const int cap_n = ((max_n < 4096 ? max_n : 4096) + 7) & ~7;
+    const size_t lds = (size_t)cap_n * (32 + 2 + 1) + 16;
+    static thread_local size_t lds_set = 0;
+    if (lds > lds_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_by_bow), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return ORBHIP_E_HIP;
+        lds_set = lds;
+    }
+    BowSide K = {d_kf_node_ids, d_kf_node_start, d_kf_feat, d_kf_nnodes, d_kf_kp, d_kf_desc};
+    BowSide F = {d_f_node_ids, d_f_node_start, d_f_feat, d_f_nnodes, d_f_kp, d_f_desc};
+    hipLaunchKernelGGL(k_search_by_bow, dim3(pairs), dim3(64), lds, orbhip_ctx_stream_internal(ctx), K, d_kf_valid, F, d_nF, max_nodes, max_n,
+                       frame_stride_kp, nn_ratio, check_orientation, cap_n, d_match_f, d_nmatches, orbhip_ctx_status_internal(ctx));
+    return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
+}

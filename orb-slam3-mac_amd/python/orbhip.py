@@ -485,3 +485,14 @@ def fuse_search_device(ctx, d_q, d_desc_q, d_nq, max_q, d_kp, d_desc, d_u_right,
     _chk(lib.orbhip_fuse_search_device(ctx.h, d_q, d_desc_q, d_nq, max_q, d_kp, d_desc, d_u_right, d_n, max_n, kp_stride, pairs,
                                        sig.ctypes.data, len(sig), bounds[0], bounds[1], bounds[2], bounds[3], d_best_idx, d_best_dist),
          "orbhip_fuse_search_device")
+
+
+lib.orbhip_search_by_bow_device.argtypes = [vp] * 15 + [ci, ci, ci, sz, cf, ci, vp, vp]
+
+
+def search_by_bow_device(ctx, kf, f, d_nF, pairs, max_nodes, max_n, kp_stride, nn_ratio, check_ori, d_match_f, d_nmatches):
+    """ORBmatcher::SearchByBoW(KeyFrame, Frame), batched.  kf = (d_node_ids, d_node_start, d_feat, d_nnodes, d_valid, d_kp, d_desc),
+    f = (d_node_ids, d_node_start, d_feat, d_nnodes, d_kp, d_desc): device addresses (ints)."""
+    _chk(lib.orbhip_search_by_bow_device(ctx.h, kf[0], kf[1], kf[2], kf[3], kf[4], kf[5], kf[6], f[0], f[1], f[2], f[3], f[4], f[5], d_nF,
+                                         pairs, max_nodes, max_n, kp_stride, nn_ratio, 1 if check_ori else 0, d_match_f, d_nmatches),
+         "orbhip_search_by_bow_device")

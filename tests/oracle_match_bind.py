@@ -14,6 +14,8 @@ lib.orc_search_by_projection_map.argtypes = [vp, vp, ci, vp, vp, vp, ci, cf, cf,
 lib.orc_search_by_projection_map.restype = ci
 lib.orc_fuse_search.argtypes = [vp, vp, ci, vp, vp, vp, ci, vp, cf, cf, cf, cf, vp, vp]
 lib.orc_fuse_search.restype = None
+lib.orc_search_by_bow.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, vp, vp, ci, cf, ci, vp]
+lib.orc_search_by_bow.restype = ci
 lib.orc_distinctive_descriptor.argtypes = [vp, ci]
 lib.orc_distinctive_descriptor.restype = ci
 lib.orc_bow_transform.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, vp, vp, vp]
@@ -147,3 +149,46 @@ def fuse_search(q, dq, kp, d, u_right, inv_level_sigma2, bounds):
     lib.orc_fuse_search(q.ctypes.data, dq.ctypes.data, len(q), kp.ctypes.data, d.ctypes.data, None if ur is None else ur.ctypes.data,
                         len(kp), sig.ctypes.data, bounds[0], bounds[1], bounds[2], bounds[3], bi.ctypes.data, bd.ctypes.data)
     return bi[:len(q)], bd[:len(q)]
+
+
+def feature_vector_csr(nids):
+    """Flatten a DBoW2 FeatureVector (node of every feature -> map<node, [feature indices in order]>): ids asc, start, feat."""
+    nids = np.asarray(nids, np.int64)
+    ids = np.unique(nids).astype(np.int32)
+    order = np.argsort(nids, kind="stable").astype(np.int32)
+    counts = np.array([(nids == i).sum() for i in ids], np.int32)
+    start = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    return ids, start, order
+
+
+def make_bow_case(rng, nk, nf, n_nodes=40):
+    """Keyframe / frame with features spread over shared and private vocabulary nodes; frame descriptors are noisy copies of
+    keyframe descriptors (same node) plus distractors and exact duplicates (ties)."""
+    kp_k = np.zeros(nk, KP_DTYPE); kp_f = np.zeros(nf, KP_DTYPE)
+    kp_k["angle"] = rng.uniform(0, 360, nk).astype(np.float32)
+    d_k = rng.integers(0, 256, (nk, 32), dtype=np.uint8)
+    nid_k = rng.integers(0, n_nodes, nk) * 3 + 100
+    src = rng.integers(0, max(nk, 1), nf) if nk else np.zeros(nf, np.int64)
+    if nk:
+        d_f = d_k[src] ^ (rng.integers(0, 256, (nf, 32), dtype=np.uint8) & rng.integers(0, 256, (nf, 32), dtype=np.uint8) & rng.integers(0, 256, (nf, 32), dtype=np.uint8))
+        nid_f = np.where(rng.random(nf) < 0.8, nid_k[src], rng.integers(0, n_nodes + 10, nf) * 3 + 101)
+        kp_f["angle"] = (kp_k["angle"][src] + rng.choice([0, 0, 0, 120], nf) + rng.normal(0, 4, nf)).astype(np.float32) % np.float32(360)
+        if nf > 10:
+            d_f[nf // 2] = d_f[nf // 2 - 1]; nid_f[nf // 2] = nid_f[nf // 2 - 1]
+    else:
+        d_f = rng.integers(0, 256, (nf, 32), dtype=np.uint8); nid_f = rng.integers(0, n_nodes, nf) * 3 + 100
+    valid = (rng.random(nk) < 0.85).astype(np.uint8)
+    return dict(kp_k=kp_k, d_k=d_k, nid_k=nid_k, valid=valid, kp_f=kp_f, d_f=d_f, nid_f=nid_f)
+
+
+def search_by_bow(c, nn_ratio=0.7, check_ori=True):
+    ki, ks, kf = feature_vector_csr(c["nid_k"]); fi, fs, ff = feature_vector_csr(c["nid_f"])
+    nF = len(c["kp_f"])
+    m = np.zeros(max(nF, 1), np.int32)
+    kpk = np.ascontiguousarray(c["kp_k"], KP_DTYPE); kpf = np.ascontiguousarray(c["kp_f"], KP_DTYPE)
+    dk = np.ascontiguousarray(c["d_k"], np.uint8); df = np.ascontiguousarray(c["d_f"], np.uint8)
+    va = np.ascontiguousarray(c["valid"], np.uint8)
+    n = lib.orc_search_by_bow(ki.ctypes.data, ks.ctypes.data, kf.ctypes.data, len(ki), va.ctypes.data, kpk.ctypes.data, dk.ctypes.data,
+                              fi.ctypes.data, fs.ctypes.data, ff.ctypes.data, len(fi), kpf.ctypes.data, df.ctypes.data, nF,
+                              nn_ratio, 1 if check_ori else 0, m.ctypes.data)
+    return n, m[:nF]

@@ -398,3 +398,40 @@ def test_fuse_search_parity(gpu_ctx, stereo):
         np.testing.assert_array_equal(bi[p, :nq[p]], ri); np.testing.assert_array_equal(bd[p, :nq[p]], rd)
         hits += int((ri >= 0).sum())
     assert hits > 200
+
+
+@pytest.mark.parametrize("ratio,check_ori", [(0.7, True), (0.9, False)])
+def test_search_by_bow_parity(gpu_ctx, ratio, check_ori):
+    """TrackReferenceKeyFrame / Relocalization matcher (ORBmatcher.cc:273-475) on ragged pairs incl. empty sides."""
+    import torch
+    import orbhip
+    import oracle_match_bind as om
+    rng = np.random.default_rng(61)
+    cases = [om.make_bow_case(rng, nk, nf, nn) for nk, nf, nn in ((0, 20, 10), (30, 0, 10), (200, 260, 40), (1000, 950, 100), (2000, 2048, 300), (600, 1500, 900))]
+    P, MN, MNODE = len(cases), 2048, 2048
+    arr = dict(ki=np.zeros((P, MNODE), np.int32), ks=np.zeros((P, MNODE + 1), np.int32), kf=np.zeros((P, MN), np.int32), kn=np.zeros(P, np.int32),
+               fi=np.zeros((P, MNODE), np.int32), fs=np.zeros((P, MNODE + 1), np.int32), ff=np.zeros((P, MN), np.int32), fn=np.zeros(P, np.int32),
+               va=np.zeros((P, MN), np.uint8), kpk=np.zeros((P, MN), orbhip.KP_DTYPE), kpf=np.zeros((P, MN), orbhip.KP_DTYPE),
+               dk=np.zeros((P, MN, 32), np.uint8), df=np.zeros((P, MN, 32), np.uint8), nF=np.zeros(P, np.int32))
+    for p, c in enumerate(cases):
+        ki, ks, kf = om.feature_vector_csr(c["nid_k"]); fi, fs, ff = om.feature_vector_csr(c["nid_f"])
+        arr["ki"][p, :len(ki)] = ki; arr["ks"][p, :len(ks)] = ks; arr["kf"][p, :len(kf)] = kf; arr["kn"][p] = len(ki)
+        arr["fi"][p, :len(fi)] = fi; arr["fs"][p, :len(fs)] = fs; arr["ff"][p, :len(ff)] = ff; arr["fn"][p] = len(fi)
+        nk, nf = len(c["kp_k"]), len(c["kp_f"])
+        arr["va"][p, :nk] = c["valid"]; arr["kpk"][p, :nk] = c["kp_k"]; arr["kpf"][p, :nf] = c["kp_f"]
+        arr["dk"][p, :nk] = c["d_k"]; arr["df"][p, :nf] = c["d_f"]; arr["nF"][p] = nf
+    t = {k: torch.from_numpy(v.view(np.uint8) if v.dtype == orbhip.KP_DTYPE else v).cuda() for k, v in arr.items()}
+    mf = torch.full((P, MN), -9, dtype=torch.int32, device="cuda"); nm = torch.full((P,), -9, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    orbhip.search_by_bow_device(gpu_ctx, [t[k].data_ptr() for k in ("ki", "ks", "kf", "kn", "va", "kpk", "dk")],
+                                [t[k].data_ptr() for k in ("fi", "fs", "ff", "fn", "kpf", "df")], t["nF"].data_ptr(), P, MNODE, MN, MN,
+                                ratio, check_ori, mf.data_ptr(), nm.data_ptr())
+    gpu_ctx.check_status()
+    mf, nm = mf.cpu().numpy(), nm.cpu().numpy()
+    tot = 0
+    for p, c in enumerate(cases):
+        n_ref, m_ref = om.search_by_bow(c, ratio, check_ori)
+        assert nm[p] == n_ref, (p, nm[p], n_ref)
+        np.testing.assert_array_equal(mf[p, :len(m_ref)], m_ref)
+        tot += n_ref
+    assert tot > 300

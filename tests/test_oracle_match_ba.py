@@ -588,3 +588,52 @@ def test_fuse_search_oracle_against_python():
                 assert (bi[t], bd[t]) == (besti, best), (t, bi[t], bd[t], besti, best)
             if n == 250:
                 assert (bi >= 0).sum() > 8
+
+
+def test_search_by_bow_oracle_against_python():
+    """ORBmatcher::SearchByBoW(KeyFrame, Frame) restated; the Python model walks the two std::map-like dicts."""
+    import oracle_match_bind as om
+    rng = np.random.default_rng(5)
+    for nk, nf in ((0, 20), (30, 0), (200, 260), (500, 450)):
+        c = om.make_bow_case(rng, nk, nf)
+        for ratio, ori in ((0.7, True), (0.9, False)):
+            n1, m1 = om.search_by_bow(c, ratio, ori)
+            fvk = {}; fvf = {}
+            for i, x in enumerate(c["nid_k"]): fvk.setdefault(int(x), []).append(i)
+            for i, x in enumerate(c["nid_f"]): fvf.setdefault(int(x), []).append(i)
+            m = np.full(nf, -1, np.int64); nm = 0; hist = [[] for _ in range(30)]
+            for node in sorted(set(fvk) & set(fvf)):
+                for ri in fvk[node]:
+                    if not c["valid"][ri]:
+                        continue
+                    b1, b2, bi = 256, 256, -1
+                    for rj in fvf[node]:
+                        if m[rj] >= 0:
+                            continue
+                        dist = int(np.unpackbits(c["d_k"][ri] ^ c["d_f"][rj]).sum())
+                        if dist < b1: b2, b1, bi = b1, dist, rj
+                        elif dist < b2: b2 = dist
+                    if b1 <= 50 and np.float32(b1) < np.float32(ratio) * np.float32(b2):
+                        m[bi] = ri; nm += 1
+                        if ori:
+                            rot = np.float32(c["kp_k"]["angle"][ri]) - np.float32(c["kp_f"]["angle"][bi])
+                            if rot < 0: rot = np.float32(rot + np.float32(360.0))
+                            b = int(np.floor(np.float32(rot * np.float32(1.0 / 30)) + 0.5))
+                            hist[0 if b == 30 else b].append(bi)
+            if ori:
+                sizes = [len(h) for h in hist]
+                m1_, m2_, m3_ = 0, 0, 0; i1 = i2 = i3 = -1
+                for i, sz in enumerate(sizes):
+                    if sz > m1_: m3_, m2_, m1_, i3, i2, i1 = m2_, m1_, sz, i2, i1, i
+                    elif sz > m2_: m3_, m2_, i3, i2 = m2_, sz, i2, i
+                    elif sz > m3_: m3_, i3 = sz, i
+                if m2_ < np.float32(0.1) * np.float32(m1_): i2 = i3 = -1
+                elif m3_ < np.float32(0.1) * np.float32(m1_): i3 = -1
+                for i in range(30):
+                    if i not in (i1, i2, i3):
+                        for bi in hist[i]:
+                            m[bi] = -1; nm -= 1
+            assert n1 == nm
+            np.testing.assert_array_equal(m1, m)
+        if nk >= 200:
+            assert n1 > 20
