@@ -37,4 +37,44 @@ for P in (B - 1, 256, 1):
         tm.fill_(-1); torch.cuda.synchronize()
         t0 = time.perf_counter(); fn(); ctx.synchronize(); dt = time.perf_counter() - t0
     out["%s_%dpairs_ms" % (name, P)] = round(dt * 1e3, 3); out[name + "_matches_per_pair"] = round(float(nm[:P].float().mean().item()), 1)
+# ---- BoW tree descent + SearchByBoW + Fuse search + pose-only BA on the same batch
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_match_bind as om            # only its host-side synthetic-vocabulary / CSR helpers are used here
+rng = np.random.default_rng(1)
+voc = om.make_vocabulary(rng, 10, 4)
+dv = [torch.from_numpy(np.ascontiguousarray(voc[k])).cuda() for k in ("node_desc", "child_start", "child_ids", "node_word", "node_weight")]
+wid = torch.zeros((B, M), dtype=torch.int32, device="cuda"); ww = torch.zeros((B, M), dtype=torch.float64, device="cuda"); nid = torch.zeros((B, M), dtype=torch.int32, device="cuda")
+for it in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    orbhip.bow_transform_device(ctx, desc_p, cnt_p, B, M, M, [t.data_ptr() for t in dv], 4, 2, wid.data_ptr(), ww.data_ptr(), nid.data_ptr())
+    ctx.synchronize(); dt = time.perf_counter() - t0
+out["bow_transform_1024frames_ms"] = round(dt * 1e3, 3)
+h_nid = nid.cpu().numpy()
+P = 256
+arr = dict(ki=np.zeros((P, M), np.int32), ks=np.zeros((P, M + 1), np.int32), kf=np.zeros((P, M), np.int32), kn=np.zeros(P, np.int32),
+           fi=np.zeros((P, M), np.int32), fs=np.zeros((P, M + 1), np.int32), ff=np.zeros((P, M), np.int32), fn=np.zeros(P, np.int32))
+for p in range(P):
+    for side, f in (("k", p), ("f", p + 1)):
+        ids, st, fe = om.feature_vector_csr(h_nid[f, :cnt[f]])
+        arr[side + "i"][p, :len(ids)] = ids; arr[side + "s"][p, :len(st)] = st; arr[side + ("f" if side == "k" else "f")][p, :len(fe)] = fe
+        arr[side + "n"][p] = len(ids)
+t = {k: torch.from_numpy(v).cuda() for k, v in arr.items()}
+valid = torch.ones((P, M), dtype=torch.uint8, device="cuda"); mf = torch.zeros((P, M), dtype=torch.int32, device="cuda")
+for it in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    orbhip.search_by_bow_device(ctx, [t["ki"].data_ptr(), t["ks"].data_ptr(), t["kf"].data_ptr(), t["kn"].data_ptr(), valid.data_ptr(), kp_p, desc_p],
+                                [t["fi"].data_ptr(), t["fs"].data_ptr(), t["ff"].data_ptr(), t["fn"].data_ptr(), kp_p + M * 28, desc_p + M * 32], cnt_p + 4,
+                                P, M, M, M, 0.7, True, mf.data_ptr(), nm.data_ptr())
+    ctx.synchronize(); dt = time.perf_counter() - t0
+out["search_by_bow_256pairs_ms"] = round(dt * 1e3, 3); out["search_by_bow_matches_per_pair"] = round(float(nm[:P].float().mean().item()), 1)
+q2 = q.copy(); q2["min_level"] = kp["octave"] - 1; q2["max_level"] = kp["octave"]; q2["radius"] = np.float32(3.0) * sf[np.clip(kp["octave"], 0, 7)]
+d_q2 = torch.from_numpy(q2.view(np.uint8)).cuda()
+bi = torch.zeros((B, M), dtype=torch.int32, device="cuda"); bd = torch.zeros((B, M), dtype=torch.int32, device="cuda")
+sig = (1.0 / sf.astype(np.float32) ** 2).astype(np.float32)
+for it in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    orbhip.fuse_search_device(ctx, d_q2.data_ptr(), desc_p, cnt_p, M, kp_p + M * 28, desc_p + M * 32, None, cnt_p + 4, M, M, B - 1, sig,
+                              (0.0, 0.0, float(W), float(H)), bi.data_ptr(), bd.data_ptr())
+    ctx.synchronize(); dt = time.perf_counter() - t0
+out["fuse_search_1023pairs_ms"] = round(dt * 1e3, 3)
 print(json.dumps(out))
