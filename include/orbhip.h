@@ -369,10 +369,11 @@ int orbhip_ba_batch_download(orbhip_ba_batch *b, double *const *poses_out, doubl
 int orbhip_ba_batch_ticks(const orbhip_ba_batch *b);   /* LM trials of the slowest graph, last solve */
 void orbhip_ba_batch_destroy(orbhip_ba_batch *b);
 /* Measurement hooks: hipEvent timing of the Schur GEMM launches (on the context's stream), the
- * MFMA flops one launch issues, and a measured FP64 matrix-core peak for this device. */
+ * MFMA flops of the tiles that hold data (flops_per_launch), of everything issued, and a measured FP64 matrix-core peak. */
 int orbhip_ba_batch_set_profiling(orbhip_ba_batch *b, int enable);
 int orbhip_ba_batch_gemm_profile(const orbhip_ba_batch *b, float *total_ms, int *launches, double *flops_per_launch);
 double orbhip_ba_batch_gemm_dense_flops(const orbhip_ba_batch *b);   /* same tiles without block-sparsity skipping */
+double orbhip_ba_batch_gemm_issued_flops(const orbhip_ba_batch *b);  /* MFMA flops one launch issues (whole row strips a point touches) */
 int orbhip_mfma_f64_peak_tflops(orbhip_ctx *ctx, double *tflops_out);
 
 /* ------------------------------------------------------------------ pose-only BA

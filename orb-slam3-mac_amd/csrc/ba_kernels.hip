@@ -677,6 +677,8 @@ __global__ __launch_bounds__(256) void k_ba_point_prep(BaBatch B)
 // by ~10 of ~48 free keyframes; its static 16-column occupancy mask turns ~79 % of the (point, tile)
 // MFMAs into a wave-uniform scalar branch.  D^-1 is applied to the A fragment in registers.
 #define GEMM_PS 8
+#define GEMM_DENSE_STRIP 1     // every tile of a row strip the point touches is multiplied (no per-tile column test: 22 scalar
+                               // tests per point cost more than the ~10 extra MFMAs on zero blocks); 0 = skip empty tiles
 #define GEMM_TPW 22
 #define GEMM_WAVES 8
 __global__ __launch_bounds__(64 * GEMM_WAVES) void k_ba_schur_gemm(BaBatch B)
@@ -751,15 +753,17 @@ __global__ __launch_bounds__(64 * GEMM_WAVES) void k_ba_schur_gemm(BaBatch B)
             const double *rows = stage + (size_t)p * 4 * ld;
             const double d0 = s_dinv[cur][p][s0], d1 = s_dinv[cur][p][s1], d2 = s_dinv[cur][p][s2];
             double a = 0.0;
+            bool rowhit = false;
 #pragma unroll
             for (int s = 0; s < GEMM_TPW; s++) {
                 if (s == 0 || trs[s] != trs[s - 1]) {       // new row strip: (re)build the A fragment if the strip is hit
-                    if (trs[s] >= 0 && ((mask >> trs[s]) & 1u)) {
+                    rowhit = trs[s] >= 0 && ((mask >> trs[s]) & 1u);
+                    if (rowhit) {
                         const double *q = rows + 16 * trs[s] + li;
                         a = live * (d0 * q[0] + d1 * q[ld] + d2 * q[2 * ld]);
                     }
                 }
-                if ((mask & need[s]) == need[s]) {
+                if (GEMM_DENSE_STRIP ? rowhit : ((mask & need[s]) == need[s])) {
                     const double b = rows[lk * ld + 16 * tcs[s] + li];          // K-row 3 is the zero pad
                     acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[s], 0, 0, 0);
                 }
@@ -1138,6 +1142,7 @@ struct orbhip_ba_batch {
     float gemm_ms_total; int gemm_launches;
     double gemm_flops_per_launch;            // MFMA flops actually issued by one launch (all graphs)
     double gemm_flops_dense;                 // what the same upper tiles would cost without block-sparsity skipping
+    double gemm_flops_issued;                // MFMA flops issued by one launch (GEMM_DENSE_STRIP: whole row strips the point touches)
 };
 
 template <typename T>
@@ -1188,7 +1193,7 @@ extern "C" int orbhip_ba_batch_create(orbhip_ctx *ctx, const orbhip_ba_graph *gr
     if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
     orbhip_ba_batch *b = new orbhip_ba_batch();
     b->ctx = ctx; b->h_n_active = nullptr; b->ticks_last = 0;
-    b->profile = false; b->ev0 = b->ev1 = nullptr; b->gemm_ms_total = 0; b->gemm_launches = 0; b->gemm_flops_per_launch = 0; b->gemm_flops_dense = 0;
+    b->profile = false; b->ev0 = b->ev1 = nullptr; b->gemm_ms_total = 0; b->gemm_launches = 0; b->gemm_flops_per_launch = 0; b->gemm_flops_dense = 0; b->gemm_flops_issued = 0;
     BaBatch &B = b->B;
     memset(&B, 0, sizeof(B));
     B.G = n_graphs;
@@ -1274,8 +1279,13 @@ extern "C" int orbhip_ba_batch_create(orbhip_ctx *ctx, const orbhip_ba_graph *gr
                 const int h = local_h[H.edge_pose[e]];
                 if (h >= 0) pmv[H.edge_point[e]] |= (1u << ((6 * h) >> 4)) | (1u << ((6 * h + 5) >> 4));
             }
-            for (int l = 0; l < H.n_points; l++) { const double k = __builtin_popcount(pmv[l]); issued += k * (k + 1) / 2; }
-            b->gemm_flops_per_launch += issued * 2048.0;                               // one 16x16x4 f64 MFMA (2048 flop) per (point, upper tile) hit
+            double strips = 0;
+            for (int l = 0; l < H.n_points; l++) {
+                const double k = __builtin_popcount(pmv[l]); issued += k * (k + 1) / 2;
+                for (int tr = 0; tr < nt; tr++) if ((pmv[l] >> tr) & 1u) strips += nt - tr;
+            }
+            b->gemm_flops_per_launch += issued * 2048.0;                               // one 16x16x4 f64 MFMA (2048 flop) per (point, upper tile) that holds data
+            b->gemm_flops_issued += (GEMM_DENSE_STRIP ? strips : issued) * 2048.0;
             b->gemm_flops_dense += (double)ntiles * 2048.0 * (double)H.n_points;        // same tiles without the masks
         }
         D.wd_off = wd; wd += (size_t)4 * H.n_points * D.ld;
@@ -1460,6 +1470,7 @@ extern "C" int orbhip_ba_batch_gemm_profile(const orbhip_ba_batch *b, float *tot
     return ORBHIP_OK;
 }
 extern "C" double orbhip_ba_batch_gemm_dense_flops(const orbhip_ba_batch *b) { return b ? b->gemm_flops_dense : 0.0; }
+extern "C" double orbhip_ba_batch_gemm_issued_flops(const orbhip_ba_batch *b) { return b ? b->gemm_flops_issued : 0.0; }
 
 // FP64 matrix-core peak of this device, measured: every wave issues independent
 // v_mfma_f64_16x16x4_f64 chains (the local micro-architecture guide lists no FP64 MFMA peak).

@@ -331,6 +331,8 @@ lib.orbhip_ba_batch_set_profiling.argtypes = [vp, ci]
 lib.orbhip_ba_batch_gemm_profile.argtypes = [vp, C.POINTER(cf), C.POINTER(ci), C.POINTER(cd)]
 lib.orbhip_mfma_f64_peak_tflops.argtypes = [vp, C.POINTER(cd)]
 lib.orbhip_ba_batch_gemm_dense_flops.argtypes = [vp]
+lib.orbhip_ba_batch_gemm_issued_flops.argtypes = [vp]
+lib.orbhip_ba_batch_gemm_issued_flops.restype = cd
 lib.orbhip_ba_batch_gemm_dense_flops.restype = cd
 
 
@@ -406,6 +408,9 @@ class BaBatch:
 
     def gemm_dense_flops(self):
         return lib.orbhip_ba_batch_gemm_dense_flops(self.h)
+
+    def gemm_issued_flops(self):
+        return lib.orbhip_ba_batch_gemm_issued_flops(self.h)
 
     def download(self):
         poses = [a.copy() for a in self.poses]
