@@ -250,6 +250,33 @@ int orbhip_search_by_bow_device(orbhip_ctx *ctx,
         int pairs, int max_nodes, int max_n, size_t frame_stride_kp, float nn_ratio, int check_orientation,
         int32_t *d_match_f, int32_t *d_nmatches);
 
+/* Per keyframe pair of orbhip_search_for_triangulation_device: F12 = K1^-T [t12]x R12 K2^-1 (row-major; computed by the
+ * caller with the reference's own matrix arithmetic, CameraModels/Pinhole.cpp:124-127), the epipole of KF1's centre in KF2
+ * (ORBmatcher.cc:978-992), and the bOnlyStereo / bCoarse arguments. */
+typedef struct orbhip_tri_pair { float F12[9]; float ep_x, ep_y; int32_t only_stereo, coarse; } orbhip_tri_pair;
+
+/* ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo, bCoarse) (src/ORBmatcher.cc:969-1210;
+ * Pinhole cameras, mpCamera2 == 0) -- the matcher of LocalMapping::CreateNewMapPoints (src/LocalMapping.cc:459-460),
+ * batched over keyframe pairs.  d_nid1 [pairs][max_n]: vocabulary node of every KF1 feature (orbhip_bow_transform_device);
+ * KF2's FeatureVector flattened as in orbhip_search_by_bow_device.  d_has_mp* [pairs][max_n]: the keypoint already has a map
+ * point (:1039, :1067); d_u_right* [pairs][max_n] = mvuRight or NULL (monocular).  Per KF1 keypoint without a map point:
+ * the KF2 keypoint of the same node, without a map point, with the smallest descriptor distance <= TH_LOW (a later
+ * candidate at equal distance replaces an earlier one, :1073) that is not within 10*sqrt(scale) px of the epipole (both
+ * monocular, :1083-1091) and passes Pinhole::epipolarConstrain (or any, if coarse); this fork never sets vbMatched2, so
+ * KF1 keypoints are independent.  Rotation consistency (:1171-1189) when check_orientation.  d_matches12 [pairs][max_n] =
+ * vMatches12 (idx2 or -1; vMatchedPairs is its non-negative entries in index order), d_nmatches [pairs] = the return
+ * value.  scale_factors / level_sigma2: HOST arrays of nlevels floats (KF2's mvScaleFactors / mvLevelSigma2).  At most 4096
+ * features per keyframe.  KannalaBrandt8 pairs (epipolarConstrain by triangulation) and rigs (mpCamera2) are not covered.
+ * All other pointers DEVICE. */
+int orbhip_search_for_triangulation_device(orbhip_ctx *ctx,
+        const int32_t *d_nid1, const uint8_t *d_has_mp1, const orbhip_keypoint *d_kp1, const uint8_t *d_desc1, const float *d_u_right1,
+        const int32_t *d_n1,
+        const int32_t *d_node_ids2, const int32_t *d_node_start2, const int32_t *d_feat2, const int32_t *d_nnodes2,
+        const uint8_t *d_has_mp2, const orbhip_keypoint *d_kp2, const uint8_t *d_desc2, const float *d_u_right2, const int32_t *d_n2,
+        const orbhip_tri_pair *d_pair, int pairs, int max_nodes, int max_n, size_t frame_stride_kp,
+        const float *scale_factors, const float *level_sigma2, int nlevels, int check_orientation,
+        int32_t *d_matches12, int32_t *d_nmatches);
+
 /* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:327-403), batched over map points: point p
  * has d_n[p] observing descriptors at d_desc + p*max_n*32 (the loop of :347-361 packs them, left then right index);
  * d_best_idx[p] = BestIdx: the descriptor with the least median Hamming distance to all of them (median = sorted

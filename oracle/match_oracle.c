@@ -406,3 +406,70 @@ int orc_search_by_bow(const int32_t *kf_node_ids, const int32_t *kf_node_start, 
     free(hist_items); free(hist_n);
     return nmatches;
 }
+
+/* Pinhole::epipolarConstrain, Pinhole.cpp:129-143, F12 given */
+static int epipolar_ok(const float F[9], const orc_keypoint *k1, const orc_keypoint *k2, float unc)
+{
+    const float a = k1->x * F[0] + k1->y * F[3] + F[6];
+    const float b = k1->x * F[1] + k1->y * F[4] + F[7];
+    const float c = k1->x * F[2] + k1->y * F[5] + F[8];
+    const float num = a * k2->x + b * k2->y + c;
+    const float den = a * a + b * b;
+    if (den == 0) return 0;
+    const float dsqr = num * num / den;
+    return dsqr < 3.84 * unc;
+}
+/* ORBm:969-1210 (mpCamera2 == 0, Pinhole) */
+int orc_search_for_triangulation(const int32_t *nid1, const uint8_t *has_mp1, const orc_keypoint *kp1, const uint8_t *desc1,
+                                 const float *u_right1, int n1,
+                                 const int32_t *node_ids2, const int32_t *node_start2, const int32_t *feat2, int nnodes2,
+                                 const uint8_t *has_mp2, const orc_keypoint *kp2, const uint8_t *desc2, const float *u_right2,
+                                 const float F12[9], float ep_x, float ep_y, const float *scale_factors, const float *level_sigma2,
+                                 int only_stereo, int coarse, int check_orientation, int32_t *matches12)
+{
+    int nmatches = 0;
+    int hist[HISTO_LENGTH]; memset(hist, 0, sizeof(hist));
+    int *bin_of = (int *)malloc(sizeof(int) * (n1 ? n1 : 1));
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int idx1 = 0; idx1 < n1; idx1++) {                         /* node-major in the reference; the keypoints are independent */
+        matches12[idx1] = -1; bin_of[idx1] = -1;
+        if (has_mp1[idx1]) continue;                                /* ORBm:1029-1034 */
+        const int bStereo1 = u_right1 && u_right1[idx1] >= 0;
+        if (only_stereo && !bStereo1) continue;
+        int lo = 0, hi = nnodes2;                                   /* the node of idx1 in KF2's FeatureVector */
+        while (lo < hi) { const int mid = (lo + hi) / 2; if (node_ids2[mid] < nid1[idx1]) lo = mid + 1; else hi = mid; }
+        if (lo >= nnodes2 || node_ids2[lo] != nid1[idx1]) continue;
+        int bestDist = TH_LOW, bestIdx2 = -1;                       /* ORBm:1048-1049 */
+        for (int j = node_start2[lo]; j < node_start2[lo + 1]; j++) {
+            const int idx2 = feat2[j];
+            if (has_mp2[idx2]) continue;                            /* vbMatched2 is never set in this fork */
+            const int bStereo2 = u_right2 && u_right2[idx2] >= 0;
+            if (only_stereo && !bStereo2) continue;
+            const int dist = orc_descriptor_distance(desc1 + 32 * (size_t)idx1, desc2 + 32 * (size_t)idx2);
+            if (dist > TH_LOW || dist > bestDist) continue;         /* ORBm:1073-1074 */
+            if (!bStereo1 && !bStereo2) {                           /* ORBm:1083-1091 */
+                const float distex = ep_x - kp2[idx2].x, distey = ep_y - kp2[idx2].y;
+                if (distex * distex + distey * distey < 100 * scale_factors[kp2[idx2].octave]) continue;
+            }
+            if (epipolar_ok(F12, &kp1[idx1], &kp2[idx2], level_sigma2[kp2[idx2].octave]) || coarse) { bestIdx2 = idx2; bestDist = dist; }
+        }
+        if (bestIdx2 >= 0) {
+            matches12[idx1] = bestIdx2; nmatches++;
+            if (check_orientation) {
+                float rot = kp1[idx1].angle - kp2[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                hist[bin]++; bin_of[idx1] = bin;
+            }
+        }
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(hist, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < n1; i++)
+            if (bin_of[i] >= 0 && bin_of[i] != ind1 && bin_of[i] != ind2 && bin_of[i] != ind3) { matches12[i] = -1; nmatches--; }
+    }
+    free(bin_of);
+    return nmatches;
+}

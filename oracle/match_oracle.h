@@ -77,6 +77,21 @@ int orc_search_by_bow(const int32_t *kf_node_ids, const int32_t *kf_node_start, 
                       const int32_t *f_node_ids, const int32_t *f_node_start, const int32_t *f_feat, int f_nnodes,
                       const orc_keypoint *f_kp, const uint8_t *f_desc, int nF,
                       float nn_ratio, int check_orientation, int32_t *match_f);
+/* ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo, bCoarse) (ORBmatcher.cc:969-1210),
+ * Pinhole cameras without a second camera (mpCamera2 == 0): for every keypoint of KF1 without a map point, the keypoint of
+ * KF2 in the same vocabulary node, without a map point, with the smallest descriptor distance <= TH_LOW (a later candidate
+ * at EQUAL distance replaces an earlier one, :1046-1047) that is >= 10*sqrt(scale) px away from the epipole when both are
+ * monocular (:1056-1064) and satisfies Pinhole::epipolarConstrain (CameraModels/Pinhole.cpp:122-144) with the
+ * fundamental matrix F12 (row-major 3x3, computed by the caller as in :124-127) -- or any candidate when coarse.  This
+ * fork never sets vbMatched2, so KF1 keypoints are independent.  Rotation consistency (:1171-1189) when check_orientation.
+ * nid1 [n1]: vocabulary node of every KF1 feature; KF2's FeatureVector flattened as in orc_search_by_bow.
+ * has_mp* : the keypoint already has a map point; u_right* may be NULL (monocular).  matches12 [n1] out.  Returns nmatches. */
+int orc_search_for_triangulation(const int32_t *nid1, const uint8_t *has_mp1, const orc_keypoint *kp1, const uint8_t *desc1,
+                                 const float *u_right1, int n1,
+                                 const int32_t *node_ids2, const int32_t *node_start2, const int32_t *feat2, int nnodes2,
+                                 const uint8_t *has_mp2, const orc_keypoint *kp2, const uint8_t *desc2, const float *u_right2,
+                                 const float F12[9], float ep_x, float ep_y, const float *scale_factors, const float *level_sigma2,
+                                 int only_stereo, int coarse, int check_orientation, int32_t *matches12);
 /* MapPoint::ComputeDistinctiveDescriptors (/root/reference/src/MapPoint.cc:327-403): among the n
  * descriptors that observe a map point, the one with the least median Hamming distance to all of them
  * (median = sorted row [int(0.5*(n-1))], self distance 0 included; first minimum wins).  Returns BestIdx (0 if n<=0). */

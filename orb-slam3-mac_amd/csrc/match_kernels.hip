@@ -969,3 +969,152 @@ extern "C" int orbhip_search_by_bow_device(orbhip_ctx *ctx,
                        frame_stride_kp, nn_ratio, check_orientation, cap_n, d_match_f, d_nmatches, orbhip_ctx_status_internal(ctx));
     return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
 }
+
+// ---------------------------------------------------------------------------- SearchForTriangulation
+// ORBmatcher::SearchForTriangulation (ORBmatcher.cc:969-1210; Pinhole, mpCamera2 == 0) -- the matcher of
+// LocalMapping::CreateNewMapPoints.  This fork never sets vbMatched2, so every KF1 keypoint is independent: one block per
+// keyframe pair, one thread per KF1 keypoint, KF2's descriptors and flags LDS-resident.
+struct TriSide { const int32_t *node_ids, *node_start, *feat, *nnodes; };
+struct TriLevels { float scale[16], sigma2[16]; };
+#define TRI_THREADS 256
+__global__ __launch_bounds__(TRI_THREADS) void k_search_triangulation(const int32_t *nid1_, const uint8_t *mp1_, const orbhip_keypoint *kp1_,
+        const uint8_t *desc1_, const float *ur1_, const int32_t *n1_, TriSide S2, const uint8_t *mp2_, const orbhip_keypoint *kp2_,
+        const uint8_t *desc2_, const float *ur2_, const int32_t *n2_, const orbhip_tri_pair *geom_, int max_nodes, int max_n,
+        size_t kp_stride, TriLevels lv, int check_ori, int cap_n, int32_t *matches12_, int32_t *nmatches_, int32_t *status)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t tri_lds[];
+    uint4 *dlds = reinterpret_cast<uint4 *>(tri_lds);                        // [cap_n][2] KF2 descriptors
+    uint8_t *flag2 = reinterpret_cast<uint8_t *>(dlds + 2 * (size_t)cap_n);  // [cap_n] bit0: has a map point, bit1: stereo
+    int8_t *bin1 = reinterpret_cast<int8_t *>(flag2 + cap_n);                // [cap_n] rotation bin of KF1 keypoint i's match
+    __shared__ int hist[SI_HISTO];
+    __shared__ int s_keep[3];
+    __shared__ int s_cnt;
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const int n1 = n1_[pair], n2 = n2_[pair], nn2 = S2.nnodes[pair];
+    int32_t *matches12 = matches12_ + (size_t)pair * max_n;
+    if (n1 > cap_n || n2 > cap_n || n1 > max_n || n2 > max_n || nn2 > max_nodes) {
+        if (tid == 0) { atomicExch(status, ORBHIP_E_CAPACITY); nmatches_[pair] = 0; }
+        return;
+    }
+    const int32_t *nid1 = nid1_ + (size_t)pair * max_n;
+    const uint8_t *mp1 = mp1_ + (size_t)pair * max_n, *mp2 = mp2_ + (size_t)pair * max_n;
+    const float *ur1 = ur1_ ? ur1_ + (size_t)pair * max_n : nullptr, *ur2 = ur2_ ? ur2_ + (size_t)pair * max_n : nullptr;
+    const int32_t *ids2 = S2.node_ids + (size_t)pair * max_nodes, *st2 = S2.node_start + (size_t)pair * (max_nodes + 1), *fe2 = S2.feat + (size_t)pair * max_n;
+    const orbhip_keypoint *kp1 = kp1_ + (size_t)pair * kp_stride, *kp2 = kp2_ + (size_t)pair * kp_stride;
+    const uint4 *d1 = reinterpret_cast<const uint4 *>(desc1_ + (size_t)pair * kp_stride * 32);
+    const uint4 *d2 = reinterpret_cast<const uint4 *>(desc2_ + (size_t)pair * kp_stride * 32);
+    const orbhip_tri_pair g = geom_[pair];
+    for (int i = tid; i < SI_HISTO; i += TRI_THREADS) hist[i] = 0;
+    if (tid == 0) s_cnt = 0;
+    for (int j = tid; j < n2; j += TRI_THREADS) {
+        dlds[2 * j] = d2[2 * j]; dlds[2 * j + 1] = d2[2 * j + 1];
+        flag2[j] = (uint8_t)((mp2[j] ? 1 : 0) | ((ur2 && ur2[j] >= 0.0f) ? 2 : 0));
+    }
+    __syncthreads();
+    const float factor = 1.0f / SI_HISTO;
+    int mine = 0;
+    for (int idx1 = tid; idx1 < n1; idx1 += TRI_THREADS) {
+        int best_idx = -1;
+        bin1[idx1] = -1;
+        const bool st1 = ur1 && ur1[idx1] >= 0.0f;
+        if (!mp1[idx1] && !(g.only_stereo && !st1)) {                        // :1039-1048
+            const int nid = nid1[idx1];
+            int lo = 0, hi = nn2;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (ids2[mid] < nid) lo = mid + 1; else hi = mid; }
+            if (lo < nn2 && ids2[lo] == nid) {
+                const uint4 a0 = d1[2 * idx1], a1 = d1[2 * idx1 + 1];
+                const float x1 = kp1[idx1].x, y1 = kp1[idx1].y;
+                // epipolar line in the second image, Pinhole.cpp:130-132
+                const float la = __fadd_rn(__fadd_rn(__fmul_rn(x1, g.F12[0]), __fmul_rn(y1, g.F12[3])), g.F12[6]);
+                const float lb = __fadd_rn(__fadd_rn(__fmul_rn(x1, g.F12[1]), __fmul_rn(y1, g.F12[4])), g.F12[7]);
+                const float lc = __fadd_rn(__fadd_rn(__fmul_rn(x1, g.F12[2]), __fmul_rn(y1, g.F12[5])), g.F12[8]);
+                const float den = __fadd_rn(__fmul_rn(la, la), __fmul_rn(lb, lb));
+                int best = SI_TH_LOW;
+                for (int j = st2[lo]; j < st2[lo + 1]; j++) {                // :1062-1143
+                    const int idx2 = fe2[j];
+                    const int fl = flag2[idx2];
+                    if ((fl & 1) || (g.only_stereo && !(fl & 2))) continue;
+                    const int dist = hamming256(a0, a1, dlds[2 * idx2], dlds[2 * idx2 + 1]);
+                    if (dist > best) continue;                               // :1073 (best <= TH_LOW always)
+                    const orbhip_keypoint k2 = kp2[idx2];
+                    if (!st1 && !(fl & 2)) {                                 // :1083-1091
+                        const float ex = __fsub_rn(g.ep_x, k2.x), ey = __fsub_rn(g.ep_y, k2.y);
+                        if (__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)) < __fmul_rn(100.0f, lv.scale[k2.octave & 15])) continue;
+                    }
+                    bool ok = g.coarse != 0;
+                    if (!ok && den != 0.0f) {                                // Pinhole.cpp:134-143
+                        const float num = __fadd_rn(__fadd_rn(__fmul_rn(la, k2.x), __fmul_rn(lb, k2.y)), lc);
+                        const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
+                        ok = (double)dsqr < 3.84 * (double)lv.sigma2[k2.octave & 15];
+                    }
+                    if (ok) { best_idx = idx2; best = dist; }
+                }
+            }
+        }
+        if (best_idx >= 0) {
+            mine++;
+            if (check_ori) {                                                 // :1154-1164
+                float rot = __fsub_rn(kp1[idx1].angle, kp2[best_idx].angle);
+                if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                int bin = (int)roundf(__fmul_rn(rot, factor));
+                if (bin == SI_HISTO) bin = 0;
+                atomicAdd(&hist[bin], 1); bin1[idx1] = (int8_t)bin;
+            }
+        }
+        matches12[idx1] = best_idx;
+    }
+    __syncthreads();
+    if (check_ori) {                                                         // :1171-1189
+        if (tid == 0) {
+            int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+            for (int i = 0; i < SI_HISTO; i++) {
+                const int sz = hist[i];
+                if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+                else if (sz > max3) { max3 = sz; ind3 = i; }
+            }
+            if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+            else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) ind3 = -1;
+            s_keep[0] = ind1; s_keep[1] = ind2; s_keep[2] = ind3;
+        }
+        __syncthreads();
+        for (int i = tid; i < n1; i += TRI_THREADS) {
+            const int b = bin1[i];
+            if (b < 0 || b == s_keep[0] || b == s_keep[1] || b == s_keep[2]) continue;
+            matches12[i] = -1; mine--;
+        }
+    }
+    if (mine) atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    if (tid == 0) nmatches_[pair] = s_cnt;
+}
+
+extern "C" int orbhip_search_for_triangulation_device(orbhip_ctx *ctx,
+        const int32_t *d_nid1, const uint8_t *d_has_mp1, const orbhip_keypoint *d_kp1, const uint8_t *d_desc1, const float *d_u_right1,
+        const int32_t *d_n1,
+        const int32_t *d_node_ids2, const int32_t *d_node_start2, const int32_t *d_feat2, const int32_t *d_nnodes2,
+        const uint8_t *d_has_mp2, const orbhip_keypoint *d_kp2, const uint8_t *d_desc2, const float *d_u_right2, const int32_t *d_n2,
+        const orbhip_tri_pair *d_pair, int pairs, int max_nodes, int max_n, size_t frame_stride_kp,
+        const float *scale_factors, const float *level_sigma2, int nlevels, int check_orientation,
+        int32_t *d_matches12, int32_t *d_nmatches)
+{
+    if (!ctx || !d_nid1 || !d_has_mp1 || !d_kp1 || !d_desc1 || !d_n1 || !d_node_ids2 || !d_node_start2 || !d_feat2 || !d_nnodes2 ||
+        !d_has_mp2 || !d_kp2 || !d_desc2 || !d_n2 || !d_pair || pairs <= 0 || max_nodes <= 0 || max_n <= 0 || !scale_factors ||
+        !level_sigma2 || nlevels <= 0 || nlevels > 16 || !d_matches12 || !d_nmatches) return ORBHIP_E_BADARG;
+    if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
+    TriLevels lv;
+    for (int l = 0; l < 16; l++) { lv.scale[l] = l < nlevels ? scale_factors[l] : 0.0f; lv.sigma2[l] = l < nlevels ? level_sigma2[l] : 0.0f; }
+    const int cap_n = ((max_n < 4096 ? max_n : 4096) + 15) & ~15;
+    const size_t lds = (size_t)cap_n * (32 + 1 + 1) + 16;
+    static thread_local size_t lds_set = 0;
+    if (lds > lds_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_triangulation), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return ORBHIP_E_HIP;
+        lds_set = lds;
+    }
+    TriSide S2 = {d_node_ids2, d_node_start2, d_feat2, d_nnodes2};
+    hipLaunchKernelGGL(k_search_triangulation, dim3(pairs), dim3(TRI_THREADS), lds, orbhip_ctx_stream_internal(ctx), d_nid1, d_has_mp1, d_kp1,
+                       d_desc1, d_u_right1, d_n1, S2, d_has_mp2, d_kp2, d_desc2, d_u_right2, d_n2, d_pair, max_nodes, max_n, frame_stride_kp, lv,
+                       check_orientation, cap_n, d_matches12, d_nmatches, orbhip_ctx_status_internal(ctx));
+    return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
+}

@@ -492,6 +492,22 @@ def fuse_search_device(ctx, d_q, d_desc_q, d_nq, max_q, d_kp, d_desc, d_u_right,
          "orbhip_fuse_search_device")
 
 
+TRI_PAIR_DTYPE = np.dtype([("F12", "<f4", (9,)), ("ep_x", "<f4"), ("ep_y", "<f4"), ("only_stereo", "<i4"), ("coarse", "<i4")])
+lib.orbhip_search_for_triangulation_device.argtypes = [vp] * 17 + [ci, ci, ci, sz, vp, vp, ci, ci, vp, vp]
+
+
+def search_for_triangulation_device(ctx, kf1, kf2, d_pair, pairs, max_nodes, max_n, kp_stride, scale_factors, level_sigma2,
+                                    check_ori, d_matches12, d_nmatches):
+    """ORBmatcher::SearchForTriangulation, batched.  kf1 = (d_nid, d_has_mp, d_kp, d_desc, d_u_right|0, d_n),
+    kf2 = (d_node_ids, d_node_start, d_feat, d_nnodes, d_has_mp, d_kp, d_desc, d_u_right|0, d_n): device addresses (ints);
+    d_pair: [pairs] TRI_PAIR_DTYPE records; scale_factors / level_sigma2: host float32 arrays."""
+    sf = np.ascontiguousarray(scale_factors, np.float32); ls = np.ascontiguousarray(level_sigma2, np.float32)
+    assert len(sf) == len(ls)
+    _chk(lib.orbhip_search_for_triangulation_device(ctx.h, *[a or None for a in kf1], *[a or None for a in kf2], d_pair, pairs, max_nodes,
+                                                    max_n, kp_stride, sf.ctypes.data, ls.ctypes.data, len(sf), 1 if check_ori else 0,
+                                                    d_matches12, d_nmatches), "orbhip_search_for_triangulation_device")
+
+
 lib.orbhip_search_by_bow_device.argtypes = [vp] * 15 + [ci, ci, ci, sz, cf, ci, vp, vp]
 
 

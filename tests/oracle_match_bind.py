@@ -192,3 +192,69 @@ def search_by_bow(c, nn_ratio=0.7, check_ori=True):
                               fi.ctypes.data, fs.ctypes.data, ff.ctypes.data, len(fi), kpf.ctypes.data, df.ctypes.data, nF,
                               nn_ratio, 1 if check_ori else 0, m.ctypes.data)
     return n, m[:nF]
+
+
+# ------------------------------------------------------------------ ORBmatcher::SearchForTriangulation oracle
+def skew(t):
+    return np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]], np.float32)
+
+
+def make_tri_case(rng, n1, n2, n_nodes=60, stereo_frac=0.0, only_stereo=False, coarse=False):
+    """Two keyframes seeing the same synthetic points: KF2's keypoints are reprojections (plus outliers off the epipolar line,
+    points near the epipole, exact duplicate descriptors for the equal-distance rule)."""
+    fx, fy, cx, cy = 458.0, 457.0, 367.0, 248.0
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], np.float32)
+    ang = 0.05
+    R12 = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], np.float32)   # X1 = R12 X2 + t12
+    t12 = np.array([0.35, 0.02, 0.9], np.float32)
+    # float32 arithmetic throughout, as the cv::Mat (CV_32F) chain of Pinhole.cpp:124-127
+    Kinv = np.linalg.inv(K.astype(np.float64)).astype(np.float32)
+    F12 = (Kinv.T @ skew(t12) @ R12 @ Kinv).astype(np.float32)
+    # epipole: KF1's centre in KF2 (ORBm:978-992): C2 = R2w*Cw+t2w = R12^T (0 - t12)
+    C2 = (-(R12.T @ t12)).astype(np.float32)
+    ep = (np.float32(fx) * C2[0] / C2[2] + np.float32(cx), np.float32(fy) * C2[1] / C2[2] + np.float32(cy))
+    scale = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    sigma2 = (scale * scale).astype(np.float32)
+    kp1 = np.zeros(n1, KP_DTYPE); kp2 = np.zeros(n2, KP_DTYPE)
+    X2 = np.stack([rng.uniform(-4, 4, n1), rng.uniform(-3, 3, n1), rng.uniform(2, 12, n1)], 1).astype(np.float32)
+    X1 = (X2 @ R12.T + t12).astype(np.float32)
+    kp1["x"] = fx * X1[:, 0] / X1[:, 2] + cx; kp1["y"] = fy * X1[:, 1] / X1[:, 2] + cy
+    kp1["octave"] = rng.integers(0, 8, n1); kp1["angle"] = rng.uniform(0, 360, n1).astype(np.float32)
+    d1 = rng.integers(0, 256, (n1, 32), dtype=np.uint8)
+    nid1 = (rng.integers(0, n_nodes, n1) * 3 + 100).astype(np.int32)
+    src = rng.integers(0, max(n1, 1), n2) if n1 else np.zeros(n2, np.int64)
+    if n1:
+        noise = rng.integers(0, 256, (n2, 32), dtype=np.uint8) & rng.integers(0, 256, (n2, 32), dtype=np.uint8) & rng.integers(0, 256, (n2, 32), dtype=np.uint8)
+        noise[rng.random(n2) < 0.3] = 0                                   # exact copies: equal distances inside a node
+        d2 = d1[src] ^ noise
+        nid2 = np.where(rng.random(n2) < 0.85, nid1[src], rng.integers(0, n_nodes + 10, n2) * 3 + 101).astype(np.int32)
+        kp2["x"] = fx * X2[src, 0] / X2[src, 2] + cx + rng.normal(0, 1.0, n2) * rng.choice([0.3, 1, 4], n2)
+        kp2["y"] = fy * X2[src, 1] / X2[src, 2] + cy + rng.normal(0, 1.0, n2) * rng.choice([0.3, 1, 4], n2)
+        near = rng.random(n2) < 0.05                                      # a few keypoints next to the epipole
+        kp2["x"][near] = ep[0] + rng.uniform(-12, 12, near.sum()); kp2["y"][near] = ep[1] + rng.uniform(-12, 12, near.sum())
+        kp2["angle"] = (kp1["angle"][src] + rng.choice([0, 0, 0, 90], n2) + rng.normal(0, 4, n2)).astype(np.float32) % np.float32(360)
+    else:
+        d2 = rng.integers(0, 256, (n2, 32), dtype=np.uint8); nid2 = (rng.integers(0, n_nodes, n2) * 3 + 100).astype(np.int32)
+    kp2["octave"] = rng.integers(0, 8, n2)
+    ur1 = np.where(rng.random(n1) < stereo_frac, kp1["x"] - 5, -1).astype(np.float32)
+    ur2 = np.where(rng.random(n2) < stereo_frac, kp2["x"] - 5, -1).astype(np.float32)
+    return dict(kp1=kp1, d1=d1, nid1=nid1, mp1=(rng.random(n1) < 0.3).astype(np.uint8), ur1=ur1,
+                kp2=kp2, d2=d2, nid2=nid2, mp2=(rng.random(n2) < 0.2).astype(np.uint8), ur2=ur2,
+                F12=F12.reshape(9).copy(), ep=ep, scale=scale, sigma2=sigma2, only_stereo=only_stereo, coarse=coarse)
+
+
+lib.orc_search_for_triangulation.restype = ci
+lib.orc_search_for_triangulation.argtypes = [vp] * 5 + [ci] + [vp] * 3 + [ci] + [vp] * 5 + [C.c_float, C.c_float, vp, vp, ci, ci, ci, vp]
+
+
+def search_for_triangulation(c, check_ori=True, mono=False):
+    i2, s2, f2 = feature_vector_csr(c["nid2"])
+    n1 = len(c["kp1"])
+    m = np.zeros(max(n1, 1), np.int32)
+    a = {k: np.ascontiguousarray(c[k]) for k in ("nid1", "mp1", "kp1", "d1", "ur1", "mp2", "kp2", "d2", "ur2", "F12", "scale", "sigma2")}
+    n = lib.orc_search_for_triangulation(a["nid1"].ctypes.data, a["mp1"].ctypes.data, a["kp1"].ctypes.data, a["d1"].ctypes.data,
+                                         None if mono else a["ur1"].ctypes.data, n1, i2.ctypes.data, s2.ctypes.data, f2.ctypes.data, len(i2),
+                                         a["mp2"].ctypes.data, a["kp2"].ctypes.data, a["d2"].ctypes.data, None if mono else a["ur2"].ctypes.data,
+                                         a["F12"].ctypes.data, float(c["ep"][0]), float(c["ep"][1]), a["scale"].ctypes.data, a["sigma2"].ctypes.data,
+                                         1 if c["only_stereo"] else 0, 1 if c["coarse"] else 0, 1 if check_ori else 0, m.ctypes.data)
+    return n, m[:n1]

@@ -435,3 +435,48 @@ def test_search_by_bow_parity(gpu_ctx, ratio, check_ori):
         np.testing.assert_array_equal(mf[p, :len(m_ref)], m_ref)
         tot += n_ref
     assert tot > 300
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stereo_frac,only_stereo,coarse,mono,check_ori", [(0.0, False, False, True, True), (0.4, False, False, False, True),
+                                                                             (0.5, True, False, False, False), (0.0, False, True, True, True)])
+def test_search_for_triangulation_parity(gpu_ctx, stereo_frac, only_stereo, coarse, mono, check_ori):
+    """CreateNewMapPoints matcher (ORBmatcher.cc:969-1210) on ragged keyframe pairs incl. empty sides, bit-exact vs the oracle."""
+    import torch
+    import orbhip
+    import oracle_match_bind as om
+    rng = np.random.default_rng(83)
+    cases = [om.make_tri_case(rng, a, b, nn, stereo_frac, only_stereo, coarse)
+             for a, b, nn in ((0, 20, 10), (30, 0, 10), (200, 260, 40), (1000, 950, 100), (2000, 2048, 300), (600, 1500, 900))]
+    P, MN, MNODE = len(cases), 2048, 2048
+    arr = dict(nid1=np.zeros((P, MN), np.int32), mp1=np.zeros((P, MN), np.uint8), kp1=np.zeros((P, MN), orbhip.KP_DTYPE),
+               d1=np.zeros((P, MN, 32), np.uint8), ur1=np.full((P, MN), -1, np.float32), n1=np.zeros(P, np.int32),
+               i2=np.zeros((P, MNODE), np.int32), s2=np.zeros((P, MNODE + 1), np.int32), f2=np.zeros((P, MN), np.int32), nn2=np.zeros(P, np.int32),
+               mp2=np.zeros((P, MN), np.uint8), kp2=np.zeros((P, MN), orbhip.KP_DTYPE), d2=np.zeros((P, MN, 32), np.uint8),
+               ur2=np.full((P, MN), -1, np.float32), n2=np.zeros(P, np.int32), geom=np.zeros(P, orbhip.TRI_PAIR_DTYPE))
+    for p, c in enumerate(cases):
+        a, b = len(c["kp1"]), len(c["kp2"])
+        i2, s2, f2 = om.feature_vector_csr(c["nid2"])
+        arr["nid1"][p, :a] = c["nid1"]; arr["mp1"][p, :a] = c["mp1"]; arr["kp1"][p, :a] = c["kp1"]; arr["d1"][p, :a] = c["d1"]
+        arr["ur1"][p, :a] = c["ur1"]; arr["n1"][p] = a
+        arr["i2"][p, :len(i2)] = i2; arr["s2"][p, :len(s2)] = s2; arr["f2"][p, :len(f2)] = f2; arr["nn2"][p] = len(i2)
+        arr["mp2"][p, :b] = c["mp2"]; arr["kp2"][p, :b] = c["kp2"]; arr["d2"][p, :b] = c["d2"]; arr["ur2"][p, :b] = c["ur2"]; arr["n2"][p] = b
+        arr["geom"][p] = (c["F12"], c["ep"][0], c["ep"][1], int(only_stereo), int(coarse))
+    t = {k: torch.from_numpy(v.view(np.uint8) if v.dtype.fields else v).cuda() for k, v in arr.items()}
+    m12 = torch.full((P, MN), -9, dtype=torch.int32, device="cuda"); nm = torch.full((P,), -9, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ur1 = 0 if mono else t["ur1"].data_ptr(); ur2 = 0 if mono else t["ur2"].data_ptr()
+    orbhip.search_for_triangulation_device(gpu_ctx, [t["nid1"].data_ptr(), t["mp1"].data_ptr(), t["kp1"].data_ptr(), t["d1"].data_ptr(), ur1, t["n1"].data_ptr()],
+                                           [t["i2"].data_ptr(), t["s2"].data_ptr(), t["f2"].data_ptr(), t["nn2"].data_ptr(), t["mp2"].data_ptr(),
+                                            t["kp2"].data_ptr(), t["d2"].data_ptr(), ur2, t["n2"].data_ptr()],
+                                           t["geom"].data_ptr(), P, MNODE, MN, MN, cases[0]["scale"], cases[0]["sigma2"], check_ori,
+                                           m12.data_ptr(), nm.data_ptr())
+    gpu_ctx.check_status()
+    m12, nm = m12.cpu().numpy(), nm.cpu().numpy()
+    tot = 0
+    for p, c in enumerate(cases):
+        n_ref, m_ref = om.search_for_triangulation(c, check_ori, mono)
+        assert nm[p] == n_ref, (p, nm[p], n_ref)
+        np.testing.assert_array_equal(m12[p, :len(m_ref)], m_ref)
+        tot += n_ref
+    assert tot > 300

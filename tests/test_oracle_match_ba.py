@@ -637,3 +637,101 @@ def test_search_by_bow_oracle_against_python():
             np.testing.assert_array_equal(m1, m)
         if nk >= 200:
             assert n1 > 20
+
+
+def _py_search_for_triangulation(c, check_ori, mono):
+    """Independent numpy/python restatement of ORBmatcher.cc:969-1210 + Pinhole.cpp:122-144 (node-major, like the reference)."""
+    f32 = np.float32
+    n1 = len(c["kp1"])
+    F = c["F12"].reshape(3, 3)
+    m = np.full(n1, -1, np.int32)
+    hist = [[] for _ in range(30)]
+    nodes2 = {}
+    for j, nid in enumerate(c["nid2"]):
+        nodes2.setdefault(int(nid), []).append(j)
+    nodes1 = {}
+    for i, nid in enumerate(c["nid1"]):
+        nodes1.setdefault(int(nid), []).append(i)
+    nm = 0
+    for nid in sorted(nodes1):
+        if nid not in nodes2:
+            continue
+        for i1 in nodes1[nid]:
+            if c["mp1"][i1]:
+                continue
+            st1 = (not mono) and c["ur1"][i1] >= 0
+            if c["only_stereo"] and not st1:
+                continue
+            k1 = c["kp1"][i1]
+            best, bi = 50, -1
+            for i2 in nodes2[nid]:
+                if c["mp2"][i2]:
+                    continue
+                st2 = (not mono) and c["ur2"][i2] >= 0
+                if c["only_stereo"] and not st2:
+                    continue
+                dist = int(np.unpackbits(c["d1"][i1] ^ c["d2"][i2]).sum())
+                if dist > 50 or dist > best:
+                    continue
+                k2 = c["kp2"][i2]
+                if not st1 and not st2:
+                    ex = f32(c["ep"][0]) - k2["x"]; ey = f32(c["ep"][1]) - k2["y"]
+                    if f32(f32(ex * ex) + f32(ey * ey)) < f32(f32(100) * c["scale"][k2["octave"]]):
+                        continue
+                a = f32(f32(f32(k1["x"] * F[0, 0]) + f32(k1["y"] * F[1, 0])) + F[2, 0])
+                b = f32(f32(f32(k1["x"] * F[0, 1]) + f32(k1["y"] * F[1, 1])) + F[2, 1])
+                cc = f32(f32(f32(k1["x"] * F[0, 2]) + f32(k1["y"] * F[1, 2])) + F[2, 2])
+                num = f32(f32(f32(a * k2["x"]) + f32(b * k2["y"])) + cc)
+                den = f32(f32(a * a) + f32(b * b))
+                ok = den != 0 and float(f32(f32(num * num) / den)) < 3.84 * float(c["sigma2"][k2["octave"]])
+                if ok or c["coarse"]:
+                    bi, best = i2, dist
+            if bi >= 0:
+                m[i1] = bi; nm += 1
+                if check_ori:
+                    rot = f32(k1["angle"] - c["kp2"][bi]["angle"])
+                    if rot < 0:
+                        rot = f32(rot + f32(360))
+                    v = float(f32(rot * f32(1.0 / 30)))
+                    b_ = int(np.floor(abs(v) + 0.5) * np.sign(v))
+                    if b_ == 30:
+                        b_ = 0
+                    hist[b_].append(i1)
+    if check_ori:
+        sz = [len(h) for h in hist]
+        order = []
+        m1 = m2 = m3 = 0; i1_ = i2_ = i3_ = -1
+        for i, s_ in enumerate(sz):
+            if s_ > m1:
+                m3, m2, m1 = m2, m1, s_; i3_, i2_, i1_ = i2_, i1_, i
+            elif s_ > m2:
+                m3, m2 = m2, s_; i3_, i2_ = i2_, i
+            elif s_ > m3:
+                m3, i3_ = s_, i
+        if m2 < f32(0.1) * f32(m1):
+            i2_ = i3_ = -1
+        elif m3 < f32(0.1) * f32(m1):
+            i3_ = -1
+        for i in range(30):
+            if i not in (i1_, i2_, i3_):
+                for j in hist[i]:
+                    m[j] = -1; nm -= 1
+    return nm, m
+
+
+@pytest.mark.parametrize("stereo_frac,only_stereo,coarse,mono", [(0.0, False, False, True), (0.4, False, False, False), (0.5, True, False, False),
+                                                                   (0.0, False, True, True)])
+def test_search_for_triangulation_oracle_against_python(stereo_frac, only_stereo, coarse, mono):
+    """CreateNewMapPoints matcher (ORBmatcher.cc:969-1210): C oracle vs an independent python restatement.  parity unpinned
+    against the running reference (OpenCV / DBoW2 absent); F12 is an input, computed by the caller as Pinhole.cpp:124-127."""
+    rng = np.random.default_rng(77)
+    tot = 0
+    for n1, n2 in ((0, 10), (25, 0), (150, 170), (400, 380)):
+        c = om.make_tri_case(rng, n1, n2, 25, stereo_frac, only_stereo, coarse)
+        for ori in (True, False):
+            n_a, m_a = om.search_for_triangulation(c, ori, mono)
+            n_b, m_b = _py_search_for_triangulation(c, ori, mono)
+            assert n_a == n_b
+            np.testing.assert_array_equal(m_a, m_b)
+            tot += n_a
+    assert tot > 40

@@ -67,6 +67,17 @@ for it in range(3):
                                 P, M, M, M, 0.7, True, mf.data_ptr(), nm.data_ptr())
     ctx.synchronize(); dt = time.perf_counter() - t0
 out["search_by_bow_256pairs_ms"] = round(dt * 1e3, 3); out["search_by_bow_matches_per_pair"] = round(float(nm[:P].float().mean().item()), 1)
+geom = np.zeros(P, orbhip.TRI_PAIR_DTYPE); geom["F12"] = np.array([0, 0, 0, 0, 0, -1, 0, 1, 0], np.float32); geom["ep_x"] = 1e6; geom["ep_y"] = 1e6
+d_geom = torch.from_numpy(geom.view(np.uint8)).cuda(); nomp = torch.zeros((B, M), dtype=torch.uint8, device="cuda")
+m12 = torch.zeros((P, M), dtype=torch.int32, device="cuda")
+for it in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    orbhip.search_for_triangulation_device(ctx, [nid.data_ptr(), nomp.data_ptr(), kp_p, desc_p, 0, cnt_p],
+                                           [t["fi"].data_ptr(), t["fs"].data_ptr(), t["ff"].data_ptr(), t["fn"].data_ptr(), nomp.data_ptr(),
+                                            kp_p + M * 28, desc_p + M * 32, 0, cnt_p + 4], d_geom.data_ptr(), P, M, M, M, sf, sf * sf, True,
+                                           m12.data_ptr(), nm.data_ptr())
+    ctx.synchronize(); dt = time.perf_counter() - t0
+out["search_for_triangulation_256pairs_ms"] = round(dt * 1e3, 3); out["search_for_triangulation_matches_per_pair"] = round(float(nm[:P].float().mean().item()), 1)
 q2 = q.copy(); q2["min_level"] = kp["octave"] - 1; q2["max_level"] = kp["octave"]; q2["radius"] = np.float32(3.0) * sf[np.clip(kp["octave"], 0, 7)]
 d_q2 = torch.from_numpy(q2.view(np.uint8)).cuda()
 bi = torch.zeros((B, M), dtype=torch.int32, device="cuda"); bd = torch.zeros((B, M), dtype=torch.int32, device="cuda")
