@@ -250,6 +250,21 @@ int orbhip_search_by_bow_device(orbhip_ctx *ctx,
         int pairs, int max_nodes, int max_n, size_t frame_stride_kp, float nn_ratio, int check_orientation,
         int32_t *d_match_f, int32_t *d_nmatches);
 
+/* ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12) (src/ORBmatcher.cc:827-967,
+ * NLeft == -1) -- the matcher of LoopClosing's Sim3 candidates (src/LoopClosing.cc:1005, 2284), batched over keyframe
+ * pairs.  Layout as orbhip_search_by_bow_device; both sides carry d_valid [pairs][max_n] (map point exists and is not
+ * bad, :867-871, :887-894) and their feature counts d_n1 / d_n2 [pairs].  Inside a shared node every valid KF1 feature,
+ * in order, takes the best valid, still unclaimed KF2 feature if best < TH_LOW (strict, :909) and best < nn_ratio *
+ * second.  d_matches12 [pairs][max_n]: per KF1 feature the KF2 feature whose map point it receives, or -1
+ * (vpMatches12[i] = vpMapPoints2[d_matches12[i]]).  At most 4096 features per keyframe.  All pointers DEVICE. */
+int orbhip_search_by_bow_kf_device(orbhip_ctx *ctx,
+        const int32_t *d_node_ids1, const int32_t *d_node_start1, const int32_t *d_feat1, const int32_t *d_nnodes1,
+        const uint8_t *d_valid1, const orbhip_keypoint *d_kp1, const uint8_t *d_desc1, const int32_t *d_n1,
+        const int32_t *d_node_ids2, const int32_t *d_node_start2, const int32_t *d_feat2, const int32_t *d_nnodes2,
+        const uint8_t *d_valid2, const orbhip_keypoint *d_kp2, const uint8_t *d_desc2, const int32_t *d_n2,
+        int pairs, int max_nodes, int max_n, size_t frame_stride_kp, float nn_ratio, int check_orientation,
+        int32_t *d_matches12, int32_t *d_nmatches);
+
 /* Per keyframe pair of orbhip_search_for_triangulation_device: F12 = K1^-T [t12]x R12 K2^-1 (row-major; computed by the
  * caller with the reference's own matrix arithmetic, CameraModels/Pinhole.cpp:124-127), the epipole of KF1's centre in KF2
  * (ORBmatcher.cc:978-992), and the bOnlyStereo / bCoarse arguments. */

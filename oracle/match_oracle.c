@@ -473,3 +473,107 @@ int orc_search_for_triangulation(const int32_t *nid1, const uint8_t *has_mp1, co
     free(bin_of);
     return nmatches;
 }
+
+/* ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12), ORBm:827-967, NLeft == -1 */
+int orc_search_by_bow_kf(const int32_t *node_ids1, const int32_t *node_start1, const int32_t *feat1, int nnodes1,
+                         const uint8_t *valid1, const orc_keypoint *kp1, const uint8_t *desc1, int n1,
+                         const int32_t *node_ids2, const int32_t *node_start2, const int32_t *feat2, int nnodes2,
+                         const uint8_t *valid2, const orc_keypoint *kp2, const uint8_t *desc2, int n2,
+                         float nn_ratio, int check_orientation, int32_t *matches12)
+{
+    int nmatches = 0;
+    int *hist_n = (int *)calloc(HISTO_LENGTH, sizeof(int));
+    int *hist_items = (int *)malloc(sizeof(int) * (size_t)HISTO_LENGTH * (n1 ? n1 : 1));
+    uint8_t *matched2 = (uint8_t *)calloc(n2 ? n2 : 1, 1);                    /* vbMatched2, :840 */
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    int a = 0, b = 0;
+    while (a < nnodes1 && b < nnodes2) {                                      /* :856-942 */
+        if (node_ids1[a] == node_ids2[b]) {
+            for (int i1 = node_start1[a]; i1 < node_start1[a + 1]; i1++) {
+                const int idx1 = feat1[i1];
+                if (!valid1[idx1]) continue;                                  /* :867-871 */
+                int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+                for (int i2 = node_start2[b]; i2 < node_start2[b + 1]; i2++) {
+                    const int idx2 = feat2[i2];
+                    if (matched2[idx2] || !valid2[idx2]) continue;            /* :887-891 */
+                    const int dist = orc_descriptor_distance(desc1 + 32 * (size_t)idx1, desc2 + 32 * (size_t)idx2);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = idx2; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 < TH_LOW && (float)bestDist1 < nn_ratio * (float)bestDist2) {   /* :909-911, strict */
+                    matches12[idx1] = bestIdx2; matched2[bestIdx2] = 1;
+                    if (check_orientation) {
+                        float rot = kp1[idx1].angle - kp2[bestIdx2].angle;
+                        if (rot < 0.0) rot += 360.0f;
+                        int bin = (int)roundf(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        hist_items[(size_t)bin * n1 + hist_n[bin]++] = idx1;
+                    }
+                    nmatches++;
+                }
+            }
+            a++; b++;
+        } else if (node_ids1[a] < node_ids2[b]) { while (a < nnodes1 && node_ids1[a] < node_ids2[b]) a++; }
+        else { while (b < nnodes2 && node_ids2[b] < node_ids1[a]) b++; }
+    }
+    if (check_orientation) {                                                  /* :944-963 */
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(hist_n, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int j = 0; j < hist_n[i]; j++) { matches12[hist_items[(size_t)i * n1 + j]] = -1; nmatches--; }
+    }
+    free(matched2); free(hist_items); free(hist_n);
+    return nmatches;
+}
+
+/* The search loop of ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th, ratioHamming), ORBm:553-595
+ * (and of its vpPointsKFs twin, :676-705): queries in order, candidates from KeyFrame::GetFeaturesInArea (KeyFrame.cc:770-814),
+ * keypoints that already hold a point are skipped, octave in [pred-1, pred], first minimum, claim if <= TH_LOW*ratioHamming. */
+int orc_search_by_projection_sim3(const orc_proj_query *q, const uint8_t *desc_q, int nq,
+                                  const orc_keypoint *kp, const uint8_t *desc, int n,
+                                  float min_x, float min_y, float max_x, float max_y, float ratio_hamming, int32_t *matched)
+{
+    struct grid g;
+    grid_build(&g, kp, n, min_x, min_y, max_x, max_y);
+    int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * (n ? n : 1));
+    int nmatches = 0;
+    for (int t = 0; t < nq; t++) {
+        const int nc = grid_query(&g, kp, q[t].u, q[t].v, q[t].radius, -1, -1, cand, n);     /* ORBm:541 */
+        int bestDist = 256, bestIdx = -1;
+        for (int c = 0; c < nc; c++) {
+            const int idx = cand[c];
+            if (matched[idx] != -1) continue;                                                /* ORBm:556-557 */
+            const int kpLevel = kp[idx].octave;
+            if (kpLevel < q[t].min_level || kpLevel > q[t].max_level) continue;              /* ORBm:561-562 */
+            const int dist = orc_descriptor_distance(desc_q + 32 * (size_t)t, desc + 32 * (size_t)idx);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestDist <= TH_LOW * ratio_hamming) { matched[bestIdx] = t; nmatches++; }        /* ORBm:575-579 */
+    }
+    free(cand); grid_free(&g);
+    return nmatches;
+}
+
+/* The per-point search of ORBmatcher::SearchBySim3 (ORBm:1825-1851, 1905-1931) and of Fuse(KeyFrame*, Scw, ...) (ORBm:1697-1720):
+ * independent queries, octave in [pred-1, pred], first minimum, no gate.  best_dist = INT_MAX when there is no candidate. */
+void orc_window_best(const orc_proj_query *q, const uint8_t *desc_q, int nq, const orc_keypoint *kp, const uint8_t *desc, int n,
+                     float min_x, float min_y, float max_x, float max_y, int32_t *best_idx, int32_t *best_dist)
+{
+    struct grid g;
+    grid_build(&g, kp, n, min_x, min_y, max_x, max_y);
+    int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * (n ? n : 1));
+    for (int t = 0; t < nq; t++) {
+        const int nc = grid_query(&g, kp, q[t].u, q[t].v, q[t].radius, -1, -1, cand, n);
+        int bestDist = 2147483647, bestIdx = -1;
+        for (int c = 0; c < nc; c++) {
+            const int idx = cand[c];
+            if (kp[idx].octave < q[t].min_level || kp[idx].octave > q[t].max_level) continue;
+            const int dist = orc_descriptor_distance(desc_q + 32 * (size_t)t, desc + 32 * (size_t)idx);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        best_idx[t] = bestIdx; best_dist[t] = bestDist;
+    }
+    free(cand); grid_free(&g);
+}

@@ -92,6 +92,22 @@ int orc_search_for_triangulation(const int32_t *nid1, const uint8_t *has_mp1, co
                                  const uint8_t *has_mp2, const orc_keypoint *kp2, const uint8_t *desc2, const float *u_right2,
                                  const float F12[9], float ep_x, float ep_y, const float *scale_factors, const float *level_sigma2,
                                  int only_stereo, int coarse, int check_orientation, int32_t *matches12);
+/* ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vpMatches12) (ORBmatcher.cc:827-967, NLeft == -1): as
+ * orc_search_by_bow but both sides carry a "has a good map point" flag, a KF2 feature is claimed through vbMatched2, the
+ * distance test is strict (best < TH_LOW, :909) and the result is indexed by the KF1 feature: matches12 [n1] = idx2 or -1. */
+int orc_search_by_bow_kf(const int32_t *node_ids1, const int32_t *node_start1, const int32_t *feat1, int nnodes1,
+                         const uint8_t *valid1, const orc_keypoint *kp1, const uint8_t *desc1, int n1,
+                         const int32_t *node_ids2, const int32_t *node_start2, const int32_t *feat2, int nnodes2,
+                         const uint8_t *valid2, const orc_keypoint *kp2, const uint8_t *desc2, int n2,
+                         float nn_ratio, int check_orientation, int32_t *matches12);
+/* Search loop of the Sim3 SearchByProjection overloads (ORBmatcher.cc:477-598, 600-708; LoopClosing).  matched [n] in/out:
+ * -1 = vpMatched[idx] == NULL, anything else = taken; a claimed keypoint receives the query index.  Returns nmatches. */
+int orc_search_by_projection_sim3(const orc_proj_query *q, const uint8_t *desc_q, int nq,
+                                  const orc_keypoint *kp, const uint8_t *desc, int n,
+                                  float min_x, float min_y, float max_x, float max_y, float ratio_hamming, int32_t *matched);
+/* Per-point window search of SearchBySim3 (ORBmatcher.cc:1813-1851, 1893-1931) and Fuse(KeyFrame*, Scw, ...) (:1687-1720). */
+void orc_window_best(const orc_proj_query *q, const uint8_t *desc_q, int nq, const orc_keypoint *kp, const uint8_t *desc, int n,
+                     float min_x, float min_y, float max_x, float max_y, int32_t *best_idx, int32_t *best_dist);
 /* MapPoint::ComputeDistinctiveDescriptors (/root/reference/src/MapPoint.cc:327-403): among the n
  * descriptors that observe a map point, the one with the least median Hamming distance to all of them
  * (median = sorted row [int(0.5*(n-1))], self distance 0 included; first minimum wins).  Returns BestIdx (0 if n<=0). */

@@ -853,23 +853,30 @@ extern "C" int orbhip_fuse_search_device(orbhip_ctx *ctx, const orbhip_proj_quer
 // independent.  One wave per (keyframe, frame) pair, one lane per shared node (binary search of the frame's sorted node list),
 // the node's KF features in order, the frame's descriptors and match slots LDS-resident.
 struct BowSide { const int32_t *node_ids, *node_start, *feat, *nnodes; const orbhip_keypoint *kp; const uint8_t *desc; };
-__global__ __launch_bounds__(64) void k_search_by_bow(BowSide K, const uint8_t *kf_valid_, BowSide F, const int32_t *nF_, int max_nodes, int max_n,
+// KF_MODE: SearchByBoW(KeyFrame*, KeyFrame*) (ORBmatcher.cc:827-967): side F is the second keyframe with its own validity
+// flags, the distance test is strict (:909) and the result is indexed by the first keyframe's feature (vpMatches12).
+template <bool KF_MODE>
+__global__ __launch_bounds__(64) void k_search_by_bow(BowSide K, const uint8_t *kf_valid_, const int32_t *nK_, BowSide F, const uint8_t *f_valid_,
+                                                      const int32_t *nF_, int max_nodes, int max_n,
                                                       size_t kp_stride, float nn_ratio, int check_ori, int cap_n,
                                                       int32_t *match_f_, int32_t *nmatches_, int32_t *status)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t bow_lds[];
     uint4 *dlds = reinterpret_cast<uint4 *>(bow_lds);                       // [cap_n][2] frame descriptors
-    int16_t *mf = reinterpret_cast<int16_t *>(dlds + 2 * (size_t)cap_n);    // [cap_n] KF feature matched to frame feature j, or -1
-    int8_t *fbin = reinterpret_cast<int8_t *>(mf + cap_n);                  // [cap_n] rotation bin of that match
+    int16_t *mf = reinterpret_cast<int16_t *>(dlds + 2 * (size_t)cap_n);    // [cap_n] KF feature matched to frame feature j, -1 free, -2 invalid
+    int16_t *inv = mf + cap_n;                                              // [cap_n] (KF_MODE) match of KF1 feature i
+    int8_t *fbin = reinterpret_cast<int8_t *>(inv + (KF_MODE ? cap_n : 0)); // [cap_n] rotation bin of that match
     __shared__ int hist[SI_HISTO];
     __shared__ int s_keep[3];
     const int pair = blockIdx.x, lane = threadIdx.x;
     const int nF = nF_[pair], nk = K.nnodes[pair], nf = F.nnodes[pair];
     int32_t *match_f = match_f_ + (size_t)pair * max_n;
-    if (nF > cap_n || nF > max_n || nk > max_nodes || nf > max_nodes) {
+    const int nK = KF_MODE ? nK_[pair] : 0;
+    if (nF > cap_n || nF > max_n || nK > cap_n || nK > max_n || nk > max_nodes || nf > max_nodes) {
         if (lane == 0) { atomicExch(status, ORBHIP_E_CAPACITY); nmatches_[pair] = 0; }
         return;
     }
+    const uint8_t *fvalid = KF_MODE ? f_valid_ + (size_t)pair * max_n : nullptr;
     const int32_t *kids = K.node_ids + (size_t)pair * max_nodes, *kst = K.node_start + (size_t)pair * (max_nodes + 1), *kfe = K.feat + (size_t)pair * max_n;
     const int32_t *fids = F.node_ids + (size_t)pair * max_nodes, *fst = F.node_start + (size_t)pair * (max_nodes + 1), *ffe = F.feat + (size_t)pair * max_n;
     const uint8_t *kvalid = kf_valid_ + (size_t)pair * max_n;
@@ -877,7 +884,11 @@ __global__ __launch_bounds__(64) void k_search_by_bow(BowSide K, const uint8_t *
     const uint4 *dK = reinterpret_cast<const uint4 *>(K.desc + (size_t)pair * kp_stride * 32);
     const uint4 *dF = reinterpret_cast<const uint4 *>(F.desc + (size_t)pair * kp_stride * 32);
     for (int i = lane; i < SI_HISTO; i += 64) hist[i] = 0;
-    for (int j = lane; j < nF; j += 64) { dlds[2 * j] = dF[2 * j]; dlds[2 * j + 1] = dF[2 * j + 1]; mf[j] = -1; fbin[j] = -1; }
+    for (int j = lane; j < nF; j += 64) {
+        dlds[2 * j] = dF[2 * j]; dlds[2 * j + 1] = dF[2 * j + 1]; fbin[j] = -1;
+        mf[j] = (KF_MODE && !fvalid[j]) ? -2 : -1;                          // :887-891
+    }
+    if (KF_MODE) for (int i = lane; i < nK; i += 64) inv[i] = -1;
     __syncthreads();
     const float factor = 1.0f / SI_HISTO;
     int mine = 0;
@@ -896,12 +907,12 @@ __global__ __launch_bounds__(64) void k_search_by_bow(BowSide K, const uint8_t *
             int b1 = 256, b2 = 256, bi = -1;
             for (int jf = f0; jf < f1; jf++) {                               // :317-336
                 const int rj = ffe[jf];
-                if (mf[rj] >= 0) continue;
+                if (mf[rj] != -1) continue;
                 const int dist = hamming256(a0v, a1v, dlds[2 * rj], dlds[2 * rj + 1]);
                 if (dist < b1) { b2 = b1; b1 = dist; bi = rj; }
                 else if (dist < b2) b2 = dist;
             }
-            if (b1 <= SI_TH_LOW && (float)b1 < __fmul_rn(nn_ratio, (float)b2)) {   // :362-366
+            if ((KF_MODE ? b1 < SI_TH_LOW : b1 <= SI_TH_LOW) && (float)b1 < __fmul_rn(nn_ratio, (float)b2)) {   // :362-366 / :909-911
                 mf[bi] = (int16_t)ri;
                 mine++;
                 if (check_ori) {                                             // :376-388
@@ -939,8 +950,36 @@ __global__ __launch_bounds__(64) void k_search_by_bow(BowSide K, const uint8_t *
         for (int d = 32; d >= 1; d >>= 1) removed += __shfl_xor(removed, d, 64);
     }
     __syncthreads();
-    for (int j = lane; j < nF; j += 64) match_f[j] = mf[j];
+    if (KF_MODE) {
+        for (int j = lane; j < nF; j += 64) if (mf[j] >= 0) inv[mf[j]] = (int16_t)j;
+        __syncthreads();
+        for (int i = lane; i < nK; i += 64) match_f[i] = inv[i];
+    } else {
+        for (int j = lane; j < nF; j += 64) match_f[j] = mf[j];
+    }
     if (lane == 0) nmatches_[pair] = mine - removed;
+}
+
+static int bow_launch(orbhip_ctx *ctx, bool kf_mode, const BowSide &K, const uint8_t *d_kf_valid, const int32_t *d_nK, const BowSide &F,
+                      const uint8_t *d_f_valid, const int32_t *d_nF, int pairs, int max_nodes, int max_n, size_t frame_stride_kp, float nn_ratio,
+                      int check_orientation, int32_t *d_match, int32_t *d_nmatches)
+{
+    if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
+    const int cap_n = ((max_n < 4096 ? max_n : 4096) + 7) & ~7;
+    const size_t lds = (size_t)cap_n * (32 + 2 + 1 + (kf_mode ? 2 : 0)) + 16;
+    static thread_local size_t lds_set[2] = {0, 0};
+    if (lds > lds_set[kf_mode]) {
+        const void *fn = kf_mode ? reinterpret_cast<const void *>(k_search_by_bow<true>) : reinterpret_cast<const void *>(k_search_by_bow<false>);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ORBHIP_E_HIP;
+        lds_set[kf_mode] = lds;
+    }
+    if (kf_mode)
+        hipLaunchKernelGGL(k_search_by_bow<true>, dim3(pairs), dim3(64), lds, orbhip_ctx_stream_internal(ctx), K, d_kf_valid, d_nK, F, d_f_valid, d_nF,
+                           max_nodes, max_n, frame_stride_kp, nn_ratio, check_orientation, cap_n, d_match, d_nmatches, orbhip_ctx_status_internal(ctx));
+    else
+        hipLaunchKernelGGL(k_search_by_bow<false>, dim3(pairs), dim3(64), lds, orbhip_ctx_stream_internal(ctx), K, d_kf_valid, d_nK, F, d_f_valid, d_nF,
+                           max_nodes, max_n, frame_stride_kp, nn_ratio, check_orientation, cap_n, d_match, d_nmatches, orbhip_ctx_status_internal(ctx));
+    return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
 }
 
 extern "C" int orbhip_search_by_bow_device(orbhip_ctx *ctx,
@@ -954,20 +993,27 @@ extern "C" int orbhip_search_by_bow_device(orbhip_ctx *ctx,
     if (!ctx || !d_kf_node_ids || !d_kf_node_start || !d_kf_feat || !d_kf_nnodes || !d_kf_valid || !d_kf_kp || !d_kf_desc || !d_f_node_ids ||
         !d_f_node_start || !d_f_feat || !d_f_nnodes || !d_f_kp || !d_f_desc || !d_nF || pairs <= 0 || max_nodes <= 0 || max_n <= 0 ||
         !d_match_f || !d_nmatches) return ORBHIP_E_BADARG;
-    if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
-    const int cap_n = ((max_n < 4096 ? max_n : 4096) + 7) & ~7;
-    const size_t lds = (size_t)cap_n * (32 + 2 + 1) + 16;
-    static thread_local size_t lds_set = 0;
-    if (lds > lds_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_by_bow), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return ORBHIP_E_HIP;
-        lds_set = lds;
-    }
     BowSide K = {d_kf_node_ids, d_kf_node_start, d_kf_feat, d_kf_nnodes, d_kf_kp, d_kf_desc};
     BowSide F = {d_f_node_ids, d_f_node_start, d_f_feat, d_f_nnodes, d_f_kp, d_f_desc};
-    hipLaunchKernelGGL(k_search_by_bow, dim3(pairs), dim3(64), lds, orbhip_ctx_stream_internal(ctx), K, d_kf_valid, F, d_nF, max_nodes, max_n,
-                       frame_stride_kp, nn_ratio, check_orientation, cap_n, d_match_f, d_nmatches, orbhip_ctx_status_internal(ctx));
-    return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
+    return bow_launch(ctx, false, K, d_kf_valid, nullptr, F, nullptr, d_nF, pairs, max_nodes, max_n, frame_stride_kp, nn_ratio, check_orientation,
+                      d_match_f, d_nmatches);
+}
+
+extern "C" int orbhip_search_by_bow_kf_device(orbhip_ctx *ctx,
+        const int32_t *d_node_ids1, const int32_t *d_node_start1, const int32_t *d_feat1, const int32_t *d_nnodes1,
+        const uint8_t *d_valid1, const orbhip_keypoint *d_kp1, const uint8_t *d_desc1, const int32_t *d_n1,
+        const int32_t *d_node_ids2, const int32_t *d_node_start2, const int32_t *d_feat2, const int32_t *d_nnodes2,
+        const uint8_t *d_valid2, const orbhip_keypoint *d_kp2, const uint8_t *d_desc2, const int32_t *d_n2,
+        int pairs, int max_nodes, int max_n, size_t frame_stride_kp, float nn_ratio, int check_orientation,
+        int32_t *d_matches12, int32_t *d_nmatches)
+{
+    if (!ctx || !d_node_ids1 || !d_node_start1 || !d_feat1 || !d_nnodes1 || !d_valid1 || !d_kp1 || !d_desc1 || !d_n1 || !d_node_ids2 ||
+        !d_node_start2 || !d_feat2 || !d_nnodes2 || !d_valid2 || !d_kp2 || !d_desc2 || !d_n2 || pairs <= 0 || max_nodes <= 0 || max_n <= 0 ||
+        !d_matches12 || !d_nmatches) return ORBHIP_E_BADARG;
+    BowSide K = {d_node_ids1, d_node_start1, d_feat1, d_nnodes1, d_kp1, d_desc1};
+    BowSide F = {d_node_ids2, d_node_start2, d_feat2, d_nnodes2, d_kp2, d_desc2};
+    return bow_launch(ctx, true, K, d_valid1, d_n1, F, d_valid2, d_n2, pairs, max_nodes, max_n, frame_stride_kp, nn_ratio, check_orientation,
+                      d_matches12, d_nmatches);
 }
 
 // ---------------------------------------------------------------------------- SearchForTriangulation

@@ -492,6 +492,16 @@ def fuse_search_device(ctx, d_q, d_desc_q, d_nq, max_q, d_kp, d_desc, d_u_right,
          "orbhip_fuse_search_device")
 
 
+lib.orbhip_search_by_bow_kf_device.argtypes = [vp] * 17 + [ci, ci, ci, sz, cf, ci, vp, vp]
+
+
+def search_by_bow_kf_device(ctx, kf1, kf2, pairs, max_nodes, max_n, kp_stride, nn_ratio, check_ori, d_matches12, d_nmatches):
+    """ORBmatcher::SearchByBoW(KeyFrame, KeyFrame), batched.  kf1 / kf2 = (d_node_ids, d_node_start, d_feat, d_nnodes, d_valid, d_kp,
+    d_desc, d_n): device addresses (ints)."""
+    _chk(lib.orbhip_search_by_bow_kf_device(ctx.h, *kf1, *kf2, pairs, max_nodes, max_n, kp_stride, nn_ratio, 1 if check_ori else 0,
+                                            d_matches12, d_nmatches), "orbhip_search_by_bow_kf_device")
+
+
 TRI_PAIR_DTYPE = np.dtype([("F12", "<f4", (9,)), ("ep_x", "<f4"), ("ep_y", "<f4"), ("only_stereo", "<i4"), ("coarse", "<i4")])
 lib.orbhip_search_for_triangulation_device.argtypes = [vp] * 17 + [ci, ci, ci, sz, vp, vp, ci, ci, vp, vp]
 

@@ -258,3 +258,45 @@ def search_for_triangulation(c, check_ori=True, mono=False):
                                          a["F12"].ctypes.data, float(c["ep"][0]), float(c["ep"][1]), a["scale"].ctypes.data, a["sigma2"].ctypes.data,
                                          1 if c["only_stereo"] else 0, 1 if c["coarse"] else 0, 1 if check_ori else 0, m.ctypes.data)
     return n, m[:n1]
+
+
+# ------------------------------------------------------------------ KF-KF SearchByBoW and the Sim3 searches
+lib.orc_search_by_bow_kf.restype = ci
+lib.orc_search_by_bow_kf.argtypes = [vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, ci, cf, ci, vp]
+
+
+def search_by_bow_kf(c, nn_ratio=0.75, check_ori=True):
+    """c: make_bow_case dict + 'valid2'.  Returns (nmatches, matches12 [n1])."""
+    i1, s1, f1 = feature_vector_csr(c["nid_k"]); i2, s2, f2 = feature_vector_csr(c["nid_f"])
+    n1, n2 = len(c["kp_k"]), len(c["kp_f"])
+    m = np.zeros(max(n1, 1), np.int32)
+    a = {k: np.ascontiguousarray(c[k]) for k in ("kp_k", "d_k", "valid", "kp_f", "d_f", "valid2")}
+    n = lib.orc_search_by_bow_kf(i1.ctypes.data, s1.ctypes.data, f1.ctypes.data, len(i1), a["valid"].ctypes.data, a["kp_k"].ctypes.data,
+                                 a["d_k"].ctypes.data, n1, i2.ctypes.data, s2.ctypes.data, f2.ctypes.data, len(i2), a["valid2"].ctypes.data,
+                                 a["kp_f"].ctypes.data, a["d_f"].ctypes.data, n2, nn_ratio, 1 if check_ori else 0, m.ctypes.data)
+    return n, m[:n1]
+
+
+lib.orc_search_by_projection_sim3.restype = ci
+lib.orc_search_by_projection_sim3.argtypes = [vp, vp, ci, vp, vp, ci, cf, cf, cf, cf, cf, vp]
+lib.orc_window_best.argtypes = [vp, vp, ci, vp, vp, ci, cf, cf, cf, cf, vp, vp]
+
+
+def search_by_projection_sim3(q, dq, kp, d, bounds, matched, ratio_hamming):
+    q = np.ascontiguousarray(q, PROJ_QUERY_DTYPE); dq = np.ascontiguousarray(dq, np.uint8)
+    kp = np.ascontiguousarray(kp, KP_DTYPE); d = np.ascontiguousarray(d, np.uint8)
+    tm = np.ascontiguousarray(matched, np.int32).copy()
+    if len(tm) == 0:
+        tm = np.zeros(1, np.int32)
+    n = lib.orc_search_by_projection_sim3(q.ctypes.data, dq.ctypes.data, len(q), kp.ctypes.data, d.ctypes.data, len(kp),
+                                          bounds[0], bounds[1], bounds[2], bounds[3], ratio_hamming, tm.ctypes.data)
+    return n, tm[:len(kp)]
+
+
+def window_best(q, dq, kp, d, bounds):
+    q = np.ascontiguousarray(q, PROJ_QUERY_DTYPE); dq = np.ascontiguousarray(dq, np.uint8)
+    kp = np.ascontiguousarray(kp, KP_DTYPE); d = np.ascontiguousarray(d, np.uint8)
+    bi = np.zeros(max(len(q), 1), np.int32); bd = np.zeros(max(len(q), 1), np.int32)
+    lib.orc_window_best(q.ctypes.data, dq.ctypes.data, len(q), kp.ctypes.data, d.ctypes.data, len(kp), bounds[0], bounds[1], bounds[2],
+                        bounds[3], bi.ctypes.data, bd.ctypes.data)
+    return bi[:len(q)], bd[:len(q)]

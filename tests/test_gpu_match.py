@@ -480,3 +480,88 @@ def test_search_for_triangulation_parity(gpu_ctx, stereo_frac, only_stereo, coar
         np.testing.assert_array_equal(m12[p, :len(m_ref)], m_ref)
         tot += n_ref
     assert tot > 300
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ratio,check_ori", [(0.75, True), (0.9, False)])
+def test_search_by_bow_kf_parity(gpu_ctx, ratio, check_ori):
+    """LoopClosing's KF-KF matcher (ORBmatcher.cc:827-967) on ragged pairs incl. empty sides, bit-exact vs the oracle."""
+    import torch
+    import orbhip
+    import oracle_match_bind as om
+    rng = np.random.default_rng(67)
+    cases = [om.make_bow_case(rng, nk, nf, nn) for nk, nf, nn in ((0, 20, 10), (30, 0, 10), (200, 260, 40), (1000, 950, 100), (2048, 2000, 300), (600, 1500, 900))]
+    for c in cases:
+        c["valid2"] = (rng.random(len(c["kp_f"])) < 0.8).astype(np.uint8)
+    P, MN, MNODE = len(cases), 2048, 2048
+    arr = dict(ki=np.zeros((P, MNODE), np.int32), ks=np.zeros((P, MNODE + 1), np.int32), kf=np.zeros((P, MN), np.int32), kn=np.zeros(P, np.int32),
+               fi=np.zeros((P, MNODE), np.int32), fs=np.zeros((P, MNODE + 1), np.int32), ff=np.zeros((P, MN), np.int32), fn=np.zeros(P, np.int32),
+               va=np.zeros((P, MN), np.uint8), vb=np.zeros((P, MN), np.uint8), kpk=np.zeros((P, MN), orbhip.KP_DTYPE), kpf=np.zeros((P, MN), orbhip.KP_DTYPE),
+               dk=np.zeros((P, MN, 32), np.uint8), df=np.zeros((P, MN, 32), np.uint8), n1=np.zeros(P, np.int32), n2=np.zeros(P, np.int32))
+    for p, c in enumerate(cases):
+        ki, ks, kf = om.feature_vector_csr(c["nid_k"]); fi, fs, ff = om.feature_vector_csr(c["nid_f"])
+        arr["ki"][p, :len(ki)] = ki; arr["ks"][p, :len(ks)] = ks; arr["kf"][p, :len(kf)] = kf; arr["kn"][p] = len(ki)
+        arr["fi"][p, :len(fi)] = fi; arr["fs"][p, :len(fs)] = fs; arr["ff"][p, :len(ff)] = ff; arr["fn"][p] = len(fi)
+        nk, nf = len(c["kp_k"]), len(c["kp_f"])
+        arr["va"][p, :nk] = c["valid"]; arr["vb"][p, :nf] = c["valid2"]; arr["kpk"][p, :nk] = c["kp_k"]; arr["kpf"][p, :nf] = c["kp_f"]
+        arr["dk"][p, :nk] = c["d_k"]; arr["df"][p, :nf] = c["d_f"]; arr["n1"][p] = nk; arr["n2"][p] = nf
+    t = {k: torch.from_numpy(v.view(np.uint8) if v.dtype == orbhip.KP_DTYPE else v).cuda() for k, v in arr.items()}
+    m12 = torch.full((P, MN), -9, dtype=torch.int32, device="cuda"); nm = torch.full((P,), -9, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    orbhip.search_by_bow_kf_device(gpu_ctx, [t[k].data_ptr() for k in ("ki", "ks", "kf", "kn", "va", "kpk", "dk", "n1")],
+                                   [t[k].data_ptr() for k in ("fi", "fs", "ff", "fn", "vb", "kpf", "df", "n2")], P, MNODE, MN, MN,
+                                   ratio, check_ori, m12.data_ptr(), nm.data_ptr())
+    gpu_ctx.check_status()
+    m12, nm = m12.cpu().numpy(), nm.cpu().numpy()
+    tot = 0
+    for p, c in enumerate(cases):
+        n_ref, m_ref = om.search_by_bow_kf(c, ratio, check_ori)
+        assert nm[p] == n_ref, (p, nm[p], n_ref)
+        np.testing.assert_array_equal(m12[p, :len(m_ref)], m_ref)
+        tot += n_ref
+    assert tot > 300
+
+
+@pytest.mark.gpu
+def test_sim3_searches_parity(gpu_ctx):
+    """LoopClosing's Sim3 matchers through the existing kernels: SearchByProjection(KF, Scw, ...)
+    (ORBmatcher.cc:477-708) = orbhip_search_by_projection_device with has_obs = 1, no uRight, no rotation check,
+    th_high = floor(TH_LOW*ratioHamming); the per-point searches of SearchBySim3 (:1813-1851) and Fuse(KF, Scw) (:1687-1720) =
+    orbhip_fuse_search_device with an all-zero inverse sigma table.  Bit-exact vs oracles restated from those reference lines."""
+    import torch
+    import orbhip
+    import oracle_match_bind as om
+    from test_oracle_match_ba import _sim3_case
+    rng = np.random.default_rng(71)
+    bounds = (0.0, 0.0, 640.0, 480.0)
+    cases = [_sim3_case(rng, n, nq) for n, nq in ((0, 10), (60, 0), (300, 500), (1000, 900), (2000, 2048))]
+    P, MQ, MN = len(cases), 2048, 2048
+    Q = np.zeros((P, MQ), orbhip.PROJ_QUERY_DTYPE); DQ = np.zeros((P, MQ, 32), np.uint8)
+    KP = np.zeros((P, MN), orbhip.KP_DTYPE); D = np.zeros((P, MN, 32), np.uint8); TM = np.full((P, MN), -1, np.int32)
+    nq = np.array([len(c[0]) for c in cases], np.int32); n = np.array([len(c[2]) for c in cases], np.int32)
+    for p, (q, dq, kp, d, tm) in enumerate(cases):
+        Q[p, :nq[p]] = q; DQ[p, :nq[p]] = dq; KP[p, :n[p]] = kp; D[p, :n[p]] = d; TM[p, :n[p]] = tm
+    t = [torch.from_numpy(a.view(np.uint8) if a.dtype in (orbhip.KP_DTYPE, orbhip.PROJ_QUERY_DTYPE) else a).cuda() for a in (Q, DQ, nq, KP, D, n)]
+    tot = 0
+    for ratio in (1.0, 0.5):
+        tm_d = torch.from_numpy(TM).cuda(); nm = torch.full((P,), -9, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        orbhip.search_by_projection_device(gpu_ctx, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), MQ, t[3].data_ptr(), t[4].data_ptr(), None,
+                                           t[5].data_ptr(), MN, MN, P, bounds, int(np.floor(np.float32(50) * np.float32(ratio))), False,
+                                           tm_d.data_ptr(), nm.data_ptr())
+        gpu_ctx.check_status()
+        got, nm = tm_d.cpu().numpy(), nm.cpu().numpy()
+        for p, (q, dq, kp, d, tm) in enumerate(cases):
+            n_ref, m_ref = om.search_by_projection_sim3(q, dq, kp, d, bounds, tm, ratio)
+            assert nm[p] == n_ref
+            np.testing.assert_array_equal(got[p, :n[p]], np.where(tm != -1, -2, m_ref))
+            tot += n_ref
+    assert tot > 300
+    bi = torch.full((P, MQ), -9, dtype=torch.int32, device="cuda"); bd = torch.full((P, MQ), -9, dtype=torch.int32, device="cuda")
+    orbhip.fuse_search_device(gpu_ctx, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), MQ, t[3].data_ptr(), t[4].data_ptr(), None, t[5].data_ptr(),
+                              MN, MN, P, np.zeros(8, np.float32), bounds, bi.data_ptr(), bd.data_ptr())
+    gpu_ctx.check_status()
+    bi, bd = bi.cpu().numpy(), bd.cpu().numpy()
+    for p, (q, dq, kp, d, tm) in enumerate(cases):
+        ri, rd = om.window_best(q, dq, kp, d, bounds)
+        np.testing.assert_array_equal(bi[p, :nq[p]], ri); np.testing.assert_array_equal(bd[p, :nq[p]], np.where(ri < 0, 256, rd))

@@ -735,3 +735,83 @@ def test_search_for_triangulation_oracle_against_python(stereo_frac, only_stereo
             np.testing.assert_array_equal(m_a, m_b)
             tot += n_a
     assert tot > 40
+
+
+def test_search_by_bow_kf_oracle_against_python():
+    """ORBmatcher::SearchByBoW(KeyFrame, KeyFrame) (ORBmatcher.cc:827-967): C oracle vs a python walk of the two maps."""
+    rng = np.random.default_rng(15)
+    for nk, nf in ((0, 20), (30, 0), (200, 260), (500, 450)):
+        c = om.make_bow_case(rng, nk, nf)
+        c["valid2"] = (rng.random(nf) < 0.8).astype(np.uint8)
+        for ratio, ori in ((0.75, True), (0.9, False)):
+            n1, m1 = om.search_by_bow_kf(c, ratio, ori)
+            fv1 = {}; fv2 = {}
+            for i, x in enumerate(c["nid_k"]): fv1.setdefault(int(x), []).append(i)
+            for i, x in enumerate(c["nid_f"]): fv2.setdefault(int(x), []).append(i)
+            m = np.full(nk, -1, np.int64); taken = np.zeros(nf, bool); nm = 0; hist = [[] for _ in range(30)]
+            for node in sorted(set(fv1) & set(fv2)):
+                for ri in fv1[node]:
+                    if not c["valid"][ri]:
+                        continue
+                    b1, b2, bi = 256, 256, -1
+                    for rj in fv2[node]:
+                        if taken[rj] or not c["valid2"][rj]:
+                            continue
+                        dist = int(np.unpackbits(c["d_k"][ri] ^ c["d_f"][rj]).sum())
+                        if dist < b1: b2, b1, bi = b1, dist, rj
+                        elif dist < b2: b2 = dist
+                    if b1 < 50 and np.float32(b1) < np.float32(ratio) * np.float32(b2):
+                        m[ri] = bi; taken[bi] = True; nm += 1
+                        if ori:
+                            rot = np.float32(c["kp_k"]["angle"][ri]) - np.float32(c["kp_f"]["angle"][bi])
+                            if rot < 0: rot = np.float32(rot + np.float32(360.0))
+                            b = int(np.floor(np.float32(rot * np.float32(1.0 / 30)) + 0.5))
+                            hist[0 if b == 30 else b].append(ri)
+            if ori:
+                sizes = [len(h) for h in hist]
+                m1_, m2_, m3_ = 0, 0, 0; i1 = i2 = i3 = -1
+                for i, sz in enumerate(sizes):
+                    if sz > m1_: m3_, m2_, m1_, i3, i2, i1 = m2_, m1_, sz, i2, i1, i
+                    elif sz > m2_: m3_, m2_, i3, i2 = m2_, sz, i2, i
+                    elif sz > m3_: m3_, i3 = sz, i
+                if m2_ < np.float32(0.1) * np.float32(m1_): i2 = i3 = -1
+                elif m3_ < np.float32(0.1) * np.float32(m1_): i3 = -1
+                for i in range(30):
+                    if i not in (i1, i2, i3):
+                        for ri in hist[i]:
+                            m[ri] = -1; nm -= 1
+            assert n1 == nm
+            np.testing.assert_array_equal(m1, m)
+        if nk >= 200:
+            assert n1 > 20
+
+
+def _sim3_case(rng, n, nq):
+    q, dq, kp, d, _, tm = make_sbp_case(rng, n, nq, False)
+    q["min_level"] = np.maximum(q["max_level"], 0) - 1; q["max_level"] = q["min_level"] + 1        # (pred-1, pred)
+    q["radius"] = np.float32(8.0) * np.float32(1.2) ** q["max_level"].astype(np.float32)
+    q["has_obs"] = 1; q["ur"] = -1
+    return q, dq, kp, d, tm
+
+
+def test_sim3_searches_map_onto_the_windowed_oracles():
+    """The Sim3 SearchByProjection overloads (ORBmatcher.cc:477-708) are the last-frame claim-rule search with every query owning
+    observations, no uRight gate, no rotation histogram and th_high = floor(TH_LOW*ratioHamming); the per-point searches of
+    SearchBySim3 (:1813-1851) and Fuse(KF, Scw) (:1687-1720) are the Fuse search with the chi2 gates open (zero inverse sigma
+    table).  Checked here oracle against oracle; tests/test_gpu_match.py runs the same mapping through the kernels."""
+    rng = np.random.default_rng(21)
+    bounds = (0.0, 0.0, 640.0, 480.0)
+    tot = 0
+    for n, nq in ((0, 5), (40, 0), (300, 250), (600, 500)):
+        q, dq, kp, d, tm = _sim3_case(rng, n, nq)
+        for ratio in (1.0, 0.9, 0.5):
+            n_a, m_a = om.search_by_projection_sim3(q, dq, kp, d, bounds, tm, ratio)
+            n_b, m_b = om.search_by_projection(q, dq, kp, d, None, bounds, tm, int(np.floor(np.float32(50) * np.float32(ratio))), False)
+            assert n_a == n_b
+            np.testing.assert_array_equal(np.where(tm != -1, -2, m_a), m_b)
+            tot += n_a
+        bi_a, bd_a = om.window_best(q, dq, kp, d, bounds)
+        bi_b, bd_b = om.fuse_search(q, dq, kp, d, None, np.zeros(8, np.float32), bounds)
+        np.testing.assert_array_equal(bi_a, bi_b)
+        np.testing.assert_array_equal(np.where(bi_a < 0, 256, bd_a), bd_b)
+    assert tot > 150
