@@ -39,7 +39,7 @@ struct BaGraphDev {
     size_t wd_off, s_off, spart_off, xl_off;         // element offsets
     int ks;                                          // split-K factor of the Schur GEMM (point chunks)
     int nt16;                                        // 16-column tiles per side (ld / 16)
-    int ngrp;                                        // tile groups (each workgroup keeps <= GEMM_WAVES*GEMM_TPW tiles in registers)
+    int ngrp;                                        // chunk groups (each workgroup keeps <= GEMM_WAVES*GEMM_NCH chunks of GEMM_C tiles in registers)
     double fx, fy, cx, cy, bf;
     int cam_model;                                   // 0 Pinhole, 1 KannalaBrandt8 (monocular edges)
     double kb[4];
@@ -670,47 +670,63 @@ __global__ __launch_bounds__(256) void k_ba_point_prep(BaBatch B)
 // Schur GEMM on the FP64 matrix cores:  S_sub = (D^-1 Wd)^T Wd  over the K-padded dense panel
 // Wd[4l+b][c] (K = 4 per point: 3 + zero pad), v_mfma_f64_16x16x4_f64:
 //   A[i][k] (lane i=l&15,k=l>>4), B[k][j] (lane j=l&15,k=l>>4), C/D 4 regs: col = l&15, row = (l>>4) + 4*reg.
-// One 512-thread workgroup (8 waves, up to 256 VGPRs each) owns a chunk of points of one graph.  The chunk's three Wd rows per point
-// are streamed through LDS ONCE (GEMM_PS points per stage) and every wave keeps its share of the upper
-// 16x16 output tiles (<= GEMM_TPW consecutive tiles per wave) in accumulator registers, so HBM/L2
-// sees each Wd byte once per launch instead of once per output tile.  Block sparsity: a point is seen
-// by ~10 of ~48 free keyframes; its static 16-column occupancy mask turns ~79 % of the (point, tile)
-// MFMAs into a wave-uniform scalar branch.  D^-1 is applied to the A fragment in registers.
+// One 512-thread workgroup (8 waves, up to 256 VGPRs each) owns a range of points of one graph.  The three Wd rows of every point
+// are streamed through LDS ONCE (GEMM_PS points per stage, LDS-DMA, double buffered) and the upper 16x16 output tiles stay in
+// accumulator registers, so HBM/L2 sees each Wd byte once per launch instead of once per output tile.
+// Tile ownership: every row strip of the upper triangle is cut into CHUNKS of GEMM_C consecutive tiles; chunk i belongs to wave
+// i % 8, slot i / 8 (GEMM_NCH slots per wave).  Block sparsity: a point is seen by ~10 of ~48 free keyframes; a chunk is multiplied
+// only if the point's static 16-column occupancy mask hits the chunk's row tile AND one of its column tiles -- ONE wave-uniform
+// scalar test per chunk, after which the A fragment (D^-1 applied in registers) and the GEMM_C B fragments are loaded back to back
+// and the GEMM_C MFMAs issue back to back (per-tile tests and per-tile loads left the matrix pipe waiting on LDS latency).
+// LDS rows are padded to ld+48 doubles so that the four K-rows of a B fragment fall into different bank halves.
 #define GEMM_PS 8
-#define GEMM_DENSE_STRIP 1     // every tile of a row strip the point touches is multiplied (no per-tile column test: 22 scalar
-                               // tests per point cost more than the ~10 extra MFMAs on zero blocks); 0 = skip empty tiles
-#define GEMM_TPW 22
+#define GEMM_C 3               // tiles per chunk
+#define GEMM_NCH 8             // chunks per wave
 #define GEMM_WAVES 8
+#define GEMM_LDS_PAD 48       // = 32 dwords mod 64 (bank halves) and room for the GEMM_C-1 tiles a short chunk reads past the row
+static_assert(GEMM_PS * GEMM_NCH <= 64 && GEMM_NCH * GEMM_C <= 32, "one lane per (stage point, chunk); one valid bit per tile");
+static inline __host__ __device__ int gemm_strip_chunks(int nt, int tr) { return (nt - tr + GEMM_C - 1) / GEMM_C; }
 __global__ __launch_bounds__(64 * GEMM_WAVES) void k_ba_schur_gemm(BaBatch B)
 {
-    extern __shared__ double glds[];               // [2][GEMM_PS][4][ld] staged Wd rows (row 3 = zero pad), double buffered
+    extern __shared__ double glds[];               // [2][GEMM_PS][3][ld + pad] staged Wd rows, double buffered
     __shared__ double s_dinv[2][GEMM_PS][6];
     __shared__ uint32_t s_mask[2][GEMM_PS];
     const int g = blockIdx.y;
     const BaState &st = B.st[g];
     if (!st.active) return;
     const BaGraphDev &G = B.gd[g];
-    const int nt = G.nt16, ntiles = nt * (nt + 1) / 2;
+    const int nt = G.nt16;
     if ((int)blockIdx.x >= G.ks * G.ngrp) return;
     const int ksi = blockIdx.x / G.ngrp, grp = blockIdx.x - ksi * G.ngrp;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lk = lane >> 4;
-    const int ld = G.ld;
-    // this wave's tiles: GEMM_TPW CONSECUTIVE tiles of the row-major upper-triangle enumeration, so they span
-    // at most a few row strips and the A fragment (which depends on the row tile only) is reused along a strip.
-    // tr/tc/need are wave-uniform -> scalar registers.
-    int trs[GEMM_TPW], tcs[GEMM_TPW];
-    uint32_t need[GEMM_TPW];
-    v4d acc[GEMM_TPW];
-    uint32_t rowbits = 0;                              // row tiles this wave touches
+    const int ld = G.ld, ldp = ld + GEMM_LDS_PAD;
+    // this wave's chunks: byte offsets of the row tile / first column tile inside an LDS row (wave-uniform -> scalar registers)
+    int aoff[GEMM_NCH], boffc[GEMM_NCH];
+    uint32_t cvalid = 0;                                 // tiles that exist: bit c*GEMM_C + j
+    v4d acc[GEMM_NCH * GEMM_C];
 #pragma unroll
-    for (int s = 0; s < GEMM_TPW; s++) {
-        acc[s] = (v4d){0, 0, 0, 0};
-        int t = (grp * GEMM_WAVES + wv) * GEMM_TPW + s, tr = 0;
-        if (t < ntiles) {
-            while (t >= nt - tr) { t -= nt - tr; tr++; }
-            trs[s] = tr; tcs[s] = tr + t; need[s] = (1u << tr) | (1u << (tr + t)); rowbits |= 1u << tr;
-        } else { trs[s] = -1; tcs[s] = -1; need[s] = 0xFFFFFFFFu; }
+    for (int c = 0; c < GEMM_NCH; c++) {
+        int id = (grp * GEMM_NCH + c) * GEMM_WAVES + wv, tr = 0;
+        while (tr < nt && id >= gemm_strip_chunks(nt, tr)) { id -= gemm_strip_chunks(nt, tr); tr++; }
+        if (tr < nt) {
+            const int tc = tr + id * GEMM_C, len = min(GEMM_C, nt - tc);
+            aoff[c] = 16 * tr; boffc[c] = 16 * tc; cvalid |= ((1u << len) - 1u) << (c * GEMM_C);
+        } else { aoff[c] = 0; boffc[c] = 0; }
+#pragma unroll
+        for (int j = 0; j < GEMM_C; j++) acc[c * GEMM_C + j] = (v4d){0, 0, 0, 0};
+    }
+    // the same table per LANE for the once-per-stage hit evaluation: lane = 8*point + chunk decides (point, chunk) for all
+    // GEMM_PS x GEMM_NCH = 64 combinations at once; the ballots replace ~20 scalar instructions per (point, chunk)
+    uint32_t lrow = 0, lcolbit[GEMM_C];
+    {
+        const int c = lane % GEMM_NCH;
+        int id = (grp * GEMM_NCH + c) * GEMM_WAVES + wv, tr = 0;
+        while (tr < nt && id >= gemm_strip_chunks(nt, tr)) { id -= gemm_strip_chunks(nt, tr); tr++; }
+        const int tc = tr + id * GEMM_C;
+#pragma unroll
+        for (int j = 0; j < GEMM_C; j++) lcolbit[j] = (tr < nt && tc + j < nt) ? 1u << (tc + j) : 0u;
+        if (tr < nt) lrow = 1u << tr;
     }
     const int per = (G.n_points + G.ks - 1) / G.ks;
     const int l0 = ksi * per, l1 = min(G.n_points, l0 + per);
@@ -718,9 +734,11 @@ __global__ __launch_bounds__(64 * GEMM_WAVES) void k_ba_schur_gemm(BaBatch B)
     const double *Dv = B.Dinv + (size_t)G.point_off * 6;
     const uint32_t *pm = B.ptmask + G.point_off;
     const int s0 = lk == 0 ? 0 : lk == 1 ? 1 : 2, s1 = lk == 0 ? 1 : lk == 1 ? 3 : 4, s2 = lk == 0 ? 2 : lk == 1 ? 4 : 5;
-    const double live = lk < 3 ? 1.0 : 0.0;
+    const double live = lk < 3 ? 1.0 : 0.0;          // K-row 3 is the pad: A is zero there, B re-reads row 2 (finite)
+    const int boff = min(lk, 2) * ldp + li;
     // double-buffered stages: the LDS-DMA of stage k+1 is in flight while stage k is multiplied
-    const size_t stage_doubles = (size_t)GEMM_PS * 4 * ld;
+    const size_t stage_doubles = (size_t)GEMM_PS * 3 * ldp;
+    const int row_bytes = ld * 8, ppr = (row_bytes + 1023) >> 10;      // 1-KiB pieces per Wd row
     auto issue_stage = [&](int lb, int buf) {
         const int np = min(GEMM_PS, l1 - lb);
         // ordinary loads first: hipcc waits vmcnt(0) at the first use of an ordinary load while an LDS-DMA is in
@@ -728,15 +746,16 @@ __global__ __launch_bounds__(64 * GEMM_WAVES) void k_ba_schur_gemm(BaBatch B)
         if (tid < np * 6) s_dinv[buf][tid / 6][tid % 6] = Dv[(size_t)(lb + tid / 6) * 6 + tid % 6];
         if (tid < np) s_mask[buf][tid] = pm[lb + tid];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // asynchronous global -> LDS copy (global_load_lds_dwordx4): a point's four K-rows are one contiguous
-        // block of 4*ld doubles = ld/32 pieces of 1 KiB; no staging registers, all pieces in flight at once
-        const int ppp = ld >> 5;                            // 1-KiB pieces per point (ld is a multiple of 32)
-        for (int piece = wv; piece < np * ppp; piece += GEMM_WAVES) {
-            const int p = piece / ppp, k = piece - p * ppp;
-            const char *gsrc = reinterpret_cast<const char *>(Wd + (size_t)(4 * (lb + p)) * ld) + k * 1024 + lane * 16;
-            char *ldst = reinterpret_cast<char *>(glds + buf * stage_doubles) + ((size_t)p * 4 * ld * 8) + k * 1024;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
-                                             (__attribute__((address_space(3))) void *)ldst, 16, 0, 0);
+        // asynchronous global -> LDS copy (global_load_lds_dwordx4), one Wd row = ppr pieces of <= 1 KiB
+        for (int piece = wv; piece < np * 3 * ppr; piece += GEMM_WAVES) {
+            const int row = piece / ppr, k = piece - row * ppr;          // row = 3*p + b
+            const int p = row / 3, b3 = row - 3 * p;
+            if (k * 1024 + lane * 16 < row_bytes) {
+                const char *gsrc = reinterpret_cast<const char *>(Wd + (size_t)(4 * (lb + p) + b3) * ld) + k * 1024 + lane * 16;
+                char *ldst = reinterpret_cast<char *>(glds + buf * stage_doubles + (size_t)row * ldp) + k * 1024;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                                 (__attribute__((address_space(3))) void *)ldst, 16, 0, 0);
+            }
         }
     };
     if (l0 < l1) issue_stage(l0, 0);
@@ -747,35 +766,49 @@ __global__ __launch_bounds__(64 * GEMM_WAVES) void k_ba_schur_gemm(BaBatch B)
         __syncthreads();                                    // ... everyone's have, and stage k-1 is fully consumed
         if (lb + GEMM_PS < l1) issue_stage(lb + GEMM_PS, cur ^ 1);
         const double *stage = glds + cur * stage_doubles;
-        for (int p = 0; p < np; p++) {
-            const uint32_t mask = __builtin_amdgcn_readfirstlane(s_mask[cur][p]);
-            if ((mask & rowbits) == 0) continue;            // the point touches none of this wave's row strips
-            const double *rows = stage + (size_t)p * 4 * ld;
-            const double d0 = s_dinv[cur][p][s0], d1 = s_dinv[cur][p][s1], d2 = s_dinv[cur][p][s2];
-            double a = 0.0;
-            bool rowhit = false;
+        // which (point, chunk, tile) combinations of this stage hold data: one evaluation per lane, GEMM_C ballots
+        unsigned long long hit[GEMM_C];
+        {
+            const int pl = lane / GEMM_NCH;
+            const uint32_t m = pl < np ? s_mask[cur][pl] : 0u;
+            const bool rh = (m & lrow) != 0;
 #pragma unroll
-            for (int s = 0; s < GEMM_TPW; s++) {
-                if (s == 0 || trs[s] != trs[s - 1]) {       // new row strip: (re)build the A fragment if the strip is hit
-                    rowhit = trs[s] >= 0 && ((mask >> trs[s]) & 1u);
-                    if (rowhit) {
-                        const double *q = rows + 16 * trs[s] + li;
-                        a = live * (d0 * q[0] + d1 * q[ld] + d2 * q[2 * ld]);
-                    }
-                }
-                if (GEMM_DENSE_STRIP ? rowhit : ((mask & need[s]) == need[s])) {
-                    const double b = rows[lk * ld + 16 * tcs[s] + li];          // K-row 3 is the zero pad
-                    acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[s], 0, 0, 0);
+            for (int j = 0; j < GEMM_C; j++) hit[j] = __ballot(rh && (m & lcolbit[j]));
+        }
+        for (int p = 0; p < np; p++) {
+            uint32_t tj[GEMM_C], any = 0;
+#pragma unroll
+            for (int j = 0; j < GEMM_C; j++) { tj[j] = (uint32_t)(hit[j] >> (GEMM_NCH * p)) & ((1u << GEMM_NCH) - 1u); any |= tj[j]; }
+            if (any == 0) continue;                         // the point touches none of this wave's chunks
+            const double *rows = stage + (size_t)p * 3 * ldp;
+            const double d0 = s_dinv[cur][p][s0], d1 = s_dinv[cur][p][s1], d2 = s_dinv[cur][p][s2];
+#pragma unroll
+            for (int c = 0; c < GEMM_NCH; c++) {
+                if (any & (1u << c)) {
+                    const double *q = rows + aoff[c] + li;
+                    const double q0 = q[0], q1 = q[ldp], q2 = q[2 * ldp];
+                    double bf[GEMM_C];
+#pragma unroll
+                    for (int j = 0; j < GEMM_C; j++) bf[j] = rows[boff + boffc[c] + 16 * j];   // tiles past nt: pad garbage, never multiplied
+                    __builtin_amdgcn_sched_barrier(0);          // all 3 + GEMM_C LDS reads in flight before the first wait
+                    const double a = live * (d0 * q0 + d1 * q1 + d2 * q2);
+#pragma unroll
+                    for (int j = 0; j < GEMM_C; j++)
+                        if (tj[j] & (1u << c))                  // the fragments are already in registers: an empty tile costs one scalar test
+                            acc[c * GEMM_C + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bf[j], acc[c * GEMM_C + j], 0, 0, 0);
                 }
             }
         }
     }
     double *Sp = B.Spart + G.spart_off + (size_t)ksi * ld * ld;
 #pragma unroll
-    for (int s = 0; s < GEMM_TPW; s++) {
-        if (trs[s] >= 0) {
+    for (int c = 0; c < GEMM_NCH; c++) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) Sp[(size_t)(16 * trs[s] + lk + 4 * r) * ld + 16 * tcs[s] + li] = acc[s][r];
+        for (int j = 0; j < GEMM_C; j++) {
+            if ((cvalid >> (c * GEMM_C + j)) & 1u) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) Sp[(size_t)(aoff[c] + lk + 4 * r) * ld + boffc[c] + 16 * j + li] = acc[c * GEMM_C + j][r];
+            }
         }
     }
 }
@@ -1142,7 +1175,7 @@ struct orbhip_ba_batch {
     float gemm_ms_total; int gemm_launches;
     double gemm_flops_per_launch;            // MFMA flops actually issued by one launch (all graphs)
     double gemm_flops_dense;                 // what the same upper tiles would cost without block-sparsity skipping
-    double gemm_flops_issued;                // MFMA flops issued by one launch (GEMM_DENSE_STRIP: whole row strips the point touches)
+    double gemm_flops_issued;                // MFMA flops issued by one launch (every tile of a chunk whose row tile and one column tile the point touches)
 };
 
 template <typename T>
@@ -1266,7 +1299,9 @@ extern "C" int orbhip_ba_batch_create(orbhip_ctx *ctx, const orbhip_ba_graph *gr
             eis2.push_back(H.edge_inv_sigma2[e]); est.push_back(H.edge_stereo ? H.edge_stereo[e] : 0);
         }
         const int nt = D.ld / 16, ntiles = nt * (nt + 1) / 2;
-        D.nt16 = nt; D.ngrp = (ntiles + GEMM_WAVES * GEMM_TPW - 1) / (GEMM_WAVES * GEMM_TPW);
+        int nchunks = 0;
+        for (int tr = 0; tr < nt; tr++) nchunks += gemm_strip_chunks(nt, tr);
+        D.nt16 = nt; D.ngrp = (nchunks + GEMM_WAVES * GEMM_NCH - 1) / (GEMM_WAVES * GEMM_NCH);
         // split the points so that ~2 workgroups per CU are in flight (each streams its chunk of Wd once)
         int ks = (512 + n_graphs * D.ngrp - 1) / (n_graphs * D.ngrp);
         ks = std::max(1, std::min(ks, std::max(1, H.n_points / (4 * GEMM_PS))));
@@ -1279,13 +1314,20 @@ extern "C" int orbhip_ba_batch_create(orbhip_ctx *ctx, const orbhip_ba_graph *gr
                 const int h = local_h[H.edge_pose[e]];
                 if (h >= 0) pmv[H.edge_point[e]] |= (1u << ((6 * h) >> 4)) | (1u << ((6 * h + 5) >> 4));
             }
-            double strips = 0;
+            double chunks = 0;                                                         // the kernel's issue rule: row tile hit AND a column tile of the chunk hit
             for (int l = 0; l < H.n_points; l++) {
                 const double k = __builtin_popcount(pmv[l]); issued += k * (k + 1) / 2;
-                for (int tr = 0; tr < nt; tr++) if ((pmv[l] >> tr) & 1u) strips += nt - tr;
+                for (int tr = 0; tr < nt; tr++) {
+                    if (!((pmv[l] >> tr) & 1u)) continue;
+                    for (int tc = tr; tc < nt; tc += GEMM_C) {
+                        const int len = std::min(GEMM_C, nt - tc);
+                        const uint32_t hit = pmv[l] & (((1u << len) - 1u) << tc);
+                        if (hit) chunks += __builtin_popcount(hit);
+                    }
+                }
             }
             b->gemm_flops_per_launch += issued * 2048.0;                               // one 16x16x4 f64 MFMA (2048 flop) per (point, upper tile) that holds data
-            b->gemm_flops_issued += (GEMM_DENSE_STRIP ? strips : issued) * 2048.0;
+            b->gemm_flops_issued += chunks * 2048.0;
             b->gemm_flops_dense += (double)ntiles * 2048.0 * (double)H.n_points;        // same tiles without the masks
         }
         D.wd_off = wd; wd += (size_t)4 * H.n_points * D.ld;
@@ -1372,7 +1414,7 @@ extern "C" int orbhip_ba_batch_solve(orbhip_ba_batch *b, const orbhip_ba_params 
     const dim3 gf(std::max(B.max_nf, 1), G);
     int max_items = 0, max_poses = 0;
     for (auto &D : b->gd) { max_items = std::max(max_items, D.ks * D.ngrp); max_poses = std::max(max_poses, D.n_poses); }
-    const size_t gemm_lds = sizeof(double) * 2 * GEMM_PS * 4 * (size_t)B.max_ld;
+    const size_t gemm_lds = sizeof(double) * 2 * GEMM_PS * 3 * (size_t)(B.max_ld + GEMM_LDS_PAD);
     TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_schur_gemm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds));
     const size_t ldlt_lds = ba_ldlt_lds_bytes(B.max_ld);
     TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_ldlt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldlt_lds));
