@@ -36,8 +36,10 @@ struct BaGraphDev {
     int n_poses, n_points, n_edges, nf, n, ld;      // n = 6*nf, ld = n rounded up to 96
     int pose_off, point_off, edge_off, free_off;     // offsets into the concatenated arrays
     int ptstart_off, posestart_off;                  // into pt_start / pose_start (+g extra entries)
-    size_t wd_off, s_off, spart_off, xl_off;         // element offsets
-    int ks;                                          // split-K factor of the Schur GEMM (point chunks)
+    size_t s_off, spart_off, xl_off;                 // element offsets
+    int gemm_off, stage_off, n_stages;               // Schur GEMM work lists: first entry of gemm_task / gemm_stage, number of stages
+    int gemm_ps;                                     // points per stage (<= GEMM_PS; fewer when ld is large: the LDS panel is [2][gemm_ps][3][ld+16])
+    int ks;                                          // split-K factor of the Schur GEMM (ranges of stages)
     int nt16;                                        // 16-column tiles per side (ld / 16)
     int ngrp;                                        // chunk groups (each workgroup keeps <= GEMM_WAVES*GEMM_NCH chunks of GEMM_C tiles in registers)
     double fx, fy, cx, cy, bf;
@@ -83,7 +85,13 @@ struct BaBatch {      // kernel argument (by value)
     // system
     double *Hll, *bl, *Dinv, *db;        // [sumL*6] [sumL*3] [sumL*6] [sumL*3]
     double *Hpp, *bp, *bs;               // [sumF*36] [sumF*6] [sumF*6]
-    double *Wd;                          // per graph [4*L][ld]
+    double *Wsp;                         // [tasks][18] Hpl block of edge_task[e], [b*6 + a] = (J_T^T w Omega J_X)[a][b] (first edge of a twin chain: the sum)
+    const int *edge_task;                // [sumE] index of the edge's Hpl block in Wsp / gemm_task (batch-global), -1: fixed pose or later twin
+    double *Linv;                        // [sumL*6] rows of C^-1 (lower), D = Hll + lambda I = C C^T: l00 l10 l11 l20 l21 l22
+    // Schur GEMM work lists (static): the edges with a free pose and no earlier twin, point-major, cut into stages of
+    // <= GEMM_PS points and <= GEMM_STAGE_EDGES edges
+    const int4 *gemm_task;               // {graph-local edge, 6*h, point, 0}
+    const int4 *gemm_stage;              // per stage {first point, number of points, first task, number of tasks}
     const uint32_t *ptmask;              // [sumL] bit t: the point's Hpl column is non-zero inside columns [16t, 16t+16) (static)
     double *S, *Spart;                   // per graph [ld*ld], [ks][ld*ld]
     double *xp, *xl;                     // [sumF*6], [sumL*3]
@@ -437,8 +445,7 @@ __global__ __launch_bounds__(256) void k_ba_reduce(BaBatch B, int which)
 // buildSystem, landmark side: 16 lanes per point share its (contiguous) edges -- one edge per lane and trip, so the
 // Jacobians of a point's ~10 observations are evaluated side by side and their scattered Hpl writes are in flight
 // together; Hll / bl are reduced over the 16 lanes in a fixed (butterfly) order.
-// Hll (sym 6), bl, and the point's column of Hpl written into the dense K-padded panel
-// Wd[4*l + b][6*h + a] = (J_T^T w Omega J_X)[a][b].
+// Hll (sym 6), bl, and the edge's Hpl block Wsp[e][6*b + a] = (J_T^T w Omega J_X)[a][b].
 __global__ __launch_bounds__(256) void k_ba_build_points(BaBatch B)
 {
     const int g = blockIdx.y;
@@ -452,7 +459,6 @@ __global__ __launch_bounds__(256) void k_ba_build_points(BaBatch B)
     const int e0 = ps[l], e1 = ps[l + 1];
     const double *X = B.points + ((size_t)st.cur * B.sumL + G.point_off + l) * 3;
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // H (6, upper) then b (3)
-    double *Wd = B.Wd + G.wd_off + (size_t)(4 * l) * G.ld;
     for (int e = e0 + sub; e < e1; e += 16) {
         const int ge = G.edge_off + e;
         const int pi = B.edge_pose[ge];
@@ -520,10 +526,9 @@ __global__ __launch_bounds__(256) void k_ba_build_points(BaBatch B)
                         Wb[6 * bb + a] += h;
                     }
             }
+            double *wo = B.Wsp + (size_t)B.edge_task[ge] * 18;
 #pragma unroll
-            for (int bb = 0; bb < 3; bb++)
-#pragma unroll
-                for (int a = 0; a < 6; a++) Wd[(size_t)bb * G.ld + 6 * hi + a] = Wb[6 * bb + a];
+            for (int k = 0; k < 18; k++) wo[k] = Wb[k];
         }
     }
 #pragma unroll
@@ -653,7 +658,7 @@ __global__ __launch_bounds__(256) void k_ba_point_prep(BaBatch B)
     if (l >= G.n_points) return;
     const int *ps = B.pt_start + G.ptstart_off;
     double *Di = B.Dinv + (size_t)(G.point_off + l) * 6, *db = B.db + (size_t)(G.point_off + l) * 3;
-    if (ps[l + 1] == ps[l]) { for (int i = 0; i < 6; i++) Di[i] = 0; db[0] = db[1] = db[2] = 0; return; }
+    if (ps[l + 1] == ps[l]) { for (int i = 0; i < 6; i++) { Di[i] = 0; B.Linv[(size_t)(G.point_off + l) * 6 + i] = 0; } db[0] = db[1] = db[2] = 0; return; }
     const double *H = B.Hll + (size_t)(G.point_off + l) * 6;
     const double a00 = H[0] + st.lambda, a01 = H[1], a02 = H[2], a11 = H[3] + st.lambda, a12 = H[4], a22 = H[5] + st.lambda;
     const double c0 = a11 * a22 - a12 * a12, c1 = a12 * a02 - a01 * a22, c2 = a01 * a12 - a11 * a02;
@@ -661,36 +666,54 @@ __global__ __launch_bounds__(256) void k_ba_point_prep(BaBatch B)
     const double i00 = c0 * id, i01 = c1 * id, i02 = c2 * id;
     const double i11 = (a00 * a22 - a02 * a02) * id, i12 = (a02 * a01 - a00 * a12) * id, i22 = (a00 * a11 - a01 * a01) * id;
     Di[0] = i00; Di[1] = i01; Di[2] = i02; Di[3] = i11; Di[4] = i12; Di[5] = i22;
+    {   // D = C C^T (Cholesky), Linv = C^-1: the Schur GEMM multiplies Z = C^-1 W, so that W^T D^-1 W = Z^T Z
+        const double c00 = sqrt(a00), l00 = 1.0 / c00;
+        const double c10 = a01 * l00, c20 = a02 * l00;
+        const double c11 = sqrt(a11 - c10 * c10), l11 = 1.0 / c11;
+        const double c21 = (a12 - c20 * c10) * l11;
+        const double c22 = sqrt(a22 - c20 * c20 - c21 * c21), l22 = 1.0 / c22;
+        const double l10 = -c10 * l00 * l11, l21 = -c21 * l11 * l22, l20 = -(l21 * c10 + l22 * c20) * l00;
+        double *Lo = B.Linv + (size_t)(G.point_off + l) * 6;
+        Lo[0] = l00; Lo[1] = l10; Lo[2] = l11; Lo[3] = l20; Lo[4] = l21; Lo[5] = l22;
+    }
     const double *b = B.bl + (size_t)(G.point_off + l) * 3;
     db[0] = i00 * b[0] + i01 * b[1] + i02 * b[2];
     db[1] = i01 * b[0] + i11 * b[1] + i12 * b[2];
     db[2] = i02 * b[0] + i12 * b[1] + i22 * b[2];
 }
 
-// Schur GEMM on the FP64 matrix cores:  S_sub = (D^-1 Wd)^T Wd  over the K-padded dense panel
-// Wd[4l+b][c] (K = 4 per point: 3 + zero pad), v_mfma_f64_16x16x4_f64:
+// Schur GEMM on the FP64 matrix cores:  S_sub = W^T D^-1 W = Z^T Z  with  Z = C^-1 W,  D = C C^T  (k_ba_point_prep), over the
+// K-padded dense panel Z[4l+b][c] (K = 4 per point: 3 + pad), v_mfma_f64_16x16x4_f64:
 //   A[i][k] (lane i=l&15,k=l>>4), B[k][j] (lane j=l&15,k=l>>4), C/D 4 regs: col = l&15, row = (l>>4) + 4*reg.
-// One 512-thread workgroup (8 waves, up to 256 VGPRs each) owns a range of points of one graph.  The three Wd rows of every point
-// are streamed through LDS ONCE (GEMM_PS points per stage, LDS-DMA, double buffered) and the upper 16x16 output tiles stay in
-// accumulator registers, so HBM/L2 sees each Wd byte once per launch instead of once per output tile.
+// One 512-thread workgroup (8 waves, up to 256 VGPRs each) owns a range of STAGES (<= GEMM_PS points, <= GEMM_STAGE_EDGES Hpl
+// blocks) of one graph.  The dense panel exists only in LDS: per stage every thread fetches ONE column of ONE sparse Hpl block
+// (3 doubles of Wsp, loaded a stage ahead into registers), multiplies it by the point's C^-1 and scatters it into the cleared stage
+// buffer -- HBM sees the 144-byte blocks (0.7 GB per 256 graphs) instead of a 79 %-zero dense panel (3.5 GB), and both MFMA
+// fragments come straight from the same LDS panel (no D^-1 arithmetic between load and MFMA).  The upper 16x16 output tiles stay
+// in accumulator registers for the whole launch.
 // Tile ownership: every row strip of the upper triangle is cut into CHUNKS of GEMM_C consecutive tiles; chunk i belongs to wave
-// i % 8, slot i / 8 (GEMM_NCH slots per wave).  Block sparsity: a point is seen by ~10 of ~48 free keyframes; a chunk is multiplied
-// only if the point's static 16-column occupancy mask hits the chunk's row tile AND one of its column tiles -- ONE wave-uniform
-// scalar test per chunk, after which the A fragment (D^-1 applied in registers) and the GEMM_C B fragments are loaded back to back
-// and the GEMM_C MFMAs issue back to back (per-tile tests and per-tile loads left the matrix pipe waiting on LDS latency).
-// LDS rows are padded to ld+48 doubles so that the four K-rows of a B fragment fall into different bank halves.
+// i % 8, slot i / 8 (GEMM_NCH slots per wave).  Block sparsity: a point is seen by ~10 of ~48 free keyframes; which (point, chunk,
+// tile) combinations of a stage hold data is decided once per stage by all 64 lanes (lane = 8*point + chunk) and three ballots;
+// a hit chunk loads its A fragment and GEMM_C B fragments back to back and issues the MFMAs of its non-empty tiles.
+// LDS rows are padded to ld+16 doubles so that the K-rows of a fragment fall into different bank halves.
 #define GEMM_PS 8
 #define GEMM_C 3               // tiles per chunk
 #define GEMM_NCH 8             // chunks per wave
 #define GEMM_WAVES 8
-#define GEMM_LDS_PAD 48       // = 32 dwords mod 64 (bank halves) and room for the GEMM_C-1 tiles a short chunk reads past the row
+#define GEMM_LDS_PAD 16        // = 32 dwords mod 64
+#define GEMM_LDS_TAIL 32       // a short chunk reads up to GEMM_C-1 tiles past the end of a row (never multiplied)
+#define GEMM_STAGE_EDGES 85    // 6 column tasks per Hpl block, one task per thread
+#define GEMM_PANEL_LDS_BYTES (126 * 1024)   // of the CU's 160 KB: the rest holds the raw blocks, task descriptors, C^-1 rows, masks
 static_assert(GEMM_PS * GEMM_NCH <= 64 && GEMM_NCH * GEMM_C <= 32, "one lane per (stage point, chunk); one valid bit per tile");
+static_assert(6 * GEMM_STAGE_EDGES <= 64 * GEMM_WAVES && 6 * GEMM_PS <= 64 * GEMM_WAVES, "one column task per thread");
 static inline __host__ __device__ int gemm_strip_chunks(int nt, int tr) { return (nt - tr + GEMM_C - 1) / GEMM_C; }
 __global__ __launch_bounds__(64 * GEMM_WAVES) void k_ba_schur_gemm(BaBatch B)
 {
-    extern __shared__ double glds[];               // [2][GEMM_PS][3][ld + pad] staged Wd rows, double buffered
-    __shared__ double s_dinv[2][GEMM_PS][6];
-    __shared__ uint32_t s_mask[2][GEMM_PS];
+    extern __shared__ double glds[];               // [2][gemm_ps][3][ld + pad] Z rows of the stage, double buffered (+ tail)
+    __shared__ __attribute__((aligned(16))) double s_raw[2][GEMM_STAGE_EDGES * 18];   // the stage's Hpl blocks as they lie in Wsp
+    __shared__ __attribute__((aligned(16))) int4 s_task[2][GEMM_STAGE_EDGES];
+    __shared__ __attribute__((aligned(16))) double s_linv[2][GEMM_PS][6];
+    __shared__ __attribute__((aligned(16))) uint32_t s_mask[3][GEMM_PS];
     const int g = blockIdx.y;
     const BaState &st = B.st[g];
     if (!st.active) return;
@@ -701,7 +724,7 @@ __global__ __launch_bounds__(64 * GEMM_WAVES) void k_ba_schur_gemm(BaBatch B)
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lk = lane >> 4;
     const int ld = G.ld, ldp = ld + GEMM_LDS_PAD;
-    // this wave's chunks: byte offsets of the row tile / first column tile inside an LDS row (wave-uniform -> scalar registers)
+    // this wave's chunks: offsets of the row tile / first column tile inside an LDS row (wave-uniform -> scalar registers)
     int aoff[GEMM_NCH], boffc[GEMM_NCH];
     uint32_t cvalid = 0;                                 // tiles that exist: bit c*GEMM_C + j
     v4d acc[GEMM_NCH * GEMM_C];
@@ -728,49 +751,78 @@ __global__ __launch_bounds__(64 * GEMM_WAVES) void k_ba_schur_gemm(BaBatch B)
         for (int j = 0; j < GEMM_C; j++) lcolbit[j] = (tr < nt && tc + j < nt) ? 1u << (tc + j) : 0u;
         if (tr < nt) lrow = 1u << tr;
     }
-    const int per = (G.n_points + G.ks - 1) / G.ks;
-    const int l0 = ksi * per, l1 = min(G.n_points, l0 + per);
-    const double *Wd = B.Wd + G.wd_off;
-    const double *Dv = B.Dinv + (size_t)G.point_off * 6;
-    const uint32_t *pm = B.ptmask + G.point_off;
-    const int s0 = lk == 0 ? 0 : lk == 1 ? 1 : 2, s1 = lk == 0 ? 1 : lk == 1 ? 3 : 4, s2 = lk == 0 ? 2 : lk == 1 ? 4 : 5;
-    const double live = lk < 3 ? 1.0 : 0.0;          // K-row 3 is the pad: A is zero there, B re-reads row 2 (finite)
+    const int per = (G.n_stages + G.ks - 1) / G.ks;
+    const int sb = ksi * per, se = min(G.n_stages, sb + per);
+    const int4 *stg = B.gemm_stage + G.stage_off;          // {first point, points, first task, tasks}
+    const int4 *tsk = B.gemm_task + G.gemm_off;            // {edge, 6*h, point, -}
+    const double live = lk < 3 ? 1.0 : 0.0;                // K-row 3 is the pad: A is zero there, B re-reads row 2 (finite)
     const int boff = min(lk, 2) * ldp + li;
-    // double-buffered stages: the LDS-DMA of stage k+1 is in flight while stage k is multiplied
-    const size_t stage_doubles = (size_t)GEMM_PS * 3 * ldp;
-    const int row_bytes = ld * 8, ppr = (row_bytes + 1023) >> 10;      // 1-KiB pieces per Wd row
-    auto issue_stage = [&](int lb, int buf) {
-        const int np = min(GEMM_PS, l1 - lb);
-        // ordinary loads first: hipcc waits vmcnt(0) at the first use of an ordinary load while an LDS-DMA is in
-        // flight, which would drain the prefetch -- so nothing but LDS-DMA is outstanding after this point
-        if (tid < np * 6) s_dinv[buf][tid / 6][tid % 6] = Dv[(size_t)(lb + tid / 6) * 6 + tid % 6];
-        if (tid < np) s_mask[buf][tid] = pm[lb + tid];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // asynchronous global -> LDS copy (global_load_lds_dwordx4), one Wd row = ppr pieces of <= 1 KiB
-        for (int piece = wv; piece < np * 3 * ppr; piece += GEMM_WAVES) {
-            const int row = piece / ppr, k = piece - row * ppr;          // row = 3*p + b
-            const int p = row / 3, b3 = row - 3 * p;
-            if (k * 1024 + lane * 16 < row_bytes) {
-                const char *gsrc = reinterpret_cast<const char *>(Wd + (size_t)(4 * (lb + p) + b3) * ld) + k * 1024 + lane * 16;
-                char *ldst = reinterpret_cast<char *>(glds + buf * stage_doubles + (size_t)row * ldp) + k * 1024;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
-                                                 (__attribute__((address_space(3))) void *)ldst, 16, 0, 0);
-            }
+    const size_t stage_doubles = (size_t)G.gemm_ps * 3 * ldp;
+    // stage s -> LDS by asynchronous global -> LDS copies (no staging registers): its Hpl blocks (contiguous in Wsp), task
+    // descriptors, C^-1 rows and occupancy masks; issued two stages ahead of the multiply
+    auto dma16 = [&](const void *src, void *dst, int bytes) {          // wave-strided 1-KiB pieces, 16 B per lane
+        for (int piece = wv; piece * 1024 < bytes; piece += GEMM_WAVES)
+            if (piece * 1024 + lane * 16 < bytes)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const char *)src + piece * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void *)((char *)dst + piece * 1024), 16, 0, 0);
+    };
+    auto load_stage = [&](int s) {
+        const int4 sd = stg[s];
+        const int b2 = s & 1;
+        dma16(B.Wsp + (size_t)(G.gemm_off + sd.z) * 18, &s_raw[b2][0], sd.w * 144);
+        dma16(tsk + sd.z, &s_task[b2][0], sd.w * 16);
+        if (wv == 0) {
+            if (lane * 16 < sd.y * 48)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const char *)(B.Linv + (size_t)(G.point_off + sd.x) * 6) + lane * 16),
+                                                 (__attribute__((address_space(3))) void *)&s_linv[b2][0][0], 16, 0, 0);
+        } else if (wv == 1) {
+            if (lane < sd.y)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(B.ptmask + G.point_off + sd.x + lane),
+                                                 (__attribute__((address_space(3))) void *)&s_mask[s % 3][0], 4, 0, 0);
         }
     };
-    if (l0 < l1) issue_stage(l0, 0);
+    auto clear = [&](int buf) {                            // the stage buffer starts from zero
+        double2 *z = reinterpret_cast<double2 *>(glds + buf * stage_doubles);
+        for (int i = tid; i < (int)(stage_doubles / 2); i += 64 * GEMM_WAVES) z[i] = make_double2(0.0, 0.0);
+    };
+    auto scatter = [&](int s, int buf) {                   // Z = C^-1 W, one column of one block per thread
+        const int b2 = s & 1, ntask = stg[s].w, pt0 = stg[s].x;
+        if (tid < 6 * ntask) {
+            const int i = tid / 6, a = tid - 6 * i;
+            const int4 t = s_task[b2][i];
+            const double *w = &s_raw[b2][18 * i + a];
+            const double w0 = w[0], w1 = w[6], w2 = w[12];
+            const int wp = t.z - pt0;
+            const double *L = s_linv[b2][wp];
+            double *dst = glds + buf * stage_doubles + (size_t)wp * 3 * ldp + t.y + a;
+            dst[0] = L[0] * w0;
+            dst[ldp] = L[1] * w0 + L[2] * w1;
+            dst[2 * ldp] = L[3] * w0 + L[4] * w1 + L[5] * w2;
+        }
+    };
+    if (sb < se) {
+        load_stage(sb);
+        if (sb + 1 < se) load_stage(sb + 1);
+        clear(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        scatter(sb, 0);
+    }
     int cur = 0;
-    for (int lb = l0; lb < l1; lb += GEMM_PS, cur ^= 1) {
-        const int np = min(GEMM_PS, l1 - lb);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of the current stage have landed
-        __syncthreads();                                    // ... everyone's have, and stage k-1 is fully consumed
-        if (lb + GEMM_PS < l1) issue_stage(lb + GEMM_PS, cur ^ 1);
+    for (int s = sb; s < se; s++, cur ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's copies of stage s+1 have landed
+        __syncthreads();                                    // stage s is scattered; everyone is done with the other buffer and has its copies
+        if (s + 1 < se) clear(cur ^ 1);
+        __syncthreads();
+        if (s + 1 < se) { scatter(s + 1, cur ^ 1); }
+        if (s + 2 < se) load_stage(s + 2);                  // reuses the raw / task / C^-1 slots of stage s (scattered one iteration ago)
+        const int np = stg[s].y;
         const double *stage = glds + cur * stage_doubles;
         // which (point, chunk, tile) combinations of this stage hold data: one evaluation per lane, GEMM_C ballots
         unsigned long long hit[GEMM_C];
         {
             const int pl = lane / GEMM_NCH;
-            const uint32_t m = pl < np ? s_mask[cur][pl] : 0u;
+            const uint32_t m = pl < np ? s_mask[s % 3][pl] : 0u;
             const bool rh = (m & lrow) != 0;
 #pragma unroll
             for (int j = 0; j < GEMM_C; j++) hit[j] = __ballot(rh && (m & lcolbit[j]));
@@ -780,18 +832,16 @@ __global__ __launch_bounds__(64 * GEMM_WAVES) void k_ba_schur_gemm(BaBatch B)
 #pragma unroll
             for (int j = 0; j < GEMM_C; j++) { tj[j] = (uint32_t)(hit[j] >> (GEMM_NCH * p)) & ((1u << GEMM_NCH) - 1u); any |= tj[j]; }
             if (any == 0) continue;                         // the point touches none of this wave's chunks
-            const double *rows = stage + (size_t)p * 3 * ldp;
-            const double d0 = s_dinv[cur][p][s0], d1 = s_dinv[cur][p][s1], d2 = s_dinv[cur][p][s2];
+            const double *rows = stage + (size_t)p * 3 * ldp + boff;
 #pragma unroll
             for (int c = 0; c < GEMM_NCH; c++) {
                 if (any & (1u << c)) {
-                    const double *q = rows + aoff[c] + li;
-                    const double q0 = q[0], q1 = q[ldp], q2 = q[2 * ldp];
+                    const double az = rows[aoff[c]];
                     double bf[GEMM_C];
 #pragma unroll
-                    for (int j = 0; j < GEMM_C; j++) bf[j] = rows[boff + boffc[c] + 16 * j];   // tiles past nt: pad garbage, never multiplied
-                    __builtin_amdgcn_sched_barrier(0);          // all 3 + GEMM_C LDS reads in flight before the first wait
-                    const double a = live * (d0 * q0 + d1 * q1 + d2 * q2);
+                    for (int j = 0; j < GEMM_C; j++) bf[j] = rows[boffc[c] + 16 * j];   // tiles past nt: pad garbage, never multiplied
+                    __builtin_amdgcn_sched_barrier(0);          // all 1 + GEMM_C LDS reads in flight before the first wait
+                    const double a = live * az;
 #pragma unroll
                     for (int j = 0; j < GEMM_C; j++)
                         if (tj[j] & (1u << c))                  // the fragments are already in registers: an empty tile costs one scalar test
@@ -848,14 +898,13 @@ __global__ __launch_bounds__(64) void k_ba_bschur(BaBatch B)
     const int lane = threadIdx.x;
     const int *qs = B.pose_start + G.posestart_off;
     const int *pe = B.pose_edges + G.edge_off;
-    const double *Wd = B.Wd + G.wd_off;
     double acc[6] = {0, 0, 0, 0, 0, 0};
     for (int k = qs[h] + lane; k < qs[h + 1]; k += 64) {
         if (B.edge_dup[G.edge_off + pe[k]]) continue;                      // one Hpl block per (point, pose)
         const int l = B.edge_point[G.edge_off + pe[k]];
         const double *db = B.db + (size_t)(G.point_off + l) * 3;
-        const double *w = Wd + (size_t)(4 * l) * G.ld + 6 * h;
-        for (int a = 0; a < 6; a++) acc[a] += w[a] * db[0] + w[G.ld + a] * db[1] + w[2 * (size_t)G.ld + a] * db[2];
+        const double *w = B.Wsp + (size_t)B.edge_task[G.edge_off + pe[k]] * 18;
+        for (int a = 0; a < 6; a++) acc[a] += w[a] * db[0] + w[6 + a] * db[1] + w[12 + a] * db[2];
     }
     for (int a = 0; a < 6; a++) {
         double v = acc[a];
@@ -1013,7 +1062,7 @@ __global__ __launch_bounds__(1024) void k_ba_ldlt(BaBatch B)
 // (sparse_optimizer.cpp:422-435) + computeScale partials (levenberg.cpp:187-194)
 __global__ __launch_bounds__(256) void k_ba_backsub_points(BaBatch B)
 {
-    // 16 lanes per point: one observing pose per lane and trip (the point's Hpl blocks are scattered 48-byte runs of Wd)
+    // 16 lanes per point: one observing pose per lane and trip
     const int g = blockIdx.y;
     const BaState &st = B.st[g];
     if (!st.active) return;
@@ -1031,14 +1080,13 @@ __global__ __launch_bounds__(256) void k_ba_backsub_points(BaBatch B)
     double x0 = xl[0], x1 = xl[1], x2 = xl[2];                     // a failed solve keeps the previous increment
     if (st.ok) {
         double c0 = 0, c1 = 0, c2 = 0;
-        const double *Wd = B.Wd + G.wd_off + (size_t)(4 * l) * G.ld;
         for (int e = ps[l] + sub; e < ps[l + 1]; e += 16) {
             const int h = B.hidx[G.pose_off + B.edge_pose[G.edge_off + e]];
             if (h < 0 || B.edge_dup[G.edge_off + e]) continue;              // one Hpl block per (point, pose)
             const double *xp = B.xp + (size_t)(G.free_off + h) * 6;
-            const double *w = Wd + 6 * h;
+            const double *w = B.Wsp + (size_t)B.edge_task[G.edge_off + e] * 18;
 #pragma unroll
-            for (int a = 0; a < 6; a++) { c0 -= w[a] * xp[a]; c1 -= w[G.ld + a] * xp[a]; c2 -= w[2 * (size_t)G.ld + a] * xp[a]; }
+            for (int a = 0; a < 6; a++) { c0 -= w[a] * xp[a]; c1 -= w[6 + a] * xp[a]; c2 -= w[12 + a] * xp[a]; }
         }
 #pragma unroll
         for (int d = 8; d >= 1; d >>= 1) { c0 += __shfl_xor(c0, d, 16); c1 += __shfl_xor(c1, d, 16); c2 += __shfl_xor(c2, d, 16); }
@@ -1232,11 +1280,13 @@ extern "C" int orbhip_ba_batch_create(orbhip_ctx *ctx, const orbhip_ba_graph *gr
     B.G = n_graphs;
     std::vector<int> hidx, epose, epoint, ptstart, posestart, poseedges;
     std::vector<uint32_t> ptmask;
+    std::vector<int4> gtask, gstage;
+    std::vector<int> etask;
     std::vector<double> eobs, eis2;
     std::vector<uint8_t> est, edup;
     std::vector<int> enext;
     int sumP = 0, sumL = 0, sumE = 0, sumF = 0;
-    size_t wd = 0, s = 0, sp = 0;
+    size_t s = 0, sp = 0;
     // split-K so that the Schur GEMM launches >= ~4096 waves
     for (int g = 0; g < n_graphs; g++) {
         const orbhip_ba_graph &H = graphs[g];
@@ -1302,9 +1352,33 @@ extern "C" int orbhip_ba_batch_create(orbhip_ctx *ctx, const orbhip_ba_graph *gr
         int nchunks = 0;
         for (int tr = 0; tr < nt; tr++) nchunks += gemm_strip_chunks(nt, tr);
         D.nt16 = nt; D.ngrp = (nchunks + GEMM_WAVES * GEMM_NCH - 1) / (GEMM_WAVES * GEMM_NCH);
-        // split the points so that ~2 workgroups per CU are in flight (each streams its chunk of Wd once)
+        {   // Schur GEMM work lists: Hpl blocks (free pose, first edge of a twin chain) point-major, cut into stages
+            D.gemm_off = (int)gtask.size(); D.stage_off = (int)gstage.size();
+            D.gemm_ps = (int)std::min<size_t>(GEMM_PS, GEMM_PANEL_LDS_BYTES / (sizeof(double) * 2 * 3 * (size_t)(D.ld + GEMM_LDS_PAD)));
+            if (D.gemm_ps < 1) { delete b; g_ba_error = "too many free keyframes for the LDS panel of the Schur GEMM"; return ORBHIP_E_BADARG; }
+            const uint8_t *dupv = edup.data() + (edup.size() - H.n_edges);
+            int e = 0, pt0 = 0, npts = 0, t0 = (int)gtask.size() - D.gemm_off, ntask = 0;
+            for (int l = 0; l < H.n_points; l++) {
+                int e1 = e, cnt = 0;
+                while (e1 < H.n_edges && H.edge_point[e1] == l) { if (local_h[H.edge_pose[e1]] >= 0 && !dupv[e1]) cnt++; e1++; }
+                if (cnt > GEMM_STAGE_EDGES) { delete b; g_ba_error = "a point has more Hpl blocks than free keyframes fit (ld <= 512)"; return ORBHIP_E_BADARG; }
+                if (npts == D.gemm_ps || ntask + cnt > GEMM_STAGE_EDGES) {
+                    gstage.push_back(make_int4(pt0, npts, t0, ntask));
+                    pt0 = l; npts = 0; t0 += ntask; ntask = 0;
+                }
+                for (int k = e; k < e1; k++) {
+                    const bool blk = local_h[H.edge_pose[k]] >= 0 && !dupv[k];
+                    etask.push_back(blk ? (int)gtask.size() : -1);
+                    if (blk) gtask.push_back(make_int4(k, 6 * local_h[H.edge_pose[k]], l, 0));
+                }
+                npts++; ntask += cnt; e = e1;
+            }
+            if (npts) gstage.push_back(make_int4(pt0, npts, t0, ntask));
+            D.n_stages = (int)gstage.size() - D.stage_off;
+        }
+        // split the stages so that ~2 workgroups per CU are in flight
         int ks = (512 + n_graphs * D.ngrp - 1) / (n_graphs * D.ngrp);
-        ks = std::max(1, std::min(ks, std::max(1, H.n_points / (4 * GEMM_PS))));
+        ks = std::max(1, std::min(ks, std::max(1, D.n_stages / 4)));
         D.ks = ks;
         {   // static block-sparsity masks: 16-column tiles of the point's Hpl column that hold a non-zero block
             double issued = 0;
@@ -1330,7 +1404,6 @@ extern "C" int orbhip_ba_batch_create(orbhip_ctx *ctx, const orbhip_ba_graph *gr
             b->gemm_flops_issued += chunks * 2048.0;
             b->gemm_flops_dense += (double)ntiles * 2048.0 * (double)H.n_points;        // same tiles without the masks
         }
-        D.wd_off = wd; wd += (size_t)4 * H.n_points * D.ld;
         D.s_off = s; s += (size_t)D.ld * D.ld;
         D.spart_off = sp; sp += (size_t)ks * D.ld * D.ld;
         B.max_edges = std::max(B.max_edges, H.n_edges); B.max_points = std::max(B.max_points, H.n_points);
@@ -1349,19 +1422,19 @@ extern "C" int orbhip_ba_batch_create(orbhip_ctx *ctx, const orbhip_ba_graph *gr
         b->gd.push_back(D);
     }
     B.sumP = sumP; B.sumL = sumL; B.sumE = sumE; B.sumF = sumF;
-    b->wd_total = wd; b->s_total = s; b->spart_total = sp;
+    b->s_total = s; b->spart_total = sp;
     bool ok = true;
 #define UP(dst, vec) do { auto *_p = ba_upload(b, vec); ok = ok && _p; dst = _p; } while (0)
 #define AL(dst, T, n) do { auto *_p = ba_alloc<T>(b, n); ok = ok && _p; dst = _p; } while (0)
     UP(B.gd, b->gd); UP(B.hidx, hidx); UP(B.edge_pose, epose); UP(B.edge_point, epoint); UP(B.edge_obs, eobs);
     UP(B.edge_is2, eis2); UP(B.edge_stereo, est); UP(B.edge_dup, edup); UP(B.edge_next, enext); UP(B.pt_start, ptstart); UP(B.pose_start, posestart); UP(B.pose_edges, poseedges);
-    UP(B.ptmask, ptmask);
+    UP(B.ptmask, ptmask); UP(B.gemm_task, gtask); UP(B.gemm_stage, gstage); UP(B.edge_task, etask);
     AL(B.st, BaState, n_graphs);
     AL(B.poses, double, (size_t)2 * sumP * 7); AL(B.points, double, (size_t)2 * sumL * 3);
     AL(B.err, double, (size_t)sumE * 3); AL(B.chi2, double, sumE); AL(B.rho0, double, sumE);
     AL(B.Hll, double, (size_t)sumL * 6); AL(B.bl, double, (size_t)sumL * 3); AL(B.Dinv, double, (size_t)sumL * 6); AL(B.db, double, (size_t)sumL * 3);
     AL(B.Hpp, double, (size_t)sumF * 36); AL(B.bp, double, (size_t)sumF * 6); AL(B.bs, double, (size_t)sumF * 6);
-    AL(B.Wd, double, wd); AL(B.S, double, s); AL(B.Spart, double, sp);
+    AL(B.Wsp, double, gtask.size() * 18); AL(B.Linv, double, (size_t)sumL * 6); AL(B.S, double, s); AL(B.Spart, double, sp);
     AL(B.xp, double, (size_t)sumF * 6); AL(B.xl, double, (size_t)sumL * 3);
     AL(B.scale_pt, double, sumL); AL(B.scale_pose, double, sumF);
     AL(B.chi, double, n_graphs); AL(B.scale, double, n_graphs); AL(B.maxdiag, double, n_graphs);
@@ -1369,8 +1442,6 @@ extern "C" int orbhip_ba_batch_create(orbhip_ctx *ctx, const orbhip_ba_graph *gr
 #undef UP
 #undef AL
     if (!ok || hipHostMalloc((void **)&b->h_n_active, sizeof(int)) != hipSuccess) { orbhip_ba_batch_destroy(b); g_ba_error = "device allocation failed"; return ORBHIP_E_HIP; }
-    // the dense W panel keeps its zero pattern for the life of the batch: clear once
-    if (hipMemset(B.Wd, 0, wd * sizeof(double)) != hipSuccess) { orbhip_ba_batch_destroy(b); return ORBHIP_E_HIP; }
     *out = b;
     return ORBHIP_OK;
 }
@@ -1414,7 +1485,8 @@ extern "C" int orbhip_ba_batch_solve(orbhip_ba_batch *b, const orbhip_ba_params 
     const dim3 gf(std::max(B.max_nf, 1), G);
     int max_items = 0, max_poses = 0;
     for (auto &D : b->gd) { max_items = std::max(max_items, D.ks * D.ngrp); max_poses = std::max(max_poses, D.n_poses); }
-    const size_t gemm_lds = sizeof(double) * 2 * GEMM_PS * 3 * (size_t)(B.max_ld + GEMM_LDS_PAD);
+    size_t gemm_lds = 0;
+    for (auto &D : b->gd) gemm_lds = std::max(gemm_lds, sizeof(double) * (2 * (size_t)D.gemm_ps * 3 * (size_t)(D.ld + GEMM_LDS_PAD) + GEMM_LDS_TAIL));
     TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_schur_gemm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds));
     const size_t ldlt_lds = ba_ldlt_lds_bytes(B.max_ld);
     TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_ldlt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldlt_lds));
