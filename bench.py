@@ -289,7 +289,7 @@ def main():
                            "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),
                            "mfma_flops_of_data_tiles_per_launch": gemm_fl, "mfma_flops_issued_per_launch": gemm_issued,
                            "flops_per_launch_without_sparsity_skipping": gemm_dense,
-                           "note": "achieved = flops of the 16x16x4 MFMAs whose tiles hold data / hipEvent time; every tile of a row strip a point touches is issued"}}
+                           "note": "achieved = flops of the 16x16x4 MFMAs whose tiles hold data / hipEvent time; only tiles that hold data are issued (per-stage ballot hit maps)"}}
 
     pose = None
     pose_probs = None
