@@ -927,6 +927,44 @@ __global__ __launch_bounds__(64) void k_ba_bschur(BaBatch B)
 #define LD_PP 33
 size_t ba_ldlt_lds_bytes(int max_n) { return sizeof(double) * ((size_t)max_n * LD_PP + 2 * (size_t)max_n + LD_NB + 32 * 32); }
 
+// One row of a panel through the nb elimination steps of its diagonal block (right-looking LDL^T without pivoting):
+//   l = a[jj] / d_jj;  a[kk] -= l * U[jj][kk]  (jj < kk <= min(r, nb-1));  a[jj] = l;  y_r -= l * y_jj.
+// DIAG: the caller is the single wave that owns rows 0..nb-1 (lane = row); it produces d_jj, U[jj][.] and the final y_jj as it goes
+// (lock-step execution orders the LDS traffic).  Otherwise U, d and y[0..nb) are complete and rows are independent.
+template <bool DIAG>
+__device__ __forceinline__ void ldlt_rows(double *P, double *U, double *dv, double *yv, int r, int nb, int *s_ok)
+{
+    // No per-element predicates: entries right of the diagonal (kk > r) and, in a partial last panel, columns >= nb carry
+    // garbage that is never read back (keeps the unrolled code at ~3 instructions per update).
+    double a[LD_NB];
+    asm volatile("" : "+v"(U), "+v"(yv), "+v"(dv));       // vector base registers + immediate offsets (else ~500 hoisted scalar addresses spill)
+#pragma unroll
+    for (int c = 0; c < LD_NB; c++) a[c] = P[r * LD_PP + c];
+    double yr = yv[r];
+    bool ok = true;
+#pragma unroll
+    for (int jj = 0; jj < LD_NB; jj++) {
+        if (jj >= nb || !ok) continue;                      // uniform
+        if (DIAG) {
+            U[jj * LD_NB + r] = a[jj];                      // unscaled column jj (entry jj = the pivot)
+            if (r == jj) yv[jj] = yr;                        // y_jj is final
+        }
+        const double d = DIAG ? U[jj * LD_NB + jj] : dv[jj];
+        if (DIAG) {
+            if (d == 0.0 || !isfinite(d)) { ok = false; if (r == 0) *s_ok = 0; continue; }
+            if (r == jj) dv[jj] = d;
+        }
+        const double l = a[jj] / d;
+        yr -= l * yv[jj];
+#pragma unroll
+        for (int kk = jj + 1; kk < LD_NB; kk++) a[kk] -= l * U[jj * LD_NB + kk];
+        if (!DIAG || r > jj) a[jj] = l;
+    }
+#pragma unroll
+    for (int c = 0; c < LD_NB; c++) if (!DIAG || c <= r) P[r * LD_PP + c] = a[c];
+    if (!DIAG) yv[r] = yr;
+}
+
 __global__ __launch_bounds__(1024) void k_ba_ldlt(BaBatch B)
 {
     extern __shared__ double lds[];
@@ -940,9 +978,8 @@ __global__ __launch_bounds__(1024) void k_ba_ldlt(BaBatch B)
     double *P = lds;                              // panel [rows][LD_PP]
     double *y = P + (size_t)B.max_ld * LD_PP;     // right-hand side / solution
     double *dval = y + B.max_ld;                  // pivots d_c of every column
-    double *lcol = dval + B.max_ld;               // scaled current column (max n entries) -- aliases red below
-    double *red = lcol;                           // [32][32] partial sums of the back substitution
-    // NB: lcol needs n entries, red needs 1024: both fit in max(n,1024) doubles reserved by the host
+    double *red = dval + B.max_ld;                // [32][32] partial sums of the back substitution
+    double *U = red;                              // [32][32] unscaled columns of the current diagonal block (factorisation phase)
     for (int i = tid; i < n; i += nth) y[i] = B.bs[(size_t)G.free_off * 6 + i];
     if (tid == 0) s_ok = 1;
     __syncthreads();
@@ -953,25 +990,13 @@ __global__ __launch_bounds__(1024) void k_ba_ldlt(BaBatch B)
             if (c < nb) P[r * LD_PP + c] = S[(size_t)(p0 + r) * ld + p0 + c];
         }
         __syncthreads();
-        for (int jj = 0; jj < nb; jj++) {
-            const double d = P[jj * LD_PP + jj];
-            if (d == 0.0 || !isfinite(d)) { if (tid == 0) s_ok = 0; break; }      // uniform: every thread reads the same d
-            for (int r = jj + 1 + tid; r < m; r += nth) lcol[r] = P[r * LD_PP + jj] / d;
-            if (tid == 0) dval[p0 + jj] = d;
-            __syncthreads();
-            const int cnt = nb - jj - 1, rows = m - jj - 1;
-            // P[r][kk] -= (col[r]/d) * col[kk]  for jj < kk < nb, r >= kk   (lower triangle only)
-            for (int idx = tid; idx < rows * cnt; idx += nth) {
-                const int r = jj + 1 + idx / cnt, kk = jj + 1 + idx % cnt;
-                if (r >= kk) P[r * LD_PP + kk] -= lcol[r] * P[kk * LD_PP + jj];
-            }
-            const double yj = y[p0 + jj];
-            for (int r = jj + 1 + tid; r < m; r += nth) y[p0 + r] -= lcol[r] * yj;   // forward substitution rides along
-            __syncthreads();
-            for (int r = jj + 1 + tid; r < m; r += nth) P[r * LD_PP + jj] = lcol[r];  // column jj now holds L
-            // (column jj is not read again inside this panel; the barrier at the top of the next step orders lcol reuse)
-            __syncthreads();
-        }
+        // (1) the nb x nb diagonal block: ONE wave, one row per lane, the row in registers, no block barriers.  Step jj publishes the
+        //     still unscaled column jj (U[jj][r] = A[r][jj]) in LDS; every lane reads it back as wave-wide broadcasts.
+        if (tid < nb) ldlt_rows<true>(P, U, dval + p0, y + p0, tid, nb, &s_ok);
+        __syncthreads();
+        if (!s_ok) break;
+        // (2) the rows below the block: independent forward substitutions against U / d, one row per thread
+        if (nb + tid < m) ldlt_rows<false>(P, U, dval + p0, y + p0, nb + tid, nb, &s_ok);     // m <= BA_LDLT_MAXN < blockDim
         __syncthreads();
         if (!s_ok) break;
         // write the factored panel back: L below the diagonal, d on it
