@@ -183,3 +183,14 @@ def test_ba_second_camera_tobody_edges(gpu_ctx):
     bad = dict(graphs[0]); bad["rig2"] = None
     with pytest.raises(orbhip.OrbHipError):
         orbhip.BaBatch(gpu_ctx, [bad])
+
+
+def test_ba_large_window_and_dense_observations(gpu_ctx):
+    """Schur GEMM corner shapes: 70 free keyframes (ld = 480: 5 points per LDS stage, 165 tile chunks = three workgroups per point
+    range), points seen by almost every keyframe (stages cut by the 85-block limit, not by the point count), next to a small graph."""
+    import synth_ba
+    graphs = [synth_ba.make_graph(n_kf=72, n_pts=500, obs=12, seed=51),
+              synth_ba.make_graph(n_kf=40, n_pts=90, obs=37, seed=52, outlier_frac=0.02),
+              synth_ba.make_graph(n_kf=6, n_pts=40, obs=4, seed=53)]
+    stats = _check(gpu_ctx, graphs)
+    assert not any(s["discarded"] for s in stats)
