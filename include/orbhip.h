@@ -292,6 +292,22 @@ int orbhip_search_for_triangulation_device(orbhip_ctx *ctx,
         const float *scale_factors, const float *level_sigma2, int nlevels, int check_orientation,
         int32_t *d_matches12, int32_t *d_nmatches);
 
+/* Frame::UndistortKeyPoints (src/Frame.cc:738-771), batched: d_kp_un = d_kp with pt replaced by
+ * cv::undistortPoints(pt, K, mDistCoef, R = I, P = K) (OpenCV 3.4.1 cvUndistortPoints: 5 fixed-point iterations in double,
+ * rounded to float).  dist_coef: HOST array (k1, k2, p1, p2[, k3]), n_dist 4 or 5; k1 == 0 copies (Frame.cc:740-744).
+ * d_kp and d_kp_un may be the same buffer.  Other pointers DEVICE. */
+int orbhip_undistort_keypoints_device(orbhip_ctx *ctx, const orbhip_keypoint *d_kp, const int32_t *d_n, int frames, int max_n,
+                                      size_t frame_stride_kp, float fx, float fy, float cx, float cy, const float *dist_coef,
+                                      int n_dist, orbhip_keypoint *d_kp_un);
+
+/* Frame::AssignFeaturesToGrid (src/Frame.cc:377-408, Nleft == -1), batched, as a CSR per frame: d_cell_start
+ * [frames][64*48+1], d_items [frames][max_n]; cell (ix, iy) = index ix*48+iy holds the keypoint indices
+ * d_items[cell_start[c] .. cell_start[c+1]) in insertion (= index) order -- mGrid[ix][iy] of the reference
+ * (PosInGrid rounds, Frame.cc:716-726).  At most 8192 keypoints per frame.  All pointers DEVICE. */
+int orbhip_assign_features_to_grid_device(orbhip_ctx *ctx, const orbhip_keypoint *d_kp, const int32_t *d_n, int frames, int max_n,
+                                          size_t frame_stride_kp, float min_x, float min_y, float max_x, float max_y,
+                                          int32_t *d_cell_start, int32_t *d_items);
+
 /* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:327-403), batched over map points: point p
  * has d_n[p] observing descriptors at d_desc + p*max_n*32 (the loop of :347-361 packs them, left then right index);
  * d_best_idx[p] = BestIdx: the descriptor with the least median Hamming distance to all of them (median = sorted

@@ -577,3 +577,43 @@ void orc_window_best(const orc_proj_query *q, const uint8_t *desc_q, int nq, con
     }
     free(cand); grid_free(&g);
 }
+
+/* Frame::AssignFeaturesToGrid, Frame.cc:377-408 (Nleft == -1): the 64x48 cell lists as a CSR, cells numbered ix*48+iy */
+void orc_assign_features_to_grid(const orc_keypoint *kp, int n, float min_x, float min_y, float max_x, float max_y,
+                                 int32_t *cell_start, int32_t *items)
+{
+    struct grid g;
+    grid_build(&g, kp, n, min_x, min_y, max_x, max_y);
+    for (int c = 0; c <= GRID_COLS * GRID_ROWS; c++) cell_start[c] = g.cell_start[c];
+    for (int i = 0; i < g.cell_start[GRID_COLS * GRID_ROWS]; i++) items[i] = g.items[i];
+    grid_free(&g);
+}
+
+/* Frame::UndistortKeyPoints, Frame.cc:738-771: cv::undistortPoints(mat, mat, K, mDistCoef, Mat(), K) (OpenCV 3.4.1
+ * cvUndistortPoints, un-vendored: restated -- 5 fixed-point iterations of the inverse Brown model in double, output rounded to
+ * float; k = (k1, k2, p1, p2, k3), R = I, P = K).  parity unpinned (no OpenCV here). */
+void orc_undistort_keypoints(const orc_keypoint *kp, int n, float fx_, float fy_, float cx_, float cy_, const float *dist, int ndist,
+                             orc_keypoint *out)
+{
+    double k[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < ndist && i < 5; i++) k[i] = dist[i];
+    const double fx = fx_, fy = fy_, cx = cx_, cy = cy_, ifx = 1. / fx, ify = 1. / fy;
+    for (int i = 0; i < n; i++) {
+        out[i] = kp[i];
+        if (dist[0] == 0.0f) continue;                             /* Frame.cc:740-744 */
+        double x = kp[i].x, y = kp[i].y;
+        x = (x - cx) * ifx; y = (y - cy) * ify;
+        const double x0 = x, y0 = y;
+        for (int j = 0; j < 5; j++) {
+            const double r2 = x * x + y * y;
+            const double icdist = (1 + ((0 * r2 + 0) * r2 + 0) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+            const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x);
+            const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y;
+            x = (x0 - deltaX) * icdist;
+            y = (y0 - deltaY) * icdist;
+        }
+        /* RR = P * R = K:  xx = fx x + cx, yy = fy y + cy, ww = 1 */
+        const double xx = fx * x + 0 * y + cx, yy = 0 * x + fy * y + cy, ww = 1. / (0 * x + 0 * y + 1);
+        out[i].x = (float)(xx * ww); out[i].y = (float)(yy * ww);
+    }
+}

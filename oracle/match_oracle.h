@@ -108,6 +108,14 @@ int orc_search_by_projection_sim3(const orc_proj_query *q, const uint8_t *desc_q
 /* Per-point window search of SearchBySim3 (ORBmatcher.cc:1813-1851, 1893-1931) and Fuse(KeyFrame*, Scw, ...) (:1687-1720). */
 void orc_window_best(const orc_proj_query *q, const uint8_t *desc_q, int nq, const orc_keypoint *kp, const uint8_t *desc, int n,
                      float min_x, float min_y, float max_x, float max_y, int32_t *best_idx, int32_t *best_dist);
+/* Frame::AssignFeaturesToGrid (src/Frame.cc:377-408, Nleft == -1) as a CSR: cell_start [64*48+1], items [n] (cell ix*48+iy,
+ * insertion = index order; keypoints outside the grid are in no cell). */
+void orc_assign_features_to_grid(const orc_keypoint *kp, int n, float min_x, float min_y, float max_x, float max_y,
+                                 int32_t *cell_start, int32_t *items);
+/* Frame::UndistortKeyPoints (src/Frame.cc:738-771): out = kp with pt replaced by cv::undistortPoints(pt, K, dist, R = I, P = K);
+ * dist = (k1, k2, p1, p2[, k3]); a zero k1 copies (Frame.cc:740-744). */
+void orc_undistort_keypoints(const orc_keypoint *kp, int n, float fx, float fy, float cx, float cy, const float *dist, int ndist,
+                             orc_keypoint *out);
 /* MapPoint::ComputeDistinctiveDescriptors (/root/reference/src/MapPoint.cc:327-403): among the n
  * descriptors that observe a map point, the one with the least median Hamming distance to all of them
  * (median = sorted row [int(0.5*(n-1))], self distance 0 included; first minimum wins).  Returns BestIdx (0 if n<=0). */

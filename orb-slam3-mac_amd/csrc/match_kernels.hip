@@ -1164,3 +1164,91 @@ extern "C" int orbhip_search_for_triangulation_device(orbhip_ctx *ctx,
                        check_orientation, cap_n, d_matches12, d_nmatches, orbhip_ctx_status_internal(ctx));
     return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
 }
+
+// ---------------------------------------------------------------------------- Frame glue: UndistortKeyPoints, AssignFeaturesToGrid
+// Frame::UndistortKeyPoints (Frame.cc:738-771): cv::undistortPoints(pt, K, dist, R = I, P = K) of OpenCV 3.4.1 (cvUndistortPoints:
+// 5 fixed-point iterations of the inverse Brown model in double, result rounded to float); one thread per keypoint.
+struct UndistortArgs { double fx, fy, cx, cy, ifx, ify, k[5]; int copy_only; };
+__global__ __launch_bounds__(256) void k_undistort(const orbhip_keypoint *kp_, const int32_t *n_, int max_n, size_t kp_stride, UndistortArgs A,
+                                                   orbhip_keypoint *out_)
+{
+    const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_[f] || i >= max_n) return;
+    orbhip_keypoint k = kp_[(size_t)f * kp_stride + i];
+    if (!A.copy_only) {
+        double x = k.x, y = k.y;
+        x = (x - A.cx) * A.ifx; y = (y - A.cy) * A.ify;
+        const double x0 = x, y0 = y;
+#pragma unroll 1
+        for (int j = 0; j < 5; j++) {
+            const double r2 = x * x + y * y;
+            const double icdist = 1.0 / (1 + ((A.k[4] * r2 + A.k[1]) * r2 + A.k[0]) * r2);
+            const double dX = 2 * A.k[2] * x * y + A.k[3] * (r2 + 2 * x * x);
+            const double dY = A.k[2] * (r2 + 2 * y * y) + 2 * A.k[3] * x * y;
+            x = (x0 - dX) * icdist;
+            y = (y0 - dY) * icdist;
+        }
+        k.x = (float)(A.fx * x + A.cx); k.y = (float)(A.fy * y + A.cy);
+    }
+    out_[(size_t)f * kp_stride + i] = k;
+}
+
+extern "C" int orbhip_undistort_keypoints_device(orbhip_ctx *ctx, const orbhip_keypoint *d_kp, const int32_t *d_n, int frames, int max_n,
+                                                 size_t frame_stride_kp, float fx, float fy, float cx, float cy, const float *dist_coef,
+                                                 int n_dist, orbhip_keypoint *d_kp_un)
+{
+    if (!ctx || !d_kp || !d_n || frames <= 0 || max_n <= 0 || !dist_coef || n_dist < 4 || n_dist > 5 || !d_kp_un) return ORBHIP_E_BADARG;
+    if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
+    UndistortArgs A;
+    A.fx = fx; A.fy = fy; A.cx = cx; A.cy = cy; A.ifx = 1.0 / (double)fx; A.ify = 1.0 / (double)fy;
+    for (int i = 0; i < 5; i++) A.k[i] = i < n_dist ? (double)dist_coef[i] : 0.0;
+    A.copy_only = dist_coef[0] == 0.0f;                                    // Frame.cc:740-744
+    hipLaunchKernelGGL(k_undistort, dim3((max_n + 255) / 256, frames), dim3(256), 0, orbhip_ctx_stream_internal(ctx), d_kp, d_n, max_n,
+                       frame_stride_kp, A, d_kp_un);
+    return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
+}
+
+// Frame::AssignFeaturesToGrid (Frame.cc:377-408, Nleft == -1) as a CSR per frame (the layout the windowed matchers build privately
+// in LDS, exported for host-side GetFeaturesInArea callers): one wave per frame.
+__global__ __launch_bounds__(64) void k_assign_grid(const orbhip_keypoint *kp_, const int32_t *n_, int max_n, size_t kp_stride, float min_x,
+                                                    float min_y, float inv_w, float inv_h, int cap_n, int32_t *cell_start_, int32_t *items_,
+                                                    int32_t *status)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t ag_lds[];
+    uint32_t *cell_start = reinterpret_cast<uint32_t *>(ag_lds);             // [SBP_CELLS + 1]
+    float *kx = reinterpret_cast<float *>(cell_start + SBP_CELLS + 1);
+    float *ky = kx + cap_n;
+    uint16_t *items = reinterpret_cast<uint16_t *>(ky + cap_n);
+    uint16_t *cell_of = items + cap_n, *rank_of = cell_of + cap_n;
+    uint8_t *oct = reinterpret_cast<uint8_t *>(rank_of + cap_n);
+    const int f = blockIdx.x, lane = threadIdx.x;
+    const int n = n_[f];
+    int32_t *cs = cell_start_ + (size_t)f * (SBP_CELLS + 1), *it = items_ + (size_t)f * max_n;
+    if (n > cap_n || n > max_n) { if (lane == 0) atomicExch(status, ORBHIP_E_CAPACITY); for (int c = lane; c <= SBP_CELLS; c += 64) cs[c] = 0; return; }
+    for (int c = lane; c <= SBP_CELLS; c += 64) cell_start[c] = 0;
+    __syncthreads();
+    sbp_build_grid(cell_start, kx, ky, oct, items, cell_of, rank_of, kp_ + (size_t)f * kp_stride, n, min_x, min_y, inv_w, inv_h, lane);
+    for (int c = lane; c <= SBP_CELLS; c += 64) cs[c] = (int32_t)cell_start[c];
+    const int tot = (int)cell_start[SBP_CELLS];
+    for (int i = lane; i < tot; i += 64) it[i] = items[i];
+}
+
+extern "C" int orbhip_assign_features_to_grid_device(orbhip_ctx *ctx, const orbhip_keypoint *d_kp, const int32_t *d_n, int frames, int max_n,
+                                                     size_t frame_stride_kp, float min_x, float min_y, float max_x, float max_y,
+                                                     int32_t *d_cell_start, int32_t *d_items)
+{
+    if (!ctx || !d_kp || !d_n || frames <= 0 || max_n <= 0 || !(max_x > min_x) || !(max_y > min_y) || !d_cell_start || !d_items) return ORBHIP_E_BADARG;
+    if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
+    const int cap_n = ((max_n < 8192 ? max_n : 8192) + 7) & ~7;
+    const size_t lds = sizeof(uint32_t) * (SBP_CELLS + 1) + (size_t)cap_n * (4 + 4 + 2 + 2 + 2 + 1) + 16;
+    static thread_local size_t lds_set = 0;
+    if (lds > lds_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_assign_grid), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return ORBHIP_E_HIP;
+        lds_set = lds;
+    }
+    const float inv_w = (float)SI_COLS / (max_x - min_x), inv_h = (float)SI_ROWS / (max_y - min_y);      // Frame.cc:334-335
+    hipLaunchKernelGGL(k_assign_grid, dim3(frames), dim3(64), lds, orbhip_ctx_stream_internal(ctx), d_kp, d_n, max_n, frame_stride_kp, min_x,
+                       min_y, inv_w, inv_h, cap_n, d_cell_start, d_items, orbhip_ctx_status_internal(ctx));
+    return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
+}

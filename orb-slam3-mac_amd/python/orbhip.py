@@ -502,6 +502,23 @@ def search_by_bow_kf_device(ctx, kf1, kf2, pairs, max_nodes, max_n, kp_stride, n
                                             d_matches12, d_nmatches), "orbhip_search_by_bow_kf_device")
 
 
+lib.orbhip_undistort_keypoints_device.argtypes = [vp, vp, vp, ci, ci, sz, cf, cf, cf, cf, vp, ci, vp]
+lib.orbhip_assign_features_to_grid_device.argtypes = [vp, vp, vp, ci, ci, sz, cf, cf, cf, cf, vp, vp]
+
+
+def undistort_keypoints_device(ctx, d_kp, d_n, frames, max_n, kp_stride, K, dist, d_kp_un):
+    """Frame::UndistortKeyPoints, batched.  K = (fx, fy, cx, cy); dist: 4 or 5 host floats."""
+    dc = np.ascontiguousarray(dist, np.float32)
+    _chk(lib.orbhip_undistort_keypoints_device(ctx.h, d_kp, d_n, frames, max_n, kp_stride, K[0], K[1], K[2], K[3], dc.ctypes.data, len(dc),
+                                               d_kp_un), "orbhip_undistort_keypoints_device")
+
+
+def assign_features_to_grid_device(ctx, d_kp, d_n, frames, max_n, kp_stride, bounds, d_cell_start, d_items):
+    """Frame::AssignFeaturesToGrid as a CSR per frame (cell ix*48+iy)."""
+    _chk(lib.orbhip_assign_features_to_grid_device(ctx.h, d_kp, d_n, frames, max_n, kp_stride, bounds[0], bounds[1], bounds[2], bounds[3],
+                                                   d_cell_start, d_items), "orbhip_assign_features_to_grid_device")
+
+
 TRI_PAIR_DTYPE = np.dtype([("F12", "<f4", (9,)), ("ep_x", "<f4"), ("ep_y", "<f4"), ("only_stereo", "<i4"), ("coarse", "<i4")])
 lib.orbhip_search_for_triangulation_device.argtypes = [vp] * 17 + [ci, ci, ci, sz, vp, vp, ci, ci, vp, vp]
 

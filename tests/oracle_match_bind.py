@@ -300,3 +300,22 @@ def window_best(q, dq, kp, d, bounds):
     lib.orc_window_best(q.ctypes.data, dq.ctypes.data, len(q), kp.ctypes.data, d.ctypes.data, len(kp), bounds[0], bounds[1], bounds[2],
                         bounds[3], bi.ctypes.data, bd.ctypes.data)
     return bi[:len(q)], bd[:len(q)]
+
+
+# ------------------------------------------------------------------ Frame glue
+lib.orc_assign_features_to_grid.argtypes = [vp, ci, cf, cf, cf, cf, vp, vp]
+lib.orc_undistort_keypoints.argtypes = [vp, ci, cf, cf, cf, cf, vp, ci, vp]
+
+
+def assign_features_to_grid(kp, bounds):
+    kp = np.ascontiguousarray(kp, KP_DTYPE)
+    cs = np.zeros(64 * 48 + 1, np.int32); it = np.zeros(max(len(kp), 1), np.int32)
+    lib.orc_assign_features_to_grid(kp.ctypes.data, len(kp), bounds[0], bounds[1], bounds[2], bounds[3], cs.ctypes.data, it.ctypes.data)
+    return cs, it[:cs[-1]]
+
+
+def undistort_keypoints(kp, K, dist):
+    kp = np.ascontiguousarray(kp, KP_DTYPE); dc = np.ascontiguousarray(dist, np.float32)
+    out = np.zeros(max(len(kp), 1), KP_DTYPE)
+    lib.orc_undistort_keypoints(kp.ctypes.data, len(kp), K[0], K[1], K[2], K[3], dc.ctypes.data, len(dc), out.ctypes.data)
+    return out[:len(kp)]

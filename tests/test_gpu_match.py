@@ -565,3 +565,36 @@ def test_sim3_searches_parity(gpu_ctx):
     for p, (q, dq, kp, d, tm) in enumerate(cases):
         ri, rd = om.window_best(q, dq, kp, d, bounds)
         np.testing.assert_array_equal(bi[p, :nq[p]], ri); np.testing.assert_array_equal(bd[p, :nq[p]], np.where(ri < 0, 256, rd))
+
+
+@pytest.mark.gpu
+def test_frame_glue_parity(gpu_ctx):
+    """Frame::UndistortKeyPoints + Frame::AssignFeaturesToGrid on a ragged batch (incl. an empty frame): bit-exact vs the oracle."""
+    import torch
+    import orbhip
+    import oracle_match_bind as om
+    from test_oracle_match_ba import make_sbp_case, EUROC_K, EUROC_DIST
+    rng = np.random.default_rng(91)
+    ns = (0, 1, 300, 2500, 4096)
+    F, MN = len(ns), 4096
+    KP = np.zeros((F, MN), orbhip.KP_DTYPE)
+    for f, n in enumerate(ns):
+        KP[f, :n] = make_sbp_case(rng, n, 0, False)[2]
+    d_kp = torch.from_numpy(KP.view(np.uint8)).cuda(); d_n = torch.tensor(ns, dtype=torch.int32, device="cuda")
+    for dist in (EUROC_DIST, EUROC_DIST + (0.01,), (0.0, 0.1, 0.0, 0.0)):
+        d_un = torch.zeros_like(d_kp)
+        orbhip.undistort_keypoints_device(gpu_ctx, d_kp.data_ptr(), d_n.data_ptr(), F, MN, MN, EUROC_K, dist, d_un.data_ptr())
+        gpu_ctx.synchronize()
+        un = d_un.cpu().numpy().view(orbhip.KP_DTYPE).reshape(F, MN)
+        for f, n in enumerate(ns):
+            ref = om.undistort_keypoints(KP[f, :n], EUROC_K, dist)
+            assert un[f, :n].tobytes() == ref.tobytes(), (f, dist)
+    bounds = (-12.5, -9.0, 760.0, 490.0)
+    cs = torch.full((F, 64 * 48 + 1), -9, dtype=torch.int32, device="cuda"); it = torch.full((F, MN), -9, dtype=torch.int32, device="cuda")
+    orbhip.assign_features_to_grid_device(gpu_ctx, d_un.data_ptr(), d_n.data_ptr(), F, MN, MN, bounds, cs.data_ptr(), it.data_ptr())
+    gpu_ctx.check_status()
+    cs, it = cs.cpu().numpy(), it.cpu().numpy()
+    for f, n in enumerate(ns):
+        rcs, rit = om.assign_features_to_grid(un[f, :n], bounds)
+        np.testing.assert_array_equal(cs[f], rcs)
+        np.testing.assert_array_equal(it[f, :len(rit)], rit)

@@ -815,3 +815,63 @@ def test_sim3_searches_map_onto_the_windowed_oracles():
         np.testing.assert_array_equal(bi_a, bi_b)
         np.testing.assert_array_equal(np.where(bi_a < 0, 256, bd_a), bd_b)
     assert tot > 150
+
+
+EUROC_K = (458.654, 457.296, 367.215, 248.375)
+EUROC_DIST = (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05)      # Examples/Monocular/EuRoC.yaml:14-17
+
+
+def test_undistort_keypoints_oracle():
+    """Frame::UndistortKeyPoints (Frame.cc:738-771): oracle vs a numpy float64 restatement of OpenCV's 5-iteration inverse Brown
+    model, the forward distortion of the result lands back on the input (5 iterations: < 0.5 px at the corners), zero k1 copies.
+    parity unpinned against OpenCV itself (absent here)."""
+    from oracle_bind import KP_DTYPE
+    rng = np.random.default_rng(3)
+    n = 500
+    kp = np.zeros(n, KP_DTYPE)
+    kp["x"] = rng.uniform(0, 752, n).astype(np.float32); kp["y"] = rng.uniform(0, 480, n).astype(np.float32)
+    kp["octave"] = rng.integers(0, 8, n); kp["angle"] = rng.uniform(0, 360, n).astype(np.float32)
+    for dist in (EUROC_DIST, EUROC_DIST + (0.01,)):
+        out = om.undistort_keypoints(kp, EUROC_K, dist)
+        fx, fy, cx, cy = (float(np.float32(v)) for v in EUROC_K)
+        k = [float(np.float32(v)) for v in dist] + [0.0] * (5 - len(dist))
+        x0 = (kp["x"].astype(np.float64) - cx) * (1.0 / fx); y0 = (kp["y"].astype(np.float64) - cy) * (1.0 / fy)
+        x, y = x0.copy(), y0.copy()
+        for _ in range(5):
+            r2 = x * x + y * y
+            ic = 1.0 / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2)
+            dx = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x); dy = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y
+            x = (x0 - dx) * ic; y = (y0 - dy) * ic
+        np.testing.assert_array_equal(out["x"], (fx * x + cx).astype(np.float32))
+        np.testing.assert_array_equal(out["y"], (fy * y + cy).astype(np.float32))
+        for f in ("size", "angle", "response", "octave", "class_id"):
+            np.testing.assert_array_equal(out[f], kp[f])
+        # forward model on the undistorted points
+        xu = (out["x"].astype(np.float64) - cx) / fx; yu = (out["y"].astype(np.float64) - cy) / fy
+        r2 = xu * xu + yu * yu
+        cd = 1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2
+        xd = xu * cd + 2 * k[2] * xu * yu + k[3] * (r2 + 2 * xu * xu); yd = yu * cd + k[2] * (r2 + 2 * yu * yu) + 2 * k[3] * xu * yu
+        err = np.hypot(fx * xd + cx - kp["x"], fy * yd + cy - kp["y"])
+        assert err.max() < 0.5 and np.median(err) < 0.01, (err.max(), np.median(err))   # 5 iterations: corners converge to ~0.3 px
+    same = om.undistort_keypoints(kp, EUROC_K, (0.0, 0.1, 0.0, 0.0))
+    assert same.tobytes() == kp.tobytes()
+
+
+def test_assign_features_to_grid_oracle():
+    """Frame::AssignFeaturesToGrid (Frame.cc:377-408) as a CSR: every in-grid keypoint sits in the cell PosInGrid rounds it to,
+    cells keep index order, and GetFeaturesInArea over the whole image returns exactly the CSR's items."""
+    rng = np.random.default_rng(4)
+    bounds = (-12.5, -9.0, 760.0, 490.0)
+    for n in (0, 1, 300, 2500):
+        _, _, kp, _, _, _ = make_sbp_case(rng, n, 0, False)
+        cs, it = om.assign_features_to_grid(kp, bounds)
+        iw = np.float32(64) / (np.float32(bounds[2]) - np.float32(bounds[0])); ih = np.float32(48) / (np.float32(bounds[3]) - np.float32(bounds[1]))
+        cells = {}
+        for i in range(n):
+            vx = float(np.float32(np.float32(kp["x"][i] - np.float32(bounds[0])) * iw)); vy = float(np.float32(np.float32(kp["y"][i] - np.float32(bounds[1])) * ih))
+            px = int(np.floor(abs(vx) + 0.5) * np.sign(vx)); py = int(np.floor(abs(vy) + 0.5) * np.sign(vy))
+            if 0 <= px < 64 and 0 <= py < 48:
+                cells.setdefault(px * 48 + py, []).append(i)
+        assert cs[0] == 0 and cs[-1] == sum(len(v) for v in cells.values()) == len(it)
+        for c in range(64 * 48):
+            assert list(it[cs[c]:cs[c + 1]]) == cells.get(c, [])
