@@ -426,6 +426,26 @@ int orbhip_ba_batch_download(orbhip_ba_batch *b, double *const *poses_out, doubl
                              uint8_t *const *edge_outlier_out, orbhip_ba_stats *stats_out);
 int orbhip_ba_batch_ticks(const orbhip_ba_batch *b);   /* LM trials of the slowest graph, last solve */
 void orbhip_ba_batch_destroy(orbhip_ba_batch *b);
+/* Landmark-sharded solve of the same graphs by `world` ranks (one process per GPU) -- the optional single-graph mode of the
+ * multi-GPU path: g2o iterates landmarks independently (Thirdparty/g2o/g2o/core/block_solver.hpp:381-432), so rank r owns points
+ * [r*L/world, (r+1)*L/world) of every graph with their edges, poses are replicated, and the partial sums meet in ONE all-gather
+ * per exchange: (1) Hpp, bp, chi2 and max |Hll diag| after buildSystem, (2) the shared Schur block sum_l W D^-1 W^T and W D^-1 b
+ * every LM trial, (3) trial chi2, computeScale and the abort flag, (4) outlier / edge counts at the end.  Every rank reduces the
+ * gathered slots in rank order, so all ranks solve the same reduced system and take the same LM decisions (deterministic).
+ * create_sharded: every rank passes the SAME full graphs and initial estimates.  set_exchange_buffer: a DEVICE buffer of at least
+ * world * orbhip_ba_batch_exchange_doubles(b) doubles, laid out [world][exchange_doubles].  solve_sharded: before calling
+ * `exchange(user, stage, count)` the library has written `count` doubles into slot `rank` and drained its stream; the callback
+ * must all-gather so that slot r of every rank's buffer holds rank r's `count` doubles (RCCL: ncclAllGather(buf + rank*stride,
+ * buf, stride, ncclDouble, comm, stream) + stream sync) and return 0.  download writes this rank's points
+ * and edge flags at their positions in the caller's full-size arrays (other ranks' entries untouched), all poses, and stats that
+ * are identical on every rank.  The abort flag of any rank stops all of them at the same trial. */
+typedef int (*orbhip_ba_exchange_fn)(void *user, int stage, size_t count);
+int orbhip_ba_batch_create_sharded(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_graphs, double *const *poses,
+                                   double *const *points, int rank, int world, orbhip_ba_batch **out);
+size_t orbhip_ba_batch_exchange_doubles(const orbhip_ba_batch *b);
+int orbhip_ba_batch_set_exchange_buffer(orbhip_ba_batch *b, double *d_buf, size_t capacity_doubles);
+int orbhip_ba_batch_solve_sharded(orbhip_ba_batch *b, const orbhip_ba_params *params, volatile const uint8_t *abort,
+                                  orbhip_ba_exchange_fn exchange, void *user);
 /* Measurement hooks: hipEvent timing of the Schur GEMM launches (on the context's stream), the
  * MFMA flops of the tiles that hold data (flops_per_launch), of everything issued, and a measured FP64 matrix-core peak. */
 int orbhip_ba_batch_set_profiling(orbhip_ba_batch *b, int enable);

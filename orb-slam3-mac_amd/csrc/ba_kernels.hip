@@ -104,6 +104,16 @@ struct BaBatch {      // kernel argument (by value)
     double delta_m, dsqr_m, delta_s, dsqr_s, gate_m, gate_s, user_lambda, tau;
     int iters[2], max_trials;
     int ex2, nr2;                        // merge variant: exclude first-pass outliers / drop the robust kernel in pass 2
+    // landmark-sharded solve (optional single-graph mode): this rank owns a slice of every graph's points and their
+    // edges, poses are replicated; partial sums meet in xbuf [world][xcount] (slot r = rank r's payload, filled by the caller's
+    // all-gather) and are reduced in rank order on every rank, so all ranks take identical LM decisions.
+    int rank, world;
+    double *xbuf;
+    size_t xcount;
+    const int *x1_off, *x2_off;          // [G] payload offsets of exchange 1 (Hpp, bp, chi2, max |Hll diag|) and 2 (sum_ks Spart, W db)
+    double *bacc;                        // [sumF*6] sum over this rank's edges of W db (k_ba_bschur)
+    int *x_abort;                        // [1] any rank saw the abort flag (exchange 3)
+    double *edges_total;                 // [G] number of edges over all ranks (>= 50 % outlier rule)
 };
 
 // ------------------------------------------------------------------ SE3 helpers (B1)
@@ -434,7 +444,7 @@ __global__ __launch_bounds__(256) void k_ba_reduce(BaBatch B, int which)
         __syncthreads();
         double t = 0;
         for (int l = tid; l < G.n_points; l += 256) t += B.scale_pt[G.point_off + l];
-        for (int h = tid; h < G.nf; h += 256) t += B.scale_pose[G.free_off + h];
+        if (B.rank == 0) for (int h = tid; h < G.nf; h += 256) t += B.scale_pose[G.free_off + h];   // replicated: counted once
         red[tid] = t;
         __syncthreads();
         for (int d = 128; d > 0; d >>= 1) { if (tid < d) red[tid] += red[tid + d]; __syncthreads(); }
@@ -615,8 +625,9 @@ __global__ __launch_bounds__(256) void k_ba_maxdiag(BaBatch B)
     const BaGraphDev &G = B.gd[g];
     const int *ps = B.pt_start + G.ptstart_off;
     double m = 0;
-    for (int h = tid; h < G.nf; h += 256)
-        for (int a = 0; a < 6; a++) m = fmax(m, fabs(B.Hpp[(size_t)(G.free_off + h) * 36 + 7 * a]));
+    if (B.world == 1)                                   // sharded: Hpp is still a partial sum here (k_ba_shard_sum1 finishes the max)
+        for (int h = tid; h < G.nf; h += 256)
+            for (int a = 0; a < 6; a++) m = fmax(m, fabs(B.Hpp[(size_t)(G.free_off + h) * 36 + 7 * a]));
     for (int l = tid; l < G.n_points; l += 256)
         if (ps[l + 1] > ps[l]) {
             const double *H = B.Hll + (size_t)(G.point_off + l) * 6;
@@ -878,9 +889,14 @@ __global__ __launch_bounds__(256) void k_ba_schur_finish(BaBatch B)
     else {
         if (r / 6 == c / 6) v = B.Hpp[(size_t)(G.free_off + r / 6) * 36 + (r % 6) * 6 + (c % 6)] + (r == c ? st.lambda : 0.0);
         const int ur = (r / 16 <= c / 16) ? r : c, uc = (r / 16 <= c / 16) ? c : r;   // upper-tile source
-        const double *Sp = B.Spart + G.spart_off + (size_t)ur * G.ld + uc;
         double s = 0;
-        for (int k = 0; k < G.ks; k++) s += Sp[(size_t)k * G.ld * G.ld];
+        if (B.world == 1) {
+            const double *Sp = B.Spart + G.spart_off + (size_t)ur * G.ld + uc;
+            for (int k = 0; k < G.ks; k++) s += Sp[(size_t)k * G.ld * G.ld];
+        } else {
+            const double *X = B.xbuf + B.x2_off[g] + (size_t)ur * G.ld + uc;          // every rank's sum_ks Spart, rank order
+            for (int r = 0; r < B.world; r++) s += X[(size_t)r * B.xcount];
+        }
         v -= s;
     }
     B.S[G.s_off + idx] = v;
@@ -912,7 +928,10 @@ __global__ __launch_bounds__(64) void k_ba_bschur(BaBatch B)
         acc[a] = v;
     }
     if (lane == 0)
-        for (int a = 0; a < 6; a++) B.bs[(size_t)(G.free_off + h) * 6 + a] = B.bp[(size_t)(G.free_off + h) * 6 + a] - acc[a];
+        for (int a = 0; a < 6; a++) {
+            B.bacc[(size_t)(G.free_off + h) * 6 + a] = acc[a];
+            B.bs[(size_t)(G.free_off + h) * 6 + a] = B.bp[(size_t)(G.free_off + h) * 6 + a] - acc[a];      // sharded: redone by k_ba_shard_sum2
+        }
 }
 
 // Reduced pose system: dense LDL^T without pivoting + solve, one workgroup per graph (stands in for
@@ -1150,10 +1169,11 @@ __global__ __launch_bounds__(64) void k_ba_update_poses(BaBatch B)
 
 // LM accept/reject + iteration bookkeeping: levenberg.cpp:121-169, sparse_optimizer.cpp:372-418,
 // Optimizer.cc:2048-2122 (two passes).  One thread per graph.
-__global__ void k_ba_control(BaBatch B, int abort_flag)
+__global__ void k_ba_control(BaBatch B, int abort_arg)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= B.G) return;
+    const int abort_flag = B.world > 1 ? *B.x_abort : abort_arg;       // sharded: every rank must see the same flag
     BaState &st = B.st[g];
     if (!st.active) return;
     double temp_chi = B.chi[g];
@@ -1196,6 +1216,96 @@ __global__ void k_ba_control(BaBatch B, int abort_flag)
 
 // Merge variant, between the passes (Optimizer.cc:6546-6579): chi2 of the last evaluation > gate or depth <= 0 at the
 // current estimate => setLevel(1).  Runs at the start of the tick after the pass switch (apply_levels).
+// ---- landmark-sharded solve: pack this rank's partial sums into its slot of xbuf / reduce all slots in rank order
+__global__ __launch_bounds__(256) void k_ba_shard_pack1(BaBatch B)
+{
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const BaState &st = B.st[g];
+    if (!st.active || !st.need_build) return;
+    const BaGraphDev &G = B.gd[g];
+    double *X = B.xbuf + (size_t)B.rank * B.xcount + B.x1_off[g];
+    for (int i = tid; i < G.nf * 36; i += 256) X[i] = B.Hpp[(size_t)G.free_off * 36 + i];
+    for (int i = tid; i < G.nf * 6; i += 256) X[G.nf * 36 + i] = B.bp[(size_t)G.free_off * 6 + i];
+    if (tid == 0) { X[G.nf * 42] = B.chi[g]; X[G.nf * 42 + 1] = B.maxdiag[g]; }
+}
+__global__ __launch_bounds__(256) void k_ba_shard_sum1(BaBatch B)
+{
+    __shared__ double red[256];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const BaState &st = B.st[g];
+    if (!st.active || !st.need_build) return;
+    const BaGraphDev &G = B.gd[g];
+    const double *X = B.xbuf + B.x1_off[g];
+    double m = 0;
+    for (int i = tid; i < G.nf * 36; i += 256) {
+        double v = 0;
+        for (int r = 0; r < B.world; r++) v += X[(size_t)r * B.xcount + i];
+        B.Hpp[(size_t)G.free_off * 36 + i] = v;
+        if (i % 36 % 7 == 0) m = fmax(m, fabs(v));
+    }
+    for (int i = tid; i < G.nf * 6; i += 256) {
+        double v = 0;
+        for (int r = 0; r < B.world; r++) v += X[(size_t)r * B.xcount + G.nf * 36 + i];
+        B.bp[(size_t)G.free_off * 6 + i] = v;
+    }
+    red[tid] = m;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) { if (tid < d) red[tid] = fmax(red[tid], red[tid + d]); __syncthreads(); }
+    if (tid == 0) {
+        double c = 0, mh = red[0];
+        for (int r = 0; r < B.world; r++) { c += X[(size_t)r * B.xcount + G.nf * 42]; mh = fmax(mh, X[(size_t)r * B.xcount + G.nf * 42 + 1]); }
+        B.chi[g] = c;
+        if (st.need_lambda_init) B.maxdiag[g] = mh;
+    }
+}
+__global__ __launch_bounds__(256) void k_ba_shard_pack2(BaBatch B)
+{
+    const int g = blockIdx.y;
+    const BaState &st = B.st[g];
+    if (!st.active) return;
+    const BaGraphDev &G = B.gd[g];
+    const int idx = blockIdx.x * 256 + threadIdx.x, n2 = G.ld * G.ld;
+    double *X = B.xbuf + (size_t)B.rank * B.xcount + B.x2_off[g];
+    if (idx < n2) {
+        const double *Sp = B.Spart + G.spart_off + idx;
+        double s = 0;
+        for (int k = 0; k < G.ks; k++) s += Sp[(size_t)k * n2];
+        X[idx] = s;
+    }
+    if (idx < G.nf * 6) X[n2 + idx] = B.bacc[(size_t)G.free_off * 6 + idx];
+}
+__global__ __launch_bounds__(256) void k_ba_shard_sum2(BaBatch B)
+{
+    const int g = blockIdx.x;
+    const BaState &st = B.st[g];
+    if (!st.active) return;
+    const BaGraphDev &G = B.gd[g];
+    const double *X = B.xbuf + B.x2_off[g] + (size_t)G.ld * G.ld;
+    for (int i = threadIdx.x; i < G.nf * 6; i += 256) {
+        double a = 0;
+        for (int r = 0; r < B.world; r++) a += X[(size_t)r * B.xcount + i];
+        B.bs[(size_t)G.free_off * 6 + i] = B.bp[(size_t)G.free_off * 6 + i] - a;
+    }
+}
+// stage 3: trial chi2, computeScale partial, abort flag; stage 4: outlier / edge counts.  payload 3 doubles per graph.
+__global__ void k_ba_shard_pack34(BaBatch B, int stage, int abort_arg)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= B.G) return;
+    double *X = B.xbuf + (size_t)B.rank * B.xcount + 3 * (size_t)g;
+    if (stage == 3) { X[0] = B.chi[g]; X[1] = B.scale[g]; X[2] = (double)abort_arg; }
+    else { X[0] = (double)B.st[g].n_outliers; X[1] = (double)B.gd[g].n_edges; X[2] = 0; }
+}
+__global__ void k_ba_shard_sum34(BaBatch B, int stage)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= B.G) return;
+    double a = 0, b2 = 0, c = 0;
+    for (int r = 0; r < B.world; r++) { const double *X = B.xbuf + (size_t)r * B.xcount + 3 * (size_t)g; a += X[0]; b2 += X[1]; c = fmax(c, X[2]); }
+    if (stage == 3) { if (B.st[g].active) { B.chi[g] = a; B.scale[g] = b2; } if (g == 0) *B.x_abort = c > 0 ? 1 : 0; }
+    else { B.st[g].n_outliers = (int)a; B.edges_total[g] = b2; }
+}
+
 __global__ __launch_bounds__(256) void k_ba_levels(BaBatch B)
 {
     const int g = blockIdx.y;
@@ -1249,6 +1359,10 @@ struct orbhip_ba_batch {
     double gemm_flops_per_launch;            // MFMA flops actually issued by one launch (all graphs)
     double gemm_flops_dense;                 // what the same upper tiles would cost without block-sparsity skipping
     double gemm_flops_issued;                // MFMA flops issued by one launch (every tile of a chunk whose row tile and one column tile the point touches)
+    // landmark-sharded batches: the slice of every full graph this rank owns
+    struct Slice { int pt0, npts, e0, ne; };
+    std::vector<Slice> slices;
+    size_t x_need;                           // doubles per rank slot of the exchange buffer
 };
 
 template <typename T>
@@ -1292,8 +1406,10 @@ extern "C" void orbhip_ba_batch_destroy(orbhip_ba_batch *b)
     delete b;
 }
 
-extern "C" int orbhip_ba_batch_create(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_graphs,
-                                      double *const *poses, double *const *points, orbhip_ba_batch **out)
+// pose_in_system[g] (optional): which poses take part in the reduced system even without an edge in THIS graph -- a sharded
+// batch sees only a slice of the edges but must number the free poses like every other rank.
+static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_graphs, const double *const *poses, const double *const *points,
+                          const std::vector<std::vector<uint8_t>> *pose_in_system, int rank, int world, orbhip_ba_batch **out)
 {
     if (!ctx || !graphs || n_graphs <= 0 || !poses || !points || !out) return ORBHIP_E_BADARG;
     if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
@@ -1302,7 +1418,9 @@ extern "C" int orbhip_ba_batch_create(orbhip_ctx *ctx, const orbhip_ba_graph *gr
     b->profile = false; b->ev0 = b->ev1 = nullptr; b->gemm_ms_total = 0; b->gemm_launches = 0; b->gemm_flops_per_launch = 0; b->gemm_flops_dense = 0; b->gemm_flops_issued = 0;
     BaBatch &B = b->B;
     memset(&B, 0, sizeof(B));
-    B.G = n_graphs;
+    B.G = n_graphs; B.rank = rank; B.world = world;
+    std::vector<int> x1off, x2off;
+    size_t x1 = 0, x2 = 0;
     std::vector<int> hidx, epose, epoint, ptstart, posestart, poseedges;
     std::vector<uint32_t> ptmask;
     std::vector<int4> gtask, gstage;
@@ -1330,6 +1448,7 @@ extern "C" int orbhip_ba_batch_create(orbhip_ctx *ctx, const orbhip_ba_graph *gr
                 (e > 0 && H.edge_point[e] < H.edge_point[e - 1])) { delete b; g_ba_error = "edges must be point-major with valid ids"; return ORBHIP_E_BADARG; }
             has[H.edge_pose[e]] = 1;
         }
+        if (pose_in_system) for (int i = 0; i < H.n_poses; i++) has[i] = (*pose_in_system)[g][i];
         int nf = 0;
         for (int i = 0; i < H.n_poses; i++) { local_h[i] = (!H.pose_fixed[i] && has[i]) ? nf++ : -1; hidx.push_back(local_h[i]); }
         D.nf = nf; D.n = 6 * nf; D.ld = std::max(96, (D.n + 95) / 96 * 96);   // multiple of 16 (MFMA tiles) and of 32 (1-KiB LDS-DMA pieces)
@@ -1429,6 +1548,8 @@ extern "C" int orbhip_ba_batch_create(orbhip_ctx *ctx, const orbhip_ba_graph *gr
             b->gemm_flops_issued += chunks * 2048.0;
             b->gemm_flops_dense += (double)ntiles * 2048.0 * (double)H.n_points;        // same tiles without the masks
         }
+        x1off.push_back((int)x1); x1 += (size_t)nf * 42 + 2;
+        x2off.push_back((int)x2); x2 += (size_t)D.ld * D.ld + (size_t)nf * 6;
         D.s_off = s; s += (size_t)D.ld * D.ld;
         D.spart_off = sp; sp += (size_t)ks * D.ld * D.ld;
         B.max_edges = std::max(B.max_edges, H.n_edges); B.max_points = std::max(B.max_points, H.n_points);
@@ -1448,12 +1569,13 @@ extern "C" int orbhip_ba_batch_create(orbhip_ctx *ctx, const orbhip_ba_graph *gr
     }
     B.sumP = sumP; B.sumL = sumL; B.sumE = sumE; B.sumF = sumF;
     b->s_total = s; b->spart_total = sp;
+    b->x_need = std::max(std::max(x1, x2), (size_t)3 * n_graphs);
     bool ok = true;
 #define UP(dst, vec) do { auto *_p = ba_upload(b, vec); ok = ok && _p; dst = _p; } while (0)
 #define AL(dst, T, n) do { auto *_p = ba_alloc<T>(b, n); ok = ok && _p; dst = _p; } while (0)
     UP(B.gd, b->gd); UP(B.hidx, hidx); UP(B.edge_pose, epose); UP(B.edge_point, epoint); UP(B.edge_obs, eobs);
     UP(B.edge_is2, eis2); UP(B.edge_stereo, est); UP(B.edge_dup, edup); UP(B.edge_next, enext); UP(B.pt_start, ptstart); UP(B.pose_start, posestart); UP(B.pose_edges, poseedges);
-    UP(B.ptmask, ptmask); UP(B.gemm_task, gtask); UP(B.gemm_stage, gstage); UP(B.edge_task, etask);
+    UP(B.ptmask, ptmask); UP(B.gemm_task, gtask); UP(B.gemm_stage, gstage); UP(B.edge_task, etask); UP(B.x1_off, x1off); UP(B.x2_off, x2off);
     AL(B.st, BaState, n_graphs);
     AL(B.poses, double, (size_t)2 * sumP * 7); AL(B.points, double, (size_t)2 * sumL * 3);
     AL(B.err, double, (size_t)sumE * 3); AL(B.chi2, double, sumE); AL(B.rho0, double, sumE);
@@ -1464,6 +1586,7 @@ extern "C" int orbhip_ba_batch_create(orbhip_ctx *ctx, const orbhip_ba_graph *gr
     AL(B.scale_pt, double, sumL); AL(B.scale_pose, double, sumF);
     AL(B.chi, double, n_graphs); AL(B.scale, double, n_graphs); AL(B.maxdiag, double, n_graphs);
     AL(B.n_active, int, 1); AL(B.outlier, uint8_t, sumE); AL(B.level, uint8_t, sumE);
+    AL(B.bacc, double, (size_t)sumF * 6); AL(B.x_abort, int, 1); AL(B.edges_total, double, n_graphs);
 #undef UP
 #undef AL
     if (!ok || hipHostMalloc((void **)&b->h_n_active, sizeof(int)) != hipSuccess) { orbhip_ba_batch_destroy(b); g_ba_error = "device allocation failed"; return ORBHIP_E_HIP; }
@@ -1471,13 +1594,62 @@ extern "C" int orbhip_ba_batch_create(orbhip_ctx *ctx, const orbhip_ba_graph *gr
     return ORBHIP_OK;
 }
 
+extern "C" int orbhip_ba_batch_create(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_graphs,
+                                      double *const *poses, double *const *points, orbhip_ba_batch **out)
+{
+    return ba_create_impl(ctx, graphs, n_graphs, poses, points, nullptr, 0, 1, out);
+}
+
+// Landmark-sharded batch (optional single-graph mode): every rank passes the SAME full graphs and estimates; rank r
+// keeps points [r*L/world, (r+1)*L/world) of every graph with their edges (contiguous: edges are point-major) and all poses.
+extern "C" int orbhip_ba_batch_create_sharded(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_graphs, double *const *poses,
+                                              double *const *points, int rank, int world, orbhip_ba_batch **out)
+{
+    if (!ctx || !graphs || n_graphs <= 0 || !poses || !points || !out || world < 1 || rank < 0 || rank >= world) return ORBHIP_E_BADARG;
+    std::vector<orbhip_ba_graph> sub(graphs, graphs + n_graphs);
+    std::vector<std::vector<int32_t>> ept(n_graphs);
+    std::vector<std::vector<uint8_t>> has(n_graphs);
+    std::vector<const double *> pts(n_graphs);
+    std::vector<orbhip_ba_batch::Slice> slices(n_graphs);
+    for (int g = 0; g < n_graphs; g++) {
+        const orbhip_ba_graph &H = graphs[g];
+        if (H.n_poses <= 0 || H.n_points < world || H.n_edges < 0) { g_ba_error = "a sharded graph needs at least one point per rank"; return ORBHIP_E_BADARG; }
+        has[g].assign(H.n_poses, 0);
+        for (int e = 0; e < H.n_edges; e++) {
+            if (H.edge_pose[e] < 0 || H.edge_pose[e] >= H.n_poses || H.edge_point[e] < 0 || H.edge_point[e] >= H.n_points ||
+                (e > 0 && H.edge_point[e] < H.edge_point[e - 1])) { g_ba_error = "edges must be point-major with valid ids"; return ORBHIP_E_BADARG; }
+            has[g][H.edge_pose[e]] = 1;
+        }
+        const int p0 = (int)((long long)rank * H.n_points / world), p1 = (int)((long long)(rank + 1) * H.n_points / world);
+        int e0 = 0;
+        while (e0 < H.n_edges && H.edge_point[e0] < p0) e0++;
+        int e1 = e0;
+        while (e1 < H.n_edges && H.edge_point[e1] < p1) e1++;
+        slices[g] = {p0, p1 - p0, e0, e1 - e0};
+        ept[g].resize(e1 - e0);
+        for (int e = e0; e < e1; e++) ept[g][e - e0] = H.edge_point[e] - p0;
+        orbhip_ba_graph &S = sub[g];
+        S.n_points = p1 - p0; S.n_edges = e1 - e0;
+        S.edge_pose = H.edge_pose + e0; S.edge_point = ept[g].data(); S.edge_obs = H.edge_obs + 3 * (size_t)e0;
+        S.edge_inv_sigma2 = H.edge_inv_sigma2 + e0; S.edge_stereo = H.edge_stereo ? H.edge_stereo + e0 : nullptr;
+        pts[g] = points[g] + 3 * (size_t)p0;
+    }
+    const int rc = ba_create_impl(ctx, sub.data(), n_graphs, poses, pts.data(), &has, rank, world, out);
+    if (rc == ORBHIP_OK) (*out)->slices = slices;
+    return rc;
+}
+
+extern "C" size_t orbhip_ba_batch_exchange_doubles(const orbhip_ba_batch *b) { return b ? b->x_need : 0; }
+
 // Runs optimize(iters1) + optimize(iters2) + outlier classification for every graph of the batch,
 // starting from the initial estimates given at creation.  Device-resident; returns after completion.
-extern "C" int orbhip_ba_batch_solve(orbhip_ba_batch *b, const orbhip_ba_params *params, volatile const uint8_t *abort_flag)
+static int ba_solve_impl(orbhip_ba_batch *b, const orbhip_ba_params *params, volatile const uint8_t *abort_flag, orbhip_ba_exchange_fn xch, void *xuser)
 {
     if (!b || !params) return ORBHIP_E_BADARG;
+    const bool sharded = b->B.world > 1;
+    if (sharded && (!xch || !b->B.xbuf)) { g_ba_error = "a sharded batch needs orbhip_ba_batch_set_exchange_buffer and an exchange callback"; return ORBHIP_E_BADARG; }
     if (hipSetDevice(orbhip_ctx_device_internal(b->ctx)) != hipSuccess) return ORBHIP_E_HIP;
-    if (abort_flag && *abort_flag) return ORBHIP_E_ABORTED;                    // Optimizer.cc:2041-2043
+    if (!sharded && abort_flag && *abort_flag) return ORBHIP_E_ABORTED;       // Optimizer.cc:2041-2043 (sharded: the flag travels through exchange 3)
     hipStream_t s = orbhip_ctx_stream_internal(b->ctx);
     BaBatch &B = b->B;
     B.delta_m = (double)(float)sqrt(params->huber_mono2); B.dsqr_m = (double)(float)(B.delta_m * B.delta_m);
@@ -1504,7 +1676,11 @@ extern "C" int orbhip_ba_batch_solve(orbhip_ba_batch *b, const orbhip_ba_params 
     TRY(hipMemsetAsync(B.xp, 0, sizeof(double) * (size_t)B.sumF * 6, s));
     TRY(hipMemsetAsync(B.xl, 0, sizeof(double) * (size_t)B.sumL * 3, s));
     TRY(hipMemsetAsync(B.level, 0, (size_t)std::max(B.sumE, 1), s));
+    TRY(hipMemsetAsync(B.x_abort, 0, sizeof(int), s));
     TRY(hipStreamSynchronize(s));     // st / n_active host buffers must outlive the copies
+    // sharded: the caller's all-gather runs between two kernels; the stream is drained around it
+#define XCHG(stage, cnt) do { TRY(hipStreamSynchronize(s)); if (xch(xuser, (stage), (size_t)(cnt)) != 0) { g_ba_error = "exchange callback failed"; return ORBHIP_E_HIP; } } while (0)
+    const size_t x1n = b->x_need, x3n = (size_t)3 * B.G;
     const int G = B.G;
     const dim3 ge((B.max_edges + 255) / 256, G), gp128((B.max_points + 127) / 128, G), gp256((B.max_points + 255) / 256, G);
     const dim3 gf(std::max(B.max_nf, 1), G);
@@ -1525,18 +1701,33 @@ extern "C" int orbhip_ba_batch_solve(orbhip_ba_batch *b, const orbhip_ba_params 
         hipLaunchKernelGGL(k_ba_build_points, dim3((B.max_points + 15) / 16, G), dim3(256), 0, s, B);
         hipLaunchKernelGGL(k_ba_build_poses, gf, dim3(64), 0, s, B);
         hipLaunchKernelGGL(k_ba_maxdiag, dim3(G), dim3(256), 0, s, B);
+        if (sharded) {                                           // exchange 1: Hpp, bp, chi2, max |Hll diag|
+            hipLaunchKernelGGL(k_ba_shard_pack1, dim3(G), dim3(256), 0, s, B);
+            XCHG(1, x1n);
+            hipLaunchKernelGGL(k_ba_shard_sum1, dim3(G), dim3(256), 0, s, B);
+        }
         hipLaunchKernelGGL(k_ba_pretrial, dim3((G + 63) / 64), dim3(64), 0, s, B);
         hipLaunchKernelGGL(k_ba_point_prep, gp256, dim3(256), 0, s, B);
         if (b->profile) TRY(hipEventRecord(b->ev0, s));
         hipLaunchKernelGGL(k_ba_schur_gemm, dim3(max_items, G), dim3(64 * GEMM_WAVES), gemm_lds, s, B);
         if (b->profile) TRY(hipEventRecord(b->ev1, s));
-        hipLaunchKernelGGL(k_ba_schur_finish, dim3((B.max_ld * B.max_ld + 255) / 256, G), dim3(256), 0, s, B);
         hipLaunchKernelGGL(k_ba_bschur, gf, dim3(64), 0, s, B);
+        if (sharded) {                                           // exchange 2: the shared Schur block (sum_ks Spart) and W db
+            hipLaunchKernelGGL(k_ba_shard_pack2, dim3((B.max_ld * B.max_ld + 255) / 256, G), dim3(256), 0, s, B);
+            XCHG(2, x1n);
+            hipLaunchKernelGGL(k_ba_shard_sum2, dim3(G), dim3(256), 0, s, B);
+        }
+        hipLaunchKernelGGL(k_ba_schur_finish, dim3((B.max_ld * B.max_ld + 255) / 256, G), dim3(256), 0, s, B);
         hipLaunchKernelGGL(k_ba_ldlt, dim3(G), dim3(1024), ldlt_lds, s, B);
         hipLaunchKernelGGL(k_ba_backsub_points, dim3((B.max_points + 15) / 16, G), dim3(256), 0, s, B);
         hipLaunchKernelGGL(k_ba_update_poses, dim3((max_poses + 63) / 64, G), dim3(64), 0, s, B);
         hipLaunchKernelGGL(k_ba_errors, ge, dim3(256), 0, s, B, 1);
         hipLaunchKernelGGL(k_ba_reduce, dim3(G), dim3(256), 0, s, B, 1);
+        if (sharded) {                                           // exchange 3: trial chi2, computeScale, abort flag
+            hipLaunchKernelGGL(k_ba_shard_pack34, dim3((G + 63) / 64), dim3(64), 0, s, B, 3, ab);
+            XCHG(3, x3n);
+            hipLaunchKernelGGL(k_ba_shard_sum34, dim3((G + 63) / 64), dim3(64), 0, s, B, 3);
+        }
         hipLaunchKernelGGL(k_ba_control, dim3((G + 63) / 64), dim3(64), 0, s, B, ab);
         TRY(hipMemcpyAsync(b->h_n_active, B.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
         TRY(hipStreamSynchronize(s));
@@ -1549,10 +1740,37 @@ extern "C" int orbhip_ba_batch_solve(orbhip_ba_batch *b, const orbhip_ba_params 
     }
     b->ticks_last = tick;
     hipLaunchKernelGGL(k_ba_finalize, ge, dim3(256), 0, s, B);
+    if (sharded) {                                               // exchange 4: outlier and edge counts for the >= 50 % rule
+        hipLaunchKernelGGL(k_ba_shard_pack34, dim3((G + 63) / 64), dim3(64), 0, s, B, 4, 0);
+        XCHG(4, x3n);
+        hipLaunchKernelGGL(k_ba_shard_sum34, dim3((G + 63) / 64), dim3(64), 0, s, B, 4);
+    }
     TRY(hipStreamSynchronize(s));
     TRY(hipGetLastError());
+#undef XCHG
 #undef TRY
     return ORBHIP_OK;
+}
+
+extern "C" int orbhip_ba_batch_solve(orbhip_ba_batch *b, const orbhip_ba_params *params, volatile const uint8_t *abort_flag)
+{
+    if (b && b->B.world > 1) { g_ba_error = "sharded batch: use orbhip_ba_batch_solve_sharded"; return ORBHIP_E_BADARG; }
+    return ba_solve_impl(b, params, abort_flag, nullptr, nullptr);
+}
+
+extern "C" int orbhip_ba_batch_set_exchange_buffer(orbhip_ba_batch *b, double *d_buf, size_t capacity_doubles)
+{
+    if (!b || !d_buf || capacity_doubles < (size_t)b->B.world * b->x_need) return ORBHIP_E_BADARG;
+    b->B.xbuf = d_buf; b->B.xcount = b->x_need;
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_ba_batch_solve_sharded(orbhip_ba_batch *b, const orbhip_ba_params *params, volatile const uint8_t *abort_flag,
+                                             orbhip_ba_exchange_fn exchange, void *user)
+{
+    if (!b || !exchange) return ORBHIP_E_BADARG;
+    if (b->B.world == 1) return ba_solve_impl(b, params, abort_flag, nullptr, nullptr);
+    return ba_solve_impl(b, params, abort_flag, exchange, user);
 }
 
 // D2H of the results of the last solve.  poses_out[g]/points_out[g] are written unless the graph
@@ -1570,14 +1788,18 @@ extern "C" int orbhip_ba_batch_download(orbhip_ba_batch *b, double *const *poses
     if (hipMemcpy(poses.data(), B.poses, poses.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return ORBHIP_E_HIP;
     if (hipMemcpy(points.data(), B.points, points.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return ORBHIP_E_HIP;
     if (B.sumE && hipMemcpy(outl.data(), B.outlier, B.sumE, hipMemcpyDeviceToHost) != hipSuccess) return ORBHIP_E_HIP;
+    std::vector<double> etot(B.G, 0.0);
+    if (B.world > 1 && hipMemcpy(etot.data(), B.edges_total, sizeof(double) * B.G, hipMemcpyDeviceToHost) != hipSuccess) return ORBHIP_E_HIP;
     for (int g = 0; g < B.G; g++) {
         const BaGraphDev &D = b->gd[g];
-        const int discarded = (!b->no_discard && D.n_edges > 0 && st[g].n_outliers >= D.n_edges * 0.5) ? 1 : 0;
-        if (!discarded) {
+        const double n_edges_all = B.world > 1 ? etot[g] : (double)D.n_edges;          // sharded: counts of all ranks (exchange 4)
+        const int discarded = (!b->no_discard && n_edges_all > 0 && st[g].n_outliers >= n_edges_all * 0.5) ? 1 : 0;
+        const size_t pt0 = b->slices.empty() ? 0 : (size_t)b->slices[g].pt0, e0 = b->slices.empty() ? 0 : (size_t)b->slices[g].e0;
+        if (!discarded) {                                      // sharded: this rank's points / edges land at their place in the full arrays
             if (poses_out && poses_out[g]) memcpy(poses_out[g], poses.data() + ((size_t)st[g].cur * B.sumP + D.pose_off) * 7, sizeof(double) * 7 * D.n_poses);
-            if (points_out && points_out[g]) memcpy(points_out[g], points.data() + ((size_t)st[g].cur * B.sumL + D.point_off) * 3, sizeof(double) * 3 * D.n_points);
+            if (points_out && points_out[g]) memcpy(points_out[g] + 3 * pt0, points.data() + ((size_t)st[g].cur * B.sumL + D.point_off) * 3, sizeof(double) * 3 * D.n_points);
         }
-        if (edge_outlier_out && edge_outlier_out[g]) memcpy(edge_outlier_out[g], outl.data() + D.edge_off, D.n_edges);
+        if (edge_outlier_out && edge_outlier_out[g]) memcpy(edge_outlier_out[g] + e0, outl.data() + D.edge_off, D.n_edges);
         if (stats_out) {
             orbhip_ba_stats &o = stats_out[g];
             o.iterations_run[0] = st[g].iters_run[0]; o.iterations_run[1] = st[g].iters_run[1];

@@ -355,13 +355,23 @@ def ba_default_params():
     return p
 
 
+BA_EXCHANGE_FN = C.CFUNCTYPE(ci, vp, ci, C.c_size_t)
+lib.orbhip_ba_batch_exchange_doubles.restype = C.c_size_t
+lib.orbhip_ba_batch_exchange_doubles.argtypes = [vp]
+lib.orbhip_ba_batch_set_exchange_buffer.argtypes = [vp, vp, C.c_size_t]
+lib.orbhip_ba_batch_solve_sharded.argtypes = [vp, vp, vp, BA_EXCHANGE_FN, vp]
+lib.orbhip_ba_batch_create_sharded.argtypes = [vp, vp, ci, vp, vp, ci, ci, vp]
+
+
 class BaBatch:
     """Device-resident batch of keyframe-window graphs (dicts as produced by synth_ba.make_graph:
     n_poses, n_points, n_edges, pose_fixed, edge_pose, edge_point, edge_obs, edge_inv_sigma2,
     edge_stereo, fx, fy, cx, cy, bf, poses0, points0)."""
 
-    def __init__(self, ctx, graphs):
+    def __init__(self, ctx, graphs, rank=0, world=1):
+        """world > 1: landmark-sharded batch (orbhip_ba_batch_create_sharded): every rank passes the same graphs."""
         self.ctx, self.n = ctx, len(graphs)
+        self.rank, self.world = rank, world
         self._keep = []
         arr = (BaGraph * self.n)()
         self.sizes = []
@@ -380,9 +390,41 @@ class BaBatch:
         pp = (vp * self.n)(*[a.ctypes.data for a in self.poses])
         pq = (vp * self.n)(*[a.ctypes.data for a in self.points])
         h = vp()
-        _chk(lib.orbhip_ba_batch_create(ctx.h, C.cast(arr, vp), self.n, C.cast(pp, vp), C.cast(pq, vp), C.byref(h)),
-             "orbhip_ba_batch_create")
+        if world == 1:
+            _chk(lib.orbhip_ba_batch_create(ctx.h, C.cast(arr, vp), self.n, C.cast(pp, vp), C.cast(pq, vp), C.byref(h)),
+                 "orbhip_ba_batch_create")
+        else:
+            _chk(lib.orbhip_ba_batch_create_sharded(ctx.h, C.cast(arr, vp), self.n, C.cast(pp, vp), C.cast(pq, vp), rank, world,
+                                                    C.byref(h)), "orbhip_ba_batch_create_sharded")
         self.h = h
+
+    @property
+    def exchange_doubles(self):
+        """Doubles per rank slot of the exchange buffer (sharded batches)."""
+        return lib.orbhip_ba_batch_exchange_doubles(self.h)
+
+    def set_exchange_buffer(self, d_ptr, capacity_doubles):
+        _chk(lib.orbhip_ba_batch_set_exchange_buffer(self.h, d_ptr, capacity_doubles), "orbhip_ba_batch_set_exchange_buffer")
+
+    def solve_sharded(self, exchange, params=None, abort=None):
+        """exchange(stage, count) -> None: all-gather `count` doubles per rank inside the exchange buffer (slot r = rank r)."""
+        p = params or ba_default_params()
+        err = []
+
+        def _cb(user, stage, count):
+            try:
+                exchange(int(stage), int(count))
+                return 0
+            except BaseException as e:          # never let an exception cross the C boundary
+                err.append(e)
+                return 1
+        cb = BA_EXCHANGE_FN(_cb)
+        rc = lib.orbhip_ba_batch_solve_sharded(self.h, C.byref(p), abort.ctypes.data if abort is not None else None, cb, None)
+        if err:
+            raise err[0]
+        if rc not in (OK, E_ABORTED):
+            raise OrbHipError(rc, "orbhip_ba_batch_solve_sharded")
+        return rc
 
     def solve(self, params=None, abort=None):
         p = params or ba_default_params()

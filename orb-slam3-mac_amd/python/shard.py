@@ -35,3 +35,31 @@ def allgather_records(records):
     flat = torch.empty((world * records.shape[0],) + tuple(records.shape[1:]), dtype=records.dtype, device=records.device)
     dist.all_gather_into_tensor(flat, records.contiguous())        # concatenation form: accepted by gloo and RCCL
     return flat.view((world,) + tuple(records.shape))
+
+
+def make_ba_exchange(xbuf, stride, group=None):
+    """Exchange callback for orbhip.BaBatch.solve_sharded: xbuf = 1-D float64 torch tensor [world * stride] on the GPU the batch
+    lives on; slot r = xbuf[r*stride : (r+1)*stride].  One all-gather per call (backend "nccl" = RCCL over xGMI on GPUs; with a
+    CPU backend such as gloo -- rehearsals on one card -- the payload takes a round trip through host memory)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    on_gpu = dist.get_backend(group) == "nccl"
+
+    def exchange(stage, count):
+        mine = xbuf[rank * stride: rank * stride + count]
+        if on_gpu:
+            send = mine.clone()
+            outs = [xbuf[r * stride: r * stride + count] for r in range(world)]
+            dist.all_gather(outs, send, group=group)
+            torch.cuda.synchronize()
+        else:
+            send = mine.cpu()
+            outs = [torch.empty_like(send) for _ in range(world)]
+            dist.all_gather(outs, send, group=group)
+            for r in range(world):
+                if r != rank:
+                    xbuf[r * stride: r * stride + count].copy_(outs[r])
+            torch.cuda.synchronize()
+    return exchange

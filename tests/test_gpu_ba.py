@@ -194,3 +194,106 @@ def test_ba_large_window_and_dense_observations(gpu_ctx):
               synth_ba.make_graph(n_kf=6, n_pts=40, obs=4, seed=53)]
     stats = _check(gpu_ctx, graphs)
     assert not any(s["discarded"] for s in stats)
+
+
+def _solve_sharded_in_process(device, graphs, world, params=None, abort_rank=None):
+    """`world` ranks as threads of this process (own context / stream / batch / exchange buffer each, one GPU): the exchange
+    callback is an all-gather between the threads' buffers.  The solver code path is the multi-process one."""
+    import threading
+    import torch
+    import orbhip
+    ctxs = [orbhip.Context(device) for _ in range(world)]
+    bbs = [orbhip.BaBatch(ctxs[r], graphs, rank=r, world=world) for r in range(world)]
+    stride = bbs[0].exchange_doubles
+    assert all(b.exchange_doubles == stride for b in bbs)
+    bufs = [torch.zeros(world * stride, dtype=torch.float64, device="cuda") for _ in range(world)]
+    for r in range(world):
+        bbs[r].set_exchange_buffer(bufs[r].data_ptr(), world * stride)
+    torch.cuda.synchronize()
+    bar = threading.Barrier(world)
+    stages = [[] for _ in range(world)]
+    errs = []
+
+    def make_exchange(r):
+        def exchange(stage, count):
+            stages[r].append(stage)
+            bar.wait(timeout=60)
+            for o in range(world):
+                if o != r:
+                    bufs[o][r * stride: r * stride + count].copy_(bufs[r][r * stride: r * stride + count])
+            torch.cuda.synchronize()
+            bar.wait(timeout=60)
+        return exchange
+
+    def run(r):
+        try:
+            ab = None
+            if abort_rank is not None:
+                ab = np.zeros(1, np.uint8)
+                ab[0] = 1 if r == abort_rank else 0
+            bbs[r].solve_sharded(make_exchange(r), params, ab)
+        except BaseException as e:
+            errs.append(e)
+            bar.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(120)
+    assert not errs, errs
+    outs = [b.download() for b in bbs]
+    for b in bbs:
+        b.close()
+    for c in ctxs:
+        c.close()
+    return outs, stages
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ba_landmark_sharded_matches_single_rank(gpu_ctx, world):
+    """SURVEY 8e optional mode: points sharded over `world` ranks, Schur block all-gathered every trial.  Every rank must report
+    the same stats and poses; points / outlier flags of the ranks tile the full arrays; result == the unsharded GPU solve and the
+    oracle within the BA tolerance."""
+    import orbhip
+    import oracle_ba_bind as ob
+    import synth_ba
+    graphs = [synth_ba.make_graph(n_kf=14, n_pts=310, obs=7, seed=61, stereo_frac=0.3),
+              synth_ba.make_graph(n_kf=8, n_pts=101, obs=5, seed=62)]
+    outs, stages = _solve_sharded_in_process(0, graphs, world)
+    assert all(st == stages[0] for st in stages) and stages[0][-1] == 4 and stages[0].count(2) == stages[0].count(3)
+    bb = orbhip.BaBatch(gpu_ctx, graphs)
+    bb.solve()
+    poses1, points1, outl1, stats1 = bb.download()
+    bb.close()
+    for i, g in enumerate(graphs):
+        L, E = g["n_points"], g["n_edges"]
+        pts = np.array(g["points0"], np.float64).copy(); out = np.zeros(E, np.uint8)
+        for r in range(world):
+            poses_r, points_r, outl_r, stats_r = outs[r]
+            assert stats_r[i] == outs[0][3][i], (r, stats_r[i], outs[0][3][i])
+            np.testing.assert_array_equal(poses_r[i], outs[0][0][i])
+            p0, p1 = r * L // world, (r + 1) * L // world
+            pts[p0:p1] = points_r[i][p0:p1]
+            e_sel = (g["edge_point"] >= p0) & (g["edge_point"] < p1)
+            out[e_sel] = outl_r[i][e_sel]
+        st = outs[0][3][i]
+        assert st["iterations_run"] == stats1[i]["iterations_run"] and st["lm_trials"] == stats1[i]["lm_trials"], (st, stats1[i])
+        assert _rmse(outs[0][0][i], poses1[i]) < 1e-9 and _rmse(pts, points1[i]) < 1e-9
+        assert st["n_outliers"] == stats1[i]["n_outliers"] and int(np.sum(out != outl1[i])) == 0
+        rc, o_poses, o_pts, o_out, o_st = ob.solve(g, None)
+        assert _rmse(outs[0][0][i][:, 4:], o_poses[:, 4:]) <= TOL and _rmse(pts, o_pts) <= TOL
+
+
+def test_ba_landmark_sharded_abort_and_discard(gpu_ctx):
+    """The abort flag of ONE rank stops every rank at the same trial; the >= 50 % outlier rule uses the counts of all ranks."""
+    import synth_ba
+    g = synth_ba.make_graph(n_kf=8, n_pts=120, obs=5, seed=21, outlier_frac=0.9)
+    outs, stages = _solve_sharded_in_process(0, [g], 2)
+    assert all(o[3][0]["discarded"] == 1 for o in outs)
+    for o in outs:
+        np.testing.assert_array_equal(o[0][0], g["poses0"])
+    g2 = synth_ba.make_graph(n_kf=6, n_pts=40, obs=4, seed=3)
+    outs, stages = _solve_sharded_in_process(0, [g2], 2, abort_rank=1)
+    assert stages[0] == stages[1] and stages[0].count(3) == 1            # one trial, then both ranks stop
+    assert outs[0][3][0] == outs[1][3][0]
