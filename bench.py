@@ -141,6 +141,7 @@ def main():
     ap.add_argument("--nfeatures", type=int, default=1000)
     ap.add_argument("--ba-graphs", type=int, default=256, help="local-BA graphs solved concurrently per GPU (0 = skip BA leg)")
     ap.add_argument("--ba-steps", type=int, default=3)
+    ap.add_argument("--ba-sharded-graphs", type=int, default=0, help="N > 1 only, opt-in: graphs solved cooperatively with the points sharded over the ranks and the Schur block all-gathered every LM trial (SURVEY 8e optional mode)")
     ap.add_argument("--pose-frames", type=int, default=1024, help="frames of pose-only BA solved per launch (0 = skip)")
     ap.add_argument("--stereo-pairs", type=int, default=256, help="rectified stereo pairs for the ComputeStereoMatches leg (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -291,6 +292,43 @@ def main():
                            "flops_per_launch_without_sparsity_skipping": gemm_dense,
                            "note": "achieved = flops of the 16x16x4 MFMAs whose tiles hold data / hipEvent time; only tiles that hold data are issued (per-stage ballot hit maps)"}}
 
+    # ---- landmark-sharded single-graph mode (optional): the SAME graphs solved by all ranks together, the shared Schur
+    # block all-gathered every LM trial (RCCL over xGMI with backend nccl).  Latency-bound by design; reported, not hidden.
+    ba_sh = None
+    if world > 1 and args.ba_graphs > 0 and args.ba_sharded_graphs > 0:
+        try:
+            import shard
+            import synth_ba
+            gs = [synth_ba.make_graph(seed=9000 + i) for i in range(min(args.ba_sharded_graphs, 4))]
+            gl = [gs[i % len(gs)] for i in range(args.ba_sharded_graphs)]
+            sb = orbhip.BaBatch(ctx, gl, rank=rank, world=world)
+            stride = sb.exchange_doubles
+            xbuf = torch.zeros(world * stride, dtype=torch.float64, device="cuda")
+            sb.set_exchange_buffer(xbuf.data_ptr(), world * stride)
+            n_x = [0]
+            gather = shard.make_ba_exchange(xbuf, stride)
+
+            def xch(stage, count):
+                n_x[0] += 1
+                gather(stage, count)
+            sb.solve_sharded(xch)                        # warm-up
+            n_x[0] = 0
+            dist.barrier(); sync()
+            t0 = time.perf_counter()
+            sb.solve_sharded(xch)
+            sync(); dist.barrier()
+            dt_sh = time.perf_counter() - t0
+            t = torch.tensor([dt_sh], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            st_sh = sb.download()[3]
+            ba_sh = {"metric": "local-BA solves/sec, points sharded over all GPUs (one all-gather of the Schur block per LM trial)",
+                     "value": round(args.ba_sharded_graphs / float(t.item()), 2), "unit": "solves/s", "graphs": args.ba_sharded_graphs,
+                     "ranks": world, "all_gathers": n_x[0], "doubles_per_rank_and_gather": int(stride),
+                     "lm_trials_graph0": st_sh[0]["lm_trials"], "backend": backend}
+            sb.close()
+        except Exception as e:                           # never lose the main line to the optional leg
+            ba_sh = {"error": repr(e)[:300]}
+
     pose = None
     pose_probs = None
     if args.pose_frames > 0:
@@ -416,6 +454,8 @@ def main():
         }
         if ba is not None:
             out["ba"] = ba
+        if ba_sh is not None:
+            out["ba_sharded"] = ba_sh
         if pose is not None:
             out["pose_opt"] = pose
         if stereo is not None:

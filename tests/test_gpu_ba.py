@@ -297,3 +297,51 @@ def test_ba_landmark_sharded_abort_and_discard(gpu_ctx):
     outs, stages = _solve_sharded_in_process(0, [g2], 2, abort_rank=1)
     assert stages[0] == stages[1] and stages[0].count(3) == 1            # one trial, then both ranks stop
     assert outs[0][3][0] == outs[1][3][0]
+
+
+_SHARD_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, os.path.join(ROOT, "orb-slam3-mac_amd", "python"))
+import numpy as np, torch, torch.distributed as dist
+import orbhip, shard, synth_ba
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+torch.cuda.set_device(0)
+graphs = [synth_ba.make_graph(n_kf=12, n_pts=240, obs=6, seed=81), synth_ba.make_graph(n_kf=7, n_pts=90, obs=4, seed=82)]
+ctx = orbhip.Context(0)
+bb = orbhip.BaBatch(ctx, graphs, rank=rank, world=world)
+stride = bb.exchange_doubles
+xbuf = torch.zeros(world * stride, dtype=torch.float64, device="cuda")
+bb.set_exchange_buffer(xbuf.data_ptr(), world * stride)
+bb.solve_sharded(shard.make_ba_exchange(xbuf, stride))
+poses, points, outl, stats = bb.download()
+# the points of the other ranks: one all-gather of the owned slices
+full = []
+for i, g in enumerate(graphs):
+    L = g["n_points"]
+    parts = [None] * world
+    dist.all_gather_object(parts, points[i][rank * L // world:(rank + 1) * L // world])
+    full.append(np.concatenate(parts))
+if rank == 0:
+    single = orbhip.BaBatch(ctx, graphs); single.solve(); p1, q1, o1, s1 = single.download(); single.close()
+    for i in range(len(graphs)):
+        assert stats[i]["lm_trials"] == s1[i]["lm_trials"] and stats[i]["iterations_run"] == s1[i]["iterations_run"], (stats[i], s1[i])
+        assert np.sqrt(np.mean((poses[i] - p1[i]) ** 2)) < 1e-9 and np.sqrt(np.mean((full[i] - q1[i]) ** 2)) < 1e-9
+    print("SHARD_OK", json.dumps(stats[0]))
+bb.close(); ctx.close()
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_ba_landmark_sharded_two_processes_torch_distributed(tmp_path):
+    """Two processes (torch.distributed, gloo rendezvous on 127.0.0.1, both on this box's one GPU) run shard.make_ba_exchange --
+    the code path the multi-GPU bench leg uses with backend nccl (= RCCL)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "w.py"
+    script.write_text("ROOT = %r\n" % root + _SHARD_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29621", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29621", str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=400)
+    assert r.returncode == 0 and "SHARD_OK" in r.stdout, r.stdout[-3000:]
