@@ -279,6 +279,14 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt_ba = float(t.item())
         peak64 = orbhip.mfma_f64_peak_tflops(ctx)
+        ba_traffic, ba_traffic_src = None, None
+        try:     # HBM bytes per GEMM launch from the committed PMC passes (256-graph workload only)
+            if args.ba_graphs == 256:
+                pmc_ba = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_ba.json")))
+                ba_traffic = pmc_ba["kernels"]["k_ba_schur_gemm"]["hbm_bytes_per_launch"]
+                ba_traffic_src = "profiles/r01_pmc_traffic_ba.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)"
+        except Exception:
+            pass
         tfl = gemm_fl * gemm_n / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         ba = {"metric": "local-BA solves/sec", "value": round(world * args.ba_graphs * args.ba_steps / dt_ba, 2),
               "unit": "solves/s", "graphs_per_gpu": args.ba_graphs, "ms_per_batch": round(dt_ba / args.ba_steps * 1e3, 2),
@@ -286,7 +294,8 @@ def main():
               "lm_trials_graph0": stats[0]["lm_trials"], "dtype": "f64",
               "roofline": {"bound": "mfma", "kernel": "k_ba_schur_gemm", "achieved": round(tfl, 2),
                            "peak": round(peak64, 2), "unit": "TFLOP/s", "frac": round(tfl / peak64, 4) if peak64 else None,
-                           "traffic": None, "peak_source": "measured v_mfma_f64_16x16x4_f64 micro-benchmark on this device",
+                           "traffic": ba_traffic, "traffic_source": ba_traffic_src,
+                           "peak_source": "measured v_mfma_f64_16x16x4_f64 micro-benchmark on this device",
                            "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),
                            "mfma_flops_of_data_tiles_per_launch": gemm_fl, "mfma_flops_issued_per_launch": gemm_issued,
                            "flops_per_launch_without_sparsity_skipping": gemm_dense,
