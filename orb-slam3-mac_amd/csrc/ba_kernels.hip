@@ -714,6 +714,9 @@ __global__ __launch_bounds__(256) void k_ba_point_prep(BaBatch B)
 #define GEMM_LDS_PAD 16        // = 32 dwords mod 64
 #define GEMM_LDS_TAIL 32       // a short chunk reads up to GEMM_C-1 tiles past the end of a row (never multiplied)
 #define GEMM_STAGE_EDGES 85    // 6 column tasks per Hpl block, one task per thread
+#ifndef GEMM_TARGET_WGS
+#define GEMM_TARGET_WGS 256     // one resident workgroup per CU (VGPR-bound); more splits only add Spart traffic (512: -2 %)
+#endif
 #define GEMM_PANEL_LDS_BYTES (126 * 1024)   // of the CU's 160 KB: the rest holds the raw blocks, task descriptors, C^-1 rows, masks
 static_assert(GEMM_PS * GEMM_NCH <= 64 && GEMM_NCH * GEMM_C <= 32, "one lane per (stage point, chunk); one valid bit per tile");
 static_assert(6 * GEMM_STAGE_EDGES <= 64 * GEMM_WAVES && 6 * GEMM_PS <= 64 * GEMM_WAVES, "one column task per thread");
@@ -1520,8 +1523,8 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
             if (npts) gstage.push_back(make_int4(pt0, npts, t0, ntask));
             D.n_stages = (int)gstage.size() - D.stage_off;
         }
-        // split the stages so that ~2 workgroups per CU are in flight
-        int ks = (512 + n_graphs * D.ngrp - 1) / (n_graphs * D.ngrp);
+        // split the stages so that every CU has a workgroup
+        int ks = (GEMM_TARGET_WGS + n_graphs * D.ngrp - 1) / (n_graphs * D.ngrp);
         ks = std::max(1, std::min(ks, std::max(1, D.n_stages / 4)));
         D.ks = ks;
         {   // static block-sparsity masks: 16-column tiles of the point's Hpl column that hold a non-zero block
