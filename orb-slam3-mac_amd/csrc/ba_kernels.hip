@@ -77,6 +77,8 @@ struct BaBatch {      // kernel argument (by value)
     const int *pt_start;        // per graph n_points+1
     const int *pose_start;      // per graph nf+1  (free poses only, by hessian index)
     const int *pose_edges;      // [sumE'] edge ids (graph-local) grouped by free pose
+    // static edge data once more in that pose-major order, so that k_ba_build_poses streams it (only the point is a gather)
+    const int *pm_point, *pm_task; const uint8_t *pm_type; const double *pm_is2, *pm_obs;
     // estimates, double buffered: buffer b at poses + b*sumP*7
     double *poses, *points;
     int sumP, sumL, sumE, sumF;
@@ -570,27 +572,27 @@ __global__ __launch_bounds__(64) void k_ba_build_poses(BaBatch B)
     const int *pe = B.pose_edges + G.edge_off;
     double acc[27];
     for (int i = 0; i < 27; i++) acc[i] = 0;
+    // every edge of this list has the same pose; the edge's error / chi2 are recomputed from the pose-major copy of its static data
+    // (bit-identical to k_ba_errors: same inputs, same code) instead of being gathered from the point-major arrays
+    const double *pose = B.poses + ((size_t)st.cur * B.sumP + G.pose_off + (qs[h] < qs[h + 1] ? B.edge_pose[G.edge_off + pe[qs[h]]] : 0)) * 7;
     for (int k = qs[h] + lane; k < qs[h + 1]; k += 64) {
-        const int e = pe[k];
-        const int ge = G.edge_off + e;
-        const double *pose = B.poses + ((size_t)st.cur * B.sumP + G.pose_off + B.edge_pose[ge]) * 7;
-        const double *X = B.points + ((size_t)st.cur * B.sumL + G.point_off + B.edge_point[ge]) * 3;
-        const int type = B.edge_stereo[ge], stereo = type == 1;
+        const size_t gk = (size_t)G.edge_off + k;
+        const double *X = B.points + ((size_t)st.cur * B.sumL + G.point_off + B.pm_point[gk]) * 3;
+        const int type = B.pm_type[gk], stereo = type == 1;
         const int D = stereo ? 3 : 2;
-        double P[3], R[9], Jx[9], Jt[18];
-        if (type == 2) tobody_jacobians(G, pose, X, Jx, Jt);
+        double P[3], R[9], Jx[9], Jt[18], es[3];
+        if (type == 2) { tobody_error(G, pose, X, B.pm_obs + 3 * gk, P, es); tobody_jacobians(G, pose, X, Jx, Jt); }
         else {
-            quat_rot(pose, X, P);
-            P[0] += pose[4]; P[1] += pose[5]; P[2] += pose[6];
+            edge_error(G, pose, X, B.pm_obs + 3 * gk, stereo, P, es);
             quat_to_R(pose, R);
             edge_jacobians(G, P, R, stereo, Jx, Jt);
         }
+        const double is2 = B.pm_is2[gk];
+        const double chi2 = (es[0] * es[0] + es[1] * es[1] + es[2] * es[2]) * is2;
         double r0, r1;
-        const double chi2 = B.chi2[ge];
         if (!st.robust) r1 = 1.;
         else if (stereo) huber(chi2, B.delta_s, B.dsqr_s, &r0, &r1); else huber(chi2, B.delta_m, B.dsqr_m, &r0, &r1);
-        const double w = B.level[ge] ? 0.0 : r1 * B.edge_is2[ge];
-        const double *es = B.err + 3 * (size_t)ge;
+        const double w = (B.ex2 && B.level[G.edge_off + pe[k]]) ? 0.0 : r1 * is2;      // levels exist only in the merge variant
         for (int d = 0; d < D; d++) {
             const double we = -w * es[d];
             int idx = 0;
@@ -919,10 +921,11 @@ __global__ __launch_bounds__(64) void k_ba_bschur(BaBatch B)
     const int *pe = B.pose_edges + G.edge_off;
     double acc[6] = {0, 0, 0, 0, 0, 0};
     for (int k = qs[h] + lane; k < qs[h + 1]; k += 64) {
-        if (B.edge_dup[G.edge_off + pe[k]]) continue;                      // one Hpl block per (point, pose)
-        const int l = B.edge_point[G.edge_off + pe[k]];
+        const int task = B.pm_task[(size_t)G.edge_off + k];                // pose-major copies: only the block and db are gathers
+        if (task < 0) continue;                                            // one Hpl block per (point, pose)
+        const int l = B.pm_point[(size_t)G.edge_off + k];
         const double *db = B.db + (size_t)(G.point_off + l) * 3;
-        const double *w = B.Wsp + (size_t)B.edge_task[G.edge_off + pe[k]] * 18;
+        const double *w = B.Wsp + (size_t)task * 18;
         for (int a = 0; a < 6; a++) acc[a] += w[a] * db[0] + w[6 + a] * db[1] + w[12 + a] * db[2];
     }
     for (int a = 0; a < 6; a++) {
@@ -1427,7 +1430,9 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
     std::vector<int> hidx, epose, epoint, ptstart, posestart, poseedges;
     std::vector<uint32_t> ptmask;
     std::vector<int4> gtask, gstage;
-    std::vector<int> etask;
+    std::vector<int> etask, pmpoint, pmtask;
+    std::vector<uint8_t> pmtype;
+    std::vector<double> pmis2, pmobs;
     std::vector<double> eobs, eis2;
     std::vector<uint8_t> est, edup;
     std::vector<int> enext;
@@ -1469,6 +1474,12 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
         for (int e = 0; e < H.n_edges; e++) { const int h = local_h[H.edge_pose[e]]; if (h >= 0) pel[fill[h]++] = e; }
         posestart.insert(posestart.end(), pc.begin(), pc.end());
         poseedges.insert(poseedges.end(), pel.begin(), pel.end());
+        for (int k = 0; k < H.n_edges; k++) {                     // pose-major copy of the static edge data (entries past pc[nf] unused)
+            const int e = k < pc[nf] ? pel[k] : 0;
+            pmpoint.push_back(H.n_edges ? H.edge_point[e] : 0); pmtype.push_back(H.n_edges && H.edge_stereo ? H.edge_stereo[e] : 0);
+            pmis2.push_back(H.n_edges ? H.edge_inv_sigma2[e] : 0.0);
+            for (int d = 0; d < 3; d++) pmobs.push_back(H.n_edges ? H.edge_obs[3 * e + d] : 0.0);
+        }
         {   // edge types: 0 mono, 1 stereo, 2 second camera (needs a rigid transform mTrl with a non-zero quaternion)
             bool any2 = false;
             for (int e = 0; e < H.n_edges && H.edge_stereo; e++) {
@@ -1522,6 +1533,12 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
             }
             if (npts) gstage.push_back(make_int4(pt0, npts, t0, ntask));
             D.n_stages = (int)gstage.size() - D.stage_off;
+        }
+        {   // pose-major copy of edge_task (k_ba_bschur)
+            const int *et = etask.data() + (etask.size() - H.n_edges);
+            const int *pl = poseedges.data() + (poseedges.size() - H.n_edges);
+            const int npm = posestart[posestart.size() - 1];
+            for (int k = 0; k < H.n_edges; k++) pmtask.push_back(k < npm ? et[pl[k]] : -1);
         }
         // split the stages so that every CU has a workgroup
         int ks = (GEMM_TARGET_WGS + n_graphs * D.ngrp - 1) / (n_graphs * D.ngrp);
@@ -1579,6 +1596,7 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
     UP(B.gd, b->gd); UP(B.hidx, hidx); UP(B.edge_pose, epose); UP(B.edge_point, epoint); UP(B.edge_obs, eobs);
     UP(B.edge_is2, eis2); UP(B.edge_stereo, est); UP(B.edge_dup, edup); UP(B.edge_next, enext); UP(B.pt_start, ptstart); UP(B.pose_start, posestart); UP(B.pose_edges, poseedges);
     UP(B.ptmask, ptmask); UP(B.gemm_task, gtask); UP(B.gemm_stage, gstage); UP(B.edge_task, etask); UP(B.x1_off, x1off); UP(B.x2_off, x2off);
+    UP(B.pm_point, pmpoint); UP(B.pm_task, pmtask); UP(B.pm_type, pmtype); UP(B.pm_is2, pmis2); UP(B.pm_obs, pmobs);
     AL(B.st, BaState, n_graphs);
     AL(B.poses, double, (size_t)2 * sumP * 7); AL(B.points, double, (size_t)2 * sumL * 3);
     AL(B.err, double, (size_t)sumE * 3); AL(B.chi2, double, sumE); AL(B.rho0, double, sumE);
