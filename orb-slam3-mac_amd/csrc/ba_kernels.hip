@@ -1032,16 +1032,21 @@ __global__ __launch_bounds__(1024) void k_ba_ldlt(BaBatch B)
         // trailing update S[i][k] -= sum_c L[i][c] d_c L[k][c]  (i >= k >= p0+nb), 4x4 register tiles
         const int m2 = m - nb;
         if (m2 > 0) {
-            const int T = (m2 + 3) >> 2;
-            for (int t = tid; t < T * T; t += nth) {
-                const int ti = t / T, tk = t - ti * T;
-                if (ti < tk) continue;
+            const int T = (m2 + 3) >> 2, ntri = T * (T + 1) / 2;
+            for (int t = tid; t < ntri; t += nth) {               // lower-triangular tiles only, evenly dealt (row ti, column tk <= ti)
+                int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+                while (ti * (ti + 1) / 2 > t) ti--;
+                while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
+                const int tk = t - ti * (ti + 1) / 2;
                 const int i0 = nb + 4 * ti, k0 = nb + 4 * tk;
-                double acc[4][4];
+                double acc[4][4], sv[4][4];
 #pragma unroll
                 for (int a = 0; a < 4; a++)
 #pragma unroll
-                    for (int b2 = 0; b2 < 4; b2++) acc[a][b2] = 0.0;
+                    for (int b2 = 0; b2 < 4; b2++) {               // the tile's current values: in flight while the products are formed
+                        acc[a][b2] = 0.0;
+                        sv[a][b2] = (i0 + a < m && k0 + b2 < m && i0 + a >= k0 + b2) ? S[(size_t)(p0 + i0 + a) * ld + p0 + k0 + b2] : 0.0;
+                    }
                 for (int c = 0; c < nb; c++) {
                     const double dc = dval[p0 + c];
                     double av[4], bv[4];
@@ -1060,7 +1065,7 @@ __global__ __launch_bounds__(1024) void k_ba_ldlt(BaBatch B)
 #pragma unroll
                     for (int b2 = 0; b2 < 4; b2++)
                         if (i0 + a < m && k0 + b2 < m && i0 + a >= k0 + b2)
-                            S[(size_t)(p0 + i0 + a) * ld + p0 + k0 + b2] -= acc[a][b2];
+                            S[(size_t)(p0 + i0 + a) * ld + p0 + k0 + b2] = sv[a][b2] - acc[a][b2];
             }
         }
         __syncthreads();
