@@ -956,6 +956,13 @@ size_t ba_ldlt_lds_bytes(int max_n) { return sizeof(double) * ((size_t)max_n * L
 //   l = a[jj] / d_jj;  a[kk] -= l * U[jj][kk]  (jj < kk <= min(r, nb-1));  a[jj] = l;  y_r -= l * y_jj.
 // DIAG: the caller is the single wave that owns rows 0..nb-1 (lane = row); it produces d_jj, U[jj][.] and the final y_jj as it goes
 // (lock-step execution orders the LDS traffic).  Otherwise U, d and y[0..nb) are complete and rows are independent.
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(u & 0xffffffffu), lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(u >> 32), lane);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 template <bool DIAG>
 __device__ __forceinline__ void ldlt_rows(double *P, double *U, double *dv, double *yv, int r, int nb, int *s_ok)
 {
@@ -974,13 +981,15 @@ __device__ __forceinline__ void ldlt_rows(double *P, double *U, double *dv, doub
             U[jj * LD_NB + r] = a[jj];                      // unscaled column jj (entry jj = the pivot)
             if (r == jj) yv[jj] = yr;                        // y_jj is final
         }
-        const double d = DIAG ? U[jj * LD_NB + jj] : dv[jj];
+        // DIAG: pivot and y_jj straight from lane jj's registers (no LDS round trip on the critical path)
+        const double d = DIAG ? readlane_f64(a[jj], jj) : dv[jj];
         if (DIAG) {
             if (d == 0.0 || !isfinite(d)) { ok = false; if (r == 0) *s_ok = 0; continue; }
             if (r == jj) dv[jj] = d;
         }
+        const double yj = DIAG ? readlane_f64(yr, jj) : yv[jj];
         const double l = a[jj] / d;
-        yr -= l * yv[jj];
+        yr -= l * yj;
 #pragma unroll
         for (int kk = jj + 1; kk < LD_NB; kk++) a[kk] -= l * U[jj * LD_NB + kk];
         if (!DIAG || r > jj) a[jj] = l;
