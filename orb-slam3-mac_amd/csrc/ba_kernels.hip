@@ -310,12 +310,13 @@ __device__ __forceinline__ double edge_depth(const BaGraphDev &g, const double *
 }
 
 // ------------------------------------------------------------------ edge math (B2, B3)
+template <bool KB = true>      // KB = false: Pinhole only (the KannalaBrandt8 branch and its registers compile away)
 __device__ __forceinline__ void edge_error(const BaGraphDev &g, const double *pose, const double *X, const double *obs,
                                            int stereo, double *P, double *err)
 {
     quat_rot(pose, X, P);
     P[0] += pose[4]; P[1] += pose[5]; P[2] += pose[6];
-    if (!stereo && g.cam_model == 1) {   // KannalaBrandt8::project, KannalaBrandt8.cpp:52-69; atan2f as the float rounding of the double atan2 (see oracle/ba_oracle.c)
+    if (KB && !stereo && g.cam_model == 1) {   // KannalaBrandt8::project, KannalaBrandt8.cpp:52-69; atan2f as the float rounding of the double atan2 (see oracle/ba_oracle.c)
         const double x2y2 = P[0] * P[0] + P[1] * P[1];
         const double theta = (double)(float)atan2((double)sqrtf((float)x2y2), (double)(float)P[2]);
         const double psi = (double)(float)atan2((double)(float)P[1], (double)(float)P[0]);
@@ -341,10 +342,11 @@ __device__ __forceinline__ void edge_error(const BaGraphDev &g, const double *po
 }
 
 // Jacobians at camera-frame point P with rotation R.  Jx: D x 3, Jt: D x 6 (row-major)
+template <bool KB = true>
 __device__ __forceinline__ void edge_jacobians(const BaGraphDev &g, const double *P, const double *R, int stereo, double *Jx, double *Jt)
 {
     const double x = P[0], y = P[1], z = P[2];
-    if (!stereo && g.cam_model == 1) {   // KannalaBrandt8::projectJac, KannalaBrandt8.cpp:166-195
+    if (KB && !stereo && g.cam_model == 1) {   // KannalaBrandt8::projectJac, KannalaBrandt8.cpp:166-195
         const double x2 = x * x, y2 = y * y, z2 = z * z, r2 = x2 + y2, r = sqrt(r2), r3 = r2 * r;
         const double theta = atan2(r, z);
         const double t2 = theta * theta, t3 = t2 * theta, t4 = t2 * t2, t5 = t4 * theta, t6 = t2 * t4, t7 = t6 * theta, t8 = t4 * t4, t9 = t8 * theta;
@@ -400,6 +402,8 @@ __device__ __forceinline__ void huber(double e, double delta, double dsqr, doubl
 // ------------------------------------------------------------------ kernels
 // which: 0 -> evaluate at the CURRENT estimate for graphs that need a (re)build;
 //        1 -> evaluate at the TRIAL estimate for every active graph.
+// GENERAL = false: every graph of the batch is Pinhole without second-camera edges and without twin edges (the usual local BA)
+template <bool GENERAL>
 __global__ __launch_bounds__(256) void k_ba_errors(BaBatch B, int which)
 {
     const int g = blockIdx.y;
@@ -415,8 +419,8 @@ __global__ __launch_bounds__(256) void k_ba_errors(BaBatch B, int which)
     const double *X = B.points + ((size_t)buf * B.sumL + G.point_off + B.edge_point[ge]) * 3;
     double P[3], er[3];
     const int type = B.edge_stereo[ge], stereo = type == 1;          // 0 mono, 1 stereo, 2 second camera (ToBody)
-    if (type == 2) tobody_error(G, pose, X, B.edge_obs + 3 * (size_t)ge, P, er);
-    else edge_error(G, pose, X, B.edge_obs + 3 * (size_t)ge, stereo, P, er);
+    if (GENERAL && type == 2) tobody_error(G, pose, X, B.edge_obs + 3 * (size_t)ge, P, er);
+    else edge_error<GENERAL>(G, pose, X, B.edge_obs + 3 * (size_t)ge, stereo, P, er);
     const double chi2 = (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * B.edge_is2[ge];
     double r0, r1;
     if (!st.robust) { r0 = chi2; r1 = 1.; }
@@ -458,6 +462,7 @@ __global__ __launch_bounds__(256) void k_ba_reduce(BaBatch B, int which)
 // Jacobians of a point's ~10 observations are evaluated side by side and their scattered Hpl writes are in flight
 // together; Hll / bl are reduced over the 16 lanes in a fixed (butterfly) order.
 // Hll (sym 6), bl, and the edge's Hpl block Wsp[e][6*b + a] = (J_T^T w Omega J_X)[a][b].
+template <bool GENERAL>
 __global__ __launch_bounds__(256) void k_ba_build_points(BaBatch B)
 {
     const int g = blockIdx.y;
@@ -482,12 +487,12 @@ __global__ __launch_bounds__(256) void k_ba_build_points(BaBatch B)
         for (int k = 6; k < 9; k++) Jx[k] = 0;
 #pragma unroll
         for (int k = 12; k < 18; k++) Jt[k] = 0;                                     // monocular edge: third row empty
-        if (type == 2) tobody_jacobians(G, pose, X, Jx, Jt);
+        if (GENERAL && type == 2) tobody_jacobians(G, pose, X, Jx, Jt);
         else {
             quat_rot(pose, X, P);
             P[0] += pose[4]; P[1] += pose[5]; P[2] += pose[6];
             quat_to_R(pose, R);
-            edge_jacobians(G, P, R, stereo, Jx, Jt);
+            edge_jacobians<GENERAL>(G, P, R, stereo, Jx, Jt);
         }
         const double chi2 = B.chi2[ge];
         double r0, r1;
@@ -503,7 +508,7 @@ __global__ __launch_bounds__(256) void k_ba_build_points(BaBatch B)
             acc[0] += j0 * w * j0; acc[1] += j0 * w * j1; acc[2] += j0 * w * j2;
             acc[3] += j1 * w * j1; acc[4] += j1 * w * j2; acc[5] += j2 * w * j2;
         }
-        if (hi >= 0 && !B.edge_dup[ge]) {
+        if (hi >= 0 && (!GENERAL || !B.edge_dup[ge])) {
             double Wb[18];
 #pragma unroll
             for (int bb = 0; bb < 3; bb++)
@@ -514,7 +519,7 @@ __global__ __launch_bounds__(256) void k_ba_build_points(BaBatch B)
                     for (int d = 0; d < 3; d++) h += Jt[6 * d + a] * w * Jx[3 * d + bb];
                     Wb[6 * bb + a] = h;
                 }
-            for (int e2 = B.edge_next[ge]; e2 >= 0; e2 = B.edge_next[G.edge_off + e2]) {      // the same keyframe's other camera (rare)
+            for (int e2 = GENERAL ? B.edge_next[ge] : -1; e2 >= 0; e2 = B.edge_next[G.edge_off + e2]) {      // the same keyframe's other camera (rare)
                 const int g2 = G.edge_off + e2;
                 const int type2 = B.edge_stereo[g2], st2 = type2 == 1;
                 double P2[3], R2[9], Jx2[9], Jt2[18];
@@ -559,6 +564,7 @@ __global__ __launch_bounds__(256) void k_ba_build_points(BaBatch B)
 }
 
 // buildSystem, pose side: one wave per free pose over its edges (pose-major list).
+template <bool GENERAL>
 __global__ __launch_bounds__(64) void k_ba_build_poses(BaBatch B)
 {
     const int g = blockIdx.y;
@@ -579,13 +585,14 @@ __global__ __launch_bounds__(64) void k_ba_build_poses(BaBatch B)
         const size_t gk = (size_t)G.edge_off + k;
         const double *X = B.points + ((size_t)st.cur * B.sumL + G.point_off + B.pm_point[gk]) * 3;
         const int type = B.pm_type[gk], stereo = type == 1;
-        const int D = stereo ? 3 : 2;
         double P[3], R[9], Jx[9], Jt[18], es[3];
-        if (type == 2) { tobody_error(G, pose, X, B.pm_obs + 3 * gk, P, es); tobody_jacobians(G, pose, X, Jx, Jt); }
+#pragma unroll
+        for (int q = 12; q < 18; q++) Jt[q] = 0;                  // monocular edge: third row empty (the loops below run all 3 rows)
+        if (GENERAL && type == 2) { tobody_error(G, pose, X, B.pm_obs + 3 * gk, P, es); tobody_jacobians(G, pose, X, Jx, Jt); }
         else {
-            edge_error(G, pose, X, B.pm_obs + 3 * gk, stereo, P, es);
+            edge_error<GENERAL>(G, pose, X, B.pm_obs + 3 * gk, stereo, P, es);
             quat_to_R(pose, R);
-            edge_jacobians(G, P, R, stereo, Jx, Jt);
+            edge_jacobians<GENERAL>(G, P, R, stereo, Jx, Jt);
         }
         const double is2 = B.pm_is2[gk];
         const double chi2 = (es[0] * es[0] + es[1] * es[1] + es[2] * es[2]) * is2;
@@ -593,12 +600,15 @@ __global__ __launch_bounds__(64) void k_ba_build_poses(BaBatch B)
         if (!st.robust) r1 = 1.;
         else if (stereo) huber(chi2, B.delta_s, B.dsqr_s, &r0, &r1); else huber(chi2, B.delta_m, B.dsqr_m, &r0, &r1);
         const double w = (B.ex2 && B.level[G.edge_off + pe[k]]) ? 0.0 : r1 * is2;      // levels exist only in the merge variant
-        for (int d = 0; d < D; d++) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) {                             // compile-time indices: acc stays in registers
             const double we = -w * es[d];
             int idx = 0;
+#pragma unroll
             for (int a = 0; a < 6; a++) {
                 const double ja = Jt[6 * d + a];
                 acc[21 + a] += ja * we;
+#pragma unroll
                 for (int bb = a; bb < 6; bb++) acc[idx++] += ja * w * Jt[6 * d + bb];
             }
         }
@@ -1380,6 +1390,7 @@ struct orbhip_ba_batch {
     double gemm_flops_dense;                 // what the same upper tiles would cost without block-sparsity skipping
     double gemm_flops_issued;                // MFMA flops issued by one launch (every tile of a chunk whose row tile and one column tile the point touches)
     // landmark-sharded batches: the slice of every full graph this rank owns
+    bool general;                            // some graph needs KannalaBrandt8, second-camera edges or twin-edge chains
     struct Slice { int pt0, npts, e0, ne; };
     std::vector<Slice> slices;
     size_t x_need;                           // doubles per rank slot of the exchange buffer
@@ -1439,6 +1450,7 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
     BaBatch &B = b->B;
     memset(&B, 0, sizeof(B));
     B.G = n_graphs; B.rank = rank; B.world = world;
+    b->general = false;
     std::vector<int> x1off, x2off;
     size_t x1 = 0, x2 = 0;
     std::vector<int> hidx, epose, epoint, ptstart, posestart, poseedges;
@@ -1514,6 +1526,8 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
                 e0 = e1;
             }
             edup.insert(edup.end(), dup.begin(), dup.end()); enext.insert(enext.end(), nxt.begin(), nxt.end());
+            for (int e = 0; e < H.n_edges; e++) if (dup[e] || (H.edge_stereo && H.edge_stereo[e] == 2)) b->general = true;
+            if (H.camera_model != 0) b->general = true;
         }
         for (int e = 0; e < H.n_edges; e++) {
             epose.push_back(H.edge_pose[e]); epoint.push_back(H.edge_point[e]);
@@ -1731,10 +1745,11 @@ static int ba_solve_impl(orbhip_ba_batch *b, const orbhip_ba_params *params, vol
     for (; tick < max_ticks && n_active > 0; tick++) {
         const int ab = (abort_flag && *abort_flag) ? 1 : 0;
         if (B.ex2) hipLaunchKernelGGL(k_ba_levels, ge, dim3(256), 0, s, B);
-        hipLaunchKernelGGL(k_ba_errors, ge, dim3(256), 0, s, B, 0);
+        if (b->general) hipLaunchKernelGGL(k_ba_errors<true>, ge, dim3(256), 0, s, B, 0); else hipLaunchKernelGGL(k_ba_errors<false>, ge, dim3(256), 0, s, B, 0);
         hipLaunchKernelGGL(k_ba_reduce, dim3(G), dim3(256), 0, s, B, 0);
-        hipLaunchKernelGGL(k_ba_build_points, dim3((B.max_points + 15) / 16, G), dim3(256), 0, s, B);
-        hipLaunchKernelGGL(k_ba_build_poses, gf, dim3(64), 0, s, B);
+        if (b->general) hipLaunchKernelGGL(k_ba_build_points<true>, dim3((B.max_points + 15) / 16, G), dim3(256), 0, s, B);
+        else hipLaunchKernelGGL(k_ba_build_points<false>, dim3((B.max_points + 15) / 16, G), dim3(256), 0, s, B);
+        if (b->general) hipLaunchKernelGGL(k_ba_build_poses<true>, gf, dim3(64), 0, s, B); else hipLaunchKernelGGL(k_ba_build_poses<false>, gf, dim3(64), 0, s, B);
         hipLaunchKernelGGL(k_ba_maxdiag, dim3(G), dim3(256), 0, s, B);
         if (sharded) {                                           // exchange 1: Hpp, bp, chi2, max |Hll diag|
             hipLaunchKernelGGL(k_ba_shard_pack1, dim3(G), dim3(256), 0, s, B);
@@ -1756,7 +1771,7 @@ static int ba_solve_impl(orbhip_ba_batch *b, const orbhip_ba_params *params, vol
         hipLaunchKernelGGL(k_ba_ldlt, dim3(G), dim3(1024), ldlt_lds, s, B);
         hipLaunchKernelGGL(k_ba_backsub_points, dim3((B.max_points + 15) / 16, G), dim3(256), 0, s, B);
         hipLaunchKernelGGL(k_ba_update_poses, dim3((max_poses + 63) / 64, G), dim3(64), 0, s, B);
-        hipLaunchKernelGGL(k_ba_errors, ge, dim3(256), 0, s, B, 1);
+        if (b->general) hipLaunchKernelGGL(k_ba_errors<true>, ge, dim3(256), 0, s, B, 1); else hipLaunchKernelGGL(k_ba_errors<false>, ge, dim3(256), 0, s, B, 1);
         hipLaunchKernelGGL(k_ba_reduce, dim3(G), dim3(256), 0, s, B, 1);
         if (sharded) {                                           // exchange 3: trial chi2, computeScale, abort flag
             hipLaunchKernelGGL(k_ba_shard_pack34, dim3((G + 63) / 64), dim3(64), 0, s, B, 3, ab);
