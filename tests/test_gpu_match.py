@@ -598,3 +598,29 @@ def test_frame_glue_parity(gpu_ctx):
         rcs, rit = om.assign_features_to_grid(un[f, :n], bounds)
         np.testing.assert_array_equal(cs[f], rcs)
         np.testing.assert_array_equal(it[f, :len(rit)], rit)
+
+
+@pytest.mark.gpu
+def test_windowed_matchers_random_sizes(gpu_ctx):
+    """Randomised sizes (odd counts, one-off-capacity, tiny / empty sides) through the claim-rule matcher, the all-pairs matcher and
+    the BoW matcher: bit-exact vs the oracle for every pair of 3 x 12 random cases."""
+    import oracle_match_bind as om
+    from test_oracle_match_ba import make_sbp_case
+    rng = np.random.default_rng(2024)
+    bounds = (0.0, 0.0, 640.0, 480.0)
+    sizes = [0, 1, 2, 7, 63, 64, 65, 127, 511, 1000, 2047, 2048]
+    for rep in range(3):
+        ns = rng.permutation(sizes); nqs = rng.permutation(sizes)
+        stereo = bool(rep & 1)
+        cases = [make_sbp_case(rng, int(n), int(nq), stereo) for n, nq in zip(ns, nqs)]
+        got = _sbp(gpu_ctx, cases, 2048, 2048, bounds, 100, True, stereo)
+        for p, (q, dq, kp, d, ur, tm) in enumerate(cases):
+            n_ref, tm_ref = om.search_by_projection(q, dq, kp, d, ur if stereo else None, bounds, tm, 100, True)
+            assert got[p][0] == n_ref, (rep, p, ns[p], nqs[p])
+            np.testing.assert_array_equal(got[p][1], tm_ref)
+        # all-pairs 2-NN on the same descriptor sets
+        da = [c[1] for c in cases]; db = [c[3] for c in cases]
+        res = _bf(gpu_ctx, da, db, 2048, 0.7)
+        for p in range(len(cases)):
+            i2, d2, ac = om.bf2nn(da[p], db[p], 0.7)
+            np.testing.assert_array_equal(res[p][0], i2); np.testing.assert_array_equal(res[p][1], d2); np.testing.assert_array_equal(res[p][2], ac)
