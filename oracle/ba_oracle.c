@@ -39,6 +39,15 @@ void orc_ba_merge_params(orc_ba_params *p)
     p->stage2_exclude_outliers = 1; p->stage2_drop_robust = 1; p->no_discard = 1;
 }
 
+/* Optimizer::BundleAdjustment, Optimizer.cc:62-330: one optimize(nIterations) (:284), sqrt(5.99) / sqrt(7.815) (:133-134) */
+void orc_ba_global_params(orc_ba_params *p, int iterations, int robust)
+{
+    orc_ba_default_params(p);
+    p->iters1 = iterations; p->iters2 = 0; p->no_discard = 1;
+    p->huber_mono2 = robust ? 5.99 : 1e300; p->huber_stereo2 = robust ? 7.815 : 1e300;
+    p->gate_mono2 = 5.991; p->gate_stereo2 = 7.815;
+}
+
 /* ---------------------------------------------------------------- quaternion / SE3 (B1) */
 static void quat_to_R(const double q[4], double R[9])   /* Eigen::Quaterniond::toRotationMatrix */
 {

@@ -54,7 +54,9 @@ typedef struct {
 } orc_ba_stats;
 
 void orc_ba_default_params(orc_ba_params *p);
-void orc_ba_merge_params(orc_ba_params *p);   /* Optimizer::LocalBundleAdjustment(pMainKF, vpAdjustKF, vpFixedKF, pbStopFlag) */
+void orc_ba_merge_params(orc_ba_params *p);
+/* Optimizer::BundleAdjustment / GlobalBundleAdjustemnt (src/Optimizer.cc:54-330): one pass, no outlier stage */
+void orc_ba_global_params(orc_ba_params *p, int iterations, int robust);   /* Optimizer::LocalBundleAdjustment(pMainKF, vpAdjustKF, vpFixedKF, pbStopFlag) */
 /* Returns 0 ok, -5 aborted before start.  poses [n_poses*7] (qx,qy,qz,qw,tx,ty,tz), points [n_points*3]. */
 int orc_ba_solve(const orc_ba_graph *g, const orc_ba_params *p, const volatile uint8_t *abort_flag,
                  double *poses, double *points, uint8_t *edge_outlier, orc_ba_stats *stats);

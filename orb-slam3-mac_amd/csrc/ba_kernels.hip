@@ -1427,6 +1427,16 @@ extern "C" void orbhip_ba_merge_params(orbhip_ba_params *p)
     p->stage2_exclude_outliers = 1; p->stage2_drop_robust = 1; p->no_discard = 1;
 }
 
+// Optimizer::BundleAdjustment(vpKFs, vpMP, nIterations, pbStopFlag, nLoopKF, bRobust), Optimizer.cc:62-330: ONE optimize(nIterations),
+// thHuber2D = sqrt(5.99) / thHuber3D = sqrt(7.815) (:133-134) when bRobust, no outlier stage, results always written back
+extern "C" void orbhip_ba_global_params(orbhip_ba_params *p, int iterations, int robust)
+{
+    orbhip_ba_default_params(p);
+    p->iters1 = iterations; p->iters2 = 0; p->no_discard = 1;
+    p->huber_mono2 = robust ? 5.99 : 1e300; p->huber_stereo2 = robust ? 7.815 : 1e300;     // delta -> inf: rho(x) = x, no kernel
+    p->gate_mono2 = 5.991; p->gate_stereo2 = 7.815;                                          // informational outlier flags only
+}
+
 extern "C" void orbhip_ba_batch_destroy(orbhip_ba_batch *b)
 {
     if (!b) return;

@@ -349,6 +349,13 @@ def ba_merge_params():
     return p
 
 
+def ba_global_params(iterations, robust=True):
+    """Optimizer::BundleAdjustment / GlobalBundleAdjustemnt parameters (one optimize(iterations) pass)."""
+    p = BaParams()
+    lib.orbhip_ba_global_params(C.byref(p), iterations, 1 if robust else 0)
+    return p
+
+
 def ba_default_params():
     p = BaParams()
     lib.orbhip_ba_default_params(C.byref(p))

@@ -61,6 +61,12 @@ def merge_params():
     return p
 
 
+def global_params(iterations, robust=True):
+    p = Params()
+    lib.orc_ba_global_params(C.byref(p), iterations, 1 if robust else 0)
+    return p
+
+
 def make_cgraph(g, cls=Graph):
     """g: dict from synth_ba.make_graph.  Returns (struct, keepalive list)."""
     keep = [np.ascontiguousarray(g["pose_fixed"], np.uint8), np.ascontiguousarray(g["edge_pose"], np.int32),

@@ -345,3 +345,35 @@ def test_ba_landmark_sharded_two_processes_torch_distributed(tmp_path):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                         "--master-port", "29621", str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=400)
     assert r.returncode == 0 and "SHARD_OK" in r.stdout, r.stdout[-3000:]
+
+
+@pytest.mark.parametrize("robust", [True, False])
+def test_ba_global_bundle_adjustment_params(gpu_ctx, robust):
+    """Optimizer::BundleAdjustment (Optimizer.cc:62-330): one optimize(N) pass, only the first keyframe fixed, optional robust
+    kernel, no outlier stage / bail-out -- the same solver under orbhip_ba_global_params, checked against the oracle."""
+    import orbhip
+    import oracle_ba_bind as ob
+    import synth_ba
+    # one fixed keyframe: stereo observations pin the scale, so the problem is well posed and trajectories must agree
+    graphs = [synth_ba.make_graph(n_kf=25, n_pts=400, obs=8, seed=102, n_fixed=1, outlier_frac=0.04, stereo_frac=0.3),
+              synth_ba.make_graph(n_kf=9, n_pts=150, obs=5, seed=103, n_fixed=1, outlier_frac=0.0, stereo_frac=1.0)]
+    # monocular map initialisation (2 keyframes, one fixed): the scale is a free gauge, the reduced system is singular along it and
+    # any two implementations wander differently along that direction -- only the cost is comparable
+    ginit = synth_ba.make_graph(n_kf=2, n_pts=120, obs=2, seed=101, n_fixed=1, outlier_frac=0.0)
+    p = orbhip.ba_global_params(20 if robust else 10, robust)
+    bb = orbhip.BaBatch(gpu_ctx, graphs + [ginit])
+    bb.solve(p)
+    poses, points, outl, stats = bb.download()
+    bb.close()
+    for i, g in enumerate(graphs):
+        rc, o_poses, o_pts, o_out, o_st = ob.solve(g, ob.global_params(20 if robust else 10, robust))
+        assert stats[i]["discarded"] == 0 and o_st["discarded"] == 0
+        assert stats[i]["iterations_run"] == o_st["iterations_run"] and stats[i]["iterations_run"][1] == 0, (stats[i], o_st)
+        assert stats[i]["lm_trials"] == o_st["lm_trials"]
+        assert _rmse(poses[i], o_poses) <= TOL and _rmse(points[i], o_pts) <= TOL
+        assert abs(stats[i]["chi2_final"] - o_st["chi2_final"]) <= 1e-6 * abs(o_st["chi2_final"])
+    rc, o_poses, o_pts, o_out, o_st = ob.solve(ginit, ob.global_params(20 if robust else 10, robust))
+    st = stats[len(graphs)]
+    assert st["discarded"] == 0 and st["iterations_run"][1] == 0
+    assert np.isfinite(st["chi2_final"]) and st["chi2_final"] < st["chi2_initial"] and o_st["chi2_final"] < o_st["chi2_initial"]
+    assert np.all(np.isfinite(poses[len(graphs)])) and np.all(np.isfinite(points[len(graphs)]))
