@@ -308,6 +308,20 @@ int orbhip_assign_features_to_grid_device(orbhip_ctx *ctx, const orbhip_keypoint
                                           size_t frame_stride_kp, float min_x, float min_y, float max_x, float max_y,
                                           int32_t *d_cell_start, int32_t *d_items);
 
+/* Second half of Frame::ComputeBoW (src/Frame.cc:729-736): TemplatedVocabulary::transform(features, mBowVec, mFeatVec, 4)
+ * (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1139-1208, TF_IDF weighting + L1 norm as in ORBvoc) from the per-feature
+ * (word id, weight, node id) of orbhip_bow_transform_device, batched over frames:
+ *   mFeatVec as the CSR the SearchByBoW / SearchForTriangulation kernels read: d_node_ids [frames][max_nodes] ascending,
+ *     d_node_start [frames][max_nodes+1] into d_feat [frames][max_n] (feature indices in feature order), d_nnodes [frames];
+ *   mBowVec as d_bow_word / d_bow_value [frames][max_n] (ascending word ids, L1-normalised sums), d_nwords [frames].
+ * Features whose word has weight <= 0 ("stopped") are in neither.  std::map order, BowVector::addWeight's accumulation order and
+ * BowVector::normalize's summation order (BowVector.cpp) are reproduced, so the values are bit-identical to DBoW2's.
+ * max_n <= 4096.  All pointers DEVICE. */
+int orbhip_bow_vectors_device(orbhip_ctx *ctx, const int32_t *d_word_id, const double *d_weight, const int32_t *d_node_id,
+                              const int32_t *d_n, int frames, int max_n, int max_nodes,
+                              int32_t *d_node_ids, int32_t *d_node_start, int32_t *d_feat, int32_t *d_nnodes,
+                              int32_t *d_bow_word, double *d_bow_value, int32_t *d_nwords);
+
 /* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:327-403), batched over map points: point p
  * has d_n[p] observing descriptors at d_desc + p*max_n*32 (the loop of :347-361 packs them, left then right index);
  * d_best_idx[p] = BestIdx: the descriptor with the least median Hamming distance to all of them (median = sorted

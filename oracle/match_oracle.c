@@ -617,3 +617,48 @@ void orc_undistort_keypoints(const orc_keypoint *kp, int n, float fx_, float fy_
         out[i].x = (float)(xx * ww); out[i].y = (float)(yy * ww);
     }
 }
+
+/* TemplatedVocabulary::transform(features, v, fv, levelsup), TemplatedVocabulary.h:1139-1208 (TF_IDF, L1) after the per-feature
+ * tree descent: std::map semantics restated with sorted arrays. */
+void orc_bow_vectors(const int32_t *wid, const double *w, const int32_t *nid, int n,
+                     int32_t *node_ids, int32_t *node_start, int32_t *feat, int32_t *nnodes,
+                     int32_t *bow_word, double *bow_value, int32_t *nwords)
+{
+    int nn = 0, nw = 0;
+    /* FeatureVector: map<NodeId, vector<i_feature>>; BowVector: map<WordId, double> */
+    int32_t *fv_cnt = (int32_t *)calloc(n ? n : 1, sizeof(int32_t));
+    int32_t **fv_list = (int32_t **)calloc(n ? n : 1, sizeof(int32_t *));
+    for (int i = 0; i < n; i++) {
+        if (!(w[i] > 0)) continue;                                  /* :1170 not stopped */
+        {   /* v.addWeight(id, w), BowVector.cpp */
+            int lo = 0;
+            while (lo < nw && bow_word[lo] < wid[i]) lo++;
+            if (lo < nw && bow_word[lo] == wid[i]) bow_value[lo] += w[i];
+            else {
+                for (int k = nw; k > lo; k--) { bow_word[k] = bow_word[k - 1]; bow_value[k] = bow_value[k - 1]; }
+                bow_word[lo] = wid[i]; bow_value[lo] = w[i]; nw++;
+            }
+        }
+        {   /* fv.addFeature(nid, i_feature), FeatureVector.cpp */
+            int lo = 0;
+            while (lo < nn && node_ids[lo] < nid[i]) lo++;
+            if (!(lo < nn && node_ids[lo] == nid[i])) {
+                for (int k = nn; k > lo; k--) { node_ids[k] = node_ids[k - 1]; fv_cnt[k] = fv_cnt[k - 1]; fv_list[k] = fv_list[k - 1]; }
+                node_ids[lo] = nid[i]; fv_cnt[lo] = 0; fv_list[lo] = (int32_t *)malloc(sizeof(int32_t) * n); nn++;
+            }
+            fv_list[lo][fv_cnt[lo]++] = i;
+        }
+    }
+    double norm = 0.0;                                              /* v.normalize(L1), BowVector.cpp */
+    for (int k = 0; k < nw; k++) norm += fabs(bow_value[k]);
+    if (norm > 0.0) for (int k = 0; k < nw; k++) bow_value[k] /= norm;
+    int pos = 0;
+    for (int k = 0; k < nn; k++) {
+        node_start[k] = pos;
+        for (int j = 0; j < fv_cnt[k]; j++) feat[pos++] = fv_list[k][j];
+        free(fv_list[k]);
+    }
+    node_start[nn] = pos;
+    *nnodes = nn; *nwords = nw;
+    free(fv_list); free(fv_cnt);
+}

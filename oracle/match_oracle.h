@@ -116,6 +116,11 @@ void orc_assign_features_to_grid(const orc_keypoint *kp, int n, float min_x, flo
  * dist = (k1, k2, p1, p2[, k3]); a zero k1 copies (Frame.cc:740-744). */
 void orc_undistort_keypoints(const orc_keypoint *kp, int n, float fx, float fy, float cx, float cy, const float *dist, int ndist,
                              orc_keypoint *out);
+/* BowVector / FeatureVector assembly of TemplatedVocabulary::transform (TemplatedVocabulary.h:1139-1208; TF_IDF + L1) from the
+ * per-feature (word, weight, node) of orc_bow_transform.  Arrays sized n (node_start n+1). */
+void orc_bow_vectors(const int32_t *wid, const double *w, const int32_t *nid, int n,
+                     int32_t *node_ids, int32_t *node_start, int32_t *feat, int32_t *nnodes,
+                     int32_t *bow_word, double *bow_value, int32_t *nwords);
 /* MapPoint::ComputeDistinctiveDescriptors (/root/reference/src/MapPoint.cc:327-403): among the n
  * descriptors that observe a map point, the one with the least median Hamming distance to all of them
  * (median = sorted row [int(0.5*(n-1))], self distance 0 included; first minimum wins).  Returns BestIdx (0 if n<=0). */

@@ -1252,3 +1252,137 @@ extern "C" int orbhip_assign_features_to_grid_device(orbhip_ctx *ctx, const orbh
                        min_y, inv_w, inv_h, cap_n, d_cell_start, d_items, orbhip_ctx_status_internal(ctx));
     return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
 }
+
+// ---------------------------------------------------------------------------- BowVector / FeatureVector assembly
+// Second half of TemplatedVocabulary::transform(features, v, fv, levelsup) (TemplatedVocabulary.h:1139-1208; TF_IDF weighting,
+// L1 norm: the ORBvoc settings): from the per-feature (word, weight, node) of k_bow_transform build, per frame,
+//   fv  = map<NodeId, vector<feature index>>  flattened as the CSR the SearchByBoW kernels read (nodes ascending, indices in feature order),
+//   v   = map<WordId, sum of weights>          as sorted (word, value) arrays, L1-normalised.
+// std::map order and accumulation order are reproduced exactly: keys (id << 16 | feature index) are sorted (bitonic, LDS), a word's
+// weights are added in feature order (BowVector::addWeight), the norm is the SEQUENTIAL sum over ascending words (BowVector::normalize).
+#define BV_THREADS 256
+__device__ void bv_bitonic_sort(unsigned long long *k, int np2, int tid)
+{
+    for (int size = 2; size <= np2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = tid; t < (np2 >> 1); t += BV_THREADS) {
+                const int lo = ((t / stride) * (stride << 1)) + (t % stride), hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const unsigned long long a = k[lo], b = k[hi];
+                if ((a > b) == up) { k[lo] = b; k[hi] = a; }
+            }
+        }
+    __syncthreads();
+}
+__global__ __launch_bounds__(BV_THREADS) void k_bow_vectors(const int32_t *wid_, const double *w_, const int32_t *nid_, const int32_t *n_, int max_n,
+                                                            int cap_n, int max_nodes, int32_t *node_ids_, int32_t *node_start_, int32_t *feat_,
+                                                            int32_t *nnodes_, int32_t *word_ids_, double *word_val_, int32_t *nwords_, int32_t *status)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t bv_lds[];
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(bv_lds);      // [cap_n] (power of two)
+    int32_t *head = reinterpret_cast<int32_t *>(keys + cap_n);                         // [cap_n] 1 where a new id starts / exclusive scan
+    __shared__ int s_cnt, s_scan[BV_THREADS];
+    __shared__ double s_norm;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int n = n_[f];
+    const int32_t *wid = wid_ + (size_t)f * max_n, *nid = nid_ + (size_t)f * max_n;
+    const double *w = w_ + (size_t)f * max_n;
+    int32_t *node_ids = node_ids_ + (size_t)f * max_nodes, *node_start = node_start_ + (size_t)f * (max_nodes + 1), *feat = feat_ + (size_t)f * max_n;
+    int32_t *word_ids = word_ids_ + (size_t)f * max_n;
+    double *word_val = word_val_ + (size_t)f * max_n;
+    if (n > cap_n || n > max_n) {
+        if (tid == 0) { atomicExch(status, ORBHIP_E_CAPACITY); nnodes_[f] = 0; nwords_[f] = 0; node_start[0] = 0; }
+        return;
+    }
+    for (int pass = 0; pass < 2; pass++) {                   // pass 0: nodes -> FeatureVector, pass 1: words -> BowVector
+        const int32_t *id = pass == 0 ? nid : wid;
+        for (int i = tid; i < cap_n; i += BV_THREADS)        // stopped words (w <= 0) sort to the end and are dropped
+            keys[i] = (i < n && w[i] > 0.0) ? (((unsigned long long)(uint32_t)id[i] << 16) | (unsigned)i) : ~0ull;
+        if (tid == 0) s_cnt = 0;
+        bv_bitonic_sort(keys, cap_n, tid);
+        // number of kept entries and segment heads
+        int mine = 0;
+        for (int i = tid; i < cap_n; i += BV_THREADS) {
+            const bool kept = keys[i] != ~0ull;
+            mine += kept;
+            head[i] = kept && (i == 0 || (keys[i] >> 16) != (keys[i - 1] >> 16)) ? 1 : 0;
+        }
+        atomicAdd(&s_cnt, mine);
+        __syncthreads();
+        const int m = s_cnt;
+        // exclusive scan of head[] in blocks of cap_n / BV_THREADS consecutive entries per thread
+        const int per = (cap_n + BV_THREADS - 1) / BV_THREADS, b0 = tid * per;
+        int loc = 0;
+        for (int i = b0; i < min(b0 + per, cap_n); i++) loc += head[i];
+        s_scan[tid] = loc;
+        __syncthreads();
+        if (tid == 0) { int run = 0; for (int t = 0; t < BV_THREADS; t++) { const int v = s_scan[t]; s_scan[t] = run; run += v; } s_cnt = run; }
+        __syncthreads();
+        const int nseg = s_cnt;
+        if (nseg > (pass == 0 ? max_nodes : max_n)) { if (tid == 0) atomicExch(status, ORBHIP_E_CAPACITY); }
+        int run = s_scan[tid];
+        for (int i = b0; i < min(b0 + per, cap_n); i++) {
+            if (i >= m) break;
+            const int seg = run + head[i] - 1;               // index of the segment entry i belongs to
+            if (head[i]) {
+                run++;
+                if (pass == 0) { if (seg < max_nodes) { node_ids[seg] = (int32_t)(keys[i] >> 16); node_start[seg] = i; } }
+                else if (seg < max_n) word_ids[seg] = (int32_t)(keys[i] >> 16);
+            }
+            if (pass == 0) feat[i] = (int32_t)(keys[i] & 0xFFFFu);
+            else head[i] = head[i] ? -(seg + 1) : 0;         // mark heads with their segment for the sums below
+        }
+        __syncthreads();
+        if (pass == 0) {
+            if (tid == 0) { nnodes_[f] = min(nseg, max_nodes); node_start[min(nseg, max_nodes)] = m; }
+        } else {
+            // a word's weights in feature order (addWeight), one thread per word
+            for (int i = tid; i < m; i += BV_THREADS) {
+                if (head[i] >= 0) continue;
+                const int seg = -head[i] - 1;
+                double acc = 0.0;
+                const unsigned long long wkey = keys[i] >> 16;
+                for (int j = i; j < m && (keys[j] >> 16) == wkey; j++) acc += w[(int)(keys[j] & 0xFFFFu)];
+                if (seg < max_n) word_val[seg] = acc;
+            }
+            __syncthreads();
+            __threadfence_block();
+            if (tid == 0) {                                   // BowVector::normalize(L1): sequential sum in ascending word order
+                const int nw = min(nseg, max_n);
+                double norm = 0.0;
+                for (int k2 = 0; k2 < nw; k2++) norm += fabs(word_val[k2]);
+                s_norm = norm;
+                nwords_[f] = nw;
+            }
+            __syncthreads();
+            if (s_norm > 0.0) {
+                const double norm = s_norm;
+                for (int k2 = tid; k2 < min(nseg, max_n); k2 += BV_THREADS) word_val[k2] /= norm;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int orbhip_bow_vectors_device(orbhip_ctx *ctx, const int32_t *d_word_id, const double *d_weight, const int32_t *d_node_id,
+                                         const int32_t *d_n, int frames, int max_n, int max_nodes,
+                                         int32_t *d_node_ids, int32_t *d_node_start, int32_t *d_feat, int32_t *d_nnodes,
+                                         int32_t *d_bow_word, double *d_bow_value, int32_t *d_nwords)
+{
+    if (!ctx || !d_word_id || !d_weight || !d_node_id || !d_n || frames <= 0 || max_n <= 0 || max_n > 4096 || max_nodes <= 0 || !d_node_ids ||
+        !d_node_start || !d_feat || !d_nnodes || !d_bow_word || !d_bow_value || !d_nwords) return ORBHIP_E_BADARG;
+    if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
+    int cap_n = 64;
+    while (cap_n < max_n) cap_n <<= 1;
+    const size_t lds = (size_t)cap_n * (8 + 4) + 16;
+    static thread_local size_t lds_set = 0;
+    if (lds > lds_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_bow_vectors), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return ORBHIP_E_HIP;
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(k_bow_vectors, dim3(frames), dim3(BV_THREADS), lds, orbhip_ctx_stream_internal(ctx), d_word_id, d_weight, d_node_id, d_n, max_n,
+                       cap_n, max_nodes, d_node_ids, d_node_start, d_feat, d_nnodes, d_bow_word, d_bow_value, d_nwords, orbhip_ctx_status_internal(ctx));
+    return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
+}

@@ -568,6 +568,16 @@ def assign_features_to_grid_device(ctx, d_kp, d_n, frames, max_n, kp_stride, bou
                                                    d_cell_start, d_items), "orbhip_assign_features_to_grid_device")
 
 
+lib.orbhip_bow_vectors_device.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]
+
+
+def bow_vectors_device(ctx, d_wid, d_w, d_nid, d_n, frames, max_n, max_nodes, d_node_ids, d_node_start, d_feat, d_nnodes, d_bow_word,
+                       d_bow_value, d_nwords):
+    """mFeatVec (CSR) and mBowVec (sorted, L1-normalised) from bow_transform_device's per-feature output."""
+    _chk(lib.orbhip_bow_vectors_device(ctx.h, d_wid, d_w, d_nid, d_n, frames, max_n, max_nodes, d_node_ids, d_node_start, d_feat, d_nnodes,
+                                       d_bow_word, d_bow_value, d_nwords), "orbhip_bow_vectors_device")
+
+
 TRI_PAIR_DTYPE = np.dtype([("F12", "<f4", (9,)), ("ep_x", "<f4"), ("ep_y", "<f4"), ("only_stereo", "<i4"), ("coarse", "<i4")])
 lib.orbhip_search_for_triangulation_device.argtypes = [vp] * 17 + [ci, ci, ci, sz, vp, vp, ci, ci, vp, vp]
 

@@ -319,3 +319,16 @@ def undistort_keypoints(kp, K, dist):
     out = np.zeros(max(len(kp), 1), KP_DTYPE)
     lib.orc_undistort_keypoints(kp.ctypes.data, len(kp), K[0], K[1], K[2], K[3], dc.ctypes.data, len(dc), out.ctypes.data)
     return out[:len(kp)]
+
+
+lib.orc_bow_vectors.argtypes = [vp, vp, vp, ci] + [vp] * 7
+
+
+def bow_vectors(wid, w, nid):
+    wid = np.ascontiguousarray(wid, np.int32); w = np.ascontiguousarray(w, np.float64); nid = np.ascontiguousarray(nid, np.int32)
+    n = len(wid); m = max(n, 1)
+    ni = np.zeros(m, np.int32); ns = np.zeros(m + 1, np.int32); ft = np.zeros(m, np.int32); nn = ci()
+    bw = np.zeros(m, np.int32); bv = np.zeros(m, np.float64); nw = ci()
+    lib.orc_bow_vectors(wid.ctypes.data, w.ctypes.data, nid.ctypes.data, n, ni.ctypes.data, ns.ctypes.data, ft.ctypes.data, C.byref(nn),
+                        bw.ctypes.data, bv.ctypes.data, C.byref(nw))
+    return ni[:nn.value], ns[:nn.value + 1], ft[:ns[nn.value]], bw[:nw.value], bv[:nw.value]

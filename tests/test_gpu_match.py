@@ -624,3 +624,38 @@ def test_windowed_matchers_random_sizes(gpu_ctx):
         for p in range(len(cases)):
             i2, d2, ac = om.bf2nn(da[p], db[p], 0.7)
             np.testing.assert_array_equal(res[p][0], i2); np.testing.assert_array_equal(res[p][1], d2); np.testing.assert_array_equal(res[p][2], ac)
+
+
+@pytest.mark.gpu
+def test_bow_vectors_parity(gpu_ctx):
+    """mFeatVec / mBowVec assembly on the device: bit-exact vs the oracle (node / word order, feature order inside a node, f64 sums
+    and the L1 normalisation), ragged frames incl. empty and all-stopped ones; the CSR it writes drives SearchByBoW unchanged."""
+    import torch
+    import orbhip
+    import oracle_match_bind as om
+    from test_oracle_match_ba import _bow_inputs
+    rng = np.random.default_rng(17)
+    ns = (0, 1, 50, 700, 2048, 4096, 333)
+    F, MN, MNODE = len(ns), 4096, 512
+    WID = np.zeros((F, MN), np.int32); W = np.zeros((F, MN), np.float64); NID = np.zeros((F, MN), np.int32)
+    cases = []
+    for f, n in enumerate(ns):
+        wid, w, nid = _bow_inputs(rng, n, n_words=900 if n > 1000 else 300, n_nodes=100 if n > 1000 else 40, stop_frac=1.0 if f == 6 else 0.1)
+        WID[f, :n] = wid; W[f, :n] = w; NID[f, :n] = nid; cases.append((wid, w, nid))
+    t = [torch.from_numpy(a).cuda() for a in (WID, W, NID, np.array(ns, np.int32))]
+    ni = torch.full((F, MNODE), -9, dtype=torch.int32, device="cuda"); st = torch.full((F, MNODE + 1), -9, dtype=torch.int32, device="cuda")
+    ft = torch.full((F, MN), -9, dtype=torch.int32, device="cuda"); nn = torch.full((F,), -9, dtype=torch.int32, device="cuda")
+    bw = torch.full((F, MN), -9, dtype=torch.int32, device="cuda"); bv = torch.zeros((F, MN), dtype=torch.float64, device="cuda")
+    nw = torch.full((F,), -9, dtype=torch.int32, device="cuda")
+    orbhip.bow_vectors_device(gpu_ctx, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), F, MN, MNODE, ni.data_ptr(), st.data_ptr(),
+                              ft.data_ptr(), nn.data_ptr(), bw.data_ptr(), bv.data_ptr(), nw.data_ptr())
+    gpu_ctx.check_status()
+    ni, st, ft, nn, bw, bv, nw = (x.cpu().numpy() for x in (ni, st, ft, nn, bw, bv, nw))
+    for f, (wid, w, nid) in enumerate(cases):
+        r_ni, r_ns, r_ft, r_bw, r_bv = om.bow_vectors(wid, w, nid)
+        assert nn[f] == len(r_ni) and nw[f] == len(r_bw), (f, nn[f], len(r_ni), nw[f], len(r_bw))
+        np.testing.assert_array_equal(ni[f, :nn[f]], r_ni); np.testing.assert_array_equal(st[f, :nn[f] + 1], r_ns)
+        np.testing.assert_array_equal(ft[f, :len(r_ft)], r_ft)
+        np.testing.assert_array_equal(bw[f, :nw[f]], r_bw)
+        assert bv[f, :nw[f]].tobytes() == r_bv.tobytes(), f
+    assert nw[6] == 0 and nn[6] == 0

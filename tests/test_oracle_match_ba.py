@@ -875,3 +875,35 @@ def test_assign_features_to_grid_oracle():
         assert cs[0] == 0 and cs[-1] == sum(len(v) for v in cells.values()) == len(it)
         for c in range(64 * 48):
             assert list(it[cs[c]:cs[c + 1]]) == cells.get(c, [])
+
+
+def _bow_inputs(rng, n, n_words=300, n_nodes=40, stop_frac=0.1):
+    wid = rng.integers(0, n_words, n).astype(np.int32) * 7 + 3
+    nid = (rng.integers(0, n_nodes, n) * 5 + 11).astype(np.int32)
+    w = rng.uniform(0.1, 9.0, n)
+    w[rng.random(n) < stop_frac] = 0.0                           # stopped words
+    return wid, w, nid
+
+
+def test_bow_vectors_oracle_against_python():
+    """TemplatedVocabulary::transform's BowVector / FeatureVector (TemplatedVocabulary.h:1139-1208): the oracle's sorted arrays vs
+    python dicts replaying addWeight / addFeature in feature order and the sequential L1 norm."""
+    rng = np.random.default_rng(8)
+    for n in (0, 1, 50, 700):
+        wid, w, nid = _bow_inputs(rng, n)
+        ni, ns, ft, bw, bv = om.bow_vectors(wid, w, nid)
+        v = {}; fv = {}
+        for i in range(n):
+            if w[i] > 0:
+                v[int(wid[i])] = v.get(int(wid[i]), 0.0) + float(w[i])
+                fv.setdefault(int(nid[i]), []).append(i)
+        norm = 0.0
+        for k in sorted(v):
+            norm += abs(v[k])
+        assert list(bw) == sorted(v)
+        np.testing.assert_array_equal(bv, np.array([v[k] / norm for k in sorted(v)], np.float64) if v else np.zeros(0))
+        assert list(ni) == sorted(fv)
+        for j, k in enumerate(sorted(fv)):
+            assert list(ft[ns[j]:ns[j + 1]]) == fv[k]
+        if n >= 50:
+            assert abs(bv.sum() - 1.0) < 1e-12
