@@ -659,3 +659,52 @@ def test_bow_vectors_parity(gpu_ctx):
         np.testing.assert_array_equal(bw[f, :nw[f]], r_bw)
         assert bv[f, :nw[f]].tobytes() == r_bv.tobytes(), f
     assert nw[6] == 0 and nn[6] == 0
+
+
+@pytest.mark.gpu
+def test_bow_pipeline_stays_on_device(gpu_ctx):
+    """ComputeBoW -> SearchByBoW without a host round trip: descriptors -> orbhip_bow_transform_device -> orbhip_bow_vectors_device ->
+    orbhip_search_by_bow_device (the CSR buffers passed straight through); result == the oracle chain on the same inputs."""
+    import torch
+    import orbhip
+    import oracle_match_bind as om
+    rng = np.random.default_rng(31)
+    voc = om.make_vocabulary(rng, 10, 4)
+    P, MN, MNODE, L, LUP = 5, 1024, 1024, 4, 2
+    n = np.array([0, 40, 900, 1024, 333, 777], np.int32)               # frames 0..P: pair p = (keyframe p, frame p+1)
+    F = P + 1
+    desc = np.zeros((F, MN, 32), np.uint8); kp = np.zeros((F, MN), orbhip.KP_DTYPE)
+    base = voc["node_desc"][rng.integers(1, len(voc["node_desc"]), 1024)]
+    for f in range(F):
+        src = rng.integers(0, 1024, n[f])
+        desc[f, :n[f]] = base[src] ^ (rng.integers(0, 256, (n[f], 32), dtype=np.uint8) & rng.integers(0, 256, (n[f], 32), dtype=np.uint8) & rng.integers(0, 256, (n[f], 32), dtype=np.uint8))
+        kp[f, :n[f]]["angle"] = rng.uniform(0, 360, n[f]).astype(np.float32)
+    valid = (rng.random((F, MN)) < 0.85).astype(np.uint8)
+    dv = [torch.from_numpy(np.ascontiguousarray(voc[key])).cuda() for key in ("node_desc", "child_start", "child_ids", "node_word", "node_weight")]
+    d_desc = torch.from_numpy(desc).cuda(); d_kp = torch.from_numpy(kp.view(np.uint8)).cuda(); d_n = torch.from_numpy(n).cuda(); d_valid = torch.from_numpy(valid).cuda()
+    wid = torch.zeros((F, MN), dtype=torch.int32, device="cuda"); w = torch.zeros((F, MN), dtype=torch.float64, device="cuda"); nid = torch.zeros((F, MN), dtype=torch.int32, device="cuda")
+    ni = torch.zeros((F, MNODE), dtype=torch.int32, device="cuda"); st = torch.zeros((F, MNODE + 1), dtype=torch.int32, device="cuda")
+    ft = torch.zeros((F, MN), dtype=torch.int32, device="cuda"); nn = torch.zeros((F,), dtype=torch.int32, device="cuda")
+    bw = torch.zeros((F, MN), dtype=torch.int32, device="cuda"); bv = torch.zeros((F, MN), dtype=torch.float64, device="cuda"); nw = torch.zeros((F,), dtype=torch.int32, device="cuda")
+    mf = torch.full((P, MN), -9, dtype=torch.int32, device="cuda"); nm = torch.full((P,), -9, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    orbhip.bow_transform_device(gpu_ctx, d_desc.data_ptr(), d_n.data_ptr(), F, MN, MN, [t.data_ptr() for t in dv], L, LUP, wid.data_ptr(), w.data_ptr(), nid.data_ptr())
+    orbhip.bow_vectors_device(gpu_ctx, wid.data_ptr(), w.data_ptr(), nid.data_ptr(), d_n.data_ptr(), F, MN, MNODE, ni.data_ptr(), st.data_ptr(), ft.data_ptr(),
+                              nn.data_ptr(), bw.data_ptr(), bv.data_ptr(), nw.data_ptr())
+    # pair p: keyframe = frame p, frame = frame p+1 -> the "frame" side pointers start one row later
+    orbhip.search_by_bow_device(gpu_ctx, [ni.data_ptr(), st.data_ptr(), ft.data_ptr(), nn.data_ptr(), d_valid.data_ptr(), d_kp.data_ptr(), d_desc.data_ptr()],
+                                [ni.data_ptr() + 4 * MNODE, st.data_ptr() + 4 * (MNODE + 1), ft.data_ptr() + 4 * MN, nn.data_ptr() + 4,
+                                 d_kp.data_ptr() + 28 * MN, d_desc.data_ptr() + 32 * MN], d_n.data_ptr() + 4, P, MNODE, MN, MN, 0.7, True, mf.data_ptr(), nm.data_ptr())
+    gpu_ctx.check_status()
+    mf, nm, h_nid = mf.cpu().numpy(), nm.cpu().numpy(), nid.cpu().numpy()
+    tot = 0
+    for p in range(P):
+        nid_k = np.array([om.bow_transform(desc[p, i], voc, LUP)[2] for i in range(n[p])], np.int32)
+        nid_f = np.array([om.bow_transform(desc[p + 1, i], voc, LUP)[2] for i in range(n[p + 1])], np.int32)
+        np.testing.assert_array_equal(h_nid[p, :n[p]], nid_k)
+        c = dict(kp_k=kp[p, :n[p]], d_k=desc[p, :n[p]], nid_k=nid_k, valid=valid[p, :n[p]], kp_f=kp[p + 1, :n[p + 1]], d_f=desc[p + 1, :n[p + 1]], nid_f=nid_f)
+        n_ref, m_ref = om.search_by_bow(c, 0.7, True)
+        assert nm[p] == n_ref, (p, nm[p], n_ref)
+        np.testing.assert_array_equal(mf[p, :len(m_ref)], m_ref)
+        tot += n_ref
+    assert tot > 30
