@@ -255,3 +255,36 @@ def test_extract_random_geometries(gpu_ctx):
             assert got[f][2] == mono and got[f][0].tobytes() == kp.tobytes() and got[f][1].tobytes() == desc.tobytes(), (w, h, nlev, scale, nfeat, ini, mn, lap)
         ext.close()
         done += 1
+
+
+def test_two_extractors_in_two_threads(gpu_ctx):
+    """"One ORBextractor instance per thread" (src/Frame.cc:109-110: left / right extraction threads): two contexts + extractors driven
+    concurrently from two host threads give exactly what each gives alone."""
+    import threading
+    import orbhip
+    imgs = [orbhip.synth_frames(640, 480, 12, seed=40 + k) for k in range(2)]
+    ref = []
+    for k in range(2):
+        ext, _ = _mk(gpu_ctx)
+        ref.append(ext.extract_host(imgs[k], (0, 0)))
+        ext.close()
+    ctxs = [orbhip.Context(0) for _ in range(2)]
+    exts = [orbhip.Extractor(ctxs[k], 1000, 1.2, 8, 20, 7) for k in range(2)]
+    out, errs = [None, None], []
+
+    def run(k):
+        try:
+            for _ in range(6):                                   # several overlapping calls per thread
+                out[k] = exts[k].extract_host(imgs[k], (0, 0))
+        except BaseException as e:
+            errs.append(e)
+    th = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(120)
+    assert not errs, errs
+    for k in range(2):
+        for f in range(12):
+            assert out[k][f][0].tobytes() == ref[k][f][0].tobytes() and out[k][f][1].tobytes() == ref[k][f][1].tobytes() and out[k][f][2] == ref[k][f][2]
+        exts[k].close(); ctxs[k].close()
