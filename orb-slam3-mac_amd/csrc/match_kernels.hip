@@ -6,6 +6,7 @@
 // Integer popcount work: v_bcnt_u32_b32 on 8 dwords per pair; train descriptors are
 // staged in LDS and read as wave-uniform (broadcast) 128-bit loads.
 #include "orb_internal.h"
+#include "wave_dpp.h"
 #include <climits>
 #include <cstring>
 #include <string>
@@ -488,11 +489,10 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
             start = (int)cell_start[(c0 + lane) * SI_ROWS + r0];
             len = (int)cell_start[(c0 + lane) * SI_ROWS + r1 + 1] - start;
         }
-        const int inc = wave_incl_scan_i(len);
-        const int off = inc - len, total = __shfl(inc, 63, 64);
+        const int inc = wave_scan_add_dpp(len);                      // DPP scans / reductions: no LDS round trips in the per-query chain
+        const int off = inc - len, total = __builtin_amdgcn_readlane(inc, 63);
         if (total == 0) continue;
-        int maxlen = len;
-        for (int d = 32; d >= 1; d >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, d, 64));
+        const int maxlen = wave_max_dpp(len);
         for (int j = 0; j < maxlen; j++) if (j < len) cand[off + j] = items[start + j];
         __syncthreads();
         const bool check_lv = qq.min_level > 0 || qq.max_level >= 0;            // Frame.cc:676
@@ -517,11 +517,7 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
                 }
             }
         }
-        for (int d = 32; d >= 1; d >>= 1) {
-            const uint32_t o1 = (uint32_t)__shfl_xor((int)key, d, 64), o2 = (uint32_t)__shfl_xor((int)key2, d, 64);
-            key2 = min(max(key, o1), min(key2, o2));
-            key = min(key, o1);
-        }
+        wave_min2_u32_dpp(key, key2);
         bool accept = key != 0xFFFFFFFFu && (int)(key >> 12) <= th_high && (int)(key >> 12) < 256;       // ORBmatcher.cc:2030,2058 / 85,131
         if (accept && mode == 1) {
             // local-map variant (ORBmatcher.cc:131-137): ratio test against the second best of the same octave.
