@@ -249,19 +249,19 @@ __global__ __launch_bounds__(64) void k_search_init(const orbhip_keypoint *kpA_,
             }
         }
         uint32_t k1 = lk1;
-        for (int d = 32; d >= 1; d >>= 1) {
-            const uint32_t ok1 = __shfl_xor(k1, d, 64);
-            const int od2 = __shfl_xor(d2, d, 64);
-            const uint32_t lose = max(k1, ok1);
-            d2 = min(min(d2, od2), lose == 0xFFFFFFFFu ? INT_MAX : (int)(lose >> 23));
-            k1 = min(k1, ok1);
-        }
+        // (best key, second-best distance) over the wave on the DPP path (scan order; the operation is associative and commutative)
+#define SI_STEP(CTRL, RM) do { const uint32_t ok1 = (uint32_t)dpp_mov<CTRL, RM>(-1, (int)k1); const int od2 = dpp_mov<CTRL, RM>(INT_MAX, d2); \
+            const uint32_t lose = max(k1, ok1); d2 = min(min(d2, od2), lose == 0xFFFFFFFFu ? INT_MAX : (int)(lose >> 23)); k1 = min(k1, ok1); } while (0)
+        SI_STEP(ORB_DPP_ROW_SHR(1), 0xF); SI_STEP(ORB_DPP_ROW_SHR(2), 0xF); SI_STEP(ORB_DPP_ROW_SHR(4), 0xF); SI_STEP(ORB_DPP_ROW_SHR(8), 0xF);
+        SI_STEP(ORB_DPP_ROW_BCAST15, 0xA); SI_STEP(ORB_DPP_ROW_BCAST31, 0xC);
+#undef SI_STEP
+        k1 = (uint32_t)__builtin_amdgcn_readlane((int)k1, 63); d2 = __builtin_amdgcn_readlane(d2, 63);
         __syncthreads();                                                    // cand_* reused by the next F1 point
         if (k1 == 0xFFFFFFFFu) continue;                                    // bestDist stays INT_MAX > TH_LOW
         const int best = (int)(k1 >> 23);
         if (!(best <= SI_TH_LOW && (float)best < __fmul_rn((float)d2, nn_ratio))) continue;   // ORBmatcher.cc:764-766
         const unsigned long long owner = __ballot(lk1 == k1);              // keys are unique: exactly one lane
-        const int bli = __shfl(best_li, __ffsll((long long)owner) - 1, 64);
+        const int bli = __builtin_amdgcn_readlane(best_li, __builtin_amdgcn_readfirstlane(__ffsll((long long)owner) - 1));
         if (lane == 0) {
             const int best_idx = gidx[bli];
             const int old = m21[bli];
