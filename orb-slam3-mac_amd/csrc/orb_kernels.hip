@@ -5,22 +5,14 @@
 // Integer/byte work throughout: HBM/LDS/VALU-bound, no MFMA (nothing here is GEMM-shaped).
 // Wave = 64 lanes everywhere.  Compile: hipcc --offload-arch=gfx950 -ffp-contract=off.
 #include "orb_internal.h"
+#include "wave_dpp.h"
 
 #define WAVE 64
 
 // ----------------------------------------------------------------------------------
 // helpers
 // ----------------------------------------------------------------------------------
-__device__ __forceinline__ int wave_incl_scan(int v)
-{
-    const int lane = threadIdx.x & (WAVE - 1);
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        int t = __shfl_up(v, d, WAVE);
-        if (lane >= d) v += t;
-    }
-    return v;
-}
+__device__ __forceinline__ int wave_incl_scan(int v) { return wave_scan_add_dpp(v); }   // DPP path: no ds_bpermute round trips (wave_dpp.h)
 
 // Exclusive scan of one int per thread over a 256-thread block. `wsum` = 8 ints of LDS.
 // Returns exclusive prefix; *total = block sum.  Contains two __syncthreads().
@@ -400,7 +392,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbParams P)
                     list[offs] = ORB_PACK_KEY(4 * gx + j + 3 + cj * L.wcell, yy + 3 + ci * L.hcell, (cbytes >> (8 * j)) & 0xFFu);
                 offs++;
             }
-        total += __shfl(inc, 63, 64);
+        total += __builtin_amdgcn_readlane(inc, 63);
     }
     if (total > L.cell_cap) { if (lane == 0) atomicExch(P.status, ORBHIP_E_CAPACITY); total = L.cell_cap; }
     if (lane == 0) *cnt_out = (uint32_t)total;
@@ -863,7 +855,7 @@ __global__ __launch_bounds__(256) void k_blur_score(OrbParams P)
             const unsigned long long bal = __ballot(pass[j]);
             int base = 0;
             if (lane == 0 && bal) base = atomicAdd(&qn[j], __popcll(bal));
-            base = __shfl(base, 0, 64);
+            base = __builtin_amdgcn_readfirstlane(base);
             if (pass[j]) queue[j][base + __popcll(bal & ((1ull << lane) - 1))] = (uint16_t)gi;
         }
     }
@@ -1117,8 +1109,7 @@ __global__ __launch_bounds__(OD_THREADS) void k_orient_desc(OrbParams P)
                 if (i < 39 * 3) *reinterpret_cast<uint4 *>(&bp32[r * (OD_BP / 4) + 4 * c3]) = br[k];
             }
         }
-#pragma unroll
-        for (int dd = 8; dd >= 1; dd >>= 1) { m10 += __shfl_xor(m10, dd, 16); m01 += __shfl_xor(m01, dd, 16); }
+        m10 = row16_allreduce_add_dpp(m10); m01 = row16_allreduce_add_dpp(m01);        // the keypoint's 16 lanes = one DPP row
         const float angle = fast_atan2_deg((float)m01, (float)m10);
         // ---- steered BRIEF on the blurred level (ORBextractor.cc:106-145)
         double sd, cd;

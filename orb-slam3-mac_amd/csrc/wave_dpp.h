@@ -79,4 +79,13 @@ __device__ __forceinline__ double wave_sum_f64_dpp(double v)
     const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(u & 0xffffffffu), 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(u >> 32), 63);
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
+// sum over each row of 16 lanes, result in all 16 lanes (rotations inside the row)
+__device__ __forceinline__ int row16_allreduce_add_dpp(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x120 + 8, 0xF, 0xF, false);       // row_ror:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x120 + 4, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x120 + 2, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x120 + 1, 0xF, 0xF, false);
+    return v;
+}
 #endif
