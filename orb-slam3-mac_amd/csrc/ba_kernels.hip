@@ -18,6 +18,7 @@
 // edge list (deterministic reductions).  The only dense contraction, S -= (W D^-1) W^T, runs
 // on the FP64 matrix cores (v_mfma_f64_16x16x4_f64) over a K-padded dense W panel.
 #include "orb_internal.h"
+#include "wave_dpp.h"
 #include <cfloat>
 #include <cmath>
 #include <cstring>
@@ -550,10 +551,7 @@ __global__ __launch_bounds__(256) void k_ba_build_points(BaBatch B)
     }
 #pragma unroll
     for (int k = 0; k < 9; k++) {
-        double v = acc[k];
-#pragma unroll
-        for (int d = 8; d >= 1; d >>= 1) v += __shfl_xor(v, d, 16);
-        acc[k] = v;
+        acc[k] = row16_allreduce_f64_dpp(acc[k]);          // the point's 16 lanes = one DPP row
     }
     if (sub == 0) {
         double *Ho = B.Hll + (size_t)(G.point_off + l) * 6, *bo = B.bl + (size_t)(G.point_off + l) * 3;
@@ -615,7 +613,7 @@ __global__ __launch_bounds__(64) void k_ba_build_poses(BaBatch B)
     }
     for (int i = 0; i < 27; i++) {
         double v = acc[i];
-        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        v = wave_sum_f64_dpp(v);
         acc[i] = v;
     }
     if (lane == 0) {
@@ -940,7 +938,7 @@ __global__ __launch_bounds__(64) void k_ba_bschur(BaBatch B)
     }
     for (int a = 0; a < 6; a++) {
         double v = acc[a];
-        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        v = wave_sum_f64_dpp(v);
         acc[a] = v;
     }
     if (lane == 0)
@@ -1162,8 +1160,7 @@ __global__ __launch_bounds__(256) void k_ba_backsub_points(BaBatch B)
 #pragma unroll
             for (int a = 0; a < 6; a++) { c0 -= w[a] * xp[a]; c1 -= w[6 + a] * xp[a]; c2 -= w[12 + a] * xp[a]; }
         }
-#pragma unroll
-        for (int d = 8; d >= 1; d >>= 1) { c0 += __shfl_xor(c0, d, 16); c1 += __shfl_xor(c1, d, 16); c2 += __shfl_xor(c2, d, 16); }
+        c0 = row16_allreduce_f64_dpp(c0); c1 = row16_allreduce_f64_dpp(c1); c2 = row16_allreduce_f64_dpp(c2);
         c0 += bl[0]; c1 += bl[1]; c2 += bl[2];
         const double *Di = B.Dinv + gl * 6;
         x0 = Di[0] * c0 + Di[1] * c1 + Di[2] * c2;
@@ -1974,10 +1971,7 @@ __device__ __forceinline__ void po_block_sum(double (&v)[N], double (*red)[PO_NR
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < N; k++) {
-        double x = v[k];
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
-        v[k] = x;
+        v[k] = wave_sum_f64_dpp(v[k]);                    // DPP path: the ~100 block sums per frame were ds_bpermute bound
     }
     __syncthreads();                                   // previous readers of red are done
     if (lane == 0) {

@@ -79,6 +79,18 @@ __device__ __forceinline__ double wave_sum_f64_dpp(double v)
     const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(u & 0xffffffffu), 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(u >> 32), 63);
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
+// sum of a double over each row of 16 lanes, every lane of the row gets a full sum (rotations; each lane's association is fixed)
+__device__ __forceinline__ double row16_allreduce_f64_dpp(double v)
+{
+#define ORB_STEP(N) do { const unsigned long long u = __builtin_bit_cast(unsigned long long, v); \
+        const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(u & 0xffffffffu), 0x120 + (N), 0xF, 0xF, false), \
+                       hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(u >> 32), 0x120 + (N), 0xF, 0xF, false); \
+        v += __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo); } while (0)
+    ORB_STEP(8); ORB_STEP(4); ORB_STEP(2); ORB_STEP(1);
+#undef ORB_STEP
+    return v;
+}
+
 // sum over each row of 16 lanes, result in all 16 lanes (rotations inside the row)
 __device__ __forceinline__ int row16_allreduce_add_dpp(int v)
 {
