@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include "orb_internal.h"
+#include "wave_dpp.h"
 
 #define ST_TH_HIGH 100        // ORBmatcher::TH_HIGH (ORBmatcher.cc:40)
 #define ST_TH_ORB 75          // (TH_HIGH + TH_LOW) / 2 (Frame.cc:807)
@@ -78,8 +79,9 @@ __global__ __launch_bounds__(64) void k_stereo_match(StereoArgs A)
     while (todo) {
         const int l = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
-        const float uLl = __shfl(uL, l, 64), vLl = __shfl(vL, l, 64);
-        const int lev = __shfl(levelL, l, 64), bR = __shfl(bestR, l, 64);
+        // lane l's values as scalars (v_readlane), the SAD sums on the DPP path: no ds_bpermute in this per-keypoint chain
+        const float uLl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, uL), l)), vLl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vL), l));
+        const int lev = __builtin_amdgcn_readlane(levelL, l), bR = __builtin_amdgcn_readlane(bestR, l);
         const float uR0 = kpR[bR].x;
         const StereoLevel &SL = A.lv[lev];
         const float sfac = SL.inv_scale;
@@ -111,8 +113,7 @@ __global__ __launch_bounds__(64) void k_stereo_match(StereoArgs A)
             }
         }
 #pragma unroll
-        for (int k = 0; k < 11; k++)
-            for (int d = 32; d >= 1; d >>= 1) s[k] += __shfl_xor(s[k], d, 64);
+        for (int k = 0; k < 11; k++) s[k] = wave_sum_dpp(s[k]);
         int bd = INT_MAX, binc = 0;
 #pragma unroll
         for (int k = 0; k < 11; k++) if ((float)s[k] < (float)bd) { bd = s[k]; binc = k - 5; }   // float dist < int bestDist (Frame.cc:929)
