@@ -37,12 +37,7 @@ __device__ __forceinline__ int hamming256(const uint4 &a0, const uint4 &a1, cons
            __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
 }
 
-__device__ __forceinline__ int wave_incl_scan_i(int v)
-{
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(v, d, 64); if ((int)(threadIdx.x & 63) >= d) v += o; }
-    return v;
-}
+__device__ __forceinline__ int wave_incl_scan_i(int v) { return wave_scan_add_dpp(v); }      // DPP path (wave_dpp.h)
 
 // ---------------------------------------------------------------------------- M2
 // grid = (ceil(max_n/256), pairs); one query per thread; train tile of 256 descriptors in LDS.
@@ -304,7 +299,7 @@ __global__ __launch_bounds__(64) void k_search_init(const orbhip_keypoint *kpA_,
             if (b < 0 || b == s_keep[0] || b == s_keep[1] || b == s_keep[2]) continue;
             if (m12[i1] >= 0) { m12[i1] = -1; removed++; }
         }
-        for (int d = 32; d >= 1; d >>= 1) removed += __shfl_xor(removed, d, 64);
+        removed = wave_sum_dpp(removed);
         nmatches -= removed;                                                // lane 0's copy is the one written out
     }
     __syncthreads();
@@ -409,7 +404,7 @@ __device__ void sbp_build_grid(uint32_t *cell_start, float *kx, float *ky, uint8
             const int v = c <= SBP_CELLS ? (int)cell_start[c] : 0;
             const int inc = wave_incl_scan_i(v);
             if (c <= SBP_CELLS) cell_start[c] = carry + (uint32_t)inc;
-            carry += (uint32_t)__shfl(inc, 63, 64);
+            carry += (uint32_t)__builtin_amdgcn_readlane(inc, 63);
         }
     }
     __syncthreads();
@@ -571,7 +566,7 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
             if (b < 0 || b == s_keep[0] || b == s_keep[1] || b == s_keep[2]) continue;
             holder[qm[t]] = -1; removed++;
         }
-        for (int d = 32; d >= 1; d >>= 1) removed += __shfl_xor(removed, d, 64);
+        removed = wave_sum_dpp(removed);
         nmatches -= removed;
     }
     __syncthreads();
@@ -921,7 +916,7 @@ __global__ __launch_bounds__(64) void k_search_by_bow(BowSide K, const uint8_t *
             }
         }
     }
-    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d, 64);
+    mine = wave_sum_dpp(mine);
     __syncthreads();
     int removed = 0;
     if (check_ori) {                                                         // :445-470
@@ -943,7 +938,7 @@ __global__ __launch_bounds__(64) void k_search_by_bow(BowSide K, const uint8_t *
             if (b < 0 || b == s_keep[0] || b == s_keep[1] || b == s_keep[2]) continue;
             mf[j] = -1; removed++;
         }
-        for (int d = 32; d >= 1; d >>= 1) removed += __shfl_xor(removed, d, 64);
+        removed = wave_sum_dpp(removed);
     }
     __syncthreads();
     if (KF_MODE) {
