@@ -435,6 +435,14 @@ def main():
         achieved = dom_bytes / (stage[dom] * 1e-3) / 1e9 if stage[dom] > 0 else 0.0
         # HBM traffic of the dominant kernel: PMC counters are collected in separate rocprofv3 passes (they cannot be
         # read from inside this process); the per-step sums of the committed pass are reported when the workload matches.
+        valu_busy, valu_src = None, None
+        try:
+            if (B, W, H) == (1024, 640, 480):
+                pv = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_valu_issue.json")))
+                valu_busy = pv["kernels"][kern[dom]]["valu_issue_busy_frac"]
+                valu_src = "profiles/r01_pmc_valu_issue.json (rocprofv3 --pmc: SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs))"
+        except Exception:
+            pass
         traffic, traffic_src = None, None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
@@ -459,7 +467,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kern[dom], "stage": dom, "launches_per_step": launches,
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_step": int(dom_bytes)},
+                         "algorithmic_bytes_per_step": int(dom_bytes),
+                         # what actually limits this kernel: its vector-instruction issue slots (committed PMC pass, VGA/1024 workload)
+                         "valu_issue_busy_frac": valu_busy, "valu_issue_source": valu_src},
         }
         if ba is not None:
             out["ba"] = ba
