@@ -708,3 +708,16 @@ def test_bow_pipeline_stays_on_device(gpu_ctx):
         np.testing.assert_array_equal(mf[p, :len(m_ref)], m_ref)
         tot += n_ref
     assert tot > 30
+
+
+@pytest.mark.gpu
+def test_matchers_against_committed_fixture(gpu_ctx):
+    """The claim-rule matcher (both modes) and the Fuse search against tests/golden/match_golden.npz -- no oracle involved."""
+    import os
+    from test_oracle_match_ba import _load_match_golden
+    g, bounds = _load_match_golden()
+    case = (g["sbp_q"], g["sbp_dq"], g["sbp_kp"], g["sbp_d"], g["sbp_ur"], g["sbp_tm"])
+    got = _sbp(gpu_ctx, [case], 256, 256, bounds, 100, True, True)
+    assert got[0][0] == int(g["sbp_n"]); np.testing.assert_array_equal(got[0][1], g["sbp_m"])
+    got = _sbp(gpu_ctx, [case], 256, 256, bounds, 100, False, True, map_ratio=0.8)
+    assert got[0][0] == int(g["map_n"]); np.testing.assert_array_equal(got[0][1], g["map_m"])

@@ -1,4 +1,5 @@
 """CPU tests pinning the matching and BA oracles (no GPU)."""
+import os
 import numpy as np
 import pytest
 
@@ -907,3 +908,34 @@ def test_bow_vectors_oracle_against_python():
             assert list(ft[ns[j]:ns[j + 1]]) == fv[k]
         if n >= 50:
             assert abs(bv.sum() - 1.0) < 1e-12
+
+
+def _load_match_golden():
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "match_golden.npz"))
+    return g, tuple(float(v) for v in g["bounds"])
+
+
+def test_matcher_golden_regression():
+    """Committed fixture (tests/golden/match_golden.npz, made by tools/gen_golden.py): the matcher oracles must not drift."""
+    g, bounds = _load_match_golden()
+    n0, m0 = om.search_by_projection(g["sbp_q"], g["sbp_dq"], g["sbp_kp"], g["sbp_d"], g["sbp_ur"], bounds, g["sbp_tm"], 100, True)
+    assert n0 == int(g["sbp_n"]); np.testing.assert_array_equal(m0, g["sbp_m"])
+    n1, m1 = om.search_by_projection_map(g["sbp_q"], g["sbp_dq"], g["sbp_kp"], g["sbp_d"], g["sbp_ur"], bounds, g["sbp_tm"], 100, 0.8)
+    assert n1 == int(g["map_n"]); np.testing.assert_array_equal(m1, g["map_m"])
+    bi, bd = om.fuse_search(g["fuse_q"], g["sbp_dq"], g["sbp_kp"], g["sbp_d"], g["sbp_ur"], g["fuse_sig"], bounds)
+    np.testing.assert_array_equal(bi, g["fuse_bi"]); np.testing.assert_array_equal(bd, g["fuse_bd"])
+    c = {k[4:]: g[k] for k in g.files if k.startswith("bow_") and k not in ("bow_n", "bow_m")}
+    nb, mb = om.search_by_bow(c, 0.7, True); nk, mk = om.search_by_bow_kf(c, 0.75, True)
+    assert nb == int(g["bow_n"]) and nk == int(g["bowkf_n"])
+    np.testing.assert_array_equal(mb, g["bow_m"]); np.testing.assert_array_equal(mk, g["bowkf_m"])
+    t = {k[4:]: g[k] for k in g.files if k.startswith("tri_") and k not in ("tri_n", "tri_m")}
+    t["ep"] = tuple(float(v) for v in t["ep"]); t["only_stereo"] = bool(t["only_stereo"]); t["coarse"] = bool(t["coarse"])
+    nt, mt = om.search_for_triangulation(t, True, False)
+    assert nt == int(g["tri_n"]); np.testing.assert_array_equal(mt, g["tri_m"])
+    un = om.undistort_keypoints(g["sbp_kp"], EUROC_K, EUROC_DIST)
+    assert un.tobytes() == g["un_kp"].tobytes()
+    cs, it = om.assign_features_to_grid(un, bounds)
+    np.testing.assert_array_equal(cs, g["grid_cs"]); np.testing.assert_array_equal(it, g["grid_it"])
+    ni, ns, ft, bw, bv = om.bow_vectors(g["bv_wid"], g["bv_w"], g["bv_nid"])
+    np.testing.assert_array_equal(ni, g["bv_ni"]); np.testing.assert_array_equal(ft, g["bv_ft"]); np.testing.assert_array_equal(bw, g["bv_bw"])
+    assert bv.tobytes() == g["bv_bv"].tobytes()

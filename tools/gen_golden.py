@@ -32,6 +32,7 @@ def main():
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "orb_golden.npz"), **out)
     pose_goldens()
+    match_goldens()
 
 
 def pose_goldens():
@@ -49,6 +50,40 @@ def pose_goldens():
         print("pose", k, r, st)
     out["count"] = np.int32(len(cases))
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "pose_golden.npz"), **out)
+
+
+def match_goldens():
+    """Known-answer vectors of the matcher oracles (windowed claim-rule search in both modes, Fuse search, both BoW matchers,
+    SearchForTriangulation, the Frame glue and the BowVector assembly) on small seeded cases."""
+    import oracle_match_bind as om
+    from test_oracle_match_ba import make_sbp_case, _bow_inputs, EUROC_K, EUROC_DIST
+    rng = np.random.default_rng(4242)
+    bounds = (0.0, 0.0, 640.0, 480.0)
+    out = {"bounds": np.array(bounds, np.float32)}
+    q, dq, kp, d, ur, tm = make_sbp_case(rng, 180, 150, True)
+    out.update(sbp_q=q, sbp_dq=dq, sbp_kp=kp, sbp_d=d, sbp_ur=ur, sbp_tm=tm)
+    n0, m0 = om.search_by_projection(q, dq, kp, d, ur, bounds, tm, 100, True)
+    n1, m1 = om.search_by_projection_map(q, dq, kp, d, ur, bounds, tm, 100, 0.8)
+    out.update(sbp_n=np.int32(n0), sbp_m=m0, map_n=np.int32(n1), map_m=m1)
+    q2 = q.copy(); q2["min_level"] = np.maximum(q2["max_level"], 0) - 1; q2["max_level"] = q2["min_level"] + 1
+    q2["radius"] = np.float32(3.0) * np.float32(1.2) ** q2["max_level"].astype(np.float32)
+    sig = (np.float32(1.0) / (np.float32(1.2) ** np.arange(8, dtype=np.float32)) ** 2).astype(np.float32)
+    bi, bd = om.fuse_search(q2, dq, kp, d, ur, sig, bounds)
+    out.update(fuse_q=q2, fuse_sig=sig, fuse_bi=bi, fuse_bd=bd)
+    c = om.make_bow_case(rng, 160, 170, 25); c["valid2"] = (rng.random(170) < 0.8).astype(np.uint8)
+    nb, mb = om.search_by_bow(c, 0.7, True); nk, mk = om.search_by_bow_kf(c, 0.75, True)
+    out.update({"bow_" + k: v for k, v in c.items()}); out.update(bow_n=np.int32(nb), bow_m=mb, bowkf_n=np.int32(nk), bowkf_m=mk)
+    t = om.make_tri_case(rng, 150, 160, 25, 0.3, False, False)
+    nt, mt = om.search_for_triangulation(t, True, False)
+    out.update({"tri_" + k: (np.asarray(v) if not isinstance(v, (bool, tuple)) else np.array(v)) for k, v in t.items()})
+    out.update(tri_n=np.int32(nt), tri_m=mt)
+    un = om.undistort_keypoints(kp, EUROC_K, EUROC_DIST); cs, it = om.assign_features_to_grid(un, bounds)
+    out.update(un_kp=un, grid_cs=cs, grid_it=it)
+    wid, w, nid = _bow_inputs(rng, 200)
+    ni, ns, ft, bw, bv = om.bow_vectors(wid, w, nid)
+    out.update(bv_wid=wid, bv_w=w, bv_nid=nid, bv_ni=ni, bv_ns=ns, bv_ft=ft, bv_bw=bw, bv_bv=bv)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "match_golden.npz"), **out)
+    print("match goldens:", n0, n1, int((bi >= 0).sum()), nb, nk, nt, len(bw))
 
 
 if __name__ == "__main__":
