@@ -496,6 +496,8 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
             const int k = k0 + lane;
             if (k < total) {
                 const int i2 = cand[k];
+                // the descriptor is fetched together with the keypoint's other data (one latency instead of two on the chain)
+                const uint4 t0 = DESC_LDS ? dlds[2 * i2] : dT[2 * i2], t1 = DESC_LDS ? dlds[2 * i2 + 1] : dT[2 * i2 + 1];
                 const int o = oct[i2], h = holder[i2];
                 bool ok = !(check_lv && (o < qq.min_level || (qq.max_level >= 0 && o > qq.max_level)));   // Frame.cc:693-701
                 ok = ok && fabsf(__fsub_rn(kx[i2], x)) < r && fabsf(__fsub_rn(ky[i2], y)) < r;           // Frame.cc:704-708
@@ -505,7 +507,7 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
                     if (ur2 > 0 && fabsf(__fsub_rn(qq.ur, ur2)) > r) ok = false;                           // ORBmatcher.cc:2041-2047 / 100-105
                 }
                 if (ok) {
-                    const int dist = DESC_LDS ? hamming256(a0, a1, dlds[2 * i2], dlds[2 * i2 + 1]) : hamming256(a0, a1, dT[2 * i2], dT[2 * i2 + 1]);
+                    const int dist = hamming256(a0, a1, t0, t1);
                     const uint32_t kk = ((uint32_t)dist << 12) | (uint32_t)k;
                     key2 = min(key2, max(key, kk));
                     key = min(key, kk);

@@ -558,6 +558,7 @@ def test_sim3_searches_parity(gpu_ctx):
             tot += n_ref
     assert tot > 300
     bi = torch.full((P, MQ), -9, dtype=torch.int32, device="cuda"); bd = torch.full((P, MQ), -9, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
     orbhip.fuse_search_device(gpu_ctx, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), MQ, t[3].data_ptr(), t[4].data_ptr(), None, t[5].data_ptr(),
                               MN, MN, P, np.zeros(8, np.float32), bounds, bi.data_ptr(), bd.data_ptr())
     gpu_ctx.check_status()
@@ -583,6 +584,7 @@ def test_frame_glue_parity(gpu_ctx):
     d_kp = torch.from_numpy(KP.view(np.uint8)).cuda(); d_n = torch.tensor(ns, dtype=torch.int32, device="cuda")
     for dist in (EUROC_DIST, EUROC_DIST + (0.01,), (0.0, 0.1, 0.0, 0.0)):
         d_un = torch.zeros_like(d_kp)
+        torch.cuda.synchronize()                  # torch's fill runs on torch's stream, the library on its own
         orbhip.undistort_keypoints_device(gpu_ctx, d_kp.data_ptr(), d_n.data_ptr(), F, MN, MN, EUROC_K, dist, d_un.data_ptr())
         gpu_ctx.synchronize()
         un = d_un.cpu().numpy().view(orbhip.KP_DTYPE).reshape(F, MN)
@@ -591,6 +593,7 @@ def test_frame_glue_parity(gpu_ctx):
             assert un[f, :n].tobytes() == ref.tobytes(), (f, dist)
     bounds = (-12.5, -9.0, 760.0, 490.0)
     cs = torch.full((F, 64 * 48 + 1), -9, dtype=torch.int32, device="cuda"); it = torch.full((F, MN), -9, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
     orbhip.assign_features_to_grid_device(gpu_ctx, d_un.data_ptr(), d_n.data_ptr(), F, MN, MN, bounds, cs.data_ptr(), it.data_ptr())
     gpu_ctx.check_status()
     cs, it = cs.cpu().numpy(), it.cpu().numpy()
@@ -647,6 +650,7 @@ def test_bow_vectors_parity(gpu_ctx):
     ft = torch.full((F, MN), -9, dtype=torch.int32, device="cuda"); nn = torch.full((F,), -9, dtype=torch.int32, device="cuda")
     bw = torch.full((F, MN), -9, dtype=torch.int32, device="cuda"); bv = torch.zeros((F, MN), dtype=torch.float64, device="cuda")
     nw = torch.full((F,), -9, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
     orbhip.bow_vectors_device(gpu_ctx, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), F, MN, MNODE, ni.data_ptr(), st.data_ptr(),
                               ft.data_ptr(), nn.data_ptr(), bw.data_ptr(), bv.data_ptr(), nw.data_ptr())
     gpu_ctx.check_status()
