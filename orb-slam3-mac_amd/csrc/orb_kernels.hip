@@ -680,7 +680,18 @@ __global__ __launch_bounds__(256) void k_octree(OrbParams P)
     uint32_t *out = P.lvl_kp + (size_t)frame * P.kps_per_frame + L.kp_base;
     int nout = size;
     if (nout > L.kp_cap) { if (tid == 0) atomicExch(P.status, ORBHIP_E_CAPACITY); nout = L.kp_cap; }
+    // processing order for k_orient_desc: rows of 32-pixel tiles, x inside a row (rank by counting over LDS; nout <= quota + 8)
+    uint16_t *perm = P.lvl_perm + (size_t)frame * P.kps_per_frame + L.kp_base;
     for (int i = tid; i < nout; i += 256) out[i] = keys[0xFFFFF - (S.best[i] & 0xFFFFF)];
+    __syncthreads();                                      // everyone has read S.best: it now holds the spatial sort keys
+    for (int i = tid; i < nout; i += 256) { const uint32_t ki = out[i]; S.best[i] = ((uint32_t)(ORB_KEY_Y(ki) >> 5) << 16) | (uint32_t)ORB_KEY_X(ki); }
+    __syncthreads();
+    for (int i = tid; i < nout; i += 256) {
+        const uint32_t si = S.best[i];
+        int rank = 0;
+        for (int j = 0; j < nout; j++) { const uint32_t sj = S.best[j]; rank += (sj < si) || (sj == si && j < i); }
+        perm[rank] = (uint16_t)i;
+    }
     if (tid == 0) *count_out = nout;
 }
 
@@ -1034,9 +1045,10 @@ __global__ __launch_bounds__(OD_THREADS) void k_orient_desc(OrbParams P)
         for (int l = 1; l < P.nlevels; l++) if (slot0 >= P.lv[l].kp_base) lvl = l;
         lvl = __builtin_amdgcn_readfirstlane(lvl);
         const OrbLevel &L = P.lv[lvl];
-        const int slot = slot0 + sub;
+        const int slot_w = slot0 + sub;                                  // work slot: the slot_w-th keypoint of the level in spatial order
         const int nk = P.lvl_count[frame * P.nlevels + lvl];
-        const bool valid = (slot - L.kp_base) < nk;
+        const bool valid = (slot_w - L.kp_base) < nk;
+        const int slot = valid ? L.kp_base + (int)P.lvl_perm[(size_t)frame * P.kps_per_frame + slot_w] : slot_w;
         if (slot0 - L.kp_base >= nk) continue;
         int x = 19, y = 19;
         if (valid) {

@@ -319,6 +319,7 @@ extern "C" int orbhip_extractor_reserve(orbhip_extractor *e, int width, int heig
     if ((rc = dev_alloc(e, &P.keys, B * keys))) return rc;
     if ((rc = dev_alloc(e, &P.node_of, B * keys))) return rc;
     if ((rc = dev_alloc(e, &P.lvl_kp, B * kps))) return rc;
+    if ((rc = dev_alloc(e, &P.lvl_perm, B * kps))) return rc;
     if ((rc = dev_alloc(e, &P.lvl_angle, B * kps))) return rc;
     if ((rc = dev_alloc(e, &P.lvl_desc, B * kps * 32))) return rc;
     if ((rc = dev_alloc(e, &P.lvl_count, B * e->nlevels))) return rc;
