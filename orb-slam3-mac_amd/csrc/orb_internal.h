@@ -52,6 +52,7 @@ struct OrbParams {
     uint32_t *keys;           // [batch][keys_per_frame] ordered candidates (packed)
     uint16_t *node_of;        // [batch][keys_per_frame]
     uint32_t *lvl_kp;         // [batch][kps_per_frame] selected keypoints (packed)
+#define ORB_PERM_MIN_BATCH 16   // below this batch size k_orient_desc keeps the slot order (single-frame latency)
     uint16_t *lvl_perm;       // [batch][kps_per_frame] per level: position (inside the level slice) of the r-th keypoint in spatial order -- the order
                               // k_orient_desc WORKS in (patches of neighbours share cache lines); results stay in the reference's slots
     float *lvl_angle;         // [batch][kps_per_frame]
