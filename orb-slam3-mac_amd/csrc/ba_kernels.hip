@@ -1744,9 +1744,9 @@ static int ba_solve_impl(orbhip_ba_batch *b, const orbhip_ba_params *params, vol
     for (auto &D : b->gd) { max_items = std::max(max_items, D.ks * D.ngrp); max_poses = std::max(max_poses, D.n_poses); }
     size_t gemm_lds = 0;
     for (auto &D : b->gd) gemm_lds = std::max(gemm_lds, sizeof(double) * (2 * (size_t)D.gemm_ps * 3 * (size_t)(D.ld + GEMM_LDS_PAD) + GEMM_LDS_TAIL));
-    TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_schur_gemm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds));
+    if (orb_lds_optin(reinterpret_cast<const void *>(k_ba_schur_gemm), orbhip_ctx_device_internal(b->ctx), gemm_lds)) { g_ba_error = "LDS opt-in (k_ba_schur_gemm)"; return ORBHIP_E_HIP; }
     const size_t ldlt_lds = ba_ldlt_lds_bytes(B.max_ld);
-    TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_ldlt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldlt_lds));
+    if (orb_lds_optin(reinterpret_cast<const void *>(k_ba_ldlt), orbhip_ctx_device_internal(b->ctx), ldlt_lds)) { g_ba_error = "LDS opt-in (k_ba_ldlt)"; return ORBHIP_E_HIP; }
     const int max_ticks = (params->iters1 + params->iters2) * params->max_trials + 4;
     int tick = 0;
     for (; tick < max_ticks && n_active > 0; tick++) {
@@ -1788,6 +1788,7 @@ static int ba_solve_impl(orbhip_ba_batch *b, const orbhip_ba_params *params, vol
         hipLaunchKernelGGL(k_ba_control, dim3((G + 63) / 64), dim3(64), 0, s, B, ab);
         TRY(hipMemcpyAsync(b->h_n_active, B.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
         TRY(hipStreamSynchronize(s));
+        TRY(hipGetLastError());                  // a rejected launch fails here, loudly, instead of spinning to max_ticks
         n_active = *b->h_n_active;
         if (b->profile) {
             float ms = 0;

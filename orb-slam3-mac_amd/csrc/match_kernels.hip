@@ -323,12 +323,7 @@ extern "C" int orbhip_search_for_initialization_device(orbhip_ctx *ctx,
     // LDS is sized from the caller's row capacity: every keypoint of a frame may be octave 0
     const int maxn = max_n < SI_MAXN ? max_n : SI_MAXN, cap0 = max_n < SI_CAP0 ? max_n : SI_CAP0;
     const size_t lds = (size_t)cap0 * (4 * 4 + 7 * 2) + (size_t)maxn * 3;
-    static thread_local size_t lds_set = 0;
-    if (lds > lds_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_init), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return ORBHIP_E_HIP;
-        lds_set = lds;
-    }
+    if (orb_lds_optin(reinterpret_cast<const void *>(k_search_init), orbhip_ctx_device_internal(ctx), lds)) return ORBHIP_E_HIP;
     hipLaunchKernelGGL(k_search_init, dim3(pairs), dim3(64), lds, orbhip_ctx_stream_internal(ctx), d_kpA, d_descA, d_nA,
                        d_kpB, d_descB, d_nB, max_n, frame_stride_kp, min_x, min_y, max_x, max_y, window_size, nn_ratio,
                        check_orientation, cap0, maxn, d_prev_matched, d_matches12, d_nmatches, d_status);
@@ -594,13 +589,8 @@ static int sbp_launch(orbhip_ctx *ctx, const orbhip_proj_query *d_q, const uint8
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const bool desc_lds = with_desc <= 150 * 1024 && (size_t)pairs * with_desc <= (size_t)cus * 150 * 1024;
     const size_t lds = desc_lds ? with_desc : base;
-    static thread_local size_t lds_set[2] = {0, 0};
     auto kern = desc_lds ? k_search_by_projection<true> : k_search_by_projection<false>;
-    if (lds > lds_set[desc_lds]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return ORBHIP_E_HIP;
-        lds_set[desc_lds] = lds;
-    }
+    if (orb_lds_optin(reinterpret_cast<const void *>(kern), orbhip_ctx_device_internal(ctx), lds)) return ORBHIP_E_HIP;
     hipLaunchKernelGGL(kern, dim3(pairs), dim3(64), lds, orbhip_ctx_stream_internal(ctx), d_q, d_desc_q, d_nq,
                        max_q, d_kp, d_desc, d_u_right, d_n, max_n, frame_stride_kp, min_x, min_y, max_x, max_y, th_high,
                        check_orientation, mode, nn_ratio, cap_n, cap_q, d_train_match, d_nmatches, orbhip_ctx_status_internal(ctx));
@@ -683,12 +673,7 @@ extern "C" int orbhip_distinctive_descriptors_device(orbhip_ctx *ctx, const uint
     if (!ctx || !d_desc || !d_n || points <= 0 || max_n <= 0 || max_n > 256 || !d_best_idx) return ORBHIP_E_BADARG;
     if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
     const size_t lds = sizeof(uint16_t) * (size_t)max_n * max_n;
-    static thread_local size_t lds_set = 0;
-    if (lds > lds_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_distinctive), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return ORBHIP_E_HIP;
-        lds_set = lds;
-    }
+    if (orb_lds_optin(reinterpret_cast<const void *>(k_distinctive), orbhip_ctx_device_internal(ctx), lds)) return ORBHIP_E_HIP;
     hipLaunchKernelGGL(k_distinctive, dim3(points), dim3(64), lds, orbhip_ctx_stream_internal(ctx), d_desc, d_n, max_n, d_best_idx, d_best_desc);
     return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
 }
@@ -828,12 +813,7 @@ extern "C" int orbhip_fuse_search_device(orbhip_ctx *ctx, const orbhip_proj_quer
     const int cap_n = ((max_n < 2900 ? max_n : 2900) + 7) & ~7;        // keypoints AND descriptors of a keyframe live in LDS (160 KB)
     const size_t lds = (size_t)cap_n * (32 + 4 + 4 + 4 + 2 + 2 + 2 + 1) + sizeof(uint32_t) * (SBP_CELLS + 1) + 16;
     if (lds > 160 * 1024 - 512) return ORBHIP_E_BADARG;
-    static thread_local size_t lds_set = 0;
-    if (lds > lds_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fuse_search), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return ORBHIP_E_HIP;
-        lds_set = lds;
-    }
+    if (orb_lds_optin(reinterpret_cast<const void *>(k_fuse_search), orbhip_ctx_device_internal(ctx), lds)) return ORBHIP_E_HIP;
     hipLaunchKernelGGL(k_fuse_search, dim3(pairs), dim3(64), lds, orbhip_ctx_stream_internal(ctx), d_q, d_desc_q, d_nq, max_q, d_kp, d_desc,
                        d_u_right, d_n, max_n, frame_stride_kp, sig, min_x, min_y, max_x, max_y, cap_n, d_best_idx, d_best_dist,
                        orbhip_ctx_status_internal(ctx));
@@ -960,11 +940,9 @@ static int bow_launch(orbhip_ctx *ctx, bool kf_mode, const BowSide &K, const uin
     if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
     const int cap_n = ((max_n < 4096 ? max_n : 4096) + 7) & ~7;
     const size_t lds = (size_t)cap_n * (32 + 2 + 1 + (kf_mode ? 2 : 0)) + 16;
-    static thread_local size_t lds_set[2] = {0, 0};
-    if (lds > lds_set[kf_mode]) {
+    {
         const void *fn = kf_mode ? reinterpret_cast<const void *>(k_search_by_bow<true>) : reinterpret_cast<const void *>(k_search_by_bow<false>);
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ORBHIP_E_HIP;
-        lds_set[kf_mode] = lds;
+        if (orb_lds_optin(fn, orbhip_ctx_device_internal(ctx), lds)) return ORBHIP_E_HIP;
     }
     if (kf_mode)
         hipLaunchKernelGGL(k_search_by_bow<true>, dim3(pairs), dim3(64), lds, orbhip_ctx_stream_internal(ctx), K, d_kf_valid, d_nK, F, d_f_valid, d_nF,
@@ -1145,12 +1123,7 @@ extern "C" int orbhip_search_for_triangulation_device(orbhip_ctx *ctx,
     for (int l = 0; l < 16; l++) { lv.scale[l] = l < nlevels ? scale_factors[l] : 0.0f; lv.sigma2[l] = l < nlevels ? level_sigma2[l] : 0.0f; }
     const int cap_n = ((max_n < 4096 ? max_n : 4096) + 15) & ~15;
     const size_t lds = (size_t)cap_n * (32 + 1 + 1) + 16;
-    static thread_local size_t lds_set = 0;
-    if (lds > lds_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_triangulation), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return ORBHIP_E_HIP;
-        lds_set = lds;
-    }
+    if (orb_lds_optin(reinterpret_cast<const void *>(k_search_triangulation), orbhip_ctx_device_internal(ctx), lds)) return ORBHIP_E_HIP;
     TriSide S2 = {d_node_ids2, d_node_start2, d_feat2, d_nnodes2};
     hipLaunchKernelGGL(k_search_triangulation, dim3(pairs), dim3(TRI_THREADS), lds, orbhip_ctx_stream_internal(ctx), d_nid1, d_has_mp1, d_kp1,
                        d_desc1, d_u_right1, d_n1, S2, d_has_mp2, d_kp2, d_desc2, d_u_right2, d_n2, d_pair, max_nodes, max_n, frame_stride_kp, lv,
@@ -1234,12 +1207,7 @@ extern "C" int orbhip_assign_features_to_grid_device(orbhip_ctx *ctx, const orbh
     if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
     const int cap_n = ((max_n < 8192 ? max_n : 8192) + 7) & ~7;
     const size_t lds = sizeof(uint32_t) * (SBP_CELLS + 1) + (size_t)cap_n * (4 + 4 + 2 + 2 + 2 + 1) + 16;
-    static thread_local size_t lds_set = 0;
-    if (lds > lds_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_assign_grid), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return ORBHIP_E_HIP;
-        lds_set = lds;
-    }
+    if (orb_lds_optin(reinterpret_cast<const void *>(k_assign_grid), orbhip_ctx_device_internal(ctx), lds)) return ORBHIP_E_HIP;
     const float inv_w = (float)SI_COLS / (max_x - min_x), inv_h = (float)SI_ROWS / (max_y - min_y);      // Frame.cc:334-335
     hipLaunchKernelGGL(k_assign_grid, dim3(frames), dim3(64), lds, orbhip_ctx_stream_internal(ctx), d_kp, d_n, max_n, frame_stride_kp, min_x,
                        min_y, inv_w, inv_h, cap_n, d_cell_start, d_items, orbhip_ctx_status_internal(ctx));
@@ -1369,12 +1337,7 @@ extern "C" int orbhip_bow_vectors_device(orbhip_ctx *ctx, const int32_t *d_word_
     int cap_n = 64;
     while (cap_n < max_n) cap_n <<= 1;
     const size_t lds = (size_t)cap_n * (8 + 4) + 16;
-    static thread_local size_t lds_set = 0;
-    if (lds > lds_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_bow_vectors), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return ORBHIP_E_HIP;
-        lds_set = lds;
-    }
+    if (orb_lds_optin(reinterpret_cast<const void *>(k_bow_vectors), orbhip_ctx_device_internal(ctx), lds)) return ORBHIP_E_HIP;
     hipLaunchKernelGGL(k_bow_vectors, dim3(frames), dim3(BV_THREADS), lds, orbhip_ctx_stream_internal(ctx), d_word_id, d_weight, d_node_id, d_n, max_n,
                        cap_n, max_nodes, d_node_ids, d_node_start, d_feat, d_nnodes, d_bow_word, d_bow_value, d_nwords, orbhip_ctx_status_internal(ctx));
     return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;

@@ -42,6 +42,7 @@ struct OrbParams {
     int keys_per_frame;       // sum of key_cap
     int kps_per_frame;        // sum of kp_cap  (== staging slots per frame)
     int max_kp;               // output row capacity per frame
+    int oct_nc;               // k_octree: node capacity of its LDS arrays = max over levels of max(quota + 16, 4*nIni + 4)
     int fc_pd, fc_rows;       // k_fast_cells per-wave LDS geometry: dword pitch and rows of the score band (+ aprons)
     int bs_tiles[ORB_MAX_LEVELS + 1];   // k_blur_score: prefix of 64x32 tiles per frame over the levels (one launch for all levels)
     int lap0, lap1;
@@ -93,6 +94,10 @@ struct StereoArgs {
 };
 void orb_launch_stereo(const StereoArgs &A, hipStream_t s);
 
+// Opt a kernel into the largest dynamic-LDS size a workgroup may have (160 KB minus its static LDS), once per (kernel, device);
+// thread-safe, never lowers the limit again.  `need` = the dynamic bytes of the coming launch: more than the limit -> error.
+int orb_lds_optin(const void *func, int device, size_t need);
+
 // kernel launchers (orb_kernels.hip)
 void orb_launch_resize(const OrbParams &P, int level, hipStream_t s);
 void orb_launch_fast_cells(const OrbParams &P, hipStream_t s);
@@ -100,4 +105,6 @@ void orb_launch_blur_score(const OrbParams &P, hipStream_t s);
 void orb_launch_octree(const OrbParams &P, hipStream_t s);
 void orb_launch_orient_desc(const OrbParams &P, hipStream_t s);
 void orb_launch_assemble(const OrbParams &P, hipStream_t s);
-size_t orb_octree_lds_bytes(int max_quota);
+size_t orb_octree_lds_bytes(int nc);
+int orb_octree_nc(const OrbParams &P);
+const void *orb_octree_func();

@@ -432,9 +432,15 @@ struct OctLds {
     uint32_t *best;      // [NC]
 };
 
-size_t orb_octree_lds_bytes(int max_quota)
+int orb_octree_nc(const OrbParams &P)
 {
-    int nc = max_quota + 16;
+    int nc = 0;
+    for (int l = 0; l < P.nlevels; l++) { const int a = P.lv[l].quota + 16, b = 4 * P.lv[l].n_ini + 4; nc = a > nc ? a : nc; nc = b > nc ? b : nc; }
+    return nc;
+}
+
+size_t orb_octree_lds_bytes(int nc)
+{
     return (size_t)nc * 4 * (6 + 4 + 6) + 64;
 }
 
@@ -457,7 +463,7 @@ __global__ __launch_bounds__(256) void k_octree(OrbParams P)
     const int frame = blockIdx.x - lvl * P.batch;
     const OrbLevel &L = P.lv[lvl];
     const int N = L.quota;
-    const int NC = [&] { int m = 0; for (int l = 0; l < P.nlevels; l++) m = max(m, P.lv[l].quota); return m + 16; }();
+    const int NC = P.oct_nc;
     // double-buffered node arrays (by list position): box0 = UL.x|UL.y<<16, box1 = BR.x|BR.y<<16, cnt = #keys
     uint32_t *box0 = smem, *box1 = smem + NC, *cnt = smem + 2 * NC;
     uint32_t *nbox0 = smem + 3 * NC, *nbox1 = smem + 4 * NC, *ncnt = smem + 5 * NC;
@@ -696,11 +702,11 @@ __global__ __launch_bounds__(256) void k_octree(OrbParams P)
     if (tid == 0) *count_out = nout;
 }
 
+const void *orb_octree_func() { return reinterpret_cast<const void *>(k_octree); }
+
 void orb_launch_octree(const OrbParams &P, hipStream_t s)
 {
-    int mq = 0;
-    for (int l = 0; l < P.nlevels; l++) mq = P.lv[l].quota > mq ? P.lv[l].quota : mq;
-    size_t lds = orb_octree_lds_bytes(mq);
+    const size_t lds = orb_octree_lds_bytes(P.oct_nc);      // > 64 KB from about 4000 features per level on: opted in by the caller
     hipLaunchKernelGGL(k_octree, dim3(P.nlevels * P.batch), dim3(256), lds, s, P);
 }
 

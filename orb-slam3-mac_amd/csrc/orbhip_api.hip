@@ -10,6 +10,8 @@
 #include <string>
 #include <vector>
 #include <mutex>
+#include <set>
+#include <utility>
 
 static thread_local std::string g_last_error;
 extern "C" const char *orbhip_last_error(void) { return g_last_error.c_str(); }
@@ -23,6 +25,23 @@ extern "C" const char *orbhip_version(void) { return "orbhip 0.1 (gfx950)"; }
             return ORBHIP_E_HIP;                                                        \
         }                                                                               \
     } while (0)
+
+int orb_lds_optin(const void *func, int device, size_t need)
+{
+    static std::mutex mu;
+    static std::set<std::pair<const void *, int>> done;
+    const size_t total = 160 * 1024;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!done.count({func, device})) {
+        hipFuncAttributes fa;
+        if (hipFuncGetAttributes(&fa, func) != hipSuccess) { g_last_error = "hipFuncGetAttributes"; return ORBHIP_E_HIP; }
+        const int maxdyn = (int)(total - std::min(total, (size_t)fa.sharedSizeBytes));
+        if (hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, maxdyn) != hipSuccess) { g_last_error = "hipFuncSetAttribute(MaxDynamicSharedMemorySize)"; return ORBHIP_E_HIP; }
+        done.insert({func, device});
+    }
+    if (need > total) { g_last_error = "dynamic LDS request exceeds 160 KB"; return ORBHIP_E_BADARG; }
+    return ORBHIP_OK;
+}
 
 struct orbhip_ctx {
     int device;
@@ -330,10 +349,11 @@ extern "C" int orbhip_extractor_reserve(orbhip_extractor *e, int width, int heig
     if ((rc = dev_alloc(e, &P.out_count, B))) return rc;
     if ((rc = dev_alloc(e, &P.out_mono, B))) return rc;
     HIP_TRY(hipMemset(P.status, 0, sizeof(int32_t)));
-    // the octree kernel's dynamic LDS may exceed the 64 KB default for large quotas
-    int mq = 0;
-    for (int l = 0; l < e->nlevels; l++) mq = std::max(mq, P.lv[l].quota);
-    if (orb_octree_lds_bytes(mq) > 150 * 1024) { g_last_error = "per-level quota too large for the LDS-resident octree"; return ORBHIP_E_BADARG; }
+    // the octree kernel keeps its node arrays in LDS: capacity = the largest node count any level can reach -- quota + 3 in the
+    // subdivision loop, but the first pass splits every root unconditionally (up to 4 * nIni nodes; wide images, small budgets)
+    P.oct_nc = orb_octree_nc(P);
+    if (orb_octree_lds_bytes(P.oct_nc) > 150 * 1024) { g_last_error = "per-level quota (or nIni) too large for the LDS-resident octree"; return ORBHIP_E_BADARG; }
+    if ((rc = orb_lds_optin(orb_octree_func(), e->ctx->device, orb_octree_lds_bytes(P.oct_nc)))) return rc;
     e->width = width; e->height = height; e->max_batch = max_batch;
     return ORBHIP_OK;
 }
@@ -376,6 +396,15 @@ extern "C" int orbhip_compute_stereo_matches_device(orbhip_extractor *left, orbh
     A.mb = mb; A.mbf = mbf; A.u_right = d_u_right; A.depth = d_depth; A.sad = left->d_stereo_sad; A.n_kept = d_n_matches;
     orb_launch_stereo(A, left->ctx->stream);
     HIP_TRY(hipGetLastError());
+    if (right->ctx->stream != left->ctx->stream) {
+        // ... and the right extractor's NEXT extraction must not overwrite its pyramid / keypoints / descriptors while the stereo
+        // kernels on the left stream still read them (write-after-read): its stream waits for them
+        hipEvent_t ev;
+        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ev, left->ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(right->ctx->stream, ev, 0));
+        HIP_TRY(hipEventDestroy(ev));
+    }
     return ORBHIP_OK;
 }
 

@@ -72,7 +72,8 @@ class OracleExtractor:
     def extract(self, img, lap=(0, 1000)):
         img = np.ascontiguousarray(img, np.uint8)
         H, W = img.shape
-        cap = self.nfeatures + 64 * self.nlevels
+        # the octree's first pass splits all nIni = round(W/H) roots: up to 4 * nIni keypoints per level whatever the budget
+        cap = self.nfeatures + (64 + 4 * (W // max(H - 32, 1) + 2)) * self.nlevels
         kp = np.zeros(cap, KP_DTYPE)
         desc = np.zeros((cap, 32), np.uint8)
         n = ci()

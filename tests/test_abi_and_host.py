@@ -127,3 +127,46 @@ def test_two_rank_gloo_shard_and_gather(tmp_path):
                         "--master-addr", "127.0.0.1", "--master-port", "29611", str(script)],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=300)
     assert r.returncode == 0 and "GLOO_OK" in r.stdout, r.stdout[-3000:]
+
+
+def test_bench_spawns_ranks_before_touching_the_gpu(monkeypatch):
+    """`bench.py --gpus N` outside a torch.distributed environment: N ranks are started as a child `torch.distributed.run`, from a
+    process that has imported neither torch nor the HIP library (a process that has initialised the GPU must never re-launch)."""
+    import importlib
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--workload", "hd"])
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        seen["torch_loaded"] = "torch" in sys.modules and getattr(sys.modules["torch"], "cuda", None) is not None and sys.modules["torch"].cuda.is_initialized()
+        seen["orbhip_loaded"] = "orbhip" in sys.modules
+        return 7
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    was_orbhip = "orbhip" in sys.modules
+    with pytest.raises(SystemExit) as ex:
+        bench.main()
+    assert ex.value.code == 7                                  # the child's return code is passed through
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--workload", "hd"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and not seen["torch_loaded"]
+    assert seen["orbhip_loaded"] == was_orbhip                 # spawning itself loads nothing
+    # inside a launcher's environment nothing is spawned; a mismatching --gpus is refused loudly
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit) as ex:
+        bench.main()
+    assert "WORLD_SIZE" in str(ex.value.code)
+
+
+def test_bench_workloads_match_baseline_configs():
+    import importlib
+    bench = importlib.import_module("bench")
+    a = bench.parse_args([])
+    assert (a.workload, a.width, a.height, a.nfeatures, a.batch, a.gpus) == ("vga", 640, 480, 1000, 1024, 1)      # configs[1]
+    a = bench.parse_args(["--workload", "hd", "--gpus", "8"])
+    assert (a.width, a.height, a.nfeatures, a.batch * a.gpus) == (1920, 1080, 2000, 4096)                         # configs[2]
+    ab = bench.algorithmic_bytes(640, 480, 1000, 0)
+    assert ab["S"] == 950532 and ab["total"] == 5742474                                                           # SURVEY 8(d)

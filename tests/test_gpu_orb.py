@@ -288,3 +288,71 @@ def test_two_extractors_in_two_threads(gpu_ctx):
         for f in range(12):
             assert out[k][f][0].tobytes() == ref[k][f][0].tobytes() and out[k][f][1].tobytes() == ref[k][f][1].tobytes() and out[k][f][2] == ref[k][f][2]
         exts[k].close(); ctxs[k].close()
+
+
+def test_golden_fixture_without_oracle(gpu_ctx):
+    """The HIP path against the committed vectors of tests/golden/orb_golden.npz (tools/gen_golden.py) -- no live oracle involved:
+    keypoints (all 28 bytes each), descriptors, order and return value, through the host and the device entry point."""
+    import os
+    import orbhip
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "orb_golden.npz"))
+    for name in ("a", "b"):
+        img = g["img_" + name]
+        lap = tuple(int(v) for v in g["lap_" + name])
+        ext = orbhip.Extractor(gpu_ctx, int(g["nfeat_" + name]), 1.2, 8, 20, 7)
+        for kp, desc, mono in (ext.extract_host(img, lap)[0], _dev_extract(gpu_ctx, ext, img[None], lap)[0]):
+            assert mono == int(g["mono_" + name])
+            assert kp.tobytes() == g["kp_" + name].tobytes(), "keypoints differ from the golden fixture " + name
+            assert desc.tobytes() == g["desc_" + name].tobytes(), "descriptors differ from the golden fixture " + name
+        ext.close()
+
+
+def test_octree_5000_features_initializer_extractor(gpu_ctx):
+    """The monocular initialiser's extractor, ORBextractor(5 * nFeatures, ...) (src/Tracking.cc:210-212): 5000 features per VGA
+    frame.  The octree's LDS node arrays then exceed the 64 KB default (dynamic-LDS opt-in) -- bit-exact, every stage."""
+    import orbhip
+    ext, ora = _mk(gpu_ctx, 5000)
+    imgs = orbhip.synth_frames(640, 480, 2, seed=5000)
+    got = ext.extract_host(imgs, (0, 1000))
+    n = sum(_compare_frame(ext, ora, imgs, f, (0, 1000), got) for f in range(2))
+    assert n > 2 * 3500
+    ext.close()
+
+
+@pytest.mark.parametrize("w,h,nfeat,nlev", [(2000, 100, 20, 2), (1500, 110, 40, 1), (3000, 140, 12, 3)])
+def test_wide_image_small_budget(gpu_ctx, w, h, nfeat, nlev):
+    """nIni = round(width / height) roots (ORBextractor.cc:541) and a small budget: the first octree pass creates up to 4 * nIni
+    nodes, more than quota + 16 -- the LDS node capacity must follow nIni, not only the quota."""
+    import orbhip
+    import oracle_bind as ob
+    ext = orbhip.Extractor(gpu_ctx, nfeat, 1.2, nlev, 20, 7)
+    ora = ob.OracleExtractor(nfeat, 1.2, nlev, 20, 7)
+    imgs = orbhip.synth_frames(w, h, 2, seed=w + nfeat)
+    got = ext.extract_host(imgs, (0, 1000))
+    for f in range(2):
+        assert _compare_frame(ext, ora, imgs, f, (0, 1000), got) >= nfeat // 2
+    ext.close()
+
+
+def test_hd_batch_properties(gpu_ctx):
+    """BASELINE config #3's frame shape at batch 64 (1920x1080, 2000 features; one GPU's shard is 512 such frames): sampled frames
+    bit-exact vs the oracle, run-to-run determinism (checksum of checksums), structural invariants of every frame."""
+    import hashlib
+    import orbhip
+    ext, ora = _mk(gpu_ctx, 2000)
+    imgs = orbhip.synth_frames(1920, 1080, 64, seed=20241004)
+    r1 = _dev_extract(gpu_ctx, ext, imgs, (0, 0))
+    digest1 = hashlib.sha256(b"".join(hashlib.sha256(k.tobytes() + d.tobytes()).digest() for k, d, _ in r1)).hexdigest()
+    for f in (0, 31, 63):
+        kp, desc, mono = ora.extract(imgs[f], (0, 0))
+        assert r1[f][2] == mono and r1[f][0].tobytes() == kp.tobytes() and r1[f][1].tobytes() == desc.tobytes(), f
+    quota = ext.features_per_level()
+    for k, d, m in r1:
+        assert 1800 < len(k) <= ext.max_keypoints and m == len(k)
+        assert (np.diff(k["octave"]) >= 0).all()
+        assert (np.bincount(k["octave"], minlength=8) <= quota + 2).all()
+        assert (k["x"] >= 19).all() and (k["y"] >= 19).all() and (k["x"] < 1920 - 19).all() and (k["y"] < 1080 - 19).all()
+    r2 = _dev_extract(gpu_ctx, ext, imgs, (0, 0))
+    digest2 = hashlib.sha256(b"".join(hashlib.sha256(k.tobytes() + d.tobytes()).digest() for k, d, _ in r2)).hexdigest()
+    assert digest1 == digest2
+    ext.close()
