@@ -97,6 +97,10 @@ int orbhip_extract_batch_host(orbhip_extractor *ext, const uint8_t *h_images, in
 int orbhip_extractor_level_dims(const orbhip_extractor *ext, int level, int *w, int *h);
 int orbhip_extractor_get_pyramid_level(orbhip_extractor *ext, int frame, int level, int padded,
                                        uint8_t *h_out, size_t out_stride);
+/* All levels of frame `frame` at once, as the reference holds them after operator(): levels_out[l] receives the
+ * (w_l+38) x (h_l+38) reflect-101 padded parent of level l (ORBextractor.cc:1160-1173) with row stride strides[l] >= w_l+38;
+ * mvImagePyramid[l] is its ROI at (19,19).  One device-to-host pass and one synchronisation for the whole pyramid. */
+int orbhip_extractor_get_pyramid_padded(orbhip_extractor *ext, int frame, uint8_t *const *levels_out, const size_t *strides);
 /* Parity taps (test hooks; synchronous D2H of intermediate stages of the last batch). */
 int orbhip_extractor_get_blurred_level(orbhip_extractor *ext, int frame, int level,
                                        uint8_t *h_out, size_t out_stride);
@@ -213,6 +217,21 @@ int orbhip_search_local_map_device(orbhip_ctx *ctx, const orbhip_proj_query *d_q
                                    size_t frame_stride_kp, int pairs, float min_x, float min_y, float max_x,
                                    float max_y, int th_high, float nn_ratio, int32_t *d_train_match,
                                    int32_t *d_nmatches);
+
+/* Host-pointer forms of the two calls above for ONE frame (what an ORBmatcher method with the reference's signature needs:
+ * host/ORBmatcher.cc): upload into the context's arena, run the same kernel, download, synchronise.  mode 0 =
+ * orbhip_search_by_projection_device (nn_ratio unused), 1 = orbhip_search_local_map_device (check_orientation unused).
+ * u_right may be NULL (monocular).  train_match_inout [n] as d_train_match.  All pointers HOST. */
+int orbhip_search_by_projection_host(orbhip_ctx *ctx, int mode, const orbhip_proj_query *q, const uint8_t *desc_q, int nq,
+                                     const orbhip_keypoint *kp, const uint8_t *desc, const float *u_right, int n,
+                                     float min_x, float min_y, float max_x, float max_y, int th_high, float nn_ratio,
+                                     int check_orientation, int32_t *train_match_inout, int32_t *nmatches_out);
+/* Host-pointer form of orbhip_search_for_initialization_device for one frame pair: prev_matched_inout [nA][2] is vbPrevMatched
+ * (in/out), matches12_out [nA] is vnMatches12, *nmatches_out the return value.  All pointers HOST. */
+int orbhip_search_for_initialization_host(orbhip_ctx *ctx, const orbhip_keypoint *kpA, const uint8_t *descA, int nA,
+                                          const orbhip_keypoint *kpB, const uint8_t *descB, int nB, float min_x, float min_y,
+                                          float max_x, float max_y, int window_size, float nn_ratio, int check_orientation,
+                                          float *prev_matched_inout, int32_t *matches12_out, int32_t *nmatches_out);
 
 /* The search part of ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, th, bRight)
  * (src/ORBmatcher.cc:1403-1613, NLeft == -1; LocalMapping::SearchInNeighbors, src/LocalMapping.cc:781-860), batched over

@@ -48,6 +48,8 @@ struct orbhip_ctx {
     hipStream_t stream;
     bool own_stream;
     int32_t *d_status;      // sticky device-side error word (capacity overflows in matcher kernels)
+    void *scratch;          // grow-only device arena of the host-pointer convenience entry points (host_entry.hip)
+    size_t scratch_bytes;
 };
 
 extern "C" int orbhip_ctx_create(int device, void *stream, orbhip_ctx **out)
@@ -72,9 +74,23 @@ extern "C" int orbhip_ctx_create(int device, void *stream, orbhip_ctx **out)
         if (c->own_stream) (void)hipStreamDestroy(c->stream);
         delete c; g_last_error = "hipMalloc(status)"; return ORBHIP_E_HIP;
     }
+    c->scratch = nullptr; c->scratch_bytes = 0;
     *out = c;
     return ORBHIP_OK;
 }
+// Device arena of at least `bytes` (256-byte aligned), kept across calls; growing drains the stream first.
+void *orbhip_ctx_scratch_internal(orbhip_ctx *c, size_t bytes)
+{
+    if (bytes <= c->scratch_bytes) return c->scratch;
+    (void)hipStreamSynchronize(c->stream);
+    if (c->scratch) (void)hipFree(c->scratch);
+    c->scratch = nullptr; c->scratch_bytes = 0;
+    const size_t want = std::max<size_t>(bytes + bytes / 2, 1 << 20);
+    if (hipMalloc(&c->scratch, want) != hipSuccess) { g_last_error = "hipMalloc(scratch arena)"; return nullptr; }
+    c->scratch_bytes = want;
+    return c->scratch;
+}
+void orbhip_set_last_error_internal(const char *msg) { g_last_error = msg; }
 extern "C" int orbhip_ctx_check_status(orbhip_ctx *c)
 {
     if (!c) return ORBHIP_E_BADARG;
@@ -89,6 +105,7 @@ extern "C" void orbhip_ctx_destroy(orbhip_ctx *c)
 {
     if (!c) return;
     (void)hipFree(c->d_status);
+    if (c->scratch) (void)hipFree(c->scratch);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -619,6 +636,38 @@ extern "C" int orbhip_extractor_get_pyramid_level(orbhip_extractor *e, int frame
         const uint8_t *srow = tmp.data() + (size_t)reflect101_host(y - ORB_EDGE, L.h) * L.w;
         uint8_t *drow = h_out + (size_t)y * out_stride;
         for (int x = 0; x < pw; x++) drow[x] = srow[reflect101_host(x - ORB_EDGE, L.w)];
+    }
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_extractor_get_pyramid_padded(orbhip_extractor *e, int frame, uint8_t *const *levels_out, const size_t *strides)
+{
+    if (!e || !levels_out || !strides || frame < 0 || frame >= e->last_batch) return ORBHIP_E_BADARG;
+    HIP_TRY(hipSetDevice(e->ctx->device));
+    hipStream_t s = e->ctx->stream;
+    for (int l = 0; l < e->nlevels; l++) {
+        const OrbLevel &L = e->P.lv[l];
+        if (!levels_out[l] || strides[l] < (size_t)L.w + 2 * ORB_EDGE) return ORBHIP_E_BADARG;
+        HIP_TRY(hipMemcpy2DAsync(levels_out[l] + (size_t)ORB_EDGE * strides[l] + ORB_EDGE, strides[l], L.img + (size_t)frame * L.img_frame_stride,
+                                 L.img_pitch, L.w, L.h, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    // the 19-px BORDER_REFLECT_101 frame (ORBextractor.cc:1167-1173), synthesised on the host: the extraction never reads it
+    for (int l = 0; l < e->nlevels; l++) {
+        const OrbLevel &L = e->P.lv[l];
+        const size_t st = strides[l];
+        uint8_t *base = levels_out[l];
+        for (int y = ORB_EDGE; y < L.h + ORB_EDGE; y++) {
+            uint8_t *row = base + (size_t)y * st;
+            for (int x = 0; x < ORB_EDGE; x++) {
+                row[x] = row[ORB_EDGE + reflect101_host(x - ORB_EDGE, L.w)];
+                row[L.w + ORB_EDGE + x] = row[ORB_EDGE + reflect101_host(L.w + x, L.w)];
+            }
+        }
+        for (int y = 0; y < ORB_EDGE; y++) {
+            memcpy(base + (size_t)y * st, base + (size_t)(ORB_EDGE + reflect101_host(y - ORB_EDGE, L.h)) * st, (size_t)L.w + 2 * ORB_EDGE);
+            memcpy(base + (size_t)(L.h + ORB_EDGE + y) * st, base + (size_t)(ORB_EDGE + reflect101_host(L.h + y, L.h)) * st, (size_t)L.w + 2 * ORB_EDGE);
+        }
     }
     return ORBHIP_OK;
 }

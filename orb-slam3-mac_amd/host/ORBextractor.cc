@@ -1,21 +1,27 @@
-// ORBextractor.cc -- host marshalling for the signature-preserving ORBextractor (see header).
+// ORBextractor.cc -- host marshalling for the signature-preserving ORBextractor (see header).  No exceptions cross this
+// boundary (the reference uses none): a device that is missing at construction aborts with a message (the reference's
+// constructor cannot fail and there is no CPU path to fall back to); a device error inside operator() is reported on stderr
+// and answered like the reference's only failure, the empty image: -1, no keypoints (ORBextractor.cc:1072-1073).
 #include "ORBextractor.h"
-#include <stdexcept>
-#include <string>
+#include <cstdio>
+#include <cstdlib>
 
 namespace ORB_SLAM3 {
 
-static void chk(int rc, const char *what)
+static void die(int rc, const char *what)
 {
-    if (rc != ORBHIP_OK) throw std::runtime_error(std::string(what) + ": " + orbhip_last_error());
+    fprintf(stderr, "ORBextractor (HIP): %s failed: %d (%s) -- this build needs an MI355X, there is no CPU fallback\n", what, rc, orbhip_last_error());
+    std::abort();
 }
 
 ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST)
     : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST),
-      ctx_(nullptr), ext_(nullptr)
+      ctx_(nullptr), ext_(nullptr), stageW_(0), stageH_(0), cap_(0), syncPyramid_(true)
 {
-    chk(orbhip_ctx_create(0, nullptr, &ctx_), "orbhip_ctx_create");        // fails loudly without a GPU
-    chk(orbhip_extractor_create(ctx_, _nfeatures, _scaleFactor, _nlevels, _iniThFAST, _minThFAST, &ext_), "orbhip_extractor_create");
+    int rc = orbhip_ctx_create(0, nullptr, &ctx_);                          // one context (stream) per extractor instance: Frame.cc:109-110
+    if (rc != ORBHIP_OK) die(rc, "orbhip_ctx_create");
+    rc = orbhip_extractor_create(ctx_, _nfeatures, _scaleFactor, _nlevels, _iniThFAST, _minThFAST, &ext_);
+    if (rc != ORBHIP_OK) die(rc, "orbhip_extractor_create");
     mvScaleFactor.resize(nlevels); mvInvScaleFactor.resize(nlevels); mvLevelSigma2.resize(nlevels); mvInvLevelSigma2.resize(nlevels);
     orbhip_extractor_table(ext_, 0, mvScaleFactor.data());
     orbhip_extractor_table(ext_, 1, mvInvScaleFactor.data());
@@ -39,47 +45,63 @@ int ORBextractor::operator()(cv::InputArray image, cv::InputArray /*mask*/, std:
 {
 #ifdef ORBHIP_WITH_OPENCV
     cv::Mat img = image.getMat();
-    if (img.empty()) return -1;
 #else
     const cv::Mat &img = image;
-    if (img.empty()) return -1;
 #endif
-    chk(orbhip_extractor_reserve(ext_, img.cols, img.rows, 1), "orbhip_extractor_reserve");
-    const int cap = orbhip_extractor_max_keypoints(ext_);
-    std::vector<orbhip_keypoint> kp(cap);
-    std::vector<uint8_t> desc((size_t)cap * 32);
+    if (img.empty()) return -1;                                             // ORBextractor.cc:1072-1073
+    if (img.cols != stageW_ || img.rows != stageH_) {                       // device buffers + staging rows: once per image size
+        const int rc = orbhip_extractor_reserve(ext_, img.cols, img.rows, 1);
+        if (rc != ORBHIP_OK) { fprintf(stderr, "ORBextractor (HIP): reserve %dx%d: %d (%s)\n", img.cols, img.rows, rc, orbhip_last_error()); return -1; }
+        cap_ = orbhip_extractor_max_keypoints(ext_);
+        kpStage_.resize(cap_); descStage_.resize((size_t)cap_ * 32);
+        stageW_ = img.cols; stageH_ = img.rows;
+    }
     int32_t count = 0, mono = 0;
-    int rc = orbhip_extract_batch_host(ext_, img.data, img.cols, img.rows, img.step, img.step * img.rows, 1, vLappingArea[0],
-                                       vLappingArea[1], kp.data(), desc.data(), cap, &count, &mono);
-    if (rc == ORBHIP_E_EMPTY) return -1;
-    chk(rc, "orbhip_extract_batch_host");
-    keypoints.resize(count);
+    const int rc = orbhip_extract_batch_host(ext_, img.data, img.cols, img.rows, img.step, img.step * img.rows, 1, vLappingArea[0],
+                                             vLappingArea[1], kpStage_.data(), descStage_.data(), cap_, &count, &mono);
+    if (rc != ORBHIP_OK) {
+        if (rc != ORBHIP_E_EMPTY) fprintf(stderr, "ORBextractor (HIP): extract: %d (%s)\n", rc, orbhip_last_error());
+        keypoints.clear(); descriptors.release();
+        return -1;
+    }
     static_assert(sizeof(cv::KeyPoint) == sizeof(orbhip_keypoint), "KeyPoint layout");
-    if (count) memcpy((void *)keypoints.data(), kp.data(), sizeof(orbhip_keypoint) * count);
+    keypoints.resize(count);                                                // _keypoints = vector<cv::KeyPoint>(nkeypoints), :1100
+    if (count) memcpy((void *)keypoints.data(), kpStage_.data(), sizeof(orbhip_keypoint) * count);
+    if (count == 0) descriptors.release();                                  // :1090-1091
+    else {
+        descriptors.create(count, 32, CV_8U);                               // :1094
 #ifdef ORBHIP_WITH_OPENCV
-    if (count == 0) descriptors.release();
-    else { descriptors.create(count, 32, CV_8U); memcpy(descriptors.getMat().data, desc.data(), (size_t)count * 32); }
+        memcpy(descriptors.getMat().data, descStage_.data(), (size_t)count * 32);
 #else
-    if (count == 0) descriptors.release();
-    else { descriptors.create(count, 32, cv::CV_8U); memcpy(descriptors.data, desc.data(), (size_t)count * 32); }
+        memcpy(descriptors.data, descStage_.data(), (size_t)count * 32);
 #endif
+    }
+    if (syncPyramid_) SyncImagePyramid();
     return mono;
 }
 
 void ORBextractor::SyncImagePyramid()
 {
     padded_.resize(nlevels);
+    std::vector<uint8_t *> lv(nlevels);
+    std::vector<size_t> st(nlevels);
+    std::vector<int> ws(nlevels), hs(nlevels);
     for (int l = 0; l < nlevels; l++) {
-        int w = 0, h = 0;
-        chk(orbhip_extractor_level_dims(ext_, l, &w, &h), "orbhip_extractor_level_dims");
-        const int pw = w + 38, ph = h + 38;
-        padded_[l].resize((size_t)pw * ph);
-        chk(orbhip_extractor_get_pyramid_level(ext_, 0, l, 1, padded_[l].data(), pw), "orbhip_extractor_get_pyramid_level");
+        if (orbhip_extractor_level_dims(ext_, l, &ws[l], &hs[l]) != ORBHIP_OK) return;          // nothing extracted yet
+        const size_t need = (size_t)(ws[l] + 38) * (hs[l] + 38);
+        if (padded_[l].size() != need) padded_[l].resize(need);
+        lv[l] = padded_[l].data(); st[l] = (size_t)ws[l] + 38;
+    }
+    const int rc = orbhip_extractor_get_pyramid_padded(ext_, 0, lv.data(), st.data());
+    if (rc != ORBHIP_OK) { fprintf(stderr, "ORBextractor (HIP): pyramid copy-out: %d (%s)\n", rc, orbhip_last_error()); return; }
+    for (int l = 0; l < nlevels; l++) {
+        const int pw = ws[l] + 38, ph = hs[l] + 38;
         // ROI view at (19,19) inside the reflect-101 padded parent, like ORBextractor.cc:1160
 #ifdef ORBHIP_WITH_OPENCV
-        mvImagePyramid[l] = cv::Mat(ph, pw, CV_8U, padded_[l].data(), pw)(cv::Rect(19, 19, w, h));
+        mvImagePyramid[l] = cv::Mat(ph, pw, CV_8U, padded_[l].data(), pw)(cv::Rect(19, 19, ws[l], hs[l]));
 #else
-        mvImagePyramid[l] = cv::Mat(h, w, cv::CV_8U, padded_[l].data() + (size_t)19 * pw + 19, pw);
+        (void)ph;
+        mvImagePyramid[l] = cv::Mat(hs[l], ws[l], CV_8U, padded_[l].data() + (size_t)19 * pw + 19, pw);
 #endif
     }
 }

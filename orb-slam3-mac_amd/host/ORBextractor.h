@@ -32,11 +32,14 @@ public:
     std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
     std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
 
-    // PUBLIC in the reference (include/ORBextractor.h:83), read by Frame::ComputeStereoMatches
-    // (src/Frame.cc:809,899,913,918).  Filled lazily: call SyncImagePyramid() after operator() when
-    // the rectified-stereo path needs it; levels are the ROI views of padded buffers.
+    // PUBLIC in the reference (include/ORBextractor.h:83), read by Frame::ComputeStereoMatches (src/Frame.cc:809,899,913,918)
+    // right after operator() with no further call: operator() fills it itself -- level l is the w_l x h_l ROI at (19,19) of a
+    // reflect-101 padded (w_l+38) x (h_l+38) parent, as ORBextractor.cc:1160-1173 builds it.  That costs one device-to-host
+    // copy of the pyramid per call; callers that never read it (monocular / fisheye tracking, or stereo through
+    // orbhip_compute_stereo_matches_device, which reads the device pyramids) switch it off with SetImagePyramidSync(false).
     std::vector<cv::Mat> mvImagePyramid;
-    void SyncImagePyramid();
+    void SetImagePyramidSync(bool on) { syncPyramid_ = on; }
+    void SyncImagePyramid();                       // explicit refresh (the opt-out case)
 
 protected:
     int nfeatures; double scaleFactor; int nlevels; int iniThFAST; int minThFAST;
@@ -47,7 +50,11 @@ protected:
 private:
     orbhip_ctx *ctx_;
     orbhip_extractor *ext_;
-    std::vector<std::vector<uint8_t>> padded_;     // backing store of mvImagePyramid
+    std::vector<std::vector<uint8_t>> padded_;     // backing store of mvImagePyramid (kept across calls)
+    std::vector<orbhip_keypoint> kpStage_;         // staging of the C ABI's output rows (kept across calls, sized once per image size)
+    std::vector<uint8_t> descStage_;
+    int stageW_, stageH_, cap_;
+    bool syncPyramid_;
     ORBextractor(const ORBextractor &);            // one instance = one device context (not copyable)
     ORBextractor &operator=(const ORBextractor &);
 };

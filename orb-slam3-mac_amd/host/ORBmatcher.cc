@@ -1,0 +1,184 @@
+// ORBmatcher.cc -- host side of the signature-preserving ORBmatcher (see header).  Each method keeps the reference's per-point
+// host loop up to the point where it would call Frame::GetFeaturesInArea, turns every surviving point into one
+// orbhip_proj_query, and hands the whole frame to the device: grid, window query, descriptor distances, claim rule
+// (ORBmatcher.cc:110-112, 2037-2039), thresholds / ratio tests and the rotation histogram run in k_search_by_projection /
+// k_search_init.  Frames of a fisheye rig (Nleft != -1) are handled by the rig entry points (see SearchByProjection below).
+#include "ORBmatcher.h"
+#include <cstdio>
+#include <cstdlib>
+
+namespace ORB_SLAM3 {
+
+const int ORBmatcher::TH_HIGH = 100;
+const int ORBmatcher::TH_LOW = 50;
+const int ORBmatcher::HISTO_LENGTH = 30;
+
+namespace {
+struct Ctx {                // one device context per calling thread: matcher objects are stack temporaries in Tracking,
+    orbhip_ctx *h;          // LocalMapping and LoopClosing, which run concurrently (SURVEY 8b "Threading")
+    Ctx() : h(nullptr) {}
+    ~Ctx() { if (h) orbhip_ctx_destroy(h); }
+};
+orbhip_ctx *thread_ctx()
+{
+    static thread_local Ctx c;
+    if (!c.h) {
+        const int rc = orbhip_ctx_create(0, nullptr, &c.h);
+        if (rc != ORBHIP_OK) { fprintf(stderr, "ORBmatcher (HIP): no device context: %d (%s) -- there is no CPU fallback\n", rc, orbhip_last_error()); std::abort(); }
+    }
+    return c.h;
+}
+
+static_assert(sizeof(cv::KeyPoint) == sizeof(orbhip_keypoint), "KeyPoint layout");
+
+// x3Dc = Rcw * x3Dw + tcw on CV_32F matrices: cv::gemm accumulates float products in double and rounds the sum once
+inline void transform(const cv::Mat &T, const cv::Mat &Xw, float (&Xc)[3])
+{
+    for (int i = 0; i < 3; i++) {
+        double a = 0;
+        for (int k = 0; k < 3; k++) a += (double)T.at<float>(i, k) * (double)Xw.at<float>(k);
+        Xc[i] = (float)(a + (double)T.at<float>(i, 3));
+    }
+}
+
+// mvpMapPoints as the kernels' claim array: -1 = free (no map point, or one without observations: ORBmatcher.cc:110-112)
+void claims_from(const std::vector<MapPoint *> &mps, int n, std::vector<int32_t> &tm)
+{
+    tm.resize(n);
+    for (int i = 0; i < n; i++) tm[i] = (mps[i] && mps[i]->Observations() > 0) ? -2 : -1;
+}
+}  // namespace
+
+ORBmatcher::ORBmatcher(float nnratio, bool checkOri) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+
+int ORBmatcher::DescriptorDistance(const cv::Mat &a, const cv::Mat &b) { return orbhip_descriptor_distance(a.ptr<uint8_t>(), b.ptr<uint8_t>()); }
+
+float ORBmatcher::RadiusByViewingCos(const float &viewCos)
+{
+    if (viewCos > 0.998) return 2.5;
+    else return 4.0;
+}
+
+int ORBmatcher::SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMapPoints, const float th, const bool bFarPoints, const float thFarPoints)
+{
+    if (F.Nleft != -1) { fprintf(stderr, "ORBmatcher (HIP): SearchByProjection(Frame, MapPoints) on a fisheye rig frame: use orbhip_search_local_map_rig_device\n"); return 0; }
+    const bool bFactor = th != 1.0;
+    std::vector<orbhip_proj_query> q;
+    std::vector<uint8_t> dq;
+    std::vector<MapPoint *> owner;
+    q.reserve(vpMapPoints.size()); dq.reserve(vpMapPoints.size() * 32); owner.reserve(vpMapPoints.size());
+    for (size_t iMP = 0; iMP < vpMapPoints.size(); iMP++) {                       // ORBmatcher.cc:54-79
+        MapPoint *pMP = vpMapPoints[iMP];
+        if (!pMP->mbTrackInView && !pMP->mbTrackInViewR) continue;
+        if (bFarPoints && pMP->mTrackDepth > thFarPoints) continue;
+        if (pMP->isBad()) continue;
+        if (pMP->mbTrackInView) {
+            const int &nPredictedLevel = pMP->mnTrackScaleLevel;
+            // The size of the window will depend on the viewing direction
+            float r = RadiusByViewingCos(pMP->mTrackViewCos);
+            if (bFactor) r *= th;
+            orbhip_proj_query e;
+            e.u = pMP->mTrackProjX; e.v = pMP->mTrackProjY; e.radius = r * F.mvScaleFactors[nPredictedLevel];
+            e.ur = pMP->mTrackProjXR; e.angle = 0.f;
+            e.min_level = nPredictedLevel - 1; e.max_level = nPredictedLevel;
+            e.has_obs = pMP->Observations() > 0;
+            q.push_back(e); owner.push_back(pMP);
+            const cv::Mat MPdescriptor = pMP->GetDescriptor();
+            dq.insert(dq.end(), MPdescriptor.ptr<uint8_t>(), MPdescriptor.ptr<uint8_t>() + 32);
+        }
+    }
+    const int n = F.N;
+    std::vector<int32_t> tm;
+    claims_from(F.mvpMapPoints, n, tm);
+    int32_t nmatches = 0;
+    const int rc = orbhip_search_by_projection_host(thread_ctx(), 1, q.data(), dq.data(), (int)q.size(), (const orbhip_keypoint *)F.mvKeysUn.data(),
+                                                    F.mDescriptors.ptr<uint8_t>(), F.mvuRight.empty() ? nullptr : F.mvuRight.data(), n, Frame::mnMinX,
+                                                    Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY, TH_HIGH, mfNNratio, 0, tm.data(), &nmatches);
+    if (rc != ORBHIP_OK) { fprintf(stderr, "ORBmatcher (HIP): SearchByProjection: %d (%s)\n", rc, orbhip_last_error()); return 0; }
+    for (int i = 0; i < n; i++) if (tm[i] >= 0) F.mvpMapPoints[i] = owner[tm[i]];  // F.mvpMapPoints[bestIdx]=pMP, :140
+    return nmatches;
+}
+
+int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono)
+{
+    if (CurrentFrame.Nleft != -1) { fprintf(stderr, "ORBmatcher (HIP): SearchByProjection(Frame, Frame) on a fisheye rig frame: use orbhip_search_by_projection_rig_device\n"); return 0; }
+    // twc = -Rcw^T tcw ; tlc = Rlw twc + tlw (ORBmatcher.cc:1976-1984), CV_32F matrix products (double accumulation, one rounding each)
+    float twc[3], tlc[3];
+    for (int i = 0; i < 3; i++) {
+        double a = 0;
+        for (int k = 0; k < 3; k++) a += (double)(-CurrentFrame.mTcw.at<float>(k, i)) * (double)CurrentFrame.mTcw.at<float>(k, 3);
+        twc[i] = (float)a;
+    }
+    for (int i = 0; i < 3; i++) {
+        double a = 0;
+        for (int k = 0; k < 3; k++) a += (double)LastFrame.mTcw.at<float>(i, k) * (double)twc[k];
+        tlc[i] = (float)(a + (double)LastFrame.mTcw.at<float>(i, 3));
+    }
+    const bool bForward = tlc[2] > CurrentFrame.mb && !bMono;
+    const bool bBackward = -tlc[2] > CurrentFrame.mb && !bMono;
+
+    std::vector<orbhip_proj_query> q;
+    std::vector<uint8_t> dq;
+    std::vector<MapPoint *> owner;
+    for (int i = 0; i < LastFrame.N; i++) {                                        // :1989-2023
+        MapPoint *pMP = LastFrame.mvpMapPoints[i];
+        if (!pMP) continue;
+        if (LastFrame.mvbOutlier[i]) continue;
+        // Project
+        float x3Dc[3];
+        transform(CurrentFrame.mTcw, pMP->GetWorldPos(), x3Dc);
+        const float invzc = 1.0 / x3Dc[2];
+        if (invzc < 0) continue;
+        cv::Mat m3D(3, 1, CV_32F);
+        for (int k = 0; k < 3; k++) m3D.at<float>(k) = x3Dc[k];
+        cv::Point2f uv = CurrentFrame.mpCamera->project(m3D);
+        if (uv.x < CurrentFrame.mnMinX || uv.x > CurrentFrame.mnMaxX) continue;
+        if (uv.y < CurrentFrame.mnMinY || uv.y > CurrentFrame.mnMaxY) continue;
+        int nLastOctave = (LastFrame.Nleft == -1 || i < LastFrame.Nleft) ? LastFrame.mvKeys[i].octave : LastFrame.mvKeysRight[i - LastFrame.Nleft].octave;
+        // Search in a window. Size depends on scale
+        float radius = th * CurrentFrame.mvScaleFactors[nLastOctave];
+        orbhip_proj_query e;
+        e.u = uv.x; e.v = uv.y; e.radius = radius;
+        e.ur = uv.x - CurrentFrame.mbf * invzc;                                   // :2043
+        const cv::KeyPoint &kpLF = (LastFrame.Nleft == -1) ? LastFrame.mvKeysUn[i] : (i < LastFrame.Nleft) ? LastFrame.mvKeys[i] : LastFrame.mvKeysRight[i - LastFrame.Nleft];
+        e.angle = kpLF.angle;                                                     // :2067-2073
+        if (bForward) { e.min_level = nLastOctave; e.max_level = -1; }            // GetFeaturesInArea(.., nLastOctave)
+        else if (bBackward) { e.min_level = 0; e.max_level = nLastOctave; }
+        else { e.min_level = nLastOctave - 1; e.max_level = nLastOctave + 1; }
+        e.has_obs = pMP->Observations() > 0;
+        q.push_back(e); owner.push_back(pMP);
+        const cv::Mat dMP = pMP->GetDescriptor();
+        dq.insert(dq.end(), dMP.ptr<uint8_t>(), dMP.ptr<uint8_t>() + 32);
+    }
+    const int n = CurrentFrame.N;
+    std::vector<int32_t> tm;
+    claims_from(CurrentFrame.mvpMapPoints, n, tm);
+    int32_t nmatches = 0;
+    const int rc = orbhip_search_by_projection_host(thread_ctx(), 0, q.data(), dq.data(), (int)q.size(), (const orbhip_keypoint *)CurrentFrame.mvKeysUn.data(),
+                                                    CurrentFrame.mDescriptors.ptr<uint8_t>(), CurrentFrame.mvuRight.empty() ? nullptr : CurrentFrame.mvuRight.data(),
+                                                    n, Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY, TH_HIGH, 0.f, mbCheckOrientation ? 1 : 0,
+                                                    tm.data(), &nmatches);
+    if (rc != ORBHIP_OK) { fprintf(stderr, "ORBmatcher (HIP): SearchByProjection: %d (%s)\n", rc, orbhip_last_error()); return 0; }
+    // A keypoint taken in this call holds the taker's map point.  One that was taken and then dropped by the rotation check comes
+    // back as free (-1): the reference sets it to NULL (:2170), which it already is at the reference's call sites
+    // (Tracking::TrackWithMotionModel fills mvpMapPoints with NULL before both calls, src/Tracking.cc:1901, 1917).
+    for (int i = 0; i < n; i++)
+        if (tm[i] >= 0) CurrentFrame.mvpMapPoints[i] = owner[tm[i]];
+    return nmatches;
+}
+
+int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Point2f> &vbPrevMatched, std::vector<int> &vnMatches12, int windowSize)
+{
+    const int n1 = F1.mvKeysUn.size(), n2 = F2.mvKeysUn.size();
+    vnMatches12 = std::vector<int>(n1, -1);                                        // :713
+    static_assert(sizeof(cv::Point2f) == 8 && sizeof(int) == 4, "layout");
+    int32_t nmatches = 0;
+    const int rc = orbhip_search_for_initialization_host(thread_ctx(), (const orbhip_keypoint *)F1.mvKeysUn.data(), F1.mDescriptors.ptr<uint8_t>(), n1,
+                                                         (const orbhip_keypoint *)F2.mvKeysUn.data(), F2.mDescriptors.ptr<uint8_t>(), n2, Frame::mnMinX,
+                                                         Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY, windowSize, mfNNratio, mbCheckOrientation ? 1 : 0,
+                                                         (float *)vbPrevMatched.data(), (int32_t *)vnMatches12.data(), &nmatches);
+    if (rc != ORBHIP_OK) { fprintf(stderr, "ORBmatcher (HIP): SearchForInitialization: %d (%s)\n", rc, orbhip_last_error()); return 0; }
+    return nmatches;
+}
+
+}  // namespace ORB_SLAM3

@@ -1,27 +1,46 @@
-// ORBmatcher.h -- host mirror of the ORBmatcher entry points that have a HIP implementation
-// (reference include/ORBmatcher.h:39-88).  DescriptorDistance is the same static function;
-// SearchForInitialization keeps the reference's argument meaning but takes plain keypoint /
-// descriptor arrays instead of Frame objects (Frame is the caller, out of scope: SURVEY 8b).
+// ORBmatcher.h -- signature-preserving host mirror of ORB_SLAM3::ORBmatcher (reference include/ORBmatcher.h:39-88) for the
+// methods whose search runs in a HIP kernel behind the C ABI: Tracking calls them unchanged
+//   SearchByProjection(Frame&, const vector<MapPoint*>&, th, bFarPoints, thFarPoints)   src/Tracking.cc:3096  (TrackLocalMap)
+//   SearchByProjection(Frame&, const Frame&, th, bMono)                                  src/Tracking.cc:2683  (TrackWithMotionModel)
+//   SearchForInitialization(Frame&, Frame&, vbPrevMatched, vnMatches12, windowSize)      src/Tracking.cc:1506  (MonocularInitialization)
+//   DescriptorDistance(a, b)
+// The per-point host geometry in front of each search (projection, frustum record, radius, level range) is kept as the
+// reference writes it; the windowed best / second-best search with the claim rule, the ratio tests and the rotation
+// histogram run on the device.  The remaining searches (BoW, triangulation, Fuse, Sim3) have batched device entry points in
+// include/orbhip.h and INTEGRATION.md shows their call sites; their class methods are not mirrored here.
 #pragma once
 #include <vector>
-#include "cvlite.h"
-#ifdef ORBHIP_WITH_OPENCV
-#include <opencv2/core.hpp>
-#endif
+#include "slam_types.h"
 #include "../../include/orbhip.h"
 
 namespace ORB_SLAM3 {
 
 class ORBmatcher {
 public:
-    ORBmatcher(float nnratio = 0.6, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+    ORBmatcher(float nnratio = 0.6, bool checkOri = true);
 
     // Computes the Hamming distance between two ORB descriptors (ORBmatcher.cc:2353-2369).
-    static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b) { return orbhip_descriptor_distance(a.ptr<uint8_t>(), b.ptr<uint8_t>()); }
+    static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b);
 
-    static const int TH_LOW = 50;        // ORBmatcher.cc:41
-    static const int TH_HIGH = 100;      // ORBmatcher.cc:40
-    static const int HISTO_LENGTH = 30;  // ORBmatcher.cc:42
+    // Search matches between Frame keypoints and projected MapPoints. Returns number of matches.
+    // Used to track the local map (Tracking)                                   include/ORBmatcher.h:49, src/ORBmatcher.cc:48-218
+    int SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMapPoints, const float th = 3, const bool bFarPoints = false,
+                           const float thFarPoints = 50.0f);
+
+    // Project MapPoints tracked in last frame into the current frame and search matches.
+    // Used to track from previous frame (Tracking)                             include/ORBmatcher.h:53, src/ORBmatcher.cc:1965-2181
+    int SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono);
+
+    // Matching for the Map Initialization (only used in the monocular case)    include/ORBmatcher.h:66, src/ORBmatcher.cc:710-825
+    int SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Point2f> &vbPrevMatched, std::vector<int> &vnMatches12,
+                                int windowSize = 10);
+
+    static const int TH_LOW;         // 50   ORBmatcher.cc:41
+    static const int TH_HIGH;        // 100  ORBmatcher.cc:40
+    static const int HISTO_LENGTH;   // 30   ORBmatcher.cc:42
+
+protected:
+    float RadiusByViewingCos(const float &viewCos);        // ORBmatcher.cc:220-226
 
     float mfNNratio;
     bool mbCheckOrientation;

@@ -1,0 +1,14 @@
+// Optimizer.h -- signature-preserving host mirror of the ORB_SLAM3::Optimizer entry point on the hot path
+// (reference include/Optimizer.h:58).  LocalMapping (src/LocalMapping.cc:154) calls it unchanged.
+#pragma once
+#include "slam_types.h"
+
+namespace ORB_SLAM3 {
+
+class Optimizer {
+public:
+    // reference include/Optimizer.h:58, src/Optimizer.cc:1699-2344
+    void static LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Map *pMap, int &num_fixedKF);
+};
+
+}  // namespace ORB_SLAM3

@@ -1,0 +1,285 @@
+// Optimizer_LocalBA.cc -- Optimizer::LocalBundleAdjustment(KeyFrame*, bool*, Map*, int&) with the reference's signature
+// (include/Optimizer.h:58) around the HIP solver.  The host parts of the reference function stay host code, restated here in
+// the reference's order (src/Optimizer.cc): window selection :1703-1761, fixed keyframes :1763-1819 incl. the ">= 2 fixed"
+// rule, abort check :2041-2043, outlier list :2126-2173, ">= 50 % outliers" bail-out :2177-2181, locked erase + write-back
+// :2204-2343.  What was the g2o block (:1828-2039 graph build, :2045-2122 optimize(5) / optimize(10)) is SoA packing in
+// exactly the insertion order of :1850-2034 plus ONE call of orbhip_ba_solve_batch (LM + Schur on the device).
+// Not carried over: the "Too much distance" statistics of :2261-2313 (Verbose prints at VERBOSITY_DEBUG only) and the
+// unreachable bRedrawError file dump (:2183-2200, :2209-2251: behind a `return`).
+#include "Optimizer.h"
+#include <cstdio>
+#include <list>
+#include <utility>
+#include "../../include/orbhip.h"
+
+namespace ORB_SLAM3 {
+
+namespace {
+
+// Converter::toSE3Quat (src/Converter.cc:34-44): float 4x4 -> double R, t -> g2o::SE3Quat(R, t), whose constructor
+// (Thirdparty/g2o/g2o/types/se3quat.h:58-60) builds Eigen::Quaterniond(R) and normalizeRotation() (:280-285: w >= 0, unit norm).
+void toSE3Quat(const cv::Mat &cvT, double *q7)
+{
+    double R[3][3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[i][j] = (double)cvT.at<float>(i, j);
+    double q[4];                                        // x, y, z, w
+    const double tr = R[0][0] + R[1][1] + R[2][2];
+    if (tr > 0) {
+        double s = std::sqrt(tr + 1.0);
+        q[3] = 0.5 * s; s = 0.5 / s;
+        q[0] = (R[2][1] - R[1][2]) * s; q[1] = (R[0][2] - R[2][0]) * s; q[2] = (R[1][0] - R[0][1]) * s;
+    } else {
+        int i = 0;
+        if (R[1][1] > R[0][0]) i = 1;
+        if (R[2][2] > R[i][i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        double s = std::sqrt(R[i][i] - R[j][j] - R[k][k] + 1.0);
+        q[i] = 0.5 * s; s = 0.5 / s;
+        q[3] = (R[k][j] - R[j][k]) * s; q[j] = (R[j][i] + R[i][j]) * s; q[k] = (R[k][i] + R[i][k]) * s;
+    }
+    if (q[3] < 0) for (double &v : q) v = -v;
+    const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int i = 0; i < 4; i++) q7[i] = q[i] / n;
+    for (int i = 0; i < 3; i++) q7[4 + i] = (double)cvT.at<float>(i, 3);
+}
+
+// Converter::toCvMat(g2o::SE3Quat) (src/Converter.cc:46-50, 60-68): to_homogeneous_matrix (Quaterniond::toRotationMatrix) -> CV_32F
+cv::Mat toCvMat(const double *q7)
+{
+    const double x = q7[0], y = q7[1], z = q7[2], w = q7[3];
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z, twx = tx * w, twy = ty * w, twz = tz * w;
+    const double txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    const double R[3][3] = {{1 - (tyy + tzz), txy - twz, txz + twy}, {txy + twz, 1 - (txx + tzz), tyz - twx}, {txz - twy, tyz + twx, 1 - (txx + tyy)}};
+    cv::Mat m = cv::Mat::eye(4, 4, CV_32F);
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) m.at<float>(i, j) = (float)R[i][j]; m.at<float>(i, 3) = (float)q7[4 + i]; }
+    return m;
+}
+
+struct Ctx {                // one device context per calling thread (LocalMapping's LBA may overlap LoopClosing's merge-LBA)
+    orbhip_ctx *h;
+    Ctx() : h(nullptr) {}
+    ~Ctx() { if (h) orbhip_ctx_destroy(h); }
+};
+orbhip_ctx *thread_ctx()
+{
+    static thread_local Ctx c;
+    if (!c.h && orbhip_ctx_create(0, nullptr, &c.h) != ORBHIP_OK) c.h = nullptr;
+    return c.h;
+}
+
+void camera_fields(GeometricCamera *cam, double &fx, double &fy, double &cx, double &cy, int32_t &model, double (&kb)[4])
+{
+    fx = cam->getParameter(0); fy = cam->getParameter(1); cx = cam->getParameter(2); cy = cam->getParameter(3);
+    model = cam->GetType() == cam->CAM_FISHEYE ? 1 : 0;
+    for (int i = 0; i < 4; i++) kb[i] = model ? (double)cam->getParameter(4 + i) : 0.0;
+}
+
+}  // namespace
+
+void Optimizer::LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Map *pMap, int &num_fixedKF)
+{
+    // Local KeyFrames: First Breath Search from Current Keyframe (:1703-1717)
+    std::list<KeyFrame *> lLocalKeyFrames;
+    lLocalKeyFrames.push_back(pKF);
+    pKF->mnBALocalForKF = pKF->mnId;
+    Map *pCurrentMap = pKF->GetMap();
+
+    const std::vector<KeyFrame *> vNeighKFs = pKF->GetVectorCovisibleKeyFrames();
+    for (int i = 0, iend = vNeighKFs.size(); i < iend; i++) {
+        KeyFrame *pKFi = vNeighKFs[i];
+        pKFi->mnBALocalForKF = pKF->mnId;
+        if (!pKFi->isBad() && pKFi->GetMap() == pCurrentMap) lLocalKeyFrames.push_back(pKFi);
+    }
+
+    // Local MapPoints seen in Local KeyFrames (:1719-1761)
+    num_fixedKF = 0;
+    std::list<MapPoint *> lLocalMapPoints;
+    for (std::list<KeyFrame *>::iterator lit = lLocalKeyFrames.begin(), lend = lLocalKeyFrames.end(); lit != lend; lit++) {
+        KeyFrame *pKFi = *lit;
+        if (pKFi->mnId == pMap->GetInitKFid()) num_fixedKF = 1;
+        std::vector<MapPoint *> vpMPs = pKFi->GetMapPointMatches();
+        for (std::vector<MapPoint *>::iterator vit = vpMPs.begin(), vend = vpMPs.end(); vit != vend; vit++) {
+            MapPoint *pMP = *vit;
+            if (pMP)
+                if (!pMP->isBad() && pMP->GetMap() == pCurrentMap)
+                    if (pMP->mnBALocalForKF != pKF->mnId) {
+                        lLocalMapPoints.push_back(pMP);
+                        pMP->mnBALocalForKF = pKF->mnId;
+                    }
+        }
+    }
+
+    // Fixed Keyframes. Keyframes that see Local MapPoints but that are not Local Keyframes (:1763-1780)
+    std::list<KeyFrame *> lFixedCameras;
+    for (std::list<MapPoint *>::iterator lit = lLocalMapPoints.begin(), lend = lLocalMapPoints.end(); lit != lend; lit++) {
+        std::map<KeyFrame *, std::tuple<int, int>> observations = (*lit)->GetObservations();
+        for (std::map<KeyFrame *, std::tuple<int, int>>::iterator mit = observations.begin(), mend = observations.end(); mit != mend; mit++) {
+            KeyFrame *pKFi = mit->first;
+            if (pKFi->mnBALocalForKF != pKF->mnId && pKFi->mnBAFixedForKF != pKF->mnId) {
+                pKFi->mnBAFixedForKF = pKF->mnId;
+                if (!pKFi->isBad() && pKFi->GetMap() == pCurrentMap) lFixedCameras.push_back(pKFi);
+            }
+        }
+    }
+    num_fixedKF = lFixedCameras.size() + num_fixedKF;
+    if (num_fixedKF < 2) {
+        // "We set 2 KFs to fixed to avoid a degree of freedom in scale" (:1782-1817).  The reference reads pLowerKf / pSecondLowerKF
+        // uninitialised when the window has no candidate; here a missing candidate is simply not fixed.
+        std::list<KeyFrame *>::iterator lit = lLocalKeyFrames.begin();
+        int lowerId = pKF->mnId;
+        KeyFrame *pLowerKf = nullptr;
+        int secondLowerId = pKF->mnId;
+        KeyFrame *pSecondLowerKF = nullptr;
+        for (; lit != lLocalKeyFrames.end(); lit++) {
+            KeyFrame *pKFi = *lit;
+            if (pKFi == pKF || pKFi->mnId == pMap->GetInitKFid()) continue;
+            if ((int)pKFi->mnId < lowerId) { lowerId = pKFi->mnId; pLowerKf = pKFi; }
+            else if ((int)pKFi->mnId < secondLowerId) { secondLowerId = pKFi->mnId; pSecondLowerKF = pKFi; }
+        }
+        if (pLowerKf) { lFixedCameras.push_back(pLowerKf); lLocalKeyFrames.remove(pLowerKf); num_fixedKF++; }
+        if (num_fixedKF < 2 && pSecondLowerKF) { lFixedCameras.push_back(pSecondLowerKF); lLocalKeyFrames.remove(pSecondLowerKF); num_fixedKF++; }
+    }
+
+    // ---- SoA packing in the vertex / edge insertion order of :1850-2034 (was: the g2o graph) -------------------------------
+    std::map<KeyFrame *, int> kfIndex;
+    std::vector<KeyFrame *> vpKFs;
+    std::vector<uint8_t> fixed;
+    for (KeyFrame *pKFi : lLocalKeyFrames) { kfIndex[pKFi] = vpKFs.size(); vpKFs.push_back(pKFi); fixed.push_back(pKFi->mnId == pMap->GetInitKFid()); }   // :1850-1860
+    for (KeyFrame *pKFi : lFixedCameras) { kfIndex[pKFi] = vpKFs.size(); vpKFs.push_back(pKFi); fixed.push_back(1); }                                         // :1864-1874
+    const int nKF = vpKFs.size();
+    std::vector<double> poses((size_t)7 * nKF);
+    for (int i = 0; i < nKF; i++) toSE3Quat(vpKFs[i]->GetPose(), &poses[(size_t)7 * i]);
+
+    std::vector<MapPoint *> vpMPs(lLocalMapPoints.begin(), lLocalMapPoints.end());
+    const int nMP = vpMPs.size();
+    std::vector<double> points((size_t)3 * nMP);
+    std::vector<int32_t> ePose, ePoint; std::vector<double> obs, invS2; std::vector<uint8_t> eType;
+    std::vector<KeyFrame *> vpEdgeKF; std::vector<MapPoint *> vpEdgeMP;
+    size_t nMonoEdges = 0, nStereoEdges = 0;
+    KeyFrame *pRigKF = nullptr;
+    for (int l = 0; l < nMP; l++) {
+        MapPoint *pMP = vpMPs[l];
+        const cv::Mat Xw = pMP->GetWorldPos();                                        // Converter::toVector3d, :1923
+        for (int k = 0; k < 3; k++) points[(size_t)3 * l + k] = (double)Xw.at<float>(k);
+        const std::map<KeyFrame *, std::tuple<int, int>> observations = pMP->GetObservations();
+        for (std::map<KeyFrame *, std::tuple<int, int>>::const_iterator mit = observations.begin(), mend = observations.end(); mit != mend; mit++) {
+            KeyFrame *pKFi = mit->first;
+            if (pKFi->isBad() || pKFi->GetMap() != pCurrentMap) continue;             // :1937
+            std::map<KeyFrame *, int>::iterator ki = kfIndex.find(pKFi);
+            if (ki == kfIndex.end()) continue;                                        // (g2o: optimizer.vertex(id) == NULL -> addEdge refuses the edge)
+            const int leftIndex = std::get<0>(mit->second);
+            if (leftIndex != -1 && pKFi->mvuRight[leftIndex] < 0) {                   // Monocular observation (:1942-1968)
+                const cv::KeyPoint &kpUn = pKFi->mvKeysUn[leftIndex];
+                ePose.push_back(ki->second); ePoint.push_back(l); eType.push_back(0);
+                obs.push_back(kpUn.pt.x); obs.push_back(kpUn.pt.y); obs.push_back(0.0);
+                invS2.push_back((double)pKFi->mvInvLevelSigma2[kpUn.octave]);
+                vpEdgeKF.push_back(pKFi); vpEdgeMP.push_back(pMP); nMonoEdges++;
+            } else if (leftIndex != -1 && pKFi->mvuRight[leftIndex] >= 0) {           // Stereo observation (:1970-2000)
+                const cv::KeyPoint &kpUn = pKFi->mvKeysUn[leftIndex];
+                const float kp_ur = pKFi->mvuRight[leftIndex];
+                ePose.push_back(ki->second); ePoint.push_back(l); eType.push_back(1);
+                obs.push_back(kpUn.pt.x); obs.push_back(kpUn.pt.y); obs.push_back(kp_ur);
+                invS2.push_back((double)pKFi->mvInvLevelSigma2[kpUn.octave]);
+                vpEdgeKF.push_back(pKFi); vpEdgeMP.push_back(pMP); nStereoEdges++;
+            }
+            if (pKFi->mpCamera2) {                                                    // observation in the second camera (:2002-2032)
+                int rightIndex = std::get<1>(mit->second);
+                if (rightIndex != -1) {
+                    rightIndex -= pKFi->NLeft;
+                    const cv::KeyPoint kp = pKFi->mvKeysRight[rightIndex];
+                    ePose.push_back(ki->second); ePoint.push_back(l); eType.push_back(2);
+                    obs.push_back(kp.pt.x); obs.push_back(kp.pt.y); obs.push_back(0.0);
+                    invS2.push_back((double)pKFi->mvInvLevelSigma2[kp.octave]);
+                    vpEdgeKF.push_back(pKFi); vpEdgeMP.push_back(pMP);
+                    pRigKF = pKFi;
+                }
+            }
+        }
+    }
+    const int nE = ePose.size();
+
+    if (pbStopFlag)
+        if (*pbStopFlag) return;                                                      // :2041-2043
+
+    orbhip_ba_graph g;
+    memset(&g, 0, sizeof(g));
+    g.n_poses = nKF; g.n_points = nMP; g.n_edges = nE;
+    g.pose_fixed = fixed.data(); g.edge_pose = ePose.data(); g.edge_point = ePoint.data(); g.edge_obs = obs.data();
+    g.edge_inv_sigma2 = invS2.data(); g.edge_stereo = eType.data();
+    // every keyframe of a map shares the calibration (the reference hands each edge its keyframe's: :1961, :1990-1994)
+    camera_fields(pKF->mpCamera, g.fx, g.fy, g.cx, g.cy, g.camera_model, g.kb);
+    g.fx = pKF->fx; g.fy = pKF->fy; g.cx = pKF->cx; g.cy = pKF->cy; g.bf = pKF->mbf;
+    g.Trl[3] = 1.0;
+    if (pRigKF) {
+        cv::Mat T = cv::Mat::eye(4, 4, CV_32F);                                      // mTrl is 3x4 (Converter::toSE3Quat reads rows 0..2)
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) T.at<float>(i, j) = pRigKF->mTrl.at<float>(i, j);
+        toSE3Quat(T, g.Trl);
+        camera_fields(pRigKF->mpCamera2, g.fx2, g.fy2, g.cx2, g.cy2, g.camera2_model, g.kb2);
+    }
+    orbhip_ba_params p;
+    orbhip_ba_default_params(&p);                                                     // optimize(5) + optimize(10), Huber sqrt(5.991) / sqrt(7.815)
+    if (pMap->IsInertial()) p.user_lambda_init = 100.0;                               // :1837-1838
+    p.no_discard = 1;                                                                 // the bail-out is decided below, with the reference's own count
+
+    std::vector<uint8_t> outlier(nE ? nE : 1, 0);
+    orbhip_ba_stats st;
+    memset(&st, 0, sizeof(st));
+    if (nE > 0 && nKF > 0 && nMP > 0) {
+        orbhip_ctx *ctx = thread_ctx();
+        double *pp = poses.data(), *px = points.data();
+        uint8_t *po = outlier.data();
+        const int rc = ctx ? orbhip_ba_solve_batch(ctx, &g, 1, &p, (volatile const uint8_t *)pbStopFlag, &pp, &px, &po, &st) : ORBHIP_E_NODEVICE;
+        if (rc == ORBHIP_E_ABORTED) return;                                           // stop flag raised before the first iteration (:2041-2043)
+        if (rc != ORBHIP_OK) {
+            // the reference has no failure path here (g2o rejects a step it cannot solve and carries on): leave the map untouched
+            fprintf(stderr, "LM-LBA: HIP solver failed (%d: %s), map left unchanged\n", rc, orbhip_last_error());
+            return;
+        }
+    }
+
+    // Check inlier observations (:2122-2173): edges whose chi2 exceeds the gate or whose depth is not positive
+    std::vector<std::pair<KeyFrame *, MapPoint *>> vToErase;
+    vToErase.reserve(nE);
+    for (int pass = 0; pass < 3; pass++) {                                            // vpEdgesMono, then vpEdgesBody, then vpEdgesStereo
+        const uint8_t type = pass == 0 ? 0 : pass == 1 ? 2 : 1;
+        for (int e = 0; e < nE; e++) {
+            if (eType[e] != type) continue;
+            MapPoint *pMP = vpEdgeMP[e];
+            if (pMP->isBad()) continue;
+            if (outlier[e]) vToErase.push_back(std::make_pair(vpEdgeKF[e], pMP));
+        }
+    }
+    if (vToErase.size() >= (nMonoEdges + nStereoEdges) * 0.5) {
+        fprintf(stderr, "LM-LBA: ERROR IN THE OPTIMIZATION, MOST OF THE POINTS HAS BECOME OUTLIERS\n");   // :2177-2181
+        return;
+    }
+
+    // Get Map Mutex (:2204)
+    std::unique_lock<std::mutex> lock(pMap->mMutexMapUpdate);
+
+    if (!vToErase.empty()) {
+        for (size_t i = 0; i < vToErase.size(); i++) {                                // :2220-2226
+            KeyFrame *pKFi = vToErase[i].first;
+            MapPoint *pMPi = vToErase[i].second;
+            pKFi->EraseMapPointMatch(pMPi);
+            pMPi->EraseObservation(pKFi);
+        }
+    }
+
+    // Recover optimized data (:2254-2330)
+    for (std::list<KeyFrame *>::iterator lit = lLocalKeyFrames.begin(), lend = lLocalKeyFrames.end(); lit != lend; lit++) {
+        KeyFrame *pKFi = *lit;
+        pKFi->SetPose(toCvMat(&poses[(size_t)7 * kfIndex[pKFi]]));
+    }
+    for (int l = 0; l < nMP; l++) {
+        MapPoint *pMP = vpMPs[l];
+        cv::Mat X(3, 1, CV_32F);
+        for (int k = 0; k < 3; k++) X.at<float>(k) = (float)points[(size_t)3 * l + k];
+        pMP->SetWorldPos(X);
+        pMP->UpdateNormalAndDepth();
+    }
+
+    pMap->IncreaseChangeIndex();                                                      // :2343
+}
+
+}  // namespace ORB_SLAM3

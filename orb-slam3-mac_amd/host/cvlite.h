@@ -4,6 +4,7 @@
 // OpenCV's: cv::KeyPoint is 28 bytes {pt.x, pt.y, size, angle, response, octave, class_id}.
 #pragma once
 #ifndef ORBHIP_WITH_OPENCV
+#include <cstddef>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -40,8 +41,8 @@ public:
     bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
     int type() const { return type_; }
     size_t elemSize() const { return esz(type_); }
-    uint8_t *ptr(int r) { return data + (size_t)r * step; }
-    const uint8_t *ptr(int r) const { return data + (size_t)r * step; }
+    uint8_t *ptr(int r) { return data + (ptrdiff_t)r * (ptrdiff_t)step; }            // r may be negative inside a padded parent (ROI views)
+    const uint8_t *ptr(int r) const { return data + (ptrdiff_t)r * (ptrdiff_t)step; }
     template <typename T> const T *ptr(int r = 0) const { return reinterpret_cast<const T *>(data + (size_t)r * step); }
     template <typename T> T *ptr(int r = 0) { return reinterpret_cast<T *>(data + (size_t)r * step); }
     template <typename T> T &at(int r, int c) { return reinterpret_cast<T *>(data + (size_t)r * step)[c]; }

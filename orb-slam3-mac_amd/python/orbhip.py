@@ -57,6 +57,7 @@ lib.orbhip_extract_batch_host.argtypes = [vp, vp, ci, ci, sz, sz, ci, ci, ci, vp
 lib.orbhip_extractor_level_dims.argtypes = [vp, ci, C.POINTER(ci), C.POINTER(ci)]
 lib.orbhip_extractor_get_pyramid_level.argtypes = [vp, ci, ci, ci, vp, sz]
 lib.orbhip_extractor_get_blurred_level.argtypes = [vp, ci, ci, vp, sz]
+lib.orbhip_extractor_get_pyramid_padded.argtypes = [vp, ci, vp, vp]
 lib.orbhip_extractor_get_fast_candidates.argtypes = [vp, ci, ci, vp, vp, vp, ci, C.POINTER(C.c_int32)]
 lib.orbhip_extractor_get_level_keypoints.argtypes = [vp, ci, ci, vp, ci, C.POINTER(C.c_int32)]
 lib.orbhip_extractor_set_profiling.argtypes = [vp, ci]
@@ -194,6 +195,14 @@ class Extractor:
         _chk(lib.orbhip_extractor_get_pyramid_level(self.h, frame, level, 1 if padded else 0, out.ctypes.data, w),
              "get_pyramid_level")
         return out
+
+    def pyramid_padded(self, frame):
+        """All levels as (w+38) x (h+38) reflect-101 padded parents (what mvImagePyramid's ROI views live in)."""
+        outs = [np.zeros((h + 38, w + 38), np.uint8) for w, h in (self.level_dims(l) for l in range(self.nlevels))]
+        ptrs = (vp * self.nlevels)(*[o.ctypes.data for o in outs])
+        strides = (C.c_size_t * self.nlevels)(*[o.shape[1] for o in outs])
+        _chk(lib.orbhip_extractor_get_pyramid_padded(self.h, frame, ptrs, strides), "get_pyramid_padded")
+        return outs
 
     def blurred_level(self, frame, level):
         w, h = self.level_dims(level)

@@ -1,17 +1,360 @@
-"""The signature-preserving C++ host classes (orb-slam3-mac_amd/host) run end to end on the GPU."""
+"""The signature-preserving C++ host classes (orb-slam3-mac_amd/host) run end to end on the GPU:
+ORBextractor::operator() / mvImagePyramid, ORBmatcher::SearchByProjection (x2) / SearchForInitialization over Frame objects, and
+Optimizer::LocalBundleAdjustment(KeyFrame*, bool*, Map*, int&) over a KeyFrame / MapPoint / Map pointer graph -- each checked
+against the CPU oracle run on the same inputs (the C++ program only dumps what the classes did)."""
 import os
 import subprocess
+
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "orb-slam3-mac_amd", "lib", "host_smoke")
+
+
+def test_host_cpp_built():
+    assert os.path.exists(EXE)
 
 
 @pytest.mark.gpu
 def test_host_cpp_smoke():
-    exe = os.path.join(ROOT, "orb-slam3-mac_amd", "lib", "host_smoke")
-    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    r = subprocess.run([EXE], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
     assert r.returncode == 0 and "HOST_CPP_OK" in r.stdout, r.stdout
 
 
-def test_host_cpp_built():
-    assert os.path.exists(os.path.join(ROOT, "orb-slam3-mac_amd", "lib", "host_smoke"))
+# ------------------------------------------------------------------------------------------------ Optimizer::LocalBundleAdjustment
+def _R_from_quat(q):
+    import synth_ba
+    return synth_ba._R_from_quat(q)
+
+
+def _lba_case(seed, n_kf=50, n_pts=2000, obs=10, stereo_frac=0.0, n_cov=None, init_in_window=True, inertial=False):
+    """A keyframe window as LocalMapping would hand it over: the current keyframe (last one), its covisible keyframes, further
+    keyframes that only observe the window's points (they become lFixedCameras), float32 poses / points (cv::Mat CV_32F)."""
+    import synth_ba
+    g = synth_ba.make_graph(n_kf=n_kf, n_pts=n_pts, obs=obs, seed=seed, stereo_frac=stereo_frac, n_fixed=0, pose_noise=(0.003, 0.015))
+    rng = np.random.default_rng(seed + 7)
+    ids = (np.arange(n_kf) * 2 + 5).astype(np.int32)                  # mnId: ascending with the index, not contiguous
+    cur = n_kf - 1
+    T = np.zeros((n_kf, 4, 4), np.float32)
+    for i in range(n_kf):
+        T[i, :3, :3] = _R_from_quat(g["poses0"][i, :4]).astype(np.float32)
+        T[i, :3, 3] = g["poses0"][i, 4:].astype(np.float32)
+        T[i, 3, 3] = 1.0
+    # covisibility of the current keyframe: keyframes sharing points with it, best first
+    ep, el = g["edge_pose"], g["edge_point"]
+    seen_by_cur = np.zeros(n_pts, bool); seen_by_cur[el[ep == cur]] = True
+    w = np.array([np.count_nonzero(seen_by_cur[el[ep == k]]) for k in range(n_kf)]); w[cur] = -1
+    order = [int(k) for k in np.argsort(-w, kind="stable") if w[k] > 0]
+    cov = order[:n_cov] if n_cov is not None else order
+    init_id = int(ids[cov[-1]] if init_in_window else 1)              # 1: no keyframe carries that id
+    octave = np.round(-0.5 * np.log(g["edge_inv_sigma2"]) / np.log(1.2)).astype(np.int32)
+    inv_s2 = (np.float32(1.0) / (np.cumprod(np.concatenate([[np.float32(1.0)], np.full(7, np.float32(1.2))]).astype(np.float32)) ** 2)).astype(np.float32)
+    assert np.array_equal(inv_s2[octave].astype(np.float64), g["edge_inv_sigma2"])
+    obs3 = g["edge_obs"].astype(np.float32).copy()
+    obs3[g["edge_stereo"] == 0, 2] = -1.0
+    return dict(g=g, ids=ids, cur=cur, T=T, cov=np.array(cov, np.int32), init_id=init_id, octave=octave, inv_s2=inv_s2, obs3=obs3,
+                X=g["points0"].astype(np.float32), inertial=inertial, rng=rng)
+
+
+def _write_lba(path, c, abort=False):
+    g = c["g"]
+    with open(path, "wb") as f:
+        np.array([g["n_poses"], g["n_points"], g["n_edges"], c["cur"], c["init_id"], len(c["cov"]), int(c["inertial"]), int(abort)], np.int32).tofile(f)
+        np.array([g["fx"], g["fy"], g["cx"], g["cy"], g["bf"]], np.float32).tofile(f)
+        c["ids"].tofile(f); c["T"].tofile(f); c["cov"].tofile(f); c["X"].tofile(f)
+        g["edge_pose"].astype(np.int32).tofile(f); g["edge_point"].astype(np.int32).tofile(f); c["obs3"].tofile(f); c["octave"].tofile(f)
+        c["inv_s2"].tofile(f)
+
+
+def _read_lba(path, n_kf, n_pts):
+    with open(path, "rb") as f:
+        num_fixed = int(np.fromfile(f, np.int32, 1)[0])
+        T = np.fromfile(f, np.float32, n_kf * 16).reshape(n_kf, 4, 4)
+        X = np.fromfile(f, np.float32, n_pts * 3).reshape(n_pts, 3)
+        ne = int(np.fromfile(f, np.int32, 1)[0])
+        er = np.fromfile(f, np.int32, 2 * ne).reshape(ne, 2)
+        change, updates = (int(v) for v in np.fromfile(f, np.int32, 2))
+    return num_fixed, T, X, er, change, updates
+
+
+def _expected_window(c):
+    """Optimizer.cc:1703-1819 restated on the flat description: local keyframes (list order), local points (list order), fixed."""
+    g = c["g"]
+    ep, el = g["edge_pose"], g["edge_point"]
+    local = [c["cur"]] + [int(k) for k in c["cov"]]
+    num_fixed = 1 if any(int(c["ids"][k]) == c["init_id"] for k in local) else 0
+    # map points in the order the keyframes' match vectors list them (the generator's edges are point-major: a keyframe's
+    # keypoints were appended in edge order)
+    pts, seen = [], set()
+    for k in local:
+        for l in el[ep == k]:
+            if int(l) not in seen:
+                seen.add(int(l)); pts.append(int(l))
+    in_local = set(local)
+    obs_kfs = {}
+    for e in range(len(ep)):
+        obs_kfs.setdefault(int(el[e]), []).append(int(ep[e]))
+    fixed = []
+    for l in pts:
+        for k in obs_kfs[l]:                          # std::map<KeyFrame*, ...> order is by address: only the SET of fixed cameras is defined
+            if k not in in_local and k not in fixed:
+                fixed.append(k)
+    num_fixed += len(fixed)
+    if num_fixed < 2:
+        lower, second = c["ids"][c["cur"]], c["ids"][c["cur"]]
+        p_lower = p_second = None
+        for k in local:
+            if k == c["cur"] or int(c["ids"][k]) == c["init_id"]:
+                continue
+            if c["ids"][k] < lower:
+                lower, p_lower = c["ids"][k], k
+            elif c["ids"][k] < second:
+                second, p_second = c["ids"][k], k
+        if p_lower is not None:
+            fixed.append(p_lower); local.remove(p_lower); num_fixed += 1
+        if num_fixed < 2 and p_second is not None:
+            fixed.append(p_second); local.remove(p_second); num_fixed += 1
+    return local, fixed, pts, num_fixed
+
+
+def _expected_lba(c):
+    """The oracle on exactly the window the reference would optimise."""
+    import oracle_ba_bind as obb
+    import synth_ba
+    g = c["g"]
+    local, fixed, pts, num_fixed = _expected_window(c)
+    kfs = local + sorted(fixed)
+    kidx = {k: i for i, k in enumerate(kfs)}
+    pidx = {l: i for i, l in enumerate(pts)}
+    keep = [e for e in range(g["n_edges"]) if int(g["edge_pose"][e]) in kidx and int(g["edge_point"][e]) in pidx]
+    keep.sort(key=lambda e: (pidx[int(g["edge_point"][e])], e))
+    poses0 = np.zeros((len(kfs), 7))
+    for i, k in enumerate(kfs):
+        poses0[i, :4] = synth_ba._quat_from_R(c["T"][k, :3, :3].astype(np.float64))         # Converter::toSE3Quat
+        poses0[i, 4:] = c["T"][k, :3, 3].astype(np.float64)
+    pf = np.array([1 if (k in fixed or int(c["ids"][k]) == c["init_id"]) else 0 for k in kfs], np.uint8)
+    sub = dict(n_poses=len(kfs), n_points=len(pts), n_edges=len(keep), pose_fixed=pf,
+               edge_pose=np.array([kidx[int(g["edge_pose"][e])] for e in keep], np.int32),
+               edge_point=np.array([pidx[int(g["edge_point"][e])] for e in keep], np.int32),
+               edge_obs=np.where(g["edge_stereo"][keep, None] > 0, c["obs3"][keep].astype(np.float64), np.concatenate([c["obs3"][keep, :2], np.zeros((len(keep), 1), np.float32)], 1).astype(np.float64)),
+               edge_inv_sigma2=g["edge_inv_sigma2"][keep], edge_stereo=g["edge_stereo"][keep], fx=g["fx"], fy=g["fy"], cx=g["cx"], cy=g["cy"], bf=g["bf"],
+               poses0=poses0, points0=c["X"][pts].astype(np.float64))
+    p = obb.default_params()
+    p.no_discard = 1
+    if c["inertial"]:
+        p.user_lambda_init = 100.0
+    rc, poses, points, outl, st = obb.solve(sub, p)
+    erased = {(int(g["edge_pose"][e]), int(g["edge_point"][e])) for e, o in zip(keep, outl) if o}
+    n_ms = len(keep)
+    return dict(local=local, fixed=fixed, pts=pts, kfs=kfs, num_fixed=num_fixed, poses=poses, points=points, erased=erased,
+                bail=len(erased) >= 0.5 * n_ms, stats=st)
+
+
+def _check_lba(tmp_path, c):
+    import synth_ba
+    fin, fout = str(tmp_path / "lba.in"), str(tmp_path / "lba.out")
+    _write_lba(fin, c)
+    r = subprocess.run([EXE, "lba", fin, fout], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and "HOST_LBA_OK" in r.stdout, r.stdout
+    g = c["g"]
+    num_fixed, T, X, er, change, updates = _read_lba(fout, g["n_poses"], g["n_points"])
+    ex = _expected_lba(c)
+    assert num_fixed == ex["num_fixed"], (num_fixed, ex["num_fixed"])
+    assert not ex["bail"]
+    got_erased = {(int(a), int(b)) for a, b in er}
+    assert len(got_erased ^ ex["erased"]) <= max(2, len(ex["erased"]) // 200), (len(got_erased), len(ex["erased"]))
+    # free keyframes moved to the oracle's estimate (float32 write-back of a <= 1e-4 RMSE solution), everything else untouched
+    free = [k for i, k in enumerate(ex["kfs"]) if k in ex["local"] and int(c["ids"][k]) != c["init_id"]]
+    err_t, err_R = [], []
+    for k in free:
+        i = ex["kfs"].index(k)
+        Rw = synth_ba._R_from_quat(ex["poses"][i, :4])
+        err_R.append(np.abs(T[k, :3, :3] - Rw).max()); err_t.append(np.abs(T[k, :3, 3] - ex["poses"][i, 4:]).max())
+    assert np.sqrt(np.mean(np.square(err_t))) <= 1e-4 and np.sqrt(np.mean(np.square(err_R))) <= 1e-4, (max(err_t), max(err_R))
+    untouched = [k for k in range(g["n_poses"]) if k not in free]
+    assert np.array_equal(T[untouched], c["T"][untouched]), "fixed keyframes / keyframes outside the window must keep their pose bits"
+    assert np.sqrt(np.mean((X[ex["pts"]] - ex["points"]) ** 2)) <= 1e-4
+    outside = np.setdiff1d(np.arange(g["n_points"]), np.array(ex["pts"], np.int64))
+    assert np.array_equal(X[outside], c["X"][outside])
+    assert change == 1 and updates == len(ex["pts"])                       # IncreaseChangeIndex once, UpdateNormalAndDepth per local point
+    return ex
+
+
+@pytest.mark.gpu
+def test_local_bundle_adjustment_drop_in_50_keyframes(tmp_path):
+    """BASELINE config #4's window shape through the reference's own signature: 50 keyframes, 2000 points, 10 observations each;
+    35 covisible keyframes are optimised, the rest only observe local points and are fixed (Optimizer.cc:1763-1780)."""
+    c = _lba_case(seed=11, n_cov=35)
+    ex = _check_lba(tmp_path, c)
+    assert len(ex["local"]) == 36 and len(ex["fixed"]) >= 10 and ex["stats"]["iterations_run"][0] == 5
+
+
+@pytest.mark.gpu
+def test_local_bundle_adjustment_drop_in_two_fixed_rule_and_stereo(tmp_path):
+    """Every keyframe that sees the window's points is itself in the window and the map's first keyframe is elsewhere: the
+    'at least 2 fixed keyframes' rule (Optimizer.cc:1782-1817) picks the two lowest ids.  Stereo + monocular observations."""
+    c = _lba_case(seed=12, n_kf=14, n_pts=400, obs=6, stereo_frac=0.5, init_in_window=False)
+    ex = _check_lba(tmp_path, c)
+    assert ex["num_fixed"] == 2 and len(ex["fixed"]) == 2 and min(c["ids"][ex["fixed"]]) == c["ids"][0]
+
+
+@pytest.mark.gpu
+def test_local_bundle_adjustment_drop_in_abort_and_inertial(tmp_path):
+    """pbStopFlag already raised: the function returns before optimising and the map keeps its bits (Optimizer.cc:2041-2043);
+    an inertial map starts Levenberg-Marquardt at lambda = 100 (:1837-1838)."""
+    c = _lba_case(seed=13, n_kf=12, n_pts=300, obs=5, inertial=True)
+    fin, fout = str(tmp_path / "a.in"), str(tmp_path / "a.out")
+    _write_lba(fin, c, abort=True)
+    r = subprocess.run([EXE, "lba", fin, fout], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout
+    num_fixed, T, X, er, change, updates = _read_lba(fout, c["g"]["n_poses"], c["g"]["n_points"])
+    assert np.array_equal(T, c["T"]) and np.array_equal(X, c["X"]) and len(er) == 0 and change == 0 and updates == 0
+    _check_lba(tmp_path, c)
+
+
+# ------------------------------------------------------------------------------------------------ ORBmatcher methods
+def _f32(x):
+    return np.float32(x)
+
+
+def _match_case(seed, bMono, forward=0.0):
+    import oracle_match_bind as om
+    from oracle_bind import KP_DTYPE
+    rng = np.random.default_rng(seed)
+    n, nLast, nMap, nI = 900, 700, 800, 600
+    bounds = (0.0, 0.0, 640.0, 480.0)
+    fx, fy, cx, cy, mbf, mb, th, ratio = 458.0, 457.0, 320.0, 240.0, 40.0, 40.0 / 458.0, (15.0 if bMono else 7.0), 0.8
+    scales = np.cumprod(np.concatenate([[np.float32(1.0)], np.full(7, np.float32(1.2))]).astype(np.float32)).astype(np.float32)
+    kp = np.zeros(n, KP_DTYPE)
+    kp["x"] = rng.uniform(5, 635, n).astype(np.float32); kp["y"] = rng.uniform(5, 475, n).astype(np.float32)
+    kp["angle"] = rng.uniform(0, 360, n).astype(np.float32); kp["octave"] = rng.integers(0, 8, n); kp["size"] = 31; kp["class_id"] = -1
+    base = rng.integers(0, 256, (n // 5, 32), dtype=np.uint8)
+    d = base[rng.integers(0, len(base), n)].copy(); d[:, 1] ^= rng.integers(0, 8, n).astype(np.uint8)
+    ur = np.where(rng.random(n) < (0.0 if bMono else 0.6), kp["x"] - rng.uniform(1, 40, n), -1.0).astype(np.float32)
+    holder = rng.choice([-1, -1, -1, -1, 0, 1], n).astype(np.int32)
+    # current pose: small rotation about y + translation; last pose = current moved back by `forward` along z
+    a = 0.03
+    Tcw = np.eye(4, dtype=np.float32); Tcw[:3, :3] = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], np.float32)
+    Tcw[:3, 3] = np.array([0.1, -0.05, 0.2], np.float32)
+    Tlw = Tcw.copy(); Tlw[2, 3] += np.float32(forward)
+    # last frame: map points that project next to current keypoints
+    src = rng.integers(0, n, nLast)
+    kpL = kp[src].copy()
+    kpL["angle"] = ((kp["angle"][src] + rng.choice([0, 0, 0, 90, 200], nLast) + rng.normal(0, 3, nLast)) % 360).astype(np.float32)
+    z = rng.uniform(1.0, 12.0, nLast)
+    uu = kp["x"][src] + rng.normal(0, 3, nLast); vv = kp["y"][src] + rng.normal(0, 3, nLast)
+    Xc = np.stack([(uu - cx) / fx * z, (vv - cy) / fy * z, z], 1)
+    Xc[rng.random(nLast) < 0.03, 2] *= -1                                   # a few behind the camera
+    R, t = Tcw[:3, :3].astype(np.float64), Tcw[:3, 3].astype(np.float64)
+    Xw = ((Xc - t) @ R).astype(np.float32)                                   # R^T (Xc - t)
+    hasMP = (rng.random(nLast) < 0.85).astype(np.int32); outl = (rng.random(nLast) < 0.1).astype(np.int32)
+    nobs = rng.choice([0, 0, 3, 5], nLast).astype(np.int32)
+    dL = d[src].copy(); dL[:, 2] ^= rng.integers(0, 4, nLast).astype(np.uint8)
+    # local map points: Tracking's frustum record
+    msrc = rng.integers(0, n, nMap)
+    mp = np.zeros((nMap, 8), np.float32)
+    mp[:, 0] = kp["x"][msrc] + rng.normal(0, 2, nMap); mp[:, 1] = kp["y"][msrc] + rng.normal(0, 2, nMap)
+    mp[:, 2] = mp[:, 0] - rng.uniform(1, 40, nMap); mp[:, 3] = rng.choice([0.9, 0.9985, 0.9999], nMap); mp[:, 4] = rng.uniform(1, 60, nMap)
+    mp[:, 5] = np.clip(kp["octave"][msrc] + rng.integers(0, 2, nMap), 0, 7); mp[:, 6] = rng.random(nMap) < 0.9; mp[:, 7] = rng.choice([0, 2, 4], nMap)
+    dM = d[msrc].copy(); dM[:, 3] ^= rng.integers(0, 4, nMap).astype(np.uint8)
+    # initialisation pair
+    k1 = kp[:nI].copy(); k1["octave"] = rng.choice([0, 0, 0, 1, 2], nI); d1 = d[:nI].copy()
+    k2 = k1.copy(); k2["x"] += rng.normal(0, 6, nI).astype(np.float32); k2["y"] += rng.normal(0, 6, nI).astype(np.float32)
+    perm = rng.permutation(nI); k2 = k2[perm]; d2 = d1[perm].copy(); d2[:, 5] ^= rng.integers(0, 4, nI).astype(np.uint8)
+    prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
+    return dict(n=n, nLast=nLast, nMap=nMap, nI=nI, bMono=bMono, bounds=bounds, cam=(fx, fy, cx, cy), mbf=mbf, mb=mb, th=th, ratio=ratio,
+                scales=scales, kp=kp, d=d, ur=ur, holder=holder, Tcw=Tcw, Tlw=Tlw, kpL=kpL, hasMP=hasMP, outl=outl, nobs=nobs, Xw=Xw, dL=dL,
+                mp=mp, dM=dM, k1=k1, d1=d1, k2=k2, d2=d2, prev=prev, window=100)
+
+
+def _write_match(path, c):
+    with open(path, "wb") as f:
+        np.array([c["n"], c["nLast"], c["nMap"], int(c["bMono"]), c["nI"], c["nI"], c["window"], 0], np.int32).tofile(f)
+        np.array(list(c["bounds"]) + list(c["cam"]) + [c["mbf"], c["mb"], c["th"], c["ratio"]], np.float32).tofile(f)
+        c["scales"].tofile(f)
+        c["kp"].tofile(f); c["d"].tofile(f); c["ur"].tofile(f); c["holder"].tofile(f); c["Tcw"].tofile(f)
+        c["kpL"].tofile(f); c["Tlw"].tofile(f); c["hasMP"].tofile(f); c["outl"].tofile(f); c["nobs"].tofile(f); c["Xw"].tofile(f); c["dL"].tofile(f)
+        c["mp"].tofile(f); c["dM"].tofile(f)
+        c["k1"].tofile(f); c["d1"].tofile(f); c["k2"].tofile(f); c["d2"].tofile(f); c["prev"].tofile(f)
+
+
+def _expected_last_frame(c):
+    """ORBmatcher.cc:1976-2023 restated in numpy float32 (matrix products accumulate in double and round once, as cv::gemm),
+    then the claim-rule search of the oracle."""
+    import oracle_match_bind as om
+    fx, fy, cx, cy = (np.float32(v) for v in c["cam"])
+    Tcw, Tlw = c["Tcw"], c["Tlw"]
+    twc = np.array([np.float32(sum(np.float64(-Tcw[k, i]) * np.float64(Tcw[k, 3]) for k in range(3))) for i in range(3)], np.float32)
+    tlc = np.array([np.float32(sum(np.float64(Tlw[i, k]) * np.float64(twc[k]) for k in range(3)) + np.float64(Tlw[i, 3])) for i in range(3)], np.float32)
+    fwd = bool(tlc[2] > np.float32(c["mb"])) and not c["bMono"]
+    bwd = bool(-tlc[2] > np.float32(c["mb"])) and not c["bMono"]
+    q, dq, qsrc = [], [], []
+    for i in range(c["nLast"]):
+        if not c["hasMP"][i] or c["outl"][i]:
+            continue
+        X = c["Xw"][i]
+        xc = [np.float32(sum(np.float64(Tcw[r, k]) * np.float64(X[k]) for k in range(3)) + np.float64(Tcw[r, 3])) for r in range(3)]
+        invzc = np.float32(1.0 / np.float64(xc[2]))
+        if invzc < 0:
+            continue
+        u = np.float32(np.float32(np.float32(fx * xc[0]) / xc[2]) + cx); v = np.float32(np.float32(np.float32(fy * xc[1]) / xc[2]) + cy)
+        if u < c["bounds"][0] or u > c["bounds"][2] or v < c["bounds"][1] or v > c["bounds"][3]:
+            continue
+        octv = int(c["kpL"]["octave"][i])
+        radius = np.float32(np.float32(c["th"]) * c["scales"][octv])
+        lv = (octv, -1) if fwd else (0, octv) if bwd else (octv - 1, octv + 1)
+        q.append((u, v, radius, np.float32(u - np.float32(np.float32(c["mbf"]) * invzc)), c["kpL"]["angle"][i], lv[0], lv[1], int(c["nobs"][i] > 0)))
+        dq.append(c["dL"][i]); qsrc.append(i)
+    q = np.array(q, om.PROJ_QUERY_DTYPE); dq = np.array(dq, np.uint8).reshape(-1, 32)
+    tm0 = np.where(c["holder"] == 1, -2, -1).astype(np.int32)
+    nm, tm = om.search_by_projection(q, dq, c["kp"], c["d"], c["ur"], c["bounds"], tm0, 100, True)
+    res = np.where(tm >= 0, np.array(qsrc + [0], np.int64)[np.clip(tm, 0, None)], np.where(c["holder"] >= 0, -2, -1))
+    return nm, res.astype(np.int32), (fwd, bwd), len(q)
+
+
+def _expected_local_map(c):
+    import oracle_match_bind as om
+    q, dq, qsrc = [], [], []
+    for j in range(c["nMap"]):
+        m = c["mp"][j]
+        if not m[6] or m[4] > np.float32(40.0):
+            continue
+        lvl = int(m[5])
+        r = np.float32(2.5) if m[3] > np.float32(0.998) else np.float32(4.0)
+        r = np.float32(r * np.float32(c["th"]))
+        q.append((m[0], m[1], np.float32(r * c["scales"][lvl]), m[2], 0.0, lvl - 1, lvl, int(m[7] > 0)))
+        dq.append(c["dM"][j]); qsrc.append(j)
+    q = np.array(q, om.PROJ_QUERY_DTYPE); dq = np.array(dq, np.uint8).reshape(-1, 32)
+    tm0 = np.where(c["holder"] == 1, -2, -1).astype(np.int32)
+    nm, tm = om.search_by_projection_map(q, dq, c["kp"], c["d"], c["ur"], c["bounds"], tm0, 100, np.float32(c["ratio"]))
+    res = np.where(tm >= 0, np.array(qsrc + [0], np.int64)[np.clip(tm, 0, None)], np.where(c["holder"] >= 0, -2, -1))
+    return nm, res.astype(np.int32), len(q)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bMono,forward", [(True, 0.0), (False, 0.0), (False, 0.5), (False, -0.5)])
+def test_orbmatcher_methods_over_frames(tmp_path, bMono, forward):
+    """ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono), SearchByProjection(Frame&, vector<MapPoint*>, th, bFarPoints,
+    thFarPoints) and SearchForInitialization(F1, F2, ...) called on Frame / MapPoint objects as Tracking does; what they did to
+    the frames must equal the reference's loops restated (host geometry in numpy + the matcher oracle)."""
+    import oracle_match_bind as om
+    c = _match_case(31 + int(bMono) + int(forward * 10), bMono, forward)
+    fin, fout = str(tmp_path / "m.in"), str(tmp_path / "m.out")
+    _write_match(fin, c)
+    r = subprocess.run([EXE, "match", fin, fout], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and "HOST_MATCH_OK" in r.stdout, r.stdout
+    with open(fout, "rb") as f:
+        nm_last = int(np.fromfile(f, np.int32, 1)[0]); res_last = np.fromfile(f, np.int32, c["n"])
+        nm_map = int(np.fromfile(f, np.int32, 1)[0]); res_map = np.fromfile(f, np.int32, c["n"])
+        nm_init = int(np.fromfile(f, np.int32, 1)[0]); m12 = np.fromfile(f, np.int32, c["nI"]); prev = np.fromfile(f, np.float32, 2 * c["nI"]).reshape(-1, 2)
+    e_nm, e_res, (fwd, bwd), nq = _expected_last_frame(c)
+    assert (fwd, bwd) == (forward > 0.2 and not bMono, forward < -0.2 and not bMono)
+    assert nq > 300 and e_nm > 100
+    assert nm_last == e_nm and np.array_equal(res_last, e_res)
+    e_nm, e_res, nq = _expected_local_map(c)
+    assert nq > 300 and e_nm > 100
+    assert nm_map == e_nm and np.array_equal(res_map, e_res)
+    e_nm, e_m12, e_prev = om.search_for_initialization(c["k1"], c["d1"], c["k2"], c["d2"], c["bounds"], c["prev"], c["window"], 0.9, True)
+    assert e_nm > 50
+    assert nm_init == e_nm and np.array_equal(m12, e_m12) and prev.tobytes() == e_prev.tobytes()

@@ -72,6 +72,9 @@ def test_extract_padded_pyramid(gpu_ctx):
     ora.extract(imgs[0])
     for l in (0, 3, 7):
         np.testing.assert_array_equal(ext.pyramid_level(0, l, padded=True), ora.pyramid_level(l, padded=True))
+    allp = ext.pyramid_padded(0)                 # the whole pyramid in one pass: what ORBextractor::operator() leaves in mvImagePyramid
+    for l in range(8):
+        np.testing.assert_array_equal(allp[l], ora.pyramid_level(l, padded=True), err_msg="padded level %d" % l)
     ext.close()
 
 
