@@ -123,8 +123,8 @@ int orbhip_extractor_set_graph_mode(orbhip_extractor *ext, int enable);
  * (at most the 32 most recent), measured with hipEvents recorded on the context's stream
  * around each stage's launches while profiling is enabled.  Stage ids: ORBHIP_STAGE_*. */
 #define ORBHIP_STAGE_PYRAMID 0      /* k_resize, nlevels-1 launches */
-#define ORBHIP_STAGE_BLUR_SCORE 1   /* k_blur_score (7x7 blur + FAST score map, one staged tile), nlevels launches */
-#define ORBHIP_STAGE_FAST_CELLS 2   /* k_fast_cells, 1 launch */
+#define ORBHIP_STAGE_FAST_CELLS 1   /* k_fast_cells (per-cell FAST score + NMS + two-threshold retry, all levels), 1 launch */
+#define ORBHIP_STAGE_BLUR 2         /* k_blur (7x7 Gaussian, all levels), 1 launch */
 #define ORBHIP_STAGE_OCTREE 3       /* k_octree, 1 launch */
 #define ORBHIP_STAGE_DESC 4         /* k_orient_desc, 1 launch */
 #define ORBHIP_STAGE_ASSEMBLE 5     /* k_assemble, 1 launch */

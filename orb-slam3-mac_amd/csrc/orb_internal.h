@@ -13,8 +13,6 @@
 struct OrbLevel {
     uint8_t *img;             // un-padded level image (level 0 may alias the caller's input)
     uint8_t *blur;            // 7x7 sigma-2 blurred level
-    uint8_t *score;           // FAST score map (S-1 where S > minThFAST, else 0)
-    size_t score_frame_stride; int score_pitch;
     size_t img_frame_stride;
     size_t blur_frame_stride;
     int w, h, img_pitch, blur_pitch;
@@ -43,8 +41,7 @@ struct OrbParams {
     int kps_per_frame;        // sum of kp_cap  (== staging slots per frame)
     int max_kp;               // output row capacity per frame
     int oct_nc;               // k_octree: node capacity of its LDS arrays = max over levels of max(quota + 16, 4*nIni + 4)
-    int fc_pd, fc_rows;       // k_fast_cells per-wave LDS geometry: dword pitch and rows of the score band (+ aprons)
-    int bs_tiles[ORB_MAX_LEVELS + 1];   // k_blur_score: prefix of 64x32 tiles per frame over the levels (one launch for all levels)
+    int bs_tiles[ORB_MAX_LEVELS + 1];   // k_blur: prefix of 64x32 tiles per frame over the levels (one launch for all levels)
     int lap0, lap1;
     // per-frame scratch
     uint32_t *cell_count;     // [batch][cells_per_frame]
@@ -68,6 +65,23 @@ struct OrbParams {
     int32_t *out_mono;        // [batch]
     int umax[ORB_HALF_PATCH + 1];
     int gauss_q8[7];
+};
+
+// k_fast_cells has its own, compact parameter block (scalar loads of per-level fields are what a persistent wave does most)
+struct FcLevel {
+    const uint8_t *img; size_t frame_stride; int img_pitch;
+    int max_bx, max_by;           // w - minBorder, h - minBorder
+    int ncols, nrows, wcell, hcell, cell_base, cell_cap;
+    int tpr, rpt;                 // lane layout of the per-pair passes: two-pair tasks per row (nominal cell width), rows per trip
+};
+struct FastParams {
+    FcLevel lv[ORB_MAX_LEVELS];
+    int nlevels, batch, ini_th, min_th, cells_per_frame;
+    uint32_t *cell_count, *cell_list; size_t cell_list_frame_stride; int32_t *status;
+    // per-wave LDS geometry (from the largest cell of this extractor): pair tile [rows][PITCH] dwords, score tile [srows + 2][SPITCH]
+    // dwords, queue of qcap u16; wave_dw = dwords per wave.  small_cells: every level fits the <28, 24, 9> instantiation
+    int rows, srows, qcap, wave_dw, small_cells;
+    uint32_t div_magic[34];       // floor(i / n) == (i * div_magic[n]) >> 16 whenever i * n < 65536, n = 1 .. 33
 };
 
 #define ORB_PACK_KEY(x, y, s) ((uint32_t)(x) | ((uint32_t)(y) << 12) | ((uint32_t)(s) << 24))
@@ -100,8 +114,10 @@ int orb_lds_optin(const void *func, int device, size_t need);
 
 // kernel launchers (orb_kernels.hip)
 void orb_launch_resize(const OrbParams &P, int level, hipStream_t s);
-void orb_launch_fast_cells(const OrbParams &P, hipStream_t s);
-void orb_launch_blur_score(const OrbParams &P, hipStream_t s);
+void orb_launch_fast_cells(const FastParams &F, hipStream_t s, int max_per_cu);      // max_per_cu: 0 = as many waves as fit
+#define ORB_OVERLAP_MIN_BATCH 16
+void orb_launch_blur(const OrbParams &P, hipStream_t s, int wgs_per_cu);
+const void *orb_fast_cells_func(int small);
 void orb_launch_octree(const OrbParams &P, hipStream_t s);
 void orb_launch_orient_desc(const OrbParams &P, hipStream_t s);
 void orb_launch_assemble(const OrbParams &P, hipStream_t s);

@@ -165,245 +165,333 @@ void orb_launch_resize(const OrbParams &P, int level, hipStream_t s)
 }
 
 // ----------------------------------------------------------------------------------
-// A3/A4  per-cell FAST-9/16 + score + 3x3 NMS + two-threshold retry
-// (ORBextractor.cc:783-854 calling cv::FAST twice; OpenCV FAST_t<16>/cornerScore<16>).
+// A3/A4  per-cell FAST-9/16 + score + 3x3 NMS + two-threshold retry, ONE kernel, one wave per cell
+// (ORBextractor.cc:783-854 calling cv::FAST twice; OpenCV FAST_t<16> / cornerScore<16>).
 //
 // Identity used (tests/test_oracle_orb.py::test_fast_arc_score_identity):
 //   S = max over the 16 contiguous 9-arcs of min(v-p) and of min(p-v);
 //   corner at threshold t  <=>  S > t ;  cornerScore == S-1.
-// So one pass (k_blur_score, fused with the blur) computes a threshold-independent score map of the whole
-// level; k_fast_cells then applies the reference's per-cell semantics to it (3x3 NMS inside the cell's
-// detection band only, iniThFAST with minThFAST retry, cv::FAST emission order).
+// On RAW pixel values:  S = max(v - Hi, Lo - v),  Hi = min over arcs of (max of the arc's pixels), Lo = max over arcs of
+// (min of the arc's pixels): the sixteen subtractions v - p disappear from the arc search.
+//
+// Per cell (one wave, no workgroup barriers): (1) the cell's sub-image (band + 3 px) is staged into LDS as packed u16
+// PAIRS -- dword p of a row holds pixels (2p-1, 2p) relative to the sub-image, so a band pixel pair and its circle
+// neighbours at even dx are plain dword reads and odd dx is one v_alignbit; (2) every band pixel pair runs the cheap
+// necessary test ("a 9-arc contains one pixel of every diametral pair", 4 compass pairs, raw values) and is classified
+// against BOTH thresholds; pairs that may hold a corner at iniThFAST go to an ordered queue; (3) the queue is scored
+// densely (one pair per lane); (4) 3x3 strict NMS from an LDS score tile and ordered emission (cv::FAST order).  Only if
+// the cell yields nothing at iniThFAST are the remaining candidates (minThFAST < M <= iniThFAST) scored and the NMS
+// repeated at minThFAST (ORBextractor.cc:825-828).  NMS is threshold independent on raw scores: a corner at t survives
+// iff score >= t and score > every neighbour's raw score, and a neighbour that is no corner at t has a smaller score
+// anyway, so scores that were never computed count as 0.  No score map leaves the kernel.
 // ----------------------------------------------------------------------------------
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32_unaligned __attribute__((aligned(1)));
 
 __device__ __forceinline__ s16x2 as_s16x2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
+__device__ __forceinline__ uint32_t as_u32(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ s16x2 pkmin(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ s16x2 pkmax(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
+// pixel pair starting one pixel to the right of dword `lo`'s first pixel: (lo.hi, hi.lo)
+__device__ __forceinline__ s16x2 pair_odd(uint32_t hi, uint32_t lo) { return as_s16x2(__builtin_amdgcn_alignbit(hi, lo, 16)); }
 
-// Two horizontally adjacent pixels (window byte i and i+1 of a 12-byte row window w0|w1|w2) as
-// packed u16x2, one v_perm_b32.  I is a compile-time constant in [0,10].
-template <int I>
-__device__ __forceinline__ uint32_t pair_at(uint32_t w0, uint32_t w1, uint32_t w2)
+// Necessary-test value M of the band pixel pair whose centre dword is q[0] (q points into the pair tile, PITCH dwords per
+// row): M = max(v - max_j min(a_j, b_j), min_j max(a_j, b_j) - v) over the 4 compass diametral pairs; S > t implies M > t.
+template <int PITCH>
+__device__ __forceinline__ s16x2 fc_compass(const uint32_t *q)
 {
-    if (I <= 6) return __builtin_amdgcn_perm(w1, w0, 0x0c000c00u | (uint32_t)I | ((uint32_t)(I + 1) << 16));
-    return __builtin_amdgcn_perm(w2, w1, 0x0c000c00u | (uint32_t)(I - 4) | ((uint32_t)(I - 3) << 16));
+    const s16x2 v = as_s16x2(q[0]);
+    const s16x2 n = as_s16x2(q[3 * PITCH]), s = as_s16x2(q[-3 * PITCH]);
+    const s16x2 e = pair_odd(q[2], q[1]), w = pair_odd(q[-1], q[-2]);
+    const s16x2 se = as_s16x2(q[2 * PITCH + 1]), nw = as_s16x2(q[-2 * PITCH - 1]);
+    const s16x2 ne = as_s16x2(q[-2 * PITCH + 1]), sw = as_s16x2(q[2 * PITCH - 1]);
+    const s16x2 lo = pkmax(pkmax(pkmin(n, s), pkmin(e, w)), pkmax(pkmin(se, nw), pkmin(ne, sw)));
+    const s16x2 hi = pkmin(pkmin(pkmax(n, s), pkmax(e, w)), pkmin(pkmax(se, nw), pkmax(ne, sw)));
+    return pkmax(v - lo, hi - v);
 }
 
-// Arc score of the pixel pair whose left pixel sits at window byte 4+J (J = 0 or 2) of the centre row.
-// rows[r][0..2] = the three dwords of tile row (y-3+r).  Returns packed S (threshold independent).
-// Bresenham circle r=3 in cv::makeOffsets order: (dx,dy) k=0..15 =
+// Arc score S (threshold independent, packed) of the band pixel pair at q[0].  Circle in cv::makeOffsets order, k = 0..15:
 // (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
-template <int J>
-__device__ __forceinline__ s16x2 fast_pair_score(const uint32_t (&rows)[7][3])
+template <int PITCH>
+__device__ __forceinline__ s16x2 fc_arc_score(const uint32_t *q)
 {
-#define PX(DX, DY) as_s16x2(pair_at<4 + J + (DX)>(rows[3 + (DY)][0], rows[3 + (DY)][1], rows[3 + (DY)][2]))
-    const s16x2 v = PX(0, 0);
-    s16x2 d[16];
-    d[0] = v - PX(0, 3); d[8] = v - PX(0, -3); d[4] = v - PX(3, 0); d[12] = v - PX(-3, 0);
-    d[2] = v - PX(2, 2); d[10] = v - PX(-2, -2); d[6] = v - PX(2, -2); d[14] = v - PX(-2, 2);
-    d[1] = v - PX(1, 3); d[3] = v - PX(3, 1); d[5] = v - PX(3, -1); d[7] = v - PX(1, -3);
-    d[9] = v - PX(-1, -3); d[11] = v - PX(-3, -1); d[13] = v - PX(-3, 1); d[15] = v - PX(-1, 3);
-#undef PX
+    s16x2 p[16];
+    {
+        const uint32_t *r = q + 3 * PITCH;                      // dy = +3: k = 15, 0, 1
+        p[15] = pair_odd(r[0], r[-1]); p[0] = as_s16x2(r[0]); p[1] = pair_odd(r[1], r[0]);
+        r = q + 2 * PITCH; p[14] = as_s16x2(r[-1]); p[2] = as_s16x2(r[1]);
+        r = q + PITCH; p[13] = pair_odd(r[-1], r[-2]); p[3] = pair_odd(r[2], r[1]);
+        p[12] = pair_odd(q[-1], q[-2]); p[4] = pair_odd(q[2], q[1]);
+        r = q - PITCH; p[11] = pair_odd(r[-1], r[-2]); p[5] = pair_odd(r[2], r[1]);
+        r = q - 2 * PITCH; p[10] = as_s16x2(r[-1]); p[6] = as_s16x2(r[1]);
+        r = q - 3 * PITCH; p[9] = pair_odd(r[0], r[-1]); p[8] = as_s16x2(r[0]); p[7] = pair_odd(r[1], r[0]);
+    }
     // The two 9-arcs starting at j-1 and at j (j odd) share the 8 pixels j..j+7:
-    //   max(min(arc_{j-1}), min(arc_j)) = min(min(d[j..j+7]), max(d[j-1], d[j+8]))
+    //   best of the two = combine(run8(j..j+7), better of the end pixels p[j-1], p[j+8])
     // so only the 8 odd-start 8-runs are needed (index m <-> j = 2m+1), built by doubling.
     s16x2 lo2[8], hi2[8], lo4[8], hi4[8];
 #pragma unroll
-    for (int m = 0; m < 8; m++) { lo2[m] = pkmin(d[2 * m + 1], d[(2 * m + 2) & 15]); hi2[m] = pkmax(d[2 * m + 1], d[(2 * m + 2) & 15]); }
+    for (int m = 0; m < 8; m++) { lo2[m] = pkmin(p[2 * m + 1], p[(2 * m + 2) & 15]); hi2[m] = pkmax(p[2 * m + 1], p[(2 * m + 2) & 15]); }
 #pragma unroll
     for (int m = 0; m < 8; m++) { lo4[m] = pkmin(lo2[m], lo2[(m + 1) & 7]); hi4[m] = pkmax(hi2[m], hi2[(m + 1) & 7]); }
-    s16x2 A = (s16x2){-256, -256}, B = (s16x2){256, 256};
+    s16x2 Lo = (s16x2){-1, -1}, Hi = (s16x2){256, 256};
 #pragma unroll
     for (int m = 0; m < 8; m++) {
-        const s16x2 e0 = d[2 * m], e1 = d[(2 * m + 9) & 15];
-        A = pkmax(A, pkmin(pkmin(lo4[m], lo4[(m + 2) & 7]), pkmax(e0, e1)));
-        B = pkmin(B, pkmax(pkmax(hi4[m], hi4[(m + 2) & 7]), pkmin(e0, e1)));
+        const s16x2 e0 = p[2 * m], e1 = p[(2 * m + 9) & 15];
+        Lo = pkmax(Lo, pkmin(pkmin(lo4[m], lo4[(m + 2) & 7]), pkmax(e0, e1)));      // brightest "darkest pixel of an arc"
+        Hi = pkmin(Hi, pkmax(pkmax(hi4[m], hi4[(m + 2) & 7]), pkmin(e0, e1)));      // darkest "brightest pixel of an arc"
     }
-    return pkmax(A, (s16x2){0, 0} - B);
+    const s16x2 v = as_s16x2(q[0]);
+    return pkmax(v - Hi, Lo - v);
 }
 
-// Pass 1: threshold-independent score map of a whole level (regular stencil, no cell structure).
-// score = S-1 where S > minThFAST, else 0.  Tile 64x32 per 256-thread workgroup staged with aligned
-// dword loads.  Two phases, because only ~10 % of the pixels survive the cheap necessary test
-// ("a 9-arc contains one pixel of every diametral pair", 4 compass pairs) but almost every wave
-// holds a survivor:  (1) every pixel pair runs the compass test, survivors are compacted into an
-// LDS queue;  (2) queue entries are scored densely, one pair per lane.  Scores land in an LDS tile
-// that is written out with coalesced dword stores.
-// Necessary test for S > th on the pixel pair at window byte 4+J: a 9-arc contains at least one pixel
-// of every diametral pair, here checked on the 4 compass pairs.  rw = tile rows -3,-2,0,+2,+3.
-template <int J>
-__device__ __forceinline__ bool fast_compass(const uint32_t (&rw)[5][3], s16x2 th1)
-{
-#define PXR(R, DX) as_s16x2(pair_at<4 + J + (DX)>(rw[R][0], rw[R][1], rw[R][2]))
-    const s16x2 v = PXR(2, 0);
-    const s16x2 d0 = v - PXR(4, 0), d8 = v - PXR(0, 0), d4 = v - PXR(2, 3), d12 = v - PXR(2, -3);
-    const s16x2 d2 = v - PXR(3, 2), d10 = v - PXR(1, -2), d6 = v - PXR(1, 2), d14 = v - PXR(3, -2);
-#undef PXR
-    const s16x2 dark = pkmin(pkmin(pkmax(d0, d8), pkmax(d4, d12)), pkmin(pkmax(d2, d10), pkmax(d6, d14)));
-    const s16x2 brig = pkmax(pkmax(pkmin(d0, d8), pkmin(d4, d12)), pkmax(pkmin(d2, d10), pkmin(d6, d14)));
-    // either half > th  <=>  a sign bit of max(dark, -brig) - (th+1) is clear
-    const s16x2 M = pkmax(dark, (s16x2){0, 0} - brig) - th1;
-    return (__builtin_bit_cast(uint32_t, M) & 0x80008000u) != 0x80008000u;
-}
+#define FC_ID(by, bp) (((by) << 5) | (bp))      // band pixel pair id: row | pair (pairs per row <= 32)
 
-// Pass 2: per cell (ORBextractor.cc:783-854): 3x3 strict NMS inside the cell's detection band only
-// (cv::FAST never looks across the sub-image border), iniThFAST first, minThFAST iff nothing
-// survives, emission in cv::FAST order.  One wave per cell, four cells per workgroup, no barriers.
-__global__ __launch_bounds__(256) void k_fast_cells(OrbParams P)
+// Scalar description of one cell (ORBextractor.cc:783-806), everything a wave needs in SGPRs
+struct FcCell {
+    int frame, lvl, ci, cj;             // cj, ci: cell column / row inside the level
+    int dw, dh;                         // detection band (dw <= 0: the reference skips the cell)
+    int ipitch;                         // image row pitch
+    const uint8_t *src;                 // pixel (ini_x - 1, ini_y) of the level image: first byte staged
+    int ncols, nrows, wcell, hcell, cell_base, cell_cap, tpr, rpt;
+};
+#define FC_SGPR(x) __builtin_amdgcn_readfirstlane(x)
+__device__ __forceinline__ void fc_cell_geom(const FastParams &P, FcCell &C)
 {
-    // per-wave LDS: score band [fc_rows][fc_pd dwords] + list of non-zero 4-pixel groups; sized by the host from
-    // the largest cell of this extractor so that small cells do not pay for the 64x64 worst case (occupancy)
-    extern __shared__ uint32_t fc_lds[];
-    const int fc_pd = P.fc_pd, fc_rows = P.fc_rows;
-    const int fc_wave_dw = fc_rows * fc_pd + (fc_rows * fc_pd + 1) / 2;
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform: cell geometry stays in scalar registers
-    const int bpf = (P.cells_per_frame + 3) >> 2;              // workgroups per frame
-    const unsigned lid = xcd_logical_id(blockIdx.x, gridDim.x);
-    const int frame = lid / bpf;
-    const int cell = (lid - frame * bpf) * 4 + wv;
-    if (cell >= P.cells_per_frame) return;
-    int lvl = 0;
-    for (int l = 1; l < P.nlevels; l++) if (cell >= P.lv[l].cell_base) lvl = l;
-    const OrbLevel &L = P.lv[lvl];
-    const int c = cell - L.cell_base;
-    const int ci = c / L.ncols, cj = c - ci * L.ncols;
-    uint32_t *cnt_out = P.cell_count + (size_t)frame * P.cells_per_frame + cell;
-    const int max_bx = L.w - ORB_MINB, max_by = L.h - ORB_MINB;
-    const int ini_y = ORB_MINB + ci * L.hcell, ini_x = ORB_MINB + cj * L.wcell;
-    int max_y = ini_y + L.hcell + 6, max_x = ini_x + L.wcell + 6;
-    if (ini_y >= max_by - 3 || ini_x >= max_bx - 6) {       // ORBextractor.cc:788,797
-        if (lane == 0) *cnt_out = 0;
-        return;
-    }
+    const FcLevel &L = P.lv[C.lvl];
+    C.ncols = FC_SGPR(L.ncols); C.nrows = FC_SGPR(L.nrows); C.wcell = FC_SGPR(L.wcell); C.hcell = FC_SGPR(L.hcell);
+    C.cell_base = FC_SGPR(L.cell_base); C.cell_cap = FC_SGPR(L.cell_cap); C.tpr = FC_SGPR(L.tpr); C.rpt = FC_SGPR(L.rpt);
+    C.ipitch = FC_SGPR(L.img_pitch) & 0xFFFF;
+    const int max_bx = FC_SGPR(L.max_bx), max_by = FC_SGPR(L.max_by);
+    const int ini_y = ORB_MINB + C.ci * C.hcell, ini_x = ORB_MINB + C.cj * C.wcell;
+    int max_y = ini_y + C.hcell + 6, max_x = ini_x + C.wcell + 6;
+    C.src = L.img + (size_t)C.frame * L.frame_stride + (size_t)(ini_y * C.ipitch + ini_x - 1);
+    C.dw = 0; C.dh = 0;
+    if (ini_y >= max_by - 3 || ini_x >= max_bx - 6) return;               // ORBextractor.cc:788,797
     if (max_y > max_by) max_y = max_by;
     if (max_x > max_bx) max_x = max_bx;
-    const int dw = max_x - ini_x - 6, dh = max_y - ini_y - 6;  // detection band of cv::FAST
-    if (dw <= 0 || dh <= 0) {
-        if (lane == 0) *cnt_out = 0;
-        return;
+    C.dw = max_x - ini_x - 6; C.dh = max_y - ini_y - 6;
+    if (C.dw <= 0 || C.dh <= 0) { C.dw = 0; C.dh = 0; }
+}
+struct __attribute__((packed, aligned(1))) u32x4_unaligned { uint32_t x, y, z, w; };
+// Staging loads of a cell: its sub-image rows as NCH 16-byte chunks each (chunk c = pixels ini_x - 1 + 16c .. + 15 = pairs 8c .. 8c+7),
+// flattened (row, chunk) tasks, NLD per lane, branch-free (surplus lanes repeat the last task), all in flight together.  A chunk may
+// run past the sub-image: those bytes are never used and lie inside the frame (the sub-image ends >= 16 rows above the image's end).
+template <int NCH, int NLD>
+__device__ __forceinline__ void fc_issue_loads(const FcCell &C, int lane, uint4 (&ld)[NLD])
+{
+    const int last = max((C.dh + 6) * NCH - 1, 0);
+#pragma unroll
+    for (int t = 0; t < NLD; t++) {
+        const int i = min(lane + 64 * t, last);
+        const int r = (int)(__umul24((uint32_t)i, 65536u / NCH + 1) >> 16), c = i - r * NCH;      // i / NCH for i < 1024
+        const u32x4_unaligned v = *reinterpret_cast<const u32x4_unaligned *>(C.src + (uint32_t)(__umul24((uint32_t)r, (uint32_t)C.ipitch) + 16u * (uint32_t)c));
+        ld[t] = make_uint4(v.x, v.y, v.z, v.w);
     }
-    // stage the band's scores: LDS (row yy+1, byte xx+4) <- score(bx+xx, by+yy); everything else zero
-    uint32_t *sc32 = fc_lds + (size_t)wv * fc_wave_dw;
-    uint8_t *sc = reinterpret_cast<uint8_t *>(sc32);
-    const int bx = ini_x + 3, by = ini_y + 3;
-    const uint8_t *smap = L.score + (size_t)frame * L.score_frame_stride;
-    const int spitch = L.score_pitch & 0xFFFF;                // known-small operands: v_mul_u32_u24 instead of the quarter-rate v_mul_lo_u32
-    const int ndw = ((dw + 4) >> 2) + 1;                      // LDS dwords per row covering bytes [0, dw+4] (band + aprons)
-    const int gx0 = bx - 4;                                   // image x of LDS byte 0 (>= 15)
-    // lanes = (row sub-index, dword): rpt rows are staged per trip (no integer division in the loop).  ~97 % of
-    // the band's scores are zero and almost every wave holds a non-zero one, so while staging, the non-zero
-    // 4-pixel groups (group gx = band x 4gx..4gx+3 = LDS dword 1+gx) are compacted into a per-wave list
-    // (yy << 4 | gx); lane order within a trip and trip order are both row-major = cv::FAST's emission order.
-    uint16_t *lst = reinterpret_cast<uint16_t *>(sc32 + fc_rows * fc_pd);
-    const unsigned long long lt = (1ull << lane) - 1;
-    const int ngx = (dw + 3) >> 2;
-    int nl = 0;
-    {
-        const int rpt = 64 / ndw;                                  // rows per trip (ndw <= 16)
-        const int r0 = lane / ndw, d = lane - r0 * ndw;
-        uint32_t mask = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) { const int xx = 4 * d - 4 + j; if (xx >= 0 && xx < dw) mask |= 0xFFu << (8 * j); }
-        const bool isgrp = r0 < rpt && d >= 1 && d <= ngx;
-        // eight trips per batch (a whole VGA cell), one unaligned dword load each, all issued together: the
-        // ballots below would otherwise serialise every trip on its own load latency
-        for (int y0 = 0; y0 < dh; y0 += 8 * rpt) {
-            uint32_t ld[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int yy = y0 + k * rpt + r0;
-                ld[k] = 0;
-                if (r0 < rpt && yy < dh)                           // within the row pitch (pad bytes are masked off)
-                    ld[k] = *reinterpret_cast<const u32_unaligned *>(smap + (uint32_t)(((by + yy) & 0xFFFF) * spitch + gx0 + 4 * d));
-            }
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int yy = y0 + k * rpt + r0;
-                const uint32_t v = ld[k] & mask;
-                if (r0 < rpt && yy < dh) sc32[(yy + 1) * fc_pd + d] = v;
-                const bool nz = isgrp && v != 0;
-                const unsigned long long bal = __ballot(nz);
-                if (nz) lst[nl + __popcll(bal & lt)] = (uint16_t)((yy << 4) | (d - 1));
-                nl += __popcll(bal);
-            }
-        }
-    }
-    for (int d = lane; d < ndw; d += 64) { sc32[d] = 0; sc32[(dh + 1) * fc_pd + d] = 0; }
-    // the staging buffer is private to this wave: order its own LDS writes before its reads (no workgroup barrier:
-    // sibling waves may already have returned)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // NMS, threshold independent: with v(th) = score if score >= th else 0, "v(th) > every neighbour's v(th)"
-    // is (score >= th) && (score > raw neighbour maximum), so the strict 3x3 peaks are found once (one listed
-    // group per lane, column maxima shared by the four pixels) and both thresholds only gate the centre.
-    bool any_ini = false;
-    for (int i0 = 0; i0 < nl; i0 += 64) {
-        const int i = i0 + lane;
-        if (i < nl) {
-            const uint32_t e = lst[i];
-            const uint32_t *q = &sc32[((e >> 4) + 1) * fc_pd + 1 + (e & 15)];   // centre dword; rows +-1, dwords +-1 around it
-            uint32_t b[3][6];                                                   // bytes = band x 4gx-1 .. 4gx+4 of the three rows
-#pragma unroll
-            for (int r = 0; r < 3; r++) {
-                const uint32_t *qq = q + (r - 1) * fc_pd;
-                const uint32_t w0 = qq[-1], w1 = qq[0], w2 = qq[1];
-                b[r][0] = w0 >> 24; b[r][1] = w1 & 0xFFu; b[r][2] = (w1 >> 8) & 0xFFu; b[r][3] = (w1 >> 16) & 0xFFu; b[r][4] = w1 >> 24; b[r][5] = w2 & 0xFFu;
-            }
-            uint32_t cm[6];
-#pragma unroll
-            for (int k = 0; k < 6; k++) cm[k] = max(max(b[0][k], b[1][k]), b[2][k]);
-            uint32_t pk = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t m = max(max(cm[j], cm[j + 2]), max(b[0][j + 1], b[2][j + 1]));
-                const uint32_t c = b[1][j + 1];
-                if (c > m) { pk |= 1u << j; any_ini |= (int)c >= P.ini_th; }
-            }
-            lst[i] = (uint16_t)(e | (pk << 12));
-        }
-    }
-    const int th = __ballot(any_ini) ? P.ini_th : P.min_th;       // vKeysCell empty at iniThFAST: retry (ORBextractor.cc:825-828)
-    uint32_t *list = P.cell_list + (size_t)frame * P.cell_list_frame_stride + (size_t)cell * L.cell_cap;
-    int total = 0;
-    for (int i0 = 0; i0 < nl; i0 += 64) {
-        const int i = i0 + lane;
-        uint32_t keep = 0, cbytes = 0;
-        int yy = 0, gx = 0;
-        if (i < nl) {
-            const uint32_t e = lst[i];
-            yy = (e >> 4) & 63; gx = e & 15;
-            cbytes = sc32[(yy + 1) * fc_pd + 1 + gx];
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                if ((e >> (12 + j)) & 1u) { if ((int)((cbytes >> (8 * j)) & 0xFFu) >= th) keep |= 1u << j; }
-        }
-        const int mine = __popc(keep);
-        const int inc = wave_incl_scan(mine);
-        int offs = total + inc - mine;
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            if (keep & (1u << j)) {
-                if (offs < L.cell_cap)
-                    list[offs] = ORB_PACK_KEY(4 * gx + j + 3 + cj * L.wcell, yy + 3 + ci * L.hcell, (cbytes >> (8 * j)) & 0xFFu);
-                offs++;
-            }
-        total += __builtin_amdgcn_readlane(inc, 63);
-    }
-    if (total > L.cell_cap) { if (lane == 0) atomicExch(P.status, ORBHIP_E_CAPACITY); total = L.cell_cap; }
-    if (lane == 0) *cnt_out = (uint32_t)total;
 }
 
-void orb_launch_fast_cells(const OrbParams &P, hipStream_t s)
+// One wave per workgroup, persistent over a contiguous range of cells (frame-major, then level, then row-major): the next
+// cell's staging loads are in flight while the current cell is processed.  LDS (private to the wave, no barriers): pair tile
+// PT [rows][PITCH = 8 NCH], score tile SC [srows + 2][SPITCH] (one guard row / pair all around), queue Q.
+template <int NCH, int SPITCH, int NLD>
+__global__ __launch_bounds__(64) void k_fast_cells(FastParams P)
 {
-    const unsigned nblocks = (unsigned)((P.cells_per_frame + 3) / 4) * (unsigned)P.batch;
-    const int wave_dw = P.fc_rows * P.fc_pd + (P.fc_rows * P.fc_pd + 1) / 2;
-    hipLaunchKernelGGL(k_fast_cells, dim3(nblocks), dim3(256), sizeof(uint32_t) * 4 * (size_t)wave_dw, s, P);
+    constexpr int PITCH = 8 * NCH;
+    extern __shared__ __attribute__((aligned(16))) uint32_t fc_lds[];
+    const int lane = threadIdx.x;
+    uint32_t *PT = fc_lds;
+    uint32_t *SC = PT + P.rows * PITCH;
+    uint16_t *Q = reinterpret_cast<uint16_t *>(SC + (P.srows + 2) * SPITCH);
+    const unsigned long long lt = (1ull << lane) - 1;
+    // this wave's cells [g0, g1) of batch * cells_per_frame
+    const unsigned lid = xcd_logical_id(blockIdx.x, gridDim.x);
+    const long total_cells = (long)P.batch * P.cells_per_frame;
+    const long g0 = total_cells * lid / gridDim.x, g1 = total_cells * (lid + 1) / gridDim.x;
+    if (g0 >= g1) return;
+    const int nlevels = FC_SGPR(P.nlevels), ini_th = FC_SGPR(P.ini_th), min_th = FC_SGPR(P.min_th), cpf = FC_SGPR(P.cells_per_frame);
+    FcCell C;
+    {
+        C.frame = (int)(g0 / cpf);
+        const int cell = (int)(g0 - (long)C.frame * cpf);
+        C.lvl = 0;
+        for (int l = 1; l < nlevels; l++) if (cell >= P.lv[l].cell_base) C.lvl = l;
+        const int c = cell - P.lv[C.lvl].cell_base;
+        C.ci = c / P.lv[C.lvl].ncols; C.cj = c - C.ci * P.lv[C.lvl].ncols;
+        fc_cell_geom(P, C);
+    }
+    uint4 ld[NLD];
+    fc_issue_loads<NCH, NLD>(C, lane, ld);
+    const int lo_th = min(ini_th, min_th);
+    const s16x2 thI = (s16x2){(short)(ini_th + 1), (short)(ini_th + 1)}, thL = (s16x2){(short)(lo_th + 1), (short)(lo_th + 1)};
+#define FC_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_s_waitcnt(0xc07f); \
+                            __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+    for (long g = g0; g < g1; g++) {
+        const int dw = C.dw, dh = C.dh;
+        const int npb = (dw + 1) >> 1;                             // band pixel pairs per row
+        const int cell = C.cell_base + C.ci * C.ncols + C.cj;
+        uint32_t *cnt_out = P.cell_count + (size_t)C.frame * cpf + cell;
+        uint32_t *list = P.cell_list + (size_t)C.frame * P.cell_list_frame_stride + (size_t)cell * C.cell_cap;
+        const int key_x0 = 3 + C.cj * C.wcell, key_y0 = 3 + C.ci * C.hcell;
+        const int cell_cap = C.cell_cap, tpr = C.tpr, rptT = C.rpt;
+        // ---- (1) stage: PT[r][p] = pixels (ini_x + 2p - 1, ini_x + 2p) of sub-image row r as u16 | u16 << 16
+        if (dw > 0) {
+            const int last = (dh + 6) * NCH - 1;
+#pragma unroll
+            for (int t = 0; t < NLD; t++) {
+                const int i = min(lane + 64 * t, last);
+                const int r = (int)(__umul24((uint32_t)i, 65536u / NCH + 1) >> 16), c = i - r * NCH;
+                uint4 a, b;
+                a.x = __builtin_amdgcn_perm(0u, ld[t].x, 0x0c010c00u); a.y = __builtin_amdgcn_perm(0u, ld[t].x, 0x0c030c02u);
+                a.z = __builtin_amdgcn_perm(0u, ld[t].y, 0x0c010c00u); a.w = __builtin_amdgcn_perm(0u, ld[t].y, 0x0c030c02u);
+                b.x = __builtin_amdgcn_perm(0u, ld[t].z, 0x0c010c00u); b.y = __builtin_amdgcn_perm(0u, ld[t].z, 0x0c030c02u);
+                b.z = __builtin_amdgcn_perm(0u, ld[t].w, 0x0c010c00u); b.w = __builtin_amdgcn_perm(0u, ld[t].w, 0x0c030c02u);
+                uint4 *dst = reinterpret_cast<uint4 *>(&PT[r * PITCH + 8 * c]);
+                dst[0] = a; dst[1] = b;
+            }
+            // guards of the score tile (its interior is written by the necessary test below)
+            for (int i = lane; i < SPITCH; i += 64) { SC[i] = 0; SC[(dh + 1) * SPITCH + i] = 0; }
+            for (int i = lane; i < dh; i += 64) { SC[(i + 1) * SPITCH] = 0; SC[(i + 1) * SPITCH + npb + 1] = 0; }
+        }
+        // ---- next cell: its loads stay in flight while this one is processed
+        FcCell N = C;
+        {
+            N.cj++;
+            if (N.cj == C.ncols) { N.cj = 0; N.ci++; }
+            bool relevel = false;
+            if (N.ci == C.nrows) { N.ci = 0; N.lvl++; relevel = true; }
+            if (N.lvl == nlevels) { N.lvl = 0; N.frame++; }
+            if (g + 1 < g1) { fc_cell_geom(P, N); fc_issue_loads<NCH, NLD>(N, lane, ld); }
+            (void)relevel;
+        }
+        if (dw <= 0) { if (lane == 0) *cnt_out = 0; C = N; continue; }
+        FC_WAVE_SYNC();           // (also: the previous cell's LDS reads are done before this cell's writes -- same wave, program order)
+        // ---- (2) necessary test on every band pixel pair, two adjacent pairs per lane, rows in order (queue order = cv::FAST order).
+        // Lane layout from the level's nominal cell width (clipped border cells leave lanes idle): tasks per row tpr, rows per trip rpt
+        const int tr0 = (int)(__umul24((uint32_t)lane, P.div_magic[tpr]) >> 16), tg = lane - tr0 * tpr;
+        int nq1 = 0;                                               // entries of Q (wave-uniform)
+        for (int y0 = 0; y0 < dh; y0 += rptT) {
+            const int by = y0 + tr0;
+            uint32_t f = 0;                                        // bit 0/1: pair 0/1 may hold a corner at iniThFAST
+            if (tr0 < rptT && by < dh && 2 * tg < npb) {
+                const uint32_t *q = &PT[(by + 3) * PITCH + 2 * tg + 2];
+                uint32_t *sc = &SC[(by + 1) * SPITCH + 2 * tg + 1];
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int bp = 2 * tg + j;
+                    const s16x2 M = fc_compass<PITCH>(q + j);      // (an odd band's last pair tests one pixel beyond the band: its score is masked in (3))
+                    const int mm = max((int)M.x, (int)M.y);
+                    const uint32_t cI = mm > ini_th, cL = mm > lo_th;
+                    if (bp < npb) { sc[j] = (cI + cL) << 8; f |= cI << j; }           // class (0, 1, 2) in bits 8-9 until the pair is scored
+                }
+            }
+            const unsigned long long b0 = __ballot(f & 1u), b1 = __ballot(f & 2u);
+            const int pos = nq1 + __popcll(b0 & lt) + __popcll(b1 & lt);
+            if (f & 1u) Q[pos] = (uint16_t)FC_ID(by, 2 * tg);
+            if (f & 2u) Q[pos + (f & 1u)] = (uint16_t)FC_ID(by, 2 * tg + 1);
+            nq1 += __popcll(b0) + __popcll(b1);
+        }
+        FC_WAVE_SYNC();
+        int total = 0;
+        for (int pass = 0; pass < 2; pass++) {
+            if (pass == 1) {
+                // nothing at iniThFAST (ORBextractor.cc:825-828): score what only the low threshold lets through (class 1)
+                nq1 = 0;
+                for (int y0 = 0; y0 < dh; y0 += rptT) {
+                    const int by = y0 + tr0;
+                    uint32_t f = 0;
+                    if (tr0 < rptT && by < dh) {
+                        if (2 * tg < npb) f |= ((SC[(by + 1) * SPITCH + 2 * tg + 1] >> 8) & 3u) == 1u ? 1u : 0u;
+                        if (2 * tg + 1 < npb) f |= ((SC[(by + 1) * SPITCH + 2 * tg + 2] >> 8) & 3u) == 1u ? 2u : 0u;
+                    }
+                    const unsigned long long b0 = __ballot(f & 1u), b1 = __ballot(f & 2u);
+                    const int pos = nq1 + __popcll(b0 & lt) + __popcll(b1 & lt);
+                    if (f & 1u) Q[pos] = (uint16_t)FC_ID(by, 2 * tg);
+                    if (f & 2u) Q[pos + (f & 1u)] = (uint16_t)FC_ID(by, 2 * tg + 1);
+                    nq1 += __popcll(b0) + __popcll(b1);
+                }
+                FC_WAVE_SYNC();
+            }
+            // ---- (3) dense arc score, one pair per lane; scored pairs carry class 2
+            for (int i0 = 0; i0 < nq1; i0 += 64) {
+                const int i = min(i0 + lane, nq1 - 1);
+                const int id = Q[i], by = id >> 5, bp = id & 31;
+                const s16x2 S = fc_arc_score<PITCH>(&PT[(by + 3) * PITCH + bp + 2]);
+                if (i0 + lane < nq1) {
+                    const uint32_t lo = S.x > lo_th ? (uint32_t)(S.x - 1) : 0u;
+                    const uint32_t hi = (S.y > lo_th && 2 * bp + 1 < dw) ? (uint32_t)(S.y - 1) : 0u;
+                    SC[(by + 1) * SPITCH + bp + 1] = lo | (hi << 16) | 0x200u;
+                }
+            }
+            FC_WAVE_SYNC();
+            if (pass == 1) {
+                // every candidate (now class 2) in order -> Q
+                nq1 = 0;
+                for (int y0 = 0; y0 < dh; y0 += rptT) {
+                    const int by = y0 + tr0;
+                    uint32_t f = 0;
+                    if (tr0 < rptT && by < dh) {
+                        if (2 * tg < npb) f |= (SC[(by + 1) * SPITCH + 2 * tg + 1] & 0x300u) ? 1u : 0u;
+                        if (2 * tg + 1 < npb) f |= (SC[(by + 1) * SPITCH + 2 * tg + 2] & 0x300u) ? 2u : 0u;
+                    }
+                    const unsigned long long b0 = __ballot(f & 1u), b1 = __ballot(f & 2u);
+                    const int pos = nq1 + __popcll(b0 & lt) + __popcll(b1 & lt);
+                    if (f & 1u) Q[pos] = (uint16_t)FC_ID(by, 2 * tg);
+                    if (f & 2u) Q[pos + (f & 1u)] = (uint16_t)FC_ID(by, 2 * tg + 1);
+                    nq1 += __popcll(b0) + __popcll(b1);
+                }
+                FC_WAVE_SYNC();
+            }
+            // ---- (4) 3x3 strict NMS on raw scores + threshold gate + ordered emission
+            const int th = pass == 0 ? ini_th : min_th;
+            for (int i0 = 0; i0 < nq1; i0 += 64) {
+                const int i = i0 + lane;
+                uint32_t keep = 0, sc = 0;
+                int by = 0, bp = 0;
+                if (i < nq1) {
+                    const int id = Q[i];
+                    by = id >> 5; bp = id & 31;
+                    const uint32_t *q = &SC[(by + 1) * SPITCH + bp + 1];
+                    const uint32_t K = 0x00FF00FFu;                                                  // drop the class bits
+                    sc = q[0] & K;
+                    const s16x2 V = pkmax(as_s16x2(q[-SPITCH] & K), as_s16x2(q[SPITCH] & K));         // above / below each pixel
+                    const s16x2 Lc = pkmax(pkmax(as_s16x2(q[-SPITCH - 1] & K), as_s16x2(q[-1] & K)), as_s16x2(q[SPITCH - 1] & K));   // .y: column left of the pair
+                    const s16x2 Rc = pkmax(pkmax(as_s16x2(q[-SPITCH + 1] & K), as_s16x2(q[1] & K)), as_s16x2(q[SPITCH + 1] & K));    // .x: column right of the pair
+                    const int sl = (int)(sc & 0xFFFFu), sr = (int)(sc >> 16);
+                    const int nbl = max(max((int)V.x, (int)V.y), max((int)Lc.y, sr));                // L: above, below, the R column (3 rows), left column
+                    const int nbr = max(max((int)V.x, (int)V.y), max((int)Rc.x, sl));
+                    if (sl >= th && sl > nbl) keep |= 1u;
+                    if (sr >= th && sr > nbr) keep |= 2u;
+                }
+                const int mine = __popc(keep);
+                const int inc = wave_incl_scan(mine);
+                int offs = total + inc - mine;
+                if (keep & 1u) { if (offs < cell_cap) list[offs] = ORB_PACK_KEY(2 * bp + key_x0, by + key_y0, sc & 0xFFu); offs++; }
+                if (keep & 2u) { if (offs < cell_cap) list[offs] = ORB_PACK_KEY(2 * bp + 1 + key_x0, by + key_y0, (sc >> 16) & 0xFFu); }
+                total += __builtin_amdgcn_readlane(inc, 63);
+            }
+            if (total > 0 || min_th == ini_th) break;              // vKeysCell not empty at iniThFAST: done
+        }
+        if (total > cell_cap) { if (lane == 0) atomicExch(P.status, ORBHIP_E_CAPACITY); total = cell_cap; }
+        if (lane == 0) *cnt_out = (uint32_t)total;
+        C = N;
+    }
+#undef FC_WAVE_SYNC
 }
+
+void orb_launch_fast_cells(const FastParams &F, hipStream_t s, int max_per_cu)
+{
+    // persistent single-wave workgroups: as many as the LDS lets a CU hold, a whole number per XCD
+    const size_t lds = sizeof(uint32_t) * (size_t)F.wave_dw;
+    int per_cu = (int)((160 * 1024) / (lds + 512));
+    per_cu = per_cu > 24 ? 24 : per_cu < 1 ? 1 : per_cu;
+    if (max_per_cu > 0 && per_cu > max_per_cu) per_cu = max_per_cu;      // leave LDS and wave slots to a kernel running beside this one
+    long nblocks = 256L * per_cu;
+    const long total = (long)F.batch * F.cells_per_frame;
+    if (nblocks > total) nblocks = (total + 7) / 8 * 8;
+    if (F.small_cells) hipLaunchKernelGGL((k_fast_cells<3, 24, 2>), dim3((unsigned)nblocks), dim3(64), lds, s, F);
+    else hipLaunchKernelGGL((k_fast_cells<5, 32, 5>), dim3((unsigned)nblocks), dim3(64), lds, s, F);
+}
+const void *orb_fast_cells_func(int small) { return small ? reinterpret_cast<const void *>(k_fast_cells<3, 24, 2>) : reinterpret_cast<const void *>(k_fast_cells<5, 32, 5>); }
 
 // ----------------------------------------------------------------------------------
 // A5  DistributeOctTree (ORBextractor.cc:537-761), one 256-thread workgroup per
@@ -756,181 +844,149 @@ __device__ __forceinline__ uint32_t bl_dot2(uint32_t a, uint32_t b, uint32_t c)
     return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b), c, false);
 }
 
-// FAST phase 2 for the pairs of one parity (J = 0: pixels 4g,4g+1; J = 2: pixels 4g+2,4g+3): full arc
-// score, one pair per lane; waves beyond the queue's end skip.
-template <int J>
-__device__ __forceinline__ void bl_score_queue(const uint32_t *in, const uint16_t *queue, int nq, int th, uint16_t *out16, int tid)
+// ----------------------------------------------------------------------------------
+// A7 over every pyramid level in ONE launch: the 64x32 tile (+3 rows / +4 columns of apron, BORDER_REFLECT_101) is staged
+// with one 16-byte load per lane; row pass on v_dot4_u32_u8 (two rows per task, u16 sums written vertically PAIRED),
+// column pass on v_dot2_u32_u16 (a 7-tap column = four dot2), saturate + pack, dword stores.
+// Bound by vector-instruction issue (~19 lane-ops per pixel).  Algorithmic bytes: S read + S written.
+// ----------------------------------------------------------------------------------
+// tile cursor of a persistent k_blur workgroup: (level, frame, tile row / column), advanced without divisions
+struct BlTile { int level, frame, tx, ty, ntx, nty, w, h, pitch; const uint8_t *src; uint8_t *dst; int dpitch; };
+__device__ __forceinline__ void bl_tile_level(const OrbParams &P, BlTile &T)
 {
-    const int lane = tid & 63;
-    for (int q0 = tid & ~63; q0 < nq; q0 += 256) {
-        const int qi = q0 + lane;
-        const int p = queue[min(qi, nq - 1)];
-        const int row = p >> 4, g = p & 15;
-        const uint32_t *q = &in[row * BL_IPD + 3 + g];
-        uint32_t rows[7][3];
-#pragma unroll
-        for (int r = 0; r < 7; r++) { rows[r][0] = q[r * BL_IPD]; rows[r][1] = q[r * BL_IPD + 1]; rows[r][2] = q[r * BL_IPD + 2]; }
-        const s16x2 S = fast_pair_score<J>(rows);
-        if (qi < nq) {
-            const uint32_t lo = S.x > th ? (uint32_t)(S.x - 1) : 0u, hi = S.y > th ? (uint32_t)(S.y - 1) : 0u;
-            out16[row * (BL_TW / 2) + 2 * g + J / 2] = (uint16_t)(lo | (hi << 8));
-        }
+    const OrbLevel &L = P.lv[T.level];
+    T.w = __builtin_amdgcn_readfirstlane(L.w); T.h = __builtin_amdgcn_readfirstlane(L.h);
+    T.pitch = __builtin_amdgcn_readfirstlane(L.img_pitch); T.dpitch = __builtin_amdgcn_readfirstlane(L.blur_pitch);
+    T.ntx = (T.w + BL_TW - 1) / BL_TW; T.nty = (T.h + BL_TH - 1) / BL_TH;
+}
+__device__ __forceinline__ void bl_tile_frame(const OrbParams &P, BlTile &T)
+{
+    const OrbLevel &L = P.lv[T.level];
+    T.src = L.img + (size_t)T.frame * L.img_frame_stride; T.dst = L.blur + (size_t)T.frame * L.blur_frame_stride;
+}
+// this lane's share of a tile's staging: lanes 0..151 one 16-byte chunk (38 rows x 4), lanes 152..227 one apron dword
+__device__ __forceinline__ uint4 bl_stage_load(const BlTile &T, int tid)
+{
+    const bool chunk = tid < 4 * BL_ROWS;
+    const int a = tid - 4 * BL_ROWS;
+    const int r = chunk ? tid >> 2 : a >> 1;
+    const int x0 = T.tx * BL_TW, y0 = T.ty * BL_TH, w = T.w;
+    int y = reflect101(y0 + r - 3, T.h);
+    y = min(max(y, 0), T.h - 1);
+    const uint8_t *row = T.src + (uint32_t)__umul24((uint32_t)y, (uint32_t)T.pitch);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (chunk) {
+        const int x = x0 + 16 * (tid & 3);
+        if (x + 15 < w) v = *reinterpret_cast<const uint4 *>(row + x);
+        else { v.x = bl_load4(row, x, w); v.y = bl_load4(row, x + 4, w); v.z = bl_load4(row, x + 8, w); v.w = bl_load4(row, x + 12, w); }
+    } else if (a < 2 * BL_ROWS) {
+        v.x = bl_load4(row, (a & 1) ? x0 + BL_TW : x0 - 4, w);
     }
+    return v;
 }
 
-// ----------------------------------------------------------------------------------
-// Fused A7 + A4 pass over one pyramid level: the 64x32 tile (+3 rows / +4 columns of apron) is
-// staged ONCE and feeds both the 7x7 Gaussian (blurred level, for rBRIEF) and the FAST score map.
-// Staging uses BORDER_REFLECT_101 (needed by the blur); FAST scores within 19 px of the border are
-// never consumed (cells cover [19, w-19) x [19, h-19)), so the reflected apron is harmless there.
-// The kernel is bound by vector-instruction issue (~100 lane-ops per pixel), not by HBM: staging is
-// one 16-byte load per lane, the Gaussian's column pass runs on v_dot2_u32_u16 over vertically
-// paired u16 row sums, and FAST is two-phase (compass test on every pixel pair, dense arc score on
-// the ~15 % that survive, queued per parity so no realignment is needed).
-// Algorithmic bytes: S read + S blurred write (+ S score write, an internal product).
-// ----------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_blur_score(OrbParams P)
+__global__ __launch_bounds__(256) void k_blur(OrbParams P)
 {
     __shared__ __attribute__((aligned(16))) uint32_t in[BL_ROWS * BL_IPD + 4];
     __shared__ __attribute__((aligned(16))) uint32_t hz2[(BL_ROWS / 2) * BL_TW];     // [row pair][x]: row 2m | row 2m+1 << 16
-    __shared__ uint32_t outt[BL_TH * BL_TW / 4];
-    __shared__ uint16_t queue[2][BL_TH * BL_TW / 4];
-    __shared__ int qn[2];
-    const int tid = threadIdx.x, lane = tid & 63;
-    // one launch covers every level: logical block id -> (level, frame, tile), level-major so that each XCD's
-    // contiguous range of logical ids stays inside few frames of one level
+    const int tid = threadIdx.x;
+    // persistent workgroup: a contiguous range of tiles in (level, frame, tile row, tile column) order -- each XCD's contiguous range of
+    // logical ids stays inside few frames of one level; the next tile's loads are in flight while the current one is filtered
     const unsigned lid = xcd_logical_id(blockIdx.x, gridDim.x);
-    int level = 0;
-    for (int l = 1; l < P.nlevels; l++) if (lid >= (unsigned)P.bs_tiles[l] * (unsigned)P.batch) level = l;
-    const OrbLevel &L = P.lv[level];
-    const int w = L.w, h = L.h, th = P.min_th;
-    const int ntx = (w + BL_TW - 1) / BL_TW, nty = (h + BL_TH - 1) / BL_TH;
-    const unsigned lrel = lid - (unsigned)P.bs_tiles[level] * (unsigned)P.batch;
-    const int frame = lrel / (ntx * nty), trem = lrel - frame * (ntx * nty);
-    const int x0 = (trem % ntx) * BL_TW, y0 = (trem / ntx) * BL_TH;
-    const uint8_t *src = L.img + (size_t)frame * L.img_frame_stride;
-    // ---- stage: lanes 0..151 one 16-byte chunk each (38 rows x 4), lanes 152..227 one apron dword each
+    const long total = (long)P.bs_tiles[P.nlevels] * P.batch;
+    const long t0 = total * lid / gridDim.x, t1 = total * (lid + 1) / gridDim.x;
+    if (t0 >= t1) return;
+    BlTile T;
     {
-        const bool chunk = tid < 4 * BL_ROWS;
-        const int a = tid - 4 * BL_ROWS;
-        const int r = chunk ? tid >> 2 : a >> 1;
-        int y = reflect101(y0 + r - 3, h);
-        y = min(max(y, 0), h - 1);
-        const uint8_t *row = src + (size_t)y * L.img_pitch;
-        if (chunk) {
-            const int c = tid & 3, x = x0 + 16 * c;
-            uint4 v;
-            if (x + 15 < w) v = *reinterpret_cast<const uint4 *>(row + x);
-            else { v.x = bl_load4(row, x, w); v.y = bl_load4(row, x + 4, w); v.z = bl_load4(row, x + 8, w); v.w = bl_load4(row, x + 12, w); }
-            *reinterpret_cast<uint4 *>(&in[r * BL_IPD + 4 + 4 * c]) = v;
-        } else if (a < 2 * BL_ROWS) {
-            const int side = a & 1;
-            in[r * BL_IPD + (side ? BL_IPD : 3)] = bl_load4(row, side ? x0 + BL_TW : x0 - 4, w);
-        }
+        T.level = 0;
+        for (int l = 1; l < P.nlevels; l++) if (t0 >= (long)P.bs_tiles[l] * P.batch) T.level = l;
+        bl_tile_level(P, T);
+        const long rel = t0 - (long)P.bs_tiles[T.level] * P.batch;
+        T.frame = (int)(rel / (T.ntx * T.nty));
+        const int trem = (int)(rel - (long)T.frame * (T.ntx * T.nty));
+        T.ty = trem / T.ntx; T.tx = trem - T.ty * T.ntx;
+        bl_tile_frame(P, T);
     }
-    outt[tid] = 0; outt[tid + 256] = 0;
-    if (tid < 2) qn[tid] = 0;
-    __syncthreads();
-    // ---- blur row pass: two rows x four pixels per task, u16 sums (q8 kernel, sum 257 -> 255*257 fits)
     const uint32_t klo = (uint32_t)P.gauss_q8[0] | ((uint32_t)P.gauss_q8[1] << 8) | ((uint32_t)P.gauss_q8[2] << 16) | ((uint32_t)P.gauss_q8[3] << 24);
     const uint32_t khi = (uint32_t)P.gauss_q8[4] | ((uint32_t)P.gauss_q8[5] << 8) | ((uint32_t)P.gauss_q8[6] << 16);
-    for (int i = tid; i < (BL_ROWS / 2) * (BL_TW / 4); i += 256) {
-        const int rp = i >> 4, c4 = i & 15;
-        const uint32_t *q = &in[2 * rp * BL_IPD + 3 + c4];
-        uint32_t oa[4], ob[4];
-        bl_row4(q[0], q[1], q[2], klo, khi, oa);
-        bl_row4(q[BL_IPD], q[BL_IPD + 1], q[BL_IPD + 2], klo, khi, ob);
-        uint4 pk;
-        pk.x = oa[0] | (ob[0] << 16); pk.y = oa[1] | (ob[1] << 16); pk.z = oa[2] | (ob[2] << 16); pk.w = oa[3] | (ob[3] << 16);
-        *reinterpret_cast<uint4 *>(&hz2[rp * BL_TW + 4 * c4]) = pk;
-    }
-    // ---- FAST phase 1: compass test, one group of 4 pixels (two pairs, one 3-dword window) per task
-    const s16x2 th1 = (s16x2){(short)(th + 1), (short)(th + 1)};
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const int gi = tid + 256 * k;
-        const int row = gi >> 4, g = gi & 15;
-        // FAST is only ever consumed inside the cells' detection bands, [19, w-19) x [19, h-19): pixels outside
-        // never enter the queue, and a wave whose four rows lie outside skips the test altogether
-        const int yy = y0 + row;
-        const int wrow0 = y0 + ((gi & ~63) >> 4);                      // first of the 4 rows this wave covers
-        bool pass[2] = {false, false};
-        if (wrow0 + 3 >= ORB_EDGE && wrow0 < h - ORB_EDGE) {           // uniform
-            uint32_t rw[5][3];
-            const int rsel[5] = {0, 1, 3, 5, 6};                        // rows -3,-2,0,+2,+3
-#pragma unroll
-            for (int r = 0; r < 5; r++) {
-                const uint32_t *q = &in[(row + rsel[r]) * BL_IPD + 3 + g];
-                rw[r][0] = q[0]; rw[r][1] = q[1]; rw[r][2] = q[2];
-            }
-            const bool rowin = yy >= ORB_EDGE && yy < h - ORB_EDGE;
-            const int xg = x0 + 4 * g;
-            pass[0] = rowin && xg + 1 >= ORB_EDGE && xg < w - ORB_EDGE && fast_compass<0>(rw, th1);
-            pass[1] = rowin && xg + 3 >= ORB_EDGE && xg + 2 < w - ORB_EDGE && fast_compass<2>(rw, th1);
+    const uint32_t k0 = P.gauss_q8[0], k1 = P.gauss_q8[1], k2 = P.gauss_q8[2], k3 = P.gauss_q8[3];
+    const uint32_t wt[2][4] = {{k0 | (k1 << 16), k2 | (k3 << 16), k2 | (k1 << 16), k0},
+                               {k0 << 16, k1 | (k2 << 16), k3 | (k2 << 16), k1 | (k0 << 16)}};
+    // where this lane's staging share lands in LDS (same for every tile)
+    const bool chunk = tid < 4 * BL_ROWS;
+    const int sa = tid - 4 * BL_ROWS;
+    const int sidx = chunk ? (tid >> 2) * BL_IPD + 4 + 4 * (tid & 3) : (sa >> 1) * BL_IPD + ((sa & 1) ? BL_IPD : 3);
+    auto advance = [&](BlTile &X) {
+        X.tx++;
+        if (X.tx == X.ntx) { X.tx = 0; X.ty++; }
+        if (X.ty == X.nty) {
+            X.ty = 0; X.frame++;
+            if (X.frame == P.batch) { X.frame = 0; X.level++; bl_tile_level(P, X); }
+            bl_tile_frame(P, X);
         }
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const unsigned long long bal = __ballot(pass[j]);
-            int base = 0;
-            if (lane == 0 && bal) base = atomicAdd(&qn[j], __popcll(bal));
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (pass[j]) queue[j][base + __popcll(bal & ((1ull << lane) - 1))] = (uint16_t)gi;
+    };
+    auto body = [&](uint4 &ld, BlTile &T, long t) {
+        const int x0 = T.tx * BL_TW, y0 = T.ty * BL_TH, w = T.w, h = T.h, dpitch = T.dpitch;
+        uint8_t *bdst = T.dst;
+        if (chunk) *reinterpret_cast<uint4 *>(&in[sidx]) = ld;
+        else if (sa < 2 * BL_ROWS) in[sidx] = ld.x;
+        __syncthreads();
+        if (t + 1 < t1) { advance(T); ld = bl_stage_load(T, tid); }                   // the next tile's loads are in flight during the passes
+        // ---- row pass: two rows x four pixels per task, u16 sums (q8 kernel, sum 257 -> 255*257 fits)
+        for (int i = tid; i < (BL_ROWS / 2) * (BL_TW / 4); i += 256) {
+            const int rp = i >> 4, c4 = i & 15;
+            const uint32_t *q = &in[2 * rp * BL_IPD + 3 + c4];
+            uint32_t oa[4], ob[4];
+            bl_row4(q[0], q[1], q[2], klo, khi, oa);
+            bl_row4(q[BL_IPD], q[BL_IPD + 1], q[BL_IPD + 2], klo, khi, ob);
+            uint4 pk;
+            pk.x = oa[0] | (ob[0] << 16); pk.y = oa[1] | (ob[1] << 16); pk.z = oa[2] | (ob[2] << 16); pk.w = oa[3] | (ob[3] << 16);
+            *reinterpret_cast<uint4 *>(&hz2[rp * BL_TW + 4 * c4]) = pk;
         }
-    }
-    __syncthreads();
-    // ---- blur column pass: rows come vertically paired, so a 7-tap column is four v_dot2_u32_u16
-    uint8_t *bdst = L.blur + (size_t)frame * L.blur_frame_stride;
-    {
-        const int c4 = tid & 15, rg = tid >> 4;
-        const int x = x0 + 4 * c4;
-        if (x < w) {
-            const uint32_t k0 = P.gauss_q8[0], k1 = P.gauss_q8[1], k2 = P.gauss_q8[2], k3 = P.gauss_q8[3];
-            const uint32_t wt[2][4] = {{k0 | (k1 << 16), k2 | (k3 << 16), k2 | (k1 << 16), k0},
-                                       {k0 << 16, k1 | (k2 << 16), k3 | (k2 << 16), k1 | (k0 << 16)}};
-            uint4 pr[4];
+        __syncthreads();
+        // ---- column pass: rows come vertically paired, so a 7-tap column is four v_dot2_u32_u16
+        {
+            const int c4 = tid & 15, rg = tid >> 4;
+            const int x = x0 + 4 * c4;
+            if (x < w) {
+                uint4 pr[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) pr[k] = *reinterpret_cast<const uint4 *>(&hz2[(rg + k) * BL_TW + 4 * c4]);
+                for (int k = 0; k < 4; k++) pr[k] = *reinterpret_cast<const uint4 *>(&hz2[(rg + k) * BL_TW + 4 * c4]);
 #pragma unroll
-            for (int rr = 0; rr < 2; rr++) {
-                const int y = y0 + 2 * rg + rr;
-                if (y < h) {
-                    uint32_t acc[4];
+                for (int rr = 0; rr < 2; rr++) {
+                    const int y = y0 + 2 * rg + rr;
+                    if (y < h) {
+                        uint32_t acc[4];
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        uint32_t a = 32768u;
+                        for (int j = 0; j < 4; j++) {
+                            uint32_t a = 32768u;
 #pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const uint32_t pv = j == 0 ? pr[k].x : j == 1 ? pr[k].y : j == 2 ? pr[k].z : pr[k].w;
-                            a = bl_dot2(pv, wt[rr][k], a);
+                            for (int k = 0; k < 4; k++) {
+                                const uint32_t pv = j == 0 ? pr[k].x : j == 1 ? pr[k].y : j == 2 ? pr[k].z : pr[k].w;
+                                a = bl_dot2(pv, wt[rr][k], a);
+                            }
+                            acc[j] = min(a, 0x00FFFFFFu);                  // byte 2 = min((sum + 2^15) >> 16, 255)
                         }
-                        acc[j] = min(a, 0x00FFFFFFu);                  // byte 2 = min((sum + 2^15) >> 16, 255)
+                        const uint32_t p01 = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u);
+                        const uint32_t p23 = __builtin_amdgcn_perm(acc[3], acc[2], 0x0c0c0602u);
+                        *reinterpret_cast<uint32_t *>(bdst + (uint32_t)__umul24((uint32_t)y, (uint32_t)dpitch) + x) = p01 | (p23 << 16);
                     }
-                    const uint32_t p01 = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u);
-                    const uint32_t p23 = __builtin_amdgcn_perm(acc[3], acc[2], 0x0c0c0602u);
-                    *reinterpret_cast<uint32_t *>(bdst + (size_t)y * L.blur_pitch + x) = p01 | (p23 << 16);
                 }
             }
         }
-    }
-    // ---- FAST phase 2
-    uint16_t *out16 = reinterpret_cast<uint16_t *>(outt);
-    bl_score_queue<0>(in, queue[0], qn[0], th, out16, tid);
-    bl_score_queue<2>(in, queue[1], qn[1], th, out16, tid);
-    __syncthreads();
-    uint8_t *sdst = L.score + (size_t)frame * L.score_frame_stride;
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const int i = tid + 256 * k;
-        const int row = i >> 4, g = i & 15;
-        const int x = x0 + 4 * g, y = y0 + row;
-        if (x < w && y < h) *reinterpret_cast<uint32_t *>(sdst + (size_t)y * L.score_pitch + x) = outt[i];
-    }
+        // (the next tile's staging writes to `in` come after this tile's row pass: second barrier above;
+        //  its row-pass writes to `hz2` come after its first barrier, i.e. after this column pass)
+    };
+    uint4 ld = bl_stage_load(T, tid);
+    for (long t = t0; t < t1; t++) body(ld, T, t);
 }
 
-void orb_launch_blur_score(const OrbParams &P, hipStream_t s)
+void orb_launch_blur(const OrbParams &P, hipStream_t s, int wgs_per_cu)
 {
-    const unsigned nblocks = (unsigned)P.bs_tiles[P.nlevels] * (unsigned)P.batch;
-    hipLaunchKernelGGL(k_blur_score, dim3(nblocks), dim3(256), 0, s, P);
+    const long total = (long)P.bs_tiles[P.nlevels] * P.batch;
+    long nblocks = 256L * wgs_per_cu;                           // persistent: 8 workgroups (32 waves) per CU when alone on the chip
+    if (nblocks > total) nblocks = total;
+    hipLaunchKernelGGL(k_blur, dim3((unsigned)nblocks), dim3(256), 0, s, P);
 }
 
 // ----------------------------------------------------------------------------------

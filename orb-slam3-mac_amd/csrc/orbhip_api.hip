@@ -137,6 +137,7 @@ struct orbhip_extractor {
     int width, height, max_batch;
     bool level0_owned;          // level-0 buffer allocated (host path / stride mismatch)
     OrbParams P;
+    FastParams F;
     std::vector<void *> allocs;
     size_t bytes_reserved;
     int last_batch;
@@ -149,6 +150,8 @@ struct orbhip_extractor {
     int32_t *d_stereo_sad;      // [max_batch][max_kp] scratch of orbhip_compute_stereo_matches_device (lazy)
     // graph mode (small batches are launch bound): the 19 launches of one extract call replayed as one hipGraph
     bool graph_mode, graph_valid;
+    // k_blur (memory-wait bound) runs beside k_fast_cells / k_octree (issue / latency bound) on a second stream of the extractor
+    hipStream_t aux; hipEvent_t ev_fork, ev_join; bool aux_ok; int overlap;
     hipGraphExec_t graph_exec;
     int g_w, g_h, g_batch, g_lap0, g_lap1;
     size_t level0_frame_stride; int level0_pitch;
@@ -166,6 +169,7 @@ extern "C" int orbhip_extractor_create(orbhip_ctx *ctx, int nfeatures, float sca
     e->profiling = false; e->ev_created = false; e->ev_calls = 0; e->d_level0 = nullptr; e->level0_owned = false;
     e->d_stereo_sad = nullptr;
     e->graph_mode = false; e->graph_valid = false; e->graph_exec = nullptr;
+    e->aux = nullptr; e->ev_fork = e->ev_join = nullptr; e->aux_ok = false; e->overlap = 1;
     memset(&e->P, 0, sizeof(e->P));
     memset(e->stage_ms, 0, sizeof(e->stage_ms));
     // scale tables, ORBextractor.cc:413-429
@@ -201,11 +205,19 @@ static void ext_free_all(orbhip_extractor *e)
     e->bytes_reserved = 0; e->width = e->height = e->max_batch = 0; e->d_level0 = nullptr; e->d_stereo_sad = nullptr;
     if (e->graph_valid) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_valid = false; }
 }
+static void ext_free_aux(orbhip_extractor *e)
+{
+    if (!e->aux_ok) return;
+    (void)hipStreamSynchronize(e->aux);
+    (void)hipEventDestroy(e->ev_fork); (void)hipEventDestroy(e->ev_join); (void)hipStreamDestroy(e->aux);
+    e->aux_ok = false;
+}
 
 extern "C" void orbhip_extractor_destroy(orbhip_extractor *e)
 {
     if (!e) return;
     (void)hipStreamSynchronize(e->ctx->stream);
+    ext_free_aux(e);
     ext_free_all(e);
     if (e->ev_created) for (auto &slot : e->ev) for (auto &ev : slot) (void)hipEventDestroy(ev);
     delete e;
@@ -314,11 +326,29 @@ extern "C" int orbhip_extractor_reserve(orbhip_extractor *e, int width, int heig
         keys += align_up(L.key_cap, 4);
     }
     P.cells_per_frame = cells; P.keys_per_frame = keys; P.kps_per_frame = kps; P.max_kp = align_up(kps, 8);
-    {   // k_fast_cells LDS geometry from the largest detection band (wcell x hcell) of this extractor
+    {   // k_fast_cells: compact parameter block + per-wave LDS geometry from the largest cell of this extractor
+        FastParams &F = e->F;
+        memset(&F, 0, sizeof(F));
         int mw = 0, mh = 0;
-        for (int l = 0; l < e->nlevels; l++) { mw = std::max(mw, P.lv[l].wcell); mh = std::max(mh, P.lv[l].hcell); }
-        P.fc_pd = ((mw + 4) >> 2) + 2;          // bytes [0, dw+4] (band + 4-byte aprons) + one dword of slack for the 16-byte window reads
-        P.fc_rows = mh + 2;
+        bool small = true;
+        for (int l = 0; l < e->nlevels; l++) {
+            const OrbLevel &L = P.lv[l];
+            FcLevel &f = F.lv[l];
+            mw = std::max(mw, L.wcell); mh = std::max(mh, L.hcell);
+            f.max_bx = L.w - ORB_MINB; f.max_by = L.h - ORB_MINB;
+            f.ncols = L.ncols; f.nrows = L.nrows; f.wcell = L.wcell; f.hcell = L.hcell; f.cell_base = L.cell_base; f.cell_cap = L.cell_cap;
+            const int npb = (L.wcell + 1) >> 1, nq = (npb + 5) >> 1;       // band pixel pairs per row; quads staged per row (pairs 0 .. npb+3)
+            f.tpr = (npb + 1) >> 1; f.rpt = 64 / f.tpr;
+            (void)nq;
+            small = small && npb + 4 <= 24 && npb + 2 <= 24 && (L.hcell + 6) * 3 <= 64 * 2;       // <3, 24, 2>: 24 pairs per row, 128 chunk tasks
+        }
+        const int npb = (mw + 1) >> 1;
+        F.small_cells = small ? 1 : 0;
+        F.rows = mh + 6; F.srows = mh; F.qcap = (mh * npb + 1) & ~1;
+        F.wave_dw = F.rows * (small ? 24 : 40) + (F.srows + 2) * (small ? 24 : 32) + F.qcap / 2;
+        F.wave_dw = (F.wave_dw + 3) & ~3;
+        F.nlevels = e->nlevels; F.ini_th = e->ini_th; F.min_th = e->min_th; F.cells_per_frame = cells;
+        for (int n = 1; n < 34; n++) F.div_magic[n] = (uint32_t)(65536 / n + 1);
     }
     P.bs_tiles[0] = 0;
     for (int l = 0; l < e->nlevels; l++) P.bs_tiles[l + 1] = P.bs_tiles[l] + ((P.lv[l].w + 63) / 64) * ((P.lv[l].h + 31) / 32);
@@ -331,8 +361,6 @@ extern "C" int orbhip_extractor_reserve(orbhip_extractor *e, int width, int heig
         L.img_frame_stride = (size_t)L.img_pitch * L.h; L.blur_frame_stride = L.img_frame_stride;
         if ((rc = dev_alloc(e, &L.img, B * L.img_frame_stride + 64))) return rc;
         if ((rc = dev_alloc(e, &L.blur, B * L.blur_frame_stride + 64))) return rc;
-        L.score_pitch = L.blur_pitch; L.score_frame_stride = L.blur_frame_stride;
-        if ((rc = dev_alloc(e, &L.score, B * L.score_frame_stride + 64))) return rc;
         if (l > 0) {
             std::vector<int16_t> xo, xa, yo, yb;
             resize_tables(P.lv[l - 1].w, L.w, true, xo, xa);
@@ -371,6 +399,7 @@ extern "C" int orbhip_extractor_reserve(orbhip_extractor *e, int width, int heig
     P.oct_nc = orb_octree_nc(P);
     if (orb_octree_lds_bytes(P.oct_nc) > 150 * 1024) { g_last_error = "per-level quota (or nIni) too large for the LDS-resident octree"; return ORBHIP_E_BADARG; }
     if ((rc = orb_lds_optin(orb_octree_func(), e->ctx->device, orb_octree_lds_bytes(P.oct_nc)))) return rc;
+    if ((rc = orb_lds_optin(orb_fast_cells_func(e->F.small_cells), e->ctx->device, sizeof(uint32_t) * (size_t)e->F.wave_dw))) return rc;
     e->width = width; e->height = height; e->max_batch = max_batch;
     return ORBHIP_OK;
 }
@@ -456,6 +485,8 @@ extern "C" int orbhip_extractor_stage_ms(orbhip_extractor *e, float *ms_out)
     return ORBHIP_OK;
 }
 
+static int tune_int(const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; }      // tuning hook (development)
+
 static int run_pipeline(orbhip_extractor *e, int batch, int lap0, int lap1)
 {
     OrbParams &P = e->P;
@@ -466,13 +497,33 @@ static int run_pipeline(orbhip_extractor *e, int batch, int lap0, int lap1)
 #define STAGE_MARK(i) do { if (prof) HIP_TRY(hipEventRecord(e->ev[slot][i], s)); } while (0)
     STAGE_MARK(ORBHIP_STAGE_PYRAMID);
     for (int l = 1; l < e->nlevels; l++) orb_launch_resize(P, l, s);
-    STAGE_MARK(ORBHIP_STAGE_BLUR_SCORE);
-    orb_launch_blur_score(P, s);
     STAGE_MARK(ORBHIP_STAGE_FAST_CELLS);
-    orb_launch_fast_cells(P, s);
+    // fork: the blur only needs the pyramid; it joins before the descriptors.  Stage profiling measures the kernels one by one.
+    const bool fork = e->overlap && !prof && batch >= ORB_OVERLAP_MIN_BATCH;
+    if (fork && !e->aux_ok) {
+        HIP_TRY(hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+        e->aux_ok = true;
+    }
+    if (fork) {
+        HIP_TRY(hipEventRecord(e->ev_fork, s));
+        HIP_TRY(hipStreamWaitEvent(e->aux, e->ev_fork, 0));
+        orb_launch_blur(P, e->aux, tune_int("ORBHIP_TUNE_BLUR_WGS", 5));
+        HIP_TRY(hipEventRecord(e->ev_join, e->aux));
+    }
+    {
+        FastParams &F = e->F;
+        for (int l = 0; l < e->nlevels; l++) { F.lv[l].img = P.lv[l].img; F.lv[l].frame_stride = P.lv[l].img_frame_stride; F.lv[l].img_pitch = P.lv[l].img_pitch; }
+        F.batch = batch; F.cell_count = P.cell_count; F.cell_list = P.cell_list; F.cell_list_frame_stride = P.cell_list_frame_stride; F.status = P.status;
+        orb_launch_fast_cells(F, s, fork ? tune_int("ORBHIP_TUNE_FAST_WAVES", 10) : 0);
+    }
+    STAGE_MARK(ORBHIP_STAGE_BLUR);
+    if (!fork) orb_launch_blur(P, s, 8);
     STAGE_MARK(ORBHIP_STAGE_OCTREE);
     orb_launch_octree(P, s);
     STAGE_MARK(ORBHIP_STAGE_DESC);
+    if (fork) HIP_TRY(hipStreamWaitEvent(s, e->ev_join, 0));
     orb_launch_orient_desc(P, s);
     STAGE_MARK(ORBHIP_STAGE_ASSEMBLE);
     orb_launch_assemble(P, s);

@@ -29,7 +29,7 @@ if not os.path.exists(LIB_PATH):
 lib = C.CDLL(LIB_PATH)
 
 OK, E_BADARG, E_NODEVICE, E_HIP, E_CAPACITY, E_ABORTED, E_NOTSPD, E_EMPTY = 0, -1, -2, -3, -4, -5, -6, -7
-STAGES = ["pyramid", "blur_score", "fast_cells", "octree", "desc", "assemble"]
+STAGES = ["pyramid", "fast_cells", "blur", "octree", "desc", "assemble"]
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                      ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
