@@ -1391,6 +1391,8 @@ struct orbhip_ba_batch {
     struct Slice { int pt0, npts, e0, ne; };
     std::vector<Slice> slices;
     size_t x_need;                           // doubles per rank slot of the exchange buffer
+    // one LM tick (about 20 dependent launches) captured as a hipGraph: small batches are launch bound
+    hipGraphExec_t tick_graph; bool tick_graph_valid; BaBatch tick_B;
 };
 
 template <typename T>
@@ -1441,6 +1443,7 @@ extern "C" void orbhip_ba_batch_destroy(orbhip_ba_batch *b)
     for (void *p : b->allocs) (void)hipFree(p);
     if (b->h_n_active) (void)hipHostFree(b->h_n_active);
     if (b->ev0) { (void)hipEventDestroy(b->ev0); (void)hipEventDestroy(b->ev1); }
+    if (b->tick_graph_valid) (void)hipGraphExecDestroy(b->tick_graph);
     delete b;
 }
 
@@ -1452,7 +1455,7 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
     if (!ctx || !graphs || n_graphs <= 0 || !poses || !points || !out) return ORBHIP_E_BADARG;
     if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
     orbhip_ba_batch *b = new orbhip_ba_batch();
-    b->ctx = ctx; b->h_n_active = nullptr; b->ticks_last = 0;
+    b->ctx = ctx; b->h_n_active = nullptr; b->ticks_last = 0; b->tick_graph = nullptr; b->tick_graph_valid = false;
     b->profile = false; b->ev0 = b->ev1 = nullptr; b->gemm_ms_total = 0; b->gemm_launches = 0; b->gemm_flops_per_launch = 0; b->gemm_flops_dense = 0; b->gemm_flops_issued = 0;
     BaBatch &B = b->B;
     memset(&B, 0, sizeof(B));
@@ -1749,8 +1752,8 @@ static int ba_solve_impl(orbhip_ba_batch *b, const orbhip_ba_params *params, vol
     if (orb_lds_optin(reinterpret_cast<const void *>(k_ba_ldlt), orbhip_ctx_device_internal(b->ctx), ldlt_lds)) { g_ba_error = "LDS opt-in (k_ba_ldlt)"; return ORBHIP_E_HIP; }
     const int max_ticks = (params->iters1 + params->iters2) * params->max_trials + 4;
     int tick = 0;
-    for (; tick < max_ticks && n_active > 0; tick++) {
-        const int ab = (abort_flag && *abort_flag) ? 1 : 0;
+    // one LM tick: every graph that is still active evaluates, builds, solves and tries one step (inactive graphs return at once)
+    auto launch_tick = [&](int ab) -> int {
         if (B.ex2) hipLaunchKernelGGL(k_ba_levels, ge, dim3(256), 0, s, B);
         if (b->general) hipLaunchKernelGGL(k_ba_errors<true>, ge, dim3(256), 0, s, B, 0); else hipLaunchKernelGGL(k_ba_errors<false>, ge, dim3(256), 0, s, B, 0);
         hipLaunchKernelGGL(k_ba_reduce, dim3(G), dim3(256), 0, s, B, 0);
@@ -1786,6 +1789,33 @@ static int ba_solve_impl(orbhip_ba_batch *b, const orbhip_ba_params *params, vol
             hipLaunchKernelGGL(k_ba_shard_sum34, dim3((G + 63) / 64), dim3(64), 0, s, B, 3);
         }
         hipLaunchKernelGGL(k_ba_control, dim3((G + 63) / 64), dim3(64), 0, s, B, ab);
+        return ORBHIP_OK;
+    };
+    // Replay form of a tick (no exchange, no event timing, abort flag down): captured once per batch and parameter set.  The
+    // kernels of a graph that has finished return at once, so several ticks may be queued per host round trip.
+    const bool use_graph = !sharded && !b->profile;
+    if (use_graph && !(b->tick_graph_valid && memcmp(&b->tick_B, &B, sizeof(BaBatch)) == 0)) {
+        if (b->tick_graph_valid) { (void)hipGraphExecDestroy(b->tick_graph); b->tick_graph_valid = false; }
+        hipGraph_t graph = nullptr;
+        TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        const int rc = launch_tick(0);
+        const hipError_t ce = hipStreamEndCapture(s, &graph);
+        if (rc != ORBHIP_OK || ce != hipSuccess) { if (graph) (void)hipGraphDestroy(graph); g_ba_error = "tick capture"; return ORBHIP_E_HIP; }
+        const hipError_t ie = hipGraphInstantiate(&b->tick_graph, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ie != hipSuccess) { g_ba_error = "hipGraphInstantiate(tick)"; return ORBHIP_E_HIP; }
+        b->tick_graph_valid = true; b->tick_B = B;
+    }
+    const int ticks_per_sync = use_graph ? (G <= 16 ? 4 : 2) : 1;
+    while (tick < max_ticks && n_active > 0) {
+        const int ab = (abort_flag && *abort_flag) ? 1 : 0;
+        if (use_graph && !ab) {
+            for (int k = 0; k < ticks_per_sync && tick < max_ticks; k++, tick++) TRY(hipGraphLaunch(b->tick_graph, s));
+        } else {
+            const int rc = launch_tick(ab);
+            if (rc != ORBHIP_OK) return rc;
+            tick++;
+        }
         TRY(hipMemcpyAsync(b->h_n_active, B.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
         TRY(hipStreamSynchronize(s));
         TRY(hipGetLastError());                  // a rejected launch fails here, loudly, instead of spinning to max_ticks
