@@ -450,7 +450,8 @@ int orbhip_ba_solve_batch(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
 /* Parameters of Optimizer::BundleAdjustment / GlobalBundleAdjustemnt (src/Optimizer.cc:54-330; map initialisation
  * src/Tracking.cc:1603 with 20 iterations, LoopClosing::RunGlobalBundleAdjustment src/LoopClosing.cc:2437 with 10, bRobust = false):
  * the same graph and solver, ONE optimize(iterations) pass, Huber sqrt(5.99) / sqrt(7.815) when robust (else no kernel), no outlier
- * stage and no bail-out.  pose_fixed = (mnId == InitKFid) (:126).  Capacity: 80 free keyframes (dense reduced system). */
+ * stage and no bail-out.  pose_fixed = (mnId == InitKFid) (:126).  Up to 80 free keyframes the reduced system is built on the FP64
+ * matrix cores and factored inside one workgroup; larger windows (to 682 free keyframes) take a global-memory path. */
 void orbhip_ba_global_params(orbhip_ba_params *p, int iterations, int robust);
 
 /* Two-phase form of the same solver for callers that keep graphs resident in HBM (bench,

@@ -48,6 +48,8 @@ struct BaGraphDev {
     double kb[4];
     double Trl[7], fx2, fy2, cx2, cy2, kb2[4];       // second camera of a rigid pair (edge type 2, EdgeSE3ProjectXYZToBody)
     int cam2_model;
+    // windows with more than 80 free keyframes (n > BA_LDLT_MAXN): global-memory Schur complement and blocked LDL^T
+    size_t pair_off, pent_off;                       // into big_pair_start (nf (nf + 1) / 2 + 1 entries) / big_pair_ent
 };
 
 struct BaState {
@@ -117,6 +119,12 @@ struct BaBatch {      // kernel argument (by value)
     double *bacc;                        // [sumF*6] sum over this rank's edges of W db (k_ba_bschur)
     int *x_abort;                        // [1] any rank saw the abort flag (exchange 3)
     double *edges_total;                 // [G] number of edges over all ranks (>= 50 % outlier rule)
+    // big windows (any graph of the batch with n > BA_LDLT_MAXN): per graph, per pair of free poses i <= j (row-major over the upper
+    // triangle) the Hpl blocks of the points both see -- the Schur complement is summed per 6x6 block in a fixed order
+    int big;
+    const int *big_pair_start; const int2 *big_pair_ent;     // entries: {Hpl block of pose i, Hpl block of pose j} (batch-global block ids)
+    double *big_y, *big_d, *big_U;                           // [sumF*6] forward-substituted right-hand side, pivots; [G][32*32] unscaled diagonal-block columns
+    int *big_fail;                                           // [G] a zero / non-finite pivot was met
 };
 
 // ------------------------------------------------------------------ SE3 helpers (B1)
@@ -1130,6 +1138,233 @@ __global__ __launch_bounds__(1024) void k_ba_ldlt(BaBatch B)
     if (tid == 0) st.ok = 1;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Windows with more than 80 free keyframes (n = 6 nf > BA_LDLT_MAXN; the reference has no cap: Optimizer.cc:1703-1819 takes
+// every covisible keyframe, the merge variant :6255 two whole neighbourhoods).  The reduced system no longer fits the
+// single-workgroup kernels, so it is built and factored in global memory by many workgroups:
+//   k_ba_schur_big      S_ij = sum over the points seen by free poses i and j of W_i D^-1 W_j^T, one wave per 6x6 block pair,
+//                       fixed summation order (block_solver.hpp:381-432 restated per output block)
+//   k_ba_big_diag / _rows / _trail   right-looking blocked LDL^T, 32-column panels: diagonal block (one wave), the rows below
+//                       (one row per thread, many workgroups), rank-32 trailing update (64x64 tiles, many workgroups)
+//   k_ba_big_backsub    D^-1, L^T x = y
+// The arithmetic per entry is the LDS-panel kernel's (same ldlt_rows), so small and big windows factor alike.
+#define BA_BIG_MAXN 4096
+__global__ __launch_bounds__(64) void k_ba_schur_big(BaBatch B)
+{
+    const int g = blockIdx.y;
+    const BaState &st = B.st[g];
+    if (!st.active) return;
+    const BaGraphDev &G = B.gd[g];
+    const int nf = G.nf;
+    int bp = blockIdx.x;
+    if (bp >= nf * (nf + 1) / 2) return;
+    int i = 0;
+    while (bp >= nf - i) { bp -= nf - i; i++; }
+    const int j = i + bp;
+    const int lane = threadIdx.x;
+    const int *ps = B.big_pair_start + G.pair_off + blockIdx.x;
+    const int2 *ent = B.big_pair_ent + G.pent_off;
+    double acc[36];
+#pragma unroll
+    for (int k = 0; k < 36; k++) acc[k] = 0.0;
+    for (int e = ps[0] + lane; e < ps[1]; e += 64) {
+        const int2 t = ent[e];
+        const int l = B.gemm_task[t.x].z;
+        const double *L = B.Linv + (size_t)(G.point_off + l) * 6;
+        const double l0 = L[0], l1 = L[1], l2 = L[2], l3 = L[3], l4 = L[4], l5 = L[5];
+        const double *wa = B.Wsp + (size_t)t.x * 18, *wb = B.Wsp + (size_t)t.y * 18;
+        double za[3][6], zb[3][6];                                 // Z = C^-1 W (rows: the point's 3 coordinates)
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+            const double a0 = wa[a], a1 = wa[6 + a], a2 = wa[12 + a], b0 = wb[a], b1 = wb[6 + a], b2 = wb[12 + a];
+            za[0][a] = l0 * a0; za[1][a] = l1 * a0 + l2 * a1; za[2][a] = l3 * a0 + l4 * a1 + l5 * a2;
+            zb[0][a] = l0 * b0; zb[1][a] = l1 * b0 + l2 * b1; zb[2][a] = l3 * b0 + l4 * b1 + l5 * b2;
+        }
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int c = 0; c < 6; c++) acc[6 * r + c] += za[0][r] * zb[0][c] + za[1][r] * zb[1][c] + za[2][r] * zb[2][c];
+    }
+    double *Sp = B.Spart + G.spart_off;                            // ks == 1: k_ba_schur_finish subtracts this from blockdiag(Hpp + lambda I)
+#pragma unroll
+    for (int k = 0; k < 36; k++) {
+        const double v = wave_sum_f64_dpp(acc[k]);
+        if (lane == 0) {
+            const int r = k / 6, c = k - 6 * r;
+            Sp[(size_t)(6 * i + r) * G.ld + 6 * j + c] = v;
+            Sp[(size_t)(6 * j + c) * G.ld + 6 * i + r] = v;       // (i == j: the block is symmetric up to rounding; the later write wins, both are valid sums)
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ba_big_init(BaBatch B)
+{
+    const int g = blockIdx.y;
+    const BaState &st = B.st[g];
+    if (!st.active) return;
+    const BaGraphDev &G = B.gd[g];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < G.n) B.big_y[(size_t)G.free_off * 6 + i] = B.bs[(size_t)G.free_off * 6 + i];
+    if (i == 0) B.big_fail[g] = 0;
+}
+
+__global__ __launch_bounds__(64) void k_ba_big_diag(BaBatch B, int p0)
+{
+    __shared__ double P[LD_NB * LD_PP], U[LD_NB * LD_NB], dv[LD_NB], yv[LD_NB];
+    __shared__ int s_ok;
+    const int g = blockIdx.x, lane = threadIdx.x;
+    const BaState &st = B.st[g];
+    if (!st.active) return;
+    const BaGraphDev &G = B.gd[g];
+    if (p0 >= G.n || B.big_fail[g]) return;
+    const int nb = min(LD_NB, G.n - p0), ld = G.ld;
+    double *S = B.S + G.s_off, *y = B.big_y + (size_t)G.free_off * 6, *d = B.big_d + (size_t)G.free_off * 6;
+    if (lane == 0) s_ok = 1;
+    if (lane < nb) {
+        for (int c = 0; c < nb; c++) P[lane * LD_PP + c] = S[(size_t)(p0 + lane) * ld + p0 + c];
+        yv[lane] = y[p0 + lane];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < nb) ldlt_rows<true>(P, U, dv, yv, lane, nb, &s_ok);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (!s_ok) { if (lane == 0) B.big_fail[g] = 1; return; }
+    if (lane < nb) {
+        for (int c = 0; c <= lane; c++) S[(size_t)(p0 + lane) * ld + p0 + c] = (c == lane) ? dv[c] : P[lane * LD_PP + c];
+        d[p0 + lane] = dv[lane]; y[p0 + lane] = yv[lane];
+    }
+    double *Ug = B.big_U + (size_t)g * LD_NB * LD_NB;
+    for (int k = lane; k < LD_NB * LD_NB; k += 64) Ug[k] = U[k];
+}
+
+__global__ __launch_bounds__(256) void k_ba_big_rows(BaBatch B, int p0)
+{
+    extern __shared__ double brl[];                  // P [32 + 256][LD_PP] (rows 0..31 unused), U [32*32], dv [32], yv [32 + 256]
+    __shared__ int s_dummy;
+    const int g = blockIdx.y, tid = threadIdx.x;
+    const BaState &st = B.st[g];
+    if (!st.active) return;
+    const BaGraphDev &G = B.gd[g];
+    if (p0 >= G.n || B.big_fail[g]) return;
+    const int nb = min(LD_NB, G.n - p0), m = G.n - p0, ld = G.ld;
+    const int r = nb + blockIdx.x * 256 + tid;           // row of the panel (relative to p0)
+    if (nb + blockIdx.x * 256 >= m) return;
+    double *P = brl, *U = P + (size_t)(LD_NB + 256) * LD_PP, *dv = U + LD_NB * LD_NB, *yv = dv + LD_NB;
+    double *S = B.S + G.s_off, *y = B.big_y + (size_t)G.free_off * 6;
+    const double *Ug = B.big_U + (size_t)g * LD_NB * LD_NB, *d = B.big_d + (size_t)G.free_off * 6;
+    for (int k = tid; k < LD_NB * LD_NB; k += 256) U[k] = Ug[k];
+    if (tid < nb) { dv[tid] = d[p0 + tid]; yv[tid] = y[p0 + tid]; }
+    const int rl = LD_NB + tid;                          // this thread's row inside the LDS panel
+    if (r < m) {
+        for (int c = 0; c < nb; c++) P[rl * LD_PP + c] = S[(size_t)(p0 + r) * ld + p0 + c];
+        yv[rl] = y[p0 + r];
+    }
+    __syncthreads();
+    if (r < m) {
+        ldlt_rows<false>(P, U, dv, yv, rl, nb, &s_dummy);
+        for (int c = 0; c < nb; c++) S[(size_t)(p0 + r) * ld + p0 + c] = P[rl * LD_PP + c];
+        y[p0 + r] = yv[rl];
+    }
+}
+
+// trailing update S[i][k] -= sum_c L[i][c] d_c L[k][c] for i >= k >= p0 + nb: 64x64 tiles of the lower triangle, 4x4 per thread
+__global__ __launch_bounds__(256) void k_ba_big_trail(BaBatch B, int p0)
+{
+    __shared__ double LI[64 * LD_PP], LK[64 * LD_PP], dv[LD_NB];
+    const int g = blockIdx.z, tid = threadIdx.x;
+    const BaState &st = B.st[g];
+    if (!st.active) return;
+    const BaGraphDev &G = B.gd[g];
+    if (p0 >= G.n || B.big_fail[g]) return;
+    const int nb = min(LD_NB, G.n - p0), ld = G.ld;
+    const int base = p0 + nb, m2 = G.n - base;
+    const int ti = blockIdx.y, tk = blockIdx.x;
+    if (tk > ti || 64 * ti >= m2) return;
+    double *S = B.S + G.s_off;
+    const double *d = B.big_d + (size_t)G.free_off * 6;
+    for (int idx = tid; idx < 64 * LD_NB; idx += 256) {
+        const int r = idx >> 5, c = idx & 31;
+        const int gi = base + 64 * ti + r, gk = base + 64 * tk + r;
+        LI[r * LD_PP + c] = (c < nb && gi < G.n) ? S[(size_t)gi * ld + p0 + c] : 0.0;
+        LK[r * LD_PP + c] = (c < nb && gk < G.n) ? S[(size_t)gk * ld + p0 + c] : 0.0;
+    }
+    if (tid < LD_NB) dv[tid] = tid < nb ? d[p0 + tid] : 0.0;
+    __syncthreads();
+    const int a0 = 4 * (tid >> 4), b0 = 4 * (tid & 15);
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b2 = 0; b2 < 4; b2++) acc[a][b2] = 0.0;
+    for (int c = 0; c < nb; c++) {
+        const double dc = dv[c];
+        double av[4], bv[4];
+#pragma unroll
+        for (int a = 0; a < 4; a++) { av[a] = LI[(a0 + a) * LD_PP + c] * dc; bv[a] = LK[(b0 + a) * LD_PP + c]; }
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b2 = 0; b2 < 4; b2++) acc[a][b2] += av[a] * bv[b2];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b2 = 0; b2 < 4; b2++) {
+            const int gi = base + 64 * ti + a0 + a, gk = base + 64 * tk + b0 + b2;
+            if (gi < G.n && gk <= gi) S[(size_t)gi * ld + gk] -= acc[a][b2];
+        }
+}
+
+__global__ __launch_bounds__(1024) void k_ba_big_backsub(BaBatch B)
+{
+    extern __shared__ double bbl[];                  // y [max_ld], red [32*32], P [32][LD_PP]
+    const int g = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
+    BaState &st = B.st[g];
+    if (!st.active) return;
+    const BaGraphDev &G = B.gd[g];
+    const int n = G.n, ld = G.ld;
+    if (B.big_fail[g]) { if (tid == 0) st.ok = 0; return; }      // x untouched (as the reference on failure)
+    double *y = bbl, *red = y + B.max_ld, *P = red + 32 * 32;
+    const double *S = B.S + G.s_off, *dval = B.big_d + (size_t)G.free_off * 6;
+    // y <- D^-1 y, then L^T x = y panel by panel from the bottom
+    for (int i = tid; i < n; i += nth) y[i] = B.big_y[(size_t)G.free_off * 6 + i] / dval[i];
+    __syncthreads();
+    const int last_p0 = ((n - 1) / LD_NB) * LD_NB;
+    for (int p0 = last_p0; p0 >= 0; p0 -= LD_NB) {
+        const int nb = min(LD_NB, n - p0), m = n - p0;
+        {
+            const int c = tid & 31, rg = tid >> 5;          // 1024 threads = 32 columns x 32 row groups
+            double part = 0.0;
+            if (c < nb)
+                for (int r = nb + rg; r < m; r += 32) part += S[(size_t)(p0 + r) * ld + p0 + c] * y[p0 + r];
+            red[rg * 32 + c] = part;
+        }
+        for (int idx = tid; idx < nb * LD_NB; idx += nth) {   // diagonal block of L into LDS
+            const int r = idx >> 5, c = idx & 31;
+            if (c < nb) P[r * LD_PP + c] = S[(size_t)(p0 + r) * ld + p0 + c];
+        }
+        __syncthreads();
+        if (tid < nb) {
+            double t = 0.0;
+            for (int rg = 0; rg < 32; rg++) t += red[rg * 32 + tid];
+            y[p0 + tid] -= t;
+        }
+        __syncthreads();
+        if (tid < 64) {                                       // 32x32 triangular solve inside one wave
+            for (int jj = nb - 1; jj >= 0; jj--) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const double xj = y[p0 + jj];
+                if (tid < jj) y[p0 + tid] -= P[jj * LD_PP + tid] * xj;
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += nth) B.xp[(size_t)G.free_off * 6 + i] = y[i];
+    if (tid == 0) st.ok = 1;
+}
+
 // landmark back-substitution (block_solver.hpp:461-481) + trial update of every vertex
 // (sparse_optimizer.cpp:422-435) + computeScale partials (levenberg.cpp:187-194)
 __global__ __launch_bounds__(256) void k_ba_backsub_points(BaBatch B)
@@ -1474,6 +1709,8 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
     std::vector<int> enext;
     int sumP = 0, sumL = 0, sumE = 0, sumF = 0;
     size_t s = 0, sp = 0;
+    bool any_big = false;
+    std::vector<std::vector<int>> g_local_h;                 // hessian index of every pose, per graph (big windows: pair lists)
     // split-K so that the Schur GEMM launches >= ~4096 waves
     for (int g = 0; g < n_graphs; g++) {
         const orbhip_ba_graph &H = graphs[g];
@@ -1496,7 +1733,10 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
         int nf = 0;
         for (int i = 0; i < H.n_poses; i++) { local_h[i] = (!H.pose_fixed[i] && has[i]) ? nf++ : -1; hidx.push_back(local_h[i]); }
         D.nf = nf; D.n = 6 * nf; D.ld = std::max(96, (D.n + 95) / 96 * 96);   // multiple of 16 (MFMA tiles) and of 32 (1-KiB LDS-DMA pieces)
-        if (D.n > BA_LDLT_MAXN) { delete b; g_ba_error = "too many free keyframes for the LDS-panel LDLT (max 80)"; return ORBHIP_E_BADARG; }
+        if (D.n > BA_BIG_MAXN) { delete b; g_ba_error = "more than 682 free keyframes in one window"; return ORBHIP_E_BADARG; }
+        const bool big_graph = D.n > BA_LDLT_MAXN;               // > 80 free keyframes: global-memory Schur complement + blocked LDL^T
+        if (big_graph && world > 1) { delete b; g_ba_error = "landmark-sharded solve: at most 80 free keyframes per window"; return ORBHIP_E_BADARG; }
+        any_big = any_big || big_graph;
         D.ptstart_off = (int)ptstart.size();
         std::vector<int> cnt(H.n_points + 1, 0);
         for (int e = 0; e < H.n_edges; e++) cnt[H.edge_point[e] + 1]++;
@@ -1557,8 +1797,8 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
             for (int l = 0; l < H.n_points; l++) {
                 int e1 = e, cnt = 0;
                 while (e1 < H.n_edges && H.edge_point[e1] == l) { if (local_h[H.edge_pose[e1]] >= 0 && !dupv[e1]) cnt++; e1++; }
-                if (cnt > GEMM_STAGE_EDGES) { delete b; g_ba_error = "a point has more Hpl blocks than free keyframes fit (ld <= 512)"; return ORBHIP_E_BADARG; }
-                if (npts == D.gemm_ps || ntask + cnt > GEMM_STAGE_EDGES) {
+                if (cnt > GEMM_STAGE_EDGES && !big_graph) { delete b; g_ba_error = "a point has more Hpl blocks than free keyframes fit (ld <= 512)"; return ORBHIP_E_BADARG; }
+                if (npts == D.gemm_ps || ntask + cnt > GEMM_STAGE_EDGES) {       // (big windows: the stage lists are built but not used)
                     gstage.push_back(make_int4(pt0, npts, t0, ntask));
                     pt0 = l; npts = 0; t0 += ntask; ntask = 0;
                 }
@@ -1581,14 +1821,16 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
         // split the stages so that every CU has a workgroup
         int ks = (GEMM_TARGET_WGS + n_graphs * D.ngrp - 1) / (n_graphs * D.ngrp);
         ks = std::max(1, std::min(ks, std::max(1, D.n_stages / 4)));
+        if (big_graph) ks = 1;                                   // k_ba_schur_big writes the whole block matrix once
         D.ks = ks;
+        g_local_h.push_back(local_h);
         {   // static block-sparsity masks: 16-column tiles of the point's Hpl column that hold a non-zero block
             double issued = 0;
             for (int l = 0; l < H.n_points; l++) ptmask.push_back(0u);
             uint32_t *pmv = ptmask.data() + (ptmask.size() - H.n_points);
             for (int e = 0; e < H.n_edges; e++) {
                 const int h = local_h[H.edge_pose[e]];
-                if (h >= 0) pmv[H.edge_point[e]] |= (1u << ((6 * h) >> 4)) | (1u << ((6 * h + 5) >> 4));
+                if (h >= 0 && !big_graph) pmv[H.edge_point[e]] |= (1u << ((6 * h) >> 4)) | (1u << ((6 * h + 5) >> 4));
             }
             double chunks = 0;                                                         // the kernel's issue rule: row tile hit AND a column tile of the chunk hit
             for (int l = 0; l < H.n_points; l++) {
@@ -1627,6 +1869,46 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
     }
     B.sumP = sumP; B.sumL = sumL; B.sumE = sumE; B.sumF = sumF;
     b->s_total = s; b->spart_total = sp;
+    // big windows: every graph of the batch takes the global-memory path; per graph and pair of free poses (i <= j) the Hpl blocks
+    // of the points both see, in point order (the summation order of k_ba_schur_big)
+    std::vector<int> pair_start; std::vector<int2> pair_ent;
+    B.big = any_big ? 1 : 0;
+    if (any_big) {
+        for (int g = 0; g < n_graphs; g++) {
+            BaGraphDev &D = b->gd[g];
+            D.ks = 1;                                            // k_ba_schur_big writes slice 0 only
+            const orbhip_ba_graph &H = graphs[g];
+            const std::vector<int> &lh = g_local_h[g];
+            const int nf = D.nf, npair = nf * (nf + 1) / 2;
+            D.pair_off = pair_start.size(); D.pent_off = pair_ent.size();
+            std::vector<int> cnt(npair + 1, 0);
+            auto pidx = [&](int i, int j) { return i * nf - i * (i - 1) / 2 + (j - i); };
+            const int *et = etask.data() + D.edge_off;
+            for (int pass = 0; pass < 2; pass++) {
+                std::vector<int> fill(cnt.begin(), cnt.end() - 1);
+                for (int e0 = 0; e0 < H.n_edges;) {
+                    int e1 = e0;
+                    while (e1 < H.n_edges && H.edge_point[e1] == H.edge_point[e0]) e1++;
+                    for (int a = e0; a < e1; a++) {
+                        if (et[a] < 0) continue;
+                        for (int c = e0; c < e1; c++) {
+                            if (et[c] < 0) continue;
+                            const int i = lh[H.edge_pose[a]], j = lh[H.edge_pose[c]];
+                            if (i > j || (i == j && a != c)) continue;           // every unordered pair once; the diagonal pair is (a, a)
+                            if (pass == 0) cnt[pidx(i, j) + 1]++;
+                            else pair_ent[D.pent_off + fill[pidx(i, j)]++] = make_int2(et[a], et[c]);
+                        }
+                    }
+                    e0 = e1;
+                }
+                if (pass == 0) {
+                    for (int k = 0; k < npair; k++) cnt[k + 1] += cnt[k];
+                    pair_ent.resize(D.pent_off + cnt[npair]);
+                }
+            }
+            pair_start.insert(pair_start.end(), cnt.begin(), cnt.end());
+        }
+    }
     b->x_need = std::max(std::max(x1, x2), (size_t)3 * n_graphs);
     bool ok = true;
 #define UP(dst, vec) do { auto *_p = ba_upload(b, vec); ok = ok && _p; dst = _p; } while (0)
@@ -1635,6 +1917,11 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
     UP(B.edge_is2, eis2); UP(B.edge_stereo, est); UP(B.edge_dup, edup); UP(B.edge_next, enext); UP(B.pt_start, ptstart); UP(B.pose_start, posestart); UP(B.pose_edges, poseedges);
     UP(B.ptmask, ptmask); UP(B.gemm_task, gtask); UP(B.gemm_stage, gstage); UP(B.edge_task, etask); UP(B.x1_off, x1off); UP(B.x2_off, x2off);
     UP(B.pm_point, pmpoint); UP(B.pm_task, pmtask); UP(B.pm_type, pmtype); UP(B.pm_is2, pmis2); UP(B.pm_obs, pmobs);
+    if (any_big) {
+        UP(B.big_pair_start, pair_start); UP(B.big_pair_ent, pair_ent);
+        AL(B.big_y, double, (size_t)sumF * 6); AL(B.big_d, double, (size_t)sumF * 6); AL(B.big_U, double, (size_t)n_graphs * LD_NB * LD_NB);
+        AL(B.big_fail, int, n_graphs);
+    }
     AL(B.st, BaState, n_graphs);
     AL(B.poses, double, (size_t)2 * sumP * 7); AL(B.points, double, (size_t)2 * sumL * 3);
     AL(B.err, double, (size_t)sumE * 3); AL(B.chi2, double, sumE); AL(B.rho0, double, sumE);
@@ -1748,8 +2035,16 @@ static int ba_solve_impl(orbhip_ba_batch *b, const orbhip_ba_params *params, vol
     size_t gemm_lds = 0;
     for (auto &D : b->gd) gemm_lds = std::max(gemm_lds, sizeof(double) * (2 * (size_t)D.gemm_ps * 3 * (size_t)(D.ld + GEMM_LDS_PAD) + GEMM_LDS_TAIL));
     if (orb_lds_optin(reinterpret_cast<const void *>(k_ba_schur_gemm), orbhip_ctx_device_internal(b->ctx), gemm_lds)) { g_ba_error = "LDS opt-in (k_ba_schur_gemm)"; return ORBHIP_E_HIP; }
-    const size_t ldlt_lds = ba_ldlt_lds_bytes(B.max_ld);
-    if (orb_lds_optin(reinterpret_cast<const void *>(k_ba_ldlt), orbhip_ctx_device_internal(b->ctx), ldlt_lds)) { g_ba_error = "LDS opt-in (k_ba_ldlt)"; return ORBHIP_E_HIP; }
+    const size_t ldlt_lds = B.big ? 0 : ba_ldlt_lds_bytes(B.max_ld);
+    if (!B.big && orb_lds_optin(reinterpret_cast<const void *>(k_ba_ldlt), orbhip_ctx_device_internal(b->ctx), ldlt_lds)) { g_ba_error = "LDS opt-in (k_ba_ldlt)"; return ORBHIP_E_HIP; }
+    const size_t rows_lds = sizeof(double) * ((size_t)(LD_NB + 256) * LD_PP + LD_NB * LD_NB + LD_NB + LD_NB + 256);
+    const size_t bsub_lds = sizeof(double) * ((size_t)B.max_ld + 32 * 32 + LD_NB * LD_PP);
+    int max_n = 0, max_nfp = 0;
+    for (auto &D : b->gd) { max_n = std::max(max_n, D.n); max_nfp = std::max(max_nfp, D.nf * (D.nf + 1) / 2); }
+    if (B.big) {
+        if (orb_lds_optin(reinterpret_cast<const void *>(k_ba_big_rows), orbhip_ctx_device_internal(b->ctx), rows_lds) ||
+            orb_lds_optin(reinterpret_cast<const void *>(k_ba_big_backsub), orbhip_ctx_device_internal(b->ctx), bsub_lds)) { g_ba_error = "LDS opt-in (big LDLT)"; return ORBHIP_E_HIP; }
+    }
     const int max_ticks = (params->iters1 + params->iters2) * params->max_trials + 4;
     int tick = 0;
     // one LM tick: every graph that is still active evaluates, builds, solves and tries one step (inactive graphs return at once)
@@ -1769,7 +2064,8 @@ static int ba_solve_impl(orbhip_ba_batch *b, const orbhip_ba_params *params, vol
         hipLaunchKernelGGL(k_ba_pretrial, dim3((G + 63) / 64), dim3(64), 0, s, B);
         hipLaunchKernelGGL(k_ba_point_prep, gp256, dim3(256), 0, s, B);
         if (b->profile) TRY(hipEventRecord(b->ev0, s));
-        hipLaunchKernelGGL(k_ba_schur_gemm, dim3(max_items, G), dim3(64 * GEMM_WAVES), gemm_lds, s, B);
+        if (B.big) hipLaunchKernelGGL(k_ba_schur_big, dim3(max_nfp, G), dim3(64), 0, s, B);
+        else hipLaunchKernelGGL(k_ba_schur_gemm, dim3(max_items, G), dim3(64 * GEMM_WAVES), gemm_lds, s, B);
         if (b->profile) TRY(hipEventRecord(b->ev1, s));
         hipLaunchKernelGGL(k_ba_bschur, gf, dim3(64), 0, s, B);
         if (sharded) {                                           // exchange 2: the shared Schur block (sum_ks Spart) and W db
@@ -1778,7 +2074,20 @@ static int ba_solve_impl(orbhip_ba_batch *b, const orbhip_ba_params *params, vol
             hipLaunchKernelGGL(k_ba_shard_sum2, dim3(G), dim3(256), 0, s, B);
         }
         hipLaunchKernelGGL(k_ba_schur_finish, dim3((B.max_ld * B.max_ld + 255) / 256, G), dim3(256), 0, s, B);
-        hipLaunchKernelGGL(k_ba_ldlt, dim3(G), dim3(1024), ldlt_lds, s, B);
+        if (!B.big) hipLaunchKernelGGL(k_ba_ldlt, dim3(G), dim3(1024), ldlt_lds, s, B);
+        else {
+            hipLaunchKernelGGL(k_ba_big_init, dim3((max_n + 255) / 256, G), dim3(256), 0, s, B);
+            for (int p0 = 0; p0 < max_n; p0 += LD_NB) {
+                const int m2 = max_n - p0 - LD_NB;
+                hipLaunchKernelGGL(k_ba_big_diag, dim3(G), dim3(64), 0, s, B, p0);
+                if (m2 > 0) {
+                    hipLaunchKernelGGL(k_ba_big_rows, dim3((m2 + 255) / 256, G), dim3(256), rows_lds, s, B, p0);
+                    const int nt = (m2 + 63) / 64;
+                    hipLaunchKernelGGL(k_ba_big_trail, dim3(nt, nt, G), dim3(256), 0, s, B, p0);
+                }
+            }
+            hipLaunchKernelGGL(k_ba_big_backsub, dim3(G), dim3(1024), bsub_lds, s, B);
+        }
         hipLaunchKernelGGL(k_ba_backsub_points, dim3((B.max_points + 15) / 16, G), dim3(256), 0, s, B);
         hipLaunchKernelGGL(k_ba_update_poses, dim3((max_poses + 63) / 64, G), dim3(64), 0, s, B);
         if (b->general) hipLaunchKernelGGL(k_ba_errors<true>, ge, dim3(256), 0, s, B, 1); else hipLaunchKernelGGL(k_ba_errors<false>, ge, dim3(256), 0, s, B, 1);

@@ -398,3 +398,15 @@ def test_ba_golden_fixture_without_oracle(gpu_ctx):
     assert _rmse(poses[0], gold["poses"]) <= 1e-7, "closer than the tolerance in practice: a drift worth looking at"
     np.testing.assert_array_equal(outl[0], gold["outlier"])
     assert stats[0]["iterations_run"] == gold["iterations_run"].tolist() and stats[0]["lm_trials"] == int(gold["lm_trials"])
+
+
+@pytest.mark.parametrize("n_kf,n_pts", [(122, 2500), (202, 3000)])
+def test_ba_more_than_80_free_keyframes(gpu_ctx, n_kf, n_pts):
+    """The reference takes every covisible keyframe into the window (Optimizer.cc:1703-1819; the merge variant two whole
+    neighbourhoods): 120 and 200 free keyframes -- a reduced system of 720 / 1200 unknowns, built per 6x6 block and factored by
+    the global-memory blocked LDL^T -- against the oracle; a smaller window in the same batch takes the same path."""
+    import synth_ba
+    graphs = [synth_ba.make_graph(n_kf=n_kf, n_pts=n_pts, obs=10, seed=300 + n_kf),
+              synth_ba.make_graph(n_kf=9, n_pts=120, obs=5, seed=301 + n_kf)]
+    st = _check(gpu_ctx, graphs)
+    assert st[0]["iterations_run"][0] == 5
