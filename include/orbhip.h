@@ -218,6 +218,24 @@ int orbhip_search_local_map_device(orbhip_ctx *ctx, const orbhip_proj_query *d_q
                                    float max_y, int th_high, float nn_ratio, int32_t *d_train_match,
                                    int32_t *d_nmatches);
 
+/* The two searches above on frames of a two-camera rig (CurrentFrame.Nleft != -1: TUM-VI stereo-fisheye, src/Frame.cc:1034-1126) --
+ * ORBmatcher.cc:2013-2016 + :2089-2153 (mode 0: SearchByProjection(CurrentFrame, LastFrame, ...)) and :113-122 + :136-214 (mode 1:
+ * SearchByProjection(F, vpMapPoints, ...)).  The train side is the whole frame: keypoints [0, d_nleft[pair]) = F.mvKeys (left camera),
+ * [d_nleft[pair], d_n[pair]) = F.mvKeysRight, descriptors likewise (F.mDescriptors rows, ORBmatcher.cc:176); each camera has its own
+ * grid (mGrid / mGridRight, src/Frame.cc:395-405) and there is no uRight gate.  A query searches the LEFT camera's grid, or the RIGHT
+ * one's when bit 1 of has_obs is set (bit 0 keeps its meaning); the caller emits a point's left query (u, v = projection in the left
+ * camera) and then its right query (projection in the right camera: :2090-2092, or mTrackProjXR / YR with radius
+ * RadiusByViewingCos(mTrackViewCosR) * scale[mnTrackScaleLevelR], :151-156) in the reference's order, so the claim rule sees the same
+ * sequence.  d_mirror [pairs][max_n] (mode 1; may be NULL): for every keypoint the frame-wide index of the same point's keypoint in the
+ * other camera -- mvLeftToRightMatch[i] + Nleft for i < Nleft, mvRightToLeftMatch[i - Nleft] otherwise -- or -1: a match also assigns
+ * that keypoint and counts twice (:142-146, :203-207).  Outputs as in the single-camera calls (d_train_match indexed frame-wide). */
+int orbhip_search_by_projection_rig_device(orbhip_ctx *ctx, int mode, const orbhip_proj_query *d_q, const uint8_t *d_desc_q,
+                                           const int32_t *d_nq, int max_q, const orbhip_keypoint *d_kp, const uint8_t *d_desc,
+                                           const int32_t *d_n, const int32_t *d_nleft, const int32_t *d_mirror, int max_n,
+                                           size_t frame_stride_kp, int pairs, float min_x, float min_y, float max_x, float max_y,
+                                           int th_high, float nn_ratio, int check_orientation, int32_t *d_train_match,
+                                           int32_t *d_nmatches);
+
 /* Host-pointer forms of the two calls above for ONE frame (what an ORBmatcher method with the reference's signature needs:
  * host/ORBmatcher.cc): upload into the context's arena, run the same kernel, download, synchronise.  mode 0 =
  * orbhip_search_by_projection_device (nn_ratio unused), 1 = orbhip_search_local_map_device (check_orientation unused).
@@ -226,6 +244,11 @@ int orbhip_search_by_projection_host(orbhip_ctx *ctx, int mode, const orbhip_pro
                                      const orbhip_keypoint *kp, const uint8_t *desc, const float *u_right, int n,
                                      float min_x, float min_y, float max_x, float max_y, int th_high, float nn_ratio,
                                      int check_orientation, int32_t *train_match_inout, int32_t *nmatches_out);
+/* ... and of orbhip_search_by_projection_rig_device: kp / desc are the frame's left | right keypoints, nleft = Nleft, mirror [n] or NULL. */
+int orbhip_search_by_projection_rig_host(orbhip_ctx *ctx, int mode, const orbhip_proj_query *q, const uint8_t *desc_q, int nq,
+                                         const orbhip_keypoint *kp, const uint8_t *desc, int n, int nleft, const int32_t *mirror,
+                                         float min_x, float min_y, float max_x, float max_y, int th_high, float nn_ratio,
+                                         int check_orientation, int32_t *train_match_inout, int32_t *nmatches_out);
 /* Host-pointer form of orbhip_search_for_initialization_device for one frame pair: prev_matched_inout [nA][2] is vbPrevMatched
  * (in/out), matches12_out [nA] is vnMatches12, *nmatches_out the return value.  All pointers HOST. */
 int orbhip_search_for_initialization_host(orbhip_ctx *ctx, const orbhip_keypoint *kpA, const uint8_t *descA, int nA,
@@ -266,6 +289,19 @@ int orbhip_search_by_bow_device(orbhip_ctx *ctx,
         const uint8_t *d_kf_valid, const orbhip_keypoint *d_kf_kp, const uint8_t *d_kf_desc,
         const int32_t *d_f_node_ids, const int32_t *d_f_node_start, const int32_t *d_f_feat, const int32_t *d_f_nnodes,
         const orbhip_keypoint *d_f_kp, const uint8_t *d_f_desc, const int32_t *d_nF,
+        int pairs, int max_nodes, int max_n, size_t frame_stride_kp, float nn_ratio, int check_orientation,
+        int32_t *d_match_f, int32_t *d_nmatches);
+
+/* orbhip_search_by_bow_device for frames of a two-camera rig (F.Nleft != -1, ORBmatcher.cc:338-359, :393-425): frame features
+ * [0, d_nleft[pair]) are the left camera's, the rest the right camera's (F.mDescriptors order; keypoints concatenated mvKeys | mvKeysRight,
+ * on the keyframe side too).  Every keyframe feature keeps a best / second best PER CAMERA; when the left best passes TH_LOW the left
+ * match needs the ratio test and the right camera's best is taken whenever it passes TH_LOW (the reference's "|| true").  Everything
+ * else as orbhip_search_by_bow_device. */
+int orbhip_search_by_bow_rig_device(orbhip_ctx *ctx,
+        const int32_t *d_kf_node_ids, const int32_t *d_kf_node_start, const int32_t *d_kf_feat, const int32_t *d_kf_nnodes,
+        const uint8_t *d_kf_valid, const orbhip_keypoint *d_kf_kp, const uint8_t *d_kf_desc,
+        const int32_t *d_f_node_ids, const int32_t *d_f_node_start, const int32_t *d_f_feat, const int32_t *d_f_nnodes,
+        const orbhip_keypoint *d_f_kp, const uint8_t *d_f_desc, const int32_t *d_nF, const int32_t *d_nleft,
         int pairs, int max_nodes, int max_n, size_t frame_stride_kp, float nn_ratio, int check_orientation,
         int32_t *d_match_f, int32_t *d_nmatches);
 
@@ -326,6 +362,13 @@ int orbhip_undistort_keypoints_device(orbhip_ctx *ctx, const orbhip_keypoint *d_
 int orbhip_assign_features_to_grid_device(orbhip_ctx *ctx, const orbhip_keypoint *d_kp, const int32_t *d_n, int frames, int max_n,
                                           size_t frame_stride_kp, float min_x, float min_y, float max_x, float max_y,
                                           int32_t *d_cell_start, int32_t *d_items);
+
+/* Frame::AssignFeaturesToGrid for frames of a two-camera rig (Nleft != -1, src/Frame.cc:395-405): keypoints [0, d_nleft[f]) fill mGrid,
+ * the others mGridRight.  d_cell_start [frames][2*64*48+1]: cells 0 .. 3071 = mGrid (cell ix*48+iy), 3072 .. 6143 = mGridRight, one
+ * running CSR into d_items [frames][max_n]; mGrid items are keypoint indices, mGridRight items are i - Nleft (:403). */
+int orbhip_assign_features_to_grid_rig_device(orbhip_ctx *ctx, const orbhip_keypoint *d_kp, const int32_t *d_n, const int32_t *d_nleft,
+                                              int frames, int max_n, size_t frame_stride_kp, float min_x, float min_y, float max_x,
+                                              float max_y, int32_t *d_cell_start, int32_t *d_items);
 
 /* Second half of Frame::ComputeBoW (src/Frame.cc:729-736): TemplatedVocabulary::transform(features, mBowVec, mFeatVec, 4)
  * (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1139-1208, TF_IDF weighting + L1 norm as in ORBvoc) from the per-feature

@@ -662,3 +662,123 @@ void orc_bow_vectors(const int32_t *wid, const double *w, const int32_t *nid, in
     *nnodes = nn; *nwords = nw;
     free(fv_list); free(fv_cnt);
 }
+
+/* ---- frames of a two-camera rig (Nleft != -1; TUM-VI stereo-fisheye, Frame.cc:1034-1126) ---------------------------------------
+ * Keypoints [0, nleft) = F.mvKeys, [nleft, n) = F.mvKeysRight; mGrid / mGridRight (Frame.cc:395-405, :686).  has_obs bit 1 of a query =
+ * the search runs in the right camera (GetFeaturesInArea(..., bRight = true)); candidates are frame-wide indices (idx + Nleft). */
+/* ORBm:1965-2181 with CurrentFrame.Nleft != -1 (mode 0) and ORBm:48-218 with F.Nleft != -1 (mode 1); the caller lists a point's left
+ * query and then its right query (ORBm:2089-2153 / :149-214) */
+int orc_search_by_projection_rig(int mode, const orc_proj_query *q, const uint8_t *desc_q, int nq,
+                                 const orc_keypoint *kp, const uint8_t *desc, int n, int nleft, const int32_t *mirror,
+                                 float min_x, float min_y, float max_x, float max_y,
+                                 int th_high, float nn_ratio, int check_orientation, int32_t *train_match)
+{
+    int nmatches = 0;
+    struct grid g[2];
+    grid_build(&g[0], kp, nleft, min_x, min_y, max_x, max_y);
+    grid_build(&g[1], kp + nleft, n - nleft, min_x, min_y, max_x, max_y);
+    int *hist_n = (int *)calloc(HISTO_LENGTH, sizeof(int));
+    int *hist_items = (int *)malloc(sizeof(int) * (size_t)HISTO_LENGTH * (nq ? nq : 1));
+    int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * (n ? n : 1));
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int i = 0; i < n; i++) if (train_match[i] != -1) train_match[i] = -2;
+    for (int t = 0; t < nq; t++) {
+        const int cam = (q[t].has_obs >> 1) & 1, off = cam ? nleft : 0;
+        const float radius = q[t].radius;
+        const int nc = grid_query(&g[cam], kp + off, q[t].u, q[t].v, radius, q[t].min_level, q[t].max_level, cand, n);
+        if (nc == 0) continue;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int c = 0; c < nc; c++) {
+            const int idx = cand[c] + off;
+            const int h = train_match[idx];
+            if (h <= -2 || (h >= 0 && (q[h].has_obs & 1))) continue;                                           /* ORBm:110-112, 174-176, 2037-2039, 2120-2122 */
+            const int dist = orc_descriptor_distance(desc_q + 32 * (size_t)t, desc + 32 * (size_t)idx);
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = kp[idx].octave; bestIdx = idx; }
+            else if (dist < bestDist2) { bestLevel2 = kp[idx].octave; bestDist2 = dist; }
+        }
+        if (bestDist > th_high) continue;
+        if (mode == 1) {                                                                                       /* ORBm:131-150, 197-212 */
+            if (bestLevel == bestLevel2 && bestDist > nn_ratio * bestDist2) continue;
+            train_match[bestIdx] = t; nmatches++;
+            if (mirror && mirror[bestIdx] >= 0) { train_match[mirror[bestIdx]] = t; nmatches++; }
+        } else {                                                                                               /* ORBm:2058-2086, 2135-2152 */
+            train_match[bestIdx] = t; nmatches++;
+            if (check_orientation) {
+                float rot = q[t].angle - kp[bestIdx].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                hist_items[(size_t)bin * nq + hist_n[bin]++] = bestIdx;
+            }
+        }
+    }
+    if (mode == 0 && check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(hist_n, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int j = 0; j < hist_n[i]; j++) { train_match[hist_items[(size_t)i * nq + j]] = -1; nmatches--; }
+    }
+    free(cand); free(hist_items); free(hist_n); grid_free(&g[0]); grid_free(&g[1]);
+    return nmatches;
+}
+
+/* ORBm:273-475 with F.Nleft != -1 */
+int orc_search_by_bow_rig(const int32_t *kf_node_ids, const int32_t *kf_node_start, const int32_t *kf_feat, int kf_nnodes,
+                          const uint8_t *kf_valid, const orc_keypoint *kf_kp, const uint8_t *kf_desc,
+                          const int32_t *f_node_ids, const int32_t *f_node_start, const int32_t *f_feat, int f_nnodes,
+                          const orc_keypoint *f_kp, const uint8_t *f_desc, int nF, int nleft,
+                          float nn_ratio, int check_orientation, int32_t *match_f)
+{
+    int nmatches = 0;
+    int *hist_n = (int *)calloc(HISTO_LENGTH, sizeof(int));
+    int *hist_items = (int *)malloc(sizeof(int) * (size_t)HISTO_LENGTH * (nF ? nF : 1));
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int j = 0; j < nF; j++) match_f[j] = -1;
+    int a = 0, b = 0;
+    while (a < kf_nnodes && b < f_nnodes) {
+        if (kf_node_ids[a] == f_node_ids[b]) {
+            for (int ik = kf_node_start[a]; ik < kf_node_start[a + 1]; ik++) {
+                const int realIdxKF = kf_feat[ik];
+                if (!kf_valid[realIdxKF]) continue;
+                int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256, bestDist1R = 256, bestIdxFR = -1, bestDist2R = 256;
+                for (int jf = f_node_start[b]; jf < f_node_start[b + 1]; jf++) {                               /* ORBm:338-359 */
+                    const int realIdxF = f_feat[jf];
+                    if (match_f[realIdxF] >= 0) continue;
+                    const int dist = orc_descriptor_distance(kf_desc + 32 * (size_t)realIdxKF, f_desc + 32 * (size_t)realIdxF);
+                    if (realIdxF < nleft && dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+                    else if (realIdxF < nleft && dist < bestDist2) bestDist2 = dist;
+                    if (realIdxF >= nleft && dist < bestDist1R) { bestDist2R = bestDist1R; bestDist1R = dist; bestIdxFR = realIdxF; }
+                    else if (realIdxF >= nleft && dist < bestDist2R) bestDist2R = dist;
+                }
+                if (bestDist1 <= TH_LOW) {                                                                     /* ORBm:362-426 */
+                    for (int side = 0; side < 2; side++) {
+                        int idx;
+                        if (side == 0) { if (!((float)bestDist1 < nn_ratio * (float)bestDist2)) continue; idx = bestIdxF; }
+                        else { if (bestDist1R > TH_LOW) continue; idx = bestIdxFR; }                           /* "|| true": no ratio test */
+                        match_f[idx] = realIdxKF;
+                        if (check_orientation) {
+                            float rot = kf_kp[realIdxKF].angle - f_kp[idx].angle;
+                            if (rot < 0.0) rot += 360.0f;
+                            int bin = (int)roundf(rot * factor);
+                            if (bin == HISTO_LENGTH) bin = 0;
+                            hist_items[(size_t)bin * nF + hist_n[bin]++] = idx;
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            a++; b++;
+        } else if (kf_node_ids[a] < f_node_ids[b]) { while (a < kf_nnodes && kf_node_ids[a] < f_node_ids[b]) a++; }
+        else { while (b < f_nnodes && f_node_ids[b] < kf_node_ids[a]) b++; }
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(hist_n, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int j = 0; j < hist_n[i]; j++) { match_f[hist_items[(size_t)i * nF + j]] = -1; nmatches--; }
+    }
+    free(hist_items); free(hist_n);
+    return nmatches;
+}

@@ -138,4 +138,14 @@ void orc_bow_transform(const uint8_t *feature32, const uint8_t *node_desc, const
 #ifdef __cplusplus
 }
 #endif
+/* two-camera rig frames (Nleft != -1): ORBm:113-122, 136-214, 338-359, 393-425, 2013-2016, 2089-2153; Frame.cc:395-405, 686 */
+int orc_search_by_projection_rig(int mode, const orc_proj_query *q, const uint8_t *desc_q, int nq,
+                                 const orc_keypoint *kp, const uint8_t *desc, int n, int nleft, const int32_t *mirror,
+                                 float min_x, float min_y, float max_x, float max_y,
+                                 int th_high, float nn_ratio, int check_orientation, int32_t *train_match);
+int orc_search_by_bow_rig(const int32_t *kf_node_ids, const int32_t *kf_node_start, const int32_t *kf_feat, int kf_nnodes,
+                          const uint8_t *kf_valid, const orc_keypoint *kf_kp, const uint8_t *kf_desc,
+                          const int32_t *f_node_ids, const int32_t *f_node_start, const int32_t *f_feat, int f_nnodes,
+                          const orc_keypoint *f_kp, const uint8_t *f_desc, int nF, int nleft,
+                          float nn_ratio, int check_orientation, int32_t *match_f);
 #endif

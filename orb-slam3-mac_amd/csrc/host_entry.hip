@@ -18,10 +18,34 @@ inline size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
 #define HTRY(e) do { if ((e) != hipSuccess) { orbhip_set_last_error_internal(#e); return ORBHIP_E_HIP; } } while (0)
 }  // namespace
 
+static int sbp_host(orbhip_ctx *ctx, int mode, const orbhip_proj_query *q, const uint8_t *desc_q, int nq,
+                    const orbhip_keypoint *kp, const uint8_t *desc, const float *u_right, int n, int nleft, const int32_t *mirror,
+                    float min_x, float min_y, float max_x, float max_y, int th_high, float nn_ratio,
+                    int check_orientation, int32_t *train_match_inout, int32_t *nmatches_out);
+
 extern "C" int orbhip_search_by_projection_host(orbhip_ctx *ctx, int mode, const orbhip_proj_query *q, const uint8_t *desc_q, int nq,
                                                 const orbhip_keypoint *kp, const uint8_t *desc, const float *u_right, int n,
                                                 float min_x, float min_y, float max_x, float max_y, int th_high, float nn_ratio,
                                                 int check_orientation, int32_t *train_match_inout, int32_t *nmatches_out)
+{
+    return sbp_host(ctx, mode, q, desc_q, nq, kp, desc, u_right, n, -1, nullptr, min_x, min_y, max_x, max_y, th_high, nn_ratio, check_orientation,
+                    train_match_inout, nmatches_out);
+}
+
+extern "C" int orbhip_search_by_projection_rig_host(orbhip_ctx *ctx, int mode, const orbhip_proj_query *q, const uint8_t *desc_q, int nq,
+                                                    const orbhip_keypoint *kp, const uint8_t *desc, int n, int nleft, const int32_t *mirror,
+                                                    float min_x, float min_y, float max_x, float max_y, int th_high, float nn_ratio,
+                                                    int check_orientation, int32_t *train_match_inout, int32_t *nmatches_out)
+{
+    if (nleft < 0 || nleft > n) return ORBHIP_E_BADARG;
+    return sbp_host(ctx, mode, q, desc_q, nq, kp, desc, nullptr, n, nleft, mirror, min_x, min_y, max_x, max_y, th_high, nn_ratio, check_orientation,
+                    train_match_inout, nmatches_out);
+}
+
+static int sbp_host(orbhip_ctx *ctx, int mode, const orbhip_proj_query *q, const uint8_t *desc_q, int nq,
+                    const orbhip_keypoint *kp, const uint8_t *desc, const float *u_right, int n, int nleft, const int32_t *mirror,
+                    float min_x, float min_y, float max_x, float max_y, int th_high, float nn_ratio,
+                    int check_orientation, int32_t *train_match_inout, int32_t *nmatches_out)
 {
     if (!ctx || nq < 0 || n < 0 || (nq && (!q || !desc_q)) || (n && (!kp || !desc || !train_match_inout)) || !nmatches_out || (mode != 0 && mode != 1))
         return ORBHIP_E_BADARG;
@@ -30,13 +54,13 @@ extern "C" int orbhip_search_by_projection_host(orbhip_ctx *ctx, int mode, const
     HTRY(hipSetDevice(orbhip_ctx_device_internal(ctx)));
     hipStream_t s = orbhip_ctx_stream_internal(ctx);
     const size_t need = al(sizeof(orbhip_proj_query) * nq) + al(32 * (size_t)nq) + al(sizeof(orbhip_keypoint) * n) + al(32 * (size_t)n) +
-                        al(4 * (size_t)n) * 2 + 4 * 256;
+                        al(4 * (size_t)n) * 3 + 5 * 256;
     Arena A = {(uint8_t *)orbhip_ctx_scratch_internal(ctx, need), 0, need};
     if (!A.base) return ORBHIP_E_HIP;
     orbhip_proj_query *dq = A.take<orbhip_proj_query>(nq); uint8_t *ddq = A.take<uint8_t>(32 * (size_t)nq);
     orbhip_keypoint *dkp = A.take<orbhip_keypoint>(n); uint8_t *dd = A.take<uint8_t>(32 * (size_t)n);
-    float *dur = A.take<float>(n); int32_t *dtm = A.take<int32_t>(n);
-    int32_t *dnq = A.take<int32_t>(1), *dn = A.take<int32_t>(1), *dnm = A.take<int32_t>(1);
+    float *dur = A.take<float>(n); int32_t *dtm = A.take<int32_t>(n), *dmi = A.take<int32_t>(n);
+    int32_t *dnq = A.take<int32_t>(1), *dn = A.take<int32_t>(1), *dnm = A.take<int32_t>(1), *dnl = A.take<int32_t>(1);
     HTRY(hipMemcpyAsync(dq, q, sizeof(orbhip_proj_query) * nq, hipMemcpyHostToDevice, s));
     HTRY(hipMemcpyAsync(ddq, desc_q, 32 * (size_t)nq, hipMemcpyHostToDevice, s));
     HTRY(hipMemcpyAsync(dkp, kp, sizeof(orbhip_keypoint) * n, hipMemcpyHostToDevice, s));
@@ -46,7 +70,12 @@ extern "C" int orbhip_search_by_projection_host(orbhip_ctx *ctx, int mode, const
     HTRY(hipMemcpyAsync(dnq, &nq, 4, hipMemcpyHostToDevice, s));
     HTRY(hipMemcpyAsync(dn, &n, 4, hipMemcpyHostToDevice, s));
     int rc;
-    if (mode == 0)
+    if (nleft >= 0) {
+        HTRY(hipMemcpyAsync(dnl, &nleft, 4, hipMemcpyHostToDevice, s));
+        if (mirror) HTRY(hipMemcpyAsync(dmi, mirror, 4 * (size_t)n, hipMemcpyHostToDevice, s));
+        rc = orbhip_search_by_projection_rig_device(ctx, mode, dq, ddq, dnq, nq, dkp, dd, dn, dnl, mirror ? dmi : nullptr, n, (size_t)n, 1, min_x, min_y,
+                                                    max_x, max_y, th_high, nn_ratio, check_orientation, dtm, dnm);
+    } else if (mode == 0)
         rc = orbhip_search_by_projection_device(ctx, dq, ddq, dnq, nq, dkp, dd, u_right ? dur : nullptr, dn, n, (size_t)n, 1, min_x, min_y, max_x,
                                                 max_y, th_high, check_orientation, dtm, dnm);
     else

@@ -366,8 +366,11 @@ struct OrbLevelSigma { float inv_sigma2[16]; };       // mvInvLevelSigma2, passe
 // insertion order = index order.  rank = number of earlier keypoints in the same cell = the cell's counter before this trip +
 // the earlier lanes of the trip with the same cell.  cell_start must be zeroed by the caller; on return cell_start[c] is the
 // first slot of cell c = ix*48+iy in items[], and kx / ky / oct hold the keypoints' coordinates and octaves.
+// Rig frames (Nleft != -1, Frame.cc:395-405): keypoints nleft .. n-1 are the right camera's and fill mGridRight, here the cells
+// SBP_CELLS .. 2*SBP_CELLS-1 of the same CSR (ncells = 2*SBP_CELLS); items hold frame-wide indices (i = right index + Nleft).
 __device__ void sbp_build_grid(uint32_t *cell_start, float *kx, float *ky, uint8_t *oct, uint16_t *items, uint16_t *cell_of,
-                               uint16_t *rank_of, const orbhip_keypoint *kp, int n, float min_x, float min_y, float inv_w, float inv_h, int lane)
+                               uint16_t *rank_of, const orbhip_keypoint *kp, int n, float min_x, float min_y, float inv_w, float inv_h, int lane,
+                               int ncells = SI_COLS * SI_ROWS, int nleft = -1)
 {
     for (int i0 = 0; i0 < n; i0 += 64) {
         const int i = i0 + lane;
@@ -377,7 +380,7 @@ __device__ void sbp_build_grid(uint32_t *cell_start, float *kx, float *ky, uint8
             kx[i] = k.x; ky[i] = k.y; oct[i] = (uint8_t)k.octave;
             const int px = (int)roundf(__fmul_rn(__fsub_rn(k.x, min_x), inv_w));
             const int py = (int)roundf(__fmul_rn(__fsub_rn(k.y, min_y), inv_h));
-            if (px >= 0 && px < SI_COLS && py >= 0 && py < SI_ROWS) c = px * SI_ROWS + py;
+            if (px >= 0 && px < SI_COLS && py >= 0 && py < SI_ROWS) c = px * SI_ROWS + py + ((nleft >= 0 && i >= nleft) ? SI_COLS * SI_ROWS : 0);
         }
         int intra = 0;
         for (int l = 0; l < 64; l++) {
@@ -394,11 +397,11 @@ __device__ void sbp_build_grid(uint32_t *cell_start, float *kx, float *ky, uint8
     }
     {   // exclusive prefix over the cell counts (cell_start[c+1] holds count(c))
         uint32_t carry = 0;
-        for (int c0 = 1; c0 <= SBP_CELLS; c0 += 64) {
+        for (int c0 = 1; c0 <= ncells; c0 += 64) {
             const int c = c0 + lane;
-            const int v = c <= SBP_CELLS ? (int)cell_start[c] : 0;
+            const int v = c <= ncells ? (int)cell_start[c] : 0;
             const int inc = wave_incl_scan_i(v);
-            if (c <= SBP_CELLS) cell_start[c] = carry + (uint32_t)inc;
+            if (c <= ncells) cell_start[c] = carry + (uint32_t)inc;
             carry += (uint32_t)__builtin_amdgcn_readlane(inc, 63);
         }
     }
@@ -413,13 +416,14 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
                                                              const int32_t *n_, int max_n, size_t kp_stride,
                                                              float min_x, float min_y, float max_x, float max_y,
                                                              int th_high, int check_ori, int mode, float nn_ratio, int cap_n, int cap_q,
-                                                             int32_t *tm_, int32_t *nmatches_, int32_t *status)
+                                                             int32_t *tm_, int32_t *nmatches_, int32_t *status,
+                                                             const int32_t *nleft_, const int32_t *mirror_, int ncells)
 {
     // dynamic LDS carved by the launcher's capacities (cap_n keypoints, cap_q queries per pair): small frames keep
     // four pairs per CU resident
     extern __shared__ __attribute__((aligned(16))) uint8_t sbp_lds[];
-    uint32_t *cell_start = reinterpret_cast<uint32_t *>(sbp_lds);                   // [SBP_CELLS + 1]
-    float *kx = reinterpret_cast<float *>(cell_start + SBP_CELLS + 1), *ky = kx + cap_n;
+    uint32_t *cell_start = reinterpret_cast<uint32_t *>(sbp_lds);                   // [ncells + 1]: SBP_CELLS, twice that for rig frames
+    float *kx = reinterpret_cast<float *>(cell_start + ncells + 1), *ky = kx + cap_n;
     int16_t *holder = reinterpret_cast<int16_t *>(ky + cap_n);                       // -1 free, -2 pre-held, else (query << 1 | has_obs)
     uint16_t *items = reinterpret_cast<uint16_t *>(holder + cap_n), *cand = items + cap_n, *cell_of = cand + cap_n, *rank_of = cell_of + cap_n;
     int16_t *qm = reinterpret_cast<int16_t *>(rank_of + cap_n);                      // query -> claimed keypoint
@@ -427,12 +431,17 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
     uint8_t *oct = reinterpret_cast<uint8_t *>(qbin + cap_q);
     // optional: the train descriptors too (32 B each) -- removes the one global round trip left in every query; used when
     // the launch is small enough that fewer resident pairs per CU do not matter
-    uint4 *dlds = reinterpret_cast<uint4 *>(sbp_lds + ((sizeof(uint32_t) * (SBP_CELLS + 1) + (size_t)cap_n * 19 + (size_t)cap_q * 3 + 15) & ~(size_t)15));
+    uint4 *dlds = reinterpret_cast<uint4 *>(sbp_lds + ((sizeof(uint32_t) * ((size_t)ncells + 1) + (size_t)cap_n * 19 + (size_t)cap_q * 3 + 15) & ~(size_t)15));
     __shared__ int hist[SI_HISTO];
     __shared__ int s_keep[3];
     const int pair = blockIdx.x, lane = threadIdx.x;
     const unsigned long long lt_mask = (1ull << lane) - 1;
     const int n = n_[pair], nq = nq_[pair];
+    // rig frames (Nleft != -1): keypoints [0, nleft) are the left camera's, [nleft, n) the right camera's; a query carries the camera
+    // it searches in bit 1 of has_obs; mirror[i] = the same point's keypoint in the other camera (mvLeftToRightMatch / mvRightToLeftMatch
+    // as frame-wide indices) or -1
+    const int nleft = nleft_ ? nleft_[pair] : -1;
+    const int32_t *mirror = mirror_ ? mirror_ + (size_t)pair * max_n : nullptr;
     const orbhip_proj_query *Q = q_ + (size_t)pair * max_q;
     const uint4 *dQ = reinterpret_cast<const uint4 *>(descq_ + (size_t)pair * max_q * 32);
     const orbhip_keypoint *kp = kp_ + (size_t)pair * kp_stride;
@@ -446,14 +455,14 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
     const float inv_w = __fdiv_rn((float)SI_COLS, __fsub_rn(max_x, min_x));       // Frame.cc:334-335
     const float inv_h = __fdiv_rn((float)SI_ROWS, __fsub_rn(max_y, min_y));
     for (int i = lane; i < SI_HISTO; i += 64) hist[i] = 0;
-    for (int c = lane; c <= SBP_CELLS; c += 64) cell_start[c] = 0;
+    for (int c = lane; c <= ncells; c += 64) cell_start[c] = 0;
     for (int t = lane; t < nq; t += 64) { qm[t] = -1; qbin[t] = -1; }
     __syncthreads();
     for (int i = lane; i < n; i += 64) {
         holder[i] = tm[i] == -1 ? (int16_t)-1 : (int16_t)-2;
         if (DESC_LDS) { dlds[2 * i] = dT[2 * i]; dlds[2 * i + 1] = dT[2 * i + 1]; }
     }
-    sbp_build_grid(cell_start, kx, ky, oct, items, cell_of, rank_of, kp, n, min_x, min_y, inv_w, inv_h, lane);
+    sbp_build_grid(cell_start, kx, ky, oct, items, cell_of, rank_of, kp, n, min_x, min_y, inv_w, inv_h, lane, ncells, nleft);
     // ---- sequential query loop (ORBmatcher.cc:1987-2088)
     int nmatches = 0;
     const float factor = 1.0f / SI_HISTO;
@@ -473,11 +482,12 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
         if (r0 >= SI_ROWS) continue;
         int r1 = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, min_y), r), inv_h)); if (r1 > SI_ROWS - 1) r1 = SI_ROWS - 1;
         if (r1 < 0) continue;
-        // lane = grid column c0+lane: its cells r0..r1 are one run of `items`
+        // lane = grid column c0+lane: its cells r0..r1 are one run of `items` (rig: the queried camera's half of the cells)
+        const int cbase = (nleft >= 0 && (qq.has_obs & 2)) ? SBP_CELLS : 0;
         int start = 0, len = 0;
         if (c0 + lane <= c1) {
-            start = (int)cell_start[(c0 + lane) * SI_ROWS + r0];
-            len = (int)cell_start[(c0 + lane) * SI_ROWS + r1 + 1] - start;
+            start = (int)cell_start[cbase + (c0 + lane) * SI_ROWS + r0];
+            len = (int)cell_start[cbase + (c0 + lane) * SI_ROWS + r1 + 1] - start;
         }
         const int inc = wave_scan_add_dpp(len);                      // DPP scans / reductions: no LDS round trips in the per-query chain
         const int off = inc - len, total = __builtin_amdgcn_readlane(inc, 63);
@@ -522,10 +532,14 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
         if (accept) {
             if (lane == 0) {
                 const int best = cand[key & 0xFFFu];
-                holder[best] = (int16_t)((t << 1) | (qq.has_obs ? 1 : 0));
+                holder[best] = (int16_t)((t << 1) | (qq.has_obs & 1));
                 qm[t] = (int16_t)best;
             }
             nmatches++;
+            if (mirror) {                                                       // also the stereo observation in the other camera (:142-146, :203-207)
+                const int m = mirror[cand[key & 0xFFFu]];
+                if (m >= 0) { if (lane == 0) holder[m] = (int16_t)((t << 1) | (qq.has_obs & 1)); nmatches++; }
+            }
         }
         __syncthreads();                                                        // cand / holder reused by the next query
     }
@@ -572,17 +586,19 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
 }
 
 // LDS of k_search_by_projection for the given row capacities (keypoints / queries per pair)
-static size_t sbp_lds_bytes(int cap_n, int cap_q)
+static size_t sbp_lds_bytes(int cap_n, int cap_q, int ncells)
 {
-    return sizeof(uint32_t) * (SBP_CELLS + 1) + (size_t)cap_n * (4 + 4 + 2 + 2 + 2 + 2 + 2 + 1) + (size_t)cap_q * (2 + 1) + 16;
+    return sizeof(uint32_t) * ((size_t)ncells + 1) + (size_t)cap_n * (4 + 4 + 2 + 2 + 2 + 2 + 2 + 1) + (size_t)cap_q * (2 + 1) + 16;
 }
 static int sbp_launch(orbhip_ctx *ctx, const orbhip_proj_query *d_q, const uint8_t *d_desc_q, const int32_t *d_nq, int max_q,
                       const orbhip_keypoint *d_kp, const uint8_t *d_desc, const float *d_u_right, const int32_t *d_n, int max_n,
                       size_t frame_stride_kp, int pairs, float min_x, float min_y, float max_x, float max_y, int th_high,
-                      int check_orientation, int mode, float nn_ratio, int32_t *d_train_match, int32_t *d_nmatches)
+                      int check_orientation, int mode, float nn_ratio, int32_t *d_train_match, int32_t *d_nmatches,
+                      const int32_t *d_nleft = nullptr, const int32_t *d_mirror = nullptr)
 {
     const int cap_n = ((max_n < SBP_CAP ? max_n : SBP_CAP) + 7) & ~7, cap_q = ((max_q < SBP_CAP ? max_q : SBP_CAP) + 7) & ~7;
-    const size_t base = sbp_lds_bytes(cap_n, cap_q), with_desc = base + (size_t)cap_n * 32;
+    const int ncells = d_nleft ? 2 * SBP_CELLS : SBP_CELLS;
+    const size_t base = sbp_lds_bytes(cap_n, cap_q, ncells), with_desc = base + (size_t)cap_n * 32;
     // descriptors in LDS when at most two rounds of workgroups are needed anyway (<= 2 pairs per CU resident is enough)
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
@@ -593,8 +609,23 @@ static int sbp_launch(orbhip_ctx *ctx, const orbhip_proj_query *d_q, const uint8
     if (orb_lds_optin(reinterpret_cast<const void *>(kern), orbhip_ctx_device_internal(ctx), lds)) return ORBHIP_E_HIP;
     hipLaunchKernelGGL(kern, dim3(pairs), dim3(64), lds, orbhip_ctx_stream_internal(ctx), d_q, d_desc_q, d_nq,
                        max_q, d_kp, d_desc, d_u_right, d_n, max_n, frame_stride_kp, min_x, min_y, max_x, max_y, th_high,
-                       check_orientation, mode, nn_ratio, cap_n, cap_q, d_train_match, d_nmatches, orbhip_ctx_status_internal(ctx));
+                       check_orientation, mode, nn_ratio, cap_n, cap_q, d_train_match, d_nmatches, orbhip_ctx_status_internal(ctx), d_nleft, d_mirror, ncells);
     return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
+}
+
+extern "C" int orbhip_search_by_projection_rig_device(orbhip_ctx *ctx, int mode, const orbhip_proj_query *d_q, const uint8_t *d_desc_q,
+                                                      const int32_t *d_nq, int max_q, const orbhip_keypoint *d_kp, const uint8_t *d_desc,
+                                                      const int32_t *d_n, const int32_t *d_nleft, const int32_t *d_mirror, int max_n,
+                                                      size_t frame_stride_kp, int pairs, float min_x, float min_y, float max_x, float max_y,
+                                                      int th_high, float nn_ratio, int check_orientation, int32_t *d_train_match,
+                                                      int32_t *d_nmatches)
+{
+    if (!ctx || (mode != 0 && mode != 1) || !d_q || !d_desc_q || !d_nq || !d_kp || !d_desc || !d_n || !d_nleft || pairs <= 0 || max_n <= 0 ||
+        max_q <= 0 || !d_train_match || !d_nmatches || !(max_x > min_x) || !(max_y > min_y))
+        return ORBHIP_E_BADARG;
+    if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
+    return sbp_launch(ctx, d_q, d_desc_q, d_nq, max_q, d_kp, d_desc, nullptr, d_n, max_n, frame_stride_kp, pairs, min_x, min_y, max_x, max_y,
+                      th_high, mode == 0 ? check_orientation : 0, mode, nn_ratio, d_train_match, d_nmatches, d_nleft, mode == 1 ? d_mirror : nullptr);
 }
 
 extern "C" int orbhip_search_by_projection_device(orbhip_ctx *ctx, const orbhip_proj_query *d_q, const uint8_t *d_desc_q,
@@ -832,7 +863,7 @@ template <bool KF_MODE>
 __global__ __launch_bounds__(64) void k_search_by_bow(BowSide K, const uint8_t *kf_valid_, const int32_t *nK_, BowSide F, const uint8_t *f_valid_,
                                                       const int32_t *nF_, int max_nodes, int max_n,
                                                       size_t kp_stride, float nn_ratio, int check_ori, int cap_n,
-                                                      int32_t *match_f_, int32_t *nmatches_, int32_t *status)
+                                                      int32_t *match_f_, int32_t *nmatches_, int32_t *status, const int32_t *nleft_)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t bow_lds[];
     uint4 *dlds = reinterpret_cast<uint4 *>(bow_lds);                       // [cap_n][2] frame descriptors
@@ -845,6 +876,9 @@ __global__ __launch_bounds__(64) void k_search_by_bow(BowSide K, const uint8_t *
     const int nF = nF_[pair], nk = K.nnodes[pair], nf = F.nnodes[pair];
     int32_t *match_f = match_f_ + (size_t)pair * max_n;
     const int nK = KF_MODE ? nK_[pair] : 0;
+    // rig frames (F.Nleft != -1, ORBmatcher.cc:338-359): frame features [0, nleft) are the left camera's, the rest the right camera's;
+    // each keyframe feature keeps a best / second best per camera
+    const int nleft = (!KF_MODE && nleft_) ? nleft_[pair] : -1;
     if (nF > cap_n || nF > max_n || nK > cap_n || nK > max_n || nk > max_nodes || nf > max_nodes) {
         if (lane == 0) { atomicExch(status, ORBHIP_E_CAPACITY); nmatches_[pair] = 0; }
         return;
@@ -877,24 +911,34 @@ __global__ __launch_bounds__(64) void k_search_by_bow(BowSide K, const uint8_t *
             const int ri = kfe[ik];
             if (!kvalid[ri]) continue;                                       // :297-302
             const uint4 a0v = dK[2 * ri], a1v = dK[2 * ri + 1];
-            int b1 = 256, b2 = 256, bi = -1;
-            for (int jf = f0; jf < f1; jf++) {                               // :317-336
+            int b1 = 256, b2 = 256, bi = -1, b1r = 256, b2r = 256, bir = -1;
+            for (int jf = f0; jf < f1; jf++) {                               // :317-360
                 const int rj = ffe[jf];
                 if (mf[rj] != -1) continue;
                 const int dist = hamming256(a0v, a1v, dlds[2 * rj], dlds[2 * rj + 1]);
-                if (dist < b1) { b2 = b1; b1 = dist; bi = rj; }
-                else if (dist < b2) b2 = dist;
+                if (nleft < 0 || rj < nleft) {
+                    if (dist < b1) { b2 = b1; b1 = dist; bi = rj; }
+                    else if (dist < b2) b2 = dist;
+                } else {
+                    if (dist < b1r) { b2r = b1r; b1r = dist; bir = rj; }
+                    else if (dist < b2r) b2r = dist;
+                }
             }
-            if ((KF_MODE ? b1 < SI_TH_LOW : b1 <= SI_TH_LOW) && (float)b1 < __fmul_rn(nn_ratio, (float)b2)) {   // :362-366 / :909-911
-                mf[bi] = (int16_t)ri;
+            auto take = [&](int j) {
+                mf[j] = (int16_t)ri;
                 mine++;
-                if (check_ori) {                                             // :376-388
-                    float rot = __fsub_rn(kkp[ri].angle, fkp[bi].angle);
+                if (check_ori) {                                             // :376-388, :406-421
+                    float rot = __fsub_rn(kkp[ri].angle, fkp[j].angle);
                     if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
                     int bin = (int)roundf(__fmul_rn(rot, factor));
                     if (bin == SI_HISTO) bin = 0;
-                    atomicAdd(&hist[bin], 1); fbin[bi] = (int8_t)bin;
+                    atomicAdd(&hist[bin], 1); fbin[j] = (int8_t)bin;
                 }
+            };
+            if (KF_MODE ? b1 < SI_TH_LOW : b1 <= SI_TH_LOW) {                // :362 / :909
+                if ((float)b1 < __fmul_rn(nn_ratio, (float)b2)) take(bi);     // :364-391 / :911
+                // the right camera's best: inside the left test's TH_LOW branch, no ratio test ("|| true", :393-396)
+                if (nleft >= 0 && b1r <= SI_TH_LOW) take(bir);
             }
         }
     }
@@ -935,7 +979,7 @@ __global__ __launch_bounds__(64) void k_search_by_bow(BowSide K, const uint8_t *
 
 static int bow_launch(orbhip_ctx *ctx, bool kf_mode, const BowSide &K, const uint8_t *d_kf_valid, const int32_t *d_nK, const BowSide &F,
                       const uint8_t *d_f_valid, const int32_t *d_nF, int pairs, int max_nodes, int max_n, size_t frame_stride_kp, float nn_ratio,
-                      int check_orientation, int32_t *d_match, int32_t *d_nmatches)
+                      int check_orientation, int32_t *d_match, int32_t *d_nmatches, const int32_t *d_nleft = nullptr)
 {
     if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
     const int cap_n = ((max_n < 4096 ? max_n : 4096) + 7) & ~7;
@@ -946,10 +990,10 @@ static int bow_launch(orbhip_ctx *ctx, bool kf_mode, const BowSide &K, const uin
     }
     if (kf_mode)
         hipLaunchKernelGGL(k_search_by_bow<true>, dim3(pairs), dim3(64), lds, orbhip_ctx_stream_internal(ctx), K, d_kf_valid, d_nK, F, d_f_valid, d_nF,
-                           max_nodes, max_n, frame_stride_kp, nn_ratio, check_orientation, cap_n, d_match, d_nmatches, orbhip_ctx_status_internal(ctx));
+                           max_nodes, max_n, frame_stride_kp, nn_ratio, check_orientation, cap_n, d_match, d_nmatches, orbhip_ctx_status_internal(ctx), nullptr);
     else
         hipLaunchKernelGGL(k_search_by_bow<false>, dim3(pairs), dim3(64), lds, orbhip_ctx_stream_internal(ctx), K, d_kf_valid, d_nK, F, d_f_valid, d_nF,
-                           max_nodes, max_n, frame_stride_kp, nn_ratio, check_orientation, cap_n, d_match, d_nmatches, orbhip_ctx_status_internal(ctx));
+                           max_nodes, max_n, frame_stride_kp, nn_ratio, check_orientation, cap_n, d_match, d_nmatches, orbhip_ctx_status_internal(ctx), d_nleft);
     return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
 }
 
@@ -968,6 +1012,23 @@ extern "C" int orbhip_search_by_bow_device(orbhip_ctx *ctx,
     BowSide F = {d_f_node_ids, d_f_node_start, d_f_feat, d_f_nnodes, d_f_kp, d_f_desc};
     return bow_launch(ctx, false, K, d_kf_valid, nullptr, F, nullptr, d_nF, pairs, max_nodes, max_n, frame_stride_kp, nn_ratio, check_orientation,
                       d_match_f, d_nmatches);
+}
+
+extern "C" int orbhip_search_by_bow_rig_device(orbhip_ctx *ctx,
+        const int32_t *d_kf_node_ids, const int32_t *d_kf_node_start, const int32_t *d_kf_feat, const int32_t *d_kf_nnodes,
+        const uint8_t *d_kf_valid, const orbhip_keypoint *d_kf_kp, const uint8_t *d_kf_desc,
+        const int32_t *d_f_node_ids, const int32_t *d_f_node_start, const int32_t *d_f_feat, const int32_t *d_f_nnodes,
+        const orbhip_keypoint *d_f_kp, const uint8_t *d_f_desc, const int32_t *d_nF, const int32_t *d_nleft,
+        int pairs, int max_nodes, int max_n, size_t frame_stride_kp, float nn_ratio, int check_orientation,
+        int32_t *d_match_f, int32_t *d_nmatches)
+{
+    if (!ctx || !d_kf_node_ids || !d_kf_node_start || !d_kf_feat || !d_kf_nnodes || !d_kf_valid || !d_kf_kp || !d_kf_desc || !d_f_node_ids ||
+        !d_f_node_start || !d_f_feat || !d_f_nnodes || !d_f_kp || !d_f_desc || !d_nF || !d_nleft || pairs <= 0 || max_nodes <= 0 || max_n <= 0 ||
+        !d_match_f || !d_nmatches) return ORBHIP_E_BADARG;
+    BowSide K = {d_kf_node_ids, d_kf_node_start, d_kf_feat, d_kf_nnodes, d_kf_kp, d_kf_desc};
+    BowSide F = {d_f_node_ids, d_f_node_start, d_f_feat, d_f_nnodes, d_f_kp, d_f_desc};
+    return bow_launch(ctx, false, K, d_kf_valid, nullptr, F, nullptr, d_nF, pairs, max_nodes, max_n, frame_stride_kp, nn_ratio, check_orientation,
+                      d_match_f, d_nmatches, d_nleft);
 }
 
 extern "C" int orbhip_search_by_bow_kf_device(orbhip_ctx *ctx,
@@ -1178,25 +1239,40 @@ extern "C" int orbhip_undistort_keypoints_device(orbhip_ctx *ctx, const orbhip_k
 // in LDS, exported for host-side GetFeaturesInArea callers): one wave per frame.
 __global__ __launch_bounds__(64) void k_assign_grid(const orbhip_keypoint *kp_, const int32_t *n_, int max_n, size_t kp_stride, float min_x,
                                                     float min_y, float inv_w, float inv_h, int cap_n, int32_t *cell_start_, int32_t *items_,
-                                                    int32_t *status)
+                                                    int32_t *status, const int32_t *nleft_, int ncells)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t ag_lds[];
-    uint32_t *cell_start = reinterpret_cast<uint32_t *>(ag_lds);             // [SBP_CELLS + 1]
-    float *kx = reinterpret_cast<float *>(cell_start + SBP_CELLS + 1);
+    uint32_t *cell_start = reinterpret_cast<uint32_t *>(ag_lds);             // [ncells + 1]
+    float *kx = reinterpret_cast<float *>(cell_start + ncells + 1);
     float *ky = kx + cap_n;
     uint16_t *items = reinterpret_cast<uint16_t *>(ky + cap_n);
     uint16_t *cell_of = items + cap_n, *rank_of = cell_of + cap_n;
     uint8_t *oct = reinterpret_cast<uint8_t *>(rank_of + cap_n);
     const int f = blockIdx.x, lane = threadIdx.x;
     const int n = n_[f];
-    int32_t *cs = cell_start_ + (size_t)f * (SBP_CELLS + 1), *it = items_ + (size_t)f * max_n;
-    if (n > cap_n || n > max_n) { if (lane == 0) atomicExch(status, ORBHIP_E_CAPACITY); for (int c = lane; c <= SBP_CELLS; c += 64) cs[c] = 0; return; }
-    for (int c = lane; c <= SBP_CELLS; c += 64) cell_start[c] = 0;
+    const int nleft = nleft_ ? nleft_[f] : -1;
+    int32_t *cs = cell_start_ + (size_t)f * (ncells + 1), *it = items_ + (size_t)f * max_n;
+    if (n > cap_n || n > max_n) { if (lane == 0) atomicExch(status, ORBHIP_E_CAPACITY); for (int c = lane; c <= ncells; c += 64) cs[c] = 0; return; }
+    for (int c = lane; c <= ncells; c += 64) cell_start[c] = 0;
     __syncthreads();
-    sbp_build_grid(cell_start, kx, ky, oct, items, cell_of, rank_of, kp_ + (size_t)f * kp_stride, n, min_x, min_y, inv_w, inv_h, lane);
-    for (int c = lane; c <= SBP_CELLS; c += 64) cs[c] = (int32_t)cell_start[c];
-    const int tot = (int)cell_start[SBP_CELLS];
-    for (int i = lane; i < tot; i += 64) it[i] = items[i];
+    sbp_build_grid(cell_start, kx, ky, oct, items, cell_of, rank_of, kp_ + (size_t)f * kp_stride, n, min_x, min_y, inv_w, inv_h, lane, ncells, nleft);
+    for (int c = lane; c <= ncells; c += 64) cs[c] = (int32_t)cell_start[c];
+    const int tot = (int)cell_start[ncells];
+    const int first_right = nleft >= 0 ? (int)cell_start[SBP_CELLS] : tot;       // mGridRight holds i - Nleft (Frame.cc:403)
+    for (int i = lane; i < tot; i += 64) it[i] = i < first_right ? items[i] : (int)items[i] - nleft;
+}
+
+static int assign_grid_launch(orbhip_ctx *ctx, const orbhip_keypoint *d_kp, const int32_t *d_n, const int32_t *d_nleft, int frames, int max_n,
+                              size_t frame_stride_kp, float min_x, float min_y, float max_x, float max_y, int32_t *d_cell_start, int32_t *d_items)
+{
+    const int cap_n = ((max_n < 8192 ? max_n : 8192) + 7) & ~7;
+    const int ncells = d_nleft ? 2 * SBP_CELLS : SBP_CELLS;
+    const size_t lds = sizeof(uint32_t) * ((size_t)ncells + 1) + (size_t)cap_n * (4 + 4 + 2 + 2 + 2 + 1) + 16;
+    if (orb_lds_optin(reinterpret_cast<const void *>(k_assign_grid), orbhip_ctx_device_internal(ctx), lds)) return ORBHIP_E_HIP;
+    const float inv_w = (float)SI_COLS / (max_x - min_x), inv_h = (float)SI_ROWS / (max_y - min_y);      // Frame.cc:334-335
+    hipLaunchKernelGGL(k_assign_grid, dim3(frames), dim3(64), lds, orbhip_ctx_stream_internal(ctx), d_kp, d_n, max_n, frame_stride_kp, min_x,
+                       min_y, inv_w, inv_h, cap_n, d_cell_start, d_items, orbhip_ctx_status_internal(ctx), d_nleft, ncells);
+    return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
 }
 
 extern "C" int orbhip_assign_features_to_grid_device(orbhip_ctx *ctx, const orbhip_keypoint *d_kp, const int32_t *d_n, int frames, int max_n,
@@ -1205,13 +1281,16 @@ extern "C" int orbhip_assign_features_to_grid_device(orbhip_ctx *ctx, const orbh
 {
     if (!ctx || !d_kp || !d_n || frames <= 0 || max_n <= 0 || !(max_x > min_x) || !(max_y > min_y) || !d_cell_start || !d_items) return ORBHIP_E_BADARG;
     if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
-    const int cap_n = ((max_n < 8192 ? max_n : 8192) + 7) & ~7;
-    const size_t lds = sizeof(uint32_t) * (SBP_CELLS + 1) + (size_t)cap_n * (4 + 4 + 2 + 2 + 2 + 1) + 16;
-    if (orb_lds_optin(reinterpret_cast<const void *>(k_assign_grid), orbhip_ctx_device_internal(ctx), lds)) return ORBHIP_E_HIP;
-    const float inv_w = (float)SI_COLS / (max_x - min_x), inv_h = (float)SI_ROWS / (max_y - min_y);      // Frame.cc:334-335
-    hipLaunchKernelGGL(k_assign_grid, dim3(frames), dim3(64), lds, orbhip_ctx_stream_internal(ctx), d_kp, d_n, max_n, frame_stride_kp, min_x,
-                       min_y, inv_w, inv_h, cap_n, d_cell_start, d_items, orbhip_ctx_status_internal(ctx));
-    return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
+    return assign_grid_launch(ctx, d_kp, d_n, nullptr, frames, max_n, frame_stride_kp, min_x, min_y, max_x, max_y, d_cell_start, d_items);
+}
+
+extern "C" int orbhip_assign_features_to_grid_rig_device(orbhip_ctx *ctx, const orbhip_keypoint *d_kp, const int32_t *d_n, const int32_t *d_nleft,
+                                                         int frames, int max_n, size_t frame_stride_kp, float min_x, float min_y, float max_x,
+                                                         float max_y, int32_t *d_cell_start, int32_t *d_items)
+{
+    if (!ctx || !d_kp || !d_n || !d_nleft || frames <= 0 || max_n <= 0 || !(max_x > min_x) || !(max_y > min_y) || !d_cell_start || !d_items) return ORBHIP_E_BADARG;
+    if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
+    return assign_grid_launch(ctx, d_kp, d_n, d_nleft, frames, max_n, frame_stride_kp, min_x, min_y, max_x, max_y, d_cell_start, d_items);
 }
 
 // ---------------------------------------------------------------------------- BowVector / FeatureVector assembly

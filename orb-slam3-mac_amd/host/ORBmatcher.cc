@@ -2,7 +2,7 @@
 // host loop up to the point where it would call Frame::GetFeaturesInArea, turns every surviving point into one
 // orbhip_proj_query, and hands the whole frame to the device: grid, window query, descriptor distances, claim rule
 // (ORBmatcher.cc:110-112, 2037-2039), thresholds / ratio tests and the rotation histogram run in k_search_by_projection /
-// k_search_init.  Frames of a fisheye rig (Nleft != -1) are handled by the rig entry points (see SearchByProjection below).
+// k_search_init.  Frames of a two-camera rig (Nleft != -1) add the right camera's query per point and go through the rig entry point.
 #include "ORBmatcher.h"
 #include <cstdio>
 #include <cstdlib>
@@ -59,19 +59,31 @@ float ORBmatcher::RadiusByViewingCos(const float &viewCos)
     else return 4.0;
 }
 
+// the keypoints / cross-camera links of a rig frame as the rig entry points take them: mvKeys | mvKeysRight, and for every keypoint the
+// frame-wide index of the same point's keypoint in the other camera (mvLeftToRightMatch / mvRightToLeftMatch) or -1
+static void rig_arrays(const Frame &F, std::vector<cv::KeyPoint> &kp, std::vector<int32_t> &mirror)
+{
+    kp.assign(F.mvKeys.begin(), F.mvKeys.begin() + F.Nleft);
+    kp.insert(kp.end(), F.mvKeysRight.begin(), F.mvKeysRight.end());
+    mirror.assign(kp.size(), -1);
+    for (size_t i = 0; i < F.mvLeftToRightMatch.size() && (int)i < F.Nleft; i++) if (F.mvLeftToRightMatch[i] != -1) mirror[i] = F.mvLeftToRightMatch[i] + F.Nleft;
+    for (size_t i = 0; i < F.mvRightToLeftMatch.size() && F.Nleft + i < kp.size(); i++) if (F.mvRightToLeftMatch[i] != -1) mirror[F.Nleft + i] = F.mvRightToLeftMatch[i];
+}
+
 int ORBmatcher::SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMapPoints, const float th, const bool bFarPoints, const float thFarPoints)
 {
-    if (F.Nleft != -1) { fprintf(stderr, "ORBmatcher (HIP): SearchByProjection(Frame, MapPoints) on a fisheye rig frame: use orbhip_search_local_map_rig_device\n"); return 0; }
     const bool bFactor = th != 1.0;
+    const bool rig = F.Nleft != -1;
     std::vector<orbhip_proj_query> q;
     std::vector<uint8_t> dq;
     std::vector<MapPoint *> owner;
     q.reserve(vpMapPoints.size()); dq.reserve(vpMapPoints.size() * 32); owner.reserve(vpMapPoints.size());
-    for (size_t iMP = 0; iMP < vpMapPoints.size(); iMP++) {                       // ORBmatcher.cc:54-79
+    for (size_t iMP = 0; iMP < vpMapPoints.size(); iMP++) {                       // ORBmatcher.cc:54-79, 149-156
         MapPoint *pMP = vpMapPoints[iMP];
         if (!pMP->mbTrackInView && !pMP->mbTrackInViewR) continue;
         if (bFarPoints && pMP->mTrackDepth > thFarPoints) continue;
         if (pMP->isBad()) continue;
+        const int obs = pMP->Observations() > 0;
         if (pMP->mbTrackInView) {
             const int &nPredictedLevel = pMP->mnTrackScaleLevel;
             // The size of the window will depend on the viewing direction
@@ -81,27 +93,50 @@ int ORBmatcher::SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMa
             e.u = pMP->mTrackProjX; e.v = pMP->mTrackProjY; e.radius = r * F.mvScaleFactors[nPredictedLevel];
             e.ur = pMP->mTrackProjXR; e.angle = 0.f;
             e.min_level = nPredictedLevel - 1; e.max_level = nPredictedLevel;
-            e.has_obs = pMP->Observations() > 0;
+            e.has_obs = obs;
             q.push_back(e); owner.push_back(pMP);
             const cv::Mat MPdescriptor = pMP->GetDescriptor();
             dq.insert(dq.end(), MPdescriptor.ptr<uint8_t>(), MPdescriptor.ptr<uint8_t>() + 32);
+        }
+        if (rig && pMP->mbTrackInViewR) {                                         // the same point in the right camera (:149-156)
+            const int &nPredictedLevel = pMP->mnTrackScaleLevelR;
+            if (nPredictedLevel != -1) {
+                float r = RadiusByViewingCos(pMP->mTrackViewCosR);
+                orbhip_proj_query e;
+                e.u = pMP->mTrackProjXR; e.v = pMP->mTrackProjYR; e.radius = r * F.mvScaleFactors[nPredictedLevel];
+                e.ur = -1.f; e.angle = 0.f;
+                e.min_level = nPredictedLevel - 1; e.max_level = nPredictedLevel;
+                e.has_obs = obs | 2;                                              // search mGridRight
+                q.push_back(e); owner.push_back(pMP);
+                const cv::Mat MPdescriptor = pMP->GetDescriptor();
+                dq.insert(dq.end(), MPdescriptor.ptr<uint8_t>(), MPdescriptor.ptr<uint8_t>() + 32);
+            }
         }
     }
     const int n = F.N;
     std::vector<int32_t> tm;
     claims_from(F.mvpMapPoints, n, tm);
     int32_t nmatches = 0;
-    const int rc = orbhip_search_by_projection_host(thread_ctx(), 1, q.data(), dq.data(), (int)q.size(), (const orbhip_keypoint *)F.mvKeysUn.data(),
-                                                    F.mDescriptors.ptr<uint8_t>(), F.mvuRight.empty() ? nullptr : F.mvuRight.data(), n, Frame::mnMinX,
-                                                    Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY, TH_HIGH, mfNNratio, 0, tm.data(), &nmatches);
+    int rc;
+    if (!rig)
+        rc = orbhip_search_by_projection_host(thread_ctx(), 1, q.data(), dq.data(), (int)q.size(), (const orbhip_keypoint *)F.mvKeysUn.data(),
+                                              F.mDescriptors.ptr<uint8_t>(), F.mvuRight.empty() ? nullptr : F.mvuRight.data(), n, Frame::mnMinX,
+                                              Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY, TH_HIGH, mfNNratio, 0, tm.data(), &nmatches);
+    else {
+        std::vector<cv::KeyPoint> kp; std::vector<int32_t> mirror;
+        rig_arrays(F, kp, mirror);
+        rc = orbhip_search_by_projection_rig_host(thread_ctx(), 1, q.data(), dq.data(), (int)q.size(), (const orbhip_keypoint *)kp.data(),
+                                                  F.mDescriptors.ptr<uint8_t>(), n, F.Nleft, mirror.data(), Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX,
+                                                  Frame::mnMaxY, TH_HIGH, mfNNratio, 0, tm.data(), &nmatches);
+    }
     if (rc != ORBHIP_OK) { fprintf(stderr, "ORBmatcher (HIP): SearchByProjection: %d (%s)\n", rc, orbhip_last_error()); return 0; }
-    for (int i = 0; i < n; i++) if (tm[i] >= 0) F.mvpMapPoints[i] = owner[tm[i]];  // F.mvpMapPoints[bestIdx]=pMP, :140
+    for (int i = 0; i < n; i++) if (tm[i] >= 0) F.mvpMapPoints[i] = owner[tm[i]];  // F.mvpMapPoints[bestIdx]=pMP (:140, :145, :205, :210)
     return nmatches;
 }
 
 int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono)
 {
-    if (CurrentFrame.Nleft != -1) { fprintf(stderr, "ORBmatcher (HIP): SearchByProjection(Frame, Frame) on a fisheye rig frame: use orbhip_search_by_projection_rig_device\n"); return 0; }
+    const bool rig = CurrentFrame.Nleft != -1;
     // twc = -Rcw^T tcw ; tlc = Rlw twc + tlw (ORBmatcher.cc:1976-1984), CV_32F matrix products (double accumulation, one rounding each)
     float twc[3], tlc[3];
     for (int i = 0; i < 3; i++) {
@@ -149,15 +184,39 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, 
         q.push_back(e); owner.push_back(pMP);
         const cv::Mat dMP = pMP->GetDescriptor();
         dq.insert(dq.end(), dMP.ptr<uint8_t>(), dMP.ptr<uint8_t>() + 32);
+        if (rig) {                                                                // the same point in the right camera (:2089-2105)
+            float x3Dr[3];
+            for (int a = 0; a < 3; a++) {                                         // mTrl.colRange(0,3).rowRange(0,3) * x3Dc + mTrl.col(3)
+                double acc = 0;
+                for (int k = 0; k < 3; k++) acc += (double)CurrentFrame.mTrl.at<float>(a, k) * (double)x3Dc[k];
+                x3Dr[a] = (float)(acc + (double)CurrentFrame.mTrl.at<float>(a, 3));
+            }
+            cv::Mat m3Dr(3, 1, CV_32F);
+            for (int k = 0; k < 3; k++) m3Dr.at<float>(k) = x3Dr[k];
+            const cv::Point2f uvr = CurrentFrame.mpCamera->project(m3Dr);        // (the reference projects through mpCamera here, :2092)
+            orbhip_proj_query er = e;
+            er.u = uvr.x; er.v = uvr.y; er.has_obs = e.has_obs | 2;
+            q.push_back(er); owner.push_back(pMP);
+            dq.insert(dq.end(), dMP.ptr<uint8_t>(), dMP.ptr<uint8_t>() + 32);
+        }
     }
     const int n = CurrentFrame.N;
     std::vector<int32_t> tm;
     claims_from(CurrentFrame.mvpMapPoints, n, tm);
     int32_t nmatches = 0;
-    const int rc = orbhip_search_by_projection_host(thread_ctx(), 0, q.data(), dq.data(), (int)q.size(), (const orbhip_keypoint *)CurrentFrame.mvKeysUn.data(),
-                                                    CurrentFrame.mDescriptors.ptr<uint8_t>(), CurrentFrame.mvuRight.empty() ? nullptr : CurrentFrame.mvuRight.data(),
-                                                    n, Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY, TH_HIGH, 0.f, mbCheckOrientation ? 1 : 0,
-                                                    tm.data(), &nmatches);
+    int rc;
+    if (!rig)
+        rc = orbhip_search_by_projection_host(thread_ctx(), 0, q.data(), dq.data(), (int)q.size(), (const orbhip_keypoint *)CurrentFrame.mvKeysUn.data(),
+                                              CurrentFrame.mDescriptors.ptr<uint8_t>(), CurrentFrame.mvuRight.empty() ? nullptr : CurrentFrame.mvuRight.data(),
+                                              n, Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY, TH_HIGH, 0.f, mbCheckOrientation ? 1 : 0,
+                                              tm.data(), &nmatches);
+    else {
+        std::vector<cv::KeyPoint> kp; std::vector<int32_t> mirror;
+        rig_arrays(CurrentFrame, kp, mirror);
+        rc = orbhip_search_by_projection_rig_host(thread_ctx(), 0, q.data(), dq.data(), (int)q.size(), (const orbhip_keypoint *)kp.data(),
+                                                  CurrentFrame.mDescriptors.ptr<uint8_t>(), n, CurrentFrame.Nleft, nullptr, Frame::mnMinX, Frame::mnMinY,
+                                                  Frame::mnMaxX, Frame::mnMaxY, TH_HIGH, 0.f, mbCheckOrientation ? 1 : 0, tm.data(), &nmatches);
+    }
     if (rc != ORBHIP_OK) { fprintf(stderr, "ORBmatcher (HIP): SearchByProjection: %d (%s)\n", rc, orbhip_last_error()); return 0; }
     // A keypoint taken in this call holds the taker's map point.  One that was taken and then dropped by the rotation check comes
     // back as free (-1): the reference sets it to NULL (:2170), which it already is at the reference's call sites

@@ -68,6 +68,12 @@ int match_smoke(const char *in, const char *out)
     const std::vector<cv::KeyPoint> k2 = r.vec<cv::KeyPoint>(nI2);
     const std::vector<uint8_t> d2 = r.vec<uint8_t>((size_t)nI2 * 32);
     const std::vector<float> prev = r.vec<float>((size_t)nI1 * 2);
+    // rig scenario (appended): int32 nleft; int32[n] cross-camera link of every keypoint (frame-wide index or -1); float[12] mTrl (3x4);
+    // float[nMap*5] {mTrackProjXR, mTrackProjYR, mTrackViewCosR, mnTrackScaleLevelR, mbTrackInViewR}
+    const int nleftRig = r.vec<int32_t>(1)[0];
+    const std::vector<int32_t> link = r.vec<int32_t>(n);
+    const std::vector<float> trl = r.vec<float>(12);
+    const std::vector<float> mpR = r.vec<float>((size_t)nMap * 5);
 
     auto mat44 = [](const std::vector<float> &p) { cv::Mat m(4, 4, CV_32F); for (int i = 0; i < 16; i++) m.at<float>(i / 4, i % 4) = p[i]; return m; };
     std::vector<std::unique_ptr<MapPoint>> pool;
@@ -147,6 +153,64 @@ int match_smoke(const char *in, const char *out)
         std::vector<int32_t> m12(vnMatches12.begin(), vnMatches12.end());
         put(fo, m12);
         if (nI1) fwrite(vbPrevMatched.data(), 8, nI1, fo);
+    }
+    // ---- the same two searches on a two-camera rig frame (Nleft != -1): left | right keypoints, mvLeftToRightMatch / mvRightToLeftMatch
+    auto make_rig = [&](Frame &F) {
+        make_current(F);
+        F.Nleft = nleftRig; F.Nright = n - nleftRig;
+        F.mvKeys.assign(kp.begin(), kp.begin() + nleftRig); F.mvKeysRight.assign(kp.begin() + nleftRig, kp.end()); F.mvKeysUn.clear();
+        F.mvuRight.assign(n, -1.f);
+        F.mvLeftToRightMatch.assign(nleftRig, -1); F.mvRightToLeftMatch.assign(n - nleftRig, -1);
+        for (int i = 0; i < n; i++) {
+            if (link[i] < 0) continue;
+            if (i < nleftRig) F.mvLeftToRightMatch[i] = link[i] - nleftRig; else F.mvRightToLeftMatch[i - nleftRig] = link[i];
+        }
+        F.mTrl = cv::Mat(3, 4, CV_32F);
+        for (int i = 0; i < 12; i++) F.mTrl.at<float>(i / 4, i % 4) = trl[i];
+    };
+    {
+        Frame cur, last;
+        make_rig(cur);
+        last.N = nLast; last.mvKeys = kpL; last.mvKeysUn = kpL; last.mTcw = mat44(Tlw); last.mvpMapPoints.assign(nLast, nullptr);
+        last.mvbOutlier.assign(nLast, false);
+        std::vector<MapPoint *> lastMP(nLast, nullptr);
+        for (int i = 0; i < nLast; i++) {
+            if (hasMP[i]) last.mvpMapPoints[i] = lastMP[i] = new_mp(&Xw[(size_t)3 * i], &dL[(size_t)32 * i], nobs[i]);
+            last.mvbOutlier[i] = outl[i] != 0;
+        }
+        const std::vector<MapPoint *> before = cur.mvpMapPoints;
+        ORBmatcher matcher(0.9, true);
+        const int nm = matcher.SearchByProjection(cur, last, fp[10], bMono);
+        std::vector<int32_t> res(n, -1);
+        for (int i = 0; i < n; i++) {
+            if (cur.mvpMapPoints[i] == nullptr) continue;
+            res[i] = -2;
+            if (cur.mvpMapPoints[i] != before[i]) for (int j = 0; j < nLast; j++) if (lastMP[j] == cur.mvpMapPoints[i]) res[i] = j;
+        }
+        fwrite(&nm, 4, 1, fo); put(fo, res);
+    }
+    {
+        Frame cur;
+        make_rig(cur);
+        std::vector<MapPoint *> local(nMap);
+        for (int j = 0; j < nMap; j++) {
+            const float *m = &mp[(size_t)8 * j], *mr = &mpR[(size_t)5 * j];
+            MapPoint *p = new_mp(nullptr, &dM[(size_t)32 * j], (int)m[7]);
+            p->mTrackProjX = m[0]; p->mTrackProjY = m[1]; p->mTrackProjXR = mr[0]; p->mTrackProjYR = mr[1]; p->mTrackViewCos = m[3]; p->mTrackDepth = m[4];
+            p->mnTrackScaleLevel = (int)m[5]; p->mbTrackInView = m[6] != 0.f;
+            p->mTrackViewCosR = mr[2]; p->mnTrackScaleLevelR = (int)mr[3]; p->mbTrackInViewR = mr[4] != 0.f;
+            local[j] = p;
+        }
+        const std::vector<MapPoint *> before = cur.mvpMapPoints;
+        ORBmatcher matcher(fp[11]);
+        const int nm = matcher.SearchByProjection(cur, local, fp[10], true, 40.0f);
+        std::vector<int32_t> res(n, -1);
+        for (int i = 0; i < n; i++) {
+            if (cur.mvpMapPoints[i] == nullptr) continue;
+            res[i] = -2;
+            if (cur.mvpMapPoints[i] != before[i]) for (int j = 0; j < nMap; j++) if (local[j] == cur.mvpMapPoints[i]) res[i] = j;
+        }
+        fwrite(&nm, 4, 1, fo); put(fo, res);
     }
     fclose(fo);
     printf("HOST_MATCH_OK\n");

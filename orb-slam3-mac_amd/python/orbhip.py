@@ -612,3 +612,29 @@ def search_by_bow_device(ctx, kf, f, d_nF, pairs, max_nodes, max_n, kp_stride, n
     _chk(lib.orbhip_search_by_bow_device(ctx.h, kf[0], kf[1], kf[2], kf[3], kf[4], kf[5], kf[6], f[0], f[1], f[2], f[3], f[4], f[5], d_nF,
                                          pairs, max_nodes, max_n, kp_stride, nn_ratio, 1 if check_ori else 0, d_match_f, d_nmatches),
          "orbhip_search_by_bow_device")
+
+
+lib.orbhip_search_by_projection_rig_device.argtypes = [vp, ci, vp, vp, vp, ci, vp, vp, vp, vp, vp, ci, sz, ci, cf, cf, cf, cf, ci, cf, ci, vp, vp]
+lib.orbhip_search_by_bow_rig_device.argtypes = [vp] * 16 + [ci, ci, ci, sz, cf, ci, vp, vp]
+lib.orbhip_assign_features_to_grid_rig_device.argtypes = [vp, vp, vp, vp, ci, ci, sz, cf, cf, cf, cf, vp, vp]
+
+
+def search_by_projection_rig_device(ctx, mode, d_q, d_desc_q, d_nq, max_q, d_kp, d_desc, d_n, d_nleft, d_mirror, max_n, kp_stride, pairs, bounds,
+                                    th_high, nn_ratio, check_ori, d_train_match, d_nmatches):
+    """ORBmatcher::SearchByProjection on frames of a two-camera rig (Nleft != -1); mode 0: from the last frame, 1: local map points."""
+    _chk(lib.orbhip_search_by_projection_rig_device(ctx.h, mode, d_q, d_desc_q, d_nq, max_q, d_kp, d_desc, d_n, d_nleft, d_mirror, max_n, kp_stride,
+                                                    pairs, bounds[0], bounds[1], bounds[2], bounds[3], th_high, nn_ratio, 1 if check_ori else 0,
+                                                    d_train_match, d_nmatches), "orbhip_search_by_projection_rig_device")
+
+
+def search_by_bow_rig_device(ctx, kf, f, d_nF, d_nleft, pairs, max_nodes, max_n, kp_stride, nn_ratio, check_ori, d_match_f, d_nmatches):
+    """ORBmatcher::SearchByBoW(KeyFrame, Frame) on rig frames; kf / f as in search_by_bow_device."""
+    _chk(lib.orbhip_search_by_bow_rig_device(ctx.h, kf[0], kf[1], kf[2], kf[3], kf[4], kf[5], kf[6], f[0], f[1], f[2], f[3], f[4], f[5], d_nF, d_nleft,
+                                             pairs, max_nodes, max_n, kp_stride, nn_ratio, 1 if check_ori else 0, d_match_f, d_nmatches),
+         "orbhip_search_by_bow_rig_device")
+
+
+def assign_features_to_grid_rig_device(ctx, d_kp, d_n, d_nleft, frames, max_n, kp_stride, bounds, d_cell_start, d_items):
+    """Frame::AssignFeaturesToGrid on rig frames: mGrid | mGridRight as one CSR (2*3072+1 cell starts per frame)."""
+    _chk(lib.orbhip_assign_features_to_grid_rig_device(ctx.h, d_kp, d_n, d_nleft, frames, max_n, kp_stride, bounds[0], bounds[1], bounds[2],
+                                                       bounds[3], d_cell_start, d_items), "orbhip_assign_features_to_grid_rig_device")

@@ -332,3 +332,37 @@ def bow_vectors(wid, w, nid):
     lib.orc_bow_vectors(wid.ctypes.data, w.ctypes.data, nid.ctypes.data, n, ni.ctypes.data, ns.ctypes.data, ft.ctypes.data, C.byref(nn),
                         bw.ctypes.data, bv.ctypes.data, C.byref(nw))
     return ni[:nn.value], ns[:nn.value + 1], ft[:ns[nn.value]], bw[:nw.value], bv[:nw.value]
+
+
+# ------------------------------------------------------------------ two-camera rig frames (Nleft != -1)
+lib.orc_search_by_projection_rig.restype = ci
+lib.orc_search_by_projection_rig.argtypes = [ci, vp, vp, ci, vp, vp, ci, ci, vp, C.c_float, C.c_float, C.c_float, C.c_float, ci, C.c_float, ci, vp]
+lib.orc_search_by_bow_rig.restype = ci
+lib.orc_search_by_bow_rig.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, vp, vp, ci, ci, C.c_float, ci, vp]
+
+
+def search_by_projection_rig(mode, q, dq, kp, d, nleft, mirror, bounds, train_match, th_high=100, nn_ratio=0.8, check_ori=True):
+    """ORBmatcher::SearchByProjection on a rig frame (mode 0: from the last frame, 1: local map points); returns (nmatches, train_match)."""
+    q = np.ascontiguousarray(q, PROJ_QUERY_DTYPE); dq = np.ascontiguousarray(dq, np.uint8)
+    kp = np.ascontiguousarray(kp, KP_DTYPE); d = np.ascontiguousarray(d, np.uint8)
+    tm = np.ascontiguousarray(train_match, np.int32).copy()
+    if len(tm) == 0:
+        tm = np.zeros(1, np.int32)
+    mi = None if mirror is None else np.ascontiguousarray(mirror, np.int32)
+    n = lib.orc_search_by_projection_rig(mode, q.ctypes.data, dq.ctypes.data, len(q), kp.ctypes.data, d.ctypes.data, len(kp), nleft,
+                                         None if mi is None else mi.ctypes.data, bounds[0], bounds[1], bounds[2], bounds[3], th_high, nn_ratio,
+                                         1 if check_ori else 0, tm.ctypes.data)
+    return n, tm[:len(kp)]
+
+
+def search_by_bow_rig(c, nleft, nn_ratio=0.7, check_ori=True):
+    ki, ks, kf = feature_vector_csr(c["nid_k"]); fi, fs, ff = feature_vector_csr(c["nid_f"])
+    nF = len(c["kp_f"])
+    m = np.zeros(max(nF, 1), np.int32)
+    kpk = np.ascontiguousarray(c["kp_k"], KP_DTYPE); kpf = np.ascontiguousarray(c["kp_f"], KP_DTYPE)
+    dk = np.ascontiguousarray(c["d_k"], np.uint8); df = np.ascontiguousarray(c["d_f"], np.uint8)
+    va = np.ascontiguousarray(c["valid"], np.uint8)
+    n = lib.orc_search_by_bow_rig(ki.ctypes.data, ks.ctypes.data, kf.ctypes.data, len(ki), va.ctypes.data, kpk.ctypes.data, dk.ctypes.data,
+                                  fi.ctypes.data, fs.ctypes.data, ff.ctypes.data, len(fi), kpf.ctypes.data, df.ctypes.data, nF, nleft,
+                                  nn_ratio, 1 if check_ori else 0, m.ctypes.data)
+    return n, m[:nF]

@@ -263,7 +263,21 @@ def _match_case(seed, bMono, forward=0.0):
     k2 = k1.copy(); k2["x"] += rng.normal(0, 6, nI).astype(np.float32); k2["y"] += rng.normal(0, 6, nI).astype(np.float32)
     perm = rng.permutation(nI); k2 = k2[perm]; d2 = d1[perm].copy(); d2[:, 5] ^= rng.integers(0, 4, nI).astype(np.uint8)
     prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
-    return dict(n=n, nLast=nLast, nMap=nMap, nI=nI, bMono=bMono, bounds=bounds, cam=(fx, fy, cx, cy), mbf=mbf, mb=mb, th=th, ratio=ratio,
+    # rig scenario: the same keypoints split into a left and a right camera, a third of them linked across the cameras
+    nleft = n * 11 // 20
+    link = np.full(n, -1, np.int32)
+    kk = (n - nleft) // 3
+    li = rng.choice(nleft, kk, replace=False); ri = rng.choice(n - nleft, kk, replace=False) + nleft
+    link[li] = ri; link[ri] = li
+    ar = 0.02
+    Trl = np.zeros((3, 4), np.float32)
+    Trl[:, :3] = np.array([[np.cos(ar), 0, -np.sin(ar)], [0, 1, 0], [np.sin(ar), 0, np.cos(ar)]], np.float32); Trl[:, 3] = np.array([-0.1, 0.0, 0.01], np.float32)
+    rsrc = rng.integers(nleft, n, nMap)
+    mpR = np.zeros((nMap, 5), np.float32)
+    mpR[:, 0] = kp["x"][rsrc] + rng.normal(0, 2, nMap); mpR[:, 1] = kp["y"][rsrc] + rng.normal(0, 2, nMap)
+    mpR[:, 2] = rng.choice([0.9, 0.9985, 0.9999], nMap); mpR[:, 3] = np.where(rng.random(nMap) < 0.9, np.clip(kp["octave"][rsrc] + rng.integers(0, 2, nMap), 0, 7), -1)
+    mpR[:, 4] = rng.random(nMap) < 0.7
+    return dict(nleft=nleft, link=link, Trl=Trl, mpR=mpR, n=n, nLast=nLast, nMap=nMap, nI=nI, bMono=bMono, bounds=bounds, cam=(fx, fy, cx, cy), mbf=mbf, mb=mb, th=th, ratio=ratio,
                 scales=scales, kp=kp, d=d, ur=ur, holder=holder, Tcw=Tcw, Tlw=Tlw, kpL=kpL, hasMP=hasMP, outl=outl, nobs=nobs, Xw=Xw, dL=dL,
                 mp=mp, dM=dM, k1=k1, d1=d1, k2=k2, d2=d2, prev=prev, window=100)
 
@@ -277,11 +291,12 @@ def _write_match(path, c):
         c["kpL"].tofile(f); c["Tlw"].tofile(f); c["hasMP"].tofile(f); c["outl"].tofile(f); c["nobs"].tofile(f); c["Xw"].tofile(f); c["dL"].tofile(f)
         c["mp"].tofile(f); c["dM"].tofile(f)
         c["k1"].tofile(f); c["d1"].tofile(f); c["k2"].tofile(f); c["d2"].tofile(f); c["prev"].tofile(f)
+        np.array([c["nleft"]], np.int32).tofile(f); c["link"].tofile(f); c["Trl"].tofile(f); c["mpR"].tofile(f)
 
 
-def _expected_last_frame(c):
-    """ORBmatcher.cc:1976-2023 restated in numpy float32 (matrix products accumulate in double and round once, as cv::gemm),
-    then the claim-rule search of the oracle."""
+def _expected_last_frame(c, rig=False):
+    """ORBmatcher.cc:1976-2023 (+ :2089-2105 on a rig frame) restated in numpy float32 (matrix products accumulate in double and round
+    once, as cv::gemm), then the claim-rule search of the oracle."""
     import oracle_match_bind as om
     fx, fy, cx, cy = (np.float32(v) for v in c["cam"])
     Tcw, Tlw = c["Tcw"], c["Tlw"]
@@ -306,28 +321,47 @@ def _expected_last_frame(c):
         lv = (octv, -1) if fwd else (0, octv) if bwd else (octv - 1, octv + 1)
         q.append((u, v, radius, np.float32(u - np.float32(np.float32(c["mbf"]) * invzc)), c["kpL"]["angle"][i], lv[0], lv[1], int(c["nobs"][i] > 0)))
         dq.append(c["dL"][i]); qsrc.append(i)
+        if rig:
+            T = c["Trl"]
+            xr = [np.float32(sum(np.float64(T[r, k]) * np.float64(xc[k]) for k in range(3)) + np.float64(T[r, 3])) for r in range(3)]
+            ur_ = np.float32(np.float32(np.float32(fx * xr[0]) / xr[2]) + cx); vr_ = np.float32(np.float32(np.float32(fy * xr[1]) / xr[2]) + cy)
+            q.append((ur_, vr_, radius, q[-1][3], c["kpL"]["angle"][i], lv[0], lv[1], int(c["nobs"][i] > 0) | 2))
+            dq.append(c["dL"][i]); qsrc.append(i)
     q = np.array(q, om.PROJ_QUERY_DTYPE); dq = np.array(dq, np.uint8).reshape(-1, 32)
     tm0 = np.where(c["holder"] == 1, -2, -1).astype(np.int32)
-    nm, tm = om.search_by_projection(q, dq, c["kp"], c["d"], c["ur"], c["bounds"], tm0, 100, True)
+    if rig:
+        nm, tm = om.search_by_projection_rig(0, q, dq, c["kp"], c["d"], c["nleft"], None, c["bounds"], tm0, 100, 0.0, True)
+    else:
+        nm, tm = om.search_by_projection(q, dq, c["kp"], c["d"], c["ur"], c["bounds"], tm0, 100, True)
     res = np.where(tm >= 0, np.array(qsrc + [0], np.int64)[np.clip(tm, 0, None)], np.where(c["holder"] >= 0, -2, -1))
     return nm, res.astype(np.int32), (fwd, bwd), len(q)
 
 
-def _expected_local_map(c):
+def _expected_local_map(c, rig=False):
     import oracle_match_bind as om
     q, dq, qsrc = [], [], []
     for j in range(c["nMap"]):
-        m = c["mp"][j]
-        if not m[6] or m[4] > np.float32(40.0):
+        m, mr = c["mp"][j], c["mpR"][j]
+        in_l, in_r = bool(m[6]), bool(mr[4]) and rig
+        if (not in_l and not in_r) or m[4] > np.float32(40.0):                            # ORBmatcher.cc:57-61
             continue
-        lvl = int(m[5])
-        r = np.float32(2.5) if m[3] > np.float32(0.998) else np.float32(4.0)
-        r = np.float32(r * np.float32(c["th"]))
-        q.append((m[0], m[1], np.float32(r * c["scales"][lvl]), m[2], 0.0, lvl - 1, lvl, int(m[7] > 0)))
-        dq.append(c["dM"][j]); qsrc.append(j)
+        if in_l:
+            lvl = int(m[5])
+            r = np.float32(2.5) if m[3] > np.float32(0.998) else np.float32(4.0)
+            r = np.float32(r * np.float32(c["th"]))
+            q.append((m[0], m[1], np.float32(r * c["scales"][lvl]), mr[0] if rig else m[2], 0.0, lvl - 1, lvl, int(m[7] > 0)))
+            dq.append(c["dM"][j]); qsrc.append(j)
+        if in_r and int(mr[3]) != -1:
+            lvl = int(mr[3])
+            r = np.float32(2.5) if mr[2] > np.float32(0.998) else np.float32(4.0)        # no th factor in the right camera (ORBmatcher.cc:152)
+            q.append((mr[0], mr[1], np.float32(r * c["scales"][lvl]), -1.0, 0.0, lvl - 1, lvl, int(m[7] > 0) | 2))
+            dq.append(c["dM"][j]); qsrc.append(j)
     q = np.array(q, om.PROJ_QUERY_DTYPE); dq = np.array(dq, np.uint8).reshape(-1, 32)
     tm0 = np.where(c["holder"] == 1, -2, -1).astype(np.int32)
-    nm, tm = om.search_by_projection_map(q, dq, c["kp"], c["d"], c["ur"], c["bounds"], tm0, 100, np.float32(c["ratio"]))
+    if rig:
+        nm, tm = om.search_by_projection_rig(1, q, dq, c["kp"], c["d"], c["nleft"], c["link"], c["bounds"], tm0, 100, np.float32(c["ratio"]), False)
+    else:
+        nm, tm = om.search_by_projection_map(q, dq, c["kp"], c["d"], c["ur"], c["bounds"], tm0, 100, np.float32(c["ratio"]))
     res = np.where(tm >= 0, np.array(qsrc + [0], np.int64)[np.clip(tm, 0, None)], np.where(c["holder"] >= 0, -2, -1))
     return nm, res.astype(np.int32), len(q)
 
@@ -348,6 +382,8 @@ def test_orbmatcher_methods_over_frames(tmp_path, bMono, forward):
         nm_last = int(np.fromfile(f, np.int32, 1)[0]); res_last = np.fromfile(f, np.int32, c["n"])
         nm_map = int(np.fromfile(f, np.int32, 1)[0]); res_map = np.fromfile(f, np.int32, c["n"])
         nm_init = int(np.fromfile(f, np.int32, 1)[0]); m12 = np.fromfile(f, np.int32, c["nI"]); prev = np.fromfile(f, np.float32, 2 * c["nI"]).reshape(-1, 2)
+        nm_rl = int(np.fromfile(f, np.int32, 1)[0]); res_rl = np.fromfile(f, np.int32, c["n"])
+        nm_rm = int(np.fromfile(f, np.int32, 1)[0]); res_rm = np.fromfile(f, np.int32, c["n"])
     e_nm, e_res, (fwd, bwd), nq = _expected_last_frame(c)
     assert (fwd, bwd) == (forward > 0.2 and not bMono, forward < -0.2 and not bMono)
     assert nq > 300 and e_nm > 100
@@ -358,3 +394,10 @@ def test_orbmatcher_methods_over_frames(tmp_path, bMono, forward):
     e_nm, e_m12, e_prev = om.search_for_initialization(c["k1"], c["d1"], c["k2"], c["d2"], c["bounds"], c["prev"], c["window"], 0.9, True)
     assert e_nm > 50
     assert nm_init == e_nm and np.array_equal(m12, e_m12) and prev.tobytes() == e_prev.tobytes()
+    # the same calls on a two-camera rig frame: right-camera queries, mGridRight, cross-camera mirroring
+    e_nm, e_res, _, nq = _expected_last_frame(c, rig=True)
+    assert e_nm > 100 and (e_res[c["nleft"]:] >= 0).sum() > 20
+    assert nm_rl == e_nm and np.array_equal(res_rl, e_res)
+    e_nm, e_res, nq = _expected_local_map(c, rig=True)
+    assert e_nm > 100 and (e_res[c["nleft"]:] >= 0).sum() > 20
+    assert nm_rm == e_nm and np.array_equal(res_rm, e_res)

@@ -725,3 +725,106 @@ def test_matchers_against_committed_fixture(gpu_ctx):
     assert got[0][0] == int(g["sbp_n"]); np.testing.assert_array_equal(got[0][1], g["sbp_m"])
     got = _sbp(gpu_ctx, [case], 256, 256, bounds, 100, False, True, map_ratio=0.8)
     assert got[0][0] == int(g["map_n"]); np.testing.assert_array_equal(got[0][1], g["map_m"])
+
+
+# ------------------------------------------------------------------ frames of a two-camera rig (Nleft != -1)
+@pytest.mark.parametrize("mode", [0, 1])
+def test_rig_search_by_projection_parity(gpu_ctx, mode):
+    """SearchByProjection on stereo-fisheye frames (ORBmatcher.cc:2013-2016, 2089-2153 / 113-122, 136-214): left and right camera
+    queries in the reference's order over mGrid / mGridRight, cross-camera mirroring of a match (mode 1), bit-exact vs the oracle."""
+    import torch
+    import orbhip
+    import oracle_match_bind as om
+    from test_oracle_match_ba import make_rig_case
+    rng = np.random.default_rng(900 + mode)
+    bounds = (0.0, 0.0, 512.0, 512.0)
+    cases = [make_rig_case(rng, nl, nr, npts, mode) for nl, nr, npts in ((0, 30, 20), (50, 0, 40), (300, 280, 250), (1000, 1040, 900), (700, 500, 1100))]
+    P, MN, MQ = len(cases), 2048, 2048
+    aq = np.zeros((P, MQ), orbhip.PROJ_QUERY_DTYPE); adq = np.zeros((P, MQ, 32), np.uint8); anq = np.zeros(P, np.int32)
+    akp = np.zeros((P, MN), orbhip.KP_DTYPE); ad = np.zeros((P, MN, 32), np.uint8); an = np.zeros(P, np.int32); anl = np.zeros(P, np.int32)
+    ami = np.full((P, MN), -1, np.int32); atm = np.full((P, MN), -1, np.int32)
+    for p, (q, dq, kp, d, mirror, tm) in enumerate(cases):
+        aq[p, :len(q)] = q; adq[p, :len(q)] = dq; anq[p] = len(q)
+        akp[p, :len(kp)] = kp; ad[p, :len(kp)] = d; an[p] = len(kp); ami[p, :len(kp)] = mirror; atm[p, :len(kp)] = tm
+    for p, nl in enumerate((0, 50, 300, 1000, 700)):
+        anl[p] = nl
+    t = {k: torch.from_numpy(v.view(np.uint8) if v.dtype in (orbhip.KP_DTYPE, orbhip.PROJ_QUERY_DTYPE) else v).cuda()
+         for k, v in dict(q=aq, dq=adq, nq=anq, kp=akp, d=ad, n=an, nl=anl, mi=ami, tm=atm).items()}
+    nm = torch.full((P,), -9, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    orbhip.search_by_projection_rig_device(gpu_ctx, mode, t["q"].data_ptr(), t["dq"].data_ptr(), t["nq"].data_ptr(), MQ, t["kp"].data_ptr(),
+                                           t["d"].data_ptr(), t["n"].data_ptr(), t["nl"].data_ptr(), t["mi"].data_ptr() if mode == 1 else None, MN, MN, P,
+                                           bounds, 100, 0.8, True, t["tm"].data_ptr(), nm.data_ptr())
+    gpu_ctx.check_status()
+    got_tm, got_nm = t["tm"].cpu().numpy(), nm.cpu().numpy()
+    tot = right = 0
+    for p, (q, dq, kp, d, mirror, tm) in enumerate(cases):
+        n_ref, tm_ref = om.search_by_projection_rig(mode, q, dq, kp, d, int(anl[p]), mirror if mode == 1 else None, bounds, tm, 100, 0.8, True)
+        assert got_nm[p] == n_ref, (p, got_nm[p], n_ref)
+        np.testing.assert_array_equal(got_tm[p, :len(kp)], tm_ref)
+        tot += n_ref; right += int((tm_ref[int(anl[p]):] >= 0).sum())
+    assert tot > 500 and right > 150
+
+
+def test_rig_search_by_bow_parity(gpu_ctx):
+    """SearchByBoW(KeyFrame, Frame) with F.Nleft != -1 (ORBmatcher.cc:338-359, 393-425), bit-exact vs the oracle."""
+    import torch
+    import orbhip
+    import oracle_match_bind as om
+    rng = np.random.default_rng(161)
+    cases = [om.make_bow_case(rng, nk, nf, nn) for nk, nf, nn in ((30, 0, 10), (200, 260, 40), (1000, 950, 100), (2000, 2048, 300), (600, 1500, 900))]
+    nlefts = [0, 130, 500, 1024, 1500]                          # the last frame has no right-camera features at all
+    P, MN, MNODE = len(cases), 2048, 2048
+    arr = dict(ki=np.zeros((P, MNODE), np.int32), ks=np.zeros((P, MNODE + 1), np.int32), kf=np.zeros((P, MN), np.int32), kn=np.zeros(P, np.int32),
+               fi=np.zeros((P, MNODE), np.int32), fs=np.zeros((P, MNODE + 1), np.int32), ff=np.zeros((P, MN), np.int32), fn=np.zeros(P, np.int32),
+               va=np.zeros((P, MN), np.uint8), kpk=np.zeros((P, MN), orbhip.KP_DTYPE), kpf=np.zeros((P, MN), orbhip.KP_DTYPE),
+               dk=np.zeros((P, MN, 32), np.uint8), df=np.zeros((P, MN, 32), np.uint8), nF=np.zeros(P, np.int32), nl=np.array(nlefts, np.int32))
+    for p, c in enumerate(cases):
+        ki, ks, kf = om.feature_vector_csr(c["nid_k"]); fi, fs, ff = om.feature_vector_csr(c["nid_f"])
+        arr["ki"][p, :len(ki)] = ki; arr["ks"][p, :len(ks)] = ks; arr["kf"][p, :len(kf)] = kf; arr["kn"][p] = len(ki)
+        arr["fi"][p, :len(fi)] = fi; arr["fs"][p, :len(fs)] = fs; arr["ff"][p, :len(ff)] = ff; arr["fn"][p] = len(fi)
+        nk, nf = len(c["kp_k"]), len(c["kp_f"])
+        arr["va"][p, :nk] = c["valid"]; arr["kpk"][p, :nk] = c["kp_k"]; arr["kpf"][p, :nf] = c["kp_f"]
+        arr["dk"][p, :nk] = c["d_k"]; arr["df"][p, :nf] = c["d_f"]; arr["nF"][p] = nf
+    t = {k: torch.from_numpy(v.view(np.uint8) if v.dtype == orbhip.KP_DTYPE else v).cuda() for k, v in arr.items()}
+    mf = torch.full((P, MN), -9, dtype=torch.int32, device="cuda"); nm = torch.full((P,), -9, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    orbhip.search_by_bow_rig_device(gpu_ctx, [t[k].data_ptr() for k in ("ki", "ks", "kf", "kn", "va", "kpk", "dk")],
+                                    [t[k].data_ptr() for k in ("fi", "fs", "ff", "fn", "kpf", "df")], t["nF"].data_ptr(), t["nl"].data_ptr(), P, MNODE,
+                                    MN, MN, 0.7, True, mf.data_ptr(), nm.data_ptr())
+    gpu_ctx.check_status()
+    mf, nm = mf.cpu().numpy(), nm.cpu().numpy()
+    tot = 0
+    for p, c in enumerate(cases):
+        n_ref, m_ref = om.search_by_bow_rig(c, nlefts[p], 0.7, True)
+        assert nm[p] == n_ref, (p, nm[p], n_ref)
+        np.testing.assert_array_equal(mf[p, :len(m_ref)], m_ref)
+        tot += n_ref
+    assert tot > 300
+
+
+def test_rig_assign_features_to_grid(gpu_ctx):
+    """Frame::AssignFeaturesToGrid with Nleft != -1: mGrid from the left keypoints, mGridRight from the right ones with indices i - Nleft
+    (Frame.cc:395-405) == the single-camera oracle on each half."""
+    import torch
+    import orbhip
+    import oracle_match_bind as om
+    rng = np.random.default_rng(5)
+    bounds = (0.0, 0.0, 512.0, 512.0)
+    F, MN = 3, 1500
+    kps, ns, nls = np.zeros((F, MN), orbhip.KP_DTYPE), np.array([1500, 700, 40], np.int32), np.array([800, 700, 0], np.int32)
+    for f in range(F):
+        kps["x"][f, :ns[f]] = rng.uniform(-10, 530, ns[f]); kps["y"][f, :ns[f]] = rng.uniform(-10, 530, ns[f])
+    d_kp = torch.from_numpy(kps.view(np.uint8)).cuda(); d_n = torch.from_numpy(ns).cuda(); d_nl = torch.from_numpy(nls).cuda()
+    cs = torch.zeros((F, 2 * 3072 + 1), dtype=torch.int32, device="cuda"); it = torch.full((F, MN), -7, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    orbhip.assign_features_to_grid_rig_device(gpu_ctx, d_kp.data_ptr(), d_n.data_ptr(), d_nl.data_ptr(), F, MN, MN, bounds, cs.data_ptr(), it.data_ptr())
+    gpu_ctx.check_status()
+    cs, it = cs.cpu().numpy(), it.cpu().numpy()
+    for f in range(F):
+        csl, itl = om.assign_features_to_grid(kps[f, :nls[f]], bounds)
+        csr, itr = om.assign_features_to_grid(kps[f, nls[f]:ns[f]], bounds)
+        np.testing.assert_array_equal(cs[f, :3073], csl)
+        np.testing.assert_array_equal(cs[f, 3072:], csr + csl[-1])
+        np.testing.assert_array_equal(it[f, :csl[-1]], itl[:csl[-1]])
+        np.testing.assert_array_equal(it[f, csl[-1]:csl[-1] + csr[-1]], itr[:csr[-1]])

@@ -939,3 +939,172 @@ def test_matcher_golden_regression():
     ni, ns, ft, bw, bv = om.bow_vectors(g["bv_wid"], g["bv_w"], g["bv_nid"])
     np.testing.assert_array_equal(ni, g["bv_ni"]); np.testing.assert_array_equal(ft, g["bv_ft"]); np.testing.assert_array_equal(bw, g["bv_bw"])
     assert bv.tobytes() == g["bv_bv"].tobytes()
+
+
+# ------------------------------------------------------------------ two-camera rig frames (Nleft != -1): independent models
+def make_rig_case(rng, nleft, nright, npts, mode):
+    """A rig frame (left | right keypoints, cross links between the cameras) and the query list the reference's loop would issue:
+    per point a left-camera query and / or a right-camera query (has_obs bit 1), in order."""
+    import oracle_match_bind as om
+    from oracle_bind import KP_DTYPE
+    n = nleft + nright
+    kp = np.zeros(n, KP_DTYPE)
+    kp["x"] = rng.uniform(-5, 520, n).astype(np.float32); kp["y"] = rng.uniform(-5, 520, n).astype(np.float32)
+    kp["angle"] = rng.uniform(0, 360, n).astype(np.float32); kp["octave"] = rng.integers(0, 8, n)
+    base = rng.integers(0, 256, (max(n // 6, 1), 32), dtype=np.uint8)
+    d = base[rng.integers(0, len(base), n)].copy(); d[:, 1] ^= rng.integers(0, 8, n).astype(np.uint8)
+    mirror = np.full(n, -1, np.int32)                       # stereo matches between the cameras (mvLeftToRightMatch / mvRightToLeftMatch)
+    k = min(nleft, nright) // 3
+    if k:
+        li = rng.choice(nleft, k, replace=False); ri = rng.choice(nright, k, replace=False) + nleft
+        mirror[li] = ri; mirror[ri] = li
+    tm = rng.choice([-1, -1, -1, 5], n).astype(np.int32)   # a few keypoints already hold a map point with observations
+    q, dq = [], []
+    for _ in range(npts):
+        obs = int(rng.integers(0, 2))
+        for cam in (0, 1):
+            if rng.random() < (0.8 if cam == 0 else 0.6):
+                lo, hi = (0, nleft) if cam == 0 else (nleft, n)
+                if hi <= lo:
+                    continue
+                s = int(rng.integers(lo, hi))
+                octv = int(kp["octave"][s])
+                m = int(rng.integers(0, 3))
+                lv = (octv, -1) if (mode == 0 and m == 0) else (0, octv) if (mode == 0 and m == 1) else (octv - 1, octv + (1 if mode == 0 else 0))
+                dd = d[s].copy(); dd[2] ^= int(rng.integers(0, 4))
+                q.append((kp["x"][s] + rng.normal(0, 4), kp["y"][s] + rng.normal(0, 4), np.float32(15.0) * np.float32(1.2) ** np.float32(octv), -1.0,
+                          (kp["angle"][s] + rng.choice([0, 0, 0, 90, 200]) + rng.normal(0, 3)) % 360, lv[0], lv[1], obs | (cam << 1)))
+                dq.append(dd)
+    return np.array(q, om.PROJ_QUERY_DTYPE), np.array(dq, np.uint8).reshape(-1, 32), kp, d, mirror, tm
+
+
+def _rig_sbp_python(mode, q, dq, kp, d, nleft, mirror, bounds, tm, th_high, ratio, check_ori):
+    """ORBmatcher.cc:48-218 / 1965-2181 with Nleft != -1, written against GetFeaturesInArea(..., bRight) of each camera's own grid."""
+    import oracle_match_bind as om
+    tm = tm.copy(); tm[tm != -1] = -2
+    nm = 0
+    hist = [[] for _ in range(30)]
+    halves = (kp[:nleft], kp[nleft:])
+    for t in range(len(q)):
+        cam = (int(q["has_obs"][t]) >> 1) & 1
+        off = nleft if cam else 0
+        cand = om.features_in_area(halves[cam], bounds, float(q["u"][t]), float(q["v"][t]), float(q["radius"][t]), int(q["min_level"][t]), int(q["max_level"][t]))
+        best = best2 = 256; lv = lv2 = -1; bi = -1
+        for i2 in cand:
+            g = int(i2) + off
+            h = tm[g]
+            if h <= -2 or (h >= 0 and (q["has_obs"][h] & 1)):
+                continue
+            dist = int(np.unpackbits(dq[t] ^ d[g]).sum())
+            if dist < best:
+                best2, best, lv2, lv, bi = best, dist, lv, int(kp["octave"][g]), g
+            elif dist < best2:
+                lv2, best2 = int(kp["octave"][g]), dist
+        if best > th_high:
+            continue
+        if mode == 1:
+            if lv == lv2 and best > np.float32(ratio) * np.float32(best2):
+                continue
+            tm[bi] = t; nm += 1
+            if mirror is not None and mirror[bi] >= 0:
+                tm[mirror[bi]] = t; nm += 1
+        else:
+            tm[bi] = t; nm += 1
+            if check_ori:
+                rot = np.float32(q["angle"][t]) - np.float32(kp["angle"][bi])
+                if rot < 0:
+                    rot = np.float32(rot + np.float32(360.0))
+                b = int(np.round(np.float32(rot * np.float32(1.0 / 30))))
+                hist[0 if b == 30 else b].append(bi)
+    if mode == 0 and check_ori:
+        sizes = [len(h) for h in hist]
+        order = sorted(range(30), key=lambda i: -sizes[i])
+        m1, m2, m3 = order[0], order[1], order[2]
+        keep = {m1}
+        if sizes[m2] >= 0.1 * sizes[m1]:
+            keep.add(m2)
+            if sizes[m3] >= 0.1 * sizes[m1]:
+                keep.add(m3)
+        # ComputeThreeMaxima picks the first of equal sizes; sorted() with a stable key does the same
+        for i in range(30):
+            if i not in keep:
+                for j in hist[i]:
+                    tm[j] = -1; nm -= 1
+    return nm, tm
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_rig_search_by_projection_oracle_against_python(mode):
+    import oracle_match_bind as om
+    rng = np.random.default_rng(500 + mode)
+    bounds = (0.0, 0.0, 512.0, 512.0)
+    tot = 0
+    for nleft, nright, npts in ((120, 100, 90), (300, 340, 260), (40, 0, 30)):
+        q, dq, kp, d, mirror, tm = make_rig_case(rng, nleft, nright, npts, mode)
+        n_ref, tm_ref = om.search_by_projection_rig(mode, q, dq, kp, d, nleft, mirror if mode == 1 else None, bounds, tm, 100, 0.8, True)
+        n_py, tm_py = _rig_sbp_python(mode, q, dq, kp, d, nleft, mirror if mode == 1 else None, bounds, tm, 100, 0.8, True)
+        assert n_ref == n_py
+        np.testing.assert_array_equal(tm_ref, tm_py)
+        tot += n_ref
+        if nright:
+            assert (tm_ref[nleft:] >= 0).sum() > 5           # the right camera's keypoints do get matched
+    assert tot > 150
+
+
+def test_rig_search_by_bow_oracle_against_python():
+    """SearchByBoW on a rig frame: per keyframe feature a best / second best per camera, the right camera's best rides on the left
+    test's TH_LOW branch without a ratio test (ORBmatcher.cc:338-359, 393-425), restated with plain Python containers."""
+    import oracle_match_bind as om
+    rng = np.random.default_rng(77)
+    for nk, nf, nn in ((150, 200, 25), (400, 520, 60)):
+        c = om.make_bow_case(rng, nk, nf, nn)
+        nleft = nf * 3 // 5
+        n_ref, m_ref = om.search_by_bow_rig(c, nleft, 0.7, True)
+        # python model
+        fk, ff = {}, {}
+        for i, v in enumerate(c["nid_k"]):
+            fk.setdefault(int(v), []).append(i)
+        for j, v in enumerate(c["nid_f"]):
+            ff.setdefault(int(v), []).append(j)
+        m = np.full(nf, -1, np.int64); nm = 0; hist = [[] for _ in range(30)]
+        for node in sorted(set(fk) & set(ff)):
+            for ri in fk[node]:
+                if not c["valid"][ri]:
+                    continue
+                b = [256, 256]; b2 = [256, 256]; bi = [-1, -1]
+                for rj in ff[node]:
+                    if m[rj] >= 0:
+                        continue
+                    dist = int(np.unpackbits(c["d_k"][ri] ^ c["d_f"][rj]).sum())
+                    s = 0 if rj < nleft else 1
+                    if dist < b[s]:
+                        b2[s], b[s], bi[s] = b[s], dist, rj
+                    elif dist < b2[s]:
+                        b2[s] = dist
+                if b[0] <= 50:
+                    picks = []
+                    if np.float32(b[0]) < np.float32(0.7) * np.float32(b2[0]):
+                        picks.append(bi[0])
+                    if b[1] <= 50:
+                        picks.append(bi[1])
+                    for j in picks:
+                        m[j] = ri; nm += 1
+                        rot = np.float32(c["kp_k"]["angle"][ri]) - np.float32(c["kp_f"]["angle"][j])
+                        if rot < 0:
+                            rot = np.float32(rot + np.float32(360.0))
+                        bb = int(np.round(np.float32(rot * np.float32(1.0 / 30))))
+                        hist[0 if bb == 30 else bb].append(j)
+        sizes = [len(h) for h in hist]
+        order = sorted(range(30), key=lambda i: -sizes[i])
+        keep = {order[0]}
+        if sizes[order[1]] >= 0.1 * sizes[order[0]]:
+            keep.add(order[1])
+            if sizes[order[2]] >= 0.1 * sizes[order[0]]:
+                keep.add(order[2])
+        for i in range(30):
+            if i not in keep:
+                for j in hist[i]:
+                    m[j] = -1; nm -= 1
+        assert n_ref == nm and n_ref > 20
+        np.testing.assert_array_equal(m_ref, m)
+        assert (m_ref[nleft:] >= 0).sum() > 3
