@@ -58,8 +58,9 @@ def algorithmic_bytes(w, h, n_kp, n_cand, nlevels=8):
     S_lo = S - dims[-1][0] * dims[-1][1]
     S_hi = S - dims[0][0] * dims[0][1]
     return {"pyramid": S_lo + S_hi,                      # pyramid reads + writes
-            "blur_score": 3 * S,                         # FAST read S + blur read S + blur write S
-            "fast_cells": S,                             # (two-kernel layout only) the score map read back once
+            "blur": 2 * S,                               # Gaussian blur: read S, write S
+            "fast_cells": S,                             # FAST: every pyramid pixel read once (scores, the per-cell NMS and the
+                                                         # two-threshold rule stay on chip; the candidate list is n_cand * 4, in "octree")
             "octree": n_cand * 4 * 2 + n_kp * 4,         # candidate keys in, node ids, selected keys out
             "desc": n_kp * (749 + 512) + n_kp * 36,      # orientation patch + BRIEF samples + angle/descriptor out
             "assemble": n_kp * 60 * 2,
@@ -581,11 +582,15 @@ def main():
         fps = world * B * args.steps / dt
         ab = algorithmic_bytes(W, H, n_kp_avg, n_cand_avg)
         # the dominant kernel of the step: largest device time among ALL of its kernels (separate profiled pass).
-        # one stage == one kernel (k_blur_score = SURVEY's "FAST read S" + "blur read+write 2S" done from one staged tile)
-        kern = {"pyramid": "k_resize", "blur_score": "k_blur_score", "fast_cells": "k_fast_cells", "octree": "k_octree",
+        # one stage == one kernel (SURVEY's "FAST read S" = k_fast_cells, "blur read+write 2S" = k_blur)
+        kern = {"pyramid": "k_resize", "blur": "k_blur", "fast_cells": "k_fast_cells", "octree": "k_octree",
                 "desc": "k_orient_desc", "assemble": "k_assemble", "match_bf2nn": "k_bf2nn", "search_init": "k_search_init"}
-        if stage.get("fast_cells", 0.0) <= 0.0:             # fused layout: the FAST cell logic lives in k_blur_score
-            kern.pop("fast_cells")
+
+        def profile_entry(table, name):                     # template instances are listed as "k_fast_cells<3, 24, 2>"
+            for k, v in (table or {}).items():
+                if k == name or k.startswith(name + "<"):
+                    return v
+            return None
         cand = [k for k in kern if k in ab]                  # kernels priced in bytes (the matchers are lane-op work: listed in stage_ms)
         dom = max(cand, key=lambda k: stage.get(k, 0.0))
         launches = {"pyramid": 7}.get(dom, 1)
@@ -595,8 +600,8 @@ def main():
         # (they cannot be read from inside this process); the committed pass is reported when the workload matches.
         valu = None
         pv = load_profile_json(PROFILE_TAG + "_pmc_valu_issue.json") or load_profile_json("r01_pmc_valu_issue.json")
-        if pv and (B, W, H) == (1024, 640, 480) and kern[dom] in pv.get("kernels", {}):
-            kv = pv["kernels"][kern[dom]]
+        if pv and (B, W, H) == (1024, 640, 480) and profile_entry(pv.get("kernels"), kern[dom]):
+            kv = profile_entry(pv.get("kernels"), kern[dom])
             insts = kv.get("SQ_INSTS_VALU_per_step")
             valu = {"valu_issue_busy_frac": kv.get("valu_issue_busy_frac"), "source": "profiles/%s (rocprofv3 --pmc: SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs))" % pv.get("file", "*_pmc_valu_issue.json")}
             if insts:
@@ -606,8 +611,8 @@ def main():
                              "frac_of_issue_slot_roofline": round(floor_ms / stage[dom], 4) if stage[dom] > 0 else None})
         traffic, traffic_src = None, None
         pmc = load_profile_json(PROFILE_TAG + "_pmc_traffic.json") or load_profile_json("r01_pmc_traffic.json")
-        if pmc and (W, H, B, args.nfeatures) == (640, 480, 1024, 1000) and kern[dom] in pmc.get("kernels", {}):
-            traffic = pmc["kernels"][kern[dom]]["hbm_bytes_per_step"]
+        if pmc and (W, H, B, args.nfeatures) == (640, 480, 1024, 1000) and profile_entry(pmc.get("kernels"), kern[dom]):
+            traffic = profile_entry(pmc.get("kernels"), kern[dom])["hbm_bytes_per_step"]
             traffic_src = "profiles/*_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per step)"
         out = {
             "metric": "ORB extract+match frames/sec", "value": round(fps, 1), "unit": "frames/s",

@@ -21,5 +21,5 @@ python3 tools/profile_summary.py trace $(find $out/trace -name "*kernel_trace.cs
 cp $(find $out/trace -name "*kernel_stats.csv") $out/${tag}_kernel_stats.csv
 python3 tools/profile_summary.py traffic $(find $out/fetch -name "*counter_collection.csv") $(find $out/write -name "*counter_collection.csv") $out/${tag}_pmc_traffic.json
 python3 tools/profile_summary.py valu $(find $out/sq -name "*counter_collection.csv") $out/${tag}_pmc_valu_issue.json
-tail -1 $out/trace.log > $out/${tag}_bench_under_trace.json
+grep "^{\"metric\"" $out/trace.log | tail -1 > $out/${tag}_bench_under_trace.json
 echo done
