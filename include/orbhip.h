@@ -537,6 +537,62 @@ double orbhip_ba_batch_gemm_dense_flops(const orbhip_ba_batch *b);   /* same til
 double orbhip_ba_batch_gemm_issued_flops(const orbhip_ba_batch *b);  /* MFMA flops one launch issues (whole row strips a point touches) */
 int orbhip_mfma_f64_peak_tflops(orbhip_ctx *ctx, double *tflops_out);
 
+/* ------------------------------------------------------------------ inertial local BA (LocalInertialBA)
+ * The numerical core of Optimizer::LocalInertialBA(KeyFrame*, bool *pbStopFlag, Map*, bool bLarge, bool bRecInit)
+ *                                            include/Optimizer.h:98, src/Optimizer.cc:4574-5187
+ * i.e. computeActiveErrors + activeRobustChi2, ONE optimize(opt_it) with lambda_init set (:5045-5049; the stop flag is only
+ * handed to the optimizer afterwards and has no effect, :5050-5051), the outlier gates (:5056-5088) and the fail check (:5096),
+ * on `n_windows` independent windows at once (one workgroup each).  Graph: per keyframe a VertexPose (ImuCamPose: body pose
+ * Rwb, twb; the camera pose follows through Tcb) and, when it has IMU states, VertexVelocity / VertexGyroBias / VertexAccBias
+ * (include/G2oTypes.h:131-240); EdgeMono / EdgeStereo to the landmarks (src/G2oTypes.cc:349-482), one EdgeInertial + EdgeGyroRW
+ * + EdgeAccRW per pair of consecutive keyframes (src/G2oTypes.cc:693-800, include/G2oTypes.h:632-700).  The caller builds the
+ * window exactly as :4588-4682 does (temporal keyframes, the fixed previous one, fixed covisible ones) and passes flat arrays.
+ * Pinhole cameras, one camera per keyframe (the KannalaBrandt8 / second-camera EdgeMono(1) branches are not covered).
+ * Up to 32 keyframes with IMU states (480 unknowns; the reference caps the window at 10, 25 when bLarge).
+ * Deviations from the reference's arithmetic, all far below the 1e-4 parity tolerance: the bias-corrected preintegrated deltas
+ * (src/ImuTypes.cc:357-378) and ExpSO3's re-orthonormalisation (src/G2oTypes.cc:991-1008) are evaluated in double instead of
+ * float cv::Mat arithmetic; dense LDL^T instead of Eigen::SimplicialLDLT.  Parity is unpinned (no reference vectors exist). */
+#define ORBHIP_IBA_KF 21        /* keyframe state: Rwb[9] row-major, twb[3], velocity[3], gyro bias[3], accelerometer bias[3] */
+#define ORBHIP_IBA_PREINT 67    /* IMU::Preintegrated: dT, dR[9], dV[3], dP[3], JRg[9], JVg[9], JVa[9], JPg[9], JPa[9], bias bg[3], ba[3] */
+typedef struct {
+    int32_t n_kf;
+    const uint8_t *kf_fixed;        /* setFixed(true): lFixedKeyFrames (:4757-4781) */
+    const uint8_t *kf_imu;          /* pKFi->bImu (:4726-4740); keyframes without it have only the pose vertex */
+    double Rcb[9], tcb[3];          /* mImuCalib.Tcb */
+    double fx, fy, cx, cy, bf;
+    int32_t n_points;
+    int32_t n_edges;                /* grouped by point: edge_point ascending, as :4914-5034 creates them */
+    const int32_t *edge_kf, *edge_point;
+    const double *edge_obs;         /* [3]: kpUn.pt.x, kpUn.pt.y, mvuRight */
+    const uint8_t *edge_stereo;     /* 0 EdgeMono(0), 1 EdgeStereo(0) */
+    const double *edge_inv_sigma2;  /* mvInvLevelSigma2[octave] / uncertainty2 (:4949-4952) */
+    const uint8_t *edge_close;      /* pMP->mTrackDepth < 10 (:5063); may be NULL */
+    int32_t n_inertial;
+    const int32_t *in_kf1, *in_kf2; /* pKFi->mPrevKF, pKFi (both with IMU states) */
+    const double *in_preint;        /* [ORBHIP_IBA_PREINT] */
+    const double *in_info;          /* [81] EdgeInertial information (src/G2oTypes.cc:702-714; x 1e-2 on the edge into the fixed keyframe, :4836) */
+    const double *in_info_g, *in_info_a;   /* [9] each (:4845-4863) */
+    const uint8_t *in_robust;       /* Huber sqrt(16.92) (:4828-4838) */
+} orbhip_iba_window;
+typedef struct {
+    int32_t iterations;             /* 10, or 4 when bLarge */
+    double lambda_init;             /* 1.0, or 1e-2 when bLarge */
+    int32_t large;                  /* bLarge: no fail check */
+    int32_t max_trials;             /* 100 */
+} orbhip_iba_params;
+typedef struct {
+    int32_t iterations_run, lm_trials, n_outliers;
+    int32_t failed;                 /* 2*err < err_end or NaN (:5096-5100): the estimates are NOT written back */
+    double err, err_end;            /* activeRobustChi2 before / after */
+} orbhip_iba_stats;
+void orbhip_iba_default_params(orbhip_iba_params *p, int large);
+/* Host pointers.  kf_state_inout[w] = double[n_kf * ORBHIP_IBA_KF], points_inout[w] = double[n_points * 3] (updated unless
+ * failed), edge_outlier_out[w] = uint8[n_edges] = the observation goes to vToErase (may be NULL), stats_out[n_windows] (may be
+ * NULL).  Synchronous. */
+int orbhip_inertial_ba_solve_batch(orbhip_ctx *ctx, const orbhip_iba_window *windows, int n_windows, const orbhip_iba_params *params,
+                                   double *const *kf_state_inout, double *const *points_inout, uint8_t *const *edge_outlier_out,
+                                   orbhip_iba_stats *stats_out);
+
 /* ------------------------------------------------------------------ pose-only BA
  * Optimizer::PoseOptimization (src/Optimizer.cc:854-1168), batched over frames: per frame one free
  * VertexSE3Expmap and n unary edges -- EdgeSE3ProjectXYZOnlyPose (include/OptimizableTypes.h:31-57) when

@@ -1,0 +1,897 @@
+// iba_kernels.hip -- Optimizer::LocalInertialBA's numerical core on gfx950 (reference src/Optimizer.cc:4574-5187; vertices and
+// edges include/G2oTypes.h + src/G2oTypes.cc: ImuCamPose :25-220, EdgeMono / EdgeStereo :349-482, EdgeInertial :693-800,
+// EdgeGyroRW / EdgeAccRW G2oTypes.h:632-700; bias-corrected preintegration src/ImuTypes.cc:351-378; g2o Levenberg-Marquardt
+// with the landmark Schur complement as in ba_kernels.hip).
+//
+// Shape of the problem: <= 25 keyframes with 15 unknowns each (pose 6, velocity 3, gyro bias 3, accelerometer bias 3), up to 200
+// fixed keyframes, a few thousand landmarks, a chain of <= 25 inertial edges.  The reduced system is at most 375 x 375 and every
+// LM trial is a short dependent chain (errors -> Schur -> LDL^T -> update -> errors), so ONE workgroup of 1024 threads owns a
+// window for the whole optimisation: no host round trips, no inter-workgroup synchronisation, all LM decisions taken redundantly
+// by every thread from block-uniform sums.  A batch of windows is a grid of such workgroups (256 CUs = 256 windows in flight).
+// Every sum has a fixed order (per-thread sequential, DPP tree inside a wave, waves in index order): results are deterministic.
+//
+// Scratch (Jacobian blocks W, H, S ...) lives in global memory and stays L2-resident (a window's working set is < 4 MB); the
+// LDL^T panel is the only LDS user (ba_ldlt.h).
+#include "orb_internal.h"
+#include "wave_dpp.h"
+#include "ba_ldlt.h"
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <vector>
+
+hipStream_t orbhip_ctx_stream_internal(orbhip_ctx *c);
+int orbhip_ctx_device_internal(orbhip_ctx *c);
+void *orbhip_ctx_scratch_internal(orbhip_ctx *c, size_t bytes);
+void orbhip_set_last_error_internal(const char *msg);
+
+#define IBA_KF ORBHIP_IBA_KF
+#define IBA_PRE ORBHIP_IBA_PREINT
+#define IBA_THREADS 1024
+#define IBA_WAVES (IBA_THREADS / 64)
+enum { K_R = 0, K_T = 9, K_V = 12, K_BG = 15, K_BA = 18 };
+enum { P_DT = 0, P_DR = 1, P_DV = 10, P_DP = 13, P_JRG = 16, P_JVG = 25, P_JVA = 34, P_JPG = 43, P_JPA = 52, P_BG = 61, P_BA = 64 };
+
+struct IbaWin {
+    int n_kf, L, E, M, n, nfree, ncolors, npairs;
+    int kf_off, pt_off, e_off, m_off, x_off, free_off, ptstart_off, kfstart_off, kfe_off, pairstart_off;
+    long long pent_off, h_off;
+    double Rcb[9], tcb[3], fx, fy, cx, cy, bf;
+};
+
+struct IbaArgs {
+    const IbaWin *win;
+    const int *kf_xoff;                 // [sumKF] first unknown of the keyframe's block, -1 = fixed
+    const uint8_t *kf_imu;
+    const int *free_kf;                 // [sumFree] keyframe of free block f
+    const int *edge_kf, *edge_point;    // [sumE] window-local indices
+    const double *edge_obs, *edge_is2;
+    const uint8_t *edge_stereo, *edge_close;
+    const int *pt_start;                // per window L + 1 entries
+    const int *kf_start, *kf_edges;     // per window nfree + 1 entries; the edges of every free keyframe
+    const int *pair_start; const int2 *pair_ent;   // per window npairs + 1; {edge of block i, edge of block j} of every point both see
+    const int *in_kf1, *in_kf2, *in_color; const uint8_t *in_robust;
+    const double *in_pre, *in_info, *in_info_g, *in_info_a;
+    double *kfs, *cam, *pts;            // estimates, two buffers each: [2][sumKF][21], [2][sumKF][12] (Rcw, tcw), [2][sumL][3]
+    long long kfs_stride, cam_stride, pts_stride;
+    double *err, *chi2, *W, *Hll, *bl, *Dinv, *db, *xl;
+    double *ierr, *ichi2, *Jb, *OJ, *Oe;
+    double *H, *S, *b, *bs, *x;
+    uint8_t *outlier;
+    orbhip_iba_stats *stats;
+    int iterations, max_trials, large, max_n;
+    double lambda_init;
+};
+
+// ------------------------------------------------------------------ small dense helpers (row-major 3x3)
+namespace {
+__device__ __forceinline__ void mm3(const double *A, const double *B, double *C)
+{
+    double t[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) t[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+#pragma unroll
+    for (int i = 0; i < 9; i++) C[i] = t[i];
+}
+__device__ __forceinline__ void mtm3(const double *A, const double *B, double *C)     // A^T B
+{
+    double t[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) t[3 * i + j] = A[i] * B[j] + A[3 + i] * B[3 + j] + A[6 + i] * B[6 + j];
+#pragma unroll
+    for (int i = 0; i < 9; i++) C[i] = t[i];
+}
+__device__ __forceinline__ void mv3(const double *A, const double *v, double *o)
+{
+    const double a = A[0] * v[0] + A[1] * v[1] + A[2] * v[2], b = A[3] * v[0] + A[4] * v[1] + A[5] * v[2], c = A[6] * v[0] + A[7] * v[1] + A[8] * v[2];
+    o[0] = a; o[1] = b; o[2] = c;
+}
+__device__ __forceinline__ void mtv3(const double *A, const double *v, double *o)     // A^T v
+{
+    const double a = A[0] * v[0] + A[3] * v[1] + A[6] * v[2], b = A[1] * v[0] + A[4] * v[1] + A[7] * v[2], c = A[2] * v[0] + A[5] * v[1] + A[8] * v[2];
+    o[0] = a; o[1] = b; o[2] = c;
+}
+__device__ __forceinline__ void skew3(const double *w, double *W)
+{
+    W[0] = 0; W[1] = -w[2]; W[2] = w[1]; W[3] = w[2]; W[4] = 0; W[5] = -w[0]; W[6] = -w[1]; W[7] = w[0]; W[8] = 0;
+}
+__device__ __forceinline__ void inv3(const double *A, double *I)
+{
+    const double c0 = A[4] * A[8] - A[5] * A[7], c1 = A[5] * A[6] - A[3] * A[8], c2 = A[3] * A[7] - A[4] * A[6];
+    const double id = 1.0 / (A[0] * c0 + A[1] * c1 + A[2] * c2);
+    I[0] = c0 * id; I[1] = (A[2] * A[7] - A[1] * A[8]) * id; I[2] = (A[1] * A[5] - A[2] * A[4]) * id;
+    I[3] = c1 * id; I[4] = (A[0] * A[8] - A[2] * A[6]) * id; I[5] = (A[2] * A[3] - A[0] * A[5]) * id;
+    I[6] = c2 * id; I[7] = (A[1] * A[6] - A[0] * A[7]) * id; I[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+}
+// nearest rotation (IMU::NormalizeRotation, ImuTypes.cc:30-36, takes U V^T of an SVD): two Newton polar steps
+__device__ __forceinline__ void normalize_rotation(double *R)
+{
+    for (int it = 0; it < 2; it++) {
+        double I[9];
+        inv3(R, I);
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) R[3 * i + j] = 0.5 * (R[3 * i + j] + I[3 * j + i]);
+    }
+}
+__device__ __forceinline__ void rodrigues(const double *w, double a, double b, double *R)     // I + a W + b W W
+{
+    double W[9], W2[9];
+    skew3(w, W); mm3(W, W, W2);
+#pragma unroll
+    for (int i = 0; i < 9; i++) R[i] = a * W[i] + b * W2[i];
+    R[0] += 1; R[4] += 1; R[8] += 1;
+}
+__device__ void exp_so3(const double *w, double *R, double eps, bool normalize)     // G2oTypes.cc:991-1008 (1e-5, normalised) / ImuTypes.cc:48-60 (1e-4)
+{
+    const double d2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], d = sqrt(d2);
+    if (d < eps) rodrigues(w, 1.0, 0.5, R);
+    else rodrigues(w, sin(d) / d, (1.0 - cos(d)) / d2, R);
+    if (normalize) normalize_rotation(R);
+}
+__device__ void log_so3(const double *R, double *w)     // G2oTypes.cc:1010-1025
+{
+    const double tr = R[0] + R[4] + R[8];
+    w[0] = (R[7] - R[5]) / 2; w[1] = (R[2] - R[6]) / 2; w[2] = (R[3] - R[1]) / 2;
+    const double costheta = (tr - 1.0) * 0.5;
+    if (costheta > 1 || costheta < -1) return;
+    const double theta = acos(costheta), s = sin(theta);
+    if (fabs(s) < 1e-5) return;
+    for (int i = 0; i < 3; i++) w[i] = theta * w[i] / s;
+}
+__device__ void inv_right_jac(const double *v, double *J)     // G2oTypes.cc:1032-1044
+{
+    const double d2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2], d = sqrt(d2);
+    if (d < 1e-5) { for (int i = 0; i < 9; i++) J[i] = (i % 4 == 0) ? 1.0 : 0.0; return; }
+    rodrigues(v, 0.5, 1.0 / d2 - (1.0 + cos(d)) / (2.0 * d * sin(d)), J);
+}
+__device__ void right_jac(const double *v, double *J)         // G2oTypes.cc:1046-1061
+{
+    const double d2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2], d = sqrt(d2);
+    if (d < 1e-5) { for (int i = 0; i < 9; i++) J[i] = (i % 4 == 0) ? 1.0 : 0.0; return; }
+    rodrigues(v, -(1.0 - cos(d)) / d2, (d - sin(d)) / (d2 * d), J);
+}
+__device__ __forceinline__ void huber(double e, double delta, double dsqr, double &rho0, double &rho1)
+{
+    if (e <= dsqr) { rho0 = e; rho1 = 1.0; }
+    else { const double s = sqrt(e); rho0 = 2 * s * delta - dsqr; rho1 = delta / s; }
+}
+
+// block-uniform sum: per-thread values -> DPP tree inside each wave -> the 16 wave sums added in index order by every thread
+__device__ __forceinline__ double block_sum(double v, double *red)
+{
+    v = wave_sum_f64_dpp(v);
+    __syncthreads();                                         // red may still be read by the previous call
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0;
+#pragma unroll
+    for (int w = 0; w < IBA_WAVES; w++) s += red[w];
+    return s;
+}
+
+// Rcw = Rcb Rbw, tcw = Rcb tbw + tcb (ImuCamPose::Update, G2oTypes.cc:212-219)
+__device__ void cam_pose(const IbaWin &W, const double *s, double *c)
+{
+    double Rbw[9], tbw[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) Rbw[3 * i + j] = s[K_R + 3 * j + i];
+    mv3(Rbw, s + K_T, tbw);
+    for (int i = 0; i < 3; i++) tbw[i] = -tbw[i];
+    double R[9], t[3];
+    mm3(W.Rcb, Rbw, R);
+    mv3(W.Rcb, tbw, t);
+    for (int i = 0; i < 9; i++) c[i] = R[i];
+    for (int i = 0; i < 3; i++) c[9 + i] = t[i] + W.tcb[i];
+}
+
+// EdgeMono / EdgeStereo::computeError (G2oTypes.h:350-355, G2oTypes.cc:170-185)
+__device__ __forceinline__ void visual_error(const IbaWin &W, const double *c, const double *X, const double *obs, int stereo, double *er, double *Xc)
+{
+    mv3(c, X, Xc);
+    Xc[0] += c[9]; Xc[1] += c[10]; Xc[2] += c[11];
+    const double u = W.fx * Xc[0] / Xc[2] + W.cx, v = W.fy * Xc[1] / Xc[2] + W.cy;
+    er[0] = obs[0] - u; er[1] = obs[1] - v;
+    er[2] = stereo ? obs[2] - (u - W.bf * (1 / Xc[2])) : 0.0;
+}
+
+// linearizeOplus (G2oTypes.cc:349-373, :397-423): Jx [3][3], Jp [3][6]; row 2 zero when mono
+__device__ void visual_jac(const IbaWin &W, const double *c, const double *Xc, int stereo, double *Jx, double *Jp)
+{
+    const double iz = Xc[2], iz2 = Xc[2] * Xc[2];
+    double pj[9] = {W.fx / iz, 0, -W.fx * Xc[0] / iz2, 0, W.fy / iz, -W.fy * Xc[1] / iz2, 0, 0, 0};
+    if (stereo) { pj[6] = pj[0]; pj[7] = pj[1]; pj[8] = pj[2] + W.bf * (1.0 / iz2); }
+#pragma unroll
+    for (int d = 0; d < 3; d++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) Jx[3 * d + j] = -(pj[3 * d] * c[j] + pj[3 * d + 1] * c[3 + j] + pj[3 * d + 2] * c[6 + j]);
+    double Xb[3];
+    const double d0[3] = {Xc[0] - W.tcb[0], Xc[1] - W.tcb[1], Xc[2] - W.tcb[2]};
+    mtv3(W.Rcb, d0, Xb);
+    double PR[9];
+    mm3(pj, W.Rcb, PR);
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        const double p0 = PR[3 * d], p1 = PR[3 * d + 1], p2 = PR[3 * d + 2];
+        Jp[6 * d + 0] = p1 * -Xb[2] + p2 * Xb[1];            // SE3deriv columns: (0,-z,y) (z,0,-x) (-y,x,0) | I
+        Jp[6 * d + 1] = p0 * Xb[2] + p2 * -Xb[0];
+        Jp[6 * d + 2] = p0 * -Xb[1] + p1 * Xb[0];
+        Jp[6 * d + 3] = p0; Jp[6 * d + 4] = p1; Jp[6 * d + 5] = p2;
+    }
+}
+
+// EdgeInertial::computeError (+ linearizeOplus into J [9][24] when J != nullptr), G2oTypes.cc:720-800
+__device__ __noinline__ void inertial_edge(const double *s1, const double *s2, const double *pi, double *err, double *J)
+{
+    const double dt = pi[P_DT];
+    const double g[3] = {0, 0, -(double)9.81f};
+    double dbg[3], dba[3], w[3], E[9], dR[9], dV[3], dP[3], t[3];
+    for (int i = 0; i < 3; i++) { dbg[i] = s1[K_BG + i] - pi[P_BG + i]; dba[i] = s1[K_BA + i] - pi[P_BA + i]; }
+    mv3(pi + P_JRG, dbg, w);
+    exp_so3(w, E, 1e-4, false);
+    mm3(pi + P_DR, E, dR);
+    normalize_rotation(dR);
+    mv3(pi + P_JVG, dbg, dV); mv3(pi + P_JVA, dba, t);
+    for (int i = 0; i < 3; i++) dV[i] = pi[P_DV + i] + dV[i] + t[i];
+    mv3(pi + P_JPG, dbg, dP); mv3(pi + P_JPA, dba, t);
+    for (int i = 0; i < 3; i++) dP[i] = pi[P_DP + i] + dP[i] + t[i];
+    double R12[9], eR[9], er[3], a[3], b[3], va[3], vb[3];
+    mtm3(s1 + K_R, s2 + K_R, R12);
+    mtm3(dR, R12, eR);
+    log_so3(eR, er);
+    for (int i = 0; i < 3; i++) {
+        a[i] = s2[K_V + i] - s1[K_V + i] - g[i] * dt;
+        b[i] = s2[K_T + i] - s1[K_T + i] - s1[K_V + i] * dt - g[i] * dt * dt / 2;
+    }
+    mtv3(s1 + K_R, a, va); mtv3(s1 + K_R, b, vb);
+    for (int i = 0; i < 3; i++) { err[i] = er[i]; err[3 + i] = va[i] - dV[i]; err[6 + i] = vb[i] - dP[i]; }
+    if (!J) return;
+    for (int i = 0; i < 216; i++) J[i] = 0.0;
+    double invJr[9], T[9], S[9];
+    inv_right_jac(er, invJr);
+#define SETB(r0, c0, M, sgn) for (int i_ = 0; i_ < 3; i_++) for (int j_ = 0; j_ < 3; j_++) J[24 * ((r0) + i_) + (c0) + j_] = (sgn) * (M)[3 * i_ + j_]
+    mtm3(s2 + K_R, s1 + K_R, T); mm3(invJr, T, T); SETB(0, 0, T, -1.0);
+    skew3(va, S); SETB(3, 0, S, 1.0);
+    skew3(vb, S); SETB(6, 0, S, 1.0);
+    const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    SETB(6, 3, I3, -1.0);
+    double Rbw1[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rbw1[3 * i + j] = s1[K_R + 3 * j + i];
+    SETB(3, 6, Rbw1, -1.0);
+    SETB(6, 6, Rbw1, -dt);
+    double RJ[9], eRt[9];
+    right_jac(w, RJ);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) eRt[3 * i + j] = eR[3 * j + i];
+    mm3(invJr, eRt, T); mm3(T, RJ, T); mm3(T, pi + P_JRG, T); SETB(0, 9, T, -1.0);
+    SETB(3, 9, pi + P_JVG, -1.0);
+    SETB(6, 9, pi + P_JPG, -1.0);
+    SETB(3, 12, pi + P_JVA, -1.0);
+    SETB(6, 12, pi + P_JPA, -1.0);
+    SETB(0, 15, invJr, 1.0);
+    SETB(6, 18, R12, 1.0);
+    SETB(3, 21, Rbw1, 1.0);
+#undef SETB
+}
+
+struct IbaCtx {            // per-window views (all threads hold the same values)
+    const IbaWin *W;
+    const IbaArgs *A;
+    double delta_m, dsqr_m, delta_s, dsqr_s, delta_i, dsqr_i;
+};
+
+// computeActiveErrors + activeRobustChi2 at estimate buffer `buf`; the per-edge errors / chi2 stay in global memory
+__device__ __noinline__ double iba_errors(const IbaCtx &C, int buf, double *red)
+{
+    const IbaWin &W = *C.W; const IbaArgs &A = *C.A;
+    const int tid = threadIdx.x;
+    const double *cam = A.cam + buf * A.cam_stride + (size_t)W.kf_off * 12;
+    const double *pts = A.pts + buf * A.pts_stride + (size_t)W.pt_off * 3;
+    const double *kfs = A.kfs + buf * A.kfs_stride + (size_t)W.kf_off * IBA_KF;
+    double part = 0.0;
+    for (int e = tid; e < W.E; e += IBA_THREADS) {
+        const size_t ge = (size_t)W.e_off + e;
+        const int st = A.edge_stereo[ge];
+        double er[3], Xc[3];
+        visual_error(W, cam + 12 * A.edge_kf[ge], pts + 3 * A.edge_point[ge], A.edge_obs + 3 * ge, st, er, Xc);
+        const double chi = (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * A.edge_is2[ge];
+        A.err[3 * ge] = er[0]; A.err[3 * ge + 1] = er[1]; A.err[3 * ge + 2] = er[2];
+        A.chi2[ge] = chi;
+        double r0, r1;
+        huber(chi, st ? C.delta_s : C.delta_m, st ? C.dsqr_s : C.dsqr_m, r0, r1);
+        part += r0;
+    }
+    if (tid < W.M) {
+        const size_t gm = (size_t)W.m_off + tid;
+        const double *s1 = kfs + IBA_KF * A.in_kf1[gm], *s2 = kfs + IBA_KF * A.in_kf2[gm];
+        double er[15];
+        inertial_edge(s1, s2, A.in_pre + IBA_PRE * gm, er, nullptr);
+        for (int i = 0; i < 3; i++) { er[9 + i] = s2[K_BG + i] - s1[K_BG + i]; er[12 + i] = s2[K_BA + i] - s1[K_BA + i]; }
+        const double *I9 = A.in_info + 81 * gm, *Ig = A.in_info_g + 9 * gm, *Ia = A.in_info_a + 9 * gm;
+        double c9 = 0, cg = 0, ca = 0;
+        for (int i = 0; i < 9; i++) { double r = 0; for (int j = 0; j < 9; j++) r += I9[9 * i + j] * er[j]; c9 += er[i] * r; }
+        for (int i = 0; i < 3; i++) {
+            double r = 0, q = 0;
+            for (int j = 0; j < 3; j++) { r += Ig[3 * i + j] * er[9 + j]; q += Ia[3 * i + j] * er[12 + j]; }
+            cg += er[9 + i] * r; ca += er[12 + i] * q;
+        }
+        for (int i = 0; i < 15; i++) A.ierr[15 * gm + i] = er[i];
+        A.ichi2[3 * gm] = c9; A.ichi2[3 * gm + 1] = cg; A.ichi2[3 * gm + 2] = ca;
+        double r0 = c9, r1;
+        if (A.in_robust[gm]) huber(c9, C.delta_i, C.dsqr_i, r0, r1);
+        part += r0 + cg + ca;
+    }
+    return block_sum(part, red);
+}
+
+// buildSystem at buffer `buf` from the stored errors: Hll, bl, W per edge; H (dense, lower + upper) and b of the keyframe unknowns
+__device__ __noinline__ void iba_build(const IbaCtx &C, int buf)
+{
+    const IbaWin &W = *C.W; const IbaArgs &A = *C.A;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = W.n;
+    const double *cam = A.cam + buf * A.cam_stride + (size_t)W.kf_off * 12;
+    const double *pts = A.pts + buf * A.pts_stride + (size_t)W.pt_off * 3;
+    const double *kfs = A.kfs + buf * A.kfs_stride + (size_t)W.kf_off * IBA_KF;
+    double *H = A.H + W.h_off, *b = A.b + W.x_off;
+    for (int i = tid; i < n * n; i += IBA_THREADS) H[i] = 0.0;
+    for (int i = tid; i < n; i += IBA_THREADS) b[i] = 0.0;
+    // (1) landmarks: Hll, bl and the pose-landmark blocks
+    const int *pt_start = A.pt_start + W.ptstart_off;
+    for (int l = tid; l < W.L; l += IBA_THREADS) {
+        double h[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
+        const double *X = pts + 3 * l;
+        for (int e = pt_start[l]; e < pt_start[l + 1]; e++) {
+            const size_t ge = (size_t)W.e_off + e;
+            const int st = A.edge_stereo[ge], k = A.edge_kf[ge];
+            const double *c = cam + 12 * k;
+            double Xc[3], Jx[9], Jp[18], r0, r1;
+            mv3(c, X, Xc); Xc[0] += c[9]; Xc[1] += c[10]; Xc[2] += c[11];
+            visual_jac(W, c, Xc, st, Jx, Jp);
+            huber(A.chi2[ge], st ? C.delta_s : C.delta_m, st ? C.dsqr_s : C.dsqr_m, r0, r1);
+            const double w = r1 * A.edge_is2[ge];
+            const double e0 = A.err[3 * ge], e1 = A.err[3 * ge + 1], e2 = A.err[3 * ge + 2];
+            const int D = st ? 3 : 2;
+            const double es[3] = {e0, e1, e2};
+            for (int a = 0; a < 3; a++) {
+                double s = 0;
+                for (int d = 0; d < D; d++) s += Jx[3 * d + a] * (-w * es[d]);
+                bl[a] += s;
+            }
+            int q = 0;
+            for (int a = 0; a < 3; a++)
+                for (int cc = 0; cc <= a; cc++, q++) {
+                    double s = 0;
+                    for (int d = 0; d < D; d++) s += Jx[3 * d + a] * w * Jx[3 * d + cc];
+                    h[q] += s;
+                }
+            if (A.kf_xoff[W.kf_off + k] >= 0) {
+                double *Wd = A.W + 18 * ge;
+                for (int a = 0; a < 6; a++)
+                    for (int cc = 0; cc < 3; cc++) {
+                        double s = 0;
+                        for (int d = 0; d < D; d++) s += Jp[6 * d + a] * w * Jx[3 * d + cc];
+                        Wd[3 * a + cc] = s;
+                    }
+            }
+        }
+        double *Hl = A.Hll + 6 * ((size_t)W.pt_off + l), *Bl = A.bl + 3 * ((size_t)W.pt_off + l);
+        for (int i = 0; i < 6; i++) Hl[i] = h[i];
+        for (int i = 0; i < 3; i++) Bl[i] = bl[i];
+    }
+    // (2) inertial edges: Jacobians, Omega-weighted Jacobians and errors into scratch
+    if (tid < W.M) {
+        const size_t gm = (size_t)W.m_off + tid;
+        double er[9];
+        inertial_edge(kfs + IBA_KF * A.in_kf1[gm], kfs + IBA_KF * A.in_kf2[gm], A.in_pre + IBA_PRE * gm, er, A.Jb + 216 * gm);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < W.M * 216; idx += IBA_THREADS) {
+        const int m = idx / 216, r = idx - m * 216, i = r / 24, c = r - i * 24;
+        const size_t gm = (size_t)W.m_off + m;
+        double r0, r1 = 1.0;
+        if (A.in_robust[gm]) huber(A.ichi2[3 * gm], C.delta_i, C.dsqr_i, r0, r1);
+        const double *I9 = A.in_info + 81 * gm + 9 * i, *J = A.Jb + 216 * gm + c;
+        double s = 0;
+        for (int k = 0; k < 9; k++) s += r1 * I9[k] * J[24 * k];
+        A.OJ[216 * gm + r] = s;
+        if (c == 0) {
+            const double *er = A.ierr + 15 * gm;
+            double q = 0;
+            for (int k = 0; k < 9; k++) q += I9[k] * er[k];
+            A.Oe[15 * gm + i] = -r1 * q;
+        }
+    }
+    // (3) keyframe pose blocks from the visual edges: one wave per free keyframe, lanes over its edges
+    const int *kf_start = A.kf_start + W.kfstart_off, *kf_edges = A.kf_edges + W.kfe_off;
+    for (int f = wave; f < W.nfree; f += IBA_WAVES) {
+        const int k = A.free_kf[W.free_off + f], o = A.kf_xoff[W.kf_off + k];
+        const double *c = cam + 12 * k;
+        double acc[27];
+#pragma unroll
+        for (int i = 0; i < 27; i++) acc[i] = 0.0;
+        for (int j = kf_start[f] + lane; j < kf_start[f + 1]; j += 64) {
+            const int e = kf_edges[j];
+            const size_t ge = (size_t)W.e_off + e;
+            const int st = A.edge_stereo[ge];
+            const double *X = pts + 3 * A.edge_point[ge];
+            double Xc[3], Jx[9], Jp[18], r0, r1;
+            mv3(c, X, Xc); Xc[0] += c[9]; Xc[1] += c[10]; Xc[2] += c[11];
+            visual_jac(W, c, Xc, st, Jx, Jp);
+            huber(A.chi2[ge], st ? C.delta_s : C.delta_m, st ? C.dsqr_s : C.dsqr_m, r0, r1);
+            const double w = r1 * A.edge_is2[ge];
+            const double es[3] = {A.err[3 * ge], A.err[3 * ge + 1], st ? A.err[3 * ge + 2] : 0.0};
+            int q = 0;
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+#pragma unroll
+                for (int cc = 0; cc <= a; cc++, q++)
+                    acc[q] += Jp[a] * w * Jp[cc] + Jp[6 + a] * w * Jp[6 + cc] + Jp[12 + a] * w * Jp[12 + cc];      // row 2 of Jp is zero when mono
+                acc[21 + a] += Jp[a] * (-w * es[0]) + Jp[6 + a] * (-w * es[1]) + Jp[12 + a] * (-w * es[2]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 27; i++) acc[i] = wave_sum_f64_dpp(acc[i]);
+        if (lane == 0) {
+            int q = 0;
+            for (int a = 0; a < 6; a++) {
+                for (int cc = 0; cc <= a; cc++, q++) { H[(size_t)(o + a) * n + o + cc] = acc[q]; H[(size_t)(o + cc) * n + o + a] = acc[q]; }
+                b[o + a] = acc[21 + a];
+            }
+        }
+    }
+    __syncthreads();
+    // (4) inertial + random-walk edges into H / b: edges of one colour share no keyframe, colours run one after the other
+    const int *kf_xoff = A.kf_xoff + W.kf_off;
+    for (int col = 0; col < W.ncolors; col++) {
+        for (int m = wave; m < W.M; m += IBA_WAVES) {
+            const size_t gm = (size_t)W.m_off + m;
+            if (A.in_color[gm] != col) continue;
+            const int o1 = kf_xoff[A.in_kf1[gm]], o2 = kf_xoff[A.in_kf2[gm]];
+            const double *J = A.Jb + 216 * gm, *OJ = A.OJ + 216 * gm, *Oe = A.Oe + 15 * gm;
+            for (int idx = lane; idx < 576; idx += 64) {
+                const int a = idx / 24, c = idx - a * 24;
+                const int ga = a < 15 ? (o1 < 0 ? -1 : o1 + a) : (o2 < 0 ? -1 : o2 + a - 15);
+                const int gc = c < 15 ? (o1 < 0 ? -1 : o1 + c) : (o2 < 0 ? -1 : o2 + c - 15);
+                if (ga < 0 || gc < 0) continue;
+                double s = 0;
+                for (int k = 0; k < 9; k++) s += J[24 * k + a] * OJ[24 * k + c];
+                H[(size_t)ga * n + gc] += s;
+            }
+            if (lane < 24) {
+                const int a = lane, ga = a < 15 ? (o1 < 0 ? -1 : o1 + a) : (o2 < 0 ? -1 : o2 + a - 15);
+                if (ga >= 0) {
+                    double s = 0;
+                    for (int k = 0; k < 9; k++) s += J[24 * k + a] * Oe[k];
+                    b[ga] += s;
+                }
+            }
+            // EdgeGyroRW / EdgeAccRW: J = [-I, I] (G2oTypes.h:648-651): lanes 32..49 = 2 edges x 3 x 3
+            if (lane >= 32 && lane < 50) {
+                const int t = lane - 32, which = t / 9, r = (t % 9) / 3, c = t % 3;
+                const double *If = (which ? A.in_info_a : A.in_info_g) + 9 * gm;
+                const int base = which ? 12 : 9;
+                const double v = If[3 * r + c];
+                if (o1 >= 0) H[(size_t)(o1 + base + r) * n + o1 + base + c] += v;
+                if (o2 >= 0) H[(size_t)(o2 + base + r) * n + o2 + base + c] += v;
+                if (o1 >= 0 && o2 >= 0) { H[(size_t)(o1 + base + r) * n + o2 + base + c] -= v; H[(size_t)(o2 + base + r) * n + o1 + base + c] -= v; }
+            }
+            if (lane >= 50 && lane < 56) {
+                const int t = lane - 50, which = t / 3, r = t % 3;
+                const double *If = (which ? A.in_info_a : A.in_info_g) + 9 * gm, *er = A.ierr + 15 * gm + (which ? 12 : 9);
+                const int base = which ? 12 : 9;
+                const double v = If[3 * r] * er[0] + If[3 * r + 1] * er[1] + If[3 * r + 2] * er[2];
+                if (o1 >= 0) b[o1 + base + r] += v;              // J1 = -I: b1 += -J1^T (-Omega e) ... = +Omega e
+                if (o2 >= 0) b[o2 + base + r] -= v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// One LM trial: (Hll + lambda)^-1, S = H + lambda I - sum W D^-1 W^T, LDL^T, landmark back-substitution, oplus into buffer buf^1.
+// Returns (block-uniform) ok of the linear solve; *scale_out = computeScale's sum (levenberg.cpp:187-194).
+__device__ __noinline__ bool iba_trial(const IbaCtx &C, int buf, double lambda, double *lds, double *red, double *scale_out)
+{
+    const IbaWin &W = *C.W; const IbaArgs &A = *C.A;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = W.n;
+    double *H = A.H + W.h_off, *S = A.S + W.h_off, *b = A.b + W.x_off, *bs = A.bs + W.x_off, *x = A.x + W.x_off;
+    const int *pt_start = A.pt_start + W.ptstart_off;
+    for (int l = tid; l < W.L; l += IBA_THREADS) {
+        const size_t gl = (size_t)W.pt_off + l;
+        double *Di = A.Dinv + 6 * gl, *db = A.db + 3 * gl;
+        if (pt_start[l + 1] == pt_start[l]) { for (int i = 0; i < 6; i++) Di[i] = 0.0; for (int i = 0; i < 3; i++) db[i] = 0.0; continue; }
+        const double *h = A.Hll + 6 * gl, *bl = A.bl + 3 * gl;
+        const double D[9] = {h[0] + lambda, h[1], h[3], h[1], h[2] + lambda, h[4], h[3], h[4], h[5] + lambda};
+        double I[9];
+        inv3(D, I);
+        Di[0] = I[0]; Di[1] = I[3]; Di[2] = I[4]; Di[3] = I[6]; Di[4] = I[7]; Di[5] = I[8];       // lower triangle of the inverse
+        mv3(I, bl, db);
+    }
+    for (int i = tid; i < n * n; i += IBA_THREADS) { const int r = i / n, c = i - r * n; S[i] = H[i] + (r == c ? lambda : 0.0); }
+    for (int i = tid; i < n; i += IBA_THREADS) bs[i] = b[i];
+    __syncthreads();
+    // Schur complement, one wave per pair of free keyframes (i <= j): block (j, i) of the lower triangle
+    const int *pair_start = A.pair_start + W.pairstart_off;
+    const int2 *pair_ent = A.pair_ent + W.pent_off;
+    const int nf = W.nfree;
+    for (int p = wave; p < W.npairs; p += IBA_WAVES) {
+        // p -> (i, j), row-major over the upper triangle
+        int i = 0, rem = p;
+        while (rem >= nf - i) { rem -= nf - i; i++; }
+        const int j = i + rem;
+        const int oi = A.kf_xoff[W.kf_off + A.free_kf[W.free_off + i]], oj = A.kf_xoff[W.kf_off + A.free_kf[W.free_off + j]];
+        double acc[42];
+#pragma unroll
+        for (int q = 0; q < 42; q++) acc[q] = 0.0;
+        for (int t = pair_start[p] + lane; t < pair_start[p + 1]; t += 64) {
+            const int2 en = pair_ent[t];
+            const size_t gi = (size_t)W.e_off + en.x, gj = (size_t)W.e_off + en.y;
+            const size_t gl = (size_t)W.pt_off + A.edge_point[gi];
+            const double *Wi = A.W + 18 * gi, *Wj = A.W + 18 * gj, *Di = A.Dinv + 6 * gl;
+            const double d00 = Di[0], d10 = Di[1], d11 = Di[2], d20 = Di[3], d21 = Di[4], d22 = Di[5];
+            double wi[18];
+#pragma unroll
+            for (int q = 0; q < 18; q++) wi[q] = Wi[q];
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+                const double w0 = Wj[3 * a], w1 = Wj[3 * a + 1], w2 = Wj[3 * a + 2];
+                const double y0 = w0 * d00 + w1 * d10 + w2 * d20, y1 = w0 * d10 + w1 * d11 + w2 * d21, y2 = w0 * d20 + w1 * d21 + w2 * d22;
+#pragma unroll
+                for (int c = 0; c < 6; c++) acc[6 * a + c] += y0 * wi[3 * c] + y1 * wi[3 * c + 1] + y2 * wi[3 * c + 2];
+            }
+            if (i == j) {
+                const double *db = A.db + 3 * gl;
+#pragma unroll
+                for (int a = 0; a < 6; a++) acc[36 + a] += wi[3 * a] * db[0] + wi[3 * a + 1] * db[1] + wi[3 * a + 2] * db[2];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 42; q++) acc[q] = wave_sum_f64_dpp(acc[q]);
+        if (lane == 0) {
+            for (int a = 0; a < 6; a++) {
+                for (int c = 0; c < 6; c++) S[(size_t)(oj + a) * n + oi + c] -= acc[6 * a + c];
+                if (i == j) bs[oi + a] -= acc[36 + a];
+            }
+        }
+    }
+    __syncthreads();
+    const bool ok = n > 0 ? ldlt_solve_wg(S, n, n, bs, x, lds, A.max_n) : true;
+    __syncthreads();
+    const double *cur_pts = A.pts + buf * A.pts_stride + (size_t)W.pt_off * 3;
+    double *new_pts = A.pts + (buf ^ 1) * A.pts_stride + (size_t)W.pt_off * 3;
+    double part = 0.0;
+    for (int l = tid; l < W.L; l += IBA_THREADS) {
+        const size_t gl = (size_t)W.pt_off + l;
+        double *xl = A.xl + 3 * gl;
+        const bool active = pt_start[l + 1] > pt_start[l];
+        if (ok && active) {                                        // block_solver.hpp:461-481 (skipped when the pose solve failed: x stays stale)
+            const double *bl = A.bl + 3 * gl, *Di = A.Dinv + 6 * gl;
+            double cl[3] = {bl[0], bl[1], bl[2]};
+            for (int e = pt_start[l]; e < pt_start[l + 1]; e++) {
+                const size_t ge = (size_t)W.e_off + e;
+                const int o = A.kf_xoff[W.kf_off + A.edge_kf[ge]];
+                if (o < 0) continue;
+                const double *We = A.W + 18 * ge, *xp = x + o;
+                for (int c = 0; c < 3; c++)
+                    for (int a = 0; a < 6; a++) cl[c] -= We[3 * a + c] * xp[a];
+            }
+            xl[0] = Di[0] * cl[0] + Di[1] * cl[1] + Di[3] * cl[2];
+            xl[1] = Di[1] * cl[0] + Di[2] * cl[1] + Di[4] * cl[2];
+            xl[2] = Di[3] * cl[0] + Di[4] * cl[1] + Di[5] * cl[2];
+        }
+        for (int a = 0; a < 3; a++) {
+            const double dx = active ? xl[a] : 0.0;
+            new_pts[3 * l + a] = cur_pts[3 * l + a] + dx;
+            if (active) part += dx * (lambda * dx + A.bl[3 * gl + a]);
+        }
+    }
+    for (int i = tid; i < n; i += IBA_THREADS) part += x[i] * (lambda * x[i] + b[i]);
+    // oplus on the keyframe vertices (ImuCamPose::Update, G2oTypes.cc:192-220; the velocity / bias vertices add)
+    const double *cur_kf = A.kfs + buf * A.kfs_stride + (size_t)W.kf_off * IBA_KF;
+    double *new_kf = A.kfs + (buf ^ 1) * A.kfs_stride + (size_t)W.kf_off * IBA_KF;
+    double *new_cam = A.cam + (buf ^ 1) * A.cam_stride + (size_t)W.kf_off * 12;
+    for (int k = tid; k < W.n_kf; k += IBA_THREADS) {
+        double s[IBA_KF];
+        for (int i = 0; i < IBA_KF; i++) s[i] = cur_kf[IBA_KF * k + i];
+        const int o = A.kf_xoff[W.kf_off + k];
+        if (o >= 0) {
+            const double *dx = x + o;
+            double t[3], E[9];
+            mv3(s + K_R, dx + 3, t);
+            for (int i = 0; i < 3; i++) s[K_T + i] += t[i];
+            exp_so3(dx, E, 1e-5, true);
+            mm3(s + K_R, E, s + K_R);
+            if (A.kf_imu[W.kf_off + k]) for (int i = 0; i < 9; i++) s[K_V + i] += dx[6 + i];
+        }
+        for (int i = 0; i < IBA_KF; i++) new_kf[IBA_KF * k + i] = s[i];
+        cam_pose(W, s, new_cam + 12 * k);
+    }
+    *scale_out = block_sum(part, red);        // its barriers also publish the new estimates
+    return ok;
+}
+}  // namespace
+
+__global__ __launch_bounds__(IBA_THREADS) void k_iba_solve(IbaArgs A)
+{
+    extern __shared__ double lds[];
+    __shared__ double red[IBA_WAVES];
+    const IbaWin &W = A.win[blockIdx.x];
+    const int tid = threadIdx.x;
+    IbaCtx C;
+    C.W = &W; C.A = &A;
+    C.delta_m = (double)sqrtf(5.991f); C.dsqr_m = C.delta_m * C.delta_m;        // thHuberMono etc. are floats (Optimizer.cc:4893-4896)
+    C.delta_s = (double)sqrtf(7.815f); C.dsqr_s = C.delta_s * C.delta_s;
+    C.delta_i = sqrt(16.92); C.dsqr_i = C.delta_i * C.delta_i;                  // :4838
+    int cur = 0;
+    {
+        const double *kf0 = A.kfs + (size_t)W.kf_off * IBA_KF;
+        double *cam0 = A.cam + (size_t)W.kf_off * 12;
+        for (int k = tid; k < W.n_kf; k += IBA_THREADS) cam_pose(W, kf0 + IBA_KF * k, cam0 + 12 * k);
+    }
+    __syncthreads();
+    double chi = iba_errors(C, cur, red);                  // computeActiveErrors + activeRobustChi2 (:5046-5047)
+    const double err0 = chi;
+    double lambda = A.lambda_init, ni = 2.0, last_chi = chi;
+    int nbad = 0, trials = 0, its = 0;
+    for (int it = 0; it < A.iterations; it++) {            // SparseOptimizer::optimize -> OptimizationAlgorithmLevenberg::solve
+        if (it > 0) chi = iba_errors(C, cur, red);         // levenberg.cpp:71 (the stored errors may be a rejected trial's)
+        double current_chi = chi;
+        const double ini_chi = chi;
+        iba_build(C, cur);
+        if (it == 0) { lambda = A.lambda_init; ni = 2.0; nbad = 0; }
+        double rho = 0.0;
+        int qmax = 0;
+        do {
+            double scale;
+            const bool ok = iba_trial(C, cur, lambda, lds, red, &scale);
+            double tmp = iba_errors(C, cur ^ 1, red);
+            last_chi = tmp;
+            if (!ok) tmp = DBL_MAX;
+            rho = (current_chi - tmp) / (scale + 1e-3);
+            if (rho > 0 && isfinite(tmp)) {
+                double alpha = 1. - pow(2 * rho - 1, 3);
+                alpha = fmin(alpha, 2. / 3.);
+                lambda *= fmax(1. / 3., alpha); ni = 2.0; current_chi = tmp;
+                cur ^= 1;
+            } else {
+                lambda *= ni; ni *= 2;
+            }
+            qmax++; trials++;
+        } while (rho < 0 && qmax < A.max_trials);
+        its++;
+        if (qmax == A.max_trials || rho == 0) break;
+        if ((ini_chi - current_chi) * 1e3 < ini_chi) nbad++; else nbad = 0;
+        if (nbad >= 3) break;
+    }
+    // outlier gates on the stored chi2, depth of the final estimates (Optimizer.cc:5056-5088)
+    const double *cam = A.cam + cur * A.cam_stride + (size_t)W.kf_off * 12;
+    const double *pts = A.pts + cur * A.pts_stride + (size_t)W.pt_off * 3;
+    double nout = 0.0;
+    for (int e = tid; e < W.E; e += IBA_THREADS) {
+        const size_t ge = (size_t)W.e_off + e;
+        const double c2 = A.chi2[ge];
+        bool out;
+        if (A.edge_stereo[ge]) out = c2 > (double)7.815f;
+        else {
+            const double *c = cam + 12 * A.edge_kf[ge], *X = pts + 3 * A.edge_point[ge];
+            const bool depth_pos = (c[6] * X[0] + c[7] * X[1] + c[8] * X[2] + c[11]) > 0.0;
+            const bool close = A.edge_close[ge] != 0;
+            out = (c2 > (double)5.991f && !close) || (c2 > (double)(1.5f * 5.991f) && close) || !depth_pos;
+        }
+        A.outlier[ge] = out ? 1 : 0;
+        nout += out ? 1.0 : 0.0;
+    }
+    nout = block_sum(nout, red);
+    if (cur == 1) {                                         // results are read from buffer 0
+        double *k0 = A.kfs + (size_t)W.kf_off * IBA_KF, *p0 = A.pts + (size_t)W.pt_off * 3;
+        const double *k1 = k0 + A.kfs_stride, *p1 = p0 + A.pts_stride;
+        for (int i = tid; i < W.n_kf * IBA_KF; i += IBA_THREADS) k0[i] = k1[i];
+        for (int i = tid; i < W.L * 3; i += IBA_THREADS) p0[i] = p1[i];
+    }
+    if (tid == 0) {
+        orbhip_iba_stats &st = A.stats[blockIdx.x];
+        st.iterations_run = its; st.lm_trials = trials; st.n_outliers = (int)nout;
+        st.err = err0; st.err_end = last_chi;
+        const float fe = (float)err0, fl = (float)last_chi;
+        st.failed = ((2 * fe < fl || isnan(fe) || isnan(fl)) && !A.large) ? 1 : 0;        // :5096
+    }
+}
+
+// ------------------------------------------------------------------ host side
+extern "C" void orbhip_iba_default_params(orbhip_iba_params *p, int large)
+{
+    if (!p) return;
+    p->iterations = large ? 4 : 10;
+    p->lambda_init = large ? 1e-2 : 1.0;
+    p->large = large ? 1 : 0;
+    p->max_trials = 100;
+}
+
+namespace {
+struct Blob {                        // host image of the constant device data; offsets are stable, pointers taken after the upload
+    std::vector<uint8_t> bytes;
+    template <typename T> size_t put(const std::vector<T> &v)
+    {
+        size_t off = (bytes.size() + 255) & ~(size_t)255;
+        bytes.resize(off + sizeof(T) * std::max<size_t>(v.size(), 1));
+        if (!v.empty()) memcpy(bytes.data() + off, v.data(), sizeof(T) * v.size());
+        return off;
+    }
+};
+inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+#define ITRY(e) do { if ((e) != hipSuccess) { orbhip_set_last_error_internal(#e); return ORBHIP_E_HIP; } } while (0)
+}  // namespace
+
+extern "C" int orbhip_inertial_ba_solve_batch(orbhip_ctx *ctx, const orbhip_iba_window *wins, int n_windows, const orbhip_iba_params *params,
+                                              double *const *kf_state_inout, double *const *points_inout, uint8_t *const *edge_outlier_out,
+                                              orbhip_iba_stats *stats_out)
+{
+    if (!ctx || n_windows < 0 || (n_windows && (!wins || !kf_state_inout || !points_inout)) || !params) return ORBHIP_E_BADARG;
+    if (n_windows == 0) return ORBHIP_OK;
+    if (params->iterations < 0 || params->max_trials < 1 || !(params->lambda_init > 0)) return ORBHIP_E_BADARG;
+    std::vector<IbaWin> hw(n_windows);
+    std::vector<int> kf_xoff, free_kf, edge_kf, edge_point, pt_start, kf_start, kf_edges, pair_start, in1, in2, in_color;
+    std::vector<int2> pair_ent;
+    std::vector<uint8_t> kf_imu, edge_stereo, edge_close, in_robust;
+    std::vector<double> edge_obs, edge_is2, in_pre, in_info, in_info_g, in_info_a, kfs, pts;
+    size_t sumKF = 0, sumL = 0, sumE = 0, sumM = 0, sumX = 0, sumH = 0;
+    int max_n = 0;
+    for (int w = 0; w < n_windows; w++) {
+        const orbhip_iba_window &g = wins[w];
+        if (g.n_kf <= 0 || g.n_points < 0 || g.n_edges < 0 || g.n_inertial < 0 || !g.kf_fixed || !g.kf_imu || !kf_state_inout[w] ||
+            (g.n_points && !points_inout[w]) ||
+            (g.n_edges && (!g.edge_kf || !g.edge_point || !g.edge_obs || !g.edge_stereo || !g.edge_inv_sigma2)) ||
+            (g.n_inertial && (!g.in_kf1 || !g.in_kf2 || !g.in_preint || !g.in_info || !g.in_info_g || !g.in_info_a || !g.in_robust)))
+            return ORBHIP_E_BADARG;
+        IbaWin &W = hw[w];
+        memset(&W, 0, sizeof(W));
+        W.n_kf = g.n_kf; W.L = g.n_points; W.E = g.n_edges; W.M = g.n_inertial;
+        W.kf_off = (int)sumKF; W.pt_off = (int)sumL; W.e_off = (int)sumE; W.m_off = (int)sumM; W.x_off = (int)sumX; W.h_off = (long long)sumH;
+        W.free_off = (int)free_kf.size(); W.ptstart_off = (int)pt_start.size(); W.kfstart_off = (int)kf_start.size();
+        W.kfe_off = (int)kf_edges.size(); W.pairstart_off = (int)pair_start.size(); W.pent_off = (long long)pair_ent.size();
+        memcpy(W.Rcb, g.Rcb, sizeof(W.Rcb)); memcpy(W.tcb, g.tcb, sizeof(W.tcb));
+        W.fx = g.fx; W.fy = g.fy; W.cx = g.cx; W.cy = g.cy; W.bf = g.bf;
+        std::vector<int> fidx(g.n_kf, -1);
+        int n = 0;
+        for (int k = 0; k < g.n_kf; k++) {
+            kf_imu.push_back(g.kf_imu[k] ? 1 : 0);
+            if (g.kf_fixed[k]) { kf_xoff.push_back(-1); continue; }
+            kf_xoff.push_back(n); fidx[k] = W.nfree++; free_kf.push_back(k);
+            n += g.kf_imu[k] ? 15 : 6;
+        }
+        W.n = n;
+        if (n > BA_LDLT_MAXN || g.n_inertial > IBA_THREADS) { orbhip_set_last_error_internal("inertial BA: more than 480 keyframe unknowns (32 inertial keyframes)"); return ORBHIP_E_CAPACITY; }
+        max_n = std::max(max_n, n);
+        // edges: grouped by point (the reference creates them point by point, Optimizer.cc:4914-5034)
+        std::vector<int> pstart(g.n_points + 1, 0);
+        std::vector<std::vector<int>> kfe(W.nfree);
+        for (int e = 0; e < g.n_edges; e++) {
+            const int k = g.edge_kf[e], l = g.edge_point[e];
+            if (k < 0 || k >= g.n_kf || l < 0 || l >= g.n_points || (e && l < g.edge_point[e - 1])) return ORBHIP_E_BADARG;
+            pstart[l + 1]++;
+            if (fidx[k] >= 0) kfe[fidx[k]].push_back(e);
+            edge_kf.push_back(k); edge_point.push_back(l);
+            edge_obs.push_back(g.edge_obs[3 * e]); edge_obs.push_back(g.edge_obs[3 * e + 1]); edge_obs.push_back(g.edge_obs[3 * e + 2]);
+            edge_is2.push_back(g.edge_inv_sigma2[e]);
+            edge_stereo.push_back(g.edge_stereo[e] ? 1 : 0);
+            edge_close.push_back(g.edge_close ? (g.edge_close[e] ? 1 : 0) : 0);
+        }
+        for (int l = 0; l < g.n_points; l++) pstart[l + 1] += pstart[l];
+        pt_start.insert(pt_start.end(), pstart.begin(), pstart.end());
+        int acc = 0;
+        for (int f = 0; f < W.nfree; f++) { kf_start.push_back(acc); kf_edges.insert(kf_edges.end(), kfe[f].begin(), kfe[f].end()); acc += (int)kfe[f].size(); }
+        kf_start.push_back(acc);
+        // pair lists: for every point, every (i <= j) pair of the free keyframes that see it
+        W.npairs = W.nfree * (W.nfree + 1) / 2;
+        std::vector<std::vector<int2>> pl(W.npairs);
+        auto pair_id = [&](int i, int j) { return i * W.nfree - i * (i - 1) / 2 + (j - i); };
+        std::vector<std::pair<int, int>> fe;
+        for (int l = 0; l < g.n_points; l++) {
+            fe.clear();
+            for (int e = pstart[l]; e < pstart[l + 1]; e++) if (fidx[g.edge_kf[e]] >= 0) fe.push_back({fidx[g.edge_kf[e]], e});
+            for (size_t a = 0; a < fe.size(); a++)
+                for (size_t b2 = a; b2 < fe.size(); b2++) {
+                    if (b2 != a && fe[a].first == fe[b2].first) { orbhip_set_last_error_internal("inertial BA: a point is observed twice by one keyframe"); return ORBHIP_E_BADARG; }
+                    const bool sw = fe[a].first > fe[b2].first;
+                    const int i = sw ? fe[b2].first : fe[a].first, j = sw ? fe[a].first : fe[b2].first;
+                    pl[pair_id(i, j)].push_back(make_int2(sw ? fe[b2].second : fe[a].second, sw ? fe[a].second : fe[b2].second));
+                }
+        }
+        int pacc = 0;
+        for (int p = 0; p < W.npairs; p++) { pair_start.push_back(pacc); pair_ent.insert(pair_ent.end(), pl[p].begin(), pl[p].end()); pacc += (int)pl[p].size(); }
+        pair_start.push_back(pacc);
+        // inertial edges + greedy colouring (edges of one colour share no keyframe)
+        std::vector<std::vector<int>> used(g.n_kf);
+        for (int m = 0; m < g.n_inertial; m++) {
+            const int k1 = g.in_kf1[m], k2 = g.in_kf2[m];
+            if (k1 < 0 || k1 >= g.n_kf || k2 < 0 || k2 >= g.n_kf || k1 == k2 || !g.kf_imu[k1] || !g.kf_imu[k2]) return ORBHIP_E_BADARG;
+            int c = 0;
+            auto taken = [&](int col) { for (int u : used[k1]) if (u == col) return true; for (int u : used[k2]) if (u == col) return true; return false; };
+            while (taken(c)) c++;
+            used[k1].push_back(c); used[k2].push_back(c);
+            W.ncolors = std::max(W.ncolors, c + 1);
+            in1.push_back(k1); in2.push_back(k2); in_color.push_back(c); in_robust.push_back(g.in_robust[m] ? 1 : 0);
+            in_pre.insert(in_pre.end(), g.in_preint + (size_t)IBA_PRE * m, g.in_preint + (size_t)IBA_PRE * (m + 1));
+            in_info.insert(in_info.end(), g.in_info + 81 * (size_t)m, g.in_info + 81 * (size_t)(m + 1));
+            in_info_g.insert(in_info_g.end(), g.in_info_g + 9 * (size_t)m, g.in_info_g + 9 * (size_t)(m + 1));
+            in_info_a.insert(in_info_a.end(), g.in_info_a + 9 * (size_t)m, g.in_info_a + 9 * (size_t)(m + 1));
+        }
+        kfs.insert(kfs.end(), kf_state_inout[w], kf_state_inout[w] + (size_t)IBA_KF * g.n_kf);
+        if (g.n_points) pts.insert(pts.end(), points_inout[w], points_inout[w] + 3 * (size_t)g.n_points);
+        sumKF += g.n_kf; sumL += g.n_points; sumE += g.n_edges; sumM += g.n_inertial; sumX += n; sumH += (size_t)n * n;
+    }
+    Blob B;
+    const size_t o_win = B.put(hw), o_xoff = B.put(kf_xoff), o_imu = B.put(kf_imu), o_free = B.put(free_kf), o_ekf = B.put(edge_kf),
+                 o_ept = B.put(edge_point), o_obs = B.put(edge_obs), o_is2 = B.put(edge_is2), o_est = B.put(edge_stereo), o_ecl = B.put(edge_close),
+                 o_pst = B.put(pt_start), o_kst = B.put(kf_start), o_ked = B.put(kf_edges), o_prs = B.put(pair_start), o_pre = B.put(pair_ent),
+                 o_in1 = B.put(in1), o_in2 = B.put(in2), o_col = B.put(in_color), o_rob = B.put(in_robust), o_ipr = B.put(in_pre),
+                 o_inf = B.put(in_info), o_ig = B.put(in_info_g), o_ia = B.put(in_info_a);
+    const size_t constant_bytes = al256(B.bytes.size());
+    // work area
+    size_t off = constant_bytes;
+    auto take = [&](size_t bytes) { const size_t o = off; off = al256(off + std::max<size_t>(bytes, 8)); return o; };
+    const size_t w_kfs = take(16 * IBA_KF * sumKF), w_cam = take(16 * 12 * sumKF), w_pts = take(16 * 3 * sumL), w_err = take(24 * sumE), w_chi = take(8 * sumE),
+                 w_W = take(144 * sumE), w_Hll = take(48 * sumL), w_bl = take(24 * sumL), w_Di = take(48 * sumL), w_db = take(24 * sumL), w_xl = take(24 * sumL),
+                 w_ierr = take(120 * sumM), w_ichi = take(24 * sumM), w_Jb = take(1728 * sumM), w_OJ = take(1728 * sumM), w_Oe = take(120 * sumM),
+                 w_H = take(8 * sumH), w_S = take(8 * sumH), w_b = take(8 * sumX), w_bs = take(8 * sumX), w_x = take(8 * sumX), w_out = take(sumE),
+                 w_stats = take(sizeof(orbhip_iba_stats) * n_windows);
+    ITRY(hipSetDevice(orbhip_ctx_device_internal(ctx)));
+    hipStream_t s = orbhip_ctx_stream_internal(ctx);
+    uint8_t *d = (uint8_t *)orbhip_ctx_scratch_internal(ctx, off);
+    if (!d) return ORBHIP_E_HIP;
+    ITRY(hipMemcpyAsync(d, B.bytes.data(), B.bytes.size(), hipMemcpyHostToDevice, s));
+    ITRY(hipMemcpyAsync(d + w_kfs, kfs.data(), 8 * kfs.size(), hipMemcpyHostToDevice, s));
+    if (!pts.empty()) ITRY(hipMemcpyAsync(d + w_pts, pts.data(), 8 * pts.size(), hipMemcpyHostToDevice, s));
+    ITRY(hipMemsetAsync(d + w_xl, 0, 24 * sumL + 8, s));
+    ITRY(hipMemsetAsync(d + w_x, 0, 8 * sumX + 8, s));
+    ITRY(hipMemsetAsync(d + w_W, 0, 144 * sumE + 8, s));
+    IbaArgs A;
+    memset(&A, 0, sizeof(A));
+#define CP(T, o) reinterpret_cast<const T *>(d + (o))
+#define WP(T, o) reinterpret_cast<T *>(d + (o))
+    A.win = CP(IbaWin, o_win); A.kf_xoff = CP(int, o_xoff); A.kf_imu = CP(uint8_t, o_imu); A.free_kf = CP(int, o_free);
+    A.edge_kf = CP(int, o_ekf); A.edge_point = CP(int, o_ept); A.edge_obs = CP(double, o_obs); A.edge_is2 = CP(double, o_is2);
+    A.edge_stereo = CP(uint8_t, o_est); A.edge_close = CP(uint8_t, o_ecl); A.pt_start = CP(int, o_pst); A.kf_start = CP(int, o_kst);
+    A.kf_edges = CP(int, o_ked); A.pair_start = CP(int, o_prs); A.pair_ent = CP(int2, o_pre); A.in_kf1 = CP(int, o_in1); A.in_kf2 = CP(int, o_in2);
+    A.in_color = CP(int, o_col); A.in_robust = CP(uint8_t, o_rob); A.in_pre = CP(double, o_ipr); A.in_info = CP(double, o_inf);
+    A.in_info_g = CP(double, o_ig); A.in_info_a = CP(double, o_ia);
+    A.kfs = WP(double, w_kfs); A.cam = WP(double, w_cam); A.pts = WP(double, w_pts);
+    A.kfs_stride = (long long)IBA_KF * sumKF; A.cam_stride = 12 * (long long)sumKF; A.pts_stride = 3 * (long long)sumL;
+    A.err = WP(double, w_err); A.chi2 = WP(double, w_chi); A.W = WP(double, w_W); A.Hll = WP(double, w_Hll); A.bl = WP(double, w_bl);
+    A.Dinv = WP(double, w_Di); A.db = WP(double, w_db); A.xl = WP(double, w_xl); A.ierr = WP(double, w_ierr); A.ichi2 = WP(double, w_ichi);
+    A.Jb = WP(double, w_Jb); A.OJ = WP(double, w_OJ); A.Oe = WP(double, w_Oe); A.H = WP(double, w_H); A.S = WP(double, w_S);
+    A.b = WP(double, w_b); A.bs = WP(double, w_bs); A.x = WP(double, w_x); A.outlier = WP(uint8_t, w_out); A.stats = WP(orbhip_iba_stats, w_stats);
+#undef CP
+#undef WP
+    A.iterations = params->iterations; A.max_trials = params->max_trials; A.large = params->large; A.lambda_init = params->lambda_init;
+    A.max_n = std::max(max_n, 32);
+    const size_t lds = ba_ldlt_lds_bytes(A.max_n);
+    if (orb_lds_optin((const void *)k_iba_solve, orbhip_ctx_device_internal(ctx), lds) != 0) return ORBHIP_E_HIP;
+    hipLaunchKernelGGL(k_iba_solve, dim3(n_windows), dim3(IBA_THREADS), lds, s, A);
+    ITRY(hipGetLastError());
+    std::vector<orbhip_iba_stats> st(n_windows);
+    std::vector<double> kfo((size_t)IBA_KF * sumKF), pto(3 * sumL);
+    std::vector<uint8_t> outl(sumE);
+    ITRY(hipMemcpyAsync(st.data(), d + w_stats, sizeof(orbhip_iba_stats) * n_windows, hipMemcpyDeviceToHost, s));
+    ITRY(hipMemcpyAsync(kfo.data(), d + w_kfs, 8 * kfo.size(), hipMemcpyDeviceToHost, s));
+    if (sumL) ITRY(hipMemcpyAsync(pto.data(), d + w_pts, 8 * pto.size(), hipMemcpyDeviceToHost, s));
+    if (sumE) ITRY(hipMemcpyAsync(outl.data(), d + w_out, sumE, hipMemcpyDeviceToHost, s));
+    ITRY(hipStreamSynchronize(s));
+    for (int w = 0; w < n_windows; w++) {
+        const IbaWin &W = hw[w];
+        if (!st[w].failed) {                               // "FAIL LOCAL-INERTIAL BA": the reference returns before any write-back (Optimizer.cc:5096-5100)
+            memcpy(kf_state_inout[w], kfo.data() + (size_t)W.kf_off * IBA_KF, 8 * (size_t)IBA_KF * W.n_kf);
+            if (W.L) memcpy(points_inout[w], pto.data() + (size_t)W.pt_off * 3, 24 * (size_t)W.L);
+        }
+        if (edge_outlier_out && edge_outlier_out[w] && W.E) memcpy(edge_outlier_out[w], outl.data() + W.e_off, W.E);
+        if (stats_out) stats_out[w] = st[w];
+    }
+    return ORBHIP_OK;
+}

@@ -488,6 +488,59 @@ class BaBatch:
             self.h = None
 
 
+# ---------------------------------------------------------------------------------------------- inertial local BA
+class IbaWindow(C.Structure):
+    """orbhip_iba_window (include/orbhip.h): the flat description of one Optimizer::LocalInertialBA window."""
+    _fields_ = [("n_kf", C.c_int32), ("kf_fixed", vp), ("kf_imu", vp), ("Rcb", cd * 9), ("tcb", cd * 3),
+                ("fx", cd), ("fy", cd), ("cx", cd), ("cy", cd), ("bf", cd),
+                ("n_points", C.c_int32), ("n_edges", C.c_int32), ("edge_kf", vp), ("edge_point", vp), ("edge_obs", vp),
+                ("edge_stereo", vp), ("edge_inv_sigma2", vp), ("edge_close", vp),
+                ("n_inertial", C.c_int32), ("in_kf1", vp), ("in_kf2", vp), ("in_preint", vp), ("in_info", vp),
+                ("in_info_g", vp), ("in_info_a", vp), ("in_robust", vp)]
+
+
+class IbaParams(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("lambda_init", cd), ("large", C.c_int32), ("max_trials", C.c_int32)]
+
+
+class IbaStats(C.Structure):
+    _fields_ = [("iterations_run", C.c_int32), ("lm_trials", C.c_int32), ("n_outliers", C.c_int32), ("failed", C.c_int32),
+                ("err", cd), ("err_end", cd)]
+
+    def as_dict(self):
+        return dict(iterations_run=self.iterations_run, lm_trials=self.lm_trials, n_outliers=self.n_outliers, failed=self.failed,
+                    err=self.err, err_end=self.err_end)
+
+
+IBA_KF, IBA_PREINT = 21, 67
+lib.orbhip_iba_default_params.argtypes = [C.POINTER(IbaParams), ci]
+lib.orbhip_inertial_ba_solve_batch.argtypes = [vp, vp, ci, C.POINTER(IbaParams), vp, vp, vp, vp]
+
+
+def iba_default_params(large=False):
+    p = IbaParams()
+    lib.orbhip_iba_default_params(C.byref(p), 1 if large else 0)
+    return p
+
+
+def inertial_ba_solve_batch(ctx, windows, kf_states, points, params=None):
+    """windows: list of IbaWindow (their arrays kept alive by the caller); kf_states[w] float64 [n_kf, 21], points[w] float64
+    [n_points, 3] -> (kf_states, points, edge_outlier, stats) as new arrays (inputs untouched)."""
+    n = len(windows)
+    p = params or iba_default_params()
+    arr = (IbaWindow * n)(*windows)
+    kfs = [np.ascontiguousarray(a, np.float64).copy() for a in kf_states]
+    pts = [np.ascontiguousarray(a, np.float64).copy() for a in points]
+    outl = [np.zeros(max(w.n_edges, 1), np.uint8) for w in windows]
+    stats = (IbaStats * n)()
+    pk = (vp * n)(*[a.ctypes.data for a in kfs])
+    pq = (vp * n)(*[a.ctypes.data for a in pts])
+    po = (vp * n)(*[a.ctypes.data for a in outl])
+    _chk(lib.orbhip_inertial_ba_solve_batch(ctx.h, C.cast(arr, vp), n, C.byref(p), C.cast(pk, vp), C.cast(pq, vp), C.cast(po, vp),
+                                            C.cast(stats, vp)), "orbhip_inertial_ba_solve_batch")
+    return kfs, pts, [o[:w.n_edges] for o, w in zip(outl, windows)], [st.as_dict() for st in stats]
+
+
 class Camera2(C.Structure):
     _fields_ = [("Trl", cd * 7), ("fx", cd), ("fy", cd), ("cx", cd), ("cy", cd), ("camera_model", C.c_int32), ("kb", cd * 4)]
 

@@ -1,0 +1,93 @@
+"""GPU parity of the inertial local BA (orbhip_inertial_ba_solve_batch, csrc/iba_kernels.hip) against the CPU oracle
+(oracle/iba_oracle.c) on the same synthetic visual-inertial windows.  Tolerance: RMSE <= 1e-4 on keyframe states and points
+(BASELINE.json north_star's BA tolerance), identical outlier flags and LM trial counts.  PARITY UNPINNED against the real
+reference (see oracle/iba_oracle.h)."""
+import ctypes as C
+import numpy as np
+import pytest
+import oracle_iba_bind as ib
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import orbhip
+    ctx = orbhip.Context(0)
+    yield orbhip, ctx
+    ctx.close()
+
+
+def _gpu_solve(hip, wins, large=False, params=None):
+    orbhip, ctx = hip
+    structs = [w.struct(orbhip.IbaWindow) for w in wins]
+    p = params or orbhip.iba_default_params(large)
+    return orbhip.inertial_ba_solve_batch(ctx, structs, [w.kf0 for w in wins], [w.pts0 for w in wins], p)
+
+
+def _rmse(a, b):
+    return float(np.sqrt(np.mean((np.asarray(a) - np.asarray(b)) ** 2))) if np.size(a) else 0.0
+
+
+def _compare(win, gpu, cpu, tol=1e-4):
+    kf_g, pts_g, out_g, st_g = gpu
+    kf_c, pts_c, out_c, st_c = cpu
+    assert st_g["failed"] == st_c.failed
+    assert st_g["iterations_run"] == st_c.iterations_run and st_g["lm_trials"] == st_c.lm_trials, (st_g, st_c.iterations_run, st_c.lm_trials)
+    assert abs(st_g["err"] - st_c.err) <= 1e-9 * max(1.0, abs(st_c.err))
+    assert abs(st_g["err_end"] - st_c.err_end) <= 1e-6 * max(1.0, abs(st_c.err_end))
+    assert _rmse(kf_g, kf_c) <= tol and _rmse(pts_g, pts_c) <= tol, (_rmse(kf_g, kf_c), _rmse(pts_g, pts_c))
+    assert np.array_equal(out_g, out_c)
+    assert st_g["n_outliers"] == int(out_c.sum())
+
+
+@pytest.mark.parametrize("seed,kw", [(21, dict(n_opt=8, n_fixed_vis=10, n_points=300)),
+                                     (22, dict(n_opt=3, n_fixed_vis=2, n_points=60)),
+                                     (23, dict(n_opt=10, n_fixed_vis=30, n_points=900, stereo_frac=0.0)),
+                                     (24, dict(n_opt=10, n_fixed_vis=25, n_points=700, stereo_frac=1.0))])
+def test_inertial_ba_matches_oracle(hip, seed, kw):
+    win = ib.make_window(seed, **kw)
+    gpu = _gpu_solve(hip, [win])
+    _compare(win, [x[0] for x in gpu], ib.solve(win))
+
+
+def test_inertial_ba_large_variant(hip):
+    win = ib.make_window(31, n_opt=25, n_fixed_vis=40, n_points=1200, large=True)
+    gpu = _gpu_solve(hip, [win], large=True)
+    _compare(win, [x[0] for x in gpu], ib.solve(win, ib.default_params(large=True)))
+
+
+def test_inertial_ba_batch_of_windows_and_determinism(hip):
+    wins = [ib.make_window(40 + i, n_opt=4 + i % 7, n_fixed_vis=3 + 2 * i, n_points=120 + 40 * i) for i in range(9)]
+    gpu = _gpu_solve(hip, wins)
+    again = _gpu_solve(hip, wins)
+    for i, w in enumerate(wins):
+        _compare(w, [x[i] for x in gpu], ib.solve(w))
+        assert np.array_equal(gpu[0][i], again[0][i]) and np.array_equal(gpu[1][i], again[1][i])      # fixed summation orders
+
+
+def test_inertial_ba_fail_check_leaves_inputs(hip):
+    win = ib.make_window(13, n_opt=4, n_fixed_vis=3, n_points=60)
+    win.arrays["in_preint"][:, 13:16] += 40.0
+    orbhip, _ = hip
+    p = orbhip.iba_default_params(False)
+    p.iterations, p.max_trials = 1, 1
+    po = ib.default_params()
+    po.iterations, po.max_trials = 1, 1
+    gpu = _gpu_solve(hip, [win], params=p)
+    cpu = ib.solve(win, po)
+    assert gpu[3][0]["failed"] == cpu[3].failed
+    if cpu[3].failed:
+        assert np.array_equal(gpu[0][0], win.kf0) and np.array_equal(gpu[1][0], win.pts0)
+
+
+def test_inertial_ba_rejects_malformed_windows(hip):
+    orbhip, ctx = hip
+    win = ib.make_window(50, n_opt=3, n_fixed_vis=1, n_points=30)
+    win.arrays["edge_point"][:] = win.arrays["edge_point"][::-1].copy()           # not grouped by point
+    with pytest.raises(orbhip.OrbHipError):
+        _gpu_solve(hip, [win])
+    win2 = ib.make_window(51, n_opt=3, n_fixed_vis=1, n_points=30)
+    win2.arrays["in_kf1"][0] = 99
+    with pytest.raises(orbhip.OrbHipError):
+        _gpu_solve(hip, [win2])
