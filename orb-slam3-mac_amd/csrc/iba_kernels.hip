@@ -17,6 +17,8 @@
 #include "ba_ldlt.h"
 #include <cfloat>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <vector>
@@ -30,12 +32,15 @@ void orbhip_set_last_error_internal(const char *msg);
 #define IBA_PRE ORBHIP_IBA_PREINT
 #define IBA_THREADS 1024
 #define IBA_WAVES (IBA_THREADS / 64)
+#define IBA_MAXG 16
+#define IBA_KF_CHUNK 256
+#define IBA_PAIR_CHUNK 256
 enum { K_R = 0, K_T = 9, K_V = 12, K_BG = 15, K_BA = 18 };
 enum { P_DT = 0, P_DR = 1, P_DV = 10, P_DP = 13, P_JRG = 16, P_JVG = 25, P_JVA = 34, P_JPG = 43, P_JPA = 52, P_BG = 61, P_BA = 64 };
 
 struct IbaWin {
-    int n_kf, L, E, M, n, nfree, ncolors, npairs;
-    int kf_off, pt_off, e_off, m_off, x_off, free_off, ptstart_off, kfstart_off, kfe_off, pairstart_off;
+    int n_kf, L, E, M, n, nfree, ncolors, npairs, nktask, nptask;
+    int kf_off, pt_off, e_off, m_off, x_off, free_off, ptstart_off, kfe_off, ktask_off, ktstart_off, ptask_off, ptstart2_off;
     long long pent_off, h_off;
     double Rcb[9], tcb[3], fx, fy, cx, cy, bf;
 };
@@ -49,8 +54,12 @@ struct IbaArgs {
     const double *edge_obs, *edge_is2;
     const uint8_t *edge_stereo, *edge_close;
     const int *pt_start;                // per window L + 1 entries
-    const int *kf_start, *kf_edges;     // per window nfree + 1 entries; the edges of every free keyframe
-    const int *pair_start; const int2 *pair_ent;   // per window npairs + 1; {edge of block i, edge of block j} of every point both see
+    const int *kf_edges;                // the visual edges of every free keyframe, keyframe by keyframe
+    const int4 *kf_task;                // {free block f, first, end (into kf_edges), 0}: chunks of <= IBA_KF_CHUNK edges
+    const int *kf_task_start;           // per window nfree + 1: the chunks of block f
+    const int2 *pair_ent;               // {edge of block i, edge of block j} of every landmark both see, pair by pair (i <= j, row-major)
+    const int4 *pair_task;              // {pair, first, end (into pair_ent), i == j}: chunks of <= IBA_PAIR_CHUNK entries
+    const int *pair_task_start;         // per window npairs + 1
     const int *in_kf1, *in_kf2, *in_color; const uint8_t *in_robust;
     const double *in_pre, *in_info, *in_info_g, *in_info_a;
     double *kfs, *cam, *pts;            // estimates, two buffers each: [2][sumKF][21], [2][sumKF][12] (Rcw, tcw), [2][sumL][3]
@@ -58,10 +67,15 @@ struct IbaArgs {
     double *err, *chi2, *W, *Hll, *bl, *Dinv, *db, *xl;
     double *ierr, *ichi2, *Jb, *OJ, *Oe;
     double *H, *S, *b, *bs, *x;
+    double *kpart, *ppart;              // [kf tasks][27], [pair tasks][42] partial sums
+    unsigned *counters; int *fail, *okflag;   // per window: team barrier counter, barrier time-out flag, LDL^T status
+    double *wpart;                      // per window [2][IBA_MAXG][2]
+    int G, n_windows;                   // workgroups per window
     uint8_t *outlier;
     orbhip_iba_stats *stats;
     int iterations, max_trials, large, max_n;
     double lambda_init;
+    long long *prof;                    // optional [windows][8] shader-clock cycles per phase (ORBHIP_IBA_PROF=1): errors, build, prep+Schur, LDL^T, update
 };
 
 // ------------------------------------------------------------------ small dense helpers (row-major 3x3)
@@ -163,17 +177,19 @@ __device__ __forceinline__ void huber(double e, double delta, double dsqr, doubl
     else { const double s = sqrt(e); rho0 = 2 * s * delta - dsqr; rho1 = delta / s; }
 }
 
-// block-uniform sum: per-thread values -> DPP tree inside each wave -> the 16 wave sums added in index order by every thread
-__device__ __forceinline__ double block_sum(double v, double *red)
+// sum over each group of 8 consecutive lanes, every lane of the group gets the total (quad butterflies + half-row mirror;
+// each lane's association is fixed)
+__device__ __forceinline__ double oct_allreduce_f64(double v)
 {
-    v = wave_sum_f64_dpp(v);
-    __syncthreads();                                         // red may still be read by the previous call
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    double s = 0;
-#pragma unroll
-    for (int w = 0; w < IBA_WAVES; w++) s += red[w];
-    return s;
+#define IBA_STEP(CTRL) do { const unsigned long long u = __builtin_bit_cast(unsigned long long, v); \
+        const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(u & 0xffffffffu), CTRL, 0xF, 0xF, false), \
+                       hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(u >> 32), CTRL, 0xF, 0xF, false); \
+        v += __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo); } while (0)
+    IBA_STEP(0xB1);      // quad_perm [1,0,3,2]
+    IBA_STEP(0x4E);      // quad_perm [2,3,0,1]
+    IBA_STEP(0x141);     // row_half_mirror
+#undef IBA_STEP
+    return v;
 }
 
 // Rcw = Rcb Rbw, tcw = Rcb tbw + tcb (ImuCamPose::Update, G2oTypes.cc:212-219)
@@ -281,22 +297,83 @@ __device__ __noinline__ void inertial_edge(const double *s1, const double *s2, c
 #undef SETB
 }
 
+// ------------------------------------------------------------------ a window's team of workgroups
+// G workgroups work on one window (G = 1 for big batches: plain __syncthreads semantics).  team_sync is a monotonic-counter
+// barrier (MI355X_MICROARCH.md "barrier-counter": lane-0 agent release fence + drained vmcnt before the arrive, relaxed polls
+// with s_sleep, agent acquire fence after); the grid is sized by the host so that all workgroups are resident (cooperative
+// launch), and every spin is bounded: a barrier that does not complete sets *fail and lets the kernel run out.
+struct Team {
+    int w, g, G, gtid, gsize, gwave, gwaves;
+    unsigned *counter;          // per window, zeroed by the host
+    unsigned epoch;             // barriers passed so far (uniform)
+    double *wpart;              // [2][IBA_MAXG][2] cross-workgroup partial sums, double buffered
+    int slot;
+    int *fail;                  // per window
+};
+
+__device__ __forceinline__ void team_sync(Team &T)
+{
+    __syncthreads();
+    if (T.G > 1) {
+        T.epoch++;
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(T.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = T.epoch * (unsigned)T.G;
+            long long spins = 0;
+            while (__hip_atomic_load(T.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1ll << 22) || __hip_atomic_load(T.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {       // seconds: never in a resident grid
+                    __hip_atomic_store(T.fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+    }
+}
+
+// team-uniform sums of two per-thread values: DPP tree inside each wave, the 16 wave sums in index order, then the G workgroup
+// sums in index order (fixed association for a given G)
+__device__ __forceinline__ void team_sum2(Team &T, double &a, double &b, double *red)
+{
+    a = wave_sum_f64_dpp(a); b = wave_sum_f64_dpp(b);
+    __syncthreads();                                         // red may still be read by the previous call
+    if ((threadIdx.x & 63) == 0) { red[2 * (threadIdx.x >> 6)] = a; red[2 * (threadIdx.x >> 6) + 1] = b; }
+    __syncthreads();
+    double sa = 0, sb = 0;
+#pragma unroll
+    for (int w = 0; w < IBA_WAVES; w++) { sa += red[2 * w]; sb += red[2 * w + 1]; }
+    if (T.G > 1) {
+        double *wp = T.wpart + (size_t)T.slot * IBA_MAXG * 2;
+        if (threadIdx.x == 0) { wp[2 * T.g] = sa; wp[2 * T.g + 1] = sb; }
+        team_sync(T);
+        sa = 0; sb = 0;
+        for (int g = 0; g < T.G; g++) { sa += wp[2 * g]; sb += wp[2 * g + 1]; }
+        T.slot ^= 1;
+    }
+    a = sa; b = sb;
+}
+
 struct IbaCtx {            // per-window views (all threads hold the same values)
     const IbaWin *W;
     const IbaArgs *A;
     double delta_m, dsqr_m, delta_s, dsqr_s, delta_i, dsqr_i;
 };
 
-// computeActiveErrors + activeRobustChi2 at estimate buffer `buf`; the per-edge errors / chi2 stay in global memory
-__device__ __noinline__ double iba_errors(const IbaCtx &C, int buf, double *red)
+// computeActiveErrors at estimate buffer `buf`: per-edge errors / chi2 to global memory; returns this THREAD's share of
+// activeRobustChi2 (the caller sums over the team)
+__device__ __noinline__ double iba_errors(const IbaCtx &C, const Team &T, int buf)
 {
     const IbaWin &W = *C.W; const IbaArgs &A = *C.A;
-    const int tid = threadIdx.x;
     const double *cam = A.cam + buf * A.cam_stride + (size_t)W.kf_off * 12;
     const double *pts = A.pts + buf * A.pts_stride + (size_t)W.pt_off * 3;
     const double *kfs = A.kfs + buf * A.kfs_stride + (size_t)W.kf_off * IBA_KF;
     double part = 0.0;
-    for (int e = tid; e < W.E; e += IBA_THREADS) {
+    for (int e = T.gtid; e < W.E; e += T.gsize) {
         const size_t ge = (size_t)W.e_off + e;
         const int st = A.edge_stereo[ge];
         double er[3], Xc[3];
@@ -308,8 +385,10 @@ __device__ __noinline__ double iba_errors(const IbaCtx &C, int buf, double *red)
         huber(chi, st ? C.delta_s : C.delta_m, st ? C.dsqr_s : C.dsqr_m, r0, r1);
         part += r0;
     }
-    if (tid < W.M) {
-        const size_t gm = (size_t)W.m_off + tid;
+    // inertial edges: the last threads of the team (the first ones carry the most visual edges)
+    const int m = T.gsize - 1 - T.gtid;
+    if (m < W.M) {
+        const size_t gm = (size_t)W.m_off + m;
         const double *s1 = kfs + IBA_KF * A.in_kf1[gm], *s2 = kfs + IBA_KF * A.in_kf2[gm];
         double er[15];
         inertial_edge(s1, s2, A.in_pre + IBA_PRE * gm, er, nullptr);
@@ -328,11 +407,58 @@ __device__ __noinline__ double iba_errors(const IbaCtx &C, int buf, double *red)
         if (A.in_robust[gm]) huber(c9, C.delta_i, C.dsqr_i, r0, r1);
         part += r0 + cg + ca;
     }
-    return block_sum(part, red);
+    return part;
 }
 
-// buildSystem at buffer `buf` from the stored errors: Hll, bl, W per edge; H (dense, lower + upper) and b of the keyframe unknowns
-__device__ __noinline__ void iba_build(const IbaCtx &C, int buf)
+// One chunk of a free keyframe's visual edges -> partial sums of its 6x6 pose block (lower triangle, 21) and right-hand side (6).
+// HALF 0: rows 0..3 of the block (10 entries) + the right-hand side; HALF 1: rows 4, 5 (11 entries): two waves per chunk keep the
+// accumulators + the 3x6 Jacobian inside the 128-VGPR budget of a 16-wave workgroup.
+template <int HALF>
+__device__ __forceinline__ void kf_block_task(const IbaCtx &C, const double *cam, const double *pts, int4 task, double *out)
+{
+    const IbaWin &W = *C.W; const IbaArgs &A = *C.A;
+    constexpr int A0 = HALF ? 4 : 0, A1 = HALF ? 6 : 4, Q0 = HALF ? 10 : 0, NQ = HALF ? 11 : 10, NB = HALF ? 0 : 6;
+    const int lane = threadIdx.x & 63;
+    const int k = A.free_kf[W.free_off + task.x];
+    const double *c = cam + 12 * k;
+    const int *kf_edges = A.kf_edges + W.kfe_off;
+    double acc[NQ + NB + 1];
+#pragma unroll
+    for (int i = 0; i < NQ + NB; i++) acc[i] = 0.0;
+    for (int j = task.y + lane; j < task.z; j += 64) {
+        const size_t ge = (size_t)W.e_off + kf_edges[j];
+        const int st = A.edge_stereo[ge];
+        const double *X = pts + 3 * A.edge_point[ge];
+        double Xc[3], Jx[9], Jp[18], r0, r1;
+        mv3(c, X, Xc); Xc[0] += c[9]; Xc[1] += c[10]; Xc[2] += c[11];
+        visual_jac(W, c, Xc, st, Jx, Jp);
+        huber(A.chi2[ge], st ? C.delta_s : C.delta_m, st ? C.dsqr_s : C.dsqr_m, r0, r1);
+        const double w = r1 * A.edge_is2[ge];
+        int q = 0;
+#pragma unroll
+        for (int a = A0; a < A1; a++)
+#pragma unroll
+            for (int cc = 0; cc <= a; cc++, q++)
+                acc[q] += Jp[a] * w * Jp[cc] + Jp[6 + a] * w * Jp[6 + cc] + Jp[12 + a] * w * Jp[12 + cc];      // row 2 of Jp is zero when mono
+        if (!HALF) {
+            const double e0 = -w * A.err[3 * ge], e1 = -w * A.err[3 * ge + 1], e2 = st ? -w * A.err[3 * ge + 2] : 0.0;
+#pragma unroll
+            for (int a = 0; a < 6; a++) acc[NQ + a] += Jp[a] * e0 + Jp[6 + a] * e1 + Jp[12 + a] * e2;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NQ + NB; i++) acc[i] = wave_sum_f64_dpp(acc[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NQ; i++) out[Q0 + i] = acc[i];
+#pragma unroll
+        for (int i = 0; i < NB; i++) out[21 + i] = acc[NQ + i];
+    }
+}
+
+// buildSystem at buffer `buf` from the stored errors.  Team: Hll, bl and the pose-landmark blocks W per landmark; per-chunk partial
+// pose blocks; the Omega-weighted inertial Jacobians.  Workgroup 0 then assembles H (dense, both triangles) and b.
+__device__ __noinline__ void iba_build(const IbaCtx &C, Team &T, int buf)
 {
     const IbaWin &W = *C.W; const IbaArgs &A = *C.A;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = W.n;
@@ -340,14 +466,28 @@ __device__ __noinline__ void iba_build(const IbaCtx &C, int buf)
     const double *pts = A.pts + buf * A.pts_stride + (size_t)W.pt_off * 3;
     const double *kfs = A.kfs + buf * A.kfs_stride + (size_t)W.kf_off * IBA_KF;
     double *H = A.H + W.h_off, *b = A.b + W.x_off;
-    for (int i = tid; i < n * n; i += IBA_THREADS) H[i] = 0.0;
-    for (int i = tid; i < n; i += IBA_THREADS) b[i] = 0.0;
-    // (1) landmarks: Hll, bl and the pose-landmark blocks
+    if (T.g == 0) {
+        for (int i = tid; i < n * n; i += IBA_THREADS) H[i] = 0.0;
+        for (int i = tid; i < n; i += IBA_THREADS) b[i] = 0.0;
+    }
+    // (1) inertial Jacobians (the last threads of the team, as in iba_errors)
+    {
+        const int m = T.gsize - 1 - T.gtid;
+        if (m < W.M) {
+            const size_t gm = (size_t)W.m_off + m;
+            double er[9];
+            inertial_edge(kfs + IBA_KF * A.in_kf1[gm], kfs + IBA_KF * A.in_kf2[gm], A.in_pre + IBA_PRE * gm, er, A.Jb + 216 * gm);
+        }
+    }
+    // (2) landmarks: Hll, bl and the pose-landmark blocks; 8 lanes share a landmark's edges
     const int *pt_start = A.pt_start + W.ptstart_off;
-    for (int l = tid; l < W.L; l += IBA_THREADS) {
+    const int sub = tid & 7;
+    for (int l0 = (T.gtid >> 3); l0 < ((W.L + 7) & ~7); l0 += (T.gsize >> 3)) {      // whole waves stay in the loop (DPP reductions)
+        const int l = min(l0, W.L - 1);
         double h[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
         const double *X = pts + 3 * l;
-        for (int e = pt_start[l]; e < pt_start[l + 1]; e++) {
+        const int e_end = l0 < W.L ? pt_start[l + 1] : 0;
+        for (int e = pt_start[l] + sub; e < e_end; e += 8) {
             const size_t ge = (size_t)W.e_off + e;
             const int st = A.edge_stereo[ge], k = A.edge_kf[ge];
             const double *c = cam + 12 * k;
@@ -356,42 +496,45 @@ __device__ __noinline__ void iba_build(const IbaCtx &C, int buf)
             visual_jac(W, c, Xc, st, Jx, Jp);
             huber(A.chi2[ge], st ? C.delta_s : C.delta_m, st ? C.dsqr_s : C.dsqr_m, r0, r1);
             const double w = r1 * A.edge_is2[ge];
-            const double e0 = A.err[3 * ge], e1 = A.err[3 * ge + 1], e2 = A.err[3 * ge + 2];
-            const int D = st ? 3 : 2;
-            const double es[3] = {e0, e1, e2};
-            for (int a = 0; a < 3; a++) {
-                double s = 0;
-                for (int d = 0; d < D; d++) s += Jx[3 * d + a] * (-w * es[d]);
-                bl[a] += s;
-            }
+            const double es[3] = {-w * A.err[3 * ge], -w * A.err[3 * ge + 1], st ? -w * A.err[3 * ge + 2] : 0.0};
             int q = 0;
-            for (int a = 0; a < 3; a++)
-                for (int cc = 0; cc <= a; cc++, q++) {
-                    double s = 0;
-                    for (int d = 0; d < D; d++) s += Jx[3 * d + a] * w * Jx[3 * d + cc];
-                    h[q] += s;
-                }
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                bl[a] += Jx[a] * es[0] + Jx[3 + a] * es[1] + Jx[6 + a] * es[2];      // row 2 of Jx is zero when mono
+#pragma unroll
+                for (int cc = 0; cc <= a; cc++, q++) h[q] += Jx[a] * w * Jx[cc] + Jx[3 + a] * w * Jx[3 + cc] + Jx[6 + a] * w * Jx[6 + cc];
+            }
             if (A.kf_xoff[W.kf_off + k] >= 0) {
                 double *Wd = A.W + 18 * ge;
+#pragma unroll
                 for (int a = 0; a < 6; a++)
-                    for (int cc = 0; cc < 3; cc++) {
-                        double s = 0;
-                        for (int d = 0; d < D; d++) s += Jp[6 * d + a] * w * Jx[3 * d + cc];
-                        Wd[3 * a + cc] = s;
-                    }
+#pragma unroll
+                    for (int cc = 0; cc < 3; cc++) Wd[3 * a + cc] = Jp[a] * w * Jx[cc] + Jp[6 + a] * w * Jx[3 + cc] + Jp[12 + a] * w * Jx[6 + cc];
             }
         }
-        double *Hl = A.Hll + 6 * ((size_t)W.pt_off + l), *Bl = A.bl + 3 * ((size_t)W.pt_off + l);
-        for (int i = 0; i < 6; i++) Hl[i] = h[i];
-        for (int i = 0; i < 3; i++) Bl[i] = bl[i];
+#pragma unroll
+        for (int i = 0; i < 6; i++) h[i] = oct_allreduce_f64(h[i]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) bl[i] = oct_allreduce_f64(bl[i]);
+        if (sub == 0 && l0 < W.L) {
+            double *Hl = A.Hll + 6 * ((size_t)W.pt_off + l), *Bl = A.bl + 3 * ((size_t)W.pt_off + l);
+            for (int i = 0; i < 6; i++) Hl[i] = h[i];
+            for (int i = 0; i < 3; i++) Bl[i] = bl[i];
+        }
     }
-    // (2) inertial edges: Jacobians, Omega-weighted Jacobians and errors into scratch
-    if (tid < W.M) {
-        const size_t gm = (size_t)W.m_off + tid;
-        double er[9];
-        inertial_edge(kfs + IBA_KF * A.in_kf1[gm], kfs + IBA_KF * A.in_kf2[gm], A.in_pre + IBA_PRE * gm, er, A.Jb + 216 * gm);
+    // (3) per-chunk partial pose blocks, two waves per chunk
+    {
+        const int4 *kf_task = A.kf_task + W.ktask_off;
+        double *kpart = A.kpart + 27 * (size_t)W.ktask_off;
+        for (int t = T.gwave; t < 2 * W.nktask; t += T.gwaves) {
+            const int4 task = kf_task[t >> 1];
+            if (t & 1) kf_block_task<1>(C, cam, pts, task, kpart + 27 * (size_t)(t >> 1));
+            else kf_block_task<0>(C, cam, pts, task, kpart + 27 * (size_t)(t >> 1));
+        }
     }
-    __syncthreads();
+    team_sync(T);                      // Jb, kpart complete
+    if (T.g != 0) return;
+    // ---- workgroup 0: Omega-weighted inertial Jacobians / errors
     for (int idx = tid; idx < W.M * 216; idx += IBA_THREADS) {
         const int m = idx / 216, r = idx - m * 216, i = r / 24, c = r - i * 24;
         const size_t gm = (size_t)W.m_off + m;
@@ -408,46 +551,25 @@ __device__ __noinline__ void iba_build(const IbaCtx &C, int buf)
             A.Oe[15 * gm + i] = -r1 * q;
         }
     }
-    // (3) keyframe pose blocks from the visual edges: one wave per free keyframe, lanes over its edges
-    const int *kf_start = A.kf_start + W.kfstart_off, *kf_edges = A.kf_edges + W.kfe_off;
-    for (int f = wave; f < W.nfree; f += IBA_WAVES) {
-        const int k = A.free_kf[W.free_off + f], o = A.kf_xoff[W.kf_off + k];
-        const double *c = cam + 12 * k;
-        double acc[27];
-#pragma unroll
-        for (int i = 0; i < 27; i++) acc[i] = 0.0;
-        for (int j = kf_start[f] + lane; j < kf_start[f + 1]; j += 64) {
-            const int e = kf_edges[j];
-            const size_t ge = (size_t)W.e_off + e;
-            const int st = A.edge_stereo[ge];
-            const double *X = pts + 3 * A.edge_point[ge];
-            double Xc[3], Jx[9], Jp[18], r0, r1;
-            mv3(c, X, Xc); Xc[0] += c[9]; Xc[1] += c[10]; Xc[2] += c[11];
-            visual_jac(W, c, Xc, st, Jx, Jp);
-            huber(A.chi2[ge], st ? C.delta_s : C.delta_m, st ? C.dsqr_s : C.dsqr_m, r0, r1);
-            const double w = r1 * A.edge_is2[ge];
-            const double es[3] = {A.err[3 * ge], A.err[3 * ge + 1], st ? A.err[3 * ge + 2] : 0.0};
-            int q = 0;
-#pragma unroll
-            for (int a = 0; a < 6; a++) {
-#pragma unroll
-                for (int cc = 0; cc <= a; cc++, q++)
-                    acc[q] += Jp[a] * w * Jp[cc] + Jp[6 + a] * w * Jp[6 + cc] + Jp[12 + a] * w * Jp[12 + cc];      // row 2 of Jp is zero when mono
-                acc[21 + a] += Jp[a] * (-w * es[0]) + Jp[6 + a] * (-w * es[1]) + Jp[12 + a] * (-w * es[2]);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 27; i++) acc[i] = wave_sum_f64_dpp(acc[i]);
-        if (lane == 0) {
-            int q = 0;
-            for (int a = 0; a < 6; a++) {
-                for (int cc = 0; cc <= a; cc++, q++) { H[(size_t)(o + a) * n + o + cc] = acc[q]; H[(size_t)(o + cc) * n + o + a] = acc[q]; }
-                b[o + a] = acc[21 + a];
+    // pose blocks: the chunks of every keyframe summed in order
+    {
+        const int *kts = A.kf_task_start + W.ktstart_off;
+        const double *kpart = A.kpart + 27 * (size_t)W.ktask_off;
+        for (int idx = tid; idx < W.nfree * 27; idx += IBA_THREADS) {
+            const int f = idx / 27, q = idx - 27 * f;
+            const int o = A.kf_xoff[W.kf_off + A.free_kf[W.free_off + f]];
+            double s = 0;
+            for (int t = kts[f]; t < kts[f + 1]; t++) s += kpart[27 * (size_t)t + q];
+            if (q >= 21) b[o + q - 21] = s;
+            else {
+                int a = 0, rem = q;
+                while (rem > a) { rem -= a + 1; a++; }          // q -> (a, cc) of the lower triangle
+                H[(size_t)(o + a) * n + o + rem] = s; H[(size_t)(o + rem) * n + o + a] = s;
             }
         }
     }
     __syncthreads();
-    // (4) inertial + random-walk edges into H / b: edges of one colour share no keyframe, colours run one after the other
+    // inertial + random-walk edges into H / b: edges of one colour share no keyframe, colours run one after the other
     const int *kf_xoff = A.kf_xoff + W.kf_off;
     for (int col = 0; col < W.ncolors; col++) {
         for (int m = wave; m < W.M; m += IBA_WAVES) {
@@ -487,7 +609,7 @@ __device__ __noinline__ void iba_build(const IbaCtx &C, int buf)
                 const double *If = (which ? A.in_info_a : A.in_info_g) + 9 * gm, *er = A.ierr + 15 * gm + (which ? 12 : 9);
                 const int base = which ? 12 : 9;
                 const double v = If[3 * r] * er[0] + If[3 * r + 1] * er[1] + If[3 * r + 2] * er[2];
-                if (o1 >= 0) b[o1 + base + r] += v;              // J1 = -I: b1 += -J1^T (-Omega e) ... = +Omega e
+                if (o1 >= 0) b[o1 + base + r] += v;              // J1 = -I: b1 += -J1^T (-Omega e) = +Omega e
                 if (o2 >= 0) b[o2 + base + r] -= v;
             }
         }
@@ -495,15 +617,61 @@ __device__ __noinline__ void iba_build(const IbaCtx &C, int buf)
     }
 }
 
-// One LM trial: (Hll + lambda)^-1, S = H + lambda I - sum W D^-1 W^T, LDL^T, landmark back-substitution, oplus into buffer buf^1.
-// Returns (block-uniform) ok of the linear solve; *scale_out = computeScale's sum (levenberg.cpp:187-194).
-__device__ __noinline__ bool iba_trial(const IbaCtx &C, int buf, double lambda, double *lds, double *red, double *scale_out)
+// One chunk of one keyframe pair's shared landmarks -> partial W_j D^-1 W_i^T (6x6) and, on the diagonal pairs, W_i D^-1 b_l.
+// HALF 0: rows 0..2 + the right-hand side, HALF 1: rows 3..5.
+template <int HALF>
+__device__ __forceinline__ void pair_task(const IbaCtx &C, int4 task, bool diag, double *out)
 {
     const IbaWin &W = *C.W; const IbaArgs &A = *C.A;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = W.n;
+    const int lane = threadIdx.x & 63;
+    const int2 *pair_ent = A.pair_ent + W.pent_off;
+    constexpr int NB = HALF ? 0 : 6;
+    double acc[18 + NB + 1];
+#pragma unroll
+    for (int q = 0; q < 18 + NB; q++) acc[q] = 0.0;
+    for (int t = task.y + lane; t < task.z; t += 64) {
+        const int2 en = pair_ent[t];
+        const size_t gi = (size_t)W.e_off + en.x, gj = (size_t)W.e_off + en.y;
+        const size_t gl = (size_t)W.pt_off + A.edge_point[gi];
+        const double *Wi = A.W + 18 * gi, *Wj = A.W + 18 * gj + 9 * HALF, *Di = A.Dinv + 6 * gl;
+        const double d00 = Di[0], d10 = Di[1], d11 = Di[2], d20 = Di[3], d21 = Di[4], d22 = Di[5];
+        double wi[18];
+#pragma unroll
+        for (int q = 0; q < 18; q++) wi[q] = Wi[q];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const double w0 = Wj[3 * a], w1 = Wj[3 * a + 1], w2 = Wj[3 * a + 2];
+            const double y0 = w0 * d00 + w1 * d10 + w2 * d20, y1 = w0 * d10 + w1 * d11 + w2 * d21, y2 = w0 * d20 + w1 * d21 + w2 * d22;
+#pragma unroll
+            for (int c = 0; c < 6; c++) acc[6 * a + c] += y0 * wi[3 * c] + y1 * wi[3 * c + 1] + y2 * wi[3 * c + 2];
+        }
+        if (!HALF && diag) {
+            const double *db = A.db + 3 * gl;
+#pragma unroll
+            for (int a = 0; a < 6; a++) acc[18 + a] += wi[3 * a] * db[0] + wi[3 * a + 1] * db[1] + wi[3 * a + 2] * db[2];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 18 + NB; q++) acc[q] = wave_sum_f64_dpp(acc[q]);
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 18; q++) out[18 * HALF + q] = acc[q];
+#pragma unroll
+        for (int q = 0; q < NB; q++) out[36 + q] = acc[18 + q];
+    }
+}
+
+// One LM trial: (Hll + lambda)^-1, S = H + lambda I - sum W D^-1 W^T, LDL^T, landmark back-substitution, oplus into buffer buf^1.
+// Returns (team-uniform) ok of the linear solve; the return value of *scale_part is this THREAD's share of computeScale's sum
+// (levenberg.cpp:187-194).
+__device__ __noinline__ bool iba_trial(const IbaCtx &C, Team &T, int buf, double lambda, double *lds, double *scale_part)
+{
+    const IbaWin &W = *C.W; const IbaArgs &A = *C.A;
+    const long long t_begin = clock64();
+    const int tid = threadIdx.x, n = W.n;
     double *H = A.H + W.h_off, *S = A.S + W.h_off, *b = A.b + W.x_off, *bs = A.bs + W.x_off, *x = A.x + W.x_off;
     const int *pt_start = A.pt_start + W.ptstart_off;
-    for (int l = tid; l < W.L; l += IBA_THREADS) {
+    for (int l = (T.gtid >> 3); l < W.L && (tid & 7) == 0; l += (T.gsize >> 3)) {          // the lane that wrote Hll / bl in iba_build
         const size_t gl = (size_t)W.pt_off + l;
         double *Di = A.Dinv + 6 * gl, *db = A.db + 3 * gl;
         if (pt_start[l + 1] == pt_start[l]) { for (int i = 0; i < 6; i++) Di[i] = 0.0; for (int i = 0; i < 3; i++) db[i] = 0.0; continue; }
@@ -514,74 +682,80 @@ __device__ __noinline__ bool iba_trial(const IbaCtx &C, int buf, double lambda, 
         Di[0] = I[0]; Di[1] = I[3]; Di[2] = I[4]; Di[3] = I[6]; Di[4] = I[7]; Di[5] = I[8];       // lower triangle of the inverse
         mv3(I, bl, db);
     }
-    for (int i = tid; i < n * n; i += IBA_THREADS) { const int r = i / n, c = i - r * n; S[i] = H[i] + (r == c ? lambda : 0.0); }
-    for (int i = tid; i < n; i += IBA_THREADS) bs[i] = b[i];
-    __syncthreads();
-    // Schur complement, one wave per pair of free keyframes (i <= j): block (j, i) of the lower triangle
-    const int *pair_start = A.pair_start + W.pairstart_off;
-    const int2 *pair_ent = A.pair_ent + W.pent_off;
-    const int nf = W.nfree;
-    for (int p = wave; p < W.npairs; p += IBA_WAVES) {
-        // p -> (i, j), row-major over the upper triangle
-        int i = 0, rem = p;
-        while (rem >= nf - i) { rem -= nf - i; i++; }
-        const int j = i + rem;
-        const int oi = A.kf_xoff[W.kf_off + A.free_kf[W.free_off + i]], oj = A.kf_xoff[W.kf_off + A.free_kf[W.free_off + j]];
-        double acc[42];
-#pragma unroll
-        for (int q = 0; q < 42; q++) acc[q] = 0.0;
-        for (int t = pair_start[p] + lane; t < pair_start[p + 1]; t += 64) {
-            const int2 en = pair_ent[t];
-            const size_t gi = (size_t)W.e_off + en.x, gj = (size_t)W.e_off + en.y;
-            const size_t gl = (size_t)W.pt_off + A.edge_point[gi];
-            const double *Wi = A.W + 18 * gi, *Wj = A.W + 18 * gj, *Di = A.Dinv + 6 * gl;
-            const double d00 = Di[0], d10 = Di[1], d11 = Di[2], d20 = Di[3], d21 = Di[4], d22 = Di[5];
-            double wi[18];
-#pragma unroll
-            for (int q = 0; q < 18; q++) wi[q] = Wi[q];
-#pragma unroll
-            for (int a = 0; a < 6; a++) {
-                const double w0 = Wj[3 * a], w1 = Wj[3 * a + 1], w2 = Wj[3 * a + 2];
-                const double y0 = w0 * d00 + w1 * d10 + w2 * d20, y1 = w0 * d10 + w1 * d11 + w2 * d21, y2 = w0 * d20 + w1 * d21 + w2 * d22;
-#pragma unroll
-                for (int c = 0; c < 6; c++) acc[6 * a + c] += y0 * wi[3 * c] + y1 * wi[3 * c + 1] + y2 * wi[3 * c + 2];
-            }
-            if (i == j) {
-                const double *db = A.db + 3 * gl;
-#pragma unroll
-                for (int a = 0; a < 6; a++) acc[36 + a] += wi[3 * a] * db[0] + wi[3 * a + 1] * db[1] + wi[3 * a + 2] * db[2];
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 42; q++) acc[q] = wave_sum_f64_dpp(acc[q]);
-        if (lane == 0) {
-            for (int a = 0; a < 6; a++) {
-                for (int c = 0; c < 6; c++) S[(size_t)(oj + a) * n + oi + c] -= acc[6 * a + c];
-                if (i == j) bs[oi + a] -= acc[36 + a];
-            }
-        }
+    if (T.g == 0) {
+        for (int i = tid; i < n * n; i += IBA_THREADS) { const int r = i / n, c = i - r * n; S[i] = H[i] + (r == c ? lambda : 0.0); }
+        for (int i = tid; i < n; i += IBA_THREADS) bs[i] = b[i];
     }
-    __syncthreads();
-    const bool ok = n > 0 ? ldlt_solve_wg(S, n, n, bs, x, lds, A.max_n) : true;
-    __syncthreads();
+    team_sync(T);
+    // Schur complement partials: (pair of free keyframes i <= j, chunk of the landmarks both see), two waves per chunk
+    {
+        const int4 *ptask = A.pair_task + W.ptask_off;
+        double *ppart = A.ppart + 42 * (size_t)W.ptask_off;
+        const int nf = W.nfree;
+        for (int t = T.gwave; t < 2 * W.nptask; t += T.gwaves) {
+            const int4 task = ptask[t >> 1];
+            const bool diag = task.w != 0;
+            if (t & 1) pair_task<1>(C, task, diag, ppart + 42 * (size_t)(t >> 1));
+            else pair_task<0>(C, task, diag, ppart + 42 * (size_t)(t >> 1));
+        }
+        (void)nf;
+    }
+    team_sync(T);
+    bool ok = true;
+    long long t_schur = 0, t_ldlt = 0;
+    if (T.g == 0) {
+        // combine: block (j, i) of the lower triangle -= sum of the pair's chunks, in order
+        const int *pts_ = A.pair_task_start + W.ptstart2_off;
+        const double *ppart = A.ppart + 42 * (size_t)W.ptask_off;
+        const int nf = W.nfree;
+        for (int idx = tid; idx < W.npairs * 42; idx += IBA_THREADS) {
+            const int p = idx / 42, q = idx - 42 * p;
+            if (pts_[p + 1] == pts_[p]) continue;
+            int i = 0, rem = p;
+            while (rem >= nf - i) { rem -= nf - i; i++; }
+            const int j = i + rem;
+            if (q >= 36 && i != j) continue;
+            double s = 0;
+            for (int t = pts_[p]; t < pts_[p + 1]; t++) s += ppart[42 * (size_t)t + q];
+            const int oi = A.kf_xoff[W.kf_off + A.free_kf[W.free_off + i]], oj = A.kf_xoff[W.kf_off + A.free_kf[W.free_off + j]];
+            if (q >= 36) bs[oi + q - 36] -= s;
+            else { const int a = q / 6, c = q - 6 * a; S[(size_t)(oj + a) * n + oi + c] -= s; }
+        }
+        __syncthreads();
+        t_schur = clock64();
+        ok = n > 0 ? ldlt_solve_wg(S, n, n, bs, x, lds, A.max_n) : true;
+        if (tid == 0) A.okflag[T.w] = ok ? 1 : 0;
+        t_ldlt = clock64();
+    }
+    team_sync(T);
+    ok = A.okflag[T.w] != 0;
     const double *cur_pts = A.pts + buf * A.pts_stride + (size_t)W.pt_off * 3;
     double *new_pts = A.pts + (buf ^ 1) * A.pts_stride + (size_t)W.pt_off * 3;
     double part = 0.0;
-    for (int l = tid; l < W.L; l += IBA_THREADS) {
+    for (int l0 = (T.gtid >> 3); l0 < ((W.L + 7) & ~7); l0 += (T.gsize >> 3)) {      // 8 lanes per landmark, whole waves stay in the loop
+        const int l = min(l0, W.L - 1), sub = tid & 7;
         const size_t gl = (size_t)W.pt_off + l;
         double *xl = A.xl + 3 * gl;
-        const bool active = pt_start[l + 1] > pt_start[l];
+        const bool active = l0 < W.L && pt_start[l + 1] > pt_start[l];
+        double cl[3] = {0, 0, 0};
         if (ok && active) {                                        // block_solver.hpp:461-481 (skipped when the pose solve failed: x stays stale)
-            const double *bl = A.bl + 3 * gl, *Di = A.Dinv + 6 * gl;
-            double cl[3] = {bl[0], bl[1], bl[2]};
-            for (int e = pt_start[l]; e < pt_start[l + 1]; e++) {
+            for (int e = pt_start[l] + sub; e < pt_start[l + 1]; e += 8) {
                 const size_t ge = (size_t)W.e_off + e;
                 const int o = A.kf_xoff[W.kf_off + A.edge_kf[ge]];
                 if (o < 0) continue;
                 const double *We = A.W + 18 * ge, *xp = x + o;
+#pragma unroll
                 for (int c = 0; c < 3; c++)
+#pragma unroll
                     for (int a = 0; a < 6; a++) cl[c] -= We[3 * a + c] * xp[a];
             }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) cl[c] = oct_allreduce_f64(cl[c]);
+        if (sub != 0 || l0 >= W.L) continue;
+        if (ok && active) {
+            const double *bl = A.bl + 3 * gl, *Di = A.Dinv + 6 * gl;
+            cl[0] += bl[0]; cl[1] += bl[1]; cl[2] += bl[2];
             xl[0] = Di[0] * cl[0] + Di[1] * cl[1] + Di[3] * cl[2];
             xl[1] = Di[1] * cl[0] + Di[2] * cl[1] + Di[4] * cl[2];
             xl[2] = Di[3] * cl[0] + Di[4] * cl[1] + Di[5] * cl[2];
@@ -592,12 +766,12 @@ __device__ __noinline__ bool iba_trial(const IbaCtx &C, int buf, double lambda, 
             if (active) part += dx * (lambda * dx + A.bl[3 * gl + a]);
         }
     }
-    for (int i = tid; i < n; i += IBA_THREADS) part += x[i] * (lambda * x[i] + b[i]);
+    if (T.g == 0) for (int i = tid; i < n; i += IBA_THREADS) part += x[i] * (lambda * x[i] + b[i]);
     // oplus on the keyframe vertices (ImuCamPose::Update, G2oTypes.cc:192-220; the velocity / bias vertices add)
     const double *cur_kf = A.kfs + buf * A.kfs_stride + (size_t)W.kf_off * IBA_KF;
     double *new_kf = A.kfs + (buf ^ 1) * A.kfs_stride + (size_t)W.kf_off * IBA_KF;
     double *new_cam = A.cam + (buf ^ 1) * A.cam_stride + (size_t)W.kf_off * 12;
-    for (int k = tid; k < W.n_kf; k += IBA_THREADS) {
+    for (int k = T.gsize - 1 - T.gtid; k < W.n_kf; k += T.gsize) {
         double s[IBA_KF];
         for (int i = 0; i < IBA_KF; i++) s[i] = cur_kf[IBA_KF * k + i];
         const int o = A.kf_xoff[W.kf_off + k];
@@ -613,7 +787,12 @@ __device__ __noinline__ bool iba_trial(const IbaCtx &C, int buf, double lambda, 
         for (int i = 0; i < IBA_KF; i++) new_kf[IBA_KF * k + i] = s[i];
         cam_pose(W, s, new_cam + 12 * k);
     }
-    *scale_out = block_sum(part, red);        // its barriers also publish the new estimates
+    team_sync(T);                              // the new estimates are complete
+    *scale_part = part;
+    if (A.prof && T.g == 0 && threadIdx.x == 0) {
+        long long *pf = A.prof + 8 * T.w;
+        pf[2] += t_schur - t_begin; pf[3] += t_ldlt - t_schur; pf[4] += clock64() - t_ldlt;
+    }
     return ok;
 }
 }  // namespace
@@ -621,9 +800,18 @@ __device__ __noinline__ bool iba_trial(const IbaCtx &C, int buf, double lambda, 
 __global__ __launch_bounds__(IBA_THREADS) void k_iba_solve(IbaArgs A)
 {
     extern __shared__ double lds[];
-    __shared__ double red[IBA_WAVES];
-    const IbaWin &W = A.win[blockIdx.x];
+    __shared__ double red[2 * IBA_WAVES];
+    // blockIdx -> (window, member): with G > 1 the members of a team sit on ONE XCD (workgroups are dealt round-robin over the 8
+    // XCDs), so that the team's scratch stays in that XCD's L2; correctness does not depend on it (agent-scope fences)
+    int w, g;
+    if (A.G == 1) { w = blockIdx.x; g = 0; }
+    else { const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3; w = xcd + 8 * (slot / A.G); g = slot % A.G; }
+    if (w >= A.n_windows) return;
+    const IbaWin &W = A.win[w];
     const int tid = threadIdx.x;
+    Team T;
+    T.w = w; T.g = g; T.G = A.G; T.gtid = g * IBA_THREADS + tid; T.gsize = A.G * IBA_THREADS; T.gwave = g * IBA_WAVES + (tid >> 6); T.gwaves = A.G * IBA_WAVES;
+    T.counter = A.counters + w; T.epoch = 0; T.wpart = A.wpart + (size_t)w * 2 * IBA_MAXG * 2; T.slot = 0; T.fail = A.fail + w;
     IbaCtx C;
     C.W = &W; C.A = &A;
     C.delta_m = (double)sqrtf(5.991f); C.dsqr_m = C.delta_m * C.delta_m;        // thHuberMono etc. are floats (Optimizer.cc:4893-4896)
@@ -633,25 +821,35 @@ __global__ __launch_bounds__(IBA_THREADS) void k_iba_solve(IbaArgs A)
     {
         const double *kf0 = A.kfs + (size_t)W.kf_off * IBA_KF;
         double *cam0 = A.cam + (size_t)W.kf_off * 12;
-        for (int k = tid; k < W.n_kf; k += IBA_THREADS) cam_pose(W, kf0 + IBA_KF * k, cam0 + 12 * k);
+        for (int k = T.gtid; k < W.n_kf; k += T.gsize) cam_pose(W, kf0 + IBA_KF * k, cam0 + 12 * k);
     }
-    __syncthreads();
-    double chi = iba_errors(C, cur, red);                  // computeActiveErrors + activeRobustChi2 (:5046-5047)
+    team_sync(T);
+    long long t_err = 0, t_build = 0;
+    const long long t_k0 = clock64();
+    double chi = iba_errors(C, T, cur), zero = 0.0;        // computeActiveErrors + activeRobustChi2 (:5046-5047)
+    team_sum2(T, chi, zero, red);
+    t_err += clock64() - t_k0;
     const double err0 = chi;
     double lambda = A.lambda_init, ni = 2.0, last_chi = chi;
     int nbad = 0, trials = 0, its = 0;
     for (int it = 0; it < A.iterations; it++) {            // SparseOptimizer::optimize -> OptimizationAlgorithmLevenberg::solve
-        if (it > 0) chi = iba_errors(C, cur, red);         // levenberg.cpp:71 (the stored errors may be a rejected trial's)
+        long long t0 = clock64();
+        if (it > 0) { chi = iba_errors(C, T, cur); zero = 0.0; team_sum2(T, chi, zero, red); }      // levenberg.cpp:71 (the stored errors may be a rejected trial's)
         double current_chi = chi;
         const double ini_chi = chi;
-        iba_build(C, cur);
+        long long t1 = clock64();
+        iba_build(C, T, cur);
+        t_err += t1 - t0; t_build += clock64() - t1;
         if (it == 0) { lambda = A.lambda_init; ni = 2.0; nbad = 0; }
         double rho = 0.0;
         int qmax = 0;
         do {
             double scale;
-            const bool ok = iba_trial(C, cur, lambda, lds, red, &scale);
-            double tmp = iba_errors(C, cur ^ 1, red);
+            const bool ok = iba_trial(C, T, cur, lambda, lds, &scale);
+            t0 = clock64();
+            double tmp = iba_errors(C, T, cur ^ 1);
+            team_sum2(T, tmp, scale, red);
+            t_err += clock64() - t0;
             last_chi = tmp;
             if (!ok) tmp = DBL_MAX;
             rho = (current_chi - tmp) / (scale + 1e-3);
@@ -664,9 +862,9 @@ __global__ __launch_bounds__(IBA_THREADS) void k_iba_solve(IbaArgs A)
                 lambda *= ni; ni *= 2;
             }
             qmax++; trials++;
-        } while (rho < 0 && qmax < A.max_trials);
+        } while (rho < 0 && qmax < A.max_trials && !__hip_atomic_load(T.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         its++;
-        if (qmax == A.max_trials || rho == 0) break;
+        if (qmax == A.max_trials || rho == 0 || __hip_atomic_load(T.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
         if ((ini_chi - current_chi) * 1e3 < ini_chi) nbad++; else nbad = 0;
         if (nbad >= 3) break;
     }
@@ -674,7 +872,7 @@ __global__ __launch_bounds__(IBA_THREADS) void k_iba_solve(IbaArgs A)
     const double *cam = A.cam + cur * A.cam_stride + (size_t)W.kf_off * 12;
     const double *pts = A.pts + cur * A.pts_stride + (size_t)W.pt_off * 3;
     double nout = 0.0;
-    for (int e = tid; e < W.E; e += IBA_THREADS) {
+    for (int e = T.gtid; e < W.E; e += T.gsize) {
         const size_t ge = (size_t)W.e_off + e;
         const double c2 = A.chi2[ge];
         bool out;
@@ -688,15 +886,17 @@ __global__ __launch_bounds__(IBA_THREADS) void k_iba_solve(IbaArgs A)
         A.outlier[ge] = out ? 1 : 0;
         nout += out ? 1.0 : 0.0;
     }
-    nout = block_sum(nout, red);
+    zero = 0.0;
+    team_sum2(T, nout, zero, red);
     if (cur == 1) {                                         // results are read from buffer 0
         double *k0 = A.kfs + (size_t)W.kf_off * IBA_KF, *p0 = A.pts + (size_t)W.pt_off * 3;
         const double *k1 = k0 + A.kfs_stride, *p1 = p0 + A.pts_stride;
-        for (int i = tid; i < W.n_kf * IBA_KF; i += IBA_THREADS) k0[i] = k1[i];
-        for (int i = tid; i < W.L * 3; i += IBA_THREADS) p0[i] = p1[i];
+        for (int i = T.gtid; i < W.n_kf * IBA_KF; i += T.gsize) k0[i] = k1[i];
+        for (int i = T.gtid; i < W.L * 3; i += T.gsize) p0[i] = p1[i];
     }
-    if (tid == 0) {
-        orbhip_iba_stats &st = A.stats[blockIdx.x];
+    if (A.prof && g == 0 && tid == 0) { long long *pf = A.prof + 8 * w; pf[0] = t_err; pf[1] = t_build; pf[5] = clock64() - t_k0; }
+    if (g == 0 && tid == 0) {
+        orbhip_iba_stats &st = A.stats[w];
         st.iterations_run = its; st.lm_trials = trials; st.n_outliers = (int)nout;
         st.err = err0; st.err_end = last_chi;
         const float fe = (float)err0, fl = (float)last_chi;
@@ -737,8 +937,9 @@ extern "C" int orbhip_inertial_ba_solve_batch(orbhip_ctx *ctx, const orbhip_iba_
     if (n_windows == 0) return ORBHIP_OK;
     if (params->iterations < 0 || params->max_trials < 1 || !(params->lambda_init > 0)) return ORBHIP_E_BADARG;
     std::vector<IbaWin> hw(n_windows);
-    std::vector<int> kf_xoff, free_kf, edge_kf, edge_point, pt_start, kf_start, kf_edges, pair_start, in1, in2, in_color;
+    std::vector<int> kf_xoff, free_kf, edge_kf, edge_point, pt_start, kf_edges, in1, in2, in_color, kf_task_start, pair_task_start;
     std::vector<int2> pair_ent;
+    std::vector<int4> kf_task, pair_task;
     std::vector<uint8_t> kf_imu, edge_stereo, edge_close, in_robust;
     std::vector<double> edge_obs, edge_is2, in_pre, in_info, in_info_g, in_info_a, kfs, pts;
     size_t sumKF = 0, sumL = 0, sumE = 0, sumM = 0, sumX = 0, sumH = 0;
@@ -754,8 +955,10 @@ extern "C" int orbhip_inertial_ba_solve_batch(orbhip_ctx *ctx, const orbhip_iba_
         memset(&W, 0, sizeof(W));
         W.n_kf = g.n_kf; W.L = g.n_points; W.E = g.n_edges; W.M = g.n_inertial;
         W.kf_off = (int)sumKF; W.pt_off = (int)sumL; W.e_off = (int)sumE; W.m_off = (int)sumM; W.x_off = (int)sumX; W.h_off = (long long)sumH;
-        W.free_off = (int)free_kf.size(); W.ptstart_off = (int)pt_start.size(); W.kfstart_off = (int)kf_start.size();
-        W.kfe_off = (int)kf_edges.size(); W.pairstart_off = (int)pair_start.size(); W.pent_off = (long long)pair_ent.size();
+        W.free_off = (int)free_kf.size(); W.ptstart_off = (int)pt_start.size();
+        W.kfe_off = (int)kf_edges.size(); W.pent_off = (long long)pair_ent.size();
+        W.ktask_off = (int)kf_task.size(); W.ktstart_off = (int)kf_task_start.size();
+        W.ptask_off = (int)pair_task.size(); W.ptstart2_off = (int)pair_task_start.size();
         memcpy(W.Rcb, g.Rcb, sizeof(W.Rcb)); memcpy(W.tcb, g.tcb, sizeof(W.tcb));
         W.fx = g.fx; W.fy = g.fy; W.cx = g.cx; W.cy = g.cy; W.bf = g.bf;
         std::vector<int> fidx(g.n_kf, -1);
@@ -772,22 +975,34 @@ extern "C" int orbhip_inertial_ba_solve_batch(orbhip_ctx *ctx, const orbhip_iba_
         // edges: grouped by point (the reference creates them point by point, Optimizer.cc:4914-5034)
         std::vector<int> pstart(g.n_points + 1, 0);
         std::vector<std::vector<int>> kfe(W.nfree);
+        const size_t e_base = edge_kf.size();
+        edge_kf.resize(e_base + g.n_edges); edge_point.resize(e_base + g.n_edges); edge_obs.resize(3 * (e_base + g.n_edges));
+        edge_is2.resize(e_base + g.n_edges); edge_stereo.resize(e_base + g.n_edges); edge_close.resize(e_base + g.n_edges);
         for (int e = 0; e < g.n_edges; e++) {
             const int k = g.edge_kf[e], l = g.edge_point[e];
             if (k < 0 || k >= g.n_kf || l < 0 || l >= g.n_points || (e && l < g.edge_point[e - 1])) return ORBHIP_E_BADARG;
             pstart[l + 1]++;
             if (fidx[k] >= 0) kfe[fidx[k]].push_back(e);
-            edge_kf.push_back(k); edge_point.push_back(l);
-            edge_obs.push_back(g.edge_obs[3 * e]); edge_obs.push_back(g.edge_obs[3 * e + 1]); edge_obs.push_back(g.edge_obs[3 * e + 2]);
-            edge_is2.push_back(g.edge_inv_sigma2[e]);
-            edge_stereo.push_back(g.edge_stereo[e] ? 1 : 0);
-            edge_close.push_back(g.edge_close ? (g.edge_close[e] ? 1 : 0) : 0);
+            edge_kf[e_base + e] = k; edge_point[e_base + e] = l;
+            edge_stereo[e_base + e] = g.edge_stereo[e] ? 1 : 0;
+            edge_close[e_base + e] = g.edge_close ? (g.edge_close[e] ? 1 : 0) : 0;
+        }
+        if (g.n_edges) {
+            memcpy(edge_obs.data() + 3 * e_base, g.edge_obs, 24 * (size_t)g.n_edges);
+            memcpy(edge_is2.data() + e_base, g.edge_inv_sigma2, 8 * (size_t)g.n_edges);
         }
         for (int l = 0; l < g.n_points; l++) pstart[l + 1] += pstart[l];
         pt_start.insert(pt_start.end(), pstart.begin(), pstart.end());
-        int acc = 0;
-        for (int f = 0; f < W.nfree; f++) { kf_start.push_back(acc); kf_edges.insert(kf_edges.end(), kfe[f].begin(), kfe[f].end()); acc += (int)kfe[f].size(); }
-        kf_start.push_back(acc);
+        // per-keyframe edge lists, cut into chunks of <= IBA_KF_CHUNK edges (one wave pair each)
+        for (int f = 0; f < W.nfree; f++) {
+            kf_task_start.push_back((int)kf_task.size() - W.ktask_off);
+            const int base = (int)kf_edges.size() - W.kfe_off;
+            kf_edges.insert(kf_edges.end(), kfe[f].begin(), kfe[f].end());
+            for (int o = 0; o < (int)kfe[f].size(); o += IBA_KF_CHUNK)
+                kf_task.push_back(make_int4(f, base + o, base + std::min<int>(o + IBA_KF_CHUNK, (int)kfe[f].size()), 0));
+        }
+        kf_task_start.push_back((int)kf_task.size() - W.ktask_off);
+        W.nktask = (int)kf_task.size() - W.ktask_off;
         // pair lists: for every point, every (i <= j) pair of the free keyframes that see it
         W.npairs = W.nfree * (W.nfree + 1) / 2;
         std::vector<std::vector<int2>> pl(W.npairs);
@@ -804,9 +1019,16 @@ extern "C" int orbhip_inertial_ba_solve_batch(orbhip_ctx *ctx, const orbhip_iba_
                     pl[pair_id(i, j)].push_back(make_int2(sw ? fe[b2].second : fe[a].second, sw ? fe[a].second : fe[b2].second));
                 }
         }
-        int pacc = 0;
-        for (int p = 0; p < W.npairs; p++) { pair_start.push_back(pacc); pair_ent.insert(pair_ent.end(), pl[p].begin(), pl[p].end()); pacc += (int)pl[p].size(); }
-        pair_start.push_back(pacc);
+        for (int i = 0, p = 0; i < W.nfree; i++)
+            for (int j = i; j < W.nfree; j++, p++) {
+                pair_task_start.push_back((int)pair_task.size() - W.ptask_off);
+                const int base = (int)((long long)pair_ent.size() - W.pent_off);
+                pair_ent.insert(pair_ent.end(), pl[p].begin(), pl[p].end());
+                for (int o = 0; o < (int)pl[p].size(); o += IBA_PAIR_CHUNK)
+                    pair_task.push_back(make_int4(p, base + o, base + std::min<int>(o + IBA_PAIR_CHUNK, (int)pl[p].size()), i == j ? 1 : 0));
+            }
+        pair_task_start.push_back((int)pair_task.size() - W.ptask_off);
+        W.nptask = (int)pair_task.size() - W.ptask_off;
         // inertial edges + greedy colouring (edges of one colour share no keyframe)
         std::vector<std::vector<int>> used(g.n_kf);
         for (int m = 0; m < g.n_inertial; m++) {
@@ -818,10 +1040,12 @@ extern "C" int orbhip_inertial_ba_solve_batch(orbhip_ctx *ctx, const orbhip_iba_
             used[k1].push_back(c); used[k2].push_back(c);
             W.ncolors = std::max(W.ncolors, c + 1);
             in1.push_back(k1); in2.push_back(k2); in_color.push_back(c); in_robust.push_back(g.in_robust[m] ? 1 : 0);
-            in_pre.insert(in_pre.end(), g.in_preint + (size_t)IBA_PRE * m, g.in_preint + (size_t)IBA_PRE * (m + 1));
-            in_info.insert(in_info.end(), g.in_info + 81 * (size_t)m, g.in_info + 81 * (size_t)(m + 1));
-            in_info_g.insert(in_info_g.end(), g.in_info_g + 9 * (size_t)m, g.in_info_g + 9 * (size_t)(m + 1));
-            in_info_a.insert(in_info_a.end(), g.in_info_a + 9 * (size_t)m, g.in_info_a + 9 * (size_t)(m + 1));
+        }
+        if (g.n_inertial) {
+            in_pre.insert(in_pre.end(), g.in_preint, g.in_preint + (size_t)IBA_PRE * g.n_inertial);
+            in_info.insert(in_info.end(), g.in_info, g.in_info + 81 * (size_t)g.n_inertial);
+            in_info_g.insert(in_info_g.end(), g.in_info_g, g.in_info_g + 9 * (size_t)g.n_inertial);
+            in_info_a.insert(in_info_a.end(), g.in_info_a, g.in_info_a + 9 * (size_t)g.n_inertial);
         }
         kfs.insert(kfs.end(), kf_state_inout[w], kf_state_inout[w] + (size_t)IBA_KF * g.n_kf);
         if (g.n_points) pts.insert(pts.end(), points_inout[w], points_inout[w] + 3 * (size_t)g.n_points);
@@ -830,7 +1054,8 @@ extern "C" int orbhip_inertial_ba_solve_batch(orbhip_ctx *ctx, const orbhip_iba_
     Blob B;
     const size_t o_win = B.put(hw), o_xoff = B.put(kf_xoff), o_imu = B.put(kf_imu), o_free = B.put(free_kf), o_ekf = B.put(edge_kf),
                  o_ept = B.put(edge_point), o_obs = B.put(edge_obs), o_is2 = B.put(edge_is2), o_est = B.put(edge_stereo), o_ecl = B.put(edge_close),
-                 o_pst = B.put(pt_start), o_kst = B.put(kf_start), o_ked = B.put(kf_edges), o_prs = B.put(pair_start), o_pre = B.put(pair_ent),
+                 o_pst = B.put(pt_start), o_ked = B.put(kf_edges), o_pre = B.put(pair_ent), o_ktk = B.put(kf_task), o_kts = B.put(kf_task_start),
+                 o_ptk = B.put(pair_task), o_pts = B.put(pair_task_start),
                  o_in1 = B.put(in1), o_in2 = B.put(in2), o_col = B.put(in_color), o_rob = B.put(in_robust), o_ipr = B.put(in_pre),
                  o_inf = B.put(in_info), o_ig = B.put(in_info_g), o_ia = B.put(in_info_a);
     const size_t constant_bytes = al256(B.bytes.size());
@@ -841,7 +1066,10 @@ extern "C" int orbhip_inertial_ba_solve_batch(orbhip_ctx *ctx, const orbhip_iba_
                  w_W = take(144 * sumE), w_Hll = take(48 * sumL), w_bl = take(24 * sumL), w_Di = take(48 * sumL), w_db = take(24 * sumL), w_xl = take(24 * sumL),
                  w_ierr = take(120 * sumM), w_ichi = take(24 * sumM), w_Jb = take(1728 * sumM), w_OJ = take(1728 * sumM), w_Oe = take(120 * sumM),
                  w_H = take(8 * sumH), w_S = take(8 * sumH), w_b = take(8 * sumX), w_bs = take(8 * sumX), w_x = take(8 * sumX), w_out = take(sumE),
-                 w_stats = take(sizeof(orbhip_iba_stats) * n_windows);
+                 w_kpart = take(27 * 8 * kf_task.size()), w_ppart = take(42 * 8 * pair_task.size()),
+                 w_stats = take(sizeof(orbhip_iba_stats) * n_windows), w_prof = take(64 * (size_t)n_windows),
+                 w_sync = take((4 + 4 + 4) * (size_t)n_windows), w_wpart = take(8 * 2 * IBA_MAXG * 2 * (size_t)n_windows);
+    const bool want_prof = getenv("ORBHIP_IBA_PROF") != nullptr;
     ITRY(hipSetDevice(orbhip_ctx_device_internal(ctx)));
     hipStream_t s = orbhip_ctx_stream_internal(ctx);
     uint8_t *d = (uint8_t *)orbhip_ctx_scratch_internal(ctx, off);
@@ -852,14 +1080,16 @@ extern "C" int orbhip_inertial_ba_solve_batch(orbhip_ctx *ctx, const orbhip_iba_
     ITRY(hipMemsetAsync(d + w_xl, 0, 24 * sumL + 8, s));
     ITRY(hipMemsetAsync(d + w_x, 0, 8 * sumX + 8, s));
     ITRY(hipMemsetAsync(d + w_W, 0, 144 * sumE + 8, s));
+    ITRY(hipMemsetAsync(d + w_sync, 0, 12 * (size_t)n_windows, s));
     IbaArgs A;
     memset(&A, 0, sizeof(A));
 #define CP(T, o) reinterpret_cast<const T *>(d + (o))
 #define WP(T, o) reinterpret_cast<T *>(d + (o))
     A.win = CP(IbaWin, o_win); A.kf_xoff = CP(int, o_xoff); A.kf_imu = CP(uint8_t, o_imu); A.free_kf = CP(int, o_free);
     A.edge_kf = CP(int, o_ekf); A.edge_point = CP(int, o_ept); A.edge_obs = CP(double, o_obs); A.edge_is2 = CP(double, o_is2);
-    A.edge_stereo = CP(uint8_t, o_est); A.edge_close = CP(uint8_t, o_ecl); A.pt_start = CP(int, o_pst); A.kf_start = CP(int, o_kst);
-    A.kf_edges = CP(int, o_ked); A.pair_start = CP(int, o_prs); A.pair_ent = CP(int2, o_pre); A.in_kf1 = CP(int, o_in1); A.in_kf2 = CP(int, o_in2);
+    A.edge_stereo = CP(uint8_t, o_est); A.edge_close = CP(uint8_t, o_ecl); A.pt_start = CP(int, o_pst);
+    A.kf_edges = CP(int, o_ked); A.pair_ent = CP(int2, o_pre); A.kf_task = CP(int4, o_ktk); A.kf_task_start = CP(int, o_kts);
+    A.pair_task = CP(int4, o_ptk); A.pair_task_start = CP(int, o_pts); A.in_kf1 = CP(int, o_in1); A.in_kf2 = CP(int, o_in2);
     A.in_color = CP(int, o_col); A.in_robust = CP(uint8_t, o_rob); A.in_pre = CP(double, o_ipr); A.in_info = CP(double, o_inf);
     A.in_info_g = CP(double, o_ig); A.in_info_a = CP(double, o_ia);
     A.kfs = WP(double, w_kfs); A.cam = WP(double, w_cam); A.pts = WP(double, w_pts);
@@ -868,22 +1098,54 @@ extern "C" int orbhip_inertial_ba_solve_batch(orbhip_ctx *ctx, const orbhip_iba_
     A.Dinv = WP(double, w_Di); A.db = WP(double, w_db); A.xl = WP(double, w_xl); A.ierr = WP(double, w_ierr); A.ichi2 = WP(double, w_ichi);
     A.Jb = WP(double, w_Jb); A.OJ = WP(double, w_OJ); A.Oe = WP(double, w_Oe); A.H = WP(double, w_H); A.S = WP(double, w_S);
     A.b = WP(double, w_b); A.bs = WP(double, w_bs); A.x = WP(double, w_x); A.outlier = WP(uint8_t, w_out); A.stats = WP(orbhip_iba_stats, w_stats);
+    A.kpart = WP(double, w_kpart); A.ppart = WP(double, w_ppart);
+    A.counters = WP(unsigned, w_sync); A.fail = WP(int, w_sync + 4 * (size_t)n_windows); A.okflag = WP(int, w_sync + 8 * (size_t)n_windows);
+    A.wpart = WP(double, w_wpart);
 #undef CP
 #undef WP
+    if (want_prof) { ITRY(hipMemsetAsync(d + w_prof, 0, 64 * (size_t)n_windows, s)); A.prof = reinterpret_cast<long long *>(d + w_prof); }
     A.iterations = params->iterations; A.max_trials = params->max_trials; A.large = params->large; A.lambda_init = params->lambda_init;
     A.max_n = std::max(max_n, 32);
+    A.n_windows = n_windows;
+    const int device = orbhip_ctx_device_internal(ctx);
     const size_t lds = ba_ldlt_lds_bytes(A.max_n);
-    if (orb_lds_optin((const void *)k_iba_solve, orbhip_ctx_device_internal(ctx), lds) != 0) return ORBHIP_E_HIP;
-    hipLaunchKernelGGL(k_iba_solve, dim3(n_windows), dim3(IBA_THREADS), lds, s, A);
-    ITRY(hipGetLastError());
+    if (orb_lds_optin((const void *)k_iba_solve, device, lds) != 0) return ORBHIP_E_HIP;
+    // team size: every workgroup of a team must be resident (the barrier spins), so teams are only used while the whole grid fits
+    // the device at one 1024-thread workgroup per CU; bigger batches run one workgroup per window
+    int cus = 0, per_cu = 0;
+    ITRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+    ITRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_iba_solve, IBA_THREADS, lds));
+    const int forced = getenv("ORBHIP_IBA_TEAM") ? atoi(getenv("ORBHIP_IBA_TEAM")) : 0;
+    const int slots_per_xcd = std::max(1, (cus / 8) * std::min(per_cu, 1));          // co-resident workgroups per XCD we rely on
+    const int win_per_xcd = (n_windows + 7) / 8;
+    int G = std::min(IBA_MAXG, slots_per_xcd / win_per_xcd);
+    if (forced > 0) G = std::min(forced, G);
+    if (G < 2 || per_cu < 1) G = 1;
+    A.G = G;
+    if (G == 1) {
+        hipLaunchKernelGGL(k_iba_solve, dim3(n_windows), dim3(IBA_THREADS), lds, s, A);
+        ITRY(hipGetLastError());
+    } else {
+        void *kargs[] = {&A};
+        ITRY(hipLaunchCooperativeKernel((const void *)k_iba_solve, dim3(8 * G * win_per_xcd), dim3(IBA_THREADS), kargs, (unsigned)lds, s));
+    }
     std::vector<orbhip_iba_stats> st(n_windows);
     std::vector<double> kfo((size_t)IBA_KF * sumKF), pto(3 * sumL);
     std::vector<uint8_t> outl(sumE);
+    std::vector<int> failv(n_windows);
     ITRY(hipMemcpyAsync(st.data(), d + w_stats, sizeof(orbhip_iba_stats) * n_windows, hipMemcpyDeviceToHost, s));
+    ITRY(hipMemcpyAsync(failv.data(), d + w_sync + 4 * (size_t)n_windows, 4 * (size_t)n_windows, hipMemcpyDeviceToHost, s));
     ITRY(hipMemcpyAsync(kfo.data(), d + w_kfs, 8 * kfo.size(), hipMemcpyDeviceToHost, s));
     if (sumL) ITRY(hipMemcpyAsync(pto.data(), d + w_pts, 8 * pto.size(), hipMemcpyDeviceToHost, s));
     if (sumE) ITRY(hipMemcpyAsync(outl.data(), d + w_out, sumE, hipMemcpyDeviceToHost, s));
     ITRY(hipStreamSynchronize(s));
+    for (int w = 0; w < n_windows; w++)
+        if (failv[w]) { orbhip_set_last_error_internal("inertial BA: a team barrier did not complete (workgroups not co-resident)"); return ORBHIP_E_HIP; }
+    if (want_prof) {
+        long long pf[8];
+        ITRY(hipMemcpy(pf, d + w_prof, 64, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[orbhip iba] G=%d window 0 shader cycles: errors %lld, build %lld, prep+schur %lld, ldlt %lld, update %lld, total %lld\n", G, pf[0], pf[1], pf[2], pf[3], pf[4], pf[5]);
+    }
     for (int w = 0; w < n_windows; w++) {
         const IbaWin &W = hw[w];
         if (!st[w].failed) {                               // "FAIL LOCAL-INERTIAL BA": the reference returns before any write-back (Optimizer.cc:5096-5100)
