@@ -959,12 +959,11 @@ __global__ __launch_bounds__(64) void k_ba_bschur(BaBatch B)
 
 __global__ __launch_bounds__(1024) void k_ba_ldlt(BaBatch B)
 {
-    extern __shared__ double lds[];
     const int g = blockIdx.x;
     BaState &st = B.st[g];
     if (!st.active) return;
     const BaGraphDev &G = B.gd[g];
-    const bool ok = ldlt_solve_wg(B.S + G.s_off, G.ld, G.n, B.bs + (size_t)G.free_off * 6, B.xp + (size_t)G.free_off * 6, lds, B.max_ld);
+    const bool ok = ldlt_solve_wg(B.S + G.s_off, G.ld, G.n, B.bs + (size_t)G.free_off * 6, B.xp + (size_t)G.free_off * 6, B.max_ld);
     if (threadIdx.x == 0) st.ok = ok ? 1 : 0;
 }
 
@@ -1055,7 +1054,7 @@ __global__ __launch_bounds__(64) void k_ba_big_diag(BaBatch B, int p0)
         yv[lane] = y[p0 + lane];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (lane < nb) ldlt_rows<true>(P, U, dv, yv, lane, nb, &s_ok);
+    if (lane < nb) ldlt_rows<true>((lds_f64 *)P, (lds_f64 *)U, (lds_f64 *)dv, (lds_f64 *)yv, lane, nb, &s_ok);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (!s_ok) { if (lane == 0) B.big_fail[g] = 1; return; }
     if (lane < nb) {
@@ -1090,7 +1089,7 @@ __global__ __launch_bounds__(256) void k_ba_big_rows(BaBatch B, int p0)
     }
     __syncthreads();
     if (r < m) {
-        ldlt_rows<false>(P, U, dv, yv, rl, nb, &s_dummy);
+        ldlt_rows<false>((lds_f64 *)P, (lds_f64 *)U, (lds_f64 *)dv, (lds_f64 *)yv, rl, nb, &s_dummy);
         for (int c = 0; c < nb; c++) S[(size_t)(p0 + r) * ld + p0 + c] = P[rl * LD_PP + c];
         y[p0 + r] = yv[rl];
     }

@@ -12,7 +12,7 @@
 #define BA_LDLT_MAXN 480
 #define LD_NB 32
 #define LD_PP 33
-static inline size_t ba_ldlt_lds_bytes(int max_n) { return sizeof(double) * ((size_t)max_n * LD_PP + 2 * (size_t)max_n + LD_NB + 32 * 32); }
+static inline size_t ba_ldlt_lds_bytes(int max_n) { return sizeof(double) * ((size_t)max_n * LD_PP + 3 * (size_t)max_n + LD_NB + 32 * 32); }
 
 // One row of a panel through the nb elimination steps of its diagonal block (right-looking LDL^T without pivoting):
 //   l = a[jj] / d_jj;  a[kk] -= l * U[jj][kk]  (jj < kk <= min(r, nb-1));  a[jj] = l;  y_r -= l * y_jj.
@@ -25,9 +25,23 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
     const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(u >> 32), lane);
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
-template <bool DIAG>
-__device__ __forceinline__ void ldlt_rows(double *P, double *U, double *dv, double *yv, int r, int nb, int *s_ok)
+typedef __attribute__((address_space(3))) double lds_f64;        // explicit LDS pointers: the accesses below must stay ds_read / ds_write
+// 1 / d by v_rcp_f64 + two Newton steps (5 dependent instructions; the compiler's 1.0 / d adds range scaling and a fix-up, 12).
+// Pivots of these systems are far from the denormal / overflow range the extra steps exist for.
+__device__ __forceinline__ double ldlt_rcp(double d)
 {
+#pragma clang fp contract(fast)
+    double r = __builtin_amdgcn_rcp(d);
+    r = r + r * (1.0 - d * r);
+    r = r + r * (1.0 - d * r);
+    return r;
+}
+// FULL: the panel has all LD_NB columns (no per-step column test: straight-line code the scheduler can pipeline).
+// A zero / non-finite pivot only clears *s_ok; the arithmetic runs on (its results are discarded by the caller).
+template <bool DIAG, bool FULL>
+__device__ __forceinline__ void ldlt_rows2(lds_f64 *P, lds_f64 *U, lds_f64 *dv, lds_f64 *yv, int r, int nb, int *s_ok)
+{
+#pragma clang fp contract(fast)      // a -= l * u as one v_fma_f64 (the library builds with -ffp-contract=off for the bit-exact ORB paths)
     // No per-element predicates: entries right of the diagonal (kk > r) and, in a partial last panel, columns >= nb carry
     // garbage that is never read back (keeps the unrolled code at ~3 instructions per update).
     double a[LD_NB];
@@ -38,41 +52,152 @@ __device__ __forceinline__ void ldlt_rows(double *P, double *U, double *dv, doub
     bool ok = true;
 #pragma unroll
     for (int jj = 0; jj < LD_NB; jj++) {
-        if (jj >= nb || !ok) continue;                      // uniform
+        if (!FULL && jj >= nb) continue;                    // uniform
         if (DIAG) {
             U[jj * LD_NB + r] = a[jj];                      // unscaled column jj (entry jj = the pivot)
             if (r == jj) yv[jj] = yr;                        // y_jj is final
         }
-        // DIAG: pivot and y_jj straight from lane jj's registers (no LDS round trip on the critical path)
+        // DIAG: pivot, y_jj and the unscaled column jj (U[jj][kk] = A[kk][jj] = lane kk's a[jj]) straight from the lanes' registers:
+        // no LDS round trip on the critical path, and the broadcasts issue while the reciprocal is still in flight
         const double d = DIAG ? readlane_f64(a[jj], jj) : dv[jj];
         if (DIAG) {
-            if (d == 0.0 || !isfinite(d)) { ok = false; if (r == 0) *s_ok = 0; continue; }
+            ok = ok && d != 0.0 && isfinite(d);
             if (r == jj) dv[jj] = d;
         }
         const double yj = DIAG ? readlane_f64(yr, jj) : yv[jj];
-        const double l = a[jj] / d;
+        const double l = a[jj] * ldlt_rcp(d);                // one reciprocal per column, not a division per entry
         yr -= l * yj;
 #pragma unroll
-        for (int kk = jj + 1; kk < LD_NB; kk++) a[kk] -= l * U[jj * LD_NB + kk];
+        for (int kk = jj + 1; kk < LD_NB; kk++) a[kk] -= l * (DIAG ? readlane_f64(a[jj], kk) : U[jj * LD_NB + kk]);
         if (!DIAG || r > jj) a[jj] = l;
     }
+    if (DIAG && !ok && r == 0) *s_ok = 0;
 #pragma unroll
     for (int c = 0; c < LD_NB; c++) if (!DIAG || c <= r) P[r * LD_PP + c] = a[c];
     if (!DIAG) yv[r] = yr;
 }
-
-// S: [n][ld] row-major, lower triangle read and overwritten with L / d; rhs, x: n doubles in global memory (x may alias rhs); lds:
-// ba_ldlt_lds_bytes(max_ld) bytes of dynamic LDS with max_ld >= n.  Every thread of the (<= 1024-thread, >= n - 32) block calls
-// it; the return value is block-uniform: false = zero / non-finite pivot, x untouched.
-__device__ __forceinline__ bool ldlt_solve_wg(double *S, int ld, int n, const double *rhs, double *x, double *lds, int max_ld)
+template <bool DIAG>
+__device__ __forceinline__ void ldlt_rows(lds_f64 *P, lds_f64 *U, lds_f64 *dv, lds_f64 *yv, int r, int nb, int *s_ok)
 {
-    __shared__ int s_ok;
+    ldlt_rows2<DIAG, false>(P, U, dv, yv, r, nb, s_ok);
+}
+
+// broadcast of lane OS of every quad to the quad's four lanes
+template <int OS>
+__device__ __forceinline__ double quad_bcast_f64(double v)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(u & 0xffffffffu), OS * 0x55, 0xF, 0xF, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(u >> 32), OS * 0x55, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+// The rows below the diagonal block, FOUR lanes per row (lane s of a quad owns columns s, s+4, ..., s+28): per elimination step one
+// multiply, one quad broadcast and <= 8 fused multiply-adds per lane instead of <= 31 on a single lane -- the dependency chain of a
+// panel is ~4x shorter and four times as many waves hide it.  Same arithmetic per entry as ldlt_rows<false>.
+template <int JJ, bool FULL>
+__device__ __forceinline__ void ldlt_quad_step(double (&a)[8], double &yr, lds_f64 *U, lds_f64 *rdv, lds_f64 *yv, int s, int nb)
+{
+#pragma clang fp contract(fast)
+    if (FULL || JJ < nb) {                                  // uniform
+        constexpr int OI = JJ >> 2, OS = JJ & 3, I0 = (JJ + 1) >> 2;
+        const double l = quad_bcast_f64<OS>(a[OI]) * rdv[JJ];       // the reciprocal pivots were published by the diagonal wave
+        yr -= l * yv[JJ];
+        if constexpr (I0 < 8) {                             // the group that holds column JJ + 1: only the lanes right of the pivot column update
+            const double t = a[I0] - l * U[JJ * LD_NB + 4 * I0 + s];
+            a[I0] = (4 * I0 + s > JJ) ? t : a[I0];
+        }
+#pragma unroll
+        for (int i = I0 + 1; i < 8; i++) a[i] -= l * U[JJ * LD_NB + 4 * i + s];
+        a[OI] = (s == OS) ? l : a[OI];
+    }
+    if constexpr (FULL && (JJ & 1)) __builtin_amdgcn_sched_barrier(0);      // two steps' loads in flight at most (else all 256 are hoisted and spill)
+    if constexpr (JJ + 1 < LD_NB) ldlt_quad_step<JJ + 1, FULL>(a, yr, U, rdv, yv, s, nb);
+}
+template <bool FULL>
+__device__ __forceinline__ void ldlt_rows_quad(lds_f64 *P, lds_f64 *U, lds_f64 *rdv, lds_f64 *yv, int r, int s, int nb)
+{
+    double a[8];
+    asm volatile("" : "+v"(U), "+v"(yv), "+v"(rdv));
+#pragma unroll
+    for (int i = 0; i < 8; i++) a[i] = P[r * LD_PP + 4 * i + s];
+    double yr = yv[r];
+    ldlt_quad_step<0, FULL>(a, yr, U, rdv, yv, s, nb);
+#pragma unroll
+    for (int i = 0; i < 8; i++) P[r * LD_PP + 4 * i + s] = a[i];
+    if (s == 0) yv[r] = yr;
+}
+
+// trailing update S[i][k] -= sum_c L[i][c] d_c L[k][c]  (i >= k >= p0 + nb) in TS x TS register tiles, lower-triangular tiles only,
+// evenly dealt over the block.  TS = 4 when that fills the block, 2 for the small trailing matrices near the end.
+template <int TS>
+__device__ __forceinline__ void ldlt_trailing(double *S, int ld, lds_f64 *P, lds_f64 *dv, int p0, int nb, int m)
+{
+#pragma clang fp contract(fast)
     const int tid = threadIdx.x, nth = blockDim.x;
-    double *P = lds;                              // panel [rows][LD_PP]
-    double *y = P + (size_t)max_ld * LD_PP;     // right-hand side / solution
-    double *dval = y + max_ld;                  // pivots d_c of every column
-    double *red = dval + max_ld;                // [32][32] partial sums of the back substitution
-    double *U = red;                              // [32][32] unscaled columns of the current diagonal block (factorisation phase)
+    const int m2 = m - nb, T = (m2 + TS - 1) / TS, ntri = T * (T + 1) / 2;
+    for (int t = tid; t < ntri; t += nth) {
+        int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+        while (ti * (ti + 1) / 2 > t) ti--;
+        while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
+        const int tk = t - ti * (ti + 1) / 2;
+        const int i0 = nb + TS * ti, k0 = nb + TS * tk;
+        double acc[TS][TS], sv[TS][TS];
+#pragma unroll
+        for (int a = 0; a < TS; a++)
+#pragma unroll
+            for (int b2 = 0; b2 < TS; b2++) {               // the tile's current values: in flight while the products are formed
+                acc[a][b2] = 0.0;
+                sv[a][b2] = (i0 + a < m && k0 + b2 < m && i0 + a >= k0 + b2) ? S[(size_t)(p0 + i0 + a) * ld + p0 + k0 + b2] : 0.0;
+            }
+        for (int c = 0; c < nb; c++) {
+            const double dc = dv[c];
+            double av[TS], bv[TS];
+#pragma unroll
+            for (int a = 0; a < TS; a++) {
+                av[a] = (i0 + a < m) ? P[(i0 + a) * LD_PP + c] * dc : 0.0;
+                bv[a] = (k0 + a < m) ? P[(k0 + a) * LD_PP + c] : 0.0;
+            }
+#pragma unroll
+            for (int a = 0; a < TS; a++)
+#pragma unroll
+                for (int b2 = 0; b2 < TS; b2++) acc[a][b2] += av[a] * bv[b2];
+        }
+#pragma unroll
+        for (int a = 0; a < TS; a++)
+#pragma unroll
+            for (int b2 = 0; b2 < TS; b2++)
+                if (i0 + a < m && k0 + b2 < m && i0 + a >= k0 + b2)
+                    S[(size_t)(p0 + i0 + a) * ld + p0 + k0 + b2] = sv[a][b2] - acc[a][b2];
+    }
+}
+
+// S: [n][ld] row-major, lower triangle read and overwritten with L / d; rhs, x: n doubles in global memory (x may alias rhs); uses
+// the first ba_ldlt_lds_bytes(max_ld) bytes of the kernel's dynamic LDS, max_ld >= n.  Every thread of the (<= 1024-thread, >= n - 32) block calls
+// it; the return value is block-uniform: false = zero / non-finite pivot, x untouched.
+#ifdef LDLT_PROF
+__device__ long long g_ldlt_prof[8];          // debug build only: shader cycles of load / diag / rows / trailing / back substitution
+#define LDLT_T(i) do { if (threadIdx.x == 0) { const long long t_ = clock64(); g_ldlt_prof[i] += t_ - t_prev; t_prev = t_; } } while (0)
+#else
+#define LDLT_T(i) do { } while (0)
+#endif
+__device__ __forceinline__ bool ldlt_solve_wg(double *S, int ld, int n, const double *rhs, double *x, int max_ld)
+{
+    // the kernel's dynamic LDS, named HERE so that every panel access stays an LDS instruction (through a pointer parameter the
+    // address space is lost and the panel code turns into flat loads with a full wait after each)
+#pragma clang fp contract(fast)
+    extern __shared__ double lds[];
+    __shared__ int s_ok;
+#ifdef LDLT_PROF
+    long long t_prev = clock64();
+#endif
+    const int tid = threadIdx.x, nth = blockDim.x;
+    lds_f64 *P = (lds_f64 *)lds;                 // panel [rows][LD_PP]
+    lds_f64 *y = P + (size_t)max_ld * LD_PP;     // right-hand side / solution
+    lds_f64 *dval = y + max_ld;                  // pivots d_c of every column
+    lds_f64 *rdval = dval + max_ld;              // their reciprocals
+    lds_f64 *red = rdval + max_ld;               // [32][32] partial sums of the back substitution
+    lds_f64 *U = red;                            // [32][32] unscaled columns of the current diagonal block (factorisation phase)
     for (int i = tid; i < n; i += nth) y[i] = rhs[i];
     if (tid == 0) s_ok = 1;
     __syncthreads();
@@ -83,65 +208,40 @@ __device__ __forceinline__ bool ldlt_solve_wg(double *S, int ld, int n, const do
             if (c < nb) P[r * LD_PP + c] = S[(size_t)(p0 + r) * ld + p0 + c];
         }
         __syncthreads();
+        LDLT_T(0);
         // (1) the nb x nb diagonal block: ONE wave, one row per lane, the row in registers, no block barriers.  Step jj publishes the
         //     still unscaled column jj (U[jj][r] = A[r][jj]) in LDS; every lane reads it back as wave-wide broadcasts.
-        if (tid < nb) ldlt_rows<true>(P, U, dval + p0, y + p0, tid, nb, &s_ok);
+        if (tid < nb) {
+            ldlt_rows2<true, false>(P, U, dval + p0, y + p0, tid, nb, &s_ok);      // (the per-step column test also keeps the scheduler from
+                                                                                   //  hoisting several steps' broadcasts: ~60 SGPRs per step)
+            rdval[p0 + tid] = ldlt_rcp(dval[p0 + tid]);          // same lane wrote dval[p0 + tid]
+        }
         __syncthreads();
+        LDLT_T(1);
         if (!s_ok) break;
-        // (2) the rows below the block: independent forward substitutions against U / d, one row per thread
-        if (nb + tid < m) ldlt_rows<false>(P, U, dval + p0, y + p0, nb + tid, nb, &s_ok);     // m <= BA_LDLT_MAXN < blockDim
+        // (2) the rows below the block: independent forward substitutions against U / d, four lanes per row
+        // (the straight-line FULL instantiation makes the register allocator hoist and spill the U loads: not used)
+        for (int q = tid >> 2; q < m - nb; q += nth >> 2) ldlt_rows_quad<false>(P, U, rdval + p0, y + p0, nb + q, tid & 3, nb);
         __syncthreads();
+        LDLT_T(2);
         if (!s_ok) break;
         // write the factored panel back: L below the diagonal, d on it
         for (int idx = tid; idx < m * LD_NB; idx += nth) {
             const int r = idx >> 5, c = idx & 31;
             if (c < nb && r >= c) S[(size_t)(p0 + r) * ld + p0 + c] = (r == c) ? dval[p0 + c] : P[r * LD_PP + c];
         }
-        // trailing update S[i][k] -= sum_c L[i][c] d_c L[k][c]  (i >= k >= p0+nb), 4x4 register tiles
-        const int m2 = m - nb;
-        if (m2 > 0) {
-            const int T = (m2 + 3) >> 2, ntri = T * (T + 1) / 2;
-            for (int t = tid; t < ntri; t += nth) {               // lower-triangular tiles only, evenly dealt (row ti, column tk <= ti)
-                int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-                while (ti * (ti + 1) / 2 > t) ti--;
-                while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
-                const int tk = t - ti * (ti + 1) / 2;
-                const int i0 = nb + 4 * ti, k0 = nb + 4 * tk;
-                double acc[4][4], sv[4][4];
-#pragma unroll
-                for (int a = 0; a < 4; a++)
-#pragma unroll
-                    for (int b2 = 0; b2 < 4; b2++) {               // the tile's current values: in flight while the products are formed
-                        acc[a][b2] = 0.0;
-                        sv[a][b2] = (i0 + a < m && k0 + b2 < m && i0 + a >= k0 + b2) ? S[(size_t)(p0 + i0 + a) * ld + p0 + k0 + b2] : 0.0;
-                    }
-                for (int c = 0; c < nb; c++) {
-                    const double dc = dval[p0 + c];
-                    double av[4], bv[4];
-#pragma unroll
-                    for (int a = 0; a < 4; a++) {
-                        av[a] = (i0 + a < m) ? P[(i0 + a) * LD_PP + c] * dc : 0.0;
-                        bv[a] = (k0 + a < m) ? P[(k0 + a) * LD_PP + c] : 0.0;
-                    }
-#pragma unroll
-                    for (int a = 0; a < 4; a++)
-#pragma unroll
-                        for (int b2 = 0; b2 < 4; b2++) acc[a][b2] += av[a] * bv[b2];
-                }
-#pragma unroll
-                for (int a = 0; a < 4; a++)
-#pragma unroll
-                    for (int b2 = 0; b2 < 4; b2++)
-                        if (i0 + a < m && k0 + b2 < m && i0 + a >= k0 + b2)
-                            S[(size_t)(p0 + i0 + a) * ld + p0 + k0 + b2] = sv[a][b2] - acc[a][b2];
-            }
+        if (m > nb) {
+            const int T4 = (m - nb + 3) >> 2;
+            if (T4 * (T4 + 1) / 2 >= nth) ldlt_trailing<4>(S, ld, P, dval + p0, p0, nb, m);
+            else ldlt_trailing<2>(S, ld, P, dval + p0, p0, nb, m);
         }
         __syncthreads();
+        LDLT_T(3);
     }
     __syncthreads();
     if (!s_ok) return false;                             // x untouched (as the reference on failure)
     // y <- D^-1 y, then L^T x = y panel by panel from the bottom
-    for (int i = tid; i < n; i += nth) y[i] /= dval[i];
+    for (int i = tid; i < n; i += nth) y[i] *= rdval[i];
     __syncthreads();
     const int last_p0 = ((n - 1) / LD_NB) * LD_NB;
     for (int p0 = last_p0; p0 >= 0; p0 -= LD_NB) {
@@ -159,24 +259,22 @@ __device__ __forceinline__ bool ldlt_solve_wg(double *S, int ld, int n, const do
             if (c < nb) P[r * LD_PP + c] = S[(size_t)(p0 + r) * ld + p0 + c];
         }
         __syncthreads();
-        if (tid < nb) {
-            double t = 0.0;
-            for (int rg = 0; rg < 32; rg++) t += red[rg * 32 + tid];
-            y[p0 + tid] -= t;
-        }
-        __syncthreads();
-        if (tid < 64) {                                       // 32x32 triangular solve inside one wave
-            for (int jj = nb - 1; jj >= 0; jj--) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const double xj = y[p0 + jj];
-                if (tid < jj) y[p0 + tid] -= P[jj * LD_PP + tid] * xj;
+        if (tid < LD_NB) {                                    // 32 lanes: lane c holds y_c and column c of the block's L; x_jj by readlane
+            double yc = 0.0, col[LD_NB];
+            if (tid < nb) {
+                double t = 0.0;
+                for (int rg = 0; rg < 32; rg++) t += red[rg * 32 + tid];
+                yc = y[p0 + tid] - t;
             }
+#pragma unroll
+            for (int jj = 0; jj < LD_NB; jj++) col[jj] = (jj > tid && jj < nb) ? P[jj * LD_PP + tid] : 0.0;
+#pragma unroll
+            for (int jj = LD_NB - 1; jj >= 1; jj--) yc -= col[jj] * readlane_f64(yc, jj);      // col is zero for jj <= c and jj >= nb
+            if (tid < nb) y[p0 + tid] = yc;
         }
         __syncthreads();
     }
     for (int i = tid; i < n; i += nth) x[i] = y[i];
+    LDLT_T(4);
     return true;
 }

@@ -664,7 +664,7 @@ __device__ __forceinline__ void pair_task(const IbaCtx &C, int4 task, bool diag,
 // One LM trial: (Hll + lambda)^-1, S = H + lambda I - sum W D^-1 W^T, LDL^T, landmark back-substitution, oplus into buffer buf^1.
 // Returns (team-uniform) ok of the linear solve; the return value of *scale_part is this THREAD's share of computeScale's sum
 // (levenberg.cpp:187-194).
-__device__ __noinline__ bool iba_trial(const IbaCtx &C, Team &T, int buf, double lambda, double *lds, double *scale_part)
+__device__ __noinline__ bool iba_trial(const IbaCtx &C, Team &T, int buf, double lambda, double *scale_part)
 {
     const IbaWin &W = *C.W; const IbaArgs &A = *C.A;
     const long long t_begin = clock64();
@@ -723,7 +723,7 @@ __device__ __noinline__ bool iba_trial(const IbaCtx &C, Team &T, int buf, double
         }
         __syncthreads();
         t_schur = clock64();
-        ok = n > 0 ? ldlt_solve_wg(S, n, n, bs, x, lds, A.max_n) : true;
+        ok = n > 0 ? ldlt_solve_wg(S, n, n, bs, x, A.max_n) : true;
         if (tid == 0) A.okflag[T.w] = ok ? 1 : 0;
         t_ldlt = clock64();
     }
@@ -799,7 +799,6 @@ __device__ __noinline__ bool iba_trial(const IbaCtx &C, Team &T, int buf, double
 
 __global__ __launch_bounds__(IBA_THREADS) void k_iba_solve(IbaArgs A)
 {
-    extern __shared__ double lds[];
     __shared__ double red[2 * IBA_WAVES];
     // blockIdx -> (window, member): with G > 1 the members of a team sit on ONE XCD (workgroups are dealt round-robin over the 8
     // XCDs), so that the team's scratch stays in that XCD's L2; correctness does not depend on it (agent-scope fences)
@@ -845,7 +844,7 @@ __global__ __launch_bounds__(IBA_THREADS) void k_iba_solve(IbaArgs A)
         int qmax = 0;
         do {
             double scale;
-            const bool ok = iba_trial(C, T, cur, lambda, lds, &scale);
+            const bool ok = iba_trial(C, T, cur, lambda, &scale);
             t0 = clock64();
             double tmp = iba_errors(C, T, cur ^ 1);
             team_sum2(T, tmp, scale, red);
@@ -1141,6 +1140,13 @@ extern "C" int orbhip_inertial_ba_solve_batch(orbhip_ctx *ctx, const orbhip_iba_
     ITRY(hipStreamSynchronize(s));
     for (int w = 0; w < n_windows; w++)
         if (failv[w]) { orbhip_set_last_error_internal("inertial BA: a team barrier did not complete (workgroups not co-resident)"); return ORBHIP_E_HIP; }
+#ifdef LDLT_PROF
+    {
+        long long lp[8];
+        ITRY(hipMemcpyFromSymbol(lp, HIP_SYMBOL(g_ldlt_prof), sizeof(lp)));
+        fprintf(stderr, "[orbhip iba] LDLT cycles (cumulative): load %lld diag %lld rows %lld trailing %lld backsub %lld\n", lp[0], lp[1], lp[2], lp[3], lp[4]);
+    }
+#endif
     if (want_prof) {
         long long pf[8];
         ITRY(hipMemcpy(pf, d + w_prof, 64, hipMemcpyDeviceToHost));
