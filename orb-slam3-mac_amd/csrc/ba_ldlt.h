@@ -212,8 +212,10 @@ __device__ __forceinline__ bool ldlt_solve_wg(double *S, int ld, int n, const do
         // (1) the nb x nb diagonal block: ONE wave, one row per lane, the row in registers, no block barriers.  Step jj publishes the
         //     still unscaled column jj (U[jj][r] = A[r][jj]) in LDS; every lane reads it back as wave-wide broadcasts.
         if (tid < nb) {
-            ldlt_rows2<true, false>(P, U, dval + p0, y + p0, tid, nb, &s_ok);      // (the per-step column test also keeps the scheduler from
-                                                                                   //  hoisting several steps' broadcasts: ~60 SGPRs per step)
+            // (measured alternatives: the column through LDS with look-ahead publishing of column jj + 1: 29.6 k cycles per 32 x 32 block
+            //  against 23.5 k for the register broadcasts below; straight-line FULL code: the scheduler hoists every step's broadcasts
+            //  and spills ~700 SGPRs)
+            ldlt_rows2<true, false>(P, U, dval + p0, y + p0, tid, nb, &s_ok);
             rdval[p0 + tid] = ldlt_rcp(dval[p0 + tid]);          // same lane wrote dval[p0 + tid]
         }
         __syncthreads();
