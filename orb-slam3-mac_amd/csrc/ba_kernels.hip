@@ -20,6 +20,9 @@
 #include "orb_internal.h"
 #include "wave_dpp.h"
 #include "ba_ldlt.h"
+// The library is built with -ffp-contract=off for the bit-exact integer / float ORB paths.  The double-precision optimisers are
+// compared with the oracle to 1e-4, not bit for bit: let a * b + c contract to v_fma_f64 here (half the FP64 instructions).
+#pragma clang fp contract(fast)
 #include <cfloat>
 #include <cmath>
 #include <cstring>
