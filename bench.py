@@ -155,6 +155,28 @@ def ba_cpu_baseline(graphs, seconds_budget=12.0):
                       % (cores, per_thread, 1.0 / t1)}
 
 
+def iba_cpu_baseline(wins, seconds_budget=6.0):
+    """Oracle LocalInertialBA (oracle/iba_oracle.c) on the host cores, one window per thread at a time: kind 'port'."""
+    from concurrent.futures import ThreadPoolExecutor
+    import oracle_iba_bind as oib
+    cores = min(os.cpu_count() or 1, 16)
+    t0 = time.time()
+    oib.solve(wins[0])
+    t1 = time.time() - t0
+    per_thread = max(1, min(16, int(seconds_budget / max(t1, 1e-3))))
+
+    def work(tid):
+        for i in range(per_thread):
+            oib.solve(wins[(tid + i) % len(wins)])
+        return per_thread
+    t0 = time.time()
+    with ThreadPoolExecutor(cores) as ex:
+        done = sum(ex.map(work, range(cores)))
+    dt = time.time() - t0
+    return {"value": round(done / dt, 2), "unit": "windows/s", "cores": cores, "kind": "port",
+            "sample": "%d threads x %d solves of the bench windows; single-thread %.1f ms per window" % (cores, per_thread, t1 * 1e3)}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,6 +192,7 @@ def parse_args(argv=None):
     ap.add_argument("--ba-steps", type=int, default=3)
     ap.add_argument("--ba-sharded-graphs", type=int, default=0, help="N > 1 only, opt-in: graphs solved cooperatively with the points sharded over the ranks and the Schur block all-gathered every LM trial (SURVEY 8e optional mode)")
     ap.add_argument("--pose-frames", type=int, default=1024, help="frames of pose-only BA solved per launch (0 = skip)")
+    ap.add_argument("--inertial-windows", type=int, default=32, help="LocalInertialBA windows solved per call (0 = skip)")
     ap.add_argument("--stereo-pairs", type=int, default=None, help="rectified stereo pairs for the ComputeStereoMatches leg (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args(argv)
@@ -529,6 +552,34 @@ def main():
                 "workload": "Optimizer::PoseOptimization: 1000 unary edges/frame (0-75 % stereo), 10 % gross outliers, 4 rounds x 10 LM its",
                 "mean_inliers": round(float(dni.float().mean().item()), 1)}
 
+    inertial = None
+    iba_wins = None
+    if args.inertial_windows > 0:
+        import synth_iba
+        iba_wins = [synth_iba.make_window(9100 + 8 * rank + k, n_opt=10, n_fixed_vis=20, n_points=600) for k in range(8)]
+        NW = args.inertial_windows
+        structs = [iba_wins[i % 8].struct(orbhip.IbaWindow) for i in range(NW)]
+        kfs0 = [iba_wins[i % 8].kf0 for i in range(NW)]
+        pts0 = [iba_wins[i % 8].pts0 for i in range(NW)]
+        ip = orbhip.iba_default_params(False)
+        orbhip.inertial_ba_solve_batch(ctx, structs, kfs0, pts0, ip)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.ba_steps):
+            iba_res = orbhip.inertial_ba_solve_batch(ctx, structs, kfs0, pts0, ip)
+        barrier()
+        (dt_ib,) = max_over_ranks(time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        for _ in range(args.ba_steps):
+            orbhip.inertial_ba_solve_batch(ctx, structs[:1], kfs0[:1], pts0[:1], ip)
+        dt_one = (time.perf_counter() - t0) / args.ba_steps
+        inertial = {"metric": "inertial local-BA windows/sec", "value": round(world * NW * args.ba_steps / dt_ib, 1), "unit": "windows/s",
+                    "windows_per_gpu": NW, "ms_per_batch": round(dt_ib / args.ba_steps * 1e3, 3), "single_window_ms": round(dt_one * 1e3, 3),
+                    "dtype": "f64", "lm_trials_window0": iba_res[3][0]["lm_trials"],
+                    "workload": "Optimizer::LocalInertialBA: 10 IMU keyframes (15 unknowns each) + 1 fixed IMU keyframe + 20 fixed visual "
+                                "keyframes, 600 landmarks (%d visual edges), optimize(10), host arrays in / out (packing + H2D + kernel + D2H)"
+                                % iba_wins[0].n_edges}
+
     stereo = None
     if args.stereo_pairs > 0:
         S = args.stereo_pairs
@@ -648,12 +699,16 @@ def main():
             out["pose_opt"] = pose
         if stereo is not None:
             out["stereo"] = stereo
+        if inertial is not None:
+            out["inertial_ba"] = inertial
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, H, args.nfeatures)
             if graphs is not None:
                 out["ba"]["cpu_baseline"] = ba_cpu_baseline(graphs)
             if pose_probs is not None:
                 out["pose_opt"]["cpu_baseline"] = pose_cpu_baseline(pose_probs)
+            if iba_wins is not None:
+                out["inertial_ba"]["cpu_baseline"] = iba_cpu_baseline(iba_wins)
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()

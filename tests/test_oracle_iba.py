@@ -59,15 +59,15 @@ def test_visual_edge_jacobians_match_finite_differences():
     h = 1e-6
     for e in range(0, win.n_edges, 7):
         s, X, obs, st = win.kf0[a["edge_kf"][e]], win.pts0[a["edge_point"][e]], a["edge_obs"][e], int(a["edge_stereo"][e])
-        err, Jx, Jp = win.edge_visual(s, X, obs, st)
+        err, Jx, Jp = ib.edge_visual(win, s, X, obs, st)
         D = 3 if st else 2
         for c in range(3):
             d = np.zeros(3); d[c] = h
-            ep = win.edge_visual(s, X + d, obs, st)[0]; em = win.edge_visual(s, X - d, obs, st)[0]
+            ep = ib.edge_visual(win, s, X + d, obs, st)[0]; em = ib.edge_visual(win, s, X - d, obs, st)[0]
             assert np.allclose(((ep - em) / (2 * h))[:D], Jx[:D, c], rtol=1e-5, atol=1e-4)
         for c in range(6):
             d = np.zeros(15); d[c] = h
-            ep = win.edge_visual(ib.kf_update(s, d), X, obs, st)[0]; em = win.edge_visual(ib.kf_update(s, -d), X, obs, st)[0]
+            ep = ib.edge_visual(win, ib.kf_update(s, d), X, obs, st)[0]; em = ib.edge_visual(win, ib.kf_update(s, -d), X, obs, st)[0]
             assert np.allclose(((ep - em) / (2 * h))[:D], Jp[:D, c], rtol=1e-5, atol=1e-4)
 
 
