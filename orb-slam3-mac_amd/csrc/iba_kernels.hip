@@ -19,6 +19,7 @@
 // compared with the oracle to 1e-4, not bit for bit: let a * b + c contract to v_fma_f64 here (half the FP64 instructions).
 #pragma clang fp contract(fast)
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -938,6 +939,7 @@ extern "C" int orbhip_inertial_ba_solve_batch(orbhip_ctx *ctx, const orbhip_iba_
     if (!ctx || n_windows < 0 || (n_windows && (!wins || !kf_state_inout || !points_inout)) || !params) return ORBHIP_E_BADARG;
     if (n_windows == 0) return ORBHIP_OK;
     if (params->iterations < 0 || params->max_trials < 1 || !(params->lambda_init > 0)) return ORBHIP_E_BADARG;
+    const auto t_host0 = std::chrono::steady_clock::now();
     std::vector<IbaWin> hw(n_windows);
     std::vector<int> kf_xoff, free_kf, edge_kf, edge_point, pt_start, kf_edges, in1, in2, in_color, kf_task_start, pair_task_start;
     std::vector<int2> pair_ent;
@@ -946,6 +948,14 @@ extern "C" int orbhip_inertial_ba_solve_batch(orbhip_ctx *ctx, const orbhip_iba_
     std::vector<double> edge_obs, edge_is2, in_pre, in_info, in_info_g, in_info_a, kfs, pts;
     size_t sumKF = 0, sumL = 0, sumE = 0, sumM = 0, sumX = 0, sumH = 0;
     int max_n = 0;
+    std::vector<int> tmp_pstart, tmp_kcount, tmp_kpos, tmp_pcount, tmp_ppos;
+    std::vector<std::pair<int, int>> tmp_fe;
+    {
+        size_t te = 0, tl = 0, tk = 0;
+        for (int w = 0; w < n_windows; w++) { te += (size_t)std::max(wins[w].n_edges, 0); tl += (size_t)std::max(wins[w].n_points, 0); tk += (size_t)std::max(wins[w].n_kf, 0); }
+        edge_kf.reserve(te); edge_point.reserve(te); edge_obs.reserve(3 * te); edge_is2.reserve(te); edge_stereo.reserve(te); edge_close.reserve(te);
+        kf_edges.reserve(te); pair_ent.reserve(3 * te); pt_start.reserve(tl + n_windows); pts.reserve(3 * tl); kfs.reserve(IBA_KF * tk);
+    }
     for (int w = 0; w < n_windows; w++) {
         const orbhip_iba_window &g = wins[w];
         if (g.n_kf <= 0 || g.n_points < 0 || g.n_edges < 0 || g.n_inertial < 0 || !g.kf_fixed || !g.kf_imu || !kf_state_inout[w] ||
@@ -975,8 +985,8 @@ extern "C" int orbhip_inertial_ba_solve_batch(orbhip_ctx *ctx, const orbhip_iba_
         if (n > BA_LDLT_MAXN || g.n_inertial > IBA_THREADS) { orbhip_set_last_error_internal("inertial BA: more than 480 keyframe unknowns (32 inertial keyframes)"); return ORBHIP_E_CAPACITY; }
         max_n = std::max(max_n, n);
         // edges: grouped by point (the reference creates them point by point, Optimizer.cc:4914-5034)
-        std::vector<int> pstart(g.n_points + 1, 0);
-        std::vector<std::vector<int>> kfe(W.nfree);
+        std::vector<int> &pstart = tmp_pstart; pstart.assign(g.n_points + 1, 0);
+        std::vector<int> &kcount = tmp_kcount; kcount.assign(W.nfree + 1, 0);
         const size_t e_base = edge_kf.size();
         edge_kf.resize(e_base + g.n_edges); edge_point.resize(e_base + g.n_edges); edge_obs.resize(3 * (e_base + g.n_edges));
         edge_is2.resize(e_base + g.n_edges); edge_stereo.resize(e_base + g.n_edges); edge_close.resize(e_base + g.n_edges);
@@ -984,7 +994,7 @@ extern "C" int orbhip_inertial_ba_solve_batch(orbhip_ctx *ctx, const orbhip_iba_
             const int k = g.edge_kf[e], l = g.edge_point[e];
             if (k < 0 || k >= g.n_kf || l < 0 || l >= g.n_points || (e && l < g.edge_point[e - 1])) return ORBHIP_E_BADARG;
             pstart[l + 1]++;
-            if (fidx[k] >= 0) kfe[fidx[k]].push_back(e);
+            if (fidx[k] >= 0) kcount[fidx[k] + 1]++;
             edge_kf[e_base + e] = k; edge_point[e_base + e] = l;
             edge_stereo[e_base + e] = g.edge_stereo[e] ? 1 : 0;
             edge_close[e_base + e] = g.edge_close ? (g.edge_close[e] ? 1 : 0) : 0;
@@ -995,39 +1005,54 @@ extern "C" int orbhip_inertial_ba_solve_batch(orbhip_ctx *ctx, const orbhip_iba_
         }
         for (int l = 0; l < g.n_points; l++) pstart[l + 1] += pstart[l];
         pt_start.insert(pt_start.end(), pstart.begin(), pstart.end());
-        // per-keyframe edge lists, cut into chunks of <= IBA_KF_CHUNK edges (one wave pair each)
+        // per-keyframe edge lists (counting sort, edge order kept), cut into chunks of <= IBA_KF_CHUNK edges (one wave pair each)
+        for (int f = 0; f < W.nfree; f++) kcount[f + 1] += kcount[f];
+        {
+            const size_t kbase = kf_edges.size();
+            kf_edges.resize(kbase + kcount[W.nfree]);
+            std::vector<int> &kpos = tmp_kpos; kpos.assign(kcount.begin(), kcount.end() - 1);
+            for (int e = 0; e < g.n_edges; e++) { const int f = fidx[g.edge_kf[e]]; if (f >= 0) kf_edges[kbase + kpos[f]++] = e; }
+        }
         for (int f = 0; f < W.nfree; f++) {
             kf_task_start.push_back((int)kf_task.size() - W.ktask_off);
-            const int base = (int)kf_edges.size() - W.kfe_off;
-            kf_edges.insert(kf_edges.end(), kfe[f].begin(), kfe[f].end());
-            for (int o = 0; o < (int)kfe[f].size(); o += IBA_KF_CHUNK)
-                kf_task.push_back(make_int4(f, base + o, base + std::min<int>(o + IBA_KF_CHUNK, (int)kfe[f].size()), 0));
+            for (int o = kcount[f]; o < kcount[f + 1]; o += IBA_KF_CHUNK)
+                kf_task.push_back(make_int4(f, o, std::min<int>(o + IBA_KF_CHUNK, kcount[f + 1]), 0));
         }
         kf_task_start.push_back((int)kf_task.size() - W.ktask_off);
         W.nktask = (int)kf_task.size() - W.ktask_off;
-        // pair lists: for every point, every (i <= j) pair of the free keyframes that see it
+        // pair lists: for every point, every (i <= j) pair of the free keyframes that see it (two counting passes, point order kept)
         W.npairs = W.nfree * (W.nfree + 1) / 2;
-        std::vector<std::vector<int2>> pl(W.npairs);
         auto pair_id = [&](int i, int j) { return i * W.nfree - i * (i - 1) / 2 + (j - i); };
-        std::vector<std::pair<int, int>> fe;
-        for (int l = 0; l < g.n_points; l++) {
-            fe.clear();
-            for (int e = pstart[l]; e < pstart[l + 1]; e++) if (fidx[g.edge_kf[e]] >= 0) fe.push_back({fidx[g.edge_kf[e]], e});
-            for (size_t a = 0; a < fe.size(); a++)
-                for (size_t b2 = a; b2 < fe.size(); b2++) {
-                    if (b2 != a && fe[a].first == fe[b2].first) { orbhip_set_last_error_internal("inertial BA: a point is observed twice by one keyframe"); return ORBHIP_E_BADARG; }
-                    const bool sw = fe[a].first > fe[b2].first;
-                    const int i = sw ? fe[b2].first : fe[a].first, j = sw ? fe[a].first : fe[b2].first;
-                    pl[pair_id(i, j)].push_back(make_int2(sw ? fe[b2].second : fe[a].second, sw ? fe[a].second : fe[b2].second));
-                }
+        std::vector<int> &pcount = tmp_pcount; pcount.assign(W.npairs + 1, 0);
+        std::vector<std::pair<int, int>> &fe = tmp_fe;
+        for (int pass = 0; pass < 2; pass++) {
+            const size_t pbase = pair_ent.size() - (pass ? (size_t)pcount[W.npairs] : 0);
+            std::vector<int> &ppos = tmp_ppos;
+            if (pass) ppos.assign(pcount.begin(), pcount.end() - 1);
+            for (int l = 0; l < g.n_points; l++) {
+                fe.clear();
+                for (int e = pstart[l]; e < pstart[l + 1]; e++) if (fidx[g.edge_kf[e]] >= 0) fe.push_back({fidx[g.edge_kf[e]], e});
+                for (size_t a2 = 0; a2 < fe.size(); a2++)
+                    for (size_t b2 = a2; b2 < fe.size(); b2++) {
+                        const bool sw = fe[a2].first > fe[b2].first;
+                        const int i = sw ? fe[b2].first : fe[a2].first, j = sw ? fe[a2].first : fe[b2].first;
+                        if (!pass) {
+                            if (b2 != a2 && i == j) { orbhip_set_last_error_internal("inertial BA: a point is observed twice by one keyframe"); return ORBHIP_E_BADARG; }
+                            pcount[pair_id(i, j) + 1]++;
+                        } else
+                            pair_ent[pbase + ppos[pair_id(i, j)]++] = make_int2(sw ? fe[b2].second : fe[a2].second, sw ? fe[a2].second : fe[b2].second);
+                    }
+            }
+            if (!pass) {
+                for (int q = 0; q < W.npairs; q++) pcount[q + 1] += pcount[q];
+                pair_ent.resize(pair_ent.size() + pcount[W.npairs]);
+            }
         }
-        for (int i = 0, p = 0; i < W.nfree; i++)
-            for (int j = i; j < W.nfree; j++, p++) {
+        for (int i = 0, q = 0; i < W.nfree; i++)
+            for (int j = i; j < W.nfree; j++, q++) {
                 pair_task_start.push_back((int)pair_task.size() - W.ptask_off);
-                const int base = (int)((long long)pair_ent.size() - W.pent_off);
-                pair_ent.insert(pair_ent.end(), pl[p].begin(), pl[p].end());
-                for (int o = 0; o < (int)pl[p].size(); o += IBA_PAIR_CHUNK)
-                    pair_task.push_back(make_int4(p, base + o, base + std::min<int>(o + IBA_PAIR_CHUNK, (int)pl[p].size()), i == j ? 1 : 0));
+                for (int o = pcount[q]; o < pcount[q + 1]; o += IBA_PAIR_CHUNK)
+                    pair_task.push_back(make_int4(q, o, std::min<int>(o + IBA_PAIR_CHUNK, pcount[q + 1]), i == j ? 1 : 0));
             }
         pair_task_start.push_back((int)pair_task.size() - W.ptask_off);
         W.nptask = (int)pair_task.size() - W.ptask_off;
@@ -1072,6 +1097,7 @@ extern "C" int orbhip_inertial_ba_solve_batch(orbhip_ctx *ctx, const orbhip_iba_
                  w_stats = take(sizeof(orbhip_iba_stats) * n_windows), w_prof = take(64 * (size_t)n_windows),
                  w_sync = take((4 + 4 + 4) * (size_t)n_windows), w_wpart = take(8 * 2 * IBA_MAXG * 2 * (size_t)n_windows);
     const bool want_prof = getenv("ORBHIP_IBA_PROF") != nullptr;
+    const auto t_host1 = std::chrono::steady_clock::now();
     ITRY(hipSetDevice(orbhip_ctx_device_internal(ctx)));
     hipStream_t s = orbhip_ctx_stream_internal(ctx);
     uint8_t *d = (uint8_t *)orbhip_ctx_scratch_internal(ctx, off);
@@ -1150,6 +1176,12 @@ extern "C" int orbhip_inertial_ba_solve_batch(orbhip_ctx *ctx, const orbhip_iba_
         fprintf(stderr, "[orbhip iba] LDLT cycles (cumulative): load %lld diag %lld rows %lld trailing %lld backsub %lld\n", lp[0], lp[1], lp[2], lp[3], lp[4]);
     }
 #endif
+    if (want_prof) {
+        const auto t_host2 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[orbhip iba] %d windows: host packing %.3f ms, upload + kernel + download %.3f ms (%zu B constant, %zu B total)\n", n_windows,
+                std::chrono::duration<double, std::milli>(t_host1 - t_host0).count(), std::chrono::duration<double, std::milli>(t_host2 - t_host1).count(),
+                constant_bytes, off);
+    }
     if (want_prof) {
         long long pf[8];
         ITRY(hipMemcpy(pf, d + w_prof, 64, hipMemcpyDeviceToHost));
