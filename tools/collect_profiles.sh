@@ -8,8 +8,8 @@ root=$PWD
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $root
-ORB="--no-cpu-baseline --ba-graphs 0 --pose-frames 0 --stereo-pairs 0"
-timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $out/trace -o run --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --stereo-pairs 0 "$@" > $out/trace.log 2>&1 || { tail -5 $out/trace.log; exit 1; }
+ORB="--no-cpu-baseline --ba-graphs 0 --pose-frames 0 --stereo-pairs 0 --inertial-windows 0"
+timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $out/trace -o run --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --stereo-pairs 0 --inertial-windows 0 "$@" > $out/trace.log 2>&1 || { tail -5 $out/trace.log; exit 1; }
 echo trace done
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE -d $out/fetch -o run --output-format csv -- python3 bench.py --steps 2 --warmup 1 $ORB "$@" > $out/fetch.log 2>&1 || { tail -5 $out/fetch.log; exit 1; }
 echo fetch done
@@ -22,4 +22,13 @@ cp $(find $out/trace -name "*kernel_stats.csv") $out/${tag}_kernel_stats.csv
 python3 tools/profile_summary.py traffic $(find $out/fetch -name "*counter_collection.csv") $(find $out/write -name "*counter_collection.csv") $out/${tag}_pmc_traffic.json
 python3 tools/profile_summary.py valu $(find $out/sq -name "*counter_collection.csv") $out/${tag}_pmc_valu_issue.json
 grep "^{\"metric\"" $out/trace.log | tail -1 > $out/${tag}_bench_under_trace.json
+# the inertial local BA in its own trace (a cooperative launch under rocprofv3 has been seen to crash in the tool's exit handler
+# AFTER the trace is written: the exit status of this step is not checked)
+timeout -k 10 300 rocprofv3 --kernel-trace -d $out/iba -o run --output-format csv -- python3 tools/iba_probe.py 64 > $out/iba.log 2>&1
+python3 - $out/iba/run_kernel_trace.csv $out/${tag}_iba_kernel_trace.csv <<'P'
+import csv, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "k_iba" in r["Kernel_Name"]]
+w = csv.writer(open(sys.argv[2], "w")); w.writerow(["kernel", "grid_threads", "workgroup", "duration_us"])
+for r in rows: w.writerow(["k_iba_solve", r.get("Grid_Size_X") or r.get("Grid_Size"), r.get("Workgroup_Size_X") or r.get("Workgroup_Size"), round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, 2)])
+P
 echo done
