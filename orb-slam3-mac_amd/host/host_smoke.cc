@@ -5,6 +5,7 @@
 //                                   Optimizer::LocalBundleAdjustment on it and dumps the resulting map (the test compares it
 //                                   with the CPU oracle run on the same window)
 //   host_smoke match <in> <out>     builds Frames + MapPoints, runs the ORBmatcher methods and dumps their results
+//   host_smoke liba <in> <out>      builds a temporal chain of inertial KeyFrames (+ fixed visual ones), runs Optimizer::LocalInertialBA
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -139,11 +140,104 @@ static int lba_smoke(const char *in, const char *out)
     return 0;
 }
 
+// in:  int32[8] {nKF, nMP, nE, index of pKF, KeyFramesInMap, bLarge, bRecInit, 0}; float[5] fx fy cx cy bf; float[16] Tcb;
+//      int32[nKF] mnId; float[nKF*16] Tcw; int32[nKF] index of mPrevKF or -1; int32[nKF] bImu; float[nKF*3] velocity;
+//      float[nKF*6] bias (bax bay baz bwx bwy bwz); int32[nKF] has a preintegration; float[nKF*292] {dT, C 15x15, dR, dV, dP, JRg,
+//      JVg, JVa, JPg, JPa, b (bax..bwz)}; float[nMP*3] positions; float[nMP] mTrackDepth; int32[nE] edge keyframe, int32[nE] edge
+//      map point, float[nE*3] (u, v, uRight or -1), int32[nE] octave; float[8] mvInvLevelSigma2
+// out: float[nKF*16] Tcw; float[nKF*3] velocity; float[nKF*6] bias; float[nMP*3]; int32 nErased; int32[nErased*2]; int32 map change index
+static int liba_smoke(const char *in, const char *out)
+{
+    Reader r(in);
+    if (!r.f) { fprintf(stderr, "cannot open %s\n", in); return 2; }
+    const std::vector<int32_t> hd = r.vec<int32_t>(8);
+    const int nKF = hd[0], nMP = hd[1], nE = hd[2], cur = hd[3];
+    const std::vector<float> cam = r.vec<float>(5), Tcb = r.vec<float>(16);
+    const std::vector<int32_t> ids = r.vec<int32_t>(nKF);
+    const std::vector<float> Tcw = r.vec<float>((size_t)nKF * 16);
+    const std::vector<int32_t> prev = r.vec<int32_t>(nKF), bimu = r.vec<int32_t>(nKF);
+    const std::vector<float> vel = r.vec<float>((size_t)nKF * 3), bias = r.vec<float>((size_t)nKF * 6);
+    const std::vector<int32_t> hasp = r.vec<int32_t>(nKF);
+    const std::vector<float> pre = r.vec<float>((size_t)nKF * 292);
+    const std::vector<float> X = r.vec<float>((size_t)nMP * 3), depth = r.vec<float>(nMP);
+    const std::vector<int32_t> eKF = r.vec<int32_t>(nE), eMP = r.vec<int32_t>(nE);
+    const std::vector<float> eObs = r.vec<float>((size_t)nE * 3);
+    const std::vector<int32_t> eOct = r.vec<int32_t>(nE);
+    const std::vector<float> invS2 = r.vec<float>(8);
+
+    Map map;
+    map.mbIsInertial = true; map.nKeyFrames = hd[4];
+    GeometricCamera camera({cam[0], cam[1], cam[2], cam[3]}, 0);
+    std::vector<std::unique_ptr<KeyFrame>> kfs;
+    std::vector<std::unique_ptr<MapPoint>> mps;
+    std::vector<std::unique_ptr<IMU::Preintegrated>> pints;
+    auto mat = [](const float *p, int rows, int cols) { cv::Mat m(rows, cols, CV_32F); for (int i = 0; i < rows; i++) for (int j = 0; j < cols; j++) m.at<float>(i, j) = p[cols * i + j]; return m; };
+    for (int i = 0; i < nKF; i++) {
+        kfs.emplace_back(new KeyFrame(ids[i], &map, cam[0], cam[1], cam[2], cam[3], cam[4], &camera));
+        KeyFrame *k = kfs[i].get();
+        k->mImuCalib.Tcb = mat(Tcb.data(), 4, 4);
+        k->SetPose(mat(&Tcw[(size_t)16 * i], 4, 4));
+        k->mvInvLevelSigma2 = invS2;
+        k->bImu = bimu[i] != 0;
+        k->SetVelocity(mat(&vel[(size_t)3 * i], 3, 1));
+        const float *b = &bias[(size_t)6 * i];
+        k->SetNewBias(IMU::Bias(b[0], b[1], b[2], b[3], b[4], b[5]));
+    }
+    for (int i = 0; i < nKF; i++) {
+        if (prev[i] >= 0) { kfs[i]->mPrevKF = kfs[prev[i]].get(); kfs[prev[i]]->mNextKF = kfs[i].get(); }
+        if (hasp[i]) {
+            const float *p = &pre[(size_t)292 * i];
+            pints.emplace_back(new IMU::Preintegrated());
+            IMU::Preintegrated *q = pints.back().get();
+            q->dT = p[0]; q->C = mat(p + 1, 15, 15); q->dR = mat(p + 226, 3, 3); q->dV = mat(p + 235, 3, 1); q->dP = mat(p + 238, 3, 1);
+            q->JRg = mat(p + 241, 3, 3); q->JVg = mat(p + 250, 3, 3); q->JVa = mat(p + 259, 3, 3); q->JPg = mat(p + 268, 3, 3); q->JPa = mat(p + 277, 3, 3);
+            q->b = IMU::Bias(p[286], p[287], p[288], p[289], p[290], p[291]);
+            kfs[i]->mpImuPreintegrated = q;
+        }
+    }
+    for (int l = 0; l < nMP; l++) {
+        mps.emplace_back(new MapPoint(1000 + l, mat(&X[(size_t)3 * l], 3, 1), &map));
+        mps[l]->mTrackDepth = depth[l];
+    }
+    for (int e = 0; e < nE; e++) {
+        KeyFrame *kf = kfs[eKF[e]].get();
+        cv::KeyPoint kp; kp.pt.x = eObs[3 * e]; kp.pt.y = eObs[3 * e + 1]; kp.octave = eOct[e];
+        const int idx = kf->mvKeysUn.size();
+        kf->mvKeysUn.push_back(kp); kf->mvuRight.push_back(eObs[3 * e + 2]); kf->mvpMapPoints.push_back(mps[eMP[e]].get());
+        mps[eMP[e]]->AddObservation(kf, idx);
+    }
+    bool stop = false;
+    Optimizer::LocalInertialBA(kfs[cur].get(), &stop, &map, hd[5] != 0, hd[6] != 0);      // LocalMapping.cc:131-155 call shape
+
+    Writer w(out);
+    std::vector<float> To((size_t)nKF * 16), Vo((size_t)nKF * 3), Bo((size_t)nKF * 6), Xo((size_t)nMP * 3);
+    for (int i = 0; i < nKF; i++) {
+        const cv::Mat T = kfs[i]->GetPose(), V = kfs[i]->GetVelocity();
+        for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) To[(size_t)16 * i + 4 * a + b] = T.at<float>(a, b);
+        for (int a = 0; a < 3; a++) Vo[(size_t)3 * i + a] = V.at<float>(a);
+        const IMU::Bias bb = kfs[i]->GetImuBias();
+        const float bv[6] = {bb.bax, bb.bay, bb.baz, bb.bwx, bb.bwy, bb.bwz};
+        for (int a = 0; a < 6; a++) Bo[(size_t)6 * i + a] = bv[a];
+    }
+    for (int l = 0; l < nMP; l++) { const cv::Mat P = mps[l]->GetWorldPos(); for (int k = 0; k < 3; k++) Xo[(size_t)3 * l + k] = P.at<float>(k); }
+    w.vec(To); w.vec(Vo); w.vec(Bo); w.vec(Xo);
+    std::vector<int32_t> erased;
+    for (int e = 0; e < nE; e++) {
+        KeyFrame *kf = kfs[eKF[e]].get();
+        if (mps[eMP[e]]->mObservations.count(kf) == 0) { erased.push_back(eKF[e]); erased.push_back(eMP[e]); }
+    }
+    w.i32((int32_t)erased.size() / 2); w.vec(erased);
+    w.i32(map.mnMapChange);
+    printf("HOST_LIBA_OK erased=%zu\n", erased.size() / 2);
+    return 0;
+}
+
 int match_smoke(const char *in, const char *out);            // host_match_smoke.cc
 
 int main(int argc, char **argv)
 {
     if (argc == 4 && std::string(argv[1]) == "lba") return lba_smoke(argv[2], argv[3]);
     if (argc == 4 && std::string(argv[1]) == "match") return match_smoke(argv[2], argv[3]);
+    if (argc == 4 && std::string(argv[1]) == "liba") return liba_smoke(argv[2], argv[3]);
     return extractor_smoke();
 }

@@ -27,6 +27,31 @@ namespace ORB_SLAM3 {
 class KeyFrame;
 class Map;
 
+// include/ImuTypes.h (the members Optimizer.cc:4574-5187 and G2oTypes.cc:25-71, 693-715 read)
+namespace IMU {
+class Bias {
+public:
+    Bias() : bax(0), bay(0), baz(0), bwx(0), bwy(0), bwz(0) {}
+    Bias(const float &b_acc_x, const float &b_acc_y, const float &b_acc_z, const float &b_ang_vel_x, const float &b_ang_vel_y, const float &b_ang_vel_z)
+        : bax(b_acc_x), bay(b_acc_y), baz(b_acc_z), bwx(b_ang_vel_x), bwy(b_ang_vel_y), bwz(b_ang_vel_z) {}
+    float bax, bay, baz, bwx, bwy, bwz;
+};
+class Calib {
+public:
+    cv::Mat Tcb, Tbc;
+};
+class Preintegrated {
+public:
+    Preintegrated() : dT(0) {}
+    void SetNewBias(const Bias &bu_) { bu = bu_; }       // ImuTypes.cc:334-349 (db = bu - b is recomputed by the consumers here)
+    float dT;
+    cv::Mat C;                                           // 15 x 15 covariance
+    Bias b;                                              // the bias the measurements were integrated with
+    cv::Mat dR, dV, dP, JRg, JVg, JVa, JPg, JPa;
+    Bias bu;
+};
+}  // namespace IMU
+
 // include/CameraModels/GeometricCamera.h:36-104 (type tag + parameter vector; project(cv::Mat) as Pinhole.cpp:34-39 /
 // KannalaBrandt8.cpp:52-69 compute it, in float)
 class GeometricCamera {
@@ -98,9 +123,36 @@ class KeyFrame {
 public:
     KeyFrame(long unsigned int id, Map *pMap, float fx_, float fy_, float cx_, float cy_, float mbf_, GeometricCamera *cam)
         : mnId(id), mnBALocalForKF(0), mnBAFixedForKF(0), fx(fx_), fy(fy_), cx(cx_), cy(cy_), mbf(mbf_), mpCamera(cam), mpCamera2(nullptr),
-          NLeft(-1), mpMap(pMap), mbBad(false) {}
+          NLeft(-1), mPrevKF(nullptr), mNextKF(nullptr), bImu(false), mpImuPreintegrated(nullptr), mpMap(pMap), mbBad(false) {}
     void SetPose(const cv::Mat &Tcw_) { Tcw = Tcw_.clone(); }
     cv::Mat GetPose() { return Tcw.clone(); }
+    // src/KeyFrame.cc:161-172: Owb = Rwc tcb + Ow, Rwb = Rwc Rcb (float cv::Mat arithmetic)
+    cv::Mat GetImuPosition()
+    {
+        cv::Mat o(3, 1, CV_32F);
+        for (int i = 0; i < 3; i++) {
+            float a = 0;                                  // Ow = -Rwc tcw
+            for (int k = 0; k < 3; k++) a += Tcw.at<float>(k, i) * (mImuCalib.Tcb.at<float>(k, 3) - Tcw.at<float>(k, 3));
+            o.at<float>(i) = a;
+        }
+        return o;
+    }
+    cv::Mat GetImuRotation()
+    {
+        cv::Mat R(3, 3, CV_32F);
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+            float a = 0;
+            for (int k = 0; k < 3; k++) a += Tcw.at<float>(k, i) * mImuCalib.Tcb.at<float>(k, j);
+            R.at<float>(i, j) = a;
+        }
+        return R;
+    }
+    cv::Mat GetVelocity() { return Vw.clone(); }
+    void SetVelocity(const cv::Mat &Vw_) { Vw = Vw_.clone(); }
+    void SetNewBias(const IMU::Bias &b) { mImuBias = b; if (mpImuPreintegrated) mpImuPreintegrated->SetNewBias(b); }     // KeyFrame.cc:871-877
+    IMU::Bias GetImuBias() { return mImuBias; }
+    cv::Mat GetGyroBias() { cv::Mat m(3, 1, CV_32F); m.at<float>(0) = mImuBias.bwx; m.at<float>(1) = mImuBias.bwy; m.at<float>(2) = mImuBias.bwz; return m; }
+    cv::Mat GetAccBias() { cv::Mat m(3, 1, CV_32F); m.at<float>(0) = mImuBias.bax; m.at<float>(1) = mImuBias.bay; m.at<float>(2) = mImuBias.baz; return m; }
     std::vector<KeyFrame *> GetVectorCovisibleKeyFrames() { return mvpOrderedConnectedKeyFrames; }
     std::vector<MapPoint *> GetMapPointMatches() { return mvpMapPoints; }
     void EraseMapPointMatch(MapPoint *pMP) { for (auto &p : mvpMapPoints) if (p == pMP) p = nullptr; }
@@ -116,8 +168,14 @@ public:
     cv::Mat mTrl;
     std::vector<cv::KeyPoint> mvKeysRight;
     int NLeft;
+    // inertial members (include/KeyFrame.h:405-470)
+    KeyFrame *mPrevKF, *mNextKF;
+    bool bImu;
+    IMU::Preintegrated *mpImuPreintegrated;
+    IMU::Calib mImuCalib;
     // stand-in state
-    cv::Mat Tcw;
+    cv::Mat Tcw, Vw;
+    IMU::Bias mImuBias;
     std::vector<KeyFrame *> mvpOrderedConnectedKeyFrames;
     std::vector<MapPoint *> mvpMapPoints;
     Map *mpMap;
@@ -127,7 +185,8 @@ public:
 // include/Map.h
 class Map {
 public:
-    Map() : mnInitKFid(0), mbIsInertial(false), mnMapChange(0) {}
+    Map() : mnInitKFid(0), mbIsInertial(false), mnMapChange(0), nKeyFrames(0) {}
+    long unsigned int KeyFramesInMap() { return nKeyFrames; }
     long unsigned int GetInitKFid() { return mnInitKFid; }
     bool IsInertial() { return mbIsInertial; }
     void IncreaseChangeIndex() { mnMapChange++; }
@@ -135,6 +194,7 @@ public:
     long unsigned int mnInitKFid;
     bool mbIsInertial;
     int mnMapChange;
+    long unsigned int nKeyFrames;
 };
 
 // include/Frame.h (the members ORBmatcher.cc:48-218, 710-825, 1965-2181 read or write)

@@ -401,3 +401,159 @@ def test_orbmatcher_methods_over_frames(tmp_path, bMono, forward):
     e_nm, e_res, nq = _expected_local_map(c, rig=True)
     assert e_nm > 100 and (e_res[c["nleft"]:] >= 0).sum() > 20
     assert nm_rm == e_nm and np.array_equal(res_rm, e_res)
+
+
+# ------------------------------------------------------------------------------------------- Optimizer::LocalInertialBA drop-in
+def _liba_case(seed, n_opt=6, n_fixed_vis=5, n_points=150, large=False):
+    """A synthetic visual-inertial window (tests/synth_iba.py) turned into what the reference's objects hold: float Tcw, float
+    velocities / biases, the preintegration with its 15 x 15 covariance, per-point mTrackDepth."""
+    import synth_iba
+    win = synth_iba.make_window(seed, n_opt=n_opt, n_fixed_vis=n_fixed_vis, n_points=n_points, large=large)
+    a = win.arrays
+    # keep only the points an optimizable keyframe sees (LocalInertialBA's lLocalMapPoints, Optimizer.cc:4611-4627)
+    seen = np.zeros(win.n_points, bool)
+    for k, l in zip(a["edge_kf"], a["edge_point"]):
+        if k < n_opt:
+            seen[l] = True
+    keep_e = seen[a["edge_point"]]
+    remap = -np.ones(win.n_points, np.int64)
+    remap[seen] = np.arange(seen.sum())
+    c = dict(win=win, n_opt=n_opt, large=large)
+    c["edge_kf"] = a["edge_kf"][keep_e].astype(np.int32)
+    c["edge_point"] = remap[a["edge_point"][keep_e]].astype(np.int32)
+    c["edge_obs"] = a["edge_obs"][keep_e]
+    c["edge_stereo"] = a["edge_stereo"][keep_e]
+    levels = (1.0 / (1.2 ** (2 * np.arange(8)))).astype(np.float32)
+    c["edge_oct"] = np.array([int(np.argmin(np.abs(levels - np.float32(v)))) for v in a["edge_inv_sigma2"][keep_e]], np.int32)
+    c["inv_s2"] = levels
+    c["points"] = win.pts0[seen].astype(np.float32)
+    # per-point mTrackDepth from the first edge's "close" flag
+    close_pt = np.zeros(seen.sum(), np.uint8)
+    first = {}
+    for e, l in enumerate(c["edge_point"]):
+        first.setdefault(int(l), e)
+    ec = a["edge_close"][keep_e]
+    for l, e in first.items():
+        close_pt[l] = ec[e]
+    c["depth"] = np.where(close_pt > 0, 5.0, 20.0).astype(np.float32)
+    # keyframe objects: Tcw = Tcb Twb^-1 in float
+    n_kf = win.n_kf
+    Tcb = np.eye(4); Tcb[:3, :3] = win.Rcb; Tcb[:3, 3] = win.tcb
+    c["Tcb"] = Tcb.astype(np.float32)
+    Tcw = np.zeros((n_kf, 4, 4), np.float32)
+    for k in range(n_kf):
+        R = win.kf0[k, :9].reshape(3, 3); t = win.kf0[k, 9:12]
+        Rcw = win.Rcb @ R.T
+        T = np.eye(4); T[:3, :3] = Rcw; T[:3, 3] = -Rcw @ t + win.tcb
+        Tcw[k] = T.astype(np.float32)
+    c["Tcw"] = Tcw
+    c["vel"] = win.kf0[:, 12:15].astype(np.float32)
+    c["bias"] = np.concatenate([win.kf0[:, 18:21], win.kf0[:, 15:18]], 1).astype(np.float32)      # (acc, gyro)
+    c["bimu"] = a["kf_imu"].astype(np.int32)
+    c["ids"] = np.array([1000 - k for k in range(n_kf)], np.int32)                                 # newest keyframe = largest id
+    prev = -np.ones(n_kf, np.int32)
+    for k in range(n_opt):
+        prev[k] = k + 1                                                                            # ... -> the fixed keyframe before the window
+    c["prev"] = prev
+    pre = np.zeros((n_kf, 292), np.float32)
+    hasp = np.zeros(n_kf, np.int32)
+    infos = {}
+    for m in range(win.n_inertial):
+        k2 = int(a["in_kf2"][m])
+        rec = a["in_preint"][m]
+        I9 = a["in_info"][m].reshape(9, 9) / (1e-2 if a["in_robust"][m] else 1.0)                 # the window generator already scaled the last edge
+        C = np.zeros((15, 15))
+        C[:9, :9] = np.linalg.inv(I9); C[9:12, 9:12] = np.linalg.inv(a["in_info_g"][m].reshape(3, 3)); C[12:15, 12:15] = np.linalg.inv(a["in_info_a"][m].reshape(3, 3))
+        C32 = C.astype(np.float32)
+        row = np.concatenate([[rec[0]], C32.reshape(-1), rec[1:10], rec[10:13], rec[13:16], rec[16:61], rec[64:67], rec[61:64]])   # b as (acc, gyro)
+        pre[k2] = row.astype(np.float32)
+        hasp[k2] = 1
+        Cs = 0.5 * (C32[:9, :9].astype(np.float64) + C32[:9, :9].astype(np.float64).T)
+        wv, V = np.linalg.eigh(Cs)
+        infos[m] = ((V * (1.0 / wv)) @ V.T, np.linalg.inv(C32[9:12, 9:12].astype(np.float64)).astype(np.float32).astype(np.float64),
+                    np.linalg.inv(C32[12:15, 12:15].astype(np.float64)).astype(np.float32).astype(np.float64))
+    c["pre"], c["hasp"], c["infos"] = pre, hasp, infos
+    return c
+
+
+def _write_liba(path, c, n_in_map):
+    win = c["win"]
+    with open(path, "wb") as f:
+        np.array([win.n_kf, len(c["points"]), len(c["edge_kf"]), 0, n_in_map, 1 if c["large"] else 0, 0, 0], np.int32).tofile(f)
+        np.array(win.cam, np.float32).tofile(f); c["Tcb"].tofile(f)
+        c["ids"].tofile(f); c["Tcw"].tofile(f); c["prev"].tofile(f); c["bimu"].tofile(f); c["vel"].tofile(f); c["bias"].tofile(f)
+        c["hasp"].tofile(f); c["pre"].tofile(f); c["points"].tofile(f); c["depth"].tofile(f)
+        c["edge_kf"].tofile(f); c["edge_point"].tofile(f); c["edge_obs"].astype(np.float32).tofile(f); c["edge_oct"].tofile(f); c["inv_s2"].tofile(f)
+
+
+def _expected_liba(c):
+    """The oracle on exactly what the C++ function reads from the objects (float poses / states widened to double)."""
+    import oracle_iba_bind as oib
+    import synth_iba
+    win = c["win"]
+    a = win.arrays
+    n_kf = win.n_kf
+    kf = np.zeros((n_kf, 21))
+    Tcb = c["Tcb"]
+    for k in range(n_kf):
+        T = c["Tcw"][k]
+        Rwc = T[:3, :3].T
+        kf[k, :9] = (Rwc @ Tcb[:3, :3]).astype(np.float32).astype(np.float64).reshape(-1)                 # KeyFrame::GetImuRotation (float)
+        kf[k, 9:12] = (Rwc @ (Tcb[:3, 3] - T[:3, 3])).astype(np.float32).astype(np.float64)                # Owb = Rwc tcb + Ow
+        if c["bimu"][k]:
+            kf[k, 12:15] = c["vel"][k]; kf[k, 15:18] = c["bias"][k, 3:6]; kf[k, 18:21] = c["bias"][k, 0:3]
+    pre = a["in_preint"].copy()
+    info = np.stack([c["infos"][m][0] * (1e-2 if a["in_robust"][m] else 1.0) for m in range(win.n_inertial)])
+    d = dict(kf_fixed=a["kf_fixed"], kf_imu=a["kf_imu"], kf_state=kf, points=c["points"].astype(np.float64), cam=win.cam,
+             Rcb=Tcb[:3, :3].astype(np.float64), tcb=Tcb[:3, 3].astype(np.float64),
+             edge_kf=c["edge_kf"], edge_point=c["edge_point"], edge_obs=c["edge_obs"].astype(np.float32).astype(np.float64),
+             edge_stereo=c["edge_stereo"], edge_inv_sigma2=c["inv_s2"][c["edge_oct"]].astype(np.float64),
+             edge_close=(c["depth"][c["edge_point"]] < 10).astype(np.uint8),
+             in_kf1=a["in_kf1"], in_kf2=a["in_kf2"], in_preint=pre, in_info=info.reshape(len(info), -1),
+             in_info_g=np.stack([c["infos"][m][1].reshape(-1) for m in range(win.n_inertial)]),
+             in_info_a=np.stack([c["infos"][m][2].reshape(-1) for m in range(win.n_inertial)]), in_robust=a["in_robust"])
+    w2 = synth_iba.Window(d)
+    return w2, oib.solve(w2, oib.default_params(c["large"]))
+
+
+@pytest.mark.parametrize("variant", ["prev_outside_window", "chain_ends_inside"])
+def test_local_inertial_ba_drop_in(tmp_path, variant):
+    c = _liba_case(61 if variant == "prev_outside_window" else 63)
+    win = c["win"]
+    n_opt = c["n_opt"]
+    # KeyFramesInMap decides Nd = min(n - 2, 10): either the chain is cut after n_opt keyframes (the next one becomes the fixed
+    # keyframe, Optimizer.cc:4630-4634) or it runs to its end and the LAST keyframe is turned into the fixed one (:4635-4642)
+    n_in_map = n_opt + 2 if variant == "prev_outside_window" else 50
+    fin, fout = str(tmp_path / "liba_in.bin"), str(tmp_path / "liba_out.bin")
+    _write_liba(fin, c, n_in_map)
+    r = subprocess.run([EXE, "liba", fin, fout], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "HOST_LIBA_OK" in r.stdout, r.stdout + r.stderr
+    n_kf, n_pts = win.n_kf, len(c["points"])
+    with open(fout, "rb") as f:
+        Tcw = np.fromfile(f, np.float32, n_kf * 16).reshape(n_kf, 4, 4)
+        vel = np.fromfile(f, np.float32, n_kf * 3).reshape(n_kf, 3)
+        bias = np.fromfile(f, np.float32, n_kf * 6).reshape(n_kf, 6)
+        pts = np.fromfile(f, np.float32, n_pts * 3).reshape(n_pts, 3)
+        n_er = int(np.fromfile(f, np.int32, 1)[0])
+        erased = np.fromfile(f, np.int32, 2 * n_er).reshape(n_er, 2)
+        change = int(np.fromfile(f, np.int32, 1)[0])
+    # The oracle gets the object state re-derived in numpy (float products in another summation order than the C++ accessors):
+    # inputs agree to one float ulp, results to ~1e-7 unless an LM stopping test is within that of a tie (then ~1e-4, the
+    # north_star tolerance; the seeds used here are not such cases)
+    w2, (okf, opts, oout, ost) = _expected_liba(c)
+    assert ost.failed == 0 and change == 1
+    Tcb = c["Tcb"].astype(np.float64)
+    for k in range(n_kf):
+        R = okf[k, :9].reshape(3, 3); t = okf[k, 9:12]
+        Rcw = Tcb[:3, :3] @ R.T
+        assert np.allclose(Tcw[k, :3, :3], Rcw, atol=2e-5), (k, np.abs(Tcw[k, :3, :3] - Rcw).max())
+        assert np.allclose(Tcw[k, :3, 3], -Rcw @ t + Tcb[:3, 3], atol=5e-5)
+        if k < n_opt:
+            assert np.allclose(vel[k], okf[k, 12:15], atol=2e-5) and np.allclose(bias[k, 3:6], okf[k, 15:18], atol=1e-6) and np.allclose(bias[k, 0:3], okf[k, 18:21], atol=1e-5)
+        else:                                                                                     # fixed keyframes: untouched
+            assert np.array_equal(Tcw[k], c["Tcw"][k]) and np.array_equal(vel[k], c["vel"][k])
+    assert np.allclose(pts, opts, atol=5e-5), np.abs(pts - opts).max()
+    moved = np.linalg.norm(Tcw[:n_opt, :3, 3] - c["Tcw"][:n_opt, :3, 3], axis=1)
+    assert moved.max() > 1e-3                                                                     # the optimisation really ran
+    exp = {(int(k), int(l)) for k, l, o in zip(c["edge_kf"], c["edge_point"], oout) if o}
+    assert {(int(k), int(l)) for k, l in erased} == exp
