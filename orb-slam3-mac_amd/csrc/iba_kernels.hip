@@ -835,9 +835,12 @@ __global__ __launch_bounds__(IBA_THREADS) void k_iba_solve(IbaArgs A)
     const double err0 = chi;
     double lambda = A.lambda_init, ni = 2.0, last_chi = chi;
     int nbad = 0, trials = 0, its = 0;
+    bool errors_current = true;
     for (int it = 0; it < A.iterations; it++) {            // SparseOptimizer::optimize -> OptimizationAlgorithmLevenberg::solve
         long long t0 = clock64();
-        if (it > 0) { chi = iba_errors(C, T, cur); zero = 0.0; team_sum2(T, chi, zero, red); }      // levenberg.cpp:71 (the stored errors may be a rejected trial's)
+        // levenberg.cpp:71 computeActiveErrors: after an ACCEPTED trial the stored errors already are those of the current
+        // estimate (same inputs, same code: recomputing gives the same bits), only a rejected trial leaves stale ones behind
+        if (it > 0 && !errors_current) { chi = iba_errors(C, T, cur); zero = 0.0; team_sum2(T, chi, zero, red); }
         double current_chi = chi;
         const double ini_chi = chi;
         long long t1 = clock64();
@@ -861,8 +864,10 @@ __global__ __launch_bounds__(IBA_THREADS) void k_iba_solve(IbaArgs A)
                 alpha = fmin(alpha, 2. / 3.);
                 lambda *= fmax(1. / 3., alpha); ni = 2.0; current_chi = tmp;
                 cur ^= 1;
+                errors_current = true; chi = tmp;
             } else {
                 lambda *= ni; ni *= 2;
+                errors_current = false;
             }
             qmax++; trials++;
         } while (rho < 0 && qmax < A.max_trials && !__hip_atomic_load(T.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
