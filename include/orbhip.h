@@ -547,7 +547,7 @@ int orbhip_mfma_f64_peak_tflops(orbhip_ctx *ctx, double *tflops_out);
  * (include/G2oTypes.h:131-240); EdgeMono / EdgeStereo to the landmarks (src/G2oTypes.cc:349-482), one EdgeInertial + EdgeGyroRW
  * + EdgeAccRW per pair of consecutive keyframes (src/G2oTypes.cc:693-800, include/G2oTypes.h:632-700).  The caller builds the
  * window exactly as :4588-4682 does (temporal keyframes, the fixed previous one, fixed covisible ones) and passes flat arrays.
- * Pinhole cameras, one camera per keyframe (the KannalaBrandt8 / second-camera EdgeMono(1) branches are not covered).
+ * Pinhole and KannalaBrandt8 cameras; keyframes of a two-camera rig (mpCamera2, mTrl) with EdgeMono(1) edges on the right camera.
  * Up to 32 keyframes with IMU states (480 unknowns; the reference caps the window at 10, 25 when bLarge).
  * Deviations from the reference's arithmetic, all far below the 1e-4 parity tolerance: the bias-corrected preintegrated deltas
  * (src/ImuTypes.cc:357-378) and ExpSO3's re-orthonormalisation (src/G2oTypes.cc:991-1008) are evaluated in double instead of
@@ -559,12 +559,20 @@ typedef struct {
     const uint8_t *kf_fixed;        /* setFixed(true): lFixedKeyFrames (:4757-4781) */
     const uint8_t *kf_imu;          /* pKFi->bImu (:4726-4740); keyframes without it have only the pose vertex */
     double Rcb[9], tcb[3];          /* mImuCalib.Tcb */
-    double fx, fy, cx, cy, bf;
+    double fx, fy, cx, cy, bf;      /* pKF->mpCamera, mbf */
+    int32_t camera_model;           /* 0 Pinhole, 1 KannalaBrandt8 */
+    double kb[4];
+    int32_t has_cam2;               /* pKF->mpCamera2 != NULL: ImuCamPose carries a second camera (src/G2oTypes.cc:57-67) */
+    double Trl[12];                 /* pKF->mTrl, 3x4 row-major */
+    double fx2, fy2, cx2, cy2;
+    int32_t camera2_model;
+    double kb2[4];
     int32_t n_points;
     int32_t n_edges;                /* grouped by point: edge_point ascending, as :4914-5034 creates them */
     const int32_t *edge_kf, *edge_point;
     const double *edge_obs;         /* [3]: kpUn.pt.x, kpUn.pt.y, mvuRight */
-    const uint8_t *edge_stereo;     /* 0 EdgeMono(0), 1 EdgeStereo(0) */
+    const uint8_t *edge_stereo;     /* 0 EdgeMono(0), 1 EdgeStereo(0), 2 EdgeMono(1): right-camera observation (:5000-5031; has_cam2);
+                                       a keyframe may hold a left and a right edge to the same point */
     const double *edge_inv_sigma2;  /* mvInvLevelSigma2[octave] / uncertainty2 (:4949-4952) */
     const uint8_t *edge_close;      /* pMP->mTrackDepth < 10 (:5063); may be NULL */
     int32_t n_inertial;

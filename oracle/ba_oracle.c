@@ -147,7 +147,7 @@ static void map_point(const double pose[7], const double X[3], double Xc[3])   /
 }
 
 /* KannalaBrandt8::project(Eigen::Vector3d), KannalaBrandt8.cpp:52-69: float atan2f / sqrtf, double cos / sin */
-static void kb8_project(const double P[3], double fx, double fy, double cx, double cy, const double k[4], double uv[2])
+void orc_kb8_project(const double P[3], double fx, double fy, double cx, double cy, const double k[4], double uv[2])
 {
     const double x2_plus_y2 = P[0] * P[0] + P[1] * P[1];
     /* the reference calls libm atan2f / sqrtf on floats; libm's atan2f differs between platforms in the last float ulp
@@ -161,7 +161,7 @@ static void kb8_project(const double P[3], double fx, double fy, double cx, doub
     uv[1] = fy * r * sin(psi) + cy;
 }
 /* KannalaBrandt8::projectJac(Eigen::Vector3d), KannalaBrandt8.cpp:166-195; J row-major 2x3 */
-static void kb8_project_jac(const double v[3], double fx, double fy, const double k[4], double J[6])
+void orc_kb8_project_jac(const double v[3], double fx, double fy, const double k[4], double J[6])
 {
     const double x2 = v[0] * v[0], y2 = v[1] * v[1], z2 = v[2] * v[2];
     const double r2 = x2 + y2, r = sqrt(r2), r3 = r2 * r;
@@ -185,7 +185,7 @@ static void edge_error_cam(const double pose[7], const double X[3], const double
     map_point(pose, X, P);
     if (!stereo && kb) {                              /* OptimizableTypes.h:99-104 with pCamera = KannalaBrandt8 */
         double uv[2];
-        kb8_project(P, fx, fy, cx, cy, kb, uv);
+        orc_kb8_project(P, fx, fy, cx, cy, kb, uv);
         err[0] = obs[0] - uv[0]; err[1] = obs[1] - uv[1]; err[2] = 0;
         return;
     }
@@ -217,7 +217,7 @@ void orc_ba_edge_kb8(const double pose[7], const double X[3], const double obs[3
     edge_error_cam(pose, X, obs, 0, fx, fy, cx, cy, 0.0, k, err);
     map_point(pose, X, P);
     quat_to_R(pose, R);
-    kb8_project_jac(P, fx, fy, k, J);
+    orc_kb8_project_jac(P, fx, fy, k, J);
     const double x = P[0], y = P[1], z = P[2];
     for (int r = 0; r < 2; r++)
         for (int c = 0; c < 3; c++)
@@ -274,12 +274,12 @@ static void se3_mul(const double a[7], const double b[7], double o[7])
 }
 static void cam2_project(const orc_ba_graph *g, const double P[3], double uv[2])
 {
-    if (g->camera2_model == 1) kb8_project(P, g->fx2, g->fy2, g->cx2, g->cy2, g->kb2, uv);
+    if (g->camera2_model == 1) orc_kb8_project(P, g->fx2, g->fy2, g->cx2, g->cy2, g->kb2, uv);
     else { uv[0] = g->fx2 * P[0] / P[2] + g->cx2; uv[1] = g->fy2 * P[1] / P[2] + g->cy2; }      /* Pinhole.cpp:41-47 */
 }
 static void cam2_project_jac(const orc_ba_graph *g, const double P[3], double J[6])
 {
-    if (g->camera2_model == 1) kb8_project_jac(P, g->fx2, g->fy2, g->kb2, J);
+    if (g->camera2_model == 1) orc_kb8_project_jac(P, g->fx2, g->fy2, g->kb2, J);
     else {                                                                                   /* Pinhole.cpp:81-91 */
         J[0] = g->fx2 / P[2]; J[1] = 0; J[2] = -g->fx2 * P[0] / (P[2] * P[2]);
         J[3] = 0; J[4] = g->fy2 / P[2]; J[5] = -g->fy2 * P[1] / (P[2] * P[2]);
@@ -713,7 +713,7 @@ static void po_edge_error(const orc_pose_problem *P, const double pose[7], int e
     map_point(pose, P->Xw + 3 * e, Xc);
     if (obs[2] < 0 && P->camera_model == 1) {              /* OptimizableTypes.h:41-45 with pCamera = KannalaBrandt8 */
         double uv[2];
-        kb8_project(Xc, P->fx, P->fy, P->cx, P->cy, P->kb, uv);
+        orc_kb8_project(Xc, P->fx, P->fy, P->cx, P->cy, P->kb, uv);
         er[0] = obs[0] - uv[0]; er[1] = obs[1] - uv[1]; er[2] = 0;
     } else if (obs[2] < 0) {                               /* OptimizableTypes.h:41-45, Pinhole.cpp:41-47 */
         er[0] = obs[0] - (P->fx * Xc[0] / Xc[2] + P->cx);

@@ -102,6 +102,10 @@ typedef struct {
 } orc_pose_problem;
 typedef struct { int32_t rounds, iterations[4], lm_trials, n_bad; } orc_pose_stats;
 int orc_pose_optimization(const orc_pose_problem *P, double pose7[7], uint8_t *outlier, orc_pose_stats *stats);
+/* KannalaBrandt8::project / projectJac (KannalaBrandt8.cpp:52-69, 166-195), shared with iba_oracle.c; J row-major 2x3 */
+void orc_kb8_project(const double P[3], double fx, double fy, double cx, double cy, const double k[4], double uv[2]);
+void orc_kb8_project_jac(const double v[3], double fx, double fy, const double k[4], double J[6]);
+
 #ifdef __cplusplus
 }
 #endif

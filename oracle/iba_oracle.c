@@ -3,6 +3,7 @@
  * "IMU" = src/ImuTypes.cc, "LM" = Thirdparty/g2o/g2o/core/optimization_algorithm_levenberg.cpp,
  * "BS" = Thirdparty/g2o/g2o/core/block_solver.hpp, "BME" = Thirdparty/g2o/g2o/core/base_multi_edge.hpp. */
 #include "iba_oracle.h"
+#include "ba_oracle.h"
 #include <float.h>
 #include <math.h>
 #include <stdlib.h>
@@ -122,46 +123,75 @@ void orc_iba_kf_update(double *s, const double *dx, int imu)
     if (imu) for (int i = 0; i < 9; i++) s[K_V + i] += dx[6 + i];       /* G2H:202-206 and the two bias vertices */
 }
 
+/* camera cam_idx of the rig: Rcb, tcb (G2T:49-52, 57-67) and its intrinsics */
+struct camview { double Rcb[9], tcb[3], fx, fy, cx, cy; int model; const double *kb; };
+static void cam_view(const orc_iba_problem *g, int cam_idx, struct camview *c)
+{
+    if (!cam_idx) {
+        memcpy(c->Rcb, g->Rcb, sizeof(c->Rcb)); memcpy(c->tcb, g->tcb, sizeof(c->tcb));
+        c->fx = g->fx; c->fy = g->fy; c->cx = g->cx; c->cy = g->cy; c->model = g->camera_model; c->kb = g->kb;
+    } else {
+        double Rrl[9];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rrl[3 * i + j] = g->Trl[4 * i + j];
+        mm(Rrl, g->Rcb, c->Rcb);
+        mv(Rrl, g->tcb, c->tcb);
+        for (int i = 0; i < 3; i++) c->tcb[i] += g->Trl[4 * i + 3];
+        c->fx = g->fx2; c->fy = g->fy2; c->cx = g->cx2; c->cy = g->cy2; c->model = g->camera2_model; c->kb = g->kb2;
+    }
+}
 /* Rcw = Rcb Rbw, tcw = Rcb tbw + tcb (G2T:212-219) */
-static void cam_pose(const orc_iba_problem *g, const double *s, double *Rcw, double *tcw)
+static void cam_pose_of(const struct camview *c, const double *s, double *Rcw, double *tcw)
 {
     double Rbw[9], tbw[3];
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rbw[3 * i + j] = s[K_R + 3 * j + i];
     mv(Rbw, s + K_T, tbw);
     for (int i = 0; i < 3; i++) tbw[i] = -tbw[i];
-    mm(g->Rcb, Rbw, Rcw);
-    mv(g->Rcb, tbw, tcw);
-    for (int i = 0; i < 3; i++) tcw[i] += g->tcb[i];
+    mm(c->Rcb, Rbw, Rcw);
+    mv(c->Rcb, tbw, tcw);
+    for (int i = 0; i < 3; i++) tcw[i] += c->tcb[i];
+}
+static void cam_pose(const orc_iba_problem *g, const double *s, double *Rcw, double *tcw)      /* left camera */
+{
+    struct camview c;
+    cam_view(g, 0, &c);
+    cam_pose_of(&c, s, Rcw, tcw);
 }
 
-/* ------------------------------------------------------------------ edges */
-static void visual_error(const orc_iba_problem *g, const double *s, const double X[3], const double obs[3], int stereo, double err[3], double Xc[3], double Rcw[9])
+/* ------------------------------------------------------------------ edges (type: 0 EdgeMono(0), 1 EdgeStereo(0), 2 EdgeMono(1)) */
+static void visual_error(const orc_iba_problem *g, const double *s, const double X[3], const double obs[3], int type, double err[3], double Xc[3], double Rcw[9])
 {
-    double tcw[3];
-    cam_pose(g, s, Rcw, tcw);
+    struct camview c;
+    double tcw[3], uv[2];
+    cam_view(g, type == 2, &c);
+    cam_pose_of(&c, s, Rcw, tcw);
     mv(Rcw, X, Xc);
     for (int i = 0; i < 3; i++) Xc[i] += tcw[i];
-    const double u = g->fx * Xc[0] / Xc[2] + g->cx, v = g->fy * Xc[1] / Xc[2] + g->cy;      /* Pinhole::project */
-    err[0] = obs[0] - u; err[1] = obs[1] - v;                                               /* G2H:350-355 */
-    err[2] = stereo ? obs[2] - (u - g->bf * (1 / Xc[2])) : 0.0;                             /* G2T:177-185 */
+    if (c.model == 1) orc_kb8_project(Xc, c.fx, c.fy, c.cx, c.cy, c.kb, uv);
+    else { uv[0] = c.fx * Xc[0] / Xc[2] + c.cx; uv[1] = c.fy * Xc[1] / Xc[2] + c.cy; }      /* Pinhole::project */
+    err[0] = obs[0] - uv[0]; err[1] = obs[1] - uv[1];                                        /* G2H:350-355 */
+    err[2] = type == 1 ? obs[2] - (uv[0] - g->bf * (1 / Xc[2])) : 0.0;                       /* G2T:177-185 */
 }
 
-void orc_iba_edge_visual(const orc_iba_problem *g, const double *s, const double X[3], const double obs[3], int stereo,
+void orc_iba_edge_visual(const orc_iba_problem *g, const double *s, const double X[3], const double obs[3], int type,
                          double err[3], double Jx[9], double Jp[18])
 {
+    struct camview c;
     double Xc[3], Rcw[9];
-    visual_error(g, s, X, obs, stereo, err, Xc, Rcw);
+    cam_view(g, type == 2, &c);
+    visual_error(g, s, X, obs, type, err, Xc, Rcw);
     /* G2T:349-373 / :397-423 */
-    double pj[9] = {g->fx / Xc[2], 0, -g->fx * Xc[0] / (Xc[2] * Xc[2]), 0, g->fy / Xc[2], -g->fy * Xc[1] / (Xc[2] * Xc[2]), 0, 0, 0};
-    const int D = stereo ? 3 : 2;
+    double pj[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (c.model == 1) orc_kb8_project_jac(Xc, c.fx, c.fy, c.kb, pj);
+    else { pj[0] = c.fx / Xc[2]; pj[2] = -c.fx * Xc[0] / (Xc[2] * Xc[2]); pj[4] = c.fy / Xc[2]; pj[5] = -c.fy * Xc[1] / (Xc[2] * Xc[2]); }
+    const int stereo = type == 1, D = stereo ? 3 : 2;
     if (stereo) { pj[6] = pj[0]; pj[7] = pj[1]; pj[8] = pj[2] + g->bf * (1.0 / (Xc[2] * Xc[2])); }
     memset(Jx, 0, 72); memset(Jp, 0, 144);
     for (int d = 0; d < D; d++) for (int j = 0; j < 3; j++) Jx[3 * d + j] = -(pj[3 * d] * Rcw[j] + pj[3 * d + 1] * Rcw[3 + j] + pj[3 * d + 2] * Rcw[6 + j]);
-    double Xb[3], d0[3] = {Xc[0] - g->tcb[0], Xc[1] - g->tcb[1], Xc[2] - g->tcb[2]};
-    mtv(g->Rcb, d0, Xb);                     /* Xb = Rbc Xc + tbc with Tbc = Tcb^-1 */
+    double Xb[3], d0[3] = {Xc[0] - c.tcb[0], Xc[1] - c.tcb[1], Xc[2] - c.tcb[2]};
+    mtv(c.Rcb, d0, Xb);                      /* Xb = Rbc Xc + tbc with Tbc = Tcb^-1 */
     const double SE3[18] = {0, Xb[2], -Xb[1], 1, 0, 0, -Xb[2], 0, Xb[0], 0, 1, 0, Xb[1], -Xb[0], 0, 0, 0, 1};
     double PR[9];
-    mm(pj, g->Rcb, PR);
+    mm(pj, c.Rcb, PR);
     for (int d = 0; d < D; d++) for (int j = 0; j < 6; j++) Jp[6 * d + j] = PR[3 * d] * SE3[j] + PR[3 * d + 1] * SE3[6 + j] + PR[3 * d + 2] * SE3[12 + j];
 }
 
@@ -280,7 +310,7 @@ static double robust_chi2(const struct iba *B)
 {
     double chi = 0, rho[2];
     for (int e = 0; e < B->E; e++) {
-        if (B->g->edge_stereo[e]) huber(B->chi2[e], B->delta_s, B->dsqr_s, rho); else huber(B->chi2[e], B->delta_m, B->dsqr_m, rho);
+        if (B->g->edge_stereo[e] == 1) huber(B->chi2[e], B->delta_s, B->dsqr_s, rho); else huber(B->chi2[e], B->delta_m, B->dsqr_m, rho);
         chi += rho[0];
     }
     for (int m = 0; m < B->M; m++) {
@@ -329,11 +359,11 @@ static void build_system(struct iba *B)
     memset(B->bl, 0, sizeof(double) * 3 * B->L);
     memset(B->W, 0, sizeof(double) * 18 * B->E);
     for (int e = 0; e < B->E; e++) {
-        const int st = g->edge_stereo[e], D = st ? 3 : 2, k = g->edge_kf[e], li = g->edge_point[e], o = B->off[k];
+        const int st = g->edge_stereo[e], D = st == 1 ? 3 : 2, k = g->edge_kf[e], li = g->edge_point[e], o = B->off[k];
         double er[3], Jx[9], Jp[18], rho[2];
         orc_iba_edge_visual(g, B->kf + ORC_IBA_KF * k, B->pts + 3 * li, g->edge_obs + 3 * e, st, er, Jx, Jp);
         const double *es = B->err + 3 * e;            /* the stored _error of the last computeActiveErrors (same state) */
-        if (st) huber(B->chi2[e], B->delta_s, B->dsqr_s, rho); else huber(B->chi2[e], B->delta_m, B->dsqr_m, rho);
+        if (st == 1) huber(B->chi2[e], B->delta_s, B->dsqr_s, rho); else huber(B->chi2[e], B->delta_m, B->dsqr_m, rho);
         const double w = rho[1] * g->edge_inv_sigma2[e];
         for (int a = 0; a < 3; a++) {
             double s = 0;
@@ -546,12 +576,14 @@ int orc_iba_solve(const orc_iba_problem *g, const orc_iba_params *p, double *kf_
     /* LIBA:5056-5088 (chi2() of the stored errors, isDepthPositive of the final estimates) */
     for (int e = 0; e < E; e++) {
         int out;
-        if (g->edge_stereo[e]) out = B.chi2[e] > (double)7.815f;
+        if (g->edge_stereo[e] == 1) out = B.chi2[e] > (double)7.815f;
         else {
+            struct camview c;
             double Rcw[9], tcw[3];
-            cam_pose(g, B.kf + ORC_IBA_KF * g->edge_kf[e], Rcw, tcw);
+            cam_view(g, g->edge_stereo[e] == 2, &c);
+            cam_pose_of(&c, B.kf + ORC_IBA_KF * g->edge_kf[e], Rcw, tcw);
             const double *X = B.pts + 3 * g->edge_point[e];
-            const int depth_pos = (Rcw[6] * X[0] + Rcw[7] * X[1] + Rcw[8] * X[2] + tcw[2]) > 0.0;
+            const int depth_pos = (Rcw[6] * X[0] + Rcw[7] * X[1] + Rcw[8] * X[2] + tcw[2]) > 0.0;      /* isDepthPositive(Xw, cam_idx) */
             const int close = g->edge_close ? g->edge_close[e] : 0;
             out = (B.chi2[e] > (double)5.991f && !close) || (B.chi2[e] > (double)(1.5f * 5.991f) && close) || !depth_pos;
         }

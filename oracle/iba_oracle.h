@@ -34,12 +34,20 @@ typedef struct {
     const uint8_t *kf_fixed;        /* setFixed(true): lFixedKeyFrames (Optimizer.cc:4757-4781) */
     const uint8_t *kf_imu;          /* pKFi->bImu: the keyframe has VertexVelocity / GyroBias / AccBias (:4726-4740) */
     double Rcb[9], tcb[3];          /* mImuCalib.Tcb (G2oTypes.cc:49-52) */
-    double fx, fy, cx, cy, bf;      /* Pinhole */
+    double fx, fy, cx, cy, bf;      /* pCamera[0] */
+    int32_t camera_model;           /* 0 Pinhole, 1 KannalaBrandt8 (project / projectJac of src/CameraModels/) */
+    double kb[4];
+    int32_t has_cam2;               /* pKF->mpCamera2: ImuCamPose holds a second camera (G2oTypes.cc:57-67) */
+    double Trl[12];                 /* pKF->mTrl, 3x4 row-major: Rcb[1] = Rrl Rcb[0], tcb[1] = Rrl tcb[0] + trl */
+    double fx2, fy2, cx2, cy2;
+    int32_t camera2_model;
+    double kb2[4];
     int32_t n_points;
     int32_t n_edges;                /* EdgeMono / EdgeStereo, grouped by point (ascending edge_point), as :4914-5034 creates them */
     const int32_t *edge_kf, *edge_point;
     const double *edge_obs;         /* [3]: kpUn.pt.x, kpUn.pt.y, mvuRight (unused when mono) */
-    const uint8_t *edge_stereo;     /* 0 EdgeMono(0), 1 EdgeStereo(0) */
+    const uint8_t *edge_stereo;     /* 0 EdgeMono(0), 1 EdgeStereo(0), 2 EdgeMono(1) (right camera, Optimizer.cc:5000-5031); a keyframe may
+                                       hold a left and a right edge to the same point */
     const double *edge_inv_sigma2;  /* mvInvLevelSigma2[octave] / uncertainty2 (:4949-4952) */
     const uint8_t *edge_close;      /* pMP->mTrackDepth < 10 (:5063): monocular gate 1.5 x 5.991 */
     int32_t n_inertial;             /* EdgeInertial + EdgeGyroRW + EdgeAccRW triples (:4784-4868) */
@@ -74,7 +82,7 @@ void orc_iba_kf_update(double *s, const double *dx, int imu);      /* ImuCamPose
 /* EdgeInertial::computeError / linearizeOplus: J [9][24], columns = pose1(6) v1(3) bg1(3) ba1(3) pose2(6) v2(3) */
 void orc_iba_edge_inertial(const double *s1, const double *s2, const double *preint, double err[9], double J[216]);
 /* EdgeMono / EdgeStereo: err[3], Jx [3][3] (point), Jp [3][6] (pose); rows 0..1 only when mono */
-void orc_iba_edge_visual(const orc_iba_problem *g, const double *s, const double X[3], const double obs[3], int stereo,
+void orc_iba_edge_visual(const orc_iba_problem *g, const double *s, const double X[3], const double obs[3], int type,
                          double err[3], double Jx[9], double Jp[18]);
 void orc_iba_exp_so3(const double w[3], double R[9]);
 void orc_iba_log_so3(const double R[9], double w[3]);

@@ -15,6 +15,7 @@
 #include "orb_internal.h"
 #include "wave_dpp.h"
 #include "ba_ldlt.h"
+#include "ba_camera.h"
 // The library is built with -ffp-contract=off for the bit-exact integer / float ORB paths.  The double-precision optimisers are
 // compared with the oracle to 1e-4, not bit for bit: let a * b + c contract to v_fma_f64 here (half the FP64 instructions).
 #pragma clang fp contract(fast)
@@ -47,6 +48,8 @@ struct IbaWin {
     int kf_off, pt_off, e_off, m_off, x_off, free_off, ptstart_off, kfe_off, ktask_off, ktstart_off, ptask_off, ptstart2_off;
     long long pent_off, h_off;
     double Rcb[9], tcb[3], fx, fy, cx, cy, bf;
+    int cam_model, has_cam2, cam2_model;            // camera 0; a second camera of the rig (EdgeMono(1) edges, edge type 2)
+    double kb[4], Rcb2[9], tcb2[3], fx2, fy2, cx2, cy2, kb2[4];
 };
 
 struct IbaArgs {
@@ -66,7 +69,7 @@ struct IbaArgs {
     const int *pair_task_start;         // per window npairs + 1
     const int *in_kf1, *in_kf2, *in_color; const uint8_t *in_robust;
     const double *in_pre, *in_info, *in_info_g, *in_info_a;
-    double *kfs, *cam, *pts;            // estimates, two buffers each: [2][sumKF][21], [2][sumKF][12] (Rcw, tcw), [2][sumL][3]
+    double *kfs, *cam, *pts;            // estimates, two buffers each: [2][sumKF][21], [2][sumKF][2 cameras][12] (Rcw, tcw), [2][sumL][3]
     long long kfs_stride, cam_stride, pts_stride;
     double *err, *chi2, *W, *Hll, *bl, *Dinv, *db, *xl;
     double *ierr, *ichi2, *Jb, *OJ, *Oe;
@@ -196,7 +199,16 @@ __device__ __forceinline__ double oct_allreduce_f64(double v)
     return v;
 }
 
-// Rcw = Rcb Rbw, tcw = Rcb tbw + tcb (ImuCamPose::Update, G2oTypes.cc:212-219)
+// camera `idx` of the rig: extrinsics w.r.t. the body (G2oTypes.cc:49-52, 57-67) and intrinsics
+struct CamView { const double *Rcb, *tcb, *kb; double fx, fy, cx, cy; int model; };
+__device__ __forceinline__ CamView cam_view(const IbaWin &W, int idx)
+{
+    CamView V;
+    if (idx == 0) { V.Rcb = W.Rcb; V.tcb = W.tcb; V.kb = W.kb; V.fx = W.fx; V.fy = W.fy; V.cx = W.cx; V.cy = W.cy; V.model = W.cam_model; }
+    else { V.Rcb = W.Rcb2; V.tcb = W.tcb2; V.kb = W.kb2; V.fx = W.fx2; V.fy = W.fy2; V.cx = W.cx2; V.cy = W.cy2; V.model = W.cam2_model; }
+    return V;
+}
+// Rcw = Rcb Rbw, tcw = Rcb tbw + tcb for every camera of the keyframe (ImuCamPose::Update, G2oTypes.cc:212-219); c: [2][12]
 __device__ void cam_pose(const IbaWin &W, const double *s, double *c)
 {
     double Rbw[9], tbw[3];
@@ -206,38 +218,43 @@ __device__ void cam_pose(const IbaWin &W, const double *s, double *c)
         for (int j = 0; j < 3; j++) Rbw[3 * i + j] = s[K_R + 3 * j + i];
     mv3(Rbw, s + K_T, tbw);
     for (int i = 0; i < 3; i++) tbw[i] = -tbw[i];
-    double R[9], t[3];
-    mm3(W.Rcb, Rbw, R);
-    mv3(W.Rcb, tbw, t);
-    for (int i = 0; i < 9; i++) c[i] = R[i];
-    for (int i = 0; i < 3; i++) c[9 + i] = t[i] + W.tcb[i];
+    for (int cam = 0; cam <= W.has_cam2; cam++) {
+        const CamView V = cam_view(W, cam);
+        double R[9], t[3];
+        mm3(V.Rcb, Rbw, R);
+        mv3(V.Rcb, tbw, t);
+        for (int i = 0; i < 9; i++) c[12 * cam + i] = R[i];
+        for (int i = 0; i < 3; i++) c[12 * cam + 9 + i] = t[i] + V.tcb[i];
+    }
 }
 
-// EdgeMono / EdgeStereo::computeError (G2oTypes.h:350-355, G2oTypes.cc:170-185)
-__device__ __forceinline__ void visual_error(const IbaWin &W, const double *c, const double *X, const double *obs, int stereo, double *er, double *Xc)
+// EdgeMono / EdgeStereo::computeError (G2oTypes.h:350-355, G2oTypes.cc:170-185); type 0 EdgeMono(0), 1 EdgeStereo(0), 2 EdgeMono(1);
+// c = the pose of the edge's camera
+__device__ __forceinline__ void visual_error(const IbaWin &W, const CamView &V, const double *c, const double *X, const double *obs, int type, double *er, double *Xc)
 {
     mv3(c, X, Xc);
     Xc[0] += c[9]; Xc[1] += c[10]; Xc[2] += c[11];
-    const double u = W.fx * Xc[0] / Xc[2] + W.cx, v = W.fy * Xc[1] / Xc[2] + W.cy;
-    er[0] = obs[0] - u; er[1] = obs[1] - v;
-    er[2] = stereo ? obs[2] - (u - W.bf * (1 / Xc[2])) : 0.0;
+    double uv[2];
+    cam_project(V.fx, V.fy, V.cx, V.cy, V.model, V.kb, Xc, uv);
+    er[0] = obs[0] - uv[0]; er[1] = obs[1] - uv[1];
+    er[2] = type == 1 ? obs[2] - (uv[0] - W.bf * (1 / Xc[2])) : 0.0;
 }
 
 // linearizeOplus (G2oTypes.cc:349-373, :397-423): Jx [3][3], Jp [3][6]; row 2 zero when mono
-__device__ void visual_jac(const IbaWin &W, const double *c, const double *Xc, int stereo, double *Jx, double *Jp)
+__device__ void visual_jac(const IbaWin &W, const CamView &V, const double *c, const double *Xc, int type, double *Jx, double *Jp)
 {
-    const double iz = Xc[2], iz2 = Xc[2] * Xc[2];
-    double pj[9] = {W.fx / iz, 0, -W.fx * Xc[0] / iz2, 0, W.fy / iz, -W.fy * Xc[1] / iz2, 0, 0, 0};
-    if (stereo) { pj[6] = pj[0]; pj[7] = pj[1]; pj[8] = pj[2] + W.bf * (1.0 / iz2); }
+    double pj[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    cam_project_jac(V.fx, V.fy, V.model, V.kb, Xc, pj);
+    if (type == 1) { pj[6] = pj[0]; pj[7] = pj[1]; pj[8] = pj[2] + W.bf * (1.0 / (Xc[2] * Xc[2])); }
 #pragma unroll
     for (int d = 0; d < 3; d++)
 #pragma unroll
         for (int j = 0; j < 3; j++) Jx[3 * d + j] = -(pj[3 * d] * c[j] + pj[3 * d + 1] * c[3 + j] + pj[3 * d + 2] * c[6 + j]);
     double Xb[3];
-    const double d0[3] = {Xc[0] - W.tcb[0], Xc[1] - W.tcb[1], Xc[2] - W.tcb[2]};
-    mtv3(W.Rcb, d0, Xb);
+    const double d0[3] = {Xc[0] - V.tcb[0], Xc[1] - V.tcb[1], Xc[2] - V.tcb[2]};
+    mtv3(V.Rcb, d0, Xb);
     double PR[9];
-    mm3(pj, W.Rcb, PR);
+    mm3(pj, V.Rcb, PR);
 #pragma unroll
     for (int d = 0; d < 3; d++) {
         const double p0 = PR[3 * d], p1 = PR[3 * d + 1], p2 = PR[3 * d + 2];
@@ -373,15 +390,15 @@ struct IbaCtx {            // per-window views (all threads hold the same values
 __device__ __noinline__ double iba_errors(const IbaCtx &C, const Team &T, int buf)
 {
     const IbaWin &W = *C.W; const IbaArgs &A = *C.A;
-    const double *cam = A.cam + buf * A.cam_stride + (size_t)W.kf_off * 12;
+    const double *cam = A.cam + buf * A.cam_stride + (size_t)W.kf_off * 24;
     const double *pts = A.pts + buf * A.pts_stride + (size_t)W.pt_off * 3;
     const double *kfs = A.kfs + buf * A.kfs_stride + (size_t)W.kf_off * IBA_KF;
     double part = 0.0;
     for (int e = T.gtid; e < W.E; e += T.gsize) {
         const size_t ge = (size_t)W.e_off + e;
-        const int st = A.edge_stereo[ge];
+        const int type = A.edge_stereo[ge], st = type == 1;
         double er[3], Xc[3];
-        visual_error(W, cam + 12 * A.edge_kf[ge], pts + 3 * A.edge_point[ge], A.edge_obs + 3 * ge, st, er, Xc);
+        visual_error(W, cam_view(W, type == 2), cam + 24 * A.edge_kf[ge] + 12 * (type == 2), pts + 3 * A.edge_point[ge], A.edge_obs + 3 * ge, type, er, Xc);
         const double chi = (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * A.edge_is2[ge];
         A.err[3 * ge] = er[0]; A.err[3 * ge + 1] = er[1]; A.err[3 * ge + 2] = er[2];
         A.chi2[ge] = chi;
@@ -424,18 +441,18 @@ __device__ __forceinline__ void kf_block_task(const IbaCtx &C, const double *cam
     constexpr int A0 = HALF ? 4 : 0, A1 = HALF ? 6 : 4, Q0 = HALF ? 10 : 0, NQ = HALF ? 11 : 10, NB = HALF ? 0 : 6;
     const int lane = threadIdx.x & 63;
     const int k = A.free_kf[W.free_off + task.x];
-    const double *c = cam + 12 * k;
     const int *kf_edges = A.kf_edges + W.kfe_off;
     double acc[NQ + NB + 1];
 #pragma unroll
     for (int i = 0; i < NQ + NB; i++) acc[i] = 0.0;
     for (int j = task.y + lane; j < task.z; j += 64) {
         const size_t ge = (size_t)W.e_off + kf_edges[j];
-        const int st = A.edge_stereo[ge];
+        const int type = A.edge_stereo[ge], st = type == 1;
+        const double *c = cam + 24 * k + 12 * (type == 2);
         const double *X = pts + 3 * A.edge_point[ge];
         double Xc[3], Jx[9], Jp[18], r0, r1;
         mv3(c, X, Xc); Xc[0] += c[9]; Xc[1] += c[10]; Xc[2] += c[11];
-        visual_jac(W, c, Xc, st, Jx, Jp);
+        visual_jac(W, cam_view(W, type == 2), c, Xc, type, Jx, Jp);
         huber(A.chi2[ge], st ? C.delta_s : C.delta_m, st ? C.dsqr_s : C.dsqr_m, r0, r1);
         const double w = r1 * A.edge_is2[ge];
         int q = 0;
@@ -466,7 +483,7 @@ __device__ __noinline__ void iba_build(const IbaCtx &C, Team &T, int buf)
 {
     const IbaWin &W = *C.W; const IbaArgs &A = *C.A;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = W.n;
-    const double *cam = A.cam + buf * A.cam_stride + (size_t)W.kf_off * 12;
+    const double *cam = A.cam + buf * A.cam_stride + (size_t)W.kf_off * 24;
     const double *pts = A.pts + buf * A.pts_stride + (size_t)W.pt_off * 3;
     const double *kfs = A.kfs + buf * A.kfs_stride + (size_t)W.kf_off * IBA_KF;
     double *H = A.H + W.h_off, *b = A.b + W.x_off;
@@ -493,11 +510,11 @@ __device__ __noinline__ void iba_build(const IbaCtx &C, Team &T, int buf)
         const int e_end = l0 < W.L ? pt_start[l + 1] : 0;
         for (int e = pt_start[l] + sub; e < e_end; e += 8) {
             const size_t ge = (size_t)W.e_off + e;
-            const int st = A.edge_stereo[ge], k = A.edge_kf[ge];
-            const double *c = cam + 12 * k;
+            const int type = A.edge_stereo[ge], st = type == 1, k = A.edge_kf[ge];
+            const double *c = cam + 24 * k + 12 * (type == 2);
             double Xc[3], Jx[9], Jp[18], r0, r1;
             mv3(c, X, Xc); Xc[0] += c[9]; Xc[1] += c[10]; Xc[2] += c[11];
-            visual_jac(W, c, Xc, st, Jx, Jp);
+            visual_jac(W, cam_view(W, type == 2), c, Xc, type, Jx, Jp);
             huber(A.chi2[ge], st ? C.delta_s : C.delta_m, st ? C.dsqr_s : C.dsqr_m, r0, r1);
             const double w = r1 * A.edge_is2[ge];
             const double es[3] = {-w * A.err[3 * ge], -w * A.err[3 * ge + 1], st ? -w * A.err[3 * ge + 2] : 0.0};
@@ -649,7 +666,7 @@ __device__ __forceinline__ void pair_task(const IbaCtx &C, int4 task, bool diag,
 #pragma unroll
             for (int c = 0; c < 6; c++) acc[6 * a + c] += y0 * wi[3 * c] + y1 * wi[3 * c + 1] + y2 * wi[3 * c + 2];
         }
-        if (!HALF && diag) {
+        if (!HALF && diag && en.x == en.y) {                  // W db once per edge (a keyframe's left / right twin edges also pair with each other)
             const double *db = A.db + 3 * gl;
 #pragma unroll
             for (int a = 0; a < 6; a++) acc[18 + a] += wi[3 * a] * db[0] + wi[3 * a + 1] * db[1] + wi[3 * a + 2] * db[2];
@@ -774,7 +791,7 @@ __device__ __noinline__ bool iba_trial(const IbaCtx &C, Team &T, int buf, double
     // oplus on the keyframe vertices (ImuCamPose::Update, G2oTypes.cc:192-220; the velocity / bias vertices add)
     const double *cur_kf = A.kfs + buf * A.kfs_stride + (size_t)W.kf_off * IBA_KF;
     double *new_kf = A.kfs + (buf ^ 1) * A.kfs_stride + (size_t)W.kf_off * IBA_KF;
-    double *new_cam = A.cam + (buf ^ 1) * A.cam_stride + (size_t)W.kf_off * 12;
+    double *new_cam = A.cam + (buf ^ 1) * A.cam_stride + (size_t)W.kf_off * 24;
     for (int k = T.gsize - 1 - T.gtid; k < W.n_kf; k += T.gsize) {
         double s[IBA_KF];
         for (int i = 0; i < IBA_KF; i++) s[i] = cur_kf[IBA_KF * k + i];
@@ -789,7 +806,7 @@ __device__ __noinline__ bool iba_trial(const IbaCtx &C, Team &T, int buf, double
             if (A.kf_imu[W.kf_off + k]) for (int i = 0; i < 9; i++) s[K_V + i] += dx[6 + i];
         }
         for (int i = 0; i < IBA_KF; i++) new_kf[IBA_KF * k + i] = s[i];
-        cam_pose(W, s, new_cam + 12 * k);
+        cam_pose(W, s, new_cam + 24 * k);
     }
     team_sync(T);                              // the new estimates are complete
     *scale_part = part;
@@ -823,8 +840,8 @@ __global__ __launch_bounds__(IBA_THREADS) void k_iba_solve(IbaArgs A)
     int cur = 0;
     {
         const double *kf0 = A.kfs + (size_t)W.kf_off * IBA_KF;
-        double *cam0 = A.cam + (size_t)W.kf_off * 12;
-        for (int k = T.gtid; k < W.n_kf; k += T.gsize) cam_pose(W, kf0 + IBA_KF * k, cam0 + 12 * k);
+        double *cam0 = A.cam + (size_t)W.kf_off * 24;
+        for (int k = T.gtid; k < W.n_kf; k += T.gsize) cam_pose(W, kf0 + IBA_KF * k, cam0 + 24 * k);
     }
     team_sync(T);
     long long t_err = 0, t_build = 0;
@@ -877,16 +894,16 @@ __global__ __launch_bounds__(IBA_THREADS) void k_iba_solve(IbaArgs A)
         if (nbad >= 3) break;
     }
     // outlier gates on the stored chi2, depth of the final estimates (Optimizer.cc:5056-5088)
-    const double *cam = A.cam + cur * A.cam_stride + (size_t)W.kf_off * 12;
+    const double *cam = A.cam + cur * A.cam_stride + (size_t)W.kf_off * 24;
     const double *pts = A.pts + cur * A.pts_stride + (size_t)W.pt_off * 3;
     double nout = 0.0;
     for (int e = T.gtid; e < W.E; e += T.gsize) {
         const size_t ge = (size_t)W.e_off + e;
         const double c2 = A.chi2[ge];
         bool out;
-        if (A.edge_stereo[ge]) out = c2 > (double)7.815f;
+        if (A.edge_stereo[ge] == 1) out = c2 > (double)7.815f;
         else {
-            const double *c = cam + 12 * A.edge_kf[ge], *X = pts + 3 * A.edge_point[ge];
+            const double *c = cam + 24 * A.edge_kf[ge] + 12 * (A.edge_stereo[ge] == 2), *X = pts + 3 * A.edge_point[ge];
             const bool depth_pos = (c[6] * X[0] + c[7] * X[1] + c[8] * X[2] + c[11]) > 0.0;
             const bool close = A.edge_close[ge] != 0;
             out = (c2 > (double)5.991f && !close) || (c2 > (double)(1.5f * 5.991f) && close) || !depth_pos;
@@ -978,6 +995,15 @@ extern "C" int orbhip_inertial_ba_solve_batch(orbhip_ctx *ctx, const orbhip_iba_
         W.ptask_off = (int)pair_task.size(); W.ptstart2_off = (int)pair_task_start.size();
         memcpy(W.Rcb, g.Rcb, sizeof(W.Rcb)); memcpy(W.tcb, g.tcb, sizeof(W.tcb));
         W.fx = g.fx; W.fy = g.fy; W.cx = g.cx; W.cy = g.cy; W.bf = g.bf;
+        W.cam_model = g.camera_model == 1 ? 1 : 0; memcpy(W.kb, g.kb, sizeof(W.kb));
+        W.has_cam2 = g.has_cam2 ? 1 : 0;
+        if (W.has_cam2) {                                  // Rcb[1] = Rrl Rcb[0], tcb[1] = Rrl tcb[0] + trl (G2oTypes.cc:60-63)
+            for (int r = 0; r < 3; r++) {
+                for (int c = 0; c < 3; c++) W.Rcb2[3 * r + c] = g.Trl[4 * r] * g.Rcb[c] + g.Trl[4 * r + 1] * g.Rcb[3 + c] + g.Trl[4 * r + 2] * g.Rcb[6 + c];
+                W.tcb2[r] = g.Trl[4 * r] * g.tcb[0] + g.Trl[4 * r + 1] * g.tcb[1] + g.Trl[4 * r + 2] * g.tcb[2] + g.Trl[4 * r + 3];
+            }
+            W.fx2 = g.fx2; W.fy2 = g.fy2; W.cx2 = g.cx2; W.cy2 = g.cy2; W.cam2_model = g.camera2_model == 1 ? 1 : 0; memcpy(W.kb2, g.kb2, sizeof(W.kb2));
+        }
         std::vector<int> fidx(g.n_kf, -1);
         int n = 0;
         for (int k = 0; k < g.n_kf; k++) {
@@ -1001,7 +1027,8 @@ extern "C" int orbhip_inertial_ba_solve_batch(orbhip_ctx *ctx, const orbhip_iba_
             pstart[l + 1]++;
             if (fidx[k] >= 0) kcount[fidx[k] + 1]++;
             edge_kf[e_base + e] = k; edge_point[e_base + e] = l;
-            edge_stereo[e_base + e] = g.edge_stereo[e] ? 1 : 0;
+            if (g.edge_stereo[e] > 2 || (g.edge_stereo[e] == 2 && !g.has_cam2)) return ORBHIP_E_BADARG;
+            edge_stereo[e_base + e] = g.edge_stereo[e];
             edge_close[e_base + e] = g.edge_close ? (g.edge_close[e] ? 1 : 0) : 0;
         }
         if (g.n_edges) {
@@ -1041,11 +1068,14 @@ extern "C" int orbhip_inertial_ba_solve_batch(orbhip_ctx *ctx, const orbhip_iba_
                     for (size_t b2 = a2; b2 < fe.size(); b2++) {
                         const bool sw = fe[a2].first > fe[b2].first;
                         const int i = sw ? fe[b2].first : fe[a2].first, j = sw ? fe[a2].first : fe[b2].first;
-                        if (!pass) {
-                            if (b2 != a2 && i == j) { orbhip_set_last_error_internal("inertial BA: a point is observed twice by one keyframe"); return ORBHIP_E_BADARG; }
-                            pcount[pair_id(i, j) + 1]++;
-                        } else
+                        // a keyframe's left and right edges to one point (i == j, two edges) add W_a D^-1 W_b^T AND its transpose to the
+                        // diagonal block (g2o keeps ONE Hpl block per (pose, point) pair: both edges accumulate into it)
+                        const bool twin = b2 != a2 && i == j;
+                        if (!pass) pcount[pair_id(i, j) + 1] += twin ? 2 : 1;
+                        else {
                             pair_ent[pbase + ppos[pair_id(i, j)]++] = make_int2(sw ? fe[b2].second : fe[a2].second, sw ? fe[a2].second : fe[b2].second);
+                            if (twin) pair_ent[pbase + ppos[pair_id(i, j)]++] = make_int2(fe[b2].second, fe[a2].second);
+                        }
                     }
             }
             if (!pass) {
@@ -1094,7 +1124,7 @@ extern "C" int orbhip_inertial_ba_solve_batch(orbhip_ctx *ctx, const orbhip_iba_
     // work area
     size_t off = constant_bytes;
     auto take = [&](size_t bytes) { const size_t o = off; off = al256(off + std::max<size_t>(bytes, 8)); return o; };
-    const size_t w_kfs = take(16 * IBA_KF * sumKF), w_cam = take(16 * 12 * sumKF), w_pts = take(16 * 3 * sumL), w_err = take(24 * sumE), w_chi = take(8 * sumE),
+    const size_t w_kfs = take(16 * IBA_KF * sumKF), w_cam = take(16 * 24 * sumKF), w_pts = take(16 * 3 * sumL), w_err = take(24 * sumE), w_chi = take(8 * sumE),
                  w_W = take(144 * sumE), w_Hll = take(48 * sumL), w_bl = take(24 * sumL), w_Di = take(48 * sumL), w_db = take(24 * sumL), w_xl = take(24 * sumL),
                  w_ierr = take(120 * sumM), w_ichi = take(24 * sumM), w_Jb = take(1728 * sumM), w_OJ = take(1728 * sumM), w_Oe = take(120 * sumM),
                  w_H = take(8 * sumH), w_S = take(8 * sumH), w_b = take(8 * sumX), w_bs = take(8 * sumX), w_x = take(8 * sumX), w_out = take(sumE),
@@ -1126,7 +1156,7 @@ extern "C" int orbhip_inertial_ba_solve_batch(orbhip_ctx *ctx, const orbhip_iba_
     A.in_color = CP(int, o_col); A.in_robust = CP(uint8_t, o_rob); A.in_pre = CP(double, o_ipr); A.in_info = CP(double, o_inf);
     A.in_info_g = CP(double, o_ig); A.in_info_a = CP(double, o_ia);
     A.kfs = WP(double, w_kfs); A.cam = WP(double, w_cam); A.pts = WP(double, w_pts);
-    A.kfs_stride = (long long)IBA_KF * sumKF; A.cam_stride = 12 * (long long)sumKF; A.pts_stride = 3 * (long long)sumL;
+    A.kfs_stride = (long long)IBA_KF * sumKF; A.cam_stride = 24 * (long long)sumKF; A.pts_stride = 3 * (long long)sumL;
     A.err = WP(double, w_err); A.chi2 = WP(double, w_chi); A.W = WP(double, w_W); A.Hll = WP(double, w_Hll); A.bl = WP(double, w_bl);
     A.Dinv = WP(double, w_Di); A.db = WP(double, w_db); A.xl = WP(double, w_xl); A.ierr = WP(double, w_ierr); A.ichi2 = WP(double, w_ichi);
     A.Jb = WP(double, w_Jb); A.OJ = WP(double, w_OJ); A.Oe = WP(double, w_Oe); A.H = WP(double, w_H); A.S = WP(double, w_S);

@@ -8,7 +8,9 @@
 // 1e-12 clamped) is computed here in double from the float covariance by a cyclic Jacobi eigen-decomposition (pseudo-inverse
 // with the same clamp); the random-walk informations (:4845-4863) by a 3x3 inverse.  pbStopFlag is handed to g2o only after
 // optimize() in the reference (:5050-5051) and therefore has no effect; it has none here.
-// Not covered: keyframes with a second camera (EdgeMono(1), :5000-5031) -- the function reports it on stderr and returns.
+// Pinhole and KannalaBrandt8 cameras; keyframes of a two-camera rig (mpCamera2, mTrl, NLeft, mvKeysRight) get EdgeMono(1) edges for
+// their right-camera observations (:5000-5031), with the reference's quirk that such an edge takes its inverse sigma^2 from the
+// octave of the LEFT keypoint variable (kpUn, :5019-5020), a default-constructed keypoint (octave 0) when there is no left one.
 #include "Optimizer.h"
 #include <algorithm>
 #include <cmath>
@@ -161,7 +163,6 @@ void Optimizer::LocalInertialBA(KeyFrame *pKF, bool *pbStopFlag, Map *pMap, bool
         kfIndex[pKFi] = i;
         fixed[i] = i >= N;
         imu[i] = pKFi->bImu ? 1 : 0;
-        if (pKFi->mpCamera2) { fprintf(stderr, "orbhip LocalInertialBA: second-camera keyframes are not covered\n"); return; }
         double *s = &kf[(size_t)ORBHIP_IBA_KF * i];
         put3x3(s, pKFi->GetImuRotation()); put3(s + 9, pKFi->GetImuPosition());               // ImuCamPose(KeyFrame*), G2oTypes.cc:25-30
         if (pKFi->bImu) { put3(s + 12, pKFi->GetVelocity()); put3(s + 15, pKFi->GetGyroBias()); put3(s + 18, pKFi->GetAccBias()); }
@@ -171,6 +172,16 @@ void Optimizer::LocalInertialBA(KeyFrame *pKF, bool *pbStopFlag, Map *pMap, bool
     for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) w.Rcb[3 * r + c] = (double)pKF->mImuCalib.Tcb.at<float>(r, c); w.tcb[r] = (double)pKF->mImuCalib.Tcb.at<float>(r, 3); }
     w.fx = pKF->mpCamera->getParameter(0); w.fy = pKF->mpCamera->getParameter(1); w.cx = pKF->mpCamera->getParameter(2); w.cy = pKF->mpCamera->getParameter(3);
     w.bf = pKF->mbf;
+    w.camera_model = pKF->mpCamera->GetType() == pKF->mpCamera->CAM_FISHEYE ? 1 : 0;
+    for (int i = 0; i < 4; i++) w.kb[i] = w.camera_model ? (double)pKF->mpCamera->getParameter(4 + i) : 0.0;
+    if (pKF->mpCamera2) {                                                      // ImuCamPose(KeyFrame*), G2oTypes.cc:57-67
+        GeometricCamera *c2 = pKF->mpCamera2;
+        w.has_cam2 = 1;
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) w.Trl[4 * r + c] = (double)pKF->mTrl.at<float>(r, c);
+        w.fx2 = c2->getParameter(0); w.fy2 = c2->getParameter(1); w.cx2 = c2->getParameter(2); w.cy2 = c2->getParameter(3);
+        w.camera2_model = c2->GetType() == c2->CAM_FISHEYE ? 1 : 0;
+        for (int i = 0; i < 4; i++) w.kb2[i] = w.camera2_model ? (double)c2->getParameter(4 + i) : 0.0;
+    }
 
     // ---- inertial edges (:4784-4868)
     std::vector<int32_t> in1, in2;
@@ -224,15 +235,30 @@ void Optimizer::LocalInertialBA(KeyFrame *pKF, bool *pbStopFlag, Map *pMap, bool
             auto it = kfIndex.find(pKFi);
             if (it == kfIndex.end()) continue;
             const int leftIndex = std::get<0>(ob.second);
-            if (leftIndex == -1) continue;
-            const cv::KeyPoint &kpUn = pKFi->mvKeysUn[leftIndex];
-            const float ur = pKFi->mvuRight[leftIndex];
-            eKF.push_back(it->second); ePoint.push_back((int32_t)l);
-            obs.push_back(kpUn.pt.x); obs.push_back(kpUn.pt.y); obs.push_back(ur);
-            stereo.push_back(ur < 0 ? 0 : 1);
-            invS2.push_back((double)(pKFi->mvInvLevelSigma2[kpUn.octave] / 1.0f));           // uncertainty2 == 1 for Pinhole (:4949-4952)
-            close_.push_back(pMP->mTrackDepth < 10.f ? 1 : 0);
-            edgeOwner.push_back(std::make_pair(pKFi, pMP));
+            cv::KeyPoint kpUn;                                                 // as in the reference: stays default (octave 0) without a left observation
+            if (leftIndex != -1) {
+                kpUn = pKFi->mvKeysUn[leftIndex];
+                const float ur = pKFi->mvuRight[leftIndex];
+                eKF.push_back(it->second); ePoint.push_back((int32_t)l);
+                obs.push_back(kpUn.pt.x); obs.push_back(kpUn.pt.y); obs.push_back(ur);
+                stereo.push_back(ur < 0 ? 0 : 1);                              // :4933 / :4966
+                invS2.push_back((double)(pKFi->mvInvLevelSigma2[kpUn.octave] / 1.0f));       // uncertainty2 == 1 for Pinhole and KannalaBrandt8
+                close_.push_back(pMP->mTrackDepth < 10.f ? 1 : 0);
+                edgeOwner.push_back(std::make_pair(pKFi, pMP));
+            }
+            if (pKFi->mpCamera2) {                                             // :5000-5031
+                int rightIndex = std::get<1>(ob.second);
+                if (rightIndex != -1) {
+                    rightIndex -= pKFi->NLeft;
+                    const cv::KeyPoint &kp = pKFi->mvKeysRight[rightIndex];
+                    eKF.push_back(it->second); ePoint.push_back((int32_t)l);
+                    obs.push_back(kp.pt.x); obs.push_back(kp.pt.y); obs.push_back(-1.0);
+                    stereo.push_back(2);
+                    invS2.push_back((double)(pKFi->mvInvLevelSigma2[kpUn.octave] / 1.0f));
+                    close_.push_back(pMP->mTrackDepth < 10.f ? 1 : 0);
+                    edgeOwner.push_back(std::make_pair(pKFi, pMP));
+                }
+            }
         }
     }
     w.n_points = vMP.size(); w.n_edges = eKF.size(); w.edge_kf = eKF.data(); w.edge_point = ePoint.data(); w.edge_obs = obs.data();

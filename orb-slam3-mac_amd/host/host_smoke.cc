@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <string>
 #include "ORBextractor.h"
@@ -144,8 +145,11 @@ static int lba_smoke(const char *in, const char *out)
 //      int32[nKF] mnId; float[nKF*16] Tcw; int32[nKF] index of mPrevKF or -1; int32[nKF] bImu; float[nKF*3] velocity;
 //      float[nKF*6] bias (bax bay baz bwx bwy bwz); int32[nKF] has a preintegration; float[nKF*292] {dT, C 15x15, dR, dV, dP, JRg,
 //      JVg, JVa, JPg, JPa, b (bax..bwz)}; float[nMP*3] positions; float[nMP] mTrackDepth; int32[nE] edge keyframe, int32[nE] edge
-//      map point, float[nE*3] (u, v, uRight or -1), int32[nE] octave; float[8] mvInvLevelSigma2
-// out: float[nKF*16] Tcw; float[nKF*3] velocity; float[nKF*6] bias; float[nMP*3]; int32 nErased; int32[nErased*2]; int32 map change index
+//      map point, float[nE*3] (u, v, uRight or -1), int32[nE] octave; float[8] mvInvLevelSigma2;
+//      when header[7] != 0 (two KannalaBrandt8 cameras): float[12] mTrl, float[4] camera 2 fx fy cx cy, float[4] k (camera 1), float[4] k
+//      (camera 2), int32[nE] 1 = the observation was made in the right camera
+// out: float[nKF*16] Tcw; float[nKF*3] velocity; float[nKF*6] bias; float[nMP*3]; int32 nErased; int32[nErased*3] (keyframe, map
+//      point, camera); int32 map change index
 static int liba_smoke(const char *in, const char *out)
 {
     Reader r(in);
@@ -164,10 +168,15 @@ static int liba_smoke(const char *in, const char *out)
     const std::vector<float> eObs = r.vec<float>((size_t)nE * 3);
     const std::vector<int32_t> eOct = r.vec<int32_t>(nE);
     const std::vector<float> invS2 = r.vec<float>(8);
+    const bool rig = hd[7] != 0;
+    std::vector<float> Trl, cam2v, k1, k2;
+    std::vector<int32_t> eRight(nE, 0);
+    if (rig) { Trl = r.vec<float>(12); cam2v = r.vec<float>(4); k1 = r.vec<float>(4); k2 = r.vec<float>(4); eRight = r.vec<int32_t>(nE); }
 
     Map map;
     map.mbIsInertial = true; map.nKeyFrames = hd[4];
-    GeometricCamera camera({cam[0], cam[1], cam[2], cam[3]}, 0);
+    GeometricCamera camera(rig ? std::vector<float>{cam[0], cam[1], cam[2], cam[3], k1[0], k1[1], k1[2], k1[3]} : std::vector<float>{cam[0], cam[1], cam[2], cam[3]}, rig ? 1 : 0);
+    GeometricCamera camera2(rig ? std::vector<float>{cam2v[0], cam2v[1], cam2v[2], cam2v[3], k2[0], k2[1], k2[2], k2[3]} : std::vector<float>{0, 0, 0, 0}, 1);
     std::vector<std::unique_ptr<KeyFrame>> kfs;
     std::vector<std::unique_ptr<MapPoint>> mps;
     std::vector<std::unique_ptr<IMU::Preintegrated>> pints;
@@ -179,6 +188,7 @@ static int liba_smoke(const char *in, const char *out)
         k->SetPose(mat(&Tcw[(size_t)16 * i], 4, 4));
         k->mvInvLevelSigma2 = invS2;
         k->bImu = bimu[i] != 0;
+        if (rig) { k->mpCamera2 = &camera2; k->mTrl = mat(Trl.data(), 3, 4); }
         k->SetVelocity(mat(&vel[(size_t)3 * i], 3, 1));
         const float *b = &bias[(size_t)6 * i];
         k->SetNewBias(IMU::Bias(b[0], b[1], b[2], b[3], b[4], b[5]));
@@ -199,12 +209,28 @@ static int liba_smoke(const char *in, const char *out)
         mps.emplace_back(new MapPoint(1000 + l, mat(&X[(size_t)3 * l], 3, 1), &map));
         mps[l]->mTrackDepth = depth[l];
     }
-    for (int e = 0; e < nE; e++) {
-        KeyFrame *kf = kfs[eKF[e]].get();
-        cv::KeyPoint kp; kp.pt.x = eObs[3 * e]; kp.pt.y = eObs[3 * e + 1]; kp.octave = eOct[e];
-        const int idx = kf->mvKeysUn.size();
-        kf->mvKeysUn.push_back(kp); kf->mvuRight.push_back(eObs[3 * e + 2]); kf->mvpMapPoints.push_back(mps[eMP[e]].get());
-        mps[eMP[e]]->AddObservation(kf, idx);
+    {
+        // left keypoints first (indices 0 .. NLeft-1), then the right camera's (NLeft ..), as Frame lays a rig frame out
+        std::vector<int> leftIdx(nE, -1), rightIdx(nE, -1);
+        for (int e = 0; e < nE; e++) if (!eRight[e]) {
+            KeyFrame *kf = kfs[eKF[e]].get();
+            cv::KeyPoint kp; kp.pt.x = eObs[3 * e]; kp.pt.y = eObs[3 * e + 1]; kp.octave = eOct[e];
+            leftIdx[e] = kf->mvKeysUn.size();
+            kf->mvKeysUn.push_back(kp); kf->mvuRight.push_back(eObs[3 * e + 2]); kf->mvpMapPoints.push_back(mps[eMP[e]].get());
+        }
+        if (rig) for (int i = 0; i < nKF; i++) kfs[i]->NLeft = kfs[i]->mvKeysUn.size();
+        for (int e = 0; e < nE; e++) if (eRight[e]) {
+            KeyFrame *kf = kfs[eKF[e]].get();
+            cv::KeyPoint kp; kp.pt.x = eObs[3 * e]; kp.pt.y = eObs[3 * e + 1]; kp.octave = eOct[e];
+            rightIdx[e] = kf->NLeft + (int)kf->mvKeysRight.size();
+            kf->mvKeysRight.push_back(kp); kf->mvpMapPoints.push_back(mps[eMP[e]].get());
+        }
+        std::map<std::pair<int, int>, std::pair<int, int>> both;              // (keyframe, map point) -> (left index, right index)
+        for (int e = 0; e < nE; e++) {
+            auto &b = both.emplace(std::make_pair(eKF[e], eMP[e]), std::make_pair(-1, -1)).first->second;
+            if (eRight[e]) b.second = rightIdx[e]; else b.first = leftIdx[e];
+        }
+        for (auto &kv : both) mps[kv.first.second]->AddObservation(kfs[kv.first.first].get(), kv.second.first, kv.second.second);
     }
     bool stop = false;
     Optimizer::LocalInertialBA(kfs[cur].get(), &stop, &map, hd[5] != 0, hd[6] != 0);      // LocalMapping.cc:131-155 call shape
@@ -224,11 +250,11 @@ static int liba_smoke(const char *in, const char *out)
     std::vector<int32_t> erased;
     for (int e = 0; e < nE; e++) {
         KeyFrame *kf = kfs[eKF[e]].get();
-        if (mps[eMP[e]]->mObservations.count(kf) == 0) { erased.push_back(eKF[e]); erased.push_back(eMP[e]); }
+        if (mps[eMP[e]]->mObservations.count(kf) == 0) { erased.push_back(eKF[e]); erased.push_back(eMP[e]); erased.push_back(eRight[e]); }
     }
-    w.i32((int32_t)erased.size() / 2); w.vec(erased);
+    w.i32((int32_t)erased.size() / 3); w.vec(erased);
     w.i32(map.mnMapChange);
-    printf("HOST_LIBA_OK erased=%zu\n", erased.size() / 2);
+    printf("HOST_LIBA_OK erased=%zu\n", erased.size() / 3);
     return 0;
 }
 

@@ -493,6 +493,8 @@ class IbaWindow(C.Structure):
     """orbhip_iba_window (include/orbhip.h): the flat description of one Optimizer::LocalInertialBA window."""
     _fields_ = [("n_kf", C.c_int32), ("kf_fixed", vp), ("kf_imu", vp), ("Rcb", cd * 9), ("tcb", cd * 3),
                 ("fx", cd), ("fy", cd), ("cx", cd), ("cy", cd), ("bf", cd),
+                ("camera_model", C.c_int32), ("kb", cd * 4), ("has_cam2", C.c_int32), ("Trl", cd * 12),
+                ("fx2", cd), ("fy2", cd), ("cx2", cd), ("cy2", cd), ("camera2_model", C.c_int32), ("kb2", cd * 4),
                 ("n_points", C.c_int32), ("n_edges", C.c_int32), ("edge_kf", vp), ("edge_point", vp), ("edge_obs", vp),
                 ("edge_stereo", vp), ("edge_inv_sigma2", vp), ("edge_close", vp),
                 ("n_inertial", C.c_int32), ("in_kf1", vp), ("in_kf2", vp), ("in_preint", vp), ("in_info", vp),

@@ -37,6 +37,17 @@ class Window:
         for i in range(3):
             p.tcb[i] = float(self.tcb[i])
         p.fx, p.fy, p.cx, p.cy, p.bf = [float(x) for x in self.cam]
+        p.camera_model = int(self.d.get("camera_model", 0))
+        for i in range(4):
+            p.kb[i] = float(self.d.get("kb", (0, 0, 0, 0))[i])
+        p.has_cam2 = 1 if "Trl" in self.d else 0
+        if p.has_cam2:
+            for i in range(12):
+                p.Trl[i] = float(np.asarray(self.d["Trl"]).reshape(-1)[i])
+            p.fx2, p.fy2, p.cx2, p.cy2 = [float(x) for x in self.d["cam2"]]
+            p.camera2_model = int(self.d.get("camera2_model", 0))
+            for i in range(4):
+                p.kb2[i] = float(self.d.get("kb2", (0, 0, 0, 0))[i])
         return p
 
 
@@ -51,12 +62,25 @@ def _rot(w):
 
 
 def make_window(seed, n_opt=8, n_fixed_vis=12, n_points=400, stereo_frac=0.5, outlier_frac=0.03, noise_px=0.6,
-                state_noise=1.0, large=False):
+                state_noise=1.0, large=False, fisheye_rig=False):
     """A temporal window as LocalInertialBA builds it (Optimizer.cc:4574-4868): n_opt consecutive keyframes with IMU states, the
     keyframe before them fixed (with IMU states), n_fixed_vis older fixed keyframes that only see the points.  Keyframe order in
     the arrays: optimizable newest first (vpOptimizableKFs), then the fixed previous keyframe, then the visual-only fixed ones."""
     rng = np.random.default_rng(seed)
     fx, fy, cx, cy, bf = 458.0, 457.0, 367.0, 248.0, 47.9
+    kb = (0.0035, 0.0007, -0.0021, 0.0002)               # KannalaBrandt8 k1..k4 (TUM-VI-like)
+    if fisheye_rig:                                      # two KannalaBrandt8 cameras, no rectified stereo (config #5's rig)
+        fx, fy, cx, cy, bf = 190.9, 190.8, 254.9, 256.9, 0.0
+        stereo_frac = 0.0
+        Rrl = _rot(np.array([0.004, -0.012, 0.003]))
+        Trl = np.concatenate([Rrl, np.array([[-0.101], [0.0019], [0.0012]])], 1)
+        cam2 = (190.4, 190.3, 252.6, 255.0)
+        kb2 = (0.0034, 0.0008, -0.0020, 0.0002)
+
+    def kb_project(Xc, f, kk):
+        th = np.arctan2(np.hypot(Xc[0], Xc[1]), Xc[2]); psi = np.arctan2(Xc[1], Xc[0])
+        r = th + kk[0] * th ** 3 + kk[1] * th ** 5 + kk[2] * th ** 7 + kk[3] * th ** 9
+        return f[0] * r * np.cos(psi) + f[2], f[1] * r * np.sin(psi) + f[3]
     Rcb = _rot(np.array([0.02, -0.01, 1.55]))            # camera/body extrinsics of an EuRoC-like rig
     tcb = np.array([0.065, -0.02, 0.01])
     dt_kf = 0.25 if not large else 0.3
@@ -111,19 +135,37 @@ def make_window(seed, n_opt=8, n_fixed_vis=12, n_points=400, stereo_frac=0.5, ou
             Xc = Rcb @ (R.T @ (X - t)) + tcb
             if Xc[2] < 0.5:
                 continue
-            u, v = fx * Xc[0] / Xc[2] + cx, fy * Xc[1] / Xc[2] + cy
-            if not (0 < u < 752 and 0 < v < 480) or rng.random() < 0.25:
-                continue
+            if fisheye_rig:
+                u, v = kb_project(Xc, (fx, fy, cx, cy), kb)
+                if not (0 < u < 512 and 0 < v < 512):
+                    continue
+            else:
+                u, v = fx * Xc[0] / Xc[2] + cx, fy * Xc[1] / Xc[2] + cy
+                if not (0 < u < 752 and 0 < v < 480):
+                    continue
             octv = int(rng.integers(0, 8))
             s = noise_px * 1.2 ** octv
-            is_st = rng.random() < stereo_frac and Xc[2] < 40 * bf / fx
-            ob = np.array([u + rng.normal(0, s), v + rng.normal(0, s), (u - bf / Xc[2] + rng.normal(0, s)) if is_st else -1.0])
-            if rng.random() < outlier_frac:
-                ob[:2] += rng.uniform(-25, 25, 2)
-            ob = ob.astype(np.float32).astype(np.float64)                # cv::KeyPoint / mvuRight are float
-            ekf.append(a); ept.append(l); eobs.append(ob); est.append(1 if is_st else 0)
-            eis2.append(float(np.float32(inv_sigma2_levels[octv]))); eclose.append(1 if Xc[2] < 10 else 0)
-            seen += 1
+            close = 1 if Xc[2] < 10 else 0
+            if rng.random() >= 0.25:                                     # left / main camera observation
+                is_st = rng.random() < stereo_frac and Xc[2] < 40 * bf / fx
+                ob = np.array([u + rng.normal(0, s), v + rng.normal(0, s), (u - bf / Xc[2] + rng.normal(0, s)) if is_st else -1.0])
+                if rng.random() < outlier_frac:
+                    ob[:2] += rng.uniform(-25, 25, 2)
+                ob = ob.astype(np.float32).astype(np.float64)            # cv::KeyPoint / mvuRight are float
+                ekf.append(a); ept.append(l); eobs.append(ob); est.append(1 if is_st else 0)
+                eis2.append(float(np.float32(inv_sigma2_levels[octv]))); eclose.append(close)
+                seen += 1
+            if fisheye_rig and rng.random() < 0.6:                       # right camera: EdgeMono(1) on the same pose vertex
+                Xr = Trl[:, :3] @ Xc + Trl[:, 3]
+                if Xr[2] > 0.5:
+                    ur, vr = kb_project(Xr, cam2, kb2)
+                    if 0 < ur < 512 and 0 < vr < 512:
+                        ob = np.array([ur + rng.normal(0, s), vr + rng.normal(0, s), -1.0])
+                        if rng.random() < outlier_frac:
+                            ob[:2] += rng.uniform(-25, 25, 2)
+                        ob = ob.astype(np.float32).astype(np.float64)
+                        ekf.append(a); ept.append(l); eobs.append(ob); est.append(2)
+                        eis2.append(float(np.float32(inv_sigma2_levels[octv]))); eclose.append(close)
     # inertial edges: keyframe at time ti (ti >= 1) to ti - 1; exact preintegrated deltas + noise, integrated at a bias slightly off
     in1, in2, pre, info, infog, infoa, rob = [], [], [], [], [], [], []
     for a, ti in enumerate(order_t):
@@ -174,4 +216,6 @@ def make_window(seed, n_opt=8, n_fixed_vis=12, n_points=400, stereo_frac=0.5, ou
              edge_kf=ekf, edge_point=ept, edge_obs=np.array(eobs).reshape(-1, 3), edge_stereo=est, edge_inv_sigma2=eis2, edge_close=eclose,
              in_kf1=in1, in_kf2=in2, in_preint=np.array(pre), in_info=np.array(info), in_info_g=np.array(infog), in_info_a=np.array(infoa),
              in_robust=rob, kf_true=kf_true, pts_true=pts_true)
+    if fisheye_rig:
+        d.update(camera_model=1, kb=kb, Trl=Trl, cam2=cam2, camera2_model=1, kb2=kb2)
     return Window(d)

@@ -404,11 +404,11 @@ def test_orbmatcher_methods_over_frames(tmp_path, bMono, forward):
 
 
 # ------------------------------------------------------------------------------------------- Optimizer::LocalInertialBA drop-in
-def _liba_case(seed, n_opt=6, n_fixed_vis=5, n_points=150, large=False):
+def _liba_case(seed, n_opt=6, n_fixed_vis=5, n_points=150, large=False, fisheye_rig=False):
     """A synthetic visual-inertial window (tests/synth_iba.py) turned into what the reference's objects hold: float Tcw, float
     velocities / biases, the preintegration with its 15 x 15 covariance, per-point mTrackDepth."""
     import synth_iba
-    win = synth_iba.make_window(seed, n_opt=n_opt, n_fixed_vis=n_fixed_vis, n_points=n_points, large=large)
+    win = synth_iba.make_window(seed, n_opt=n_opt, n_fixed_vis=n_fixed_vis, n_points=n_points, large=large, fisheye_rig=fisheye_rig)
     a = win.arrays
     # keep only the points an optimizable keyframe sees (LocalInertialBA's lLocalMapPoints, Optimizer.cc:4611-4627)
     seen = np.zeros(win.n_points, bool)
@@ -418,7 +418,7 @@ def _liba_case(seed, n_opt=6, n_fixed_vis=5, n_points=150, large=False):
     keep_e = seen[a["edge_point"]]
     remap = -np.ones(win.n_points, np.int64)
     remap[seen] = np.arange(seen.sum())
-    c = dict(win=win, n_opt=n_opt, large=large)
+    c = dict(win=win, n_opt=n_opt, large=large, rig=fisheye_rig)
     c["edge_kf"] = a["edge_kf"][keep_e].astype(np.int32)
     c["edge_point"] = remap[a["edge_point"][keep_e]].astype(np.int32)
     c["edge_obs"] = a["edge_obs"][keep_e]
@@ -426,6 +426,17 @@ def _liba_case(seed, n_opt=6, n_fixed_vis=5, n_points=150, large=False):
     levels = (1.0 / (1.2 ** (2 * np.arange(8)))).astype(np.float32)
     c["edge_oct"] = np.array([int(np.argmin(np.abs(levels - np.float32(v)))) for v in a["edge_inv_sigma2"][keep_e]], np.int32)
     c["inv_s2"] = levels
+    if fisheye_rig:
+        # Optimizer.cc:5019-5020: a right-camera edge is weighted with the octave of the LEFT keypoint of the same observation
+        # (kpUn), octave 0 when the keyframe has no left observation of the point
+        left_oct = {}
+        for e in range(len(c["edge_kf"])):
+            if c["edge_stereo"][e] != 2:
+                left_oct[(int(c["edge_kf"][e]), int(c["edge_point"][e]))] = int(c["edge_oct"][e])
+        c["edge_oct_eff"] = np.array([left_oct.get((int(k), int(l)), 0) if t == 2 else int(o)
+                                      for k, l, t, o in zip(c["edge_kf"], c["edge_point"], c["edge_stereo"], c["edge_oct"])], np.int32)
+    else:
+        c["edge_oct_eff"] = c["edge_oct"]
     c["points"] = win.pts0[seen].astype(np.float32)
     # per-point mTrackDepth from the first edge's "close" flag
     close_pt = np.zeros(seen.sum(), np.uint8)
@@ -479,11 +490,16 @@ def _liba_case(seed, n_opt=6, n_fixed_vis=5, n_points=150, large=False):
 def _write_liba(path, c, n_in_map):
     win = c["win"]
     with open(path, "wb") as f:
-        np.array([win.n_kf, len(c["points"]), len(c["edge_kf"]), 0, n_in_map, 1 if c["large"] else 0, 0, 0], np.int32).tofile(f)
+        np.array([win.n_kf, len(c["points"]), len(c["edge_kf"]), 0, n_in_map, 1 if c["large"] else 0, 0, 1 if c["rig"] else 0], np.int32).tofile(f)
         np.array(win.cam, np.float32).tofile(f); c["Tcb"].tofile(f)
         c["ids"].tofile(f); c["Tcw"].tofile(f); c["prev"].tofile(f); c["bimu"].tofile(f); c["vel"].tofile(f); c["bias"].tofile(f)
         c["hasp"].tofile(f); c["pre"].tofile(f); c["points"].tofile(f); c["depth"].tofile(f)
         c["edge_kf"].tofile(f); c["edge_point"].tofile(f); c["edge_obs"].astype(np.float32).tofile(f); c["edge_oct"].tofile(f); c["inv_s2"].tofile(f)
+        if c["rig"]:
+            d = win.d
+            np.asarray(d["Trl"], np.float32).tofile(f); np.asarray(d["cam2"], np.float32).tofile(f)
+            np.asarray(d["kb"], np.float32).tofile(f); np.asarray(d["kb2"], np.float32).tofile(f)
+            (c["edge_stereo"] == 2).astype(np.int32).tofile(f)
 
 
 def _expected_liba(c):
@@ -507,18 +523,22 @@ def _expected_liba(c):
     d = dict(kf_fixed=a["kf_fixed"], kf_imu=a["kf_imu"], kf_state=kf, points=c["points"].astype(np.float64), cam=win.cam,
              Rcb=Tcb[:3, :3].astype(np.float64), tcb=Tcb[:3, 3].astype(np.float64),
              edge_kf=c["edge_kf"], edge_point=c["edge_point"], edge_obs=c["edge_obs"].astype(np.float32).astype(np.float64),
-             edge_stereo=c["edge_stereo"], edge_inv_sigma2=c["inv_s2"][c["edge_oct"]].astype(np.float64),
+             edge_stereo=c["edge_stereo"], edge_inv_sigma2=c["inv_s2"][c["edge_oct_eff"]].astype(np.float64),
              edge_close=(c["depth"][c["edge_point"]] < 10).astype(np.uint8),
              in_kf1=a["in_kf1"], in_kf2=a["in_kf2"], in_preint=pre, in_info=info.reshape(len(info), -1),
              in_info_g=np.stack([c["infos"][m][1].reshape(-1) for m in range(win.n_inertial)]),
              in_info_a=np.stack([c["infos"][m][2].reshape(-1) for m in range(win.n_inertial)]), in_robust=a["in_robust"])
+    if c["rig"]:                        # the objects hold float camera parameters
+        f32 = lambda v: np.asarray(v, np.float32).astype(np.float64)
+        d.update(camera_model=1, kb=f32(win.d["kb"]), Trl=f32(win.d["Trl"]), cam2=f32(win.d["cam2"]), camera2_model=1, kb2=f32(win.d["kb2"]))
+        d["cam"] = tuple(f32(win.cam))
     w2 = synth_iba.Window(d)
     return w2, oib.solve(w2, oib.default_params(c["large"]))
 
 
-@pytest.mark.parametrize("variant", ["prev_outside_window", "chain_ends_inside"])
+@pytest.mark.parametrize("variant", ["prev_outside_window", "chain_ends_inside", "fisheye_rig"])
 def test_local_inertial_ba_drop_in(tmp_path, variant):
-    c = _liba_case(61 if variant == "prev_outside_window" else 63)
+    c = _liba_case({"prev_outside_window": 61, "chain_ends_inside": 63, "fisheye_rig": 64}[variant], fisheye_rig=variant == "fisheye_rig")
     win = c["win"]
     n_opt = c["n_opt"]
     # KeyFramesInMap decides Nd = min(n - 2, 10): either the chain is cut after n_opt keyframes (the next one becomes the fixed
@@ -535,7 +555,7 @@ def test_local_inertial_ba_drop_in(tmp_path, variant):
         bias = np.fromfile(f, np.float32, n_kf * 6).reshape(n_kf, 6)
         pts = np.fromfile(f, np.float32, n_pts * 3).reshape(n_pts, 3)
         n_er = int(np.fromfile(f, np.int32, 1)[0])
-        erased = np.fromfile(f, np.int32, 2 * n_er).reshape(n_er, 2)
+        erased = np.fromfile(f, np.int32, 3 * n_er).reshape(n_er, 3)
         change = int(np.fromfile(f, np.int32, 1)[0])
     # The oracle gets the object state re-derived in numpy (float products in another summation order than the C++ accessors):
     # inputs agree to one float ulp, results to ~1e-7 unless an LM stopping test is within that of a tie (then ~1e-4, the
@@ -555,5 +575,6 @@ def test_local_inertial_ba_drop_in(tmp_path, variant):
     assert np.allclose(pts, opts, atol=5e-5), np.abs(pts - opts).max()
     moved = np.linalg.norm(Tcw[:n_opt, :3, 3] - c["Tcw"][:n_opt, :3, 3], axis=1)
     assert moved.max() > 1e-3                                                                     # the optimisation really ran
+    # an outlier edge erases the whole (keyframe, map point) association, i.e. its twin in the other camera too (Optimizer.cc:5113-5114)
     exp = {(int(k), int(l)) for k, l, o in zip(c["edge_kf"], c["edge_point"], oout) if o}
-    assert {(int(k), int(l)) for k, l in erased} == exp
+    assert {(int(k), int(l)) for k, l, _ in erased} == exp

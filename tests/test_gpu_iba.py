@@ -44,7 +44,10 @@ def _compare(win, gpu, cpu, tol=1e-4):
 @pytest.mark.parametrize("seed,kw", [(21, dict(n_opt=8, n_fixed_vis=10, n_points=300)),
                                      (22, dict(n_opt=3, n_fixed_vis=2, n_points=60)),
                                      (23, dict(n_opt=10, n_fixed_vis=30, n_points=900, stereo_frac=0.0)),
-                                     (24, dict(n_opt=10, n_fixed_vis=25, n_points=700, stereo_frac=1.0))])
+                                     (24, dict(n_opt=10, n_fixed_vis=25, n_points=700, stereo_frac=1.0)),
+                                     # two KannalaBrandt8 cameras per keyframe, EdgeMono(1) edges, twin edges on one (pose, point) pair
+                                     (25, dict(n_opt=8, n_fixed_vis=10, n_points=400, fisheye_rig=True)),
+                                     (26, dict(n_opt=10, n_fixed_vis=30, n_points=900, fisheye_rig=True))])
 def test_inertial_ba_matches_oracle(hip, seed, kw):
     win = ib.make_window(seed, **kw)
     gpu = _gpu_solve(hip, [win])
@@ -58,7 +61,7 @@ def test_inertial_ba_large_variant(hip):
 
 
 def test_inertial_ba_batch_of_windows_and_determinism(hip):
-    wins = [ib.make_window(40 + i, n_opt=4 + i % 7, n_fixed_vis=3 + 2 * i, n_points=120 + 40 * i) for i in range(9)]
+    wins = [ib.make_window(40 + i, n_opt=4 + i % 7, n_fixed_vis=3 + 2 * i, n_points=120 + 40 * i, fisheye_rig=(i % 3 == 2)) for i in range(9)]
     gpu = _gpu_solve(hip, wins)
     again = _gpu_solve(hip, wins)
     for i, w in enumerate(wins):

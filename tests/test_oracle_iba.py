@@ -112,3 +112,34 @@ def test_fail_check_leaves_inputs_untouched():
         assert np.array_equal(kf, win.kf0) and np.array_equal(pts, win.pts0)
     else:
         assert st.err_end <= 2 * st.err * (1 + 1e-6)
+
+
+def test_fisheye_rig_edges_and_solve():
+    """KannalaBrandt8 cameras + EdgeMono(1) right-camera edges (Optimizer.cc:5000-5031, G2oTypes.cc:57-67): Jacobians against
+    finite differences (step 1e-3: KannalaBrandt8::project rounds theta and psi to float, the error is piecewise constant at the
+    1e-5 px level), then the whole optimisation on a rig window where keyframes hold left and right edges to the same point."""
+    win = ib.make_window(71, n_opt=5, n_fixed_vis=4, n_points=150, fisheye_rig=True)
+    a = win.arrays
+    assert set(np.unique(a["edge_stereo"])) == {0, 2}
+    h = 1e-3
+    for typ in (0, 2):
+        es = [e for e in range(win.n_edges) if a["edge_stereo"][e] == typ][:12]
+        for e in es:
+            s, X, obs = win.kf0[a["edge_kf"][e]], win.pts0[a["edge_point"][e]], a["edge_obs"][e]
+            err, Jx, Jp = ib.edge_visual(win, s, X, obs, typ)
+            for c in range(3):
+                d = np.zeros(3); d[c] = h
+                fd = (ib.edge_visual(win, s, X + d, obs, typ)[0] - ib.edge_visual(win, s, X - d, obs, typ)[0]) / (2 * h)
+                assert np.allclose(fd[:2], Jx[:2, c], rtol=2e-3, atol=2e-2)
+            for c in range(6):
+                d = np.zeros(15); d[c] = h
+                fd = (ib.edge_visual(win, ib.kf_update(s, d), X, obs, typ)[0] - ib.edge_visual(win, ib.kf_update(s, -d), X, obs, typ)[0]) / (2 * h)
+                assert np.allclose(fd[:2], Jp[:2, c], rtol=2e-3, atol=5e-2)
+    twins = sum(1 for e in range(1, win.n_edges) if a["edge_point"][e] == a["edge_point"][e - 1] and a["edge_kf"][e] == a["edge_kf"][e - 1])
+    assert twins > 50                                   # both cameras of one keyframe see the point
+    kf, pts, out, st = ib.solve(win)
+    assert st.failed == 0 and st.err_end < 0.5 * st.err
+    n = 5
+    e0 = np.linalg.norm(win.kf0[:n, 9:12] - win.d["kf_true"][:n, 9:12], axis=1).mean()
+    e1 = np.linalg.norm(kf[:n, 9:12] - win.d["kf_true"][:n, 9:12], axis=1).mean()
+    assert e1 < 0.5 * e0
