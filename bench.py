@@ -476,47 +476,80 @@ def main():
         (dt_ba,) = max_over_ranks(dt_ba)
         ticks = bb.ticks
         _, _, _, stats = bb.download()
-        # separate profiled solve (hipEvents around every Schur-GEMM launch), not part of `value`
+        # separate profiled solve (hipEvents around every Schur launch), not part of `value`
         bb.set_profiling(True)
         bb.solve()
         sync()
-        gemm_ms, gemm_n, gemm_fl = bb.gemm_profile()
-        gemm_dense = bb.gemm_dense_flops()
-        gemm_issued = bb.gemm_issued_flops()
+        schur_ms, schur_n, _ = bb.gemm_profile()
         bb.set_profiling(False)
         bb.close()
+        # the same batch through the FP64-MFMA panel GEMM (the round-1 design, selectable): reported beside the default
+        orbhip.ba_set_schur_mode(2)
+        bg = orbhip.BaBatch(ctx, glist)
+        orbhip.ba_set_schur_mode(0)
+        bg.solve()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.ba_steps):
+            bg.solve()
+        sync()
+        dt_gemm = time.perf_counter() - t0
+        bg.set_profiling(True)
+        bg.solve()
+        sync()
+        gemm_ms, gemm_n, gemm_fl = bg.gemm_profile()
+        gemm_dense = bg.gemm_dense_flops()
+        gemm_issued = bg.gemm_issued_flops()
+        bg.set_profiling(False)
+        bg.close()
         peak64 = orbhip.mfma_f64_peak_tflops(ctx)
-        ba_traffic, ba_traffic_src = None, None
-        pmc_ba = load_profile_json(PROFILE_TAG + "_pmc_traffic_ba.json") or load_profile_json("r01_pmc_traffic_ba.json")
-        if pmc_ba and args.ba_graphs == 256 and "k_ba_schur_gemm" in pmc_ba.get("kernels", {}):
-            ba_traffic = pmc_ba["kernels"]["k_ba_schur_gemm"]["hbm_bytes_per_launch"]
-            ba_traffic_src = "profiles/*_pmc_traffic_ba.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)"
         tfl = gemm_fl * gemm_n / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         # sparse-exact flops of the Schur complement (what g2o's per-block products do): per point with k free observers
-        # k(k+1)/2 products 6x3 . 3x6 (2*6*3*6 flop) + k products 6x3 . 3x3 (2*6*3*3)
-        useful = 0.0
+        # k(k+1)/2 products 6x3 . 3x6 (2*6*3*6 flop) + k products 6x3 . 3x3 (2*6*3*3); algorithmic bytes of the pair kernel:
+        # every Hpl block (144 B) and C^-1 (48 B per point) read once, the reduced matrix written once
+        useful, blocks, pts_n, s_bytes, pair_entries = 0.0, 0.0, 0.0, 0.0, 0.0
         for g in glist:
             free = 1 - np.asarray(g["pose_fixed"], np.int64)
             kfree = np.bincount(np.asarray(g["edge_point"]), weights=free[np.asarray(g["edge_pose"])], minlength=g["n_points"])
             useful += float(np.sum(kfree * (kfree + 1) / 2 * 216 + kfree * 108))
+            pair_entries += float(np.sum(kfree * (kfree + 1) / 2))
+            blocks += float(kfree.sum()); pts_n += g["n_points"]; s_bytes += 8.0 * (6 * int(free.sum())) ** 2
+        alg_bytes = blocks * 144 + pts_n * 48 + s_bytes
+        launch_ms = schur_ms / max(schur_n, 1)
+        ach = alg_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+        ba_traffic, ba_traffic_src = None, None
+        pmc_ba = load_profile_json(PROFILE_TAG + "_pmc_traffic_ba.json")
+        if pmc_ba and args.ba_graphs == 256 and "k_ba_schur_big" in pmc_ba.get("kernels", {}):
+            ba_traffic = pmc_ba["kernels"]["k_ba_schur_big"]["hbm_bytes_per_launch"]
+            ba_traffic_src = "profiles/%s_pmc_traffic_ba.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)" % PROFILE_TAG
         ba = {"metric": "local-BA solves/sec", "value": round(world * args.ba_graphs * args.ba_steps / dt_ba, 2),
               "unit": "solves/s", "graphs_per_gpu": args.ba_graphs, "ms_per_batch": round(dt_ba / args.ba_steps * 1e3, 2),
               "lm_ticks": ticks, "workload": "50 KF (2 fixed) x 2000 points x 10 obs, 5+10 LM iterations, Huber, Schur",
               "lm_trials_graph0": stats[0]["lm_trials"], "dtype": "f64",
-              "roofline": {"bound": "mfma", "kernel": "k_ba_schur_gemm", "achieved": round(tfl, 2),
-                           "peak": round(MFMA_F64_PEAK_TFLOPS, 1), "unit": "TFLOP/s", "frac": round(tfl / MFMA_F64_PEAK_TFLOPS, 4),
-                           "peak_source": "v_mfma_f64_16x16x4_f64: 2048 flop / 64 cycles x 1024 SIMDs x 2.4 GHz max clock (fixed)",
-                           "peak_measured_on_device": round(peak64, 2),
-                           "frac_of_measured_peak": round(tfl / peak64, 4) if peak64 else None,
-                           "useful_flop_frac": round(useful / (gemm_fl * 1.0), 4) if gemm_fl else None,
+              "roofline": {"bound": "hbm", "kernel": "k_ba_schur_big", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(ach / HBM_PEAK_GBS, 4), "peak_measured": HBM_MEASURED_GBS,
+                           "frac_of_measured_peak": round(ach / HBM_MEASURED_GBS, 4),
                            "traffic": ba_traffic, "traffic_source": ba_traffic_src,
-                           "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),
-                           "mfma_flops_of_data_tiles_per_launch": gemm_fl, "mfma_flops_issued_per_launch": gemm_issued,
+                           "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(launch_ms, 4),
                            "sparse_exact_flops_per_launch": useful,
-                           "flops_per_launch_without_sparsity_skipping": gemm_dense,
-                           "note": "achieved = flops of the 16x16x4 MFMAs whose tiles hold data / hipEvent time of a separate profiled solve; "
-                                   "useful_flop_frac = g2o's per-block Schur products / those flops; peak_measured_on_device is an in-process "
-                                   "micro-benchmark at whatever clock the chip holds under FP64 matrix load (moves between runs)"}}
+                           "achieved_tflops_of_useful_flops": round(useful / (launch_ms * 1e-3) / 1e12, 2) if launch_ms > 0 else None,
+                           "l2_gather_bytes_per_launch": int(pair_entries * (2 * 144 + 48 + 12)),
+                           "note": "the Schur complement from per-block-pair lists: every (pair of free keyframes, shared point) gathers two 144-byte "
+                                   "Hpl blocks + C^-1, one 16-lane row per pair, a graph's blocks pinned to one XCD's L2; bound by the L2 gather "
+                                   "stream (l2_gather_bytes_per_launch), not by HBM"},
+              "mfma_gemm_variant": {"value": round(world * args.ba_graphs * args.ba_steps / dt_gemm, 2), "unit": "solves/s",
+                                    "ms_per_batch": round(dt_gemm / args.ba_steps * 1e3, 2),
+                                    "roofline": {"bound": "mfma", "kernel": "k_ba_schur_gemm", "achieved": round(tfl, 2),
+                                                 "peak": round(MFMA_F64_PEAK_TFLOPS, 1), "unit": "TFLOP/s", "frac": round(tfl / MFMA_F64_PEAK_TFLOPS, 4),
+                                                 "peak_source": "v_mfma_f64_16x16x4_f64: 2048 flop / 64 cycles x 1024 SIMDs x 2.4 GHz max clock (fixed)",
+                                                 "peak_measured_on_device": round(peak64, 2),
+                                                 "frac_of_measured_peak": round(tfl / peak64, 4) if peak64 else None,
+                                                 "useful_flop_frac": round(useful / (gemm_fl * 1.0), 4) if gemm_fl else None,
+                                                 "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),
+                                                 "mfma_flops_of_data_tiles_per_launch": gemm_fl, "mfma_flops_issued_per_launch": gemm_issued,
+                                                 "flops_per_launch_without_sparsity_skipping": gemm_dense},
+                                    "note": "orbhip_ba_set_schur_mode(2): S = Z^T Z on v_mfma_f64_16x16x4_f64 with block-sparsity skipping (the round-1 "
+                                            "design); 16x16 tiles of 6-row blocks are mostly zeros, so it issues ~9x the useful flops"}}
 
     # ---- landmark-sharded single-graph mode (optional): the SAME graphs solved by all ranks together, the shared Schur
     # block all-gathered every LM trial (RCCL over xGMI with backend nccl).  Latency-bound by design; reported, not hidden.

@@ -502,6 +502,10 @@ void orbhip_ba_global_params(orbhip_ba_params *p, int iterations, int robust);
  * the outlier gates entirely on the device (restarting from the initial estimates each call);
  * download copies estimates / outlier flags / stats back. */
 typedef struct orbhip_ba_batch orbhip_ba_batch;
+/* How batches created AFTER this call form the Schur complement (process-wide): 0 / 1 = from per-block-pair lists, one 16-lane row
+ * per pair of free keyframes (default: measured faster at every batch size), 2 = the FP64-MFMA panel GEMM (up to 80 free keyframes;
+ * always used by the landmark-sharded mode).  Results agree to rounding (different summation orders). */
+int orbhip_ba_set_schur_mode(int mode);
 int orbhip_ba_batch_create(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_graphs,
                            double *const *poses, double *const *points, orbhip_ba_batch **out);
 int orbhip_ba_batch_solve(orbhip_ba_batch *b, const orbhip_ba_params *params, volatile const uint8_t *abort);

@@ -30,6 +30,7 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <atomic>
 
 struct orbhip_ctx;
 hipStream_t orbhip_ctx_stream_internal(orbhip_ctx *c);
@@ -100,7 +101,7 @@ struct BaBatch {      // kernel argument (by value)
     double *Linv;                        // [sumL*6] rows of C^-1 (lower), D = Hll + lambda I = C C^T: l00 l10 l11 l20 l21 l22
     // Schur GEMM work lists (static): the edges with a free pose and no earlier twin, point-major, cut into stages of
     // <= GEMM_PS points and <= GEMM_STAGE_EDGES edges
-    const int4 *gemm_task;               // {graph-local edge, 6*h, point, 0}
+    const int4 *gemm_task;               // {graph-local edge, 6*h, point, graph}
     const int4 *gemm_stage;              // per stage {first point, number of points, first task, number of tasks}
     const uint32_t *ptmask;              // [sumL] bit t: the point's Hpl column is non-zero inside columns [16t, 16t+16) (static)
     double *S, *Spart;                   // per graph [ld*ld], [ks][ld*ld]
@@ -127,7 +128,8 @@ struct BaBatch {      // kernel argument (by value)
     // big windows (any graph of the batch with n > BA_LDLT_MAXN): per graph, per pair of free poses i <= j (row-major over the upper
     // triangle) the Hpl blocks of the points both see -- the Schur complement is summed per 6x6 block in a fixed order
     int big;
-    const int *big_pair_start; const int2 *big_pair_ent;     // entries: {Hpl block of pose i, Hpl block of pose j} (batch-global block ids)
+    int pair_schur;                                          // the Schur complement comes from the pair lists (k_ba_schur_big); always with big
+    const int *big_pair_start; const int2 *big_pair_ent; const int *big_pair_pt;      // big_pair_pt: the point of every entry     // entries: {Hpl block of pose i, Hpl block of pose j} (batch-global block ids)
     double *big_y, *big_d, *big_U;                           // [sumF*6] forward-substituted right-hand side, pivots; [G][32*32] unscaled diagonal-block columns
     int *big_fail;                                           // [G] a zero / non-finite pivot was met
 };
@@ -951,27 +953,37 @@ __global__ __launch_bounds__(1024) void k_ba_ldlt(BaBatch B)
 //   k_ba_big_backsub    D^-1, L^T x = y
 // The arithmetic per entry is the LDS-panel kernel's (same ldlt_rows), so small and big windows factor alike.
 #define BA_BIG_MAXN 4096
-__global__ __launch_bounds__(64) void k_ba_schur_big(BaBatch B)
+__global__ __launch_bounds__(64) void k_ba_schur_big(BaBatch B, int nblk)
 {
-    const int g = blockIdx.y;
+    // FOUR block pairs per wave, 16 lanes each: the 36 sums of a pair are reduced inside its 16-lane DPP row (4 rotate-add steps
+    // instead of 6 scan steps + a readlane over the wave) and four pairs share the issue slots -- 2.6x fewer instructions per pair
+    // than one wave per pair, which made this kernel faster than the MFMA panel GEMM for every batch size.
+    // blockIdx -> (graph, block of 4 pairs): all blocks of a graph run on ONE XCD (workgroups are dealt round-robin over the 8 XCDs), one
+    // graph after the other per XCD, so that the graph's Hpl blocks (2.9 MB at 50 x 2000 x 10; every block is read ~11 times, once per
+    // pair it belongs to) stay in that XCD's 4 MB L2 instead of being fetched again from HBM
+    int g, blk;
+    if (B.G >= 8) { const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3; g = xcd + 8 * (slot / nblk); blk = slot - (slot / nblk) * nblk; }
+    else { g = blockIdx.x / nblk; blk = blockIdx.x - g * nblk; }               // few graphs: every graph over the whole chip
+    if (g >= B.G) return;
     const BaState &st = B.st[g];
     if (!st.active) return;
     const BaGraphDev &G = B.gd[g];
     const int nf = G.nf;
-    int bp = blockIdx.x;
-    if (bp >= nf * (nf + 1) / 2) return;
-    int i = 0;
+    const int lane = threadIdx.x, sub = lane & 15;
+    const int pair = blk * 4 + (lane >> 4);
+    if (pair >= nf * (nf + 1) / 2) return;                          // whole rows leave together (row-local DPP below)
+    int i = 0, bp = pair;
     while (bp >= nf - i) { bp -= nf - i; i++; }
     const int j = i + bp;
-    const int lane = threadIdx.x;
-    const int *ps = B.big_pair_start + G.pair_off + blockIdx.x;
+    const int *ps = B.big_pair_start + G.pair_off + pair;
     const int2 *ent = B.big_pair_ent + G.pent_off;
+    const int *entl = B.big_pair_pt + G.pent_off;
     double acc[36];
 #pragma unroll
     for (int k = 0; k < 36; k++) acc[k] = 0.0;
-    for (int e = ps[0] + lane; e < ps[1]; e += 64) {
+    for (int e = ps[0] + sub; e < ps[1]; e += 16) {
         const int2 t = ent[e];
-        const int l = B.gemm_task[t.x].z;
+        const int l = entl[e];
         const double *L = B.Linv + (size_t)(G.point_off + l) * 6;
         const double l0 = L[0], l1 = L[1], l2 = L[2], l3 = L[3], l4 = L[4], l5 = L[5];
         const double *wa = B.Wsp + (size_t)t.x * 18, *wb = B.Wsp + (size_t)t.y * 18;
@@ -990,8 +1002,8 @@ __global__ __launch_bounds__(64) void k_ba_schur_big(BaBatch B)
     double *Sp = B.Spart + G.spart_off;                            // ks == 1: k_ba_schur_finish subtracts this from blockdiag(Hpp + lambda I)
 #pragma unroll
     for (int k = 0; k < 36; k++) {
-        const double v = wave_sum_f64_dpp(acc[k]);
-        if (lane == 0) {
+        const double v = row16_allreduce_f64_dpp(acc[k]);          // every lane of the row holds the sum (fixed association per lane 0)
+        if (sub == 0) {
             const int r = k / 6, c = k - 6 * r;
             Sp[(size_t)(6 * i + r) * G.ld + 6 * j + c] = v;
             Sp[(size_t)(6 * j + c) * G.ld + 6 * i + r] = v;       // (i == j: the block is symmetric up to rounding; the later write wins, both are valid sums)
@@ -1448,6 +1460,14 @@ static T *ba_upload(orbhip_ba_batch *b, const std::vector<T> &v)
     return d;
 }
 
+static std::atomic<int> g_schur_mode{0};
+extern "C" int orbhip_ba_set_schur_mode(int mode)
+{
+    if (mode < 0 || mode > 2) return ORBHIP_E_BADARG;
+    g_schur_mode.store(mode);
+    return ORBHIP_OK;
+}
+
 extern "C" void orbhip_ba_default_params(orbhip_ba_params *p)
 {
     p->iters1 = 5; p->iters2 = 10; p->huber_mono2 = 5.991; p->huber_stereo2 = 7.815;
@@ -1607,7 +1627,7 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
                 for (int k = e; k < e1; k++) {
                     const bool blk = local_h[H.edge_pose[k]] >= 0 && !dupv[k];
                     etask.push_back(blk ? (int)gtask.size() : -1);
-                    if (blk) gtask.push_back(make_int4(k, 6 * local_h[H.edge_pose[k]], l, 0));
+                    if (blk) gtask.push_back(make_int4(k, 6 * local_h[H.edge_pose[k]], l, g));
                 }
                 npts++; ntask += cnt; e = e1;
             }
@@ -1673,9 +1693,15 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
     b->s_total = s; b->spart_total = sp;
     // big windows: every graph of the batch takes the global-memory path; per graph and pair of free poses (i <= j) the Hpl blocks
     // of the points both see, in point order (the summation order of k_ba_schur_big)
-    std::vector<int> pair_start; std::vector<int2> pair_ent;
+    std::vector<int> pair_start, pair_pt; std::vector<int2> pair_ent;
     B.big = any_big ? 1 : 0;
-    if (any_big) {
+    // Schur complement: per-block-pair lists (k_ba_schur_big) by default -- measured faster than the MFMA panel GEMM at every batch
+    // size -- the GEMM on request (orbhip_ba_set_schur_mode(2)), in the landmark-sharded mode and never for big windows
+    int mode = g_schur_mode.load();
+    if (const char *ev = getenv("ORBHIP_BA_PAIRS")) mode = atoi(ev) ? 1 : 2;                                                    // development override
+    const bool pair_lists = any_big || (world == 1 && mode != 2);
+    B.pair_schur = pair_lists ? 1 : 0;
+    if (pair_lists) {
         for (int g = 0; g < n_graphs; g++) {
             BaGraphDev &D = b->gd[g];
             D.ks = 1;                                            // k_ba_schur_big writes slice 0 only
@@ -1698,14 +1724,14 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
                             const int i = lh[H.edge_pose[a]], j = lh[H.edge_pose[c]];
                             if (i > j || (i == j && a != c)) continue;           // every unordered pair once; the diagonal pair is (a, a)
                             if (pass == 0) cnt[pidx(i, j) + 1]++;
-                            else pair_ent[D.pent_off + fill[pidx(i, j)]++] = make_int2(et[a], et[c]);
+                            else { const size_t q = D.pent_off + fill[pidx(i, j)]++; pair_ent[q] = make_int2(et[a], et[c]); pair_pt[q] = H.edge_point[a]; }
                         }
                     }
                     e0 = e1;
                 }
                 if (pass == 0) {
                     for (int k = 0; k < npair; k++) cnt[k + 1] += cnt[k];
-                    pair_ent.resize(D.pent_off + cnt[npair]);
+                    pair_ent.resize(D.pent_off + cnt[npair]); pair_pt.resize(D.pent_off + cnt[npair]);
                 }
             }
             pair_start.insert(pair_start.end(), cnt.begin(), cnt.end());
@@ -1719,8 +1745,8 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
     UP(B.edge_is2, eis2); UP(B.edge_stereo, est); UP(B.edge_dup, edup); UP(B.edge_next, enext); UP(B.pt_start, ptstart); UP(B.pose_start, posestart); UP(B.pose_edges, poseedges);
     UP(B.ptmask, ptmask); UP(B.gemm_task, gtask); UP(B.gemm_stage, gstage); UP(B.edge_task, etask); UP(B.x1_off, x1off); UP(B.x2_off, x2off);
     UP(B.pm_point, pmpoint); UP(B.pm_task, pmtask); UP(B.pm_type, pmtype); UP(B.pm_is2, pmis2); UP(B.pm_obs, pmobs);
+    if (pair_lists) { UP(B.big_pair_start, pair_start); UP(B.big_pair_ent, pair_ent); UP(B.big_pair_pt, pair_pt); }
     if (any_big) {
-        UP(B.big_pair_start, pair_start); UP(B.big_pair_ent, pair_ent);
         AL(B.big_y, double, (size_t)sumF * 6); AL(B.big_d, double, (size_t)sumF * 6); AL(B.big_U, double, (size_t)n_graphs * LD_NB * LD_NB);
         AL(B.big_fail, int, n_graphs);
     }
@@ -1866,7 +1892,7 @@ static int ba_solve_impl(orbhip_ba_batch *b, const orbhip_ba_params *params, vol
         hipLaunchKernelGGL(k_ba_pretrial, dim3((G + 63) / 64), dim3(64), 0, s, B);
         hipLaunchKernelGGL(k_ba_point_prep, gp256, dim3(256), 0, s, B);
         if (b->profile) TRY(hipEventRecord(b->ev0, s));
-        if (B.big) hipLaunchKernelGGL(k_ba_schur_big, dim3(max_nfp, G), dim3(64), 0, s, B);
+        if (B.pair_schur) hipLaunchKernelGGL(k_ba_schur_big, dim3((unsigned)(((max_nfp + 3) / 4) * (G >= 8 ? ((G + 7) / 8) * 8 : G))), dim3(64), 0, s, B, (max_nfp + 3) / 4);
         else hipLaunchKernelGGL(k_ba_schur_gemm, dim3(max_items, G), dim3(64 * GEMM_WAVES), gemm_lds, s, B);
         if (b->profile) TRY(hipEventRecord(b->ev1, s));
         hipLaunchKernelGGL(k_ba_bschur, gf, dim3(64), 0, s, B);

@@ -351,6 +351,14 @@ def mfma_f64_peak_tflops(ctx):
     return v.value
 
 
+lib.orbhip_ba_set_schur_mode.argtypes = [ci]
+
+
+def ba_set_schur_mode(mode):
+    """0 / 1 = pair lists (default), 2 = FP64-MFMA panel GEMM; applies to batches created afterwards."""
+    _chk(lib.orbhip_ba_set_schur_mode(mode), "orbhip_ba_set_schur_mode")
+
+
 def ba_merge_params():
     """Parameters of the map-merge local BA (Optimizer.cc:6255)."""
     p = BaParams()
