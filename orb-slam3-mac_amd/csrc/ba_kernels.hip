@@ -953,7 +953,7 @@ __global__ __launch_bounds__(1024) void k_ba_ldlt(BaBatch B)
 //   k_ba_big_backsub    D^-1, L^T x = y
 // The arithmetic per entry is the LDS-panel kernel's (same ldlt_rows), so small and big windows factor alike.
 #define BA_BIG_MAXN 4096
-__global__ __launch_bounds__(64) void k_ba_schur_big(BaBatch B, int nblk)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ba_schur_big(BaBatch B, int nblk)
 {
     // FOUR block pairs per wave, 16 lanes each: the 36 sums of a pair are reduced inside its 16-lane DPP row (4 rotate-add steps
     // instead of 6 scan steps + a readlane over the wave) and four pairs share the issue slots -- 2.6x fewer instructions per pair
@@ -984,20 +984,23 @@ __global__ __launch_bounds__(64) void k_ba_schur_big(BaBatch B, int nblk)
     for (int e = ps[0] + sub; e < ps[1]; e += 16) {
         const int2 t = ent[e];
         const int l = entl[e];
-        const double *L = B.Linv + (size_t)(G.point_off + l) * 6;
-        const double l0 = L[0], l1 = L[1], l2 = L[2], l3 = L[3], l4 = L[4], l5 = L[5];
+        const double *Di = B.Dinv + (size_t)(G.point_off + l) * 6;       // (Hll + lambda I)^-1, upper triangle
+        const double i00 = Di[0], i01 = Di[1], i02 = Di[2], i11 = Di[3], i12 = Di[4], i22 = Di[5];
         const double *wa = B.Wsp + (size_t)t.x * 18, *wb = B.Wsp + (size_t)t.y * 18;
-        double za[3][6], zb[3][6];                                 // Z = C^-1 W (rows: the point's 3 coordinates)
+        double y0[6], y1[6], y2[6];                                     // Y = W_a D^-1 (block_solver.hpp:398-407), then acc += Y W_b^T
 #pragma unroll
         for (int a = 0; a < 6; a++) {
-            const double a0 = wa[a], a1 = wa[6 + a], a2 = wa[12 + a], b0 = wb[a], b1 = wb[6 + a], b2 = wb[12 + a];
-            za[0][a] = l0 * a0; za[1][a] = l1 * a0 + l2 * a1; za[2][a] = l3 * a0 + l4 * a1 + l5 * a2;
-            zb[0][a] = l0 * b0; zb[1][a] = l1 * b0 + l2 * b1; zb[2][a] = l3 * b0 + l4 * b1 + l5 * b2;
+            const double a0 = wa[a], a1 = wa[6 + a], a2 = wa[12 + a];
+            y0[a] = a0 * i00 + a1 * i01 + a2 * i02;
+            y1[a] = a0 * i01 + a1 * i11 + a2 * i12;
+            y2[a] = a0 * i02 + a1 * i12 + a2 * i22;
         }
 #pragma unroll
-        for (int r = 0; r < 6; r++)
+        for (int c = 0; c < 6; c++) {
+            const double b0 = wb[c], b1 = wb[6 + c], b2 = wb[12 + c];
 #pragma unroll
-            for (int c = 0; c < 6; c++) acc[6 * r + c] += za[0][r] * zb[0][c] + za[1][r] * zb[1][c] + za[2][r] * zb[2][c];
+            for (int r = 0; r < 6; r++) acc[6 * r + c] += y0[r] * b0 + y1[r] * b1 + y2[r] * b2;
+        }
     }
     double *Sp = B.Spart + G.spart_off;                            // ks == 1: k_ba_schur_finish subtracts this from blockdiag(Hpp + lambda I)
 #pragma unroll
