@@ -1002,14 +1002,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             for (int r = 0; r < 6; r++) acc[6 * r + c] += y0[r] * b0 + y1[r] * b1 + y2[r] * b2;
         }
     }
-    double *Sp = B.Spart + G.spart_off;                            // ks == 1: k_ba_schur_finish subtracts this from blockdiag(Hpp + lambda I)
+    // the finished block goes straight into S = blockdiag(Hpp + lambda I) - sum, both triangles (no partial-sum buffer, no finish
+    // kernel on this path; rows / columns >= n of the padded matrix are never read by the factorisations)
+    double *S = B.S + G.s_off;
+    const double lambda = st.lambda;
+    const double *Hd = B.Hpp + (size_t)(G.free_off + i) * 36;
 #pragma unroll
     for (int k = 0; k < 36; k++) {
-        const double v = row16_allreduce_f64_dpp(acc[k]);          // every lane of the row holds the sum (fixed association per lane 0)
+        const double v = row16_allreduce_f64_dpp(acc[k]);          // every lane of the row holds the sum
         if (sub == 0) {
             const int r = k / 6, c = k - 6 * r;
-            Sp[(size_t)(6 * i + r) * G.ld + 6 * j + c] = v;
-            Sp[(size_t)(6 * j + c) * G.ld + 6 * i + r] = v;       // (i == j: the block is symmetric up to rounding; the later write wins, both are valid sums)
+            const double out = (i == j ? Hd[k] + (r == c ? lambda : 0.0) : 0.0) - v;
+            S[(size_t)(6 * i + r) * G.ld + 6 * j + c] = out;
+            if (i != j) S[(size_t)(6 * j + c) * G.ld + 6 * i + r] = out;
         }
     }
 }
@@ -1904,7 +1909,7 @@ static int ba_solve_impl(orbhip_ba_batch *b, const orbhip_ba_params *params, vol
             XCHG(2, x1n);
             hipLaunchKernelGGL(k_ba_shard_sum2, dim3(G), dim3(256), 0, s, B);
         }
-        hipLaunchKernelGGL(k_ba_schur_finish, dim3((B.max_ld * B.max_ld + 255) / 256, G), dim3(256), 0, s, B);
+        if (!B.pair_schur) hipLaunchKernelGGL(k_ba_schur_finish, dim3((B.max_ld * B.max_ld + 255) / 256, G), dim3(256), 0, s, B);      // (the pair kernel wrote the finished S)
         if (!B.big) hipLaunchKernelGGL(k_ba_ldlt, dim3(G), dim3(1024), ldlt_lds, s, B);
         else {
             hipLaunchKernelGGL(k_ba_big_init, dim3((max_n + 255) / 256, G), dim3(256), 0, s, B);
