@@ -1017,6 +1017,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             if (i != j) S[(size_t)(6 * j + c) * G.ld + 6 * i + r] = out;
         }
     }
+    // bs = bp - W D^-1 b_l (block_solver.hpp:409-416, 435-438): the diagonal pair lists every Hpl block of pose i exactly once; a second,
+    // short pass over it (its blocks are in L2 now) -- inside the loop above the extra branch and registers cost more than they saved
+    if (i == j) {
+        double wdb[6] = {0, 0, 0, 0, 0, 0};
+        for (int e = ps[0] + sub; e < ps[1]; e += 16) {
+            const double *w = B.Wsp + (size_t)ent[e].x * 18, *db = B.db + (size_t)(G.point_off + entl[e]) * 3;
+            const double d0 = db[0], d1 = db[1], d2 = db[2];
+#pragma unroll
+            for (int a = 0; a < 6; a++) wdb[a] += w[a] * d0 + w[6 + a] * d1 + w[12 + a] * d2;
+        }
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+            const double v = row16_allreduce_f64_dpp(wdb[a]);
+            if (sub == 0) { B.bacc[(size_t)(G.free_off + i) * 6 + a] = v; B.bs[(size_t)(G.free_off + i) * 6 + a] = B.bp[(size_t)(G.free_off + i) * 6 + a] - v; }
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_ba_big_init(BaBatch B)
@@ -1903,7 +1919,7 @@ static int ba_solve_impl(orbhip_ba_batch *b, const orbhip_ba_params *params, vol
         if (B.pair_schur) hipLaunchKernelGGL(k_ba_schur_big, dim3((unsigned)(((max_nfp + 3) / 4) * (G >= 8 ? ((G + 7) / 8) * 8 : G))), dim3(64), 0, s, B, (max_nfp + 3) / 4);
         else hipLaunchKernelGGL(k_ba_schur_gemm, dim3(max_items, G), dim3(64 * GEMM_WAVES), gemm_lds, s, B);
         if (b->profile) TRY(hipEventRecord(b->ev1, s));
-        hipLaunchKernelGGL(k_ba_bschur, gf, dim3(64), 0, s, B);
+        if (!B.pair_schur) hipLaunchKernelGGL(k_ba_bschur, gf, dim3(64), 0, s, B);      // (the pair kernel's diagonal rows produced bs)
         if (sharded) {                                           // exchange 2: the shared Schur block (sum_ks Spart) and W db
             hipLaunchKernelGGL(k_ba_shard_pack2, dim3((B.max_ld * B.max_ld + 255) / 256, G), dim3(256), 0, s, B);
             XCHG(2, x1n);
