@@ -305,6 +305,16 @@ int orbhip_search_by_bow_rig_device(orbhip_ctx *ctx,
         int pairs, int max_nodes, int max_n, size_t frame_stride_kp, float nn_ratio, int check_orientation,
         int32_t *d_match_f, int32_t *d_nmatches);
 
+/* Host-pointer form for ONE (keyframe, frame) pair -- what the ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)
+ * method of host/ORBmatcher.cc calls: flattened FeatureVectors (node ids ascending, node_start [nnodes + 1], feature indices),
+ * kf_valid [nK], keypoints and descriptors of both sides; nleft < 0 for F.Nleft == -1, else the rig form.  match_f_out [nF]. */
+int orbhip_search_by_bow_host(orbhip_ctx *ctx,
+        const int32_t *kf_node_ids, const int32_t *kf_node_start, const int32_t *kf_feat, int kf_nnodes, const uint8_t *kf_valid,
+        const orbhip_keypoint *kf_kp, const uint8_t *kf_desc, int nK,
+        const int32_t *f_node_ids, const int32_t *f_node_start, const int32_t *f_feat, int f_nnodes,
+        const orbhip_keypoint *f_kp, const uint8_t *f_desc, int nF, int nleft,
+        float nn_ratio, int check_orientation, int32_t *match_f_out, int32_t *nmatches_out);
+
 /* ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12) (src/ORBmatcher.cc:827-967,
  * NLeft == -1) -- the matcher of LoopClosing's Sim3 candidates (src/LoopClosing.cc:1005, 2284), batched over keyframe
  * pairs.  Layout as orbhip_search_by_bow_device; both sides carry d_valid [pairs][max_n] (map point exists and is not

@@ -122,3 +122,60 @@ extern "C" int orbhip_search_for_initialization_host(orbhip_ctx *ctx, const orbh
     HTRY(hipMemcpyAsync(nmatches_out, dnm, 4, hipMemcpyDeviceToHost, s));
     return orbhip_ctx_check_status(ctx);
 }
+
+// ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) for ONE (keyframe, frame) pair from host memory: the two flattened
+// FeatureVectors (node ids ascending, node_start [nnodes + 1], feature indices), the keyframe's "map point exists and is not bad"
+// flags, keypoints (mvKeysUn / mvKeys, concatenated left | right for rig frames) and descriptors.  nleft < 0: F.Nleft == -1.
+extern "C" int orbhip_search_by_bow_host(orbhip_ctx *ctx,
+        const int32_t *kf_node_ids, const int32_t *kf_node_start, const int32_t *kf_feat, int kf_nnodes, const uint8_t *kf_valid,
+        const orbhip_keypoint *kf_kp, const uint8_t *kf_desc, int nK,
+        const int32_t *f_node_ids, const int32_t *f_node_start, const int32_t *f_feat, int f_nnodes,
+        const orbhip_keypoint *f_kp, const uint8_t *f_desc, int nF, int nleft,
+        float nn_ratio, int check_orientation, int32_t *match_f_out, int32_t *nmatches_out)
+{
+    if (!ctx || nK < 0 || nF < 0 || kf_nnodes < 0 || f_nnodes < 0 || !nmatches_out || (nF && !match_f_out) ||
+        (kf_nnodes && (!kf_node_ids || !kf_node_start || !kf_feat || !kf_valid || !kf_kp || !kf_desc)) ||
+        (f_nnodes && (!f_node_ids || !f_node_start || !f_feat || !f_kp || !f_desc)) || nleft > nF)
+        return ORBHIP_E_BADARG;
+    *nmatches_out = 0;
+    for (int i = 0; i < nF; i++) match_f_out[i] = -1;                   // vpMapPointMatches = vector<MapPoint*>(F.N, NULL), ORBmatcher.cc:277
+    if (nK == 0 || nF == 0 || kf_nnodes == 0 || f_nnodes == 0) return ORBHIP_OK;
+    HTRY(hipSetDevice(orbhip_ctx_device_internal(ctx)));
+    hipStream_t s = orbhip_ctx_stream_internal(ctx);
+    const int mn = kf_nnodes > f_nnodes ? kf_nnodes : f_nnodes, mx = nK > nF ? nK : nF;
+    const size_t need = 2 * (al(4 * (size_t)mn) + al(4 * (size_t)(mn + 1)) + al(4 * (size_t)mx) + al(sizeof(orbhip_keypoint) * mx) + al(32 * (size_t)mx)) +
+                        al(mx) + al(4 * (size_t)mx) + 8 * 256;
+    Arena A = {(uint8_t *)orbhip_ctx_scratch_internal(ctx, need), 0, need};
+    if (!A.base) return ORBHIP_E_HIP;
+    int32_t *dki = A.take<int32_t>(mn), *dks = A.take<int32_t>(mn + 1), *dkf = A.take<int32_t>(mx);
+    int32_t *dfi = A.take<int32_t>(mn), *dfs = A.take<int32_t>(mn + 1), *dff = A.take<int32_t>(mx);
+    orbhip_keypoint *dkk = A.take<orbhip_keypoint>(mx), *dfk = A.take<orbhip_keypoint>(mx);
+    uint8_t *dkd = A.take<uint8_t>(32 * (size_t)mx), *dfd = A.take<uint8_t>(32 * (size_t)mx), *dva = A.take<uint8_t>(mx);
+    int32_t *dm = A.take<int32_t>(mx), *dkn = A.take<int32_t>(1), *dfn = A.take<int32_t>(1), *dnF = A.take<int32_t>(1), *dnl = A.take<int32_t>(1), *dnm = A.take<int32_t>(1);
+    HTRY(hipMemcpyAsync(dki, kf_node_ids, 4 * (size_t)kf_nnodes, hipMemcpyHostToDevice, s));
+    HTRY(hipMemcpyAsync(dks, kf_node_start, 4 * (size_t)(kf_nnodes + 1), hipMemcpyHostToDevice, s));
+    HTRY(hipMemcpyAsync(dkf, kf_feat, 4 * (size_t)kf_node_start[kf_nnodes], hipMemcpyHostToDevice, s));
+    HTRY(hipMemcpyAsync(dfi, f_node_ids, 4 * (size_t)f_nnodes, hipMemcpyHostToDevice, s));
+    HTRY(hipMemcpyAsync(dfs, f_node_start, 4 * (size_t)(f_nnodes + 1), hipMemcpyHostToDevice, s));
+    HTRY(hipMemcpyAsync(dff, f_feat, 4 * (size_t)f_node_start[f_nnodes], hipMemcpyHostToDevice, s));
+    HTRY(hipMemcpyAsync(dkk, kf_kp, sizeof(orbhip_keypoint) * nK, hipMemcpyHostToDevice, s));
+    HTRY(hipMemcpyAsync(dfk, f_kp, sizeof(orbhip_keypoint) * nF, hipMemcpyHostToDevice, s));
+    HTRY(hipMemcpyAsync(dkd, kf_desc, 32 * (size_t)nK, hipMemcpyHostToDevice, s));
+    HTRY(hipMemcpyAsync(dfd, f_desc, 32 * (size_t)nF, hipMemcpyHostToDevice, s));
+    HTRY(hipMemcpyAsync(dva, kf_valid, nK, hipMemcpyHostToDevice, s));
+    HTRY(hipMemcpyAsync(dkn, &kf_nnodes, 4, hipMemcpyHostToDevice, s));
+    HTRY(hipMemcpyAsync(dfn, &f_nnodes, 4, hipMemcpyHostToDevice, s));
+    HTRY(hipMemcpyAsync(dnF, &nF, 4, hipMemcpyHostToDevice, s));
+    int rc;
+    if (nleft >= 0) {
+        HTRY(hipMemcpyAsync(dnl, &nleft, 4, hipMemcpyHostToDevice, s));
+        rc = orbhip_search_by_bow_rig_device(ctx, dki, dks, dkf, dkn, dva, dkk, dkd, dfi, dfs, dff, dfn, dfk, dfd, dnF, dnl, 1, mn, mx, (size_t)mx, nn_ratio,
+                                             check_orientation, dm, dnm);
+    } else
+        rc = orbhip_search_by_bow_device(ctx, dki, dks, dkf, dkn, dva, dkk, dkd, dfi, dfs, dff, dfn, dfk, dfd, dnF, 1, mn, mx, (size_t)mx, nn_ratio,
+                                         check_orientation, dm, dnm);
+    if (rc) return rc;
+    HTRY(hipMemcpyAsync(match_f_out, dm, 4 * (size_t)nF, hipMemcpyDeviceToHost, s));
+    HTRY(hipMemcpyAsync(nmatches_out, dnm, 4, hipMemcpyDeviceToHost, s));
+    return orbhip_ctx_check_status(ctx);
+}

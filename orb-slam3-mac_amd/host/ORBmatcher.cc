@@ -241,3 +241,51 @@ int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Po
 }
 
 }  // namespace ORB_SLAM3
+
+namespace ORB_SLAM3 {
+
+// src/ORBmatcher.cc:273-475.  The node-by-node walk over the two FeatureVectors, the per-node best / second-best search with
+// the "frame feature already matched" rule, the ratio test and the rotation histogram run in k_search_by_bow; the method
+// flattens the two std::map containers in their iteration order and maps the result back to MapPoint pointers.
+int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vpMapPointMatches)
+{
+    const std::vector<MapPoint *> vpMapPointsKF = pKF->GetMapPointMatches();
+    vpMapPointMatches = std::vector<MapPoint *>(F.N, static_cast<MapPoint *>(NULL));
+    auto flatten = [](const DBoW2::FeatureVector &fv, std::vector<int32_t> &ids, std::vector<int32_t> &start, std::vector<int32_t> &feat) {
+        start.push_back(0);
+        for (const auto &kv : fv) {
+            ids.push_back((int32_t)kv.first);
+            for (unsigned int i : kv.second) feat.push_back((int32_t)i);
+            start.push_back((int32_t)feat.size());
+        }
+    };
+    std::vector<int32_t> kIds, kStart, kFeat, fIds, fStart, fFeat;
+    flatten(pKF->mFeatVec, kIds, kStart, kFeat);
+    flatten(F.mFeatVec, fIds, fStart, fFeat);
+    const bool rig = F.Nleft != -1;
+    const int nK = rig ? (int)(pKF->mvKeysUn.size() + pKF->mvKeysRight.size()) : (int)pKF->mvKeysUn.size();
+    std::vector<uint8_t> valid(nK > 0 ? nK : 1, 0);
+    for (int k = 0; k < nK && k < (int)vpMapPointsKF.size(); k++) {
+        MapPoint *pMP = vpMapPointsKF[k];
+        valid[k] = (pMP && !pMP->isBad()) ? 1 : 0;                   // :299-305
+    }
+    std::vector<cv::KeyPoint> kk, fk;                                  // rig: left | right keypoints in descriptor order (:309-311, :393-400)
+    const cv::KeyPoint *pk = pKF->mvKeysUn.data(), *pf = F.mvKeys.data();
+    if (rig) {
+        kk = pKF->mvKeysUn; kk.insert(kk.end(), pKF->mvKeysRight.begin(), pKF->mvKeysRight.end()); pk = kk.data();
+        fk = F.mvKeys; fk.insert(fk.end(), F.mvKeysRight.begin(), F.mvKeysRight.end()); pf = fk.data();
+    }
+    std::vector<int32_t> matchF(F.N > 0 ? F.N : 1, -1);
+    int32_t nmatches = 0;
+    const int rc = orbhip_search_by_bow_host(thread_ctx(), kIds.data(), kStart.data(), kFeat.data(), (int)kIds.size(), valid.data(),
+                                             (const orbhip_keypoint *)pk, pKF->mDescriptors.ptr<uint8_t>(), nK,
+                                             fIds.data(), fStart.data(), fFeat.data(), (int)fIds.size(), (const orbhip_keypoint *)pf,
+                                             F.mDescriptors.ptr<uint8_t>(), F.N, rig ? F.Nleft : -1, mfNNratio, mbCheckOrientation ? 1 : 0,
+                                             matchF.data(), &nmatches);
+    if (rc != ORBHIP_OK) { fprintf(stderr, "orbhip SearchByBoW: %s\n", orbhip_last_error()); return 0; }
+    for (int j = 0; j < F.N; j++)
+        if (matchF[j] >= 0) vpMapPointMatches[j] = vpMapPointsKF[matchF[j]];
+    return nmatches;
+}
+
+}  // namespace ORB_SLAM3

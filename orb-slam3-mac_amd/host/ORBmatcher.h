@@ -3,10 +3,11 @@
 //   SearchByProjection(Frame&, const vector<MapPoint*>&, th, bFarPoints, thFarPoints)   src/Tracking.cc:3096  (TrackLocalMap)
 //   SearchByProjection(Frame&, const Frame&, th, bMono)                                  src/Tracking.cc:2683  (TrackWithMotionModel)
 //   SearchForInitialization(Frame&, Frame&, vbPrevMatched, vnMatches12, windowSize)      src/Tracking.cc:1506  (MonocularInitialization)
+//   SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches)                                    src/Tracking.cc:1757  (TrackReferenceKeyFrame), :3290 (Relocalization)
 //   DescriptorDistance(a, b)
 // The per-point host geometry in front of each search (projection, frustum record, radius, level range) is kept as the
 // reference writes it; the windowed best / second-best search with the claim rule, the ratio tests and the rotation
-// histogram run on the device.  The remaining searches (BoW, triangulation, Fuse, Sim3) have batched device entry points in
+// histogram run on the device.  The remaining searches (keyframe-keyframe BoW, triangulation, Fuse, Sim3) have batched device entry points in
 // include/orbhip.h and INTEGRATION.md shows their call sites; their class methods are not mirrored here.
 #pragma once
 #include <vector>
@@ -30,6 +31,10 @@ public:
     // Project MapPoints tracked in last frame into the current frame and search matches.
     // Used to track from previous frame (Tracking)                             include/ORBmatcher.h:53, src/ORBmatcher.cc:1965-2181
     int SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono);
+
+    // Search matches between MapPoints in a KeyFrame and ORB in a Frame. Brute force constrained to ORB that belong to the same vocabulary
+    // node (at a certain level). Used in Relocalisation and Loop Detection     include/ORBmatcher.h:62, src/ORBmatcher.cc:273-475
+    int SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vpMapPointMatches);
 
     // Matching for the Map Initialization (only used in the monocular case)    include/ORBmatcher.h:66, src/ORBmatcher.cc:710-825
     int SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Point2f> &vbPrevMatched, std::vector<int> &vnMatches12,

@@ -26,6 +26,18 @@ namespace ORB_SLAM3 {
 
 class KeyFrame;
 class Map;
+}  // namespace ORB_SLAM3
+
+// Thirdparty/DBoW2/DBoW2/FeatureVector.h:25-56: vocabulary node -> indices of the features below it
+namespace DBoW2 {
+typedef unsigned int NodeId;
+class FeatureVector : public std::map<NodeId, std::vector<unsigned int>> {
+public:
+    void addFeature(NodeId id, unsigned int i_feature) { (*this)[id].push_back(i_feature); }
+};
+}  // namespace DBoW2
+
+namespace ORB_SLAM3 {
 
 // include/ImuTypes.h (the members Optimizer.cc:4574-5187 and G2oTypes.cc:25-71, 693-715 read)
 namespace IMU {
@@ -168,6 +180,8 @@ public:
     cv::Mat mTrl;
     std::vector<cv::KeyPoint> mvKeysRight;
     int NLeft;
+    cv::Mat mDescriptors;
+    DBoW2::FeatureVector mFeatVec;
     // inertial members (include/KeyFrame.h:405-470)
     KeyFrame *mPrevKF, *mNextKF;
     bool bImu;
@@ -208,6 +222,7 @@ public:
     std::vector<float> mvuRight;
     cv::Mat mDescriptors;
     std::vector<bool> mvbOutlier;
+    DBoW2::FeatureVector mFeatVec;
     cv::Mat mTcw;
     std::vector<float> mvScaleFactors;
     static float mnMinX, mnMaxX, mnMinY, mnMaxY;
