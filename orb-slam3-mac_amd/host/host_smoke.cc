@@ -258,6 +258,54 @@ static int liba_smoke(const char *in, const char *out)
     return 0;
 }
 
+// in:  int32[4] {nK, nF, mbCheckOrientation, 0}; float mfNNratio; cv::KeyPoint[nK]; uint8[nK*32]; int32[nK] vocabulary node of every
+//      keyframe feature; int32[nK] 1 = has a good map point, 0 = none, 2 = a bad one; cv::KeyPoint[nF]; uint8[nF*32]; int32[nF] node
+// out: int32 return value; int32[nF] index of the keyframe feature whose map point the frame feature received, or -1
+static int bow_smoke(const char *in, const char *out)
+{
+    Reader r(in);
+    if (!r.f) { fprintf(stderr, "cannot open %s\n", in); return 2; }
+    const std::vector<int32_t> hd = r.vec<int32_t>(4);
+    const int nK = hd[0], nF = hd[1];
+    const float ratio = r.vec<float>(1)[0];
+    const std::vector<cv::KeyPoint> kk = r.vec<cv::KeyPoint>(nK);
+    const std::vector<uint8_t> dk = r.vec<uint8_t>((size_t)nK * 32);
+    const std::vector<int32_t> nodeK = r.vec<int32_t>(nK), mpK = r.vec<int32_t>(nK);
+    const std::vector<cv::KeyPoint> kf = r.vec<cv::KeyPoint>(nF);
+    const std::vector<uint8_t> df = r.vec<uint8_t>((size_t)nF * 32);
+    const std::vector<int32_t> nodeF = r.vec<int32_t>(nF);
+    Map map;
+    GeometricCamera camera({500.f, 500.f, 320.f, 240.f}, 0);
+    KeyFrame K(1, &map, 500.f, 500.f, 320.f, 240.f, 40.f, &camera);
+    K.mvKeysUn = kk;
+    K.mDescriptors = cv::Mat(nK, 32, CV_8U);
+    if (nK) memcpy(K.mDescriptors.data, dk.data(), dk.size());
+    std::vector<std::unique_ptr<MapPoint>> pool;
+    cv::Mat zero(3, 1, CV_32F);
+    for (int i = 0; i < nK; i++) {
+        K.mFeatVec.addFeature((DBoW2::NodeId)nodeK[i], (unsigned)i);           // DBoW2 fills it in feature order (TemplatedVocabulary.h:1218-1260)
+        MapPoint *p = nullptr;
+        if (mpK[i]) { pool.emplace_back(new MapPoint(100 + i, zero, &map)); p = pool.back().get(); p->mbBad = mpK[i] == 2; }
+        K.mvpMapPoints.push_back(p);
+    }
+    Frame F;
+    F.N = nF; F.mvKeys = kf; F.mvKeysUn = kf;
+    F.mDescriptors = cv::Mat(nF, 32, CV_8U);
+    if (nF) memcpy(F.mDescriptors.data, df.data(), df.size());
+    for (int i = 0; i < nF; i++) F.mFeatVec.addFeature((DBoW2::NodeId)nodeF[i], (unsigned)i);
+    ORBmatcher matcher(ratio, hd[2] != 0);
+    std::vector<MapPoint *> vpMapPointMatches;
+    const int n = matcher.SearchByBoW(&K, F, vpMapPointMatches);                // Tracking.cc:1757 call shape
+    Writer w(out);
+    w.i32(n);
+    std::vector<int32_t> res(nF, -1);
+    for (int j = 0; j < nF && j < (int)vpMapPointMatches.size(); j++)
+        if (vpMapPointMatches[j]) res[j] = (int32_t)vpMapPointMatches[j]->mnId - 100;
+    w.vec(res);
+    printf("HOST_BOW_OK %d matches\n", n);
+    return (int)vpMapPointMatches.size() == nF ? 0 : 1;
+}
+
 int match_smoke(const char *in, const char *out);            // host_match_smoke.cc
 
 int main(int argc, char **argv)
@@ -265,5 +313,6 @@ int main(int argc, char **argv)
     if (argc == 4 && std::string(argv[1]) == "lba") return lba_smoke(argv[2], argv[3]);
     if (argc == 4 && std::string(argv[1]) == "match") return match_smoke(argv[2], argv[3]);
     if (argc == 4 && std::string(argv[1]) == "liba") return liba_smoke(argv[2], argv[3]);
+    if (argc == 4 && std::string(argv[1]) == "bow") return bow_smoke(argv[2], argv[3]);
     return extractor_smoke();
 }

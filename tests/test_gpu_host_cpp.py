@@ -578,3 +578,29 @@ def test_local_inertial_ba_drop_in(tmp_path, variant):
     # an outlier edge erases the whole (keyframe, map point) association, i.e. its twin in the other camera too (Optimizer.cc:5113-5114)
     exp = {(int(k), int(l)) for k, l, o in zip(c["edge_kf"], c["edge_point"], oout) if o}
     assert {(int(k), int(l)) for k, l, _ in erased} == exp
+
+
+# ------------------------------------------------------------------------------------------- ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...)
+@pytest.mark.parametrize("ratio,check_ori,nk,nf", [(0.7, True, 900, 1000), (0.9, False, 400, 350), (0.7, True, 0, 50)])
+def test_orbmatcher_search_by_bow_method(tmp_path, ratio, check_ori, nk, nf):
+    """The class method over KeyFrame / Frame objects (DBoW2::FeatureVector maps, MapPoint pointers incl. bad and missing ones) against
+    the oracle restatement of ORBmatcher.cc:273-475 on the same data."""
+    import oracle_match_bind as om
+    rng = np.random.default_rng(1234 + nk)
+    c = om.make_bow_case(rng, nk, nf)
+    mp = np.where(c["valid"] > 0, 1, rng.integers(0, 2, nk) * 2).astype(np.int32) if nk else np.zeros(0, np.int32)   # invalid = missing or bad
+    fin, fout = str(tmp_path / "bow_in.bin"), str(tmp_path / "bow_out.bin")
+    with open(fin, "wb") as f:
+        np.array([nk, nf, 1 if check_ori else 0, 0], np.int32).tofile(f); np.array([ratio], np.float32).tofile(f)
+        np.ascontiguousarray(c["kp_k"]).tofile(f); np.ascontiguousarray(c["d_k"], np.uint8).tofile(f)
+        np.asarray(c["nid_k"], np.int32).tofile(f); mp.tofile(f)
+        np.ascontiguousarray(c["kp_f"]).tofile(f); np.ascontiguousarray(c["d_f"], np.uint8).tofile(f); np.asarray(c["nid_f"], np.int32).tofile(f)
+    r = subprocess.run([EXE, "bow", fin, fout], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "HOST_BOW_OK" in r.stdout, r.stdout + r.stderr
+    with open(fout, "rb") as f:
+        n = int(np.fromfile(f, np.int32, 1)[0])
+        got = np.fromfile(f, np.int32, nf)
+    n_ref, m_ref = om.search_by_bow(c, ratio, check_ori)
+    assert n == n_ref and np.array_equal(got, m_ref)
+    if nk:
+        assert n_ref > 20
