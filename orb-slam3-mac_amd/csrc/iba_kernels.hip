@@ -1189,8 +1189,15 @@ extern "C" int orbhip_inertial_ba_solve_batch(orbhip_ctx *ctx, const orbhip_iba_
         hipLaunchKernelGGL(k_iba_solve, dim3(n_windows), dim3(IBA_THREADS), lds, s, A);
         ITRY(hipGetLastError());
     } else {
-        void *kargs[] = {&A};
-        ITRY(hipLaunchCooperativeKernel((const void *)k_iba_solve, dim3(8 * G * win_per_xcd), dim3(IBA_THREADS), kargs, (unsigned)lds, s));
+        // the grid (8 * G * win_per_xcd <= CUs x workgroups per CU from the occupancy query above) is resident as a whole; a plain launch
+        // has the same residency as a cooperative one (MI355X_MICROARCH.md), ORBHIP_IBA_COOP=1 adds the runtime's own size check
+        if (getenv("ORBHIP_IBA_COOP")) {
+            void *kargs[] = {&A};
+            ITRY(hipLaunchCooperativeKernel((const void *)k_iba_solve, dim3(8 * G * win_per_xcd), dim3(IBA_THREADS), kargs, (unsigned)lds, s));
+        } else {
+            hipLaunchKernelGGL(k_iba_solve, dim3(8 * G * win_per_xcd), dim3(IBA_THREADS), lds, s, A);
+            ITRY(hipGetLastError());
+        }
     }
     std::vector<orbhip_iba_stats> st(n_windows);
     std::vector<double> kfo((size_t)IBA_KF * sumKF), pto(3 * sumL);

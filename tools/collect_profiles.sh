@@ -23,8 +23,7 @@ cp $(find $out/trace -name "*kernel_stats.csv") $out/${tag}_kernel_stats.csv
 python3 tools/profile_summary.py traffic $(find $out/fetch -name "*counter_collection.csv") $(find $out/write -name "*counter_collection.csv") $out/${tag}_pmc_traffic.json
 python3 tools/profile_summary.py valu $(find $out/sq -name "*counter_collection.csv") $out/${tag}_pmc_valu_issue.json
 grep "^{\"metric\"" $out/trace.log | tail -1 > $out/${tag}_bench_under_trace.json
-# the inertial local BA in its own trace (a cooperative launch under rocprofv3 has been seen to crash in the tool's exit handler
-# AFTER the trace is written: the exit status of this step is not checked)
+# the inertial local BA in its own trace
 timeout -k 10 300 rocprofv3 --kernel-trace -d $out/iba -o run --output-format csv -- python3 tools/iba_probe.py 64 > $out/iba.log 2>&1
 python3 - $out/iba/run_kernel_trace.csv $out/${tag}_iba_kernel_trace.csv <<'P'
 import csv, sys
