@@ -81,6 +81,134 @@ __global__ __launch_bounds__(256) void k_bf2nn(const uint8_t *descA, const int32
     }
 }
 
+// The same 2-NN search on the matrix cores.  With the query bits widened to -1 / +1 bytes (a' = 1 - 2a) and the train bits to 0 / 1 bytes (b),
+// <a', b> = |b| - 2 <a, b>, so Hamming(a, b) = |a| + |b| - 2 <a, b> = |a| + <a', b>: v_mfma_i32_32x32x32_i8 started from C = |a| of the row
+// leaves the Hamming distance in the accumulator (exact integers) and the key (distance << 16 | train index) is ONE v_lshl_add_u32 away.
+// Descriptor matching is VALU-bound as xor + popcount (~21 vector instructions per pair and lane); here a 32 x 32 block of pairs costs
+// 8 MFMAs plus 4 vector instructions per pair (accumulator read, key, v_med3 / v_min for the two smallest).  One workgroup = 4 waves
+// x 32 queries of one pair of frames; the train side streams through LDS in tiles of 64 descriptors, widened once per workgroup
+// (nibble * 0x00204081 & 0x01010101 puts 4 bits into 4 bytes), the next tile's fetch in flight behind this tile's MFMAs.
+// A operand: lane l = (row l & 31, half l >> 5) holds bits [32 m + 16 h, +16) of its query for MFMA m; B likewise per train column, so
+// element (h, j) of both operands is the same bit (the contraction index), whatever k the hardware assigns to it.  C: col = l & 31,
+// row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5).  Keys keep the reference's first-wins tie rule (cv::BFMatcher order).
+#define BFM_ROWB 272                     // bytes per widened train descriptor in LDS (256 + 16: a 16-lane b128 read covers all banks once)
+typedef int bfm_v4i __attribute__((ext_vector_type(4)));
+typedef int bfm_v16i __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ uint32_t bfm_widen4(uint32_t nib) { return __umul24(nib, 0x00204081u) & 0x01010101u; }      // full-rate 24-bit multiply (nib < 16, constant < 2^22)
+__device__ __forceinline__ uint32_t bfm_widen4_pm(uint32_t nib)          // 4 bits -> 4 bytes: bit 1 -> -1, bit 0 -> +1 (once per query, not in the loop)
+{
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) v |= (((nib >> k) & 1u) ? 0xFFu : 0x01u) << (8 * k);
+    return v;
+}
+__global__ __launch_bounds__(256) void k_bf2nn_mfma(const uint8_t *descA, const int32_t *nA, size_t strideA,
+                                                    const uint8_t *descB, const int32_t *nB, size_t strideB,
+                                                    int max_n, double ratio, int32_t *idx2, int32_t *dist2, uint8_t *accept)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t Bx[2][64 * BFM_ROWB];
+    const int pair = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int na = nA[pair], nb = nB[pair];
+    const int q0 = blockIdx.x * 128;
+    if (q0 >= na) return;
+    const uint32_t *A = reinterpret_cast<const uint32_t *>(descA + (size_t)pair * strideA);
+    const uint32_t *B = reinterpret_cast<const uint32_t *>(descB + (size_t)pair * strideB);
+    const int r = lane & 31, h = lane >> 5;
+    // ---- the wave's 32 queries: operand fragments (8 MFMAs x 16 bytes of -1 / +1) and |a|
+    const int qrow = q0 + 32 * wave + r;
+    bfm_v4i af[8];
+    int pa_row = 0;
+    {
+        uint32_t w[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) { w[m] = qrow < na ? A[(size_t)8 * qrow + m] : 0u; pa_row += __popc(w[m]); }
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            const uint32_t hw = (w[m] >> (16 * h)) & 0xFFFFu;
+            af[m] = (bfm_v4i){(int)bfm_widen4_pm(hw & 15u), (int)bfm_widen4_pm((hw >> 4) & 15u), (int)bfm_widen4_pm((hw >> 8) & 15u), (int)bfm_widen4_pm(hw >> 12)};
+        }
+    }
+    // C input: |a| of the 16 rows this lane sees in the C layout (lanes 0..31 hold rows 0..31)
+    bfm_v16i cinit;
+#pragma unroll
+    for (int g = 0; g < 16; g++) cinit[g] = __shfl(pa_row, (g & 3) + 8 * (g >> 2) + 4 * h, 64);
+    uint32_t k1[16], k2[16];
+#pragma unroll
+    for (int g = 0; g < 16; g++) { k1[g] = 0xFFFFFFFFu; k2[g] = 0xFFFFFFFFu; }
+    // ---- tiles of 64 train descriptors: thread t fetches dwords t & 7 of descriptors (t >> 3) and 32 + (t >> 3); the fetch of the NEXT
+    //      tile is issued before this tile's MFMAs and widened into the other LDS buffer after them (its latency hides behind them)
+    const int sc = tid >> 3, sm = tid & 7;
+    auto fetch = [&](int t0, uint32_t &w0, uint32_t &w1) {
+        w0 = (t0 + sc < nb) ? B[(size_t)8 * (t0 + sc) + sm] : 0u;
+        w1 = (t0 + 32 + sc < nb) ? B[(size_t)8 * (t0 + 32 + sc) + sm] : 0u;
+    };
+    auto widen = [&](int bufi, uint32_t w0, uint32_t w1) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const uint32_t w = k ? w1 : w0;
+            uint4 lo = make_uint4(bfm_widen4(w & 15u), bfm_widen4((w >> 4) & 15u), bfm_widen4((w >> 8) & 15u), bfm_widen4((w >> 12) & 15u));
+            uint4 hi = make_uint4(bfm_widen4((w >> 16) & 15u), bfm_widen4((w >> 20) & 15u), bfm_widen4((w >> 24) & 15u), bfm_widen4(w >> 28));
+            uint4 *dst = reinterpret_cast<uint4 *>(&Bx[bufi][(sc + 32 * k) * BFM_ROWB + sm * 32]);
+            dst[0] = lo; dst[1] = hi;
+        }
+    };
+    uint32_t nw0, nw1;
+    fetch(0, nw0, nw1);
+    widen(0, nw0, nw1);
+    __syncthreads();
+    int buf = 0;
+    for (int t0 = 0; t0 < nb; t0 += 64, buf ^= 1) {
+        const bool more = t0 + 64 < nb;
+        if (more) fetch(t0 + 64, nw0, nw1);
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            if (t0 + 32 * half >= nb) break;                  // uniform
+            bfm_v16i acc = cinit;
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const bfm_v4i bf = *reinterpret_cast<const bfm_v4i *>(&Bx[buf][(r + 32 * half) * BFM_ROWB + m * 32 + h * 16]);
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[m], bf, acc, 0, 0, 0);
+            }
+            // acc = Hamming.  key = (acc << 16) + column (plain C: the compiler's hazard recogniser places the MFMA -> VALU wait states;
+            // an inline-asm first reader would not get them); a column beyond the frame starts from 0x40000000, i.e. a distance no
+            // descriptor can have (recognised at the end)
+            const int col = t0 + 32 * half + r;
+            const uint32_t base = col < nb ? (uint32_t)col : (0x40000000u | (uint32_t)col);
+#pragma unroll
+            for (int g = 0; g < 16; g++) {
+                const uint32_t key = ((uint32_t)acc[g] << 16) + base;
+                asm("v_med3_u32 %0, %1, %2, %3" : "=v"(k2[g]) : "v"(k1[g]), "v"(key), "v"(k2[g]));      // k1 <= k2: the middle one is the new second best
+                k1[g] = min(k1[g], key);
+            }
+        }
+        if (more) widen(buf ^ 1, nw0, nw1);
+        __syncthreads();
+    }
+    // ---- merge the 32 columns (lanes of one half) of every row: through LDS (the tile buffers are free now), one thread per row
+    uint32_t (*kout)[2][16][64] = reinterpret_cast<uint32_t (*)[2][16][64]>(&Bx[0][0]);      // [wave][k1 | k2][reg][lane]: 32 KB of the 34 KB
+#pragma unroll
+    for (int g = 0; g < 16; g++) { kout[wave][0][g][lane] = k1[g]; kout[wave][1][g][lane] = k2[g]; }
+    __syncthreads();
+    if (lane < 32) {
+        const int row = lane, g = (row & 3) + 4 * (row >> 3), hh = (row >> 2) & 1;
+        uint32_t kb = 0xFFFFFFFFu, ks = 0xFFFFFFFFu;
+        for (int c = 0; c < 32; c++) {
+            const uint32_t a1 = kout[wave][0][g][32 * hh + c], a2 = kout[wave][1][g][32 * hh + c];
+            ks = min(min(ks, a2), max(kb, a1));                                    // two smallest of {kb, ks, a1, a2} (a1 <= a2, kb <= ks)
+            kb = min(kb, a1);
+        }
+        const int q = q0 + 32 * wave + row;
+        if (q < na) {
+            const bool hb = (kb >> 16) <= 256u, hs = (ks >> 16) <= 256u;            // a real descriptor distance (else: no such neighbour)
+            const int best = hb ? (int)(kb >> 16) : INT_MAX, second = hs ? (int)(ks >> 16) : INT_MAX;
+            const int bi = hb ? (int)(kb & 0xFFFFu) : -1, si = hs ? (int)(ks & 0xFFFFu) : -1;
+            const size_t o = ((size_t)pair * max_n + q) * 2;
+            idx2[o] = bi; idx2[o + 1] = si; dist2[o] = best; dist2[o + 1] = second;
+            accept[(size_t)pair * max_n + q] = (si >= 0 && (double)(float)best < (double)(float)second * ratio) ? 1 : 0;
+        }
+    }
+}
+
 extern "C" int orbhip_match_bf2nn_device(orbhip_ctx *ctx, const uint8_t *d_descA, const int32_t *d_nA, size_t strideA,
                                          const uint8_t *d_descB, const int32_t *d_nB, size_t strideB, int pairs,
                                          int max_n, double ratio, int32_t *d_idx2, int32_t *d_dist2, uint8_t *d_accept)
@@ -88,9 +216,15 @@ extern "C" int orbhip_match_bf2nn_device(orbhip_ctx *ctx, const uint8_t *d_descA
     if (!ctx || !d_descA || !d_descB || !d_nA || !d_nB || pairs <= 0 || max_n <= 0 || max_n > 65535 || !d_idx2 || !d_dist2 || !d_accept)
         return ORBHIP_E_BADARG;              // train indices ride in 16 bits of the 2-NN keys
     if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
-    dim3 grid((max_n + 255) / 256, pairs);
-    hipLaunchKernelGGL(k_bf2nn, grid, dim3(256), 0, orbhip_ctx_stream_internal(ctx), d_descA, d_nA, strideA, d_descB, d_nB,
-                       strideB, max_n, ratio, d_idx2, d_dist2, d_accept);
+    if (max_n >= 64 && !getenv("ORBHIP_BF2NN_VALU")) {          // matrix-core form (the xor / popcount kernel stays for tiny frames and as a cross-check)
+        dim3 grid((max_n + 127) / 128, pairs);
+        hipLaunchKernelGGL(k_bf2nn_mfma, grid, dim3(256), 0, orbhip_ctx_stream_internal(ctx), d_descA, d_nA, strideA, d_descB, d_nB,
+                           strideB, max_n, ratio, d_idx2, d_dist2, d_accept);
+    } else {
+        dim3 grid((max_n + 255) / 256, pairs);
+        hipLaunchKernelGGL(k_bf2nn, grid, dim3(256), 0, orbhip_ctx_stream_internal(ctx), d_descA, d_nA, strideA, d_descB, d_nB,
+                           strideB, max_n, ratio, d_idx2, d_dist2, d_accept);
+    }
     return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
 }
 
