@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void k_bf2nn(const uint8_t *descA, const int32
 // <a', b> = |b| - 2 <a, b>, so Hamming(a, b) = |a| + |b| - 2 <a, b> = |a| + <a', b>: v_mfma_i32_32x32x32_i8 started from C = |a| of the row
 // leaves the Hamming distance in the accumulator (exact integers) and the key (distance << 16 | train index) is ONE v_lshl_add_u32 away.
 // Descriptor matching is VALU-bound as xor + popcount (~21 vector instructions per pair and lane); here a 32 x 32 block of pairs costs
-// 8 MFMAs plus 4 vector instructions per pair (accumulator read, key, v_med3 / v_min for the two smallest).  One workgroup = 4 waves
+// 8 MFMAs plus 4 vector instructions per pair (accumulator read, key, v_med3 / v_min for the two smallest).  One workgroup = 8 waves
 // x 32 queries of one pair of frames; the train side streams through LDS in tiles of 64 descriptors, widened once per workgroup
 // (nibble * 0x00204081 & 0x01010101 puts 4 bits into 4 bytes), the next tile's fetch in flight behind this tile's MFMAs.
 // A operand: lane l = (row l & 31, half l >> 5) holds bits [32 m + 16 h, +16) of its query for MFMA m; B likewise per train column, so
@@ -102,14 +102,16 @@ __device__ __forceinline__ uint32_t bfm_widen4_pm(uint32_t nib)          // 4 bi
     for (int k = 0; k < 4; k++) v |= (((nib >> k) & 1u) ? 0xFFu : 0x01u) << (8 * k);
     return v;
 }
-__global__ __launch_bounds__(256) void k_bf2nn_mfma(const uint8_t *descA, const int32_t *nA, size_t strideA,
+#define BFM_WAVES 8                      // waves (x 32 queries) per workgroup: the train tiles are widened once per workgroup
+__global__ __launch_bounds__(64 * BFM_WAVES) void k_bf2nn_mfma(const uint8_t *descA, const int32_t *nA, size_t strideA,
                                                     const uint8_t *descB, const int32_t *nB, size_t strideB,
                                                     int max_n, double ratio, int32_t *idx2, int32_t *dist2, uint8_t *accept)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t Bx[2][64 * BFM_ROWB];
+    __shared__ __attribute__((aligned(16))) uint8_t Bx[BFM_WAVES * 2 * 16 * 64 * 4];      // two tile buffers of 64 x BFM_ROWB bytes; at the end the merge area
+    static_assert(2 * 64 * BFM_ROWB <= BFM_WAVES * 2 * 16 * 64 * 4, "tile buffers fit");
     const int pair = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int na = nA[pair], nb = nB[pair];
-    const int q0 = blockIdx.x * 128;
+    const int q0 = blockIdx.x * (32 * BFM_WAVES);
     if (q0 >= na) return;
     const uint32_t *A = reinterpret_cast<const uint32_t *>(descA + (size_t)pair * strideA);
     const uint32_t *B = reinterpret_cast<const uint32_t *>(descB + (size_t)pair * strideB);
@@ -135,38 +137,31 @@ __global__ __launch_bounds__(256) void k_bf2nn_mfma(const uint8_t *descA, const 
     uint32_t k1[16], k2[16];
 #pragma unroll
     for (int g = 0; g < 16; g++) { k1[g] = 0xFFFFFFFFu; k2[g] = 0xFFFFFFFFu; }
-    // ---- tiles of 64 train descriptors: thread t fetches dwords t & 7 of descriptors (t >> 3) and 32 + (t >> 3); the fetch of the NEXT
-    //      tile is issued before this tile's MFMAs and widened into the other LDS buffer after them (its latency hides behind them)
+    // ---- tiles of 64 train descriptors: thread t fetches dword t & 7 of descriptor t >> 3; the fetch of the NEXT tile is issued before
+    //      this tile's MFMAs and widened into the other LDS buffer after them (its latency hides behind them)
     const int sc = tid >> 3, sm = tid & 7;
-    auto fetch = [&](int t0, uint32_t &w0, uint32_t &w1) {
-        w0 = (t0 + sc < nb) ? B[(size_t)8 * (t0 + sc) + sm] : 0u;
-        w1 = (t0 + 32 + sc < nb) ? B[(size_t)8 * (t0 + 32 + sc) + sm] : 0u;
+    auto fetch = [&](int t0, uint32_t &w0) { w0 = (t0 + sc < nb) ? B[(size_t)8 * (t0 + sc) + sm] : 0u; };
+    auto widen = [&](int bufi, uint32_t w) {
+        uint4 lo = make_uint4(bfm_widen4(w & 15u), bfm_widen4((w >> 4) & 15u), bfm_widen4((w >> 8) & 15u), bfm_widen4((w >> 12) & 15u));
+        uint4 hi = make_uint4(bfm_widen4((w >> 16) & 15u), bfm_widen4((w >> 20) & 15u), bfm_widen4((w >> 24) & 15u), bfm_widen4(w >> 28));
+        uint4 *dst = reinterpret_cast<uint4 *>(&Bx[bufi * 64 * BFM_ROWB + sc * BFM_ROWB + sm * 32]);
+        dst[0] = lo; dst[1] = hi;
     };
-    auto widen = [&](int bufi, uint32_t w0, uint32_t w1) {
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const uint32_t w = k ? w1 : w0;
-            uint4 lo = make_uint4(bfm_widen4(w & 15u), bfm_widen4((w >> 4) & 15u), bfm_widen4((w >> 8) & 15u), bfm_widen4((w >> 12) & 15u));
-            uint4 hi = make_uint4(bfm_widen4((w >> 16) & 15u), bfm_widen4((w >> 20) & 15u), bfm_widen4((w >> 24) & 15u), bfm_widen4(w >> 28));
-            uint4 *dst = reinterpret_cast<uint4 *>(&Bx[bufi][(sc + 32 * k) * BFM_ROWB + sm * 32]);
-            dst[0] = lo; dst[1] = hi;
-        }
-    };
-    uint32_t nw0, nw1;
-    fetch(0, nw0, nw1);
-    widen(0, nw0, nw1);
+    uint32_t nw0;
+    fetch(0, nw0);
+    widen(0, nw0);
     __syncthreads();
     int buf = 0;
     for (int t0 = 0; t0 < nb; t0 += 64, buf ^= 1) {
         const bool more = t0 + 64 < nb;
-        if (more) fetch(t0 + 64, nw0, nw1);
+        if (more) fetch(t0 + 64, nw0);
 #pragma unroll
         for (int half = 0; half < 2; half++) {
             if (t0 + 32 * half >= nb) break;                  // uniform
             bfm_v16i acc = cinit;
 #pragma unroll
             for (int m = 0; m < 8; m++) {
-                const bfm_v4i bf = *reinterpret_cast<const bfm_v4i *>(&Bx[buf][(r + 32 * half) * BFM_ROWB + m * 32 + h * 16]);
+                const bfm_v4i bf = *reinterpret_cast<const bfm_v4i *>(&Bx[buf * 64 * BFM_ROWB + (r + 32 * half) * BFM_ROWB + m * 32 + h * 16]);
                 acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[m], bf, acc, 0, 0, 0);
             }
             // acc = Hamming.  key = (acc << 16) + column (plain C: the compiler's hazard recogniser places the MFMA -> VALU wait states;
@@ -181,11 +176,11 @@ __global__ __launch_bounds__(256) void k_bf2nn_mfma(const uint8_t *descA, const 
                 k1[g] = min(k1[g], key);
             }
         }
-        if (more) widen(buf ^ 1, nw0, nw1);
+        if (more) widen(buf ^ 1, nw0);
         __syncthreads();
     }
     // ---- merge the 32 columns (lanes of one half) of every row: through LDS (the tile buffers are free now), one thread per row
-    uint32_t (*kout)[2][16][64] = reinterpret_cast<uint32_t (*)[2][16][64]>(&Bx[0][0]);      // [wave][k1 | k2][reg][lane]: 32 KB of the 34 KB
+    uint32_t (*kout)[2][16][64] = reinterpret_cast<uint32_t (*)[2][16][64]>(&Bx[0]);         // [wave][k1 | k2][reg][lane]
 #pragma unroll
     for (int g = 0; g < 16; g++) { kout[wave][0][g][lane] = k1[g]; kout[wave][1][g][lane] = k2[g]; }
     __syncthreads();
@@ -217,8 +212,8 @@ extern "C" int orbhip_match_bf2nn_device(orbhip_ctx *ctx, const uint8_t *d_descA
         return ORBHIP_E_BADARG;              // train indices ride in 16 bits of the 2-NN keys
     if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
     if (max_n >= 64 && !getenv("ORBHIP_BF2NN_VALU")) {          // matrix-core form (the xor / popcount kernel stays for tiny frames and as a cross-check)
-        dim3 grid((max_n + 127) / 128, pairs);
-        hipLaunchKernelGGL(k_bf2nn_mfma, grid, dim3(256), 0, orbhip_ctx_stream_internal(ctx), d_descA, d_nA, strideA, d_descB, d_nB,
+        dim3 grid((max_n + 32 * BFM_WAVES - 1) / (32 * BFM_WAVES), pairs);
+        hipLaunchKernelGGL(k_bf2nn_mfma, grid, dim3(64 * BFM_WAVES), 0, orbhip_ctx_stream_internal(ctx), d_descA, d_nA, strideA, d_descB, d_nB,
                            strideB, max_n, ratio, d_idx2, d_dist2, d_accept);
     } else {
         dim3 grid((max_n + 255) / 256, pairs);
