@@ -417,29 +417,41 @@ __global__ __launch_bounds__(256) void k_ba_errors(BaBatch B, int which)
 
 // Deterministic per-graph sums: chi = sum rho0 over edges (activeRobustChi2, sparse_optimizer.cpp:100-114);
 // mode 1 additionally sums computeScale partials (levenberg.cpp:187-194).
-__global__ __launch_bounds__(256) void k_ba_reduce(BaBatch B, int which)
+__global__ __launch_bounds__(1024) void k_ba_reduce(BaBatch B, int which)
 {
-    __shared__ double red[256];
+    // 1024 threads, four loads in flight per thread, DPP tree per wave, the 16 wave sums added in order: a fixed association (round 1: 256
+    // threads walking 78 dependent loads each and an 8-step LDS tree -- 21 us of a single-window LM tick, twice per tick)
+    __shared__ double red[16];
     const int g = blockIdx.x, tid = threadIdx.x;
     const BaState &st = B.st[g];
     if (!st.active || (which == 0 && !st.need_build)) return;
     const BaGraphDev &G = B.gd[g];
-    double s = 0;
-    for (int e = tid; e < G.n_edges; e += 256) s += B.rho0[G.edge_off + e];
-    red[tid] = s;
-    __syncthreads();
-    for (int d = 128; d > 0; d >>= 1) { if (tid < d) red[tid] += red[tid + d]; __syncthreads(); }
-    if (tid == 0) B.chi[g] = red[0];
-    if (which == 0 && tid == 0) B.st[g].apply_levels = 0;      // k_ba_levels (earlier in this tick) has consumed it
-    if (which == 1) {
+    auto block_sum = [&](double v) {
+        v = wave_sum_f64_dpp(v);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = v;
         __syncthreads();
         double t = 0;
-        for (int l = tid; l < G.n_points; l += 256) t += B.scale_pt[G.point_off + l];
-        if (B.rank == 0) for (int h = tid; h < G.nf; h += 256) t += B.scale_pose[G.free_off + h];   // replicated: counted once
-        red[tid] = t;
-        __syncthreads();
-        for (int d = 128; d > 0; d >>= 1) { if (tid < d) red[tid] += red[tid + d]; __syncthreads(); }
-        if (tid == 0) B.scale[g] = red[0];
+#pragma unroll
+        for (int w = 0; w < 16; w++) t += red[w];
+        return t;
+    };
+    {
+        const double *r = B.rho0 + G.edge_off;
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        int e = tid;
+        for (; e + 3072 < G.n_edges; e += 4096) { s0 += r[e]; s1 += r[e + 1024]; s2 += r[e + 2048]; s3 += r[e + 3072]; }
+        for (; e < G.n_edges; e += 1024) s0 += r[e];
+        const double chi = block_sum((s0 + s1) + (s2 + s3));
+        if (tid == 0) B.chi[g] = chi;
+    }
+    if (which == 0 && tid == 0) B.st[g].apply_levels = 0;      // k_ba_levels (earlier in this tick) has consumed it
+    if (which == 1) {
+        double t = 0;
+        for (int l = tid; l < G.n_points; l += 1024) t += B.scale_pt[G.point_off + l];
+        if (B.rank == 0) for (int h = tid; h < G.nf; h += 1024) t += B.scale_pose[G.free_off + h];   // replicated: counted once
+        const double sc = block_sum(t);
+        if (tid == 0) B.scale[g] = sc;
     }
 }
 
@@ -1903,7 +1915,7 @@ static int ba_solve_impl(orbhip_ba_batch *b, const orbhip_ba_params *params, vol
     auto launch_tick = [&](int ab) -> int {
         if (B.ex2) hipLaunchKernelGGL(k_ba_levels, ge, dim3(256), 0, s, B);
         if (b->general) hipLaunchKernelGGL(k_ba_errors<true>, ge, dim3(256), 0, s, B, 0); else hipLaunchKernelGGL(k_ba_errors<false>, ge, dim3(256), 0, s, B, 0);
-        hipLaunchKernelGGL(k_ba_reduce, dim3(G), dim3(256), 0, s, B, 0);
+        hipLaunchKernelGGL(k_ba_reduce, dim3(G), dim3(1024), 0, s, B, 0);
         if (b->general) hipLaunchKernelGGL(k_ba_build_points<true>, dim3((B.max_points + 15) / 16, G), dim3(256), 0, s, B);
         else hipLaunchKernelGGL(k_ba_build_points<false>, dim3((B.max_points + 15) / 16, G), dim3(256), 0, s, B);
         if (b->general) hipLaunchKernelGGL(k_ba_build_poses<true>, gf, dim3(64), 0, s, B); else hipLaunchKernelGGL(k_ba_build_poses<false>, gf, dim3(64), 0, s, B);
@@ -1943,7 +1955,7 @@ static int ba_solve_impl(orbhip_ba_batch *b, const orbhip_ba_params *params, vol
         hipLaunchKernelGGL(k_ba_backsub_points, dim3((B.max_points + 15) / 16, G), dim3(256), 0, s, B);
         hipLaunchKernelGGL(k_ba_update_poses, dim3((max_poses + 63) / 64, G), dim3(64), 0, s, B);
         if (b->general) hipLaunchKernelGGL(k_ba_errors<true>, ge, dim3(256), 0, s, B, 1); else hipLaunchKernelGGL(k_ba_errors<false>, ge, dim3(256), 0, s, B, 1);
-        hipLaunchKernelGGL(k_ba_reduce, dim3(G), dim3(256), 0, s, B, 1);
+        hipLaunchKernelGGL(k_ba_reduce, dim3(G), dim3(1024), 0, s, B, 1);
         if (sharded) {                                           // exchange 3: trial chi2, computeScale, abort flag
             hipLaunchKernelGGL(k_ba_shard_pack34, dim3((G + 63) / 64), dim3(64), 0, s, B, 3, ab);
             XCHG(3, x3n);
