@@ -965,8 +965,12 @@ __global__ __launch_bounds__(1024) void k_ba_ldlt(BaBatch B)
 //   k_ba_big_backsub    D^-1, L^T x = y
 // The arithmetic per entry is the LDS-panel kernel's (same ldlt_rows), so small and big windows factor alike.
 #define BA_BIG_MAXN 4096
+// LPP = lanes per pair: 16 (four pairs per wave; batches) or 64 (one pair per wave: with a handful of windows the chip is empty and the
+// per-pair chain -- entries / lanes dependent gather rounds -- is what a tick waits for)
+template <int LPP>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ba_schur_big(BaBatch B, int nblk)
 {
+    constexpr int PPW = 64 / LPP;                                  // pairs per wave
     // FOUR block pairs per wave, 16 lanes each: the 36 sums of a pair are reduced inside its 16-lane DPP row (4 rotate-add steps
     // instead of 6 scan steps + a readlane over the wave) and four pairs share the issue slots -- 2.6x fewer instructions per pair
     // than one wave per pair, which made this kernel faster than the MFMA panel GEMM for every batch size.
@@ -981,8 +985,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (!st.active) return;
     const BaGraphDev &G = B.gd[g];
     const int nf = G.nf;
-    const int lane = threadIdx.x, sub = lane & 15;
-    const int pair = blk * 4 + (lane >> 4);
+    const int lane = threadIdx.x, sub = lane & (LPP - 1);
+    const int pair = blk * PPW + lane / LPP;
     if (pair >= nf * (nf + 1) / 2) return;                          // whole rows leave together (row-local DPP below)
     int i = 0, bp = pair;
     while (bp >= nf - i) { bp -= nf - i; i++; }
@@ -993,7 +997,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     double acc[36];
 #pragma unroll
     for (int k = 0; k < 36; k++) acc[k] = 0.0;
-    for (int e = ps[0] + sub; e < ps[1]; e += 16) {
+    for (int e = ps[0] + sub; e < ps[1]; e += LPP) {
         const int2 t = ent[e];
         const int l = entl[e];
         const double *Di = B.Dinv + (size_t)(G.point_off + l) * 6;       // (Hll + lambda I)^-1, upper triangle
@@ -1021,7 +1025,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const double *Hd = B.Hpp + (size_t)(G.free_off + i) * 36;
 #pragma unroll
     for (int k = 0; k < 36; k++) {
-        const double v = row16_allreduce_f64_dpp(acc[k]);          // every lane of the row holds the sum
+        const double v = LPP == 16 ? row16_allreduce_f64_dpp(acc[k]) : wave_sum_f64_dpp(acc[k]);      // every lane of the group holds the sum
         if (sub == 0) {
             const int r = k / 6, c = k - 6 * r;
             const double out = (i == j ? Hd[k] + (r == c ? lambda : 0.0) : 0.0) - v;
@@ -1033,7 +1037,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // short pass over it (its blocks are in L2 now) -- inside the loop above the extra branch and registers cost more than they saved
     if (i == j) {
         double wdb[6] = {0, 0, 0, 0, 0, 0};
-        for (int e = ps[0] + sub; e < ps[1]; e += 16) {
+        for (int e = ps[0] + sub; e < ps[1]; e += LPP) {
             const double *w = B.Wsp + (size_t)ent[e].x * 18, *db = B.db + (size_t)(G.point_off + entl[e]) * 3;
             const double d0 = db[0], d1 = db[1], d2 = db[2];
 #pragma unroll
@@ -1041,7 +1045,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
 #pragma unroll
         for (int a = 0; a < 6; a++) {
-            const double v = row16_allreduce_f64_dpp(wdb[a]);
+            const double v = LPP == 16 ? row16_allreduce_f64_dpp(wdb[a]) : wave_sum_f64_dpp(wdb[a]);
             if (sub == 0) { B.bacc[(size_t)(G.free_off + i) * 6 + a] = v; B.bs[(size_t)(G.free_off + i) * 6 + a] = B.bp[(size_t)(G.free_off + i) * 6 + a] - v; }
         }
     }
@@ -1928,7 +1932,10 @@ static int ba_solve_impl(orbhip_ba_batch *b, const orbhip_ba_params *params, vol
         hipLaunchKernelGGL(k_ba_pretrial, dim3((G + 63) / 64), dim3(64), 0, s, B);
         hipLaunchKernelGGL(k_ba_point_prep, gp256, dim3(256), 0, s, B);
         if (b->profile) TRY(hipEventRecord(b->ev0, s));
-        if (B.pair_schur) hipLaunchKernelGGL(k_ba_schur_big, dim3((unsigned)(((max_nfp + 3) / 4) * (G >= 8 ? ((G + 7) / 8) * 8 : G))), dim3(64), 0, s, B, (max_nfp + 3) / 4);
+        if (B.pair_schur) {
+            if (G >= 8) hipLaunchKernelGGL(k_ba_schur_big<16>, dim3((unsigned)(((max_nfp + 3) / 4) * (((G + 7) / 8) * 8))), dim3(64), 0, s, B, (max_nfp + 3) / 4);
+            else hipLaunchKernelGGL(k_ba_schur_big<64>, dim3((unsigned)(max_nfp * G)), dim3(64), 0, s, B, max_nfp);
+        }
         else hipLaunchKernelGGL(k_ba_schur_gemm, dim3(max_items, G), dim3(64 * GEMM_WAVES), gemm_lds, s, B);
         if (b->profile) TRY(hipEventRecord(b->ev1, s));
         if (!B.pair_schur) hipLaunchKernelGGL(k_ba_bschur, gf, dim3(64), 0, s, B);      // (the pair kernel's diagonal rows produced bs)
