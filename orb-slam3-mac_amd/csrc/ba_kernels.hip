@@ -2079,6 +2079,14 @@ extern "C" int orbhip_ba_batch_download(orbhip_ba_batch *b, double *const *poses
 }
 
 extern "C" int orbhip_ba_batch_ticks(const orbhip_ba_batch *b) { return b ? b->ticks_last : ORBHIP_E_BADARG; }
+#ifdef LDLT_PROF
+extern "C" int orbhip_debug_ldlt_prof(long long *out8, int reset)      // debug build only (EXTRA=-DLDLT_PROF): cumulative cycles of ldlt_solve_wg's phases
+{
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_ldlt_prof), 64) != hipSuccess) return ORBHIP_E_HIP;
+    if (reset) { long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_ldlt_prof), z, 64) != hipSuccess) return ORBHIP_E_HIP; }
+    return ORBHIP_OK;
+}
+#endif
 
 extern "C" int orbhip_ba_batch_set_profiling(orbhip_ba_batch *b, int enable)
 {

@@ -172,6 +172,48 @@ __device__ __forceinline__ void ldlt_trailing(double *S, int ld, lds_f64 *P, lds
     }
 }
 
+// The same trailing update on the FP64 matrix cores: one wave per 16 x 16 tile of the lower triangle, 8 x v_mfma_f64_16x16x4_f64 over the
+// panel's 32 columns.  On this chip the FP64 MFMA rate equals the vector FMA rate; what it buys is LDS traffic: a lane fetches ONE double
+// of L_i d and ONE of L_k per MFMA (1 byte per multiply-add) where the 4 x 4 register tiles read 8 doubles per 16 multiply-adds (4 bytes)
+// -- and 16 waves x 1024 threads of those tiles were bound by the LDS pipe (measured at n = 288: 356 k of the solve's 732 k cycles).
+// A[i][k] = lane (i = l & 15, k = l >> 4), B[k][j] = lane (j = l & 15, k = l >> 4); D: col j = l & 15, row i = (l >> 4) + 4 reg.
+typedef double ldlt_v4d __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ldlt_trailing_mfma(double *S, int ld, lds_f64 *P, lds_f64 *dv, int p0, int nb, int m)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int m2 = m - nb, T = (m2 + 15) >> 4, ntri = T * (T + 1) / 2;
+    const int li = lane & 15, lk = lane >> 4;
+    for (int t = wave; t < ntri; t += nwaves) {
+        int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+        while (ti * (ti + 1) / 2 > t) ti--;
+        while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
+        const int tk = t - ti * (ti + 1) / 2;
+        const int i0 = nb + 16 * ti, k0 = nb + 16 * tk;
+        const int ri = min(i0 + li, m - 1), rk = min(k0 + li, m - 1);     // rows beyond the matrix: clamped reads, results never stored
+        // the tile's current values (row i = lk + 4 r, column li): in flight while the products are formed
+        double sv[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int i = i0 + lk + 4 * r, k = k0 + li;
+            sv[r] = (i < m && k < m && i >= k) ? S[(size_t)(p0 + i) * ld + p0 + k] : 0.0;
+        }
+        ldlt_v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < LD_NB / 4; q++) {
+            const int c = 4 * q + lk;
+            const bool live = c < nb;                                     // a partial last panel: columns >= nb hold garbage
+            const double a = live ? P[ri * LD_PP + c] * dv[c] : 0.0;
+            const double b = live ? P[rk * LD_PP + c] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int i = i0 + lk + 4 * r, k = k0 + li;
+            if (i < m && k < m && i >= k) S[(size_t)(p0 + i) * ld + p0 + k] = sv[r] - acc[r];
+        }
+    }
+}
+
 // S: [n][ld] row-major, lower triangle read and overwritten with L / d; rhs, x: n doubles in global memory (x may alias rhs); uses
 // the first ba_ldlt_lds_bytes(max_ld) bytes of the kernel's dynamic LDS, max_ld >= n.  Every thread of the (<= 1024-thread, >= n - 32) block calls
 // it; the return value is block-uniform: false = zero / non-finite pivot, x untouched.
@@ -234,8 +276,13 @@ __device__ __forceinline__ bool ldlt_solve_wg(double *S, int ld, int n, const do
         }
         if (m > nb) {
             const int T4 = (m - nb + 3) >> 2;
+#ifdef LDLT_VECTOR_TRAILING
             if (T4 * (T4 + 1) / 2 >= nth) ldlt_trailing<4>(S, ld, P, dval + p0, p0, nb, m);
             else ldlt_trailing<2>(S, ld, P, dval + p0, p0, nb, m);
+#else
+            (void)T4;
+            ldlt_trailing_mfma(S, ld, P, dval + p0, p0, nb, m);
+#endif
         }
         __syncthreads();
         LDLT_T(3);
