@@ -63,6 +63,7 @@ struct BaState {
     int pass, iter, qmax, nbad;
     int need_build, need_lambda_init, active, cur;   // cur: which pose/point buffer is current
     int ok;                                          // last LDLT status
+    int errors_fresh;                                // the stored errors / chi2 are those of the current estimate (the last trial was accepted)
     int iters_run[2], lm_trials, n_outliers;
     int robust;                                      // 0 after setRobustKernel(0) (merge variant, second pass)
     int apply_levels;                                // set when pass 1 starts: k_ba_levels classifies the edges once
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(256) void k_ba_errors(BaBatch B, int which)
 {
     const int g = blockIdx.y;
     const BaState &st = B.st[g];
-    if (!st.active || (which == 0 && !st.need_build)) return;
+    if (!st.active || (which == 0 && (!st.need_build || (st.errors_fresh && B.world == 1)))) return;      // after an accepted trial the stored errors ARE the current ones
     const BaGraphDev &G = B.gd[g];
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= G.n_edges) return;
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(1024) void k_ba_reduce(BaBatch B, int which)
     __shared__ double red[16];
     const int g = blockIdx.x, tid = threadIdx.x;
     const BaState &st = B.st[g];
-    if (!st.active || (which == 0 && !st.need_build)) return;
+    if (!st.active || (which == 0 && (!st.need_build || (st.errors_fresh && B.world == 1)))) return;      // after an accepted trial the stored errors ARE the current ones
     const BaGraphDev &G = B.gd[g];
     auto block_sum = [&](double v) {
         v = wave_sum_f64_dpp(v);
@@ -1303,8 +1304,10 @@ __global__ void k_ba_control(BaBatch B, int abort_arg)
         const double sf = fmax(1. / 3., alpha);
         st.lambda *= sf; st.ni = 2; st.current_chi = temp_chi;
         st.cur ^= 1;                                   // discardTop: the trial becomes the estimate
+        st.errors_fresh = 1;
     } else {
         st.lambda *= st.ni; st.ni *= 2;                // pop: keep the old estimate
+        st.errors_fresh = 0;                           // the stored errors belong to the rejected trial
     }
     st.qmax++; st.lm_trials++;
     st.rho_dbg = rho;
@@ -1322,7 +1325,7 @@ __global__ void k_ba_control(BaBatch B, int abort_arg)
     st.need_build = 1;
     if (!ok || st.iter >= B.iters[st.pass] || abort_flag) {
         if (st.pass == 0 && !abort_flag && B.iters[1] > 0) {
-            st.pass = 1; st.iter = 0; st.need_lambda_init = 1;
+            st.pass = 1; st.iter = 0; st.need_lambda_init = 1; st.errors_fresh = 0;      // levels / robust kernel change: re-evaluate
             if (B.ex2) st.apply_levels = 1;                // Optimizer.cc:6546-6579 (merge variant)
             if (B.nr2) st.robust = 0;
         }
