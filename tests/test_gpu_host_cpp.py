@@ -536,6 +536,7 @@ def _expected_liba(c):
     return w2, oib.solve(w2, oib.default_params(c["large"]))
 
 
+@pytest.mark.gpu
 @pytest.mark.parametrize("variant", ["prev_outside_window", "chain_ends_inside", "fisheye_rig"])
 def test_local_inertial_ba_drop_in(tmp_path, variant):
     c = _liba_case({"prev_outside_window": 61, "chain_ends_inside": 63, "fisheye_rig": 64}[variant], fisheye_rig=variant == "fisheye_rig")
@@ -581,6 +582,7 @@ def test_local_inertial_ba_drop_in(tmp_path, variant):
 
 
 # ------------------------------------------------------------------------------------------- ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...)
+@pytest.mark.gpu
 @pytest.mark.parametrize("ratio,check_ori,nk,nf", [(0.7, True, 900, 1000), (0.9, False, 400, 350), (0.7, True, 0, 50)])
 def test_orbmatcher_search_by_bow_method(tmp_path, ratio, check_ori, nk, nf):
     """The class method over KeyFrame / Frame objects (DBoW2::FeatureVector maps, MapPoint pointers incl. bad and missing ones) against
