@@ -519,8 +519,9 @@ def main():
         ach = alg_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
         ba_traffic, ba_traffic_src = None, None
         pmc_ba = load_profile_json(PROFILE_TAG + "_pmc_traffic_ba.json")
-        if pmc_ba and args.ba_graphs == 256 and "k_ba_schur_big" in pmc_ba.get("kernels", {}):
-            ba_traffic = pmc_ba["kernels"]["k_ba_schur_big"]["hbm_bytes_per_launch"]
+        big = [v for k, v in (pmc_ba or {}).get("kernels", {}).items() if k == "k_ba_schur_big" or k.startswith("k_ba_schur_big<")]
+        if big and args.ba_graphs == 256:
+            ba_traffic = big[0]["hbm_bytes_per_launch"]
             ba_traffic_src = "profiles/%s_pmc_traffic_ba.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)" % PROFILE_TAG
         ba = {"metric": "local-BA solves/sec", "value": round(world * args.ba_graphs * args.ba_steps / dt_ba, 2),
               "unit": "solves/s", "graphs_per_gpu": args.ba_graphs, "ms_per_batch": round(dt_ba / args.ba_steps * 1e3, 2),

@@ -11,7 +11,7 @@ def load(path, counter):
     tot = collections.Counter(); n = collections.Counter()
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter: continue
-        k = r["Kernel_Name"].split("(")[0]; tot[k] += float(r["Counter_Value"]); n[k] += 1
+        k = r["Kernel_Name"].split("(")[0].replace("void ", ""); tot[k] += float(r["Counter_Value"]); n[k] += 1
     return tot, n
 f, nf = load(glob.glob("gpurun_out/pmc_ba_traffic/fetch/*counter_collection.csv")[0], "FETCH_SIZE")
 w, nw = load(glob.glob("gpurun_out/pmc_ba_traffic/write/*counter_collection.csv")[0], "WRITE_SIZE")
