@@ -30,6 +30,9 @@ struct OrbLevel {
     float size;               // (int)(PATCH_SIZE*scale) as float (ORBextractor.cc:862)
     // resize tables (device): xofs[w], xalpha[2w], yofs[h], ybeta[2h]  (level>0)
     const int16_t *xofs; const int16_t *xalpha; const int16_t *yofs; const int16_t *ybeta;
+    // k_resize_rows tables (level>0; xchunk == nullptr: the source span of 4 output columns does not fit 8 bytes, k_resize is used):
+    // xchunk[12 * c] = {base, sel[4], alpha[4], 0, 0, 0} per 4 output columns, ytab[dy] = {row0, row1, b0 << 12, b1 << 12}
+    const uint32_t *xchunk; const uint32_t *ytab;
 };
 
 struct OrbParams {

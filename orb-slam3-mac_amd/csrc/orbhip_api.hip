@@ -375,6 +375,42 @@ extern "C" int orbhip_extractor_reserve(orbhip_extractor *e, int width, int heig
             HIP_TRY(hipMemcpy(dyo, yo.data(), yo.size() * 2, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(dyb, yb.data(), yb.size() * 2, hipMemcpyHostToDevice));
             L.xofs = dxo; L.xalpha = dxa; L.yofs = dyo; L.ybeta = dyb;
+            // k_resize_rows: per 4 output columns the 8 source bytes they read (base clamped into the row), v_perm selectors that
+            // put (S[sx], S[sx+1]) into the two halves of a dword, and the coefficient pairs; per output row the two clamped
+            // source rows and the vertical coefficients pre-shifted for v_mul_hi_u32_u24
+            const int sw = P.lv[l - 1].w, sh = P.lv[l - 1].h, nch = (L.w + 3) / 4;
+            std::vector<uint32_t> xc((size_t)nch * 12, 0), yt((size_t)L.h * 4);
+            bool fits = sw >= 8;
+            for (int c = 0; c < nch && fits; c++) {
+                const int base = std::min((int)xo[4 * c], sw - 8);
+                xc[12 * c] = (uint32_t)base;
+                for (int j = 0; j < 4; j++) {
+                    const int col = std::min(4 * c + j, L.w - 1);
+                    const int i0 = xo[col] - base, a0 = xa[2 * col], a1 = xa[2 * col + 1];
+                    int i1 = i0 + 1;
+                    if (i0 < 0 || i0 > 7 || a0 < 0 || a1 < 0) { fits = false; break; }
+                    if (i1 > 7) { if (a1 != 0) { fits = false; break; } i1 = i0; }
+                    xc[12 * c + 1 + j] = (uint32_t)i0 | 0x0c00u | ((uint32_t)i1 << 16) | 0x0c000000u;
+                    xc[12 * c + 5 + j] = (uint32_t)a0 | ((uint32_t)a1 << 16);
+                }
+            }
+            for (int dy = 0; dy < L.h; dy++) {
+                const int r = yo[dy];
+                yt[4 * dy] = (uint32_t)std::min(std::max(r, 0), sh - 1);
+                yt[4 * dy + 1] = (uint32_t)std::min(std::max(r + 1, 0), sh - 1);
+                if (yb[2 * dy] < 0 || yb[2 * dy + 1] < 0 || yb[2 * dy] > 2048 || yb[2 * dy + 1] > 2048) fits = false;
+                yt[4 * dy + 2] = (uint32_t)yb[2 * dy] << 12;
+                yt[4 * dy + 3] = (uint32_t)yb[2 * dy + 1] << 12;
+            }
+            L.xchunk = nullptr; L.ytab = nullptr;
+            if (fits && !getenv("ORBHIP_RESIZE_TILES")) {
+                uint32_t *dxc, *dyt;
+                if ((rc = dev_alloc(e, &dxc, xc.size()))) return rc;
+                if ((rc = dev_alloc(e, &dyt, yt.size()))) return rc;
+                HIP_TRY(hipMemcpy(dxc, xc.data(), xc.size() * 4, hipMemcpyHostToDevice));
+                HIP_TRY(hipMemcpy(dyt, yt.data(), yt.size() * 4, hipMemcpyHostToDevice));
+                L.xchunk = dxc; L.ytab = dyt;
+            }
         }
     }
     e->d_level0 = P.lv[0].img; e->level0_pitch = P.lv[0].img_pitch; e->level0_frame_stride = P.lv[0].img_frame_stride;
