@@ -31,8 +31,9 @@ struct OrbLevel {
     // resize tables (device): xofs[w], xalpha[2w], yofs[h], ybeta[2h]  (level>0)
     const int16_t *xofs; const int16_t *xalpha; const int16_t *yofs; const int16_t *ybeta;
     // k_resize_rows tables (level>0; xchunk == nullptr: the source span of 4 output columns does not fit 8 bytes, k_resize is used):
-    // xchunk[12 * c] = {base, sel[4], alpha[4], 0, 0, 0} per 4 output columns, ytab[dy] = {row0, row1, b0 << 12, b1 << 12}
+    // xchunk[12 * c] = {load offset, sel[4], alpha[4], v_perm selector of the byte shift, 0, 0} per 4 output columns, ytab[dy] = {row0, row1, b0 << 12, b1 << 12}
     const uint32_t *xchunk; const uint32_t *ytab;
+    int resize_mode;          // k_resize_rows<MODE>: 0 unaligned 8-byte loads, 1 aligned dwordx3 + byte shift
 };
 
 struct OrbParams {

@@ -177,6 +177,20 @@ __device__ __forceinline__ uint32_t rs_mulhi24(uint32_t a, uint32_t b)
     return d;
 }
 #define RS_YL 512                                    // vertical-table entries staged per workgroup (host checks the band span)
+// Source bytes of one lane and one source row, as the 8 bytes starting at its (unaligned) base.  MODE 0: one unaligned
+// global_load_dwordx2 (the texture addresser splits it: measured 30-40 % slower, as is a 4-byte-aligned dwordx2); MODE 1: aligned
+// dwordx3 from base4 <= base, the bytes shifted back by two v_perm_b32 with a per-lane selector (shift 0..4: where the third dword
+// would leave a row of the caller's level-0 buffer, base4 is one dword lower instead).
+typedef uint32_t rs_u32x3 __attribute__((ext_vector_type(3)));
+typedef rs_u32x3 rs_u32x3_a4 __attribute__((aligned(4)));
+template <int MODE>
+__device__ __forceinline__ uint2 rs_load8(const uint8_t *src, uint32_t off, uint32_t shsel)
+{
+    if (MODE == 0) return *reinterpret_cast<const uint2 *>(src + off);
+    const rs_u32x3 v = *reinterpret_cast<const rs_u32x3_a4 *>(src + off);
+    return make_uint2(__builtin_amdgcn_perm(v.y, v.x, shsel), __builtin_amdgcn_perm(v.z, v.y, shsel));
+}
+template <int MODE>
 __global__ __launch_bounds__(256) void k_resize_rows(OrbParams P, int level, int nbx)
 {
     __shared__ uint4 yl[RS_YL];
@@ -195,7 +209,8 @@ __global__ __launch_bounds__(256) void k_resize_rows(OrbParams P, int level, int
     const unsigned band = g / (unsigned)nch, c = g - band * (unsigned)nch;
     const uint4 *xc = reinterpret_cast<const uint4 *>(D.xchunk) + 3 * c;
     const uint4 x0 = xc[0], x1 = xc[1];
-    const uint32_t al3 = reinterpret_cast<const uint32_t *>(xc)[8];
+    const uint4 x2 = xc[2];
+    const uint32_t al3 = x2.x, shsel = x2.y;
     const uint32_t base = x0.x, sel0 = x0.y, sel1 = x0.z, sel2 = x0.w, sel3 = x1.x, al0 = x1.y, al1 = x1.z, al2 = x1.w;
     const uint8_t *src = S.img + (size_t)frame * S.img_frame_stride;
     uint8_t *dst = D.img + (size_t)frame * D.img_frame_stride;
@@ -204,22 +219,24 @@ __global__ __launch_bounds__(256) void k_resize_rows(OrbParams P, int level, int
     const int klast = hlast - dy0;                                                         // rows of this band that exist: k <= klast
     const uint32_t spitch = (uint32_t)S.img_pitch;
     uint4 yt = yb[0];
-    uint2 qa = *reinterpret_cast<const uint2 *>(src + (__umul24(yt.x, spitch) + base));
-    uint2 qb = *reinterpret_cast<const uint2 *>(src + (__umul24(yt.y, spitch) + base));
+    uint2 qa = rs_load8<MODE>(src, __umul24(yt.x, spitch) + base, shsel);
+    uint2 qb = rs_load8<MODE>(src, __umul24(yt.y, spitch) + base, shsel);
     uint32_t doff = __umul24((uint32_t)dy0, (uint32_t)D.img_pitch) + 4 * c;
 #pragma unroll 4
     for (int k = 0; k < RSR; k++) {
         const uint4 ytn = yb[min(k + 1, klast)];
-        const uint2 na = *reinterpret_cast<const uint2 *>(src + (__umul24(ytn.x, spitch) + base));
-        const uint2 nb2 = *reinterpret_cast<const uint2 *>(src + (__umul24(ytn.y, spitch) + base));
+        const uint2 na = rs_load8<MODE>(src, __umul24(ytn.x, spitch) + base, shsel);
+        const uint2 nb2 = rs_load8<MODE>(src, __umul24(ytn.y, spitch) + base, shsel);
         const uint32_t s0 = rs_mulhi24(yt.z, rs_hpass(qa, sel0, al0)) + rs_mulhi24(yt.w, rs_hpass(qb, sel0, al0)) + 2u;
         const uint32_t s1 = rs_mulhi24(yt.z, rs_hpass(qa, sel1, al1)) + rs_mulhi24(yt.w, rs_hpass(qb, sel1, al1)) + 2u;
         const uint32_t s2 = rs_mulhi24(yt.z, rs_hpass(qa, sel2, al2)) + rs_mulhi24(yt.w, rs_hpass(qb, sel2, al2)) + 2u;
         const uint32_t s3 = rs_mulhi24(yt.z, rs_hpass(qa, sel3, al3)) + rs_mulhi24(yt.w, rs_hpass(qb, sel3, al3)) + 2u;
         const uint32_t p01 = (s0 | (s1 << 16)) >> 2, p23 = (s2 | (s3 << 16)) >> 2;          // bytes 0 and 2 hold the pixels
         const uint32_t packed = __builtin_amdgcn_perm(p23, p01, 0x06040200u);
-        if (k <= klast) *reinterpret_cast<uint32_t *>(dst + doff) = packed;
-        doff += (uint32_t)D.img_pitch;
+        // unconditional store: rows below the image repeat the last row's (identical) dword, so that no branch sits between the
+        // loads and the store and the wait for the next rows' loads never includes this store's acknowledgement
+        *reinterpret_cast<uint32_t *>(dst + doff) = packed;
+        doff += k < klast ? (uint32_t)D.img_pitch : 0u;
         qa = na; qb = nb2; yt = ytn;
     }
 }
@@ -229,7 +246,9 @@ void orb_launch_resize(const OrbParams &P, int level, hipStream_t s)
     const OrbLevel &D = P.lv[level];
     if (D.xchunk && (256 / ((D.w + 3) >> 2) + 2) * RSR + 2 <= RS_YL) {
         const int nch = (D.w + 3) >> 2, nb = (D.h + RSR - 1) / RSR, nbx = (nch * nb + 255) / 256;
-        hipLaunchKernelGGL(k_resize_rows, dim3((unsigned)nbx * (unsigned)P.batch), dim3(256), 0, s, P, level, nbx);
+        const dim3 grid((unsigned)nbx * (unsigned)P.batch);
+        if (D.resize_mode == 1) hipLaunchKernelGGL(k_resize_rows<1>, grid, dim3(256), 0, s, P, level, nbx);
+        else hipLaunchKernelGGL(k_resize_rows<0>, grid, dim3(256), 0, s, P, level, nbx);
         return;
     }
     const unsigned nblocks = (unsigned)(((D.w + RS_TW - 1) / RS_TW) * ((D.h + RS_TH - 1) / RS_TH)) * (unsigned)P.batch;

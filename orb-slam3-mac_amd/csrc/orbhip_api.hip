@@ -381,9 +381,16 @@ extern "C" int orbhip_extractor_reserve(orbhip_extractor *e, int width, int heig
             const int sw = P.lv[l - 1].w, sh = P.lv[l - 1].h, nch = (L.w + 3) / 4;
             std::vector<uint32_t> xc((size_t)nch * 12, 0), yt((size_t)L.h * 4);
             bool fits = sw >= 8;
+            const char *rm = getenv("ORBHIP_RESIZE_MODE");
+            int mode = l > 1 || (sw % 4 == 0 && sw >= 12) ? 1 : 0;       // level 0 may alias the caller's images: never read past a row there
+            if (rm && atoi(rm) == 0) mode = 0;
             for (int c = 0; c < nch && fits; c++) {
                 const int base = std::min((int)xo[4 * c], sw - 8);
-                xc[12 * c] = (uint32_t)base;
+                // the aligned variant loads 12 bytes from base4 = base & ~3 and shifts them back with v_perm; level 0 may be the
+                // caller's buffer, so there base4 is lowered where the third dword would leave the row (shift 4, width % 4 == 0)
+                const int base4 = l > 1 ? (base & ~3) : std::min(base & ~3, sw - 12);
+                xc[12 * c] = mode ? (uint32_t)base4 : (uint32_t)base;
+                xc[12 * c + 9] = 0x03020100u + 0x01010101u * (uint32_t)(base - base4);
                 for (int j = 0; j < 4; j++) {
                     const int col = std::min(4 * c + j, L.w - 1);
                     const int i0 = xo[col] - base, a0 = xa[2 * col], a1 = xa[2 * col + 1];
@@ -410,6 +417,7 @@ extern "C" int orbhip_extractor_reserve(orbhip_extractor *e, int width, int heig
                 HIP_TRY(hipMemcpy(dxc, xc.data(), xc.size() * 4, hipMemcpyHostToDevice));
                 HIP_TRY(hipMemcpy(dyt, yt.data(), yt.size() * 4, hipMemcpyHostToDevice));
                 L.xchunk = dxc; L.ytab = dyt;
+                L.resize_mode = mode;
             }
         }
     }
