@@ -176,7 +176,6 @@ __device__ __forceinline__ uint32_t rs_mulhi24(uint32_t a, uint32_t b)
     asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
     return d;
 }
-#define RS_YL 512                                    // vertical-table entries staged per workgroup (host checks the band span)
 // Source bytes of one lane and one source row, as the 8 bytes starting at its (unaligned) base.  MODE 0: one unaligned
 // global_load_dwordx2 (the texture addresser splits it: measured 30-40 % slower, as is a 4-byte-aligned dwordx2); MODE 1: aligned
 // dwordx3 from base4 <= base, the bytes shifted back by two v_perm_b32 with a per-lane selector (shift 0..4: where the third dword
@@ -193,7 +192,7 @@ __device__ __forceinline__ uint2 rs_load8(const uint8_t *src, uint32_t off, uint
 template <int MODE>
 __global__ __launch_bounds__(256) void k_resize_rows(OrbParams P, int level, int nbx)
 {
-    __shared__ uint4 yl[RS_YL];
+    extern __shared__ uint4 yl[];                       // (256 / nch + 2) * RSR + 2 entries: small, so that the kernel fits beside LDS-heavy ones
     const OrbLevel &D = P.lv[level];
     const OrbLevel &S = P.lv[level - 1];
     const unsigned lid = xcd_logical_id(blockIdx.x, gridDim.x);
@@ -218,37 +217,53 @@ __global__ __launch_bounds__(256) void k_resize_rows(OrbParams P, int level, int
     const uint4 *yb = yl + (dy0 - row_lo);
     const int klast = hlast - dy0;                                                         // rows of this band that exist: k <= klast
     const uint32_t spitch = (uint32_t)S.img_pitch;
-    uint4 yt = yb[0];
-    uint2 qa = rs_load8<MODE>(src, __umul24(yt.x, spitch) + base, shsel);
-    uint2 qb = rs_load8<MODE>(src, __umul24(yt.y, spitch) + base, shsel);
+    // the source rows of the NEXT four output rows are in flight while four are computed (the kernel is bound by bytes in flight)
+    uint4 yt[2][4];
+    uint2 qa[2][4], qb[2][4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        yt[0][u] = yb[min(u, klast)];
+        qa[0][u] = rs_load8<MODE>(src, __umul24(yt[0][u].x, spitch) + base, shsel);
+        qb[0][u] = rs_load8<MODE>(src, __umul24(yt[0][u].y, spitch) + base, shsel);
+    }
     uint32_t doff = __umul24((uint32_t)dy0, (uint32_t)D.img_pitch) + 4 * c;
-#pragma unroll 4
-    for (int k = 0; k < RSR; k++) {
-        const uint4 ytn = yb[min(k + 1, klast)];
-        const uint2 na = rs_load8<MODE>(src, __umul24(ytn.x, spitch) + base, shsel);
-        const uint2 nb2 = rs_load8<MODE>(src, __umul24(ytn.y, spitch) + base, shsel);
-        const uint32_t s0 = rs_mulhi24(yt.z, rs_hpass(qa, sel0, al0)) + rs_mulhi24(yt.w, rs_hpass(qb, sel0, al0)) + 2u;
-        const uint32_t s1 = rs_mulhi24(yt.z, rs_hpass(qa, sel1, al1)) + rs_mulhi24(yt.w, rs_hpass(qb, sel1, al1)) + 2u;
-        const uint32_t s2 = rs_mulhi24(yt.z, rs_hpass(qa, sel2, al2)) + rs_mulhi24(yt.w, rs_hpass(qb, sel2, al2)) + 2u;
-        const uint32_t s3 = rs_mulhi24(yt.z, rs_hpass(qa, sel3, al3)) + rs_mulhi24(yt.w, rs_hpass(qb, sel3, al3)) + 2u;
-        const uint32_t p01 = (s0 | (s1 << 16)) >> 2, p23 = (s2 | (s3 << 16)) >> 2;          // bytes 0 and 2 hold the pixels
-        const uint32_t packed = __builtin_amdgcn_perm(p23, p01, 0x06040200u);
-        // unconditional store: rows below the image repeat the last row's (identical) dword, so that no branch sits between the
-        // loads and the store and the wait for the next rows' loads never includes this store's acknowledgement
-        *reinterpret_cast<uint32_t *>(dst + doff) = packed;
-        doff += k < klast ? (uint32_t)D.img_pitch : 0u;
-        qa = na; qb = nb2; yt = ytn;
+#pragma unroll
+    for (int g = 0; g < RSR / 4; g++) {
+        if (g + 1 < RSR / 4) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint4 t = yb[min(4 * (g + 1) + u, klast)];
+                yt[(g + 1) & 1][u] = t;
+                qa[(g + 1) & 1][u] = rs_load8<MODE>(src, __umul24(t.x, spitch) + base, shsel);
+                qb[(g + 1) & 1][u] = rs_load8<MODE>(src, __umul24(t.y, spitch) + base, shsel);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int k = 4 * g + u;
+            const uint4 t = yt[g & 1][u];
+            const uint2 a = qa[g & 1][u], bq = qb[g & 1][u];
+            const uint32_t s0 = rs_mulhi24(t.z, rs_hpass(a, sel0, al0)) + rs_mulhi24(t.w, rs_hpass(bq, sel0, al0)) + 2u;
+            const uint32_t s1 = rs_mulhi24(t.z, rs_hpass(a, sel1, al1)) + rs_mulhi24(t.w, rs_hpass(bq, sel1, al1)) + 2u;
+            const uint32_t s2 = rs_mulhi24(t.z, rs_hpass(a, sel2, al2)) + rs_mulhi24(t.w, rs_hpass(bq, sel2, al2)) + 2u;
+            const uint32_t s3 = rs_mulhi24(t.z, rs_hpass(a, sel3, al3)) + rs_mulhi24(t.w, rs_hpass(bq, sel3, al3)) + 2u;
+            const uint32_t p01 = (s0 | (s1 << 16)) >> 2, p23 = (s2 | (s3 << 16)) >> 2;          // bytes 0 and 2 hold the pixels
+            // rows below the image repeat the last row's (identical) dword: no branch around the store
+            *reinterpret_cast<uint32_t *>(dst + doff) = __builtin_amdgcn_perm(p23, p01, 0x06040200u);
+            doff += k < klast ? (uint32_t)D.img_pitch : 0u;
+        }
     }
 }
 
 void orb_launch_resize(const OrbParams &P, int level, hipStream_t s)
 {
     const OrbLevel &D = P.lv[level];
-    if (D.xchunk && (256 / ((D.w + 3) >> 2) + 2) * RSR + 2 <= RS_YL) {
+    if (D.xchunk) {
         const int nch = (D.w + 3) >> 2, nb = (D.h + RSR - 1) / RSR, nbx = (nch * nb + 255) / 256;
         const dim3 grid((unsigned)nbx * (unsigned)P.batch);
-        if (D.resize_mode == 1) hipLaunchKernelGGL(k_resize_rows<1>, grid, dim3(256), 0, s, P, level, nbx);
-        else hipLaunchKernelGGL(k_resize_rows<0>, grid, dim3(256), 0, s, P, level, nbx);
+        const size_t lds = (size_t)((256 / nch + 2) * RSR + 2) * sizeof(uint4);          // <= 4.4 KB (nch >= 1)
+        if (D.resize_mode == 1) hipLaunchKernelGGL(k_resize_rows<1>, grid, dim3(256), lds, s, P, level, nbx);
+        else hipLaunchKernelGGL(k_resize_rows<0>, grid, dim3(256), lds, s, P, level, nbx);
         return;
     }
     const unsigned nblocks = (unsigned)(((D.w + RS_TW - 1) / RS_TW) * ((D.h + RS_TH - 1) / RS_TH)) * (unsigned)P.batch;
@@ -1072,8 +1087,103 @@ __global__ __launch_bounds__(256) void k_blur(OrbParams P)
     for (long t = t0; t < t1; t++) body(ld, T, t);
 }
 
+// Row-streaming form of the same filter (the default): no LDS, no barriers, so its waves fit into the wave slots k_fast_cells
+// leaves free (that kernel is LDS-limited to ~17 waves per CU) and fill its idle issue cycles.  A lane owns 4 output columns and
+// walks BLR_R output rows down: per source row one aligned dwordx3 (x-4 .. x+7), the row pass on v_dot4_u32_u8 as above, the
+// horizontal sums of consecutive rows paired in a register ring of 6 (statically indexed: the row loop is unrolled by 6), the
+// column pass = three v_dot2_u32_u16 on the pairs + one v_mad_u32_u24.  Chunks whose 12-byte window crosses the left / right
+// image border (BORDER_REFLECT_101) are a separate lane class at the end of each (frame, level) lane range and assemble their
+// windows bytewise.
+#define BLR_R 24
+template <bool EDGE>
+__device__ __forceinline__ void blr_load(const uint8_t *src, int r, int spitch, int x, int w, uint32_t &d0, uint32_t &d1, uint32_t &d2)
+{
+    if (EDGE) {
+        const uint8_t *row = src + (uint32_t)__umul24((uint32_t)r, (uint32_t)spitch);
+        d0 = bl_load4(row, x - 4, w); d1 = bl_load4(row, x, w); d2 = bl_load4(row, x + 4, w);
+    } else {
+        const rs_u32x3 v = *reinterpret_cast<const rs_u32x3_a4 *>(src + ((uint32_t)__umul24((uint32_t)r, (uint32_t)spitch) + (uint32_t)(x - 4)));
+        d0 = v.x; d1 = v.y; d2 = v.z;
+    }
+}
+template <bool EDGE>
+__device__ __forceinline__ void blr_band(const uint8_t *src, uint8_t *dst, int spitch, int dpitch, int w, int h, int x, int dy0,
+                                         uint32_t klo, uint32_t khi, uint32_t k01, uint32_t k23, uint32_t k21, uint32_t k0)
+{
+    auto srow = [&](int i) { int r = dy0 - 3 + i; r = max(r, -r); return min(r, 2 * h - 2 - r); };    // BORDER_REFLECT_101 (h >= BLR_R + 4)
+    // the six source rows of the NEXT group are in flight while this group is filtered (24 unique bytes per lane: the kernel is
+    // bound by bytes in flight, not by issue); buffers and ring are statically indexed, the whole band is unrolled
+    uint32_t ring[6][4], prev[4] = {0, 0, 0, 0};
+    uint32_t buf[2][6][3];
+#pragma unroll
+    for (int u = 0; u < 6; u++) blr_load<EDGE>(src, srow(u), spitch, x, w, buf[0][u][0], buf[0][u][1], buf[0][u][2]);
+    uint32_t doff = (uint32_t)__umul24((uint32_t)dy0, (uint32_t)dpitch) + (uint32_t)x;
+#pragma unroll
+    for (int g = 0; g < (BLR_R + 6) / 6; g++) {
+        if (g + 1 < (BLR_R + 6) / 6) {
+#pragma unroll
+            for (int u = 0; u < 6; u++) blr_load<EDGE>(src, srow(6 * (g + 1) + u), spitch, x, w, buf[(g + 1) & 1][u][0], buf[(g + 1) & 1][u][1], buf[(g + 1) & 1][u][2]);
+        }
+#pragma unroll
+        for (int u = 0; u < 6; u++) {
+            const int i = 6 * g + u;
+            uint32_t o[4];
+            bl_row4(buf[g & 1][u][0], buf[g & 1][u][1], buf[g & 1][u][2], klo, khi, o);
+            if (g > 0) {
+                uint32_t acc[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    uint32_t a = bl_dot2(ring[(u + 1) % 6][j], k01, 32768u);
+                    a = bl_dot2(ring[(u + 3) % 6][j], k23, a);
+                    a = bl_dot2(ring[(u + 5) % 6][j], k21, a);
+                    a = __umul24(o[j], k0) + a;
+                    acc[j] = min(a, 0x00FFFFFFu);                  // byte 2 = min((sum + 2^15) >> 16, 255)
+                }
+                const uint32_t p01 = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u);
+                const uint32_t p23 = __builtin_amdgcn_perm(acc[3], acc[2], 0x0c0c0602u);
+                if (dy0 + i - 6 < h) *reinterpret_cast<uint32_t *>(dst + doff) = p01 | (p23 << 16);
+                doff += (uint32_t)dpitch;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) { ring[u][j] = prev[j] | (o[j] << 16); prev[j] = o[j]; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_blur_rows(OrbParams P)
+{
+    const int per_frame = P.br_blocks[P.nlevels];
+    const unsigned lid = xcd_logical_id(blockIdx.x, gridDim.x);
+    const int frame = (int)(lid / (unsigned)per_frame), rem = (int)(lid - (unsigned)frame * (unsigned)per_frame);     // uniform
+    int level = 0;
+    for (int l = 1; l < P.nlevels; l++) if (rem >= P.br_blocks[l]) level = l;
+    const OrbLevel &L = P.lv[level];
+    const int w = L.w, h = L.h;
+    const int nch = (w + 3) >> 2, nint = (w - 8) >> 2, nedge = nch - nint, nb = (h + BLR_R - 1) / BLR_R;
+    const int idx = (rem - P.br_blocks[level]) * 256 + (int)threadIdx.x;
+    if (idx >= nch * nb) return;
+    const uint8_t *src = L.img + (size_t)frame * L.img_frame_stride;
+    uint8_t *dst = L.blur + (size_t)frame * L.blur_frame_stride;
+    const uint32_t klo = (uint32_t)P.gauss_q8[0] | ((uint32_t)P.gauss_q8[1] << 8) | ((uint32_t)P.gauss_q8[2] << 16) | ((uint32_t)P.gauss_q8[3] << 24);
+    const uint32_t khi = (uint32_t)P.gauss_q8[4] | ((uint32_t)P.gauss_q8[5] << 8) | ((uint32_t)P.gauss_q8[6] << 16);
+    const uint32_t k0 = P.gauss_q8[0], k1 = P.gauss_q8[1], k2 = P.gauss_q8[2], k3 = P.gauss_q8[3];
+    const uint32_t k01 = k0 | (k1 << 16), k23 = k2 | (k3 << 16), k21 = k2 | (k1 << 16);
+    if (idx < nint * nb) {
+        const int band = idx / nint, c = 1 + idx - band * nint;
+        blr_band<false>(src, dst, L.img_pitch, L.blur_pitch, w, h, 4 * c, band * BLR_R, klo, khi, k01, k23, k21, k0);
+    } else {
+        const int e = idx - nint * nb, band = e / nedge, ce = e - band * nedge;
+        const int c = ce == 0 ? 0 : nint + ce;
+        blr_band<true>(src, dst, L.img_pitch, L.blur_pitch, w, h, 4 * c, band * BLR_R, klo, khi, k01, k23, k21, k0);
+    }
+}
+
 void orb_launch_blur(const OrbParams &P, hipStream_t s, int wgs_per_cu)
 {
+    if (P.br_blocks[P.nlevels] > 0) {
+        hipLaunchKernelGGL(k_blur_rows, dim3((unsigned)P.br_blocks[P.nlevels] * (unsigned)P.batch), dim3(256), 0, s, P);
+        return;
+    }
     const long total = (long)P.bs_tiles[P.nlevels] * P.batch;
     long nblocks = 256L * wgs_per_cu;                           // persistent: 8 workgroups (32 waves) per CU when alone on the chip
     if (nblocks > total) nblocks = total;

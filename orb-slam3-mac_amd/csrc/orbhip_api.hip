@@ -352,6 +352,16 @@ extern "C" int orbhip_extractor_reserve(orbhip_extractor *e, int width, int heig
     }
     P.bs_tiles[0] = 0;
     for (int l = 0; l < e->nlevels; l++) P.bs_tiles[l + 1] = P.bs_tiles[l] + ((P.lv[l].w + 63) / 64) * ((P.lv[l].h + 31) / 32);
+    {   // k_blur_rows: lanes = 4-column chunks x bands of 24 rows; needs 24 + 4 rows for its reflected row indices and one interior chunk
+        bool ok = !getenv("ORBHIP_BLUR_TILES");
+        P.br_blocks[0] = 0;
+        for (int l = 0; l < e->nlevels; l++) {
+            const int w = P.lv[l].w, h = P.lv[l].h;
+            if (h < 28 || w < 16) ok = false;
+            P.br_blocks[l + 1] = P.br_blocks[l] + (((w + 3) / 4) * ((h + 23) / 24) + 255) / 256;
+        }
+        if (!ok) P.br_blocks[e->nlevels] = 0;
+    }
     P.cell_list_frame_stride = (size_t)cells * max_cell_cap;
     int rc;
     const size_t B = (size_t)max_batch;
@@ -553,14 +563,17 @@ static int run_pipeline(orbhip_extractor *e, int batch, int lap0, int lap1)
     if (fork) {
         HIP_TRY(hipEventRecord(e->ev_fork, s));
         HIP_TRY(hipStreamWaitEvent(e->aux, e->ev_fork, 0));
-        orb_launch_blur(P, e->aux, tune_int("ORBHIP_TUNE_BLUR_WGS", 5));
-        HIP_TRY(hipEventRecord(e->ev_join, e->aux));
     }
     {
         FastParams &F = e->F;
         for (int l = 0; l < e->nlevels; l++) { F.lv[l].img = P.lv[l].img; F.lv[l].frame_stride = P.lv[l].img_frame_stride; F.lv[l].img_pitch = P.lv[l].img_pitch; }
         F.batch = batch; F.cell_count = P.cell_count; F.cell_list = P.cell_list; F.cell_list_frame_stride = P.cell_list_frame_stride; F.status = P.status;
-        orb_launch_fast_cells(F, s, fork ? tune_int("ORBHIP_TUNE_FAST_WAVES", 10) : 0);
+        const bool rows = P.br_blocks[e->nlevels] > 0;      // the row-streaming blur needs no LDS: k_fast_cells keeps its full grid
+        orb_launch_fast_cells(F, s, fork ? tune_int("ORBHIP_TUNE_FAST_WAVES", rows ? 0 : 10) : 0);
+    }
+    if (fork) {                                             // after k_fast_cells on purpose: its waves take their LDS first, the blur fills the free wave slots
+        orb_launch_blur(P, e->aux, tune_int("ORBHIP_TUNE_BLUR_WGS", 5));
+        HIP_TRY(hipEventRecord(e->ev_join, e->aux));
     }
     STAGE_MARK(ORBHIP_STAGE_BLUR);
     if (!fork) orb_launch_blur(P, s, 8);
