@@ -192,10 +192,10 @@ def parse_args(argv=None):
     ap.add_argument("--ba-steps", type=int, default=3)
     ap.add_argument("--ba-sharded-graphs", type=int, default=0, help="N > 1 only, opt-in: graphs solved cooperatively with the points sharded over the ranks and the Schur block all-gathered every LM trial (SURVEY 8e optional mode)")
     ap.add_argument("--pose-frames", type=int, default=1024, help="frames of pose-only BA solved per launch (0 = skip)")
-    ap.add_argument("--pipelines", type=int, default=2,
-                    help="throughput mode: the K steps alternate between this many independent pipelines (own context, extractor, "
-                         "HIP streams and match buffers; every step is still one full pass over one resident batch), so the latency-bound "
-                         "kernels of one step run beside the issue-bound kernels of the next; 1 = strictly serial steps")
+    ap.add_argument("--pipelines", type=int, default=1,
+                    help="1 = strictly serial steps (default).  > 1: the K steps alternate between this many independent pipelines (own "
+                         "context, extractor, HIP streams and match buffers; every step is still one full pass over one resident batch); "
+                         "paid +7 %% before the blur became an LDS-free kernel that fills k_fast_cells' idle slots, nothing since")
     ap.add_argument("--inertial-windows", type=int, default=32, help="LocalInertialBA windows solved per call (0 = skip)")
     ap.add_argument("--stereo-pairs", type=int, default=None, help="rectified stereo pairs for the ComputeStereoMatches leg (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -755,8 +755,8 @@ def main():
                                    "ORB extract + Hamming 2-NN match (Frame.cc:1146) + SearchForInitialization "
                                    "(ORBmatcher.cc:710) vs successor frame" % (args.workload, W, H, B, args.nfeatures),
                        "pipelines": len(steppers),
-                       "pipelines_note": "the K timed steps alternate between independent pipelines (own context / streams / extractor / "
-                                         "buffers, same resident input batch); stage_ms and the roofline come from the serial profiled pass",
+                       "pipelines_note": "1 = strictly serial steps; inside a step the blur runs beside k_fast_cells on a second HIP stream; "
+                                         "stage_ms and the roofline come from the separate profiled pass, one kernel at a time",
                        "frames_total": world * B, "ranks_seen": ranks_seen, "collective_backend": backend if distributed else None,
                        "records_gathered": records_gathered,
                        "keypoints_per_frame": round(n_kp_avg, 1), "fast_candidates_per_frame": round(n_cand_avg, 1),
