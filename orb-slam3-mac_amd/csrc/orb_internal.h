@@ -82,6 +82,7 @@ struct FcLevel {
 struct FastParams {
     FcLevel lv[ORB_MAX_LEVELS];
     int nlevels, batch, ini_th, min_th, cells_per_frame;
+    int lvl_lo, lvl_hi;           // this launch covers the cells of levels [lvl_lo, lvl_hi) of every frame (level 0 can start before the pyramid exists)
     uint32_t *cell_count, *cell_list; size_t cell_list_frame_stride; int32_t *status;
     // per-wave LDS geometry (from the largest cell of this extractor): pair tile [rows][PITCH] dwords, score tile [srows + 2][SPITCH]
     // dwords, queue of qcap u16; wave_dw = dwords per wave.  small_cells: every level fits the <28, 24, 9> instantiation
@@ -119,9 +120,9 @@ int orb_lds_optin(const void *func, int device, size_t need);
 
 // kernel launchers (orb_kernels.hip)
 void orb_launch_resize(const OrbParams &P, int level, hipStream_t s);
-void orb_launch_fast_cells(const FastParams &F, hipStream_t s, int max_per_cu);      // max_per_cu: 0 = as many waves as fit
+void orb_launch_fast_cells(const FastParams &F, hipStream_t s, int max_per_cu, int lvl_lo = 0, int lvl_hi = -1);      // max_per_cu: 0 = as many waves as fit
 #define ORB_OVERLAP_MIN_BATCH 16
-void orb_launch_blur(const OrbParams &P, hipStream_t s, int wgs_per_cu);
+void orb_launch_blur(const OrbParams &P, hipStream_t s, int wgs_per_cu, int frame0 = 0, int nframes = -1);   // row kernel: frames [frame0, frame0 + nframes)
 const void *orb_fast_cells_func(int small);
 void orb_launch_octree(const OrbParams &P, hipStream_t s);
 void orb_launch_orient_desc(const OrbParams &P, hipStream_t s);

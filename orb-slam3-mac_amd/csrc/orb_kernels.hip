@@ -411,16 +411,20 @@ __global__ __launch_bounds__(64) void k_fast_cells(FastParams P)
     const unsigned long long lt = (1ull << lane) - 1;
     // this wave's cells [g0, g1) of batch * cells_per_frame
     const unsigned lid = xcd_logical_id(blockIdx.x, gridDim.x);
-    const long total_cells = (long)P.batch * P.cells_per_frame;
+    // the cells of levels [lvl_lo, lvl_hi) are one contiguous range of a frame's cell array
+    const int lvl_lo = FC_SGPR(P.lvl_lo), lvl_hi = FC_SGPR(P.lvl_hi);
+    const int cell_lo = FC_SGPR(P.lv[lvl_lo].cell_base);
+    const int cps = (lvl_hi < P.nlevels ? FC_SGPR(P.lv[lvl_hi].cell_base) : FC_SGPR(P.cells_per_frame)) - cell_lo;
+    const long total_cells = (long)P.batch * cps;
     const long g0 = total_cells * lid / gridDim.x, g1 = total_cells * (lid + 1) / gridDim.x;
     if (g0 >= g1) return;
-    const int nlevels = FC_SGPR(P.nlevels), ini_th = FC_SGPR(P.ini_th), min_th = FC_SGPR(P.min_th), cpf = FC_SGPR(P.cells_per_frame);
+    const int nlevels = lvl_hi, ini_th = FC_SGPR(P.ini_th), min_th = FC_SGPR(P.min_th), cpf = FC_SGPR(P.cells_per_frame);
     FcCell C;
     {
-        C.frame = (int)(g0 / cpf);
-        const int cell = (int)(g0 - (long)C.frame * cpf);
-        C.lvl = 0;
-        for (int l = 1; l < nlevels; l++) if (cell >= P.lv[l].cell_base) C.lvl = l;
+        C.frame = (int)(g0 / cps);
+        const int cell = cell_lo + (int)(g0 - (long)C.frame * cps);
+        C.lvl = lvl_lo;
+        for (int l = lvl_lo + 1; l < nlevels; l++) if (cell >= P.lv[l].cell_base) C.lvl = l;
         const int c = cell - P.lv[C.lvl].cell_base;
         C.ci = c / P.lv[C.lvl].ncols; C.cj = c - C.ci * P.lv[C.lvl].ncols;
         fc_cell_geom(P, C);
@@ -465,7 +469,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(FastParams P)
             if (N.cj == C.ncols) { N.cj = 0; N.ci++; }
             bool relevel = false;
             if (N.ci == C.nrows) { N.ci = 0; N.lvl++; relevel = true; }
-            if (N.lvl == nlevels) { N.lvl = 0; N.frame++; }
+            if (N.lvl == nlevels) { N.lvl = lvl_lo; N.frame++; }
             if (g + 1 < g1) { fc_cell_geom(P, N); fc_issue_loads<NCH, NLD>(N, lane, ld); }
             (void)relevel;
         }
@@ -584,15 +588,18 @@ __global__ __launch_bounds__(64) void k_fast_cells(FastParams P)
 #undef FC_WAVE_SYNC
 }
 
-void orb_launch_fast_cells(const FastParams &F, hipStream_t s, int max_per_cu)
+void orb_launch_fast_cells(const FastParams &F_, hipStream_t s, int max_per_cu, int lvl_lo, int lvl_hi)
 {
+    FastParams F = F_;
+    F.lvl_lo = lvl_lo; F.lvl_hi = lvl_hi < 0 ? F.nlevels : lvl_hi;
+    if (F.lvl_lo >= F.lvl_hi) return;
     // persistent single-wave workgroups: as many as the LDS lets a CU hold, a whole number per XCD
     const size_t lds = sizeof(uint32_t) * (size_t)F.wave_dw;
     int per_cu = (int)((160 * 1024) / (lds + 512));
     per_cu = per_cu > 24 ? 24 : per_cu < 1 ? 1 : per_cu;
     if (max_per_cu > 0 && per_cu > max_per_cu) per_cu = max_per_cu;      // leave LDS and wave slots to a kernel running beside this one
     long nblocks = 256L * per_cu;
-    const long total = (long)F.batch * F.cells_per_frame;
+    const long total = (long)F.batch * ((F.lvl_hi < F.nlevels ? F.lv[F.lvl_hi].cell_base : F.cells_per_frame) - F.lv[F.lvl_lo].cell_base);
     if (nblocks > total) nblocks = (total + 7) / 8 * 8;
     if (F.small_cells) hipLaunchKernelGGL((k_fast_cells<3, 24, 2>), dim3((unsigned)nblocks), dim3(64), lds, s, F);
     else hipLaunchKernelGGL((k_fast_cells<5, 32, 5>), dim3((unsigned)nblocks), dim3(64), lds, s, F);
@@ -1150,11 +1157,12 @@ __device__ __forceinline__ void blr_band(const uint8_t *src, uint8_t *dst, int s
     }
 }
 
-__global__ __launch_bounds__(256) void k_blur_rows(OrbParams P)
+__global__ __launch_bounds__(256) void k_blur_rows(OrbParams P, int frame0)
 {
     const int per_frame = P.br_blocks[P.nlevels];
     const unsigned lid = xcd_logical_id(blockIdx.x, gridDim.x);
-    const int frame = (int)(lid / (unsigned)per_frame), rem = (int)(lid - (unsigned)frame * (unsigned)per_frame);     // uniform
+    const int fr = (int)(lid / (unsigned)per_frame), rem = (int)(lid - (unsigned)fr * (unsigned)per_frame);     // uniform
+    const int frame = frame0 + fr;
     int level = 0;
     for (int l = 1; l < P.nlevels; l++) if (rem >= P.br_blocks[l]) level = l;
     const OrbLevel &L = P.lv[level];
@@ -1178,12 +1186,14 @@ __global__ __launch_bounds__(256) void k_blur_rows(OrbParams P)
     }
 }
 
-void orb_launch_blur(const OrbParams &P, hipStream_t s, int wgs_per_cu)
+void orb_launch_blur(const OrbParams &P, hipStream_t s, int wgs_per_cu, int frame0, int nframes)
 {
     if (P.br_blocks[P.nlevels] > 0) {
-        hipLaunchKernelGGL(k_blur_rows, dim3((unsigned)P.br_blocks[P.nlevels] * (unsigned)P.batch), dim3(256), 0, s, P);
+        if (nframes < 0) nframes = P.batch - frame0;
+        if (nframes > 0) hipLaunchKernelGGL(k_blur_rows, dim3((unsigned)P.br_blocks[P.nlevels] * (unsigned)nframes), dim3(256), 0, s, P, frame0);
         return;
     }
+    if (frame0 > 0) return;                                    // the tile kernel always takes the whole batch (first call)
     const long total = (long)P.bs_tiles[P.nlevels] * P.batch;
     long nblocks = 256L * wgs_per_cu;                           // persistent: 8 workgroups (32 waves) per CU when alone on the chip
     if (nblocks > total) nblocks = total;

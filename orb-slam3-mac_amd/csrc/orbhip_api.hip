@@ -151,7 +151,7 @@ struct orbhip_extractor {
     // graph mode (small batches are launch bound): the 19 launches of one extract call replayed as one hipGraph
     bool graph_mode, graph_valid;
     // k_blur (memory-wait bound) runs beside k_fast_cells / k_octree (issue / latency bound) on a second stream of the extractor
-    hipStream_t aux; hipEvent_t ev_fork, ev_join; bool aux_ok; int overlap;
+    hipStream_t aux; hipEvent_t ev_fork, ev_join, ev_pyr; bool aux_ok; int overlap;
     hipGraphExec_t graph_exec;
     int g_w, g_h, g_batch, g_lap0, g_lap1;
     size_t level0_frame_stride; int level0_pitch;
@@ -169,7 +169,7 @@ extern "C" int orbhip_extractor_create(orbhip_ctx *ctx, int nfeatures, float sca
     e->profiling = false; e->ev_created = false; e->ev_calls = 0; e->d_level0 = nullptr; e->level0_owned = false;
     e->d_stereo_sad = nullptr;
     e->graph_mode = false; e->graph_valid = false; e->graph_exec = nullptr;
-    e->aux = nullptr; e->ev_fork = e->ev_join = nullptr; e->aux_ok = false; e->overlap = 1;
+    e->aux = nullptr; e->ev_fork = e->ev_join = e->ev_pyr = nullptr; e->aux_ok = false; e->overlap = 1;
     memset(&e->P, 0, sizeof(e->P));
     memset(e->stage_ms, 0, sizeof(e->stage_ms));
     // scale tables, ORBextractor.cc:413-429
@@ -209,7 +209,7 @@ static void ext_free_aux(orbhip_extractor *e)
 {
     if (!e->aux_ok) return;
     (void)hipStreamSynchronize(e->aux);
-    (void)hipEventDestroy(e->ev_fork); (void)hipEventDestroy(e->ev_join); (void)hipStreamDestroy(e->aux);
+    (void)hipEventDestroy(e->ev_fork); (void)hipEventDestroy(e->ev_join); (void)hipEventDestroy(e->ev_pyr); (void)hipStreamDestroy(e->aux);
     e->aux_ok = false;
 }
 
@@ -549,31 +549,47 @@ static int run_pipeline(orbhip_extractor *e, int batch, int lap0, int lap1)
     const bool prof = e->profiling;
     const int slot = e->ev_calls % ORBHIP_PROF_SLOTS;
 #define STAGE_MARK(i) do { if (prof) HIP_TRY(hipEventRecord(e->ev[slot][i], s)); } while (0)
-    STAGE_MARK(ORBHIP_STAGE_PYRAMID);
-    for (int l = 1; l < e->nlevels; l++) orb_launch_resize(P, l, s);
-    STAGE_MARK(ORBHIP_STAGE_FAST_CELLS);
-    // fork: the blur only needs the pyramid; it joins before the descriptors.  Stage profiling measures the kernels one by one.
+    // fork: two streams inside one call.  Stage profiling measures the kernels one by one on one stream.
     const bool fork = e->overlap && !prof && batch >= ORB_OVERLAP_MIN_BATCH;
     if (fork && !e->aux_ok) {
         HIP_TRY(hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_pyr, hipEventDisableTiming));
         e->aux_ok = true;
     }
-    if (fork) {
+    FastParams &F = e->F;
+    for (int l = 0; l < e->nlevels; l++) { F.lv[l].img = P.lv[l].img; F.lv[l].frame_stride = P.lv[l].img_frame_stride; F.lv[l].img_pitch = P.lv[l].img_pitch; }
+    F.batch = batch; F.cell_count = P.cell_count; F.cell_list = P.cell_list; F.cell_list_frame_stride = P.cell_list_frame_stride; F.status = P.status;
+    const bool rows = P.br_blocks[e->nlevels] > 0;          // the row-streaming blur needs no LDS: k_fast_cells keeps its full grid
+    const int fast_waves = fork ? tune_int("ORBHIP_TUNE_FAST_WAVES", rows ? 0 : 10) : 0;
+    STAGE_MARK(ORBHIP_STAGE_PYRAMID);
+    if (fork && e->nlevels > 1 && rows && tune_int("ORBHIP_TUNE_L0_EARLY", 0)) {
+        // (off by default: measured 3.90 ms vs 3.84 ms per step)
+        // Level 0 is the input itself: its FAST cells (a third of all pixels) start at once on the main stream, the pyramid is built
+        // beside them on the second stream (k_resize_rows needs a few KB of LDS, k_fast_cells leaves half of the wave slots free and
+        // ~40 % of the issue cycles idle); levels 1.. follow when the pyramid is there, the blur runs beside them.
         HIP_TRY(hipEventRecord(e->ev_fork, s));
         HIP_TRY(hipStreamWaitEvent(e->aux, e->ev_fork, 0));
-    }
-    {
-        FastParams &F = e->F;
-        for (int l = 0; l < e->nlevels; l++) { F.lv[l].img = P.lv[l].img; F.lv[l].frame_stride = P.lv[l].img_frame_stride; F.lv[l].img_pitch = P.lv[l].img_pitch; }
-        F.batch = batch; F.cell_count = P.cell_count; F.cell_list = P.cell_list; F.cell_list_frame_stride = P.cell_list_frame_stride; F.status = P.status;
-        const bool rows = P.br_blocks[e->nlevels] > 0;      // the row-streaming blur needs no LDS: k_fast_cells keeps its full grid
-        orb_launch_fast_cells(F, s, fork ? tune_int("ORBHIP_TUNE_FAST_WAVES", rows ? 0 : 10) : 0);
-    }
-    if (fork) {                                             // after k_fast_cells on purpose: its waves take their LDS first, the blur fills the free wave slots
-        orb_launch_blur(P, e->aux, tune_int("ORBHIP_TUNE_BLUR_WGS", 5));
+        orb_launch_fast_cells(F, s, fast_waves, 0, 1);
+        for (int l = 1; l < e->nlevels; l++) orb_launch_resize(P, l, e->aux);
+        HIP_TRY(hipEventRecord(e->ev_pyr, e->aux));
+        HIP_TRY(hipStreamWaitEvent(s, e->ev_pyr, 0));
+        orb_launch_fast_cells(F, s, fast_waves, 1, e->nlevels);
+        orb_launch_blur(P, e->aux, 5);
         HIP_TRY(hipEventRecord(e->ev_join, e->aux));
+    } else {
+        for (int l = 1; l < e->nlevels; l++) orb_launch_resize(P, l, s);
+        STAGE_MARK(ORBHIP_STAGE_FAST_CELLS);
+        if (fork) {                                         // the blur only needs the pyramid; it joins before the descriptors
+            HIP_TRY(hipEventRecord(e->ev_fork, s));
+            HIP_TRY(hipStreamWaitEvent(e->aux, e->ev_fork, 0));
+        }
+        orb_launch_fast_cells(F, s, fast_waves);
+        if (fork) {                                         // after k_fast_cells on purpose: its waves take their LDS first, the blur fills the free wave slots
+            orb_launch_blur(P, e->aux, tune_int("ORBHIP_TUNE_BLUR_WGS", 5));
+            HIP_TRY(hipEventRecord(e->ev_join, e->aux));
+        }
     }
     STAGE_MARK(ORBHIP_STAGE_BLUR);
     if (!fork) orb_launch_blur(P, s, 8);
