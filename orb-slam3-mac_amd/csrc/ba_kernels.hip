@@ -998,9 +998,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     double acc[36];
 #pragma unroll
     for (int k = 0; k < 36; k++) acc[k] = 0.0;
-    for (int e = ps[0] + sub; e < ps[1]; e += LPP) {
-        const int2 t = ent[e];
-        const int l = entl[e];
+    // the list entry (two block indices + point) of the NEXT trip is fetched a trip ahead: index load and block gathers are two dependent
+    // L2 round trips, this takes the first one off the chain
+    const int e_end = ps[1];
+    int en = ps[0] + sub;
+    int2 tn = make_int2(0, 0); int ln = 0;
+    if (en < e_end) { tn = ent[en]; ln = entl[en]; }
+    for (int e = en; e < e_end; e += LPP) {
+        const int2 t = tn;
+        const int l = ln;
+        if (e + LPP < e_end) { tn = ent[e + LPP]; ln = entl[e + LPP]; }
         const double *Di = B.Dinv + (size_t)(G.point_off + l) * 6;       // (Hll + lambda I)^-1, upper triangle
         const double i00 = Di[0], i01 = Di[1], i02 = Di[2], i11 = Di[3], i12 = Di[4], i22 = Di[5];
         const double *wa = B.Wsp + (size_t)t.x * 18, *wb = B.Wsp + (size_t)t.y * 18;

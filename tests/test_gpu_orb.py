@@ -359,3 +359,27 @@ def test_hd_batch_properties(gpu_ctx):
     digest2 = hashlib.sha256(b"".join(hashlib.sha256(k.tobytes() + d.tobytes()).digest() for k, d, _ in r2)).hexdigest()
     assert digest1 == digest2
     ext.close()
+
+
+@pytest.mark.parametrize("w,h", [(640, 480), (333, 277), (1241, 376)])
+def test_row_streaming_and_tile_kernels_agree(gpu_ctx, w, h, monkeypatch):
+    """The pyramid and the blur have two kernels each: the row-streaming ones (default) and the LDS-tile ones (scale factors whose
+    4-column source span exceeds 8 bytes, levels below 28 rows).  Same bytes from both, on every level, against the oracle too.
+    1241 x 376 (KITTI): width % 4 != 0, so level 1 takes the unaligned-load variant of the row kernel."""
+    import orbhip
+    imgs = orbhip.synth_frames(w, h, 2, seed=91)
+    ext, ora = _mk(gpu_ctx, 600)
+    rows = ext.extract_host(imgs, (0, 0))
+    lv_rows = [[ext.pyramid_level(f, l).copy() for l in range(ext.nlevels)] + [ext.blurred_level(f, l).copy() for l in range(ext.nlevels)] for f in range(2)]
+    _compare_frame(ext, ora, imgs, 1, (0, 0), rows)
+    ext.close()
+    monkeypatch.setenv("ORBHIP_RESIZE_TILES", "1")
+    monkeypatch.setenv("ORBHIP_BLUR_TILES", "1")
+    ext2 = orbhip.Extractor(gpu_ctx, 600, 1.2, 8, 20, 7)
+    tiles = ext2.extract_host(imgs, (0, 0))
+    for f in range(2):
+        lv = [ext2.pyramid_level(f, l) for l in range(ext2.nlevels)] + [ext2.blurred_level(f, l) for l in range(ext2.nlevels)]
+        for a, b in zip(lv_rows[f], lv):
+            np.testing.assert_array_equal(a, b)
+        assert rows[f][0].tobytes() == tiles[f][0].tobytes() and rows[f][1].tobytes() == tiles[f][1].tobytes()
+    ext2.close()
