@@ -654,12 +654,28 @@ __device__ __forceinline__ int oct_quadrant(uint32_t key, uint32_t b0, uint32_t 
     return (kx < mx ? 0 : 1) + (ky < my ? 0 : 2);          // n1=0 n2=1 n3=2 n4=3
 }
 
+#define OCT_KR 8               // candidates per thread held in registers (x 256 threads)
+#ifdef OCT_PROF
+__device__ long long g_oct_prof[8];           // debug build only (EXTRA=-DOCT_PROF): cycles of gather / roots / subdivision / best / output+perm of workgroup 0, passes
+#define OCT_T(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const long long t_ = clock64(); g_oct_prof[i] += t_ - t_prev; t_prev = t_; } } while (0)
+extern "C" int orbhip_debug_oct_prof(long long *out8, int reset)
+{
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_oct_prof), 64) != hipSuccess) return -1;
+    if (reset) { long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_oct_prof), z, 64) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define OCT_T(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(256) void k_octree(OrbParams P)
 {
     extern __shared__ uint32_t smem[];
     __shared__ int wsum[8];
     __shared__ int s_size, s_front, s_nexpand, s_rstar, s_T, s_nproc;
     const int tid = threadIdx.x;
+#ifdef OCT_PROF
+    long long t_prev = clock64();
+#endif
     const int lvl = blockIdx.x / P.batch;              // level-major: big levels first
     const int frame = blockIdx.x - lvl * P.batch;
     const OrbLevel &L = P.lv[lvl];
@@ -681,31 +697,75 @@ __global__ __launch_bounds__(256) void k_octree(OrbParams P)
     uint32_t *keys = P.keys + (size_t)frame * P.keys_per_frame + L.key_base;
     uint16_t *node_of = P.node_of + (size_t)frame * P.keys_per_frame + L.key_base;
     const int ncells = L.ncols * L.nrows;
+    uint32_t rk[OCT_KR]; int rn[OCT_KR];
     int running = 0;
-    for (int c0 = 0; c0 < ncells; c0 += 256) {
-        const int c = c0 + tid;
-        const int n = c < ncells ? (int)ccount[c] : 0;
-        int total;
-        const int off = running + block_excl_scan256(n, wsum, &total);
-        for (int i = 0; i < n; i++)
-            if (off + i < L.key_cap) keys[off + i] = clist[(size_t)c * L.cell_cap + i];
-        running += total;
+    int32_t *count_out = P.lvl_count + frame * P.nlevels + lvl;
+    if (ncells + 1 <= 16 * NC) {
+        // cell offsets -> LDS (the node arrays are not in use yet), then ONE flat pass over the candidates: candidate k finds its cell by
+        // binary search over the offsets and is fetched straight into its register slot (all loads of a thread independent and in
+        // flight together; the per-cell copy loops this replaces were chains of dependent global round trips: 37 % of the kernel)
+        int *coff = reinterpret_cast<int *>(smem);
+        for (int c0 = 0; c0 < ncells; c0 += 256) {
+            const int c = c0 + tid;
+            const int n = c < ncells ? min((int)ccount[c], L.cell_cap) : 0;
+            int total;
+            const int off = running + block_excl_scan256(n, wsum, &total);
+            if (c < ncells) coff[c] = off;
+            running += total;
+        }
+        if (tid == 0) coff[ncells] = running;
+        __syncthreads();
+        if (running > L.key_cap) { if (tid == 0) atomicExch(P.status, ORBHIP_E_CAPACITY); running = L.key_cap; }
+        const int K0 = running;
+        auto fetch = [&](int k) {
+            int lo = 0, hi = ncells;                                 // largest c with coff[c] <= k (empty cells share offsets: take the last)
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (coff[mid] <= k) lo = mid; else hi = mid; }
+            return clist[(size_t)lo * L.cell_cap + (k - coff[lo])];
+        };
+#pragma unroll
+        for (int i = 0; i < OCT_KR; i++) { const int k = tid + 256 * i; rk[i] = k < K0 ? fetch(k) : 0u; rn[i] = 0; }
+#pragma unroll
+        for (int i = 0; i < OCT_KR; i++) { const int k = tid + 256 * i; if (k < K0) keys[k] = rk[i]; }
+        for (int k = tid + 256 * OCT_KR; k < K0; k += 256) keys[k] = fetch(k);
+        __syncthreads();                                         // coff is dead: the node arrays take the LDS over
+    } else {
+        for (int c0 = 0; c0 < ncells; c0 += 256) {
+            const int c = c0 + tid;
+            const int n = c < ncells ? (int)ccount[c] : 0;
+            int total;
+            const int off = running + block_excl_scan256(n, wsum, &total);
+            for (int i = 0; i < n; i++)
+                if (off + i < L.key_cap) keys[off + i] = clist[(size_t)c * L.cell_cap + i];
+            running += total;
+        }
+        if (running > L.key_cap) { if (tid == 0) atomicExch(P.status, ORBHIP_E_CAPACITY); running = L.key_cap; }
+        __syncthreads();                                     // keys[] visible block-wide (same CU, L1 coherent within WG)
+        __threadfence_block();
+#pragma unroll
+        for (int i = 0; i < OCT_KR; i++) { const int k = tid + 256 * i; rk[i] = k < running ? keys[k] : 0u; rn[i] = 0; }
     }
-    if (running > L.key_cap) { if (tid == 0) atomicExch(P.status, ORBHIP_E_CAPACITY); running = L.key_cap; }
     const int K = running;
     if (tid == 0) P.lvl_ncand[frame * P.nlevels + lvl] = K;
-    int32_t *count_out = P.lvl_count + frame * P.nlevels + lvl;
     if (K == 0) { if (tid == 0) *count_out = 0; return; }
-    __syncthreads();                                     // keys[] visible block-wide (same CU, L1 coherent within WG)
+    // The first OCT_KR * 256 candidates (all of them unless a level holds more than 2048) live in REGISTERS from here on, key and
+    // node id; candidates beyond that keep the global arrays.
+    __syncthreads();
     __threadfence_block();
-
+    OCT_T(0);
     // ---- roots (ORBextractor.cc:541-584)
     const int n_ini = L.n_ini;
     const int H = (L.h - ORB_MINB) - ORB_MINB;
     for (int i = tid; i < NC; i += 256) { cnt[i] = 0; ncnt[i] = 0; }
     __syncthreads();
-    for (int k = tid; k < K; k += 256) {
-        const int r = (int)__fdiv_rn((float)ORB_KEY_X(keys[k]), L.hx);   // ORBextractor.cc:568
+#pragma unroll
+    for (int i = 0; i < OCT_KR; i++)
+        if (tid + 256 * i < K) {
+            const int r = (int)__fdiv_rn((float)ORB_KEY_X(rk[i]), L.hx);     // ORBextractor.cc:568
+            rn[i] = r;
+            atomicAdd(&ncnt[r], 1u);
+        }
+    for (int k = tid + 256 * OCT_KR; k < K; k += 256) {
+        const int r = (int)__fdiv_rn((float)ORB_KEY_X(keys[k]), L.hx);
         node_of[k] = (uint16_t)r;
         atomicAdd(&ncnt[r], 1u);
     }
@@ -726,9 +786,12 @@ __global__ __launch_bounds__(256) void k_octree(OrbParams P)
         s_size = m; s_front = m;
     }
     __syncthreads();
-    for (int k = tid; k < K; k += 256) node_of[k] = (uint16_t)S.newpos[node_of[k]];
+#pragma unroll
+    for (int i = 0; i < OCT_KR; i++) if (tid + 256 * i < K) rn[i] = S.newpos[rn[i]];
+    for (int k = tid + 256 * OCT_KR; k < K; k += 256) node_of[k] = (uint16_t)S.newpos[node_of[k]];
     __syncthreads();
 
+    OCT_T(1);
     // ---- subdivision loop
     bool final_phase = false;
     for (int guard = 0; guard < 64; guard++) {
@@ -778,7 +841,13 @@ __global__ __launch_bounds__(256) void k_octree(OrbParams P)
         for (int i = tid; i < 4 * size; i += 256) S.cc[i] = 0;
         if (tid == 0) { s_nexpand = 0; s_rstar = C - 1; }
         __syncthreads();
-        for (int k = tid; k < K; k += 256) {
+#pragma unroll
+        for (int i = 0; i < OCT_KR; i++)
+            if (tid + 256 * i < K) {
+                const int p = rn[i];
+                if (S.ord[p] >= 0) atomicAdd(&S.cc[4 * p + oct_quadrant(rk[i], box0[p], box1[p])], 1u);
+            }
+        for (int k = tid + 256 * OCT_KR; k < K; k += 256) {
             const int p = node_of[k];
             if (S.ord[p] >= 0) atomicAdd(&S.cc[4 * p + oct_quadrant(keys[k], box0[p], box1[p])], 1u);
         }
@@ -852,19 +921,20 @@ __global__ __launch_bounds__(256) void k_octree(OrbParams P)
         }
         __syncthreads();
         // 6. re-label keys
-        for (int k = tid; k < K; k += 256) {
-            const int p = node_of[k];
+        auto relabel = [&](uint32_t key, int p) {
             const int o = S.ord[p];
-            int np;
             if (o >= 0 && o <= rstar) {
-                const int qd = oct_quadrant(keys[k], box0[p], box1[p]);
+                const int qd = oct_quadrant(key, box0[p], box1[p]);
                 const uint32_t *q = &S.cc[4 * p];
                 int r = 0;                                         // non-empty siblings in front (q' > qd)
                 for (int j = 3; j > qd; j--) r += q[j] > 0;
-                np = S.posbase[p] + r;
-            } else np = S.newpos[p];
-            node_of[k] = (uint16_t)np;
-        }
+                return S.posbase[p] + r;
+            }
+            return S.newpos[p];
+        };
+#pragma unroll
+        for (int i = 0; i < OCT_KR; i++) if (tid + 256 * i < K) rn[i] = relabel(rk[i], rn[i]);
+        for (int k = tid + 256 * OCT_KR; k < K; k += 256) node_of[k] = (uint16_t)relabel(keys[k], node_of[k]);
         __syncthreads();
         const int new_size = T + (size - nproc);
         const int nexpand = s_nexpand;
@@ -872,18 +942,26 @@ __global__ __launch_bounds__(256) void k_octree(OrbParams P)
         if (tid == 0) { s_size = new_size; s_front = T; }
         { uint32_t *t; t = box0; box0 = nbox0; nbox0 = t; t = box1; box1 = nbox1; nbox1 = t; t = cnt; cnt = ncnt; ncnt = t; }
         __syncthreads();
+#ifdef OCT_PROF
+        if (blockIdx.x == 0 && tid == 0) g_oct_prof[5] += 1;
+#endif
         // 7. termination (ORBextractor.cc:661-735)
         if (new_size >= N || new_size == size) break;
         if (!final_phase && new_size + 3 * nexpand > N) final_phase = true;
     }
     __syncthreads();
+    OCT_T(2);
     // ---- best key per node: max response, first in list order wins (ORBextractor.cc:739-758)
     const int size = s_size;
     for (int i = tid; i < size; i += 256) S.best[i] = 0;
     __syncthreads();
-    for (int k = tid; k < K; k += 256)
+#pragma unroll
+    for (int i = 0; i < OCT_KR; i++)
+        if (tid + 256 * i < K) atomicMax(&S.best[rn[i]], ((uint32_t)ORB_KEY_S(rk[i]) << 20) | (uint32_t)(0xFFFFF - (tid + 256 * i)));
+    for (int k = tid + 256 * OCT_KR; k < K; k += 256)
         atomicMax(&S.best[node_of[k]], ((uint32_t)ORB_KEY_S(keys[k]) << 20) | (uint32_t)(0xFFFFF - k));
     __syncthreads();
+    OCT_T(3);
     uint32_t *out = P.lvl_kp + (size_t)frame * P.kps_per_frame + L.kp_base;
     int nout = size;
     if (nout > L.kp_cap) { if (tid == 0) atomicExch(P.status, ORBHIP_E_CAPACITY); nout = L.kp_cap; }
@@ -901,6 +979,7 @@ __global__ __launch_bounds__(256) void k_octree(OrbParams P)
         perm[rank] = (uint16_t)i;
     }
     if (tid == 0) *count_out = nout;
+    OCT_T(4);
 }
 
 const void *orb_octree_func() { return reinterpret_cast<const void *>(k_octree); }
