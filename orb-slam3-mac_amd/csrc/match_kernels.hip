@@ -248,6 +248,104 @@ extern "C" int orbhip_match_bf2nn_device(orbhip_ctx *ctx, const uint8_t *d_descA
 // GetFeaturesInArea's list exactly.  The F1 loop stays sequential (vMatchedDistance, ORBmatcher.cc:749);
 // per F1 point the lanes first collect candidates (LDS only), then evaluate one candidate per lane
 // so all descriptor loads are in flight together.
+// Register-resident sequential loop of SearchForInitialization (ORBmatcher.cc:726-790) for octave-0 subsets of at most 64 * NS points
+// (level 0 holds ~0.22 x nFeatures keypoints: NS = 4 covers 1000 features, NS = 8 covers 2000).  Every lane keeps up to NS F2
+// points -- position, grid cell + rank, descriptor, vMatchedDistance, vnMatches21 -- and NS F1 points in registers; F1 point t is
+// broadcast from its lane with v_readlane, tests the window predicate on the F2 points directly and takes the Hamming distance:
+// no candidate list, no LDS or global access and no barrier inside the chain (the general loop was 60 % candidate scan over
+// LDS + 22 % descriptor fetches).  Same keys, same (best, second best), same update rules as the general loop.
+template <int NS>
+__device__ __forceinline__ int si_register_loop(int lane, int n0, int na0, const float *kx, const float *ky, const uint16_t *cellx, const uint16_t *celly,
+                                                const uint16_t *cpos, const uint16_t *gidx, const uint16_t *aidx, uint16_t *bm,
+                                                const uint4 *dA, const uint4 *dB, const float *prev, int32_t *m12,
+                                                float min_x, float min_y, float inv_w, float inv_h, float r, float nn_ratio)
+{
+    int nmatches = 0;
+    float fkx[NS], fky[NS]; uint32_t fpk[NS]; int fgi[NS], fmd[NS], fm21[NS]; uint4 fd0[NS], fd1[NS];
+#pragma unroll
+    for (int sl = 0; sl < NS; sl++) {
+        const int li = sl * 64 + lane;
+        const bool v = li < n0;
+        const int lj = v ? li : 0;
+        fkx[sl] = kx[lj]; fky[sl] = ky[lj];
+        fpk[sl] = v ? ((uint32_t)cellx[lj] | ((uint32_t)celly[lj] << 8) | ((uint32_t)min((int)cpos[lj], SI_RANKS - 1) << 16)) : 0xFFFFu;   // cell (255, 255): never inside a window
+        fgi[sl] = gidx[lj]; fmd[sl] = INT_MAX; fm21[sl] = -1;
+        fd0[sl] = dB[2 * fgi[sl]]; fd1[sl] = dB[2 * fgi[sl] + 1];
+    }
+    // the F1 points too: lane l holds points l, l + 64, ... (index, window centre, descriptor); the loop broadcasts point t
+    // from its lane with v_readlane, so the sequential chain makes no memory access at all
+    int qi[NS]; float qx[NS], qy[NS]; uint4 qd0[NS], qd1[NS];
+#pragma unroll
+    for (int sl = 0; sl < NS; sl++) {
+        const int tq = sl * 64 + lane;
+        qi[sl] = tq < na0 ? (int)aidx[tq] : 0;
+        qx[sl] = prev[2 * qi[sl]]; qy[sl] = prev[2 * qi[sl] + 1];
+        qd0[sl] = dA[2 * qi[sl]]; qd1[sl] = dA[2 * qi[sl] + 1];
+    }
+    for (int t = 0; t < na0; t++) {
+        const int tsl = t >> 6, tln = t & 63;
+        int i1 = 0; float x = 0, y = 0; uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
+#define SI_RL(v) (uint32_t)__builtin_amdgcn_readlane((int)(v), tln)
+#pragma unroll
+        for (int sl = 0; sl < NS; sl++)
+            if (tsl == sl) {                                            // uniform
+                i1 = (int)SI_RL(qi[sl]); x = __uint_as_float(SI_RL(__float_as_uint(qx[sl]))); y = __uint_as_float(SI_RL(__float_as_uint(qy[sl])));
+                a0 = make_uint4(SI_RL(qd0[sl].x), SI_RL(qd0[sl].y), SI_RL(qd0[sl].z), SI_RL(qd0[sl].w));
+                a1 = make_uint4(SI_RL(qd1[sl].x), SI_RL(qd1[sl].y), SI_RL(qd1[sl].z), SI_RL(qd1[sl].w));
+            }
+#undef SI_RL
+        int c0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, min_x), r), inv_w)); if (c0 < 0) c0 = 0;   // Frame.cc:656-674
+        if (c0 >= SI_COLS) continue;
+        int c1 = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, min_x), r), inv_w)); if (c1 > SI_COLS - 1) c1 = SI_COLS - 1;
+        if (c1 < 0) continue;
+        int r0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, min_y), r), inv_h)); if (r0 < 0) r0 = 0;
+        if (r0 >= SI_ROWS) continue;
+        int r1 = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, min_y), r), inv_h)); if (r1 > SI_ROWS - 1) r1 = SI_ROWS - 1;
+        if (r1 < 0) continue;
+        const int ncy = r1 - r0 + 1;
+        // branch-free per slot: window predicate, distance, key (0xFFFFFFFF where the point is no candidate or already matched at
+        // a distance <= this one, ORBmatcher.cc:749); per lane the smallest key and the distance of the runner-up
+        uint32_t lk1 = 0xFFFFFFFFu, ld2 = 0xFFFFFFFFu; int best_sl = 0;
+        const uint32_t cw = (uint32_t)(c1 - c0), rh = (uint32_t)(r1 - r0);
+#pragma unroll
+        for (int sl = 0; sl < NS; sl++) {
+            if (sl * 64 >= n0) break;                                   // uniform
+            const uint32_t dcx = (fpk[sl] & 255u) - (uint32_t)c0, dcy = ((fpk[sl] >> 8) & 255u) - (uint32_t)r0;
+            const int dist = hamming256(a0, a1, fd0[sl], fd1[sl]);
+            const bool c = dcx <= cw && dcy <= rh && fabsf(__fsub_rn(fkx[sl], x)) < r && fabsf(__fsub_rn(fky[sl], y)) < r && !(fmd[sl] <= dist);
+            const uint32_t key = c ? ((uint32_t)dist << 23) | ((dcx * (uint32_t)ncy + dcy) * SI_RANKS + (fpk[sl] >> 16)) : 0xFFFFFFFFu;
+            ld2 = min(ld2, max(lk1, key));                              // the larger of (best so far, new) is a runner-up
+            best_sl = key < lk1 ? sl : best_sl;
+            lk1 = min(lk1, key);
+        }
+        const uint32_t k1 = wave_min_u32_dpp(lk1);
+        // second best over the wave: every lane's runner-up, and the best of every lane that is not the winner (keys are unique)
+        const uint32_t k2 = wave_min_u32_dpp(lk1 == k1 ? ld2 : lk1);
+        const int d2 = k2 == 0xFFFFFFFFu ? INT_MAX : (int)(k2 >> 23);
+        if (k1 == 0xFFFFFFFFu) continue;                                // no candidate, or none below its vMatchedDistance
+        const int best = (int)(k1 >> 23);
+        if (!(best <= SI_TH_LOW && (float)best < __fmul_rn((float)d2, nn_ratio))) continue;   // ORBmatcher.cc:764-766
+        const unsigned long long owner = __ballot(lk1 == k1);          // keys are unique: exactly one lane
+        const int ol = __builtin_amdgcn_readfirstlane(__ffsll((long long)owner) - 1);
+        const int bsl = __builtin_amdgcn_readlane(best_sl, ol);
+        int old = -1, best_idx = 0;
+#pragma unroll
+        for (int sl = 0; sl < NS; sl++)
+            if (bsl == sl) {                                            // uniform
+                old = __builtin_amdgcn_readlane(fm21[sl], ol); best_idx = __builtin_amdgcn_readlane(fgi[sl], ol);
+                if (lane == ol) { fm21[sl] = i1; fmd[sl] = best; }
+            }
+        if (old >= 0) nmatches--;                                       // ORBmatcher.cc:768-772
+        nmatches++;
+        if (lane == 0) {
+            if (old >= 0) m12[old] = -1;
+            m12[i1] = best_idx;
+            bm[i1] = (uint16_t)best_idx;                                // its rotation-histogram entry is made after the loop
+        }
+    }
+    return nmatches;
+}
+
 #ifdef SI_PROF
 __device__ long long g_si_prof[8];            // debug build only (EXTRA=-DSI_PROF): cycles of setup / candidate scan / distances + reduction / update / tail, iterations
 #define SI_T(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const long long t_ = clock64(); g_si_prof[i] += t_ - t_prev; t_prev = t_; } } while (0)
@@ -338,97 +436,11 @@ __global__ __launch_bounds__(64) void k_search_init(const orbhip_keypoint *kpA_,
     int nmatches = 0;
     const float r = (float)window;
     const float factor = 1.0f / SI_HISTO;
-    if (n0 <= 4 * 64 && na0 <= 4 * 64) {
-        // Register-resident form (the common case: level 0 holds ~0.22 x nFeatures keypoints).  Every lane keeps up to four F2
-        // points -- position, grid cell + rank, descriptor, vMatchedDistance, vnMatches21 -- in registers; an F1 point tests the
-        // window predicate on them directly and takes the Hamming distance where it holds: no candidate list, no LDS or
-        // global access and no barrier inside the sequential loop (it was 60 % candidate scan over LDS + 22 % descriptor
-        // fetches).  Same keys, same (best, second best) reduction, same update rules as the general loop below.
-        float fkx[4], fky[4]; uint32_t fpk[4]; int fgi[4], fmd[4], fm21[4]; uint4 fd0[4], fd1[4];
-#pragma unroll
-        for (int sl = 0; sl < 4; sl++) {
-            const int li = sl * 64 + lane;
-            const bool v = li < n0;
-            const int lj = v ? li : 0;
-            fkx[sl] = kx[lj]; fky[sl] = ky[lj];
-            fpk[sl] = v ? ((uint32_t)cellx[lj] | ((uint32_t)celly[lj] << 8) | ((uint32_t)min((int)cpos[lj], SI_RANKS - 1) << 16)) : 0xFFFFu;   // cell (255, 255): never inside a window
-            fgi[sl] = gidx[lj]; fmd[sl] = INT_MAX; fm21[sl] = -1;
-            fd0[sl] = dB[2 * fgi[sl]]; fd1[sl] = dB[2 * fgi[sl] + 1];
-        }
-        // the F1 points too: lane l holds points l, l + 64, ... (index, window centre, descriptor); the loop broadcasts point t
-        // from its lane with v_readlane, so the sequential chain makes no memory access at all
-        int qi[4]; float qx[4], qy[4]; uint4 qd0[4], qd1[4];
-#pragma unroll
-        for (int sl = 0; sl < 4; sl++) {
-            const int tq = sl * 64 + lane;
-            qi[sl] = tq < na0 ? (int)aidx[tq] : 0;
-            qx[sl] = prev[2 * qi[sl]]; qy[sl] = prev[2 * qi[sl] + 1];
-            qd0[sl] = dA[2 * qi[sl]]; qd1[sl] = dA[2 * qi[sl] + 1];
-        }
-        for (int t = 0; t < na0; t++) {
-            const int tsl = t >> 6, tln = t & 63;
-            int i1 = 0; float x = 0, y = 0; uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
-#define SI_RL(v) (uint32_t)__builtin_amdgcn_readlane((int)(v), tln)
-#pragma unroll
-            for (int sl = 0; sl < 4; sl++)
-                if (tsl == sl) {                                            // uniform
-                    i1 = (int)SI_RL(qi[sl]); x = __uint_as_float(SI_RL(__float_as_uint(qx[sl]))); y = __uint_as_float(SI_RL(__float_as_uint(qy[sl])));
-                    a0 = make_uint4(SI_RL(qd0[sl].x), SI_RL(qd0[sl].y), SI_RL(qd0[sl].z), SI_RL(qd0[sl].w));
-                    a1 = make_uint4(SI_RL(qd1[sl].x), SI_RL(qd1[sl].y), SI_RL(qd1[sl].z), SI_RL(qd1[sl].w));
-                }
-#undef SI_RL
-            int c0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, min_x), r), inv_w)); if (c0 < 0) c0 = 0;   // Frame.cc:656-674
-            if (c0 >= SI_COLS) continue;
-            int c1 = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, min_x), r), inv_w)); if (c1 > SI_COLS - 1) c1 = SI_COLS - 1;
-            if (c1 < 0) continue;
-            int r0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, min_y), r), inv_h)); if (r0 < 0) r0 = 0;
-            if (r0 >= SI_ROWS) continue;
-            int r1 = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, min_y), r), inv_h)); if (r1 > SI_ROWS - 1) r1 = SI_ROWS - 1;
-            if (r1 < 0) continue;
-            const int ncy = r1 - r0 + 1;
-            // branch-free per slot: window predicate, distance, key (0xFFFFFFFF where the point is no candidate or already matched at
-            // a distance <= this one, ORBmatcher.cc:749); per lane the smallest key and the distance of the runner-up
-            uint32_t lk1 = 0xFFFFFFFFu, ld2 = 0xFFFFFFFFu; int best_sl = 0;
-            const uint32_t cw = (uint32_t)(c1 - c0), rh = (uint32_t)(r1 - r0);
-#pragma unroll
-            for (int sl = 0; sl < 4; sl++) {
-                if (sl * 64 >= n0) break;                                   // uniform
-                const uint32_t dcx = (fpk[sl] & 255u) - (uint32_t)c0, dcy = ((fpk[sl] >> 8) & 255u) - (uint32_t)r0;
-                const int dist = hamming256(a0, a1, fd0[sl], fd1[sl]);
-                const bool c = dcx <= cw && dcy <= rh && fabsf(__fsub_rn(fkx[sl], x)) < r && fabsf(__fsub_rn(fky[sl], y)) < r && !(fmd[sl] <= dist);
-                const uint32_t key = c ? ((uint32_t)dist << 23) | ((dcx * (uint32_t)ncy + dcy) * SI_RANKS + (fpk[sl] >> 16)) : 0xFFFFFFFFu;
-                ld2 = min(ld2, max(lk1, key));                              // the larger of (best so far, new) is a runner-up
-                best_sl = key < lk1 ? sl : best_sl;
-                lk1 = min(lk1, key);
-            }
-            const uint32_t k1 = wave_min_u32_dpp(lk1);
-            // second best over the wave: every lane's runner-up, and the best of every lane that is not the winner (keys are unique)
-            const uint32_t k2 = wave_min_u32_dpp(lk1 == k1 ? ld2 : lk1);
-            const int d2 = k2 == 0xFFFFFFFFu ? INT_MAX : (int)(k2 >> 23);
-            SI_T(2);
-            if (k1 == 0xFFFFFFFFu) continue;                                // no candidate, or none below its vMatchedDistance
-            const int best = (int)(k1 >> 23);
-            if (!(best <= SI_TH_LOW && (float)best < __fmul_rn((float)d2, nn_ratio))) continue;   // ORBmatcher.cc:764-766
-            const unsigned long long owner = __ballot(lk1 == k1);          // keys are unique: exactly one lane
-            const int ol = __builtin_amdgcn_readfirstlane(__ffsll((long long)owner) - 1);
-            const int bsl = __builtin_amdgcn_readlane(best_sl, ol);
-            int old = -1, best_idx = 0;
-#pragma unroll
-            for (int sl = 0; sl < 4; sl++)
-                if (bsl == sl) {                                            // uniform
-                    old = __builtin_amdgcn_readlane(fm21[sl], ol); best_idx = __builtin_amdgcn_readlane(fgi[sl], ol);
-                    if (lane == ol) { fm21[sl] = i1; fmd[sl] = best; }
-                }
-            if (old >= 0) nmatches--;                                       // ORBmatcher.cc:768-772
-            nmatches++;
-            if (lane == 0) {
-                if (old >= 0) m12[old] = -1;
-                m12[i1] = best_idx;
-                bm[i1] = (uint16_t)best_idx;                                // its rotation-histogram entry is made after the loop
-            }
-            SI_T(3);
-        }
-    } else {
+    if (n0 <= 4 * 64 && na0 <= 4 * 64)
+        nmatches = si_register_loop<4>(lane, n0, na0, kx, ky, cellx, celly, cpos, gidx, aidx, bm, dA, dB, prev, m12, min_x, min_y, inv_w, inv_h, r, nn_ratio);
+    else if (n0 <= 8 * 64 && na0 <= 8 * 64)
+        nmatches = si_register_loop<8>(lane, n0, na0, kx, ky, cellx, celly, cpos, gidx, aidx, bm, dA, dB, prev, m12, min_x, min_y, inv_w, inv_h, r, nn_ratio);
+    else {
     // the next F1 point's window centre and descriptor are fetched one iteration ahead
     int i1n = na0 > 0 ? (int)aidx[0] : 0;
     float xn = 0, yn = 0; uint4 pd0 = make_uint4(0, 0, 0, 0), pd1 = pd0;

@@ -285,6 +285,29 @@ def test_search_for_initialization_5x_features(gpu_ctx):
     ext.close()
 
 
+def test_search_for_initialization_2000_features(gpu_ctx):
+    """BASELINE config #3's extractor (2000 features at 1080p): ~434 keypoints at octave 0, the eight-slot register-resident loop
+    (the 1000-feature tests take the four-slot one, the 5000-feature test the general LDS loop)."""
+    import orbhip
+    import oracle_match_bind as om
+    ext = orbhip.Extractor(gpu_ctx, 2000, 1.2, 8, 20, 7)
+    imgs = orbhip.synth_frames(1920, 1080, 3, seed=15)
+    res = ext.extract_host(imgs, lap=(0, 0))
+    n_oct0 = int((res[0][0]["octave"] == 0).sum())
+    assert 256 < n_oct0 <= 512, n_oct0
+    fa = [(res[i][0], res[i][1]) for i in (0, 1, 2)]
+    fb = [(res[i][0], res[i][1]) for i in (1, 2, 2)]
+    bounds = (0.0, 0.0, 1920.0, 1080.0)
+    prevs = [np.stack([f[0]["x"], f[0]["y"]], 1) for f in fa]
+    got = _search_init(gpu_ctx, fa, fb, bounds, prevs, ext.max_keypoints, 100, 0.9, True)
+    for p in range(3):
+        n, m12, prev = om.search_for_initialization(fa[p][0], fa[p][1], fb[p][0], fb[p][1], bounds, prevs[p], 100, 0.9, True)
+        assert got[p][0] == n and n > 20, (p, got[p][0], n)
+        np.testing.assert_array_equal(got[p][1], m12)
+        assert got[p][2].tobytes() == prev.tobytes()
+    ext.close()
+
+
 @pytest.mark.parametrize("stereo,ratio", [(False, 0.8), (True, 0.8), (False, 0.6)])
 def test_search_local_map_parity(gpu_ctx, stereo, ratio):
     """TrackLocalMap matcher (ORBmatcher.cc:48-218): best / second best with the same-octave ratio rule, claim rule."""
