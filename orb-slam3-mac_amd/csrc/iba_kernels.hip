@@ -27,6 +27,8 @@
 #include <cstring>
 #include <map>
 #include <vector>
+#include <thread>
+#include <functional>
 
 hipStream_t orbhip_ctx_stream_internal(orbhip_ctx *c);
 int orbhip_ctx_device_internal(orbhip_ctx *c);
@@ -949,36 +951,49 @@ struct Blob {                        // host image of the constant device data; 
         if (!v.empty()) memcpy(bytes.data() + off, v.data(), sizeof(T) * v.size());
         return off;
     }
+    size_t alloc(size_t nbytes)
+    {
+        size_t off = (bytes.size() + 255) & ~(size_t)255;
+        bytes.resize(off + std::max<size_t>(nbytes, 1));
+        return off;
+    }
 };
 inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 #define ITRY(e) do { if ((e) != hipSuccess) { orbhip_set_last_error_internal(#e); return ORBHIP_E_HIP; } } while (0)
-}  // namespace
-
-extern "C" int orbhip_inertial_ba_solve_batch(orbhip_ctx *ctx, const orbhip_iba_window *wins, int n_windows, const orbhip_iba_params *params,
-                                              double *const *kf_state_inout, double *const *points_inout, uint8_t *const *edge_outlier_out,
-                                              orbhip_iba_stats *stats_out)
-{
-    if (!ctx || n_windows < 0 || (n_windows && (!wins || !kf_state_inout || !points_inout)) || !params) return ORBHIP_E_BADARG;
-    if (n_windows == 0) return ORBHIP_OK;
-    if (params->iterations < 0 || params->max_trials < 1 || !(params->lambda_init > 0)) return ORBHIP_E_BADARG;
-    const auto t_host0 = std::chrono::steady_clock::now();
-    std::vector<IbaWin> hw(n_windows);
+// Host-side packing of windows [w0, w1) into one IbaPack: SoA arrays, per-keyframe edge lists, per-pair block lists, task lists, edge colours.
+// Every offset stored in hw[w] is relative to THIS pack; orbhip_inertial_ba_solve_batch packs chunks of windows on several host threads
+// (packing was 2.5x the device time of a batch) and rebases them when it lays the chunks out in the upload blob.
+struct IbaPack {
     std::vector<int> kf_xoff, free_kf, edge_kf, edge_point, pt_start, kf_edges, in1, in2, in_color, kf_task_start, pair_task_start;
     std::vector<int2> pair_ent;
     std::vector<int4> kf_task, pair_task;
     std::vector<uint8_t> kf_imu, edge_stereo, edge_close, in_robust;
     std::vector<double> edge_obs, edge_is2, in_pre, in_info, in_info_g, in_info_a, kfs, pts;
     size_t sumKF = 0, sumL = 0, sumE = 0, sumM = 0, sumX = 0, sumH = 0;
-    int max_n = 0;
+    int max_n = 0, rc = ORBHIP_OK;
+    const char *err = nullptr;
     std::vector<int> tmp_pstart, tmp_kcount, tmp_kpos, tmp_pcount, tmp_ppos;
     std::vector<std::pair<int, int>> tmp_fe;
+};
+static int iba_pack_range(const orbhip_iba_window *wins, int w0, int w1, double *const *kf_state_inout, double *const *points_inout, IbaWin *hw, IbaPack &P)
+{
+    auto &kf_xoff = P.kf_xoff; auto &free_kf = P.free_kf; auto &edge_kf = P.edge_kf; auto &edge_point = P.edge_point; auto &pt_start = P.pt_start;
+    auto &kf_edges = P.kf_edges; auto &in1 = P.in1; auto &in2 = P.in2; auto &in_color = P.in_color; auto &kf_task_start = P.kf_task_start;
+    auto &pair_task_start = P.pair_task_start; auto &pair_ent = P.pair_ent; auto &kf_task = P.kf_task; auto &pair_task = P.pair_task;
+    auto &kf_imu = P.kf_imu; auto &edge_stereo = P.edge_stereo; auto &edge_close = P.edge_close; auto &in_robust = P.in_robust;
+    auto &edge_obs = P.edge_obs; auto &edge_is2 = P.edge_is2; auto &in_pre = P.in_pre; auto &in_info = P.in_info; auto &in_info_g = P.in_info_g;
+    auto &in_info_a = P.in_info_a; auto &kfs = P.kfs; auto &pts = P.pts;
+    auto &tmp_pstart = P.tmp_pstart; auto &tmp_kcount = P.tmp_kcount; auto &tmp_kpos = P.tmp_kpos; auto &tmp_pcount = P.tmp_pcount; auto &tmp_ppos = P.tmp_ppos;
+    auto &tmp_fe = P.tmp_fe;
+    size_t &sumKF = P.sumKF, &sumL = P.sumL, &sumE = P.sumE, &sumM = P.sumM, &sumX = P.sumX, &sumH = P.sumH;
+    int &max_n = P.max_n;
     {
         size_t te = 0, tl = 0, tk = 0;
-        for (int w = 0; w < n_windows; w++) { te += (size_t)std::max(wins[w].n_edges, 0); tl += (size_t)std::max(wins[w].n_points, 0); tk += (size_t)std::max(wins[w].n_kf, 0); }
+        for (int w = w0; w < w1; w++) { te += (size_t)std::max(wins[w].n_edges, 0); tl += (size_t)std::max(wins[w].n_points, 0); tk += (size_t)std::max(wins[w].n_kf, 0); }
         edge_kf.reserve(te); edge_point.reserve(te); edge_obs.reserve(3 * te); edge_is2.reserve(te); edge_stereo.reserve(te); edge_close.reserve(te);
-        kf_edges.reserve(te); pair_ent.reserve(3 * te); pt_start.reserve(tl + n_windows); pts.reserve(3 * tl); kfs.reserve(IBA_KF * tk);
+        kf_edges.reserve(te); pair_ent.reserve(3 * te); pt_start.reserve(tl + (size_t)(w1 - w0)); pts.reserve(3 * tl); kfs.reserve(IBA_KF * tk);
     }
-    for (int w = 0; w < n_windows; w++) {
+    for (int w = w0; w < w1; w++) {
         const orbhip_iba_window &g = wins[w];
         if (g.n_kf <= 0 || g.n_points < 0 || g.n_edges < 0 || g.n_inertial < 0 || !g.kf_fixed || !g.kf_imu || !kf_state_inout[w] ||
             (g.n_points && !points_inout[w]) ||
@@ -1013,7 +1028,7 @@ extern "C" int orbhip_inertial_ba_solve_batch(orbhip_ctx *ctx, const orbhip_iba_
             n += g.kf_imu[k] ? 15 : 6;
         }
         W.n = n;
-        if (n > BA_LDLT_MAXN || g.n_inertial > IBA_THREADS) { orbhip_set_last_error_internal("inertial BA: more than 480 keyframe unknowns (32 inertial keyframes)"); return ORBHIP_E_CAPACITY; }
+        if (n > BA_LDLT_MAXN || g.n_inertial > IBA_THREADS) { P.err = "inertial BA: more than 480 keyframe unknowns (32 inertial keyframes)"; return ORBHIP_E_CAPACITY; }
         max_n = std::max(max_n, n);
         // edges: grouped by point (the reference creates them point by point, Optimizer.cc:4914-5034)
         std::vector<int> &pstart = tmp_pstart; pstart.assign(g.n_points + 1, 0);
@@ -1113,13 +1128,92 @@ extern "C" int orbhip_inertial_ba_solve_batch(orbhip_ctx *ctx, const orbhip_iba_
         if (g.n_points) pts.insert(pts.end(), points_inout[w], points_inout[w] + 3 * (size_t)g.n_points);
         sumKF += g.n_kf; sumL += g.n_points; sumE += g.n_edges; sumM += g.n_inertial; sumX += n; sumH += (size_t)n * n;
     }
+    return ORBHIP_OK;
+}
+}  // namespace
+
+extern "C" int orbhip_inertial_ba_solve_batch(orbhip_ctx *ctx, const orbhip_iba_window *wins, int n_windows, const orbhip_iba_params *params,
+                                              double *const *kf_state_inout, double *const *points_inout, uint8_t *const *edge_outlier_out,
+                                              orbhip_iba_stats *stats_out)
+{
+    if (!ctx || n_windows < 0 || (n_windows && (!wins || !kf_state_inout || !points_inout)) || !params) return ORBHIP_E_BADARG;
+    if (n_windows == 0) return ORBHIP_OK;
+    if (params->iterations < 0 || params->max_trials < 1 || !(params->lambda_init > 0)) return ORBHIP_E_BADARG;
+    const auto t_host0 = std::chrono::steady_clock::now();
+    std::vector<IbaWin> hw(n_windows);
+    // ---- packing: chunks of windows on host threads (windows are independent), then one layout pass
+    int nthr = (int)std::thread::hardware_concurrency();
+    if (const char *ev = getenv("ORBHIP_IBA_HOST_THREADS")) nthr = atoi(ev);
+    nthr = std::max(1, std::min(std::min(nthr, 16), n_windows / 2));
+    std::vector<IbaPack> packs(nthr);
+    auto chunk_lo = [&](int c) { return (int)((long long)n_windows * c / nthr); };
+    {
+        std::vector<std::thread> th;
+        for (int c = 1; c < nthr; c++)
+            th.emplace_back([&, c] { packs[c].rc = iba_pack_range(wins, chunk_lo(c), chunk_lo(c + 1), kf_state_inout, points_inout, hw.data(), packs[c]); });
+        packs[0].rc = iba_pack_range(wins, chunk_lo(0), chunk_lo(1), kf_state_inout, points_inout, hw.data(), packs[0]);
+        for (auto &t : th) t.join();
+    }
+    for (int c = 0; c < nthr; c++)
+        if (packs[c].rc != ORBHIP_OK) { if (packs[c].err) orbhip_set_last_error_internal(packs[c].err); return packs[c].rc; }
+    // rebase every window's offsets by what the chunks in front of it hold
+    size_t sumKF = 0, sumL = 0, sumE = 0, sumM = 0, sumX = 0, sumH = 0, n_kftask = 0, n_pairtask = 0;
+    int max_n = 0;
+    struct Base { size_t kf, l, e, m, x, h, fr, pst, kfe, pent, ktask, ktstart, ptask, ptstart2; };
+    std::vector<Base> base(nthr);
+    {
+        Base b = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int c = 0; c < nthr; c++) {
+            const IbaPack &P = packs[c];
+            base[c] = b;
+            for (int w = chunk_lo(c); w < chunk_lo(c + 1); w++) {
+                IbaWin &W = hw[w];
+                W.kf_off += (int)b.kf; W.pt_off += (int)b.l; W.e_off += (int)b.e; W.m_off += (int)b.m; W.x_off += (int)b.x; W.h_off += (long long)b.h;
+                W.free_off += (int)b.fr; W.ptstart_off += (int)b.pst; W.kfe_off += (int)b.kfe; W.pent_off += (long long)b.pent;
+                W.ktask_off += (int)b.ktask; W.ktstart_off += (int)b.ktstart; W.ptask_off += (int)b.ptask; W.ptstart2_off += (int)b.ptstart2;
+            }
+            b.kf += P.sumKF; b.l += P.sumL; b.e += P.sumE; b.m += P.sumM; b.x += P.sumX; b.h += P.sumH; b.fr += P.free_kf.size(); b.pst += P.pt_start.size();
+            b.kfe += P.kf_edges.size(); b.pent += P.pair_ent.size(); b.ktask += P.kf_task.size(); b.ktstart += P.kf_task_start.size();
+            b.ptask += P.pair_task.size(); b.ptstart2 += P.pair_task_start.size();
+            max_n = std::max(max_n, P.max_n);
+        }
+        sumKF = b.kf; sumL = b.l; sumE = b.e; sumM = b.m; sumX = b.x; sumH = b.h; n_kftask = b.ktask; n_pairtask = b.ptask;
+    }
+    // the upload blob: every array is the concatenation of the chunks' pieces; the pieces are copied in place by the same threads
     Blob B;
-    const size_t o_win = B.put(hw), o_xoff = B.put(kf_xoff), o_imu = B.put(kf_imu), o_free = B.put(free_kf), o_ekf = B.put(edge_kf),
-                 o_ept = B.put(edge_point), o_obs = B.put(edge_obs), o_is2 = B.put(edge_is2), o_est = B.put(edge_stereo), o_ecl = B.put(edge_close),
-                 o_pst = B.put(pt_start), o_ked = B.put(kf_edges), o_pre = B.put(pair_ent), o_ktk = B.put(kf_task), o_kts = B.put(kf_task_start),
-                 o_ptk = B.put(pair_task), o_pts = B.put(pair_task_start),
-                 o_in1 = B.put(in1), o_in2 = B.put(in2), o_col = B.put(in_color), o_rob = B.put(in_robust), o_ipr = B.put(in_pre),
-                 o_inf = B.put(in_info), o_ig = B.put(in_info_g), o_ia = B.put(in_info_a);
+    std::vector<std::function<void(int)>> copies;
+    auto lay = [&](auto member, size_t elem_bytes) {
+        size_t total = 0;
+        std::vector<size_t> offs(nthr);
+        for (int c = 0; c < nthr; c++) { offs[c] = total; total += (packs[c].*member).size(); }
+        const size_t o = B.alloc(elem_bytes * std::max<size_t>(total, 1));
+        copies.push_back([&, member, offs, o, elem_bytes](int c) {
+            const auto &v = packs[c].*member;
+            if (!v.empty()) memcpy(B.bytes.data() + o + elem_bytes * offs[c], v.data(), elem_bytes * v.size());
+        });
+        return o;
+    };
+    const size_t o_win = B.alloc(sizeof(IbaWin) * (size_t)n_windows);
+    const size_t o_xoff = lay(&IbaPack::kf_xoff, 4), o_imu = lay(&IbaPack::kf_imu, 1), o_free = lay(&IbaPack::free_kf, 4), o_ekf = lay(&IbaPack::edge_kf, 4),
+                 o_ept = lay(&IbaPack::edge_point, 4), o_obs = lay(&IbaPack::edge_obs, 8), o_is2 = lay(&IbaPack::edge_is2, 8), o_est = lay(&IbaPack::edge_stereo, 1),
+                 o_ecl = lay(&IbaPack::edge_close, 1), o_pst = lay(&IbaPack::pt_start, 4), o_ked = lay(&IbaPack::kf_edges, 4), o_pre = lay(&IbaPack::pair_ent, 8),
+                 o_ktk = lay(&IbaPack::kf_task, 16), o_kts = lay(&IbaPack::kf_task_start, 4), o_ptk = lay(&IbaPack::pair_task, 16),
+                 o_pts = lay(&IbaPack::pair_task_start, 4), o_in1 = lay(&IbaPack::in1, 4), o_in2 = lay(&IbaPack::in2, 4), o_col = lay(&IbaPack::in_color, 4),
+                 o_rob = lay(&IbaPack::in_robust, 1), o_ipr = lay(&IbaPack::in_pre, 8), o_inf = lay(&IbaPack::in_info, 8), o_ig = lay(&IbaPack::in_info_g, 8),
+                 o_ia = lay(&IbaPack::in_info_a, 8);
+    std::vector<double> kfs((size_t)IBA_KF * sumKF), pts(3 * sumL);
+    {
+        auto copy_chunk = [&](int c) {
+            for (auto &f : copies) f(c);
+            if (!packs[c].kfs.empty()) memcpy(kfs.data() + (size_t)IBA_KF * base[c].kf, packs[c].kfs.data(), 8 * packs[c].kfs.size());
+            if (!packs[c].pts.empty()) memcpy(pts.data() + 3 * base[c].l, packs[c].pts.data(), 8 * packs[c].pts.size());
+        };
+        std::vector<std::thread> th;
+        for (int c = 1; c < nthr; c++) th.emplace_back([&, c] { copy_chunk(c); });
+        memcpy(B.bytes.data() + o_win, hw.data(), sizeof(IbaWin) * (size_t)n_windows);
+        copy_chunk(0);
+        for (auto &t : th) t.join();
+    }
     const size_t constant_bytes = al256(B.bytes.size());
     // work area
     size_t off = constant_bytes;
@@ -1128,7 +1222,7 @@ extern "C" int orbhip_inertial_ba_solve_batch(orbhip_ctx *ctx, const orbhip_iba_
                  w_W = take(144 * sumE), w_Hll = take(48 * sumL), w_bl = take(24 * sumL), w_Di = take(48 * sumL), w_db = take(24 * sumL), w_xl = take(24 * sumL),
                  w_ierr = take(120 * sumM), w_ichi = take(24 * sumM), w_Jb = take(1728 * sumM), w_OJ = take(1728 * sumM), w_Oe = take(120 * sumM),
                  w_H = take(8 * sumH), w_S = take(8 * sumH), w_b = take(8 * sumX), w_bs = take(8 * sumX), w_x = take(8 * sumX), w_out = take(sumE),
-                 w_kpart = take(27 * 8 * kf_task.size()), w_ppart = take(42 * 8 * pair_task.size()),
+                 w_kpart = take(27 * 8 * n_kftask), w_ppart = take(42 * 8 * n_pairtask),
                  w_stats = take(sizeof(orbhip_iba_stats) * n_windows), w_prof = take(64 * (size_t)n_windows),
                  w_sync = take((4 + 4 + 4) * (size_t)n_windows), w_wpart = take(8 * 2 * IBA_MAXG * 2 * (size_t)n_windows);
     const bool want_prof = getenv("ORBHIP_IBA_PROF") != nullptr;
