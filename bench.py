@@ -196,6 +196,7 @@ def parse_args(argv=None):
                     help="1 = strictly serial steps (default).  > 1: the K steps alternate between this many independent pipelines (own "
                          "context, extractor, HIP streams and match buffers; every step is still one full pass over one resident batch); "
                          "paid +7 %% before the blur became an LDS-free kernel that fills k_fast_cells' idle slots, nothing since")
+    ap.add_argument("--no-tracking", dest="tracking", action="store_false", help="skip the SearchByProjection legs")
     ap.add_argument("--inertial-windows", type=int, default=32, help="LocalInertialBA windows solved per call (0 = skip)")
     ap.add_argument("--stereo-pairs", type=int, default=None, help="rectified stereo pairs for the ComputeStereoMatches leg (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -661,6 +662,43 @@ def main():
                                 "keyframes, 600 landmarks (%d visual edges), optimize(10), host arrays in / out (packing + H2D + kernel + D2H)"
                                 % iba_wins[0].n_edges}
 
+    # ---- the tracking matchers on the bench batch (ORBmatcher::SearchByProjection, last frame and local map): every frame's keypoints
+    # as projection queries against its successor; timed on their own, not part of `value`
+    tracking = None
+    if args.tracking and B > 1:
+        import ctypes as C
+        hipl = C.CDLL("libamdhip64.so"); hipl.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        extract(); sync()
+        kp_h = np.zeros((B, max_kp), orbhip.KP_DTYPE)
+        assert hipl.hipMemcpy(kp_h.ctypes.data, kp_p, kp_h.nbytes, 2) == 0
+        sf = ext.table(0)
+        q = np.zeros((B, max_kp), orbhip.PROJ_QUERY_DTYPE)
+        q["u"] = kp_h["x"]; q["v"] = kp_h["y"]; q["angle"] = kp_h["angle"]; q["radius"] = np.float32(15.0) * sf[np.clip(kp_h["octave"], 0, 7)]
+        q["min_level"] = kp_h["octave"] - 1; q["max_level"] = kp_h["octave"] + 1; q["has_obs"] = 1; q["ur"] = -1
+        d_q = torch.from_numpy(q.view(np.uint8)).cuda()
+        d_tm = torch.full((B, max_kp), -1, dtype=torch.int32, device="cuda"); d_tn = torch.zeros((B,), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        bnds = (0.0, 0.0, float(W), float(H))
+        legs = {"search_by_projection_last_frame": lambda: orbhip.search_by_projection_device(
+                    ctx, d_q.data_ptr(), desc_p, cnt_p, max_kp, kp_p + max_kp * 28, desc_p + dstride, None, cnt_p + 4, max_kp, max_kp, B - 1, bnds,
+                    100, True, d_tm.data_ptr(), d_tn.data_ptr()),
+                "search_by_projection_local_map": lambda: orbhip.search_local_map_device(
+                    ctx, d_q.data_ptr(), desc_p, cnt_p, max_kp, kp_p + max_kp * 28, desc_p + dstride, None, cnt_p + 4, max_kp, max_kp, B - 1, bnds,
+                    100, 0.8, d_tm.data_ptr(), d_tn.data_ptr())}
+        tracking = {"workload": "%d consecutive frame pairs of the bench batch, every keypoint of frame i projected into frame i+1 (radius 15 x scale, "
+                                "levels octave-1..octave+1), ORBmatcher.cc:1965 / :48" % (B - 1)}
+        for name, fn in legs.items():
+            dt_t = 0.0
+            for it in range(5):                                  # d_tm is in/out (claimed train keypoints are skipped): reset before every call
+                d_tm.fill_(-1); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fn(); sync()
+                if it:
+                    dt_t += (time.perf_counter() - t0) / 4
+            (dt_t,) = max_over_ranks(dt_t)
+            tracking[name] = {"ms_per_batch": round(dt_t * 1e3, 3), "frame_pairs_per_s": round(world * (B - 1) / dt_t, 1),
+                              "matches_per_pair": round(float(d_tn[:B - 1].float().mean().item()), 1)}
+
     stereo = None
     if args.stereo_pairs > 0:
         S = args.stereo_pairs
@@ -783,6 +821,8 @@ def main():
             out["pose_opt"] = pose
         if stereo is not None:
             out["stereo"] = stereo
+        if tracking is not None:
+            out["tracking"] = tracking
         if inertial is not None:
             out["inertial_ba"] = inertial
         if world == 1 and not args.no_cpu_baseline:
