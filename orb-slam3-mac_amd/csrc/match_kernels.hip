@@ -666,6 +666,131 @@ __device__ void sbp_build_grid(uint32_t *cell_start, float *kx, float *ky, uint8
     __syncthreads();
 }
 
+// Register-resident sequential loop of SearchByProjection (both modes, frames of one camera, at most 64 * NS keypoints inside the
+// grid).  The CSR grid orders the train keypoints by (grid column, row, rank) = GetFeaturesInArea's visit order; slot s of lane l
+// holds the keypoint at CSR position 64 s + l -- position, cell, octave, holder state, uRight and descriptor in VGPRs.  A slot
+// covers a contiguous range of grid columns, so a query only evaluates the 2..4 slots its window's columns intersect (uniform
+// test), branch-free on all 64 lanes: cell-range + level + distance + holder + uRight gates, Hamming distance, key =
+// distance << 12 | CSR position (the old candidate list's order).  No candidate list, no LDS or global access and no barrier
+// in the chain (cycle counters, -DSBP_PROF: the list was 49 % of a query's 5200 cycles, the evaluation with its descriptor
+// fetches 30 %).  Returns nmatches; writes qm[] and the final holder[] to LDS for the rotation check that follows.
+template <int NS, bool UR>
+__device__ __forceinline__ int sbp_register_loop(int lane, int n_items, int nq, const orbhip_proj_query *Q, const uint4 *dQ, const uint4 *dT,
+                                                 const float *uright, const float *kx, const float *ky, const uint8_t *oct, const uint16_t *items,
+                                                 const uint16_t *cell_of, int16_t *holder, int16_t *qm,
+                                                 float min_x, float min_y, float inv_w, float inv_h, int th_high, int mode, float nn_ratio)
+{
+    float fkx[NS], fky[NS], fur[UR ? NS : 1]; uint32_t fpk[NS]; int fh[NS], fi[NS]; uint4 fd0[NS], fd1[NS];
+    int slo[NS], shi[NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        const int p = 64 * s + lane;
+        const bool v = p < n_items;
+        const int i2 = v ? (int)items[p] : 0;                                                          // (row 0 of the pair's arrays exists also for an empty frame)
+        fi[s] = i2; fkx[s] = kx[i2]; fky[s] = ky[i2];
+        const int cell = cell_of[i2], cx = (int)(((uint32_t)cell * 43691u) >> 21), cy = cell - SI_ROWS * cx;     // cell / 48, exact for cell < 3072
+        fpk[s] = v ? (uint32_t)cx | ((uint32_t)cy << 7) | ((uint32_t)oct[i2] << 13) : 127u;          // column 127: in no window
+        fh[s] = holder[i2]; if (UR) fur[s] = uright[i2];
+        fd0[s] = dT[2 * i2]; fd1[s] = dT[2 * i2 + 1];
+        const int lastl = min(63, n_items - 1 - 64 * s);                                              // uniform; < 0: empty slot
+        slo[s] = lastl >= 0 ? __builtin_amdgcn_readlane(cx, 0) : 127;
+        shi[s] = lastl >= 0 ? __builtin_amdgcn_readlane(cx, lastl) : -1;
+    }
+    int nmatches = 0;
+    // the query records and descriptors are fetched two queries ahead
+    orbhip_proj_query q1 = Q[0], q2 = Q[min(1, nq - 1)];
+    uint4 a1_0 = dQ[0], a1_1 = dQ[1], a2_0 = dQ[2 * min(1, nq - 1)], a2_1 = dQ[2 * min(1, nq - 1) + 1];
+    for (int t = 0; t < nq; t++) {
+        const orbhip_proj_query qq = q1;
+        const uint4 a0 = a1_0, a1 = a1_1;
+        q1 = q2; a1_0 = a2_0; a1_1 = a2_1;
+        { const int tn = min(t + 2, nq - 1); q2 = Q[tn]; a2_0 = dQ[2 * tn]; a2_1 = dQ[2 * tn + 1]; }
+        const float x = qq.u, y = qq.v, r = qq.radius;
+        int c0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, min_x), r), inv_w)); if (c0 < 0) c0 = 0;   // Frame.cc:656-674
+        if (c0 >= SI_COLS) continue;
+        int c1 = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, min_x), r), inv_w)); if (c1 > SI_COLS - 1) c1 = SI_COLS - 1;
+        if (c1 < 0) continue;
+        int r0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, min_y), r), inv_h)); if (r0 < 0) r0 = 0;
+        if (r0 >= SI_ROWS) continue;
+        int r1 = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, min_y), r), inv_h)); if (r1 > SI_ROWS - 1) r1 = SI_ROWS - 1;
+        if (r1 < 0) continue;
+        c0 = __builtin_amdgcn_readfirstlane(c0); c1 = __builtin_amdgcn_readfirstlane(c1);
+        const bool check_lv = qq.min_level > 0 || qq.max_level >= 0;            // Frame.cc:676
+        const uint32_t cw = (uint32_t)(c1 - c0), rh = (uint32_t)(r1 - r0);
+        uint32_t lk1 = 0xFFFFFFFFu, lk2 = 0xFFFFFFFFu; int sl1 = 0, sl2 = 0;    // per lane: two smallest keys and their slots
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            if (shi[s] < c0 || slo[s] > c1) continue;                           // uniform: no keypoint of this slot in the window's columns
+            const uint32_t dcx = (fpk[s] & 127u) - (uint32_t)c0, dcy = ((fpk[s] >> 7) & 63u) - (uint32_t)r0;
+            const int o = (int)(fpk[s] >> 13), h = fh[s];
+            // (bitwise &: no short-circuit branches -- every gate is a compare, the combination scalar logic)
+            bool ok = (dcx <= cw) & (dcy <= rh);
+            ok = ok & !((int)check_lv & ((int)(o < qq.min_level) | ((int)(qq.max_level >= 0) & (int)(o > qq.max_level))));   // Frame.cc:693-701
+            ok = ok & (bool)((int)(fabsf(__fsub_rn(fkx[s], x)) < r) & (int)(fabsf(__fsub_rn(fky[s], y)) < r));   // Frame.cc:704-708
+            ok = ok & !((h <= -2) | ((h >= 0) & ((h & 1) != 0)));                                       // ORBmatcher.cc:2037-2039 / 96-98
+            if (UR) ok = ok & !((fur[s] > 0) & (fabsf(__fsub_rn(qq.ur, fur[s])) > r));                  // ORBmatcher.cc:2041-2047 / 100-105
+            const int dist = hamming256(a0, a1, fd0[s], fd1[s]);
+            const uint32_t key = ok ? ((uint32_t)dist << 12) | (uint32_t)(64 * s + lane) : 0xFFFFFFFFu;
+            const bool b1 = key < lk1, b2 = key < lk2;
+            sl2 = b1 ? sl1 : (b2 ? s : sl2); lk2 = b1 ? lk1 : (b2 ? key : lk2);
+            sl1 = b1 ? s : sl1; lk1 = b1 ? key : lk1;
+        }
+        const uint32_t key = wave_min_u32_dpp(lk1);
+        if (key == 0xFFFFFFFFu) continue;
+        bool accept = (int)(key >> 12) <= th_high && (int)(key >> 12) < 256;                         // ORBmatcher.cc:2030,2058 / 85,131
+        const unsigned long long own1 = __ballot(lk1 == key);
+        const int ol = __builtin_amdgcn_readfirstlane(__ffsll((long long)own1) - 1);
+        const int bsl = __builtin_amdgcn_readlane(sl1, ol);
+        if (accept && mode == 1) {
+            // local-map variant (ORBmatcher.cc:131-137): ratio test against the second best when it is of the same octave; the second
+            // smallest key is the minimum over the winner's runner-up and every other lane's best (keys are unique)
+            const uint32_t c2 = lk1 == key ? lk2 : lk1;
+            const int cs2 = lk1 == key ? sl2 : sl1;
+            const uint32_t key2 = wave_min_u32_dpp(c2);
+            int best_lv = 0, lv2 = -1, d2 = 256;
+#pragma unroll
+            for (int s = 0; s < NS; s++) if (bsl == s) best_lv = (int)((uint32_t)__builtin_amdgcn_readlane((int)fpk[s], ol) >> 13);
+            if (key2 != 0xFFFFFFFFu && (int)(key2 >> 12) < 256) {
+                d2 = (int)(key2 >> 12);
+                const unsigned long long own2 = __ballot(c2 == key2);
+                const int ol2 = __builtin_amdgcn_readfirstlane(__ffsll((long long)own2) - 1);
+                const int s2 = __builtin_amdgcn_readlane(cs2, ol2);
+#pragma unroll
+                for (int s = 0; s < NS; s++) if (s2 == s) lv2 = (int)((uint32_t)__builtin_amdgcn_readlane((int)fpk[s], ol2) >> 13);
+            }
+            if (best_lv == lv2 && (float)(int)(key >> 12) > __fmul_rn(nn_ratio, (float)d2)) accept = false;
+        }
+        if (accept) {
+            int best = 0;
+#pragma unroll
+            for (int s = 0; s < NS; s++)
+                if (bsl == s) {                                                 // uniform
+                    best = __builtin_amdgcn_readlane(fi[s], ol);
+                    if (lane == ol) fh[s] = (t << 1) | (qq.has_obs & 1);
+                }
+            if (lane == 0) qm[t] = (int16_t)best;
+            nmatches++;
+        }
+    }
+    // the holder states go back to LDS for the rotation check and the final write-out
+#pragma unroll
+    for (int s = 0; s < NS; s++) if (64 * s + lane < n_items) holder[fi[s]] = (int16_t)fh[s];
+    return nmatches;
+}
+
+
+#ifdef SBP_PROF
+__device__ long long g_sbp_prof[8];           // debug build only (EXTRA=-DSBP_PROF): cycles of setup / candidate list / evaluation / update / tail of pair 0; queries, candidates
+#define SBP_T(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const long long t_ = clock64(); g_sbp_prof[i] += t_ - t_prev; t_prev = t_; } } while (0)
+extern "C" int orbhip_debug_sbp_prof(long long *out8, int reset)
+{
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_sbp_prof), 64) != hipSuccess) return ORBHIP_E_HIP;
+    if (reset) { long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_sbp_prof), z, 64) != hipSuccess) return ORBHIP_E_HIP; }
+    return ORBHIP_OK;
+}
+#else
+#define SBP_T(i) do { } while (0)
+#endif
 template <bool DESC_LDS>
 __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_query *q_, const uint8_t *descq_, const int32_t *nq_, int max_q,
                                                              const orbhip_keypoint *kp_, const uint8_t *desc_, const float *uright_,
@@ -691,6 +816,9 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
     __shared__ int hist[SI_HISTO];
     __shared__ int s_keep[3];
     const int pair = blockIdx.x, lane = threadIdx.x;
+#ifdef SBP_PROF
+    long long t_prev = clock64();
+#endif
     const unsigned long long lt_mask = (1ull << lane) - 1;
     const int n = n_[pair], nq = nq_[pair];
     // rig frames (Nleft != -1): keypoints [0, nleft) are the left camera's, [nleft, n) the right camera's; a query carries the camera
@@ -719,9 +847,17 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
         if (DESC_LDS) { dlds[2 * i] = dT[2 * i]; dlds[2 * i + 1] = dT[2 * i + 1]; }
     }
     sbp_build_grid(cell_start, kx, ky, oct, items, cell_of, rank_of, kp, n, min_x, min_y, inv_w, inv_h, lane, ncells, nleft);
+    SBP_T(0);
     // ---- sequential query loop (ORBmatcher.cc:1987-2088)
     int nmatches = 0;
     const float factor = 1.0f / SI_HISTO;
+    const int n_items = (int)cell_start[ncells];
+    if (nleft < 0 && !mirror && n_items <= 16 * 64 && nq > 0) {
+        nmatches = uright ? sbp_register_loop<16, true>(lane, n_items, nq, Q, dQ, dT, uright, kx, ky, oct, items, cell_of, holder, qm, min_x, min_y, inv_w, inv_h,
+                                                        th_high, mode, nn_ratio)
+                          : sbp_register_loop<16, false>(lane, n_items, nq, Q, dQ, dT, uright, kx, ky, oct, items, cell_of, holder, qm, min_x, min_y, inv_w, inv_h,
+                                                         th_high, mode, nn_ratio);
+    } else {
     // the next query's record and descriptor are fetched one iteration ahead (their latency overlaps this query's work)
     orbhip_proj_query qn = Q[0];
     uint4 n0 = dQ[0], n1 = dQ[1];
@@ -751,6 +887,7 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
         const int maxlen = wave_max_dpp(len);
         for (int j = 0; j < maxlen; j++) if (j < len) cand[off + j] = items[start + j];
         __syncthreads();
+        SBP_T(1);
         const bool check_lv = qq.min_level > 0 || qq.max_level >= 0;            // Frame.cc:676
         uint32_t key = 0xFFFFFFFFu, key2 = 0xFFFFFFFFu;                         // the two smallest (distance << 12 | position)
         for (int k0 = 0; k0 < total; k0 += 64) {
@@ -776,6 +913,10 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
             }
         }
         wave_min2_u32_dpp(key, key2);
+        SBP_T(2);
+#ifdef SBP_PROF
+        if (blockIdx.x == 0 && threadIdx.x == 0) { g_sbp_prof[5] += 1; g_sbp_prof[6] += total; }
+#endif
         bool accept = key != 0xFFFFFFFFu && (int)(key >> 12) <= th_high && (int)(key >> 12) < 256;       // ORBmatcher.cc:2030,2058 / 85,131
         if (accept && mode == 1) {
             // local-map variant (ORBmatcher.cc:131-137): ratio test against the second best of the same octave.
@@ -798,6 +939,8 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
             }
         }
         __syncthreads();                                                        // cand / holder reused by the next query
+        SBP_T(3);
+    }
     }
     __syncthreads();
     // ---- rotation consistency (ORBmatcher.cc:2156-2178): every histogram entry of a dropped bin clears its
@@ -839,6 +982,7 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
     __syncthreads();
     for (int i = lane; i < n; i += 64) { const int h = holder[i]; tm[i] = h >= 0 ? (h >> 1) : h; }
     if (lane == 0) nmatches_[pair] = nmatches;
+    SBP_T(4);
 }
 
 // LDS of k_search_by_projection for the given row capacities (keypoints / queries per pair)
