@@ -717,7 +717,7 @@ __device__ __forceinline__ int sbp_register_loop(int lane, int n_items, int nq, 
         c0 = __builtin_amdgcn_readfirstlane(c0); c1 = __builtin_amdgcn_readfirstlane(c1);
         const bool check_lv = qq.min_level > 0 || qq.max_level >= 0;            // Frame.cc:676
         const uint32_t cw = (uint32_t)(c1 - c0), rh = (uint32_t)(r1 - r0);
-        uint32_t lk1 = 0xFFFFFFFFu, lk2 = 0xFFFFFFFFu; int sl1 = 0, sl2 = 0;    // per lane: two smallest keys and their slots
+        uint32_t lk1 = 0xFFFFFFFFu, lk2 = 0xFFFFFFFFu, pay1 = 0, pay2 = 0; int sl1 = 0;    // per lane: two smallest keys, their (index | octave << 16), the best's slot
 #pragma unroll
         for (int s = 0; s < NS; s++) {
             if (shi[s] < c0 || slo[s] > c1) continue;                           // uniform: no keypoint of this slot in the window's columns
@@ -731,9 +731,10 @@ __device__ __forceinline__ int sbp_register_loop(int lane, int n_items, int nq, 
             if (UR) ok = ok & !((fur[s] > 0) & (fabsf(__fsub_rn(qq.ur, fur[s])) > r));                  // ORBmatcher.cc:2041-2047 / 100-105
             const int dist = hamming256(a0, a1, fd0[s], fd1[s]);
             const uint32_t key = ok ? ((uint32_t)dist << 12) | (uint32_t)(64 * s + lane) : 0xFFFFFFFFu;
+            const uint32_t pay = (uint32_t)fi[s] | ((uint32_t)o << 16);
             const bool b1 = key < lk1, b2 = key < lk2;
-            sl2 = b1 ? sl1 : (b2 ? s : sl2); lk2 = b1 ? lk1 : (b2 ? key : lk2);
-            sl1 = b1 ? s : sl1; lk1 = b1 ? key : lk1;
+            pay2 = b1 ? pay1 : (b2 ? pay : pay2); lk2 = b1 ? lk1 : (b2 ? key : lk2);
+            pay1 = b1 ? pay : pay1; sl1 = b1 ? s : sl1; lk1 = b1 ? key : lk1;
         }
         const uint32_t key = wave_min_u32_dpp(lk1);
         if (key == 0xFFFFFFFFu) continue;
@@ -744,30 +745,23 @@ __device__ __forceinline__ int sbp_register_loop(int lane, int n_items, int nq, 
         if (accept && mode == 1) {
             // local-map variant (ORBmatcher.cc:131-137): ratio test against the second best when it is of the same octave; the second
             // smallest key is the minimum over the winner's runner-up and every other lane's best (keys are unique)
-            const uint32_t c2 = lk1 == key ? lk2 : lk1;
-            const int cs2 = lk1 == key ? sl2 : sl1;
+            const uint32_t c2 = lk1 == key ? lk2 : lk1, cp2 = lk1 == key ? pay2 : pay1;
             const uint32_t key2 = wave_min_u32_dpp(c2);
-            int best_lv = 0, lv2 = -1, d2 = 256;
-#pragma unroll
-            for (int s = 0; s < NS; s++) if (bsl == s) best_lv = (int)((uint32_t)__builtin_amdgcn_readlane((int)fpk[s], ol) >> 13);
+            const int best_lv = (int)((uint32_t)__builtin_amdgcn_readlane((int)pay1, ol) >> 16);
+            int lv2 = -1, d2 = 256;
             if (key2 != 0xFFFFFFFFu && (int)(key2 >> 12) < 256) {
                 d2 = (int)(key2 >> 12);
                 const unsigned long long own2 = __ballot(c2 == key2);
                 const int ol2 = __builtin_amdgcn_readfirstlane(__ffsll((long long)own2) - 1);
-                const int s2 = __builtin_amdgcn_readlane(cs2, ol2);
-#pragma unroll
-                for (int s = 0; s < NS; s++) if (s2 == s) lv2 = (int)((uint32_t)__builtin_amdgcn_readlane((int)fpk[s], ol2) >> 13);
+                lv2 = (int)((uint32_t)__builtin_amdgcn_readlane((int)cp2, ol2) >> 16);
             }
             if (best_lv == lv2 && (float)(int)(key >> 12) > __fmul_rn(nn_ratio, (float)d2)) accept = false;
         }
         if (accept) {
-            int best = 0;
+            const int best = (int)((uint32_t)__builtin_amdgcn_readlane((int)pay1, ol) & 0xFFFFu);
 #pragma unroll
             for (int s = 0; s < NS; s++)
-                if (bsl == s) {                                                 // uniform
-                    best = __builtin_amdgcn_readlane(fi[s], ol);
-                    if (lane == ol) fh[s] = (t << 1) | (qq.has_obs & 1);
-                }
+                if (bsl == s) { if (lane == ol) fh[s] = (t << 1) | (qq.has_obs & 1); }          // uniform slot test
             if (lane == 0) qm[t] = (int16_t)best;
             nmatches++;
         }
