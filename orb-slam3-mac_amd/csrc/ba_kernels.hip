@@ -2180,6 +2180,7 @@ extern "C" int orbhip_ba_solve_batch(orbhip_ctx *ctx, const orbhip_ba_graph *gra
 // block-reduced sums: no broadcasts, two barriers per reduction, fixed summation order (run-to-run identical).
 #define PO_THREADS 256
 #define PO_NRED 28            // robust chi2 + 21 upper-triangle entries of H + 6 of b
+#define PO_KR 4               // edges per thread held in registers (x 256 threads: frames of up to 1024 edges never re-read them)
 #define PO_IDX(a, c) ((a) * 6 - (a) * ((a) - 1) / 2 + ((c) - (a)))      // packed upper triangle, a <= c
 struct PoArgs {
     const double *Xw, *obs, *inv_s2;
@@ -2194,7 +2195,7 @@ struct PoArgs {
     int32_t *n_inliers, *stats;
 };
 
-template <int N>
+template <int N, int NT = 256>
 __device__ __forceinline__ void po_block_sum(double (&v)[N], double (*red)[PO_NRED])
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -2202,6 +2203,7 @@ __device__ __forceinline__ void po_block_sum(double (&v)[N], double (*red)[PO_NR
     for (int k = 0; k < N; k++) {
         v[k] = wave_sum_f64_dpp(v[k]);                    // DPP path: the ~100 block sums per frame were ds_bpermute bound
     }
+    if (NT == 64) return;                              // one wave per frame: no LDS, no barrier
     __syncthreads();                                   // previous readers of red are done
     if (lane == 0) {
 #pragma unroll
@@ -2248,16 +2250,19 @@ __device__ __forceinline__ double po_edge_chi2(const PoArgs &A, const BaGraphDev
 
 // GENERAL = false: Pinhole camera, no second camera (the common case keeps its registers); true: KannalaBrandt8 and / or
 // observations in a second, rigidly attached camera.
-template <bool GENERAL>
-__global__ __launch_bounds__(PO_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pose_opt(PoArgs A)
+// NT threads per frame, KR edges per thread in registers.  <256, 0>: four waves per frame, edges re-read from global memory on every walk
+// (frames of more than 2048 edges).  <64, 16>: ONE wave per frame -- up to 1024 edges live in registers (the LM loop walks them ~80
+// times per frame: build + trial per iteration, 4 x 10 iterations; every walk was a round of dependent global loads), all sums
+// are wave-level DPP trees (no LDS, no barrier), and 1024 frames are one wave per SIMD instead of two rounds of 4-wave workgroups.
+template <bool GENERAL, int NT, int KR>
+__device__ __forceinline__ void po_body(const PoArgs &A, double (*red)[PO_NRED])
 {
-    __shared__ double red[4][PO_NRED];
     const int f = blockIdx.x, tid = threadIdx.x;
     const int n = A.n[f];
     const double *Xw = A.Xw + (size_t)f * A.max_edges * 3, *obs = A.obs + (size_t)f * A.max_edges * 3;
     const double *is2 = A.inv_s2 + (size_t)f * A.max_edges;
     uint8_t *outl = A.outlier + (size_t)f * A.max_edges;
-    for (int e = tid; e < n; e += PO_THREADS) outl[e] = 0;                       // Optimizer.cc:896
+    for (int e = tid; e < n; e += NT) outl[e] = 0;                       // Optimizer.cc:896
     if (n < 3 || n > A.max_edges) {                                             // Optimizer.cc:1040-1041
         if (tid == 0) { A.n_inliers[f] = 0; if (A.stats) { for (int k = 0; k < 4; k++) A.stats[4 * f + k] = 0; } }
         return;
@@ -2275,12 +2280,27 @@ __global__ __launch_bounds__(PO_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     const double delta_m = (double)(float)sqrt(5.991), dsqr_m = (double)(float)(delta_m * delta_m);   // Optimizer.cc:887-888
     const double delta_s = (double)(float)sqrt(7.815), dsqr_s = (double)(float)(delta_s * delta_s);
     uint32_t level = 0;                                                          // bit k: edge tid + 256*k is an outlier
+    double rX[KR ? KR : 1][3], rO[KR ? KR : 1][3], rW[KR ? KR : 1]; int rR[KR ? KR : 1];
+#pragma unroll
+    for (int k = 0; k < KR; k++) {
+        const int e = min(tid + NT * k, n - 1);
+        rX[k][0] = Xw[3 * e]; rX[k][1] = Xw[3 * e + 1]; rX[k][2] = Xw[3 * e + 2];
+        rO[k][0] = obs[3 * e]; rO[k][1] = obs[3 * e + 1]; rO[k][2] = obs[3 * e + 2];
+        rW[k] = is2[e]; rR[k] = (GENERAL && right) ? right[e] : 0;
+    }
+    // body(k, e, X, ob, w0, rt) for every edge of this thread
+    auto for_edges = [&](auto body) {
+#pragma unroll
+        for (int k = 0; k < KR; k++) { const int e = tid + NT * k; if (e < n) body(k, e, rX[k], rO[k], rW[k], rR[k]); }
+        for (int e = tid + NT * KR, k = KR; e < n; e += NT, k++)
+            body(k, e, Xw + 3 * e, obs + 3 * e, is2[e], (GENERAL && right) ? (int)right[e] : 0);
+    };
     int robust = 1, nbad = 0, lm_trials = 0, lm_iters = 0, rounds = 0;
     for (int it = 0; it < 4; it++) {
         for (int k = 0; k < 7; k++) pose[k] = pose0[k];                          // Optimizer.cc:1053
         double cnt[1] = {0};
-        for (int e = tid, k = 0; e < n; e += PO_THREADS, k++) cnt[0] += !((level >> k) & 1u);
-        po_block_sum<1>(cnt, red);
+        for (int e = tid, k = 0; e < n; e += NT, k++) cnt[0] += !((level >> k) & 1u);
+        po_block_sum<1, NT>(cnt, red);
         if (cnt[0] > 0) {
             double lambda = 0, ni = 2;
             int nb = 0, ok = 1;
@@ -2291,19 +2311,17 @@ __global__ __launch_bounds__(PO_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 for (int k = 0; k < PO_NRED; k++) acc[k] = 0;
                 double R[9];
                 quat_to_R(pose, R);
-                for (int e = tid, k = 0; e < n; e += PO_THREADS, k++) {
-                    if ((level >> k) & 1u) continue;
-                    const double *ob = obs + 3 * e;
+                for_edges([&](int k, int e, const double *Xe, const double *ob, double w0, int rt) {
+                    (void)e;
+                    if ((level >> k) & 1u) return;
                     const int stereo = !(ob[2] < 0);
                     double P[3], er[3], Jx[9], Jt[18], r0, r1;
 #pragma unroll
                     for (int k = 12; k < 18; k++) Jt[k] = 0;                     // monocular edge: third row empty (er[2] == 0)
-                    const double w0 = is2[e];
-                    const int rt = (GENERAL && right) ? right[e] : 0;
-                    const double chi2 = po_edge_chi2<GENERAL>(A, cam, pose, Xw + 3 * e, ob, w0, rt, P, er);
+                    const double chi2 = po_edge_chi2<GENERAL>(A, cam, pose, Xe, ob, w0, rt, P, er);
                     if (robust) huber(chi2, stereo ? delta_s : delta_m, stereo ? dsqr_s : dsqr_m, &r0, &r1);
                     else { r0 = chi2; r1 = 1.; }
-                    if (GENERAL && rt) tobody_jacobians(cam, pose, Xw + 3 * e, Jx, Jt);   // OptimizableTypes.cpp:82-106 (the pose block of the binary edge)
+                    if (GENERAL && rt) tobody_jacobians(cam, pose, Xe, Jx, Jt);   // OptimizableTypes.cpp:82-106 (the pose block of the binary edge)
                     else edge_jacobians(cam, P, R, stereo, Jx, Jt);
                     const double w = r1 * w0;
                     acc[0] += r0;
@@ -2325,8 +2343,8 @@ __global__ __launch_bounds__(PO_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                         for (int d = 0; d < 3; d++) s += Jt[6 * d + a] * (-w * er[d]);
                         acc[22 + a] += s;
                     }
-                }
-                po_block_sum<PO_NRED>(acc, red);
+                });
+                po_block_sum<PO_NRED, NT>(acc, red);
                 for (int k = 0; k < 7; k++) pose_ev[k] = pose[k];
                 double current_chi = acc[0];
                 const double ini_chi = current_chi;
@@ -2395,17 +2413,17 @@ __global__ __launch_bounds__(PO_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                     se3_oplus(x, pose, pn);                                      // update, SO:422-435
                     for (int k = 0; k < 7; k++) pose[k] = pn[k];
                     double tc[1] = {0};                                          // computeActiveErrors + activeRobustChi2 at the trial
-                    for (int e = tid, k = 0; e < n; e += PO_THREADS, k++) {
-                        if ((level >> k) & 1u) continue;
-                        const double *ob = obs + 3 * e;
+                    for_edges([&](int k, int e, const double *Xe, const double *ob, double w0, int rt) {
+                        (void)e;
+                        if ((level >> k) & 1u) return;
                         const int stereo = !(ob[2] < 0);
                         double P[3], er[3], r0, r1;
-                        const double chi2 = po_edge_chi2<GENERAL>(A, cam, pose, Xw + 3 * e, ob, is2[e], (GENERAL && right) ? right[e] : 0, P, er);
+                        const double chi2 = po_edge_chi2<GENERAL>(A, cam, pose, Xe, ob, w0, rt, P, er);
                         if (robust) huber(chi2, stereo ? delta_s : delta_m, stereo ? dsqr_s : dsqr_m, &r0, &r1);
                         else r0 = chi2;
                         tc[0] += r0;
-                    }
-                    po_block_sum<1>(tc, red);
+                    });
+                    po_block_sum<1, NT>(tc, red);
                     for (int k = 0; k < 7; k++) pose_ev[k] = pose[k];
                     double temp_chi = ok2 ? tc[0] : DBL_MAX;
                     rho = current_chi - temp_chi;
@@ -2435,26 +2453,38 @@ __global__ __launch_bounds__(PO_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         // ---- re-classification (Optimizer.cc:1058-1145): inliers keep the error of the last evaluation (possibly a
         // rejected trial), outliers are re-evaluated at the current estimate; the comparison is in float
         double bad[1] = {0};
-        for (int e = tid, k = 0; e < n; e += PO_THREADS, k++) {
-            const double *ob = obs + 3 * e;
+        for_edges([&](int k, int e, const double *Xe, const double *ob, double w0, int rt) {
+            (void)e;
             double P[3], er[3];
-            const double chi2d = po_edge_chi2<GENERAL>(A, cam, ((level >> k) & 1u) ? pose : pose_ev, Xw + 3 * e, ob, is2[e], (GENERAL && right) ? right[e] : 0, P, er);
+            const double chi2d = po_edge_chi2<GENERAL>(A, cam, ((level >> k) & 1u) ? pose : pose_ev, Xe, ob, w0, rt, P, er);
             const float chi2 = (float)chi2d;
             const float gate = ob[2] < 0 ? 5.991f : 7.815f;
             if (chi2 > gate) { level |= 1u << k; bad[0] += 1; } else level &= ~(1u << k);
-        }
-        po_block_sum<1>(bad, red);
+        });
+        po_block_sum<1, NT>(bad, red);
         nbad = (int)bad[0];
         if (it == 2) robust = 0;                                                 // setRobustKernel(0)
         rounds++;
         if (n < 10) break;                                                       // Optimizer.cc:1147-1148
     }
-    for (int e = tid, k = 0; e < n; e += PO_THREADS, k++) outl[e] = (uint8_t)((level >> k) & 1u);
+    for (int e = tid, k = 0; e < n; e += NT, k++) outl[e] = (uint8_t)((level >> k) & 1u);
     if (tid == 0) {
         for (int k = 0; k < 7; k++) A.pose[7 * f + k] = pose[k];
         A.n_inliers[f] = n - nbad;
         if (A.stats) { A.stats[4 * f] = rounds; A.stats[4 * f + 1] = lm_iters; A.stats[4 * f + 2] = lm_trials; A.stats[4 * f + 3] = nbad; }
     }
+}
+
+template <bool GENERAL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pose_opt(PoArgs A)
+{
+    __shared__ double red[4][PO_NRED];
+    po_body<GENERAL, 256, 0>(A, red);
+}
+template <bool GENERAL>
+__global__ __launch_bounds__(64) void k_pose_opt_wave(PoArgs A)
+{
+    po_body<GENERAL, 64, GENERAL ? 8 : 16>(A, nullptr);          // (the fisheye / second-camera edge code needs the registers: 512 edges resident)
 }
 
 extern "C" int orbhip_pose_optimization_device(orbhip_ctx *ctx, const double *d_Xw, const double *d_obs,
@@ -2476,7 +2506,13 @@ extern "C" int orbhip_pose_optimization_device(orbhip_ctx *ctx, const double *d_
     A.fx2 = cam2 ? cam2->fx : 0; A.fy2 = cam2 ? cam2->fy : 0; A.cx2 = cam2 ? cam2->cx : 0; A.cy2 = cam2 ? cam2->cy : 0;
     A.cam2_model = cam2 ? cam2->camera_model : 0; for (int k = 0; k < 4; k++) A.kb2[k] = cam2 ? cam2->kb[k] : 0.0;
     A.stats = d_stats;
-    if (A.cam_model || A.right) hipLaunchKernelGGL(k_pose_opt<true>, dim3(frames), dim3(PO_THREADS), 0, orbhip_ctx_stream_internal(ctx), A);
-    else hipLaunchKernelGGL(k_pose_opt<false>, dim3(frames), dim3(PO_THREADS), 0, orbhip_ctx_stream_internal(ctx), A);
+    const bool general = A.cam_model || A.right;
+    if (max_edges <= 2048 && !getenv("ORBHIP_POSE_BLOCK")) {            // outlier bits: 32 per lane
+        if (general) hipLaunchKernelGGL(k_pose_opt_wave<true>, dim3(frames), dim3(64), 0, orbhip_ctx_stream_internal(ctx), A);
+        else hipLaunchKernelGGL(k_pose_opt_wave<false>, dim3(frames), dim3(64), 0, orbhip_ctx_stream_internal(ctx), A);
+    } else {
+        if (general) hipLaunchKernelGGL(k_pose_opt<true>, dim3(frames), dim3(PO_THREADS), 0, orbhip_ctx_stream_internal(ctx), A);
+        else hipLaunchKernelGGL(k_pose_opt<false>, dim3(frames), dim3(PO_THREADS), 0, orbhip_ctx_stream_internal(ctx), A);
+    }
     return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
 }
