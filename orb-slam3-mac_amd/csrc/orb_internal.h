@@ -122,6 +122,9 @@ int orb_lds_optin(const void *func, int device, size_t need);
 void orb_launch_resize(const OrbParams &P, int level, hipStream_t s);
 void orb_launch_fast_cells(const FastParams &F, hipStream_t s, int max_per_cu, int lvl_lo = 0, int lvl_hi = -1);      // max_per_cu: 0 = as many waves as fit
 #define ORB_OVERLAP_MIN_BATCH 16
+#ifndef BLR_R
+#define BLR_R 24              // k_blur_rows: output rows per lane (multiple of 6)
+#endif
 void orb_launch_blur(const OrbParams &P, hipStream_t s, int wgs_per_cu, int frame0 = 0, int nframes = -1);   // row kernel: frames [frame0, frame0 + nframes)
 const void *orb_fast_cells_func(int small);
 void orb_launch_octree(const OrbParams &P, hipStream_t s);

@@ -1180,7 +1180,6 @@ __global__ __launch_bounds__(256) void k_blur(OrbParams P)
 // column pass = three v_dot2_u32_u16 on the pairs + one v_mad_u32_u24.  Chunks whose 12-byte window crosses the left / right
 // image border (BORDER_REFLECT_101) are a separate lane class at the end of each (frame, level) lane range and assemble their
 // windows bytewise.
-#define BLR_R 24
 template <bool EDGE>
 __device__ __forceinline__ void blr_load(const uint8_t *src, int r, int spitch, int x, int w, uint32_t &d0, uint32_t &d1, uint32_t &d2)
 {

@@ -352,13 +352,13 @@ extern "C" int orbhip_extractor_reserve(orbhip_extractor *e, int width, int heig
     }
     P.bs_tiles[0] = 0;
     for (int l = 0; l < e->nlevels; l++) P.bs_tiles[l + 1] = P.bs_tiles[l] + ((P.lv[l].w + 63) / 64) * ((P.lv[l].h + 31) / 32);
-    {   // k_blur_rows: lanes = 4-column chunks x bands of 24 rows; needs 24 + 4 rows for its reflected row indices and one interior chunk
+    {   // k_blur_rows: lanes = 4-column chunks x bands of BLR_R rows; needs BLR_R + 4 rows for its reflected row indices and one interior chunk
         bool ok = !getenv("ORBHIP_BLUR_TILES");
         P.br_blocks[0] = 0;
         for (int l = 0; l < e->nlevels; l++) {
             const int w = P.lv[l].w, h = P.lv[l].h;
-            if (h < 28 || w < 16) ok = false;
-            P.br_blocks[l + 1] = P.br_blocks[l] + (((w + 3) / 4) * ((h + 23) / 24) + 255) / 256;
+            if (h < BLR_R + 4 || w < 16) ok = false;
+            P.br_blocks[l + 1] = P.br_blocks[l] + (((w + 3) / 4) * ((h + BLR_R - 1) / BLR_R) + 255) / 256;
         }
         if (!ok) P.br_blocks[e->nlevels] = 0;
     }
