@@ -269,7 +269,7 @@ __device__ __forceinline__ int si_register_loop(int lane, int n0, int na0, const
         const int lj = v ? li : 0;
         fkx[sl] = kx[lj]; fky[sl] = ky[lj];
         fpk[sl] = v ? ((uint32_t)cellx[lj] | ((uint32_t)celly[lj] << 8) | ((uint32_t)min((int)cpos[lj], SI_RANKS - 1) << 16)) : 0xFFFFu;   // cell (255, 255): never inside a window
-        fgi[sl] = gidx[lj]; fmd[sl] = INT_MAX; fm21[sl] = -1;
+        fgi[sl] = v ? (int)gidx[lj] : 0; fmd[sl] = INT_MAX; fm21[sl] = -1;      // (an empty slot must not index the descriptors with LDS garbage)
         fd0[sl] = dB[2 * fgi[sl]]; fd1[sl] = dB[2 * fgi[sl] + 1];
     }
     // the F1 points too: lane l holds points l, l + 64, ... (index, window centre, descriptor); the loop broadcasts point t
