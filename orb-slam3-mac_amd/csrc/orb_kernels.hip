@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void k_resize_rows(OrbParams P, int level, int
 void orb_launch_resize(const OrbParams &P, int level, hipStream_t s)
 {
     const OrbLevel &D = P.lv[level];
-    if (D.xchunk) {
+    if (D.xchunk && P.batch >= P.rows_min_batch) {
         const int nch = (D.w + 3) >> 2, nb = (D.h + RSR - 1) / RSR, nbx = (nch * nb + 255) / 256;
         const dim3 grid((unsigned)nbx * (unsigned)P.batch);
         const size_t lds = (size_t)((256 / nch + 2) * RSR + 2) * sizeof(uint4);          // <= 4.4 KB (nch >= 1)
@@ -1266,7 +1266,7 @@ __global__ __launch_bounds__(256) void k_blur_rows(OrbParams P, int frame0)
 
 void orb_launch_blur(const OrbParams &P, hipStream_t s, int wgs_per_cu, int frame0, int nframes)
 {
-    if (P.br_blocks[P.nlevels] > 0) {
+    if (P.br_blocks[P.nlevels] > 0 && P.batch >= P.rows_min_batch) {
         if (nframes < 0) nframes = P.batch - frame0;
         if (nframes > 0) hipLaunchKernelGGL(k_blur_rows, dim3((unsigned)P.br_blocks[P.nlevels] * (unsigned)nframes), dim3(256), 0, s, P, frame0);
         return;

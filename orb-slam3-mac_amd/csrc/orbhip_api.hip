@@ -352,6 +352,7 @@ extern "C" int orbhip_extractor_reserve(orbhip_extractor *e, int width, int heig
     }
     P.bs_tiles[0] = 0;
     for (int l = 0; l < e->nlevels; l++) P.bs_tiles[l + 1] = P.bs_tiles[l] + ((P.lv[l].w + 63) / 64) * ((P.lv[l].h + 31) / 32);
+    P.rows_min_batch = getenv("ORBHIP_ROWS_MIN_BATCH") ? atoi(getenv("ORBHIP_ROWS_MIN_BATCH")) : 16;     // measured: 1 frame 122 us (tiles) vs 158 us (rows), 32 frames 252 vs 222 us
     {   // k_blur_rows: lanes = 4-column chunks x bands of BLR_R rows; needs BLR_R + 4 rows for its reflected row indices and one interior chunk
         bool ok = !getenv("ORBHIP_BLUR_TILES");
         P.br_blocks[0] = 0;
@@ -561,7 +562,7 @@ static int run_pipeline(orbhip_extractor *e, int batch, int lap0, int lap1)
     FastParams &F = e->F;
     for (int l = 0; l < e->nlevels; l++) { F.lv[l].img = P.lv[l].img; F.lv[l].frame_stride = P.lv[l].img_frame_stride; F.lv[l].img_pitch = P.lv[l].img_pitch; }
     F.batch = batch; F.cell_count = P.cell_count; F.cell_list = P.cell_list; F.cell_list_frame_stride = P.cell_list_frame_stride; F.status = P.status;
-    const bool rows = P.br_blocks[e->nlevels] > 0;          // the row-streaming blur needs no LDS: k_fast_cells keeps its full grid
+    const bool rows = P.br_blocks[e->nlevels] > 0 && batch >= P.rows_min_batch;      // the row-streaming blur needs no LDS: k_fast_cells keeps its full grid
     const int fast_waves = fork ? tune_int("ORBHIP_TUNE_FAST_WAVES", rows ? 0 : 10) : 0;
     STAGE_MARK(ORBHIP_STAGE_PYRAMID);
     if (fork && e->nlevels > 1 && rows && tune_int("ORBHIP_TUNE_L0_EARLY", 0)) {

@@ -52,8 +52,10 @@ def _compare_frame(ext, ora, imgs, f, lap, got):
     (512, 512, 1500, (0, 511)),      # TUM-VI fisheye (Frame.cc:1056)
     (333, 277, 300, (100, 150)),     # ragged sizes, few features
 ])
-def test_extract_parity_stages(gpu_ctx, w, h, nfeat, lap):
+@pytest.mark.parametrize("rows_min", ["1", "16"])         # row-streaming pyramid / blur kernels (batches >= 16 by default) and tile kernels
+def test_extract_parity_stages(gpu_ctx, w, h, nfeat, lap, rows_min, monkeypatch):
     import orbhip
+    monkeypatch.setenv("ORBHIP_ROWS_MIN_BATCH", rows_min)
     ext, ora = _mk(gpu_ctx, nfeat)
     imgs = orbhip.synth_frames(w, h, 3, seed=1000 + w + nfeat)
     got = ext.extract_host(imgs, lap)
@@ -231,11 +233,13 @@ def test_graph_mode_is_identical_and_tracks_new_input(gpu_ctx):
     eager.close(); graph.close()
 
 
-def test_extract_random_geometries(gpu_ctx):
+@pytest.mark.parametrize("rows_min", ["1", "16"])
+def test_extract_random_geometries(gpu_ctx, rows_min, monkeypatch):
     """Seeded sweep over image sizes, level counts, scale factors (up to the 2.0 limit), thresholds and feature budgets:
     bit-exact final output for every combination (catches tile / apron / table-size assumptions)."""
     import orbhip
     import oracle_bind as ob
+    monkeypatch.setenv("ORBHIP_ROWS_MIN_BATCH", rows_min)
     rng = np.random.default_rng(2024)
     done = 0
     while done < 10:
@@ -368,6 +372,7 @@ def test_row_streaming_and_tile_kernels_agree(gpu_ctx, w, h, monkeypatch):
     1241 x 376 (KITTI): width % 4 != 0, so level 1 takes the unaligned-load variant of the row kernel."""
     import orbhip
     imgs = orbhip.synth_frames(w, h, 2, seed=91)
+    monkeypatch.setenv("ORBHIP_ROWS_MIN_BATCH", "1")              # (small batches take the tile kernels by default: shorter latency)
     ext, ora = _mk(gpu_ctx, 600)
     rows = ext.extract_host(imgs, (0, 0))
     lv_rows = [[ext.pyramid_level(f, l).copy() for l in range(ext.nlevels)] + [ext.blurred_level(f, l).copy() for l in range(ext.nlevels)] for f in range(2)]
