@@ -1253,6 +1253,7 @@ extern "C" int orbhip_fuse_search_device(orbhip_ctx *ctx, const orbhip_proj_quer
 struct BowSide { const int32_t *node_ids, *node_start, *feat, *nnodes; const orbhip_keypoint *kp; const uint8_t *desc; };
 // KF_MODE: SearchByBoW(KeyFrame*, KeyFrame*) (ORBmatcher.cc:827-967): side F is the second keyframe with its own validity
 // flags, the distance test is strict (:909) and the result is indexed by the first keyframe's feature (vpMatches12).
+#define BOW_BIG_NODE 32        // frame features under one node from which the wave works on the node together
 template <bool KF_MODE>
 __global__ __launch_bounds__(64) void k_search_by_bow(BowSide K, const uint8_t *kf_valid_, const int32_t *nK_, BowSide F, const uint8_t *f_valid_,
                                                       const int32_t *nF_, int max_nodes, int max_n,
@@ -1301,6 +1302,7 @@ __global__ __launch_bounds__(64) void k_search_by_bow(BowSide K, const uint8_t *
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (fids[mid] < nid) lo = mid + 1; else hi = mid; }
         if (lo >= nf || fids[lo] != nid) continue;
         const int f0 = fst[lo], f1 = fst[lo + 1];
+        if (nleft < 0 && f1 - f0 >= BOW_BIG_NODE) continue;                 // big node: the whole wave works on it below
         for (int ik = kst[a]; ik < kst[a + 1]; ik++) {
             const int ri = kfe[ik];
             if (!kvalid[ri]) continue;                                       // :297-302
@@ -1333,6 +1335,73 @@ __global__ __launch_bounds__(64) void k_search_by_bow(BowSide K, const uint8_t *
                 if ((float)b1 < __fmul_rn(nn_ratio, (float)b2)) take(bi);     // :364-391 / :911
                 // the right camera's best: inside the left test's TH_LOW branch, no ratio test ("|| true", :393-396)
                 if (nleft >= 0 && b1r <= SI_TH_LOW) take(bir);
+            }
+        }
+    }
+    // ---- big nodes (coarse vocabularies, relocalisation with levelsup high: hundreds of features under one node): one node at a time, the
+    // keyframe features in order (a frame feature claimed by an earlier one is skipped, :317-321), the 64 lanes over the node's frame
+    // features; best = smallest (distance << 16 | position) -- the scan's strict "<" keeps the first of equal distances --, second best =
+    // distance of the second smallest key.  Nodes are independent of each other (their frame features are disjoint), so doing these
+    // after the lane-parallel pass changes nothing.
+    if (nleft < 0) {
+        for (int a = 0; a < nk; a++) {
+            const int nid = kids[a];
+            int lo = 0, hi = nf;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (fids[mid] < nid) lo = mid + 1; else hi = mid; }
+            if (lo >= nf || fids[lo] != nid) continue;
+            const int f0 = fst[lo], f1 = fst[lo + 1];
+            if (f1 - f0 < BOW_BIG_NODE) continue;
+            __syncthreads();
+            // this lane's frame features of the node (positions lane, lane + 64, ...): indices kept in registers for the whole node
+            int rjs[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) rjs[u] = f0 + lane + 64 * u < f1 ? ffe[f0 + lane + 64 * u] : -1;
+            // the keyframe feature (index, validity, descriptor) is fetched two features ahead: the chain below would otherwise start with
+            // two dependent global round trips per feature
+            const int ik0 = kst[a], ik1 = kst[a + 1];
+            int rq[2]; bool vq[2]; uint4 dq0[2], dq1[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                rq[u] = kfe[min(ik0 + u, ik1 - 1)]; vq[u] = kvalid[rq[u]] != 0; dq0[u] = dK[2 * rq[u]]; dq1[u] = dK[2 * rq[u] + 1];
+            }
+            for (int ik = ik0; ik < ik1; ik++) {
+                const int ri = rq[0]; const bool vk = vq[0];
+                const uint4 a0v = dq0[0], a1v = dq1[0];
+                rq[0] = rq[1]; vq[0] = vq[1]; dq0[0] = dq0[1]; dq1[0] = dq1[1];
+                rq[1] = kfe[min(ik + 2, ik1 - 1)]; vq[1] = kvalid[rq[1]] != 0; dq0[1] = dK[2 * rq[1]]; dq1[1] = dK[2 * rq[1] + 1];
+                if (!vk) continue;
+                uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    if (f0 + 64 * u >= f1) break;                           // uniform
+                    const int rj = rjs[u];
+                    if (rj < 0 || mf[rj] != -1) continue;
+                    const uint32_t key = ((uint32_t)hamming256(a0v, a1v, dlds[2 * rj], dlds[2 * rj + 1]) << 16) | (uint32_t)(lane + 64 * u);
+                    k2 = min(k2, max(k1, key)); k1 = min(k1, key);
+                }
+                for (int jf = f0 + 512 + lane; jf < f1; jf += 64) {           // (nodes of more than 512 frame features)
+                    const int rj = ffe[jf];
+                    if (mf[rj] != -1) continue;
+                    const uint32_t key = ((uint32_t)hamming256(a0v, a1v, dlds[2 * rj], dlds[2 * rj + 1]) << 16) | (uint32_t)(jf - f0);
+                    k2 = min(k2, max(k1, key)); k1 = min(k1, key);
+                }
+                wave_min2_u32_dpp(k1, k2);
+                const int b1 = k1 == 0xFFFFFFFFu ? 256 : (int)(k1 >> 16), b2 = k2 == 0xFFFFFFFFu ? 256 : (int)(k2 >> 16);
+                if ((KF_MODE ? b1 < SI_TH_LOW : b1 <= SI_TH_LOW) && (float)b1 < __fmul_rn(nn_ratio, (float)b2)) {
+                    const int j = ffe[f0 + (int)(k1 & 0xFFFFu)];
+                    if (lane == 0) {
+                        mf[j] = (int16_t)ri;
+                        mine++;
+                        if (check_ori) {
+                            float rot = __fsub_rn(kkp[ri].angle, fkp[j].angle);
+                            if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                            int bin = (int)roundf(__fmul_rn(rot, factor));
+                            if (bin == SI_HISTO) bin = 0;
+                            atomicAdd(&hist[bin], 1); fbin[j] = (int8_t)bin;
+                        }
+                    }
+                    __syncthreads();                                         // mf[j] is read by every lane for the next keyframe feature
+                }
             }
         }
     }
