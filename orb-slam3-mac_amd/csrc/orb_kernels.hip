@@ -792,10 +792,10 @@ __global__ __launch_bounds__(256) void k_octree(OrbParams P)
     __syncthreads();
 
     OCT_T(1);
-    // ---- subdivision loop
+    // ---- subdivision loop.  size / front are the same in every thread (derived from block-wide sums): kept in registers, no LDS broadcast
     bool final_phase = false;
+    int size = s_size, front = s_front;
     for (int guard = 0; guard < 64; guard++) {
-        const int size = s_size, front = s_front;
         // 1. candidate set + processing order
         int C;   // number of candidates
         if (!final_phase) {
@@ -871,13 +871,12 @@ __global__ __launch_bounds__(256) void k_octree(OrbParams P)
         }
         __syncthreads();
         const int rstar = s_rstar;
-        if (tid == 0) {
+        int T, nproc;
+        {   // every thread reads the same LDS words: no single-thread phase, no barrier
             const uint32_t *q = &S.cc[4 * S.by_ord[rstar]];
-            s_T = S.excl[rstar] + (q[0] > 0) + (q[1] > 0) + (q[2] > 0) + (q[3] > 0);
-            s_nproc = rstar + 1;
+            T = S.excl[rstar] + (q[0] > 0) + (q[1] > 0) + (q[2] > 0) + (q[3] > 0);
+            nproc = rstar + 1;
         }
-        __syncthreads();
-        const int T = s_T, nproc = s_nproc;
         // 4. positions of surviving nodes: T + rank among non-processed (old order)
         {
             int run = 0;
@@ -935,24 +934,22 @@ __global__ __launch_bounds__(256) void k_octree(OrbParams P)
 #pragma unroll
         for (int i = 0; i < OCT_KR; i++) if (tid + 256 * i < K) rn[i] = relabel(rk[i], rn[i]);
         for (int k = tid + 256 * OCT_KR; k < K; k += 256) node_of[k] = (uint16_t)relabel(keys[k], node_of[k]);
-        __syncthreads();
-        const int new_size = T + (size - nproc);
+        __syncthreads();                                  // relabelled keys / new node arrays / s_nexpand complete; the next pass re-initialises s_nexpand
+        const int new_size = T + (size - nproc);            // only after its own barrier (step 2), i.e. after every thread has read it here
         const int nexpand = s_nexpand;
-        __syncthreads();
-        if (tid == 0) { s_size = new_size; s_front = T; }
         { uint32_t *t; t = box0; box0 = nbox0; nbox0 = t; t = box1; box1 = nbox1; nbox1 = t; t = cnt; cnt = ncnt; ncnt = t; }
-        __syncthreads();
+        const int old_size = size;
+        size = new_size; front = T;
 #ifdef OCT_PROF
         if (blockIdx.x == 0 && tid == 0) g_oct_prof[5] += 1;
 #endif
         // 7. termination (ORBextractor.cc:661-735)
-        if (new_size >= N || new_size == size) break;
+        if (new_size >= N || new_size == old_size) break;
         if (!final_phase && new_size + 3 * nexpand > N) final_phase = true;
     }
     __syncthreads();
     OCT_T(2);
     // ---- best key per node: max response, first in list order wins (ORBextractor.cc:739-758)
-    const int size = s_size;
     for (int i = tid; i < size; i += 256) S.best[i] = 0;
     __syncthreads();
 #pragma unroll
