@@ -219,3 +219,19 @@ def make_window(seed, n_opt=8, n_fixed_vis=12, n_points=400, stereo_frac=0.5, ou
     if fisheye_rig:
         d.update(camera_model=1, kb=kb, Trl=Trl, cam2=cam2, camera2_model=1, kb2=kb2)
     return Window(d)
+
+
+def load_golden_windows():
+    """tests/golden/iba_golden.npz (made by tools/gen_golden.py from the oracle): [(Window, expected dict)]."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "iba_golden.npz"))
+    res = []
+    for name in ("w0", "w1"):
+        pre = name + "_in_"
+        d = {k[len(pre):]: g[k] for k in g.files if k.startswith(pre)}
+        for k in ("camera_model", "camera2_model"):
+            if k in d:
+                d[k] = int(d[k])
+        res.append((Window(d), {"kf": g[name + "_kf"], "pts": g[name + "_pts"], "outlier": g[name + "_outlier"],
+                                "stats": g[name + "_stats"], "err": g[name + "_err"]}))
+    return res

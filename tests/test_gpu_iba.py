@@ -94,3 +94,17 @@ def test_inertial_ba_rejects_malformed_windows(hip):
     win2.arrays["in_kf1"][0] = 99
     with pytest.raises(orbhip.OrbHipError):
         _gpu_solve(hip, [win2])
+
+
+def test_inertial_ba_golden_fixture_without_oracle(hip):
+    """The HIP solver against the committed vectors of tests/golden/iba_golden.npz (a pinhole window with stereo + mono edges and a
+    two-fisheye rig window, made by the oracle through tools/gen_golden.py) -- no live oracle involved."""
+    from synth_iba import load_golden_windows
+    cases = load_golden_windows()
+    gpu = _gpu_solve(hip, [w for w, _ in cases])
+    for i, (win, exp) in enumerate(cases):
+        st = gpu[3][i]
+        assert [st["iterations_run"], st["lm_trials"], st["n_outliers"], st["failed"]] == exp["stats"].tolist()
+        assert _rmse(gpu[0][i], exp["kf"]) <= 1e-4 and _rmse(gpu[1][i], exp["pts"]) <= 1e-4
+        assert _rmse(gpu[0][i], exp["kf"]) <= 1e-7, "closer than the tolerance in practice: a drift worth looking at"
+        assert np.array_equal(gpu[2][i], exp["outlier"])

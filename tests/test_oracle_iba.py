@@ -143,3 +143,14 @@ def test_fisheye_rig_edges_and_solve():
     e0 = np.linalg.norm(win.kf0[:n, 9:12] - win.d["kf_true"][:n, 9:12], axis=1).mean()
     e1 = np.linalg.norm(kf[:n, 9:12] - win.d["kf_true"][:n, 9:12], axis=1).mean()
     assert e1 < 0.5 * e0
+
+
+def test_iba_golden_regression():
+    """Committed fixture (tests/golden/iba_golden.npz, made by tools/gen_golden.py): guards the inertial oracle itself against drift."""
+    from synth_iba import load_golden_windows
+    for win, exp in load_golden_windows():
+        kf, pts, out, st = ib.solve(win)
+        assert [st.iterations_run, st.lm_trials, st.n_outliers, st.failed] == exp["stats"].tolist()
+        assert np.abs(kf - exp["kf"]).max() <= 1e-9 and np.abs(pts - exp["pts"]).max() <= 1e-9
+        assert np.array_equal(out, exp["outlier"])
+        assert abs(st.err - exp["err"][0]) <= 1e-9 * abs(exp["err"][0]) and abs(st.err_end - exp["err"][1]) <= 1e-6 * max(1.0, abs(exp["err"][1]))

@@ -33,6 +33,7 @@ def main():
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "orb_golden.npz"), **out)
     pose_goldens()
     match_goldens()
+    iba_goldens()
 
 
 def pose_goldens():
@@ -86,5 +87,32 @@ def match_goldens():
     print("match goldens:", n0, n1, int((bi >= 0).sum()), nb, nk, nt, len(bw))
 
 
+IBA_KEYS = ("kf_fixed", "kf_imu", "edge_kf", "edge_point", "edge_obs", "edge_stereo", "edge_inv_sigma2", "edge_close", "in_kf1", "in_kf2",
+            "in_preint", "in_info", "in_info_g", "in_info_a", "in_robust", "kf_state", "points", "cam", "Rcb", "tcb")
+IBA_OPT = ("camera_model", "kb", "Trl", "cam2", "camera2_model", "kb2")
+
+
+def iba_goldens():
+    """Two small LocalInertialBA windows (pinhole with stereo + mono edges; two-fisheye rig) with the oracle's result."""
+    import oracle_iba_bind as ib
+    out = {}
+    for name, kw in (("w0", dict(seed=501, n_opt=4, n_fixed_vis=3, n_points=80)), ("w1", dict(seed=502, n_opt=3, n_fixed_vis=2, n_points=60, fisheye_rig=True))):
+        win = ib.make_window(**kw)
+        for k in IBA_KEYS:
+            out["%s_in_%s" % (name, k)] = np.asarray(win.d[k])
+        for k in IBA_OPT:
+            if k in win.d:
+                out["%s_in_%s" % (name, k)] = np.asarray(win.d[k])
+        kf, pts, outl, st = ib.solve(win)
+        out[name + "_kf"] = kf; out[name + "_pts"] = pts; out[name + "_outlier"] = outl
+        out[name + "_stats"] = np.array([st.iterations_run, st.lm_trials, st.n_outliers, st.failed], np.int32)
+        out[name + "_err"] = np.array([st.err, st.err_end])
+        print("iba golden", name, win.n_edges, st.iterations_run, st.lm_trials, st.n_outliers, st.failed)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "iba_golden.npz"), **out)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "iba":
+        iba_goldens()
+    else:
+        main()
