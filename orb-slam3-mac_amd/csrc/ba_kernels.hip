@@ -2507,7 +2507,10 @@ extern "C" int orbhip_pose_optimization_device(orbhip_ctx *ctx, const double *d_
     A.cam2_model = cam2 ? cam2->camera_model : 0; for (int k = 0; k < 4; k++) A.kb2[k] = cam2 ? cam2->kb[k] : 0.0;
     A.stats = d_stats;
     const bool general = A.cam_model || A.right;
-    if (max_edges <= 2048 && !getenv("ORBHIP_POSE_BLOCK")) {            // outlier bits: 32 per lane
+    // one wave per frame is the throughput form (1024 frames: 1.26 ms vs 2.0 ms); four waves per frame have the shorter latency while
+    // the frames fit one round of workgroups (1 frame: 0.36 ms vs 0.71 ms, 64 frames: 0.64 vs 1.12 ms)
+    const int wave_min_frames = getenv("ORBHIP_POSE_WAVE_MIN_FRAMES") ? atoi(getenv("ORBHIP_POSE_WAVE_MIN_FRAMES")) : 513;
+    if (max_edges <= 2048 && frames >= wave_min_frames) {                // outlier bits: 32 per lane
         if (general) hipLaunchKernelGGL(k_pose_opt_wave<true>, dim3(frames), dim3(64), 0, orbhip_ctx_stream_internal(ctx), A);
         else hipLaunchKernelGGL(k_pose_opt_wave<false>, dim3(frames), dim3(64), 0, orbhip_ctx_stream_internal(ctx), A);
     } else {

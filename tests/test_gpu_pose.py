@@ -7,6 +7,14 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["block", "wave"])
+def pose_kernel_family(request, monkeypatch):
+    """Both kernels on every test: four waves per frame (the default below 513 frames: shorter latency) and one wave per frame with
+    the edges in registers (the throughput form)."""
+    monkeypatch.setenv("ORBHIP_POSE_WAVE_MIN_FRAMES", "1" if request.param == "wave" else "1000000")
+    return request.param
+
+
 def _run(gpu_ctx, probs, max_edges):
     import torch
     import orbhip
