@@ -485,9 +485,9 @@ def main():
         bb.set_profiling(False)
         bb.close()
         # the same batch through the FP64-MFMA panel GEMM (the round-1 design, selectable): reported beside the default
-        orbhip.ba_set_schur_mode(2)
+        orbhip.ba_set_schur_mode(ctx, 2)
         bg = orbhip.BaBatch(ctx, glist)
-        orbhip.ba_set_schur_mode(0)
+        orbhip.ba_set_schur_mode(ctx, 0)
         bg.solve()
         sync()
         t0 = time.perf_counter()
@@ -550,7 +550,7 @@ def main():
                                                  "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),
                                                  "mfma_flops_of_data_tiles_per_launch": gemm_fl, "mfma_flops_issued_per_launch": gemm_issued,
                                                  "flops_per_launch_without_sparsity_skipping": gemm_dense},
-                                    "note": "orbhip_ba_set_schur_mode(2): S = Z^T Z on v_mfma_f64_16x16x4_f64 with block-sparsity skipping (the round-1 "
+                                    "note": "orbhip_ctx_set_ba_schur_mode(ctx, 2): S = Z^T Z on v_mfma_f64_16x16x4_f64 with block-sparsity skipping (the round-1 "
                                             "design); 16x16 tiles of 6-row blocks are mostly zeros, so it issues ~9x the useful flops"}}
 
     # ---- landmark-sharded single-graph mode (optional): the SAME graphs solved by all ranks together, the shared Schur

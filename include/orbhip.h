@@ -512,10 +512,11 @@ void orbhip_ba_global_params(orbhip_ba_params *p, int iterations, int robust);
  * the outlier gates entirely on the device (restarting from the initial estimates each call);
  * download copies estimates / outlier flags / stats back. */
 typedef struct orbhip_ba_batch orbhip_ba_batch;
-/* How batches created AFTER this call form the Schur complement (process-wide): 0 / 1 = from per-block-pair lists, one 16-lane row
- * per pair of free keyframes (default: measured faster at every batch size), 2 = the FP64-MFMA panel GEMM (up to 80 free keyframes;
- * always used by the landmark-sharded mode).  Results agree to rounding (different summation orders). */
-int orbhip_ba_set_schur_mode(int mode);
+/* How BA batches created on this context AFTERWARDS form the Schur complement (a property of the context: two contexts may differ,
+ * and orbhip_ba_solve_batch follows its context too): 0 / 1 = from per-block-pair lists, one 16-lane row per pair of free keyframes
+ * (default: measured faster at every batch size), 2 = the FP64-MFMA panel GEMM (up to 80 free keyframes; always used by the
+ * landmark-sharded mode).  Results agree to rounding (different summation orders); both are parity-tested against the oracle. */
+int orbhip_ctx_set_ba_schur_mode(orbhip_ctx *ctx, int mode);
 int orbhip_ba_batch_create(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_graphs,
                            double *const *poses, double *const *points, orbhip_ba_batch **out);
 int orbhip_ba_batch_solve(orbhip_ba_batch *b, const orbhip_ba_params *params, volatile const uint8_t *abort);
@@ -614,6 +615,12 @@ void orbhip_iba_default_params(orbhip_iba_params *p, int large);
 int orbhip_inertial_ba_solve_batch(orbhip_ctx *ctx, const orbhip_iba_window *windows, int n_windows, const orbhip_iba_params *params,
                                    double *const *kf_state_inout, double *const *points_inout, uint8_t *const *edge_outlier_out,
                                    orbhip_iba_stats *stats_out);
+/* Diagnostics: workgroups per window ("team size" G) of the calling thread's latest inertial solve.  Small batches give a window a
+ * team of up to 16 workgroups that meet at a device-wide barrier, which needs the whole grid resident: only ONE team grid runs per
+ * device at a time (in-process mutex + advisory file lock /tmp/.orbhip_team_gpu<N>.lock); a solve that finds one in flight, and
+ * every batch of more than ~128 windows, runs G = 1.  Results for different G agree to rounding (summation order), identical LM
+ * decisions in every tested case.  ORBHIP_IBA_TEAM=<n> caps G (tests). */
+int orbhip_inertial_ba_last_team_size(void);
 
 /* ------------------------------------------------------------------ pose-only BA
  * Optimizer::PoseOptimization (src/Optimizer.cc:854-1168), batched over frames: per frame one free

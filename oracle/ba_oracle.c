@@ -610,6 +610,15 @@ static int optimize(struct ba *B, int iterations, double *chi_first, double *chi
 int orc_ba_solve(const orc_ba_graph *g, const orc_ba_params *p, const volatile uint8_t *abort_flag,
                  double *poses, double *points, uint8_t *edge_outlier, orc_ba_stats *stats)
 {
+    return orc_ba_solve_ex(g, p, abort_flag, poses, points, edge_outlier, stats, NULL, NULL);
+}
+
+/* as orc_ba_solve; edge_chi2_out / edge_depth_out [n_edges] (may be NULL) = the two numbers the outlier gates of LBA:2126-2173 test,
+ * so that a checker can tell a flag that sits on the gate from a real disagreement */
+int orc_ba_solve_ex(const orc_ba_graph *g, const orc_ba_params *p, const volatile uint8_t *abort_flag,
+                    double *poses, double *points, uint8_t *edge_outlier, orc_ba_stats *stats,
+                    double *edge_chi2_out, double *edge_depth_out)
+{
     orc_ba_stats st; memset(&st, 0, sizeof(st));
     if (abort_flag && *abort_flag) { if (stats) *stats = st; return -5; }          /* LBA:2041-2043 */
     struct ba B; memset(&B, 0, sizeof(B));
@@ -665,6 +674,8 @@ int orc_ba_solve(const orc_ba_graph *g, const orc_ba_params *p, const volatile u
         const double gate = g->edge_stereo[e] == 1 ? gate_s : gate_m;
         const int out = (B.chi2[e] > gate) || !(zc > 0.0);
         if (edge_outlier) edge_outlier[e] = (uint8_t)out;
+        if (edge_chi2_out) edge_chi2_out[e] = B.chi2[e];
+        if (edge_depth_out) edge_depth_out[e] = zc;
         st.n_outliers += out;
     }
     if (!p->no_discard && st.n_outliers >= B.E * 0.5 && B.E > 0) st.discarded = 1;           /* LBA:2177-2181 */

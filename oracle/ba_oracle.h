@@ -60,6 +60,9 @@ void orc_ba_global_params(orc_ba_params *p, int iterations, int robust);   /* Op
 /* Returns 0 ok, -5 aborted before start.  poses [n_poses*7] (qx,qy,qz,qw,tx,ty,tz), points [n_points*3]. */
 int orc_ba_solve(const orc_ba_graph *g, const orc_ba_params *p, const volatile uint8_t *abort_flag,
                  double *poses, double *points, uint8_t *edge_outlier, orc_ba_stats *stats);
+int orc_ba_solve_ex(const orc_ba_graph *g, const orc_ba_params *p, const volatile uint8_t *abort_flag,
+                    double *poses, double *points, uint8_t *edge_outlier, orc_ba_stats *stats,
+                    double *edge_chi2_out, double *edge_depth_out);   /* + the stored chi2 and the depth the outlier gates test */
 
 /* unit-test hooks */
 void orc_se3_exp(const double upd6[6], double q_out[4], double t_out[3]);          /* se3quat.h:223-257 */

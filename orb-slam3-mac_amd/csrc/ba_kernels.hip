@@ -35,6 +35,7 @@
 struct orbhip_ctx;
 hipStream_t orbhip_ctx_stream_internal(orbhip_ctx *c);
 int orbhip_ctx_device_internal(orbhip_ctx *c);
+int orbhip_ctx_ba_schur_mode_internal(orbhip_ctx *c);
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -1510,14 +1511,6 @@ static T *ba_upload(orbhip_ba_batch *b, const std::vector<T> &v)
     return d;
 }
 
-static std::atomic<int> g_schur_mode{0};
-extern "C" int orbhip_ba_set_schur_mode(int mode)
-{
-    if (mode < 0 || mode > 2) return ORBHIP_E_BADARG;
-    g_schur_mode.store(mode);
-    return ORBHIP_OK;
-}
-
 extern "C" void orbhip_ba_default_params(orbhip_ba_params *p)
 {
     p->iters1 = 5; p->iters2 = 10; p->huber_mono2 = 5.991; p->huber_stereo2 = 7.815;
@@ -1746,8 +1739,8 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
     std::vector<int> pair_start, pair_pt; std::vector<int2> pair_ent;
     B.big = any_big ? 1 : 0;
     // Schur complement: per-block-pair lists (k_ba_schur_big) by default -- measured faster than the MFMA panel GEMM at every batch
-    // size -- the GEMM on request (orbhip_ba_set_schur_mode(2)), in the landmark-sharded mode and never for big windows
-    int mode = g_schur_mode.load();
+    // size -- the GEMM on request (orbhip_ctx_set_ba_schur_mode(ctx, 2), a property of the context the batch is created on), in the landmark-sharded mode and never for big windows
+    int mode = orbhip_ctx_ba_schur_mode_internal(ctx);
     if (const char *ev = getenv("ORBHIP_BA_PAIRS")) mode = atoi(ev) ? 1 : 2;                                                    // development override
     const bool pair_lists = any_big || (world == 1 && mode != 2);
     B.pair_schur = pair_lists ? 1 : 0;

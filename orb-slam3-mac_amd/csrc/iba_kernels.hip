@@ -29,6 +29,10 @@
 #include <vector>
 #include <thread>
 #include <functional>
+#include <mutex>
+#include <fcntl.h>
+#include <unistd.h>
+#include <sys/file.h>
 
 hipStream_t orbhip_ctx_stream_internal(orbhip_ctx *c);
 int orbhip_ctx_device_internal(orbhip_ctx *c);
@@ -959,6 +963,36 @@ struct Blob {                        // host image of the constant device data; 
     }
 };
 inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+// One TEAM grid per device at a time.  The team barrier needs every workgroup of the grid resident; the grid is sized for an otherwise
+// empty device, so two team grids in flight (two contexts / threads / processes) could each hold compute units the other waits for.
+// A solve that wants teams takes this lock without blocking -- an in-process mutex per device plus an advisory file lock for other
+// processes of this library -- from launch to completion; a solve that does not get it runs one workgroup per window (G = 1: the
+// barrier is a __syncthreads, no residency assumption).  Kernels WITHOUT spin barriers running beside a team grid only delay it: they
+// finish on their own and free their compute units (the bounded spin, seconds long, is the last line of defence).
+static thread_local int g_iba_last_team = 0;
+extern "C" int orbhip_inertial_ba_last_team_size(void) { return g_iba_last_team; }
+
+struct IbaTeamLock {
+    int device = -1, fd = -1; bool held = false;
+    static std::mutex &mu(int device) { static std::mutex m[64]; return m[device & 63]; }
+    bool try_acquire(int dev)
+    {
+        if (!mu(dev).try_lock()) return false;
+        char path[64];
+        snprintf(path, sizeof(path), "/tmp/.orbhip_team_gpu%d.lock", dev);
+        fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+        if (fd >= 0 && flock(fd, LOCK_EX | LOCK_NB) != 0) { close(fd); fd = -1; mu(dev).unlock(); return false; }
+        device = dev; held = true;                              // (no lock file, e.g. read-only /tmp: the in-process lock alone)
+        return true;
+    }
+    ~IbaTeamLock()
+    {
+        if (!held) return;
+        if (fd >= 0) { flock(fd, LOCK_UN); close(fd); }
+        mu(device).unlock();
+    }
+};
+
 #define ITRY(e) do { if ((e) != hipSuccess) { orbhip_set_last_error_internal(#e); return ORBHIP_E_HIP; } } while (0)
 // Host-side packing of windows [w0, w1) into one IbaPack: SoA arrays, per-keyframe edge lists, per-pair block lists, task lists, edge colours.
 // Every offset stored in hw[w] is relative to THIS pack; orbhip_inertial_ba_solve_batch packs chunks of windows on several host threads
@@ -1278,7 +1312,10 @@ extern "C" int orbhip_inertial_ba_solve_batch(orbhip_ctx *ctx, const orbhip_iba_
     int G = std::min(IBA_MAXG, slots_per_xcd / win_per_xcd);
     if (forced > 0) G = std::min(forced, G);
     if (G < 2 || per_cu < 1) G = 1;
+    IbaTeamLock team_lock;                                           // released when this (synchronous) call returns
+    if (G > 1 && !team_lock.try_acquire(device)) G = 1;              // another team grid is in flight on this device
     A.G = G;
+    g_iba_last_team = G;
     if (G == 1) {
         hipLaunchKernelGGL(k_iba_solve, dim3(n_windows), dim3(IBA_THREADS), lds, s, A);
         ITRY(hipGetLastError());

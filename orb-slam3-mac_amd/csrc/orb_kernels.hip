@@ -598,7 +598,7 @@ void orb_launch_fast_cells(const FastParams &F_, hipStream_t s, int max_per_cu, 
     int per_cu = (int)((160 * 1024) / (lds + 512));
     per_cu = per_cu > 24 ? 24 : per_cu < 1 ? 1 : per_cu;
     if (max_per_cu > 0 && per_cu > max_per_cu) per_cu = max_per_cu;      // leave LDS and wave slots to a kernel running beside this one
-    long nblocks = 256L * per_cu;
+    long nblocks = (long)(F.n_cus > 0 ? F.n_cus : 256) * per_cu;
     const long total = (long)F.batch * ((F.lvl_hi < F.nlevels ? F.lv[F.lvl_hi].cell_base : F.cells_per_frame) - F.lv[F.lvl_lo].cell_base);
     if (nblocks > total) nblocks = (total + 7) / 8 * 8;
     if (F.small_cells) hipLaunchKernelGGL((k_fast_cells<3, 24, 2>), dim3((unsigned)nblocks), dim3(64), lds, s, F);
@@ -1270,7 +1270,7 @@ void orb_launch_blur(const OrbParams &P, hipStream_t s, int wgs_per_cu, int fram
     }
     if (frame0 > 0) return;                                    // the tile kernel always takes the whole batch (first call)
     const long total = (long)P.bs_tiles[P.nlevels] * P.batch;
-    long nblocks = 256L * wgs_per_cu;                           // persistent: 8 workgroups (32 waves) per CU when alone on the chip
+    long nblocks = (long)(P.n_cus > 0 ? P.n_cus : 256) * wgs_per_cu;                           // persistent: 8 workgroups (32 waves) per CU when alone on the chip
     if (nblocks > total) nblocks = total;
     hipLaunchKernelGGL(k_blur, dim3((unsigned)nblocks), dim3(256), 0, s, P);
 }

@@ -50,6 +50,8 @@ struct orbhip_ctx {
     int32_t *d_status;      // sticky device-side error word (capacity overflows in matcher kernels)
     void *scratch;          // grow-only device arena of the host-pointer convenience entry points (host_entry.hip)
     size_t scratch_bytes;
+    int n_cus;              // hipDeviceAttributeMultiprocessorCount of `device`: persistent grids are sized from it
+    int ba_schur_mode;      // orbhip_ctx_set_ba_schur_mode
 };
 
 extern "C" int orbhip_ctx_create(int device, void *stream, orbhip_ctx **out)
@@ -74,7 +76,8 @@ extern "C" int orbhip_ctx_create(int device, void *stream, orbhip_ctx **out)
         if (c->own_stream) (void)hipStreamDestroy(c->stream);
         delete c; g_last_error = "hipMalloc(status)"; return ORBHIP_E_HIP;
     }
-    c->scratch = nullptr; c->scratch_bytes = 0;
+    c->scratch = nullptr; c->scratch_bytes = 0; c->ba_schur_mode = 0; c->n_cus = 0;
+    if (hipDeviceGetAttribute(&c->n_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->n_cus <= 0) c->n_cus = 256;
     *out = c;
     return ORBHIP_OK;
 }
@@ -118,6 +121,14 @@ extern "C" int orbhip_ctx_synchronize(orbhip_ctx *c)
 extern "C" void *orbhip_ctx_stream(orbhip_ctx *c) { return c ? (void *)c->stream : nullptr; }
 hipStream_t orbhip_ctx_stream_internal(orbhip_ctx *c) { return c->stream; }
 int orbhip_ctx_device_internal(orbhip_ctx *c) { return c->device; }
+int orbhip_ctx_cus_internal(orbhip_ctx *c) { return c->n_cus; }
+int orbhip_ctx_ba_schur_mode_internal(orbhip_ctx *c) { return c->ba_schur_mode; }
+extern "C" int orbhip_ctx_set_ba_schur_mode(orbhip_ctx *c, int mode)
+{
+    if (!c || mode < 0 || mode > 2) return ORBHIP_E_BADARG;
+    c->ba_schur_mode = mode;
+    return ORBHIP_OK;
+}
 
 // ------------------------------------------------------------------------------------
 static inline int cv_round_f(float v) { return (int)lrintf(v); }   // round-half-even
@@ -545,7 +556,7 @@ static int tune_int(const char *name, int dflt) { const char *v = getenv(name); 
 static int run_pipeline(orbhip_extractor *e, int batch, int lap0, int lap1)
 {
     OrbParams &P = e->P;
-    P.batch = batch; P.lap0 = lap0; P.lap1 = lap1;
+    P.batch = batch; P.lap0 = lap0; P.lap1 = lap1; P.n_cus = e->ctx->n_cus;
     hipStream_t s = e->ctx->stream;
     const bool prof = e->profiling;
     const int slot = e->ev_calls % ORBHIP_PROF_SLOTS;
@@ -561,7 +572,7 @@ static int run_pipeline(orbhip_extractor *e, int batch, int lap0, int lap1)
     }
     FastParams &F = e->F;
     for (int l = 0; l < e->nlevels; l++) { F.lv[l].img = P.lv[l].img; F.lv[l].frame_stride = P.lv[l].img_frame_stride; F.lv[l].img_pitch = P.lv[l].img_pitch; }
-    F.batch = batch; F.cell_count = P.cell_count; F.cell_list = P.cell_list; F.cell_list_frame_stride = P.cell_list_frame_stride; F.status = P.status;
+    F.batch = batch; F.n_cus = e->ctx->n_cus; F.cell_count = P.cell_count; F.cell_list = P.cell_list; F.cell_list_frame_stride = P.cell_list_frame_stride; F.status = P.status;
     const bool rows = P.br_blocks[e->nlevels] > 0 && batch >= P.rows_min_batch;      // the row-streaming blur needs no LDS: k_fast_cells keeps its full grid
     const int fast_waves = fork ? tune_int("ORBHIP_TUNE_FAST_WAVES", rows ? 0 : 10) : 0;
     STAGE_MARK(ORBHIP_STAGE_PYRAMID);

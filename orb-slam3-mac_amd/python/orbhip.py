@@ -351,12 +351,12 @@ def mfma_f64_peak_tflops(ctx):
     return v.value
 
 
-lib.orbhip_ba_set_schur_mode.argtypes = [ci]
+lib.orbhip_ctx_set_ba_schur_mode.argtypes = [vp, ci]
 
 
-def ba_set_schur_mode(mode):
-    """0 / 1 = pair lists (default), 2 = FP64-MFMA panel GEMM; applies to batches created afterwards."""
-    _chk(lib.orbhip_ba_set_schur_mode(mode), "orbhip_ba_set_schur_mode")
+def ba_set_schur_mode(ctx, mode):
+    """0 / 1 = pair lists (default), 2 = FP64-MFMA panel GEMM; a property of the context, read when a batch is created on it."""
+    _chk(lib.orbhip_ctx_set_ba_schur_mode(ctx.h, mode), "orbhip_ctx_set_ba_schur_mode")
 
 
 def ba_merge_params():
@@ -549,6 +549,11 @@ def inertial_ba_solve_batch(ctx, windows, kf_states, points, params=None):
     _chk(lib.orbhip_inertial_ba_solve_batch(ctx.h, C.cast(arr, vp), n, C.byref(p), C.cast(pk, vp), C.cast(pq, vp), C.cast(po, vp),
                                             C.cast(stats, vp)), "orbhip_inertial_ba_solve_batch")
     return kfs, pts, [o[:w.n_edges] for o, w in zip(outl, windows)], [st.as_dict() for st in stats]
+
+
+def inertial_ba_last_team_size():
+    """Workgroups per window of this thread's latest inertial solve (1 = no device-wide barrier)."""
+    return int(lib.orbhip_inertial_ba_last_team_size())
 
 
 class Camera2(C.Structure):

@@ -34,6 +34,7 @@ class Stats(C.Structure):
 lib.orc_ba_default_params.argtypes = [C.POINTER(Params)]
 lib.orc_ba_merge_params.argtypes = [C.POINTER(Params)]
 lib.orc_ba_solve.argtypes = [C.POINTER(Graph), C.POINTER(Params), vp, vp, vp, vp, C.POINTER(Stats)]
+lib.orc_ba_solve_ex.argtypes = [C.POINTER(Graph), C.POINTER(Params), vp, vp, vp, vp, C.POINTER(Stats), vp, vp]
 lib.orc_se3_exp.argtypes = [vp, vp, vp]
 lib.orc_se3_oplus.argtypes = [vp, vp]
 lib.orc_ba_edge.argtypes = [vp, vp, vp, ci, cd, cd, cd, cd, cd, vp, vp, vp]
@@ -89,6 +90,21 @@ def solve(g, params=None, abort=None):
     ab = abort.ctypes.data if abort is not None else None
     rc = lib.orc_ba_solve(C.byref(cg), C.byref(p), ab, poses.ctypes.data, pts.ctypes.data, out.ctypes.data, C.byref(st))
     return rc, poses, pts, out[:g["n_edges"]], st.as_dict()
+
+
+def solve_with_gate_values(g, params=None):
+    """solve() plus the stored chi2 and the depth of every edge at the end (what the outlier gates of Optimizer.cc:2126-2173 test)."""
+    p = params or default_params()
+    cg, keep = make_cgraph(g)
+    poses = np.ascontiguousarray(g["poses0"], np.float64).copy()
+    pts = np.ascontiguousarray(g["points0"], np.float64).copy()
+    n = max(g["n_edges"], 1)
+    out = np.zeros(n, np.uint8); chi2 = np.zeros(n); depth = np.zeros(n)
+    st = Stats()
+    rc = lib.orc_ba_solve_ex(C.byref(cg), C.byref(p), None, poses.ctypes.data, pts.ctypes.data, out.ctypes.data, C.byref(st),
+                             chi2.ctypes.data, depth.ctypes.data)
+    E = g["n_edges"]
+    return rc, poses, pts, out[:E], st.as_dict(), chi2[:E], depth[:E]
 
 
 # ------------------------------------------------------------------ PoseOptimization oracle

@@ -69,6 +69,68 @@ def test_inertial_ba_batch_of_windows_and_determinism(hip):
         assert np.array_equal(gpu[0][i], again[0][i]) and np.array_equal(gpu[1][i], again[1][i])      # fixed summation orders
 
 
+@pytest.mark.parametrize("team", [1, 2, 5, 16])
+def test_inertial_ba_every_team_size(hip, team, monkeypatch):
+    """The summation order of the team-wide sums depends on the team size G (team_sum2): every G the launch rule can pick -- 1 is
+    what batches of more than ~128 windows and every solve that finds another team grid in flight run -- must reproduce the oracle's
+    LM decisions and estimates.  ORBHIP_IBA_TEAM caps G; the diagnostic says what ran."""
+    orbhip, _ = hip
+    monkeypatch.setenv("ORBHIP_IBA_TEAM", str(team))
+    wins = [ib.make_window(60 + i, n_opt=4 + 3 * i, n_fixed_vis=5 + 6 * i, n_points=150 + 250 * i, fisheye_rig=(i == 1)) for i in range(3)]
+    gpu = _gpu_solve(hip, wins)
+    assert orbhip.inertial_ba_last_team_size() == team
+    for i, w in enumerate(wins):
+        _compare(w, [x[i] for x in gpu], ib.solve(w))
+
+
+def test_inertial_ba_many_windows_take_the_single_workgroup_path(hip):
+    """More windows than the device holds teams for: G = 1 by the launch rule itself (no environment override)."""
+    orbhip, _ = hip
+    base = [ib.make_window(70 + i, n_opt=3 + i, n_fixed_vis=2 + i, n_points=60 + 30 * i) for i in range(4)]
+    wins = [base[i % 4] for i in range(160)]
+    gpu = _gpu_solve(hip, wins)
+    assert orbhip.inertial_ba_last_team_size() == 1
+    cpu = [ib.solve(w) for w in base]
+    for i in range(160):
+        _compare(wins[i], [x[i] for x in gpu], cpu[i % 4])
+
+
+def test_inertial_ba_two_contexts_solve_concurrently(hip):
+    """Two host threads, a context each, solving at the same time on one device: only one team grid may be in flight (the team
+    barrier needs its whole grid resident), the other solve falls back to one workgroup per window.  Both must succeed and match
+    the oracle; over the repetitions both kinds of launch occur."""
+    import threading
+    orbhip, _ = hip
+    wins = [ib.make_window(80 + i, n_opt=6 + i, n_fixed_vis=8, n_points=400 + 100 * i) for i in range(2)]
+    cpu = [ib.solve(w) for w in wins]
+    ctxs = [orbhip.Context(0) for _ in range(2)]
+    errs, teams = [], [[], []]
+    start = threading.Barrier(2)
+
+    def run(r):
+        try:
+            for rep in range(6):
+                start.wait(timeout=120)
+                gpu = _gpu_solve((orbhip, ctxs[r]), [wins[r]] * 3)
+                teams[r].append(orbhip.inertial_ba_last_team_size())
+                for k in range(3):
+                    _compare(wins[r], [x[k] for x in gpu], cpu[r])
+        except BaseException as e:                       # noqa: BLE001 (reported below)
+            errs.append((r, repr(e)))
+            start.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(300)
+    for c in ctxs:
+        c.close()
+    assert not errs, errs
+    assert all(len(t) == 6 for t in teams)
+    assert any(g > 1 for t in teams for g in t), teams   # teams are still used when the device is free
+
+
 def test_inertial_ba_fail_check_leaves_inputs(hip):
     win = ib.make_window(13, n_opt=4, n_fixed_vis=3, n_points=60)
     win.arrays["in_preint"][:, 13:16] += 40.0
