@@ -103,7 +103,7 @@ def cpu_baseline(w, h, nfeat, seconds_budget=20.0):
     with ThreadPoolExecutor(cores) as ex:
         done = sum(ex.map(work, range(cores)))
     dt = time.time() - t0
-    return {"value": round(done / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+    return {"value": round(done / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port", "single_thread_ms": round(t1 * 1e3, 3),
             "sample": "%d threads x %d frames %dx%d, %d feats, extract + BF 2-NN + SearchForInitialization vs successor; "
                       "single-thread %.2f frames/s" % (cores, per_thread, w, h, nfeat, 1.0 / t1)}
 
@@ -128,7 +128,7 @@ def pose_cpu_baseline(probs, seconds_budget=6.0):
     with ThreadPoolExecutor(cores) as ex:
         done = sum(ex.map(work, range(cores)))
     dt = time.time() - t0
-    return {"value": round(done / dt, 1), "unit": "frames/s", "cores": cores, "kind": "port",
+    return {"value": round(done / dt, 1), "unit": "frames/s", "cores": cores, "kind": "port", "single_thread_ms": round(t1 * 1e3, 3),
             "sample": "%d threads x %d frames of 1000 unary edges; single-thread %.1f frames/s" % (cores, per_thread, 1.0 / t1)}
 
 
@@ -150,7 +150,7 @@ def ba_cpu_baseline(graphs, seconds_budget=12.0):
     with ThreadPoolExecutor(cores) as ex:
         done = sum(ex.map(work, range(cores)))
     dt = time.time() - t0
-    return {"value": round(done / dt, 2), "unit": "solves/s", "cores": cores, "kind": "port",
+    return {"value": round(done / dt, 2), "unit": "solves/s", "cores": cores, "kind": "port", "single_thread_ms": round(t1 * 1e3, 3),
             "sample": "%d threads x %d solves of the 50KFx2000ptx10obs graph; single-thread %.2f solves/s"
                       % (cores, per_thread, 1.0 / t1)}
 
@@ -173,8 +173,74 @@ def iba_cpu_baseline(wins, seconds_budget=6.0):
     with ThreadPoolExecutor(cores) as ex:
         done = sum(ex.map(work, range(cores)))
     dt = time.time() - t0
-    return {"value": round(done / dt, 2), "unit": "windows/s", "cores": cores, "kind": "port",
+    return {"value": round(done / dt, 2), "unit": "windows/s", "cores": cores, "kind": "port", "single_thread_ms": round(t1 * 1e3, 3),
             "sample": "%d threads x %d solves of the bench windows; single-thread %.1f ms per window" % (cores, per_thread, t1 * 1e3)}
+
+
+def tracking_cpu_baseline(kp_h, desc_h, cnt_h, q, bounds, seconds_budget=5.0):
+    """Oracle ORBmatcher::SearchByProjection (last frame and local map) on the pairs of the tracking leg: kind 'port'."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    import oracle_match_bind as om
+    cores = min(os.cpu_count() or 1, 16)
+    B = len(cnt_h)
+
+    def pair(i, which):
+        a, b = i % (B - 1), i % (B - 1) + 1
+        na, nb = int(cnt_h[a]), int(cnt_h[b])
+        tm = np.full(nb, -1, np.int32)
+        if which == 0:
+            return om.search_by_projection(q[a, :na], desc_h[a, :na], kp_h[b, :nb], desc_h[b, :nb], None, bounds, tm, 100, True)[0]
+        return om.search_by_projection_map(q[a, :na], desc_h[a, :na], kp_h[b, :nb], desc_h[b, :nb], None, bounds, tm, 100, 0.8)[0]
+    out = {}
+    for which, name in ((0, "search_by_projection_last_frame"), (1, "search_by_projection_local_map")):
+        pair(0, which)
+        t0 = time.time()
+        for i in range(3):
+            pair(i, which)
+        t1 = (time.time() - t0) / 3
+        per_thread = max(4, min(200, int(seconds_budget / 2 / max(t1, 1e-4))))
+
+        def work(tid):
+            for i in range(per_thread):
+                pair(tid * per_thread + i, which)
+            return per_thread
+        t0 = time.time()
+        with ThreadPoolExecutor(cores) as ex:
+            done = sum(ex.map(work, range(cores)))
+        dt = time.time() - t0
+        out[name] = {"value": round(done / dt, 1), "unit": "frame pairs/s", "cores": cores, "kind": "port", "single_thread_ms": round(t1 * 1e3, 3),
+                     "sample": "%d threads x %d pairs of the leg's own queries / keypoints" % (cores, per_thread)}
+    return out
+
+
+def stereo_cpu_baseline(lefts, rights, nfeat, mb, mbf, seconds_budget=8.0):
+    """Oracle stereo front-end (two extractions + Frame::ComputeStereoMatches) on pairs of the stereo leg: kind 'port'."""
+    from concurrent.futures import ThreadPoolExecutor
+    import oracle_bind as ob
+    cores = min(os.cpu_count() or 1, 16)
+
+    def one(eL, eR, j):
+        kl, dl, _ = eL.extract(lefts[j], (0, 0))
+        kr, dr, _ = eR.extract(rights[j], (0, 0))
+        return ob.compute_stereo_matches(eL, eR, kl, dl, kr, dr, mb, mbf)[0]
+    eL, eR = ob.OracleExtractor(nfeat, 1.2, 8, 20, 7), ob.OracleExtractor(nfeat, 1.2, 8, 20, 7)
+    t0 = time.time()
+    one(eL, eR, 0)
+    t1 = time.time() - t0
+    per_thread = max(1, min(24, int(seconds_budget / max(t1, 1e-3))))
+
+    def work(tid):
+        a, b = ob.OracleExtractor(nfeat, 1.2, 8, 20, 7), ob.OracleExtractor(nfeat, 1.2, 8, 20, 7)
+        for i in range(per_thread):
+            one(a, b, (tid * per_thread + i) % len(lefts))
+        return per_thread
+    t0 = time.time()
+    with ThreadPoolExecutor(cores) as ex:
+        done = sum(ex.map(work, range(cores)))
+    dt = time.time() - t0
+    return {"value": round(done / dt, 2), "unit": "pairs/s", "cores": cores, "kind": "port", "single_thread_ms": round(t1 * 1e3, 3),
+            "sample": "%d threads x %d pairs of the leg's own images: 2 x extract + ComputeStereoMatches" % (cores, per_thread)}
 
 
 def parse_args(argv=None):
@@ -200,6 +266,9 @@ def parse_args(argv=None):
     ap.add_argument("--inertial-windows", type=int, default=32, help="LocalInertialBA windows solved per call (0 = skip)")
     ap.add_argument("--stereo-pairs", type=int, default=None, help="rectified stereo pairs for the ComputeStereoMatches leg (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", dest="latency", action="store_false", help="skip the batch-1 latency object")
+    ap.add_argument("--no-hd-leg", dest="hd_leg", action="store_false", help="skip the 1920x1080 leg of the default (vga) run")
+    ap.add_argument("--hd-frames", type=int, default=512, help="frames of the hd leg (512 = BASELINE config #3's per-GPU shard)")
     args = ap.parse_args(argv)
     w, h, nf, b, sp = WORKLOADS[args.workload]
     args.width = args.width or w
@@ -476,7 +545,7 @@ def main():
         dt_ba = time.perf_counter() - t0
         (dt_ba,) = max_over_ranks(dt_ba)
         ticks = bb.ticks
-        _, _, _, stats = bb.download()
+        poses_def, points_def, _, stats = bb.download()
         # separate profiled solve (hipEvents around every Schur launch), not part of `value`
         bb.set_profiling(True)
         bb.solve()
@@ -502,7 +571,13 @@ def main():
         gemm_dense = bg.gemm_dense_flops()
         gemm_issued = bg.gemm_issued_flops()
         bg.set_profiling(False)
+        # the MFMA form must reproduce the default form's solve: same LM decisions on every graph, estimates to rounding
+        poses_g, points_g, _, stats_g = bg.download()
         bg.close()
+        trials_equal = all(a["lm_trials"] == b["lm_trials"] and a["iterations_run"] == b["iterations_run"] for a, b in zip(stats, stats_g))
+        pose_rmse = max(float(np.sqrt(np.mean((a - b) ** 2))) for a, b in zip(poses_def, poses_g))
+        point_rmse = max(float(np.sqrt(np.mean((a - b) ** 2))) for a, b in zip(points_def, points_g))
+        assert trials_equal and pose_rmse <= 1e-9 and point_rmse <= 1e-9, ("MFMA Schur variant diverges from the default", trials_equal, pose_rmse, point_rmse)
         peak64 = orbhip.mfma_f64_peak_tflops(ctx)
         tfl = gemm_fl * gemm_n / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         # sparse-exact flops of the Schur complement (what g2o's per-block products do): per point with k free observers
@@ -550,6 +625,9 @@ def main():
                                                  "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),
                                                  "mfma_flops_of_data_tiles_per_launch": gemm_fl, "mfma_flops_issued_per_launch": gemm_issued,
                                                  "flops_per_launch_without_sparsity_skipping": gemm_dense},
+                                    "parity_vs_default": {"lm_trials_and_iterations_equal_on_all_graphs": bool(trials_equal), "max_pose_rmse": pose_rmse,
+                                                          "max_point_rmse": point_rmse, "asserted": "<= 1e-9; both forms are oracle-checked at this size in "
+                                                          "tests/test_gpu_ba.py::test_ba_full_size_mono[pairs|mfma]"},
                                     "note": "orbhip_ctx_set_ba_schur_mode(ctx, 2): S = Z^T Z on v_mfma_f64_16x16x4_f64 with block-sparsity skipping (the round-1 "
                                             "design); 16x16 tiles of 6-row blocks are mostly zeros, so it issues ~9x the useful flops"}}
 
@@ -671,6 +749,9 @@ def main():
         extract(); sync()
         kp_h = np.zeros((B, max_kp), orbhip.KP_DTYPE)
         assert hipl.hipMemcpy(kp_h.ctypes.data, kp_p, kp_h.nbytes, 2) == 0
+        desc_h = np.zeros((B, max_kp, 32), np.uint8)
+        assert hipl.hipMemcpy(desc_h.ctypes.data, desc_p, desc_h.nbytes, 2) == 0
+        cnt_h = d_cnt.cpu().numpy()
         sf = ext.table(0)
         q = np.zeros((B, max_kp), orbhip.PROJ_QUERY_DTYPE)
         q["u"] = kp_h["x"]; q["v"] = kp_h["y"]; q["angle"] = kp_h["angle"]; q["radius"] = np.float32(15.0) * sf[np.clip(kp_h["octave"], 0, 7)]
@@ -698,8 +779,25 @@ def main():
             (dt_t,) = max_over_ranks(dt_t)
             tracking[name] = {"ms_per_batch": round(dt_t * 1e3, 3), "frame_pairs_per_s": round(world * (B - 1) / dt_t, 1),
                               "matches_per_pair": round(float(d_tn[:B - 1].float().mean().item()), 1)}
+        # the same two calls with ONE frame pair, each waited for: what Tracking::TrackWithMotionModel / SearchLocalPoints feel
+        one_pair = {"search_by_projection_last_frame": lambda: orbhip.search_by_projection_device(
+                        ctx, d_q.data_ptr(), desc_p, cnt_p, max_kp, kp_p + max_kp * 28, desc_p + dstride, None, cnt_p + 4, max_kp, max_kp, 1, bnds,
+                        100, True, d_tm.data_ptr(), d_tn.data_ptr()),
+                    "search_by_projection_local_map": lambda: orbhip.search_local_map_device(
+                        ctx, d_q.data_ptr(), desc_p, cnt_p, max_kp, kp_p + max_kp * 28, desc_p + dstride, None, cnt_p + 4, max_kp, max_kp, 1, bnds,
+                        100, 0.8, d_tm.data_ptr(), d_tn.data_ptr())}
+        for name, fn in one_pair.items():
+            dt_t = 0.0
+            for it in range(21):
+                d_tm[0].fill_(-1); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fn(); ctx.synchronize()
+                if it:
+                    dt_t += (time.perf_counter() - t0) / 20
+            tracking[name]["one_pair_ms"] = round(dt_t * 1e3, 4)
 
     stereo = None
+    stereo_host = None
     if args.stereo_pairs > 0:
         S = args.stereo_pairs
         # a different set of pairs every step (frames change between calls, as in a replay): the right extractor's next
@@ -712,6 +810,8 @@ def main():
             lefts = np.ascontiguousarray(big[:, :, 0:W])
             rights = np.stack([big[j, :, disp[j]:disp[j] + W] for j in range(S)])
             sets.append((torch.from_numpy(lefts).cuda(), torch.from_numpy(np.ascontiguousarray(rights)).cuda()))
+            if k == 0:
+                stereo_host = (lefts[:min(S, 48)].copy(), np.ascontiguousarray(rights[:min(S, 48)]))
         ctx_r = orbhip.Context(local_rank)
         ext_l = orbhip.Extractor(ctx, args.nfeatures, 1.2, 8, 20, 7); ext_r = orbhip.Extractor(ctx_r, args.nfeatures, 1.2, 8, 20, 7)
         ext_l.reserve(W, H, S); ext_r.reserve(W, H, S)
@@ -746,6 +846,97 @@ def main():
                   "mean_stereo_matches_per_pair": round(float(d_nk.float().mean().item()), 1),
                   "workload": "synthetic rectified %dx%d pairs, disparity 4..43 px, %d feats, %d alternating sets" % (W, H, args.nfeatures, nset)}
         ext_l.close(); ext_r.close(); ctx_r.close()
+
+    # ---- per-call latencies at batch 1 (what a drop-in caller feels): each call waited for, the oracle timed single-threaded beside it
+    latency = None
+    if args.latency and world == 1:
+        latency = {"note": "one call of each entry point with ONE unit of work, waited for (hipStreamSynchronize) -- not part of `value`; "
+                           "cpu_oracle_ms_1thread = the CPU oracle on one host thread (filled in when the CPU baselines run)"}
+        ext1 = orbhip.Extractor(ctx, args.nfeatures, 1.2, 8, 20, 7)
+        ext1.reserve(W, H, 1)
+        for _ in range(20):
+            ext1.extract_device(d_imgs.data_ptr(), W, H, W, W * H, 1, (0, 0))
+        ctx.synchronize()
+        nrep = 200
+        t0 = time.perf_counter()
+        for _ in range(nrep):
+            ext1.extract_device(d_imgs.data_ptr(), W, H, W, W * H, 1, (0, 0))
+            ctx.synchronize()
+        latency["extract_one_frame"] = {"gpu_ms": round((time.perf_counter() - t0) / nrep * 1e3, 4), "what": "ORBextractor::operator() on one %dx%d frame resident in HBM" % (W, H)}
+        ext1.close()
+        if tracking is not None:
+            for name in ("search_by_projection_last_frame", "search_by_projection_local_map"):
+                latency[name + "_one_pair"] = {"gpu_ms": tracking[name]["one_pair_ms"], "what": "~%d queries against one frame" % int(cnt_h[0])}
+        if pose_probs is not None:
+            dp1 = torch.from_numpy(hp[:1].copy()).cuda()
+            tl = 0.0
+            for it in range(21):
+                dp1.copy_(torch.from_numpy(hp[:1])); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                orbhip.pose_optimization_device(ctx, dx.data_ptr(), do_.data_ptr(), dw.data_ptr(), dn.data_ptr(), 1, M, pose_probs[0]["cam"],
+                                                dp1.data_ptr(), dout.data_ptr(), dni.data_ptr())
+                ctx.synchronize()
+                if it:
+                    tl += (time.perf_counter() - t0) / 20
+            latency["pose_optimization_one_frame"] = {"gpu_ms": round(tl * 1e3, 4), "what": "1000 unary edges, 4 x 10 LM iterations"}
+        if graphs is not None:
+            b1 = orbhip.BaBatch(ctx, graphs[:1])
+            b1.solve(); sync()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                b1.solve(); sync()
+            latency["local_ba_one_window"] = {"gpu_ms": round((time.perf_counter() - t0) / 5 * 1e3, 3), "what": "50 KF x 2000 points x 10 obs, graph resident (orbhip_ba_batch_solve)"}
+            b1.close()
+        if inertial is not None:
+            latency["inertial_ba_one_window"] = {"gpu_ms": inertial["single_window_ms"], "what": "10 IMU keyframes, 600 landmarks, host arrays in / out"}
+
+    # ---- BASELINE config #3's per-GPU shard beside the default line: 1920x1080, 2000 features, 512 frames, same step
+    hd = None
+    if args.hd_leg and (W, H) == (640, 480) and world == 1:
+        import hashlib
+        HW, HH, HF, HB, HS = 1920, 1080, 2000, args.hd_frames, 3
+        h_imgs = synth_frames_parallel(orbhip, HW, HH, HB, 20241004, 0)
+        dh = torch.from_numpy(h_imgs).cuda()
+        exh = orbhip.Extractor(ctx, HF, 1.2, 8, 20, 7)
+        exh.reserve(HW, HH, HB)
+        mk = exh.max_keypoints
+        h_idx2 = torch.empty((HB, mk, 2), dtype=torch.int32, device="cuda"); h_dist2 = torch.empty((HB, mk, 2), dtype=torch.int32, device="cuda")
+        h_acc = torch.zeros((HB, mk), dtype=torch.uint8, device="cuda"); h_prev = torch.zeros((HB, mk, 2), dtype=torch.float32, device="cuda")
+        h_m12 = torch.empty((HB, mk), dtype=torch.int32, device="cuda"); h_nm = torch.zeros((HB,), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        hk, hd_, hc, _ = exh.results_device()
+        hs = mk * 32
+
+        def hd_step():
+            exh.extract_device(dh.data_ptr(), HW, HH, HW, HW * HH, HB, (0, 0))
+            orbhip.match_bf2nn_device(ctx, hd_, hc, hs, hd_ + hs, hc + 4, hs, HB - 1, mk, 0.7, h_idx2.data_ptr(), h_dist2.data_ptr(), h_acc.data_ptr())
+            orbhip.match_bf2nn_device(ctx, hd_ + (HB - 1) * hs, hc + 4 * (HB - 1), hs, hd_, hc, hs, 1, mk, 0.7, h_idx2.data_ptr() + (HB - 1) * mk * 8,
+                                      h_dist2.data_ptr() + (HB - 1) * mk * 8, h_acc.data_ptr() + (HB - 1) * mk)
+            orbhip.prev_matched_init_device(ctx, hk, mk, HB - 1, mk, h_prev.data_ptr())
+            orbhip.search_for_initialization_device(ctx, hk, hd_, hc, hk + mk * 28, hd_ + hs, hc + 4, HB - 1, mk, mk, (0.0, 0.0, float(HW), float(HH)), 100,
+                                                    0.9, True, h_prev.data_ptr(), h_m12.data_ptr(), h_nm.data_ptr())
+        hd_step(); sync()
+        t0 = time.perf_counter()
+        for _ in range(HS):
+            hd_step()
+        sync()
+        dt_hd = time.perf_counter() - t0
+        ctx.check_status()
+        # digest of sampled frames (keypoint records + descriptors as the C ABI returns them) and the oracle's digest of the same frames
+        sample = sorted({0, HB // 2, HB - 1})
+        got = exh.extract_host(h_imgs[sample], (0, 0))
+        dig = hashlib.sha256()
+        for gk, gd, gm in got:
+            dig.update(gk.tobytes()); dig.update(gd.tobytes())
+        hd = {"metric": "ORB extract+match frames/sec", "value": round(HB * HS / dt_hd, 1), "unit": "frames/s", "steps": HS, "ms_per_step": round(dt_hd / HS * 1e3, 3),
+              "config": {"workload": "hd: synthetic 1920x1080 batch=%d per GPU (BASELINE config #3's shard of 4096 frames over 8 GPUs), 8-level pyramid, 2000 feats/frame, "
+                                     "same step as the main line" % HB},
+              "keypoints_sampled_frames": [int(len(g[0])) for g in got], "sampled_frames": sample,
+              "sha256_keypoints_and_descriptors_of_sampled_frames": dig.hexdigest(),
+              "algorithmic_GBps": round(algorithmic_bytes(HW, HH, float(np.mean([len(g[0]) for g in got])), 0)["total"] * HB * HS / dt_hd / 1e9, 1)}
+        hd_sample_imgs = h_imgs[sample].copy()
+        exh.close()
+        del dh, h_imgs
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
@@ -841,6 +1032,10 @@ def main():
             out["tracking"] = tracking
         if inertial is not None:
             out["inertial_ba"] = inertial
+        if hd is not None:
+            out["hd"] = hd
+        if latency is not None:
+            out["latency"] = latency
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, H, args.nfeatures)
             if graphs is not None:
@@ -849,6 +1044,40 @@ def main():
                 out["pose_opt"]["cpu_baseline"] = pose_cpu_baseline(pose_probs)
             if iba_wins is not None:
                 out["inertial_ba"]["cpu_baseline"] = iba_cpu_baseline(iba_wins)
+            if tracking is not None:
+                tb = tracking_cpu_baseline(kp_h, desc_h, cnt_h, q, bnds)
+                for name, v in tb.items():
+                    out["tracking"][name]["cpu_baseline"] = v
+            if stereo is not None and stereo_host is not None:
+                out["stereo"]["cpu_baseline"] = stereo_cpu_baseline(stereo_host[0], stereo_host[1], args.nfeatures, 40.0 / 458.0, 40.0)
+            if hd is not None:
+                import hashlib
+                import oracle_bind as ob
+                oe = ob.OracleExtractor(2000, 1.2, 8, 20, 7)
+                dig = hashlib.sha256()
+                t0 = time.time()
+                for im in hd_sample_imgs:
+                    ok_, od_, _ = oe.extract(im, (0, 0))
+                    dig.update(ok_.tobytes()); dig.update(od_.tobytes())
+                t_or = (time.time() - t0) / len(hd_sample_imgs)
+                out["hd"]["oracle_sha256_of_the_same_frames"] = dig.hexdigest()
+                out["hd"]["bit_exact_vs_oracle_on_sampled_frames"] = dig.hexdigest() == hd["sha256_keypoints_and_descriptors_of_sampled_frames"]
+                out["hd"]["cpu_oracle_extract_ms_1thread"] = round(t_or * 1e3, 1)
+                assert out["hd"]["bit_exact_vs_oracle_on_sampled_frames"], "HD leg: sampled frames differ from the oracle"
+            if latency is not None:
+                import oracle_bind as ob
+                oe = ob.OracleExtractor(args.nfeatures, 1.2, 8, 20, 7)
+                oe.extract(imgs[0], (0, 0))
+                t0 = time.time()
+                for i in range(3):
+                    oe.extract(imgs[i % B], (0, 0))
+                latency["extract_one_frame"]["cpu_oracle_ms_1thread"] = round((time.time() - t0) / 3 * 1e3, 3)
+                for name in ("search_by_projection_last_frame", "search_by_projection_local_map"):
+                    if name + "_one_pair" in latency:
+                        latency[name + "_one_pair"]["cpu_oracle_ms_1thread"] = out["tracking"][name]["cpu_baseline"]["single_thread_ms"]
+                for key, src in (("pose_optimization_one_frame", "pose_opt"), ("local_ba_one_window", "ba"), ("inertial_ba_one_window", "inertial_ba")):
+                    if key in latency and src in out and "cpu_baseline" in out[src]:
+                        latency[key]["cpu_oracle_ms_1thread"] = out[src]["cpu_baseline"]["single_thread_ms"]
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
