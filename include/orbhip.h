@@ -357,6 +357,60 @@ int orbhip_search_for_triangulation_device(orbhip_ctx *ctx,
         const float *scale_factors, const float *level_sigma2, int nlevels, int check_orientation,
         int32_t *d_matches12, int32_t *d_nmatches);
 
+/* ORBmatcher::SearchForTriangulation for EVERY camera combination of the reference (src/ORBmatcher.cc:969-1210): single Pinhole or
+ * KannalaBrandt8 cameras and two-camera rigs (pKF->mpCamera2 != 0, NLeft != -1: TUM-VI stereo-fisheye).  Per keyframe pair: */
+typedef struct orbhip_tri_pair_general {
+    float R12[4][9], t12[4][3];          /* X1 = R12 X2 + t12 of the camera pair [2*bRight1 + bRight2]: ll, lr, rl, rr (:994-1008; the caller
+                                            keeps the reference's cv::Mat arithmetic); a single-camera pair uses [0] (:996-997) */
+    float F12[4][9];                     /* K1^-T [t12]x R12 K2^-1 of the same combinations, row-major: what Pinhole::epipolarConstrain
+                                            builds (src/CameraModels/Pinhole.cpp:124-127); read only when the first camera is a Pinhole */
+    float cam1[2][8], cam2[2][8];        /* mvParameters (fx fy cx cy k1..k4) of pKF1->mpCamera / mpCamera2 and of pKF2's */
+    int32_t cam1_type[2], cam2_type[2];  /* 0 Pinhole, 1 KannalaBrandt8 */
+    float ep_x, ep_y;                    /* pKF2->mpCamera->project(R2w Cw + t2w) (:978-984) */
+    int32_t nleft1, nleft2;              /* NLeft; -1 = single camera.  Rig keyframes: keypoints and flags in mvKeys | mvKeysRight order
+                                            (= descriptor rows), bRight = index >= NLeft (:1055, :1087) */
+    int32_t only_stereo, coarse;
+} orbhip_tri_pair_general;
+/* Layout as orbhip_search_for_triangulation_device.  The candidate test is GeometricCamera::epipolarConstrain of the FIRST camera of
+ * the picked pair: Pinhole -> distance to the epipolar line of F12[c] (Pinhole.cpp:129-143); KannalaBrandt8 -> TriangulateMatches
+ * (src/CameraModels/KannalaBrandt8.cpp:235-238, 334-401: ray parallax < 0.9998, linear triangulation by the SVD of a 4x4 system,
+ * both depths positive, reprojection errors <= 5.991 sigma^2 in both cameras, z1 > 1e-4).  Rig pairs have no stereo keypoints
+ * (bStereo needs mpCamera2 == 0, :1044) and skip the epipole test (:1091).  level_sigma2_1 = pKF1->mvLevelSigma2, scale_factors2 /
+ * level_sigma2_2 = pKF2's (HOST arrays of nlevels floats).  cv::SVD (one-sided Jacobi) and the float libm calls are restated as
+ * DESIGN.md 2 describes: parity unpinned against an OpenCV build, bit-exact against the oracle. */
+int orbhip_search_for_triangulation_general_device(orbhip_ctx *ctx,
+        const int32_t *d_nid1, const uint8_t *d_has_mp1, const orbhip_keypoint *d_kp1, const uint8_t *d_desc1, const float *d_u_right1,
+        const int32_t *d_n1,
+        const int32_t *d_node_ids2, const int32_t *d_node_start2, const int32_t *d_feat2, const int32_t *d_nnodes2,
+        const uint8_t *d_has_mp2, const orbhip_keypoint *d_kp2, const uint8_t *d_desc2, const float *d_u_right2, const int32_t *d_n2,
+        const orbhip_tri_pair_general *d_pair, int pairs, int max_nodes, int max_n, size_t frame_stride_kp,
+        const float *level_sigma2_1, const float *scale_factors2, const float *level_sigma2_2, int nlevels, int check_orientation,
+        int32_t *d_matches12, int32_t *d_nmatches);
+
+/* Host-pointer forms for ONE keyframe (pair) -- what the ORBmatcher methods of host/ORBmatcher.cc call (upload into the context's
+ * arena, the same kernels as the batched device entry points, download, synchronise).  All pointers HOST.
+ *   orbhip_search_for_triangulation_host: one pair through the general kernel (nid1 [n1]: vocabulary node of every KF1 feature, -1 =
+ *     in no node; KF2's FeatureVector flattened); matches12_out [n1].
+ *   orbhip_fuse_search_host: orbhip_fuse_search_device for one keyframe; best_idx_out / best_dist_out [nq].
+ *   orbhip_search_by_bow_kf_host: orbhip_search_by_bow_kf_device for one pair; matches12_out [n1].
+ *   orbhip_pose_optimization_host: orbhip_pose_optimization_device for one frame; Xw [n][3], obs [n][3], inv_sigma2 [n] doubles,
+ *     right [n] or NULL, pose_inout [7], outlier_out [n], *n_inliers_out, stats_out [4] or NULL. */
+int orbhip_search_for_triangulation_host(orbhip_ctx *ctx,
+        const int32_t *nid1, const uint8_t *has_mp1, const orbhip_keypoint *kp1, const uint8_t *desc1, const float *u_right1, int n1,
+        const int32_t *node_ids2, const int32_t *node_start2, const int32_t *feat2, int nnodes2,
+        const uint8_t *has_mp2, const orbhip_keypoint *kp2, const uint8_t *desc2, const float *u_right2, int n2,
+        const orbhip_tri_pair_general *pair, const float *level_sigma2_1, const float *scale_factors2, const float *level_sigma2_2,
+        int nlevels, int check_orientation, int32_t *matches12_out, int32_t *nmatches_out);
+int orbhip_fuse_search_host(orbhip_ctx *ctx, const orbhip_proj_query *q, const uint8_t *desc_q, int nq, const orbhip_keypoint *kp,
+                            const uint8_t *desc, const float *u_right, int n, const float *inv_level_sigma2, int nlevels,
+                            float min_x, float min_y, float max_x, float max_y, int32_t *best_idx_out, int32_t *best_dist_out);
+int orbhip_search_by_bow_kf_host(orbhip_ctx *ctx,
+        const int32_t *node_ids1, const int32_t *node_start1, const int32_t *feat1, int nnodes1, const uint8_t *valid1,
+        const orbhip_keypoint *kp1, const uint8_t *desc1, int n1,
+        const int32_t *node_ids2, const int32_t *node_start2, const int32_t *feat2, int nnodes2, const uint8_t *valid2,
+        const orbhip_keypoint *kp2, const uint8_t *desc2, int n2,
+        float nn_ratio, int check_orientation, int32_t *matches12_out, int32_t *nmatches_out);
+
 /* Frame::UndistortKeyPoints (src/Frame.cc:738-771), batched: d_kp_un = d_kp with pt replaced by
  * cv::undistortPoints(pt, K, mDistCoef, R = I, P = K) (OpenCV 3.4.1 cvUndistortPoints: 5 fixed-point iterations in double,
  * rounded to float).  dist_coef: HOST array (k1, k2, p1, p2[, k3]), n_dist 4 or 5; k1 == 0 copies (Frame.cc:740-744).
@@ -654,6 +708,10 @@ int orbhip_pose_optimization_device(orbhip_ctx *ctx, const double *d_Xw, const d
                                     double fx, double fy, double cx, double cy, double bf, const double *kb8_k,
                                     const orbhip_camera2 *cam2, const uint8_t *d_right,
                                     double *d_pose, uint8_t *d_outlier, int32_t *d_n_inliers, int32_t *d_stats);
+int orbhip_pose_optimization_host(orbhip_ctx *ctx, const double *Xw, const double *obs, const double *inv_sigma2, int n,
+                                  double fx, double fy, double cx, double cy, double bf, const double *kb8_k,
+                                  const orbhip_camera2 *cam2, const uint8_t *right,
+                                  double *pose_inout, uint8_t *outlier_out, int32_t *n_inliers_out, int32_t *stats_out);
 
 #ifdef __cplusplus
 }

@@ -7,6 +7,7 @@
 #include <string.h>
 #include <math.h>
 #include <limits.h>
+#include <float.h>
 
 #define GRID_COLS 64   /* FRAME_GRID_COLS, include/Frame.h:38 */
 #define GRID_ROWS 48   /* FRAME_GRID_ROWS, include/Frame.h:39 */
@@ -780,5 +781,256 @@ int orc_search_by_bow_rig(const int32_t *kf_node_ids, const int32_t *kf_node_sta
                 for (int j = 0; j < hist_n[i]; j++) { match_f[hist_items[(size_t)i * nF + j]] = -1; nmatches--; }
     }
     free(hist_items); free(hist_n);
+    return nmatches;
+}
+
+/* ================================================================= SearchForTriangulation, general form
+ * ORBmatcher::SearchForTriangulation (ORBm:969-1210) for every camera combination the reference supports: Pinhole or
+ * KannalaBrandt8 single cameras and two-camera rigs (mpCamera2 != 0, NLeft != -1: keypoints mvKeys | mvKeysRight, the relative
+ * pose and the camera pair picked per candidate from {ll, lr, rl, rr}, ORBm:1092-1121).  GeometricCamera::epipolarConstrain:
+ * Pinhole.cpp:122-144 (distance to the epipolar line of F12 = K1^-T [t12]x R12 K2^-1) and KannalaBrandt8.cpp:235-238 ->
+ * TriangulateMatches (:334-401): ray parallax, linear triangulation by the SVD of a 4x4 system, positive depths, reprojection
+ * errors in both cameras.
+ * UNPINNED parts restated from OpenCV 3.4.1 (not in the reference tree): cv::SVD::compute on a 4x4 CV_32F matrix = one-sided Jacobi
+ * (JacobiSVDImpl_<float>: rotations of the rows of A^T in float, norms / dot products accumulated in double, eps = 2*FLT_EPSILON,
+ * at most 30 sweeps, singular vectors sorted by decreasing singular value); cv::Mat float products accumulate in double and round
+ * once; Mat / scalar multiplies by the float reciprocal.  Stated deviations, applied identically in the HIP kernel (as for
+ * orb_sincos): tanf / cosf / sinf / atan2f of the platform libm are replaced by the float rounding of fixed double
+ * sequences (Cody-Waite + fdlibm kernels; double atan2), hypot(p, beta) of the Jacobi rotation by sqrt(p*p + beta*beta). */
+static void sincos_signed(double x, double *s_out, double *c_out)
+{
+    const double TWO_OVER_PI = 6.36619772367581382433e-01;
+    const double PIO2_HI = 1.57079632679489655800e+00, PIO2_LO = 6.12323399573676603587e-17;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double dk = rint(x * TWO_OVER_PI);
+    const int k = (int)dk;
+    double r = fma(-dk, PIO2_HI, x);
+    r = fma(-dk, PIO2_LO, r);
+    const double z = r * r;
+    double ps = fma(z, S6, S5); ps = fma(z, ps, S4); ps = fma(z, ps, S3); ps = fma(z, ps, S2); ps = fma(z, ps, S1);
+    const double s = fma(r * z, ps, r);
+    double pc = fma(z, C6, C5); pc = fma(z, pc, C4); pc = fma(z, pc, C3); pc = fma(z, pc, C2); pc = fma(z, pc, C1);
+    const double c = fma(z * z, pc, fma(z, -0.5, 1.0));
+    switch (k & 3) {
+    case 0: *s_out = s; *c_out = c; break;
+    case 1: *s_out = c; *c_out = -s; break;
+    case 2: *s_out = -s; *c_out = -c; break;
+    default: *s_out = -c; *c_out = s; break;
+    }
+}
+static float det_atan2f(float y, float x) { return (float)atan2((double)y, (double)x); }
+
+/* GeometricCamera::project(cv::Point3f): Pinhole.cpp:34-37, KannalaBrandt8.cpp:28-45.  p = fx fy cx cy k1 k2 k3 k4 */
+void orc_camera_project_f(int type, const float *p, const float P[3], float uv[2])
+{
+    if (type == 0) { uv[0] = p[0] * P[0] / P[2] + p[2]; uv[1] = p[1] * P[1] / P[2] + p[3]; return; }
+    const float x2_plus_y2 = P[0] * P[0] + P[1] * P[1];
+    const float theta = det_atan2f(sqrtf(x2_plus_y2), P[2]);
+    const float psi = det_atan2f(P[1], P[0]);
+    const float theta2 = theta * theta, theta3 = theta * theta2, theta5 = theta3 * theta2, theta7 = theta5 * theta2, theta9 = theta7 * theta2;
+    const float r = theta + p[4] * theta3 + p[5] * theta5 + p[6] * theta7 + p[7] * theta9;
+    double s, c;
+    sincos_signed((double)psi, &s, &c);
+    uv[0] = p[0] * r * (float)c + p[2]; uv[1] = p[1] * r * (float)s + p[3];
+}
+/* GeometricCamera::unproject: Pinhole.cpp:57-60, KannalaBrandt8.cpp:103-130 */
+void orc_camera_unproject_f(int type, const float *p, float u, float v, float ray[3])
+{
+    const float pwx = (u - p[2]) / p[0], pwy = (v - p[3]) / p[1];
+    if (type == 0) { ray[0] = pwx; ray[1] = pwy; ray[2] = 1.f; return; }
+    float scale = 1.f;
+    float theta_d = sqrtf(pwx * pwx + pwy * pwy);
+    theta_d = fminf(fmaxf((float)(-M_PI / 2.f), theta_d), (float)(M_PI / 2.f));     /* (CV_PI / 2.f is a double expression, narrowed by fminf / fmaxf) */
+    if (theta_d > 1e-8) {
+        float theta = theta_d;
+        for (int j = 0; j < 10; j++) {
+            const float theta2 = theta * theta, theta4 = theta2 * theta2, theta6 = theta4 * theta2, theta8 = theta4 * theta4;
+            const float k0_theta2 = p[4] * theta2, k1_theta4 = p[5] * theta4, k2_theta6 = p[6] * theta6, k3_theta8 = p[7] * theta8;
+            const float theta_fix = (theta * (1 + k0_theta2 + k1_theta4 + k2_theta6 + k3_theta8) - theta_d) /
+                                    (1 + 3 * k0_theta2 + 5 * k1_theta4 + 7 * k2_theta6 + 9 * k3_theta8);
+            theta = theta - theta_fix;
+            if (fabsf(theta_fix) < 1e-6f) break;                                   /* precision(1e-6), KannalaBrandt8.h:53 */
+        }
+        double s, c;
+        sincos_signed((double)theta, &s, &c);
+        scale = (float)(s / c) / theta_d;                                          /* std::tan(theta) / theta_d */
+    }
+    ray[0] = pwx * scale; ray[1] = pwy * scale; ray[2] = 1.f;
+}
+
+/* Vt of cv::SVD::compute(A 4x4 CV_32F, FULL_UV): rows = right singular vectors by decreasing singular value (lapack.cpp JacobiSVDImpl_) */
+static void jacobi_svd4_vt(const float A[16], float Vt[16])
+{
+    float At[16];
+    double W[4];
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) At[4 * i + j] = A[4 * j + i];          /* transpose(src, temp_a): m == n */
+    const float eps = FLT_EPSILON * 2;
+    for (int i = 0; i < 4; i++) {
+        double sd = 0;
+        for (int k = 0; k < 4; k++) { const float t = At[4 * i + k]; sd += (double)t * t; }
+        W[i] = sd;
+        for (int k = 0; k < 4; k++) Vt[4 * i + k] = 0;
+        Vt[4 * i + i] = 1;
+    }
+    for (int iter = 0; iter < 30; iter++) {
+        int changed = 0;
+        for (int i = 0; i < 3; i++)
+            for (int j = i + 1; j < 4; j++) {
+                float *Ai = At + 4 * i, *Aj = At + 4 * j;
+                double a = W[i], p = 0, b = W[j];
+                for (int k = 0; k < 4; k++) p += (double)Ai[k] * Aj[k];
+                if (fabs(p) <= eps * sqrt(a * b)) continue;
+                p *= 2;
+                const double beta = a - b, gamma = sqrt(p * p + beta * beta);
+                float c, s;
+                if (beta < 0) {
+                    const double delta = (gamma - beta) * 0.5;
+                    s = (float)sqrt(delta / gamma);
+                    c = (float)(p / (gamma * s * 2));
+                } else {
+                    c = (float)sqrt((gamma + beta) / (gamma * 2));
+                    s = (float)(p / (gamma * c * 2));
+                }
+                a = b = 0;
+                for (int k = 0; k < 4; k++) {
+                    const float t0 = c * Ai[k] + s * Aj[k];
+                    const float t1 = -s * Ai[k] + c * Aj[k];
+                    Ai[k] = t0; Aj[k] = t1;
+                    a += (double)t0 * t0; b += (double)t1 * t1;
+                }
+                W[i] = a; W[j] = b;
+                changed = 1;
+                float *Vi = Vt + 4 * i, *Vj = Vt + 4 * j;
+                for (int k = 0; k < 4; k++) {
+                    const float t0 = c * Vi[k] + s * Vj[k];
+                    const float t1 = -s * Vi[k] + c * Vj[k];
+                    Vi[k] = t0; Vj[k] = t1;
+                }
+            }
+        if (!changed) break;
+    }
+    for (int i = 0; i < 4; i++) {
+        double sd = 0;
+        for (int k = 0; k < 4; k++) { const float t = At[4 * i + k]; sd += (double)t * t; }
+        W[i] = sqrt(sd);
+    }
+    for (int i = 0; i < 3; i++) {
+        int j = i;
+        for (int k = i + 1; k < 4; k++) if (W[j] < W[k]) j = k;
+        if (i != j) {
+            const double tw = W[i]; W[i] = W[j]; W[j] = tw;
+            for (int k = 0; k < 4; k++) { const float t = Vt[4 * i + k]; Vt[4 * i + k] = Vt[4 * j + k]; Vt[4 * j + k] = t; }
+        }
+    }
+}
+
+/* KannalaBrandt8::TriangulateMatches (KannalaBrandt8.cpp:334-401); returns z1 or -1.  R12 row-major 3x3, t12[3] */
+float orc_kb8_triangulate_matches(int type1, const float *cam1, int type2, const float *cam2, float u1, float v1, float u2, float v2,
+                                  const float *R12, const float *t12, float sigmaLevel, float unc, float x3D_out[3])
+{
+    float r1[3], r2[3], r21[3];
+    orc_camera_unproject_f(type1, cam1, u1, v1, r1);
+    orc_camera_unproject_f(type2, cam2, u2, v2, r2);
+    for (int i = 0; i < 3; i++) r21[i] = (float)((double)R12[3 * i] * r2[0] + (double)R12[3 * i + 1] * r2[1] + (double)R12[3 * i + 2] * r2[2]);
+    const double dot = (double)r1[0] * r21[0] + (double)r1[1] * r21[1] + (double)r1[2] * r21[2];
+    const double n1 = sqrt((double)r1[0] * r1[0] + (double)r1[1] * r1[1] + (double)r1[2] * r1[2]);
+    const double n2 = sqrt((double)r21[0] * r21[0] + (double)r21[1] * r21[1] + (double)r21[2] * r21[2]);
+    const float cosParallaxRays = (float)(dot / (n1 * n2));
+    if (cosParallaxRays > 0.9998) return -1;
+    float R21[9], t21[3], T2[12], A[16], Vt[16];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R21[3 * i + j] = R12[3 * j + i];
+    for (int i = 0; i < 3; i++) t21[i] = (float)(-1.0 * ((double)R21[3 * i] * t12[0] + (double)R21[3 * i + 1] * t12[1] + (double)R21[3 * i + 2] * t12[2]));
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) T2[4 * i + j] = R21[3 * i + j]; T2[4 * i + 3] = t21[i]; }
+    static const float T1[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    for (int j = 0; j < 4; j++) {                                                  /* KannalaBrandt8.cpp:426-429 */
+        A[j] = r1[0] * T1[8 + j] - T1[j];
+        A[4 + j] = r1[1] * T1[8 + j] - T1[4 + j];
+        A[8 + j] = r2[0] * T2[8 + j] - T2[j];
+        A[12 + j] = r2[1] * T2[8 + j] - T2[4 + j];
+    }
+    jacobi_svd4_vt(A, Vt);
+    const float inv = (float)(1.0 / (double)Vt[15]);                               /* x3D.rowRange(0,3) / x3D.at<float>(3) */
+    float x3D[3] = {Vt[12] * inv, Vt[13] * inv, Vt[14] * inv};
+    const float z1 = x3D[2];
+    if (!(z1 > 0)) return -1;                                                      /* (NaN from a zero homogeneous coordinate fails every test below in the reference as well) */
+    const float z2 = (float)((double)R21[6] * x3D[0] + (double)R21[7] * x3D[1] + (double)R21[8] * x3D[2] + (double)t21[2]);
+    if (z2 <= 0) return -1;
+    float uv1[2], uv2[2], x3D2[3];
+    orc_camera_project_f(type1, cam1, x3D, uv1);
+    const float errX1 = uv1[0] - u1, errY1 = uv1[1] - v1;
+    if ((errX1 * errX1 + errY1 * errY1) > 5.991 * sigmaLevel) return -1;
+    for (int i = 0; i < 3; i++)
+        x3D2[i] = (float)((double)R21[3 * i] * x3D[0] + (double)R21[3 * i + 1] * x3D[1] + (double)R21[3 * i + 2] * x3D[2] + (double)t21[i]);
+    orc_camera_project_f(type2, cam2, x3D2, uv2);
+    const float errX2 = uv2[0] - u2, errY2 = uv2[1] - v2;
+    if ((errX2 * errX2 + errY2 * errY2) > 5.991 * unc) return -1;
+    if (x3D_out) { x3D_out[0] = x3D[0]; x3D_out[1] = x3D[1]; x3D_out[2] = x3D[2]; }
+    return z1;
+}
+
+int orc_search_for_triangulation_general(const int32_t *nid1, const uint8_t *has_mp1, const orc_keypoint *kp1, const uint8_t *desc1,
+                                         const float *u_right1, int n1,
+                                         const int32_t *node_ids2, const int32_t *node_start2, const int32_t *feat2, int nnodes2,
+                                         const uint8_t *has_mp2, const orc_keypoint *kp2, const uint8_t *desc2, const float *u_right2,
+                                         const orc_tri_general *g, const float *level_sigma2_1, const float *scale_factors2,
+                                         const float *level_sigma2_2, int check_orientation, int32_t *matches12)
+{
+    int nmatches = 0;
+    int hist[HISTO_LENGTH]; memset(hist, 0, sizeof(hist));
+    int *bin_of = (int *)malloc(sizeof(int) * (n1 ? n1 : 1));
+    const float factor = 1.0f / HISTO_LENGTH;
+    const int cam2nd1 = g->nleft1 != -1, cam2nd2 = g->nleft2 != -1;            /* pKF->mpCamera2 != 0 */
+    for (int idx1 = 0; idx1 < n1; idx1++) {
+        matches12[idx1] = -1; bin_of[idx1] = -1;
+        if (has_mp1[idx1]) continue;                                           /* ORBm:1036-1042 */
+        const int bStereo1 = !cam2nd1 && u_right1 && u_right1[idx1] >= 0;      /* :1044 */
+        if (g->only_stereo && !bStereo1) continue;
+        const int bRight1 = !(g->nleft1 == -1 || idx1 < g->nleft1);            /* :1055-1056 */
+        int lo = 0, hi = nnodes2;
+        while (lo < hi) { const int mid = (lo + hi) / 2; if (node_ids2[mid] < nid1[idx1]) lo = mid + 1; else hi = mid; }
+        if (lo >= nnodes2 || node_ids2[lo] != nid1[idx1]) continue;
+        int bestDist = TH_LOW, bestIdx2 = -1;
+        for (int j = node_start2[lo]; j < node_start2[lo + 1]; j++) {
+            const int idx2 = feat2[j];
+            if (has_mp2[idx2]) continue;
+            const int bStereo2 = !cam2nd2 && u_right2 && u_right2[idx2] >= 0;  /* :1073 */
+            if (g->only_stereo && !bStereo2) continue;
+            const int dist = orc_descriptor_distance(desc1 + 32 * (size_t)idx1, desc2 + 32 * (size_t)idx2);
+            if (dist > TH_LOW || dist > bestDist) continue;
+            const int bRight2 = !(g->nleft2 == -1 || idx2 < g->nleft2);
+            if (!bStereo1 && !bStereo2 && !cam2nd1) {                          /* :1091-1099 */
+                const float distex = g->ep_x - kp2[idx2].x, distey = g->ep_y - kp2[idx2].y;
+                if (distex * distex + distey * distey < 100 * scale_factors2[kp2[idx2].octave]) continue;
+            }
+            const int c = (cam2nd1 && cam2nd2) ? 2 * bRight1 + bRight2 : 0;    /* :1101-1130 */
+            const int ci1 = (cam2nd1 && cam2nd2) ? bRight1 : 0, ci2 = (cam2nd1 && cam2nd2) ? bRight2 : 0;
+            const float s1 = level_sigma2_1[kp1[idx1].octave], s2 = level_sigma2_2[kp2[idx2].octave];
+            int ok;
+            if (g->cam1_type[ci1] == 0) ok = epipolar_ok(g->F12[c], &kp1[idx1], &kp2[idx2], s2);
+            else ok = orc_kb8_triangulate_matches(1, g->cam1[ci1], g->cam2_type[ci2], g->cam2[ci2], kp1[idx1].x, kp1[idx1].y, kp2[idx2].x, kp2[idx2].y,
+                                                  g->R12[c], g->t12[c], s1, s2, NULL) > 0.0001f;
+            if (ok || g->coarse) { bestIdx2 = idx2; bestDist = dist; }
+        }
+        if (bestIdx2 >= 0) {
+            matches12[idx1] = bestIdx2; nmatches++;
+            if (check_orientation) {
+                float rot = kp1[idx1].angle - kp2[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                hist[bin]++; bin_of[idx1] = bin;
+            }
+        }
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(hist, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < n1; i++)
+            if (bin_of[i] >= 0 && bin_of[i] != ind1 && bin_of[i] != ind2 && bin_of[i] != ind3) { matches12[i] = -1; nmatches--; }
+    }
+    free(bin_of);
     return nmatches;
 }

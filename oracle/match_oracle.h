@@ -148,4 +148,27 @@ int orc_search_by_bow_rig(const int32_t *kf_node_ids, const int32_t *kf_node_sta
                           const int32_t *f_node_ids, const int32_t *f_node_start, const int32_t *f_feat, int f_nnodes,
                           const orc_keypoint *f_kp, const uint8_t *f_desc, int nF, int nleft,
                           float nn_ratio, int check_orientation, int32_t *match_f);
+
+/* ---- SearchForTriangulation for every camera combination (ORBm:969-1210; Pinhole.cpp:122-144, KannalaBrandt8.cpp:235-238, :334-401) */
+typedef struct {
+    float R12[4][9], t12[4][3];          /* relative pose X1 = R12 X2 + t12 of the camera pair [2*bRight1 + bRight2]: ll, lr, rl, rr (ORBm:994-1008);
+                                            a single-camera pair uses [0] */
+    float F12[4][9];                     /* K1^-T [t12]x R12 K2^-1 of the same combinations (what Pinhole::epipolarConstrain builds, Pinhole.cpp:124-127) */
+    float cam1[2][8], cam2[2][8];        /* mvParameters (fx fy cx cy k1..k4) of pKF1->mpCamera / mpCamera2 and of pKF2's */
+    int32_t cam1_type[2], cam2_type[2];  /* 0 Pinhole, 1 KannalaBrandt8 */
+    float ep_x, ep_y;                    /* pKF2->mpCamera->project(R2w Cw + t2w), ORBm:978-984 */
+    int32_t nleft1, nleft2;              /* NLeft; -1 = single camera (mpCamera2 == 0).  Rig keyframes: keypoints mvKeys | mvKeysRight */
+    int32_t only_stereo, coarse;
+} orc_tri_general;
+int orc_search_for_triangulation_general(const int32_t *nid1, const uint8_t *has_mp1, const orc_keypoint *kp1, const uint8_t *desc1,
+                                         const float *u_right1, int n1,
+                                         const int32_t *node_ids2, const int32_t *node_start2, const int32_t *feat2, int nnodes2,
+                                         const uint8_t *has_mp2, const orc_keypoint *kp2, const uint8_t *desc2, const float *u_right2,
+                                         const orc_tri_general *g, const float *level_sigma2_1, const float *scale_factors2,
+                                         const float *level_sigma2_2, int check_orientation, int32_t *matches12);
+float orc_kb8_triangulate_matches(int type1, const float *cam1, int type2, const float *cam2, float u1, float v1, float u2, float v2,
+                                  const float *R12, const float *t12, float sigmaLevel, float unc, float x3D_out[3]);
+void orc_camera_project_f(int type, const float *p, const float P[3], float uv[2]);
+void orc_camera_unproject_f(int type, const float *p, float u, float v, float ray[3]);
+
 #endif

@@ -1,27 +1,30 @@
 // ORBextractor.cc -- host marshalling for the signature-preserving ORBextractor (see header).  No exceptions cross this
-// boundary (the reference uses none): a device that is missing at construction aborts with a message (the reference's
-// constructor cannot fail and there is no CPU path to fall back to); a device error inside operator() is reported on stderr
-// and answered like the reference's only failure, the empty image: -1, no keypoints (ORBextractor.cc:1072-1073).
+// boundary (the reference uses none) and the process is never aborted: a device that is missing at construction is reported on
+// stderr (the reference's constructor cannot fail and there is no CPU path to fall back to) and every later operator() answers like
+// the reference's only failure, the empty image: -1, no keypoints (ORBextractor.cc:1072-1073); so does a device error inside
+// operator().  The GPU is hip::GetDevice() (hip_context.h: SetDevice(n) / ORBHIP_DEVICE / 0).
 #include "ORBextractor.h"
+#include "hip_context.h"
 #include <cstdio>
 #include <cstdlib>
 
 namespace ORB_SLAM3 {
 
-static void die(int rc, const char *what)
+static void complain(int rc, const char *what)
 {
-    fprintf(stderr, "ORBextractor (HIP): %s failed: %d (%s) -- this build needs an MI355X, there is no CPU fallback\n", what, rc, orbhip_last_error());
-    std::abort();
+    fprintf(stderr, "ORBextractor (HIP): %s failed: %d (%s) -- this build needs an MI355X, there is no CPU fallback; operator() will return -1\n", what, rc,
+            orbhip_last_error());
 }
 
 ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST)
     : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST),
       ctx_(nullptr), ext_(nullptr), stageW_(0), stageH_(0), cap_(0), syncPyramid_(true)
 {
-    int rc = orbhip_ctx_create(0, nullptr, &ctx_);                          // one context (stream) per extractor instance: Frame.cc:109-110
-    if (rc != ORBHIP_OK) die(rc, "orbhip_ctx_create");
+    mvImagePyramid.resize(nlevels);
+    int rc = orbhip_ctx_create(hip::GetDevice(), nullptr, &ctx_);           // one context (stream) per extractor instance: Frame.cc:109-110
+    if (rc != ORBHIP_OK) { complain(rc, "orbhip_ctx_create"); ctx_ = nullptr; return; }
     rc = orbhip_extractor_create(ctx_, _nfeatures, _scaleFactor, _nlevels, _iniThFAST, _minThFAST, &ext_);
-    if (rc != ORBHIP_OK) die(rc, "orbhip_extractor_create");
+    if (rc != ORBHIP_OK) { complain(rc, "orbhip_extractor_create"); ext_ = nullptr; return; }
     mvScaleFactor.resize(nlevels); mvInvScaleFactor.resize(nlevels); mvLevelSigma2.resize(nlevels); mvInvLevelSigma2.resize(nlevels);
     orbhip_extractor_table(ext_, 0, mvScaleFactor.data());
     orbhip_extractor_table(ext_, 1, mvInvScaleFactor.data());
@@ -31,13 +34,12 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int
     orbhip_extractor_features_per_level(ext_, mnFeaturesPerLevel.data());
     umax.resize(16);
     orbhip_extractor_umax(ext_, umax.data());
-    mvImagePyramid.resize(nlevels);
 }
 
 ORBextractor::~ORBextractor()
 {
-    orbhip_extractor_destroy(ext_);
-    orbhip_ctx_destroy(ctx_);
+    if (ext_) orbhip_extractor_destroy(ext_);
+    if (ctx_) orbhip_ctx_destroy(ctx_);
 }
 
 int ORBextractor::operator()(cv::InputArray image, cv::InputArray /*mask*/, std::vector<cv::KeyPoint> &keypoints,
@@ -49,6 +51,7 @@ int ORBextractor::operator()(cv::InputArray image, cv::InputArray /*mask*/, std:
     const cv::Mat &img = image;
 #endif
     if (img.empty()) return -1;                                             // ORBextractor.cc:1072-1073
+    if (!ext_) { keypoints.clear(); descriptors.release(); return -1; }     // no device (reported by the constructor)
     if (img.cols != stageW_ || img.rows != stageH_) {                       // device buffers + staging rows: once per image size
         const int rc = orbhip_extractor_reserve(ext_, img.cols, img.rows, 1);
         if (rc != ORBHIP_OK) { fprintf(stderr, "ORBextractor (HIP): reserve %dx%d: %d (%s)\n", img.cols, img.rows, rc, orbhip_last_error()); return -1; }
@@ -82,6 +85,7 @@ int ORBextractor::operator()(cv::InputArray image, cv::InputArray /*mask*/, std:
 
 void ORBextractor::SyncImagePyramid()
 {
+    if (!ext_) return;
     padded_.resize(nlevels);
     std::vector<uint8_t *> lv(nlevels);
     std::vector<size_t> st(nlevels);

@@ -5,6 +5,7 @@
 // k_search_init.  Frames of a two-camera rig (Nleft != -1) add the right camera's query per point and go through the rig entry point.
 #include "ORBmatcher.h"
 #include <cstdio>
+#include "hip_context.h"
 #include <cstdlib>
 
 namespace ORB_SLAM3 {
@@ -14,20 +15,7 @@ const int ORBmatcher::TH_LOW = 50;
 const int ORBmatcher::HISTO_LENGTH = 30;
 
 namespace {
-struct Ctx {                // one device context per calling thread: matcher objects are stack temporaries in Tracking,
-    orbhip_ctx *h;          // LocalMapping and LoopClosing, which run concurrently (SURVEY 8b "Threading")
-    Ctx() : h(nullptr) {}
-    ~Ctx() { if (h) orbhip_ctx_destroy(h); }
-};
-orbhip_ctx *thread_ctx()
-{
-    static thread_local Ctx c;
-    if (!c.h) {
-        const int rc = orbhip_ctx_create(0, nullptr, &c.h);
-        if (rc != ORBHIP_OK) { fprintf(stderr, "ORBmatcher (HIP): no device context: %d (%s) -- there is no CPU fallback\n", rc, orbhip_last_error()); std::abort(); }
-    }
-    return c.h;
-}
+inline orbhip_ctx *thread_ctx() { return hip::ThreadContext(); }      // one context per calling thread, GPU of hip::GetDevice() (hip_context.h)
 
 static_assert(sizeof(cv::KeyPoint) == sizeof(orbhip_keypoint), "KeyPoint layout");
 

@@ -8,6 +8,7 @@
 // unreachable bRedrawError file dump (:2183-2200, :2209-2251: behind a `return`).
 #include "Optimizer.h"
 #include <cstdio>
+#include "hip_context.h"
 #include <list>
 #include <utility>
 #include "../../include/orbhip.h"
@@ -55,17 +56,7 @@ cv::Mat toCvMat(const double *q7)
     return m;
 }
 
-struct Ctx {                // one device context per calling thread (LocalMapping's LBA may overlap LoopClosing's merge-LBA)
-    orbhip_ctx *h;
-    Ctx() : h(nullptr) {}
-    ~Ctx() { if (h) orbhip_ctx_destroy(h); }
-};
-orbhip_ctx *thread_ctx()
-{
-    static thread_local Ctx c;
-    if (!c.h && orbhip_ctx_create(0, nullptr, &c.h) != ORBHIP_OK) c.h = nullptr;
-    return c.h;
-}
+inline orbhip_ctx *thread_ctx() { return hip::ThreadContext(); }      // one context per calling thread, GPU of hip::GetDevice() (hip_context.h)
 
 void camera_fields(GeometricCamera *cam, double &fx, double &fy, double &cx, double &cy, int32_t &model, double (&kb)[4])
 {

@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstdio>
+#include "hip_context.h"
 #include <list>
 #include <map>
 #include <utility>
@@ -25,17 +26,7 @@ namespace ORB_SLAM3 {
 
 namespace {
 
-struct Ctx {
-    orbhip_ctx *h;
-    Ctx() : h(nullptr) {}
-    ~Ctx() { if (h) orbhip_ctx_destroy(h); }
-};
-orbhip_ctx *thread_ctx()
-{
-    static thread_local Ctx c;
-    if (!c.h && orbhip_ctx_create(0, nullptr, &c.h) != ORBHIP_OK) c.h = nullptr;
-    return c.h;
-}
+inline orbhip_ctx *thread_ctx() { return hip::ThreadContext(); }      // one context per calling thread, GPU of hip::GetDevice() (hip_context.h)
 
 // eigen-decomposition of a symmetric n x n matrix (n <= 9), cyclic Jacobi: A = V diag(w) V^T
 void jacobi_eig(int n, double *A, double *V, double *w)

@@ -11,6 +11,7 @@
 #include <vector>
 namespace cv {
 struct Point2f { float x, y; Point2f() : x(0), y(0) {} Point2f(float a, float b) : x(a), y(b) {} };
+struct Point3f { float x, y, z; Point3f() : x(0), y(0), z(0) {} Point3f(float a, float b, float c) : x(a), y(b), z(c) {} };
 struct KeyPoint {
     Point2f pt; float size, angle, response; int octave, class_id;
     KeyPoint() : size(0), angle(-1), response(0), octave(0), class_id(-1) {}

@@ -78,6 +78,11 @@ public:
     {
         const float *p = m3D.ptr<float>();
         const float x = m3D.cols == 1 ? m3D.at<float>(0) : p[0], y = m3D.cols == 1 ? m3D.at<float>(1) : p[1], z = m3D.cols == 1 ? m3D.at<float>(2) : p[2];
+        return project(cv::Point3f(x, y, z));
+    }
+    cv::Point2f project(const cv::Point3f &p3D)
+    {
+        const float x = p3D.x, y = p3D.y, z = p3D.z;
         if (mnType == 0) return cv::Point2f(mvParameters[0] * x / z + mvParameters[2], mvParameters[1] * y / z + mvParameters[3]);
         const float x2_plus_y2 = x * x + y * y;
         const float theta = atan2f(sqrtf(x2_plus_y2), z), psi = atan2f(y, x);
@@ -96,20 +101,35 @@ public:
     MapPoint(long unsigned int id, const cv::Mat &Pos, Map *pMap) : mnId(id), mnBALocalForKF(0), mTrackProjX(0), mTrackProjY(0),
         mTrackDepth(0), mTrackDepthR(0), mTrackProjXR(0), mTrackProjYR(0), mbTrackInView(false), mbTrackInViewR(false),
         mnTrackScaleLevel(0), mnTrackScaleLevelR(-1), mTrackViewCos(1), mTrackViewCosR(1), mWorldPos(Pos.clone()), mpMap(pMap),
-        mbBad(false), nObs(0), nNormalUpdates(0) {}
+        mbBad(false), nObs(0), nNormalUpdates(0), mfMinDistance(0), mfMaxDistance(0), mNormalVector(cv::Mat::zeros(3, 1, CV_32F)), mpReplaced(nullptr) {}
     void SetWorldPos(const cv::Mat &Pos) { mWorldPos = Pos.clone(); }
     cv::Mat GetWorldPos() { return mWorldPos.clone(); }
     std::map<KeyFrame *, std::tuple<int, int>> GetObservations() { return mObservations; }
     int Observations() { return nObs; }
-    void AddObservation(KeyFrame *pKF, int idxLeft, int idxRight = -1) { mObservations[pKF] = std::make_tuple(idxLeft, idxRight); nObs += (idxLeft != -1) + (idxRight != -1); }
-    void EraseObservation(KeyFrame *pKF)
+    // stand-in helper of the test programs (not a reference method): both indices of an observation at once
+    void AddObservation(KeyFrame *pKF, int idxLeft, int idxRight) { mObservations[pKF] = std::make_tuple(idxLeft, idxRight); nObs += (idxLeft != -1) + (idxRight != -1); }
+    inline void AddObservation(KeyFrame *pKF, int idx);               // src/MapPoint.cc:114-139 (defined below KeyFrame)
+    std::tuple<int, int> GetIndexInKeyFrame(KeyFrame *pKF)             // MapPoint.cc:412-419
     {
         auto it = mObservations.find(pKF);
-        if (it == mObservations.end()) return;
-        nObs -= (std::get<0>(it->second) != -1) + (std::get<1>(it->second) != -1);
-        mObservations.erase(it);
-        if (nObs <= 2) mbBad = true;                    // MapPoint.cc:199-201 (SetBadFlag)
+        return it != mObservations.end() ? it->second : std::tuple<int, int>(-1, -1);
     }
+    bool IsInKeyFrame(KeyFrame *pKF) { return mObservations.count(pKF) != 0; }          // MapPoint.cc:421-425
+    float GetMinDistanceInvariance() { return 0.8f * mfMinDistance; }                   // MapPoint.cc:502-506
+    float GetMaxDistanceInvariance() { return 1.2f * mfMaxDistance; }                   // MapPoint.cc:508-512
+    cv::Mat GetNormal() { return mNormalVector.clone(); }
+    template <class T> int PredictScale(const float &currentDist, T *pKF)               // MapPoint.cc:514-546 (KeyFrame* and Frame* overloads)
+    {
+        const float ratio = mfMaxDistance / currentDist;
+        int nScale = std::ceil(std::log(ratio) / pKF->mfLogScaleFactor);
+        if (nScale < 0) nScale = 0;
+        else if (nScale >= pKF->mnScaleLevels) nScale = pKF->mnScaleLevels - 1;
+        return nScale;
+    }
+    // MapPoint.cc:233-300 moves the observations over and flags this point bad; the stand-in records the decision (the tests compare it)
+    void Replace(MapPoint *pMP) { if (pMP != this) { mpReplaced = pMP; mbBad = true; } }
+    MapPoint *GetReplaced() { return mpReplaced; }
+    inline void EraseObservation(KeyFrame *pKF);                      // src/MapPoint.cc:168-201 (defined below KeyFrame)
     bool isBad() { return mbBad; }
     cv::Mat GetDescriptor() { return mDescriptor.clone(); }
     void UpdateNormalAndDepth() { nNormalUpdates++; }
@@ -128,6 +148,9 @@ public:
     Map *mpMap;
     bool mbBad;
     int nObs, nNormalUpdates;
+    float mfMinDistance, mfMaxDistance;
+    cv::Mat mNormalVector;
+    MapPoint *mpReplaced;
 };
 
 // include/KeyFrame.h
@@ -138,6 +161,70 @@ public:
           NLeft(-1), mPrevKF(nullptr), mNextKF(nullptr), bImu(false), mpImuPreintegrated(nullptr), mpMap(pMap), mbBad(false) {}
     void SetPose(const cv::Mat &Tcw_) { Tcw = Tcw_.clone(); }
     cv::Mat GetPose() { return Tcw.clone(); }
+    // src/KeyFrame.cc:131-160, 1176-1262: pose parts in the reference's float cv::Mat arithmetic (products accumulated in double,
+    // one rounding per element, as cv::gemm does for CV_32F)
+    cv::Mat GetRotation() { cv::Mat R(3, 3, CV_32F); for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R.at<float>(i, j) = Tcw.at<float>(i, j); return R; }
+    cv::Mat GetTranslation() { cv::Mat t(3, 1, CV_32F); for (int i = 0; i < 3; i++) t.at<float>(i) = Tcw.at<float>(i, 3); return t; }
+    cv::Mat GetCameraCenter()                               // Ow = -Rwc * tcw (KeyFrame.cc:113-118, SetPose)
+    {
+        cv::Mat o(3, 1, CV_32F);
+        for (int i = 0; i < 3; i++) {
+            double a = 0;
+            for (int k = 0; k < 3; k++) a += (double)Tcw.at<float>(k, i) * (double)Tcw.at<float>(k, 3);
+            o.at<float>(i) = (float)(-1.0 * a);
+        }
+        return o;
+    }
+    cv::Mat GetRightRotation()                              // Rrw = Rrl * Rlw, Rrl = mTlr.R^T (KeyFrame.cc:1243-1251)
+    {
+        cv::Mat R(3, 3, CV_32F);
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+            double a = 0;
+            for (int k = 0; k < 3; k++) a += (double)mTlr.at<float>(k, i) * (double)Tcw.at<float>(k, j);
+            R.at<float>(i, j) = (float)a;
+        }
+        return R;
+    }
+    cv::Mat GetRightTranslation()                           // trw = Rrl * tlw + trl, trl = -Rrl * tlr (KeyFrame.cc:1253-1262)
+    {
+        float trl[3];
+        for (int i = 0; i < 3; i++) {
+            double a = 0;
+            for (int k = 0; k < 3; k++) a += (double)mTlr.at<float>(k, i) * (double)mTlr.at<float>(k, 3);
+            trl[i] = (float)(-1.0 * a);
+        }
+        cv::Mat t(3, 1, CV_32F);
+        for (int i = 0; i < 3; i++) {
+            double a = 0;
+            for (int k = 0; k < 3; k++) a += (double)mTlr.at<float>(k, i) * (double)Tcw.at<float>(k, 3);
+            t.at<float>(i) = (float)(a + (double)trl[i]);
+        }
+        return t;
+    }
+    cv::Mat GetRightCameraCenter()                          // twr = Rwl * tlr + twl (KeyFrame.cc:1232-1241)
+    {
+        const cv::Mat Ow = GetCameraCenter();
+        cv::Mat t(3, 1, CV_32F);
+        for (int i = 0; i < 3; i++) {
+            double a = 0;
+            for (int k = 0; k < 3; k++) a += (double)Tcw.at<float>(k, i) * (double)mTlr.at<float>(k, 3);
+            t.at<float>(i) = (float)(a + (double)Ow.at<float>(i));
+        }
+        return t;
+    }
+    bool IsInImage(const float &x, const float &y) const { return (x >= mnMinX && x < mnMaxX && y >= mnMinY && y < mnMaxY); }    // KeyFrame.cc:816-819
+    MapPoint *GetMapPoint(const size_t &idx) { return mvpMapPoints[idx]; }
+    void AddMapPoint(MapPoint *pMP, const size_t &idx) { mvpMapPoints[idx] = pMP; }
+    std::set<MapPoint *> GetMapPoints()                     // KeyFrame.cc:600-613
+    {
+        std::set<MapPoint *> s;
+        for (size_t i = 0, iend = mvpMapPoints.size(); i < iend; i++) {
+            if (!mvpMapPoints[i]) continue;
+            MapPoint *pMP = mvpMapPoints[i];
+            if (!pMP->isBad()) s.insert(pMP);
+        }
+        return s;
+    }
     // src/KeyFrame.cc:161-172: Owb = Rwc tcb + Ow, Rwb = Rwc Rcb (float cv::Mat arithmetic)
     cv::Mat GetImuPosition()
     {
@@ -187,6 +274,14 @@ public:
     bool bImu;
     IMU::Preintegrated *mpImuPreintegrated;
     IMU::Calib mImuCalib;
+    // members the keyframe-side matchers read (include/KeyFrame.h:360-400)
+    int N = 0;
+    std::vector<cv::KeyPoint> mvKeys;
+    std::vector<float> mvScaleFactors, mvLevelSigma2;
+    int mnScaleLevels = 8;
+    float mfLogScaleFactor = std::log(1.2f);
+    int mnMinX = 0, mnMinY = 0, mnMaxX = 0, mnMaxY = 0;
+    cv::Mat mTlr;
     // stand-in state
     cv::Mat Tcw, Vw;
     IMU::Bias mImuBias;
@@ -195,6 +290,32 @@ public:
     Map *mpMap;
     bool mbBad;
 };
+
+// src/MapPoint.cc:114-139
+inline void MapPoint::AddObservation(KeyFrame *pKF, int idx)
+{
+    std::tuple<int, int> indexes = mObservations.count(pKF) ? mObservations[pKF] : std::tuple<int, int>(-1, -1);
+    if (pKF->NLeft != -1 && idx >= pKF->NLeft) std::get<1>(indexes) = idx;
+    else std::get<0>(indexes) = idx;
+    mObservations[pKF] = indexes;
+    if (!pKF->mpCamera2 && pKF->mvuRight[idx] >= 0) nObs += 2;
+    else nObs++;
+}
+
+// src/MapPoint.cc:168-201 (SetBadFlag reduced to the flag)
+inline void MapPoint::EraseObservation(KeyFrame *pKF)
+{
+    auto it = mObservations.find(pKF);
+    if (it == mObservations.end()) return;
+    const int leftIndex = std::get<0>(it->second), rightIndex = std::get<1>(it->second);
+    if (leftIndex != -1) {
+        if (!pKF->mpCamera2 && pKF->mvuRight[leftIndex] >= 0) nObs -= 2;
+        else nObs--;
+    }
+    if (rightIndex != -1) nObs--;
+    mObservations.erase(it);
+    if (nObs <= 2) mbBad = true;
+}
 
 // include/Map.h
 class Map {
@@ -214,7 +335,7 @@ public:
 // include/Frame.h (the members ORBmatcher.cc:48-218, 710-825, 1965-2181 read or write)
 class Frame {
 public:
-    Frame() : mbf(0), mb(0), N(0), mpCamera(nullptr), mpCamera2(nullptr), Nleft(-1), Nright(-1) {}
+    Frame() : mbf(0), mb(0), N(0), mpCamera(nullptr), mpCamera2(nullptr), Nleft(-1), Nright(-1), mnScaleLevels(8), mfLogScaleFactor(std::log(1.2f)) {}
     float mbf, mb;
     int N;
     std::vector<cv::KeyPoint> mvKeys, mvKeysRight, mvKeysUn;
@@ -230,6 +351,8 @@ public:
     int Nleft, Nright;
     std::vector<int> mvLeftToRightMatch, mvRightToLeftMatch;
     cv::Mat mTrl;
+    int mnScaleLevels;
+    float mfLogScaleFactor;
 };
 
 }  // namespace ORB_SLAM3

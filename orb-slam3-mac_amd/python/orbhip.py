@@ -671,6 +671,24 @@ def search_for_triangulation_device(ctx, kf1, kf2, d_pair, pairs, max_nodes, max
                                                     d_matches12, d_nmatches), "orbhip_search_for_triangulation_device")
 
 
+TRI_GENERAL_DTYPE = np.dtype([("R12", "<f4", (4, 9)), ("t12", "<f4", (4, 3)), ("F12", "<f4", (4, 9)), ("cam1", "<f4", (2, 8)), ("cam2", "<f4", (2, 8)),
+                              ("cam1_type", "<i4", (2,)), ("cam2_type", "<i4", (2,)), ("ep_x", "<f4"), ("ep_y", "<f4"), ("nleft1", "<i4"), ("nleft2", "<i4"),
+                              ("only_stereo", "<i4"), ("coarse", "<i4")])
+lib.orbhip_search_for_triangulation_general_device.argtypes = [vp] * 17 + [ci, ci, ci, sz, vp, vp, vp, ci, ci, vp, vp]
+
+
+def search_for_triangulation_general_device(ctx, kf1, kf2, d_pair, pairs, max_nodes, max_n, kp_stride, level_sigma2_1, scale_factors2,
+                                            level_sigma2_2, check_ori, d_matches12, d_nmatches):
+    """ORBmatcher::SearchForTriangulation for every camera combination (Pinhole / KannalaBrandt8 / two-camera rigs), batched.  kf1 / kf2 as
+    in search_for_triangulation_device; d_pair: [pairs] TRI_GENERAL_DTYPE records."""
+    a = [np.ascontiguousarray(x, np.float32) for x in (level_sigma2_1, scale_factors2, level_sigma2_2)]
+    assert len(a[0]) == len(a[1]) == len(a[2])
+    _chk(lib.orbhip_search_for_triangulation_general_device(ctx.h, *[x or None for x in kf1], *[x or None for x in kf2], d_pair, pairs, max_nodes,
+                                                            max_n, kp_stride, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, len(a[0]),
+                                                            1 if check_ori else 0, d_matches12, d_nmatches),
+         "orbhip_search_for_triangulation_general_device")
+
+
 lib.orbhip_search_by_bow_device.argtypes = [vp] * 15 + [ci, ci, ci, sz, cf, ci, vp, vp]
 
 

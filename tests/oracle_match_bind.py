@@ -366,3 +366,144 @@ def search_by_bow_rig(c, nleft, nn_ratio=0.7, check_ori=True):
                                   fi.ctypes.data, fs.ctypes.data, ff.ctypes.data, len(fi), kpf.ctypes.data, df.ctypes.data, nF, nleft,
                                   nn_ratio, 1 if check_ori else 0, m.ctypes.data)
     return n, m[:nF]
+
+
+# ------------------------------------------------------------------ SearchForTriangulation, every camera combination
+TRI_GENERAL_DTYPE = np.dtype([("R12", "<f4", (4, 9)), ("t12", "<f4", (4, 3)), ("F12", "<f4", (4, 9)), ("cam1", "<f4", (2, 8)), ("cam2", "<f4", (2, 8)),
+                              ("cam1_type", "<i4", (2,)), ("cam2_type", "<i4", (2,)), ("ep_x", "<f4"), ("ep_y", "<f4"), ("nleft1", "<i4"), ("nleft2", "<i4"),
+                              ("only_stereo", "<i4"), ("coarse", "<i4")])
+lib.orc_search_for_triangulation_general.restype = ci
+lib.orc_search_for_triangulation_general.argtypes = [vp] * 5 + [ci] + [vp] * 3 + [ci] + [vp] * 4 + [vp, vp, vp, vp, ci, vp]
+lib.orc_kb8_triangulate_matches.restype = cf
+lib.orc_kb8_triangulate_matches.argtypes = [ci, vp, ci, vp, cf, cf, cf, cf, vp, vp, cf, cf, vp]
+lib.orc_camera_project_f.argtypes = [ci, vp, vp, vp]
+lib.orc_camera_unproject_f.argtypes = [ci, vp, cf, cf, vp]
+
+
+def camera_project_f(cam_type, params, P):
+    p = np.ascontiguousarray(params, np.float32); x = np.ascontiguousarray(P, np.float32); uv = np.zeros(2, np.float32)
+    lib.orc_camera_project_f(cam_type, p.ctypes.data, x.ctypes.data, uv.ctypes.data)
+    return uv
+
+
+def camera_unproject_f(cam_type, params, u, v):
+    p = np.ascontiguousarray(params, np.float32); r = np.zeros(3, np.float32)
+    lib.orc_camera_unproject_f(cam_type, p.ctypes.data, float(u), float(v), r.ctypes.data)
+    return r
+
+
+def kb8_triangulate_matches(type1, cam1, type2, cam2, p1, p2, R12, t12, sigma1, sigma2):
+    """KannalaBrandt8::TriangulateMatches restated.  Returns (z1 or -1, x3D)."""
+    c1 = np.ascontiguousarray(cam1, np.float32); c2 = np.ascontiguousarray(cam2, np.float32)
+    R = np.ascontiguousarray(R12, np.float32).reshape(9); t = np.ascontiguousarray(t12, np.float32)
+    x = np.zeros(3, np.float32)
+    z = lib.orc_kb8_triangulate_matches(type1, c1.ctypes.data, type2, c2.ctypes.data, float(p1[0]), float(p1[1]), float(p2[0]), float(p2[1]),
+                                        R.ctypes.data, t.ctypes.data, float(sigma1), float(sigma2), x.ctypes.data)
+    return z, x
+
+
+def kb8_project_np(cam, P):
+    """double-precision KannalaBrandt8 / Pinhole projection for building test scenes (cam = (type, 8 params))"""
+    t, p = cam
+    P = np.asarray(P, np.float64)
+    if t == 0:
+        return np.stack([p[0] * P[..., 0] / P[..., 2] + p[2], p[1] * P[..., 1] / P[..., 2] + p[3]], -1)
+    th = np.arctan2(np.hypot(P[..., 0], P[..., 1]), P[..., 2]); psi = np.arctan2(P[..., 1], P[..., 0])
+    r = th + p[4] * th ** 3 + p[5] * th ** 5 + p[6] * th ** 7 + p[7] * th ** 9
+    return np.stack([p[0] * r * np.cos(psi) + p[2], p[1] * r * np.sin(psi) + p[3]], -1)
+
+
+def _rot(ax, ang):
+    ax = np.asarray(ax, np.float64); ax = ax / np.linalg.norm(ax)
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+
+
+def make_tri_general_case(rng, n1, n2, mode, n_nodes=60, only_stereo=False, coarse=False):
+    """Two keyframes seeing the same synthetic points, in one of the reference's camera set-ups:
+      'pinhole'  single Pinhole cameras (must agree with the fast-path kernel / oracle),
+      'kb8'      single KannalaBrandt8 cameras (monocular fisheye: epipole test + triangulation constraint),
+      'rig'      two-camera KannalaBrandt8 rigs (NLeft != -1: keypoints left | right, relative pose per camera pair).
+    KF2's keypoints are reprojections of KF1's points into (one of) its camera(s), plus outliers off the epipolar geometry."""
+    pin = np.array([458.0, 457.0, 367.0, 248.0, 0, 0, 0, 0], np.float32)
+    kbl = np.array([190.9, 190.8, 254.9, 256.8, 0.0034, 0.0007, -0.0020, 0.0002], np.float32)
+    kbr = np.array([190.4, 190.6, 252.7, 255.0, 0.0031, 0.0009, -0.0019, 0.0003], np.float32)
+    rig = mode == "rig"
+    ctype = 0 if mode == "pinhole" else 1
+    camL = pin if mode == "pinhole" else kbl
+    camR = kbr
+    # X_right = Rrl X_left + trl (mTrl); relative pose of the left cameras X1l = Rll X2l + tll
+    Rrl = _rot([0.1, 1.0, 0.05], 0.02); trl = np.array([-0.101, 0.0007, 0.0012])
+    Rll = _rot([0.0, 1.0, 0.1], 0.06); tll = np.array([0.35, 0.02, 0.15])
+    combos = {}
+    combos[0] = (Rll, tll)
+    combos[1] = (Rll @ Rrl.T, tll - Rll @ Rrl.T @ trl)                       # lr: X1l from X2r
+    combos[2] = (Rrl @ Rll, Rrl @ tll + trl)                                 # rl: X1r from X2l
+    combos[3] = (Rrl @ combos[1][0], Rrl @ combos[1][1] + trl)               # rr
+    g = np.zeros(1, TRI_GENERAL_DTYPE)[0]
+    for c in range(4 if rig else 1):
+        g["R12"][c] = combos[c][0].astype(np.float32).reshape(9); g["t12"][c] = combos[c][1].astype(np.float32)
+    g["cam1"][0] = camL; g["cam2"][0] = camL; g["cam1"][1] = camR; g["cam2"][1] = camR
+    g["cam1_type"][:] = ctype; g["cam2_type"][:] = ctype
+    if mode == "pinhole":
+        K = np.array([[pin[0], 0, pin[2]], [0, pin[1], pin[3]], [0, 0, 1]], np.float32)
+        Kinv = np.linalg.inv(K.astype(np.float64)).astype(np.float32)
+        g["F12"][0] = (Kinv.T @ skew(g["t12"][0]) @ g["R12"][0].reshape(3, 3) @ Kinv).astype(np.float32).reshape(9)
+    # epipole: KF1's (left) centre in KF2's left camera
+    C2 = -(Rll.T @ tll)
+    ep = kb8_project_np((ctype, camL.astype(np.float64)), C2)
+    g["ep_x"], g["ep_y"] = np.float32(ep[0]), np.float32(ep[1])
+    g["only_stereo"], g["coarse"] = int(only_stereo), int(coarse)
+    scale = (np.float32(1.2) ** np.arange(8)).astype(np.float32); sigma2 = (scale * scale).astype(np.float32)
+    # points in front of KF2's left camera; keypoint side (left / right camera) per keypoint
+    nl1 = int(n1 * 0.55) if rig else n1
+    nl2 = int(n2 * 0.5) if rig else n2
+    g["nleft1"], g["nleft2"] = (nl1, nl2) if rig else (-1, -1)
+    X2l = np.stack([rng.uniform(-3, 3, n1), rng.uniform(-2, 2, n1), rng.uniform(2, 10, n1)], 1)
+    X1l = X2l @ Rll.T + tll
+    right1 = np.arange(n1) >= nl1
+    X1 = np.where(right1[:, None], X1l @ Rrl.T + trl, X1l)
+    kp1 = np.zeros(n1, KP_DTYPE); kp2 = np.zeros(n2, KP_DTYPE)
+    uv1 = np.where(right1[:, None], kb8_project_np((ctype, camR.astype(np.float64)), X1), kb8_project_np((ctype, camL.astype(np.float64)), X1))
+    kp1["x"], kp1["y"] = uv1[:, 0], uv1[:, 1]
+    kp1["octave"] = rng.integers(0, 8, n1); kp1["angle"] = rng.uniform(0, 360, n1).astype(np.float32)
+    d1 = rng.integers(0, 256, (n1, 32), dtype=np.uint8)
+    nid1 = (rng.integers(0, n_nodes, n1) * 3 + 100).astype(np.int32)
+    nid1[rng.random(n1) < 0.03] = -1                                          # features in no vocabulary node
+    src = rng.integers(0, max(n1, 1), n2) if n1 else np.zeros(n2, np.int64)
+    right2 = np.arange(n2) >= nl2
+    if n1:
+        noise = rng.integers(0, 256, (n2, 32), dtype=np.uint8) & rng.integers(0, 256, (n2, 32), dtype=np.uint8) & rng.integers(0, 256, (n2, 32), dtype=np.uint8)
+        noise[rng.random(n2) < 0.3] = 0
+        d2 = d1[src] ^ noise
+        nid2 = np.where(rng.random(n2) < 0.85, np.maximum(nid1[src], 100), rng.integers(0, n_nodes + 10, n2) * 3 + 101).astype(np.int32)
+        X2 = np.where(right2[:, None], X2l[src] @ Rrl.T + trl, X2l[src])
+        uv2 = np.where(right2[:, None], kb8_project_np((ctype, camR.astype(np.float64)), X2), kb8_project_np((ctype, camL.astype(np.float64)), X2))
+        jit = rng.normal(0, 1.0, (n2, 2)) * rng.choice([0.2, 1.0, 6.0], n2)[:, None]
+        kp2["x"], kp2["y"] = uv2[:, 0] + jit[:, 0], uv2[:, 1] + jit[:, 1]
+        near = rng.random(n2) < 0.05
+        kp2["x"][near] = g["ep_x"] + rng.uniform(-12, 12, near.sum()); kp2["y"][near] = g["ep_y"] + rng.uniform(-12, 12, near.sum())
+        kp2["angle"] = (kp1["angle"][src] + rng.choice([0, 0, 0, 90], n2) + rng.normal(0, 4, n2)).astype(np.float32) % np.float32(360)
+    else:
+        d2 = rng.integers(0, 256, (n2, 32), dtype=np.uint8); nid2 = (rng.integers(0, n_nodes, n2) * 3 + 100).astype(np.int32)
+    kp2["octave"] = rng.integers(0, 8, n2)
+    sf = 0.0 if rig else 0.3                                                  # rig keyframes carry no stereo keypoints (mvuRight all -1)
+    ur1 = np.where(rng.random(n1) < sf, kp1["x"] - 5, -1).astype(np.float32)
+    ur2 = np.where(rng.random(n2) < sf, kp2["x"] - 5, -1).astype(np.float32)
+    return dict(kp1=kp1, d1=d1, nid1=nid1, mp1=(rng.random(n1) < 0.3).astype(np.uint8), ur1=ur1,
+                kp2=kp2, d2=d2, nid2=nid2, mp2=(rng.random(n2) < 0.2).astype(np.uint8), ur2=ur2, geom=g, scale=scale, sigma2=sigma2,
+                sigma2_1=(sigma2 * np.float32(1.0)).astype(np.float32), mode=mode)
+
+
+def search_for_triangulation_general(c, check_ori=True):
+    i2, s2, f2 = feature_vector_csr(c["nid2"])
+    n1 = len(c["kp1"])
+    m = np.zeros(max(n1, 1), np.int32)
+    a = {k: np.ascontiguousarray(c[k]) for k in ("nid1", "mp1", "kp1", "d1", "ur1", "mp2", "kp2", "d2", "ur2", "scale", "sigma2", "sigma2_1")}
+    g = np.ascontiguousarray(np.array([c["geom"]], TRI_GENERAL_DTYPE))
+    n = lib.orc_search_for_triangulation_general(a["nid1"].ctypes.data, a["mp1"].ctypes.data, a["kp1"].ctypes.data, a["d1"].ctypes.data,
+                                                 a["ur1"].ctypes.data, n1, i2.ctypes.data, s2.ctypes.data, f2.ctypes.data, len(i2),
+                                                 a["mp2"].ctypes.data, a["kp2"].ctypes.data, a["d2"].ctypes.data, a["ur2"].ctypes.data,
+                                                 g.ctypes.data, a["sigma2_1"].ctypes.data, a["scale"].ctypes.data, a["sigma2"].ctypes.data,
+                                                 1 if check_ori else 0, m.ctypes.data)
+    return n, m[:n1]

@@ -506,6 +506,71 @@ def test_search_for_triangulation_parity(gpu_ctx, stereo_frac, only_stereo, coar
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode,only_stereo,coarse,check_ori", [("pinhole", False, False, True), ("pinhole", True, False, False), ("kb8", False, False, True),
+                                                                ("kb8", False, True, True), ("rig", False, False, True), ("rig", False, False, False),
+                                                                ("rig", True, False, True)])
+def test_search_for_triangulation_general_parity(gpu_ctx, mode, only_stereo, coarse, check_ori):
+    """SearchForTriangulation for every camera combination (ORBmatcher.cc:969-1210): Pinhole and KannalaBrandt8 single cameras, two-fisheye
+    rigs (NLeft != -1, the four relative poses, KannalaBrandt8::epipolarConstrain by triangulation) -- ragged keyframe pairs incl. empty
+    sides, bit-exact vs the oracle; the Pinhole cases also against the fast-path kernel."""
+    import torch
+    import orbhip
+    import oracle_match_bind as om
+    rng = np.random.default_rng(1183)
+    cases = [om.make_tri_general_case(rng, a, b, mode, nn, only_stereo, coarse)
+             for a, b, nn in ((0, 20, 10), (30, 0, 10), (200, 260, 40), (1000, 950, 100), (2000, 2048, 300), (600, 1500, 900))]
+    P, MN, MNODE = len(cases), 2048, 2048
+    arr = dict(nid1=np.zeros((P, MN), np.int32), mp1=np.zeros((P, MN), np.uint8), kp1=np.zeros((P, MN), orbhip.KP_DTYPE),
+               d1=np.zeros((P, MN, 32), np.uint8), ur1=np.full((P, MN), -1, np.float32), n1=np.zeros(P, np.int32),
+               i2=np.zeros((P, MNODE), np.int32), s2=np.zeros((P, MNODE + 1), np.int32), f2=np.zeros((P, MN), np.int32), nn2=np.zeros(P, np.int32),
+               mp2=np.zeros((P, MN), np.uint8), kp2=np.zeros((P, MN), orbhip.KP_DTYPE), d2=np.zeros((P, MN, 32), np.uint8),
+               ur2=np.full((P, MN), -1, np.float32), n2=np.zeros(P, np.int32), geom=np.zeros(P, orbhip.TRI_GENERAL_DTYPE),
+               fast=np.zeros(P, orbhip.TRI_PAIR_DTYPE))
+    assert orbhip.TRI_GENERAL_DTYPE == om.TRI_GENERAL_DTYPE
+    for p, c in enumerate(cases):
+        a, b = len(c["kp1"]), len(c["kp2"])
+        i2, s2, f2 = om.feature_vector_csr(c["nid2"])
+        arr["nid1"][p, :a] = c["nid1"]; arr["mp1"][p, :a] = c["mp1"]; arr["kp1"][p, :a] = c["kp1"]; arr["d1"][p, :a] = c["d1"]
+        arr["ur1"][p, :a] = c["ur1"]; arr["n1"][p] = a
+        arr["i2"][p, :len(i2)] = i2; arr["s2"][p, :len(s2)] = s2; arr["f2"][p, :len(f2)] = f2; arr["nn2"][p] = len(i2)
+        arr["mp2"][p, :b] = c["mp2"]; arr["kp2"][p, :b] = c["kp2"]; arr["d2"][p, :b] = c["d2"]; arr["ur2"][p, :b] = c["ur2"]; arr["n2"][p] = b
+        arr["geom"][p] = c["geom"]
+        arr["fast"][p] = (c["geom"]["F12"][0], c["geom"]["ep_x"], c["geom"]["ep_y"], int(only_stereo), int(coarse))
+    t = {k: torch.from_numpy(v.view(np.uint8) if v.dtype.fields else v).cuda() for k, v in arr.items()}
+    m12 = torch.full((P, MN), -9, dtype=torch.int32, device="cuda"); nm = torch.full((P,), -9, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    kf1 = [t["nid1"].data_ptr(), t["mp1"].data_ptr(), t["kp1"].data_ptr(), t["d1"].data_ptr(), t["ur1"].data_ptr(), t["n1"].data_ptr()]
+    kf2 = [t["i2"].data_ptr(), t["s2"].data_ptr(), t["f2"].data_ptr(), t["nn2"].data_ptr(), t["mp2"].data_ptr(), t["kp2"].data_ptr(), t["d2"].data_ptr(),
+           t["ur2"].data_ptr(), t["n2"].data_ptr()]
+    orbhip.search_for_triangulation_general_device(gpu_ctx, kf1, kf2, t["geom"].data_ptr(), P, MNODE, MN, MN, cases[0]["sigma2_1"], cases[0]["scale"],
+                                                   cases[0]["sigma2"], check_ori, m12.data_ptr(), nm.data_ptr())
+    gpu_ctx.check_status()
+    m12h, nmh = m12.cpu().numpy(), nm.cpu().numpy()
+    tot = 0
+    for p, c in enumerate(cases):
+        n_ref, m_ref = om.search_for_triangulation_general(c, check_ori)
+        assert nmh[p] == n_ref, (p, nmh[p], n_ref)
+        np.testing.assert_array_equal(m12h[p, :len(m_ref)], m_ref)
+        tot += n_ref
+    if mode == "rig" and only_stereo:
+        assert tot == 0                                       # rig keyframes have no stereo keypoints (ORBmatcher.cc:1044-1048)
+    else:
+        assert tot > (100 if only_stereo else 300)
+    if mode == "rig" and not only_stereo:                     # all four camera pairs produced matches
+        c = cases[4]; m = m12h[4, :len(c["kp1"])]; i1 = np.flatnonzero(m >= 0)
+        combo = 2 * (i1 >= c["geom"]["nleft1"]) + (m[i1] >= c["geom"]["nleft2"])
+        assert set(combo.tolist()) == {0, 1, 2, 3}
+    if mode == "pinhole":
+        m12b = torch.full((P, MN), -9, dtype=torch.int32, device="cuda"); nmb = torch.full((P,), -9, dtype=torch.int32, device="cuda")
+        orbhip.search_for_triangulation_device(gpu_ctx, kf1, kf2, t["fast"].data_ptr(), P, MNODE, MN, MN, cases[0]["scale"], cases[0]["sigma2"], check_ori,
+                                               m12b.data_ptr(), nmb.data_ptr())
+        gpu_ctx.check_status()
+        assert torch.equal(nm, nmb)
+        for p, c in enumerate(cases):
+            assert torch.equal(m12[p, :len(c["kp1"])], m12b[p, :len(c["kp1"])])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("ratio,check_ori", [(0.75, True), (0.9, False)])
 def test_search_by_bow_kf_parity(gpu_ctx, ratio, check_ori):
     """LoopClosing's KF-KF matcher (ORBmatcher.cc:827-967) on ragged pairs incl. empty sides, bit-exact vs the oracle."""

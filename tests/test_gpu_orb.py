@@ -342,15 +342,16 @@ def test_wide_image_small_budget(gpu_ctx, w, h, nfeat, nlev):
 
 
 def test_hd_batch_properties(gpu_ctx):
-    """BASELINE config #3's frame shape at batch 64 (1920x1080, 2000 features; one GPU's shard is 512 such frames): sampled frames
+    """BASELINE config #3's per-GPU shard at full size: 512 frames of 1920x1080, 2000 features (4096 over 8 GPUs): sampled frames
     bit-exact vs the oracle, run-to-run determinism (checksum of checksums), structural invariants of every frame."""
     import hashlib
     import orbhip
+    import bench
     ext, ora = _mk(gpu_ctx, 2000)
-    imgs = orbhip.synth_frames(1920, 1080, 64, seed=20241004)
+    imgs = bench.synth_frames_parallel(orbhip, 1920, 1080, 512, 20241004, 0)
     r1 = _dev_extract(gpu_ctx, ext, imgs, (0, 0))
     digest1 = hashlib.sha256(b"".join(hashlib.sha256(k.tobytes() + d.tobytes()).digest() for k, d, _ in r1)).hexdigest()
-    for f in (0, 31, 63):
+    for f in (0, 31, 255, 511):
         kp, desc, mono = ora.extract(imgs[f], (0, 0))
         assert r1[f][2] == mono and r1[f][0].tobytes() == kp.tobytes() and r1[f][1].tobytes() == desc.tobytes(), f
     quota = ext.features_per_level()

@@ -1108,3 +1108,119 @@ def test_rig_search_by_bow_oracle_against_python():
         assert n_ref == nm and n_ref > 20
         np.testing.assert_array_equal(m_ref, m)
         assert (m_ref[nleft:] >= 0).sum() > 3
+
+
+# ------------------------------------------------------------------ KannalaBrandt8 epipolar constraint (SearchForTriangulation, rig / fisheye)
+def _kb8_unproject_np(p, u, v):
+    """KannalaBrandt8::unproject in double (independent model): Newton on theta_d = theta (1 + k1 theta^2 + ...)"""
+    x, y = (u - p[2]) / p[0], (v - p[3]) / p[1]
+    td = min(max(-np.pi / 2, np.hypot(x, y)), np.pi / 2)
+    s = 1.0
+    if td > 1e-8:
+        th = td
+        for _ in range(50):
+            f = th * (1 + p[4] * th ** 2 + p[5] * th ** 4 + p[6] * th ** 6 + p[7] * th ** 8) - td
+            fp = 1 + 3 * p[4] * th ** 2 + 5 * p[5] * th ** 4 + 7 * p[6] * th ** 6 + 9 * p[7] * th ** 8
+            th -= f / fp
+        s = np.tan(th) / td
+    return np.array([x * s, y * s, 1.0])
+
+
+def _triangulate_matches_np(cam1, cam2, p1, p2, R12, t12, s1, s2):
+    """KannalaBrandt8::TriangulateMatches (KannalaBrandt8.cpp:334-401) in double with numpy's SVD; returns (z1 or -1, x3D, margin) where
+    margin is the smallest relative distance of any of its tests from its threshold."""
+    import oracle_match_bind as om
+    r1, r2 = _kb8_unproject_np(cam1, *p1), _kb8_unproject_np(cam2, *p2)
+    r21 = R12 @ r2
+    cosp = r1 @ r21 / (np.linalg.norm(r1) * np.linalg.norm(r21))
+    margins = [abs(cosp - 0.9998) / 0.9998]
+    if cosp > 0.9998:
+        return -1.0, None, min(margins)
+    R21 = R12.T; t21 = -R21 @ t12
+    T1 = np.hstack([np.eye(3), np.zeros((3, 1))]); T2 = np.hstack([R21, t21[:, None]])
+    A = np.stack([r1[0] * T1[2] - T1[0], r1[1] * T1[2] - T1[1], r2[0] * T2[2] - T2[0], r2[1] * T2[2] - T2[1]])
+    v = np.linalg.svd(A)[2][3]
+    X = v[:3] / v[3]
+    z1 = X[2]; z2 = R21[2] @ X + t21[2]
+    margins += [abs(z1), abs(z2)]
+    if z1 <= 0 or z2 <= 0:
+        return -1.0, X, min(margins)
+    e1 = om.kb8_project_np((1, cam1), X) - np.asarray(p1); e2 = om.kb8_project_np((1, cam2), R21 @ X + t21) - np.asarray(p2)
+    margins += [abs(e1 @ e1 - 5.991 * s1) / (5.991 * s1), abs(e2 @ e2 - 5.991 * s2) / (5.991 * s2)]
+    if e1 @ e1 > 5.991 * s1 or e2 @ e2 > 5.991 * s2:
+        return -1.0, X, min(margins)
+    return z1, X, min(margins)
+
+
+def test_kb8_triangulate_matches_oracle_against_numpy_model():
+    """The oracle's float restatement (one-sided Jacobi SVD as OpenCV's, fixed sincos / atan2 sequences) against an independent double
+    model with numpy's SVD: same accept / reject decision wherever no test sits within 1e-3 of its threshold, triangulated point
+    within 1e-3 relative.  Covers inliers, gross outliers, low parallax, points behind a camera."""
+    import oracle_match_bind as om
+    rng = np.random.default_rng(2718)
+    cam1 = np.array([190.9, 190.8, 254.9, 256.8, 0.0034, 0.0007, -0.0020, 0.0002]); cam2 = np.array([190.4, 190.6, 252.7, 255.0, 0.0031, 0.0009, -0.0019, 0.0003])
+    decided = accepted = 0
+    for it in range(600):
+        R12 = om._rot(rng.normal(size=3), rng.uniform(0, 0.3)); t12 = rng.normal(size=3) * rng.choice([0.02, 0.3, 1.0])
+        X2 = np.array([rng.uniform(-3, 3), rng.uniform(-2, 2), rng.uniform(0.5, 12)])
+        X1 = R12 @ X2 + t12
+        if X1[2] < 0.2:
+            continue
+        p1 = om.kb8_project_np((1, cam1), X1) + rng.normal(0, 0.3, 2)
+        p2 = om.kb8_project_np((1, cam2), X2) + rng.normal(0, 0.3, 2) * rng.choice([1, 1, 30])
+        s1, s2 = float(np.float32(1.2) ** (2 * rng.integers(0, 8))), float(np.float32(1.2) ** (2 * rng.integers(0, 8)))
+        R32, t32 = R12.astype(np.float32), t12.astype(np.float32)
+        p1f, p2f = p1.astype(np.float32), p2.astype(np.float32)
+        z, x = om.kb8_triangulate_matches(1, cam1, 1, cam2, p1f, p2f, R32, t32, s1, s2)
+        zr, xr, margin = _triangulate_matches_np(cam1.astype(np.float32).astype(np.float64), cam2.astype(np.float32).astype(np.float64),
+                                                 p1f.astype(np.float64), p2f.astype(np.float64), R32.astype(np.float64), t32.astype(np.float64), s1, s2)
+        if margin < 1e-3:
+            continue
+        decided += 1
+        assert (z > 0) == (zr > 0), (it, z, zr, margin)
+        if z > 0:
+            accepted += 1
+            assert np.allclose(x, xr, rtol=2e-3, atol=2e-3), (x, xr)
+    assert decided > 300 and 50 < accepted < decided - 50, (decided, accepted)
+
+
+def test_camera_project_unproject_roundtrip_oracle():
+    """GeometricCamera::unproject then project returns the pixel (both models), and the float KB8 projection agrees with a double model."""
+    import oracle_match_bind as om
+    rng = np.random.default_rng(99)
+    kb = np.array([190.9, 190.8, 254.9, 256.8, 0.0034, 0.0007, -0.0020, 0.0002], np.float32)
+    pin = np.array([458.0, 457.0, 367.0, 248.0, 0, 0, 0, 0], np.float32)
+    for _ in range(200):
+        u, v = rng.uniform(80, 430), rng.uniform(80, 430)          # inside 85 degrees of the axis (unproject clamps theta at 90, as the reference does)
+        for t, cam in ((1, kb), (0, pin)):
+            ray = om.camera_unproject_f(t, cam, u, v)
+            uv = om.camera_project_f(t, cam, ray * np.float32(rng.uniform(0.5, 8)))
+            assert abs(uv[0] - u) < 2e-2 and abs(uv[1] - v) < 2e-2, (t, u, v, uv)
+        P = np.array([rng.uniform(-3, 3), rng.uniform(-3, 3), rng.uniform(0.3, 9)], np.float32)
+        assert np.allclose(om.camera_project_f(1, kb, P), om.kb8_project_np((1, kb.astype(np.float64)), P.astype(np.float64)), atol=2e-3)
+
+
+def test_search_for_triangulation_general_oracle_reduces_to_the_pinhole_form():
+    """The general restatement on single Pinhole cameras == the fast-path restatement (same inputs, F12 of combination 0), and on rigs every
+    match joins keypoints whose cameras were handed the right relative pose (a match's pair passes TriangulateMatches when re-evaluated)."""
+    import oracle_match_bind as om
+    rng = np.random.default_rng(5)
+    for n1, n2 in ((0, 10), (300, 0), (500, 650)):
+        c = om.make_tri_general_case(rng, n1, n2, "pinhole")
+        n, m = om.search_for_triangulation_general(c, True)
+        c2 = dict(c); c2["F12"] = c["geom"]["F12"][0]; c2["ep"] = (c["geom"]["ep_x"], c["geom"]["ep_y"]); c2["only_stereo"] = False; c2["coarse"] = False
+        n2_, m2 = om.search_for_triangulation(c2, True, False)
+        assert n == n2_ and np.array_equal(m, m2)
+    c = om.make_tri_general_case(rng, 700, 800, "rig")
+    n, m = om.search_for_triangulation_general(c, False)
+    g = c["geom"]
+    assert n > 100
+    for i1 in np.flatnonzero(m >= 0):
+        i2 = m[i1]
+        b1, b2 = int(i1 >= g["nleft1"]), int(i2 >= g["nleft2"])
+        z, _ = om.kb8_triangulate_matches(1, g["cam1"][b1], 1, g["cam2"][b2], (c["kp1"]["x"][i1], c["kp1"]["y"][i1]), (c["kp2"]["x"][i2], c["kp2"]["y"][i2]),
+                                          g["R12"][2 * b1 + b2], g["t12"][2 * b1 + b2], c["sigma2_1"][c["kp1"]["octave"][i1]], c["sigma2"][c["kp2"]["octave"][i2]])
+        assert z > 0.0001
+    # rig keyframes have no stereo keypoints: bOnlyStereo finds nothing (ORBmatcher.cc:1044-1048)
+    c = om.make_tri_general_case(rng, 300, 300, "rig", only_stereo=True)
+    assert om.search_for_triangulation_general(c, True)[0] == 0
