@@ -1935,11 +1935,11 @@ static int ba_solve_impl(orbhip_ba_batch *b, const orbhip_ba_params *params, vol
         hipLaunchKernelGGL(k_ba_pretrial, dim3((G + 63) / 64), dim3(64), 0, s, B);
         hipLaunchKernelGGL(k_ba_point_prep, gp256, dim3(256), 0, s, B);
         if (b->profile) TRY(hipEventRecord(b->ev0, s));
-        if (B.pair_schur) {
+        if (B.pair_schur && max_nfp > 0) {                       // (a batch whose poses are all fixed has no reduced system: points only)
             if (G >= 8) hipLaunchKernelGGL(k_ba_schur_big<16>, dim3((unsigned)(((max_nfp + 3) / 4) * (((G + 7) / 8) * 8))), dim3(64), 0, s, B, (max_nfp + 3) / 4);
             else hipLaunchKernelGGL(k_ba_schur_big<64>, dim3((unsigned)(max_nfp * G)), dim3(64), 0, s, B, max_nfp);
         }
-        else hipLaunchKernelGGL(k_ba_schur_gemm, dim3(max_items, G), dim3(64 * GEMM_WAVES), gemm_lds, s, B);
+        else if (!B.pair_schur) hipLaunchKernelGGL(k_ba_schur_gemm, dim3(max_items, G), dim3(64 * GEMM_WAVES), gemm_lds, s, B);
         if (b->profile) TRY(hipEventRecord(b->ev1, s));
         if (!B.pair_schur) hipLaunchKernelGGL(k_ba_bschur, gf, dim3(64), 0, s, B);      // (the pair kernel's diagonal rows produced bs)
         if (sharded) {                                           // exchange 2: the shared Schur block (sum_ks Spart) and W db

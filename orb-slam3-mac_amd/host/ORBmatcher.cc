@@ -7,6 +7,7 @@
 #include <cstdio>
 #include "hip_context.h"
 #include <cstdlib>
+#include "cvmath.h"
 
 namespace ORB_SLAM3 {
 
@@ -19,14 +20,11 @@ inline orbhip_ctx *thread_ctx() { return hip::ThreadContext(); }      // one con
 
 static_assert(sizeof(cv::KeyPoint) == sizeof(orbhip_keypoint), "KeyPoint layout");
 
-// x3Dc = Rcw * x3Dw + tcw on CV_32F matrices: cv::gemm accumulates float products in double and rounds the sum once
+// x3Dc = Rcw * x3Dw + tcw on CV_32F matrices (cvmath.h: cv::gemm's small-matrix path, float sums)
 inline void transform(const cv::Mat &T, const cv::Mat &Xw, float (&Xc)[3])
 {
-    for (int i = 0; i < 3; i++) {
-        double a = 0;
-        for (int k = 0; k < 3; k++) a += (double)T.at<float>(i, k) * (double)Xw.at<float>(k);
-        Xc[i] = (float)(a + (double)T.at<float>(i, 3));
-    }
+    const cvm::V3 x = cvm::mul_add(cvm::block3(T), cvm::vec3(Xw), cvm::col3(T));
+    for (int i = 0; i < 3; i++) Xc[i] = x(i);
 }
 
 // mvpMapPoints as the kernels' claim array: -1 = free (no map point, or one without observations: ORBmatcher.cc:110-112)
@@ -125,18 +123,10 @@ int ORBmatcher::SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMa
 int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono)
 {
     const bool rig = CurrentFrame.Nleft != -1;
-    // twc = -Rcw^T tcw ; tlc = Rlw twc + tlw (ORBmatcher.cc:1976-1984), CV_32F matrix products (double accumulation, one rounding each)
-    float twc[3], tlc[3];
-    for (int i = 0; i < 3; i++) {
-        double a = 0;
-        for (int k = 0; k < 3; k++) a += (double)(-CurrentFrame.mTcw.at<float>(k, i)) * (double)CurrentFrame.mTcw.at<float>(k, 3);
-        twc[i] = (float)a;
-    }
-    for (int i = 0; i < 3; i++) {
-        double a = 0;
-        for (int k = 0; k < 3; k++) a += (double)LastFrame.mTcw.at<float>(i, k) * (double)twc[k];
-        tlc[i] = (float)(a + (double)LastFrame.mTcw.at<float>(i, 3));
-    }
+    // twc = -Rcw.t()*tcw ; tlc = Rlw*twc + tlw (ORBmatcher.cc:1976-1984), CV_32F matrix products as cvmath.h spells them
+    const cvm::V3 twc_ = cvm::mul_t(cvm::block3(CurrentFrame.mTcw), cvm::col3(CurrentFrame.mTcw), -1.0);
+    const cvm::V3 tlc_ = cvm::mul_add(cvm::block3(LastFrame.mTcw), twc_, cvm::col3(LastFrame.mTcw));
+    const float tlc[3] = {tlc_(0), tlc_(1), tlc_(2)};
     const bool bForward = tlc[2] > CurrentFrame.mb && !bMono;
     const bool bBackward = -tlc[2] > CurrentFrame.mb && !bMono;
 
@@ -173,12 +163,8 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, 
         const cv::Mat dMP = pMP->GetDescriptor();
         dq.insert(dq.end(), dMP.ptr<uint8_t>(), dMP.ptr<uint8_t>() + 32);
         if (rig) {                                                                // the same point in the right camera (:2089-2105)
-            float x3Dr[3];
-            for (int a = 0; a < 3; a++) {                                         // mTrl.colRange(0,3).rowRange(0,3) * x3Dc + mTrl.col(3)
-                double acc = 0;
-                for (int k = 0; k < 3; k++) acc += (double)CurrentFrame.mTrl.at<float>(a, k) * (double)x3Dc[k];
-                x3Dr[a] = (float)(acc + (double)CurrentFrame.mTrl.at<float>(a, 3));
-            }
+            const cvm::V3 xr_ = cvm::mul_add(cvm::block3(CurrentFrame.mTrl), cvm::V3{{x3Dc[0], x3Dc[1], x3Dc[2]}}, cvm::col3(CurrentFrame.mTrl));   // mTrl.R * x3Dc + mTrl.col(3)
+            const float x3Dr[3] = {xr_(0), xr_(1), xr_(2)};
             cv::Mat m3Dr(3, 1, CV_32F);
             for (int k = 0; k < 3; k++) m3Dr.at<float>(k) = x3Dr[k];
             const cv::Point2f uvr = CurrentFrame.mpCamera->project(m3Dr);        // (the reference projects through mpCamera here, :2092)

@@ -7,6 +7,7 @@
 // Not carried over: the "Too much distance" statistics of :2261-2313 (Verbose prints at VERBOSITY_DEBUG only) and the
 // unreachable bRedrawError file dump (:2183-2200, :2209-2251: behind a `return`).
 #include "Optimizer.h"
+#include "optimizer_common.h"
 #include <cstdio>
 #include "hip_context.h"
 #include <list>
@@ -15,57 +16,7 @@
 
 namespace ORB_SLAM3 {
 
-namespace {
-
-// Converter::toSE3Quat (src/Converter.cc:34-44): float 4x4 -> double R, t -> g2o::SE3Quat(R, t), whose constructor
-// (Thirdparty/g2o/g2o/types/se3quat.h:58-60) builds Eigen::Quaterniond(R) and normalizeRotation() (:280-285: w >= 0, unit norm).
-void toSE3Quat(const cv::Mat &cvT, double *q7)
-{
-    double R[3][3];
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[i][j] = (double)cvT.at<float>(i, j);
-    double q[4];                                        // x, y, z, w
-    const double tr = R[0][0] + R[1][1] + R[2][2];
-    if (tr > 0) {
-        double s = std::sqrt(tr + 1.0);
-        q[3] = 0.5 * s; s = 0.5 / s;
-        q[0] = (R[2][1] - R[1][2]) * s; q[1] = (R[0][2] - R[2][0]) * s; q[2] = (R[1][0] - R[0][1]) * s;
-    } else {
-        int i = 0;
-        if (R[1][1] > R[0][0]) i = 1;
-        if (R[2][2] > R[i][i]) i = 2;
-        const int j = (i + 1) % 3, k = (j + 1) % 3;
-        double s = std::sqrt(R[i][i] - R[j][j] - R[k][k] + 1.0);
-        q[i] = 0.5 * s; s = 0.5 / s;
-        q[3] = (R[k][j] - R[j][k]) * s; q[j] = (R[j][i] + R[i][j]) * s; q[k] = (R[k][i] + R[i][k]) * s;
-    }
-    if (q[3] < 0) for (double &v : q) v = -v;
-    const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-    for (int i = 0; i < 4; i++) q7[i] = q[i] / n;
-    for (int i = 0; i < 3; i++) q7[4 + i] = (double)cvT.at<float>(i, 3);
-}
-
-// Converter::toCvMat(g2o::SE3Quat) (src/Converter.cc:46-50, 60-68): to_homogeneous_matrix (Quaterniond::toRotationMatrix) -> CV_32F
-cv::Mat toCvMat(const double *q7)
-{
-    const double x = q7[0], y = q7[1], z = q7[2], w = q7[3];
-    const double tx = 2 * x, ty = 2 * y, tz = 2 * z, twx = tx * w, twy = ty * w, twz = tz * w;
-    const double txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
-    const double R[3][3] = {{1 - (tyy + tzz), txy - twz, txz + twy}, {txy + twz, 1 - (txx + tzz), tyz - twx}, {txz - twy, tyz + twx, 1 - (txx + tyy)}};
-    cv::Mat m = cv::Mat::eye(4, 4, CV_32F);
-    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) m.at<float>(i, j) = (float)R[i][j]; m.at<float>(i, 3) = (float)q7[4 + i]; }
-    return m;
-}
-
-inline orbhip_ctx *thread_ctx() { return hip::ThreadContext(); }      // one context per calling thread, GPU of hip::GetDevice() (hip_context.h)
-
-void camera_fields(GeometricCamera *cam, double &fx, double &fy, double &cx, double &cy, int32_t &model, double (&kb)[4])
-{
-    fx = cam->getParameter(0); fy = cam->getParameter(1); cx = cam->getParameter(2); cy = cam->getParameter(3);
-    model = cam->GetType() == cam->CAM_FISHEYE ? 1 : 0;
-    for (int i = 0; i < 4; i++) kb[i] = model ? (double)cam->getParameter(4 + i) : 0.0;
-}
-
-}  // namespace
+using namespace optc;
 
 void Optimizer::LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Map *pMap, int &num_fixedKF)
 {
@@ -197,14 +148,20 @@ void Optimizer::LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Map *pMap
     g.n_poses = nKF; g.n_points = nMP; g.n_edges = nE;
     g.pose_fixed = fixed.data(); g.edge_pose = ePose.data(); g.edge_point = ePoint.data(); g.edge_obs = obs.data();
     g.edge_inv_sigma2 = invS2.data(); g.edge_stereo = eType.data();
-    // every keyframe of a map shares the calibration (the reference hands each edge its keyframe's: :1961, :1990-1994)
+    // the reference hands each edge its keyframe's calibration (e->pCamera = pKFi->mpCamera :1961, e->fx = pKFi->fx ... e->bf = pKFi->mbf
+    // :1990-1994, mTrl / mpCamera2 :2021-2023); the graph carries ONE: a window that mixes calibrations is refused, map untouched
+    for (KeyFrame *pKFi : vpKFs)
+        if (!same_calibration(pKF, pKFi)) {
+            fprintf(stderr, "LM-LBA: keyframe %lu has another calibration than keyframe %lu: window not optimised (one calibration per graph)\n", pKFi->mnId, pKF->mnId);
+            return;
+        }
+    // monocular edges project through pKFi->mpCamera (getParameter), stereo edges through the keyframe's fx, fy, cx, cy, bf members:
+    // the same numbers in every configuration of the reference (KeyFrame copies them from the same calibration, KeyFrame.cc:40-45)
     camera_fields(pKF->mpCamera, g.fx, g.fy, g.cx, g.cy, g.camera_model, g.kb);
-    g.fx = pKF->fx; g.fy = pKF->fy; g.cx = pKF->cx; g.cy = pKF->cy; g.bf = pKF->mbf;
+    g.bf = pKF->mbf;
     g.Trl[3] = 1.0;
     if (pRigKF) {
-        cv::Mat T = cv::Mat::eye(4, 4, CV_32F);                                      // mTrl is 3x4 (Converter::toSE3Quat reads rows 0..2)
-        for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) T.at<float>(i, j) = pRigKF->mTrl.at<float>(i, j);
-        toSE3Quat(T, g.Trl);
+        trl_to_se3quat(pRigKF->mTrl, g.Trl);
         camera_fields(pRigKF->mpCamera2, g.fx2, g.fy2, g.cx2, g.cy2, g.camera2_model, g.kb2);
     }
     orbhip_ba_params p;

@@ -9,6 +9,7 @@
 using namespace ORB_SLAM3;
 
 float Frame::mnMinX = 0.f, Frame::mnMaxX = 0.f, Frame::mnMinY = 0.f, Frame::mnMaxY = 0.f;
+float Frame::fx = 0.f, Frame::fy = 0.f, Frame::cx = 0.f, Frame::cy = 0.f;
 
 namespace {
 struct Reader {

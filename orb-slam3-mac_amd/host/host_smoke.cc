@@ -308,11 +308,18 @@ static int bow_smoke(const char *in, const char *out)
 
 int match_smoke(const char *in, const char *out);            // host_match_smoke.cc
 
+int kf_smoke(const char *in, const char *out);
+int poseopt_smoke(const char *in, const char *out);
+int mergeba_smoke(const char *in, const char *out);
+
 int main(int argc, char **argv)
 {
     if (argc == 4 && std::string(argv[1]) == "lba") return lba_smoke(argv[2], argv[3]);
     if (argc == 4 && std::string(argv[1]) == "match") return match_smoke(argv[2], argv[3]);
     if (argc == 4 && std::string(argv[1]) == "liba") return liba_smoke(argv[2], argv[3]);
     if (argc == 4 && std::string(argv[1]) == "bow") return bow_smoke(argv[2], argv[3]);
+    if (argc == 4 && std::string(argv[1]) == "kfmatch") return kf_smoke(argv[2], argv[3]);
+    if (argc == 4 && std::string(argv[1]) == "poseopt") return poseopt_smoke(argv[2], argv[3]);
+    if (argc == 4 && std::string(argv[1]) == "mergeba") return mergeba_smoke(argv[2], argv[3]);
     return extractor_smoke();
 }

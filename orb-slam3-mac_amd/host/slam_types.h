@@ -136,6 +136,7 @@ public:
     Map *GetMap() { return mpMap; }
     long unsigned int mnId;
     long unsigned int mnBALocalForKF;
+    long unsigned int mnBALocalForMerge = 0;
     // Tracking's per-frame projection record (Frame::isInFrustum fills it; ORBmatcher.cc:57-79 reads it)
     float mTrackProjX, mTrackProjY, mTrackDepth, mTrackDepthR, mTrackProjXR, mTrackProjYR;
     bool mbTrackInView, mbTrackInViewR;
@@ -259,6 +260,7 @@ public:
     Map *GetMap() { return mpMap; }
     long unsigned int mnId;
     long unsigned int mnBALocalForKF, mnBAFixedForKF;
+    long unsigned int mnBALocalForMerge = 0;
     const float fx, fy, cx, cy, mbf;
     std::vector<cv::KeyPoint> mvKeysUn;
     std::vector<float> mvuRight;
@@ -353,6 +355,9 @@ public:
     cv::Mat mTrl;
     int mnScaleLevels;
     float mfLogScaleFactor;
+    std::vector<float> mvInvLevelSigma2;
+    static float fx, fy, cx, cy;                          // include/Frame.h:212-217 (static calibration)
+    void SetPose(cv::Mat Tcw) { mTcw = Tcw.clone(); }     // src/Frame.cc:352-356 (UpdatePoseMatrices: derived members only)
 };
 
 }  // namespace ORB_SLAM3

@@ -170,3 +170,29 @@ def test_bench_workloads_match_baseline_configs():
     assert (a.width, a.height, a.nfeatures, a.batch * a.gpus) == (1920, 1080, 2000, 4096)                         # configs[2]
     ab = bench.algorithmic_bytes(640, 480, 1000, 0)
     assert ab["S"] == 950532 and ab["total"] == 5742474
+
+
+def test_reference_call_lines_compile_against_the_host_classes(tmp_path):
+    """The drop-in claim, compile-only: host/compile_callers.cc holds the call lines of the reference's Tracking (src/Tracking.cc:1505-1506,
+    1757-1775, 1881-1934, 1996-2002, 2405-2428, 2645-2753), LocalMapping (src/LocalMapping.cc:138-154, 407-463, 781-817), LoopClosing
+    (src/LoopClosing.cc:578-755, 1005-1008, 1722, 2284-2340) and Frame::ExtractORB (src/Frame.cc:410-417) as the reference writes them; it must
+    build against host/ORBextractor.h, host/ORBmatcher.h and host/Optimizer.h with -Wall -Werror, and every class method it calls must be
+    DEFINED by the host sources (a link of the same unit against them resolves)."""
+    import subprocess
+    host = os.path.join(ROOT, "orb-slam3-mac_amd", "host")
+    obj = str(tmp_path / "callers.o")
+    r = subprocess.run(["g++", "-std=c++17", "-O0", "-Wall", "-Werror", "-c", "-o", obj, os.path.join(host, "compile_callers.cc")],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    undefined = subprocess.run(["nm", "-C", "-u", obj], stdout=subprocess.PIPE, text=True).stdout
+    wanted = [ln.split("U ", 1)[1].strip() for ln in undefined.splitlines() if "ORB_SLAM3::ORBmatcher::" in ln or "ORB_SLAM3::Optimizer::" in ln or "ORB_SLAM3::ORBextractor::" in ln]
+    assert len(wanted) >= 18, wanted                           # 13 matcher methods + ctor, 4 optimiser entry points, the extractor's operator()
+    defined = ""
+    for src in ("ORBmatcher.cc", "ORBmatcher_keyframe.cc", "Optimizer_LocalBA.cc", "Optimizer_LocalInertialBA.cc", "Optimizer_PoseOptimization.cc",
+                "Optimizer_MergeBA.cc", "ORBextractor.cc"):
+        o = str(tmp_path / (src + ".o"))
+        r = subprocess.run(["g++", "-std=c++17", "-O0", "-c", "-o", o, os.path.join(host, src)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout[-2000:]
+        defined += subprocess.run(["nm", "-C", "--defined-only", o], stdout=subprocess.PIPE, text=True).stdout
+    missing = [w for w in wanted if w not in defined]
+    assert not missing, missing

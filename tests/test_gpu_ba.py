@@ -103,6 +103,24 @@ def test_ba_ragged_batch(ba_ctx):
     _check(gpu_ctx, graphs)
 
 
+def test_ba_all_keyframes_fixed(ba_ctx):
+    """No free keyframe at all (the map-merge LBA as the reference writes it puts edges on the FIXED keyframes only, Optimizer.cc:6292 /
+    :6424): no reduced system, the points are refined against fixed poses.  Next to a normal graph in the same batch."""
+    import orbhip
+    import synth_ba
+    gpu_ctx = ba_ctx
+    import oracle_ba_bind as ob
+    g = synth_ba.make_graph(n_kf=8, n_pts=150, obs=6, seed=5, stereo_frac=0.3, outlier_frac=0.03, pose_noise=(0.0003, 0.001))
+    g["pose_fixed"] = np.ones(8, np.uint8)
+    prm = ob.merge_params(); prm.iters2 = 0                               # premise of the merge parity (see test_ba_merge_variant): >= 2 edges per point survive
+    out1 = ob.solve(g, prm)[3]
+    assert np.bincount(g["edge_point"][out1 == 0], minlength=g["n_points"]).min() >= 2
+    st = _check(gpu_ctx, [g], orbhip.ba_merge_params())
+    assert st[0]["chi2_final"] < st[0]["chi2_initial"] and not st[0]["discarded"]
+    st = _check(gpu_ctx, [g, synth_ba.make_graph(n_kf=6, n_pts=40, obs=4, seed=6)])
+    assert not st[0]["discarded"]
+
+
 def test_ba_discards_when_mostly_outliers(ba_ctx):
     gpu_ctx = ba_ctx
     import synth_ba

@@ -218,6 +218,16 @@ def _f32(x):
     return np.float32(x)
 
 
+def _gemm_small(R, x, t=None, alpha=1.0):
+    """cv::gemm on CV_32F with no transposed operand and inner dimension 3 (host/cvmath.h): the row products are summed in FLOAT, then
+    d = (float)(sum * alpha + c * 1.0) in double."""
+    out = []
+    for i in range(3):
+        s = np.float32(np.float32(np.float32(R[i][0]) * np.float32(x[0]) + np.float32(R[i][1]) * np.float32(x[1])) + np.float32(R[i][2]) * np.float32(x[2]))
+        out.append(np.float32(np.float64(s) * alpha + (np.float64(t[i]) if t is not None else 0.0)))
+    return out
+
+
 def _match_case(seed, bMono, forward=0.0):
     import oracle_match_bind as om
     from oracle_bind import KP_DTYPE
@@ -295,13 +305,13 @@ def _write_match(path, c):
 
 
 def _expected_last_frame(c, rig=False):
-    """ORBmatcher.cc:1976-2023 (+ :2089-2105 on a rig frame) restated in numpy float32 (matrix products accumulate in double and round
-    once, as cv::gemm), then the claim-rule search of the oracle."""
+    """ORBmatcher.cc:1976-2023 (+ :2089-2105 on a rig frame) restated in numpy float32 (matrix products as host/cvmath.h states OpenCV's:
+    float sums on the plain products, double sums where an operand is transposed), then the claim-rule search of the oracle."""
     import oracle_match_bind as om
     fx, fy, cx, cy = (np.float32(v) for v in c["cam"])
     Tcw, Tlw = c["Tcw"], c["Tlw"]
     twc = np.array([np.float32(sum(np.float64(-Tcw[k, i]) * np.float64(Tcw[k, 3]) for k in range(3))) for i in range(3)], np.float32)
-    tlc = np.array([np.float32(sum(np.float64(Tlw[i, k]) * np.float64(twc[k]) for k in range(3)) + np.float64(Tlw[i, 3])) for i in range(3)], np.float32)
+    tlc = np.array(_gemm_small(Tlw[:3, :3], twc, Tlw[:3, 3]), np.float32)
     fwd = bool(tlc[2] > np.float32(c["mb"])) and not c["bMono"]
     bwd = bool(-tlc[2] > np.float32(c["mb"])) and not c["bMono"]
     q, dq, qsrc = [], [], []
@@ -309,7 +319,7 @@ def _expected_last_frame(c, rig=False):
         if not c["hasMP"][i] or c["outl"][i]:
             continue
         X = c["Xw"][i]
-        xc = [np.float32(sum(np.float64(Tcw[r, k]) * np.float64(X[k]) for k in range(3)) + np.float64(Tcw[r, 3])) for r in range(3)]
+        xc = _gemm_small(Tcw[:3, :3], X, Tcw[:3, 3])
         invzc = np.float32(1.0 / np.float64(xc[2]))
         if invzc < 0:
             continue
@@ -323,7 +333,7 @@ def _expected_last_frame(c, rig=False):
         dq.append(c["dL"][i]); qsrc.append(i)
         if rig:
             T = c["Trl"]
-            xr = [np.float32(sum(np.float64(T[r, k]) * np.float64(xc[k]) for k in range(3)) + np.float64(T[r, 3])) for r in range(3)]
+            xr = _gemm_small(T[:3, :3], xc, T[:3, 3])
             ur_ = np.float32(np.float32(np.float32(fx * xr[0]) / xr[2]) + cx); vr_ = np.float32(np.float32(np.float32(fy * xr[1]) / xr[2]) + cy)
             q.append((ur_, vr_, radius, q[-1][3], c["kpL"]["angle"][i], lv[0], lv[1], int(c["nobs"][i] > 0) | 2))
             dq.append(c["dL"][i]); qsrc.append(i)
