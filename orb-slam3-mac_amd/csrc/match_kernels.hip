@@ -792,7 +792,7 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
                                                              float min_x, float min_y, float max_x, float max_y,
                                                              int th_high, int check_ori, int mode, float nn_ratio, int cap_n, int cap_q,
                                                              int32_t *tm_, int32_t *nmatches_, int32_t *status,
-                                                             const int32_t *nleft_, const int32_t *mirror_, int ncells)
+                                                             const int32_t *nleft_, const int32_t *mirror_, int ncells, const int32_t *redo_)
 {
     // dynamic LDS carved by the launcher's capacities (cap_n keypoints, cap_q queries per pair): small frames keep
     // four pairs per CU resident
@@ -810,6 +810,7 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
     __shared__ int hist[SI_HISTO];
     __shared__ int s_keep[3];
     const int pair = blockIdx.x, lane = threadIdx.x;
+    if (redo_ && !redo_[pair]) return;                       // the low-latency form (k_sbp_replay) has done this pair
 #ifdef SBP_PROF
     long long t_prev = clock64();
 #endif
@@ -979,11 +980,285 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
     SBP_T(4);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Low-latency form of SearchByProjection (both modes, single-camera frames) for calls with FEW frame pairs -- Tracking calls the
+// matcher with one.  The register / LDS loops above walk the queries one after the other on ONE wave per pair (~1.2 us per query: 1.2 ms
+// for a frame, whatever the batch); here the expensive part of a query -- window, gates, Hamming distances -- does not depend on the
+// claim rule and is evaluated for ALL queries at once, over the whole chip:
+//   k_sbp_prep        one wave per pair: the Frame grid as a CSR (sbp_build_grid), written out in CSR order: per position a record
+//                     {x, y, cell | octave | pre-held, uRight}, the keypoint index, the descriptor, and the first position of every grid column;
+//   k_sbp_candidates  one wave per query: the window's columns are ONE contiguous range of CSR positions; every position in it is gated
+//                     (cell range, level, |dx|,|dy| < r, pre-held, uRight) and its Hamming distance taken; the keys
+//                     distance << 22 | position << 11 | keypoint index are sorted (rank by counting, in LDS) and the SBPL_K smallest stored;
+//   k_sbp_replay      one wave per pair replays the claim rule (ORBmatcher.cc:2037-2039 / :96-98) over the sorted lists, 64 queries per
+//                     trip, one per lane: a lane's best (and, local-map mode, second best) is its first (two) list entries whose keypoint no
+//                     EARLIER query with observations holds -- claims only ever block more keypoints, so a lane's cursor only moves forward.
+//                     Inside a trip the lanes are speculative: every lane publishes its claim (LDS atomicMin of the lane id per keypoint), the
+//                     prefix of lanes up to the first one whose best / second best was claimed by an earlier lane is final, the others look
+//                     again.  A trip needs 1 + (number of conflicts) rounds of a few LDS operations.
+// The result is the sequential loop's, bit for bit (same candidate sets, same key order, same claim rule); a query whose list was cut at
+// SBPL_K entries and runs out of them makes its pair fall back to the sequential kernel (flag per pair, read on the device).
+#define SBPL_K 32                  // list entries kept per query
+#define SBPL_BUF 512               // candidates a query may have before the pair falls back
+struct SbpWork {
+    float4 *rec;                   // [pairs][cap_n]   CSR order: x, y, bits(cx | cy << 7 | octave << 13 | pre-held << 17), uRight
+    uint4 *desc;                   // [pairs][cap_n][2]
+    uint16_t *idx;                 // [pairs][cap_n]   keypoint index at a CSR position
+    int32_t *col_start;            // [pairs][SI_COLS + 1]
+    uint32_t *lists;               // [pairs][chunks][SBPL_K][64]   (transposed: lane = query inside a trip of 64)
+    int32_t *count;                // [pairs][cap_q]   candidates of the query (may exceed SBPL_K; INT_MAX: more than SBPL_BUF)
+    int32_t *redo;                 // [pairs]          1 = the sequential kernel must process this pair
+    int cap_n, cap_q, chunks;
+};
+
+__global__ __launch_bounds__(64) void k_sbp_prep(const orbhip_keypoint *kp_, const uint8_t *desc_, const float *uright_, const int32_t *n_, int max_n,
+                                                 size_t kp_stride, float min_x, float min_y, float max_x, float max_y, const int32_t *tm_, SbpWork W,
+                                                 int32_t *status)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t sbp_lds[];
+    uint32_t *cell_start = reinterpret_cast<uint32_t *>(sbp_lds);
+    float *kx = reinterpret_cast<float *>(cell_start + SBP_CELLS + 1), *ky = kx + W.cap_n;
+    uint16_t *items = reinterpret_cast<uint16_t *>(ky + W.cap_n), *cell_of = items + W.cap_n, *rank_of = cell_of + W.cap_n;
+    uint8_t *oct = reinterpret_cast<uint8_t *>(rank_of + W.cap_n);
+    const int pair = blockIdx.x, lane = threadIdx.x;
+    const int n = n_[pair];
+    int32_t *cs = W.col_start + (size_t)pair * (SI_COLS + 1);
+    if (n > W.cap_n || n > max_n) {
+        if (lane == 0) { atomicExch(status, ORBHIP_E_CAPACITY); W.redo[pair] = 1; }
+        for (int c = lane; c <= SI_COLS; c += 64) cs[c] = 0;
+        return;
+    }
+    const orbhip_keypoint *kp = kp_ + (size_t)pair * kp_stride;
+    const uint4 *dT = reinterpret_cast<const uint4 *>(desc_ + (size_t)pair * kp_stride * 32);
+    const float *uright = uright_ ? uright_ + (size_t)pair * kp_stride : nullptr;
+    const int32_t *tm = tm_ + (size_t)pair * max_n;
+    const float inv_w = __fdiv_rn((float)SI_COLS, __fsub_rn(max_x, min_x)), inv_h = __fdiv_rn((float)SI_ROWS, __fsub_rn(max_y, min_y));
+    for (int c = lane; c <= SBP_CELLS; c += 64) cell_start[c] = 0;
+    __syncthreads();
+    sbp_build_grid(cell_start, kx, ky, oct, items, cell_of, rank_of, kp, n, min_x, min_y, inv_w, inv_h, lane);
+    const int n_items = (int)cell_start[SBP_CELLS];
+    float4 *rec = W.rec + (size_t)pair * W.cap_n;
+    uint4 *dC = W.desc + (size_t)pair * W.cap_n * 2;
+    uint16_t *idx = W.idx + (size_t)pair * W.cap_n;
+    for (int p = lane; p < n_items; p += 64) {
+        const int i = items[p];
+        const int cell = cell_of[i], cx = (int)(((uint32_t)cell * 43691u) >> 21), cy = cell - SI_ROWS * cx;
+        const uint32_t bits = (uint32_t)cx | ((uint32_t)cy << 7) | ((uint32_t)oct[i] << 13) | ((tm[i] != -1) ? (1u << 17) : 0u);
+        rec[p] = make_float4(kx[i], ky[i], __uint_as_float(bits), uright ? uright[i] : -1.0f);
+        idx[p] = (uint16_t)i;
+        dC[2 * p] = dT[2 * i]; dC[2 * p + 1] = dT[2 * i + 1];
+    }
+    for (int c = lane; c <= SI_COLS; c += 64) cs[c] = (int32_t)cell_start[c * SI_ROWS];
+    if (lane == 0) W.redo[pair] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_sbp_candidates(const orbhip_proj_query *q_, const uint8_t *descq_, const int32_t *nq_, int max_q,
+                                                        float min_x, float min_y, float max_x, float max_y, int use_ur, SbpWork W)
+{
+    __shared__ uint32_t kbuf_all[4][SBPL_BUF];
+    const int pair = blockIdx.y, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + w;
+    const int nq = nq_[pair];
+    if (t >= nq || nq > W.cap_q || nq > max_q) return;
+    uint32_t *kbuf = kbuf_all[w];
+    const orbhip_proj_query qq = q_[(size_t)pair * max_q + t];
+    const uint4 *dQ = reinterpret_cast<const uint4 *>(descq_ + ((size_t)pair * max_q + t) * 32);
+    const uint4 a0 = dQ[0], a1 = dQ[1];
+    const float inv_w = __fdiv_rn((float)SI_COLS, __fsub_rn(max_x, min_x)), inv_h = __fdiv_rn((float)SI_ROWS, __fsub_rn(max_y, min_y));
+    const float x = qq.u, y = qq.v, r = qq.radius;
+    int32_t *count = W.count + (size_t)pair * W.cap_q;
+    int c0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, min_x), r), inv_w)); if (c0 < 0) c0 = 0;                   // Frame.cc:656-674
+    int c1 = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, min_x), r), inv_w)); if (c1 > SI_COLS - 1) c1 = SI_COLS - 1;
+    int r0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, min_y), r), inv_h)); if (r0 < 0) r0 = 0;
+    int r1 = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, min_y), r), inv_h)); if (r1 > SI_ROWS - 1) r1 = SI_ROWS - 1;
+    if (c0 >= SI_COLS || c1 < 0 || r0 >= SI_ROWS || r1 < 0) { if (lane == 0) count[t] = 0; return; }
+    const int32_t *cs = W.col_start + (size_t)pair * (SI_COLS + 1);
+    const int p0 = cs[c0], p1 = cs[c1 + 1];
+    const float4 *rec = W.rec + (size_t)pair * W.cap_n;
+    const uint4 *dC = W.desc + (size_t)pair * W.cap_n * 2;
+    const uint16_t *idx = W.idx + (size_t)pair * W.cap_n;
+    const bool check_lv = qq.min_level > 0 || qq.max_level >= 0;                                                     // Frame.cc:676
+    const uint32_t cw = (uint32_t)(c1 - c0), rh = (uint32_t)(r1 - r0);
+    int total = 0;
+    for (int pb = p0; pb < p1; pb += 64) {
+        const int p = pb + lane;
+        bool ok = p < p1;
+        uint32_t key = 0xFFFFFFFFu;
+        if (ok) {
+            const float4 k = rec[p];
+            const uint32_t bits = __float_as_uint(k.z);
+            const uint32_t dcx = (bits & 127u) - (uint32_t)c0, dcy = ((bits >> 7) & 63u) - (uint32_t)r0;
+            const int o = (int)((bits >> 13) & 15u);
+            ok = (dcx <= cw) & (dcy <= rh);
+            ok = ok & !((int)check_lv & ((int)(o < qq.min_level) | ((int)(qq.max_level >= 0) & (int)(o > qq.max_level))));   // Frame.cc:693-701
+            ok = ok & (bool)((int)(fabsf(__fsub_rn(k.x, x)) < r) & (int)(fabsf(__fsub_rn(k.y, y)) < r));                    // Frame.cc:704-708
+            ok = ok & !((bits >> 17) & 1u);                                                                                  // holds a map point already (:2037 / :96 on entry)
+            if (use_ur) ok = ok & !((k.w > 0) & (fabsf(__fsub_rn(qq.ur, k.w)) > r));                                        // ORBmatcher.cc:2041-2047 / 100-105
+            if (ok) {
+                const int dist = hamming256(a0, a1, dC[2 * p], dC[2 * p + 1]);
+                key = ((uint32_t)dist << 22) | ((uint32_t)p << 11) | (uint32_t)idx[p];
+            }
+        }
+        const unsigned long long m = __ballot(ok);
+        const int before = __popcll(m & ((1ull << lane) - 1));
+        if (ok && total + before < SBPL_BUF) kbuf[total + before] = key;
+        total += __popcll(m);
+    }
+    if (total > SBPL_BUF) { if (lane == 0) count[t] = 0x7FFFFFFF; return; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // rank by counting (keys are unique): the SBPL_K smallest go to the list in order
+    uint32_t *L = W.lists + (((size_t)pair * W.chunks + (t >> 6)) * SBPL_K) * 64 + (t & 63);
+    for (int e = lane; e < total; e += 64) {
+        const uint32_t mine = kbuf[e];
+        int rank = 0;
+        for (int j = 0; j < total; j++) rank += kbuf[j] < mine;
+        if (rank < SBPL_K) L[(size_t)rank * 64] = mine;
+    }
+    if (lane == 0) count[t] = total;
+}
+
+__global__ __launch_bounds__(64) void k_sbp_replay(const orbhip_proj_query *q_, const int32_t *nq_, int max_q, const orbhip_keypoint *kp_,
+                                                   const int32_t *n_, int max_n, size_t kp_stride, int th_high, int check_ori, int mode, float nn_ratio,
+                                                   SbpWork W, int32_t *tm_, int32_t *nmatches_)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t sbp_lds[];
+    int32_t *holder = reinterpret_cast<int32_t *>(sbp_lds);                         // [cap_n]  -1 free, -2 pre-held, else query << 1 | has_obs
+    int32_t *owner = holder + W.cap_n;                                               // [cap_n]  lowest lane of this round that claims the keypoint (64: none)
+    int16_t *qm = reinterpret_cast<int16_t *>(owner + W.cap_n);                      // [cap_q]
+    uint8_t *oct = reinterpret_cast<uint8_t *>(qm + W.cap_q);                        // [cap_n]
+    int8_t *qbin = reinterpret_cast<int8_t *>(oct + W.cap_n);                        // [cap_q]
+    __shared__ int hist[SI_HISTO];
+    __shared__ int s_keep[3];
+    const int pair = blockIdx.x, lane = threadIdx.x;
+    if (W.redo[pair]) return;                                                        // (capacity: the sequential kernel reports it)
+    const int n = n_[pair], nq = nq_[pair];
+    if (nq > W.cap_q || nq > max_q) { if (lane == 0) W.redo[pair] = 1; return; }
+    const orbhip_proj_query *Q = q_ + (size_t)pair * max_q;
+    const orbhip_keypoint *kp = kp_ + (size_t)pair * kp_stride;
+    int32_t *tm = tm_ + (size_t)pair * max_n;
+    const int32_t *count = W.count + (size_t)pair * W.cap_q;
+    for (int i = lane; i < SI_HISTO; i += 64) hist[i] = 0;
+    for (int i = lane; i < n; i += 64) { holder[i] = tm[i] == -1 ? -1 : -2; owner[i] = 64; oct[i] = (uint8_t)kp[i].octave; }
+    for (int t = lane; t < nq; t += 64) { qm[t] = -1; qbin[t] = -1; }
+    __syncthreads();
+    int nmatches = 0;
+    bool give_up = false;
+    for (int t0 = 0; t0 < nq && !give_up; t0 += 64) {
+        const int t = t0 + lane;
+        const bool valid = t < nq;
+        const uint32_t *L = W.lists + (((size_t)pair * W.chunks + (t0 >> 6)) * SBPL_K) * 64 + lane;
+        const int cnt_all = valid ? count[t] : 0;
+        const int cnt = min(cnt_all, SBPL_K);
+        const int ho = valid ? (Q[t].has_obs & 1) : 0;
+        uint32_t kr0 = 0xFFFFFFFFu, kr1 = 0xFFFFFFFFu, kr2 = 0xFFFFFFFFu, kr3 = 0xFFFFFFFFu;      // the head of the list in registers (one batch of loads)
+        if (cnt > 0) kr0 = L[0];
+        if (cnt > 1) kr1 = L[64];
+        if (cnt > 2) kr2 = L[128];
+        if (cnt > 3) kr3 = L[192];
+        if (__ballot(cnt_all == 0x7FFFFFFF)) { give_up = true; break; }
+        int ptr = 0;
+        bool fin = !valid || cnt == 0;
+#define SBPL_ENTRY(p) ((p) == 0 ? kr0 : (p) == 1 ? kr1 : (p) == 2 ? kr2 : (p) == 3 ? kr3 : L[(size_t)(p) * 64])
+#define SBPL_BLOCKED(key) (holder[(key) & 0x7FFu] >= 0 && (holder[(key) & 0x7FFu] & 1))
+        while (true) {
+            uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+            bool accept = false, starved = false;
+            if (!fin) {
+                while (ptr < cnt) { const uint32_t k = SBPL_ENTRY(ptr); if (!SBPL_BLOCKED(k)) { k1 = k; break; } ptr++; }
+                if (k1 == 0xFFFFFFFFu) starved = cnt_all > SBPL_K;                    // ran out of a truncated list
+                else {
+                    const int d1 = (int)(k1 >> 22);
+                    accept = d1 <= th_high && d1 < 256;                                // ORBmatcher.cc:2058 / :131
+                    if (accept && mode == 1) {                                         // ratio test against the second best of the same octave (:131-137)
+                        int p2 = ptr + 1;
+                        while (p2 < cnt) { const uint32_t k = SBPL_ENTRY(p2); if (!SBPL_BLOCKED(k)) { k2 = k; break; } p2++; }
+                        if (k2 == 0xFFFFFFFFu) starved = cnt_all > SBPL_K;
+                        else {
+                            const int d2 = (int)(k2 >> 22);
+                            if (oct[k1 & 0x7FFu] == oct[k2 & 0x7FFu] && (float)d1 > __fmul_rn(nn_ratio, (float)d2)) accept = false;
+                        }
+                    }
+                }
+            }
+            if (__ballot(starved)) { give_up = true; break; }
+            // speculative claims of this round: the lowest lane that wants a keypoint (only claims of points WITH observations block others)
+            const bool claims = !fin && accept && ho;
+            if (claims) atomicMin(&owner[k1 & 0x7FFu], lane);
+            __syncthreads();
+            bool conflict = false;
+            if (!fin) {
+                if (k1 != 0xFFFFFFFFu) conflict = owner[k1 & 0x7FFu] < lane;
+                if (k2 != 0xFFFFFFFFu) conflict = conflict || owner[k2 & 0x7FFu] < lane;
+            }
+            const unsigned long long cm = __ballot(conflict);
+            const int f = cm ? __ffsll((long long)cm) - 1 : 64;                        // lanes below f are final
+            __syncthreads();
+            if (claims) owner[k1 & 0x7FFu] = 64;
+            if (!fin && lane < f) {
+                if (accept) {
+                    // several final lanes may take one keypoint when the earlier ones carry no observations: the LAST query keeps it (:2061 / :140)
+                    atomicMax(&holder[k1 & 0x7FFu], (t << 1) | ho);
+                    qm[t] = (int16_t)(k1 & 0x7FFu);
+                    nmatches++;
+                }
+                fin = true;
+            }
+            __syncthreads();
+            if (f == 64) break;
+        }
+#undef SBPL_ENTRY
+#undef SBPL_BLOCKED
+    }
+    if (give_up) { if (lane == 0) W.redo[pair] = 1; return; }                          // nothing written yet: the sequential kernel does this pair
+    nmatches = wave_sum_dpp(nmatches);
+    __syncthreads();
+    const float factor = 1.0f / SI_HISTO;
+    if (check_ori) {                                                                   // rotation consistency, as in k_search_by_projection
+        for (int t = lane; t < nq; t += 64) {
+            const int best = qm[t];
+            if (best < 0) continue;
+            float rot = __fsub_rn(Q[t].angle, kp[best].angle);
+            if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+            int bin = (int)roundf(__fmul_rn(rot, factor));
+            if (bin == SI_HISTO) bin = 0;
+            atomicAdd(&hist[bin], 1); qbin[t] = (int8_t)bin;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+            for (int i = 0; i < SI_HISTO; i++) {
+                const int sz = hist[i];
+                if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+                else if (sz > max3) { max3 = sz; ind3 = i; }
+            }
+            if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+            else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) ind3 = -1;
+            s_keep[0] = ind1; s_keep[1] = ind2; s_keep[2] = ind3;
+        }
+        __syncthreads();
+        int removed = 0;
+        for (int t = lane; t < nq; t += 64) {
+            const int b = qbin[t];
+            if (b < 0 || b == s_keep[0] || b == s_keep[1] || b == s_keep[2]) continue;
+            holder[qm[t]] = -1; removed++;
+        }
+        nmatches -= wave_sum_dpp(removed);
+    }
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) { const int h = holder[i]; tm[i] = h >= 0 ? (h >> 1) : h; }
+    if (lane == 0) nmatches_[pair] = nmatches;
+}
+
 // LDS of k_search_by_projection for the given row capacities (keypoints / queries per pair)
 static size_t sbp_lds_bytes(int cap_n, int cap_q, int ncells)
 {
     return sizeof(uint32_t) * ((size_t)ncells + 1) + (size_t)cap_n * (4 + 4 + 2 + 2 + 2 + 2 + 2 + 1) + (size_t)cap_q * (2 + 1) + 16;
 }
+void *orbhip_ctx_work_internal(orbhip_ctx *c, size_t bytes);
 static int sbp_launch(orbhip_ctx *ctx, const orbhip_proj_query *d_q, const uint8_t *d_desc_q, const int32_t *d_nq, int max_q,
                       const orbhip_keypoint *d_kp, const uint8_t *d_desc, const float *d_u_right, const int32_t *d_n, int max_n,
                       size_t frame_stride_kp, int pairs, float min_x, float min_y, float max_x, float max_y, int th_high,
@@ -997,13 +1272,44 @@ static int sbp_launch(orbhip_ctx *ctx, const orbhip_proj_query *d_q, const uint8
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    hipStream_t st = orbhip_ctx_stream_internal(ctx);
+    // few pairs: the low-latency form first (candidate lists for all queries at once, then the claim rule replayed over them); a pair it
+    // cannot finish (a truncated list ran dry, > SBPL_BUF candidates) is flagged and done by the sequential kernel below.  Many pairs: the
+    // sequential kernel alone -- one wave per pair fills the chip and does no redundant work.  ORBHIP_SBP_PARALLEL_MAX_PAIRS moves the switch.
+    const int par_max = getenv("ORBHIP_SBP_PARALLEL_MAX_PAIRS") ? atoi(getenv("ORBHIP_SBP_PARALLEL_MAX_PAIRS")) : 32;
+    const int32_t *d_redo = nullptr;
+    if (!d_nleft && !d_mirror && pairs <= par_max) {
+        SbpWork W;
+        W.cap_n = cap_n; W.cap_q = cap_q; W.chunks = (cap_q + 63) / 64;
+        auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t o_rec = 0, o_desc = o_rec + al(sizeof(float4) * (size_t)pairs * cap_n), o_idx = o_desc + al(32 * (size_t)pairs * cap_n),
+                     o_cs = o_idx + al(2 * (size_t)pairs * cap_n), o_lists = o_cs + al(4 * (size_t)pairs * (SI_COLS + 1)),
+                     o_count = o_lists + al(4 * (size_t)pairs * W.chunks * SBPL_K * 64), o_redo = o_count + al(4 * (size_t)pairs * cap_q),
+                     total = o_redo + al(4 * (size_t)pairs);
+        uint8_t *wb = (uint8_t *)orbhip_ctx_work_internal(ctx, total);
+        if (!wb) return ORBHIP_E_HIP;
+        W.rec = (float4 *)(wb + o_rec); W.desc = (uint4 *)(wb + o_desc); W.idx = (uint16_t *)(wb + o_idx); W.col_start = (int32_t *)(wb + o_cs);
+        W.lists = (uint32_t *)(wb + o_lists); W.count = (int32_t *)(wb + o_count); W.redo = (int32_t *)(wb + o_redo);
+        const size_t prep_lds = sizeof(uint32_t) * (SBP_CELLS + 1) + (size_t)cap_n * (4 + 4 + 2 + 2 + 2 + 1) + 16;
+        const size_t rep_lds = (size_t)cap_n * (4 + 4 + 1) + (size_t)cap_q * (2 + 1) + 16;
+        if (orb_lds_optin(reinterpret_cast<const void *>(k_sbp_prep), orbhip_ctx_device_internal(ctx), prep_lds) ||
+            orb_lds_optin(reinterpret_cast<const void *>(k_sbp_replay), orbhip_ctx_device_internal(ctx), rep_lds)) return ORBHIP_E_HIP;
+        hipLaunchKernelGGL(k_sbp_prep, dim3(pairs), dim3(64), prep_lds, st, d_kp, d_desc, d_u_right, d_n, max_n, frame_stride_kp, min_x, min_y, max_x, max_y,
+                           d_train_match, W, orbhip_ctx_status_internal(ctx));
+        hipLaunchKernelGGL(k_sbp_candidates, dim3((cap_q + 3) / 4, pairs), dim3(256), 0, st, d_q, d_desc_q, d_nq, max_q, min_x, min_y, max_x, max_y,
+                           d_u_right ? 1 : 0, W);
+        hipLaunchKernelGGL(k_sbp_replay, dim3(pairs), dim3(64), rep_lds, st, d_q, d_nq, max_q, d_kp, d_n, max_n, frame_stride_kp, th_high, check_orientation,
+                           mode, nn_ratio, W, d_train_match, d_nmatches);
+        d_redo = W.redo;
+    }
     const bool desc_lds = with_desc <= 150 * 1024 && (size_t)pairs * with_desc <= (size_t)cus * 150 * 1024;
     const size_t lds = desc_lds ? with_desc : base;
     auto kern = desc_lds ? k_search_by_projection<true> : k_search_by_projection<false>;
     if (orb_lds_optin(reinterpret_cast<const void *>(kern), orbhip_ctx_device_internal(ctx), lds)) return ORBHIP_E_HIP;
-    hipLaunchKernelGGL(kern, dim3(pairs), dim3(64), lds, orbhip_ctx_stream_internal(ctx), d_q, d_desc_q, d_nq,
+    hipLaunchKernelGGL(kern, dim3(pairs), dim3(64), lds, st, d_q, d_desc_q, d_nq,
                        max_q, d_kp, d_desc, d_u_right, d_n, max_n, frame_stride_kp, min_x, min_y, max_x, max_y, th_high,
-                       check_orientation, mode, nn_ratio, cap_n, cap_q, d_train_match, d_nmatches, orbhip_ctx_status_internal(ctx), d_nleft, d_mirror, ncells);
+                       check_orientation, mode, nn_ratio, cap_n, cap_q, d_train_match, d_nmatches, orbhip_ctx_status_internal(ctx), d_nleft, d_mirror, ncells,
+                       d_redo);
     return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
 }
 

@@ -50,6 +50,8 @@ struct orbhip_ctx {
     int32_t *d_status;      // sticky device-side error word (capacity overflows in matcher kernels)
     void *scratch;          // grow-only device arena of the host-pointer convenience entry points (host_entry.hip)
     size_t scratch_bytes;
+    void *work;             // grow-only device arena of the device entry points themselves (candidate lists of the low-latency matchers): separate from
+    size_t work_bytes;      // `scratch`, which holds the host-form callers' staged inputs while those entry points run
     int n_cus;              // hipDeviceAttributeMultiprocessorCount of `device`: persistent grids are sized from it
     int ba_schur_mode;      // orbhip_ctx_set_ba_schur_mode
 };
@@ -76,7 +78,7 @@ extern "C" int orbhip_ctx_create(int device, void *stream, orbhip_ctx **out)
         if (c->own_stream) (void)hipStreamDestroy(c->stream);
         delete c; g_last_error = "hipMalloc(status)"; return ORBHIP_E_HIP;
     }
-    c->scratch = nullptr; c->scratch_bytes = 0; c->ba_schur_mode = 0; c->n_cus = 0;
+    c->scratch = nullptr; c->scratch_bytes = 0; c->work = nullptr; c->work_bytes = 0; c->ba_schur_mode = 0; c->n_cus = 0;
     if (hipDeviceGetAttribute(&c->n_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->n_cus <= 0) c->n_cus = 256;
     *out = c;
     return ORBHIP_OK;
@@ -92,6 +94,18 @@ void *orbhip_ctx_scratch_internal(orbhip_ctx *c, size_t bytes)
     if (hipMalloc(&c->scratch, want) != hipSuccess) { g_last_error = "hipMalloc(scratch arena)"; return nullptr; }
     c->scratch_bytes = want;
     return c->scratch;
+}
+// Device work arena of at least `bytes`, kept across calls.  Growing waits for the stream (earlier kernels may still read the old arena).
+void *orbhip_ctx_work_internal(orbhip_ctx *c, size_t bytes)
+{
+    if (bytes <= c->work_bytes) return c->work;
+    (void)hipStreamSynchronize(c->stream);
+    if (c->work) (void)hipFree(c->work);
+    c->work = nullptr; c->work_bytes = 0;
+    const size_t want = std::max<size_t>(bytes + bytes / 4, 1 << 20);
+    if (hipMalloc(&c->work, want) != hipSuccess) { g_last_error = "hipMalloc(work arena)"; return nullptr; }
+    c->work_bytes = want;
+    return c->work;
 }
 void orbhip_set_last_error_internal(const char *msg) { g_last_error = msg; }
 extern "C" int orbhip_ctx_check_status(orbhip_ctx *c)
@@ -109,6 +123,7 @@ extern "C" void orbhip_ctx_destroy(orbhip_ctx *c)
     if (!c) return;
     (void)hipFree(c->d_status);
     if (c->scratch) (void)hipFree(c->scratch);
+    if (c->work) (void)hipFree(c->work);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -177,6 +177,14 @@ def test_search_for_initialization_edge_cases(gpu_ctx):
 
 
 # ------------------------------------------------------------------ M3 + M4: SearchByProjection (tracking)
+@pytest.fixture(params=["replay", "sequential"])
+def sbp_form(request, monkeypatch):
+    """SearchByProjection has two forms with identical results: candidate lists for all queries at once + a replay of the claim rule (calls
+    with few frame pairs: Tracking's one) and the sequential one-wave-per-pair loop (batches).  ORBHIP_SBP_PARALLEL_MAX_PAIRS moves the switch."""
+    monkeypatch.setenv("ORBHIP_SBP_PARALLEL_MAX_PAIRS", "64" if request.param == "replay" else "0")
+    return request.param
+
+
 def _sbp(gpu_ctx, cases, max_q, max_n, bounds, th_high=100, check_ori=True, stereo=False, map_ratio=None):
     """cases: list of (q, dq, kp, d, u_right|None, train_match).  Returns per pair (nmatches, train_match)."""
     import torch
@@ -208,7 +216,7 @@ def _sbp(gpu_ctx, cases, max_q, max_n, bounds, th_high=100, check_ori=True, ster
 
 
 @pytest.mark.parametrize("stereo,check_ori", [(False, True), (True, True), (False, False)])
-def test_search_by_projection_synthetic_parity(gpu_ctx, stereo, check_ori):
+def test_search_by_projection_synthetic_parity(gpu_ctx, stereo, check_ori, sbp_form):
     """Ragged batch incl. empty sides, out-of-grid keypoints, duplicated descriptors (ties), pre-held keypoints,
     re-claims by points without observations, all three level-range modes."""
     import oracle_match_bind as om
@@ -226,7 +234,7 @@ def test_search_by_projection_synthetic_parity(gpu_ctx, stereo, check_ori):
     assert tot > 500
 
 
-def test_search_by_projection_on_extracted_frames(gpu_ctx):
+def test_search_by_projection_on_extracted_frames(gpu_ctx, sbp_form):
     """TrackWithMotionModel shape: last frame's keypoints projected with the synthetic inter-frame motion."""
     import orbhip
     import oracle_match_bind as om
@@ -252,6 +260,43 @@ def test_search_by_projection_on_extracted_frames(gpu_ctx):
         np.testing.assert_array_equal(got[p][1], tm_ref)
         assert n_ref > 100
     ext.close()
+
+
+@pytest.mark.parametrize("mode", ["last_frame", "local_map"])
+def test_search_by_projection_contested_keypoints(gpu_ctx, sbp_form, mode):
+    """Many queries with near-identical descriptors over the same window, all carrying observations: every claim blocks the keypoint for
+    the later ones, so query t ends up with the t-th best -- the replay form walks deep into its lists and, where a list cut at its 32 entries
+    runs dry, hands the pair to the sequential kernel.  Mixed with queries without observations (claims that do not block) and pre-held keypoints."""
+    import oracle_match_bind as om
+    import orbhip
+    rng = np.random.default_rng(77)
+    bounds = (0.0, 0.0, 640.0, 480.0)
+    cases = []
+    for n, nq, spread in ((400, 150, 25.0), (300, 40, 8.0), (1200, 600, 60.0)):
+        kp = np.zeros(n, orbhip.KP_DTYPE)
+        kp["x"] = (320 + rng.normal(0, spread, n)).astype(np.float32); kp["y"] = (240 + rng.normal(0, spread, n)).astype(np.float32)
+        kp["octave"] = rng.integers(0, 3, n); kp["angle"] = rng.uniform(0, 360, n).astype(np.float32)
+        base = rng.integers(0, 256, 32, dtype=np.uint8)
+        d = np.tile(base, (n, 1)); flips = rng.integers(0, 32, (n, 3)); d[np.arange(n)[:, None], flips] ^= (1 << rng.integers(0, 8, (n, 3))).astype(np.uint8)
+        q = np.zeros(nq, orbhip.PROJ_QUERY_DTYPE)
+        q["u"] = (320 + rng.normal(0, 3, nq)).astype(np.float32); q["v"] = (240 + rng.normal(0, 3, nq)).astype(np.float32)
+        q["radius"] = np.float32(3 * spread); q["min_level"] = 0; q["max_level"] = 3; q["ur"] = -1; q["angle"] = rng.uniform(0, 360, nq).astype(np.float32)
+        q["has_obs"] = (rng.random(nq) < 0.8).astype(np.int32)
+        dq = np.tile(base, (nq, 1)); dq[np.arange(nq), rng.integers(0, 32, nq)] ^= (1 << rng.integers(0, 8, nq)).astype(np.uint8)
+        tm = np.where(rng.random(n) < 0.1, 5, -1).astype(np.int32)
+        cases.append((q, dq, kp, d, None, tm))
+    if mode == "last_frame":
+        got = _sbp(gpu_ctx, cases, 1024, 2048, bounds, 100, True, False)
+    else:
+        got = _sbp(gpu_ctx, cases, 1024, 2048, bounds, 100, True, False, map_ratio=0.9)
+    for p, (q, dq, kp, d, ur, tm) in enumerate(cases):
+        if mode == "last_frame":
+            n_ref, tm_ref = om.search_by_projection(q, dq, kp, d, None, bounds, tm, 100, True)
+        else:
+            n_ref, tm_ref = om.search_by_projection_map(q, dq, kp, d, None, bounds, tm, 100, 0.9)
+        assert got[p][0] == n_ref, (p, got[p][0], n_ref)
+        np.testing.assert_array_equal(got[p][1], tm_ref)
+        assert n_ref >= 10
 
 
 def test_search_by_projection_capacity(gpu_ctx):
@@ -309,7 +354,7 @@ def test_search_for_initialization_2000_features(gpu_ctx):
 
 
 @pytest.mark.parametrize("stereo,ratio", [(False, 0.8), (True, 0.8), (False, 0.6)])
-def test_search_local_map_parity(gpu_ctx, stereo, ratio):
+def test_search_local_map_parity(gpu_ctx, stereo, ratio, sbp_form):
     """TrackLocalMap matcher (ORBmatcher.cc:48-218): best / second best with the same-octave ratio rule, claim rule."""
     import oracle_match_bind as om
     from test_oracle_match_ba import make_sbp_case
@@ -611,7 +656,7 @@ def test_search_by_bow_kf_parity(gpu_ctx, ratio, check_ori):
 
 
 @pytest.mark.gpu
-def test_sim3_searches_parity(gpu_ctx):
+def test_sim3_searches_parity(gpu_ctx, sbp_form):
     """LoopClosing's Sim3 matchers through the existing kernels: SearchByProjection(KF, Scw, ...)
     (ORBmatcher.cc:477-708) = orbhip_search_by_projection_device with has_obs = 1, no uRight, no rotation check,
     th_high = floor(TH_LOW*ratioHamming); the per-point searches of SearchBySim3 (:1813-1851) and Fuse(KF, Scw) (:1687-1720) =
@@ -692,7 +737,7 @@ def test_frame_glue_parity(gpu_ctx):
 
 
 @pytest.mark.gpu
-def test_windowed_matchers_random_sizes(gpu_ctx):
+def test_windowed_matchers_random_sizes(gpu_ctx, sbp_form):
     """Randomised sizes (odd counts, one-off-capacity, tiny / empty sides) through the claim-rule matcher, the all-pairs matcher and
     the BoW matcher: bit-exact vs the oracle for every pair of 3 x 12 random cases."""
     import oracle_match_bind as om
