@@ -1273,12 +1273,16 @@ static int sbp_launch(orbhip_ctx *ctx, const orbhip_proj_query *d_q, const uint8
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     hipStream_t st = orbhip_ctx_stream_internal(ctx);
-    // few pairs: the low-latency form first (candidate lists for all queries at once, then the claim rule replayed over them); a pair it
-    // cannot finish (a truncated list ran dry, > SBPL_BUF candidates) is flagged and done by the sequential kernel below.  Many pairs: the
-    // sequential kernel alone -- one wave per pair fills the chip and does no redundant work.  ORBHIP_SBP_PARALLEL_MAX_PAIRS moves the switch.
-    const int par_max = getenv("ORBHIP_SBP_PARALLEL_MAX_PAIRS") ? atoi(getenv("ORBHIP_SBP_PARALLEL_MAX_PAIRS")) : 32;
+    // The replay form first (candidate lists for all queries at once, then the claim rule replayed over them); a pair it cannot finish
+    // (a truncated list ran dry, > SBPL_BUF candidates) is flagged and done by the sequential kernel below, which returns at once for the
+    // others.  Measured (tools/sbp_sweep.py, ~1000 queries x ~1000 keypoints per pair): 1 pair 0.15 ms against 1.18 ms, 1023 pairs 0.69 ms
+    // against 1.25 ms (last frame); 0.24 / 1.22 ms and 0.80 / 1.32 ms (local map).  Its work arena (lists + CSR copies, ~190 KB per pair
+    // at 1000 keypoints) is capped at 1 GiB; beyond that, for rig frames, and when ORBHIP_SBP_PARALLEL_MAX_PAIRS says so, the sequential
+    // kernel runs alone.
+    const int par_max = getenv("ORBHIP_SBP_PARALLEL_MAX_PAIRS") ? atoi(getenv("ORBHIP_SBP_PARALLEL_MAX_PAIRS")) : (1 << 20);
+    const size_t work_per_pair = (size_t)cap_n * (16 + 32 + 2) + 4 * (SI_COLS + 1) + 4 * (size_t)((cap_q + 63) / 64) * SBPL_K * 64 + 4 * (size_t)cap_q + 1024;
     const int32_t *d_redo = nullptr;
-    if (!d_nleft && !d_mirror && pairs <= par_max) {
+    if (!d_nleft && !d_mirror && pairs <= par_max && (size_t)pairs * work_per_pair <= ((size_t)1 << 30)) {
         SbpWork W;
         W.cap_n = cap_n; W.cap_q = cap_q; W.chunks = (cap_q + 63) / 64;
         auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
