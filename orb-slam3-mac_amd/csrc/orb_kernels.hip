@@ -479,25 +479,30 @@ __global__ __launch_bounds__(64) void k_fast_cells(FastParams P)
         // Lane layout from the level's nominal cell width (clipped border cells leave lanes idle): tasks per row tpr, rows per trip rpt
         const int tr0 = (int)(__umul24((uint32_t)lane, P.div_magic[tpr]) >> 16), tg = lane - tr0 * tpr;
         int nq1 = 0;                                               // entries of Q (wave-uniform)
+        const bool lane_rows = tr0 < rptT && 2 * tg < npb, pair1 = 2 * tg + 1 < npb;
         for (int y0 = 0; y0 < dh; y0 += rptT) {
             const int by = y0 + tr0;
-            uint32_t f = 0;                                        // bit 0/1: pair 0/1 may hold a corner at iniThFAST
-            if (tr0 < rptT && by < dh && 2 * tg < npb) {
+            bool f0 = false, f1 = false;                           // pair 0 / 1 may hold a corner at iniThFAST
+            if (lane_rows && by < dh) {
                 const uint32_t *q = &PT[(by + 3) * PITCH + 2 * tg + 2];
                 uint32_t *sc = &SC[(by + 1) * SPITCH + 2 * tg + 1];
-#pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    const int bp = 2 * tg + j;
-                    const s16x2 M = fc_compass<PITCH>(q + j);      // (an odd band's last pair tests one pixel beyond the band: its score is masked in (3))
-                    const int mm = max((int)M.x, (int)M.y);
-                    const uint32_t cI = mm > ini_th, cL = mm > lo_th;
-                    if (bp < npb) { sc[j] = (cI + cL) << 8; f |= cI << j; }           // class (0, 1, 2) in bits 8-9 until the pair is scored
-                }
+                // class of a pair = how many of (lo_th, ini_th) one of its two pixels exceeds: M - (th + 1) >= 0 in a half <=> its sign bit is clear
+                // (|M| <= 255: no overflow); the class (0, 1, 2) sits in bits 8-9 of the score dword until the pair is scored
+                const uint32_t SIGN = 0x80008000u;
+                // An odd band's last lane evaluates one pair beyond the band: its class lands on the score tile's guard dword, whose class bits
+                // nobody reads (the NMS masks them, the scans stop at npb), and its flag is dropped here; its score would be masked in (3)
+                const s16x2 M0 = fc_compass<PITCH>(q), M1 = fc_compass<PITCH>(q + 1);      // straight-line: the LDS reads of both pairs go out together
+                const bool cI0 = (as_u32(M0 - thI) & SIGN) != SIGN, cL0 = (as_u32(M0 - thL) & SIGN) != SIGN;
+                const bool cI1 = (as_u32(M1 - thI) & SIGN) != SIGN, cL1 = (as_u32(M1 - thL) & SIGN) != SIGN;
+                sc[0] = cL0 ? (cI0 ? 0x200u : 0x100u) : 0u;
+                sc[1] = cL1 ? (cI1 ? 0x200u : 0x100u) : 0u;
+                f0 = cI0; f1 = cI1 & pair1;
             }
-            const unsigned long long b0 = __ballot(f & 1u), b1 = __ballot(f & 2u);
-            const int pos = nq1 + __popcll(b0 & lt) + __popcll(b1 & lt);
-            if (f & 1u) Q[pos] = (uint16_t)FC_ID(by, 2 * tg);
-            if (f & 2u) Q[pos + (f & 1u)] = (uint16_t)FC_ID(by, 2 * tg + 1);
+            const unsigned long long b0 = __ballot(f0), b1 = __ballot(f1);      // (outside the branch: the counts below must stay wave-uniform)
+            const int pos = nq1 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u)) +
+                            (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u));
+            if (f0) Q[pos] = (uint16_t)FC_ID(by, 2 * tg);
+            if (f1) Q[pos + (f0 ? 1 : 0)] = (uint16_t)FC_ID(by, 2 * tg + 1);
             nq1 += __popcll(b0) + __popcll(b1);
         }
         FC_WAVE_SYNC();
