@@ -669,6 +669,23 @@ void orbhip_iba_default_params(orbhip_iba_params *p, int large);
 int orbhip_inertial_ba_solve_batch(orbhip_ctx *ctx, const orbhip_iba_window *windows, int n_windows, const orbhip_iba_params *params,
                                    double *const *kf_state_inout, double *const *points_inout, uint8_t *const *edge_outlier_out,
                                    orbhip_iba_stats *stats_out);
+/* The same, as a RESIDENT batch (the inertial counterpart of orbhip_ba_batch_create): create packs the windows' constant part
+ * (topology, observation and preintegration data, the kernels' task lists) and uploads it once into memory the batch owns; a solve
+ * uploads only the states (n_kf x 21 + n_points x 3 doubles per window) and launches.  LocalInertialBA is called on a window whose
+ * topology the caller rebuilds per call, so the reference path uses the one-shot form; the batch form is for callers that re-solve
+ * the same windows (the reference's own second pass with bLarge toggled, relinearisation sweeps, benchmarks) and is what the
+ * device-rate figure in bench.py times.  windows' arrays need not outlive create.  set_states replaces the initial states the next
+ * solve starts from (create's kf_states/points until then); solve is synchronous and leaves the result on the device; download
+ * follows the one-shot call's rules (failed windows are not written).  Not thread-safe per batch; the batch must be destroyed
+ * before its context. */
+typedef struct orbhip_iba_batch orbhip_iba_batch;
+int orbhip_iba_batch_create(orbhip_ctx *ctx, const orbhip_iba_window *windows, int n_windows, double *const *kf_states,
+                            double *const *points, orbhip_iba_batch **out);
+int orbhip_iba_batch_set_states(orbhip_iba_batch *b, double *const *kf_states, double *const *points);
+int orbhip_iba_batch_solve(orbhip_iba_batch *b, const orbhip_iba_params *params);
+int orbhip_iba_batch_download(orbhip_iba_batch *b, double *const *kf_states_out, double *const *points_out,
+                              uint8_t *const *edge_outlier_out, orbhip_iba_stats *stats_out);
+void orbhip_iba_batch_destroy(orbhip_iba_batch *b);
 /* Diagnostics: workgroups per window ("team size" G) of the calling thread's latest inertial solve.  Small batches give a window a
  * team of up to 16 workgroups that meet at a device-wide barrier, which needs the whole grid resident: only ONE team grid runs per
  * device at a time (in-process mutex + advisory file lock /tmp/.orbhip_team_gpu<N>.lock); a solve that finds one in flight, and

@@ -551,6 +551,61 @@ def inertial_ba_solve_batch(ctx, windows, kf_states, points, params=None):
     return kfs, pts, [o[:w.n_edges] for o, w in zip(outl, windows)], [st.as_dict() for st in stats]
 
 
+lib.orbhip_iba_batch_create.argtypes = [vp, vp, ci, vp, vp, C.POINTER(vp)]
+lib.orbhip_iba_batch_set_states.argtypes = [vp, vp, vp]
+lib.orbhip_iba_batch_solve.argtypes = [vp, C.POINTER(IbaParams)]
+lib.orbhip_iba_batch_download.argtypes = [vp, vp, vp, vp, vp]
+lib.orbhip_iba_batch_destroy.argtypes = [vp]
+lib.orbhip_iba_batch_destroy.restype = None
+
+
+class IbaBatch:
+    """orbhip_iba_batch: windows resident on the device; solve() re-solves them from the states last set."""
+
+    def __init__(self, ctx, windows, kf_states, points):
+        self.n = len(windows)
+        self.shapes = [(w.n_kf, w.n_points, w.n_edges) for w in windows]
+        arr = (IbaWindow * self.n)(*windows)
+        kfs = [np.ascontiguousarray(a, np.float64) for a in kf_states]
+        pts = [np.ascontiguousarray(a, np.float64) for a in points]
+        pk = (vp * self.n)(*[a.ctypes.data for a in kfs])
+        pq = (vp * self.n)(*[a.ctypes.data for a in pts])
+        self.h = vp()
+        _chk(lib.orbhip_iba_batch_create(ctx.h, C.cast(arr, vp), self.n, C.cast(pk, vp), C.cast(pq, vp), C.byref(self.h)),
+             "orbhip_iba_batch_create")
+
+    def set_states(self, kf_states, points):
+        kfs = [np.ascontiguousarray(a, np.float64) for a in kf_states]
+        pts = [np.ascontiguousarray(a, np.float64) for a in points]
+        pk = (vp * self.n)(*[a.ctypes.data for a in kfs])
+        pq = (vp * self.n)(*[a.ctypes.data for a in pts])
+        _chk(lib.orbhip_iba_batch_set_states(self.h, C.cast(pk, vp), C.cast(pq, vp)), "orbhip_iba_batch_set_states")
+
+    def solve(self, params=None):
+        p = params or iba_default_params()
+        _chk(lib.orbhip_iba_batch_solve(self.h, C.byref(p)), "orbhip_iba_batch_solve")
+
+    def download(self):
+        """-> (kf_states, points, edge_outlier, stats); a failed window's states come back as zeros (not written, as the one-shot call
+        leaves its inputs alone)."""
+        kfs = [np.zeros((s[0], IBA_KF)) for s in self.shapes]
+        pts = [np.zeros((max(s[1], 1), 3)) for s in self.shapes]
+        outl = [np.zeros(max(s[2], 1), np.uint8) for s in self.shapes]
+        stats = (IbaStats * self.n)()
+        pk = (vp * self.n)(*[a.ctypes.data for a in kfs])
+        pq = (vp * self.n)(*[a.ctypes.data for a in pts])
+        po = (vp * self.n)(*[a.ctypes.data for a in outl])
+        _chk(lib.orbhip_iba_batch_download(self.h, C.cast(pk, vp), C.cast(pq, vp), C.cast(po, vp), C.cast(stats, vp)),
+             "orbhip_iba_batch_download")
+        return (kfs, [p[:s[1]] for p, s in zip(pts, self.shapes)], [o[:s[2]] for o, s in zip(outl, self.shapes)],
+                [st.as_dict() for st in stats])
+
+    def close(self):
+        if self.h:
+            lib.orbhip_iba_batch_destroy(self.h)
+            self.h = None
+
+
 def inertial_ba_last_team_size():
     """Workgroups per window of this thread's latest inertial solve (1 = no device-wide barrier)."""
     return int(lib.orbhip_inertial_ba_last_team_size())

@@ -69,6 +69,48 @@ def test_inertial_ba_batch_of_windows_and_determinism(hip):
         assert np.array_equal(gpu[0][i], again[0][i]) and np.array_equal(gpu[1][i], again[1][i])      # fixed summation orders
 
 
+def test_inertial_ba_resident_batch_matches_the_one_shot_call(hip):
+    """orbhip_iba_batch_*: the constant part is packed and uploaded once, every solve starts from the states last set; results are the
+    one-shot call's bit for bit (same kernel, same team size), re-solving is repeatable, set_states moves the starting point."""
+    orbhip, ctx = hip
+    wins = [ib.make_window(140 + i, n_opt=5 + i, n_fixed_vis=4 + 3 * i, n_points=150 + 60 * i, fisheye_rig=(i == 2)) for i in range(5)]
+    structs = [w.struct(orbhip.IbaWindow) for w in wins]
+    once = _gpu_solve(hip, wins)
+    b = orbhip.IbaBatch(ctx, structs, [w.kf0 for w in wins], [w.pts0 for w in wins])
+    try:
+        del structs
+        for _ in range(2):
+            b.solve()
+            got = b.download()
+            for i, w in enumerate(wins):
+                assert np.array_equal(got[0][i], once[0][i]) and np.array_equal(got[1][i], once[1][i]) and np.array_equal(got[2][i], once[2][i])
+                assert got[3][i] == once[3][i]
+                _compare(w, [x[i] for x in got], ib.solve(w))
+        # second pass from the first pass's result, as a caller relinearising would: equals the one-shot call started there
+        b.set_states(once[0], once[1])
+        b.solve()
+        got2 = b.download()
+        for i, w in enumerate(wins):
+            w.kf0, w.pts0 = once[0][i], once[1][i]
+        twice = _gpu_solve(hip, wins)
+        for i in range(len(wins)):
+            if twice[3][i]["failed"]:
+                assert got2[3][i]["failed"]
+                continue
+            assert np.array_equal(got2[0][i], twice[0][i]) and np.array_equal(got2[1][i], twice[1][i]) and got2[3][i] == twice[3][i]
+    finally:
+        b.close()
+
+
+def test_inertial_ba_resident_batch_rejects_bad_arguments(hip):
+    orbhip, ctx = hip
+    h = C.c_void_p()
+    assert orbhip.lib.orbhip_iba_batch_create(ctx.h, None, 1, None, None, C.byref(h)) == orbhip.E_BADARG
+    assert orbhip.lib.orbhip_iba_batch_solve(None, None) == orbhip.E_BADARG
+    assert orbhip.lib.orbhip_iba_batch_download(None, None, None, None, None) == orbhip.E_BADARG
+    orbhip.lib.orbhip_iba_batch_destroy(None)
+
+
 @pytest.mark.parametrize("team", [1, 2, 5, 16])
 def test_inertial_ba_every_team_size(hip, team, monkeypatch):
     """The summation order of the team-wide sums depends on the team size G (team_sum2): every G the launch rule can pick -- 1 is
