@@ -132,6 +132,7 @@ struct BaBatch {      // kernel argument (by value)
     int big;
     int pair_schur;                                          // the Schur complement comes from the pair lists (k_ba_schur_big); always with big
     const int *big_pair_start; const int2 *big_pair_ent; const int *big_pair_pt;      // big_pair_pt: the point of every entry     // entries: {Hpl block of pose i, Hpl block of pose j} (batch-global block ids)
+    const int2 *big_pair_jr;                                 // of every entry: {Hpl block of pose j, rank of pose i's block in pose i's own (diagonal) list} (k_ba_schur_rows)
     double *big_y, *big_d, *big_U;                           // [sumF*6] forward-substituted right-hand side, pivots; [G][32*32] unscaled diagonal-block columns
     int *big_fail;                                           // [G] a zero / non-finite pivot was met
 };
@@ -1060,6 +1061,131 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
 }
 
+// The same sums, one 256-thread workgroup per ROW i of the block matrix (round 3).  k_ba_schur_big gathers, per list entry, BOTH Hpl blocks
+// and the point's D^-1 from L2: 5-6 cache lines for 162 multiply-adds, 9 GB per launch at 256 windows, and the gather path (one line per
+// lane per load instruction) is what the kernel waits for.  All pairs (i, j >= i) share pose i's side: the workgroup computes
+// Y_il = W_il D_l^-1 for every block of pose i ONCE into LDS (the diagonal pair's list enumerates them in point order; an entry carries
+// the rank of its i-side block in that list), then its sixteen 16-lane groups take the pairs of the row round-robin and gather only W_jl:
+// 2 lines per entry, a third of the multiply-adds gone.  Expressions and summation order are k_ba_schur_big<16>'s, so the two kernels
+// agree bit for bit on every off-diagonal block (the diagonal blocks and bs are summed in another association, see below).  Rows are dealt
+// like the pairs were: a graph's rows on one XCD, longest rows first.
+#define SROW_THREADS 384                              // 6 waves: 170 VGPRs each at 3 waves per SIMD, two workgroups per CU while a row is <= 500 blocks
+#define SROW_GROUPS (SROW_THREADS / 16)
+#define SROW_MAX_BLOCKS 1024                          // 147 KB of LDS; batches with a fuller row keep k_ba_schur_big
+__global__ __launch_bounds__(SROW_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_ba_schur_rows(BaBatch B, int max_nf)
+{
+    extern __shared__ __attribute__((aligned(16))) double srow_y[];          // [blocks of pose i][18]: y0[6] y1[6] y2[6]
+    __shared__ double s_part[SROW_GROUPS * 27];                              // the diagonal block's and W db's partial sums, one set per 16-lane group
+    __shared__ int s_next;                                                   // next pair of the row nobody has taken
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int g = xcd + 8 * (slot / max_nf), i = slot - (slot / max_nf) * max_nf;
+    if (g >= B.G) return;
+    const BaState &st = B.st[g];
+    if (!st.active) return;
+    const BaGraphDev &G = B.gd[g];
+    const int nf = G.nf;
+    if (i >= nf) return;
+    const int tid = threadIdx.x, sub = tid & 15, grp = tid >> 4;
+    const int *ps = B.big_pair_start + G.pair_off + (i * nf - i * (i - 1) / 2);      // pairs (i, i), (i, i + 1), ...
+    const int2 *ent = B.big_pair_ent + G.pent_off;
+    const int *entl = B.big_pair_pt + G.pent_off;
+    const int2 *entjr = B.big_pair_jr + G.pent_off;
+    if (tid == 0) s_next = i + 1 + SROW_GROUPS;
+    // ---- pose i's own blocks, one per thread: Y into LDS, and the diagonal pair (i, i) on the way -- its list IS this enumeration, and as
+    // one 16-lane group's chain (400 entries at 50 x 2000 x 10) it would outlast every other pair of the row by a factor of five while the
+    // workgroup holds its LDS.  S_ii and bs = bp - W D^-1 b_l are summed per thread, per 16-lane group (DPP), then over the groups in order.
+    {
+        const int d0 = ps[0], nblk = ps[1] - d0;
+        double dacc[21], wdb[6];                       // S_ii is symmetric: its lower triangle, row-major
+#pragma unroll
+        for (int k = 0; k < 21; k++) dacc[k] = 0.0;
+#pragma unroll
+        for (int a = 0; a < 6; a++) wdb[a] = 0.0;
+        for (int p = tid; p < nblk; p += SROW_THREADS) {
+            const int l = entl[d0 + p];
+            const double *Di = B.Dinv + (size_t)(G.point_off + l) * 6, *db = B.db + (size_t)(G.point_off + l) * 3;
+            const double i00 = Di[0], i01 = Di[1], i02 = Di[2], i11 = Di[3], i12 = Di[4], i22 = Di[5];
+            const double d0b = db[0], d1b = db[1], d2b = db[2];
+            const double2 *wa2 = reinterpret_cast<const double2 *>(B.Wsp + (size_t)ent[d0 + p].x * 18);       // 144-byte blocks: 16-byte aligned
+            double wa[18], y0[6], y1[6], y2[6];
+#pragma unroll
+            for (int k = 0; k < 9; k++) { const double2 v = wa2[k]; wa[2 * k] = v.x; wa[2 * k + 1] = v.y; }
+            double *y = srow_y + 18 * p;
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+                const double a0 = wa[a], a1 = wa[6 + a], a2 = wa[12 + a];
+                y0[a] = a0 * i00 + a1 * i01 + a2 * i02;
+                y1[a] = a0 * i01 + a1 * i11 + a2 * i12;
+                y2[a] = a0 * i02 + a1 * i12 + a2 * i22;
+                y[a] = y0[a]; y[6 + a] = y1[a]; y[12 + a] = y2[a];
+                wdb[a] += a0 * d0b + a1 * d1b + a2 * d2b;
+            }
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int c = 0; c <= r; c++) dacc[r * (r + 1) / 2 + c] += y0[r] * wa[c] + y1[r] * wa[6 + c] + y2[r] * wa[12 + c];
+        }
+#pragma unroll
+        for (int k = 0; k < 21; k++) { const double v = row16_allreduce_f64_dpp(dacc[k]); if (sub == 0) s_part[27 * grp + k] = v; }
+#pragma unroll
+        for (int a = 0; a < 6; a++) { const double v = row16_allreduce_f64_dpp(wdb[a]); if (sub == 0) s_part[27 * grp + 21 + a] = v; }
+    }
+    __syncthreads();
+    double *S = B.S + G.s_off;
+    if (tid < 27) {
+        double v = 0.0;
+        for (int q = 0; q < SROW_GROUPS; q++) v += s_part[27 * q + tid];
+        if (tid < 21) {
+            int r = 0, c = tid;
+            while (c > r) { c -= r + 1; r++; }
+            const double out = B.Hpp[(size_t)(G.free_off + i) * 36 + 6 * r + c] + (r == c ? st.lambda : 0.0) - v;
+            S[(size_t)(6 * i + r) * G.ld + 6 * i + c] = out;
+            S[(size_t)(6 * i + c) * G.ld + 6 * i + r] = out;
+        } else {
+            const size_t o = (size_t)(G.free_off + i) * 6 + tid - 21;
+            B.bacc[o] = v; B.bs[o] = B.bp[o] - v;
+        }
+    }
+    // ---- the pairs (i, j > i), handed out dynamically (list lengths differ by an order of magnitude): the first one per group by index, then
+    // from the counter
+    for (int j = i + 1 + grp; j < nf; j = row16_allreduce_add_dpp(sub == 0 ? atomicAdd(&s_next, 1) : 0)) {
+        const int e0 = ps[j - i], e_end = ps[j - i + 1];
+        double acc[36];
+#pragma unroll
+        for (int k = 0; k < 36; k++) acc[k] = 0.0;
+        const int en = e0 + sub;                                       // the NEXT trip's list entry is fetched a trip ahead
+        int2 tn = make_int2(0, 0);
+        if (en < e_end) tn = entjr[en];
+        for (int e = en; e < e_end; e += 16) {
+            const int bj = tn.x, pos = tn.y;
+            if (e + 16 < e_end) tn = entjr[e + 16];
+            const double2 *wb2 = reinterpret_cast<const double2 *>(B.Wsp + (size_t)bj * 18);
+            double wb[18];
+#pragma unroll
+            for (int k = 0; k < 9; k++) { const double2 v = wb2[k]; wb[2 * k] = v.x; wb[2 * k + 1] = v.y; }
+            const double *y = srow_y + 18 * pos;
+            double y0[6], y1[6], y2[6];
+#pragma unroll
+            for (int a = 0; a < 6; a++) { y0[a] = y[a]; y1[a] = y[6 + a]; y2[a] = y[12 + a]; }
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                const double b0 = wb[c], b1 = wb[6 + c], b2 = wb[12 + c];
+#pragma unroll
+                for (int r = 0; r < 6; r++) acc[6 * r + c] += y0[r] * b0 + y1[r] * b1 + y2[r] * b2;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 36; k++) {
+            const double v = row16_allreduce_f64_dpp(acc[k]);
+            if (sub == 0) {
+                const int r = k / 6, c = k - 6 * r;
+                S[(size_t)(6 * i + r) * G.ld + 6 * j + c] = -v;
+                S[(size_t)(6 * j + c) * G.ld + 6 * i + r] = -v;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_ba_big_init(BaBatch B)
 {
     const int g = blockIdx.y;
@@ -1493,6 +1619,7 @@ struct orbhip_ba_batch {
     size_t x_need;                           // doubles per rank slot of the exchange buffer
     // one LM tick (about 20 dependent launches) captured as a hipGraph: small batches are launch bound
     hipGraphExec_t tick_graph; bool tick_graph_valid; BaBatch tick_B;
+    int max_row_blocks;                      // most Hpl blocks any free pose of the batch holds (LDS of k_ba_schur_rows)
 };
 
 template <typename T>
@@ -1736,7 +1863,8 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
     b->s_total = s; b->spart_total = sp;
     // big windows: every graph of the batch takes the global-memory path; per graph and pair of free poses (i <= j) the Hpl blocks
     // of the points both see, in point order (the summation order of k_ba_schur_big)
-    std::vector<int> pair_start, pair_pt; std::vector<int2> pair_ent;
+    std::vector<int> pair_start, pair_pt; std::vector<int2> pair_ent, pair_jr;
+    b->max_row_blocks = 0;
     B.big = any_big ? 1 : 0;
     // Schur complement: per-block-pair lists (k_ba_schur_big) by default -- measured faster than the MFMA panel GEMM at every batch
     // size -- the GEMM on request (orbhip_ctx_set_ba_schur_mode(ctx, 2), a property of the context the batch is created on), in the landmark-sharded mode and never for big windows
@@ -1755,6 +1883,10 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
             std::vector<int> cnt(npair + 1, 0);
             auto pidx = [&](int i, int j) { return i * nf - i * (i - 1) / 2 + (j - i); };
             const int *et = etask.data() + D.edge_off;
+            // rank of every Hpl block among its pose's blocks in point order = its place in that pose's diagonal list
+            std::vector<int> rank(H.n_edges, 0), seen(nf, 0);
+            for (int a = 0; a < H.n_edges; a++) if (et[a] >= 0) rank[a] = seen[lh[H.edge_pose[a]]]++;
+            for (int k = 0; k < nf; k++) b->max_row_blocks = std::max(b->max_row_blocks, seen[k]);
             for (int pass = 0; pass < 2; pass++) {
                 std::vector<int> fill(cnt.begin(), cnt.end() - 1);
                 for (int e0 = 0; e0 < H.n_edges;) {
@@ -1767,14 +1899,14 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
                             const int i = lh[H.edge_pose[a]], j = lh[H.edge_pose[c]];
                             if (i > j || (i == j && a != c)) continue;           // every unordered pair once; the diagonal pair is (a, a)
                             if (pass == 0) cnt[pidx(i, j) + 1]++;
-                            else { const size_t q = D.pent_off + fill[pidx(i, j)]++; pair_ent[q] = make_int2(et[a], et[c]); pair_pt[q] = H.edge_point[a]; }
+                            else { const size_t q = D.pent_off + fill[pidx(i, j)]++; pair_ent[q] = make_int2(et[a], et[c]); pair_pt[q] = H.edge_point[a]; pair_jr[q] = make_int2(et[c], rank[a]); }
                         }
                     }
                     e0 = e1;
                 }
                 if (pass == 0) {
                     for (int k = 0; k < npair; k++) cnt[k + 1] += cnt[k];
-                    pair_ent.resize(D.pent_off + cnt[npair]); pair_pt.resize(D.pent_off + cnt[npair]);
+                    pair_ent.resize(D.pent_off + cnt[npair]); pair_pt.resize(D.pent_off + cnt[npair]); pair_jr.resize(D.pent_off + cnt[npair]);
                 }
             }
             pair_start.insert(pair_start.end(), cnt.begin(), cnt.end());
@@ -1788,7 +1920,7 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
     UP(B.edge_is2, eis2); UP(B.edge_stereo, est); UP(B.edge_dup, edup); UP(B.edge_next, enext); UP(B.pt_start, ptstart); UP(B.pose_start, posestart); UP(B.pose_edges, poseedges);
     UP(B.ptmask, ptmask); UP(B.gemm_task, gtask); UP(B.gemm_stage, gstage); UP(B.edge_task, etask); UP(B.x1_off, x1off); UP(B.x2_off, x2off);
     UP(B.pm_point, pmpoint); UP(B.pm_task, pmtask); UP(B.pm_type, pmtype); UP(B.pm_is2, pmis2); UP(B.pm_obs, pmobs);
-    if (pair_lists) { UP(B.big_pair_start, pair_start); UP(B.big_pair_ent, pair_ent); UP(B.big_pair_pt, pair_pt); }
+    if (pair_lists) { UP(B.big_pair_start, pair_start); UP(B.big_pair_ent, pair_ent); UP(B.big_pair_pt, pair_pt); UP(B.big_pair_jr, pair_jr); }
     if (any_big) {
         AL(B.big_y, double, (size_t)sumF * 6); AL(B.big_d, double, (size_t)sumF * 6); AL(B.big_U, double, (size_t)n_graphs * LD_NB * LD_NB);
         AL(B.big_fail, int, n_graphs);
@@ -1916,6 +2048,10 @@ static int ba_solve_impl(orbhip_ba_batch *b, const orbhip_ba_params *params, vol
         if (orb_lds_optin(reinterpret_cast<const void *>(k_ba_big_rows), orbhip_ctx_device_internal(b->ctx), rows_lds) ||
             orb_lds_optin(reinterpret_cast<const void *>(k_ba_big_backsub), orbhip_ctx_device_internal(b->ctx), bsub_lds)) { g_ba_error = "LDS opt-in (big LDLT)"; return ORBHIP_E_HIP; }
     }
+    // the row-owner form of the pair Schur kernel: whenever every pose's blocks fit the LDS (ORBHIP_BA_SCHUR_ROWS=0: keep k_ba_schur_big, for A/B runs)
+    const size_t srow_lds = sizeof(double) * 18 * (size_t)std::max(b->max_row_blocks, 1);
+    bool schur_rows = B.pair_schur && b->max_row_blocks <= SROW_MAX_BLOCKS && !(getenv("ORBHIP_BA_SCHUR_ROWS") && atoi(getenv("ORBHIP_BA_SCHUR_ROWS")) == 0);
+    if (schur_rows && orb_lds_optin(reinterpret_cast<const void *>(k_ba_schur_rows), orbhip_ctx_device_internal(b->ctx), srow_lds)) { g_ba_error = "LDS opt-in (k_ba_schur_rows)"; return ORBHIP_E_HIP; }
     const int max_ticks = (params->iters1 + params->iters2) * params->max_trials + 4;
     int tick = 0;
     // one LM tick: every graph that is still active evaluates, builds, solves and tries one step (inactive graphs return at once)
@@ -1936,7 +2072,8 @@ static int ba_solve_impl(orbhip_ba_batch *b, const orbhip_ba_params *params, vol
         hipLaunchKernelGGL(k_ba_point_prep, gp256, dim3(256), 0, s, B);
         if (b->profile) TRY(hipEventRecord(b->ev0, s));
         if (B.pair_schur && max_nfp > 0) {                       // (a batch whose poses are all fixed has no reduced system: points only)
-            if (G >= 8) hipLaunchKernelGGL(k_ba_schur_big<16>, dim3((unsigned)(((max_nfp + 3) / 4) * (((G + 7) / 8) * 8))), dim3(64), 0, s, B, (max_nfp + 3) / 4);
+            if (G >= 8 && schur_rows) hipLaunchKernelGGL(k_ba_schur_rows, dim3((unsigned)(B.max_nf * (((G + 7) / 8) * 8))), dim3(SROW_THREADS), srow_lds, s, B, B.max_nf);
+            else if (G >= 8) hipLaunchKernelGGL(k_ba_schur_big<16>, dim3((unsigned)(((max_nfp + 3) / 4) * (((G + 7) / 8) * 8))), dim3(64), 0, s, B, (max_nfp + 3) / 4);
             else hipLaunchKernelGGL(k_ba_schur_big<64>, dim3((unsigned)(max_nfp * G)), dim3(64), 0, s, B, max_nfp);
         }
         else if (!B.pair_schur) hipLaunchKernelGGL(k_ba_schur_gemm, dim3(max_items, G), dim3(64 * GEMM_WAVES), gemm_lds, s, B);
