@@ -595,7 +595,7 @@ def main():
         ach = alg_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
         ba_traffic, ba_traffic_src = None, None
         pmc_ba = load_profile_json(PROFILE_TAG + "_pmc_traffic_ba.json")
-        big = [v for k, v in (pmc_ba or {}).get("kernels", {}).items() if k == "k_ba_schur_big" or k.startswith("k_ba_schur_big<")]
+        big = [v for k, v in (pmc_ba or {}).get("kernels", {}).items() if k == "k_ba_schur_rows"]
         if big and args.ba_graphs == 256:
             ba_traffic = big[0]["hbm_bytes_per_launch"]
             ba_traffic_src = "profiles/%s_pmc_traffic_ba.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)" % PROFILE_TAG
@@ -603,17 +603,20 @@ def main():
               "unit": "solves/s", "graphs_per_gpu": args.ba_graphs, "ms_per_batch": round(dt_ba / args.ba_steps * 1e3, 2),
               "lm_ticks": ticks, "workload": "50 KF (2 fixed) x 2000 points x 10 obs, 5+10 LM iterations, Huber, Schur",
               "lm_trials_graph0": stats[0]["lm_trials"], "dtype": "f64",
-              "roofline": {"bound": "hbm", "kernel": "k_ba_schur_big", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+              "roofline": {"bound": "hbm", "kernel": "k_ba_schur_rows", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(ach / HBM_PEAK_GBS, 4), "peak_measured": HBM_MEASURED_GBS,
                            "frac_of_measured_peak": round(ach / HBM_MEASURED_GBS, 4),
                            "traffic": ba_traffic, "traffic_source": ba_traffic_src,
                            "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(launch_ms, 4),
                            "sparse_exact_flops_per_launch": useful,
                            "achieved_tflops_of_useful_flops": round(useful / (launch_ms * 1e-3) / 1e12, 2) if launch_ms > 0 else None,
-                           "l2_gather_bytes_per_launch": int(pair_entries * (2 * 144 + 48 + 12)),
-                           "note": "the Schur complement from per-block-pair lists: every (pair of free keyframes, shared point) gathers two 144-byte "
-                                   "Hpl blocks + C^-1, one 16-lane row per pair, a graph's blocks pinned to one XCD's L2; bound by the L2 gather "
-                                   "stream (l2_gather_bytes_per_launch), not by HBM"},
+                           "l2_gather_bytes_per_launch": int((pair_entries - blocks) * (144 + 8) + blocks * (144 + 48 + 24 + 12)),
+                           "note": "the Schur complement from per-block-pair lists, one 384-thread workgroup per ROW of the block matrix: pose i's "
+                                   "W D^-1 blocks are computed once into LDS (with the diagonal block and W D^-1 b on the way), every (i, j > i, shared "
+                                   "point) entry then gathers ONE 144-byte Hpl block + an 8-byte list entry, one 16-lane row per pair, a graph's blocks "
+                                   "pinned to one XCD's L2; bound by the L2 gather stream (l2_gather_bytes_per_launch), not by HBM.  Round 2's "
+                                   "k_ba_schur_big (both blocks + C^-1 gathered per entry: 1.61 ms per 256 windows) remains for rows of more than "
+                                   "1024 blocks and batches of fewer than 8 windows"},
               "mfma_gemm_variant": {"value": round(world * args.ba_graphs * args.ba_steps / dt_gemm, 2), "unit": "solves/s",
                                     "ms_per_batch": round(dt_gemm / args.ba_steps * 1e3, 2),
                                     "roofline": {"bound": "mfma", "kernel": "k_ba_schur_gemm", "achieved": round(tfl, 2),

@@ -16,6 +16,7 @@
  */
 #include "ba_oracle.h"
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
 #include <math.h>
 #include <float.h>
@@ -585,6 +586,8 @@ static int lm_iteration(struct ba *B, int iteration, double *chi_out)
             memcpy(B->points, B->points_bk, sizeof(double) * 3 * B->L);
         }
         qmax++; B->lm_trials++;
+        if (getenv("ORC_BA_TRACE"))
+            fprintf(stderr, "[oracle ba] iter %d qmax %d lambda %.6e chi %.9e rho %.6e ok %d nbad %d trials %d\n", iteration, qmax, B->lambda, current_chi, rho, ok2, B->nbad, B->lm_trials);
     } while (rho < 0 && qmax < B->p->max_trials && !terminate(B));
     *chi_out = current_chi;
     if (qmax == B->p->max_trials || rho == 0) return 0;

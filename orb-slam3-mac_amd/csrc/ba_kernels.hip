@@ -2113,7 +2113,8 @@ static int ba_solve_impl(orbhip_ba_batch *b, const orbhip_ba_params *params, vol
     };
     // Replay form of a tick (no exchange, no event timing, abort flag down): captured once per batch and parameter set.  The
     // kernels of a graph that has finished return at once, so several ticks may be queued per host round trip.
-    const bool use_graph = !sharded && !b->profile;
+    const bool trace = getenv("ORBHIP_BA_TRACE") != nullptr;      // development: graph 0's LM state after every tick on stderr (one tick per round trip)
+    const bool use_graph = !sharded && !b->profile && !trace;
     if (use_graph && !(b->tick_graph_valid && memcmp(&b->tick_B, &B, sizeof(BaBatch)) == 0)) {
         if (b->tick_graph_valid) { (void)hipGraphExecDestroy(b->tick_graph); b->tick_graph_valid = false; }
         hipGraph_t graph = nullptr;
@@ -2140,6 +2141,12 @@ static int ba_solve_impl(orbhip_ba_batch *b, const orbhip_ba_params *params, vol
         TRY(hipStreamSynchronize(s));
         TRY(hipGetLastError());                  // a rejected launch fails here, loudly, instead of spinning to max_ticks
         n_active = *b->h_n_active;
+        if (trace) {
+            BaState t0;
+            TRY(hipMemcpy(&t0, B.st, sizeof(BaState), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[orbhip ba] tick %d: pass %d iter %d qmax %d lambda %.6e chi %.9e rho %.6e ok %d nbad %d active %d trials %d\n", tick, t0.pass, t0.iter, t0.qmax,
+                    t0.lambda, t0.current_chi, t0.rho_dbg, t0.ok, t0.nbad, t0.active, t0.lm_trials);
+        }
         if (b->profile) {
             float ms = 0;
             TRY(hipEventElapsedTime(&ms, b->ev0, b->ev1));

@@ -13,7 +13,7 @@ def _rmse(a, b):
 
 @pytest.fixture(scope="module", params=["pairs", "mfma"])
 def ba_ctx(request, gpu_ctx):
-    """Both forms of the Schur complement: the per-block-pair kernel (k_ba_schur_big, the default) on the session context and the
+    """Both forms of the Schur complement: the per-block-pair kernels (k_ba_schur_rows / k_ba_schur_big, the default) on the session context and the
     FP64-MFMA panel GEMM (k_ba_schur_gemm, orbhip_ctx_set_ba_schur_mode(ctx, 2): what config #4 names and what the landmark-sharded
     mode runs) on a context of its own -- the mode is a property of the context, so the two never interfere."""
     import orbhip
@@ -100,6 +100,47 @@ def test_ba_ragged_batch(ba_ctx):
     for k in ("edge_pose", "edge_point", "edge_obs", "edge_inv_sigma2", "edge_stereo"):
         g[k] = g[k][keep]
     g["n_edges"] = int(keep.sum())
+    _check(gpu_ctx, graphs)
+
+
+@pytest.mark.parametrize("rows", [1, 0])
+def test_ba_batches_of_eight_and_more_both_pair_kernels(gpu_ctx, rows, monkeypatch):
+    """From 8 windows per call on the pair lists run four pairs per wave: k_ba_schur_rows (one workgroup per row of the block matrix,
+    pose i's W D^-1 in LDS; the default) or, with ORBHIP_BA_SCHUR_ROWS=0 and for rows of more than 1024 blocks, k_ba_schur_big<16>.
+    A ragged batch (different sizes, stereo, a point seen by fixed keyframes only, a window without a free keyframe, a window of
+    the full bench size) against the oracle through both."""
+    import synth_ba
+    monkeypatch.setenv("ORBHIP_BA_SCHUR_ROWS", str(rows))
+    graphs = [synth_ba.make_graph(n_kf=5, n_pts=30, obs=3, seed=211),
+              synth_ba.make_graph(n_kf=20, n_pts=500, obs=8, seed=212),
+              synth_ba.make_graph(n_kf=9, n_pts=77, obs=5, seed=213, n_fixed=3),
+              synth_ba.make_graph(n_kf=12, n_pts=300, obs=6, seed=214, stereo_frac=1.0),
+              synth_ba.make_graph(n_kf=12, n_pts=300, obs=6, seed=215, stereo_frac=0.4),
+              synth_ba.make_graph(n_kf=4, n_pts=50, obs=3, seed=216, n_fixed=4),
+              synth_ba.make_graph(seed=217),
+              synth_ba.make_graph(n_kf=30, n_pts=900, obs=12, seed=218),
+              synth_ba.make_graph(n_kf=4, n_pts=25, obs=3, seed=219, n_fixed=2),
+              synth_ba.make_graph(n_kf=40, n_pts=700, obs=25, seed=220)]
+    g = graphs[2]
+    # one point keeps its fixed-keyframe edges only; it must keep two of them (a single mono edge leaves Hll singular, and what a
+    # solver makes of that is rounding noise -- g2o's included)
+    fixed_e = g["pose_fixed"][g["edge_pose"]] != 0
+    nfix = np.bincount(g["edge_point"], weights=fixed_e, minlength=g["n_points"])
+    nfree = np.bincount(g["edge_point"], weights=~fixed_e, minlength=g["n_points"])
+    pt = int(np.flatnonzero((nfix >= 2) & (nfree >= 1))[0])
+    keep = ~((g["edge_point"] == pt) & ~fixed_e)
+    for k in ("edge_pose", "edge_point", "edge_obs", "edge_inv_sigma2", "edge_stereo"):
+        g[k] = g[k][keep]
+    g["n_edges"] = int(keep.sum())
+    _check(gpu_ctx, graphs)
+
+
+def test_ba_row_kernel_falls_back_when_a_row_exceeds_its_lds(gpu_ctx):
+    """A keyframe that observes more than 1024 landmarks: its W D^-1 blocks do not fit the row kernel's LDS, the whole batch takes
+    k_ba_schur_big<16>."""
+    import synth_ba
+    graphs = [synth_ba.make_graph(n_kf=4, n_pts=1300, obs=4, seed=230 + k) for k in range(8)]
+    assert max(np.bincount(g["edge_pose"]).max() for g in graphs) > 1024
     _check(gpu_ctx, graphs)
 
 
