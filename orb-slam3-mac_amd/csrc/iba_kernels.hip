@@ -88,7 +88,7 @@ struct IbaArgs {
     orbhip_iba_stats *stats;
     int iterations, max_trials, large, max_n;
     double lambda_init;
-    long long *prof;                    // optional [windows][8] shader-clock cycles per phase (ORBHIP_IBA_PROF=1): errors, build, prep+Schur, LDL^T, update
+    long long *prof;                    // optional [windows][16] shader-clock cycles per phase (ORBHIP_IBA_PROF=1): errors, build, prep+Schur, LDL^T, update
 };
 
 // ------------------------------------------------------------------ small dense helpers (row-major 3x3)
@@ -493,6 +493,10 @@ __device__ __noinline__ void iba_build(const IbaCtx &C, Team &T, int buf)
     const double *pts = A.pts + buf * A.pts_stride + (size_t)W.pt_off * 3;
     const double *kfs = A.kfs + buf * A.kfs_stride + (size_t)W.kf_off * IBA_KF;
     double *H = A.H + W.h_off, *b = A.b + W.x_off;
+    const bool bprof = A.prof && T.g == 0 && tid == 0;
+    long long *bpf = A.prof ? A.prof + 16 * T.w + 8 : nullptr;
+    long long tb = bprof ? clock64() : 0;
+#define BPROF(k) do { if (bprof) { const long long t_ = clock64(); bpf[k] += t_ - tb; tb = t_; } } while (0)
     if (T.g == 0) {
         for (int i = tid; i < n * n; i += IBA_THREADS) H[i] = 0.0;
         for (int i = tid; i < n; i += IBA_THREADS) b[i] = 0.0;
@@ -506,6 +510,7 @@ __device__ __noinline__ void iba_build(const IbaCtx &C, Team &T, int buf)
             inertial_edge(kfs + IBA_KF * A.in_kf1[gm], kfs + IBA_KF * A.in_kf2[gm], A.in_pre + IBA_PRE * gm, er, A.Jb + 216 * gm);
         }
     }
+    BPROF(0);
     // (2) landmarks: Hll, bl and the pose-landmark blocks; 8 lanes share a landmark's edges
     const int *pt_start = A.pt_start + W.ptstart_off;
     const int sub = tid & 7;
@@ -549,6 +554,7 @@ __device__ __noinline__ void iba_build(const IbaCtx &C, Team &T, int buf)
             for (int i = 0; i < 3; i++) Bl[i] = bl[i];
         }
     }
+    BPROF(1);
     // (3) per-chunk partial pose blocks, two waves per chunk
     {
         const int4 *kf_task = A.kf_task + W.ktask_off;
@@ -559,7 +565,9 @@ __device__ __noinline__ void iba_build(const IbaCtx &C, Team &T, int buf)
             else kf_block_task<0>(C, cam, pts, task, kpart + 27 * (size_t)(t >> 1));
         }
     }
+    BPROF(2);
     team_sync(T);                      // Jb, kpart complete
+    BPROF(3);
     if (T.g != 0) return;
     // ---- workgroup 0: Omega-weighted inertial Jacobians / errors
     for (int idx = tid; idx < W.M * 216; idx += IBA_THREADS) {
@@ -578,6 +586,7 @@ __device__ __noinline__ void iba_build(const IbaCtx &C, Team &T, int buf)
             A.Oe[15 * gm + i] = -r1 * q;
         }
     }
+    BPROF(4);
     // pose blocks: the chunks of every keyframe summed in order
     {
         const int *kts = A.kf_task_start + W.ktstart_off;
@@ -596,6 +605,7 @@ __device__ __noinline__ void iba_build(const IbaCtx &C, Team &T, int buf)
         }
     }
     __syncthreads();
+    BPROF(5);
     // inertial + random-walk edges into H / b: edges of one colour share no keyframe, colours run one after the other
     const int *kf_xoff = A.kf_xoff + W.kf_off;
     for (int col = 0; col < W.ncolors; col++) {
@@ -642,6 +652,8 @@ __device__ __noinline__ void iba_build(const IbaCtx &C, Team &T, int buf)
         }
         __syncthreads();
     }
+    BPROF(6);
+#undef BPROF
 }
 
 // One chunk of one keyframe pair's shared landmarks -> partial W_j D^-1 W_i^T (6x6) and, on the diagonal pairs, W_i D^-1 b_l.
@@ -817,7 +829,7 @@ __device__ __noinline__ bool iba_trial(const IbaCtx &C, Team &T, int buf, double
     team_sync(T);                              // the new estimates are complete
     *scale_part = part;
     if (A.prof && T.g == 0 && threadIdx.x == 0) {
-        long long *pf = A.prof + 8 * T.w;
+        long long *pf = A.prof + 16 * T.w;
         pf[2] += t_schur - t_begin; pf[3] += t_ldlt - t_schur; pf[4] += clock64() - t_ldlt;
     }
     return ok;
@@ -925,7 +937,7 @@ __global__ __launch_bounds__(IBA_THREADS) void k_iba_solve(IbaArgs A)
         for (int i = T.gtid; i < W.n_kf * IBA_KF; i += T.gsize) k0[i] = k1[i];
         for (int i = T.gtid; i < W.L * 3; i += T.gsize) p0[i] = p1[i];
     }
-    if (A.prof && g == 0 && tid == 0) { long long *pf = A.prof + 8 * w; pf[0] = t_err; pf[1] = t_build; pf[5] = clock64() - t_k0; }
+    if (A.prof && g == 0 && tid == 0) { long long *pf = A.prof + 16 * w; pf[0] = t_err; pf[1] = t_build; pf[5] = clock64() - t_k0; }
     if (g == 0 && tid == 0) {
         orbhip_iba_stats &st = A.stats[w];
         st.iterations_run = its; st.lm_trials = trials; st.n_outliers = (int)nout;
@@ -1271,7 +1283,7 @@ static int iba_create_impl(orbhip_ctx *ctx, const orbhip_iba_window *wins, int n
                  w_ierr = take(120 * sumM), w_ichi = take(24 * sumM), w_Jb = take(1728 * sumM), w_OJ = take(1728 * sumM), w_Oe = take(120 * sumM),
                  w_H = take(8 * sumH), w_S = take(8 * sumH), w_b = take(8 * sumX), w_bs = take(8 * sumX), w_x = take(8 * sumX), w_out = take(sumE),
                  w_kpart = take(27 * 8 * n_kftask), w_ppart = take(42 * 8 * n_pairtask),
-                 w_stats = take(sizeof(orbhip_iba_stats) * n_windows), w_prof = take(64 * (size_t)n_windows),
+                 w_stats = take(sizeof(orbhip_iba_stats) * n_windows), w_prof = take(128 * (size_t)n_windows),
                  w_sync = take((4 + 4 + 4) * (size_t)n_windows), w_wpart = take(8 * 2 * IBA_MAXG * 2 * (size_t)n_windows);
     ITRY(hipSetDevice(orbhip_ctx_device_internal(ctx)));
     hipStream_t s = orbhip_ctx_stream_internal(ctx);
@@ -1343,7 +1355,7 @@ static int iba_solve_impl(orbhip_iba_batch *b, const orbhip_iba_params *params)
     ITRY(hipMemsetAsync(d + b->w_W, 0, 144 * sumE + 8, s));
     ITRY(hipMemsetAsync(d + b->w_sync, 0, 12 * (size_t)n_windows, s));
     IbaArgs A = b->A;
-    if (want_prof) { ITRY(hipMemsetAsync(d + b->w_prof, 0, 64 * (size_t)n_windows, s)); A.prof = reinterpret_cast<long long *>(d + b->w_prof); }
+    if (want_prof) { ITRY(hipMemsetAsync(d + b->w_prof, 0, 128 * (size_t)n_windows, s)); A.prof = reinterpret_cast<long long *>(d + b->w_prof); }
     A.iterations = params->iterations; A.max_trials = params->max_trials; A.large = params->large; A.lambda_init = params->lambda_init;
     const int device = orbhip_ctx_device_internal(ctx);
     const size_t lds = ba_ldlt_lds_bytes(A.max_n);
@@ -1393,8 +1405,10 @@ static int iba_solve_impl(orbhip_iba_batch *b, const orbhip_iba_params *params)
         const auto t_host2 = std::chrono::steady_clock::now();
         fprintf(stderr, "[orbhip iba] %d windows: host packing %.3f ms (at creation), state upload + kernel %.3f ms (%zu B on the device)\n", n_windows, b->pack_ms,
                 std::chrono::duration<double, std::milli>(t_host2 - t_host1).count(), b->bytes);
-        long long pf[8];
-        ITRY(hipMemcpy(pf, d + b->w_prof, 64, hipMemcpyDeviceToHost));
+        long long pf[16];
+        ITRY(hipMemcpy(pf, d + b->w_prof, 128, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[orbhip iba] build phases (workgroup 0, cycles): inertial Jacobians %lld, landmarks %lld, pose chunks %lld, team barrier %lld, Omega J %lld, pose blocks %lld, colours %lld\n",
+                pf[8], pf[9], pf[10], pf[11], pf[12], pf[13], pf[14]);
         fprintf(stderr, "[orbhip iba] G=%d window 0 shader cycles: errors %lld, build %lld, prep+schur %lld, ldlt %lld, update %lld, total %lld\n", G, pf[0], pf[1], pf[2], pf[3], pf[4], pf[5]);
     }
     return ORBHIP_OK;
