@@ -85,6 +85,7 @@ struct FastParams {
     FcLevel lv[ORB_MAX_LEVELS];
     int nlevels, batch, ini_th, min_th, cells_per_frame;
     int n_cus;                    // compute units of the context's device (hipDeviceAttributeMultiprocessorCount): sizes the persistent grid
+    int chunk;                    // consecutive cells a wave takes at a time (set per launch)
     int lvl_lo, lvl_hi;           // this launch covers the cells of levels [lvl_lo, lvl_hi) of every frame (level 0 can start before the pyramid exists)
     uint32_t *cell_count, *cell_list; size_t cell_list_frame_stride; int32_t *status;
     // per-wave LDS geometry (from the largest cell of this extractor): pair tile [rows][PITCH] dwords, score tile [srows + 2][SPITCH]

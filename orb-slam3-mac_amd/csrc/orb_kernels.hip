@@ -406,9 +406,8 @@ __global__ __launch_bounds__(64) void k_fast_cells(FastParams P)
     extern __shared__ __attribute__((aligned(16))) uint32_t fc_lds[];
     const int lane = threadIdx.x;
     uint32_t *PT = fc_lds;
-    uint32_t *SC = PT + P.rows * PITCH;
-    uint16_t *Q = reinterpret_cast<uint16_t *>(SC + (P.srows + 2) * SPITCH);
-    const unsigned long long lt = (1ull << lane) - 1;
+    uint16_t *SC = reinterpret_cast<uint16_t *>(PT + P.rows * PITCH);          // scores, one u16 per pixel pair: left | right << 8 (cornerScore <= 254)
+    uint16_t *Q = SC + (P.srows + 2) * SPITCH;
     // this wave's cells [g0, g1) of batch * cells_per_frame
     const unsigned lid = xcd_logical_id(blockIdx.x, gridDim.x);
     // the cells of levels [lvl_lo, lvl_hi) are one contiguous range of a frame's cell array
@@ -416,26 +415,33 @@ __global__ __launch_bounds__(64) void k_fast_cells(FastParams P)
     const int cell_lo = FC_SGPR(P.lv[lvl_lo].cell_base);
     const int cps = (lvl_hi < P.nlevels ? FC_SGPR(P.lv[lvl_hi].cell_base) : FC_SGPR(P.cells_per_frame)) - cell_lo;
     const long total_cells = (long)P.batch * cps;
-    const long g0 = total_cells * lid / gridDim.x, g1 = total_cells * (lid + 1) / gridDim.x;
-    if (g0 >= g1) return;
+    // Work is dealt in CHUNKS of consecutive cells, chunk c to wave c mod #waves: cells differ a lot in cost (texture, clipped border cells,
+    // the small top levels), and contiguous equal-count ranges per wave left the kernel waiting for its slowest waves -- its time did not
+    // move between 8 and 21 waves per CU.  Neighbouring chunks still run on neighbouring waves of one XCD (shared aprons hit its L2).
+    const int chunk = FC_SGPR(P.chunk);
+    const long nchunks = (total_cells + chunk - 1) / chunk;
+    if ((long)lid >= nchunks) return;
     const int nlevels = lvl_hi, ini_th = FC_SGPR(P.ini_th), min_th = FC_SGPR(P.min_th), cpf = FC_SGPR(P.cells_per_frame);
+    auto decode = [&](long gi, FcCell &X) {
+        X.frame = (int)(gi / cps);
+        const int cell = cell_lo + (int)(gi - (long)X.frame * cps);
+        X.lvl = lvl_lo;
+        for (int l = lvl_lo + 1; l < nlevels; l++) if (cell >= P.lv[l].cell_base) X.lvl = l;
+        const int c = cell - P.lv[X.lvl].cell_base;
+        X.ci = c / P.lv[X.lvl].ncols; X.cj = c - X.ci * P.lv[X.lvl].ncols;
+        X.frame = FC_SGPR(X.frame); X.lvl = FC_SGPR(X.lvl); X.ci = FC_SGPR(X.ci); X.cj = FC_SGPR(X.cj);
+        fc_cell_geom(P, X);
+    };
+    long ch = lid;                                                  // current chunk
+    long g = ch * chunk, g_end = min(g + chunk, total_cells);       // current cell, end of the current chunk
     FcCell C;
-    {
-        C.frame = (int)(g0 / cps);
-        const int cell = cell_lo + (int)(g0 - (long)C.frame * cps);
-        C.lvl = lvl_lo;
-        for (int l = lvl_lo + 1; l < nlevels; l++) if (cell >= P.lv[l].cell_base) C.lvl = l;
-        const int c = cell - P.lv[C.lvl].cell_base;
-        C.ci = c / P.lv[C.lvl].ncols; C.cj = c - C.ci * P.lv[C.lvl].ncols;
-        fc_cell_geom(P, C);
-    }
+    decode(g, C);
     uint4 ld[NLD];
     fc_issue_loads<NCH, NLD>(C, lane, ld);
     const int lo_th = min(ini_th, min_th);
-    const s16x2 thI = (s16x2){(short)(ini_th + 1), (short)(ini_th + 1)}, thL = (s16x2){(short)(lo_th + 1), (short)(lo_th + 1)};
 #define FC_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_s_waitcnt(0xc07f); \
                             __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
-    for (long g = g0; g < g1; g++) {
+    for (bool more = true; more;) {
         const int dw = C.dw, dh = C.dh;
         const int npb = (dw + 1) >> 1;                             // band pixel pairs per row
         const int cell = C.cell_base + C.ci * C.ncols + C.cj;
@@ -458,75 +464,60 @@ __global__ __launch_bounds__(64) void k_fast_cells(FastParams P)
                 uint4 *dst = reinterpret_cast<uint4 *>(&PT[r * PITCH + 8 * c]);
                 dst[0] = a; dst[1] = b;
             }
-            // guards of the score tile (its interior is written by the necessary test below)
-            for (int i = lane; i < SPITCH; i += 64) { SC[i] = 0; SC[(dh + 1) * SPITCH + i] = 0; }
-            for (int i = lane; i < dh; i += 64) { SC[(i + 1) * SPITCH] = 0; SC[(i + 1) * SPITCH + npb + 1] = 0; }
+            // the score tile starts at zero (guards included): a pair that is never scored counts as 0 in the NMS
+            uint4 *scz = reinterpret_cast<uint4 *>(SC);
+            for (int i = lane; i < ((dh + 2) * SPITCH + 7) / 8; i += 64) scz[i] = make_uint4(0u, 0u, 0u, 0u);
         }
-        // ---- next cell: its loads stay in flight while this one is processed
+        // ---- next cell (the next one of the chunk, or the first one of this wave's next chunk): its loads stay in flight while this one is processed
         FcCell N = C;
-        {
+        g++;
+        if (g < g_end) {
             N.cj++;
             if (N.cj == C.ncols) { N.cj = 0; N.ci++; }
-            bool relevel = false;
-            if (N.ci == C.nrows) { N.ci = 0; N.lvl++; relevel = true; }
+            if (N.ci == C.nrows) { N.ci = 0; N.lvl++; }
             if (N.lvl == nlevels) { N.lvl = lvl_lo; N.frame++; }
-            if (g + 1 < g1) { fc_cell_geom(P, N); fc_issue_loads<NCH, NLD>(N, lane, ld); }
-            (void)relevel;
+            fc_cell_geom(P, N);
+        } else {
+            ch += gridDim.x;
+            more = ch < nchunks;
+            if (more) { g = ch * chunk; g_end = min(g + chunk, total_cells); decode(g, N); }
         }
+        if (more) fc_issue_loads<NCH, NLD>(N, lane, ld);
         if (dw <= 0) { if (lane == 0) *cnt_out = 0; C = N; continue; }
         FC_WAVE_SYNC();           // (also: the previous cell's LDS reads are done before this cell's writes -- same wave, program order)
-        // ---- (2) necessary test on every band pixel pair, two adjacent pairs per lane, rows in order (queue order = cv::FAST order).
-        // Lane layout from the level's nominal cell width (clipped border cells leave lanes idle): tasks per row tpr, rows per trip rpt
+        // Lane layout of the necessary test from the level's nominal cell width (clipped border cells leave lanes idle): tasks per row tpr,
+        // rows per trip rpt, two adjacent pairs per lane
         const int tr0 = (int)(__umul24((uint32_t)lane, P.div_magic[tpr]) >> 16), tg = lane - tr0 * tpr;
-        int nq1 = 0;                                               // entries of Q (wave-uniform)
         const bool lane_rows = tr0 < rptT && 2 * tg < npb, pair1 = 2 * tg + 1 < npb;
-        for (int y0 = 0; y0 < dh; y0 += rptT) {
-            const int by = y0 + tr0;
-            bool f0 = false, f1 = false;                           // pair 0 / 1 may hold a corner at iniThFAST
-            if (lane_rows && by < dh) {
-                const uint32_t *q = &PT[(by + 3) * PITCH + 2 * tg + 2];
-                uint32_t *sc = &SC[(by + 1) * SPITCH + 2 * tg + 1];
-                // class of a pair = how many of (lo_th, ini_th) one of its two pixels exceeds: M - (th + 1) >= 0 in a half <=> its sign bit is clear
-                // (|M| <= 255: no overflow); the class (0, 1, 2) sits in bits 8-9 of the score dword until the pair is scored
-                const uint32_t SIGN = 0x80008000u;
-                // An odd band's last lane evaluates one pair beyond the band: its class lands on the score tile's guard dword, whose class bits
-                // nobody reads (the NMS masks them, the scans stop at npb), and its flag is dropped here; its score would be masked in (3)
-                const s16x2 M0 = fc_compass<PITCH>(q), M1 = fc_compass<PITCH>(q + 1);      // straight-line: the LDS reads of both pairs go out together
-                const bool cI0 = (as_u32(M0 - thI) & SIGN) != SIGN, cL0 = (as_u32(M0 - thL) & SIGN) != SIGN;
-                const bool cI1 = (as_u32(M1 - thI) & SIGN) != SIGN, cL1 = (as_u32(M1 - thL) & SIGN) != SIGN;
-                sc[0] = cL0 ? (cI0 ? 0x200u : 0x100u) : 0u;
-                sc[1] = cL1 ? (cI1 ? 0x200u : 0x100u) : 0u;
-                f0 = cI0; f1 = cI1 & pair1;
-            }
-            const unsigned long long b0 = __ballot(f0), b1 = __ballot(f1);      // (outside the branch: the counts below must stay wave-uniform)
-            const int pos = nq1 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u)) +
-                            (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u));
-            if (f0) Q[pos] = (uint16_t)FC_ID(by, 2 * tg);
-            if (f1) Q[pos + (f0 ? 1 : 0)] = (uint16_t)FC_ID(by, 2 * tg + 1);
-            nq1 += __popcll(b0) + __popcll(b1);
-        }
-        FC_WAVE_SYNC();
         int total = 0;
         for (int pass = 0; pass < 2; pass++) {
-            if (pass == 1) {
-                // nothing at iniThFAST (ORBextractor.cc:825-828): score what only the low threshold lets through (class 1)
-                nq1 = 0;
-                for (int y0 = 0; y0 < dh; y0 += rptT) {
-                    const int by = y0 + tr0;
-                    uint32_t f = 0;
-                    if (tr0 < rptT && by < dh) {
-                        if (2 * tg < npb) f |= ((SC[(by + 1) * SPITCH + 2 * tg + 1] >> 8) & 3u) == 1u ? 1u : 0u;
-                        if (2 * tg + 1 < npb) f |= ((SC[(by + 1) * SPITCH + 2 * tg + 2] >> 8) & 3u) == 1u ? 2u : 0u;
-                    }
-                    const unsigned long long b0 = __ballot(f & 1u), b1 = __ballot(f & 2u);
-                    const int pos = nq1 + __popcll(b0 & lt) + __popcll(b1 & lt);
-                    if (f & 1u) Q[pos] = (uint16_t)FC_ID(by, 2 * tg);
-                    if (f & 2u) Q[pos + (f & 1u)] = (uint16_t)FC_ID(by, 2 * tg + 1);
-                    nq1 += __popcll(b0) + __popcll(b1);
+            // ---- (2) necessary test on every band pixel pair at this pass's threshold, rows in order (queue order = cv::FAST order).  No
+            // per-pair state is kept: the rare second pass (nothing at iniThFAST, ORBextractor.cc:825-828) runs the test again at minThFAST
+            // and scores everything it lets through (the pairs of the first pass among them: same scores again)
+            const int th = pass == 0 ? ini_th : min_th;
+            const s16x2 thP = (s16x2){(short)(th + 1), (short)(th + 1)};
+            int nq1 = 0;                                               // entries of Q (wave-uniform)
+            for (int y0 = 0; y0 < dh; y0 += rptT) {
+                const int by = y0 + tr0;
+                bool f0 = false, f1 = false;                           // pair 0 / 1 may hold a corner at th
+                if (lane_rows && by < dh) {
+                    const uint32_t *q = &PT[(by + 3) * PITCH + 2 * tg + 2];
+                    // M - (th + 1) >= 0 in a half <=> its sign bit is clear (|M| <= 255: no overflow).  An odd band's last lane evaluates one pair
+                    // beyond the band: its flag is dropped here
+                    const uint32_t SIGN = 0x80008000u;
+                    const s16x2 M0 = fc_compass<PITCH>(q), M1 = fc_compass<PITCH>(q + 1);      // straight-line: the LDS reads of both pairs go out together
+                    f0 = (as_u32(M0 - thP) & SIGN) != SIGN;
+                    f1 = ((as_u32(M1 - thP) & SIGN) != SIGN) & pair1;
                 }
-                FC_WAVE_SYNC();
+                const unsigned long long b0 = __ballot(f0), b1 = __ballot(f1);      // (outside the branch: the counts below must stay wave-uniform)
+                const int pos = nq1 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u)) +
+                                (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u));
+                if (f0) Q[pos] = (uint16_t)FC_ID(by, 2 * tg);
+                if (f1) Q[pos + (f0 ? 1 : 0)] = (uint16_t)FC_ID(by, 2 * tg + 1);
+                nq1 += __popcll(b0) + __popcll(b1);
             }
-            // ---- (3) dense arc score, one pair per lane; scored pairs carry class 2
+            FC_WAVE_SYNC();
+            // ---- (3) dense arc score, one pair per lane
             for (int i0 = 0; i0 < nq1; i0 += 64) {
                 const int i = min(i0 + lane, nq1 - 1);
                 const int id = Q[i], by = id >> 5, bp = id & 31;
@@ -534,30 +525,11 @@ __global__ __launch_bounds__(64) void k_fast_cells(FastParams P)
                 if (i0 + lane < nq1) {
                     const uint32_t lo = S.x > lo_th ? (uint32_t)(S.x - 1) : 0u;
                     const uint32_t hi = (S.y > lo_th && 2 * bp + 1 < dw) ? (uint32_t)(S.y - 1) : 0u;
-                    SC[(by + 1) * SPITCH + bp + 1] = lo | (hi << 16) | 0x200u;
+                    SC[(by + 1) * SPITCH + bp + 1] = (uint16_t)(lo | (hi << 8));
                 }
             }
             FC_WAVE_SYNC();
-            if (pass == 1) {
-                // every candidate (now class 2) in order -> Q
-                nq1 = 0;
-                for (int y0 = 0; y0 < dh; y0 += rptT) {
-                    const int by = y0 + tr0;
-                    uint32_t f = 0;
-                    if (tr0 < rptT && by < dh) {
-                        if (2 * tg < npb) f |= (SC[(by + 1) * SPITCH + 2 * tg + 1] & 0x300u) ? 1u : 0u;
-                        if (2 * tg + 1 < npb) f |= (SC[(by + 1) * SPITCH + 2 * tg + 2] & 0x300u) ? 2u : 0u;
-                    }
-                    const unsigned long long b0 = __ballot(f & 1u), b1 = __ballot(f & 2u);
-                    const int pos = nq1 + __popcll(b0 & lt) + __popcll(b1 & lt);
-                    if (f & 1u) Q[pos] = (uint16_t)FC_ID(by, 2 * tg);
-                    if (f & 2u) Q[pos + (f & 1u)] = (uint16_t)FC_ID(by, 2 * tg + 1);
-                    nq1 += __popcll(b0) + __popcll(b1);
-                }
-                FC_WAVE_SYNC();
-            }
             // ---- (4) 3x3 strict NMS on raw scores + threshold gate + ordered emission
-            const int th = pass == 0 ? ini_th : min_th;
             for (int i0 = 0; i0 < nq1; i0 += 64) {
                 const int i = i0 + lane;
                 uint32_t keep = 0, sc = 0;
@@ -565,13 +537,14 @@ __global__ __launch_bounds__(64) void k_fast_cells(FastParams P)
                 if (i < nq1) {
                     const int id = Q[i];
                     by = id >> 5; bp = id & 31;
-                    const uint32_t *q = &SC[(by + 1) * SPITCH + bp + 1];
-                    const uint32_t K = 0x00FF00FFu;                                                  // drop the class bits
-                    sc = q[0] & K;
-                    const s16x2 V = pkmax(as_s16x2(q[-SPITCH] & K), as_s16x2(q[SPITCH] & K));         // above / below each pixel
-                    const s16x2 Lc = pkmax(pkmax(as_s16x2(q[-SPITCH - 1] & K), as_s16x2(q[-1] & K)), as_s16x2(q[SPITCH - 1] & K));   // .y: column left of the pair
-                    const s16x2 Rc = pkmax(pkmax(as_s16x2(q[-SPITCH + 1] & K), as_s16x2(q[1] & K)), as_s16x2(q[SPITCH + 1] & K));    // .x: column right of the pair
-                    const int sl = (int)(sc & 0xFFFFu), sr = (int)(sc >> 16);
+                    const uint16_t *q = &SC[(by + 1) * SPITCH + bp + 1];
+#define FC_U(v) as_s16x2(__builtin_amdgcn_perm(0u, (uint32_t)(v), 0x0c010c00u))                          /* left | right << 8  ->  packed halves */
+                    sc = q[0];
+                    const s16x2 V = pkmax(FC_U(q[-SPITCH]), FC_U(q[SPITCH]));                                  // above / below each pixel
+                    const s16x2 Lc = pkmax(pkmax(FC_U(q[-SPITCH - 1]), FC_U(q[-1])), FC_U(q[SPITCH - 1]));     // .y: column left of the pair
+                    const s16x2 Rc = pkmax(pkmax(FC_U(q[-SPITCH + 1]), FC_U(q[1])), FC_U(q[SPITCH + 1]));      // .x: column right of the pair
+#undef FC_U
+                    const int sl = (int)(sc & 0xFFu), sr = (int)(sc >> 8);
                     const int nbl = max(max((int)V.x, (int)V.y), max((int)Lc.y, sr));                // L: above, below, the R column (3 rows), left column
                     const int nbr = max(max((int)V.x, (int)V.y), max((int)Rc.x, sl));
                     if (sl >= th && sl > nbl) keep |= 1u;
@@ -581,10 +554,11 @@ __global__ __launch_bounds__(64) void k_fast_cells(FastParams P)
                 const int inc = wave_incl_scan(mine);
                 int offs = total + inc - mine;
                 if (keep & 1u) { if (offs < cell_cap) list[offs] = ORB_PACK_KEY(2 * bp + key_x0, by + key_y0, sc & 0xFFu); offs++; }
-                if (keep & 2u) { if (offs < cell_cap) list[offs] = ORB_PACK_KEY(2 * bp + 1 + key_x0, by + key_y0, (sc >> 16) & 0xFFu); }
+                if (keep & 2u) { if (offs < cell_cap) list[offs] = ORB_PACK_KEY(2 * bp + 1 + key_x0, by + key_y0, (sc >> 8) & 0xFFu); }
                 total += __builtin_amdgcn_readlane(inc, 63);
             }
             if (total > 0 || min_th == ini_th) break;              // vKeysCell not empty at iniThFAST: done
+            FC_WAVE_SYNC();                                        // the second pass rewrites Q and SC
         }
         if (total > cell_cap) { if (lane == 0) atomicExch(P.status, ORBHIP_E_CAPACITY); total = cell_cap; }
         if (lane == 0) *cnt_out = (uint32_t)total;
@@ -593,6 +567,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(FastParams P)
 #undef FC_WAVE_SYNC
 }
 
+const void *orb_fast_cells_func(int small);
 void orb_launch_fast_cells(const FastParams &F_, hipStream_t s, int max_per_cu, int lvl_lo, int lvl_hi)
 {
     FastParams F = F_;
@@ -600,12 +575,24 @@ void orb_launch_fast_cells(const FastParams &F_, hipStream_t s, int max_per_cu, 
     if (F.lvl_lo >= F.lvl_hi) return;
     // persistent single-wave workgroups: as many as the LDS lets a CU hold, a whole number per XCD
     const size_t lds = sizeof(uint32_t) * (size_t)F.wave_dw;
-    int per_cu = (int)((160 * 1024) / (lds + 512));
-    per_cu = per_cu > 24 ? 24 : per_cu < 1 ? 1 : per_cu;
+    // as many as the runtime says fit (LDS, wave slots), asked once per kernel variant and LDS size
+    static int occ_cache[2] = {0, 0}; static size_t occ_lds[2] = {0, 0};
+    const int v = F.small_cells ? 1 : 0;
+    if (!occ_cache[v] || occ_lds[v] != lds) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, orb_fast_cells_func(v), 64, lds) != hipSuccess || n < 1) n = (int)((160 * 1024) / (lds + 512));
+        occ_cache[v] = n < 1 ? 1 : n; occ_lds[v] = lds;
+        if (getenv("ORBHIP_DEBUG_FAST")) fprintf(stderr, "[orbhip] k_fast_cells: %zu B of LDS per wave, %d waves per CU resident\n", lds, occ_cache[v]);
+    }
+    int per_cu = occ_cache[v];
     if (max_per_cu > 0 && per_cu > max_per_cu) per_cu = max_per_cu;      // leave LDS and wave slots to a kernel running beside this one
     long nblocks = (long)(F.n_cus > 0 ? F.n_cus : 256) * per_cu;
     const long total = (long)F.batch * ((F.lvl_hi < F.nlevels ? F.lv[F.lvl_hi].cell_base : F.cells_per_frame) - F.lv[F.lvl_lo].cell_base);
     if (nblocks > total) nblocks = (total + 7) / 8 * 8;
+    // chunks of up to 16 consecutive cells (they share aprons and level parameters), at least ~8 chunks per wave so that the shares even out
+    static const int chunk_env = getenv("ORBHIP_TUNE_FAST_CHUNK") ? atoi(getenv("ORBHIP_TUNE_FAST_CHUNK")) : 0;
+    const long fair = total / (8 * nblocks);
+    F.chunk = chunk_env > 0 ? chunk_env : (int)(fair < 1 ? 1 : fair > 16 ? 16 : fair);
     if (F.small_cells) hipLaunchKernelGGL((k_fast_cells<3, 24, 2>), dim3((unsigned)nblocks), dim3(64), lds, s, F);
     else hipLaunchKernelGGL((k_fast_cells<5, 32, 5>), dim3((unsigned)nblocks), dim3(64), lds, s, F);
 }

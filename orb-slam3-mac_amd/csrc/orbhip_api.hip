@@ -371,7 +371,7 @@ extern "C" int orbhip_extractor_reserve(orbhip_extractor *e, int width, int heig
         const int npb = (mw + 1) >> 1;
         F.small_cells = small ? 1 : 0;
         F.rows = mh + 6; F.srows = mh; F.qcap = (mh * npb + 1) & ~1;
-        F.wave_dw = F.rows * (small ? 24 : 40) + (F.srows + 2) * (small ? 24 : 32) + F.qcap / 2;
+        F.wave_dw = F.rows * (small ? 24 : 40) + ((F.srows + 2) * (small ? 24 : 32) + F.qcap + 1) / 2;      // pair tile (dwords) + u16 score tile + u16 queue
         F.wave_dw = (F.wave_dw + 3) & ~3;
         F.nlevels = e->nlevels; F.ini_th = e->ini_th; F.min_th = e->min_th; F.cells_per_frame = cells;
         for (int n = 1; n < 34; n++) F.div_magic[n] = (uint32_t)(65536 / n + 1);

@@ -1,0 +1,72 @@
+// Issue-rate probe for the vector instructions k_fast_cells leans on (gfx950): every lane runs 8 independent chains of ONE instruction,
+// 4 waves per SIMD, all CUs; prints cycles per wave-instruction per SIMD.  Build + run on the GPU box:
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_rate tools/valu_rate.hip && /tmp/valu_rate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#define ITER 4096
+#define DEF(name, INSN)                                                                                        \
+    __global__ __launch_bounds__(256) void name(uint32_t *out, uint32_t seed)                                     \
+    {                                                                                                             \
+        uint32_t a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19;  \
+        const uint32_t b = seed * 2654435761u, c = seed ^ 0x01020304u;                                            \
+        for (int i = 0; i < ITER; i++) {                                                                          \
+            asm volatile(INSN(%0) "\n" INSN(%1) "\n" INSN(%2) "\n" INSN(%3) "\n" INSN(%4) "\n" INSN(%5) "\n" INSN(%6) "\n" INSN(%7)       \
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));             \
+        }                                                                                                         \
+        out[blockIdx.x * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;                               \
+    }
+#define I_PKMIN(r) "v_pk_min_i16 " #r ", " #r ", %8"
+#define I_PKMAX(r) "v_pk_max_i16 " #r ", " #r ", %8"
+#define I_PKSUB(r) "v_pk_sub_i16 " #r ", " #r ", %8"
+#define I_PKADDU(r) "v_pk_add_u16 " #r ", " #r ", %8"
+#define I_ALIGN(r) "v_alignbit_b32 " #r ", " #r ", %8, 16"
+#define I_PERM(r) "v_perm_b32 " #r ", " #r ", %8, %9"
+#define I_MIN32(r) "v_min_i32 " #r ", " #r ", %8"
+#define I_ADD32(r) "v_add_u32 " #r ", " #r ", %8"
+#define I_AND(r) "v_and_b32 " #r ", " #r ", %8"
+#define I_MIN3(r) "v_min3_i32 " #r ", " #r ", %8, %9"
+#define I_MAX3I16(r) "v_max3_i16 " #r ", " #r ", %8, %9"
+#define I_MINI16(r) "v_min_i16 " #r ", " #r ", %8"
+#define I_SAD(r) "v_sad_u8 " #r ", " #r ", %8, %9"
+#define I_LSHL(r) "v_lshlrev_b32 " #r ", 1, " #r
+#define I_DOT4(r) "v_dot4_u32_u8 " #r ", " #r ", %8, %9"
+#define I_MAD24(r) "v_mad_u32_u24 " #r ", " #r ", %8, %9"
+#define I_PKMAD(r) "v_pk_mad_i16 " #r ", " #r ", %8, %9"
+#define I_BFE(r) "v_bfe_u32 " #r ", " #r ", 3, 8"
+DEF(k_pkmin, I_PKMIN) DEF(k_pkmax, I_PKMAX) DEF(k_pksub, I_PKSUB) DEF(k_pkaddu, I_PKADDU) DEF(k_align, I_ALIGN) DEF(k_perm, I_PERM)
+DEF(k_min32, I_MIN32) DEF(k_add32, I_ADD32) DEF(k_and, I_AND) DEF(k_min3, I_MIN3) DEF(k_max3i16, I_MAX3I16) DEF(k_mini16, I_MINI16)
+DEF(k_sad, I_SAD) DEF(k_lshl, I_LSHL) DEF(k_dot4, I_DOT4) DEF(k_mad24, I_MAD24) DEF(k_pkmad, I_PKMAD) DEF(k_bfe, I_BFE)
+
+int main()
+{
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, 0);
+    const int cus = prop.multiProcessorCount, blocks = cus * 4;            // 4 workgroups x 4 waves per CU = 4 waves per SIMD
+    uint32_t *out;
+    hipMalloc(&out, (size_t)blocks * 256 * 4);
+    struct { const char *name; void (*fn)(uint32_t *, uint32_t); } ks[] = {
+        {"v_pk_min_i16", k_pkmin}, {"v_pk_max_i16", k_pkmax}, {"v_pk_sub_i16", k_pksub}, {"v_pk_add_u16", k_pkaddu}, {"v_alignbit_b32", k_align},
+        {"v_perm_b32", k_perm}, {"v_min_i32", k_min32}, {"v_add_u32", k_add32}, {"v_and_b32", k_and}, {"v_min3_i32", k_min3}, {"v_max3_i16", k_max3i16},
+        {"v_min_i16", k_mini16}, {"v_sad_u8", k_sad}, {"v_lshlrev_b32", k_lshl}, {"v_dot4_u32_u8", k_dot4}, {"v_mad_u32_u24", k_mad24}, {"v_pk_mad_i16", k_pkmad},
+        {"v_bfe_u32", k_bfe}};
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    int clk_khz = 0;
+    hipDeviceGetAttribute(&clk_khz, hipDeviceAttributeClockRate, 0);
+    printf("%d CUs, clock attribute %.0f MHz; cycles per wave-instruction per SIMD assume that clock\n", cus, clk_khz / 1e3);
+    for (auto &k : ks) {
+        hipLaunchKernelGGL(k.fn, dim3(blocks), dim3(256), 0, 0, out, 1u);
+        hipDeviceSynchronize();
+        hipEventRecord(e0, 0);
+        for (int r = 0; r < 5; r++) hipLaunchKernelGGL(k.fn, dim3(blocks), dim3(256), 0, 0, out, 2u + r);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        const double insts_per_simd = 5.0 * ITER * 8 * 4;                       // 4 waves per SIMD
+        const double cyc = ms * 1e-3 * clk_khz * 1e3 / insts_per_simd;
+        printf("%-16s %.3f ms  -> %.2f cycles per wave-instruction\n", k.name, ms / 5, cyc);
+    }
+    return 0;
+}
