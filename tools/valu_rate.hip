@@ -38,6 +38,47 @@ DEF(k_pkmin, I_PKMIN) DEF(k_pkmax, I_PKMAX) DEF(k_pksub, I_PKSUB) DEF(k_pkaddu, 
 DEF(k_min32, I_MIN32) DEF(k_add32, I_ADD32) DEF(k_and, I_AND) DEF(k_min3, I_MIN3) DEF(k_max3i16, I_MAX3I16) DEF(k_mini16, I_MINI16)
 DEF(k_sad, I_SAD) DEF(k_lshl, I_LSHL) DEF(k_dot4, I_DOT4) DEF(k_mad24, I_MAD24) DEF(k_pkmad, I_PKMAD) DEF(k_bfe, I_BFE)
 
+// co-issue probes: the same 8 vector instructions per iteration with 8 independent scalar ones / 4 LDS reads interleaved
+__global__ __launch_bounds__(256) void k_mix_salu(uint32_t *out, uint32_t seed)
+{
+    uint32_t a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19;
+    const uint32_t b = seed * 2654435761u;
+    uint32_t s0 = seed, s1 = seed + 1, s2 = seed + 2, s3 = seed + 3;
+    for (int i = 0; i < ITER; i++) {
+        asm volatile("v_pk_min_i16 %0, %0, %12\n s_add_u32 %8, %8, 3\n v_pk_min_i16 %1, %1, %12\n s_xor_b32 %9, %9, 5\n v_pk_min_i16 %2, %2, %12\n s_add_u32 %10, %10, 7\n"
+                     "v_pk_min_i16 %3, %3, %12\n s_xor_b32 %11, %11, 9\n v_pk_min_i16 %4, %4, %12\n s_add_u32 %8, %8, 11\n v_pk_min_i16 %5, %5, %12\n s_xor_b32 %9, %9, 13\n"
+                     "v_pk_min_i16 %6, %6, %12\n s_add_u32 %10, %10, 15\n v_pk_min_i16 %7, %7, %12\n s_xor_b32 %11, %11, 17"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : "v"(b) : "scc");
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ s0 ^ s1 ^ s2 ^ s3;
+}
+__global__ __launch_bounds__(256) void k_salu_only(uint32_t *out, uint32_t seed)
+{
+    uint32_t s0 = seed, s1 = seed + 1, s2 = seed + 2, s3 = seed + 3;
+    for (int i = 0; i < ITER; i++) {
+        asm volatile("s_add_u32 %0, %0, 3\n s_xor_b32 %1, %1, 5\n s_add_u32 %2, %2, 7\n s_xor_b32 %3, %3, 9\n s_add_u32 %0, %0, 11\n s_xor_b32 %1, %1, 13\n s_add_u32 %2, %2, 15\n s_xor_b32 %3, %3, 17"
+                     : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : : "scc");
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = s0 ^ s1 ^ s2 ^ s3;
+}
+__global__ __launch_bounds__(256) void k_mix_lds(uint32_t *out, uint32_t seed)
+{
+    __shared__ uint32_t sh[1024];
+    for (int i = threadIdx.x; i < 1024; i += 256) sh[i] = i * seed;
+    __syncthreads();
+    uint32_t a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19;
+    const uint32_t b = seed * 2654435761u;
+    uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+    const uint32_t addr = (uint32_t)(uintptr_t)sh + 4 * threadIdx.x;
+    for (int i = 0; i < ITER; i++) {
+        asm volatile("ds_read_b32 %8, %13\n v_pk_min_i16 %0, %0, %12\n v_pk_min_i16 %1, %1, %12\n ds_read_b32 %9, %13 offset:1024\n v_pk_min_i16 %2, %2, %12\n v_pk_min_i16 %3, %3, %12\n"
+                     "ds_read_b32 %10, %13 offset:2048\n v_pk_min_i16 %4, %4, %12\n v_pk_min_i16 %5, %5, %12\n ds_read_b32 %11, %13 offset:3072\n v_pk_min_i16 %6, %6, %12\n v_pk_min_i16 %7, %7, %12\n s_waitcnt lgkmcnt(0)"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3) : "v"(b), "v"(addr) : "memory");
+        a0 ^= l0 & 1; a1 ^= l1 & 1; a2 ^= l2 & 1; a3 ^= l3 & 1;
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+}
+
 int main()
 {
     hipDeviceProp_t prop;
@@ -49,7 +90,7 @@ int main()
         {"v_pk_min_i16", k_pkmin}, {"v_pk_max_i16", k_pkmax}, {"v_pk_sub_i16", k_pksub}, {"v_pk_add_u16", k_pkaddu}, {"v_alignbit_b32", k_align},
         {"v_perm_b32", k_perm}, {"v_min_i32", k_min32}, {"v_add_u32", k_add32}, {"v_and_b32", k_and}, {"v_min3_i32", k_min3}, {"v_max3_i16", k_max3i16},
         {"v_min_i16", k_mini16}, {"v_sad_u8", k_sad}, {"v_lshlrev_b32", k_lshl}, {"v_dot4_u32_u8", k_dot4}, {"v_mad_u32_u24", k_mad24}, {"v_pk_mad_i16", k_pkmad},
-        {"v_bfe_u32", k_bfe}};
+        {"v_bfe_u32", k_bfe}, {"8 v_pk_min + 8 SALU (per 8 vector)", k_mix_salu}, {"8 SALU only (per 8 scalar)", k_salu_only}, {"8 v_pk_min + 4 ds_read + 4 v_and/v_xor (per 8)", k_mix_lds}};
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     int clk_khz = 0;
