@@ -889,6 +889,22 @@ def main():
             ctx.synchronize()
         latency["extract_one_frame"] = {"gpu_ms": round((time.perf_counter() - t0) / nrep * 1e3, 4), "what": "ORBextractor::operator() on one %dx%d frame resident in HBM" % (W, H)}
         ext1.close()
+        if B > 1:
+            # one frame pair of SearchForInitialization (what Tracking::MonocularInitialization calls), on the bench batch's frames 0 / 1
+            def si_one():
+                orbhip.prev_matched_init_device(ctx, kp_p, max_kp, 1, max_kp, d_prev.data_ptr())
+                orbhip.search_for_initialization_device(ctx, kp_p, desc_p, cnt_p, kp_p + max_kp * 28, desc_p + dstride, cnt_p + 4, 1, max_kp, max_kp,
+                                                        (0.0, 0.0, float(W), float(H)), 100, 0.9, True, d_prev.data_ptr(), d_m12.data_ptr(), d_nm.data_ptr())
+            extract(); sync()
+            for _ in range(5):
+                si_one()
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                si_one()
+                ctx.synchronize()
+            latency["search_for_initialization_one_pair"] = {"gpu_ms": round((time.perf_counter() - t0) / 50 * 1e3, 4),
+                                                              "what": "vbPrevMatched reset + ORBmatcher::SearchForInitialization of frames 0 / 1 of the batch (window 100, ratio 0.9)"}
         if tracking is not None:
             for name in ("search_by_projection_last_frame", "search_by_projection_local_map"):
                 latency[name + "_one_pair"] = {"gpu_ms": tracking[name]["one_pair_ms"], "what": "~%d queries against one frame" % int(cnt_h[0])}
@@ -1097,6 +1113,14 @@ def main():
                 for i in range(3):
                     oe.extract(imgs[i % B], (0, 0))
                 latency["extract_one_frame"]["cpu_oracle_ms_1thread"] = round((time.time() - t0) / 3 * 1e3, 3)
+                if "search_for_initialization_one_pair" in latency:
+                    import oracle_match_bind as om
+                    ka, da, _ = oe.extract(imgs[0], (0, 0)); kb, db, _ = oe.extract(imgs[1], (0, 0))
+                    pv = np.stack([ka["x"], ka["y"]], 1)
+                    t0 = time.time()
+                    for i in range(20):
+                        om.search_for_initialization(ka, da, kb, db, (0.0, 0.0, float(W), float(H)), pv, 100, 0.9, True)
+                    latency["search_for_initialization_one_pair"]["cpu_oracle_ms_1thread"] = round((time.time() - t0) / 20 * 1e3, 4)
                 for name in ("search_by_projection_last_frame", "search_by_projection_local_map"):
                     if name + "_one_pair" in latency:
                         latency[name + "_one_pair"]["cpu_oracle_ms_1thread"] = out["tracking"][name]["cpu_baseline"]["single_thread_ms"]

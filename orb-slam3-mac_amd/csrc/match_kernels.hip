@@ -346,6 +346,53 @@ __device__ __forceinline__ int si_register_loop(int lane, int n0, int na0, const
     return nmatches;
 }
 
+// Tail of SearchForInitialization shared by both forms: rotation consistency (ORBmatcher.cc:792-815, 2307-2348) and the vbPrevMatched
+// update (:818-822).  bm[i1] = the F2 index an F1 keypoint was matched to at some time (0xFFFF: never); returns nmatches (lane 0's value counts).
+__device__ __forceinline__ int si_tail(int lane, int n1, const orbhip_keypoint *kpA, const orbhip_keypoint *kpB, const uint16_t *bm, int8_t *bin_of,
+                                       int *hist, int *s_keep, int32_t *m12, float *prev, int nmatches, int check_ori)
+{
+    const float factor = 1.0f / SI_HISTO;
+    __syncthreads();
+    // Every F1 point that was matched at some time has one histogram entry (ORBmatcher.cc:778-789), also when it was displaced later.
+    if (check_ori) {
+        for (int i1 = lane; i1 < n1; i1 += 64) {
+            const int b = bm[i1];
+            if (b == 0xFFFF) continue;
+            float rot = __fsub_rn(kpA[i1].angle, kpB[b].angle);
+            if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+            int bin = (int)roundf(__fmul_rn(rot, factor));
+            if (bin == SI_HISTO) bin = 0;
+            atomicAdd(&hist[bin], 1); bin_of[i1] = (int8_t)bin;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+            for (int i = 0; i < SI_HISTO; i++) {
+                const int sz = hist[i];
+                if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+                else if (sz > max3) { max3 = sz; ind3 = i; }
+            }
+            if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+            else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) ind3 = -1;
+            s_keep[0] = ind1; s_keep[1] = ind2; s_keep[2] = ind3;
+        }
+        __syncthreads();
+        int removed = 0;
+        for (int i1 = lane; i1 < n1; i1 += 64) {
+            const int b = bin_of[i1];
+            if (b < 0 || b == s_keep[0] || b == s_keep[1] || b == s_keep[2]) continue;
+            if (m12[i1] >= 0) { m12[i1] = -1; removed++; }
+        }
+        removed = wave_sum_dpp(removed);
+        nmatches -= removed;                                                // lane 0's copy is the one written out
+    }
+    __syncthreads();
+    for (int i1 = lane; i1 < n1; i1 += 64)                                  // ORBmatcher.cc:818-822
+        if (m12[i1] >= 0) { prev[2 * i1] = kpB[m12[i1]].x; prev[2 * i1 + 1] = kpB[m12[i1]].y; }
+    return nmatches;
+}
+
 #ifdef SI_PROF
 __device__ long long g_si_prof[8];            // debug build only (EXTRA=-DSI_PROF): cycles of setup / candidate scan / distances + reduction / update / tail, iterations
 #define SI_T(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const long long t_ = clock64(); g_si_prof[i] += t_ - t_prev; t_prev = t_; } } while (0)
@@ -362,8 +409,9 @@ __global__ __launch_bounds__(64) void k_search_init(const orbhip_keypoint *kpA_,
                                                     const orbhip_keypoint *kpB_, const uint8_t *descB_, const int32_t *nB,
                                                     int max_n, size_t kp_stride, float min_x, float min_y, float max_x, float max_y,
                                                     int window, float nn_ratio, int check_ori, int cap0, int maxn,
-                                                    float *prev_, int32_t *m12_, int32_t *nmatches_, int32_t *status)
+                                                    float *prev_, int32_t *m12_, int32_t *nmatches_, int32_t *status, const int32_t *redo_)
 {
+    if (redo_ && !redo_[blockIdx.x]) return;                      // the replay form (k_si_replay) has done this pair
     // dynamic LDS, carved by the launcher's capacities: cap0 octave-0 entries per frame, maxn keypoints per frame
     extern __shared__ __attribute__((aligned(16))) uint8_t si_lds[];
     float *kx = reinterpret_cast<float *>(si_lds), *ky = kx + cap0;
@@ -435,7 +483,6 @@ __global__ __launch_bounds__(64) void k_search_init(const orbhip_keypoint *kpA_,
     // ---- sequential F1 loop
     int nmatches = 0;
     const float r = (float)window;
-    const float factor = 1.0f / SI_HISTO;
     if (n0 <= 4 * 64 && na0 <= 4 * 64)
         nmatches = si_register_loop<4>(lane, n0, na0, kx, ky, cellx, celly, cpos, gidx, aidx, bm, dA, dB, prev, m12, min_x, min_y, inv_w, inv_h, r, nn_ratio);
     else if (n0 <= 8 * 64 && na0 <= 8 * 64)
@@ -521,47 +568,242 @@ __global__ __launch_bounds__(64) void k_search_init(const orbhip_keypoint *kpA_,
         SI_T(3);
     }
     }
-    __syncthreads();
-    // ---- rotation consistency: keep the three most populated bins (ORBmatcher.cc:792-815, 2307-2348).  Every F1 point
-    // that was matched at some time has one histogram entry (ORBmatcher.cc:778-789), also when it was displaced later.
-    if (check_ori) {
-        for (int i1 = lane; i1 < n1; i1 += 64) {
-            const int b = bm[i1];
-            if (b == 0xFFFF) continue;
-            float rot = __fsub_rn(kpA[i1].angle, kpB[b].angle);
-            if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
-            int bin = (int)roundf(__fmul_rn(rot, factor));
-            if (bin == SI_HISTO) bin = 0;
-            atomicAdd(&hist[bin], 1); bin_of[i1] = (int8_t)bin;
-        }
-        __syncthreads();
-        if (lane == 0) {
-            int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
-            for (int i = 0; i < SI_HISTO; i++) {
-                const int sz = hist[i];
-                if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
-                else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
-                else if (sz > max3) { max3 = sz; ind3 = i; }
-            }
-            if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
-            else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) ind3 = -1;
-            s_keep[0] = ind1; s_keep[1] = ind2; s_keep[2] = ind3;
-        }
-        __syncthreads();
-        int removed = 0;
-        for (int i1 = lane; i1 < n1; i1 += 64) {
-            const int b = bin_of[i1];
-            if (b < 0 || b == s_keep[0] || b == s_keep[1] || b == s_keep[2]) continue;
-            if (m12[i1] >= 0) { m12[i1] = -1; removed++; }
-        }
-        removed = wave_sum_dpp(removed);
-        nmatches -= removed;                                                // lane 0's copy is the one written out
-    }
-    __syncthreads();
-    for (int i1 = lane; i1 < n1; i1 += 64)                                  // ORBmatcher.cc:818-822
-        if (m12[i1] >= 0) { prev[2 * i1] = kpB[m12[i1]].x; prev[2 * i1 + 1] = kpB[m12[i1]].y; }
+    nmatches = si_tail(lane, n1, kpA, kpB, bm, bin_of, hist, s_keep, m12, prev, nmatches, check_ori);
     if (lane == 0) nmatches_[pair] = nmatches;
     SI_T(4);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Replay form of SearchForInitialization (round 3).  The F1 loop is sequential only through vMatchedDistance
+// (ORBmatcher.cc:749): a candidate is skipped when its F2 point already holds a match at a distance <= this one.  Which F2 points lie
+// in a query's window, their Hamming distances and GetFeaturesInArea's visiting order do not depend on it.  So:
+//   k_si_prep        one wave per pair: the octave-0 subsets of both frames (the only points that take part) written out compactly --
+//                    F2: position, grid cell + rank inside the cell, frame index, descriptor; F1: frame indices;
+//   k_si_candidates  ONE WAVE PER F1 POINT over the whole chip: every F2 subset point is tested against the window, keys
+//                    distance << 23 | visit order (the sequential kernels' key) are ranked by counting and the SIL_K smallest stored with
+//                    their subset positions (transposed: lane = query of a 64-query trip);
+//   k_si_replay      one wave per pair, 64 queries per trip: a lane's best / second best are the first two list entries NOT skipped by
+//                    the current vMatchedDistance -- it only ever decreases, so a skipped entry stays skipped and a cursor only moves forward.
+//                    Lanes speculate; an accepting lane publishes its F2 point (LDS atomicMin of the lane id); the prefix of lanes up to the
+//                    first one whose best or second best an earlier lane of the round wants becomes final and applies its updates
+//                    (distinct F2 points inside a prefix by construction), the rest look again.
+// Same candidates, same keys, same update rule as k_search_init; both run in every test (si_form fixture).  A pair whose subsets exceed the
+// work area, or a query whose truncated list runs dry before a best AND a second best were found, is flagged on the device and done by
+// k_search_init, which returns at once for the others.
+void *orbhip_ctx_work_internal(orbhip_ctx *c, size_t bytes);
+#define SIL_K 64                   // list entries kept per query
+#define SIL_BUF 512                // candidates a query may have before its pair falls back
+#define SIL_CAP 1024               // octave-0 points per frame the replay form handles
+struct SiWork {
+    int cap0, chunks;
+    float4 *rec;                   // [pairs][cap0]  F2 octave-0 subset: x, y, bits(cell x | cell y << 8 | rank << 16), bits(frame index)
+    uint4 *desc;                   // [pairs][cap0][2]
+    uint16_t *aidx;                // [pairs][cap0]  F1 octave-0 subset -> frame index
+    int32_t *n0, *na0;             // [pairs]
+    uint32_t *lkey;                // [pairs][chunks][SIL_K][64]
+    uint16_t *lli;                 // [pairs][chunks][SIL_K][64]
+    int32_t *count;                // [pairs][cap0]  candidates of the query (may exceed SIL_K; INT_MAX: more than SIL_BUF)
+    int32_t *redo;                 // [pairs]
+};
+
+__global__ __launch_bounds__(64) void k_si_prep(const orbhip_keypoint *kpA_, const int32_t *nA, const orbhip_keypoint *kpB_, const uint8_t *descB_, const int32_t *nB,
+                                                size_t kp_stride, float min_x, float min_y, float max_x, float max_y, int maxn, SiWork W)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t sip_lds[];
+    uint16_t *cellx = reinterpret_cast<uint16_t *>(sip_lds), *celly = cellx + W.cap0, *gidx = celly + W.cap0;
+    const int pair = blockIdx.x, lane = threadIdx.x;
+    const unsigned long long lt_mask = (1ull << lane) - 1;
+    const int n1 = nA[pair], n2 = nB[pair];
+    const orbhip_keypoint *kpA = kpA_ + (size_t)pair * kp_stride, *kpB = kpB_ + (size_t)pair * kp_stride;
+    const uint4 *dB = reinterpret_cast<const uint4 *>(descB_ + (size_t)pair * kp_stride * 32);
+    if (lane == 0) W.redo[pair] = 0;
+    if (n1 > maxn || n2 > maxn) { if (lane == 0) W.redo[pair] = 1; return; }       // (k_search_init reports the capacity error)
+    const float inv_w = __fdiv_rn((float)SI_COLS, __fsub_rn(max_x, min_x)), inv_h = __fdiv_rn((float)SI_ROWS, __fsub_rn(max_y, min_y));
+    float4 *rec = W.rec + (size_t)pair * W.cap0;
+    uint4 *desc = W.desc + (size_t)pair * W.cap0 * 2;
+    uint16_t *aidx = W.aidx + (size_t)pair * W.cap0;
+    int n0 = 0;                                                                    // F2: octave 0 and inside the grid, index order kept
+    for (int i0 = 0; i0 < n2; i0 += 64) {
+        const int i = i0 + lane;
+        bool in = false; int px = 0, py = 0; float fx = 0, fy = 0;
+        if (i < n2) {
+            const orbhip_keypoint k = kpB[i];
+            fx = k.x; fy = k.y;
+            px = (int)roundf(__fmul_rn(__fsub_rn(fx, min_x), inv_w)); py = (int)roundf(__fmul_rn(__fsub_rn(fy, min_y), inv_h));      // Frame.cc:718-719
+            in = k.octave == 0 && px >= 0 && px < SI_COLS && py >= 0 && py < SI_ROWS;
+        }
+        const unsigned long long bal = __ballot(in);
+        const int li = n0 + __popcll(bal & lt_mask);
+        if (in && li < W.cap0) {
+            cellx[li] = (uint16_t)px; celly[li] = (uint16_t)py; gidx[li] = (uint16_t)i;
+            rec[li] = make_float4(fx, fy, 0.0f, __uint_as_float((uint32_t)i));
+            desc[2 * li] = dB[2 * i]; desc[2 * li + 1] = dB[2 * i + 1];
+        }
+        n0 += __popcll(bal);
+    }
+    int na0 = 0;                                                                   // F1: octave 0 (ORBmatcher.cc:726-728)
+    for (int i0 = 0; i0 < n1; i0 += 64) {
+        const int i = i0 + lane;
+        const bool in = i < n1 && kpA[i].octave == 0;
+        const unsigned long long bal = __ballot(in);
+        const int li = na0 + __popcll(bal & lt_mask);
+        if (in && li < W.cap0) aidx[li] = (uint16_t)i;
+        na0 += __popcll(bal);
+    }
+    if (lane == 0) { W.n0[pair] = n0; W.na0[pair] = na0; }
+    if (n0 > W.cap0 || na0 > W.cap0) { if (lane == 0) W.redo[pair] = 1; return; }
+    __syncthreads();
+    for (int li = lane; li < n0; li += 64) {                                       // rank inside the grid cell = position in the cell's vector
+        const int cx = cellx[li], cy = celly[li];
+        int rank = 0;
+        for (int j = 0; j < li; j++) rank += (cellx[j] == cx && celly[j] == cy);
+        reinterpret_cast<uint32_t *>(rec + li)[2] = (uint32_t)cx | ((uint32_t)cy << 8) | ((uint32_t)min(rank, SI_RANKS - 1) << 16);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_si_candidates(const uint8_t *descA_, size_t kp_stride, int max_n, const float *prev_, float min_x, float min_y,
+                                                       float max_x, float max_y, int window, SiWork W)
+{
+    __shared__ uint32_t kbuf_all[4][SIL_BUF];
+    __shared__ uint16_t lbuf_all[4][SIL_BUF];
+    const int pair = blockIdx.y, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + w;
+    if (W.redo[pair]) return;
+    const int n0 = W.n0[pair], na0 = W.na0[pair];
+    if (t >= na0) return;
+    uint32_t *kbuf = kbuf_all[w]; uint16_t *lbuf = lbuf_all[w];
+    const int i1 = W.aidx[(size_t)pair * W.cap0 + t];
+    const uint4 *dA = reinterpret_cast<const uint4 *>(descA_ + ((size_t)pair * kp_stride + i1) * 32);
+    const uint4 a0 = dA[0], a1 = dA[1];
+    const float x = prev_[((size_t)pair * max_n + i1) * 2], y = prev_[((size_t)pair * max_n + i1) * 2 + 1], r = (float)window;
+    const float inv_w = __fdiv_rn((float)SI_COLS, __fsub_rn(max_x, min_x)), inv_h = __fdiv_rn((float)SI_ROWS, __fsub_rn(max_y, min_y));
+    int32_t *count = W.count + (size_t)pair * W.cap0;
+    int c0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, min_x), r), inv_w)); if (c0 < 0) c0 = 0;                   // Frame.cc:656-674
+    int c1 = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, min_x), r), inv_w)); if (c1 > SI_COLS - 1) c1 = SI_COLS - 1;
+    int r0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, min_y), r), inv_h)); if (r0 < 0) r0 = 0;
+    int r1 = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, min_y), r), inv_h)); if (r1 > SI_ROWS - 1) r1 = SI_ROWS - 1;
+    if (c0 >= SI_COLS || c1 < 0 || r0 >= SI_ROWS || r1 < 0) { if (lane == 0) count[t] = 0; return; }
+    const uint32_t cw = (uint32_t)(c1 - c0), rh = (uint32_t)(r1 - r0), ncy = rh + 1;
+    const float4 *rec = W.rec + (size_t)pair * W.cap0;
+    const uint4 *dC = W.desc + (size_t)pair * W.cap0 * 2;
+    int total = 0;
+    for (int l0 = 0; l0 < n0; l0 += 64) {
+        const int li = l0 + lane;
+        bool ok = li < n0;
+        uint32_t key = 0xFFFFFFFFu;
+        if (ok) {
+            const float4 k = rec[li];
+            const uint32_t bits = __float_as_uint(k.z);
+            const uint32_t dcx = (bits & 255u) - (uint32_t)c0, dcy = ((bits >> 8) & 255u) - (uint32_t)r0;
+            ok = dcx <= cw && dcy <= rh && fabsf(__fsub_rn(k.x, x)) < r && fabsf(__fsub_rn(k.y, y)) < r;
+            if (ok) key = ((uint32_t)hamming256(a0, a1, dC[2 * li], dC[2 * li + 1]) << 23) | ((dcx * ncy + dcy) * SI_RANKS + (bits >> 16));
+        }
+        const unsigned long long m = __ballot(ok);
+        const int before = __popcll(m & ((1ull << lane) - 1));
+        if (ok && total + before < SIL_BUF) { kbuf[total + before] = key; lbuf[total + before] = (uint16_t)li; }
+        total += __popcll(m);
+    }
+    if (total > SIL_BUF) { if (lane == 0) count[t] = 0x7FFFFFFF; return; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const size_t lo = (((size_t)pair * W.chunks + (t >> 6)) * SIL_K) * 64 + (t & 63);
+    for (int e = lane; e < total; e += 64) {                                       // rank by counting (keys are unique)
+        const uint32_t mine = kbuf[e];
+        int rank = 0;
+        for (int j = 0; j < total; j++) rank += kbuf[j] < mine;
+        if (rank < SIL_K) { W.lkey[lo + (size_t)rank * 64] = mine; W.lli[lo + (size_t)rank * 64] = lbuf[e]; }
+    }
+    if (lane == 0) count[t] = total;
+}
+
+__global__ __launch_bounds__(64) void k_si_replay(const orbhip_keypoint *kpA_, const int32_t *nA, const orbhip_keypoint *kpB_, size_t kp_stride, int max_n,
+                                                  float nn_ratio, int check_ori, int maxn, SiWork W, float *prev_, int32_t *m12_, int32_t *nmatches_)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t sir_lds[];
+    int *md = reinterpret_cast<int *>(sir_lds);                          // [cap0] vMatchedDistance of the F2 subset
+    int *m21 = md + W.cap0;                                               // [cap0] vnMatches21
+    int *owner = m21 + W.cap0;                                            // [cap0] lowest lane of this round that wants the point (64: none)
+    uint32_t *tkey = reinterpret_cast<uint32_t *>(owner + W.cap0);        // [SIL_K][64] this trip's lists
+    uint16_t *tli = reinterpret_cast<uint16_t *>(tkey + SIL_K * 64);      // [SIL_K][64]
+    uint16_t *bm = tli + SIL_K * 64;                                      // [maxn]
+    int8_t *bin_of = reinterpret_cast<int8_t *>(bm + maxn);               // [maxn]
+    __shared__ int hist[SI_HISTO];
+    __shared__ int s_keep[3];
+    const int pair = blockIdx.x, lane = threadIdx.x;
+    if (W.redo[pair]) return;
+    const int n1 = nA[pair], n0 = W.n0[pair], na0 = W.na0[pair];
+    const orbhip_keypoint *kpA = kpA_ + (size_t)pair * kp_stride, *kpB = kpB_ + (size_t)pair * kp_stride;
+    float *prev = prev_ + (size_t)pair * max_n * 2;
+    int32_t *m12 = m12_ + (size_t)pair * max_n;
+    const int32_t *count = W.count + (size_t)pair * W.cap0;
+    const uint16_t *aidx = W.aidx + (size_t)pair * W.cap0;
+    const float4 *rec = W.rec + (size_t)pair * W.cap0;
+    for (int i = lane; i < SI_HISTO; i += 64) hist[i] = 0;
+    for (int i = lane; i < n0; i += 64) { md[i] = INT_MAX; m21[i] = -1; owner[i] = 64; }
+    for (int i = lane; i < n1; i += 64) { m12[i] = -1; bin_of[i] = -1; bm[i] = 0xFFFFu; }
+    __syncthreads();
+    int nmatches = 0;
+    bool give_up = false;
+    for (int t0 = 0; t0 < na0 && !give_up; t0 += 64) {
+        const int t = t0 + lane;
+        const bool valid = t < na0;
+        const int cnt_all = valid ? count[t] : 0;
+        if (__ballot(cnt_all == 0x7FFFFFFF)) { give_up = true; break; }
+        const int cnt = min(cnt_all, SIL_K);
+        const int i1 = valid ? (int)aidx[t] : 0;
+        // this trip's lists into LDS, coalesced (entry j of all 64 queries is one 256-byte row)
+        const int maxcnt = wave_max_dpp(cnt);
+        const size_t lo = (((size_t)pair * W.chunks + (t0 >> 6)) * SIL_K) * 64 + lane;
+        for (int j = 0; j < maxcnt; j++) { tkey[j * 64 + lane] = W.lkey[lo + (size_t)j * 64]; tli[j * 64 + lane] = W.lli[lo + (size_t)j * 64]; }
+        __syncthreads();
+        int ptr = 0;
+        bool fin = !valid || cnt == 0;
+        while (true) {
+            uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+            int l1 = 0, l2 = 0;
+            bool accept = false, starved = false;
+            if (!fin) {
+                while (ptr < cnt) { const uint32_t k = tkey[ptr * 64 + lane]; const int li = tli[ptr * 64 + lane]; if (!(md[li] <= (int)(k >> 23))) { k1 = k; l1 = li; break; } ptr++; }   // ORBmatcher.cc:749
+                if (k1 == 0xFFFFFFFFu) starved = cnt_all > SIL_K;                  // ran out of a truncated list
+                else {
+                    int p2 = ptr + 1;
+                    while (p2 < cnt) { const uint32_t k = tkey[p2 * 64 + lane]; const int li = tli[p2 * 64 + lane]; if (!(md[li] <= (int)(k >> 23))) { k2 = k; l2 = li; break; } p2++; }
+                    if (k2 == 0xFFFFFFFFu && cnt_all > SIL_K) starved = true;
+                    const int best = (int)(k1 >> 23), d2 = k2 == 0xFFFFFFFFu ? INT_MAX : (int)(k2 >> 23);
+                    accept = best <= SI_TH_LOW && (float)best < __fmul_rn((float)d2, nn_ratio);          // ORBmatcher.cc:764-766
+                }
+            }
+            if (__ballot(starved)) { give_up = true; break; }
+            if (!fin && accept) atomicMin(&owner[l1], lane);
+            __syncthreads();
+            bool conflict = false;
+            if (!fin) {
+                if (k1 != 0xFFFFFFFFu) conflict = owner[l1] < lane;
+                if (k2 != 0xFFFFFFFFu) conflict = conflict || owner[l2] < lane;
+            }
+            const unsigned long long cm = __ballot(conflict);
+            const int f = cm ? __ffsll((long long)cm) - 1 : 64;                    // lanes below f are final
+            __syncthreads();
+            if (!fin && accept) owner[l1] = 64;
+            if (!fin && lane < f) {
+                if (accept) {                                                      // ORBmatcher.cc:766-790
+                    const int old = m21[l1];
+                    const int best_idx = (int)__float_as_uint(rec[l1].w);
+                    if (old >= 0) { m12[old] = -1; nmatches--; }
+                    m12[i1] = best_idx; m21[l1] = i1; md[l1] = (int)(k1 >> 23); nmatches++;
+                    bm[i1] = (uint16_t)best_idx;
+                }
+                fin = true;
+            }
+            __syncthreads();
+            if (f == 64) break;
+        }
+    }
+    if (give_up) { if (lane == 0) W.redo[pair] = 1; return; }                      // k_search_init starts over (it resets m12; prev is untouched so far)
+    nmatches = wave_sum_dpp(nmatches);
+    nmatches = si_tail(lane, n1, kpA, kpB, bm, bin_of, hist, s_keep, m12, prev, nmatches, check_ori);
+    if (lane == 0) nmatches_[pair] = nmatches;
 }
 
 extern "C" int orbhip_search_for_initialization_device(orbhip_ctx *ctx,
@@ -580,9 +822,50 @@ extern "C" int orbhip_search_for_initialization_device(orbhip_ctx *ctx,
     const int maxn = max_n < SI_MAXN ? max_n : SI_MAXN, cap0 = max_n < SI_CAP0 ? max_n : SI_CAP0;
     const size_t lds = (size_t)cap0 * (4 * 4 + 7 * 2) + (size_t)maxn * 3;
     if (orb_lds_optin(reinterpret_cast<const void *>(k_search_init), orbhip_ctx_device_internal(ctx), lds)) return ORBHIP_E_HIP;
-    hipLaunchKernelGGL(k_search_init, dim3(pairs), dim3(64), lds, orbhip_ctx_stream_internal(ctx), d_kpA, d_descA, d_nA,
+    hipStream_t st = orbhip_ctx_stream_internal(ctx);
+    // Up to 512 pairs per call the replay form first (see k_si_replay); pairs it cannot finish are flagged on the device and done by the
+    // sequential kernel, which returns at once for the others.  Measured (tools/si_sweep.py, VGA / 1000 features, ~220 octave-0 points per
+    // frame; replay vs sequential, ms per call): 1 pair 0.110 / 0.231, 64: 0.136 / 0.240, 256: 0.188 / 0.244, 512: 0.250 / 0.263,
+    // 1023: 0.370 / 0.310 -- from ~600 pairs on one register-resident wave per pair on every SIMD is the better use of the chip.
+    // ORBHIP_SI_PARALLEL_MAX_PAIRS moves the switch (0: the sequential kernel alone; tests run both forms).
+    const int par_max = getenv("ORBHIP_SI_PARALLEL_MAX_PAIRS") ? atoi(getenv("ORBHIP_SI_PARALLEL_MAX_PAIRS")) : 512;
+    const int32_t *d_redo = nullptr;
+    {
+        SiWork W;
+        W.cap0 = ((max_n < SIL_CAP ? max_n : SIL_CAP) + 7) & ~7; W.chunks = (W.cap0 + 63) / 64;
+        auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t P = (size_t)pairs;
+        const size_t o_rec = 0, o_desc = o_rec + al(16 * P * W.cap0), o_aidx = o_desc + al(32 * P * W.cap0), o_n0 = o_aidx + al(2 * P * W.cap0),
+                     o_na0 = o_n0 + al(4 * P), o_lkey = o_na0 + al(4 * P), o_lli = o_lkey + al(4 * P * W.chunks * SIL_K * 64),
+                     o_count = o_lli + al(2 * P * W.chunks * SIL_K * 64), o_redo = o_count + al(4 * P * W.cap0), total = o_redo + al(4 * P);
+        if (pairs <= par_max && total <= ((size_t)1 << 30)) {
+            uint8_t *wb = (uint8_t *)orbhip_ctx_work_internal(ctx, total);
+            if (!wb) return ORBHIP_E_HIP;
+            W.rec = (float4 *)(wb + o_rec); W.desc = (uint4 *)(wb + o_desc); W.aidx = (uint16_t *)(wb + o_aidx); W.n0 = (int32_t *)(wb + o_n0);
+            W.na0 = (int32_t *)(wb + o_na0); W.lkey = (uint32_t *)(wb + o_lkey); W.lli = (uint16_t *)(wb + o_lli); W.count = (int32_t *)(wb + o_count);
+            W.redo = (int32_t *)(wb + o_redo);
+            const size_t prep_lds = (size_t)W.cap0 * 6 + 16, rep_lds = (size_t)W.cap0 * 12 + (size_t)SIL_K * 64 * 6 + (size_t)maxn * 3 + 16;
+            if (orb_lds_optin(reinterpret_cast<const void *>(k_si_prep), orbhip_ctx_device_internal(ctx), prep_lds) ||
+                orb_lds_optin(reinterpret_cast<const void *>(k_si_replay), orbhip_ctx_device_internal(ctx), rep_lds)) return ORBHIP_E_HIP;
+            hipLaunchKernelGGL(k_si_prep, dim3(pairs), dim3(64), prep_lds, st, d_kpA, d_nA, d_kpB, d_descB, d_nB, frame_stride_kp, min_x, min_y, max_x, max_y, maxn, W);
+            hipLaunchKernelGGL(k_si_candidates, dim3((W.cap0 + 3) / 4, pairs), dim3(256), 0, st, d_descA, frame_stride_kp, max_n, d_prev_matched, min_x, min_y,
+                               max_x, max_y, window_size, W);
+            hipLaunchKernelGGL(k_si_replay, dim3(pairs), dim3(64), rep_lds, st, d_kpA, d_nA, d_kpB, frame_stride_kp, max_n, nn_ratio, check_orientation, maxn, W,
+                               d_prev_matched, d_matches12, d_nmatches);
+            d_redo = W.redo;
+            if (getenv("ORBHIP_SI_DEBUG")) {                       // development: how many pairs the replay form handed back
+                std::vector<int32_t> h(pairs);
+                if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(h.data(), W.redo, 4 * (size_t)pairs, hipMemcpyDeviceToHost) == hipSuccess) {
+                    int nredo = 0;
+                    for (int v : h) nredo += v != 0;
+                    fprintf(stderr, "[orbhip] SearchForInitialization: %d of %d pairs fall back to the sequential kernel\n", nredo, pairs);
+                }
+            }
+        }
+    }
+    hipLaunchKernelGGL(k_search_init, dim3(pairs), dim3(64), lds, st, d_kpA, d_descA, d_nA,
                        d_kpB, d_descB, d_nB, max_n, frame_stride_kp, min_x, min_y, max_x, max_y, window_size, nn_ratio,
-                       check_orientation, cap0, maxn, d_prev_matched, d_matches12, d_nmatches, d_status);
+                       check_orientation, cap0, maxn, d_prev_matched, d_matches12, d_nmatches, d_status, d_redo);
     return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
 }
 

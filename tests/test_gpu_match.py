@@ -99,6 +99,15 @@ def test_bf2nn_on_extracted_frames(gpu_ctx):
 
 
 # ------------------------------------------------------------------ M3 + M4: SearchForInitialization
+@pytest.fixture(params=["replay", "sequential"])
+def si_form(request, monkeypatch):
+    """SearchForInitialization has two forms with identical results: candidate lists for all F1 points at once + a replay of the
+    vMatchedDistance rule (k_si_prep / k_si_candidates / k_si_replay, the default; pairs it cannot finish fall back on the device) and
+    the sequential one-wave-per-pair loop (k_search_init).  ORBHIP_SI_PARALLEL_MAX_PAIRS=0 keeps the sequential kernel alone."""
+    monkeypatch.setenv("ORBHIP_SI_PARALLEL_MAX_PAIRS", "1048576" if request.param == "replay" else "0")
+    return request.param
+
+
 def _search_init(gpu_ctx, frames_a, frames_b, bounds, prevs, max_n, window=100, ratio=0.9, check_ori=True):
     """frames_*: list of (kp structured array, desc [n,32]).  Returns per pair (nmatches, m12, prev)."""
     import torch
@@ -125,7 +134,7 @@ def _search_init(gpu_ctx, frames_a, frames_b, bounds, prevs, max_n, window=100, 
 
 
 @pytest.mark.parametrize("check_ori,window,ratio", [(True, 100, 0.9), (False, 100, 0.9), (True, 30, 0.6), (True, 400, 0.95)])
-def test_search_for_initialization_parity(gpu_ctx, check_ori, window, ratio):
+def test_search_for_initialization_parity(gpu_ctx, check_ori, window, ratio, si_form):
     import orbhip
     import oracle_match_bind as om
     ext = orbhip.Extractor(gpu_ctx, 1000, 1.2, 8, 20, 7)
@@ -147,7 +156,7 @@ def test_search_for_initialization_parity(gpu_ctx, check_ori, window, ratio):
     ext.close()
 
 
-def test_search_for_initialization_edge_cases(gpu_ctx):
+def test_search_for_initialization_edge_cases(gpu_ctx, si_form):
     """Empty frames, keypoints outside the grid, duplicated descriptors (ties), prev far off-image."""
     import orbhip
     import oracle_match_bind as om
@@ -174,6 +183,47 @@ def test_search_for_initialization_edge_cases(gpu_ctx):
         assert got[p][0] == n, (p, got[p][0], n)
         np.testing.assert_array_equal(got[p][1], m12)
         assert got[p][2].tobytes() == prev.tobytes()
+
+
+def test_search_for_initialization_contested_points(gpu_ctx, si_form):
+    """Dense clusters with few distinct descriptors: many F1 points want the same F2 point (vMatchedDistance displaces earlier matches,
+    later queries skip deep into their lists), windows with more than 64 candidates (truncated lists: the replay form must notice when a
+    list runs dry and hand the pair to the sequential kernel), one exact-copy pair (every point has a distance-0 twin)."""
+    import orbhip
+    import oracle_match_bind as om
+    rng = np.random.default_rng(91)
+
+    def mk(n, cx, cy, sigma, ndesc, flips):
+        kp = np.zeros(n, orbhip.KP_DTYPE)
+        kp["x"] = np.clip(rng.normal(cx, sigma, n), 1, 638).astype(np.float32)
+        kp["y"] = np.clip(rng.normal(cy, sigma, n), 1, 478).astype(np.float32)
+        kp["angle"] = rng.uniform(0, 360, n).astype(np.float32)
+        kp["octave"] = (rng.uniform(0, 1, n) < 0.1).astype(np.int32)             # 90 % at octave 0
+        base = rng.integers(0, 256, (ndesc, 32), dtype=np.uint8)
+        d = base[rng.integers(0, ndesc, n)].copy()
+        for _ in range(flips):                                                    # a few random bit flips: distances 0 .. 2 * flips
+            d[np.arange(n), rng.integers(0, 32, n)] ^= (1 << rng.integers(0, 8, n)).astype(np.uint8)
+        return kp, d
+    protos = [mk(1, 0, 0, 1, 6, 0)[1]]
+    fa, fb = [], []
+    for (n, sig, nd, fl) in [(300, 40, 6, 3), (500, 25, 4, 5), (250, 90, 12, 2), (600, 60, 3, 8), (180, 15, 2, 4)]:
+        a = mk(n, 320, 240, sig, nd, fl); b = mk(n + 30, 325, 238, sig, nd, fl)
+        b[1][:] = a[1][rng.integers(0, n, n + 30)]                                # F2 descriptors drawn from F1's: small distances everywhere
+        b[1][np.arange(n + 30), rng.integers(0, 32, n + 30)] ^= (1 << rng.integers(0, 8, n + 30)).astype(np.uint8)
+        fa.append(a); fb.append(b)
+    fa.append(fa[0]); fb.append((fa[0][0].copy(), fa[0][1].copy()))
+    bounds = (0.0, 0.0, 640.0, 480.0)
+    prevs = [np.stack([f[0]["x"], f[0]["y"]], 1) for f in fa]
+    for window, ratio in ((100, 0.9), (40, 0.99)):
+        got = _search_init(gpu_ctx, fa, fb, bounds, prevs, 800, window, ratio, True)
+        tot = 0
+        for p in range(len(fa)):
+            n, m12, prev = om.search_for_initialization(fa[p][0], fa[p][1], fb[p][0], fb[p][1], bounds, prevs[p], window, ratio, True)
+            assert got[p][0] == n, (p, window, got[p][0], n)
+            np.testing.assert_array_equal(got[p][1], m12)
+            assert got[p][2].tobytes() == prev.tobytes()
+            tot += n
+        assert tot > 100, tot
 
 
 # ------------------------------------------------------------------ M3 + M4: SearchByProjection (tracking)
@@ -309,7 +359,7 @@ def test_search_by_projection_capacity(gpu_ctx):
     gpu_ctx.check_status()          # sticky flag was cleared by the raising check
 
 
-def test_search_for_initialization_5x_features(gpu_ctx):
+def test_search_for_initialization_5x_features(gpu_ctx, si_form):
     """The monocular-initialisation extractor runs 5 x nFeatures (Tracking.cc:210): 5000 keypoints, > 1024 at octave 0."""
     import orbhip
     import oracle_match_bind as om
@@ -330,7 +380,7 @@ def test_search_for_initialization_5x_features(gpu_ctx):
     ext.close()
 
 
-def test_search_for_initialization_2000_features(gpu_ctx):
+def test_search_for_initialization_2000_features(gpu_ctx, si_form):
     """BASELINE config #3's extractor (2000 features at 1080p): ~434 keypoints at octave 0, the eight-slot register-resident loop
     (the 1000-feature tests take the four-slot one, the 5000-feature test the general LDS loop)."""
     import orbhip
