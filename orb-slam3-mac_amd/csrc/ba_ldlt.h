@@ -297,11 +297,13 @@ __device__ __forceinline__ bool ldlt_solve_wg(double *S, int ld, int n, const do
         const int nb = min(LD_NB, n - p0), m = n - p0;
         // contributions of the rows below the diagonal block: t_c = sum_{r >= nb} L[p0+r][p0+c] x[p0+r]
         {
-            const int c = tid & 31, rg = tid >> 5;          // 1024 threads = 32 columns x 32 row groups
-            double part = 0.0;
-            if (c < nb)
-                for (int r = nb + rg; r < m; r += 32) part += S[(size_t)(p0 + r) * ld + p0 + c] * y[p0 + r];
-            red[rg * 32 + c] = part;
+            const int c = tid & 31;                         // 32 columns x 32 row groups (1024 threads: one group each; fewer threads take several)
+            for (int rg = tid >> 5; rg < 32; rg += nth >> 5) {
+                double part = 0.0;
+                if (c < nb)
+                    for (int r = nb + rg; r < m; r += 32) part += S[(size_t)(p0 + r) * ld + p0 + c] * y[p0 + r];
+                red[rg * 32 + c] = part;
+            }
         }
         for (int idx = tid; idx < nb * LD_NB; idx += nth) {   // diagonal block of L into LDS
             const int r = idx >> 5, c = idx & 31;
