@@ -81,17 +81,24 @@ def test_extract_padded_pyramid(gpu_ctx):
 
 
 def test_extract_edge_inputs(gpu_ctx):
-    """Flat image (no corners at either threshold), pure noise, and a min-threshold-only image."""
+    """Flat image (no corners at either threshold), pure noise, a min-threshold-only image, and one that mixes both kinds of cells."""
     import orbhip
     ext, ora = _mk(gpu_ctx)
     rng = np.random.default_rng(3)
     flat = np.full((480, 640), 77, np.uint8)
     noise = rng.integers(0, 256, (480, 640), dtype=np.uint8)
     low = (128 + 6 * (rng.integers(0, 2, (60, 80)).repeat(8, 0).repeat(8, 1)) + rng.integers(0, 3, (480, 640))).astype(np.uint8)
-    imgs = np.stack([flat, noise, low])
+    # cells that find corners at iniThFAST next to cells that only do at minThFAST (the kernel's second pass runs per cell), in stripes
+    # narrower and wider than a cell
+    mixed = low.copy()
+    tex = orbhip.synth_frames(640, 480, 1, seed=4242)[0]
+    for x0, w in ((0, 97), (180, 20), (260, 140), (470, 33), (560, 80)):
+        mixed[:, x0:x0 + w] = tex[:, x0:x0 + w]
+    mixed[200:230, :] = low[200:230, :]
+    imgs = np.stack([flat, noise, low, mixed])
     got = ext.extract_host(imgs)
     assert len(got[0][0]) == 0 and got[0][2] == 0
-    for f in range(3):
+    for f in range(4):
         _compare_frame(ext, ora, imgs, f, (0, 1000), got)
     ext.close()
 
