@@ -72,6 +72,11 @@ struct OrbParams {
     int32_t *out_mono;        // [batch]
     int umax[ORB_HALF_PATCH + 1];
     int gauss_q8[7];
+    // k_blur_mfma (round 3): the 7x7 blur as two banded int8 matrix products per 64 x 64 window, one wave per 32-column tile column
+    const uint4 *bm_th;                 // [tile columns of all levels][2 output blocks][64 lanes] horizontal band operands, image borders folded in
+    const uint4 *bm_tv;                 // [4 output blocks][64 lanes] vertical band operands
+    int bm_cols[ORB_MAX_LEVELS + 1];    // prefix of tile columns per frame over the levels; [nlevels] == 0: the kernel is not used
+    int bm_init;                        // 128 * (sum of the taps): turns the biased int8 sums back into the plain ones
 };
 
 // k_fast_cells has its own, compact parameter block (scalar loads of per-level fields are what a persistent wave does most)

@@ -1253,8 +1253,112 @@ __global__ __launch_bounds__(256) void k_blur_rows(OrbParams P, int frame0)
     }
 }
 
+// ----------------------------------------------------------------------------------
+// A7 on the matrix cores (round 3).  The blur is exact integer arithmetic (taps q8, no intermediate rounding, one (sum + 2^15) >> 16 at the
+// end), so it can be regrouped freely: a 64 x 64 window of pixels times a banded 64 x 16 matrix of taps is the row pass for 16 output
+// columns, and the column pass is the same product along the other axis.  Why: k_fast_cells and the blur share the CUs and are bound by the
+// SUM of their vector instructions; k_blur_rows costs 14 per pixel, this form ~6, the multiply-adds go to the otherwise idle
+// matrix pipe.  No LDS (k_fast_cells owns it), no cross-lane movement:
+//   pass 1  C1[row][out col] = sum_k A[row][k] B[k][out col]: A = the window's pixels as int8 (p - 128: one xor per dword), lane (row & 15,
+//           g = lane >> 4) holds the 16 bytes of chunk g of its row -- ONE 16-byte load; B = the taps as a band, from a host-built table per
+//           (level, tile column, block) that also folds BORDER_REFLECT_101 in (a reflected column's tap is added to the column it mirrors)
+//           and mirrors the chunk rule below; the accumulators start at 128 * (sum of taps), which undoes the bias: C1 = the plain 16-bit row sum.
+//   pass 2  C2[out col][out row] = sum_k A2[out col][k] B2[k][out row]: A2 = C1 itself -- its layout (column on the lane, rows 4g + r in the
+//           registers of the four row tiles) IS an A operand whose k slot (g, 4t + r) means window row 16t + 4g + r; the band table is built
+//           in that slot order (any order works as long as both operands agree, tools/mfma_i8_probe.hip).  16-bit sums go in as two int8
+//           products (high and low byte, each biased), 256 * hi + lo + 2^15 is formed in the epilogue; the result tile has 4 consecutive
+//           COLUMNS of one output row per lane: one dword store.
+// A wave owns a 32-column tile column and walks down in steps of 58 rows (64-row windows, 3 rows of apron each side; rows are reflected by
+// index at load time).  Chunk rule (the table's too): chunk g of the window starts at 32 tx - 16 + 16 g, moved to 0 when negative and to
+// w - 16 when it would cross the row's end -- loads never leave [0, w) of a row (level 0 may be the caller's buffer).
+typedef int v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4i bm_as_v4i(uint4 v) { v4i r; r[0] = (int)v.x; r[1] = (int)v.y; r[2] = (int)v.z; r[3] = (int)v.w; return r; }
+__global__ __launch_bounds__(256) void k_blur_mfma(OrbParams P, int frame0, int nframes)
+{
+    const int per_frame = P.bm_cols[P.nlevels];
+    const unsigned wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
+    const int fr = (int)(wid / (unsigned)per_frame), rem = (int)(wid - (unsigned)fr * (unsigned)per_frame);
+    if (fr >= nframes) return;
+    int level = 0;
+    for (int l = 1; l < P.nlevels; l++) if (rem >= P.bm_cols[l]) level = l;
+    const OrbLevel &L = P.lv[level];
+    const int w = L.w, h = L.h, spitch = L.img_pitch, dpitch = L.blur_pitch;
+    const int tx = rem - P.bm_cols[level], X0 = 32 * tx;
+    const uint8_t *src = L.img + (size_t)(frame0 + fr) * L.img_frame_stride;
+    uint8_t *dst = L.blur + (size_t)(frame0 + fr) * L.blur_frame_stride;
+    int cx = X0 - 16 + 16 * g;
+    cx = cx < 0 ? 0 : cx;
+    if (cx + 16 > w) cx = w - 16;
+    const uint4 *th = P.bm_th + ((size_t)(P.bm_cols[level] + tx) * 2) * 64 + lane;
+    const v4i B0 = bm_as_v4i(th[0]), B1 = bm_as_v4i(th[64]);
+    v4i TV[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) TV[b] = bm_as_v4i(P.bm_tv[b * 64 + lane]);
+    const int init = P.bm_init;
+    const v4i c_init = {init, init, init, init}, c_init_lo = {init + 32768, init + 32768, init + 32768, init + 32768};
+    const int nty = (h + 57) / 58;
+    // the window of the NEXT step is in flight while this one is multiplied (one 16-byte load per lane and row tile)
+    auto load_window = [&](int Y0, u32x4_unaligned (&raw)[4]) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            int ya = Y0 - 3 + 16 * t + m;
+            ya = ya < 0 ? -ya : ya;
+            ya = ya >= h ? 2 * h - 2 - ya : ya;                       // BORDER_REFLECT_101; rows far below the image (last window) are never used
+            ya = min(max(ya, 0), h - 1);
+            raw[t] = *reinterpret_cast<const u32x4_unaligned *>(src + (uint32_t)(__umul24((uint32_t)ya, (uint32_t)spitch) + (uint32_t)cx));
+        }
+    };
+    u32x4_unaligned raw[4];
+    load_window(0, raw);
+    for (int ty = 0; ty < nty; ty++) {
+        const int Y0 = 58 * ty;
+        v4i A[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            A[t][0] = (int)(raw[t].x ^ 0x80808080u); A[t][1] = (int)(raw[t].y ^ 0x80808080u); A[t][2] = (int)(raw[t].z ^ 0x80808080u); A[t][3] = (int)(raw[t].w ^ 0x80808080u);
+        }
+        if (ty + 1 < nty) load_window(Y0 + 58, raw);
+        v4i C1[2][4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            C1[0][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[t], B0, c_init, 0, 0, 0);
+            C1[1][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[t], B1, c_init, 0, 0, 0);
+        }
+#pragma unroll
+        for (int cb = 0; cb < 2; cb++) {
+            v4i Ahi, Alo;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const uint32_t pab = __builtin_amdgcn_perm((uint32_t)C1[cb][t][1], (uint32_t)C1[cb][t][0], 0x05040100u);      // (lo, hi) byte pairs of rows r = 0, 1
+                const uint32_t pcd = __builtin_amdgcn_perm((uint32_t)C1[cb][t][3], (uint32_t)C1[cb][t][2], 0x05040100u);
+                Alo[t] = (int)(__builtin_amdgcn_perm(pcd, pab, 0x06040200u) ^ 0x80808080u);
+                Ahi[t] = (int)(__builtin_amdgcn_perm(pcd, pab, 0x07050301u) ^ 0x80808080u);
+            }
+            const int col = X0 + 16 * cb + 4 * g;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const v4i Chi = __builtin_amdgcn_mfma_i32_16x16x64_i8(Ahi, TV[b], c_init, 0, 0, 0);
+                const v4i Clo = __builtin_amdgcn_mfma_i32_16x16x64_i8(Alo, TV[b], c_init_lo, 0, 0, 0);
+                uint32_t v[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = min(((uint32_t)Chi[r] << 8) + (uint32_t)Clo[r], 0x00FFFFFFu);      // byte 2 = min((sum + 2^15) >> 16, 255)
+                const uint32_t p01 = __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0602u), p23 = __builtin_amdgcn_perm(v[3], v[2], 0x0c0c0602u);
+                const int row = Y0 + 16 * b + m;
+                if (16 * b + m < 58 && row < h && col < w) *reinterpret_cast<uint32_t *>(dst + (uint32_t)(__umul24((uint32_t)row, (uint32_t)dpitch) + (uint32_t)col)) = p01 | (p23 << 16);
+            }
+        }
+    }
+}
+
 void orb_launch_blur(const OrbParams &P, hipStream_t s, int wgs_per_cu, int frame0, int nframes)
 {
+    if (P.bm_cols[P.nlevels] > 0 && P.batch >= P.rows_min_batch) {
+        if (nframes < 0) nframes = P.batch - frame0;
+        const long waves = (long)P.bm_cols[P.nlevels] * nframes;
+        if (nframes > 0) hipLaunchKernelGGL(k_blur_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, P, frame0, nframes);
+        return;
+    }
     if (P.br_blocks[P.nlevels] > 0 && P.batch >= P.rows_min_batch) {
         if (nframes < 0) nframes = P.batch - frame0;
         if (nframes > 0) hipLaunchKernelGGL(k_blur_rows, dim3((unsigned)P.br_blocks[P.nlevels] * (unsigned)nframes), dim3(256), 0, s, P, frame0);

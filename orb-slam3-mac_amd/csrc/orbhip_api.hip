@@ -459,6 +459,58 @@ extern "C" int orbhip_extractor_reserve(orbhip_extractor *e, int width, int heig
         }
     }
     e->d_level0 = P.lv[0].img; e->level0_pitch = P.lv[0].img_pitch; e->level0_frame_stride = P.lv[0].img_frame_stride;
+    {   // k_blur_mfma operand tables (orb_kernels.hip): horizontal band per (level, 32-column tile column, 16-column block) with the image
+        // borders folded in and the kernel's chunk rule mirrored; vertical band per 16-row output block in the slot order the accumulator
+        // layout of pass 1 dictates.  Not used (k_blur_rows stays) for levels narrower than 32 or shorter than 8.
+        // OPT-IN (ORBHIP_BLUR_MFMA=1 when the extractor is created): bit-exact, but measured no faster than k_blur_rows at VGA (3.72-3.76 vs
+        // 3.73-3.78 ms per step) and 10 % slower at 1080p -- kept as a tested alternative, not as the default.
+        bool ok = getenv("ORBHIP_BLUR_MFMA") && atoi(getenv("ORBHIP_BLUR_MFMA")) == 1 && P.br_blocks[e->nlevels] > 0;
+        int S = 0;
+        for (int i = 0; i < 7; i++) { S += e->gauss_q8[i]; if (e->gauss_q8[i] < 0 || e->gauss_q8[i] > 63) ok = false; }     // two folded taps must fit int8
+        if (255 * S > 65535) ok = false;                                                                                  // row sums must fit 16 bits
+        P.bm_cols[0] = 0;
+        for (int l = 0; l < e->nlevels; l++) {
+            if (P.lv[l].w < 32 || P.lv[l].h < 8) ok = false;
+            P.bm_cols[l + 1] = P.bm_cols[l] + (P.lv[l].w + 31) / 32;
+        }
+        auto refl = [](int x, int n) { return x < 0 ? -x : (x >= n ? 2 * n - 2 - x : x); };
+        std::vector<int8_t> th((size_t)P.bm_cols[e->nlevels] * 2 * 64 * 16, 0), tv((size_t)4 * 64 * 16, 0);
+        for (int l = 0; l < e->nlevels && ok; l++) {
+            const int w = P.lv[l].w;
+            for (int tx = 0; tx < (w + 31) / 32; tx++) {
+                int cxs[4];
+                for (int g = 0; g < 4; g++) { int cx = 32 * tx - 16 + 16 * g; cx = cx < 0 ? 0 : cx; if (cx + 16 > w) cx = w - 16; cxs[g] = cx; }
+                for (int cb = 0; cb < 2; cb++)
+                    for (int n = 0; n < 16; n++) {
+                        const int xo = 32 * tx + 16 * cb + n;
+                        if (xo >= w) continue;
+                        for (int i = -3; i <= 3; i++) {
+                            const int col = refl(xo + i, w);
+                            int gp = -1;                                         // the first chunk that holds the column takes its tap
+                            for (int g = 0; g < 4 && gp < 0; g++) if (col >= cxs[g] && col < cxs[g] + 16) gp = g;
+                            if (gp < 0) { ok = false; break; }
+                            int8_t &c = th[((((size_t)(P.bm_cols[l] + tx) * 2 + cb) * 64) + (size_t)(n + 16 * gp)) * 16 + (col - cxs[gp])];
+                            c = (int8_t)(c + e->gauss_q8[i + 3]);
+                        }
+                    }
+            }
+        }
+        for (int b = 0; b < 4; b++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int j = 0; j < 16; j++) {
+                    const int n = lane & 15, g = lane >> 4, krow = 16 * (j >> 2) + 4 * g + (j & 3), d = krow - (16 * b + n);
+                    tv[((size_t)b * 64 + lane) * 16 + j] = (int8_t)((d >= 0 && d <= 6) ? e->gauss_q8[d] : 0);
+                }
+        P.bm_th = nullptr; P.bm_tv = nullptr; P.bm_init = 128 * S;
+        if (ok) {
+            uint4 *dth, *dtv;
+            if ((rc = dev_alloc(e, &dth, th.size() / 16))) return rc;
+            if ((rc = dev_alloc(e, &dtv, tv.size() / 16))) return rc;
+            HIP_TRY(hipMemcpy(dth, th.data(), th.size(), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(dtv, tv.data(), tv.size(), hipMemcpyHostToDevice));
+            P.bm_th = dth; P.bm_tv = dtv;
+        } else P.bm_cols[e->nlevels] = 0;
+    }
     if ((rc = dev_alloc(e, &P.cell_count, B * cells))) return rc;
     if ((rc = dev_alloc(e, &P.cell_list, B * P.cell_list_frame_stride))) return rc;
     if ((rc = dev_alloc(e, &P.keys, B * keys))) return rc;
@@ -614,7 +666,8 @@ static int run_pipeline(orbhip_extractor *e, int batch, int lap0, int lap1)
         }
         orb_launch_fast_cells(F, s, fast_waves);
         if (fork) {                                         // after k_fast_cells on purpose: its waves take their LDS first, the blur fills the free wave slots
-            orb_launch_blur(P, e->aux, tune_int("ORBHIP_TUNE_BLUR_WGS", 5));
+            if (!tune_int("ORBHIP_TUNE_SKIP_BLUR", 0))       // (timing experiment only: descriptors are wrong without the blur)
+                orb_launch_blur(P, e->aux, tune_int("ORBHIP_TUNE_BLUR_WGS", 5));
             HIP_TRY(hipEventRecord(e->ev_join, e->aux));
         }
     }

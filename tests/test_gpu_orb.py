@@ -103,6 +103,27 @@ def test_extract_edge_inputs(gpu_ctx):
     ext.close()
 
 
+def test_blur_on_the_matrix_cores_is_bit_exact(gpu_ctx, monkeypatch):
+    """k_blur_mfma (opt-in, ORBHIP_BLUR_MFMA=1 at extractor creation): the 7x7 blur as two banded int8 MFMA products per window, image
+    borders folded into the operand tables.  Descriptors are the blur's consumers: frames of several sizes (widths that are and are
+    not multiples of 16 / 32, a level count that leaves narrow top levels) must match the default path and the oracle bit for bit."""
+    import orbhip
+    monkeypatch.setenv("ORBHIP_ROWS_MIN_BATCH", "1")
+    for (W, H, nfeat, nlev, scale, seed) in ((640, 480, 1000, 8, 1.2, 31), (752, 480, 1200, 8, 1.2, 32), (1241, 376, 2000, 8, 1.2, 33), (801, 603, 1500, 6, 1.3, 34)):
+        imgs = orbhip.synth_frames(W, H, 3, seed=seed)
+        monkeypatch.setenv("ORBHIP_BLUR_MFMA", "0")
+        ext0, ora = _mk(gpu_ctx, nfeat=nfeat, nlev=nlev, scale=scale)
+        ref = ext0.extract_host(imgs)
+        ext0.close()
+        monkeypatch.setenv("ORBHIP_BLUR_MFMA", "1")
+        ext1, _ = _mk(gpu_ctx, nfeat=nfeat, nlev=nlev, scale=scale)
+        got = ext1.extract_host(imgs)
+        for f in range(3):
+            assert got[f][0].tobytes() == ref[f][0].tobytes() and got[f][1].tobytes() == ref[f][1].tobytes(), (W, H, f)
+            _compare_frame(ext1, ora, imgs, f, (0, 1000), got)          # every level's blurred image and the descriptors against the oracle
+        ext1.close()
+
+
 def test_extract_other_params(gpu_ctx):
     import orbhip
     ext, ora = _mk(gpu_ctx, nfeat=2000, nlev=5, ini=12, mn=5, scale=1.3)
