@@ -623,32 +623,43 @@ __global__ __launch_bounds__(64) void k_si_prep(const orbhip_keypoint *kpA_, con
     uint4 *desc = W.desc + (size_t)pair * W.cap0 * 2;
     uint16_t *aidx = W.aidx + (size_t)pair * W.cap0;
     int n0 = 0;                                                                    // F2: octave 0 and inside the grid, index order kept
-    for (int i0 = 0; i0 < n2; i0 += 64) {
-        const int i = i0 + lane;
-        bool in = false; int px = 0, py = 0; float fx = 0, fy = 0;
-        if (i < n2) {
-            const orbhip_keypoint k = kpB[i];
-            fx = k.x; fy = k.y;
-            px = (int)roundf(__fmul_rn(__fsub_rn(fx, min_x), inv_w)); py = (int)roundf(__fmul_rn(__fsub_rn(fy, min_y), inv_h));      // Frame.cc:718-719
-            in = k.octave == 0 && px >= 0 && px < SI_COLS && py >= 0 && py < SI_ROWS;
+    for (int i0 = 0; i0 < n2; i0 += 256) {                                         // four chunks of loads in flight (the loop is a chain of global round trips otherwise)
+        float fxs[4], fys[4]; int ocs[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = min(i0 + 64 * u + lane, n2 - 1);
+            fxs[u] = kpB[i].x; fys[u] = kpB[i].y; ocs[u] = kpB[i].octave;
         }
-        const unsigned long long bal = __ballot(in);
-        const int li = n0 + __popcll(bal & lt_mask);
-        if (in && li < W.cap0) {
-            cellx[li] = (uint16_t)px; celly[li] = (uint16_t)py; gidx[li] = (uint16_t)i;
-            rec[li] = make_float4(fx, fy, 0.0f, __uint_as_float((uint32_t)i));
-            desc[2 * li] = dB[2 * i]; desc[2 * li + 1] = dB[2 * i + 1];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + 64 * u + lane;
+            const float fx = fxs[u], fy = fys[u];
+            const int px = (int)roundf(__fmul_rn(__fsub_rn(fx, min_x), inv_w)), py = (int)roundf(__fmul_rn(__fsub_rn(fy, min_y), inv_h));      // Frame.cc:718-719
+            const bool in = i < n2 && ocs[u] == 0 && px >= 0 && px < SI_COLS && py >= 0 && py < SI_ROWS;
+            const unsigned long long bal = __ballot(in);
+            const int li = n0 + __popcll(bal & lt_mask);
+            if (in && li < W.cap0) {
+                cellx[li] = (uint16_t)px; celly[li] = (uint16_t)py; gidx[li] = (uint16_t)i;
+                rec[li] = make_float4(fx, fy, 0.0f, __uint_as_float((uint32_t)i));
+                desc[2 * li] = dB[2 * i]; desc[2 * li + 1] = dB[2 * i + 1];
+            }
+            n0 += __popcll(bal);
         }
-        n0 += __popcll(bal);
     }
     int na0 = 0;                                                                   // F1: octave 0 (ORBmatcher.cc:726-728)
-    for (int i0 = 0; i0 < n1; i0 += 64) {
-        const int i = i0 + lane;
-        const bool in = i < n1 && kpA[i].octave == 0;
-        const unsigned long long bal = __ballot(in);
-        const int li = na0 + __popcll(bal & lt_mask);
-        if (in && li < W.cap0) aidx[li] = (uint16_t)i;
-        na0 += __popcll(bal);
+    for (int i0 = 0; i0 < n1; i0 += 256) {
+        int ocs[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) ocs[u] = kpA[min(i0 + 64 * u + lane, n1 - 1)].octave;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + 64 * u + lane;
+            const bool in = i < n1 && ocs[u] == 0;
+            const unsigned long long bal = __ballot(in);
+            const int li = na0 + __popcll(bal & lt_mask);
+            if (in && li < W.cap0) aidx[li] = (uint16_t)i;
+            na0 += __popcll(bal);
+        }
     }
     if (lane == 0) { W.n0[pair] = n0; W.na0[pair] = na0; }
     if (n0 > W.cap0 || na0 > W.cap0) { if (lane == 0) W.redo[pair] = 1; return; }
