@@ -1224,3 +1224,105 @@ def test_search_for_triangulation_general_oracle_reduces_to_the_pinhole_form():
     # rig keyframes have no stereo keypoints: bOnlyStereo finds nothing (ORBmatcher.cc:1044-1048)
     c = om.make_tri_general_case(rng, 300, 300, "rig", only_stereo=True)
     assert om.search_for_triangulation_general(c, True)[0] == 0
+
+
+def test_ba_first_lm_iteration_against_an_independent_dense_numpy_model():
+    """Pins the oracle's normal equations, Schur elimination, LDL^T, update rule and lambda initialisation against a model that shares
+    no code with it: numpy only, NUMERIC Jacobians of the residual (central differences of the left-multiplied SE3 perturbation
+    [omega, upsilon], g2o's SE3Quat::exp order, and of the point), the DENSE (6 nf + 3 L)-dimensional system (H + lambda I) d = b
+    solved by numpy.linalg.solve -- no Schur complement --, Huber weights, lambda = 1e-50 * max diag(H)
+    (Thirdparty/g2o/g2o/core/optimization_algorithm_levenberg.cpp:47,171-185).  One optimize(1): the estimates after the step and
+    the robust chi2 must agree with the oracle to finite-difference accuracy."""
+    import synth_ba
+    import oracle_ba_bind as ob
+
+    def quat_to_R(q):
+        x, y, z, w = q / np.linalg.norm(q)
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+    def skew(v):
+        return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+
+    def se3_exp(d):                                   # d = [omega, upsilon] -> (R, t), closed form with series for small angles
+        om, up = d[:3], d[3:]
+        th = np.linalg.norm(om)
+        Om = skew(om)
+        if th < 1e-8:
+            R = np.eye(3) + Om + 0.5 * Om @ Om
+            V = np.eye(3) + 0.5 * Om + Om @ Om / 6
+        else:
+            R = np.eye(3) + np.sin(th) / th * Om + (1 - np.cos(th)) / th ** 2 * Om @ Om
+            V = np.eye(3) + (1 - np.cos(th)) / th ** 2 * Om + (th - np.sin(th)) / th ** 3 * Om @ Om
+        return R, V @ up
+
+    g = synth_ba.make_graph(n_kf=6, n_pts=40, obs=4, seed=321, n_fixed=2, outlier_frac=0.1)
+    p = ob.default_params()
+    p.iters1, p.iters2 = 1, 0
+    rc, o_poses, o_pts, _, o_st, _, _ = ob.solve_with_gate_values(g, p)
+    assert o_st["iterations_run"][0] == 1 and o_st["lm_trials"] == 1
+    fx, fy, cx, cy = g["fx"], g["fy"], g["cx"], g["cy"]
+    R0 = [quat_to_R(q[:4]) for q in g["poses0"]]; t0 = [q[4:].copy() for q in g["poses0"]]
+    X0 = g["points0"].astype(np.float64).copy()
+    free = np.flatnonzero(np.asarray(g["pose_fixed"]) == 0)
+    hidx = {int(k): i for i, k in enumerate(free)}
+    nf, L, E = len(free), g["n_points"], g["n_edges"]
+    assert np.all(np.asarray(g["edge_stereo"]) == 0)
+    # thHuber = (float)sqrt(5.991) and delta^2 kept as a float (Optimizer.cc:1910-1911, robust_kernel_impl.h:84)
+    delta = float(np.float32(np.sqrt(p.huber_mono2))); delta2 = float(np.float32(delta * delta))
+
+    def residual(R, t, X, e):
+        k, l = int(g["edge_pose"][e]), int(g["edge_point"][e])
+        Pc = R[k] @ X[l] + t[k]
+        return g["edge_obs"][e, :2].astype(np.float64) - np.array([fx * Pc[0] / Pc[2] + cx, fy * Pc[1] / Pc[2] + cy])
+
+    def robust_chi2(R, t, X):
+        tot = 0.0
+        for e in range(E):
+            r = residual(R, t, X, e)
+            c = float(r @ r) * float(g["edge_inv_sigma2"][e])
+            tot += c if c <= delta2 else 2 * np.sqrt(c) * delta - delta2
+        return tot
+
+    n = 6 * nf + 3 * L
+    H = np.zeros((n, n)); b = np.zeros(n)
+    h = 1e-6
+    for e in range(E):
+        k, l = int(g["edge_pose"][e]), int(g["edge_point"][e])
+        r = residual(R0, t0, X0, e)
+        is2 = float(g["edge_inv_sigma2"][e])
+        c = float(r @ r) * is2
+        w = is2 * (1.0 if c <= delta2 else delta / np.sqrt(c))
+        cols, J = [], []
+        if k in hidx:
+            Jp = np.zeros((2, 6))
+            for a in range(6):
+                d = np.zeros(6); d[a] = h
+                Rp, tp = se3_exp(d); Rm, tm = se3_exp(-d)
+                Ra = list(R0); ta = list(t0); Ra[k] = Rp @ R0[k]; ta[k] = Rp @ t0[k] + tp
+                Rb = list(R0); tb = list(t0); Rb[k] = Rm @ R0[k]; tb[k] = Rm @ t0[k] + tm
+                Jp[:, a] = (residual(Ra, ta, X0, e) - residual(Rb, tb, X0, e)) / (2 * h)
+            cols += list(range(6 * hidx[k], 6 * hidx[k] + 6)); J.append(Jp)
+        Jx = np.zeros((2, 3))
+        for a in range(3):
+            Xa = X0.copy(); Xa[l, a] += h; Xb = X0.copy(); Xb[l, a] -= h
+            Jx[:, a] = (residual(R0, t0, Xa, e) - residual(R0, t0, Xb, e)) / (2 * h)
+        cols += list(range(6 * nf + 3 * l, 6 * nf + 3 * l + 3)); J.append(Jx)
+        Je = np.hstack(J)
+        H[np.ix_(cols, cols)] += w * Je.T @ Je
+        b[cols] += -w * Je.T @ r
+    lam = 1e-50 * np.max(np.abs(np.diag(H)))
+    d = np.linalg.solve(H + lam * np.eye(n), b)
+    R1 = list(R0); t1 = list(t0)
+    for k, i in hidx.items():
+        Rd, td = se3_exp(d[6 * i:6 * i + 6])
+        R1[k] = Rd @ R0[k]; t1[k] = Rd @ t0[k] + td
+    X1 = X0 + d[6 * nf:].reshape(L, 3)
+    chi0, chi1 = robust_chi2(R0, t0, X0), robust_chi2(R1, t1, X1)
+    assert abs(chi0 - o_st["chi2_initial"]) <= 1e-9 * chi0
+    assert chi1 < chi0                                                    # the step is accepted on both sides (one trial)
+    assert abs(chi1 - o_st["chi2_final"]) <= 1e-5 * chi1, (chi1, o_st["chi2_final"])
+    for k in range(g["n_poses"]):
+        assert np.max(np.abs(quat_to_R(o_poses[k, :4]) - R1[k])) <= 1e-6 and np.max(np.abs(o_poses[k, 4:] - t1[k])) <= 1e-6, k
+    assert np.max(np.abs(o_pts - X1)) <= 1e-5
