@@ -2,6 +2,7 @@
 finite differences taken through the restated vertex updates (G2oTypes.cc:192-220), the SO3 helpers, and the LM loop on synthetic
 visual-inertial windows.  PARITY UNPINNED (no reference fixtures exist for this path; see oracle/iba_oracle.h)."""
 import numpy as np
+import pytest
 import oracle_iba_bind as ib
 
 
@@ -154,3 +155,96 @@ def test_iba_golden_regression():
         assert np.abs(kf - exp["kf"]).max() <= 1e-9 and np.abs(pts - exp["pts"]).max() <= 1e-9
         assert np.array_equal(out, exp["outlier"])
         assert abs(st.err - exp["err"][0]) <= 1e-9 * abs(exp["err"][0]) and abs(st.err_end - exp["err"][1]) <= 1e-6 * max(1.0, abs(exp["err"][1]))
+
+
+@pytest.mark.parametrize("kw", [dict(n_opt=6, n_fixed_vis=5, n_points=120, stereo_frac=0.5),
+                                dict(n_opt=4, n_fixed_vis=3, n_points=60, stereo_frac=0.0),
+                                dict(n_opt=5, n_fixed_vis=4, n_points=90, fisheye_rig=True)])
+def test_initial_robust_chi2_against_an_independent_numpy_restatement(kw):
+    """optimizer.activeRobustChi2() before optimize() (Optimizer.cc:5045) from a numpy model written from the reference text alone --
+    EdgeInertial::computeError (G2oTypes.cc:717-740) with the bias-corrected deltas of ImuTypes.cc:357-378 (ExpSO3 :48-60, the
+    nearest rotation by numpy's SVD for NormalizeRotation :30-36), EdgeGyroRW / EdgeAccRW (G2oTypes.h:632-700), EdgeMono / EdgeStereo
+    on ImuCamPose::Project / ProjectStereo (G2oTypes.cc:170-185; camera = Tcb . Twb^-1, second camera through Trl :57-67),
+    Pinhole / KannalaBrandt8 project, the Huber kernels with their float dsqr (robust_kernel_impl.cpp:65-91; deltas
+    Optimizer.cc:4834,4892-4894) -- must equal the oracle's `err`: pins every residual and information weight of the restated
+    graph (the deltas in double here as in the oracle: see oracle/iba_oracle.h for that documented deviation)."""
+    win = ib.make_window(77, **kw)
+    _, _, _, st = ib.solve(win)
+    a, d = win.arrays, win.d
+    kf, pts = win.kf0.reshape(-1, 21), win.pts0.reshape(-1, 3)
+    Rcb, tcb = win.Rcb.reshape(3, 3), win.tcb
+    fx, fy, cx, cy, bf = [float(x) for x in win.cam]
+
+    def huber(e, delta):
+        dsqr = float(np.float32(delta * delta))
+        return e if e <= dsqr else 2 * np.sqrt(e) * delta - dsqr
+
+    def project(Xc, cam, model, kb):
+        f0, f1, c0, c1 = cam
+        if model == 0:
+            return np.array([f0 * Xc[0] / Xc[2] + c0, f1 * Xc[1] / Xc[2] + c1])
+        x2y2 = Xc[0] ** 2 + Xc[1] ** 2                                       # KannalaBrandt8.cpp:52-69
+        th = np.arctan2(np.sqrt(x2y2), Xc[2]); psi = np.arctan2(Xc[1], Xc[0])
+        r = th + kb[0] * th ** 3 + kb[1] * th ** 5 + kb[2] * th ** 7 + kb[3] * th ** 9
+        return np.array([f0 * r * np.cos(psi) + c0, f1 * r * np.sin(psi) + c1])
+
+    def exp_so3(v):                                                          # ImuTypes.cc:48-60 (eps 1e-4)
+        th2 = float(v @ v); th = np.sqrt(th2)
+        W = np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+        return np.eye(3) + W + 0.5 * W @ W if th < 1e-4 else np.eye(3) + W * np.sin(th) / th + W @ W * (1 - np.cos(th)) / th2
+
+    def log_so3(R):                                                          # G2oTypes.cc:1010-1025
+        tr = np.trace(R)
+        w = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]) / 2
+        c = (tr - 1) * 0.5
+        if c > 1 or c < -1:
+            return w
+        th = np.arccos(c); s = np.sin(th)
+        return w if abs(s) < 1e-5 else th * w / s
+
+    th_mono, th_stereo = float(np.float32(np.sqrt(5.991))), float(np.float32(np.sqrt(7.815)))
+    total = 0.0
+    cam2 = model2 = kb2 = Trl = None
+    if "Trl" in d:
+        Trl = np.asarray(d["Trl"], np.float64).reshape(3, 4); cam2 = [float(x) for x in d["cam2"]]
+        model2 = int(d.get("camera2_model", 0)); kb2 = d.get("kb2", (0, 0, 0, 0))
+    model, kb = int(d.get("camera_model", 0)), d.get("kb", (0, 0, 0, 0))
+    for e in range(win.n_edges):
+        s = kf[a["edge_kf"][e]]
+        Rwb, twb = s[:9].reshape(3, 3), s[9:12]
+        Rcw = Rcb @ Rwb.T; tcw = Rcb @ (-Rwb.T @ twb) + tcb
+        X = pts[a["edge_point"][e]]
+        typ = int(a["edge_stereo"][e]); obs = a["edge_obs"][e]
+        if typ == 2:                                                         # EdgeMono(1): the second camera
+            Xc = Trl[:, :3] @ (Rcw @ X + tcw) + Trl[:, 3]
+            r = obs[:2] - project(Xc, cam2, model2, kb2)
+            total += huber(float(r @ r) * a["edge_inv_sigma2"][e], th_mono)
+        elif typ == 0:
+            r = obs[:2] - project(Rcw @ X + tcw, (fx, fy, cx, cy), model, kb)
+            total += huber(float(r @ r) * a["edge_inv_sigma2"][e], th_mono)
+        else:
+            Xc = Rcw @ X + tcw
+            uv = project(Xc, (fx, fy, cx, cy), model, kb)
+            r = obs - np.array([uv[0], uv[1], uv[0] - bf / Xc[2]])
+            total += huber(float(r @ r) * a["edge_inv_sigma2"][e], th_stereo)
+    g = np.array([0.0, 0.0, -float(np.float32(9.81))])                       # IMU::GRAVITY_VALUE is a float (ImuTypes.h:40)
+    for m in range(win.n_inertial):
+        s1, s2 = kf[a["in_kf1"][m]], kf[a["in_kf2"][m]]
+        p = a["in_preint"][m]
+        dt, dR, dV, dP = p[0], p[1:10].reshape(3, 3), p[10:13], p[13:16]
+        JRg, JVg, JVa, JPg, JPa = [p[16 + 9 * i:25 + 9 * i].reshape(3, 3) for i in range(5)]
+        bg0, ba0 = p[61:64], p[64:67]
+        R1, t1, v1, bg1, ba1 = s1[:9].reshape(3, 3), s1[9:12], s1[12:15], s1[15:18], s1[18:21]
+        R2, t2, v2, bg2, ba2 = s2[:9].reshape(3, 3), s2[9:12], s2[12:15], s2[15:18], s2[18:21]
+        dbg, dba = bg1 - bg0, ba1 - ba0
+        U, _, Vt = np.linalg.svd(dR @ exp_so3(JRg @ dbg))
+        dRc = U @ Vt
+        er = log_so3(dRc.T @ R1.T @ R2)
+        ev = R1.T @ (v2 - v1 - g * dt) - (dV + JVg @ dbg + JVa @ dba)
+        ep = R1.T @ (t2 - t1 - v1 * dt - g * dt * dt / 2) - (dP + JPg @ dbg + JPa @ dba)
+        e9 = np.concatenate([er, ev, ep])
+        c9 = float(e9 @ a["in_info"][m].reshape(9, 9) @ e9)
+        total += huber(c9, np.sqrt(16.92)) if a["in_robust"][m] else c9
+        eg, ea = bg2 - bg1, ba2 - ba1
+        total += float(eg @ a["in_info_g"][m].reshape(3, 3) @ eg) + float(ea @ a["in_info_a"][m].reshape(3, 3) @ ea)
+    assert abs(total - st.err) <= 1e-9 * abs(st.err), (total, st.err)
