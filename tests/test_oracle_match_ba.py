@@ -1326,3 +1326,86 @@ def test_ba_first_lm_iteration_against_an_independent_dense_numpy_model():
     for k in range(g["n_poses"]):
         assert np.max(np.abs(quat_to_R(o_poses[k, :4]) - R1[k])) <= 1e-6 and np.max(np.abs(o_poses[k, 4:] - t1[k])) <= 1e-6, k
     assert np.max(np.abs(o_pts - X1)) <= 1e-5
+
+
+@pytest.mark.parametrize("check_ori,window,ratio", [(True, 100, 0.9), (False, 60, 0.8), (True, 300, 0.95)])
+def test_search_for_initialization_oracle_against_python(check_ori, window, ratio):
+    """ORBmatcher::SearchForInitialization (ORBmatcher.cc:709-824) restated in plain Python on top of the GetFeaturesInArea oracle and
+    numpy popcounts: level-0 F1 points in order, vMatchedDistance skips, best / second best with strict <, TH_LOW and the ratio test in
+    float, displaced matches, the rotation histogram that keeps displaced entries (round(), bin 30 -> 0), ComputeThreeMaxima
+    (ORBmatcher.cc:2307-2348), vbPrevMatched update.  Clustered points with few distinct descriptors make displacement frequent."""
+    rng = np.random.default_rng(5 + window)
+
+    def mk(n, ndesc):
+        kp = np.zeros(n, ob.KP_DTYPE)
+        kp["x"] = np.clip(rng.normal(320, 120, n), -5, 645).astype(np.float32)
+        kp["y"] = np.clip(rng.normal(240, 90, n), -5, 485).astype(np.float32)
+        kp["angle"] = rng.uniform(0, 360, n).astype(np.float32)
+        kp["octave"] = (rng.uniform(0, 1, n) < 0.3).astype(np.int32) * rng.integers(1, 4, n)
+        base = rng.integers(0, 256, (ndesc, 32), dtype=np.uint8)
+        d = base[rng.integers(0, ndesc, n)].copy()
+        d[np.arange(n), rng.integers(0, 32, n)] ^= (1 << rng.integers(0, 8, n)).astype(np.uint8)
+        d[np.arange(n), rng.integers(0, 32, n)] ^= (1 << rng.integers(0, 8, n)).astype(np.uint8)
+        return kp, d
+    b = (0.0, 0.0, 640.0, 480.0)
+    for trial in range(3):
+        (k1, d1), (k2, d2) = mk(300, 8), mk(320, 8)
+        d2[:] = d1[rng.integers(0, len(d1), len(d2))]
+        d2[np.arange(len(d2)), rng.integers(0, 32, len(d2))] ^= (1 << rng.integers(0, 8, len(d2))).astype(np.uint8)
+        prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32) + rng.normal(0, 10, (len(k1), 2)).astype(np.float32)
+        n, m12, pv = om.search_for_initialization(k1, d1, k2, d2, b, prev, window, ratio, check_ori)
+        # ---- the Python model
+        pop = np.array([bin(i).count("1") for i in range(256)], np.int32)
+        INT_MAX = 2 ** 31 - 1
+        vm12 = [-1] * len(k1); vm21 = [-1] * len(k2); vmd = [INT_MAX] * len(k2)
+        hist = [[] for _ in range(30)]
+        nm = 0
+        for i1 in range(len(k1)):
+            if k1["octave"][i1] > 0:
+                continue
+            idx = om.features_in_area(k2, b, float(prev[i1, 0]), float(prev[i1, 1]), float(window), 0, 0)
+            if len(idx) == 0:
+                continue
+            best = best2 = INT_MAX; bi = -1
+            for i2 in idx.tolist():
+                dist = int(pop[d1[i1] ^ d2[i2]].sum())
+                if vmd[i2] <= dist:
+                    continue
+                if dist < best:
+                    best2, best, bi = best, dist, i2
+                elif dist < best2:
+                    best2 = dist
+            if best <= 50 and np.float32(best) < np.float32(best2) * np.float32(ratio):
+                if vm21[bi] >= 0:
+                    vm12[vm21[bi]] = -1; nm -= 1
+                vm12[i1] = bi; vm21[bi] = i1; vmd[bi] = best; nm += 1
+                if check_ori:
+                    rot = np.float32(k1["angle"][i1]) - np.float32(k2["angle"][bi])
+                    if rot < 0:
+                        rot = np.float32(rot + np.float32(360.0))
+                    v = float(np.float32(rot * np.float32(1.0 / 30)))
+                    bn = int(np.floor(abs(v) + 0.5) * (1 if v >= 0 else -1))       # round(): half away from zero
+                    hist[0 if bn == 30 else bn].append(i1)
+        if check_ori:
+            m1 = m2 = m3 = 0; i1_ = i2_ = i3_ = -1
+            for i in range(30):
+                s = len(hist[i])
+                if s > m1: m3, m2, m1, i3_, i2_, i1_ = m2, m1, s, i2_, i1_, i
+                elif s > m2: m3, m2, i3_, i2_ = m2, s, i2_, i
+                elif s > m3: m3, i3_ = s, i
+            if m2 < np.float32(0.1) * np.float32(m1): i2_ = i3_ = -1
+            elif m3 < np.float32(0.1) * np.float32(m1): i3_ = -1
+            for i in range(30):
+                if i in (i1_, i2_, i3_):
+                    continue
+                for j in hist[i]:
+                    if vm12[j] >= 0:
+                        vm12[j] = -1; nm -= 1
+        pv_m = prev.copy()
+        for i1 in range(len(k1)):
+            if vm12[i1] >= 0:
+                pv_m[i1] = (k2["x"][vm12[i1]], k2["y"][vm12[i1]])
+        assert n == nm, (trial, n, nm)
+        np.testing.assert_array_equal(m12, np.array(vm12, np.int32))
+        assert pv.tobytes() == pv_m.tobytes()
+        assert nm > 20
