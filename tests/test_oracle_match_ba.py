@@ -1409,3 +1409,119 @@ def test_search_for_initialization_oracle_against_python(check_ori, window, rati
         np.testing.assert_array_equal(m12, np.array(vm12, np.int32))
         assert pv.tobytes() == pv_m.tobytes()
         assert nm > 20
+
+
+@pytest.mark.parametrize("stereo_frac,seed", [(0.0, 3), (0.5, 4), (1.0, 5)])
+def test_pose_optimization_oracle_against_an_independent_numpy_model(stereo_frac, seed):
+    """Optimizer::PoseOptimization (Optimizer.cc:854-1168) and the vendored Levenberg-Marquardt (optimization_algorithm_levenberg.cpp:61-194)
+    restated in numpy without any oracle code: NUMERIC Jacobians of the two unary edges (the stereo one with its float 1 / z,
+    types_six_dof_expmap.cpp:339-346), dense 6 x 6 solve by numpy, lambda = 1e-50 max diag per optimize() call, the rho / scale accept
+    rule with lambda *= max(1/3, min(1 - (2 rho - 1)^3, 2/3)) or *= ni, ni *= 2, Raul's three-bad-iterations stop, four rounds from the
+    SAME initial pose, inliers classified on the errors of the last EVALUATED estimate (a rejected trial's when the round ends on one),
+    outliers re-evaluated at the final one, float chi2 against float gates, no robust kernel after the third round.  Same inlier set,
+    pose to 1e-6."""
+    import synth_ba
+    prob = synth_ba.make_pose_problem(seed, n=160, stereo_frac=stereo_frac, outlier_frac=0.12)
+    Xw, obs, is2, cam, pose0 = prob["Xw"], prob["obs"], prob["inv_sigma2"], prob["cam"], prob["pose0"]
+    n_in, o_pose, o_out, o_st = obb.pose_optimization(Xw, obs, is2, cam, pose0)
+    fx, fy, cx, cy, bf = [float(c) for c in cam]
+    f32 = np.float32
+
+    def quat_to_R(q):
+        x, y, z, w = q / np.linalg.norm(q)
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+    def skew(v):
+        return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+
+    def se3_exp(d):
+        om, up = d[:3], d[3:]
+        th = np.linalg.norm(om); Om = skew(om)
+        if th < 1e-8:
+            return np.eye(3) + Om + 0.5 * Om @ Om, (np.eye(3) + 0.5 * Om + Om @ Om / 6) @ up
+        R = np.eye(3) + np.sin(th) / th * Om + (1 - np.cos(th)) / th ** 2 * Om @ Om
+        V = np.eye(3) + (1 - np.cos(th)) / th ** 2 * Om + (th - np.sin(th)) / th ** 3 * Om @ Om
+        return R, V @ up
+
+    stereo = obs[:, 2] >= 0
+    n = len(Xw)
+
+    def err(R, t, e, smooth=False):                            # smooth: for the difference quotients (the float rounding of 1 / z is not differentiable)
+        Xc = R @ Xw[e] + t
+        if not stereo[e]:
+            return np.array([obs[e, 0] - (fx * Xc[0] / Xc[2] + cx), obs[e, 1] - (fy * Xc[1] / Xc[2] + cy), 0.0])
+        invz = 1.0 / Xc[2] if smooth else float(f32(1.0 / Xc[2]))
+        u = Xc[0] * invz * fx + cx
+        return np.array([obs[e, 0] - u, obs[e, 1] - (Xc[1] * invz * fy + cy), obs[e, 2] - (u - bf * invz)])
+
+    dm, ds = float(f32(np.sqrt(5.991))), float(f32(np.sqrt(7.815)))
+    dm2, ds2 = float(f32(dm * dm)), float(f32(ds * ds))
+
+    def rho(c, e, robust):
+        if not robust:
+            return c, 1.0
+        d, d2 = (ds, ds2) if stereo[e] else (dm, dm2)
+        return (c, 1.0) if c <= d2 else (2 * np.sqrt(c) * d - d2, d / np.sqrt(c))
+
+    R_init, t_init = quat_to_R(np.asarray(pose0[:4], np.float64)), np.asarray(pose0[4:], np.float64).copy()
+    level = np.zeros(n, bool)                                   # True: outlier, not optimised
+    R, t = R_init, t_init
+    robust = True
+    for it in range(4):
+        R, t = R_init, t_init
+        act = np.flatnonzero(~level)
+        Re, te = R, t                                           # estimate the stored errors belong to
+        lam = ni = 0.0; nbad = 0
+        for k in range(10):
+            Re, te = R, t
+            E = {e: err(R, t, e) for e in act}
+            cur = sum(rho(float(E[e] @ E[e]) * is2[e], e, robust)[0] for e in act)
+            ini = cur
+            H = np.zeros((6, 6)); b = np.zeros(6)
+            for e in act:
+                J = np.zeros((3, 6)); h = 1e-6
+                for a in range(6):
+                    d = np.zeros(6); d[a] = h
+                    Rp, tp = se3_exp(d); Rm, tm = se3_exp(-d)
+                    J[:, a] = (err(Rp @ R, Rp @ t + tp, e, True) - err(Rm @ R, Rm @ t + tm, e, True)) / (2 * h)
+                w = rho(float(E[e] @ E[e]) * is2[e], e, robust)[1] * is2[e]
+                H += w * J.T @ J; b += -w * J.T @ E[e]
+            if k == 0:
+                lam = 1e-50 * np.max(np.abs(np.diag(H))); ni = 2.0; nbad = 0
+            q = 0
+            while True:
+                x = np.linalg.solve(H + lam * np.eye(6), b)
+                Rd, td = se3_exp(x)
+                Rt, tt = Rd @ R, Rd @ t + td
+                Re, te = Rt, tt
+                tmp = sum(rho(float(v @ v) * is2[e], e, robust)[0] for e, v in ((e, err(Rt, tt, e)) for e in act))
+                r_ = (cur - tmp) / (float(x @ (lam * x + b)) + 1e-3)
+                if r_ > 0 and np.isfinite(tmp):
+                    lam *= max(1 / 3, min(1 - (2 * r_ - 1) ** 3, 2 / 3)); ni = 2.0; cur = tmp; R, t = Rt, tt
+                else:
+                    lam *= ni; ni *= 2
+                q += 1
+                if not (r_ < 0 and q < 100):
+                    break
+            if q == 100 or r_ == 0:
+                break
+            nbad = nbad + 1 if (ini - cur) * 1e3 < ini else 0
+            if nbad >= 3:
+                break
+        nb = 0
+        for e in range(n):
+            v = err(R, t, e) if level[e] else err(Re, te, e)
+            c = f32(float(v @ v) * is2[e])
+            if c > (f32(7.815) if stereo[e] else f32(5.991)):
+                level[e] = True; nb += 1
+            else:
+                level[e] = False
+        if it == 2:
+            robust = False
+        if n < 10:
+            break
+    assert n_in == n - nb
+    np.testing.assert_array_equal(o_out.astype(bool), level)
+    assert np.max(np.abs(quat_to_R(o_pose[:4]) - R)) <= 1e-6 and np.max(np.abs(o_pose[4:] - t)) <= 1e-6
