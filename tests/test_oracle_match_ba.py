@@ -1226,16 +1226,13 @@ def test_search_for_triangulation_general_oracle_reduces_to_the_pinhole_form():
     assert om.search_for_triangulation_general(c, True)[0] == 0
 
 
-def test_ba_first_lm_iteration_against_an_independent_dense_numpy_model():
-    """Pins the oracle's normal equations, Schur elimination, LDL^T, update rule and lambda initialisation against a model that shares
-    no code with it: numpy only, NUMERIC Jacobians of the residual (central differences of the left-multiplied SE3 perturbation
-    [omega, upsilon], g2o's SE3Quat::exp order, and of the point), the DENSE (6 nf + 3 L)-dimensional system (H + lambda I) d = b
-    solved by numpy.linalg.solve -- no Schur complement --, Huber weights, lambda = 1e-50 * max diag(H)
-    (Thirdparty/g2o/g2o/core/optimization_algorithm_levenberg.cpp:47,171-185).  One optimize(1): the estimates after the step and
-    the robust chi2 must agree with the oracle to finite-difference accuracy."""
-    import synth_ba
-    import oracle_ba_bind as ob
-
+def _dense_numpy_ba_model(g, p, schedule):
+    """Optimizer::LocalBundleAdjustment's optimisation (Optimizer.cc:2046-2122: optimize(5), then optimize(10) on the unchanged graph) on
+    the vendored Levenberg-Marquardt (optimization_algorithm_levenberg.cpp:61-194), sharing no code with the oracle: numpy only, NUMERIC
+    Jacobians of the mono residual (central differences of the left-multiplied SE3 perturbation [omega, upsilon], g2o's SE3Quat::exp
+    order, and of the point), the DENSE (6 nf + 3 L) system solved by numpy.linalg.solve (no Schur complement), Huber weights with the
+    reference's float constants, lambda = 1e-50 max diag per optimize() call.  Returns (R, t, X, chi2 first / last, trials, per-edge
+    chi2 of the last evaluated estimate, per-edge depth at the final one)."""
     def quat_to_R(q):
         x, y, z, w = q / np.linalg.norm(q)
         return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
@@ -1250,82 +1247,140 @@ def test_ba_first_lm_iteration_against_an_independent_dense_numpy_model():
         th = np.linalg.norm(om)
         Om = skew(om)
         if th < 1e-8:
-            R = np.eye(3) + Om + 0.5 * Om @ Om
-            V = np.eye(3) + 0.5 * Om + Om @ Om / 6
-        else:
-            R = np.eye(3) + np.sin(th) / th * Om + (1 - np.cos(th)) / th ** 2 * Om @ Om
-            V = np.eye(3) + (1 - np.cos(th)) / th ** 2 * Om + (th - np.sin(th)) / th ** 3 * Om @ Om
+            return np.eye(3) + Om + 0.5 * Om @ Om, (np.eye(3) + 0.5 * Om + Om @ Om / 6) @ up
+        R = np.eye(3) + np.sin(th) / th * Om + (1 - np.cos(th)) / th ** 2 * Om @ Om
+        V = np.eye(3) + (1 - np.cos(th)) / th ** 2 * Om + (th - np.sin(th)) / th ** 3 * Om @ Om
         return R, V @ up
 
-    g = synth_ba.make_graph(n_kf=6, n_pts=40, obs=4, seed=321, n_fixed=2, outlier_frac=0.1)
-    p = ob.default_params()
-    p.iters1, p.iters2 = 1, 0
-    rc, o_poses, o_pts, _, o_st, _, _ = ob.solve_with_gate_values(g, p)
-    assert o_st["iterations_run"][0] == 1 and o_st["lm_trials"] == 1
     fx, fy, cx, cy = g["fx"], g["fy"], g["cx"], g["cy"]
-    R0 = [quat_to_R(q[:4]) for q in g["poses0"]]; t0 = [q[4:].copy() for q in g["poses0"]]
-    X0 = g["points0"].astype(np.float64).copy()
+    R = [quat_to_R(q[:4]) for q in g["poses0"]]; t = [q[4:].copy() for q in g["poses0"]]
+    X = g["points0"].astype(np.float64).copy()
     free = np.flatnonzero(np.asarray(g["pose_fixed"]) == 0)
     hidx = {int(k): i for i, k in enumerate(free)}
     nf, L, E = len(free), g["n_points"], g["n_edges"]
     assert np.all(np.asarray(g["edge_stereo"]) == 0)
     # thHuber = (float)sqrt(5.991) and delta^2 kept as a float (Optimizer.cc:1910-1911, robust_kernel_impl.h:84)
     delta = float(np.float32(np.sqrt(p.huber_mono2))); delta2 = float(np.float32(delta * delta))
+    ek = [int(v) for v in g["edge_pose"]]; el = [int(v) for v in g["edge_point"]]
+    ob2 = g["edge_obs"][:, :2].astype(np.float64); is2 = g["edge_inv_sigma2"].astype(np.float64)
 
     def residual(R, t, X, e):
-        k, l = int(g["edge_pose"][e]), int(g["edge_point"][e])
-        Pc = R[k] @ X[l] + t[k]
-        return g["edge_obs"][e, :2].astype(np.float64) - np.array([fx * Pc[0] / Pc[2] + cx, fy * Pc[1] / Pc[2] + cy])
+        Pc = R[ek[e]] @ X[el[e]] + t[ek[e]]
+        return ob2[e] - np.array([fx * Pc[0] / Pc[2] + cx, fy * Pc[1] / Pc[2] + cy])
 
-    def robust_chi2(R, t, X):
-        tot = 0.0
-        for e in range(E):
-            r = residual(R, t, X, e)
-            c = float(r @ r) * float(g["edge_inv_sigma2"][e])
-            tot += c if c <= delta2 else 2 * np.sqrt(c) * delta - delta2
-        return tot
+    def chis(R, t, X):
+        return np.array([float(r @ r) for r in (residual(R, t, X, e) for e in range(E))]) * is2
+
+    def robust(c):
+        return float(np.sum(np.where(c <= delta2, c, 2 * np.sqrt(c) * delta - delta2)))
 
     n = 6 * nf + 3 * L
-    H = np.zeros((n, n)); b = np.zeros(n)
     h = 1e-6
-    for e in range(E):
-        k, l = int(g["edge_pose"][e]), int(g["edge_point"][e])
-        r = residual(R0, t0, X0, e)
-        is2 = float(g["edge_inv_sigma2"][e])
-        c = float(r @ r) * is2
-        w = is2 * (1.0 if c <= delta2 else delta / np.sqrt(c))
-        cols, J = [], []
-        if k in hidx:
-            Jp = np.zeros((2, 6))
-            for a in range(6):
-                d = np.zeros(6); d[a] = h
-                Rp, tp = se3_exp(d); Rm, tm = se3_exp(-d)
-                Ra = list(R0); ta = list(t0); Ra[k] = Rp @ R0[k]; ta[k] = Rp @ t0[k] + tp
-                Rb = list(R0); tb = list(t0); Rb[k] = Rm @ R0[k]; tb[k] = Rm @ t0[k] + tm
-                Jp[:, a] = (residual(Ra, ta, X0, e) - residual(Rb, tb, X0, e)) / (2 * h)
-            cols += list(range(6 * hidx[k], 6 * hidx[k] + 6)); J.append(Jp)
-        Jx = np.zeros((2, 3))
-        for a in range(3):
-            Xa = X0.copy(); Xa[l, a] += h; Xb = X0.copy(); Xb[l, a] -= h
-            Jx[:, a] = (residual(R0, t0, Xa, e) - residual(R0, t0, Xb, e)) / (2 * h)
-        cols += list(range(6 * nf + 3 * l, 6 * nf + 3 * l + 3)); J.append(Jx)
-        Je = np.hstack(J)
-        H[np.ix_(cols, cols)] += w * Je.T @ Je
-        b[cols] += -w * Je.T @ r
-    lam = 1e-50 * np.max(np.abs(np.diag(H)))
-    d = np.linalg.solve(H + lam * np.eye(n), b)
-    R1 = list(R0); t1 = list(t0)
-    for k, i in hidx.items():
-        Rd, td = se3_exp(d[6 * i:6 * i + 6])
-        R1[k] = Rd @ R0[k]; t1[k] = Rd @ t0[k] + td
-    X1 = X0 + d[6 * nf:].reshape(L, 3)
-    chi0, chi1 = robust_chi2(R0, t0, X0), robust_chi2(R1, t1, X1)
+    trials = 0
+    chi_first = chi_last = None
+    c_eval = None
+    for iters in schedule:
+        lam = ni = 0.0; nbad = 0
+        for it in range(iters):
+            c_eval = chis(R, t, X)
+            cur = robust(c_eval); ini = cur
+            if chi_first is None:
+                chi_first = cur
+            H = np.zeros((n, n)); b = np.zeros(n)
+            for e in range(E):
+                k, l = ek[e], el[e]
+                r = residual(R, t, X, e)
+                w = is2[e] * (1.0 if c_eval[e] <= delta2 else delta / np.sqrt(c_eval[e]))
+                cols, J = [], []
+                if k in hidx:
+                    Jp = np.zeros((2, 6))
+                    for a in range(6):
+                        d = np.zeros(6); d[a] = h
+                        Rp, tp = se3_exp(d); Rm, tm = se3_exp(-d)
+                        Ra = list(R); ta = list(t); Ra[k] = Rp @ R[k]; ta[k] = Rp @ t[k] + tp
+                        Rb = list(R); tb = list(t); Rb[k] = Rm @ R[k]; tb[k] = Rm @ t[k] + tm
+                        Jp[:, a] = (residual(Ra, ta, X, e) - residual(Rb, tb, X, e)) / (2 * h)
+                    cols += list(range(6 * hidx[k], 6 * hidx[k] + 6)); J.append(Jp)
+                Jx = np.zeros((2, 3))
+                for a in range(3):
+                    Xa = X.copy(); Xa[l, a] += h; Xb = X.copy(); Xb[l, a] -= h
+                    Jx[:, a] = (residual(R, t, Xa, e) - residual(R, t, Xb, e)) / (2 * h)
+                cols += list(range(6 * nf + 3 * l, 6 * nf + 3 * l + 3)); J.append(Jx)
+                Je = np.hstack(J)
+                H[np.ix_(cols, cols)] += w * Je.T @ Je
+                b[cols] += -w * Je.T @ r
+            if it == 0:
+                lam = 1e-50 * np.max(np.abs(np.diag(H))); ni = 2.0; nbad = 0
+            q = 0
+            while True:
+                d = np.linalg.solve(H + lam * np.eye(n), b)
+                Rt = list(R); tt = list(t)
+                for k, i in hidx.items():
+                    Rd, td = se3_exp(d[6 * i:6 * i + 6])
+                    Rt[k] = Rd @ R[k]; tt[k] = Rd @ t[k] + td
+                Xt = X + d[6 * nf:].reshape(L, 3)
+                c_eval = chis(Rt, tt, Xt)
+                tmp = robust(c_eval)
+                rho = (cur - tmp) / (float(d @ (lam * d + b)) + 1e-3)
+                if rho > 0 and np.isfinite(tmp):
+                    lam *= max(1 / 3, min(1 - (2 * rho - 1) ** 3, 2 / 3)); ni = 2.0; cur = tmp; R, t, X = Rt, tt, Xt
+                else:
+                    lam *= ni; ni *= 2
+                q += 1; trials += 1
+                if not (rho < 0 and q < p.max_trials):
+                    break
+            chi_last = cur
+            if q == p.max_trials or rho == 0:
+                break
+            nbad = nbad + 1 if (ini - cur) * 1e3 < ini else 0
+            if nbad >= 3:
+                break
+    depth = np.array([(R[ek[e]] @ X[el[e]] + t[ek[e]])[2] for e in range(E)])
+    return R, t, X, chi_first, chi_last, trials, c_eval, depth, quat_to_R
+
+
+def test_ba_first_lm_iteration_against_an_independent_dense_numpy_model():
+    """One optimize(1): pins the oracle's normal equations, Schur elimination, LDL^T, update rule and lambda initialisation
+    (Thirdparty/g2o/g2o/core/optimization_algorithm_levenberg.cpp:47,171-185) against the dense model above: estimates after the step
+    and the robust chi2 agree to finite-difference accuracy."""
+    import synth_ba
+    import oracle_ba_bind as ob
+    g = synth_ba.make_graph(n_kf=6, n_pts=40, obs=4, seed=321, n_fixed=2, outlier_frac=0.1)
+    p = ob.default_params()
+    p.iters1, p.iters2 = 1, 0
+    rc, o_poses, o_pts, _, o_st, _, _ = ob.solve_with_gate_values(g, p)
+    assert o_st["iterations_run"][0] == 1 and o_st["lm_trials"] == 1
+    R1, t1, X1, chi0, chi1, trials, _, _, quat_to_R = _dense_numpy_ba_model(g, p, [1])
+    assert trials == 1
     assert abs(chi0 - o_st["chi2_initial"]) <= 1e-9 * chi0
     assert chi1 < chi0                                                    # the step is accepted on both sides (one trial)
     assert abs(chi1 - o_st["chi2_final"]) <= 1e-5 * chi1, (chi1, o_st["chi2_final"])
     for k in range(g["n_poses"]):
         assert np.max(np.abs(quat_to_R(o_poses[k, :4]) - R1[k])) <= 1e-6 and np.max(np.abs(o_poses[k, 4:] - t1[k])) <= 1e-6, k
     assert np.max(np.abs(o_pts - X1)) <= 1e-5
+
+
+@pytest.mark.parametrize("seed", [322, 323])
+def test_ba_whole_schedule_against_an_independent_dense_numpy_model(seed):
+    """The whole LocalBundleAdjustment optimisation -- optimize(5) + optimize(10), lambda re-initialised by the second call, the accept
+    rule, the lambda schedule and the three-bad-iterations stop of the vendored LM -- on the dense model: same number of LM trials,
+    estimates to 1e-5, the same outlier set (chi2 of the last evaluated estimate > 5.991 or depth <= 0, Optimizer.cc:2126-2173) for
+    every edge whose chi2 is not within 1e-4 of the gate."""
+    import synth_ba
+    import oracle_ba_bind as ob
+    g = synth_ba.make_graph(n_kf=6, n_pts=40, obs=4, seed=seed, n_fixed=2, outlier_frac=0.1)
+    p = ob.default_params()
+    rc, o_poses, o_pts, o_out, o_st, o_chi2, o_depth = ob.solve_with_gate_values(g, p)
+    R1, t1, X1, chi0, chi1, trials, c_eval, depth, quat_to_R = _dense_numpy_ba_model(g, p, [p.iters1, p.iters2])
+    assert trials == o_st["lm_trials"], (trials, o_st)
+    assert abs(chi1 - o_st["chi2_final"]) <= 1e-5 * chi1, (chi1, o_st["chi2_final"])
+    for k in range(g["n_poses"]):
+        assert np.max(np.abs(quat_to_R(o_poses[k, :4]) - R1[k])) <= 1e-5 and np.max(np.abs(o_poses[k, 4:] - t1[k])) <= 1e-5, k
+    assert np.max(np.abs(o_pts - X1)) <= 1e-4
+    clear = np.abs(c_eval - p.huber_mono2) > 1e-4
+    out_m = (c_eval > p.huber_mono2) | ~(depth > 0)
+    np.testing.assert_array_equal(o_out.astype(bool)[clear], out_m[clear])
+    assert clear.mean() > 0.95 and 3 <= int(out_m.sum()) < g["n_edges"] // 2
 
 
 @pytest.mark.parametrize("check_ori,window,ratio", [(True, 100, 0.9), (False, 60, 0.8), (True, 300, 0.95)])
