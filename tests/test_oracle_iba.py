@@ -183,8 +183,9 @@ def test_initial_robust_chi2_against_an_independent_numpy_restatement(kw):
         f0, f1, c0, c1 = cam
         if model == 0:
             return np.array([f0 * Xc[0] / Xc[2] + c0, f1 * Xc[1] / Xc[2] + c1])
-        x2y2 = Xc[0] ** 2 + Xc[1] ** 2                                       # KannalaBrandt8.cpp:52-69
-        th = np.arctan2(np.sqrt(x2y2), Xc[2]); psi = np.arctan2(Xc[1], Xc[0])
+        x2y2 = Xc[0] ** 2 + Xc[1] ** 2                                       # KannalaBrandt8.cpp:52-69: atan2f / sqrtf, i.e. float angles
+        th = float(np.float32(np.arctan2(float(np.sqrt(np.float32(x2y2))), float(np.float32(Xc[2])))))
+        psi = float(np.float32(np.arctan2(float(np.float32(Xc[1])), float(np.float32(Xc[0])))))
         r = th + kb[0] * th ** 3 + kb[1] * th ** 5 + kb[2] * th ** 7 + kb[3] * th ** 9
         return np.array([f0 * r * np.cos(psi) + c0, f1 * r * np.sin(psi) + c1])
 
@@ -248,3 +249,197 @@ def test_initial_robust_chi2_against_an_independent_numpy_restatement(kw):
         eg, ea = bg2 - bg1, ba2 - ba1
         total += float(eg @ a["in_info_g"][m].reshape(3, 3) @ eg) + float(ea @ a["in_info_a"][m].reshape(3, 3) @ ea)
     assert abs(total - st.err) <= 1e-9 * abs(st.err), (total, st.err)
+
+
+def _numpy_inertial_lm_model(win, iterations, lambda_init, max_trials=100):
+    """Optimizer::LocalInertialBA's optimisation on the vendored Levenberg-Marquardt, numpy only, no oracle code: residuals as in the test
+    above, NUMERIC Jacobians through the vertex updates of the reference (ImuCamPose::Update: twb += Rwb ut, Rwb = Rwb ExpSO3(ur),
+    G2oTypes.cc:192-222, ExpSO3 with its nearest-rotation clean-up :986-1008; velocity / biases / points additive), the DENSE system over
+    every free vertex solved by numpy.linalg.solve (no Schur complement), robustInformation = rho' Omega (base_edge.h:96-102).
+    Returns (kf states, points, err, err_end, trials, per-edge visual chi2 of the last evaluated estimate)."""
+    a, d = win.arrays, win.d
+    Rcb, tcb = win.Rcb.reshape(3, 3), win.tcb
+    fx, fy, cx, cy, bf = [float(x) for x in win.cam]
+    model, kb = int(d.get("camera_model", 0)), d.get("kb", (0, 0, 0, 0))
+    Trl = cam2 = kb2 = None; model2 = 0
+    if "Trl" in d:
+        Trl = np.asarray(d["Trl"], np.float64).reshape(3, 4); cam2 = [float(x) for x in d["cam2"]]
+        model2 = int(d.get("camera2_model", 0)); kb2 = d.get("kb2", (0, 0, 0, 0))
+
+    smooth = [False]                                                         # difference quotients are taken on the un-rounded angles
+
+    def project(Xc, cam, mdl, kk):
+        f0, f1, c0, c1 = cam
+        if mdl == 0:
+            return np.array([f0 * Xc[0] / Xc[2] + c0, f1 * Xc[1] / Xc[2] + c1])
+        if smooth[0]:
+            th = np.arctan2(np.sqrt(Xc[0] ** 2 + Xc[1] ** 2), Xc[2]); psi = np.arctan2(Xc[1], Xc[0])
+        else:                                                                # KannalaBrandt8.cpp:52-69: atan2f / sqrtf
+            th = float(np.float32(np.arctan2(float(np.sqrt(np.float32(Xc[0] ** 2 + Xc[1] ** 2))), float(np.float32(Xc[2])))))
+            psi = float(np.float32(np.arctan2(float(np.float32(Xc[1])), float(np.float32(Xc[0])))))
+        r = th + kk[0] * th ** 3 + kk[1] * th ** 5 + kk[2] * th ** 7 + kk[3] * th ** 9
+        return np.array([f0 * r * np.cos(psi) + c0, f1 * r * np.sin(psi) + c1])
+
+    def skew(v):
+        return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+
+    def nearest_rot(M):
+        U, _, Vt = np.linalg.svd(M)
+        return U @ Vt
+
+    def exp_imu(v):                                                          # ImuTypes.cc:48-60
+        th2 = float(v @ v); th = np.sqrt(th2); W = skew(v)
+        return np.eye(3) + W + 0.5 * W @ W if th < 1e-4 else np.eye(3) + W * np.sin(th) / th + W @ W * (1 - np.cos(th)) / th2
+
+    def exp_g2o(v):                                                          # G2oTypes.cc:991-1008
+        th2 = float(v @ v); th = np.sqrt(th2); W = skew(v)
+        return nearest_rot(np.eye(3) + W + 0.5 * W @ W if th < 1e-5 else np.eye(3) + W * np.sin(th) / th + W @ W * (1 - np.cos(th)) / th2)
+
+    def log_so3(R):
+        w = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]) / 2
+        c = (np.trace(R) - 1) * 0.5
+        if c > 1 or c < -1:
+            return w
+        th = np.arccos(c); s = np.sin(th)
+        return w if abs(s) < 1e-5 else th * w / s
+
+    nk, L = win.n_kf, win.n_points
+    S = {"R": [win.kf0[k, :9].reshape(3, 3).copy() for k in range(nk)], "t": [win.kf0[k, 9:12].copy() for k in range(nk)],
+         "v": [win.kf0[k, 12:15].copy() for k in range(nk)], "g": [win.kf0[k, 15:18].copy() for k in range(nk)],
+         "a": [win.kf0[k, 18:21].copy() for k in range(nk)], "X": [win.pts0[l].copy() for l in range(L)]}
+    # free vertices and their local dimensions
+    verts = []
+    for k in range(nk):
+        if not a["kf_fixed"][k]:
+            verts.append(("P", k, 6))
+            if a["kf_imu"][k]:
+                verts += [("v", k, 3), ("g", k, 3), ("a", k, 3)]
+    verts += [("X", l, 3) for l in range(L)]
+    off = {}; n = 0
+    for (ty, i, dim) in verts:
+        off[(ty, i)] = n; n += dim
+
+    def apply(S0, ty, i, dx):
+        S1 = {key: list(val) for key, val in S0.items()}
+        if ty == "P":
+            S1["t"][i] = S0["t"][i] + S0["R"][i] @ dx[3:]
+            S1["R"][i] = S0["R"][i] @ exp_g2o(dx[:3])
+        else:
+            S1[ty][i] = S0[ty][i] + dx
+        return S1
+
+    g_ = np.array([0.0, 0.0, -float(np.float32(9.81))])
+    th_m, th_s = float(np.float32(np.sqrt(5.991))), float(np.float32(np.sqrt(7.815)))
+    edges = []                                                               # (residual fn, Omega, delta or None, vertex keys)
+    for e in range(win.n_edges):
+        k, l, typ, obs, w = int(a["edge_kf"][e]), int(a["edge_point"][e]), int(a["edge_stereo"][e]), a["edge_obs"][e], float(a["edge_inv_sigma2"][e])
+
+        def rv(S_, k=k, l=l, typ=typ, obs=obs):
+            Rwb, twb = S_["R"][k], S_["t"][k]
+            Xc = Rcb @ (Rwb.T @ (S_["X"][l] - twb)) + tcb
+            if typ == 2:
+                return obs[:2] - project(Trl[:, :3] @ Xc + Trl[:, 3], cam2, model2, kb2)
+            uv = project(Xc, (fx, fy, cx, cy), model, kb)
+            return obs[:2] - uv if typ == 0 else obs - np.array([uv[0], uv[1], uv[0] - bf / Xc[2]])
+        m = 3 if typ == 1 else 2
+        edges.append((rv, w * np.eye(m), th_s if typ == 1 else th_m, [("P", k), ("X", l)]))
+    n_vis = len(edges)
+    for m in range(win.n_inertial):
+        k1, k2, p = int(a["in_kf1"][m]), int(a["in_kf2"][m]), a["in_preint"][m]
+
+        def ri(S_, k1=k1, k2=k2, p=p):
+            dt, dR, dV, dP = p[0], p[1:10].reshape(3, 3), p[10:13], p[13:16]
+            JRg, JVg, JVa, JPg, JPa = [p[16 + 9 * i:25 + 9 * i].reshape(3, 3) for i in range(5)]
+            dbg, dba = S_["g"][k1] - p[61:64], S_["a"][k1] - p[64:67]
+            R1 = S_["R"][k1]
+            er = log_so3(nearest_rot(dR @ exp_imu(JRg @ dbg)).T @ R1.T @ S_["R"][k2])
+            ev = R1.T @ (S_["v"][k2] - S_["v"][k1] - g_ * dt) - (dV + JVg @ dbg + JVa @ dba)
+            ep = R1.T @ (S_["t"][k2] - S_["t"][k1] - S_["v"][k1] * dt - g_ * dt * dt / 2) - (dP + JPg @ dbg + JPa @ dba)
+            return np.concatenate([er, ev, ep])
+        edges.append((ri, a["in_info"][m].reshape(9, 9), np.sqrt(16.92) if a["in_robust"][m] else None,
+                      [("P", k1), ("v", k1), ("g", k1), ("a", k1), ("P", k2), ("v", k2)]))
+        edges.append((lambda S_, k1=k1, k2=k2: S_["g"][k2] - S_["g"][k1], a["in_info_g"][m].reshape(3, 3), None, [("g", k1), ("g", k2)]))
+        edges.append((lambda S_, k1=k1, k2=k2: S_["a"][k2] - S_["a"][k1], a["in_info_a"][m].reshape(3, 3), None, [("a", k1), ("a", k2)]))
+
+    def rho(c, delta):
+        if delta is None:
+            return c, 1.0
+        d2 = float(np.float32(delta * delta))
+        return (c, 1.0) if c <= d2 else (2 * np.sqrt(c) * delta - d2, delta / np.sqrt(c))
+
+    def evaluate(S_):
+        rs = [f(S_) for (f, _, _, _) in edges]
+        cs = [float(r @ Om @ r) for r, (_, Om, _, _) in zip(rs, edges)]
+        return rs, cs, sum(rho(c, dl)[0] for c, (_, _, dl, _) in zip(cs, edges))
+
+    dims = {(ty, i): dim for (ty, i, dim) in verts}
+    h = 1e-6
+    rs, cs, cur = evaluate(S)
+    err0 = cur
+    lam = lambda_init; ni = 2.0; nbad = 0; trials = 0
+    cs_eval = cs
+    for it in range(iterations):
+        rs, cs, cur = evaluate(S); cs_eval = cs
+        ini = cur
+        H = np.zeros((n, n)); b = np.zeros(n)
+        for (f, Om, dl, keys), r, c in zip(edges, rs, cs):
+            cols, J = [], []
+            for key in keys:
+                if key not in off:
+                    continue
+                dim = dims[key]; Jk = np.zeros((len(r), dim))
+                smooth[0] = True
+                for q in range(dim):
+                    dx = np.zeros(dim); dx[q] = h
+                    Jk[:, q] = (f(apply(S, key[0], key[1], dx)) - f(apply(S, key[0], key[1], -dx))) / (2 * h)
+                smooth[0] = False
+                cols += list(range(off[key], off[key] + dim)); J.append(Jk)
+            if not cols:
+                continue
+            Je = np.hstack(J); W = rho(c, dl)[1] * Om
+            H[np.ix_(cols, cols)] += Je.T @ W @ Je
+            b[cols] += -Je.T @ W @ r
+        q_ = 0
+        while True:
+            dxs = np.linalg.solve(H + lam * np.eye(n), b)
+            St = S
+            for (ty, i, dim) in verts:
+                St = apply(St, ty, i, dxs[off[(ty, i)]:off[(ty, i)] + dim])
+            rs_t, cs_t, tmp = evaluate(St); cs_eval = cs_t
+            r_ = (cur - tmp) / (float(dxs @ (lam * dxs + b)) + 1e-3)
+            if r_ > 0 and np.isfinite(tmp):
+                lam *= max(1 / 3, min(1 - (2 * r_ - 1) ** 3, 2 / 3)); ni = 2.0; cur = tmp; S = St
+            else:
+                lam *= ni; ni *= 2
+            q_ += 1; trials += 1
+            if not (r_ < 0 and q_ < max_trials):
+                break
+        if q_ == max_trials or r_ == 0:
+            break
+        nbad = nbad + 1 if (ini - cur) * 1e3 < ini else 0
+        if nbad >= 3:
+            break
+    err_end = sum(rho(c, dl)[0] for c, (_, _, dl, _) in zip(cs_eval, edges))
+    kf = np.stack([np.concatenate([S["R"][k].reshape(-1), S["t"][k], S["v"][k], S["g"][k], S["a"][k]]) for k in range(nk)])
+    return kf, np.stack(S["X"]), err0, err_end, trials, np.array(cs_eval[:n_vis]), it + 1
+
+
+@pytest.mark.parametrize("kw", [dict(n_opt=3, n_fixed_vis=2, n_points=30, stereo_frac=0.5), dict(n_opt=3, n_fixed_vis=2, n_points=24, fisheye_rig=True)])
+def test_whole_inertial_lm_against_an_independent_numpy_model(kw):
+    """The whole optimize(10) of a small LocalInertialBA window against the dense numpy model: the same LM trials and iterations, keyframe
+    states and points to 1e-5 (rotations, positions, velocities, biases), err / err_end, and the visual outlier flags
+    (Optimizer.cc:5058-5090, chi2 of the last evaluated estimate) for every edge not within 1e-4 of its gate."""
+    win = ib.make_window(91, **kw)
+    kf_o, pts_o, out_o, st = ib.solve(win)
+    kf_m, pts_m, err0, err_end, trials, cs_vis, its = _numpy_inertial_lm_model(win, 10, 1.0)
+    assert st.failed == 0
+    assert abs(err0 - st.err) <= 1e-9 * st.err
+    assert (its, trials) == (st.iterations_run, st.lm_trials), (its, trials, st.iterations_run, st.lm_trials)
+    assert abs(err_end - st.err_end) <= 1e-5 * st.err_end, (err_end, st.err_end)
+    assert np.max(np.abs(kf_m - kf_o.reshape(-1, 21))) <= 1e-5 and np.max(np.abs(pts_m - pts_o.reshape(-1, 3))) <= 1e-4
+    typ = win.arrays["edge_stereo"]; close = win.arrays["edge_close"].astype(bool)
+    gate = np.where(typ == 1, 7.815, np.where(close, 1.5 * 5.991, 5.991))
+    clear = np.abs(cs_vis - gate) > 1e-4
+    np.testing.assert_array_equal(out_o.astype(bool)[clear & (typ == 1)], (cs_vis > gate)[clear & (typ == 1)])
+    mono = clear & (typ != 1)
+    assert (out_o.astype(bool)[mono] >= (cs_vis > gate)[mono]).all()            # (a mono edge is also erased when its depth is not positive)
