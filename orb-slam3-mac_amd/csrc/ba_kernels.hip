@@ -2348,7 +2348,12 @@ __device__ __forceinline__ void po_block_sum(double (&v)[N], double (*red)[PO_NR
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < N; k++) v[k] = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+    for (int k = 0; k < N; k++) {                       // the waves' sums in wave order (a fixed association per NT)
+        double s = red[0][k];
+#pragma unroll
+        for (int w = 1; w < NT / 64; w++) s += red[w][k];
+        v[k] = s;
+    }
 }
 
 // computeError of the two unary edges; returns chi2 = e^T (inv_sigma2 I) e
