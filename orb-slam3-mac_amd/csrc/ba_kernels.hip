@@ -2330,6 +2330,7 @@ struct PoArgs {
     double *pose;
     uint8_t *outlier;
     int32_t *n_inliers, *stats;
+    int stage_cap;                      // edges per frame the four-wave kernel stages in LDS (0: none)
 };
 
 template <int N, int NT = 256>
@@ -2397,7 +2398,7 @@ __device__ __forceinline__ double po_edge_chi2(const PoArgs &A, const BaGraphDev
 // times per frame: build + trial per iteration, 4 x 10 iterations; every walk was a round of dependent global loads), all sums
 // are wave-level DPP trees (no LDS, no barrier), and 1024 frames are one wave per SIMD instead of two rounds of 4-wave workgroups.
 template <bool GENERAL, int NT, int KR>
-__device__ __forceinline__ void po_body(const PoArgs &A, double (*red)[PO_NRED])
+__device__ __forceinline__ void po_body(const PoArgs &A, double (*red)[PO_NRED], double *stage = nullptr, int stage_cap = 0)
 {
     const int f = blockIdx.x, tid = threadIdx.x;
     const int n = A.n[f];
@@ -2430,12 +2431,24 @@ __device__ __forceinline__ void po_body(const PoArgs &A, double (*red)[PO_NRED])
         rO[k][0] = obs[3 * e]; rO[k][1] = obs[3 * e + 1]; rO[k][2] = obs[3 * e + 2];
         rW[k] = is2[e]; rR[k] = (GENERAL && right) ? right[e] : 0;
     }
+    // the multi-wave form keeps the first stage_cap edges in LDS (7 doubles each): the ~80 walks over the edges of a frame are then LDS
+    // reads instead of rounds of dependent L2 reads -- what a single frame's latency is made of
+    const int n_staged = stage ? min(n, stage_cap) : 0;
+    if (stage) {
+        for (int e = tid; e < n_staged; e += NT) {
+            double *q = stage + 7 * e;
+            q[0] = Xw[3 * e]; q[1] = Xw[3 * e + 1]; q[2] = Xw[3 * e + 2]; q[3] = obs[3 * e]; q[4] = obs[3 * e + 1]; q[5] = obs[3 * e + 2]; q[6] = is2[e];
+        }
+        __syncthreads();
+    }
     // body(k, e, X, ob, w0, rt) for every edge of this thread
     auto for_edges = [&](auto body) {
 #pragma unroll
         for (int k = 0; k < KR; k++) { const int e = tid + NT * k; if (e < n) body(k, e, rX[k], rO[k], rW[k], rR[k]); }
-        for (int e = tid + NT * KR, k = KR; e < n; e += NT, k++)
-            body(k, e, Xw + 3 * e, obs + 3 * e, is2[e], (GENERAL && right) ? (int)right[e] : 0);
+        for (int e = tid + NT * KR, k = KR; e < n; e += NT, k++) {
+            if (e < n_staged) body(k, e, stage + 7 * e, stage + 7 * e + 3, stage[7 * e + 6], (GENERAL && right) ? (int)right[e] : 0);
+            else body(k, e, Xw + 3 * e, obs + 3 * e, is2[e], (GENERAL && right) ? (int)right[e] : 0);
+        }
     };
     int robust = 1, nbad = 0, lm_trials = 0, lm_iters = 0, rounds = 0;
     for (int it = 0; it < 4; it++) {
@@ -2621,7 +2634,8 @@ template <bool GENERAL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pose_opt(PoArgs A)
 {
     __shared__ double red[4][PO_NRED];
-    po_body<GENERAL, 256, 0>(A, red);
+    extern __shared__ double po_stage[];                         // [stage_cap][7] (dynamic: 0 when the launch is a big batch)
+    po_body<GENERAL, 256, 0>(A, red, A.stage_cap > 0 ? po_stage : nullptr, A.stage_cap);
 }
 template <bool GENERAL>
 __global__ __launch_bounds__(64) void k_pose_opt_wave(PoArgs A)
@@ -2647,7 +2661,7 @@ extern "C" int orbhip_pose_optimization_device(orbhip_ctx *ctx, const double *d_
     for (int k = 0; k < 7; k++) A.Trl[k] = cam2 ? cam2->Trl[k] : (k == 3 ? 1.0 : 0.0);
     A.fx2 = cam2 ? cam2->fx : 0; A.fy2 = cam2 ? cam2->fy : 0; A.cx2 = cam2 ? cam2->cx : 0; A.cy2 = cam2 ? cam2->cy : 0;
     A.cam2_model = cam2 ? cam2->camera_model : 0; for (int k = 0; k < 4; k++) A.kb2[k] = cam2 ? cam2->kb[k] : 0.0;
-    A.stats = d_stats;
+    A.stats = d_stats; A.stage_cap = 0;
     const bool general = A.cam_model || A.right;
     // one wave per frame is the throughput form (1024 frames: 1.26 ms vs 2.0 ms); four waves per frame have the shorter latency while
     // the frames fit one round of workgroups (1 frame: 0.36 ms vs 0.71 ms, 64 frames: 0.64 vs 1.12 ms)
@@ -2656,8 +2670,14 @@ extern "C" int orbhip_pose_optimization_device(orbhip_ctx *ctx, const double *d_
         if (general) hipLaunchKernelGGL(k_pose_opt_wave<true>, dim3(frames), dim3(64), 0, orbhip_ctx_stream_internal(ctx), A);
         else hipLaunchKernelGGL(k_pose_opt_wave<false>, dim3(frames), dim3(64), 0, orbhip_ctx_stream_internal(ctx), A);
     } else {
-        if (general) hipLaunchKernelGGL(k_pose_opt<true>, dim3(frames), dim3(PO_THREADS), 0, orbhip_ctx_stream_internal(ctx), A);
-        else hipLaunchKernelGGL(k_pose_opt<false>, dim3(frames), dim3(PO_THREADS), 0, orbhip_ctx_stream_internal(ctx), A);
+        // up to one workgroup per CU the edges are staged in LDS (latency form); bigger launches keep the LDS-free one (occupancy)
+        static const int stage_env = getenv("ORBHIP_POSE_STAGE_EDGES") ? atoi(getenv("ORBHIP_POSE_STAGE_EDGES")) : 2048;
+        A.stage_cap = frames <= 256 ? std::min(max_edges, stage_env) : 0;
+        const size_t lds = (size_t)A.stage_cap * 7 * sizeof(double);
+        const void *fn = general ? reinterpret_cast<const void *>(k_pose_opt<true>) : reinterpret_cast<const void *>(k_pose_opt<false>);
+        if (lds > 0 && orb_lds_optin(fn, orbhip_ctx_device_internal(ctx), lds)) { g_ba_error = "LDS opt-in (k_pose_opt)"; return ORBHIP_E_HIP; }
+        if (general) hipLaunchKernelGGL(k_pose_opt<true>, dim3(frames), dim3(PO_THREADS), lds, orbhip_ctx_stream_internal(ctx), A);
+        else hipLaunchKernelGGL(k_pose_opt<false>, dim3(frames), dim3(PO_THREADS), lds, orbhip_ctx_stream_internal(ctx), A);
     }
     return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
 }
