@@ -31,8 +31,10 @@
 #include <functional>
 #include <mutex>
 #include <fcntl.h>
+#include <errno.h>
 #include <unistd.h>
 #include <sys/file.h>
+#include <sys/stat.h>
 
 hipStream_t orbhip_ctx_stream_internal(orbhip_ctx *c);
 int orbhip_ctx_device_internal(orbhip_ctx *c);
@@ -992,9 +994,20 @@ struct IbaTeamLock {
         if (!mu(dev).try_lock()) return false;
         char path[64];
         snprintf(path, sizeof(path), "/tmp/.orbhip_team_gpu%d.lock", dev);
-        fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
-        if (fd >= 0 && flock(fd, LOCK_EX | LOCK_NB) != 0) { close(fd); fd = -1; mu(dev).unlock(); return false; }
-        device = dev; held = true;                              // (no lock file, e.g. read-only /tmp: the in-process lock alone)
+        // flock works on a read-only descriptor, so processes of OTHER users can take part whatever the creator's umask left of the
+        // mode (fchmod by the creator widens it to 0666 anyway); O_NOFOLLOW: the name is predictable in a world-writable directory.
+        fd = open(path, O_RDONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0666);
+        if (fd >= 0) (void)fchmod(fd, 0666);
+        else if (errno == EEXIST) fd = open(path, O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+        if (fd < 0) {
+            // only a file system that cannot hold the file at all leaves the in-process mutex as the whole lock; anything else
+            // (EACCES, ELOOP: somebody else's file / a symlink planted there) means "lock not acquired": the caller runs G = 1
+            if (errno == EROFS || errno == ENOENT) { device = dev; held = true; return true; }
+            mu(dev).unlock();
+            return false;
+        }
+        if (flock(fd, LOCK_EX | LOCK_NB) != 0) { close(fd); fd = -1; mu(dev).unlock(); return false; }
+        device = dev; held = true;
         return true;
     }
     ~IbaTeamLock()
@@ -1379,15 +1392,12 @@ static int iba_solve_impl(orbhip_iba_batch *b, const orbhip_iba_params *params)
         hipLaunchKernelGGL(k_iba_solve, dim3(n_windows), dim3(IBA_THREADS), lds, s, A);
         ITRY(hipGetLastError());
     } else {
-        // the grid (8 * G * win_per_xcd <= CUs x workgroups per CU from the occupancy query above) is resident as a whole; a plain launch
-        // has the same residency as a cooperative one (MI355X_MICROARCH.md), ORBHIP_IBA_COOP=1 adds the runtime's own size check
-        if (getenv("ORBHIP_IBA_COOP")) {
-            void *kargs[] = {&A};
-            ITRY(hipLaunchCooperativeKernel((const void *)k_iba_solve, dim3(8 * G * win_per_xcd), dim3(IBA_THREADS), kargs, (unsigned)lds, s));
-        } else {
-            hipLaunchKernelGGL(k_iba_solve, dim3(8 * G * win_per_xcd), dim3(IBA_THREADS), lds, s, A);
-            ITRY(hipGetLastError());
-        }
+        // the whole grid must be resident (the team barrier spins): a plain launch has the same residency as a cooperative one
+        // (MI355X_MICROARCH.md), so the size rule is checked here instead of by hipLaunchCooperativeKernel (whose launches rocprofv3
+        // cannot trace without crashing in the runtime's exit handler on this image: profiles/r03_iba_coop_exit_crash.txt)
+        if (8 * G * win_per_xcd > cus * per_cu) { orbhip_set_last_error_internal("inertial BA: team grid larger than the device"); return ORBHIP_E_HIP; }
+        hipLaunchKernelGGL(k_iba_solve, dim3(8 * G * win_per_xcd), dim3(IBA_THREADS), lds, s, A);
+        ITRY(hipGetLastError());
     }
     std::vector<int> failv(n_windows);
     ITRY(hipMemcpyAsync(failv.data(), d + b->w_sync + 4 * (size_t)n_windows, 4 * (size_t)n_windows, hipMemcpyDeviceToHost, s));

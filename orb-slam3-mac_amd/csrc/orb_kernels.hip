@@ -6,6 +6,10 @@
 // Wave = 64 lanes everywhere.  Compile: hipcc --offload-arch=gfx950 -ffp-contract=off.
 #include "orb_internal.h"
 #include "wave_dpp.h"
+#include <mutex>
+#include <vector>
+#include <cstdio>
+#include <cstdlib>
 
 #define WAVE 64
 
@@ -575,16 +579,25 @@ void orb_launch_fast_cells(const FastParams &F_, hipStream_t s, int max_per_cu, 
     if (F.lvl_lo >= F.lvl_hi) return;
     // persistent single-wave workgroups: as many as the LDS lets a CU hold, a whole number per XCD
     const size_t lds = sizeof(uint32_t) * (size_t)F.wave_dw;
-    // as many as the runtime says fit (LDS, wave slots), asked once per kernel variant and LDS size
-    static int occ_cache[2] = {0, 0}; static size_t occ_lds[2] = {0, 0};
+    // as many as the runtime says fit (LDS, wave slots), asked once per (device, kernel variant, LDS size).  The left and right images
+    // of a stereo frame are extracted on two threads (Frame.cc:109-110) and a process may drive several GPUs: the table is guarded
     const int v = F.small_cells ? 1 : 0;
-    if (!occ_cache[v] || occ_lds[v] != lds) {
-        int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, orb_fast_cells_func(v), 64, lds) != hipSuccess || n < 1) n = (int)((160 * 1024) / (lds + 512));
-        occ_cache[v] = n < 1 ? 1 : n; occ_lds[v] = lds;
-        if (getenv("ORBHIP_DEBUG_FAST")) fprintf(stderr, "[orbhip] k_fast_cells: %zu B of LDS per wave, %d waves per CU resident\n", lds, occ_cache[v]);
+    int per_cu;
+    {
+        struct Occ { int dev, v, n; size_t lds; };
+        static std::mutex occ_mu; static std::vector<Occ> occ_tab;
+        int dev = 0; (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> g(occ_mu);
+        const Occ *hit = nullptr;
+        for (const Occ &o : occ_tab) if (o.dev == dev && o.v == v && o.lds == lds) { hit = &o; break; }
+        if (!hit) {
+            int n = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, orb_fast_cells_func(v), 64, lds) != hipSuccess || n < 1) n = (int)((160 * 1024) / (lds + 512));
+            occ_tab.push_back(Occ{dev, v, n < 1 ? 1 : n, lds}); hit = &occ_tab.back();
+            if (getenv("ORBHIP_DEBUG_FAST")) fprintf(stderr, "[orbhip] k_fast_cells: %zu B of LDS per wave, %d waves per CU resident\n", lds, hit->n);
+        }
+        per_cu = hit->n;
     }
-    int per_cu = occ_cache[v];
     if (max_per_cu > 0 && per_cu > max_per_cu) per_cu = max_per_cu;      // leave LDS and wave slots to a kernel running beside this one
     long nblocks = (long)(F.n_cus > 0 ? F.n_cus : 256) * per_cu;
     const long total = (long)F.batch * ((F.lvl_hi < F.nlevels ? F.lv[F.lvl_hi].cell_base : F.cells_per_frame) - F.lv[F.lvl_lo].cell_base);

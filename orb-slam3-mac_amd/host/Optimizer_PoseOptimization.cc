@@ -9,6 +9,7 @@
 // nInitialCorrespondences - nBad (:1152-1160).
 #include "Optimizer.h"
 #include <cstdio>
+#include <mutex>
 #include <vector>
 #include "optimizer_common.h"
 
@@ -25,6 +26,11 @@ int Optimizer::PoseOptimization(Frame *pFrame)
     std::vector<int> vnIndexEdge;                              // frame index of every edge, in creation order (vnIndexEdgeMono / Right / Stereo merged)
     Xw.reserve((size_t)3 * N); obs.reserve((size_t)3 * N); invS2.reserve(N); right.reserve(N); vnIndexEdge.reserve(N);
     bool anyRight = false;
+    {
+    // :894-895: the map points' positions are snapshotted under MapPoint::mGlobalMutex, which MapPoint::SetWorldPos takes too: the
+    // write-back of a local BA / loop closing running on another thread cannot move points half-way through this loop.  Released
+    // before the device call, as the reference releases it before optimizer.optimize (:1038)
+    std::unique_lock<std::mutex> lock(MapPoint::mGlobalMutex);
     for (int i = 0; i < N; i++) {                              // :897-1037
         MapPoint *pMP = pFrame->mvpMapPoints[i];
         if (!pMP) continue;
@@ -46,6 +52,7 @@ int Optimizer::PoseOptimization(Frame *pFrame)
         invS2.push_back((double)pFrame->mvInvLevelSigma2[kpUn.octave]);
         right.push_back(isRight);
         vnIndexEdge.push_back(i);
+    }
     }
     if (nInitialCorrespondences < 3) return 0;                 // :1040-1041
 

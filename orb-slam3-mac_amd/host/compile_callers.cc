@@ -2,6 +2,7 @@
 // that reach the hot path, written as the reference writes them (file:line beside each), must build against host/ORBextractor.h,
 // host/ORBmatcher.h and host/Optimizer.h.  Nothing here runs; the surrounding control flow of the callers is not restated -- only
 // the argument types and the call shapes matter.  Built by `make lib/compile_callers.o`, asserted by tests/test_abi_and_host.py.
+#include <mutex>
 #include <set>
 #include <utility>
 #include <vector>
@@ -161,6 +162,11 @@ int loop_closing_calls(CallerState &S, vector<KeyFrame *> &vpCovKFi, vector<MapP
     {   // LoopClosing::MergeLocal, src/LoopClosing.cc:1722
         bool bStop = false;
         Optimizer::LocalBundleAdjustment(mpCurrentKF, vpLocalCurrentWindowKFs, vpMergeConnectedKFs, &bStop);
+    }
+    {   // the lock Optimizer::PoseOptimization holds while it reads map point positions (src/Optimizer.cc:895) and the one
+        // MapPoint::SetWorldPos takes (src/MapPoint.cc:118): both must name the same class-wide mutex
+        unique_lock<mutex> lock(MapPoint::mGlobalMutex);
+        total += lock.owns_lock() ? 1 : 0;
     }
     return total;
 }

@@ -102,8 +102,11 @@ public:
         mTrackDepth(0), mTrackDepthR(0), mTrackProjXR(0), mTrackProjYR(0), mbTrackInView(false), mbTrackInViewR(false),
         mnTrackScaleLevel(0), mnTrackScaleLevelR(-1), mTrackViewCos(1), mTrackViewCosR(1), mWorldPos(Pos.clone()), mpMap(pMap),
         mbBad(false), nObs(0), nNormalUpdates(0), mfMinDistance(0), mfMaxDistance(0), mNormalVector(cv::Mat::zeros(3, 1, CV_32F)), mpReplaced(nullptr) {}
-    void SetWorldPos(const cv::Mat &Pos) { mWorldPos = Pos.clone(); }
-    cv::Mat GetWorldPos() { return mWorldPos.clone(); }
+    // MapPoint.cc:116-127: SetWorldPos takes the class-wide mGlobalMutex (what Optimizer::PoseOptimization holds while it snapshots the
+    // positions, Optimizer.cc:895) and then the point's own mMutexPos; GetWorldPos the latter only
+    void SetWorldPos(const cv::Mat &Pos) { std::unique_lock<std::mutex> lock2(mGlobalMutex); std::unique_lock<std::mutex> lock(mMutexPos); mWorldPos = Pos.clone(); }
+    cv::Mat GetWorldPos() { std::unique_lock<std::mutex> lock(mMutexPos); return mWorldPos.clone(); }
+    static inline std::mutex mGlobalMutex;                            // include/MapPoint.h:226 (defined in MapPoint.cc:28 there)
     std::map<KeyFrame *, std::tuple<int, int>> GetObservations() { return mObservations; }
     int Observations() { return nObs; }
     // stand-in helper of the test programs (not a reference method): both indices of an observation at once
@@ -145,6 +148,7 @@ public:
     cv::Mat mDescriptor;
     // stand-in state
     cv::Mat mWorldPos;
+    std::mutex mMutexPos;
     std::map<KeyFrame *, std::tuple<int, int>> mObservations;
     Map *mpMap;
     bool mbBad;
