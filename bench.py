@@ -939,6 +939,28 @@ def main():
             b1.close()
         if inertial is not None:
             latency["inertial_ba_one_window"] = {"gpu_ms": inertial["single_window_ms"], "what": "10 IMU keyframes, 600 landmarks, host arrays in / out"}
+        # ---- the signature-preserving C++ classes themselves: wall time per call with host cv::Mat / std::vector in and
+        # results out -- packing, the PCIe copies, the kernels, unpacking -- measured by lib/host_smoke (host/host_latency.cc) in its own process
+        # while this one is idle; `device_resident_twin_ms` = the C-ABI call on data already in HBM from the entries above (same shapes, not
+        # the same bytes), `ratio` = host class / twin
+        torch.cuda.synchronize()
+        exe = os.path.join(ROOT, "orb-slam3-mac_amd", "lib", "host_smoke")
+        try:
+            hc = subprocess.run([exe, "latency", "40"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+            host_classes = json.loads(hc.stdout) if hc.returncode == 0 else {"error": "host_smoke latency: rc %d: %s" % (hc.returncode, hc.stderr[-400:])}
+        except Exception as e:               # the line must still print
+            host_classes = {"error": repr(e)}
+        twins = {"extract_one_frame": "extract_one_frame", "search_by_projection_last_frame": "search_by_projection_last_frame_one_pair",
+                 "search_by_projection_local_map": "search_by_projection_local_map_one_pair", "pose_optimization_one_frame": "pose_optimization_one_frame",
+                 "local_ba_one_window": "local_ba_one_window"}
+        for k, t in twins.items():
+            if k in host_classes and t in latency:
+                host_classes[k]["device_resident_twin_ms"] = latency[t]["gpu_ms"]
+                host_classes[k]["ratio"] = round(host_classes[k]["host_class_ms"] / latency[t]["gpu_ms"], 3) if latency[t]["gpu_ms"] else None
+        host_classes["note"] = ("median wall time per call of ORBextractor::operator(), ORBmatcher::SearchByProjection (both overloads), Optimizer::PoseOptimization(Frame*) "
+                                "and Optimizer::LocalBundleAdjustment(KeyFrame*, ...) through orb-slam3-mac_amd/host/ (one page-locked blob in, one out; the frame just "
+                                "extracted stays resident for the matchers; mvImagePyramid materialised on first read)")
+        latency["host_classes"] = host_classes
 
     # ---- BASELINE config #3's per-GPU shard beside the default line: 1920x1080, 2000 features, 512 frames, same step
     hd = None
@@ -1136,6 +1158,12 @@ def main():
                 for key, src in (("pose_optimization_one_frame", "pose_opt"), ("local_ba_one_window", "ba"), ("inertial_ba_one_window", "inertial_ba")):
                     if key in latency and src in out and "cpu_baseline" in out[src]:
                         latency[key]["cpu_oracle_ms_1thread"] = out[src]["cpu_baseline"]["single_thread_ms"]
+                hcl = latency.get("host_classes", {})
+                for k, t in (("extract_one_frame", "extract_one_frame"), ("search_by_projection_last_frame", "search_by_projection_last_frame_one_pair"),
+                             ("search_by_projection_local_map", "search_by_projection_local_map_one_pair"), ("pose_optimization_one_frame", "pose_optimization_one_frame"),
+                             ("local_ba_one_window", "local_ba_one_window")):
+                    if k in hcl and t in latency and "cpu_oracle_ms_1thread" in latency[t]:
+                        hcl[k]["cpu_oracle_ms_1thread"] = latency[t]["cpu_oracle_ms_1thread"]
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()

@@ -90,6 +90,19 @@ int orbhip_extract_batch_host(orbhip_extractor *ext, const uint8_t *h_images, in
                               size_t row_stride, size_t frame_stride, int batch, int lap0, int lap1,
                               orbhip_keypoint *kp_out, uint8_t *desc_out, int cap,
                               int32_t *count_out, int32_t *mono_out);
+/* The same call without the copy into caller arrays: *kp_view / *desc_view point at the extractor's page-locked mirror of the device
+ * result arrays (row f at kp_view + f * row_capacity, desc_view + f * row_capacity * 32; count_view[f], mono_view[f]), valid until the
+ * extractor's next extract call.  What host/ORBextractor.cc copies into the caller's vector<cv::KeyPoint> / cv::Mat. */
+int orbhip_extract_batch_host_view(orbhip_extractor *ext, const uint8_t *h_images, int width, int height, size_t row_stride,
+                                   size_t frame_stride, int batch, int lap0, int lap1, const orbhip_keypoint **kp_view,
+                                   const uint8_t **desc_view, int *row_capacity, const int32_t **count_view, const int32_t **mono_view);
+/* Frame `frame` of the extractor's latest HOST extract call as it still sits on the device (d_kp, d_desc: device pointers into the result
+ * arrays) together with its page-locked host mirror and a counter that changes with every extract call.  The *_host_resident matcher
+ * entry points below take d_kp / d_desc as their train side, so that Tracking's SearchByProjection(CurrentFrame, ...) right after
+ * Frame::ExtractORB (src/Frame.cc:410-417 -> src/Tracking.cc:1911) uploads queries only.  ORBHIP_E_BADARG when the latest call was a
+ * device call or failed (no mirror). */
+int orbhip_extractor_last_frame(orbhip_extractor *ext, int frame, const orbhip_keypoint **d_kp, const uint8_t **d_desc,
+                                const orbhip_keypoint **h_kp_view, const uint8_t **h_desc_view, int32_t *count, unsigned long long *generation);
 
 /* mvImagePyramid[level] of frame `frame` (include/ORBextractor.h:83; read by
  * src/Frame.cc:809,899,913,918).  padded != 0 -> the (w+38)x(h+38) reflect-101 parent
@@ -255,6 +268,23 @@ int orbhip_search_for_initialization_host(orbhip_ctx *ctx, const orbhip_keypoint
                                           const orbhip_keypoint *kpB, const uint8_t *descB, int nB, float min_x, float min_y,
                                           float max_x, float max_y, int window_size, float nn_ratio, int check_orientation,
                                           float *prev_matched_inout, int32_t *matches12_out, int32_t *nmatches_out);
+/* The same host-pointer calls with the TRAIN side already on the device: d_kp / d_desc (d_kpB / d_descB) are DEVICE pointers to n
+ * keypoints and descriptors -- the result arrays of the extraction that produced the frame (orbhip_extractor_last_frame).  This is
+ * the shape of Tracking's calls: SearchByProjection(mCurrentFrame, mLastFrame, ...) (src/Tracking.cc:1911), SearchLocalPoints'
+ * SearchByProjection(mCurrentFrame, vpMapPoints, ...) (:3083) and SearchForInitialization(mInitialFrame, mCurrentFrame, ...) (:1506)
+ * all search the frame whose features the extractor left on the device a moment ago; only the queries (map point projections and
+ * descriptors) travel.  host/frame_cache.h decides when a Frame IS that extraction (byte comparison with the page-locked mirror).
+ * d_kp may be NULL while d_desc is given: the frame's descriptors are the extraction's but its keypoints are not (mvKeysUn of a camera
+ * with distortion, src/Frame.cc:738-771) -- then kp_host [n] is uploaded.  Single-camera frames only.  Everything else HOST, results
+ * identical to the forms above. */
+int orbhip_search_by_projection_host_resident(orbhip_ctx *ctx, int mode, const orbhip_proj_query *q, const uint8_t *desc_q, int nq,
+                                              const orbhip_keypoint *kp_host, const orbhip_keypoint *d_kp, const uint8_t *d_desc, const float *u_right, int n,
+                                              float min_x, float min_y, float max_x, float max_y, int th_high, float nn_ratio,
+                                              int check_orientation, int32_t *train_match_inout, int32_t *nmatches_out);
+int orbhip_search_for_initialization_host_resident(orbhip_ctx *ctx, const orbhip_keypoint *kpA, const uint8_t *descA, int nA,
+                                                   const orbhip_keypoint *kpB_host, const orbhip_keypoint *d_kpB, const uint8_t *d_descB, int nB, float min_x, float min_y,
+                                                   float max_x, float max_y, int window_size, float nn_ratio, int check_orientation,
+                                                   float *prev_matched_inout, int32_t *matches12_out, int32_t *nmatches_out);
 
 /* The search part of ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, th, bRight)
  * (src/ORBmatcher.cc:1403-1613, NLeft == -1; LocalMapping::SearchInNeighbors, src/LocalMapping.cc:781-860), batched over
@@ -313,6 +343,13 @@ int orbhip_search_by_bow_host(orbhip_ctx *ctx,
         const orbhip_keypoint *kf_kp, const uint8_t *kf_desc, int nK,
         const int32_t *f_node_ids, const int32_t *f_node_start, const int32_t *f_feat, int f_nnodes,
         const orbhip_keypoint *f_kp, const uint8_t *f_desc, int nF, int nleft,
+        float nn_ratio, int check_orientation, int32_t *match_f_out, int32_t *nmatches_out);
+/* ... with the FRAME side (d_f_kp, d_f_desc: device pointers, nF entries) resident as above; single-camera frames. */
+int orbhip_search_by_bow_host_resident(orbhip_ctx *ctx,
+        const int32_t *kf_node_ids, const int32_t *kf_node_start, const int32_t *kf_feat, int kf_nnodes, const uint8_t *kf_valid,
+        const orbhip_keypoint *kf_kp, const uint8_t *kf_desc, int nK,
+        const int32_t *f_node_ids, const int32_t *f_node_start, const int32_t *f_feat, int f_nnodes,
+        const orbhip_keypoint *f_kp_host, const orbhip_keypoint *d_f_kp, const uint8_t *d_f_desc, int nF,
         float nn_ratio, int check_orientation, int32_t *match_f_out, int32_t *nmatches_out);
 
 /* ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12) (src/ORBmatcher.cc:827-967,

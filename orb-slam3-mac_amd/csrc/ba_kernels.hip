@@ -29,6 +29,8 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <chrono>
+#include <thread>
 #include <algorithm>
 #include <atomic>
 
@@ -1600,7 +1602,8 @@ struct orbhip_ba_batch {
     orbhip_ctx *ctx;
     BaBatch B;
     std::vector<BaGraphDev> gd;
-    std::vector<void *> allocs;
+    std::vector<void *> allocs;              // ONE device arena per batch (round 4; ~60 separate hipMalloc before), absent when the
+    bool ctx_arena, ctx_word;                // one-shot call borrowed the context's cached arena / pinned word instead
     std::vector<double> poses0, points0;     // normalised initial estimates (host copy)
     int *h_n_active;                         // pinned
     size_t wd_total, s_total, spart_total;
@@ -1622,21 +1625,26 @@ struct orbhip_ba_batch {
     int max_row_blocks;                      // most Hpl blocks any free pose of the batch holds (LDS of k_ba_schur_rows)
 };
 
-template <typename T>
-static T *ba_alloc(orbhip_ba_batch *b, size_t count)
-{
-    void *p = nullptr;
-    if (hipMalloc(&p, std::max<size_t>(count * sizeof(T), 256)) != hipSuccess) return nullptr;
-    b->allocs.push_back(p);
-    return (T *)p;
-}
-template <typename T>
-static T *ba_upload(orbhip_ba_batch *b, const std::vector<T> &v)
-{
-    T *d = ba_alloc<T>(b, v.size());
-    if (d && !v.empty() && hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
-    return d;
-}
+// Device memory of a batch: every array is a slice of ONE arena.  ba_create_impl first declares all slices (uploads first: their
+// offsets are contiguous), then takes the arena -- its own hipMalloc, or for a one-shot solve (Optimizer::LocalBundleAdjustment's
+// shape: create, solve, download, destroy) the context's cached grow-only arena -- gathers the upload slices in the context's
+// page-locked staging area and sends them in ONE host-to-device copy.  Round 3 issued ~60 hipMalloc, ~27 synchronous copies from
+// pageable vectors and ~60 hipFree per window: 1.8 + 0.96 ms of a 7 ms call (host_smoke latency).
+struct BaPlan {
+    struct It { void **dst; const void *src; size_t bytes, off; };
+    std::vector<It> items;
+    size_t total = 0, up_end = 0;
+    void add(void **dst, const void *src, size_t bytes)
+    {
+        items.push_back({dst, src, bytes, total});
+        total += (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
+        if (src) up_end = total;
+    }
+};
+void *orbhip_ctx_pinned_internal(orbhip_ctx *c, size_t bytes);
+void *orbhip_ctx_ba_arena_acquire_internal(orbhip_ctx *c, size_t bytes);
+void orbhip_ctx_ba_arena_release_internal(orbhip_ctx *c);
+int *orbhip_ctx_pinned_word_internal(orbhip_ctx *c);
 
 extern "C" void orbhip_ba_default_params(orbhip_ba_params *p)
 {
@@ -1668,7 +1676,8 @@ extern "C" void orbhip_ba_batch_destroy(orbhip_ba_batch *b)
     if (!b) return;
     (void)hipStreamSynchronize(orbhip_ctx_stream_internal(b->ctx));
     for (void *p : b->allocs) (void)hipFree(p);
-    if (b->h_n_active) (void)hipHostFree(b->h_n_active);
+    if (b->ctx_arena) orbhip_ctx_ba_arena_release_internal(b->ctx);
+    if (b->h_n_active && !b->ctx_word) (void)hipHostFree(b->h_n_active);
     if (b->ev0) { (void)hipEventDestroy(b->ev0); (void)hipEventDestroy(b->ev1); }
     if (b->tick_graph_valid) (void)hipGraphExecDestroy(b->tick_graph);
     delete b;
@@ -1677,32 +1686,66 @@ extern "C" void orbhip_ba_batch_destroy(orbhip_ba_batch *b)
 // pose_in_system[g] (optional): which poses take part in the reduced system even without an edge in THIS graph -- a sharded
 // batch sees only a slice of the edges but must number the free poses like every other rank.
 static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_graphs, const double *const *poses, const double *const *points,
-                          const std::vector<std::vector<uint8_t>> *pose_in_system, int rank, int world, orbhip_ba_batch **out)
+                          const std::vector<std::vector<uint8_t>> *pose_in_system, int rank, int world, orbhip_ba_batch **out, bool oneshot = false)
 {
-    if (!ctx || !graphs || n_graphs <= 0 || !poses || !points || !out) return ORBHIP_E_BADARG;
-    if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
+    static const bool dry = getenv("ORBHIP_BA_CREATE_DRYRUN") != nullptr;       // development: time the host list building without a device
+    const auto t_dry0 = std::chrono::steady_clock::now();
+    if (!dry && (!ctx || !graphs || n_graphs <= 0 || !poses || !points || !out)) return ORBHIP_E_BADARG;
+    if (!dry && hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
     orbhip_ba_batch *b = new orbhip_ba_batch();
-    b->ctx = ctx; b->h_n_active = nullptr; b->ticks_last = 0; b->tick_graph = nullptr; b->tick_graph_valid = false;
+    b->ctx = ctx; b->h_n_active = nullptr; b->ctx_arena = false; b->ctx_word = false; b->ticks_last = 0; b->tick_graph = nullptr; b->tick_graph_valid = false;
     b->profile = false; b->ev0 = b->ev1 = nullptr; b->gemm_ms_total = 0; b->gemm_launches = 0; b->gemm_flops_per_launch = 0; b->gemm_flops_dense = 0; b->gemm_flops_issued = 0;
     BaBatch &B = b->B;
     memset(&B, 0, sizeof(B));
     B.G = n_graphs; B.rank = rank; B.world = world;
     b->general = false;
-    std::vector<int> x1off, x2off;
+    // the host-side lists live in per-thread scratch vectors that keep their capacity from call to call: LocalMapping solves one window
+    // per keyframe from the same thread, and fresh multi-megabyte vectors cost more in page faults than in arithmetic
+    struct Scratch {
+        std::vector<int> x1off, x2off, hidx, epose, epoint, ptstart, posestart, poseedges, etask, pmpoint, pmtask, enext, pair_start, pair_pt;
+        std::vector<uint32_t> ptmask;
+        std::vector<int4> gtask, gstage;
+        std::vector<uint8_t> pmtype, est, edup;
+        std::vector<double> pmis2, pmobs, eobs, eis2;
+        std::vector<int2> pair_ent, pair_jr;
+        struct Tmp { int pi, ea, ec, ra, pt; };
+        std::vector<Tmp> tmp[4];
+        void clear()
+        {
+            x1off.clear(); x2off.clear(); hidx.clear(); epose.clear(); epoint.clear(); ptstart.clear(); posestart.clear(); poseedges.clear(); etask.clear();
+            pmpoint.clear(); pmtask.clear(); enext.clear(); pair_start.clear(); pair_pt.clear(); ptmask.clear(); gtask.clear(); gstage.clear(); pmtype.clear();
+            est.clear(); edup.clear(); pmis2.clear(); pmobs.clear(); eobs.clear(); eis2.clear(); pair_ent.clear(); pair_jr.clear();
+            for (auto &t : tmp) t.clear();
+        }
+    };
+    static thread_local Scratch SC;
+    SC.clear();
+    std::vector<int> &x1off = SC.x1off, &x2off = SC.x2off;
     size_t x1 = 0, x2 = 0;
-    std::vector<int> hidx, epose, epoint, ptstart, posestart, poseedges;
-    std::vector<uint32_t> ptmask;
-    std::vector<int4> gtask, gstage;
-    std::vector<int> etask, pmpoint, pmtask;
-    std::vector<uint8_t> pmtype;
-    std::vector<double> pmis2, pmobs;
-    std::vector<double> eobs, eis2;
-    std::vector<uint8_t> est, edup;
-    std::vector<int> enext;
+    std::vector<int> &hidx = SC.hidx, &epose = SC.epose, &epoint = SC.epoint, &ptstart = SC.ptstart, &posestart = SC.posestart, &poseedges = SC.poseedges;
+    std::vector<uint32_t> &ptmask = SC.ptmask;
+    std::vector<int4> &gtask = SC.gtask, &gstage = SC.gstage;
+    std::vector<int> &etask = SC.etask, &pmpoint = SC.pmpoint, &pmtask = SC.pmtask;
+    std::vector<uint8_t> &pmtype = SC.pmtype;
+    std::vector<double> &pmis2 = SC.pmis2, &pmobs = SC.pmobs;
+    std::vector<double> &eobs = SC.eobs, &eis2 = SC.eis2;
+    std::vector<uint8_t> &est = SC.est, &edup = SC.edup;
+    std::vector<int> &enext = SC.enext;
     int sumP = 0, sumL = 0, sumE = 0, sumF = 0;
     size_t s = 0, sp = 0;
     bool any_big = false;
     std::vector<std::vector<int>> g_local_h;                 // hessian index of every pose, per graph (big windows: pair lists)
+    int mode = dry ? 0 : orbhip_ctx_ba_schur_mode_internal(ctx);
+    if (const char *ev = getenv("ORBHIP_BA_PAIRS")) mode = atoi(ev) ? 1 : 2;                                                    // development override
+    const bool want_gemm_stats = !(world == 1 && mode != 2);    // the MFMA flop counts of the GEMM form (bench / profiling): not needed by the pair-list form
+    {   // every per-edge / per-point / per-pose array is sized once (round 4: ~25 push_back per edge were 1 ms of a one-shot solve)
+        size_t te = 0, tl = 0, tp = 0;
+        for (int g = 0; g < n_graphs; g++) { te += (size_t)std::max(graphs[g].n_edges, 0); tl += (size_t)std::max(graphs[g].n_points, 0); tp += (size_t)std::max(graphs[g].n_poses, 0); }
+        hidx.reserve(tp); epose.reserve(te); epoint.reserve(te); eobs.reserve(3 * te); eis2.reserve(te); est.reserve(te); edup.reserve(te); enext.reserve(te);
+        ptstart.reserve(tl + n_graphs); posestart.reserve(tp + n_graphs); poseedges.reserve(te); ptmask.reserve(tl); gtask.reserve(te); gstage.reserve(tl / 4 + 16);
+        etask.reserve(te); pmpoint.reserve(te); pmtask.reserve(te); pmtype.reserve(te); pmis2.reserve(te); pmobs.reserve(3 * te);
+        b->poses0.reserve(7 * tp); b->points0.reserve(3 * tl);
+    }
     // split-K so that the Schur GEMM launches >= ~4096 waves
     for (int g = 0; g < n_graphs; g++) {
         const orbhip_ba_graph &H = graphs[g];
@@ -1742,11 +1785,14 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
         for (int e = 0; e < H.n_edges; e++) { const int h = local_h[H.edge_pose[e]]; if (h >= 0) pel[fill[h]++] = e; }
         posestart.insert(posestart.end(), pc.begin(), pc.end());
         poseedges.insert(poseedges.end(), pel.begin(), pel.end());
-        for (int k = 0; k < H.n_edges; k++) {                     // pose-major copy of the static edge data (entries past pc[nf] unused)
-            const int e = k < pc[nf] ? pel[k] : 0;
-            pmpoint.push_back(H.n_edges ? H.edge_point[e] : 0); pmtype.push_back(H.n_edges && H.edge_stereo ? H.edge_stereo[e] : 0);
-            pmis2.push_back(H.n_edges ? H.edge_inv_sigma2[e] : 0.0);
-            for (int d = 0; d < 3; d++) pmobs.push_back(H.n_edges ? H.edge_obs[3 * e + d] : 0.0);
+        {                                                         // pose-major copy of the static edge data (entries past pc[nf] unused)
+            const size_t o = pmpoint.size(), ne = (size_t)H.n_edges;
+            pmpoint.resize(o + ne); pmtype.resize(o + ne); pmis2.resize(o + ne); pmobs.resize(3 * (o + ne));
+            for (size_t k = 0; k < ne; k++) {
+                const int e = (int)k < pc[nf] ? pel[k] : 0;
+                pmpoint[o + k] = H.edge_point[e]; pmtype[o + k] = H.edge_stereo ? H.edge_stereo[e] : 0; pmis2[o + k] = H.edge_inv_sigma2[e];
+                pmobs[3 * (o + k)] = H.edge_obs[3 * e]; pmobs[3 * (o + k) + 1] = H.edge_obs[3 * e + 1]; pmobs[3 * (o + k) + 2] = H.edge_obs[3 * e + 2];
+            }
         }
         {   // edge types: 0 mono, 1 stereo, 2 second camera (needs a rigid transform mTrl with a non-zero quaternion)
             bool any2 = false;
@@ -1771,11 +1817,9 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
             for (int e = 0; e < H.n_edges; e++) if (dup[e] || (H.edge_stereo && H.edge_stereo[e] == 2)) b->general = true;
             if (H.camera_model != 0) b->general = true;
         }
-        for (int e = 0; e < H.n_edges; e++) {
-            epose.push_back(H.edge_pose[e]); epoint.push_back(H.edge_point[e]);
-            eobs.push_back(H.edge_obs[3 * e]); eobs.push_back(H.edge_obs[3 * e + 1]); eobs.push_back(H.edge_obs[3 * e + 2]);
-            eis2.push_back(H.edge_inv_sigma2[e]); est.push_back(H.edge_stereo ? H.edge_stereo[e] : 0);
-        }
+        epose.insert(epose.end(), H.edge_pose, H.edge_pose + H.n_edges); epoint.insert(epoint.end(), H.edge_point, H.edge_point + H.n_edges);
+        eobs.insert(eobs.end(), H.edge_obs, H.edge_obs + 3 * (size_t)H.n_edges); eis2.insert(eis2.end(), H.edge_inv_sigma2, H.edge_inv_sigma2 + H.n_edges);
+        if (H.edge_stereo) est.insert(est.end(), H.edge_stereo, H.edge_stereo + H.n_edges); else est.insert(est.end(), (size_t)H.n_edges, (uint8_t)0);
         const int nt = D.ld / 16, ntiles = nt * (nt + 1) / 2;
         int nchunks = 0;
         for (int tr = 0; tr < nt; tr++) nchunks += gemm_strip_chunks(nt, tr);
@@ -1818,14 +1862,14 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
         g_local_h.push_back(local_h);
         {   // static block-sparsity masks: 16-column tiles of the point's Hpl column that hold a non-zero block
             double issued = 0;
-            for (int l = 0; l < H.n_points; l++) ptmask.push_back(0u);
+            ptmask.insert(ptmask.end(), (size_t)H.n_points, 0u);
             uint32_t *pmv = ptmask.data() + (ptmask.size() - H.n_points);
-            for (int e = 0; e < H.n_edges; e++) {
+            for (int e = 0; e < H.n_edges && want_gemm_stats; e++) {
                 const int h = local_h[H.edge_pose[e]];
                 if (h >= 0 && !big_graph) pmv[H.edge_point[e]] |= (1u << ((6 * h) >> 4)) | (1u << ((6 * h + 5) >> 4));
             }
             double chunks = 0;                                                         // the kernel's issue rule: row tile hit AND a column tile of the chunk hit
-            for (int l = 0; l < H.n_points; l++) {
+            for (int l = 0; l < H.n_points && want_gemm_stats; l++) {
                 const double k = __builtin_popcount(pmv[l]); issued += k * (k + 1) / 2;
                 for (int tr = 0; tr < nt; tr++) {
                     if (!((pmv[l] >> tr) & 1u)) continue;
@@ -1863,14 +1907,13 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
     b->s_total = s; b->spart_total = sp;
     // big windows: every graph of the batch takes the global-memory path; per graph and pair of free poses (i <= j) the Hpl blocks
     // of the points both see, in point order (the summation order of k_ba_schur_big)
-    std::vector<int> pair_start, pair_pt; std::vector<int2> pair_ent, pair_jr;
+    std::vector<int> &pair_start = SC.pair_start, &pair_pt = SC.pair_pt; std::vector<int2> &pair_ent = SC.pair_ent, &pair_jr = SC.pair_jr;
     b->max_row_blocks = 0;
     B.big = any_big ? 1 : 0;
     // Schur complement: per-block-pair lists (k_ba_schur_big) by default -- measured faster than the MFMA panel GEMM at every batch
     // size -- the GEMM on request (orbhip_ctx_set_ba_schur_mode(ctx, 2), a property of the context the batch is created on), in the landmark-sharded mode and never for big windows
-    int mode = orbhip_ctx_ba_schur_mode_internal(ctx);
-    if (const char *ev = getenv("ORBHIP_BA_PAIRS")) mode = atoi(ev) ? 1 : 2;                                                    // development override
     const bool pair_lists = any_big || (world == 1 && mode != 2);
+    if (dry) fprintf(stderr, "[orbhip ba] create (dry run): per-graph lists %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dry0).count());
     B.pair_schur = pair_lists ? 1 : 0;
     if (pair_lists) {
         for (int g = 0; g < n_graphs; g++) {
@@ -1887,35 +1930,84 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
             std::vector<int> rank(H.n_edges, 0), seen(nf, 0);
             for (int a = 0; a < H.n_edges; a++) if (et[a] >= 0) rank[a] = seen[lh[H.edge_pose[a]]]++;
             for (int k = 0; k < nf; k++) b->max_row_blocks = std::max(b->max_row_blocks, seen[k]);
-            for (int pass = 0; pass < 2; pass++) {
-                std::vector<int> fill(cnt.begin(), cnt.end() - 1);
-                for (int e0 = 0; e0 < H.n_edges;) {
+            // every unordered pair of a point's Hpl blocks once, oriented by hessian index (i <= j; the diagonal pair is (a, a)): one
+            // enumeration into a temporary with a count per pair, a prefix, a scatter (round 3 enumerated every ORDERED pair twice).
+            // The code can cut the points into T contiguous ranges for T host threads (ORBHIP_BA_CREATE_THREADS; ranges are in point
+            // order, so a list's entries stay in point order whatever T) -- not the default, see below.
+            typedef Scratch::Tmp Tmp;
+            static const int t_env = getenv("ORBHIP_BA_CREATE_THREADS") ? atoi(getenv("ORBHIP_BA_CREATE_THREADS")) : 0;
+            const int T = t_env > 0 ? std::min(t_env, 4) : 1;     // measured on the GPU box (one 50 x 2000 x 10 window): create 0.90 ms on one thread, 1.44-1.60 ms on four -- the spawns cost more than the split returns
+            std::vector<Tmp> *tmp = SC.tmp;
+            for (int t = 0; t < 4; t++) tmp[t].clear();
+            std::vector<std::vector<int>> tcnt(T, std::vector<int>(npair, 0));
+            std::vector<int> cut(T + 1, H.n_edges);
+            cut[0] = 0;
+            for (int t = 1; t < T; t++) {                                                     // cut at point boundaries
+                int e = (int)((long long)H.n_edges * t / T);
+                while (e < H.n_edges && e > 0 && H.edge_point[e] == H.edge_point[e - 1]) e++;
+                cut[t] = std::max(e, cut[t - 1]);
+            }
+            auto enumerate = [&](int t) {
+                std::vector<Tmp> &out = tmp[t]; std::vector<int> &c_ = tcnt[t];
+                out.reserve((size_t)(cut[t + 1] - cut[t]) * 6);
+                int blk[1024], nb;
+                for (int e0 = cut[t]; e0 < cut[t + 1];) {
                     int e1 = e0;
-                    while (e1 < H.n_edges && H.edge_point[e1] == H.edge_point[e0]) e1++;
-                    for (int a = e0; a < e1; a++) {
-                        if (et[a] < 0) continue;
-                        for (int c = e0; c < e1; c++) {
-                            if (et[c] < 0) continue;
-                            const int i = lh[H.edge_pose[a]], j = lh[H.edge_pose[c]];
-                            if (i > j || (i == j && a != c)) continue;           // every unordered pair once; the diagonal pair is (a, a)
-                            if (pass == 0) cnt[pidx(i, j) + 1]++;
-                            else { const size_t q = D.pent_off + fill[pidx(i, j)]++; pair_ent[q] = make_int2(et[a], et[c]); pair_pt[q] = H.edge_point[a]; pair_jr[q] = make_int2(et[c], rank[a]); }
+                    nb = 0;
+                    while (e1 < H.n_edges && H.edge_point[e1] == H.edge_point[e0]) { if (et[e1] >= 0 && nb < 1024) blk[nb++] = e1; e1++; }
+                    for (int x = 0; x < nb; x++) {
+                        const int a = blk[x], i = lh[H.edge_pose[a]];
+                        for (int y = x; y < nb; y++) {
+                            const int c = blk[y], j = lh[H.edge_pose[c]];
+                            if (x != y && i == j) continue;                                  // (twin edges carry no block of their own: never here)
+                            const bool fw = i <= j;
+                            const int ea = fw ? a : c, ec = fw ? c : a, pi = fw ? pidx(i, j) : pidx(j, i);
+                            c_[pi]++;
+                            out.push_back({pi, et[ea], et[ec], rank[ea], H.edge_point[a]});
                         }
                     }
                     e0 = e1;
                 }
-                if (pass == 0) {
-                    for (int k = 0; k < npair; k++) cnt[k + 1] += cnt[k];
-                    pair_ent.resize(D.pent_off + cnt[npair]); pair_pt.resize(D.pent_off + cnt[npair]); pair_jr.resize(D.pent_off + cnt[npair]);
-                }
+            };
+            {
+                std::vector<std::thread> th;
+                for (int t = 1; t < T; t++) th.emplace_back(enumerate, t);
+                enumerate(0);
+                for (std::thread &x : th) x.join();
             }
+
+            std::vector<std::vector<int>> tfill(T, std::vector<int>(npair, 0));
+            {
+                int run = 0;
+                for (int k = 0; k < npair; k++) {
+                    cnt[k] = run;
+                    for (int t = 0; t < T; t++) { tfill[t][k] = run; run += tcnt[t][k]; }
+                }
+                cnt[npair] = run;
+            }
+            pair_ent.resize(D.pent_off + cnt[npair]); pair_pt.resize(D.pent_off + cnt[npair]); pair_jr.resize(D.pent_off + cnt[npair]);
+            auto scatter = [&](int t) {
+                std::vector<int> &fill = tfill[t];
+                for (const Tmp &e : tmp[t]) { const size_t q = D.pent_off + fill[e.pi]++; pair_ent[q] = make_int2(e.ea, e.ec); pair_pt[q] = e.pt; pair_jr[q] = make_int2(e.ec, e.ra); }
+            };
+            {
+                std::vector<std::thread> th;
+                for (int t = 1; t < T; t++) th.emplace_back(scatter, t);
+                scatter(0);
+                for (std::thread &x : th) x.join();
+            }
+
             pair_start.insert(pair_start.end(), cnt.begin(), cnt.end());
         }
     }
     b->x_need = std::max(std::max(x1, x2), (size_t)3 * n_graphs);
-    bool ok = true;
-#define UP(dst, vec) do { auto *_p = ba_upload(b, vec); ok = ok && _p; dst = _p; } while (0)
-#define AL(dst, T, n) do { auto *_p = ba_alloc<T>(b, n); ok = ok && _p; dst = _p; } while (0)
+    if (dry) {
+        fprintf(stderr, "[orbhip ba] create (dry run): host lists %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dry0).count());
+        delete b; return ORBHIP_E_NODEVICE;
+    }
+    BaPlan plan;
+#define UP(dst, vec) plan.add((void **)&(dst), (vec).empty() ? (const void *)&plan : (const void *)(vec).data(), (vec).size() * sizeof((vec)[0]))
+#define AL(dst, T, n) plan.add((void **)&(dst), nullptr, (size_t)(n) * sizeof(T))
     UP(B.gd, b->gd); UP(B.hidx, hidx); UP(B.edge_pose, epose); UP(B.edge_point, epoint); UP(B.edge_obs, eobs);
     UP(B.edge_is2, eis2); UP(B.edge_stereo, est); UP(B.edge_dup, edup); UP(B.edge_next, enext); UP(B.pt_start, ptstart); UP(B.pose_start, posestart); UP(B.pose_edges, poseedges);
     UP(B.ptmask, ptmask); UP(B.gemm_task, gtask); UP(B.gemm_stage, gstage); UP(B.edge_task, etask); UP(B.x1_off, x1off); UP(B.x2_off, x2off);
@@ -1938,7 +2030,28 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
     AL(B.bacc, double, (size_t)sumF * 6); AL(B.x_abort, int, 1); AL(B.edges_total, double, n_graphs);
 #undef UP
 #undef AL
-    if (!ok || hipHostMalloc((void **)&b->h_n_active, sizeof(int)) != hipSuccess) { orbhip_ba_batch_destroy(b); g_ba_error = "device allocation failed"; return ORBHIP_E_HIP; }
+    {
+        hipStream_t st = orbhip_ctx_stream_internal(ctx);
+        uint8_t *arena = nullptr;
+        if (oneshot && (arena = (uint8_t *)orbhip_ctx_ba_arena_acquire_internal(ctx, plan.total))) b->ctx_arena = true;
+        else {
+            void *p = nullptr;
+            if (hipMalloc(&p, plan.total) != hipSuccess) { orbhip_ba_batch_destroy(b); g_ba_error = "device allocation failed"; return ORBHIP_E_HIP; }
+            b->allocs.push_back(p); arena = (uint8_t *)p;
+        }
+        uint8_t *stage = (uint8_t *)orbhip_ctx_pinned_internal(ctx, plan.up_end);
+        if (!stage) { orbhip_ba_batch_destroy(b); g_ba_error = "page-locked staging allocation failed"; return ORBHIP_E_HIP; }
+        for (const BaPlan::It &it : plan.items) {
+            *it.dst = arena + it.off;
+            if (it.src && it.bytes) memcpy(stage + it.off, it.src, it.bytes);
+        }
+        // the staging area belongs to the context and the next host-pointer call may reuse it: the copy is waited for here
+        if (hipMemcpyAsync(arena, stage, plan.up_end, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            orbhip_ba_batch_destroy(b); g_ba_error = "upload of the graph failed"; return ORBHIP_E_HIP;
+        }
+        if (oneshot && (b->h_n_active = orbhip_ctx_pinned_word_internal(ctx))) b->ctx_word = true;
+        else if (hipHostMalloc((void **)&b->h_n_active, sizeof(int)) != hipSuccess) { b->h_n_active = nullptr; orbhip_ba_batch_destroy(b); g_ba_error = "device allocation failed"; return ORBHIP_E_HIP; }
+    }
     *out = b;
     return ORBHIP_OK;
 }
@@ -2301,11 +2414,21 @@ extern "C" int orbhip_ba_solve_batch(orbhip_ctx *ctx, const orbhip_ba_graph *gra
 {
     if (abort_flag && *abort_flag) return ORBHIP_E_ABORTED;
     orbhip_ba_batch *b = nullptr;
-    int rc = orbhip_ba_batch_create(ctx, graphs, n_graphs, poses_inout, points_inout, &b);
+    static const bool prof = getenv("ORBHIP_HOST_PROF") != nullptr;       // where a one-shot call spends its time (host_smoke latency)
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = ba_create_impl(ctx, graphs, n_graphs, poses_inout, points_inout, nullptr, 0, 1, &b, true);     // borrows the context's cached arena
     if (rc) return rc;
+    const auto t1 = std::chrono::steady_clock::now();
     rc = orbhip_ba_batch_solve(b, params, abort_flag);
+    const auto t2 = std::chrono::steady_clock::now();
     if (rc == ORBHIP_OK) rc = orbhip_ba_batch_download(b, poses_inout, points_inout, edge_outlier_out, stats_out);
+    const auto t3 = std::chrono::steady_clock::now();
     orbhip_ba_batch_destroy(b);
+    if (prof) {
+        const auto t4 = std::chrono::steady_clock::now();
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
+        fprintf(stderr, "[orbhip ba] one-shot solve of %d graph(s): create %.3f  solve %.3f  download %.3f  destroy %.3f ms\n", n_graphs, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4));
+    }
     return rc;
 }
 

@@ -48,12 +48,17 @@ struct orbhip_ctx {
     hipStream_t stream;
     bool own_stream;
     int32_t *d_status;      // sticky device-side error word (capacity overflows in matcher kernels)
+    int32_t *status_redirect;
     void *scratch;          // grow-only device arena of the host-pointer convenience entry points (host_entry.hip)
     size_t scratch_bytes;
     void *work;             // grow-only device arena of the device entry points themselves (candidate lists of the low-latency matchers): separate from
     size_t work_bytes;      // `scratch`, which holds the host-form callers' staged inputs while those entry points run
     int n_cus;              // hipDeviceAttributeMultiprocessorCount of `device`: persistent grids are sized from it
     int ba_schur_mode;      // orbhip_ctx_set_ba_schur_mode
+    void *ba_arena; size_t ba_arena_bytes; bool ba_arena_busy;     // cached device arena of one-shot local-BA solves (ba_kernels.hip)
+    int *pinned_word;       // one page-locked word for such solves (the LM loop's active-graph counter)
+    void *pinned;           // grow-only page-locked host arena of the host-pointer entry points: a call's inputs are gathered here and leave in ONE
+    size_t pinned_bytes;    // host-to-device copy, its outputs come back in ONE device-to-host copy (host_entry.hip)
 };
 
 extern "C" int orbhip_ctx_create(int device, void *stream, orbhip_ctx **out)
@@ -78,7 +83,8 @@ extern "C" int orbhip_ctx_create(int device, void *stream, orbhip_ctx **out)
         if (c->own_stream) (void)hipStreamDestroy(c->stream);
         delete c; g_last_error = "hipMalloc(status)"; return ORBHIP_E_HIP;
     }
-    c->scratch = nullptr; c->scratch_bytes = 0; c->work = nullptr; c->work_bytes = 0; c->ba_schur_mode = 0; c->n_cus = 0;
+    c->status_redirect = nullptr;
+    c->scratch = nullptr; c->scratch_bytes = 0; c->work = nullptr; c->work_bytes = 0; c->ba_schur_mode = 0; c->n_cus = 0; c->pinned = nullptr; c->pinned_bytes = 0; c->ba_arena = nullptr; c->ba_arena_bytes = 0; c->ba_arena_busy = false; c->pinned_word = nullptr;
     if (hipDeviceGetAttribute(&c->n_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->n_cus <= 0) c->n_cus = 256;
     *out = c;
     return ORBHIP_OK;
@@ -95,6 +101,41 @@ void *orbhip_ctx_scratch_internal(orbhip_ctx *c, size_t bytes)
     c->scratch_bytes = want;
     return c->scratch;
 }
+// Page-locked host arena of at least `bytes`, kept across calls (the host-pointer entry points are synchronous: nothing of an earlier call
+// is in flight when the next one asks; growing drains the stream anyway).
+void *orbhip_ctx_pinned_internal(orbhip_ctx *c, size_t bytes)
+{
+    if (bytes <= c->pinned_bytes) return c->pinned;
+    (void)hipStreamSynchronize(c->stream);
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    c->pinned = nullptr; c->pinned_bytes = 0;
+    const size_t want = std::max<size_t>(bytes + bytes / 2, 1 << 20);
+    if (hipHostMalloc(&c->pinned, want, hipHostMallocDefault) != hipSuccess) { g_last_error = "hipHostMalloc(pinned staging arena)"; return nullptr; }
+    c->pinned_bytes = want;
+    return c->pinned;
+}
+// Cached device arena for one-shot BA solves (create + solve + download + destroy inside one call): nullptr when it is already lent
+// out (the caller then allocates its own) or cannot be grown.
+void *orbhip_ctx_ba_arena_acquire_internal(orbhip_ctx *c, size_t bytes)
+{
+    if (c->ba_arena_busy) return nullptr;
+    if (bytes > c->ba_arena_bytes) {
+        (void)hipStreamSynchronize(c->stream);
+        if (c->ba_arena) (void)hipFree(c->ba_arena);
+        c->ba_arena = nullptr; c->ba_arena_bytes = 0;
+        const size_t want = bytes + bytes / 4;
+        if (hipMalloc(&c->ba_arena, want) != hipSuccess) return nullptr;
+        c->ba_arena_bytes = want;
+    }
+    c->ba_arena_busy = true;
+    return c->ba_arena;
+}
+void orbhip_ctx_ba_arena_release_internal(orbhip_ctx *c) { c->ba_arena_busy = false; }
+int *orbhip_ctx_pinned_word_internal(orbhip_ctx *c)
+{
+    if (!c->pinned_word && hipHostMalloc((void **)&c->pinned_word, 256, hipHostMallocDefault) != hipSuccess) c->pinned_word = nullptr;
+    return c->pinned_word;
+}
 // Device work arena of at least `bytes`, kept across calls.  Growing waits for the stream (earlier kernels may still read the old arena).
 void *orbhip_ctx_work_internal(orbhip_ctx *c, size_t bytes)
 {
@@ -108,22 +149,29 @@ void *orbhip_ctx_work_internal(orbhip_ctx *c, size_t bytes)
     return c->work;
 }
 void orbhip_set_last_error_internal(const char *msg) { g_last_error = msg; }
+int32_t *orbhip_ctx_status_internal(orbhip_ctx *c);
 extern "C" int orbhip_ctx_check_status(orbhip_ctx *c)
 {
     if (!c) return ORBHIP_E_BADARG;
     int32_t st = 0;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(&st, c->d_status, sizeof(st), hipMemcpyDeviceToHost));
-    if (st) { HIP_TRY(hipMemset(c->d_status, 0, sizeof(int32_t))); g_last_error = "device-side capacity exceeded in a matcher kernel"; }
+    HIP_TRY(hipMemcpy(&st, orbhip_ctx_status_internal(c), sizeof(st), hipMemcpyDeviceToHost));
+    if (st) { HIP_TRY(hipMemset(orbhip_ctx_status_internal(c), 0, sizeof(int32_t))); g_last_error = "device-side capacity exceeded in a matcher kernel"; }
     return st;
 }
-int32_t *orbhip_ctx_status_internal(orbhip_ctx *c) { return c->d_status; }
+int32_t *orbhip_ctx_status_internal(orbhip_ctx *c) { return c->status_redirect ? c->status_redirect : c->d_status; }
+// A host-pointer call (host_entry.hip) points the kernels' status word at a slot of its own blob for the duration of the call, so that the
+// word travels with the call's single upload (zeroed) and single download instead of costing a copy of its own; nullptr restores
+void orbhip_ctx_redirect_status_internal(orbhip_ctx *c, int32_t *p) { c->status_redirect = p; }
 extern "C" void orbhip_ctx_destroy(orbhip_ctx *c)
 {
     if (!c) return;
     (void)hipFree(c->d_status);
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->work) (void)hipFree(c->work);
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->ba_arena) (void)hipFree(c->ba_arena);
+    if (c->pinned_word) (void)hipHostFree(c->pinned_word);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -181,6 +229,12 @@ struct orbhip_extractor {
     hipGraphExec_t graph_exec;
     int g_w, g_h, g_batch, g_lap0, g_lap1;
     size_t level0_frame_stride; int level0_pitch;
+    // host-pointer path (ORBextractor::operator()): the four result arrays are slices of ONE device allocation (counts | mono | keypoints |
+    // descriptors) with a page-locked mirror, so a call ends in one device-to-host copy; the input is gathered in a page-locked image
+    uint8_t *d_outblob; size_t outblob_bytes, ob_kp, ob_desc;      // offsets of the keypoint / descriptor slices
+    uint8_t *h_out; uint8_t *h_in; size_t h_in_bytes; int32_t *h_status;
+    uint8_t *h_pyr; size_t h_pyr_bytes;                             // page-locked landing area of the lazy pyramid copy-out
+    unsigned long long generation, view_generation;                 // extract calls so far; the call whose results h_out holds
 };
 
 extern "C" int orbhip_extractor_create(orbhip_ctx *ctx, int nfeatures, float scale_factor, int nlevels,
@@ -196,6 +250,8 @@ extern "C" int orbhip_extractor_create(orbhip_ctx *ctx, int nfeatures, float sca
     e->d_stereo_sad = nullptr;
     e->graph_mode = false; e->graph_valid = false; e->graph_exec = nullptr;
     e->aux = nullptr; e->ev_fork = e->ev_join = e->ev_pyr = nullptr; e->aux_ok = false; e->overlap = 1;
+    e->d_outblob = nullptr; e->outblob_bytes = e->ob_kp = e->ob_desc = 0; e->h_out = e->h_in = e->h_pyr = nullptr; e->h_in_bytes = e->h_pyr_bytes = 0; e->h_status = nullptr;
+    e->generation = 0; e->view_generation = ~0ull;
     memset(&e->P, 0, sizeof(e->P));
     memset(e->stage_ms, 0, sizeof(e->stage_ms));
     // scale tables, ORBextractor.cc:413-429
@@ -229,6 +285,11 @@ static void ext_free_all(orbhip_extractor *e)
     for (void *p : e->allocs) (void)hipFree(p);
     e->allocs.clear();
     e->bytes_reserved = 0; e->width = e->height = e->max_batch = 0; e->d_level0 = nullptr; e->d_stereo_sad = nullptr;
+    if (e->h_out) (void)hipHostFree(e->h_out);
+    if (e->h_in) (void)hipHostFree(e->h_in);
+    if (e->h_pyr) (void)hipHostFree(e->h_pyr);
+    if (e->h_status) (void)hipHostFree(e->h_status);
+    e->h_out = e->h_in = e->h_pyr = nullptr; e->h_status = nullptr; e->h_in_bytes = e->h_pyr_bytes = 0; e->d_outblob = nullptr; e->view_generation = ~0ull;
     if (e->graph_valid) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_valid = false; }
 }
 static void ext_free_aux(orbhip_extractor *e)
@@ -522,10 +583,14 @@ extern "C" int orbhip_extractor_reserve(orbhip_extractor *e, int width, int heig
     if ((rc = dev_alloc(e, &P.lvl_count, B * e->nlevels))) return rc;
     if ((rc = dev_alloc(e, &P.lvl_ncand, B * e->nlevels))) return rc;
     if ((rc = dev_alloc(e, &P.status, 1))) return rc;
-    if ((rc = dev_alloc(e, &P.out_kp, B * P.max_kp))) return rc;
-    if ((rc = dev_alloc(e, &P.out_desc, B * P.max_kp * 32))) return rc;
-    if ((rc = dev_alloc(e, &P.out_count, B))) return rc;
-    if ((rc = dev_alloc(e, &P.out_mono, B))) return rc;
+    {   // results: one allocation, [count B][mono B] | keypoints [B][max_kp] | descriptors [B][max_kp][32], slices 256-byte aligned
+        auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        e->ob_kp = up(8 * B); e->ob_desc = e->ob_kp + up(sizeof(orbhip_keypoint) * B * P.max_kp);
+        e->outblob_bytes = e->ob_desc + up((size_t)32 * B * P.max_kp);
+        if ((rc = dev_alloc(e, &e->d_outblob, e->outblob_bytes))) return rc;
+        P.out_count = reinterpret_cast<int32_t *>(e->d_outblob); P.out_mono = P.out_count + B;
+        P.out_kp = reinterpret_cast<orbhip_keypoint *>(e->d_outblob + e->ob_kp); P.out_desc = e->d_outblob + e->ob_desc;
+    }
     HIP_TRY(hipMemset(P.status, 0, sizeof(int32_t)));
     // the octree kernel keeps its node arrays in LDS: capacity = the largest node count any level can reach -- quota + 3 in the
     // subdivision loop, but the first pass splits every root unconditionally (up to 4 * nIni nodes; wide images, small budgets)
@@ -685,6 +750,7 @@ static int run_pipeline(orbhip_extractor *e, int batch, int lap0, int lap1)
     if (prof) e->ev_calls++;
     HIP_TRY(hipGetLastError());
     e->last_batch = batch;
+    e->generation++;
     return ORBHIP_OK;
 }
 
@@ -707,6 +773,7 @@ static int run_pipeline_graph(orbhip_extractor *e, int width, int height, int ba
     }
     HIP_TRY(hipGraphLaunch(e->graph_exec, e->ctx->stream));
     e->last_batch = batch;
+    e->generation++;
     return ORBHIP_OK;
 }
 
@@ -759,16 +826,57 @@ extern "C" int orbhip_extractor_results(orbhip_extractor *e, orbhip_keypoint **d
     return ORBHIP_OK;
 }
 
-static int check_status(orbhip_extractor *e)
+// Host-pointer extraction (what ORBextractor::operator() is): the image rows are gathered into a page-locked copy laid out like the
+// device's level 0 and leave in ONE host-to-device copy; the results (counts, mono indices, keypoints, descriptors -- one device
+// allocation) come back in ONE device-to-host copy into their page-locked mirror, the status word beside them, one synchronisation.
+// round 3 issued one pageable 2-D copy per frame in, two synchronisations and 2 + 2 per-frame copies out.
+static int extract_host_core(orbhip_extractor *e, const uint8_t *h_images, int width, int height, size_t row_stride, size_t frame_stride,
+                             int batch, int lap0, int lap1)
 {
-    int32_t st = 0;
-    HIP_TRY(hipMemcpyAsync(&st, e->P.status, sizeof(st), hipMemcpyDeviceToHost, e->ctx->stream));
-    HIP_TRY(hipStreamSynchronize(e->ctx->stream));
-    if (st) {
-        g_last_error = "device-side list capacity exceeded";
-        (void)hipMemsetAsync(e->P.status, 0, sizeof(int32_t), e->ctx->stream);
+    if (!e || batch <= 0) return ORBHIP_E_BADARG;
+    if (!h_images || width <= 0 || height <= 0) return ORBHIP_E_EMPTY;      // ORBextractor.cc:1072-1073
+    if (row_stride < (size_t)width) return ORBHIP_E_BADARG;
+    HIP_TRY(hipSetDevice(e->ctx->device));
+    int rc = orbhip_extractor_reserve(e, width, height, batch);
+    if (rc) return rc;
+    hipStream_t s = e->ctx->stream;
+    OrbLevel &L0 = e->P.lv[0];
+    L0.img = e->d_level0; L0.img_pitch = e->level0_pitch; L0.img_frame_stride = e->level0_frame_stride;
+    const size_t in_bytes = (size_t)batch * L0.img_frame_stride;
+    if (e->h_in_bytes < in_bytes) {
+        if (e->h_in) (void)hipHostFree(e->h_in);
+        e->h_in = nullptr; e->h_in_bytes = 0;
+        HIP_TRY(hipHostMalloc((void **)&e->h_in, (size_t)e->max_batch * L0.img_frame_stride, hipHostMallocDefault));
+        e->h_in_bytes = (size_t)e->max_batch * L0.img_frame_stride;
     }
-    return st;
+    if (!e->h_out) HIP_TRY(hipHostMalloc((void **)&e->h_out, e->outblob_bytes, hipHostMallocDefault));
+    if (!e->h_status) HIP_TRY(hipHostMalloc((void **)&e->h_status, 256, hipHostMallocDefault));
+    for (int f = 0; f < batch; f++) {
+        const uint8_t *src = h_images + (size_t)f * frame_stride;
+        uint8_t *dst = e->h_in + (size_t)f * L0.img_frame_stride;
+        if (row_stride == (size_t)L0.img_pitch) memcpy(dst, src, (size_t)L0.img_pitch * (height - 1) + width);
+        else for (int y = 0; y < height; y++) memcpy(dst + (size_t)y * L0.img_pitch, src + (size_t)y * row_stride, width);
+    }
+    HIP_TRY(hipMemcpyAsync(L0.img, e->h_in, in_bytes, hipMemcpyHostToDevice, s));
+    e->view_generation = ~0ull;
+    rc = (e->graph_mode && !e->profiling) ? run_pipeline_graph(e, width, height, batch, lap0, lap1) : run_pipeline(e, batch, lap0, lap1);
+    if (rc) return rc;
+    const size_t B = (size_t)e->max_batch, mk = (size_t)e->P.max_kp;
+    if ((size_t)batch == B) HIP_TRY(hipMemcpyAsync(e->h_out, e->d_outblob, e->outblob_bytes, hipMemcpyDeviceToHost, s));
+    else {                                                                   // a smaller batch than reserved: the used rows of each slice
+        HIP_TRY(hipMemcpyAsync(e->h_out, e->d_outblob, 8 * B, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(e->h_out + e->ob_kp, e->d_outblob + e->ob_kp, sizeof(orbhip_keypoint) * mk * batch, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(e->h_out + e->ob_desc, e->d_outblob + e->ob_desc, 32 * mk * batch, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipMemcpyAsync(e->h_status, e->P.status, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (*e->h_status) {
+        g_last_error = "device-side list capacity exceeded";
+        (void)hipMemsetAsync(e->P.status, 0, sizeof(int32_t), s);
+        return *e->h_status;
+    }
+    e->view_generation = e->generation;
+    return ORBHIP_OK;
 }
 
 extern "C" int orbhip_extract_batch_host(orbhip_extractor *e, const uint8_t *h_images, int width, int height,
@@ -776,32 +884,44 @@ extern "C" int orbhip_extract_batch_host(orbhip_extractor *e, const uint8_t *h_i
                                          orbhip_keypoint *kp_out, uint8_t *desc_out, int cap,
                                          int32_t *count_out, int32_t *mono_out)
 {
-    if (!e || batch <= 0) return ORBHIP_E_BADARG;
-    if (!h_images || width <= 0 || height <= 0) return ORBHIP_E_EMPTY;      // ORBextractor.cc:1072-1073
-    if (row_stride < (size_t)width || !kp_out || !desc_out || !count_out || !mono_out) return ORBHIP_E_BADARG;
-    HIP_TRY(hipSetDevice(e->ctx->device));
-    int rc = orbhip_extractor_reserve(e, width, height, batch);
+    if (e && batch > 0 && h_images && width > 0 && height > 0 && (!kp_out || !desc_out || !count_out || !mono_out)) return ORBHIP_E_BADARG;
+    const int rc = extract_host_core(e, h_images, width, height, row_stride, frame_stride, batch, lap0, lap1);
     if (rc) return rc;
-    hipStream_t s = e->ctx->stream;
-    OrbLevel &L0 = e->P.lv[0];
-    L0.img = e->d_level0; L0.img_pitch = e->level0_pitch; L0.img_frame_stride = e->level0_frame_stride;
-    for (int f = 0; f < batch; f++)
-        HIP_TRY(hipMemcpy2DAsync(L0.img + (size_t)f * L0.img_frame_stride, L0.img_pitch, h_images + (size_t)f * frame_stride,
-                                 row_stride, width, height, hipMemcpyHostToDevice, s));
-    rc = (e->graph_mode && !e->profiling) ? run_pipeline_graph(e, width, height, batch, lap0, lap1) : run_pipeline(e, batch, lap0, lap1);
-    if (rc) return rc;
-    std::vector<int32_t> cnt(batch);
-    HIP_TRY(hipMemcpyAsync(cnt.data(), e->P.out_count, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(mono_out, e->P.out_mono, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
-    if ((rc = check_status(e))) return rc;
+    const int32_t *cnt = reinterpret_cast<const int32_t *>(e->h_out), *mono = cnt + e->max_batch;
+    const size_t mk = (size_t)e->P.max_kp;
     for (int f = 0; f < batch; f++) {
-        count_out[f] = cnt[f];
+        count_out[f] = cnt[f]; mono_out[f] = mono[f];
         if (cnt[f] > cap) return ORBHIP_E_CAPACITY;
         if (cnt[f] == 0) continue;
-        HIP_TRY(hipMemcpyAsync(kp_out + (size_t)f * cap, e->P.out_kp + (size_t)f * e->P.max_kp, sizeof(orbhip_keypoint) * cnt[f], hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(desc_out + (size_t)f * cap * 32, e->P.out_desc + (size_t)f * e->P.max_kp * 32, (size_t)32 * cnt[f], hipMemcpyDeviceToHost, s));
+        memcpy(kp_out + (size_t)f * cap, e->h_out + e->ob_kp + sizeof(orbhip_keypoint) * mk * f, sizeof(orbhip_keypoint) * cnt[f]);
+        memcpy(desc_out + (size_t)f * cap * 32, e->h_out + e->ob_desc + 32 * mk * f, (size_t)32 * cnt[f]);
     }
-    HIP_TRY(hipStreamSynchronize(s));
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_extract_batch_host_view(orbhip_extractor *e, const uint8_t *h_images, int width, int height, size_t row_stride,
+                                              size_t frame_stride, int batch, int lap0, int lap1, const orbhip_keypoint **kp_view,
+                                              const uint8_t **desc_view, int *row_capacity, const int32_t **count_view, const int32_t **mono_view)
+{
+    if (e && batch > 0 && h_images && width > 0 && height > 0 && (!kp_view || !desc_view || !row_capacity || !count_view || !mono_view)) return ORBHIP_E_BADARG;
+    const int rc = extract_host_core(e, h_images, width, height, row_stride, frame_stride, batch, lap0, lap1);
+    if (rc) return rc;
+    *kp_view = reinterpret_cast<const orbhip_keypoint *>(e->h_out + e->ob_kp); *desc_view = e->h_out + e->ob_desc; *row_capacity = e->P.max_kp;
+    *count_view = reinterpret_cast<const int32_t *>(e->h_out); *mono_view = *count_view + e->max_batch;
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_extractor_last_frame(orbhip_extractor *e, int frame, const orbhip_keypoint **d_kp, const uint8_t **d_desc,
+                                           const orbhip_keypoint **h_kp_view, const uint8_t **h_desc_view, int32_t *count, unsigned long long *generation)
+{
+    if (!e || !e->max_batch || frame < 0 || frame >= e->last_batch || e->view_generation != e->generation) return ORBHIP_E_BADARG;
+    const size_t mk = (size_t)e->P.max_kp;
+    if (d_kp) *d_kp = e->P.out_kp + mk * frame;
+    if (d_desc) *d_desc = e->P.out_desc + 32 * mk * frame;
+    if (h_kp_view) *h_kp_view = reinterpret_cast<const orbhip_keypoint *>(e->h_out + e->ob_kp) + mk * frame;
+    if (h_desc_view) *h_desc_view = e->h_out + e->ob_desc + 32 * mk * frame;
+    if (count) *count = reinterpret_cast<const int32_t *>(e->h_out)[frame];
+    if (generation) *generation = e->generation;
     return ORBHIP_OK;
 }
 
@@ -849,13 +969,33 @@ extern "C" int orbhip_extractor_get_pyramid_padded(orbhip_extractor *e, int fram
     if (!e || !levels_out || !strides || frame < 0 || frame >= e->last_batch) return ORBHIP_E_BADARG;
     HIP_TRY(hipSetDevice(e->ctx->device));
     hipStream_t s = e->ctx->stream;
+    // every level is one linear device-to-host copy (pitch x rows, page-locked landing area); rows are then laid into the caller's
+    // padded parents on the host, where the border has to be synthesised anyway
+    size_t total = 0;
     for (int l = 0; l < e->nlevels; l++) {
         const OrbLevel &L = e->P.lv[l];
         if (!levels_out[l] || strides[l] < (size_t)L.w + 2 * ORB_EDGE) return ORBHIP_E_BADARG;
-        HIP_TRY(hipMemcpy2DAsync(levels_out[l] + (size_t)ORB_EDGE * strides[l] + ORB_EDGE, strides[l], L.img + (size_t)frame * L.img_frame_stride,
-                                 L.img_pitch, L.w, L.h, hipMemcpyDeviceToHost, s));
+        total += ((size_t)L.img_pitch * L.h + 255) & ~(size_t)255;
+    }
+    if (e->h_pyr_bytes < total) {
+        if (e->h_pyr) (void)hipHostFree(e->h_pyr);
+        e->h_pyr = nullptr; e->h_pyr_bytes = 0;
+        HIP_TRY(hipHostMalloc((void **)&e->h_pyr, total, hipHostMallocDefault));
+        e->h_pyr_bytes = total;
+    }
+    size_t off = 0;
+    for (int l = 0; l < e->nlevels; l++) {
+        const OrbLevel &L = e->P.lv[l];
+        HIP_TRY(hipMemcpyAsync(e->h_pyr + off, L.img + (size_t)frame * L.img_frame_stride, (size_t)L.img_pitch * (L.h - 1) + L.w, hipMemcpyDeviceToHost, s));
+        off += ((size_t)L.img_pitch * L.h + 255) & ~(size_t)255;
     }
     HIP_TRY(hipStreamSynchronize(s));
+    off = 0;
+    for (int l = 0; l < e->nlevels; l++) {
+        const OrbLevel &L = e->P.lv[l];
+        for (int y = 0; y < L.h; y++) memcpy(levels_out[l] + (size_t)(y + ORB_EDGE) * strides[l] + ORB_EDGE, e->h_pyr + off + (size_t)y * L.img_pitch, L.w);
+        off += ((size_t)L.img_pitch * L.h + 255) & ~(size_t)255;
+    }
     // the 19-px BORDER_REFLECT_101 frame (ORBextractor.cc:1167-1173), synthesised on the host: the extraction never reads it
     for (int l = 0; l < e->nlevels; l++) {
         const OrbLevel &L = e->P.lv[l];

@@ -7,6 +7,7 @@
 #include "hip_context.h"
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 namespace ORB_SLAM3 {
 
@@ -17,8 +18,8 @@ static void complain(int rc, const char *what)
 }
 
 ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST)
-    : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST),
-      ctx_(nullptr), ext_(nullptr), stageW_(0), stageH_(0), cap_(0), syncPyramid_(true)
+    : mvImagePyramid(this), nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST),
+      ctx_(nullptr), ext_(nullptr), slot_(nullptr), stageW_(0), stageH_(0), syncPyramid_(false)
 {
     mvImagePyramid.resize(nlevels);
     int rc = orbhip_ctx_create(hip::GetDevice(), nullptr, &ctx_);           // one context (stream) per extractor instance: Frame.cc:109-110
@@ -34,10 +35,12 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int
     orbhip_extractor_features_per_level(ext_, mnFeaturesPerLevel.data());
     umax.resize(16);
     orbhip_extractor_umax(ext_, umax.data());
+    slot_ = hip::RegisterExtractor(ext_, hip::GetDevice());
 }
 
 ORBextractor::~ORBextractor()
 {
+    hip::UnregisterExtractor(slot_);                                         // waits for matcher calls that still read this extractor's arrays
     if (ext_) orbhip_extractor_destroy(ext_);
     if (ctx_) orbhip_ctx_destroy(ctx_);
 }
@@ -52,40 +55,45 @@ int ORBextractor::operator()(cv::InputArray image, cv::InputArray /*mask*/, std:
 #endif
     if (img.empty()) return -1;                                             // ORBextractor.cc:1072-1073
     if (!ext_) { keypoints.clear(); descriptors.release(); return -1; }     // no device (reported by the constructor)
-    if (img.cols != stageW_ || img.rows != stageH_) {                       // device buffers + staging rows: once per image size
+    // the previous extraction's device arrays are about to be overwritten: matcher calls that read them (frame_cache.h) finish first
+    std::unique_lock<std::shared_mutex> writer = hip::LockForExtraction(slot_);
+    mvImagePyramid.stale_ = false;
+    if (img.cols != stageW_ || img.rows != stageH_) {                       // device buffers + page-locked staging: once per image size
         const int rc = orbhip_extractor_reserve(ext_, img.cols, img.rows, 1);
         if (rc != ORBHIP_OK) { fprintf(stderr, "ORBextractor (HIP): reserve %dx%d: %d (%s)\n", img.cols, img.rows, rc, orbhip_last_error()); return -1; }
-        cap_ = orbhip_extractor_max_keypoints(ext_);
-        kpStage_.resize(cap_); descStage_.resize((size_t)cap_ * 32);
         stageW_ = img.cols; stageH_ = img.rows;
     }
-    int32_t count = 0, mono = 0;
-    const int rc = orbhip_extract_batch_host(ext_, img.data, img.cols, img.rows, img.step, img.step * img.rows, 1, vLappingArea[0],
-                                             vLappingArea[1], kpStage_.data(), descStage_.data(), cap_, &count, &mono);
+    const orbhip_keypoint *kpView = nullptr; const uint8_t *descView = nullptr; const int32_t *countView = nullptr, *monoView = nullptr; int rowCap = 0;
+    const int rc = orbhip_extract_batch_host_view(ext_, img.data, img.cols, img.rows, img.step, img.step * img.rows, 1, vLappingArea[0], vLappingArea[1],
+                                                  &kpView, &descView, &rowCap, &countView, &monoView);
     if (rc != ORBHIP_OK) {
         if (rc != ORBHIP_E_EMPTY) fprintf(stderr, "ORBextractor (HIP): extract: %d (%s)\n", rc, orbhip_last_error());
         keypoints.clear(); descriptors.release();
         return -1;
     }
+    const int count = countView[0], mono = monoView[0];
     static_assert(sizeof(cv::KeyPoint) == sizeof(orbhip_keypoint), "KeyPoint layout");
     keypoints.resize(count);                                                // _keypoints = vector<cv::KeyPoint>(nkeypoints), :1100
-    if (count) memcpy((void *)keypoints.data(), kpStage_.data(), sizeof(orbhip_keypoint) * count);
+    if (count) memcpy((void *)keypoints.data(), kpView, sizeof(orbhip_keypoint) * count);       // straight from the page-locked mirror
     if (count == 0) descriptors.release();                                  // :1090-1091
     else {
         descriptors.create(count, 32, CV_8U);                               // :1094
 #ifdef ORBHIP_WITH_OPENCV
-        memcpy(descriptors.getMat().data, descStage_.data(), (size_t)count * 32);
+        memcpy(descriptors.getMat().data, descView, (size_t)count * 32);
 #else
-        memcpy(descriptors.data, descStage_.data(), (size_t)count * 32);
+        memcpy(descriptors.data, descView, (size_t)count * 32);
 #endif
     }
+    writer.unlock();
     if (syncPyramid_) SyncImagePyramid();
+    else mvImagePyramid.stale_ = true;                                      // materialised by the first mvImagePyramid[...] read (Frame.cc:809)
     return mono;
 }
 
 void ORBextractor::SyncImagePyramid()
 {
     if (!ext_) return;
+    mvImagePyramid.stale_ = false;
     padded_.resize(nlevels);
     std::vector<uint8_t *> lv(nlevels);
     std::vector<size_t> st(nlevels);
@@ -102,10 +110,10 @@ void ORBextractor::SyncImagePyramid()
         const int pw = ws[l] + 38, ph = hs[l] + 38;
         // ROI view at (19,19) inside the reflect-101 padded parent, like ORBextractor.cc:1160
 #ifdef ORBHIP_WITH_OPENCV
-        mvImagePyramid[l] = cv::Mat(ph, pw, CV_8U, padded_[l].data(), pw)(cv::Rect(19, 19, ws[l], hs[l]));
+        mvImagePyramid.v_[l] = cv::Mat(ph, pw, CV_8U, padded_[l].data(), pw)(cv::Rect(19, 19, ws[l], hs[l]));
 #else
         (void)ph;
-        mvImagePyramid[l] = cv::Mat(hs[l], ws[l], CV_8U, padded_[l].data() + (size_t)19 * pw + 19, pw);
+        mvImagePyramid.v_[l] = cv::Mat(hs[l], ws[l], CV_8U, padded_[l].data() + (size_t)19 * pw + 19, pw);
 #endif
     }
 }

@@ -10,6 +10,7 @@
 #include <opencv2/core.hpp>
 #endif
 #include "../../include/orbhip.h"
+#include "frame_cache.h"
 
 namespace ORB_SLAM3 {
 
@@ -32,14 +33,35 @@ public:
     std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
     std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
 
-    // PUBLIC in the reference (include/ORBextractor.h:83), read by Frame::ComputeStereoMatches (src/Frame.cc:809,899,913,918)
-    // right after operator() with no further call: operator() fills it itself -- level l is the w_l x h_l ROI at (19,19) of a
-    // reflect-101 padded (w_l+38) x (h_l+38) parent, as ORBextractor.cc:1160-1173 builds it.  That costs one device-to-host
-    // copy of the pyramid per call; callers that never read it (monocular / fisheye tracking, or stereo through
-    // orbhip_compute_stereo_matches_device, which reads the device pyramids) switch it off with SetImagePyramidSync(false).
-    std::vector<cv::Mat> mvImagePyramid;
+    // PUBLIC in the reference (include/ORBextractor.h:83: std::vector<cv::Mat> mvImagePyramid), read by Frame::ComputeStereoMatches
+    // (src/Frame.cc:809,899,913,918) as mvImagePyramid[level] right after operator() with no further call.  Level l is the
+    // w_l x h_l ROI at (19,19) of a reflect-101 padded (w_l+38) x (h_l+38) parent, as ORBextractor.cc:1160-1173 builds it.
+    // Round 4: the pyramid stays on the device until somebody reads it -- the member is a vector-like
+    // object whose element access materialises the host copy of the LATEST extraction on first use (one device-to-host copy per level
+    // into page-locked memory + the border synthesis), so monocular / fisheye tracking, which never reads it, pays nothing, and the
+    // unchanged stereo caller gets exactly what it got before.  SetImagePyramidSync(true) restores the eager copy inside operator().
+    class ImagePyramid {
+    public:
+        explicit ImagePyramid(ORBextractor *owner) : owner_(owner), stale_(false) {}
+        size_t size() const { return v_.size(); }
+        bool empty() const { return v_.empty(); }
+        void resize(size_t n) { v_.resize(n); }
+        cv::Mat &operator[](size_t i) { fresh(); return v_[i]; }
+        const cv::Mat &operator[](size_t i) const { fresh(); return v_[i]; }
+        cv::Mat &at(size_t i) { fresh(); return v_.at(i); }
+        std::vector<cv::Mat>::iterator begin() { fresh(); return v_.begin(); }
+        std::vector<cv::Mat>::iterator end() { fresh(); return v_.end(); }
+        operator std::vector<cv::Mat> &() { fresh(); return v_; }              // code that wants the plain vector
+    private:
+        friend class ORBextractor;
+        void fresh() const { if (stale_) { stale_ = false; owner_->SyncImagePyramid(); } }
+        ORBextractor *owner_;
+        mutable std::vector<cv::Mat> v_;
+        mutable bool stale_;
+    };
+    ImagePyramid mvImagePyramid;
     void SetImagePyramidSync(bool on) { syncPyramid_ = on; }
-    void SyncImagePyramid();                       // explicit refresh (the opt-out case)
+    void SyncImagePyramid();                       // materialise the host pyramid of the latest extraction now
 
 protected:
     int nfeatures; double scaleFactor; int nlevels; int iniThFAST; int minThFAST;
@@ -50,10 +72,9 @@ protected:
 private:
     orbhip_ctx *ctx_;
     orbhip_extractor *ext_;
+    hip::ExtractorSlot *slot_;                     // frame_cache.h: the latest extraction stays on the device for the matchers
     std::vector<std::vector<uint8_t>> padded_;     // backing store of mvImagePyramid (kept across calls)
-    std::vector<orbhip_keypoint> kpStage_;         // staging of the C ABI's output rows (kept across calls, sized once per image size)
-    std::vector<uint8_t> descStage_;
-    int stageW_, stageH_, cap_;
+    int stageW_, stageH_;
     bool syncPyramid_;
     ORBextractor(const ORBextractor &);            // one instance = one device context (not copyable)
     ORBextractor &operator=(const ORBextractor &);

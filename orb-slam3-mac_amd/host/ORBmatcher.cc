@@ -6,6 +6,8 @@
 #include "ORBmatcher.h"
 #include <cstdio>
 #include "hip_context.h"
+#include "frame_cache.h"
+#include "host_prof.h"
 #include <cstdlib>
 #include "cvmath.h"
 
@@ -58,6 +60,7 @@ static void rig_arrays(const Frame &F, std::vector<cv::KeyPoint> &kp, std::vecto
 
 int ORBmatcher::SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMapPoints, const float th, const bool bFarPoints, const float thFarPoints)
 {
+    hip::HostProf prof("SearchByProjection(Frame, vpMapPoints)");
     const bool bFactor = th != 1.0;
     const bool rig = F.Nleft != -1;
     std::vector<orbhip_proj_query> q;
@@ -104,17 +107,26 @@ int ORBmatcher::SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMa
     claims_from(F.mvpMapPoints, n, tm);
     int32_t nmatches = 0;
     int rc;
-    if (!rig)
-        rc = orbhip_search_by_projection_host(thread_ctx(), 1, q.data(), dq.data(), (int)q.size(), (const orbhip_keypoint *)F.mvKeysUn.data(),
-                                              F.mDescriptors.ptr<uint8_t>(), F.mvuRight.empty() ? nullptr : F.mvuRight.data(), n, Frame::mnMinX,
-                                              Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY, TH_HIGH, mfNNratio, 0, tm.data(), &nmatches);
-    else {
+    prof.mark();
+    if (!rig) {
+        // F is normally the frame the extractor has just produced: its features are still on the device (frame_cache.h)
+        hip::ResidentFrame res = hip::FindResident(hip::GetDevice(), F.mvKeysUn.data(), F.mDescriptors.ptr<uint8_t>(), n);
+        if (res)
+            rc = orbhip_search_by_projection_host_resident(thread_ctx(), 1, q.data(), dq.data(), (int)q.size(), (const orbhip_keypoint *)F.mvKeysUn.data(), res.d_kp,
+                                                           res.d_desc, F.mvuRight.empty() ? nullptr : F.mvuRight.data(), n, Frame::mnMinX, Frame::mnMinY,
+                                                           Frame::mnMaxX, Frame::mnMaxY, TH_HIGH, mfNNratio, 0, tm.data(), &nmatches);
+        else
+            rc = orbhip_search_by_projection_host(thread_ctx(), 1, q.data(), dq.data(), (int)q.size(), (const orbhip_keypoint *)F.mvKeysUn.data(),
+                                                  F.mDescriptors.ptr<uint8_t>(), F.mvuRight.empty() ? nullptr : F.mvuRight.data(), n, Frame::mnMinX,
+                                                  Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY, TH_HIGH, mfNNratio, 0, tm.data(), &nmatches);
+    } else {
         std::vector<cv::KeyPoint> kp; std::vector<int32_t> mirror;
         rig_arrays(F, kp, mirror);
         rc = orbhip_search_by_projection_rig_host(thread_ctx(), 1, q.data(), dq.data(), (int)q.size(), (const orbhip_keypoint *)kp.data(),
                                                   F.mDescriptors.ptr<uint8_t>(), n, F.Nleft, mirror.data(), Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX,
                                                   Frame::mnMaxY, TH_HIGH, mfNNratio, 0, tm.data(), &nmatches);
     }
+    prof.mark();
     if (rc != ORBHIP_OK) { fprintf(stderr, "ORBmatcher (HIP): SearchByProjection: %d (%s)\n", rc, orbhip_last_error()); return 0; }
     for (int i = 0; i < n; i++) if (tm[i] >= 0) F.mvpMapPoints[i] = owner[tm[i]];  // F.mvpMapPoints[bestIdx]=pMP (:140, :145, :205, :210)
     return nmatches;
@@ -122,6 +134,7 @@ int ORBmatcher::SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMa
 
 int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono)
 {
+    hip::HostProf prof("SearchByProjection(CurrentFrame, LastFrame)");
     const bool rig = CurrentFrame.Nleft != -1;
     // twc = -Rcw.t()*tcw ; tlc = Rlw*twc + tlw (ORBmatcher.cc:1976-1984), CV_32F matrix products as cvmath.h spells them
     const cvm::V3 twc_ = cvm::mul_t(cvm::block3(CurrentFrame.mTcw), cvm::col3(CurrentFrame.mTcw), -1.0);
@@ -133,6 +146,7 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, 
     std::vector<orbhip_proj_query> q;
     std::vector<uint8_t> dq;
     std::vector<MapPoint *> owner;
+    q.reserve((size_t)LastFrame.N * (rig ? 2 : 1)); dq.reserve((size_t)LastFrame.N * (rig ? 64 : 32)); owner.reserve((size_t)LastFrame.N * (rig ? 2 : 1));
     for (int i = 0; i < LastFrame.N; i++) {                                        // :1989-2023
         MapPoint *pMP = LastFrame.mvpMapPoints[i];
         if (!pMP) continue;
@@ -142,9 +156,9 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, 
         transform(CurrentFrame.mTcw, pMP->GetWorldPos(), x3Dc);
         const float invzc = 1.0 / x3Dc[2];
         if (invzc < 0) continue;
-        cv::Mat m3D(3, 1, CV_32F);
-        for (int k = 0; k < 3; k++) m3D.at<float>(k) = x3Dc[k];
-        cv::Point2f uv = CurrentFrame.mpCamera->project(m3D);
+        // (the reference hands project() the cv::Mat x3Dc, :2003: Pinhole.cpp:41-47 / KannalaBrandt8.cpp:71-76 read its three floats and call
+        // the cv::Point3f overload, which is called directly here -- one heap allocation per map point less)
+        cv::Point2f uv = CurrentFrame.mpCamera->project(cv::Point3f(x3Dc[0], x3Dc[1], x3Dc[2]));
         if (uv.x < CurrentFrame.mnMinX || uv.x > CurrentFrame.mnMaxX) continue;
         if (uv.y < CurrentFrame.mnMinY || uv.y > CurrentFrame.mnMaxY) continue;
         int nLastOctave = (LastFrame.Nleft == -1 || i < LastFrame.Nleft) ? LastFrame.mvKeys[i].octave : LastFrame.mvKeysRight[i - LastFrame.Nleft].octave;
@@ -165,9 +179,7 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, 
         if (rig) {                                                                // the same point in the right camera (:2089-2105)
             const cvm::V3 xr_ = cvm::mul_add(cvm::block3(CurrentFrame.mTrl), cvm::V3{{x3Dc[0], x3Dc[1], x3Dc[2]}}, cvm::col3(CurrentFrame.mTrl));   // mTrl.R * x3Dc + mTrl.col(3)
             const float x3Dr[3] = {xr_(0), xr_(1), xr_(2)};
-            cv::Mat m3Dr(3, 1, CV_32F);
-            for (int k = 0; k < 3; k++) m3Dr.at<float>(k) = x3Dr[k];
-            const cv::Point2f uvr = CurrentFrame.mpCamera->project(m3Dr);        // (the reference projects through mpCamera here, :2092)
+            const cv::Point2f uvr = CurrentFrame.mpCamera->project(cv::Point3f(x3Dr[0], x3Dr[1], x3Dr[2]));      // (the reference projects through mpCamera here, :2092)
             orbhip_proj_query er = e;
             er.u = uvr.x; er.v = uvr.y; er.has_obs = e.has_obs | 2;
             q.push_back(er); owner.push_back(pMP);
@@ -179,18 +191,28 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, 
     claims_from(CurrentFrame.mvpMapPoints, n, tm);
     int32_t nmatches = 0;
     int rc;
-    if (!rig)
-        rc = orbhip_search_by_projection_host(thread_ctx(), 0, q.data(), dq.data(), (int)q.size(), (const orbhip_keypoint *)CurrentFrame.mvKeysUn.data(),
-                                              CurrentFrame.mDescriptors.ptr<uint8_t>(), CurrentFrame.mvuRight.empty() ? nullptr : CurrentFrame.mvuRight.data(),
-                                              n, Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY, TH_HIGH, 0.f, mbCheckOrientation ? 1 : 0,
-                                              tm.data(), &nmatches);
-    else {
+    prof.mark();
+    if (!rig) {
+        // CurrentFrame is the frame the extractor has just produced (Tracking::TrackWithMotionModel, src/Tracking.cc:1911): its keypoints
+        // and descriptors are still on the device, only the queries travel (frame_cache.h)
+        hip::ResidentFrame res = hip::FindResident(hip::GetDevice(), CurrentFrame.mvKeysUn.data(), CurrentFrame.mDescriptors.ptr<uint8_t>(), n);
+        if (res)
+            rc = orbhip_search_by_projection_host_resident(thread_ctx(), 0, q.data(), dq.data(), (int)q.size(), (const orbhip_keypoint *)CurrentFrame.mvKeysUn.data(),
+                                                           res.d_kp, res.d_desc, CurrentFrame.mvuRight.empty() ? nullptr : CurrentFrame.mvuRight.data(), n, Frame::mnMinX,
+                                                           Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY, TH_HIGH, 0.f, mbCheckOrientation ? 1 : 0, tm.data(), &nmatches);
+        else
+            rc = orbhip_search_by_projection_host(thread_ctx(), 0, q.data(), dq.data(), (int)q.size(), (const orbhip_keypoint *)CurrentFrame.mvKeysUn.data(),
+                                                  CurrentFrame.mDescriptors.ptr<uint8_t>(), CurrentFrame.mvuRight.empty() ? nullptr : CurrentFrame.mvuRight.data(),
+                                                  n, Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY, TH_HIGH, 0.f, mbCheckOrientation ? 1 : 0,
+                                                  tm.data(), &nmatches);
+    } else {
         std::vector<cv::KeyPoint> kp; std::vector<int32_t> mirror;
         rig_arrays(CurrentFrame, kp, mirror);
         rc = orbhip_search_by_projection_rig_host(thread_ctx(), 0, q.data(), dq.data(), (int)q.size(), (const orbhip_keypoint *)kp.data(),
                                                   CurrentFrame.mDescriptors.ptr<uint8_t>(), n, CurrentFrame.Nleft, nullptr, Frame::mnMinX, Frame::mnMinY,
                                                   Frame::mnMaxX, Frame::mnMaxY, TH_HIGH, 0.f, mbCheckOrientation ? 1 : 0, tm.data(), &nmatches);
     }
+    prof.mark();
     if (rc != ORBHIP_OK) { fprintf(stderr, "ORBmatcher (HIP): SearchByProjection: %d (%s)\n", rc, orbhip_last_error()); return 0; }
     // A keypoint taken in this call holds the taker's map point.  One that was taken and then dropped by the rotation check comes
     // back as free (-1): the reference sets it to NULL (:2170), which it already is at the reference's call sites
@@ -206,10 +228,16 @@ int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Po
     vnMatches12 = std::vector<int>(n1, -1);                                        // :713
     static_assert(sizeof(cv::Point2f) == 8 && sizeof(int) == 4, "layout");
     int32_t nmatches = 0;
-    const int rc = orbhip_search_for_initialization_host(thread_ctx(), (const orbhip_keypoint *)F1.mvKeysUn.data(), F1.mDescriptors.ptr<uint8_t>(), n1,
-                                                         (const orbhip_keypoint *)F2.mvKeysUn.data(), F2.mDescriptors.ptr<uint8_t>(), n2, Frame::mnMinX,
-                                                         Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY, windowSize, mfNNratio, mbCheckOrientation ? 1 : 0,
-                                                         (float *)vbPrevMatched.data(), (int32_t *)vnMatches12.data(), &nmatches);
+    // F2 is the frame just extracted (Tracking::MonocularInitialization, src/Tracking.cc:1506): resident on the device (frame_cache.h)
+    hip::ResidentFrame res = hip::FindResident(hip::GetDevice(), F2.mvKeysUn.data(), n2 ? F2.mDescriptors.ptr<uint8_t>() : nullptr, n2);
+    const int rc = res ? orbhip_search_for_initialization_host_resident(thread_ctx(), (const orbhip_keypoint *)F1.mvKeysUn.data(), F1.mDescriptors.ptr<uint8_t>(), n1,
+                                                                        (const orbhip_keypoint *)F2.mvKeysUn.data(), res.d_kp, res.d_desc, n2, Frame::mnMinX, Frame::mnMinY,
+                                                                        Frame::mnMaxX, Frame::mnMaxY, windowSize, mfNNratio, mbCheckOrientation ? 1 : 0,
+                                                                        (float *)vbPrevMatched.data(), (int32_t *)vnMatches12.data(), &nmatches)
+                       : orbhip_search_for_initialization_host(thread_ctx(), (const orbhip_keypoint *)F1.mvKeysUn.data(), F1.mDescriptors.ptr<uint8_t>(), n1,
+                                                               (const orbhip_keypoint *)F2.mvKeysUn.data(), F2.mDescriptors.ptr<uint8_t>(), n2, Frame::mnMinX,
+                                                               Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY, windowSize, mfNNratio, mbCheckOrientation ? 1 : 0,
+                                                               (float *)vbPrevMatched.data(), (int32_t *)vnMatches12.data(), &nmatches);
     if (rc != ORBHIP_OK) { fprintf(stderr, "ORBmatcher (HIP): SearchForInitialization: %d (%s)\n", rc, orbhip_last_error()); return 0; }
     return nmatches;
 }
@@ -251,11 +279,18 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vp
     }
     std::vector<int32_t> matchF(F.N > 0 ? F.N : 1, -1);
     int32_t nmatches = 0;
-    const int rc = orbhip_search_by_bow_host(thread_ctx(), kIds.data(), kStart.data(), kFeat.data(), (int)kIds.size(), valid.data(),
-                                             (const orbhip_keypoint *)pk, pKF->mDescriptors.ptr<uint8_t>(), nK,
-                                             fIds.data(), fStart.data(), fFeat.data(), (int)fIds.size(), (const orbhip_keypoint *)pf,
-                                             F.mDescriptors.ptr<uint8_t>(), F.N, rig ? F.Nleft : -1, mfNNratio, mbCheckOrientation ? 1 : 0,
-                                             matchF.data(), &nmatches);
+    // F is the frame just extracted (Tracking::TrackReferenceKeyFrame, src/Tracking.cc:1757): resident on the device (frame_cache.h)
+    hip::ResidentFrame res;
+    if (!rig) res = hip::FindResident(hip::GetDevice(), pf, F.N > 0 ? F.mDescriptors.ptr<uint8_t>() : nullptr, F.N);
+    const int rc = res ? orbhip_search_by_bow_host_resident(thread_ctx(), kIds.data(), kStart.data(), kFeat.data(), (int)kIds.size(), valid.data(),
+                                                            (const orbhip_keypoint *)pk, pKF->mDescriptors.ptr<uint8_t>(), nK, fIds.data(), fStart.data(), fFeat.data(),
+                                                            (int)fIds.size(), (const orbhip_keypoint *)pf, res.d_kp, res.d_desc, F.N, mfNNratio,
+                                                            mbCheckOrientation ? 1 : 0, matchF.data(), &nmatches)
+                       : orbhip_search_by_bow_host(thread_ctx(), kIds.data(), kStart.data(), kFeat.data(), (int)kIds.size(), valid.data(),
+                                                   (const orbhip_keypoint *)pk, pKF->mDescriptors.ptr<uint8_t>(), nK,
+                                                   fIds.data(), fStart.data(), fFeat.data(), (int)fIds.size(), (const orbhip_keypoint *)pf,
+                                                   F.mDescriptors.ptr<uint8_t>(), F.N, rig ? F.Nleft : -1, mfNNratio, mbCheckOrientation ? 1 : 0,
+                                                   matchF.data(), &nmatches);
     if (rc != ORBHIP_OK) { fprintf(stderr, "orbhip SearchByBoW: %s\n", orbhip_last_error()); return 0; }
     for (int j = 0; j < F.N; j++)
         if (matchF[j] >= 0) vpMapPointMatches[j] = vpMapPointsKF[matchF[j]];

@@ -8,9 +8,13 @@
 // unreachable bRedrawError file dump (:2183-2200, :2209-2251: behind a `return`).
 #include "Optimizer.h"
 #include "optimizer_common.h"
+#include "host_prof.h"
 #include <cstdio>
 #include "hip_context.h"
 #include <list>
+#include <unordered_map>
+#include <tuple>
+#include <map>
 #include <utility>
 #include "../../include/orbhip.h"
 
@@ -20,6 +24,7 @@ using namespace optc;
 
 void Optimizer::LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Map *pMap, int &num_fixedKF)
 {
+    hip::HostProf prof("LocalBundleAdjustment(KeyFrame*)");
     // Local KeyFrames: First Breath Search from Current Keyframe (:1703-1717)
     std::list<KeyFrame *> lLocalKeyFrames;
     lLocalKeyFrames.push_back(pKF);
@@ -51,18 +56,26 @@ void Optimizer::LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Map *pMap
         }
     }
 
-    // Fixed Keyframes. Keyframes that see Local MapPoints but that are not Local Keyframes (:1763-1780)
+    // Fixed Keyframes. Keyframes that see Local MapPoints but that are not Local Keyframes (:1763-1780).  MapPoint::GetObservations
+    // returns a COPY of the point's std::map (under its mutex): the reference takes one here and a second one when it builds the
+    // edges (:1929); this shim keeps the first snapshot, flattened, and builds the edges from it -- 2000 map copies instead of 4000
     std::list<KeyFrame *> lFixedCameras;
+    std::vector<std::pair<KeyFrame *, std::tuple<int, int>>> obsFlat;
+    std::vector<int> obsStart;
+    obsFlat.reserve(lLocalMapPoints.size() * 8); obsStart.reserve(lLocalMapPoints.size() + 1);
     for (std::list<MapPoint *>::iterator lit = lLocalMapPoints.begin(), lend = lLocalMapPoints.end(); lit != lend; lit++) {
         std::map<KeyFrame *, std::tuple<int, int>> observations = (*lit)->GetObservations();
+        obsStart.push_back((int)obsFlat.size());
         for (std::map<KeyFrame *, std::tuple<int, int>>::iterator mit = observations.begin(), mend = observations.end(); mit != mend; mit++) {
             KeyFrame *pKFi = mit->first;
+            obsFlat.push_back(*mit);
             if (pKFi->mnBALocalForKF != pKF->mnId && pKFi->mnBAFixedForKF != pKF->mnId) {
                 pKFi->mnBAFixedForKF = pKF->mnId;
                 if (!pKFi->isBad() && pKFi->GetMap() == pCurrentMap) lFixedCameras.push_back(pKFi);
             }
         }
     }
+    obsStart.push_back((int)obsFlat.size());
     num_fixedKF = lFixedCameras.size() + num_fixedKF;
     if (num_fixedKF < 2) {
         // "We set 2 KFs to fixed to avoid a degree of freedom in scale" (:1782-1817).  The reference reads pLowerKf / pSecondLowerKF
@@ -83,7 +96,7 @@ void Optimizer::LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Map *pMap
     }
 
     // ---- SoA packing in the vertex / edge insertion order of :1850-2034 (was: the g2o graph) -------------------------------
-    std::map<KeyFrame *, int> kfIndex;
+    std::unordered_map<KeyFrame *, int> kfIndex;
     std::vector<KeyFrame *> vpKFs;
     std::vector<uint8_t> fixed;
     for (KeyFrame *pKFi : lLocalKeyFrames) { kfIndex[pKFi] = vpKFs.size(); vpKFs.push_back(pKFi); fixed.push_back(pKFi->mnId == pMap->GetInitKFid()); }   // :1850-1860
@@ -97,17 +110,18 @@ void Optimizer::LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Map *pMap
     std::vector<double> points((size_t)3 * nMP);
     std::vector<int32_t> ePose, ePoint; std::vector<double> obs, invS2; std::vector<uint8_t> eType;
     std::vector<KeyFrame *> vpEdgeKF; std::vector<MapPoint *> vpEdgeMP;
+    ePose.reserve(obsFlat.size()); ePoint.reserve(obsFlat.size()); obs.reserve(3 * obsFlat.size()); invS2.reserve(obsFlat.size()); eType.reserve(obsFlat.size());
+    vpEdgeKF.reserve(obsFlat.size()); vpEdgeMP.reserve(obsFlat.size());
     size_t nMonoEdges = 0, nStereoEdges = 0;
     KeyFrame *pRigKF = nullptr;
     for (int l = 0; l < nMP; l++) {
         MapPoint *pMP = vpMPs[l];
         const cv::Mat Xw = pMP->GetWorldPos();                                        // Converter::toVector3d, :1923
         for (int k = 0; k < 3; k++) points[(size_t)3 * l + k] = (double)Xw.at<float>(k);
-        const std::map<KeyFrame *, std::tuple<int, int>> observations = pMP->GetObservations();
-        for (std::map<KeyFrame *, std::tuple<int, int>>::const_iterator mit = observations.begin(), mend = observations.end(); mit != mend; mit++) {
+        for (const std::pair<KeyFrame *, std::tuple<int, int>> *mit = obsFlat.data() + obsStart[l], *mend = obsFlat.data() + obsStart[l + 1]; mit != mend; mit++) {     // (:1929: in std::map order)
             KeyFrame *pKFi = mit->first;
             if (pKFi->isBad() || pKFi->GetMap() != pCurrentMap) continue;             // :1937
-            std::map<KeyFrame *, int>::iterator ki = kfIndex.find(pKFi);
+            std::unordered_map<KeyFrame *, int>::iterator ki = kfIndex.find(pKFi);
             if (ki == kfIndex.end()) continue;                                        // (g2o: optimizer.vertex(id) == NULL -> addEdge refuses the edge)
             const int leftIndex = std::get<0>(mit->second);
             if (leftIndex != -1 && pKFi->mvuRight[leftIndex] < 0) {                   // Monocular observation (:1942-1968)
@@ -172,6 +186,7 @@ void Optimizer::LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Map *pMap
     std::vector<uint8_t> outlier(nE ? nE : 1, 0);
     orbhip_ba_stats st;
     memset(&st, 0, sizeof(st));
+    prof.mark();
     if (nE > 0 && nKF > 0 && nMP > 0) {
         orbhip_ctx *ctx = thread_ctx();
         double *pp = poses.data(), *px = points.data();
@@ -185,6 +200,7 @@ void Optimizer::LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Map *pMap
         }
     }
 
+    prof.mark();
     // Check inlier observations (:2122-2173): edges whose chi2 exceeds the gate or whose depth is not positive
     std::vector<std::pair<KeyFrame *, MapPoint *>> vToErase;
     vToErase.reserve(nE);
@@ -219,9 +235,9 @@ void Optimizer::LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Map *pMap
         KeyFrame *pKFi = *lit;
         pKFi->SetPose(toCvMat(&poses[(size_t)7 * kfIndex[pKFi]]));
     }
+    cv::Mat X(3, 1, CV_32F);                                                          // (SetWorldPos copies: one buffer serves every point)
     for (int l = 0; l < nMP; l++) {
         MapPoint *pMP = vpMPs[l];
-        cv::Mat X(3, 1, CV_32F);
         for (int k = 0; k < 3; k++) X.at<float>(k) = (float)points[(size_t)3 * l + k];
         pMP->SetWorldPos(X);
         pMP->UpdateNormalAndDepth();

@@ -12,6 +12,7 @@
 #include <mutex>
 #include <vector>
 #include "optimizer_common.h"
+#include "host_prof.h"
 
 namespace ORB_SLAM3 {
 
@@ -19,6 +20,7 @@ using namespace optc;
 
 int Optimizer::PoseOptimization(Frame *pFrame)
 {
+    hip::HostProf prof("PoseOptimization(Frame*)");
     int nInitialCorrespondences = 0;
     const int N = pFrame->N;
     std::vector<double> Xw, obs, invS2;
@@ -71,9 +73,11 @@ int Optimizer::PoseOptimization(Frame *pFrame)
     std::vector<uint8_t> outlier(n, 0);
     int32_t nInliers = 0, stats[4] = {0, 0, 0, 0};
     orbhip_ctx *ctx = thread_ctx();
+    prof.mark();
     const int rc = ctx ? orbhip_pose_optimization_host(ctx, Xw.data(), obs.data(), invS2.data(), n, fx, fy, cx, cy, (double)pFrame->mbf, model ? kb : nullptr,
                                                        rig ? &cam2 : nullptr, (rig && anyRight) ? right.data() : nullptr, pose, outlier.data(), &nInliers, stats)
                        : ORBHIP_E_NODEVICE;
+    prof.mark();
     if (rc != ORBHIP_OK) {
         // the reference has no failure path: leave the frame's pose and flags as they are and report no inliers (Tracking treats the frame as lost)
         fprintf(stderr, "PoseOptimization: HIP solver failed (%d: %s)\n", rc, orbhip_last_error());

@@ -5,6 +5,7 @@
 //                                   Optimizer::LocalBundleAdjustment on it and dumps the resulting map (the test compares it
 //                                   with the CPU oracle run on the same window)
 //   host_smoke match <in> <out>     builds Frames + MapPoints, runs the ORBmatcher methods and dumps their results
+//   host_smoke latency [reps]       wall-clock time per call of the classes themselves (host_latency.cc), one JSON object on stdout
 //   host_smoke liba <in> <out>      builds a temporal chain of inertial KeyFrames (+ fixed visual ones), runs Optimizer::LocalInertialBA
 #include <cstdio>
 #include <cstdlib>
@@ -311,9 +312,13 @@ int match_smoke(const char *in, const char *out);            // host_match_smoke
 int kf_smoke(const char *in, const char *out);
 int poseopt_smoke(const char *in, const char *out);
 int mergeba_smoke(const char *in, const char *out);
+int latency_main(int reps);                                   // host_latency.cc
+int cachecheck_main();
 
 int main(int argc, char **argv)
 {
+    if (argc >= 2 && std::string(argv[1]) == "cachecheck") return cachecheck_main();
+    if (argc >= 2 && std::string(argv[1]) == "latency") return latency_main(argc >= 3 ? atoi(argv[2]) : 20);
     if (argc == 4 && std::string(argv[1]) == "lba") return lba_smoke(argv[2], argv[3]);
     if (argc == 4 && std::string(argv[1]) == "match") return match_smoke(argv[2], argv[3]);
     if (argc == 4 && std::string(argv[1]) == "liba") return liba_smoke(argv[2], argv[3]);

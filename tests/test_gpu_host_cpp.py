@@ -22,6 +22,30 @@ def test_host_cpp_smoke():
     assert r.returncode == 0 and "HOST_CPP_OK" in r.stdout, r.stdout
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("pageable", [0, 1])
+def test_resident_frame_and_lazy_pyramid_change_no_result(pageable):
+    """Round 4: the host classes keep the extractor's latest frame on the device for the matchers (host/frame_cache.h), send a call's
+    arrays as one page-locked blob, and copy the pyramid back only when mvImagePyramid is read.  `host_smoke cachecheck` runs the
+    Tracking-side matchers on an extracted frame with the cache on and off (and, here, with round 3's per-array pageable copies) and
+    compares every output, and the lazily materialised pyramid with the eager copy, byte for byte."""
+    env = dict(os.environ, ORBHIP_HOST_PAGEABLE=str(pageable))
+    r = subprocess.run([EXE, "cachecheck"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120, env=env)
+    assert r.returncode == 0 and "HOST_CACHE_OK" in r.stdout, r.stdout
+
+
+@pytest.mark.gpu
+def test_host_class_latency_probe_runs():
+    """`host_smoke latency` (bench.py's latency.host_classes source) prints one JSON object with every timed call."""
+    import json
+    r = subprocess.run([EXE, "latency", "3"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout)
+    for k in ("extract_one_frame", "extract_pyramid_first_read", "search_by_projection_last_frame", "search_by_projection_local_map",
+              "pose_optimization_one_frame", "local_ba_one_window"):
+        assert d[k]["host_class_ms"] > 0
+
+
 # ------------------------------------------------------------------------------------------------ Optimizer::LocalBundleAdjustment
 def _R_from_quat(q):
     import synth_ba
