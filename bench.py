@@ -270,6 +270,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-latency", dest="latency", action="store_false", help="skip the batch-1 latency object")
     ap.add_argument("--no-hd-leg", dest="hd_leg", action="store_false", help="skip the 1920x1080 leg of the default (vga) run")
     ap.add_argument("--hd-frames", type=int, default=512, help="frames of the hd leg (512 = BASELINE config #3's per-GPU shard)")
+    ap.add_argument("--no-4k-leg", dest="uhd_leg", action="store_false", help="skip the 3840x2160 leg of the default (vga) run")
+    ap.add_argument("--4k-frames", dest="uhd_frames", type=int, default=128, help="frames of the 4k leg")
     args = ap.parse_args(argv)
     w, h, nf, b, sp = WORKLOADS[args.workload]
     args.width = args.width or w
@@ -963,11 +965,12 @@ def main():
         latency["host_classes"] = host_classes
 
     # ---- BASELINE config #3's per-GPU shard beside the default line: 1920x1080, 2000 features, 512 frames, same step
-    hd = None
-    if args.hd_leg and (W, H) == (640, 480) and world == 1:
+    # ---- the other image sizes north_star names, beside the default line: the same step (extract + 2-NN + SearchForInitialization) on
+    # 1920x1080 (BASELINE config #3's per-GPU shard) and on 3840x2160 frames; sampled frames are checked against the oracle bit for bit
+    # when the CPU baselines run
+    def big_leg(tag, HW, HH, HF, HB, HS, seed, what):
         import hashlib
-        HW, HH, HF, HB, HS = 1920, 1080, 2000, args.hd_frames, 3
-        h_imgs = synth_frames_parallel(orbhip, HW, HH, HB, 20241004, 0)
+        h_imgs = synth_frames_parallel(orbhip, HW, HH, HB, seed, 0)
         dh = torch.from_numpy(h_imgs).cuda()
         exh = orbhip.Extractor(ctx, HF, 1.2, 8, 20, 7)
         exh.reserve(HW, HH, HB)
@@ -979,7 +982,7 @@ def main():
         hk, hd_, hc, _ = exh.results_device()
         hs = mk * 32
 
-        def hd_step():
+        def leg_step():
             exh.extract_device(dh.data_ptr(), HW, HH, HW, HW * HH, HB, (0, 0))
             orbhip.match_bf2nn_device(ctx, hd_, hc, hs, hd_ + hs, hc + 4, hs, HB - 1, mk, 0.7, h_idx2.data_ptr(), h_dist2.data_ptr(), h_acc.data_ptr())
             orbhip.match_bf2nn_device(ctx, hd_ + (HB - 1) * hs, hc + 4 * (HB - 1), hs, hd_, hc, hs, 1, mk, 0.7, h_idx2.data_ptr() + (HB - 1) * mk * 8,
@@ -987,12 +990,12 @@ def main():
             orbhip.prev_matched_init_device(ctx, hk, mk, HB - 1, mk, h_prev.data_ptr())
             orbhip.search_for_initialization_device(ctx, hk, hd_, hc, hk + mk * 28, hd_ + hs, hc + 4, HB - 1, mk, mk, (0.0, 0.0, float(HW), float(HH)), 100,
                                                     0.9, True, h_prev.data_ptr(), h_m12.data_ptr(), h_nm.data_ptr())
-        hd_step(); sync()
+        leg_step(); sync()
         t0 = time.perf_counter()
         for _ in range(HS):
-            hd_step()
+            leg_step()
         sync()
-        dt_hd = time.perf_counter() - t0
+        dt_leg = time.perf_counter() - t0
         ctx.check_status()
         # digest of sampled frames (keypoint records + descriptors as the C ABI returns them) and the oracle's digest of the same frames
         sample = sorted({0, HB // 2, HB - 1})
@@ -1000,15 +1003,25 @@ def main():
         dig = hashlib.sha256()
         for gk, gd, gm in got:
             dig.update(gk.tobytes()); dig.update(gd.tobytes())
-        hd = {"metric": "ORB extract+match frames/sec", "value": round(HB * HS / dt_hd, 1), "unit": "frames/s", "steps": HS, "ms_per_step": round(dt_hd / HS * 1e3, 3),
-              "config": {"workload": "hd: synthetic 1920x1080 batch=%d per GPU (BASELINE config #3's shard of 4096 frames over 8 GPUs), 8-level pyramid, 2000 feats/frame, "
-                                     "same step as the main line" % HB},
-              "keypoints_sampled_frames": [int(len(g[0])) for g in got], "sampled_frames": sample,
-              "sha256_keypoints_and_descriptors_of_sampled_frames": dig.hexdigest(),
-              "algorithmic_GBps": round(algorithmic_bytes(HW, HH, float(np.mean([len(g[0]) for g in got])), 0)["total"] * HB * HS / dt_hd / 1e9, 1)}
-        hd_sample_imgs = h_imgs[sample].copy()
+        leg = {"metric": "ORB extract+match frames/sec", "value": round(HB * HS / dt_leg, 1), "unit": "frames/s", "steps": HS, "ms_per_step": round(dt_leg / HS * 1e3, 3),
+               "config": {"workload": what % HB}, "nfeatures": HF,
+               "keypoints_sampled_frames": [int(len(g[0])) for g in got], "sampled_frames": sample,
+               "sha256_keypoints_and_descriptors_of_sampled_frames": dig.hexdigest(),
+               "algorithmic_GBps": round(algorithmic_bytes(HW, HH, float(np.mean([len(g[0]) for g in got])), 0)["total"] * HB * HS / dt_leg / 1e9, 1)}
+        sample_imgs = h_imgs[sample].copy()
         exh.close()
         del dh, h_imgs
+        torch.cuda.empty_cache()
+        return leg, sample_imgs
+
+    hd, uhd, hd_sample_imgs, uhd_sample_imgs = None, None, None, None
+    if args.hd_leg and (W, H) == (640, 480) and world == 1:
+        hd, hd_sample_imgs = big_leg("hd", 1920, 1080, 2000, args.hd_frames, 3, 20241004,
+                                     "hd: synthetic 1920x1080 batch=%d per GPU (BASELINE config #3's shard of 4096 frames over 8 GPUs), 8-level pyramid, 2000 feats/frame, "
+                                     "same step as the main line")
+    if args.uhd_leg and (W, H) == (640, 480) and world == 1:
+        uhd, uhd_sample_imgs = big_leg("4k", 3840, 2160, 2000, args.uhd_frames, 3, 20241005,
+                                       "4k: synthetic 3840x2160 batch=%d per GPU, 8-level pyramid, 2000 feats/frame, same step as the main line (north_star: VGA / HD / 4K batches)")
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
@@ -1106,6 +1119,8 @@ def main():
             out["inertial_ba"] = inertial
         if hd is not None:
             out["hd"] = hd
+        if uhd is not None:
+            out["4k"] = uhd
         if latency is not None:
             out["latency"] = latency
         if world == 1 and not args.no_cpu_baseline:
@@ -1122,20 +1137,22 @@ def main():
                     out["tracking"][name]["cpu_baseline"] = v
             if stereo is not None and stereo_host is not None:
                 out["stereo"]["cpu_baseline"] = stereo_cpu_baseline(stereo_host[0], stereo_host[1], args.nfeatures, 40.0 / 458.0, 40.0)
-            if hd is not None:
+            for key, leg, simgs in (("hd", hd, hd_sample_imgs), ("4k", uhd, uhd_sample_imgs)):
+                if leg is None:
+                    continue
                 import hashlib
                 import oracle_bind as ob
-                oe = ob.OracleExtractor(2000, 1.2, 8, 20, 7)
+                oe = ob.OracleExtractor(leg["nfeatures"], 1.2, 8, 20, 7)
                 dig = hashlib.sha256()
                 t0 = time.time()
-                for im in hd_sample_imgs:
+                for im in simgs:
                     ok_, od_, _ = oe.extract(im, (0, 0))
                     dig.update(ok_.tobytes()); dig.update(od_.tobytes())
-                t_or = (time.time() - t0) / len(hd_sample_imgs)
-                out["hd"]["oracle_sha256_of_the_same_frames"] = dig.hexdigest()
-                out["hd"]["bit_exact_vs_oracle_on_sampled_frames"] = dig.hexdigest() == hd["sha256_keypoints_and_descriptors_of_sampled_frames"]
-                out["hd"]["cpu_oracle_extract_ms_1thread"] = round(t_or * 1e3, 1)
-                assert out["hd"]["bit_exact_vs_oracle_on_sampled_frames"], "HD leg: sampled frames differ from the oracle"
+                t_or = (time.time() - t0) / len(simgs)
+                out[key]["oracle_sha256_of_the_same_frames"] = dig.hexdigest()
+                out[key]["bit_exact_vs_oracle_on_sampled_frames"] = dig.hexdigest() == leg["sha256_keypoints_and_descriptors_of_sampled_frames"]
+                out[key]["cpu_oracle_extract_ms_1thread"] = round(t_or * 1e3, 1)
+                assert out[key]["bit_exact_vs_oracle_on_sampled_frames"], "%s leg: sampled frames differ from the oracle" % key
             if latency is not None:
                 import oracle_bind as ob
                 oe = ob.OracleExtractor(args.nfeatures, 1.2, 8, 20, 7)

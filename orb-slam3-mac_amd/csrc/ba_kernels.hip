@@ -167,7 +167,7 @@ __device__ __forceinline__ void quat_norm_rot(double *q)
 __device__ __forceinline__ void R_to_quat(const double *R, double *q)
 {
     // Eigen::Quaterniond(Matrix3d): trace branch, else the largest diagonal element picks (i,j,k); written out
-    // per case so that every index is a compile-time constant (no scratch memory)
+    // per case so that every index is a compile-time constant
     double t = R[0] + R[4] + R[8];
     if (t > 0) {
         t = sqrt(t + 1.0);
@@ -213,8 +213,10 @@ __device__ __forceinline__ void se3_oplus(const double *u, const double *pose, d
 #pragma unroll
         for (int i = 0; i < 9; i++) { R[i] = (i % 4 == 0 ? 1.0 : 0.0) + O[i] + O2[i]; V[i] = R[i]; }
     } else {
-        const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta);
-        const double c = (theta - sin(theta)) / (theta * theta * theta);
+        double sn, cs;
+        sincos(theta, &sn, &cs);                             // one argument reduction for both (the same values sin() and cos() return)
+        const double a = sn / theta, b = (1 - cs) / (theta * theta);
+        const double c = (theta - sn) / (theta * theta * theta);
 #pragma unroll
         for (int i = 0; i < 9; i++) {
             const double I = (i % 4 == 0 ? 1.0 : 0.0);
@@ -2456,6 +2458,18 @@ struct PoArgs {
     int stage_cap;                      // edges per frame the four-wave kernel stages in LDS (0: none)
 };
 
+#ifdef PO_PROF
+__device__ long long g_po_prof[8];            // debug build only (EXTRA=-DPO_PROF): cycles of build walk / 28 block sums / solve + oplus / trial walk / its sum / reclassification, trials
+#define PO_T(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const long long t_ = clock64(); g_po_prof[i] += t_ - t_prev; t_prev = t_; } } while (0)
+extern "C" int orbhip_debug_po_prof(long long *out8, int reset)
+{
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_po_prof), 64) != hipSuccess) return -1;
+    if (reset) { long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_po_prof), z, 64) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define PO_T(i) do { } while (0)
+#endif
 template <int N, int NT = 256>
 __device__ __forceinline__ void po_block_sum(double (&v)[N], double (*red)[PO_NRED])
 {
@@ -2478,6 +2492,55 @@ __device__ __forceinline__ void po_block_sum(double (&v)[N], double (*red)[PO_NR
         for (int w = 1; w < NT / 64; w++) s += red[w][k];
         v[k] = s;
     }
+}
+
+// The 28 sums of a build step for the four-wave forms (round 4).  28 wave-level DPP trees of doubles were 3.8 k cycles per step -- 17 % of
+// a one-frame call (tools/po_prof_probe.py) -- because every one of them is a chain of 6 dependent (2 x v_mov_dpp + v_add_f64).  Here the
+// workgroup transposes through LDS instead: every thread stores its 28 partial sums ([k][8 segments of 32 threads, padded to 33]), thread
+// (k, seg) adds the 32 entries of its segment (32 independent LDS reads, a balanced tree), the 8 segment sums of a k meet
+// in three DPP steps inside 8 adjacent lanes (quad swaps + half-row mirror: every lane ends with the same bits), one lane per k publishes
+// the total and every thread reads the 28 totals back (LDS broadcast).  Two barriers as before; a fixed association (run-to-run identical).
+#define PO_RED2_K 265                                  // doubles per k: 8 segments x 33
+__device__ __forceinline__ double po_dpp_f64(double v, const int ctrl_sel)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    unsigned lo, hi;
+    if (ctrl_sel == 0) { lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(u & 0xffffffffu), 0xB1, 0xF, 0xF, false); hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(u >> 32), 0xB1, 0xF, 0xF, false); }        // quad_perm:[1,0,3,2]
+    else if (ctrl_sel == 1) { lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(u & 0xffffffffu), 0x4E, 0xF, 0xF, false); hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(u >> 32), 0x4E, 0xF, 0xF, false); }   // quad_perm:[2,3,0,1]
+    else { lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(u & 0xffffffffu), 0x141, 0xF, 0xF, false); hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(u >> 32), 0x141, 0xF, 0xF, false); }                  // row_half_mirror
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+template <int N>
+__device__ __forceinline__ void po_block_sum_lds(double (&v)[N], double *red2, double *tot)
+{
+    static_assert(N * 8 <= 256, "one (k, segment) task per thread");
+    const int tid = threadIdx.x;
+    double *mine = red2 + (tid >> 5) * 33 + (tid & 31);
+#pragma unroll
+    for (int k = 0; k < N; k++) mine[k * PO_RED2_K] = v[k];
+    __syncthreads();
+    {
+        const int k = min(tid >> 3, N - 1), seg = tid & 7;
+        const double *p = red2 + k * PO_RED2_K + seg * 33;
+        double t[32];
+#pragma unroll
+        for (int i = 0; i < 32; i++) t[i] = p[i];
+        // a balanced tree over the 32 entries (depth 5 instead of a chain of 31 dependent additions: the (k, segment) thread has nothing
+        // else to overlap its chain with); the same association in every call, whatever N
+#pragma unroll
+        for (int w = 16; w >= 1; w >>= 1) {
+#pragma unroll
+            for (int i = 0; i < w; i++) t[i] = t[2 * i] + t[2 * i + 1];
+        }
+        double sacc = t[0];
+        sacc += po_dpp_f64(sacc, 0);
+        sacc += po_dpp_f64(sacc, 1);
+        sacc += po_dpp_f64(sacc, 2);
+        if (seg == 0 && (tid >> 3) < N) tot[k] = sacc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; k++) v[k] = tot[k];
 }
 
 // computeError of the two unary edges; returns chi2 = e^T (inv_sigma2 I) e
@@ -2521,7 +2584,7 @@ __device__ __forceinline__ double po_edge_chi2(const PoArgs &A, const BaGraphDev
 // times per frame: build + trial per iteration, 4 x 10 iterations; every walk was a round of dependent global loads), all sums
 // are wave-level DPP trees (no LDS, no barrier), and 1024 frames are one wave per SIMD instead of two rounds of 4-wave workgroups.
 template <bool GENERAL, int NT, int KR>
-__device__ __forceinline__ void po_body(const PoArgs &A, double (*red)[PO_NRED], double *stage = nullptr, int stage_cap = 0)
+__device__ __forceinline__ void po_body(const PoArgs &A, double (*red)[PO_NRED], double *stage = nullptr, int stage_cap = 0, double *red2 = nullptr, double *tot = nullptr)
 {
     const int f = blockIdx.x, tid = threadIdx.x;
     const int n = A.n[f];
@@ -2556,24 +2619,44 @@ __device__ __forceinline__ void po_body(const PoArgs &A, double (*red)[PO_NRED],
     }
     // the multi-wave form keeps the first stage_cap edges in LDS (7 doubles each): the ~80 walks over the edges of a frame are then LDS
     // reads instead of rounds of dependent L2 reads -- what a single frame's latency is made of
-    const int n_staged = stage ? min(n, stage_cap) : 0;
+    const int stage_lo = NT * KR;                                               // edges below live in registers
+    const int n_staged = stage ? min(n, stage_lo + stage_cap) : 0;              // edges [stage_lo, n_staged) live in LDS
     if (stage) {
-        for (int e = tid; e < n_staged; e += NT) {
-            double *q = stage + 7 * e;
+        for (int e = stage_lo + tid; e < n_staged; e += NT) {
+            double *q = stage + 7 * (e - stage_lo);
             q[0] = Xw[3 * e]; q[1] = Xw[3 * e + 1]; q[2] = Xw[3 * e + 2]; q[3] = obs[3 * e]; q[4] = obs[3 * e + 1]; q[5] = obs[3 * e + 2]; q[6] = is2[e];
         }
         __syncthreads();
     }
-    // body(k, e, X, ob, w0, rt) for every edge of this thread
-    auto for_edges = [&](auto body) {
-#pragma unroll
-        for (int k = 0; k < KR; k++) { const int e = tid + NT * k; if (e < n) body(k, e, rX[k], rO[k], rW[k], rR[k]); }
+    // body(k, e, X, ob, w0, rt) for every edge of this thread: the KR register-resident ones, then the tail (LDS stage / global memory)
+    auto for_tail_edges = [&](auto body) {
         for (int e = tid + NT * KR, k = KR; e < n; e += NT, k++) {
-            if (e < n_staged) body(k, e, stage + 7 * e, stage + 7 * e + 3, stage[7 * e + 6], (GENERAL && right) ? (int)right[e] : 0);
+            if (e < n_staged) { const double *q = stage + 7 * (e - stage_lo); body(k, e, q, q + 3, q[6], (GENERAL && right) ? (int)right[e] : 0); }
             else body(k, e, Xw + 3 * e, obs + 3 * e, is2[e], (GENERAL && right) ? (int)right[e] : 0);
         }
     };
+    auto for_edges = [&](auto body) {
+#pragma unroll
+        for (int k = 0; k < KR; k++) { const int e = tid + NT * k; if (e < n) body(k, e, rX[k], rO[k], rW[k], rR[k]); }
+        for_tail_edges(body);
+    };
+    // Frames whose edges are all monocular Pinhole ones (monocular tracking; Tracking.cc:1934) take a STRAIGHT-LINE form of the two walks
+    // over the register-resident edges (round 4): one frame is one wave per SIMD, so a walk is a chain of dependent double-precision
+    // latencies (quaternion rotation -> two divisions -> Huber's sqrt / division -> the Jacobian's four divisions), and with a branch per
+    // edge (outlier level, mono / stereo, Huber's two cases) the four edges of a thread ran one after the other: 4.0 k cycles per trial walk,
+    // 4.1 k per build walk (tools/po_prof_probe.py).  Without branches -- masked by selects -- the scheduler interleaves the four chains.
+    // Same expressions in the same order as po_edge_chi2 / huber / edge_jacobians' monocular branches: the same bits.
+    bool all_mono = false;
+    if (!GENERAL && KR > 0) {
+        double ns[1] = {0};
+        for (int e = tid; e < n; e += NT) ns[0] += !(obs[3 * e + 2] < 0) ? 1.0 : 0.0;
+        po_block_sum<1, NT>(ns, red);
+        all_mono = ns[0] == 0.0;
+    }
     int robust = 1, nbad = 0, lm_trials = 0, lm_iters = 0, rounds = 0;
+#ifdef PO_PROF
+    long long t_prev = clock64();
+#endif
     for (int it = 0; it < 4; it++) {
         for (int k = 0; k < 7; k++) pose[k] = pose0[k];                          // Optimizer.cc:1053
         double cnt[1] = {0};
@@ -2589,7 +2672,8 @@ __device__ __forceinline__ void po_body(const PoArgs &A, double (*red)[PO_NRED],
                 for (int k = 0; k < PO_NRED; k++) acc[k] = 0;
                 double R[9];
                 quat_to_R(pose, R);
-                for_edges([&](int k, int e, const double *Xe, const double *ob, double w0, int rt) {
+                PO_T(7);
+                auto build_edge = [&](int k, int e, const double *Xe, const double *ob, double w0, int rt) {
                     (void)e;
                     if ((level >> k) & 1u) return;
                     const int stereo = !(ob[2] < 0);
@@ -2621,8 +2705,53 @@ __device__ __forceinline__ void po_body(const PoArgs &A, double (*red)[PO_NRED],
                         for (int d = 0; d < 3; d++) s += Jt[6 * d + a] * (-w * er[d]);
                         acc[22 + a] += s;
                     }
-                });
-                po_block_sum<PO_NRED, NT>(acc, red);
+                };
+                if (!GENERAL && KR > 0 && all_mono) {
+#pragma unroll
+                    for (int k = 0; k < KR; k++) {
+                        const bool act = (tid + NT * k < n) && !((level >> k) & 1u);
+                        double P[3], er[2], Jt[12];
+                        quat_rot(pose, rX[k], P);
+                        P[0] += pose[4]; P[1] += pose[5]; P[2] += pose[6];
+                        er[0] = rO[k][0] - (A.fx * P[0] / P[2] + A.cx);                // po_edge_chi2, monocular Pinhole branch
+                        er[1] = rO[k][1] - (A.fy * P[1] / P[2] + A.cy);
+                        const double chi2 = (er[0] * er[0] + er[1] * er[1] + 0.0 * 0.0) * rW[k];
+                        const double sq = sqrt(chi2);
+                        const bool quad = !robust || chi2 <= dsqr_m;                   // huber(), selects instead of its two cases
+                        const double r0 = quad ? chi2 : 2 * sq * delta_m - dsqr_m, r1 = quad ? 1. : delta_m / sq;
+                        {                                                              // edge_jacobians, monocular Pinhole branch
+                            const double x = P[0], y = P[1], z = P[2];
+                            const double p00 = -(A.fx / z), p02 = A.fx * x / (z * z), p11 = -(A.fy / z), p12 = A.fy * y / (z * z);
+                            Jt[0] = p02 * y;            Jt[1] = p00 * z - p02 * x;  Jt[2] = -p00 * y;  Jt[3] = p00; Jt[4] = 0;   Jt[5] = p02;
+                            Jt[6] = -p11 * z + p12 * y; Jt[7] = -p12 * x;           Jt[8] = p11 * x;   Jt[9] = 0;   Jt[10] = p11; Jt[11] = p12;
+                        }
+                        const double w = r1 * rW[k];
+                        acc[0] += act ? r0 : 0.0;
+                        int h = 1;
+#pragma unroll
+                        for (int a = 0; a < 6; a++) {
+#pragma unroll
+                            for (int c = a; c < 6; c++) {
+                                double sacc = 0;
+                                sacc += Jt[a] * w * Jt[c];
+                                sacc += Jt[6 + a] * w * Jt[6 + c];
+                                acc[h++] += act ? sacc : 0.0;
+                            }
+                        }
+#pragma unroll
+                        for (int a = 0; a < 6; a++) {
+                            double sacc = 0;
+                            sacc += Jt[a] * (-w * er[0]);
+                            sacc += Jt[6 + a] * (-w * er[1]);
+                            acc[22 + a] += act ? sacc : 0.0;
+                        }
+                    }
+                    for_tail_edges(build_edge);
+                } else for_edges(build_edge);
+                PO_T(0);
+                if (NT == 256 && red2) po_block_sum_lds<PO_NRED>(acc, red2, tot);
+                else po_block_sum<PO_NRED, NT>(acc, red);
+                PO_T(1);
                 for (int k = 0; k < 7; k++) pose_ev[k] = pose[k];
                 double current_chi = acc[0];
                 const double ini_chi = current_chi;
@@ -2690,8 +2819,9 @@ __device__ __forceinline__ void po_body(const PoArgs &A, double (*red)[PO_NRED],
                     double pn[7];
                     se3_oplus(x, pose, pn);                                      // update, SO:422-435
                     for (int k = 0; k < 7; k++) pose[k] = pn[k];
+                    PO_T(2);
                     double tc[1] = {0};                                          // computeActiveErrors + activeRobustChi2 at the trial
-                    for_edges([&](int k, int e, const double *Xe, const double *ob, double w0, int rt) {
+                    auto trial_edge = [&](int k, int e, const double *Xe, const double *ob, double w0, int rt) {
                         (void)e;
                         if ((level >> k) & 1u) return;
                         const int stereo = !(ob[2] < 0);
@@ -2700,8 +2830,42 @@ __device__ __forceinline__ void po_body(const PoArgs &A, double (*red)[PO_NRED],
                         if (robust) huber(chi2, stereo ? delta_s : delta_m, stereo ? dsqr_s : dsqr_m, &r0, &r1);
                         else r0 = chi2;
                         tc[0] += r0;
-                    });
-                    po_block_sum<1, NT>(tc, red);
+                    };
+                    if (!GENERAL && KR > 0 && all_mono) {
+                        double c2[KR ? KR : 1];
+                        bool over = false;
+#pragma unroll
+                        for (int k = 0; k < KR; k++) {
+                            const bool act = (tid + NT * k < n) && !((level >> k) & 1u);
+                            double P[3];
+                            quat_rot(pose, rX[k], P);
+                            P[0] += pose[4]; P[1] += pose[5]; P[2] += pose[6];
+                            const double e0 = rO[k][0] - (A.fx * P[0] / P[2] + A.cx), e1 = rO[k][1] - (A.fy * P[1] / P[2] + A.cy);
+                            c2[k] = (e0 * e0 + e1 * e1 + 0.0 * 0.0) * rW[k];
+                            over = over || (act && c2[k] > dsqr_m);
+                        }
+                        // Huber's square root only where some lane of the wave needs it (after the first round the gross outliers are
+                        // at level 1 and almost every trial of the remaining rounds is quadratic throughout): a wave-uniform branch
+                        if (robust && __builtin_amdgcn_ballot_w64(over) != 0) {
+#pragma unroll
+                            for (int k = 0; k < KR; k++) {
+                                const bool act = (tid + NT * k < n) && !((level >> k) & 1u);
+                                const double r0 = c2[k] <= dsqr_m ? c2[k] : 2 * sqrt(c2[k]) * delta_m - dsqr_m;
+                                tc[0] += act ? r0 : 0.0;
+                            }
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < KR; k++) tc[0] += ((tid + NT * k < n) && !((level >> k) & 1u)) ? c2[k] : 0.0;
+                        }
+                        for_tail_edges(trial_edge);
+                    } else for_edges(trial_edge);
+                    PO_T(3);
+                    // (the SAME reduction as the build step's chi2: a trial that does not move the pose must reproduce current_chi bit for
+                    // bit -- rho == 0 is how g2o's loop ends at convergence, LM:151-152; with two different summation orders it never did
+                    // and every converged iteration burnt trials until lambda overflowed the step: 58 -> 87 trials on the probe frame)
+                    if (NT == 256 && red2) po_block_sum_lds<1>(tc, red2, tot);
+                    else po_block_sum<1, NT>(tc, red);
+                    PO_T(4);
                     for (int k = 0; k < 7; k++) pose_ev[k] = pose[k];
                     double temp_chi = ok2 ? tc[0] : DBL_MAX;
                     rho = current_chi - temp_chi;
@@ -2719,6 +2883,9 @@ __device__ __forceinline__ void po_body(const PoArgs &A, double (*red)[PO_NRED],
                         for (int k = 0; k < 7; k++) pose[k] = pose_bk[k];        // pop
                     }
                     qmax++; lm_trials++;
+#ifdef PO_PROF
+                    if (blockIdx.x == 0 && threadIdx.x == 0) g_po_prof[6]++;
+#endif
                 } while (rho < 0 && qmax < 100);
                 lm_iters++;
                 if (qmax == 100 || rho == 0) ok = 0;                             // LM:151-152
@@ -2740,6 +2907,7 @@ __device__ __forceinline__ void po_body(const PoArgs &A, double (*red)[PO_NRED],
             if (chi2 > gate) { level |= 1u << k; bad[0] += 1; } else level &= ~(1u << k);
         });
         po_block_sum<1, NT>(bad, red);
+        PO_T(5);
         nbad = (int)bad[0];
         if (it == 2) robust = 0;                                                 // setRobustKernel(0)
         rounds++;
@@ -2757,8 +2925,22 @@ template <bool GENERAL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pose_opt(PoArgs A)
 {
     __shared__ double red[4][PO_NRED];
+    __shared__ double red2[PO_NRED * PO_RED2_K], tot[32];
     extern __shared__ double po_stage[];                         // [stage_cap][7] (dynamic: 0 when the launch is a big batch)
-    po_body<GENERAL, 256, 0>(A, red, A.stage_cap > 0 ? po_stage : nullptr, A.stage_cap);
+    po_body<GENERAL, 256, 0>(A, red, A.stage_cap > 0 ? po_stage : nullptr, A.stage_cap, red2, tot);
+}
+// Latency form (round 4): what Optimizer::PoseOptimization(Frame*) launches -- ONE frame, i.e. four waves on the whole
+// chip.  k_pose_opt above is held at two waves per SIMD (256 VGPRs) for launches that fill the device and spilled there (151 VGPRs /
+// 472 B of scratch in the Pinhole instantiation); a launch of up to 256 frames is at most one workgroup per CU = one wave per SIMD, so
+// this instantiation takes the whole register file (512 VGPRs), keeps the first 4 edges of every thread (1024 per frame) in registers
+// instead of LDS and spills nothing; edges beyond 1024 are staged in LDS as before.
+template <bool GENERAL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_pose_opt_lat(PoArgs A)
+{
+    __shared__ double red[4][PO_NRED];
+    __shared__ double red2[PO_NRED * PO_RED2_K], tot[32];
+    extern __shared__ double po_stage[];                         // [stage_cap][7]: edges 1024 .. of a frame (index = edge - 1024)
+    po_body<GENERAL, 256, PO_KR>(A, red, A.stage_cap > 0 ? po_stage : nullptr, A.stage_cap, red2, tot);
 }
 template <bool GENERAL>
 __global__ __launch_bounds__(64) void k_pose_opt_wave(PoArgs A)
@@ -2795,11 +2977,17 @@ extern "C" int orbhip_pose_optimization_device(orbhip_ctx *ctx, const double *d_
     } else {
         // up to one workgroup per CU the edges are staged in LDS (latency form); bigger launches keep the LDS-free one (occupancy)
         static const int stage_env = getenv("ORBHIP_POSE_STAGE_EDGES") ? atoi(getenv("ORBHIP_POSE_STAGE_EDGES")) : 2048;
-        A.stage_cap = frames <= 256 ? std::min(max_edges, stage_env) : 0;
+        static const int lat_env = getenv("ORBHIP_POSE_LAT") ? atoi(getenv("ORBHIP_POSE_LAT")) : 1;       // 0: round 3's kernel for every launch (A/B)
+        const bool lat = frames <= 256 && lat_env;               // at most one workgroup per CU: one wave per SIMD, the whole register file
+        A.stage_cap = frames <= 256 ? std::max(0, std::min(max_edges, stage_env) - (lat ? PO_THREADS * PO_KR : 0)) : 0;
         const size_t lds = (size_t)A.stage_cap * 7 * sizeof(double);
-        const void *fn = general ? reinterpret_cast<const void *>(k_pose_opt<true>) : reinterpret_cast<const void *>(k_pose_opt<false>);
+        const void *fn = lat ? (general ? reinterpret_cast<const void *>(k_pose_opt_lat<true>) : reinterpret_cast<const void *>(k_pose_opt_lat<false>))
+                             : (general ? reinterpret_cast<const void *>(k_pose_opt<true>) : reinterpret_cast<const void *>(k_pose_opt<false>));
         if (lds > 0 && orb_lds_optin(fn, orbhip_ctx_device_internal(ctx), lds)) { g_ba_error = "LDS opt-in (k_pose_opt)"; return ORBHIP_E_HIP; }
-        if (general) hipLaunchKernelGGL(k_pose_opt<true>, dim3(frames), dim3(PO_THREADS), lds, orbhip_ctx_stream_internal(ctx), A);
+        if (lat) {
+            if (general) hipLaunchKernelGGL(k_pose_opt_lat<true>, dim3(frames), dim3(PO_THREADS), lds, orbhip_ctx_stream_internal(ctx), A);
+            else hipLaunchKernelGGL(k_pose_opt_lat<false>, dim3(frames), dim3(PO_THREADS), lds, orbhip_ctx_stream_internal(ctx), A);
+        } else if (general) hipLaunchKernelGGL(k_pose_opt<true>, dim3(frames), dim3(PO_THREADS), lds, orbhip_ctx_stream_internal(ctx), A);
         else hipLaunchKernelGGL(k_pose_opt<false>, dim3(frames), dim3(PO_THREADS), lds, orbhip_ctx_stream_internal(ctx), A);
     }
     return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;

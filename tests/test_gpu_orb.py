@@ -394,6 +394,31 @@ def test_hd_batch_properties(gpu_ctx):
     ext.close()
 
 
+def test_4k_batch_properties(gpu_ctx):
+    """north_star's third image size at batch scale (bench.py's `4k` leg): 64 frames of 3840x2160, 2000 features: sampled frames
+    bit-exact vs the oracle, run-to-run determinism (checksum of checksums), structural invariants of every frame."""
+    import hashlib
+    import orbhip
+    import bench
+    ext, ora = _mk(gpu_ctx, 2000)
+    imgs = bench.synth_frames_parallel(orbhip, 3840, 2160, 64, 20241005, 0)
+    r1 = _dev_extract(gpu_ctx, ext, imgs, (0, 0))
+    digest1 = hashlib.sha256(b"".join(hashlib.sha256(k.tobytes() + d.tobytes()).digest() for k, d, _ in r1)).hexdigest()
+    for f in (0, 33, 63):
+        kp, desc, mono = ora.extract(imgs[f], (0, 0))
+        assert r1[f][2] == mono and r1[f][0].tobytes() == kp.tobytes() and r1[f][1].tobytes() == desc.tobytes(), f
+    quota = ext.features_per_level()
+    for k, d, m in r1:
+        assert 1800 < len(k) <= ext.max_keypoints and m == len(k)
+        assert (np.diff(k["octave"]) >= 0).all()
+        assert (np.bincount(k["octave"], minlength=8) <= quota + 4).all()          # 16:9: nIni = 2 roots, up to 4 * nIni nodes after the first split
+        assert (k["x"] >= 19).all() and (k["y"] >= 19).all() and (k["x"] < 3840 - 19).all() and (k["y"] < 2160 - 19).all()
+    r2 = _dev_extract(gpu_ctx, ext, imgs, (0, 0))
+    digest2 = hashlib.sha256(b"".join(hashlib.sha256(k.tobytes() + d.tobytes()).digest() for k, d, _ in r2)).hexdigest()
+    assert digest1 == digest2
+    ext.close()
+
+
 @pytest.mark.parametrize("w,h", [(640, 480), (333, 277), (1241, 376)])
 def test_row_streaming_and_tile_kernels_agree(gpu_ctx, w, h, monkeypatch):
     """The pyramid and the blur have two kernels each: the row-streaming ones (default) and the LDS-tile ones (scale factors whose
