@@ -85,6 +85,7 @@ struct FcLevel {
     int max_bx, max_by;           // w - minBorder, h - minBorder
     int ncols, nrows, wcell, hcell, cell_base, cell_cap;
     int tpr, rpt;                 // lane layout of the per-pair passes: two-pair tasks per row (nominal cell width), rows per trip
+    int rpc, rpr, run_base;       // k_fast_runs: cells per run (2 while two cells fit 64 pixels, else 1), runs per cell row, first run of this level in a frame's run array
 };
 struct FastParams {
     FcLevel lv[ORB_MAX_LEVELS];
@@ -97,6 +98,8 @@ struct FastParams {
     // dwords, queue of qcap u16; wave_dw = dwords per wave.  small_cells: every level fits the <28, 24, 9> instantiation
     int rows, srows, qcap, wave_dw, small_cells;
     uint32_t div_magic[34];       // floor(i / n) == (i * div_magic[n]) >> 16 whenever i * n < 65536, n = 1 .. 33
+    // k_fast_runs (round 4): runs of up to two horizontally adjacent cells per wave
+    int runs_per_frame, run_rows, run_q0, run_dw, use_runs;      // LDS rows of the pair tile, entries of the first queue, dwords per wave
 };
 
 #define ORB_PACK_KEY(x, y, s) ((uint32_t)(x) | ((uint32_t)(y) << 12) | ((uint32_t)(s) << 24))
@@ -130,6 +133,7 @@ int orb_lds_optin(const void *func, int device, size_t need);
 // kernel launchers (orb_kernels.hip)
 void orb_launch_resize(const OrbParams &P, int level, hipStream_t s);
 void orb_launch_fast_cells(const FastParams &F, hipStream_t s, int max_per_cu, int lvl_lo = 0, int lvl_hi = -1);      // max_per_cu: 0 = as many waves as fit
+const void *orb_fast_runs_func(int nld);
 #define ORB_OVERLAP_MIN_BATCH 16
 #ifndef BLR_R
 #define BLR_R 24              // k_blur_rows: output rows per lane (multiple of 6)

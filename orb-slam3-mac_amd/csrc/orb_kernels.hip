@@ -387,8 +387,8 @@ struct __attribute__((packed, aligned(1))) u32x4_unaligned { uint32_t x, y, z, w
 // Staging loads of a cell: its sub-image rows as NCH 16-byte chunks each (chunk c = pixels ini_x - 1 + 16c .. + 15 = pairs 8c .. 8c+7),
 // flattened (row, chunk) tasks, NLD per lane, branch-free (surplus lanes repeat the last task), all in flight together.  A chunk may
 // run past the sub-image: those bytes are never used and lie inside the frame (the sub-image ends >= 16 rows above the image's end).
-template <int NCH, int NLD>
-__device__ __forceinline__ void fc_issue_loads(const FcCell &C, int lane, uint4 (&ld)[NLD])
+template <int NCH, int NLD, typename CELL>
+__device__ __forceinline__ void fc_issue_loads(const CELL &C, int lane, uint4 (&ld)[NLD])
 {
     const int last = max((C.dh + 6) * NCH - 1, 0);
 #pragma unroll
@@ -571,17 +571,276 @@ __global__ __launch_bounds__(64) void k_fast_cells(FastParams P)
 #undef FC_WAVE_SYNC
 }
 
+// ----------------------------------------------------------------------------------
+// k_fast_runs (round 4): the same per-cell FAST semantics (ORBextractor.cc:783-854: every cell is FASTed alone at
+// iniThFAST, again at minThFAST iff that left it empty; the 3-px ring of its sub-image is excluded, so NMS never sees a neighbour cell)
+// with the cell no longer the unit of work.  A wave owns a RUN of up to two horizontally adjacent cells of one cell row -- one
+// sub-image of (2 wCell + 6) x (hCell + 6) pixels, staged once (80-byte rows instead of two 41..48-byte ones: less apron, longer lines)
+// -- and the cell enters only as
+//   (a) a mask in the NMS: a neighbour pixel that lies in the other cell's band counts as 0,
+//   (b) the per-cell "empty at iniThFAST -> again at minThFAST" decision (the second pass is restricted to the pixels of empty cells),
+//   (c) the emission: per-cell ranks by ballot, per-cell lists and counts.
+// The necessary (compass) test, which is most of the kernel, no longer gathers its 11 dwords per pixel pair from LDS: lane = pair COLUMN
+// (32 columns x 2 half waves, the halves walking the upper / lower half of the rows), and a lane walks DOWN its column with a
+// register ring of the last seven rows' three dwords (columns c-1, c, c+1), so a row step costs 3 LDS instructions (the new row's
+// ds_read2 + ds_read, the centre row's two outer dwords) instead of 11 and no address arithmetic; the loop is unrolled by the ring
+// period so that every ring access is a fixed register.  Queue (two, one per half wave: concatenated they are in cv::FAST's raster
+// order), dense arc scoring and the score tile are k_fast_cells' -- the very same expressions, so every candidate list comes out
+// byte-identical (tests/test_gpu_orb.py compares them with the oracle cell by cell).
+// ----------------------------------------------------------------------------------
+#define FR_PITCH 40            // pair-tile dwords per row: pairs -2 .. 37 of the run's sub-image
+#define FR_SPITCH 40           // score-tile u16 per row: 32 pairs + one guard on either side
+#define FR_NCH 5               // 16-byte chunks staged per row
+struct FrRun {
+    int frame, lvl, ci, cj, nc;         // first cell of the run, cells in it (1 or 2)
+    int dw0, dw1, dh;                   // detection band widths of the two cells (0: the reference skips the cell), band height
+    int ipitch; const uint8_t *src;     // pixel (ini_x - 1, ini_y) of the first cell: first byte staged
+    int ncols, nrows, wcell, hcell, cell_base, cell_cap, rpc, rpr;
+};
+__device__ __forceinline__ void fr_run_geom(const FastParams &P, FrRun &C)
+{
+    const FcLevel &L = P.lv[C.lvl];
+    C.ncols = FC_SGPR(L.ncols); C.nrows = FC_SGPR(L.nrows); C.wcell = FC_SGPR(L.wcell); C.hcell = FC_SGPR(L.hcell);
+    C.cell_base = FC_SGPR(L.cell_base); C.cell_cap = FC_SGPR(L.cell_cap); C.rpc = FC_SGPR(L.rpc); C.rpr = FC_SGPR(L.rpr);
+    C.ipitch = FC_SGPR(L.img_pitch) & 0xFFFF;
+    C.nc = min(C.rpc, C.ncols - C.cj);
+    const int max_bx = FC_SGPR(L.max_bx), max_by = FC_SGPR(L.max_by);
+    const int ini_y = ORB_MINB + C.ci * C.hcell, ini_x = ORB_MINB + C.cj * C.wcell;
+    C.src = L.img + (size_t)C.frame * L.frame_stride + (size_t)(ini_y * C.ipitch + ini_x - 1);
+    C.dw0 = 0; C.dw1 = 0; C.dh = 0;
+    if (ini_y >= max_by - 3) return;                                          // ORBextractor.cc:788
+    C.dh = min(ini_y + C.hcell + 6, max_by) - ini_y - 6;
+    if (C.dh <= 0) { C.dh = 0; return; }
+    if (ini_x < max_bx - 6) C.dw0 = max(min(ini_x + C.wcell + 6, max_bx) - ini_x - 6, 0);     // :797-802
+    const int ini_x1 = ini_x + C.wcell;
+    if (C.nc > 1 && ini_x1 < max_bx - 6) C.dw1 = max(min(ini_x1 + C.wcell + 6, max_bx) - ini_x1 - 6, 0);
+    if (C.dw0 == 0) C.dw1 = 0;
+}
+
+// FR_NLD: staging loads per lane (rows x 5 chunks <= 64 FR_NLD): 4 for cells of up to 45 rows, 6 up to 70
+template <int FR_NLD>
+__global__ __launch_bounds__(64) void k_fast_runs(FastParams P)
+{
+    constexpr int PITCH = FR_PITCH, SPITCH = FR_SPITCH;
+    extern __shared__ __attribute__((aligned(16))) uint32_t fc_lds[];
+    const int lane = threadIdx.x;
+    uint32_t *PT = fc_lds;
+    uint16_t *SC = reinterpret_cast<uint16_t *>(PT + P.run_rows * PITCH);      // scores, one u16 per pixel pair: left | right << 8
+    uint16_t *Q = SC + (P.srows + 2) * SPITCH;                                  // [0, q0): upper half of the rows, [q0, ..): lower half
+    const int q0cap = FC_SGPR(P.run_q0);
+    const unsigned lid = xcd_logical_id(blockIdx.x, gridDim.x);
+    const int lvl_lo = FC_SGPR(P.lvl_lo), lvl_hi = FC_SGPR(P.lvl_hi);
+    const int run_lo = FC_SGPR(P.lv[lvl_lo].run_base);
+    const int rps = (lvl_hi < P.nlevels ? FC_SGPR(P.lv[lvl_hi].run_base) : FC_SGPR(P.runs_per_frame)) - run_lo;
+    const long total_runs = (long)P.batch * rps;
+    const int chunk = FC_SGPR(P.chunk);
+    const long nchunks = (total_runs + chunk - 1) / chunk;
+    if ((long)lid >= nchunks) return;
+    const int nlevels = lvl_hi, ini_th = FC_SGPR(P.ini_th), min_th = FC_SGPR(P.min_th), cpf = FC_SGPR(P.cells_per_frame);
+    auto decode = [&](long gi, FrRun &X) {
+        X.frame = (int)(gi / rps);
+        const int run = run_lo + (int)(gi - (long)X.frame * rps);
+        X.lvl = lvl_lo;
+        for (int l = lvl_lo + 1; l < nlevels; l++) if (run >= P.lv[l].run_base) X.lvl = l;
+        const int r = run - P.lv[X.lvl].run_base;
+        X.ci = r / P.lv[X.lvl].rpr; X.cj = (r - X.ci * P.lv[X.lvl].rpr) * P.lv[X.lvl].rpc;
+        X.frame = FC_SGPR(X.frame); X.lvl = FC_SGPR(X.lvl); X.ci = FC_SGPR(X.ci); X.cj = FC_SGPR(X.cj);
+        fr_run_geom(P, X);
+    };
+    long ch = lid;
+    long g = ch * chunk, g_end = min(g + chunk, total_runs);
+    FrRun C;
+    decode(g, C);
+    uint4 ld[FR_NLD];
+    fc_issue_loads<FR_NCH, FR_NLD>(C, lane, ld);
+    const int lo_th = min(ini_th, min_th);
+    const int bp = lane & 31, half = lane >> 5;                                // this lane's pair column and half wave
+#define FC_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_s_waitcnt(0xc07f); \
+                            __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+    for (bool more = true; more;) {
+        const int dw0 = C.dw0, dw1 = C.dw1, dw = dw0 + dw1, dh = C.dh;
+        const int npb = (dw + 1) >> 1;                             // band pixel pairs per row of the run
+        const int cell = C.cell_base + C.ci * C.ncols + C.cj;
+        uint32_t *cnt_out = P.cell_count + (size_t)C.frame * cpf + cell;
+        uint32_t *list = P.cell_list + (size_t)C.frame * P.cell_list_frame_stride + (size_t)cell * C.cell_cap;
+        const int key_x0 = 3 + C.cj * C.wcell, key_y0 = 3 + C.ci * C.hcell;
+        const int cell_cap = C.cell_cap, nc = C.nc;
+        // ---- (1) stage: PT[r][p] = pixels (ini_x + 2p - 1, ini_x + 2p) of sub-image row r as u16 | u16 << 16
+        if (dw > 0) {
+            const int last = (dh + 6) * FR_NCH - 1;
+#pragma unroll
+            for (int t = 0; t < FR_NLD; t++) {
+                const int i = min(lane + 64 * t, last);
+                const int r = (int)(__umul24((uint32_t)i, 65536u / FR_NCH + 1) >> 16), c = i - r * FR_NCH;
+                uint4 a, b;
+                a.x = __builtin_amdgcn_perm(0u, ld[t].x, 0x0c010c00u); a.y = __builtin_amdgcn_perm(0u, ld[t].x, 0x0c030c02u);
+                a.z = __builtin_amdgcn_perm(0u, ld[t].y, 0x0c010c00u); a.w = __builtin_amdgcn_perm(0u, ld[t].y, 0x0c030c02u);
+                b.x = __builtin_amdgcn_perm(0u, ld[t].z, 0x0c010c00u); b.y = __builtin_amdgcn_perm(0u, ld[t].z, 0x0c030c02u);
+                b.z = __builtin_amdgcn_perm(0u, ld[t].w, 0x0c010c00u); b.w = __builtin_amdgcn_perm(0u, ld[t].w, 0x0c030c02u);
+                uint4 *dst = reinterpret_cast<uint4 *>(&PT[r * PITCH + 8 * c]);
+                dst[0] = a; dst[1] = b;
+            }
+            uint4 *scz = reinterpret_cast<uint4 *>(SC);             // the score tile starts at zero (guards included)
+            for (int i = lane; i < ((dh + 2) * SPITCH + 7) / 8; i += 64) scz[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        // ---- next run: its loads stay in flight while this one is processed
+        FrRun N = C;
+        g++;
+        if (g < g_end) {
+            N.cj += C.rpc;
+            if (N.cj >= C.ncols) { N.cj = 0; N.ci++; }
+            if (N.ci == C.nrows) { N.ci = 0; N.lvl++; }
+            if (N.lvl == nlevels) { N.lvl = lvl_lo; N.frame++; }
+            fr_run_geom(P, N);
+        } else {
+            ch += gridDim.x;
+            more = ch < nchunks;
+            if (more) { g = ch * chunk; g_end = min(g + chunk, total_runs); decode(g, N); }
+        }
+        if (more) fc_issue_loads<FR_NCH, FR_NLD>(N, lane, ld);
+        if (dw <= 0) { if (lane < nc) cnt_out[lane] = 0; C = N; continue; }
+        FC_WAVE_SYNC();
+        // the cell of a band pixel: x < dw0 -> the first one.  B = first column of the second cell (or beyond every pixel)
+        const int B = dw1 > 0 ? dw0 : (1 << 20);
+        const int hh = (dh + 1) >> 1;                               // rows per half wave
+        const int rb = half * hh;                                   // first band row of this lane's half
+        const int rows_mine = min(hh, dh - rb);                     // (may be < hh for the lower half of an odd band)
+        int tot0 = 0, tot1 = 0;                                     // keypoints emitted per cell (uniform)
+        uint32_t empty = 0;                                         // second pass: bit c = cell c came out empty at iniThFAST
+        for (int pass = 0; pass < 2; pass++) {
+            const int th = pass == 0 ? ini_th : min_th;
+            const s16x2 thP = (s16x2){(short)(th + 1), (short)(th + 1)};
+            // a pair takes part if it lies in the band and, in the second pass, if one of its pixels belongs to an empty cell
+            bool col_on = bp < npb;
+            if (pass) col_on = col_on && ((((2 * bp >= B) ? 2u : 1u) | ((2 * bp + 1 >= B) ? 2u : 1u)) & empty) != 0;
+            // ---- (2) necessary test, every lane walking down its pair column, seven rows per trip: the 13 tile rows a trip touches sit in
+            // registers (six carried over from the previous trip), the seven M values are computed as seven independent chains (the
+            // packed 16-bit min / max ops need a wait state between dependent ones: alone, a chain was half s_nop), then flagged and queued
+            int nq0 = 0, nq1 = 0;
+            {
+                const uint32_t *col = PT + rb * PITCH + bp + 1;     // dwords [0], [1], [2] of a row = columns c - 1, c, c + 1 (c = bp + 2)
+                const int rows_on = col_on ? rows_mine : 0;         // rows of this lane that may flag
+                uint32_t rm[13], rc[13], rp[13];
+#pragma unroll
+                for (int i = 0; i < 6; i++) { rm[i] = col[i * PITCH]; rc[i] = col[i * PITCH + 1]; rp[i] = col[i * PITCH + 2]; }
+                const uint32_t SIGN = 0x80008000u;
+                for (int y0 = 0; y0 < hh; y0 += 7) {
+                    const uint32_t *cy = col + y0 * PITCH;
+                    uint32_t cm2[7], cp2[7];
+#pragma unroll
+                    for (int i = 0; i < 7; i++) {                   // (rows past the band: inside the tile's padding, never flagged)
+                        rm[6 + i] = cy[(6 + i) * PITCH]; rc[6 + i] = cy[(6 + i) * PITCH + 1]; rp[6 + i] = cy[(6 + i) * PITCH + 2];
+                        cm2[i] = cy[(3 + i) * PITCH - 1]; cp2[i] = cy[(3 + i) * PITCH + 3];
+                    }
+                    bool f[7];
+#pragma unroll
+                    for (int i = 0; i < 7; i++) {
+                        // fc_compass with q[0] = rc[i + 3]: n = q[3 P], s = q[-3 P], e = (q[1], q[2]), w = (q[-2], q[-1]), se = q[2 P + 1],
+                        // nw = q[-2 P - 1], ne = q[-2 P + 1], sw = q[2 P - 1]
+                        const s16x2 v = as_s16x2(rc[i + 3]);
+                        const s16x2 n = as_s16x2(rc[i + 6]), so = as_s16x2(rc[i]);
+                        const s16x2 e = pair_odd(cp2[i], rp[i + 3]), w = pair_odd(rm[i + 3], cm2[i]);
+                        const s16x2 se = as_s16x2(rp[i + 5]), nw = as_s16x2(rm[i + 1]);
+                        const s16x2 ne = as_s16x2(rp[i + 1]), sw = as_s16x2(rm[i + 5]);
+                        const s16x2 lo = pkmax(pkmax(pkmin(n, so), pkmin(e, w)), pkmax(pkmin(se, nw), pkmin(ne, sw)));
+                        const s16x2 hi = pkmin(pkmin(pkmax(n, so), pkmax(e, w)), pkmin(pkmax(se, nw), pkmax(ne, sw)));
+                        const s16x2 M = pkmax(v - lo, hi - v);
+                        f[i] = y0 + i < rows_on && (as_u32(M - thP) & SIGN) != SIGN;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 7; i++) {
+                        const unsigned long long b = __ballot(f[i]);
+                        const uint32_t blo = (uint32_t)b, bhi = (uint32_t)(b >> 32);
+                        // entries of the upper half go to Q[nq0 ..), of the lower half to Q[q0cap + nq1 ..): one expression for both
+                        const int m = (int)__builtin_amdgcn_mbcnt_hi(bhi, __builtin_amdgcn_mbcnt_lo(blo, 0u));
+                        const int pos = m + (half ? q0cap + nq1 - __popc(blo) : nq0);
+                        if (f[i]) Q[pos] = (uint16_t)FC_ID(rb + y0 + i, bp);
+                        nq0 += __popc(blo); nq1 += __popc(bhi);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 6; i++) { rm[i] = rm[7 + i]; rc[i] = rc[7 + i]; rp[i] = rp[7 + i]; }
+                }
+            }
+            const int nq = nq0 + nq1;
+            FC_WAVE_SYNC();
+            // ---- (3) dense arc score, one pair per lane (queue entry i: the upper half's entries first)
+            for (int i0 = 0; i0 < nq; i0 += 64) {
+                const int i = min(i0 + lane, nq - 1);
+                const int id = Q[i < nq0 ? i : q0cap + i - nq0], by = id >> 5, qp = id & 31;
+                const s16x2 S = fc_arc_score<PITCH>(&PT[(by + 3) * PITCH + qp + 2]);
+                if (i0 + lane < nq) {
+                    const uint32_t lo = S.x > lo_th ? (uint32_t)(S.x - 1) : 0u;
+                    const uint32_t hi = (S.y > lo_th && 2 * qp + 1 < dw) ? (uint32_t)(S.y - 1) : 0u;
+                    SC[(by + 1) * SPITCH + qp + 1] = (uint16_t)(lo | (hi << 8));
+                }
+            }
+            FC_WAVE_SYNC();
+            // ---- (4) 3x3 strict NMS on raw scores (neighbours in the other cell's band count as 0) + threshold gate + per-cell ordered emission
+            for (int i0 = 0; i0 < nq; i0 += 64) {
+                const int i = i0 + lane;
+                uint32_t keep = 0, sc = 0;
+                int by = 0, qp = 0;
+                if (i < nq) {
+                    const int id = Q[i < nq0 ? i : q0cap + i - nq0];
+                    by = id >> 5; qp = id & 31;
+                    const uint16_t *q = &SC[(by + 1) * SPITCH + qp + 1];
+#define FC_U(v) as_s16x2(__builtin_amdgcn_perm(0u, (uint32_t)(v), 0x0c010c00u))                          /* left | right << 8  ->  packed halves */
+                    sc = q[0];
+                    const s16x2 V = pkmax(FC_U(q[-SPITCH]), FC_U(q[SPITCH]));                                  // above / below each pixel
+                    const s16x2 Lc = pkmax(pkmax(FC_U(q[-SPITCH - 1]), FC_U(q[-1])), FC_U(q[SPITCH - 1]));     // .y: column left of the pair
+                    const s16x2 Rc = pkmax(pkmax(FC_U(q[-SPITCH + 1]), FC_U(q[1])), FC_U(q[SPITCH + 1]));      // .x: column right of the pair
+#undef FC_U
+                    const int xl = 2 * qp, xr = xl + 1;
+                    const int sl = (int)(sc & 0xFFu), sr = (int)(sc >> 8);
+                    // L: above / below, the column to its left (not if L is the second cell's first column), the R column (not across the boundary)
+                    const int nbl = max(max((int)V.x, xl != B ? (int)Lc.y : 0), xr != B ? max((int)V.y, sr) : 0);
+                    const int nbr = max(max((int)V.y, xr + 1 != B ? (int)Rc.x : 0), xr != B ? max((int)V.x, sl) : 0);
+                    const bool onL = !pass || ((xl >= B ? 2u : 1u) & empty), onR = !pass || ((xr >= B ? 2u : 1u) & empty);
+                    if (sl >= th && sl > nbl && onL) keep |= 1u;
+                    if (sr >= th && sr > nbr && onR) keep |= 2u;
+                }
+                const int xl = 2 * qp;
+                const bool kL = keep & 1u, kR = keep & 2u, cL = xl >= B, cR = xl + 1 >= B;      // kept flags, cell (0 / 1) of each pixel
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const bool mL = kL && (int)cL == c, mR = kR && (int)cR == c;
+                    const unsigned long long bL = __ballot(mL), bR = __ballot(mR);
+                    const int before = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bL >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bL, 0u)) +
+                                       (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bR >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bR, 0u));
+                    const int base = c ? tot1 : tot0;
+                    uint32_t *lst = list + (size_t)c * cell_cap;
+                    if (mL) { const int o = base + before; if (o < cell_cap) lst[o] = ORB_PACK_KEY(xl + key_x0, by + key_y0, sc & 0xFFu); }
+                    if (mR) { const int o = base + before + (mL ? 1 : 0); if (o < cell_cap) lst[o] = ORB_PACK_KEY(xl + 1 + key_x0, by + key_y0, (sc >> 8) & 0xFFu); }
+                    const int add = __popcll(bL) + __popcll(bR);
+                    if (c) tot1 += add; else tot0 += add;
+                }
+            }
+            if (pass || min_th == ini_th) break;
+            empty = (tot0 == 0 && dw0 > 0 ? 1u : 0u) | (tot1 == 0 && dw1 > 0 ? 2u : 0u);        // vKeysCell.empty() at iniThFAST (ORBextractor.cc:825-828)
+            if (!empty) break;
+            FC_WAVE_SYNC();                                        // the second pass rewrites Q and SC
+        }
+        if (tot0 > cell_cap || tot1 > cell_cap) { if (lane == 0) atomicExch(P.status, ORBHIP_E_CAPACITY); tot0 = min(tot0, cell_cap); tot1 = min(tot1, cell_cap); }
+        if (lane == 0) { cnt_out[0] = (uint32_t)tot0; if (nc > 1) cnt_out[1] = (uint32_t)tot1; }
+        C = N;
+    }
+#undef FC_WAVE_SYNC
+}
+const void *orb_fast_runs_func(int nld) { return nld == 4 ? reinterpret_cast<const void *>(k_fast_runs<4>) : reinterpret_cast<const void *>(k_fast_runs<6>); }
+
 const void *orb_fast_cells_func(int small);
 void orb_launch_fast_cells(const FastParams &F_, hipStream_t s, int max_per_cu, int lvl_lo, int lvl_hi)
 {
     FastParams F = F_;
     F.lvl_lo = lvl_lo; F.lvl_hi = lvl_hi < 0 ? F.nlevels : lvl_hi;
     if (F.lvl_lo >= F.lvl_hi) return;
+    const bool runs = F.use_runs != 0;
     // persistent single-wave workgroups: as many as the LDS lets a CU hold, a whole number per XCD
-    const size_t lds = sizeof(uint32_t) * (size_t)F.wave_dw;
+    const size_t lds = sizeof(uint32_t) * (size_t)(runs ? F.run_dw : F.wave_dw);
     // as many as the runtime says fit (LDS, wave slots), asked once per (device, kernel variant, LDS size).  The left and right images
     // of a stereo frame are extracted on two threads (Frame.cc:109-110) and a process may drive several GPUs: the table is guarded
-    const int v = F.small_cells ? 1 : 0;
+    const int nld = (F.run_rows - 7) * FR_NCH <= 256 ? 4 : 6;
+    const int v = runs ? (nld == 4 ? 2 : 3) : F.small_cells ? 1 : 0;
     int per_cu;
     {
         struct Occ { int dev, v, n; size_t lds; };
@@ -592,21 +851,25 @@ void orb_launch_fast_cells(const FastParams &F_, hipStream_t s, int max_per_cu, 
         for (const Occ &o : occ_tab) if (o.dev == dev && o.v == v && o.lds == lds) { hit = &o; break; }
         if (!hit) {
             int n = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, orb_fast_cells_func(v), 64, lds) != hipSuccess || n < 1) n = (int)((160 * 1024) / (lds + 512));
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, v >= 2 ? orb_fast_runs_func(nld) : orb_fast_cells_func(v), 64, lds) != hipSuccess || n < 1) n = (int)((160 * 1024) / (lds + 512));
             occ_tab.push_back(Occ{dev, v, n < 1 ? 1 : n, lds}); hit = &occ_tab.back();
-            if (getenv("ORBHIP_DEBUG_FAST")) fprintf(stderr, "[orbhip] k_fast_cells: %zu B of LDS per wave, %d waves per CU resident\n", lds, hit->n);
+            if (getenv("ORBHIP_DEBUG_FAST")) fprintf(stderr, "[orbhip] %s: %zu B of LDS per wave, %d waves per CU resident\n", v >= 2 ? "k_fast_runs" : "k_fast_cells", lds, hit->n);
         }
         per_cu = hit->n;
     }
     if (max_per_cu > 0 && per_cu > max_per_cu) per_cu = max_per_cu;      // leave LDS and wave slots to a kernel running beside this one
     long nblocks = (long)(F.n_cus > 0 ? F.n_cus : 256) * per_cu;
-    const long total = (long)F.batch * ((F.lvl_hi < F.nlevels ? F.lv[F.lvl_hi].cell_base : F.cells_per_frame) - F.lv[F.lvl_lo].cell_base);
+    const long total = runs ? (long)F.batch * ((F.lvl_hi < F.nlevels ? F.lv[F.lvl_hi].run_base : F.runs_per_frame) - F.lv[F.lvl_lo].run_base)
+                            : (long)F.batch * ((F.lvl_hi < F.nlevels ? F.lv[F.lvl_hi].cell_base : F.cells_per_frame) - F.lv[F.lvl_lo].cell_base);
     if (nblocks > total) nblocks = (total + 7) / 8 * 8;
-    // chunks of up to 16 consecutive cells (they share aprons and level parameters), at least ~8 chunks per wave so that the shares even out
+    // chunks of up to 16 consecutive cells (8 runs): they share aprons and level parameters; at least ~8 chunks per wave so that the shares even out
     static const int chunk_env = getenv("ORBHIP_TUNE_FAST_CHUNK") ? atoi(getenv("ORBHIP_TUNE_FAST_CHUNK")) : 0;
     const long fair = total / (8 * nblocks);
-    F.chunk = chunk_env > 0 ? chunk_env : (int)(fair < 1 ? 1 : fair > 16 ? 16 : fair);
-    if (F.small_cells) hipLaunchKernelGGL((k_fast_cells<3, 24, 2>), dim3((unsigned)nblocks), dim3(64), lds, s, F);
+    const int cmax = runs ? 8 : 16;
+    F.chunk = chunk_env > 0 ? chunk_env : (int)(fair < 1 ? 1 : fair > cmax ? cmax : fair);
+    if (runs && nld == 4) hipLaunchKernelGGL(k_fast_runs<4>, dim3((unsigned)nblocks), dim3(64), lds, s, F);
+    else if (runs) hipLaunchKernelGGL(k_fast_runs<6>, dim3((unsigned)nblocks), dim3(64), lds, s, F);
+    else if (F.small_cells) hipLaunchKernelGGL((k_fast_cells<3, 24, 2>), dim3((unsigned)nblocks), dim3(64), lds, s, F);
     else hipLaunchKernelGGL((k_fast_cells<5, 32, 5>), dim3((unsigned)nblocks), dim3(64), lds, s, F);
 }
 const void *orb_fast_cells_func(int small) { return small ? reinterpret_cast<const void *>(k_fast_cells<3, 24, 2>) : reinterpret_cast<const void *>(k_fast_cells<5, 32, 5>); }

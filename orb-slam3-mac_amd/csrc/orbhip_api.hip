@@ -429,6 +429,27 @@ extern "C" int orbhip_extractor_reserve(orbhip_extractor *e, int width, int heig
             (void)nq;
             small = small && npb + 4 <= 24 && npb + 2 <= 24 && (L.hcell + 6) * 3 <= 64 * 2;       // <3, 24, 2>: 24 pairs per row, 128 chunk tasks
         }
+        {   // k_fast_runs: a wave works on a RUN of cells of one cell row -- two while both fit the 32 pixel-pair columns of a half wave
+            int runs = 0;
+            bool ok = true;
+            for (int l = 0; l < e->nlevels; l++) {
+                const OrbLevel &L = P.lv[l];
+                FcLevel &f = F.lv[l];
+                f.rpc = 2 * L.wcell <= 64 ? 2 : 1;
+                f.rpr = (L.ncols + f.rpc - 1) / f.rpc;
+                f.run_base = runs; runs += f.rpr * L.nrows;
+                ok = ok && L.wcell <= 64 && L.hcell + 6 <= 70 && L.wcell >= 8 && L.hcell >= 8;
+            }
+            const int hh = (mh + 1) / 2;
+            F.runs_per_frame = runs;
+            F.run_rows = mh + 6 + 7;                                               // + the rows a seven-row trip of the column walk may read past the band
+            F.run_q0 = (hh * 32 + 7) & ~7;                                         // first queue: the upper half of the rows (u16 entries)
+            F.run_dw = F.run_rows * 40 + (((mh + 2) * 40 + 2 * F.run_q0) + 1) / 2;   // pair tile + u16 score tile + u16 queues
+            F.run_dw = (F.run_dw + 3) & ~3;
+            // OPT-IN (ORBHIP_FAST_KERNEL=runs when the extractor reserves): bit-exact (every tests/test_gpu_orb.py test with it forced), but measured
+            // SLOWER than k_fast_cells -- 1.72 ms (row-at-a-time ring) / 2.43 ms (seven-row trips) against 1.49 ms per 1024 VGA frames
+            F.use_runs = ok && getenv("ORBHIP_FAST_KERNEL") && !strcmp(getenv("ORBHIP_FAST_KERNEL"), "runs") ? 1 : 0;
+        }
         const int npb = (mw + 1) >> 1;
         F.small_cells = small ? 1 : 0;
         F.rows = mh + 6; F.srows = mh; F.qcap = (mh * npb + 1) & ~1;
@@ -598,6 +619,7 @@ extern "C" int orbhip_extractor_reserve(orbhip_extractor *e, int width, int heig
     if (orb_octree_lds_bytes(P.oct_nc) > 150 * 1024) { g_last_error = "per-level quota (or nIni) too large for the LDS-resident octree"; return ORBHIP_E_BADARG; }
     if ((rc = orb_lds_optin(orb_octree_func(), e->ctx->device, orb_octree_lds_bytes(P.oct_nc)))) return rc;
     if ((rc = orb_lds_optin(orb_fast_cells_func(e->F.small_cells), e->ctx->device, sizeof(uint32_t) * (size_t)e->F.wave_dw))) return rc;
+    if (e->F.use_runs && (rc = orb_lds_optin(orb_fast_runs_func((e->F.run_rows - 7) * 5 <= 256 ? 4 : 6), e->ctx->device, sizeof(uint32_t) * (size_t)e->F.run_dw))) return rc;
     e->width = width; e->height = height; e->max_batch = max_batch;
     return ORBHIP_OK;
 }
