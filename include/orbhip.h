@@ -547,7 +547,25 @@ typedef struct {
     double fx2, fy2, cx2, cy2;
     int32_t camera2_model;      /* as camera_model */
     double kb2[4];
+    /* Per-keyframe calibration (round 4).  The reference hands every edge its OWN keyframe's camera -- e->pCamera = pKFi->mpCamera
+     * (src/Optimizer.cc:1961), e->fx ... e->bf = pKFi->fx ... pKFi->mbf (:1990-1994), e->mTrl / e->pCamera2 = pKFi->mTrl / mpCamera2
+     * (:2021-2023) -- so a window of an Atlas map built from two cameras mixes calibrations.  n_cameras > 0: pose i projects through
+     * cameras[pose_camera[i]] (all nine groups of fields of the entry; the single-calibration fields above are then ignored);
+     * n_cameras == 0: every pose uses the fields above (cameras / pose_camera may be NULL). */
+    int32_t n_cameras;
+    const struct orbhip_ba_camera *cameras;   /* [n_cameras] */
+    const int32_t *pose_camera;               /* [n_poses] index into cameras */
 } orbhip_ba_graph;
+/* one calibration of a BA graph: the same fields, with the same meaning, as the single-calibration part of orbhip_ba_graph */
+typedef struct orbhip_ba_camera {
+    double fx, fy, cx, cy, bf;
+    int32_t camera_model;
+    double kb[4];
+    double Trl[7];
+    double fx2, fy2, cx2, cy2;
+    int32_t camera2_model;
+    double kb2[4];
+} orbhip_ba_camera;
 
 typedef struct {
     int32_t iters1, iters2;     /* optimize(5) then optimize(10): Optimizer.cc:2048,2122 */

@@ -318,10 +318,26 @@ void orc_ba_edge_tobody(const orc_ba_graph *g, const double pose[7], const doubl
         for (int c = 0; c < 6; c++)
             Jt[6 * r + c] = -(M[3 * r] * D[c] + M[3 * r + 1] * D[6 + c] + M[3 * r + 2] * D[12 + c]);
 }
+/* The graph as the edges of pose `pi` see it: with per-keyframe calibration (n_cameras > 0) a copy whose calibration fields are that
+ * keyframe's camera (e->pCamera = pKFi->mpCamera, e->fx = pKFi->fx ..., Optimizer.cc:1961, :1990-1994, :2021-2023), else g itself */
+static const orc_ba_graph *graph_of_pose(const orc_ba_graph *g, int pi, orc_ba_graph *tmp)
+{
+    if (g->n_cameras <= 0) return g;
+    const orc_ba_camera *c = g->cameras + g->pose_camera[pi];
+    *tmp = *g;
+    tmp->fx = c->fx; tmp->fy = c->fy; tmp->cx = c->cx; tmp->cy = c->cy; tmp->bf = c->bf; tmp->camera_model = c->camera_model;
+    memcpy(tmp->kb, c->kb, sizeof(tmp->kb)); memcpy(tmp->Trl, c->Trl, sizeof(tmp->Trl));
+    tmp->fx2 = c->fx2; tmp->fy2 = c->fy2; tmp->cx2 = c->cx2; tmp->cy2 = c->cy2; tmp->camera2_model = c->camera2_model;
+    memcpy(tmp->kb2, c->kb2, sizeof(tmp->kb2));
+    return tmp;
+}
+
 /* depth of the edge's camera-frame point (isDepthPositive of the three edge types) */
-static double edge_depth(const orc_ba_graph *g, const double pose[7], const double X[3], int type)
+static double edge_depth(const orc_ba_graph *g0, int pi, const double pose[7], const double X[3], int type)
 {
     double P[3];
+    orc_ba_graph gtmp;
+    const orc_ba_graph *g = graph_of_pose(g0, pi, &gtmp);              /* mTrl of the edge's own keyframe */
     if (type == 2) { double Trw[7]; se3_mul(g->Trl, pose, Trw); map_point(Trw, X, P); }
     else map_point(pose, X, P);
     return P[2];
@@ -351,9 +367,11 @@ static int terminate(const struct ba *B) { return B->abort_flag ? *B->abort_flag
 /* computeActiveErrors (SO:61-94) + chi2 (base_edge.h:58-61) */
 static void compute_errors(struct ba *B)
 {
-    const orc_ba_graph *g = B->g;
+    const orc_ba_graph *g0 = B->g;
+    orc_ba_graph gtmp;
     for (int e = 0; e < B->E; e++) {
         if (B->level[e]) continue;                      /* not an active edge: _error stays as last computed */
+        const orc_ba_graph *g = graph_of_pose(g0, g0->edge_pose[e], &gtmp);
         double *er = B->err + 3 * e;
         if (g->edge_stereo[e] == 2) { double Pr[3]; tobody_error(g, B->poses + 7 * g->edge_pose[e], B->points + 3 * g->edge_point[e], g->edge_obs + 3 * e, er, Pr); }
         else
@@ -387,7 +405,8 @@ static double robust_chi2(const struct ba *B)
 /* BlockSolver::buildSystem (BS:502-560) = linearizeOplus + constructQuadraticForm (BBE:55-120) */
 static void build_system(struct ba *B)
 {
-    const orc_ba_graph *g = B->g;
+    const orc_ba_graph *g0 = B->g;
+    orc_ba_graph gtmp;
     memset(B->Hpp, 0, sizeof(double) * 36 * (B->nf ? B->nf : 1));
     memset(B->bp, 0, sizeof(double) * (B->n ? B->n : 1));
     memset(B->Hll, 0, sizeof(double) * 9 * B->L);
@@ -395,6 +414,7 @@ static void build_system(struct ba *B)
     memset(B->W, 0, sizeof(double) * 18 * B->E);
     for (int e = 0; e < B->E; e++) {
         if (B->level[e]) continue;
+        const orc_ba_graph *g = graph_of_pose(g0, g0->edge_pose[e], &gtmp);
         const int D = g->edge_stereo[e] == 1 ? 3 : 2;
         const int pi = g->edge_pose[e], li = g->edge_point[e], hi = B->hidx[pi];
         double er[3], Jx[9], Jt[18], rho[2];
@@ -664,7 +684,7 @@ int orc_ba_solve_ex(const orc_ba_graph *g, const orc_ba_params *p, const volatil
     const double gate_m = p->gate_mono2 > 0 ? p->gate_mono2 : p->huber_mono2, gate_s = p->gate_stereo2 > 0 ? p->gate_stereo2 : p->huber_stereo2;
     if (do_more && (p->stage2_exclude_outliers || p->stage2_drop_robust)) {                  /* merge variant, Optimizer.cc:6546-6579 */
         for (int e = 0; e < B.E; e++) {
-            const double zc = edge_depth(g, B.poses + 7 * g->edge_pose[e], B.points + 3 * g->edge_point[e], g->edge_stereo[e]);
+            const double zc = edge_depth(g, g->edge_pose[e], B.poses + 7 * g->edge_pose[e], B.points + 3 * g->edge_point[e], g->edge_stereo[e]);
             if (p->stage2_exclude_outliers && (B.chi2[e] > (g->edge_stereo[e] == 1 ? gate_s : gate_m) || !(zc > 0.0))) B.level[e] = 1;
         }
         if (p->stage2_drop_robust) B.robust = 0;
@@ -673,7 +693,7 @@ int orc_ba_solve_ex(const orc_ba_graph *g, const orc_ba_params *p, const volatil
     st.lm_trials = B.lm_trials;
     /* outliers, LBA:2126-2173: chi2 from the stored (last evaluated) error; depth from current estimates */
     for (int e = 0; e < B.E; e++) {
-        const double zc = edge_depth(g, B.poses + 7 * g->edge_pose[e], B.points + 3 * g->edge_point[e], g->edge_stereo[e]);
+        const double zc = edge_depth(g, g->edge_pose[e], B.poses + 7 * g->edge_pose[e], B.points + 3 * g->edge_point[e], g->edge_stereo[e]);
         const double gate = g->edge_stereo[e] == 1 ? gate_s : gate_m;
         const int out = (B.chi2[e] > gate) || !(zc > 0.0);
         if (edge_outlier) edge_outlier[e] = (uint8_t)out;

@@ -33,7 +33,21 @@ typedef struct {
     double fx2, fy2, cx2, cy2;
     int32_t camera2_model;
     double kb2[4];
+    /* per-keyframe calibration: every edge projects through its own keyframe's camera (Optimizer.cc:1961, :1990-1994, :2021-2023).
+     * n_cameras > 0: pose i uses cameras[pose_camera[i]], the fields above are ignored */
+    int32_t n_cameras;
+    const struct orc_ba_camera *cameras;
+    const int32_t *pose_camera;
 } orc_ba_graph;
+typedef struct orc_ba_camera {
+    double fx, fy, cx, cy, bf;
+    int32_t camera_model;
+    double kb[4];
+    double Trl[7];
+    double fx2, fy2, cx2, cy2;
+    int32_t camera2_model;
+    double kb2[4];
+} orc_ba_camera;
 
 typedef struct {
     int32_t iters1, iters2;

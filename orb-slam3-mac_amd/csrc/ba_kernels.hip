@@ -59,6 +59,16 @@ struct BaGraphDev {
     int cam2_model;
     // windows with more than 80 free keyframes (n > BA_LDLT_MAXN): global-memory Schur complement and blocked LDL^T
     size_t pair_off, pent_off;                       // into big_pair_start (nf (nf + 1) / 2 + 1 entries) / big_pair_ent
+    int cam_off;                                     // >= 0: per-keyframe calibration -- pose i of this graph uses cams[cam_off + pose_cam[pose_off + i]] (round 4)
+};
+// One calibration (round 4: the reference gives every edge its keyframe's own, Optimizer.cc:1961, :1990-1994, :2021-2023).  The edge
+// functions below are templates over the calibration object: a BaGraphDev (one calibration per graph) or a BaCamDev -- same field names.
+struct BaCamDev {
+    double fx, fy, cx, cy, bf;
+    int cam_model;
+    double kb[4];
+    double Trl[7], fx2, fy2, cx2, cy2, kb2[4];
+    int cam2_model;
 };
 
 struct BaState {
@@ -76,6 +86,7 @@ struct BaState {
 struct BaBatch {      // kernel argument (by value)
     int G, max_edges, max_points, max_nf, max_ld;
     const BaGraphDev *gd;
+    const BaCamDev *cams; const int *pose_cam;       // per-keyframe calibration tables ([sum of n_cameras], [sumP]); see BaGraphDev::cam_off
     BaState *st;
     // graph topology
     const int *hidx;            // [sumP]
@@ -138,6 +149,20 @@ struct BaBatch {      // kernel argument (by value)
     double *big_y, *big_d, *big_U;                           // [sumF*6] forward-substituted right-hand side, pivots; [G][32*32] unscaled diagonal-block columns
     int *big_fail;                                           // [G] a zero / non-finite pivot was met
 };
+
+// The calibration the edges of pose `pi` (local index) of graph G project through: the keyframe's own camera when the graph carries a
+// camera table, else the graph's single calibration (uniform values: scalar loads)
+template <bool GENERAL>
+__device__ __forceinline__ void ba_cam_of(const BaBatch &B, const BaGraphDev &G, int pi, BaCamDev &c)
+{
+    if (GENERAL && G.cam_off >= 0) { c = B.cams[G.cam_off + B.pose_cam[G.pose_off + pi]]; return; }
+    c.fx = G.fx; c.fy = G.fy; c.cx = G.cx; c.cy = G.cy; c.bf = G.bf; c.cam_model = G.cam_model;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { c.kb[k] = G.kb[k]; c.kb2[k] = G.kb2[k]; }
+#pragma unroll
+    for (int k = 0; k < 7; k++) c.Trl[k] = G.Trl[k];
+    c.fx2 = G.fx2; c.fy2 = G.fy2; c.cx2 = G.cx2; c.cy2 = G.cy2; c.cam2_model = G.cam2_model;
+}
 
 // ------------------------------------------------------------------ SE3 helpers (B1)
 __device__ __forceinline__ void quat_to_R(const double *q, double *R)
@@ -255,7 +280,8 @@ __device__ __forceinline__ void se3_mul(const double *a, const double *b, double
     o[4] = a[4] + rt[0]; o[5] = a[5] + rt[1]; o[6] = a[6] + rt[2];
 }
 // EdgeSE3ProjectXYZToBody::computeError (OptimizableTypes.h:121-126): obs - cam2.project((mTrl * T_lw).map(X)); P = that point
-__device__ __forceinline__ void tobody_error(const BaGraphDev &g, const double *pose, const double *X, const double *obs, double *P, double *err)
+template <class CAM>
+__device__ __forceinline__ void tobody_error(const CAM &g, const double *pose, const double *X, const double *obs, double *P, double *err)
 {
     double Trw[7], uv[2];
     se3_mul(g.Trl, pose, Trw);
@@ -265,7 +291,8 @@ __device__ __forceinline__ void tobody_error(const BaGraphDev &g, const double *
     err[0] = obs[0] - uv[0]; err[1] = obs[1] - uv[1]; err[2] = 0;
 }
 // EdgeSE3ProjectXYZToBody::linearizeOplus (OptimizableTypes.cpp:192-213); rows 2 of Jx / Jt zeroed
-__device__ __forceinline__ void tobody_jacobians(const BaGraphDev &g, const double *pose, const double *X, double *Jx, double *Jt)
+template <class CAM>
+__device__ __forceinline__ void tobody_jacobians(const CAM &g, const double *pose, const double *X, double *Jx, double *Jt)
 {
     double Trw[7], Xl[3], Xr[3], J[6], Rrw[9], Rrl[9], M[6];
     se3_mul(g.Trl, pose, Trw);
@@ -293,7 +320,8 @@ __device__ __forceinline__ void tobody_jacobians(const BaGraphDev &g, const doub
     for (int k = 12; k < 18; k++) Jt[k] = 0;
 }
 // z of the edge's camera-frame point (isDepthPositive of the three edge types)
-__device__ __forceinline__ double edge_depth(const BaGraphDev &g, const double *pose, const double *X, int type)
+template <class CAM>
+__device__ __forceinline__ double edge_depth(const CAM &g, const double *pose, const double *X, int type)
 {
     double P[3];
     if (type == 2) { double Trw[7]; se3_mul(g.Trl, pose, Trw); quat_rot(Trw, X, P); return P[2] + Trw[6]; }
@@ -302,8 +330,8 @@ __device__ __forceinline__ double edge_depth(const BaGraphDev &g, const double *
 }
 
 // ------------------------------------------------------------------ edge math (B2, B3)
-template <bool KB = true>      // KB = false: Pinhole only (the KannalaBrandt8 branch and its registers compile away)
-__device__ __forceinline__ void edge_error(const BaGraphDev &g, const double *pose, const double *X, const double *obs,
+template <bool KB = true, class CAM = BaGraphDev>      // KB = false: Pinhole only (the KannalaBrandt8 branch and its registers compile away)
+__device__ __forceinline__ void edge_error(const CAM &g, const double *pose, const double *X, const double *obs,
                                            int stereo, double *P, double *err)
 {
     quat_rot(pose, X, P);
@@ -334,8 +362,8 @@ __device__ __forceinline__ void edge_error(const BaGraphDev &g, const double *po
 }
 
 // Jacobians at camera-frame point P with rotation R.  Jx: D x 3, Jt: D x 6 (row-major)
-template <bool KB = true>
-__device__ __forceinline__ void edge_jacobians(const BaGraphDev &g, const double *P, const double *R, int stereo, double *Jx, double *Jt)
+template <bool KB = true, class CAM = BaGraphDev>
+__device__ __forceinline__ void edge_jacobians(const CAM &g, const double *P, const double *R, int stereo, double *Jx, double *Jt)
 {
     const double x = P[0], y = P[1], z = P[2];
     if (KB && !stereo && g.cam_model == 1) {   // KannalaBrandt8::projectJac, KannalaBrandt8.cpp:166-195
@@ -411,8 +439,10 @@ __global__ __launch_bounds__(256) void k_ba_errors(BaBatch B, int which)
     const double *X = B.points + ((size_t)buf * B.sumL + G.point_off + B.edge_point[ge]) * 3;
     double P[3], er[3];
     const int type = B.edge_stereo[ge], stereo = type == 1;          // 0 mono, 1 stereo, 2 second camera (ToBody)
-    if (GENERAL && type == 2) tobody_error(G, pose, X, B.edge_obs + 3 * (size_t)ge, P, er);
-    else edge_error<GENERAL>(G, pose, X, B.edge_obs + 3 * (size_t)ge, stereo, P, er);
+    BaCamDev cam;
+    ba_cam_of<GENERAL>(B, G, B.edge_pose[ge], cam);
+    if (GENERAL && type == 2) tobody_error(cam, pose, X, B.edge_obs + 3 * (size_t)ge, P, er);
+    else edge_error<GENERAL>(cam, pose, X, B.edge_obs + 3 * (size_t)ge, stereo, P, er);
     const double chi2 = (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * B.edge_is2[ge];
     double r0, r1;
     if (!st.robust) { r0 = chi2; r1 = 1.; }
@@ -491,12 +521,14 @@ __global__ __launch_bounds__(256) void k_ba_build_points(BaBatch B)
         for (int k = 6; k < 9; k++) Jx[k] = 0;
 #pragma unroll
         for (int k = 12; k < 18; k++) Jt[k] = 0;                                     // monocular edge: third row empty
-        if (GENERAL && type == 2) tobody_jacobians(G, pose, X, Jx, Jt);
+        BaCamDev cam;
+        ba_cam_of<GENERAL>(B, G, pi, cam);
+        if (GENERAL && type == 2) tobody_jacobians(cam, pose, X, Jx, Jt);
         else {
             quat_rot(pose, X, P);
             P[0] += pose[4]; P[1] += pose[5]; P[2] += pose[6];
             quat_to_R(pose, R);
-            edge_jacobians<GENERAL>(G, P, R, stereo, Jx, Jt);
+            edge_jacobians<GENERAL>(cam, P, R, stereo, Jx, Jt);
         }
         const double chi2 = B.chi2[ge];
         double r0, r1;
@@ -529,12 +561,12 @@ __global__ __launch_bounds__(256) void k_ba_build_points(BaBatch B)
                 double P2[3], R2[9], Jx2[9], Jt2[18];
                 for (int k = 6; k < 9; k++) Jx2[k] = 0;
                 for (int k = 12; k < 18; k++) Jt2[k] = 0;
-                if (type2 == 2) tobody_jacobians(G, pose, X, Jx2, Jt2);
+                if (type2 == 2) tobody_jacobians(cam, pose, X, Jx2, Jt2);
                 else {
                     quat_rot(pose, X, P2);
                     P2[0] += pose[4]; P2[1] += pose[5]; P2[2] += pose[6];
                     quat_to_R(pose, R2);
-                    edge_jacobians(G, P2, R2, st2, Jx2, Jt2);
+                    edge_jacobians(cam, P2, R2, st2, Jx2, Jt2);
                 }
                 double q0, q1;
                 if (!st.robust) q1 = 1.;
@@ -581,7 +613,10 @@ __global__ __launch_bounds__(64) void k_ba_build_poses(BaBatch B)
     for (int i = 0; i < 27; i++) acc[i] = 0;
     // every edge of this list has the same pose; the edge's error / chi2 are recomputed from the pose-major copy of its static data
     // (bit-identical to k_ba_errors: same inputs, same code) instead of being gathered from the point-major arrays
-    const double *pose = B.poses + ((size_t)st.cur * B.sumP + G.pose_off + (qs[h] < qs[h + 1] ? B.edge_pose[G.edge_off + pe[qs[h]]] : 0)) * 7;
+    const int pose_i = qs[h] < qs[h + 1] ? B.edge_pose[G.edge_off + pe[qs[h]]] : 0;
+    const double *pose = B.poses + ((size_t)st.cur * B.sumP + G.pose_off + pose_i) * 7;
+    BaCamDev cam;
+    ba_cam_of<GENERAL>(B, G, pose_i, cam);
     for (int k = qs[h] + lane; k < qs[h + 1]; k += 64) {
         const size_t gk = (size_t)G.edge_off + k;
         const double *X = B.points + ((size_t)st.cur * B.sumL + G.point_off + B.pm_point[gk]) * 3;
@@ -589,11 +624,11 @@ __global__ __launch_bounds__(64) void k_ba_build_poses(BaBatch B)
         double P[3], R[9], Jx[9], Jt[18], es[3];
 #pragma unroll
         for (int q = 12; q < 18; q++) Jt[q] = 0;                  // monocular edge: third row empty (the loops below run all 3 rows)
-        if (GENERAL && type == 2) { tobody_error(G, pose, X, B.pm_obs + 3 * gk, P, es); tobody_jacobians(G, pose, X, Jx, Jt); }
+        if (GENERAL && type == 2) { tobody_error(cam, pose, X, B.pm_obs + 3 * gk, P, es); tobody_jacobians(cam, pose, X, Jx, Jt); }
         else {
-            edge_error<GENERAL>(G, pose, X, B.pm_obs + 3 * gk, stereo, P, es);
+            edge_error<GENERAL>(cam, pose, X, B.pm_obs + 3 * gk, stereo, P, es);
             quat_to_R(pose, R);
-            edge_jacobians<GENERAL>(G, P, R, stereo, Jx, Jt);
+            edge_jacobians<GENERAL>(cam, P, R, stereo, Jx, Jt);
         }
         const double is2 = B.pm_is2[gk];
         const double chi2 = (es[0] * es[0] + es[1] * es[1] + es[2] * es[2]) * is2;
@@ -1574,7 +1609,9 @@ __global__ __launch_bounds__(256) void k_ba_levels(BaBatch B)
     const int ge = G.edge_off + e;
     const double *pose = B.poses + ((size_t)st.cur * B.sumP + G.pose_off + B.edge_pose[ge]) * 7;
     const double *X = B.points + ((size_t)st.cur * B.sumL + G.point_off + B.edge_point[ge]) * 3;
-    const double z = edge_depth(G, pose, X, B.edge_stereo[ge]);
+    BaCamDev cam;
+    ba_cam_of<true>(B, G, B.edge_pose[ge], cam);                  // (mTrl of the edge's own keyframe)
+    const double z = edge_depth(cam, pose, X, B.edge_stereo[ge]);
     const double gate = B.edge_stereo[ge] == 1 ? B.gate_s : B.gate_m;
     if ((B.chi2[ge] > gate) || !(z > 0.0)) B.level[ge] = 1;
 }
@@ -1590,7 +1627,9 @@ __global__ __launch_bounds__(256) void k_ba_finalize(BaBatch B)
     const int ge = G.edge_off + e;
     const double *pose = B.poses + ((size_t)st.cur * B.sumP + G.pose_off + B.edge_pose[ge]) * 7;
     const double *X = B.points + ((size_t)st.cur * B.sumL + G.point_off + B.edge_point[ge]) * 3;
-    const double z = edge_depth(G, pose, X, B.edge_stereo[ge]);
+    BaCamDev cam;
+    ba_cam_of<true>(B, G, B.edge_pose[ge], cam);                  // (mTrl of the edge's own keyframe)
+    const double z = edge_depth(cam, pose, X, B.edge_stereo[ge]);
     const double gate = B.edge_stereo[ge] == 1 ? B.gate_s : B.gate_m;
     const int out = (B.chi2[ge] > gate) || !(z > 0.0);
     B.outlier[ge] = (uint8_t)out;
@@ -1722,6 +1761,8 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
     };
     static thread_local Scratch SC;
     SC.clear();
+    std::vector<BaCamDev> cams;
+    std::vector<int> posecam;
     std::vector<int> &x1off = SC.x1off, &x2off = SC.x2off;
     size_t x1 = 0, x2 = 0;
     std::vector<int> &hidx = SC.hidx, &epose = SC.epose, &epoint = SC.epoint, &ptstart = SC.ptstart, &posestart = SC.posestart, &poseedges = SC.poseedges;
@@ -1760,6 +1801,25 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
         D.cam_model = H.camera_model; for (int k = 0; k < 4; k++) D.kb[k] = H.kb[k];
         for (int k = 0; k < 7; k++) D.Trl[k] = H.Trl[k];
         D.fx2 = H.fx2; D.fy2 = H.fy2; D.cx2 = H.cx2; D.cy2 = H.cy2; D.cam2_model = H.camera2_model; for (int k = 0; k < 4; k++) D.kb2[k] = H.kb2[k];
+        D.cam_off = -1;
+        if (H.n_cameras > 0) {                                   // per-keyframe calibration (Optimizer.cc:1961, :1990-1994, :2021-2023)
+            if (!H.cameras || !H.pose_camera) { delete b; g_ba_error = "n_cameras > 0 needs cameras and pose_camera"; return ORBHIP_E_BADARG; }
+            D.cam_off = (int)cams.size();
+            for (int c = 0; c < H.n_cameras; c++) {
+                const orbhip_ba_camera &Cc = H.cameras[c];
+                BaCamDev K;
+                K.fx = Cc.fx; K.fy = Cc.fy; K.cx = Cc.cx; K.cy = Cc.cy; K.bf = Cc.bf; K.cam_model = Cc.camera_model;
+                for (int k = 0; k < 4; k++) { K.kb[k] = Cc.kb[k]; K.kb2[k] = Cc.kb2[k]; }
+                for (int k = 0; k < 7; k++) K.Trl[k] = Cc.Trl[k];
+                K.fx2 = Cc.fx2; K.fy2 = Cc.fy2; K.cx2 = Cc.cx2; K.cy2 = Cc.cy2; K.cam2_model = Cc.camera2_model;
+                cams.push_back(K);
+            }
+            for (int i = 0; i < H.n_poses; i++) {
+                if (H.pose_camera[i] < 0 || H.pose_camera[i] >= H.n_cameras) { delete b; g_ba_error = "pose_camera out of range"; return ORBHIP_E_BADARG; }
+                posecam.push_back(H.pose_camera[i]);
+            }
+            b->general = true;                                   // the camera table is read by the general instantiations only
+        } else posecam.insert(posecam.end(), (size_t)H.n_poses, 0);
         std::vector<int> has(H.n_poses, 0), local_h(H.n_poses, -1);
         for (int e = 0; e < H.n_edges; e++) {
             if (H.edge_pose[e] < 0 || H.edge_pose[e] >= H.n_poses || H.edge_point[e] < 0 || H.edge_point[e] >= H.n_points ||
@@ -1803,7 +1863,14 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
                 any2 = any2 || H.edge_stereo[e] == 2;
             }
             const double qn = H.Trl[0] * H.Trl[0] + H.Trl[1] * H.Trl[1] + H.Trl[2] * H.Trl[2] + H.Trl[3] * H.Trl[3];
-            if (any2 && !(qn > 0.0)) { delete b; g_ba_error = "edges of type 2 need Trl (mTrl) and the second camera"; return ORBHIP_E_BADARG; }
+            if (any2 && H.n_cameras <= 0 && !(qn > 0.0)) { delete b; g_ba_error = "edges of type 2 need Trl (mTrl) and the second camera"; return ORBHIP_E_BADARG; }
+            for (int e = 0; e < H.n_edges && any2 && H.n_cameras > 0 && H.cameras && H.pose_camera; e++) {
+                if (H.edge_stereo[e] != 2) continue;
+                const int ci = H.pose_camera[H.edge_pose[e]];
+                if (ci < 0 || ci >= H.n_cameras) continue;       // (reported below)
+                const double *t = H.cameras[ci].Trl;
+                if (!(t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3] > 0.0)) { delete b; g_ba_error = "edges of type 2 need their keyframe's Trl (mTrl) and second camera"; return ORBHIP_E_BADARG; }
+            }
         }
         {   // chains of edges that share (point, pose): edges are point-major, so only a point's own edges are compared
             std::vector<int> nxt(H.n_edges, -1); std::vector<uint8_t> dup(H.n_edges, 0);
@@ -2010,7 +2077,7 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
     BaPlan plan;
 #define UP(dst, vec) plan.add((void **)&(dst), (vec).empty() ? (const void *)&plan : (const void *)(vec).data(), (vec).size() * sizeof((vec)[0]))
 #define AL(dst, T, n) plan.add((void **)&(dst), nullptr, (size_t)(n) * sizeof(T))
-    UP(B.gd, b->gd); UP(B.hidx, hidx); UP(B.edge_pose, epose); UP(B.edge_point, epoint); UP(B.edge_obs, eobs);
+    UP(B.gd, b->gd); UP(B.cams, cams); UP(B.pose_cam, posecam); UP(B.hidx, hidx); UP(B.edge_pose, epose); UP(B.edge_point, epoint); UP(B.edge_obs, eobs);
     UP(B.edge_is2, eis2); UP(B.edge_stereo, est); UP(B.edge_dup, edup); UP(B.edge_next, enext); UP(B.pt_start, ptstart); UP(B.pose_start, posestart); UP(B.pose_edges, poseedges);
     UP(B.ptmask, ptmask); UP(B.gemm_task, gtask); UP(B.gemm_stage, gstage); UP(B.edge_task, etask); UP(B.x1_off, x1off); UP(B.x2_off, x2off);
     UP(B.pm_point, pmpoint); UP(B.pm_task, pmtask); UP(B.pm_type, pmtype); UP(B.pm_is2, pmis2); UP(B.pm_obs, pmobs);

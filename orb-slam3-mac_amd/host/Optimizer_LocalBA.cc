@@ -163,14 +163,12 @@ void Optimizer::LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Map *pMap
     g.pose_fixed = fixed.data(); g.edge_pose = ePose.data(); g.edge_point = ePoint.data(); g.edge_obs = obs.data();
     g.edge_inv_sigma2 = invS2.data(); g.edge_stereo = eType.data();
     // the reference hands each edge its keyframe's calibration (e->pCamera = pKFi->mpCamera :1961, e->fx = pKFi->fx ... e->bf = pKFi->mbf
-    // :1990-1994, mTrl / mpCamera2 :2021-2023); the graph carries ONE: a window that mixes calibrations is refused, map untouched
-    for (KeyFrame *pKFi : vpKFs)
-        if (!same_calibration(pKF, pKFi)) {
-            fprintf(stderr, "LM-LBA: keyframe %lu has another calibration than keyframe %lu: window not optimised (one calibration per graph)\n", pKFi->mnId, pKF->mnId);
-            return;
-        }
-    // monocular edges project through pKFi->mpCamera (getParameter), stereo edges through the keyframe's fx, fy, cx, cy, bf members:
-    // the same numbers in every configuration of the reference (KeyFrame copies them from the same calibration, KeyFrame.cc:40-45)
+    // :1990-1994, mTrl / mpCamera2 :2021-2023): one camera table entry per distinct calibration of the window, an index per keyframe
+    std::vector<orbhip_ba_camera> cams;
+    std::vector<int32_t> poseCam;
+    camera_table(vpKFs, cams, poseCam);
+    if (cams.size() > 1) { g.n_cameras = (int32_t)cams.size(); g.cameras = cams.data(); g.pose_camera = poseCam.data(); }
+    // (a single calibration -- every configuration the reference ships -- travels in the graph's own fields)
     camera_fields(pKF->mpCamera, g.fx, g.fy, g.cx, g.cy, g.camera_model, g.kb);
     g.bf = pKF->mbf;
     g.Trl[3] = 1.0;

@@ -100,11 +100,6 @@ void Optimizer::LocalBundleAdjustment(KeyFrame *pMainKF, std::vector<KeyFrame *>
 
     std::vector<uint8_t> outlier(nE ? nE : 1, 0);
     if (nE > 0) {
-        for (KeyFrame *pKFi : vpKFs)
-            if (!same_calibration(vpKFs[0], pKFi)) {
-                fprintf(stderr, "LBA (merge): keyframe %lu has another calibration than keyframe %lu: window not optimised (one calibration per graph)\n", pKFi->mnId, vpKFs[0]->mnId);
-                return;
-            }
         orbhip_ba_graph g;
         memset(&g, 0, sizeof(g));
         g.n_poses = nKF; g.n_points = nMP; g.n_edges = nE;
@@ -113,6 +108,11 @@ void Optimizer::LocalBundleAdjustment(KeyFrame *pMainKF, std::vector<KeyFrame *>
         camera_fields(vpKFs[0]->mpCamera, g.fx, g.fy, g.cx, g.cy, g.camera_model, g.kb);
         g.bf = vpKFs[0]->mbf;
         g.Trl[3] = 1.0;
+        // every edge projects through its own keyframe's camera (src/Optimizer.cc:6423, :6452-6456): a table when the window mixes calibrations
+        std::vector<orbhip_ba_camera> cams;
+        std::vector<int32_t> poseCam;
+        camera_table(vpKFs, cams, poseCam);
+        if (cams.size() > 1) { g.n_cameras = (int32_t)cams.size(); g.cameras = cams.data(); g.pose_camera = poseCam.data(); }
         orbhip_ba_params p;
         orbhip_ba_merge_params(&p);                               // Huber sqrt(5.99) / sqrt(7.815), gates 5.991 / 7.815, first-pass outliers at level 1, no robust kernel in pass 2
         orbhip_ba_stats st;

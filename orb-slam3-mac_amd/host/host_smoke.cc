@@ -60,6 +60,7 @@ struct Reader {
     explicit Reader(const char *p) : f(fopen(p, "rb")) {}
     ~Reader() { if (f) fclose(f); }
     template <typename T> std::vector<T> vec(size_t n) { std::vector<T> v(n); if (n && fread(v.data(), sizeof(T), n, f) != n) { fprintf(stderr, "short read\n"); exit(2); } return v; }
+    bool more() { const int ch = fgetc(f); if (ch == EOF) return false; ungetc(ch, f); return true; }        // an optional trailer follows
 };
 struct Writer {
     FILE *f;
@@ -96,14 +97,20 @@ static int lba_smoke(const char *in, const char *out)
     const std::vector<float> eObs = r.vec<float>((size_t)nE * 3);
     const std::vector<int32_t> eOct = r.vec<int32_t>(nE);
     const std::vector<float> invS2 = r.vec<float>(8);
+    // optional trailer: int32 nCam; float[nCam*5] fx fy cx cy bf; int32[nKF] camera of every keyframe (an Atlas window from several cameras)
+    std::vector<float> camTab(cam);
+    std::vector<int32_t> kfCam(nKF, 0);
+    if (r.more()) { const int nCam = r.vec<int32_t>(1)[0]; camTab = r.vec<float>((size_t)nCam * 5); kfCam = r.vec<int32_t>(nKF); }
 
     Map map;
     map.mnInitKFid = hd[4]; map.mbIsInertial = hd[6] != 0;
-    GeometricCamera camera({cam[0], cam[1], cam[2], cam[3]}, 0);
+    std::vector<std::unique_ptr<GeometricCamera>> cameras;
+    for (size_t c = 0; c < camTab.size() / 5; c++) cameras.emplace_back(new GeometricCamera({camTab[5 * c], camTab[5 * c + 1], camTab[5 * c + 2], camTab[5 * c + 3]}, 0));
     std::vector<std::unique_ptr<KeyFrame>> kfs;
     std::vector<std::unique_ptr<MapPoint>> mps;
     for (int i = 0; i < nKF; i++) {
-        kfs.emplace_back(new KeyFrame(ids[i], &map, cam[0], cam[1], cam[2], cam[3], cam[4], &camera));
+        const float *kc = &camTab[(size_t)5 * kfCam[i]];
+        kfs.emplace_back(new KeyFrame(ids[i], &map, kc[0], kc[1], kc[2], kc[3], kc[4], cameras[kfCam[i]].get()));
         kfs[i]->SetPose(mat44(&Tcw[(size_t)16 * i]));
         kfs[i]->mvInvLevelSigma2 = invS2;
     }

@@ -3,6 +3,8 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <cstring>
+#include <vector>
 #include "slam_types.h"
 #include "hip_context.h"
 #include "../../include/orbhip.h"
@@ -67,9 +69,10 @@ inline void trl_to_se3quat(const cv::Mat &Trl, double *q7)
     toSE3Quat(T, q7);
 }
 
-// the calibration a graph carries is ONE set (orbhip_ba_graph); the reference hands every edge its own keyframe's (Optimizer.cc:1961,
-// 1990-1994, 2021-2023).  All keyframes of a map share it in every configuration the reference ships; a window that mixes
-// calibrations is refused (the caller leaves the map untouched) rather than solved with the wrong one.
+// The reference hands every edge its own keyframe's calibration (Optimizer.cc:1961, 1990-1994, 2021-2023).  All keyframes of a map share
+// one in every configuration the reference ships, but an Atlas window may mix cameras: the shims group the window's keyframes by
+// calibration (same_calibration) and, when there is more than one group, pass the graph a camera table with an index per keyframe
+// (orbhip_ba_graph::cameras / pose_camera, round 4; before that such a window was refused).
 inline bool same_calibration(KeyFrame *a, KeyFrame *b)
 {
     if (a->fx != b->fx || a->fy != b->fy || a->cx != b->cx || a->cy != b->cy || a->mbf != b->mbf) return false;
@@ -84,6 +87,35 @@ inline bool same_calibration(KeyFrame *a, KeyFrame *b)
     if (a->mpCamera2)
         for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) if (a->mTrl.at<float>(i, j) != b->mTrl.at<float>(i, j)) return false;
     return true;
+}
+
+
+// one orbhip_ba_camera per distinct calibration among vpKFs, poseCam[i] = the entry keyframe i uses.  Monocular edges project through
+// pKFi->mpCamera (getParameter), stereo edges through the keyframe's fx, fy, cx, cy, mbf members: the same numbers in every configuration
+// of the reference (KeyFrame copies them from the same calibration, KeyFrame.cc:40-45); second-camera edges through mTrl / mpCamera2
+inline void camera_table(const std::vector<KeyFrame *> &vpKFs, std::vector<orbhip_ba_camera> &cams, std::vector<int32_t> &poseCam)
+{
+    std::vector<KeyFrame *> rep;
+    cams.clear(); poseCam.assign(vpKFs.size(), 0);
+    for (size_t i = 0; i < vpKFs.size(); i++) {
+        KeyFrame *kf = vpKFs[i];
+        size_t c = 0;
+        for (; c < rep.size(); c++) if (same_calibration(rep[c], kf)) break;
+        if (c == rep.size()) {
+            rep.push_back(kf);
+            orbhip_ba_camera K;
+            memset(&K, 0, sizeof(K));
+            camera_fields(kf->mpCamera, K.fx, K.fy, K.cx, K.cy, K.camera_model, K.kb);
+            K.bf = kf->mbf;
+            K.Trl[3] = 1.0;
+            if (kf->mpCamera2) {
+                trl_to_se3quat(kf->mTrl, K.Trl);
+                camera_fields(kf->mpCamera2, K.fx2, K.fy2, K.cx2, K.cy2, K.camera2_model, K.kb2);
+            }
+            cams.push_back(K);
+        }
+        poseCam[i] = (int32_t)c;
+    }
 }
 
 }  // namespace optc

@@ -303,13 +303,33 @@ def rig2_fields(g):
     return ((cd * 7)(*r["Trl"]), *[float(c) for c in r["cam"]], 1 if kb2 is not None else 0, (cd * 4)(*(kb2 if kb2 is not None else (0, 0, 0, 0))))
 
 
+class BaCamera(C.Structure):
+    _fields_ = [("fx", cd), ("fy", cd), ("cx", cd), ("cy", cd), ("bf", cd), ("camera_model", C.c_int32), ("kb", cd * 4),
+                ("Trl", cd * 7), ("fx2", cd), ("fy2", cd), ("cx2", cd), ("cy2", cd), ("camera2_model", C.c_int32), ("kb2", cd * 4)]
+
+
 class BaGraph(C.Structure):
     _fields_ = [("n_poses", C.c_int32), ("n_points", C.c_int32), ("n_edges", C.c_int32),
                 ("pose_fixed", vp), ("edge_pose", vp), ("edge_point", vp), ("edge_obs", vp),
                 ("edge_inv_sigma2", vp), ("edge_stereo", vp),
                 ("fx", cd), ("fy", cd), ("cx", cd), ("cy", cd), ("bf", cd),
                 ("camera_model", C.c_int32), ("kb", cd * 4),
-                ("Trl", cd * 7), ("fx2", cd), ("fy2", cd), ("cx2", cd), ("cy2", cd), ("camera2_model", C.c_int32), ("kb2", cd * 4)]
+                ("Trl", cd * 7), ("fx2", cd), ("fy2", cd), ("cx2", cd), ("cy2", cd), ("camera2_model", C.c_int32), ("kb2", cd * 4),
+                ("n_cameras", C.c_int32), ("cameras", vp), ("pose_camera", vp)]
+
+
+def camera_table(g, cls=None):
+    """(n_cameras, array of camera structs or None, pose_camera array or None) of a graph dict (per-keyframe calibration, synth_ba.make_graph(cameras=...))."""
+    cls = cls or BaCamera
+    cams = g.get("cameras")
+    if not cams:
+        return 0, None, None
+    arr = (cls * len(cams))()
+    for i, c in enumerate(cams):
+        kb = c.get("kb")
+        arr[i] = cls(c["fx"], c["fy"], c["cx"], c["cy"], c["bf"], 1 if kb is not None else 0, (cd * 4)(*(kb if kb is not None else (0, 0, 0, 0))),
+                     *rig2_fields(dict(rig2=c.get("rig2"))))
+    return len(cams), arr, np.ascontiguousarray(g["pose_camera"], np.int32)
 
 
 class BaParams(C.Structure):
@@ -405,9 +425,12 @@ class BaBatch:
                  np.ascontiguousarray(g["edge_inv_sigma2"], np.float64), np.ascontiguousarray(g["edge_stereo"], np.uint8)]
             self._keep.append(k)
             kb = g.get("kb")                      # KannalaBrandt8 k1..k4 for the monocular edges, None = Pinhole
+            ncam, cam_arr, pcam = camera_table(g)
+            self._keep_cam = getattr(self, "_keep_cam", []) + [(cam_arr, pcam)]
             arr[i] = BaGraph(g["n_poses"], g["n_points"], g["n_edges"], *[a.ctypes.data for a in k],
                              g["fx"], g["fy"], g["cx"], g["cy"], g["bf"], 1 if kb is not None else 0,
-                             (cd * 4)(*(kb if kb is not None else (0, 0, 0, 0))), *rig2_fields(g))
+                             (cd * 4)(*(kb if kb is not None else (0, 0, 0, 0))), *rig2_fields(g),
+                             ncam, C.cast(cam_arr, vp) if ncam else None, pcam.ctypes.data if ncam else None)
             self.sizes.append((g["n_poses"], g["n_points"], g["n_edges"]))
         self.poses = [np.ascontiguousarray(g["poses0"], np.float64).copy() for g in graphs]
         self.points = [np.ascontiguousarray(g["points0"], np.float64).copy() for g in graphs]

@@ -58,14 +58,20 @@ def _exp_so3(w):
 
 
 def make_graph(n_kf=50, n_pts=2000, obs=10, seed=0, n_fixed=2, outlier_frac=0.05, stereo_frac=0.0,
-               pose_noise=(0.01, 0.05), point_noise=0.05, pixel_noise=1.0, kb8=None, rig2=None, right_frac=0.5):
+               pose_noise=(0.01, 0.05), point_noise=0.05, pixel_noise=1.0, kb8=None, rig2=None, right_frac=0.5, cameras=None, pose_camera=None):
     """kb8 = (k1..k4): the monocular observations come from a KannalaBrandt8 camera (fisheye), else Pinhole.
     rig2 = dict(Trl=(qx,qy,qz,qw,tx,ty,tz), cam=(fx,fy,cx,cy), kb=(k1..k4)|None): a second, rigidly attached camera; a
-    fraction right_frac of the observations is also seen there (edge type 2, EdgeSE3ProjectXYZToBody)."""
+    fraction right_frac of the observations is also seen there (edge type 2, EdgeSE3ProjectXYZToBody).
+    cameras = [dict(fx, fy, cx, cy, bf, kb=None|(k1..k4), rig2=None|dict as above, stereo_frac), ...] + pose_camera [n_kf]: per-keyframe
+    calibration (an Atlas window built from several cameras; Optimizer.cc:1961, :1990-1994, :2021-2023): keyframe i observes through
+    cameras[pose_camera[i]].  The returned dict then carries `cameras` / `pose_camera` and the single-calibration fields are camera 0's."""
     rng = np.random.default_rng(seed)
     fx = fy = 458.0
     cx, cy, W, H = 320.0, 240.0, 640, 480
     bf = 458.0 * 0.11
+    if cameras is not None:
+        return _make_graph_multicam(rng, n_kf, n_pts, obs, n_fixed, outlier_frac, pose_noise, point_noise, pixel_noise, right_frac, cameras,
+                                    np.asarray(pose_camera, np.int32))
     # ground-truth poses (world -> camera)
     Rs, ts = [], []
     for i in range(n_kf):
@@ -140,6 +146,76 @@ def make_graph(n_kf=50, n_pts=2000, obs=10, seed=0, n_fixed=2, outlier_frac=0.05
                 edge_obs=np.array(e_obs, np.float64).reshape(-1, 3), edge_inv_sigma2=np.array(e_is2, np.float64),
                 edge_stereo=np.array(e_st, np.uint8), fx=fx, fy=fy, cx=cx, cy=cy, bf=bf, kb=kb8, rig2=rig2,
                 poses0=poses0, points0=pts0, poses_gt=poses_gt, points_gt=X.copy())
+
+
+def _make_graph_multicam(rng, n_kf, n_pts, obs, n_fixed, outlier_frac, pose_noise, point_noise, pixel_noise, right_frac, cameras, pose_camera):
+    W, H = 640, 480
+    Rs, ts = [], []
+    for i in range(n_kf):
+        ang = 2 * np.pi * i / n_kf + rng.normal(0, 0.02)
+        C = np.array([5 * np.cos(ang), rng.normal(0, 0.2), 5 * np.sin(ang)]) + rng.normal(0, 0.05, 3)
+        z = -C / np.linalg.norm(C)
+        up = np.array([0.0, -1.0, 0.0])
+        x = np.cross(up, z); x /= np.linalg.norm(x)
+        y = np.cross(z, x)
+        R = np.stack([x, y, z])
+        Rs.append(R); ts.append(-R @ C)
+    Rs, ts = np.array(Rs), np.array(ts)
+    X = rng.uniform(-2, 2, (n_pts, 3))
+    sig2 = np.cumprod(np.concatenate([[np.float32(1.0)], np.full(7, np.float32(1.2))]).astype(np.float32)) ** 2
+    inv_sig2 = (np.float32(1.0) / sig2.astype(np.float32)).astype(np.float32)
+
+    def proj(c, P):
+        if c.get("kb") is not None:
+            u, v = kb8_project(P[None, :], c["fx"], c["fy"], c["cx"], c["cy"], c["kb"])
+            return float(u[0]), float(v[0])
+        return c["fx"] * P[0] / P[2] + c["cx"], c["fy"] * P[1] / P[2] + c["cy"]
+    e_pose, e_point, e_obs, e_is2, e_st = [], [], [], [], []
+    for l in range(n_pts):
+        Pc = Rs @ X[l] + ts
+        uv = np.array([proj(cameras[pose_camera[k]], Pc[k]) if Pc[k, 2] > 0.1 else (-1.0, -1.0) for k in range(n_kf)])
+        vis = np.nonzero((Pc[:, 2] > 0.1) & (uv[:, 0] > 0) & (uv[:, 0] < W) & (uv[:, 1] > 0) & (uv[:, 1] < H))[0]
+        if len(vis) == 0:
+            vis = np.nonzero(Pc[:, 2] > 0.1)[0]
+        sel = np.sort(rng.choice(vis, size=min(obs, len(vis)), replace=False))
+        for k in sel:
+            c = cameras[pose_camera[k]]
+            octv = int(rng.integers(0, 8))
+            sd = pixel_noise * 1.2 ** octv
+            uu = uv[k, 0] + rng.normal(0, sd); vv = uv[k, 1] + rng.normal(0, sd)
+            if rng.random() < outlier_frac:
+                uu += rng.choice([-30.0, 30.0]); vv += rng.choice([-30.0, 30.0])
+            st = c.get("kb") is None and rng.random() < c.get("stereo_frac", 0.0)
+            ur = uu - c["bf"] / Pc[k, 2] + (rng.normal(0, sd) if st else 0.0)
+            e_pose.append(k); e_point.append(l); e_st.append(1 if st else 0)
+            e_obs.append([np.float32(uu), np.float32(vv), np.float32(ur) if st else 0.0]); e_is2.append(float(inv_sig2[octv]))
+            r2 = c.get("rig2")
+            if r2 is not None and rng.random() < right_frac:
+                Rrl = _R_from_quat(np.array(r2["Trl"][:4])); trl = np.array(r2["Trl"][4:])
+                Xr = Rrl @ Pc[k] + trl
+                u2, v2 = proj(dict(fx=r2["cam"][0], fy=r2["cam"][1], cx=r2["cam"][2], cy=r2["cam"][3], kb=r2.get("kb")), Xr)
+                o2 = int(rng.integers(0, 8)); s2 = pixel_noise * 1.2 ** o2
+                u2 += rng.normal(0, s2); v2 += rng.normal(0, s2)
+                e_pose.append(k); e_point.append(l); e_st.append(2)
+                e_obs.append([np.float32(u2), np.float32(v2), 0.0]); e_is2.append(float(inv_sig2[o2]))
+    poses0 = np.zeros((n_kf, 7)); poses_gt = np.zeros((n_kf, 7))
+    for i in range(n_kf):
+        poses_gt[i, :4] = _quat_from_R(Rs[i]); poses_gt[i, 4:] = ts[i]
+        if i < n_fixed:
+            R0, t0 = Rs[i], ts[i]
+        else:
+            dR = _exp_so3(rng.normal(0, pose_noise[0], 3))
+            R0 = dR @ Rs[i]; t0 = dR @ ts[i] + rng.normal(0, pose_noise[1], 3)
+        R0 = R0.astype(np.float32).astype(np.float64); t0 = t0.astype(np.float32).astype(np.float64)
+        poses0[i, :4] = _quat_from_R(R0); poses0[i, 4:] = t0
+    pts0 = (X + rng.normal(0, point_noise, X.shape)).astype(np.float32).astype(np.float64)
+    fixed = np.zeros(n_kf, np.uint8); fixed[:n_fixed] = 1
+    c0 = cameras[0]
+    return dict(n_poses=n_kf, n_points=n_pts, n_edges=len(e_pose), pose_fixed=fixed,
+                edge_pose=np.array(e_pose, np.int32), edge_point=np.array(e_point, np.int32),
+                edge_obs=np.array(e_obs, np.float64).reshape(-1, 3), edge_inv_sigma2=np.array(e_is2, np.float64),
+                edge_stereo=np.array(e_st, np.uint8), fx=c0["fx"], fy=c0["fy"], cx=c0["cx"], cy=c0["cy"], bf=c0["bf"], kb=c0.get("kb"), rig2=c0.get("rig2"),
+                cameras=cameras, pose_camera=pose_camera, poses0=poses0, points0=pts0, poses_gt=poses_gt, points_gt=X.copy())
 
 
 def make_pose_problem(seed, n=800, stereo_frac=0.0, outlier_frac=0.1, noise=True, perturb=(0.02, 0.08), kb8=None, rig2=None, right_frac=0.4):

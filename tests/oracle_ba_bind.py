@@ -6,13 +6,19 @@ from oracle_bind import lib
 vp, ci, cd = C.c_void_p, C.c_int, C.c_double
 
 
+class Camera(C.Structure):
+    _fields_ = [("fx", cd), ("fy", cd), ("cx", cd), ("cy", cd), ("bf", cd), ("camera_model", C.c_int32), ("kb", cd * 4),
+                ("Trl", cd * 7), ("fx2", cd), ("fy2", cd), ("cx2", cd), ("cy2", cd), ("camera2_model", C.c_int32), ("kb2", cd * 4)]
+
+
 class Graph(C.Structure):
     _fields_ = [("n_poses", C.c_int32), ("n_points", C.c_int32), ("n_edges", C.c_int32),
                 ("pose_fixed", vp), ("edge_pose", vp), ("edge_point", vp), ("edge_obs", vp),
                 ("edge_inv_sigma2", vp), ("edge_stereo", vp),
                 ("fx", cd), ("fy", cd), ("cx", cd), ("cy", cd), ("bf", cd),
                 ("camera_model", C.c_int32), ("kb", cd * 4),
-                ("Trl", cd * 7), ("fx2", cd), ("fy2", cd), ("cx2", cd), ("cy2", cd), ("camera2_model", C.c_int32), ("kb2", cd * 4)]
+                ("Trl", cd * 7), ("fx2", cd), ("fy2", cd), ("cx2", cd), ("cy2", cd), ("camera2_model", C.c_int32), ("kb2", cd * 4),
+                ("n_cameras", C.c_int32), ("cameras", vp), ("pose_camera", vp)]
 
 
 class Params(C.Structure):
@@ -74,9 +80,20 @@ def make_cgraph(g, cls=Graph):
             np.ascontiguousarray(g["edge_point"], np.int32), np.ascontiguousarray(g["edge_obs"], np.float64),
             np.ascontiguousarray(g["edge_inv_sigma2"], np.float64), np.ascontiguousarray(g["edge_stereo"], np.uint8)]
     kb = g.get("kb")
-    s = cls(g["n_poses"], g["n_points"], g["n_edges"], *[k.ctypes.data for k in keep],
+    cams = g.get("cameras")
+    ncam, cam_arr, pcam = 0, None, None
+    if cams:
+        ncam = len(cams)
+        cam_arr = (Camera * ncam)()
+        for i, c in enumerate(cams):
+            k2 = c.get("kb")
+            cam_arr[i] = Camera(c["fx"], c["fy"], c["cx"], c["cy"], c["bf"], 1 if k2 is not None else 0, (cd * 4)(*(k2 if k2 is not None else (0, 0, 0, 0))),
+                                *rig2_fields(dict(rig2=c.get("rig2"))))
+        pcam = np.ascontiguousarray(g["pose_camera"], np.int32)
+        keep += [cam_arr, pcam]
+    s = cls(g["n_poses"], g["n_points"], g["n_edges"], *[k.ctypes.data for k in keep[:6]],
             g["fx"], g["fy"], g["cx"], g["cy"], g["bf"], 1 if kb is not None else 0, (cd * 4)(*(kb if kb is not None else (0, 0, 0, 0))),
-            *rig2_fields(g))
+            *rig2_fields(g), ncam, C.cast(cam_arr, vp) if ncam else None, pcam.ctypes.data if ncam else None)
     return s, keep
 
 

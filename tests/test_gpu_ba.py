@@ -88,6 +88,43 @@ def test_ba_stereo_and_mixed(ba_ctx):
     _check(gpu_ctx, graphs)
 
 
+def _two_pinholes():
+    return [dict(fx=458.0, fy=458.0, cx=320.0, cy=240.0, bf=458.0 * 0.11, stereo_frac=0.3),
+            dict(fx=380.0, fy=395.0, cx=300.0, cy=255.0, bf=380.0 * 0.07, stereo_frac=0.3)]
+
+
+def test_ba_per_keyframe_calibration_two_pinholes(ba_ctx):
+    """the reference gives every edge its keyframe's own camera (Optimizer.cc:1961, :1990-1994).  One window whose
+    keyframes alternate between two Pinhole calibrations (mono and stereo edges), in a batch with a single-calibration graph: within
+    1e-4 of the oracle with the same LM trials; solving it with camera 0 for everybody must NOT agree (the table is really used)."""
+    gpu_ctx = ba_ctx
+    import synth_ba
+    cams = _two_pinholes()
+    g = synth_ba.make_graph(n_kf=14, n_pts=400, obs=6, seed=21, cameras=cams, pose_camera=[i % 2 for i in range(14)])
+    g1 = synth_ba.make_graph(n_kf=9, n_pts=120, obs=5, seed=22)
+    st = _check(gpu_ctx, [g, g1])
+    assert st[0]["chi2_final"] < 0.5 * st[0]["chi2_initial"]
+    import orbhip
+    wrong = dict(g); wrong.pop("cameras"); wrong.pop("pose_camera")
+    bb = orbhip.BaBatch(gpu_ctx, [wrong]); bb.solve(); _, _, _, sw = bb.download(); bb.close()
+    assert sw[0]["chi2_final"] > 1.5 * st[0]["chi2_final"]
+
+
+def test_ba_per_keyframe_calibration_pinhole_and_fisheye_rig(ba_ctx):
+    """A window that mixes a Pinhole keyframe set with keyframes of a KannalaBrandt8 two-camera rig (their own mTrl / mpCamera2,
+    Optimizer.cc:2021-2023): monocular KB8 edges, second-camera edges with twin chains, and Pinhole mono / stereo edges in ONE graph."""
+    gpu_ctx = ba_ctx
+    import synth_ba
+    kb = (-0.0034, 0.0007, -0.002, 0.0002)
+    q = np.array([0.0, 0.02, 0.0, 1.0]); q /= np.linalg.norm(q)
+    rig = dict(Trl=(q[0], q[1], q[2], q[3], -0.1, 0.0, 0.0), cam=(190.0, 190.0, 254.0, 256.0), kb=(0.003, 0.0009, -0.002, 0.0003))
+    cams = [dict(fx=458.0, fy=458.0, cx=320.0, cy=240.0, bf=458.0 * 0.11, stereo_frac=0.5),
+            dict(fx=190.9, fy=190.3, cx=254.9, cy=256.8, bf=0.0, kb=kb, rig2=rig)]
+    g = synth_ba.make_graph(n_kf=12, n_pts=300, obs=6, seed=23, cameras=cams, pose_camera=[0, 1, 1, 0, 1, 0, 0, 1, 1, 0, 1, 0], right_frac=0.5)
+    assert (g["edge_stereo"] == 2).sum() > 100 and (g["edge_stereo"] == 1).sum() > 100
+    _check(gpu_ctx, [g])
+
+
 def test_ba_ragged_batch(ba_ctx):
     gpu_ctx = ba_ctx
     """Graphs of different sizes in one batch, incl. a point seen only by fixed KFs."""

@@ -1580,3 +1580,26 @@ def test_pose_optimization_oracle_against_an_independent_numpy_model(stereo_frac
     assert n_in == n - nb
     np.testing.assert_array_equal(o_out.astype(bool), level)
     assert np.max(np.abs(quat_to_R(o_pose[:4]) - R)) <= 1e-6 and np.max(np.abs(o_pose[4:] - t)) <= 1e-6
+
+
+def test_ba_oracle_per_keyframe_calibration():
+    """The oracle with a camera table (round 4): (1) a table whose entries all equal the graph's single calibration reproduces the
+    single-calibration solve bit for bit; (2) a noise-free window whose keyframes alternate between two Pinhole calibrations is
+    recovered exactly -- and is NOT when every keyframe is given camera 0 (the table is really what the edges project through)."""
+    import oracle_ba_bind as ob
+    import synth_ba
+    g = synth_ba.make_graph(n_kf=8, n_pts=120, obs=5, seed=3, stereo_frac=0.3)
+    rc, p0, x0, o0, s0 = ob.solve(g)
+    gt = dict(g)
+    gt["cameras"] = [dict(fx=g["fx"], fy=g["fy"], cx=g["cx"], cy=g["cy"], bf=g["bf"])] * 3
+    gt["pose_camera"] = np.array([i % 3 for i in range(8)], np.int32)
+    rc, p1, x1, o1, s1 = ob.solve(gt)
+    assert np.array_equal(p0, p1) and np.array_equal(x0, x1) and np.array_equal(o0, o1) and s0["lm_trials"] == s1["lm_trials"]
+    cams = [dict(fx=458.0, fy=458.0, cx=320.0, cy=240.0, bf=50.0, stereo_frac=0.3), dict(fx=380.0, fy=395.0, cx=300.0, cy=255.0, bf=27.0, stereo_frac=0.3)]
+    g2 = synth_ba.make_graph(n_kf=10, n_pts=200, obs=6, seed=4, cameras=cams, pose_camera=[i % 2 for i in range(10)], pixel_noise=0.0, outlier_frac=0.0)
+    rc, p2, x2, o2, s2 = ob.solve(g2)
+    assert s2["chi2_final"] < 1e-3 and not o2.any()
+    assert np.sqrt(np.mean((x2 - g2["points_gt"]) ** 2)) < 2e-3
+    wrong = dict(g2); wrong.pop("cameras"); wrong.pop("pose_camera")
+    rc, p3, x3, o3, s3 = ob.solve(wrong)
+    assert s3["chi2_final"] > 1e3 * max(s2["chi2_final"], 1e-6)
