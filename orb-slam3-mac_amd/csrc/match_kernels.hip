@@ -13,6 +13,7 @@
 
 struct orbhip_ctx;
 hipStream_t orbhip_ctx_stream_internal(orbhip_ctx *c);
+void orbhip_set_last_error_internal(const char *msg);
 int orbhip_ctx_device_internal(orbhip_ctx *c);
 int32_t *orbhip_ctx_status_internal(orbhip_ctx *c);
 
@@ -909,7 +910,9 @@ extern "C" int orbhip_prev_matched_init_device(orbhip_ctx *ctx, const orbhip_key
 // are then evaluated one per lane with key = distance << 12 | position ("first candidate wins", :2051-2055).
 // The query loop is sequential: a keypoint claimed by a map point with observations drops out of later
 // queries (:2037-2039).
-#define SBP_CAP 2048
+#define SBP_CAP 2048          // keypoints / queries per frame of the replay form (its keys carry 11-bit positions and indices)
+#define SBP_SEQ_CAP 8192      // ... of the sequential kernel, LDS permitting (17 B per keypoint + 3 B per query + the grid: see sbp_launch)
+#define SBP_CAND_CAP 4096     // candidates of one query (12-bit position in its key)
 struct OrbLevelSigma { float inv_sigma2[16]; };       // mvInvLevelSigma2, passed by value
 #define SBP_CELLS (SI_COLS * SI_ROWS)
 // Frame::AssignFeaturesToGrid (Frame.cc:377-408) as a CSR in LDS, built by one wave: cell by round() (PosInGrid, :716-726),
@@ -1094,13 +1097,16 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
     uint32_t *cell_start = reinterpret_cast<uint32_t *>(sbp_lds);                   // [ncells + 1]: SBP_CELLS, twice that for rig frames
     float *kx = reinterpret_cast<float *>(cell_start + ncells + 1), *ky = kx + cap_n;
     int16_t *holder = reinterpret_cast<int16_t *>(ky + cap_n);                       // -1 free, -2 pre-held, else (query << 1 | has_obs)
-    uint16_t *items = reinterpret_cast<uint16_t *>(holder + cap_n), *cand = items + cap_n, *cell_of = cand + cap_n, *rank_of = cell_of + cap_n;
+    // (the candidate list of ONE query never needs more than 4096 entries -- its position travels in 12 bits of the key -- so keyframes of
+    // up to ~7 600 keypoints fit: the 5 x nFeatures keypoints of a monocular map's first two keyframes, Tracking.cc:210)
+    const int cap_c = cap_n < SBP_CAND_CAP ? cap_n : SBP_CAND_CAP;
+    uint16_t *items = reinterpret_cast<uint16_t *>(holder + cap_n), *cand = items + cap_n, *cell_of = cand + cap_c, *rank_of = cell_of + cap_n;
     int16_t *qm = reinterpret_cast<int16_t *>(rank_of + cap_n);                      // query -> claimed keypoint
     int8_t *qbin = reinterpret_cast<int8_t *>(qm + cap_q);
     uint8_t *oct = reinterpret_cast<uint8_t *>(qbin + cap_q);
     // optional: the train descriptors too (32 B each) -- removes the one global round trip left in every query; used when
     // the launch is small enough that fewer resident pairs per CU do not matter
-    uint4 *dlds = reinterpret_cast<uint4 *>(sbp_lds + ((sizeof(uint32_t) * ((size_t)ncells + 1) + (size_t)cap_n * 19 + (size_t)cap_q * 3 + 15) & ~(size_t)15));
+    uint4 *dlds = reinterpret_cast<uint4 *>(sbp_lds + ((sizeof(uint32_t) * ((size_t)ncells + 1) + (size_t)cap_n * 17 + (size_t)cap_c * 2 + (size_t)cap_q * 3 + 15) & ~(size_t)15));
     __shared__ int hist[SI_HISTO];
     __shared__ int s_keep[3];
     const int pair = blockIdx.x, lane = threadIdx.x;
@@ -1173,6 +1179,7 @@ __global__ __launch_bounds__(64) void k_search_by_projection(const orbhip_proj_q
         const int inc = wave_scan_add_dpp(len);                      // DPP scans / reductions: no LDS round trips in the per-query chain
         const int off = inc - len, total = __builtin_amdgcn_readlane(inc, 63);
         if (total == 0) continue;
+        if (total > cap_c) { if (lane == 0) atomicExch(status, ORBHIP_E_CAPACITY); continue; }      // > 4096 keypoints in one search window
         const int maxlen = wave_max_dpp(len);
         for (int j = 0; j < maxlen; j++) if (j < len) cand[off + j] = items[start + j];
         __syncthreads();
@@ -1550,7 +1557,8 @@ __global__ __launch_bounds__(64) void k_sbp_replay(const orbhip_proj_query *q_, 
 // LDS of k_search_by_projection for the given row capacities (keypoints / queries per pair)
 static size_t sbp_lds_bytes(int cap_n, int cap_q, int ncells)
 {
-    return sizeof(uint32_t) * ((size_t)ncells + 1) + (size_t)cap_n * (4 + 4 + 2 + 2 + 2 + 2 + 2 + 1) + (size_t)cap_q * (2 + 1) + 16;
+    const int cap_c = cap_n < SBP_CAND_CAP ? cap_n : SBP_CAND_CAP;
+    return sizeof(uint32_t) * ((size_t)ncells + 1) + (size_t)cap_n * (4 + 4 + 2 + 2 + 2 + 2 + 1) + (size_t)cap_c * 2 + (size_t)cap_q * (2 + 1) + 16;
 }
 void *orbhip_ctx_work_internal(orbhip_ctx *c, size_t bytes);
 static int sbp_launch(orbhip_ctx *ctx, const orbhip_proj_query *d_q, const uint8_t *d_desc_q, const int32_t *d_nq, int max_q,
@@ -1559,9 +1567,15 @@ static int sbp_launch(orbhip_ctx *ctx, const orbhip_proj_query *d_q, const uint8
                       int check_orientation, int mode, float nn_ratio, int32_t *d_train_match, int32_t *d_nmatches,
                       const int32_t *d_nleft = nullptr, const int32_t *d_mirror = nullptr)
 {
-    const int cap_n = ((max_n < SBP_CAP ? max_n : SBP_CAP) + 7) & ~7, cap_q = ((max_q < SBP_CAP ? max_q : SBP_CAP) + 7) & ~7;
+    // Frames / keyframes beyond the replay form's 2048 keypoints or queries (the two first keyframes of a monocular map carry 5 x nFeatures
+    // keypoints, Tracking.cc:210; a loop's map points can be thousands of queries) take the sequential kernel alone, whose arrays are
+    // sized by what LDS holds: 17 B per keypoint + 2 B per candidate slot + 3 B per query + the grid (round 4; round 3 refused > 2048)
+    const bool big = max_n > SBP_CAP || max_q > SBP_CAP;
+    const int lim = big ? SBP_SEQ_CAP : SBP_CAP;
+    const int cap_n = ((max_n < lim ? max_n : lim) + 7) & ~7, cap_q = ((max_q < lim ? max_q : lim) + 7) & ~7;
     const int ncells = d_nleft ? 2 * SBP_CELLS : SBP_CELLS;
     const size_t base = sbp_lds_bytes(cap_n, cap_q, ncells), with_desc = base + (size_t)cap_n * 32;
+    if (base > 160 * 1024 - 512) { orbhip_set_last_error_internal("SearchByProjection: frame too large for the LDS-resident grid (17 B per keypoint + 3 B per query <= ~145 KB)"); return ORBHIP_E_CAPACITY; }
     // descriptors in LDS when at most two rounds of workgroups are needed anyway (<= 2 pairs per CU resident is enough)
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
@@ -1576,7 +1590,7 @@ static int sbp_launch(orbhip_ctx *ctx, const orbhip_proj_query *d_q, const uint8
     const int par_max = getenv("ORBHIP_SBP_PARALLEL_MAX_PAIRS") ? atoi(getenv("ORBHIP_SBP_PARALLEL_MAX_PAIRS")) : (1 << 20);
     const size_t work_per_pair = (size_t)cap_n * (16 + 32 + 2) + 4 * (SI_COLS + 1) + 4 * (size_t)((cap_q + 63) / 64) * SBPL_K * 64 + 4 * (size_t)cap_q + 1024;
     const int32_t *d_redo = nullptr;
-    if (!d_nleft && !d_mirror && pairs <= par_max && (size_t)pairs * work_per_pair <= ((size_t)1 << 30)) {
+    if (!big && !d_nleft && !d_mirror && pairs <= par_max && (size_t)pairs * work_per_pair <= ((size_t)1 << 30)) {
         SbpWork W;
         W.cap_n = cap_n; W.cap_q = cap_q; W.chunks = (cap_q + 63) / 64;
         auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
@@ -1758,6 +1772,9 @@ extern "C" int orbhip_bow_transform_device(orbhip_ctx *ctx, const uint8_t *d_des
 // every projected map point.  The queries do not depend on each other (the Replace / AddObservation bookkeeping of :1572-1595
 // is the caller's), so one lane owns one query: it walks the grid columns of its window in GetFeaturesInArea order against
 // LDS-resident keypoints AND descriptors (no dependent global gathers inside the lane-serial loop).
+// BIG (round 4): keyframes of more than 2900 keypoints (up to 8192: the first two keyframes of a monocular map carry 5 x nFeatures,
+// Tracking.cc:210) keep only the grid and the keypoint positions in LDS; descriptors and uRight are read from global memory (L2).
+template <bool BIG>
 __global__ __launch_bounds__(64) void k_fuse_search(const orbhip_proj_query *q_, const uint8_t *descq_, const int32_t *nq_, int max_q,
                                                     const orbhip_keypoint *kp_, const uint8_t *desc_, const float *uright_,
                                                     const int32_t *n_, int max_n, size_t kp_stride, OrbLevelSigma sig,
@@ -1765,10 +1782,10 @@ __global__ __launch_bounds__(64) void k_fuse_search(const orbhip_proj_query *q_,
                                                     int32_t *best_idx_, int32_t *best_dist_, int32_t *status)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t sbp_lds[];
-    uint4 *dlds = reinterpret_cast<uint4 *>(sbp_lds);                                 // [cap_n][2]
-    uint32_t *cell_start = reinterpret_cast<uint32_t *>(dlds + 2 * (size_t)cap_n);   // [SBP_CELLS + 1]
-    float *kx = reinterpret_cast<float *>(cell_start + SBP_CELLS + 1), *ky = kx + cap_n, *ur = ky + cap_n;
-    uint16_t *items = reinterpret_cast<uint16_t *>(ur + cap_n), *cell_of = items + cap_n, *rank_of = cell_of + cap_n;
+    uint4 *dlds = reinterpret_cast<uint4 *>(sbp_lds);                                 // [cap_n][2]   (BIG: absent)
+    uint32_t *cell_start = reinterpret_cast<uint32_t *>(dlds + (BIG ? 0 : 2 * (size_t)cap_n));   // [SBP_CELLS + 1]
+    float *kx = reinterpret_cast<float *>(cell_start + SBP_CELLS + 1), *ky = kx + cap_n, *ur = ky + cap_n;      // (BIG: ur absent)
+    uint16_t *items = reinterpret_cast<uint16_t *>(BIG ? ky + cap_n : ur + cap_n), *cell_of = items + cap_n, *rank_of = cell_of + cap_n;
     uint8_t *oct = reinterpret_cast<uint8_t *>(rank_of + cap_n);
     const int pair = blockIdx.x, lane = threadIdx.x;
     const int n = n_[pair], nq = nq_[pair];
@@ -1786,7 +1803,7 @@ __global__ __launch_bounds__(64) void k_fuse_search(const orbhip_proj_query *q_,
     const float inv_w = __fdiv_rn((float)SI_COLS, __fsub_rn(max_x, min_x));       // Frame.cc:334-335
     const float inv_h = __fdiv_rn((float)SI_ROWS, __fsub_rn(max_y, min_y));
     for (int c = lane; c <= SBP_CELLS; c += 64) cell_start[c] = 0;
-    for (int i = lane; i < n; i += 64) { dlds[2 * i] = dT[2 * i]; dlds[2 * i + 1] = dT[2 * i + 1]; ur[i] = uright ? uright[i] : -1.0f; }
+    if (!BIG) for (int i = lane; i < n; i += 64) { dlds[2 * i] = dT[2 * i]; dlds[2 * i + 1] = dT[2 * i + 1]; ur[i] = uright ? uright[i] : -1.0f; }
     __syncthreads();
     sbp_build_grid(cell_start, kx, ky, oct, items, cell_of, rank_of, kp, n, min_x, min_y, inv_w, inv_h, lane);
     for (int T = 0; T < nq; T += 64) {
@@ -1810,7 +1827,7 @@ __global__ __launch_bounds__(64) void k_fuse_search(const orbhip_proj_query *q_,
                     const int lv = oct[idx];
                     if (lv < qq.min_level || lv > qq.max_level) continue;                              // ORBmatcher.cc:1527-1528
                     const float ex = __fsub_rn(x, kx[idx]), ey = __fsub_rn(y, ky[idx]);
-                    const float kr = ur[idx];
+                    const float kr = BIG ? (uright ? uright[idx] : -1.0f) : ur[idx];
                     if (kr >= 0) {                                                                      // ORBmatcher.cc:1530-1545
                         const float er = __fsub_rn(qq.ur, kr);
                         const float e2 = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(er, er));
@@ -1819,7 +1836,7 @@ __global__ __launch_bounds__(64) void k_fuse_search(const orbhip_proj_query *q_,
                         const float e2 = __fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey));
                         if ((double)__fmul_rn(e2, sig.inv_sigma2[lv]) > 5.99) continue;
                     }
-                    const int dist = hamming256(a0, a1, dlds[2 * idx], dlds[2 * idx + 1]);
+                    const int dist = BIG ? hamming256(a0, a1, dT[2 * idx], dT[2 * idx + 1]) : hamming256(a0, a1, dlds[2 * idx], dlds[2 * idx + 1]);
                     if (dist < best) { best = dist; besti = idx; }                                     // ORBmatcher.cc:1564-1568
                 }
             }
@@ -1839,13 +1856,19 @@ extern "C" int orbhip_fuse_search_device(orbhip_ctx *ctx, const orbhip_proj_quer
     if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
     OrbLevelSigma sig;
     for (int l = 0; l < 16; l++) sig.inv_sigma2[l] = l < nlevels ? inv_level_sigma2[l] : 0.0f;
-    const int cap_n = ((max_n < 2900 ? max_n : 2900) + 7) & ~7;        // keypoints AND descriptors of a keyframe live in LDS (160 KB)
-    const size_t lds = (size_t)cap_n * (32 + 4 + 4 + 4 + 2 + 2 + 2 + 1) + sizeof(uint32_t) * (SBP_CELLS + 1) + 16;
+    // up to 2900 keypoints: keypoints AND descriptors of a keyframe live in LDS (160 KB); beyond (to 8192): positions and grid only
+    const bool big = max_n > 2900;
+    const int cap_n = ((max_n < (big ? 8192 : 2900) ? max_n : (big ? 8192 : 2900)) + 7) & ~7;
+    const size_t lds = (size_t)cap_n * (big ? (4 + 4 + 2 + 2 + 2 + 1) : (32 + 4 + 4 + 4 + 2 + 2 + 2 + 1)) + sizeof(uint32_t) * (SBP_CELLS + 1) + 16;
     if (lds > 160 * 1024 - 512) return ORBHIP_E_BADARG;
-    if (orb_lds_optin(reinterpret_cast<const void *>(k_fuse_search), orbhip_ctx_device_internal(ctx), lds)) return ORBHIP_E_HIP;
-    hipLaunchKernelGGL(k_fuse_search, dim3(pairs), dim3(64), lds, orbhip_ctx_stream_internal(ctx), d_q, d_desc_q, d_nq, max_q, d_kp, d_desc,
-                       d_u_right, d_n, max_n, frame_stride_kp, sig, min_x, min_y, max_x, max_y, cap_n, d_best_idx, d_best_dist,
-                       orbhip_ctx_status_internal(ctx));
+    const void *fn = big ? reinterpret_cast<const void *>(k_fuse_search<true>) : reinterpret_cast<const void *>(k_fuse_search<false>);
+    if (orb_lds_optin(fn, orbhip_ctx_device_internal(ctx), lds)) return ORBHIP_E_HIP;
+    if (big) hipLaunchKernelGGL(k_fuse_search<true>, dim3(pairs), dim3(64), lds, orbhip_ctx_stream_internal(ctx), d_q, d_desc_q, d_nq, max_q, d_kp, d_desc,
+                                d_u_right, d_n, max_n, frame_stride_kp, sig, min_x, min_y, max_x, max_y, cap_n, d_best_idx, d_best_dist,
+                                orbhip_ctx_status_internal(ctx));
+    else hipLaunchKernelGGL(k_fuse_search<false>, dim3(pairs), dim3(64), lds, orbhip_ctx_stream_internal(ctx), d_q, d_desc_q, d_nq, max_q, d_kp, d_desc,
+                            d_u_right, d_n, max_n, frame_stride_kp, sig, min_x, min_y, max_x, max_y, cap_n, d_best_idx, d_best_dist,
+                            orbhip_ctx_status_internal(ctx));
     return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
 }
 
@@ -1858,15 +1881,16 @@ struct BowSide { const int32_t *node_ids, *node_start, *feat, *nnodes; const orb
 // KF_MODE: SearchByBoW(KeyFrame*, KeyFrame*) (ORBmatcher.cc:827-967): side F is the second keyframe with its own validity
 // flags, the distance test is strict (:909) and the result is indexed by the first keyframe's feature (vpMatches12).
 #define BOW_BIG_NODE 32        // frame features under one node from which the wave works on the node together
-template <bool KF_MODE>
+// BIG (round 4): frames / keyframes of more than 4096 features (to 16384) read the F side's descriptors from global memory
+template <bool KF_MODE, bool BIG = false>
 __global__ __launch_bounds__(64) void k_search_by_bow(BowSide K, const uint8_t *kf_valid_, const int32_t *nK_, BowSide F, const uint8_t *f_valid_,
                                                       const int32_t *nF_, int max_nodes, int max_n,
                                                       size_t kp_stride, float nn_ratio, int check_ori, int cap_n,
                                                       int32_t *match_f_, int32_t *nmatches_, int32_t *status, const int32_t *nleft_)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t bow_lds[];
-    uint4 *dlds = reinterpret_cast<uint4 *>(bow_lds);                       // [cap_n][2] frame descriptors
-    int16_t *mf = reinterpret_cast<int16_t *>(dlds + 2 * (size_t)cap_n);    // [cap_n] KF feature matched to frame feature j, -1 free, -2 invalid
+    uint4 *dlds = reinterpret_cast<uint4 *>(bow_lds);                       // [cap_n][2] frame descriptors (BIG: absent)
+    int16_t *mf = reinterpret_cast<int16_t *>(dlds + (BIG ? 0 : 2 * (size_t)cap_n));    // [cap_n] KF feature matched to frame feature j, -1 free, -2 invalid
     int16_t *inv = mf + cap_n;                                              // [cap_n] (KF_MODE) match of KF1 feature i
     int8_t *fbin = reinterpret_cast<int8_t *>(inv + (KF_MODE ? cap_n : 0)); // [cap_n] rotation bin of that match
     __shared__ int hist[SI_HISTO];
@@ -1891,7 +1915,8 @@ __global__ __launch_bounds__(64) void k_search_by_bow(BowSide K, const uint8_t *
     const uint4 *dF = reinterpret_cast<const uint4 *>(F.desc + (size_t)pair * kp_stride * 32);
     for (int i = lane; i < SI_HISTO; i += 64) hist[i] = 0;
     for (int j = lane; j < nF; j += 64) {
-        dlds[2 * j] = dF[2 * j]; dlds[2 * j + 1] = dF[2 * j + 1]; fbin[j] = -1;
+        if (!BIG) { dlds[2 * j] = dF[2 * j]; dlds[2 * j + 1] = dF[2 * j + 1]; }
+        fbin[j] = -1;
         mf[j] = (KF_MODE && !fvalid[j]) ? -2 : -1;                          // :887-891
     }
     if (KF_MODE) for (int i = lane; i < nK; i += 64) inv[i] = -1;
@@ -1915,7 +1940,7 @@ __global__ __launch_bounds__(64) void k_search_by_bow(BowSide K, const uint8_t *
             for (int jf = f0; jf < f1; jf++) {                               // :317-360
                 const int rj = ffe[jf];
                 if (mf[rj] != -1) continue;
-                const int dist = hamming256(a0v, a1v, dlds[2 * rj], dlds[2 * rj + 1]);
+                const int dist = (BIG ? hamming256(a0v, a1v, dF[2 * rj], dF[2 * rj + 1]) : hamming256(a0v, a1v, dlds[2 * rj], dlds[2 * rj + 1]));
                 if (nleft < 0 || rj < nleft) {
                     if (dist < b1) { b2 = b1; b1 = dist; bi = rj; }
                     else if (dist < b2) b2 = dist;
@@ -1980,13 +2005,13 @@ __global__ __launch_bounds__(64) void k_search_by_bow(BowSide K, const uint8_t *
                     if (f0 + 64 * u >= f1) break;                           // uniform
                     const int rj = rjs[u];
                     if (rj < 0 || mf[rj] != -1) continue;
-                    const uint32_t key = ((uint32_t)hamming256(a0v, a1v, dlds[2 * rj], dlds[2 * rj + 1]) << 16) | (uint32_t)(lane + 64 * u);
+                    const uint32_t key = ((uint32_t)(BIG ? hamming256(a0v, a1v, dF[2 * rj], dF[2 * rj + 1]) : hamming256(a0v, a1v, dlds[2 * rj], dlds[2 * rj + 1])) << 16) | (uint32_t)(lane + 64 * u);
                     k2 = min(k2, max(k1, key)); k1 = min(k1, key);
                 }
                 for (int jf = f0 + 512 + lane; jf < f1; jf += 64) {           // (nodes of more than 512 frame features)
                     const int rj = ffe[jf];
                     if (mf[rj] != -1) continue;
-                    const uint32_t key = ((uint32_t)hamming256(a0v, a1v, dlds[2 * rj], dlds[2 * rj + 1]) << 16) | (uint32_t)(jf - f0);
+                    const uint32_t key = ((uint32_t)(BIG ? hamming256(a0v, a1v, dF[2 * rj], dF[2 * rj + 1]) : hamming256(a0v, a1v, dlds[2 * rj], dlds[2 * rj + 1])) << 16) | (uint32_t)(jf - f0);
                     k2 = min(k2, max(k1, key)); k1 = min(k1, key);
                 }
                 wave_min2_u32_dpp(k1, k2);
@@ -2049,18 +2074,20 @@ static int bow_launch(orbhip_ctx *ctx, bool kf_mode, const BowSide &K, const uin
                       int check_orientation, int32_t *d_match, int32_t *d_nmatches, const int32_t *d_nleft = nullptr)
 {
     if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
-    const int cap_n = ((max_n < 4096 ? max_n : 4096) + 7) & ~7;
-    const size_t lds = (size_t)cap_n * (32 + 2 + 1 + (kf_mode ? 2 : 0)) + 16;
+    const bool big = max_n > 4096;                               // (the match slots are int16: 16384 features at most)
+    const int lim = big ? 16384 : 4096;
+    const int cap_n = ((max_n < lim ? max_n : lim) + 7) & ~7;
+    const size_t lds = (size_t)cap_n * ((big ? 0 : 32) + 2 + 1 + (kf_mode ? 2 : 0)) + 16;
     {
-        const void *fn = kf_mode ? reinterpret_cast<const void *>(k_search_by_bow<true>) : reinterpret_cast<const void *>(k_search_by_bow<false>);
+        const void *fn = kf_mode ? (big ? reinterpret_cast<const void *>(k_search_by_bow<true, true>) : reinterpret_cast<const void *>(k_search_by_bow<true, false>))
+                                 : (big ? reinterpret_cast<const void *>(k_search_by_bow<false, true>) : reinterpret_cast<const void *>(k_search_by_bow<false, false>));
         if (orb_lds_optin(fn, orbhip_ctx_device_internal(ctx), lds)) return ORBHIP_E_HIP;
     }
-    if (kf_mode)
-        hipLaunchKernelGGL(k_search_by_bow<true>, dim3(pairs), dim3(64), lds, orbhip_ctx_stream_internal(ctx), K, d_kf_valid, d_nK, F, d_f_valid, d_nF,
-                           max_nodes, max_n, frame_stride_kp, nn_ratio, check_orientation, cap_n, d_match, d_nmatches, orbhip_ctx_status_internal(ctx), nullptr);
-    else
-        hipLaunchKernelGGL(k_search_by_bow<false>, dim3(pairs), dim3(64), lds, orbhip_ctx_stream_internal(ctx), K, d_kf_valid, d_nK, F, d_f_valid, d_nF,
-                           max_nodes, max_n, frame_stride_kp, nn_ratio, check_orientation, cap_n, d_match, d_nmatches, orbhip_ctx_status_internal(ctx), d_nleft);
+#define BOW_LAUNCH(KF, BG, NL) hipLaunchKernelGGL((k_search_by_bow<KF, BG>), dim3(pairs), dim3(64), lds, orbhip_ctx_stream_internal(ctx), K, d_kf_valid, d_nK, F, d_f_valid, d_nF, \
+                           max_nodes, max_n, frame_stride_kp, nn_ratio, check_orientation, cap_n, d_match, d_nmatches, orbhip_ctx_status_internal(ctx), NL)
+    if (kf_mode) { if (big) BOW_LAUNCH(true, true, nullptr); else BOW_LAUNCH(true, false, nullptr); }
+    else { if (big) BOW_LAUNCH(false, true, d_nleft); else BOW_LAUNCH(false, false, d_nleft); }
+#undef BOW_LAUNCH
     return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
 }
 

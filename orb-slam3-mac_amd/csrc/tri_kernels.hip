@@ -228,14 +228,16 @@ struct TriLevelsG { float sigma2_1[16], scale2[16], sigma2_2[16]; };
 #define TRIG_TH_LOW 50
 #define TRIG_HISTO 30
 
+// BIG (round 4): keyframes of more than 4096 keypoints (to 16384) read KF2's descriptors from global memory instead of LDS
+template <bool BIG>
 __global__ __launch_bounds__(TRIG_THREADS) void k_search_triangulation_general(const int32_t *nid1_, const uint8_t *mp1_, const orbhip_keypoint *kp1_,
         const uint8_t *desc1_, const float *ur1_, const int32_t *n1_, TriSideG S2, const uint8_t *mp2_, const orbhip_keypoint *kp2_,
         const uint8_t *desc2_, const float *ur2_, const int32_t *n2_, const orbhip_tri_pair_general *geom_, int max_nodes, int max_n,
         size_t kp_stride, TriLevelsG lv, int check_ori, int cap_n, int32_t *matches12_, int32_t *nmatches_, int32_t *status)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t trig_lds[];
-    uint4 *dlds = reinterpret_cast<uint4 *>(trig_lds);                        // [cap_n][2] KF2 descriptors
-    uint8_t *flag2 = reinterpret_cast<uint8_t *>(dlds + 2 * (size_t)cap_n);   // [cap_n] bit0: has a map point, bit1: stereo
+    uint4 *dlds = reinterpret_cast<uint4 *>(trig_lds);                        // [cap_n][2] KF2 descriptors (BIG: absent)
+    uint8_t *flag2 = reinterpret_cast<uint8_t *>(dlds + (BIG ? 0 : 2 * (size_t)cap_n));   // [cap_n] bit0: has a map point, bit1: stereo
     int8_t *bin1 = reinterpret_cast<int8_t *>(flag2 + cap_n);                 // [cap_n] rotation bin of KF1 keypoint i's match
     __shared__ orbhip_tri_pair_general g;
     __shared__ int hist[TRIG_HISTO];
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(TRIG_THREADS) void k_search_triangulation_general(c
     __syncthreads();
     const bool cam2nd1 = g.nleft1 != -1, cam2nd2 = g.nleft2 != -1;           // pKF->mpCamera2 != 0
     for (int j = tid; j < n2; j += TRIG_THREADS) {
-        dlds[2 * j] = d2[2 * j]; dlds[2 * j + 1] = d2[2 * j + 1];
+        if (!BIG) { dlds[2 * j] = d2[2 * j]; dlds[2 * j + 1] = d2[2 * j + 1]; }
         flag2[j] = (uint8_t)((mp2[j] ? 1 : 0) | ((!cam2nd2 && ur2 && ur2[j] >= 0.0f) ? 2 : 0));      // :1073
     }
     __syncthreads();
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(TRIG_THREADS) void k_search_triangulation_general(c
                     const int idx2 = fe2[j];
                     const int fl = flag2[idx2];
                     if ((fl & 1) || (g.only_stereo && !(fl & 2))) continue;
-                    const int dist = tri_hamming256(a0, a1, dlds[2 * idx2], dlds[2 * idx2 + 1]);
+                    const int dist = BIG ? tri_hamming256(a0, a1, d2[2 * idx2], d2[2 * idx2 + 1]) : tri_hamming256(a0, a1, dlds[2 * idx2], dlds[2 * idx2 + 1]);
                     if (dist > best) continue;                                // :1082 (best <= TH_LOW always)
                     const orbhip_keypoint k2 = kp2[idx2];
                     const int bRight2 = !(g.nleft2 == -1 || idx2 < g.nleft2);
@@ -375,12 +377,20 @@ extern "C" int orbhip_search_for_triangulation_general_device(orbhip_ctx *ctx,
         lv.sigma2_1[l] = l < nlevels ? level_sigma2_1[l] : 0.0f; lv.scale2[l] = l < nlevels ? scale_factors2[l] : 0.0f;
         lv.sigma2_2[l] = l < nlevels ? level_sigma2_2[l] : 0.0f;
     }
-    const int cap_n = ((max_n < 4096 ? max_n : 4096) + 15) & ~15;
-    const size_t lds = (size_t)cap_n * (32 + 1 + 1) + 16;
-    if (orb_lds_optin(reinterpret_cast<const void *>(k_search_triangulation_general), orbhip_ctx_device_internal(ctx), lds)) return ORBHIP_E_HIP;
+    // up to 4096 keypoints KF2's descriptors live in LDS; beyond (to 16384: the 5 x nFeatures keypoints of a monocular map's first keyframes,
+    // Tracking.cc:210) they are read from global memory and only the per-keypoint flags stay in LDS
+    const bool big = max_n > 4096;
+    const int lim = big ? 16384 : 4096;
+    const int cap_n = ((max_n < lim ? max_n : lim) + 15) & ~15;
+    const size_t lds = (size_t)cap_n * (big ? (1 + 1) : (32 + 1 + 1)) + 16;
+    const void *fn = big ? reinterpret_cast<const void *>(k_search_triangulation_general<true>) : reinterpret_cast<const void *>(k_search_triangulation_general<false>);
+    if (orb_lds_optin(fn, orbhip_ctx_device_internal(ctx), lds)) return ORBHIP_E_HIP;
     TriSideG S2 = {d_node_ids2, d_node_start2, d_feat2, d_nnodes2};
-    hipLaunchKernelGGL(k_search_triangulation_general, dim3(pairs), dim3(TRIG_THREADS), lds, orbhip_ctx_stream_internal(ctx), d_nid1, d_has_mp1, d_kp1,
-                       d_desc1, d_u_right1, d_n1, S2, d_has_mp2, d_kp2, d_desc2, d_u_right2, d_n2, d_pair, max_nodes, max_n, frame_stride_kp, lv,
-                       check_orientation, cap_n, d_matches12, d_nmatches, orbhip_ctx_status_internal(ctx));
+    if (big) hipLaunchKernelGGL(k_search_triangulation_general<true>, dim3(pairs), dim3(TRIG_THREADS), lds, orbhip_ctx_stream_internal(ctx), d_nid1, d_has_mp1, d_kp1,
+                                d_desc1, d_u_right1, d_n1, S2, d_has_mp2, d_kp2, d_desc2, d_u_right2, d_n2, d_pair, max_nodes, max_n, frame_stride_kp, lv,
+                                check_orientation, cap_n, d_matches12, d_nmatches, orbhip_ctx_status_internal(ctx));
+    else hipLaunchKernelGGL(k_search_triangulation_general<false>, dim3(pairs), dim3(TRIG_THREADS), lds, orbhip_ctx_stream_internal(ctx), d_nid1, d_has_mp1, d_kp1,
+                            d_desc1, d_u_right1, d_n1, S2, d_has_mp2, d_kp2, d_desc2, d_u_right2, d_n2, d_pair, max_nodes, max_n, frame_stride_kp, lv,
+                            check_orientation, cap_n, d_matches12, d_nmatches, orbhip_ctx_status_internal(ctx));
     return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
 }

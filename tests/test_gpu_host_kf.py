@@ -340,11 +340,15 @@ def sim3_queries(W, cand, Scw, th, skip, project_camera, has_obs):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", [11, 12])
-def test_keyframe_matchers_pinhole(tmp_path, seed):
-    """Pinhole keyframes (monocular + stereo keypoints): every keyframe-side method against the Python model + oracles."""
+@pytest.mark.parametrize("seed,n1,n2,npts", [(11, 700, 800, 900), (12, 700, 800, 900), (13, 5200, 5600, 6000)])
+def test_keyframe_matchers_pinhole(tmp_path, seed, n1, n2, npts):
+    """Pinhole keyframes (monocular + stereo keypoints): every keyframe-side method against the Python model + oracles.
+    The third case has keyframes of 5200 / 5600 keypoints -- what the two first keyframes of a monocular map carry (the initialisation
+    extractor runs 5 x nFeatures, Tracking.cc:210): round 3's kernels refused them (LDS capacities of 2048 / 2900 / 4096 keypoints per
+    keyframe) and the class methods then found nothing; round 4 gives Fuse / SearchBySim3, SearchForTriangulation, SearchByBoW and the
+    Sim3 / relocalisation projections a form that keeps only the grid in LDS."""
     import oracle_match_bind as om
-    W, rng = make_world(seed)
+    W, rng = make_world(seed, n1=n1, n2=n2, M=npts)
     M = len(W["pt_obs"]); kf1, kf2 = W["kf1"], W["kf2"]
     A = world_arrays(W)
     # candidate lists: map points incl. NULL entries, duplicates of points the keyframe already holds (-> Replace), points it holds (skipped)

@@ -349,14 +349,26 @@ def test_search_by_projection_contested_keypoints(gpu_ctx, sbp_form, mode):
         assert n_ref >= 10
 
 
-def test_search_by_projection_capacity(gpu_ctx):
+def test_search_by_projection_big_keyframes_and_capacity(gpu_ctx):
+    """Frames / keyframes beyond the replay form's 2048 keypoints (the two first keyframes of a monocular map carry 5 x nFeatures,
+    Tracking.cc:210) take the sequential kernel alone (round 4; refused in round 3): 2100 and 5200 keypoints equal the oracle.  What LDS
+    cannot hold (17 B per keypoint + 3 B per query + the grid > 160 KB) is refused with ORBHIP_E_CAPACITY, loudly."""
     import orbhip
+    import oracle_match_bind as om
     from test_oracle_match_ba import make_sbp_case
     rng = np.random.default_rng(3)
-    c = make_sbp_case(rng, 2100, 10, False)
+    bounds = (0.0, 0.0, 640.0, 480.0)
+    for n, nq in ((2100, 10), (5200, 900)):
+        c = make_sbp_case(rng, n, nq, False)
+        got = _sbp(gpu_ctx, [c], max(nq, 16), n, bounds)
+        q, dq, kp, d, ur, tm = c
+        n_ref, tm_ref = om.search_by_projection(q, dq, kp, d, ur, bounds, tm, 100, True)
+        assert got[0][0] == n_ref
+        np.testing.assert_array_equal(got[0][1], tm_ref)
+    c = make_sbp_case(rng, 9000, 10, False)
     with pytest.raises(orbhip.OrbHipError):
-        _sbp(gpu_ctx, [c], 16, 2100, (0.0, 0.0, 640.0, 480.0))
-    gpu_ctx.check_status()          # sticky flag was cleared by the raising check
+        _sbp(gpu_ctx, [c], 16, 9000, bounds)
+    gpu_ctx.check_status()
 
 
 def test_search_for_initialization_5x_features(gpu_ctx, si_form):
