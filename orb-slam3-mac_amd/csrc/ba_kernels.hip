@@ -151,17 +151,17 @@ struct BaBatch {      // kernel argument (by value)
 };
 
 // The calibration the edges of pose `pi` (local index) of graph G project through: the keyframe's own camera when the graph carries a
-// camera table, else the graph's single calibration (uniform values: scalar loads)
+// camera table, else the graph's single calibration.  A REFERENCE, not a copy: BaGraphDev's calibration fields (fx ... cam2_model) are
+// laid out exactly like a BaCamDev, so both cases are one pointer and a field is loaded where it is used (a 30-double copy per edge
+// cost the general build kernel its second wave per SIMD: 232 -> 280 registers)
+static_assert(offsetof(BaGraphDev, cam2_model) - offsetof(BaGraphDev, fx) == offsetof(BaCamDev, cam2_model) && offsetof(BaGraphDev, kb) - offsetof(BaGraphDev, fx) == offsetof(BaCamDev, kb) &&
+              offsetof(BaGraphDev, Trl) - offsetof(BaGraphDev, fx) == offsetof(BaCamDev, Trl) && offsetof(BaGraphDev, kb2) - offsetof(BaGraphDev, fx) == offsetof(BaCamDev, kb2),
+              "BaGraphDev's calibration fields must mirror BaCamDev");
 template <bool GENERAL>
-__device__ __forceinline__ void ba_cam_of(const BaBatch &B, const BaGraphDev &G, int pi, BaCamDev &c)
+__device__ __forceinline__ const BaCamDev &ba_cam_ref(const BaBatch &B, const BaGraphDev &G, int pi)
 {
-    if (GENERAL && G.cam_off >= 0) { c = B.cams[G.cam_off + B.pose_cam[G.pose_off + pi]]; return; }
-    c.fx = G.fx; c.fy = G.fy; c.cx = G.cx; c.cy = G.cy; c.bf = G.bf; c.cam_model = G.cam_model;
-#pragma unroll
-    for (int k = 0; k < 4; k++) { c.kb[k] = G.kb[k]; c.kb2[k] = G.kb2[k]; }
-#pragma unroll
-    for (int k = 0; k < 7; k++) c.Trl[k] = G.Trl[k];
-    c.fx2 = G.fx2; c.fy2 = G.fy2; c.cx2 = G.cx2; c.cy2 = G.cy2; c.cam2_model = G.cam2_model;
+    if (GENERAL && G.cam_off >= 0) return B.cams[G.cam_off + B.pose_cam[G.pose_off + pi]];
+    return *reinterpret_cast<const BaCamDev *>(&G.fx);
 }
 
 // ------------------------------------------------------------------ SE3 helpers (B1)
@@ -439,8 +439,7 @@ __global__ __launch_bounds__(256) void k_ba_errors(BaBatch B, int which)
     const double *X = B.points + ((size_t)buf * B.sumL + G.point_off + B.edge_point[ge]) * 3;
     double P[3], er[3];
     const int type = B.edge_stereo[ge], stereo = type == 1;          // 0 mono, 1 stereo, 2 second camera (ToBody)
-    BaCamDev cam;
-    ba_cam_of<GENERAL>(B, G, B.edge_pose[ge], cam);
+    const BaCamDev &cam = ba_cam_ref<GENERAL>(B, G, B.edge_pose[ge]);
     if (GENERAL && type == 2) tobody_error(cam, pose, X, B.edge_obs + 3 * (size_t)ge, P, er);
     else edge_error<GENERAL>(cam, pose, X, B.edge_obs + 3 * (size_t)ge, stereo, P, er);
     const double chi2 = (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * B.edge_is2[ge];
@@ -505,8 +504,8 @@ __global__ __launch_bounds__(256) void k_ba_build_points(BaBatch B)
     const BaGraphDev &G = B.gd[g];
     const int sub = threadIdx.x & 15;
     const int l = blockIdx.x * 16 + (threadIdx.x >> 4);
-    if (l >= G.n_points) return;                      // whole 16-lane groups leave together
     const int *ps = B.pt_start + G.ptstart_off;
+    if (l >= G.n_points) return;                      // whole 16-lane groups leave together
     const int e0 = ps[l], e1 = ps[l + 1];
     const double *X = B.points + ((size_t)st.cur * B.sumL + G.point_off + l) * 3;
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // H (6, upper) then b (3)
@@ -521,8 +520,7 @@ __global__ __launch_bounds__(256) void k_ba_build_points(BaBatch B)
         for (int k = 6; k < 9; k++) Jx[k] = 0;
 #pragma unroll
         for (int k = 12; k < 18; k++) Jt[k] = 0;                                     // monocular edge: third row empty
-        BaCamDev cam;
-        ba_cam_of<GENERAL>(B, G, pi, cam);
+        const BaCamDev &cam = ba_cam_ref<GENERAL>(B, G, pi);
         if (GENERAL && type == 2) tobody_jacobians(cam, pose, X, Jx, Jt);
         else {
             quat_rot(pose, X, P);
@@ -579,6 +577,8 @@ __global__ __launch_bounds__(256) void k_ba_build_points(BaBatch B)
                         Wb[6 * bb + a] += h;
                     }
             }
+            // (round 4: parking the blocks of a workgroup's 16 points in LDS and writing the contiguous range out with consecutive lanes on
+            // consecutive 16 bytes was SLOWER: 0.55 against 0.42 ms per 256 windows -- two more barriers and the LDS round trip)
             double *wo = B.Wsp + (size_t)B.edge_task[ge] * 18;
 #pragma unroll
             for (int k = 0; k < 18; k++) wo[k] = Wb[k];
@@ -615,8 +615,7 @@ __global__ __launch_bounds__(64) void k_ba_build_poses(BaBatch B)
     // (bit-identical to k_ba_errors: same inputs, same code) instead of being gathered from the point-major arrays
     const int pose_i = qs[h] < qs[h + 1] ? B.edge_pose[G.edge_off + pe[qs[h]]] : 0;
     const double *pose = B.poses + ((size_t)st.cur * B.sumP + G.pose_off + pose_i) * 7;
-    BaCamDev cam;
-    ba_cam_of<GENERAL>(B, G, pose_i, cam);
+    const BaCamDev &cam = ba_cam_ref<GENERAL>(B, G, pose_i);
     for (int k = qs[h] + lane; k < qs[h + 1]; k += 64) {
         const size_t gk = (size_t)G.edge_off + k;
         const double *X = B.points + ((size_t)st.cur * B.sumL + G.point_off + B.pm_point[gk]) * 3;
@@ -1609,8 +1608,7 @@ __global__ __launch_bounds__(256) void k_ba_levels(BaBatch B)
     const int ge = G.edge_off + e;
     const double *pose = B.poses + ((size_t)st.cur * B.sumP + G.pose_off + B.edge_pose[ge]) * 7;
     const double *X = B.points + ((size_t)st.cur * B.sumL + G.point_off + B.edge_point[ge]) * 3;
-    BaCamDev cam;
-    ba_cam_of<true>(B, G, B.edge_pose[ge], cam);                  // (mTrl of the edge's own keyframe)
+    const BaCamDev &cam = ba_cam_ref<true>(B, G, B.edge_pose[ge]);      // (mTrl of the edge's own keyframe)
     const double z = edge_depth(cam, pose, X, B.edge_stereo[ge]);
     const double gate = B.edge_stereo[ge] == 1 ? B.gate_s : B.gate_m;
     if ((B.chi2[ge] > gate) || !(z > 0.0)) B.level[ge] = 1;
@@ -1627,8 +1625,7 @@ __global__ __launch_bounds__(256) void k_ba_finalize(BaBatch B)
     const int ge = G.edge_off + e;
     const double *pose = B.poses + ((size_t)st.cur * B.sumP + G.pose_off + B.edge_pose[ge]) * 7;
     const double *X = B.points + ((size_t)st.cur * B.sumL + G.point_off + B.edge_point[ge]) * 3;
-    BaCamDev cam;
-    ba_cam_of<true>(B, G, B.edge_pose[ge], cam);                  // (mTrl of the edge's own keyframe)
+    const BaCamDev &cam = ba_cam_ref<true>(B, G, B.edge_pose[ge]);      // (mTrl of the edge's own keyframe)
     const double z = edge_depth(cam, pose, X, B.edge_stereo[ge]);
     const double gate = B.edge_stereo[ge] == 1 ? B.gate_s : B.gate_m;
     const int out = (B.chi2[ge] > gate) || !(z > 0.0);
