@@ -37,7 +37,7 @@ WORKLOADS = {      # name -> (width, height, nfeatures, frames per GPU, stereo p
     "hd": (1920, 1080, 2000, 512, 64),
     "4k": (3840, 2160, 2000, 64, 0),
 }
-PROFILE_TAG = "r03"
+PROFILE_TAG = "r04"
 
 
 def level_dims(w, h, nlevels=8, scale=1.2):

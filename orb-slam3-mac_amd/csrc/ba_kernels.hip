@@ -2293,7 +2293,9 @@ static int ba_solve_impl(orbhip_ba_batch *b, const orbhip_ba_params *params, vol
     // Replay form of a tick (no exchange, no event timing, abort flag down): captured once per batch and parameter set.  The
     // kernels of a graph that has finished return at once, so several ticks may be queued per host round trip.
     const bool trace = getenv("ORBHIP_BA_TRACE") != nullptr;      // development: graph 0's LM state after every tick on stderr (one tick per round trip)
-    const bool use_graph = !sharded && !b->profile && !trace;
+    // (a one-shot solve would capture, instantiate and destroy a graph for ~8 replays: ORBHIP_BA_ONESHOT_GRAPH=0 / 1 decides)
+    static const int oneshot_graph = getenv("ORBHIP_BA_ONESHOT_GRAPH") ? atoi(getenv("ORBHIP_BA_ONESHOT_GRAPH")) : 0;
+    const bool use_graph = !sharded && !b->profile && !trace && (!b->ctx_arena || oneshot_graph);
     if (use_graph && !(b->tick_graph_valid && memcmp(&b->tick_B, &B, sizeof(BaBatch)) == 0)) {
         if (b->tick_graph_valid) { (void)hipGraphExecDestroy(b->tick_graph); b->tick_graph_valid = false; }
         hipGraph_t graph = nullptr;

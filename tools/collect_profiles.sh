@@ -9,7 +9,7 @@ root=$PWD
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $root
-ORB="--no-cpu-baseline --ba-graphs 0 --pose-frames 0 --stereo-pairs 0 --inertial-windows 0 --pipelines 1 --no-tracking --no-latency --no-hd-leg"
+ORB="--no-cpu-baseline --ba-graphs 0 --pose-frames 0 --stereo-pairs 0 --inertial-windows 0 --pipelines 1 --no-tracking --no-latency --no-hd-leg --no-4k-leg"
 timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $out/trace -o run --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --stereo-pairs 0 --pipelines 1 --no-tracking --no-latency "$@" > $out/trace.log 2>&1 || { tail -5 $out/trace.log; exit 1; }
 echo trace done
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE -d $out/fetch -o run --output-format csv -- python3 bench.py --steps 2 --warmup 1 $ORB "$@" > $out/fetch.log 2>&1 || { tail -5 $out/fetch.log; exit 1; }

@@ -3,8 +3,8 @@
 set -o pipefail
 root=$PWD; out=$root/gpurun_out/pmc_ba_traffic; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $root
-timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE -d $out/fetch -o run --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --batch 16 --ba-steps 1 --pose-frames 0 --stereo-pairs 0 --inertial-windows 0 --no-tracking --no-latency --no-hd-leg > $out/fetch.log 2>&1 || exit 1
-timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE -d $out/write -o run --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --batch 16 --ba-steps 1 --pose-frames 0 --stereo-pairs 0 --inertial-windows 0 --no-tracking --no-latency --no-hd-leg > $out/write.log 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE -d $out/fetch -o run --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --batch 16 --ba-steps 1 --pose-frames 0 --stereo-pairs 0 --inertial-windows 0 --no-tracking --no-latency --no-hd-leg --no-4k-leg > $out/fetch.log 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE -d $out/write -o run --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --batch 16 --ba-steps 1 --pose-frames 0 --stereo-pairs 0 --inertial-windows 0 --no-tracking --no-latency --no-hd-leg --no-4k-leg > $out/write.log 2>&1 || exit 1
 python3 - <<'P'
 import csv, json, collections, glob
 def load(path, counter):
