@@ -424,6 +424,32 @@ int orbhip_search_for_triangulation_general_device(orbhip_ctx *ctx,
         const float *level_sigma2_1, const float *scale_factors2, const float *level_sigma2_2, int nlevels, int check_orientation,
         int32_t *d_matches12, int32_t *d_nmatches);
 
+/* ORBmatcher::SearchForTriangulation, the overload that also returns the triangulated points (src/ORBmatcher.cc:1212-1402, no caller
+ * in the reference).  Per candidate the camera and pose of each side are picked by bRight (:1307-1321) and the test is
+ * GeometricCamera::matchAndtriangulate of the FIRST camera: KannalaBrandt8 (src/CameraModels/KannalaBrandt8.cpp:240-332: ray parallax
+ * < 0.9998 with the rays turned into the world frame, linear triangulation with the ABSOLUTE poses, both depths positive,
+ * reprojection errors <= 5.991 sigma^2 in both cameras) or Pinhole, whose implementation is `{ return false; }`
+ * (include/CameraModels/Pinhole.h:91-94): a pair whose first camera is a Pinhole matches nothing.  bOnlyStereo is not read by that
+ * overload, there is no epipole gate and vbMatched2 is never set.  d_pair: cam1 / cam2 / cam*_type / nleft1 / nleft2 are read (the
+ * rest ignored); d_poses: rows 0..2 of GetPose() ([0]) and GetRightPose() ([1]) of both keyframes, row-major 3x4.
+ * d_points12 [pairs][max_n][3]: x3Dtriangulated (a WORLD point) of the kept match of KF1 keypoint i (zeros where matches12 < 0;
+ * entries of matches the rotation histogram removed keep their point, as vMatchesPoints12 does). */
+typedef struct orbhip_tri_pair_poses { float Tcw1[2][12], Tcw2[2][12]; } orbhip_tri_pair_poses;
+int orbhip_match_and_triangulate_device(orbhip_ctx *ctx,
+        const int32_t *d_nid1, const uint8_t *d_has_mp1, const orbhip_keypoint *d_kp1, const uint8_t *d_desc1, const int32_t *d_n1,
+        const int32_t *d_node_ids2, const int32_t *d_node_start2, const int32_t *d_feat2, const int32_t *d_nnodes2,
+        const uint8_t *d_has_mp2, const orbhip_keypoint *d_kp2, const uint8_t *d_desc2, const int32_t *d_n2,
+        const orbhip_tri_pair_general *d_pair, const orbhip_tri_pair_poses *d_poses, int pairs, int max_nodes, int max_n, size_t frame_stride_kp,
+        const float *level_sigma2_1, const float *level_sigma2_2, int nlevels, int check_orientation,
+        int32_t *d_matches12, float *d_points12, int32_t *d_nmatches);
+/* one pair, HOST pointers (as orbhip_search_for_triangulation_host below); points12_out [n1][3] */
+int orbhip_match_and_triangulate_host(orbhip_ctx *ctx,
+        const int32_t *nid1, const uint8_t *has_mp1, const orbhip_keypoint *kp1, const uint8_t *desc1, int n1,
+        const int32_t *node_ids2, const int32_t *node_start2, const int32_t *feat2, int nnodes2,
+        const uint8_t *has_mp2, const orbhip_keypoint *kp2, const uint8_t *desc2, int n2,
+        const orbhip_tri_pair_general *pair, const orbhip_tri_pair_poses *poses, const float *level_sigma2_1, const float *level_sigma2_2,
+        int nlevels, int check_orientation, int32_t *matches12_out, float *points12_out, int32_t *nmatches_out);
+
 /* Host-pointer forms for ONE keyframe (pair) -- what the ORBmatcher methods of host/ORBmatcher.cc call (upload into the context's
  * arena, the same kernels as the batched device entry points, download, synchronise).  All pointers HOST.
  *   orbhip_search_for_triangulation_host: one pair through the general kernel (nid1 [n1]: vocabulary node of every KF1 feature, -1 =

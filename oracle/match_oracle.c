@@ -1034,3 +1034,113 @@ int orc_search_for_triangulation_general(const int32_t *nid1, const uint8_t *has
     free(bin_of);
     return nmatches;
 }
+
+/* ================================================================= SearchForTriangulation, the overload that returns the points
+ * ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo, vMatchedPoints) (ORBm:1212-1402; no caller in the
+ * reference).  Candidate walk as the first overload, with these differences (all read from the text of :1236-1402):
+ *   - only the map-point tests gate a keypoint (:1264-1265, :1289-1290): bOnlyStereo is never read, vbMatched2 is never set, and
+ *     there is no epipole test;
+ *   - camera and pose of each side by bRight (:1307-1321): Tcw = GetPose() / GetRightPose(), camera = mpCamera / mpCamera2;
+ *   - the test is pCamera1->matchAndtriangulate (:1324): Pinhole's is `{ return false; }` (include/CameraModels/Pinhole.h:91-94);
+ *     KannalaBrandt8's (KannalaBrandt8.cpp:240-332) is restated below;
+ *   - the accepted candidate's x3D is kept per KF1 keypoint (:1327, :1338).
+ * cv::Mat arithmetic as for TriangulateMatches above (products accumulate in double and round once, Mat::dot / cv::norm in double,
+ * s*row - row through addWeighted in float, cv::SVD by the restated Jacobi): parity unpinned against an OpenCV build. */
+int orc_kb8_match_and_triangulate(const float *cam1, int type2, const float *cam2, float u1, float v1, float u2, float v2,
+                                  const float T1[12], const float T2[12], float sigmaLevel1, float sigmaLevel2, float x3D_out[3])
+{
+    float r1[3], r2[3], ray1[3], ray2[3];
+    orc_camera_unproject_f(1, cam1, u1, v1, r1);                                  /* this->unproject: the callee is a KannalaBrandt8 */
+    orc_camera_unproject_f(type2, cam2, u2, v2, r2);
+    for (int i = 0; i < 3; i++) {                                                 /* Rwc = Rcw.t(); ray = Rwc * r (:266-267) */
+        ray1[i] = (float)((double)T1[i] * r1[0] + (double)T1[4 + i] * r1[1] + (double)T1[8 + i] * r1[2]);
+        ray2[i] = (float)((double)T2[i] * r2[0] + (double)T2[4 + i] * r2[1] + (double)T2[8 + i] * r2[2]);
+    }
+    const double dot = (double)ray1[0] * ray2[0] + (double)ray1[1] * ray2[1] + (double)ray1[2] * ray2[2];
+    const double n1 = sqrt((double)ray1[0] * ray1[0] + (double)ray1[1] * ray1[1] + (double)ray1[2] * ray1[2]);
+    const double n2 = sqrt((double)ray2[0] * ray2[0] + (double)ray2[1] * ray2[1] + (double)ray2[2] * ray2[2]);
+    const float cosParallaxRays = (float)(dot / (n1 * n2));
+    if (cosParallaxRays > 0.9998) return 0;                                       /* :272-274 */
+    float A[16], Vt[16];
+    for (int j = 0; j < 4; j++) {                                                 /* Triangulate, KannalaBrandt8.cpp:426-429 */
+        A[j] = r1[0] * T1[8 + j] - T1[j];
+        A[4 + j] = r1[1] * T1[8 + j] - T1[4 + j];
+        A[8 + j] = r2[0] * T2[8 + j] - T2[j];
+        A[12 + j] = r2[1] * T2[8 + j] - T2[4 + j];
+    }
+    jacobi_svd4_vt(A, Vt);
+    const float inv = (float)(1.0 / (double)Vt[15]);
+    const float x3D[3] = {Vt[12] * inv, Vt[13] * inv, Vt[14] * inv};
+    const float z1 = (float)((double)T1[8] * x3D[0] + (double)T1[9] * x3D[1] + (double)T1[10] * x3D[2] + (double)T1[11]);   /* :292 */
+    if (!(z1 > 0)) return 0;
+    const float z2 = (float)((double)T2[8] * x3D[0] + (double)T2[9] * x3D[1] + (double)T2[10] * x3D[2] + (double)T2[11]);   /* :298 */
+    if (!(z2 > 0)) return 0;
+    float uv1[2], uv2[2], xc[3];
+    for (int i = 0; i < 3; i++)
+        xc[i] = (float)((double)T1[4 * i] * x3D[0] + (double)T1[4 * i + 1] * x3D[1] + (double)T1[4 * i + 2] * x3D[2] + (double)T1[4 * i + 3]);
+    orc_camera_project_f(1, cam1, xc, uv1);
+    const float errX1 = uv1[0] - u1, errY1 = uv1[1] - v1;
+    if ((errX1 * errX1 + errY1 * errY1) > 5.991 * sigmaLevel1) return 0;          /* :311 */
+    for (int i = 0; i < 3; i++)
+        xc[i] = (float)((double)T2[4 * i] * x3D[0] + (double)T2[4 * i + 1] * x3D[1] + (double)T2[4 * i + 2] * x3D[2] + (double)T2[4 * i + 3]);
+    orc_camera_project_f(type2, cam2, xc, uv2);
+    const float errX2 = uv2[0] - u2, errY2 = uv2[1] - v2;
+    if ((errX2 * errX2 + errY2 * errY2) > 5.991 * sigmaLevel2) return 0;          /* :323 */
+    x3D_out[0] = x3D[0]; x3D_out[1] = x3D[1]; x3D_out[2] = x3D[2];
+    return 1;
+}
+
+int orc_search_for_triangulation_points(const int32_t *nid1, const uint8_t *has_mp1, const orc_keypoint *kp1, const uint8_t *desc1, int n1,
+                                        const int32_t *node_ids2, const int32_t *node_start2, const int32_t *feat2, int nnodes2,
+                                        const uint8_t *has_mp2, const orc_keypoint *kp2, const uint8_t *desc2,
+                                        const orc_tri_general *g, const orc_tri_poses *poses, const float *level_sigma2_1,
+                                        const float *level_sigma2_2, int check_orientation, int32_t *matches12, float *points12)
+{
+    int nmatches = 0;
+    int hist[HISTO_LENGTH]; memset(hist, 0, sizeof(hist));
+    int *bin_of = (int *)malloc(sizeof(int) * (n1 ? n1 : 1));
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int idx1 = 0; idx1 < n1; idx1++) {
+        matches12[idx1] = -1; bin_of[idx1] = -1;
+        points12[3 * idx1] = points12[3 * idx1 + 1] = points12[3 * idx1 + 2] = 0;
+        if (has_mp1[idx1]) continue;                                           /* :1264-1265 */
+        const int bRight1 = !(g->nleft1 == -1 || idx1 < g->nleft1);            /* :1271-1272 */
+        int lo = 0, hi = nnodes2;
+        while (lo < hi) { const int mid = (lo + hi) / 2; if (node_ids2[mid] < nid1[idx1]) lo = mid + 1; else hi = mid; }
+        if (lo >= nnodes2 || node_ids2[lo] != nid1[idx1]) continue;
+        int bestDist = TH_LOW, bestIdx2 = -1;
+        for (int j = node_start2[lo]; j < node_start2[lo + 1]; j++) {
+            const int idx2 = feat2[j];
+            if (has_mp2[idx2]) continue;                                       /* :1289 (vbMatched2 stays false) */
+            const int dist = orc_descriptor_distance(desc1 + 32 * (size_t)idx1, desc2 + 32 * (size_t)idx2);
+            if (dist > TH_LOW || dist > bestDist) continue;                    /* :1296 */
+            const int bRight2 = !(g->nleft2 == -1 || idx2 < g->nleft2);        /* :1304-1305 */
+            float x3D[3];
+            if (g->cam1_type[bRight1] == 1 &&
+                orc_kb8_match_and_triangulate(g->cam1[bRight1], g->cam2_type[bRight2], g->cam2[bRight2], kp1[idx1].x, kp1[idx1].y, kp2[idx2].x,
+                                              kp2[idx2].y, poses->Tcw1[bRight1], poses->Tcw2[bRight2], level_sigma2_1[kp1[idx1].octave],
+                                              level_sigma2_2[kp2[idx2].octave], x3D)) {
+                bestIdx2 = idx2; bestDist = dist;
+                points12[3 * idx1] = x3D[0]; points12[3 * idx1 + 1] = x3D[1]; points12[3 * idx1 + 2] = x3D[2];
+            }
+        }
+        if (bestIdx2 >= 0) {
+            matches12[idx1] = bestIdx2; nmatches++;
+            if (check_orientation) {                                           /* :1342-1352 */
+                float rot = kp1[idx1].angle - kp2[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                hist[bin]++; bin_of[idx1] = bin;
+            }
+        }
+    }
+    if (check_orientation) {                                                   /* :1370-1389 */
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(hist, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < n1; i++)
+            if (bin_of[i] >= 0 && bin_of[i] != ind1 && bin_of[i] != ind2 && bin_of[i] != ind3) { matches12[i] = -1; nmatches--; }
+    }
+    free(bin_of);
+    return nmatches;
+}

@@ -168,6 +168,15 @@ int orc_search_for_triangulation_general(const int32_t *nid1, const uint8_t *has
                                          const float *level_sigma2_2, int check_orientation, int32_t *matches12);
 float orc_kb8_triangulate_matches(int type1, const float *cam1, int type2, const float *cam2, float u1, float v1, float u2, float v2,
                                   const float *R12, const float *t12, float sigmaLevel, float unc, float x3D_out[3]);
+/* ---- SearchForTriangulation returning the triangulated points (ORBm:1212-1402; KannalaBrandt8.cpp:240-332; Pinhole.h:91-94) */
+typedef struct { float Tcw1[2][12], Tcw2[2][12]; } orc_tri_poses;   /* rows 0..2 of GetPose() [0] / GetRightPose() [1] of pKF1, pKF2 */
+int orc_kb8_match_and_triangulate(const float *cam1, int type2, const float *cam2, float u1, float v1, float u2, float v2,
+                                  const float T1[12], const float T2[12], float sigmaLevel1, float sigmaLevel2, float x3D_out[3]);
+int orc_search_for_triangulation_points(const int32_t *nid1, const uint8_t *has_mp1, const orc_keypoint *kp1, const uint8_t *desc1, int n1,
+                                        const int32_t *node_ids2, const int32_t *node_start2, const int32_t *feat2, int nnodes2,
+                                        const uint8_t *has_mp2, const orc_keypoint *kp2, const uint8_t *desc2,
+                                        const orc_tri_general *g, const orc_tri_poses *poses, const float *level_sigma2_1,
+                                        const float *level_sigma2_2, int check_orientation, int32_t *matches12, float *points12);
 void orc_camera_project_f(int type, const float *p, const float P[3], float uv[2]);
 void orc_camera_unproject_f(int type, const float *p, float u, float v, float ray[3]);
 

@@ -319,6 +319,38 @@ extern "C" int orbhip_search_for_triangulation_host(orbhip_ctx *ctx,
     return H.finish();
 }
 
+extern "C" int orbhip_match_and_triangulate_host(orbhip_ctx *ctx,
+        const int32_t *nid1, const uint8_t *has_mp1, const orbhip_keypoint *kp1, const uint8_t *desc1, int n1,
+        const int32_t *node_ids2, const int32_t *node_start2, const int32_t *feat2, int nnodes2,
+        const uint8_t *has_mp2, const orbhip_keypoint *kp2, const uint8_t *desc2, int n2,
+        const orbhip_tri_pair_general *pair, const orbhip_tri_pair_poses *poses, const float *level_sigma2_1, const float *level_sigma2_2,
+        int nlevels, int check_orientation, int32_t *matches12_out, float *points12_out, int32_t *nmatches_out)
+{
+    if (!ctx || n1 < 0 || n2 < 0 || nnodes2 < 0 || !pair || !poses || !nmatches_out || (n1 && (!nid1 || !has_mp1 || !kp1 || !desc1 || !matches12_out || !points12_out)) ||
+        (n2 && (!has_mp2 || !kp2 || !desc2)) || (nnodes2 && (!node_ids2 || !node_start2 || !feat2)) || !level_sigma2_1 || !level_sigma2_2)
+        return ORBHIP_E_BADARG;
+    *nmatches_out = 0;
+    for (int i = 0; i < n1; i++) { matches12_out[i] = -1; points12_out[3 * i] = points12_out[3 * i + 1] = points12_out[3 * i + 2] = 0.f; }
+    if (n1 == 0 || n2 == 0 || nnodes2 == 0) return ORBHIP_OK;
+    const int mx = n1 > n2 ? n1 : n2;
+    HostCall H(ctx);
+    const int a_nid = H.in(nid1, 4 * (size_t)n1), a_mp1 = H.in(has_mp1, n1);
+    const int a_ids = H.in(node_ids2, 4 * (size_t)nnodes2), a_st = H.in(node_start2, 4 * (size_t)(nnodes2 + 1)), a_fe = H.in(feat2, 4 * (size_t)node_start2[nnodes2]);
+    const int a_mp2 = H.in(has_mp2, n2);
+    const int a_kp1 = H.in(kp1, sizeof(orbhip_keypoint) * (size_t)n1, sizeof(orbhip_keypoint) * (size_t)mx);
+    const int a_kp2 = H.in(kp2, sizeof(orbhip_keypoint) * (size_t)n2, sizeof(orbhip_keypoint) * (size_t)mx);
+    const int a_d1 = H.in(desc1, 32 * (size_t)n1, 32 * (size_t)mx), a_d2 = H.in(desc2, 32 * (size_t)n2, 32 * (size_t)mx);
+    const int a_pair = H.in(pair, sizeof(*pair)), a_poses = H.in(poses, sizeof(*poses)), a_n1 = H.in(&n1, 4), a_n2 = H.in(&n2, 4), a_nn = H.in(&nnodes2, 4);
+    const int a_m = H.out(matches12_out, 4 * (size_t)n1, 4 * (size_t)mx), a_pt = H.out(points12_out, 12 * (size_t)n1, 12 * (size_t)mx), a_nm = H.out(nmatches_out, 4);
+    if (int rc = H.commit()) return rc;
+    const int rc = orbhip_match_and_triangulate_device(ctx, H.ptr<int32_t>(a_nid), H.ptr<uint8_t>(a_mp1), H.ptr<orbhip_keypoint>(a_kp1), H.ptr<uint8_t>(a_d1),
+        H.ptr<int32_t>(a_n1), H.ptr<int32_t>(a_ids), H.ptr<int32_t>(a_st), H.ptr<int32_t>(a_fe), H.ptr<int32_t>(a_nn), H.ptr<uint8_t>(a_mp2),
+        H.ptr<orbhip_keypoint>(a_kp2), H.ptr<uint8_t>(a_d2), H.ptr<int32_t>(a_n2), H.ptr<orbhip_tri_pair_general>(a_pair), H.ptr<orbhip_tri_pair_poses>(a_poses), 1,
+        nnodes2, mx, (size_t)mx, level_sigma2_1, level_sigma2_2, nlevels, check_orientation, H.ptr<int32_t>(a_m), H.ptr<float>(a_pt), H.ptr<int32_t>(a_nm));
+    if (rc) return rc;
+    return H.finish();
+}
+
 extern "C" int orbhip_fuse_search_host(orbhip_ctx *ctx, const orbhip_proj_query *q, const uint8_t *desc_q, int nq, const orbhip_keypoint *kp,
                                        const uint8_t *desc, const float *u_right, int n, const float *inv_level_sigma2, int nlevels,
                                        float min_x, float min_y, float max_x, float max_y, int32_t *best_idx_out, int32_t *best_dist_out)

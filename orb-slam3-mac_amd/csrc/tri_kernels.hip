@@ -222,24 +222,82 @@ __device__ bool tri_kb8_constrain(int type1, const float *cam1, int type2, const
     return z1 > 0.0001f;
 }
 
+// KannalaBrandt8::matchAndtriangulate (KannalaBrandt8.cpp:240-332): the candidate test of the SearchForTriangulation overload that
+// returns the triangulated points (ORBmatcher.cc:1212-1402).  T1 / T2 = rows 0..2 of Tcw1 / Tcw2 (world -> camera, row-major 3x4) of
+// the cameras the two keypoints were seen by; the first camera is a KannalaBrandt8 (the virtual call is made on it), the second any.
+// Differences from TriangulateMatches: absolute poses in the linear system, no z1 > 1e-4 test, x3D is a WORLD point.
+__device__ bool tri_kb8_match_and_triangulate(const float *cam1, int type2, const float *cam2, float u1, float v1, float u2, float v2,
+                                              const float *T1, const float *T2, float sigmaLevel1, float sigmaLevel2, float *x3D_out)
+{
+    float r1[3], r2[3], ray1[3], ray2[3];
+    tri_unproject(1, cam1, u1, v1, r1);
+    tri_unproject(type2, cam2, u2, v2, r2);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {                                              // Rwc = Rcw.t(); ray = Rwc * r
+        ray1[i] = (float)((double)T1[i] * r1[0] + (double)T1[4 + i] * r1[1] + (double)T1[8 + i] * r1[2]);
+        ray2[i] = (float)((double)T2[i] * r2[0] + (double)T2[4 + i] * r2[1] + (double)T2[8 + i] * r2[2]);
+    }
+    const double dot = (double)ray1[0] * ray2[0] + (double)ray1[1] * ray2[1] + (double)ray1[2] * ray2[2];
+    const double n1 = sqrt((double)ray1[0] * ray1[0] + (double)ray1[1] * ray1[1] + (double)ray1[2] * ray1[2]);
+    const double n2 = sqrt((double)ray2[0] * ray2[0] + (double)ray2[1] * ray2[1] + (double)ray2[2] * ray2[2]);
+    const float cosParallaxRays = (float)(dot / (n1 * n2));
+    if ((double)cosParallaxRays > 0.9998) return false;
+    // Triangulate(p11, p22, Tcw1, Tcw2, x3D) (KannalaBrandt8.cpp:422-435); stored transposed: At[j] = column j of A
+    float At[4][4], v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        At[j][0] = r1[0] * T1[8 + j] - T1[j];
+        At[j][1] = r1[1] * T1[8 + j] - T1[4 + j];
+        At[j][2] = r2[0] * T2[8 + j] - T2[j];
+        At[j][3] = r2[1] * T2[8 + j] - T2[4 + j];
+    }
+    tri_svd4_null(At, v);
+    const float inv = (float)(1.0 / (double)v[3]);
+    const float x3D[3] = {v[0] * inv, v[1] * inv, v[2] * inv};
+    const float z1 = (float)((double)T1[8] * x3D[0] + (double)T1[9] * x3D[1] + (double)T1[10] * x3D[2] + (double)T1[11]);
+    if (!(z1 > 0.f)) return false;
+    const float z2 = (float)((double)T2[8] * x3D[0] + (double)T2[9] * x3D[1] + (double)T2[10] * x3D[2] + (double)T2[11]);
+    if (!(z2 > 0.f)) return false;
+    float uv1[2], uv2[2], xc[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+        xc[i] = (float)((double)T1[4 * i] * x3D[0] + (double)T1[4 * i + 1] * x3D[1] + (double)T1[4 * i + 2] * x3D[2] + (double)T1[4 * i + 3]);
+    tri_project(1, cam1, xc, uv1);
+    const float errX1 = uv1[0] - u1, errY1 = uv1[1] - v1;
+    if ((double)(errX1 * errX1 + errY1 * errY1) > 5.991 * (double)sigmaLevel1) return false;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+        xc[i] = (float)((double)T2[4 * i] * x3D[0] + (double)T2[4 * i + 1] * x3D[1] + (double)T2[4 * i + 2] * x3D[2] + (double)T2[4 * i + 3]);
+    tri_project(type2, cam2, xc, uv2);
+    const float errX2 = uv2[0] - u2, errY2 = uv2[1] - v2;
+    if ((double)(errX2 * errX2 + errY2 * errY2) > 5.991 * (double)sigmaLevel2) return false;
+    x3D_out[0] = x3D[0]; x3D_out[1] = x3D[1]; x3D_out[2] = x3D[2];
+    return true;
+}
+
 struct TriSideG { const int32_t *node_ids, *node_start, *feat, *nnodes; };
 struct TriLevelsG { float sigma2_1[16], scale2[16], sigma2_2[16]; };
 #define TRIG_THREADS 128
 #define TRIG_TH_LOW 50
 #define TRIG_HISTO 30
 
-// BIG (round 4): keyframes of more than 4096 keypoints (to 16384) read KF2's descriptors from global memory instead of LDS
-template <bool BIG>
+// BIG (round 4): keyframes of more than 4096 keypoints (to 16384) read KF2's descriptors from global memory instead of LDS.
+// MT (round 4): the overload that also returns the triangulated points (ORBmatcher.cc:1212-1402): the candidate test is
+// GeometricCamera::matchAndtriangulate with the absolute poses of the two cameras (poses_), no stereo / epipole gates (bOnlyStereo is
+// not read there), and the world point of every kept match goes to points12_ [pairs][max_n][3].
+template <bool BIG, bool MT>
 __global__ __launch_bounds__(TRIG_THREADS) void k_search_triangulation_general(const int32_t *nid1_, const uint8_t *mp1_, const orbhip_keypoint *kp1_,
         const uint8_t *desc1_, const float *ur1_, const int32_t *n1_, TriSideG S2, const uint8_t *mp2_, const orbhip_keypoint *kp2_,
         const uint8_t *desc2_, const float *ur2_, const int32_t *n2_, const orbhip_tri_pair_general *geom_, int max_nodes, int max_n,
-        size_t kp_stride, TriLevelsG lv, int check_ori, int cap_n, int32_t *matches12_, int32_t *nmatches_, int32_t *status)
+        size_t kp_stride, TriLevelsG lv, int check_ori, int cap_n, int32_t *matches12_, int32_t *nmatches_, int32_t *status,
+        const orbhip_tri_pair_poses *poses_, float *points12_)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t trig_lds[];
     uint4 *dlds = reinterpret_cast<uint4 *>(trig_lds);                        // [cap_n][2] KF2 descriptors (BIG: absent)
     uint8_t *flag2 = reinterpret_cast<uint8_t *>(dlds + (BIG ? 0 : 2 * (size_t)cap_n));   // [cap_n] bit0: has a map point, bit1: stereo
     int8_t *bin1 = reinterpret_cast<int8_t *>(flag2 + cap_n);                 // [cap_n] rotation bin of KF1 keypoint i's match
     __shared__ orbhip_tri_pair_general g;
+    __shared__ orbhip_tri_pair_poses P;
     __shared__ int hist[TRIG_HISTO];
     __shared__ int s_keep[3];
     __shared__ int s_cnt;
@@ -261,6 +319,11 @@ __global__ __launch_bounds__(TRIG_THREADS) void k_search_triangulation_general(c
         const uint32_t *src = reinterpret_cast<const uint32_t *>(geom_ + pair);
         uint32_t *dst = reinterpret_cast<uint32_t *>(&g);
         for (int i = tid; i < (int)(sizeof(orbhip_tri_pair_general) / 4); i += TRIG_THREADS) dst[i] = src[i];
+        if (MT) {
+            const uint32_t *psrc = reinterpret_cast<const uint32_t *>(poses_ + pair);
+            uint32_t *pdst = reinterpret_cast<uint32_t *>(&P);
+            for (int i = tid; i < (int)(sizeof(orbhip_tri_pair_poses) / 4); i += TRIG_THREADS) pdst[i] = psrc[i];
+        }
     }
     for (int i = tid; i < TRIG_HISTO; i += TRIG_THREADS) hist[i] = 0;
     if (tid == 0) s_cnt = 0;
@@ -275,9 +338,10 @@ __global__ __launch_bounds__(TRIG_THREADS) void k_search_triangulation_general(c
     int mine = 0;
     for (int idx1 = tid; idx1 < n1; idx1 += TRIG_THREADS) {
         int best_idx = -1;
+        float best_pt[3] = {0.f, 0.f, 0.f};
         bin1[idx1] = -1;
         const bool st1 = !cam2nd1 && ur1 && ur1[idx1] >= 0.0f;                // :1044
-        if (!mp1[idx1] && !(g.only_stereo && !st1)) {
+        if (!mp1[idx1] && (MT || !(g.only_stereo && !st1))) {                 // (:1264-1265: only the map-point test)
             const int nid = nid1[idx1];
             int lo = 0, hi = nn2;
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (ids2[mid] < nid) lo = mid + 1; else hi = mid; }
@@ -290,20 +354,27 @@ __global__ __launch_bounds__(TRIG_THREADS) void k_search_triangulation_general(c
                 for (int j = st2[lo]; j < st2[lo + 1]; j++) {
                     const int idx2 = fe2[j];
                     const int fl = flag2[idx2];
-                    if ((fl & 1) || (g.only_stereo && !(fl & 2))) continue;
+                    if ((fl & 1) || (!MT && g.only_stereo && !(fl & 2))) continue;
                     const int dist = BIG ? tri_hamming256(a0, a1, d2[2 * idx2], d2[2 * idx2 + 1]) : tri_hamming256(a0, a1, dlds[2 * idx2], dlds[2 * idx2 + 1]);
                     if (dist > best) continue;                                // :1082 (best <= TH_LOW always)
                     const orbhip_keypoint k2 = kp2[idx2];
                     const int bRight2 = !(g.nleft2 == -1 || idx2 < g.nleft2);
-                    if (!st1 && !(fl & 2) && !cam2nd1) {                      // :1091-1099
+                    if (!MT && !st1 && !(fl & 2) && !cam2nd1) {               // :1091-1099
                         const float ex = g.ep_x - k2.x, ey = g.ep_y - k2.y;
                         if (ex * ex + ey * ey < 100.0f * lv.scale2[k2.octave & 15]) continue;
                     }
                     const bool both = cam2nd1 && cam2nd2;                     // :1101-1130
                     const int c = both ? 2 * bRight1 + bRight2 : 0, ci1 = both ? bRight1 : 0, ci2 = both ? bRight2 : 0;
                     const float s2 = lv.sigma2_2[k2.octave & 15];
-                    bool ok = g.coarse != 0;
-                    if (!ok) {
+                    bool ok = !MT && g.coarse != 0;
+                    if (MT) {                                                 // :1307-1324: camera and pose by bRight; Pinhole::matchAndtriangulate is
+                        float pt[3];                                          // { return false; } (Pinhole.h:91-94)
+                        if (g.cam1_type[bRight1] == 1 &&
+                            tri_kb8_match_and_triangulate(g.cam1[bRight1], g.cam2_type[bRight2], g.cam2[bRight2], k1.x, k1.y, k2.x, k2.y, P.Tcw1[bRight1],
+                                                          P.Tcw2[bRight2], s1, s2, pt)) {
+                            ok = true; best_pt[0] = pt[0]; best_pt[1] = pt[1]; best_pt[2] = pt[2];
+                        }
+                    } else if (!ok) {
                         if (g.cam1_type[ci1] == 0) {                          // Pinhole.cpp:129-143
                             const float *F = g.F12[c];
                             const float la = k1.x * F[0] + k1.y * F[3] + F[6];
@@ -330,6 +401,10 @@ __global__ __launch_bounds__(TRIG_THREADS) void k_search_triangulation_general(c
             }
         }
         matches12[idx1] = best_idx;
+        if (MT) {
+            float *pt = points12_ + ((size_t)pair * max_n + idx1) * 3;
+            pt[0] = best_pt[0]; pt[1] = best_pt[1]; pt[2] = best_pt[2];
+        }
     }
     __syncthreads();
     if (check_ori) {                                                          // :1171-1189
@@ -359,6 +434,45 @@ __global__ __launch_bounds__(TRIG_THREADS) void k_search_triangulation_general(c
 
 }  // namespace
 
+namespace {
+int tri_general_launch(orbhip_ctx *ctx,
+        const int32_t *d_nid1, const uint8_t *d_has_mp1, const orbhip_keypoint *d_kp1, const uint8_t *d_desc1, const float *d_u_right1,
+        const int32_t *d_n1,
+        const int32_t *d_node_ids2, const int32_t *d_node_start2, const int32_t *d_feat2, const int32_t *d_nnodes2,
+        const uint8_t *d_has_mp2, const orbhip_keypoint *d_kp2, const uint8_t *d_desc2, const float *d_u_right2, const int32_t *d_n2,
+        const orbhip_tri_pair_general *d_pair, const orbhip_tri_pair_poses *d_poses, int pairs, int max_nodes, int max_n, size_t frame_stride_kp,
+        const float *level_sigma2_1, const float *scale_factors2, const float *level_sigma2_2, int nlevels, int check_orientation,
+        int32_t *d_matches12, float *d_points12, int32_t *d_nmatches)
+{
+    if (!ctx || !d_nid1 || !d_has_mp1 || !d_kp1 || !d_desc1 || !d_n1 || !d_node_ids2 || !d_node_start2 || !d_feat2 || !d_nnodes2 ||
+        !d_has_mp2 || !d_kp2 || !d_desc2 || !d_n2 || !d_pair || pairs <= 0 || max_nodes <= 0 || max_n <= 0 || !level_sigma2_1 || !scale_factors2 ||
+        !level_sigma2_2 || nlevels <= 0 || nlevels > 16 || !d_matches12 || !d_nmatches || (d_poses != nullptr) != (d_points12 != nullptr)) return ORBHIP_E_BADARG;
+    if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
+    TriLevelsG lv;
+    for (int l = 0; l < 16; l++) {
+        lv.sigma2_1[l] = l < nlevels ? level_sigma2_1[l] : 0.0f; lv.scale2[l] = l < nlevels ? scale_factors2[l] : 0.0f;
+        lv.sigma2_2[l] = l < nlevels ? level_sigma2_2[l] : 0.0f;
+    }
+    // up to 4096 keypoints KF2's descriptors live in LDS; beyond (to 16384: the 5 x nFeatures keypoints of a monocular map's first keyframes,
+    // Tracking.cc:210) they are read from global memory and only the per-keypoint flags stay in LDS
+    const bool big = max_n > 4096, mt = d_poses != nullptr;
+    const int lim = big ? 16384 : 4096;
+    const int cap_n = ((max_n < lim ? max_n : lim) + 15) & ~15;
+    const size_t lds = (size_t)cap_n * (big ? (1 + 1) : (32 + 1 + 1)) + 16;
+    typedef void (*kern_t)(const int32_t *, const uint8_t *, const orbhip_keypoint *, const uint8_t *, const float *, const int32_t *, TriSideG, const uint8_t *,
+                           const orbhip_keypoint *, const uint8_t *, const float *, const int32_t *, const orbhip_tri_pair_general *, int, int, size_t, TriLevelsG, int,
+                           int, int32_t *, int32_t *, int32_t *, const orbhip_tri_pair_poses *, float *);
+    const kern_t kern = mt ? (big ? k_search_triangulation_general<true, true> : k_search_triangulation_general<false, true>)
+                           : (big ? k_search_triangulation_general<true, false> : k_search_triangulation_general<false, false>);
+    if (orb_lds_optin(reinterpret_cast<const void *>(kern), orbhip_ctx_device_internal(ctx), lds)) return ORBHIP_E_HIP;
+    TriSideG S2 = {d_node_ids2, d_node_start2, d_feat2, d_nnodes2};
+    hipLaunchKernelGGL(kern, dim3(pairs), dim3(TRIG_THREADS), lds, orbhip_ctx_stream_internal(ctx), d_nid1, d_has_mp1, d_kp1, d_desc1, d_u_right1, d_n1, S2,
+                       d_has_mp2, d_kp2, d_desc2, d_u_right2, d_n2, d_pair, max_nodes, max_n, frame_stride_kp, lv, check_orientation, cap_n, d_matches12,
+                       d_nmatches, orbhip_ctx_status_internal(ctx), d_poses, d_points12);
+    return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
+}
+}  // namespace
+
 extern "C" int orbhip_search_for_triangulation_general_device(orbhip_ctx *ctx,
         const int32_t *d_nid1, const uint8_t *d_has_mp1, const orbhip_keypoint *d_kp1, const uint8_t *d_desc1, const float *d_u_right1,
         const int32_t *d_n1,
@@ -368,29 +482,21 @@ extern "C" int orbhip_search_for_triangulation_general_device(orbhip_ctx *ctx,
         const float *level_sigma2_1, const float *scale_factors2, const float *level_sigma2_2, int nlevels, int check_orientation,
         int32_t *d_matches12, int32_t *d_nmatches)
 {
-    if (!ctx || !d_nid1 || !d_has_mp1 || !d_kp1 || !d_desc1 || !d_n1 || !d_node_ids2 || !d_node_start2 || !d_feat2 || !d_nnodes2 ||
-        !d_has_mp2 || !d_kp2 || !d_desc2 || !d_n2 || !d_pair || pairs <= 0 || max_nodes <= 0 || max_n <= 0 || !level_sigma2_1 || !scale_factors2 ||
-        !level_sigma2_2 || nlevels <= 0 || nlevels > 16 || !d_matches12 || !d_nmatches) return ORBHIP_E_BADARG;
-    if (hipSetDevice(orbhip_ctx_device_internal(ctx)) != hipSuccess) return ORBHIP_E_HIP;
-    TriLevelsG lv;
-    for (int l = 0; l < 16; l++) {
-        lv.sigma2_1[l] = l < nlevels ? level_sigma2_1[l] : 0.0f; lv.scale2[l] = l < nlevels ? scale_factors2[l] : 0.0f;
-        lv.sigma2_2[l] = l < nlevels ? level_sigma2_2[l] : 0.0f;
-    }
-    // up to 4096 keypoints KF2's descriptors live in LDS; beyond (to 16384: the 5 x nFeatures keypoints of a monocular map's first keyframes,
-    // Tracking.cc:210) they are read from global memory and only the per-keypoint flags stay in LDS
-    const bool big = max_n > 4096;
-    const int lim = big ? 16384 : 4096;
-    const int cap_n = ((max_n < lim ? max_n : lim) + 15) & ~15;
-    const size_t lds = (size_t)cap_n * (big ? (1 + 1) : (32 + 1 + 1)) + 16;
-    const void *fn = big ? reinterpret_cast<const void *>(k_search_triangulation_general<true>) : reinterpret_cast<const void *>(k_search_triangulation_general<false>);
-    if (orb_lds_optin(fn, orbhip_ctx_device_internal(ctx), lds)) return ORBHIP_E_HIP;
-    TriSideG S2 = {d_node_ids2, d_node_start2, d_feat2, d_nnodes2};
-    if (big) hipLaunchKernelGGL(k_search_triangulation_general<true>, dim3(pairs), dim3(TRIG_THREADS), lds, orbhip_ctx_stream_internal(ctx), d_nid1, d_has_mp1, d_kp1,
-                                d_desc1, d_u_right1, d_n1, S2, d_has_mp2, d_kp2, d_desc2, d_u_right2, d_n2, d_pair, max_nodes, max_n, frame_stride_kp, lv,
-                                check_orientation, cap_n, d_matches12, d_nmatches, orbhip_ctx_status_internal(ctx));
-    else hipLaunchKernelGGL(k_search_triangulation_general<false>, dim3(pairs), dim3(TRIG_THREADS), lds, orbhip_ctx_stream_internal(ctx), d_nid1, d_has_mp1, d_kp1,
-                            d_desc1, d_u_right1, d_n1, S2, d_has_mp2, d_kp2, d_desc2, d_u_right2, d_n2, d_pair, max_nodes, max_n, frame_stride_kp, lv,
-                            check_orientation, cap_n, d_matches12, d_nmatches, orbhip_ctx_status_internal(ctx));
-    return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
+    return tri_general_launch(ctx, d_nid1, d_has_mp1, d_kp1, d_desc1, d_u_right1, d_n1, d_node_ids2, d_node_start2, d_feat2, d_nnodes2, d_has_mp2, d_kp2, d_desc2,
+                              d_u_right2, d_n2, d_pair, nullptr, pairs, max_nodes, max_n, frame_stride_kp, level_sigma2_1, scale_factors2, level_sigma2_2, nlevels,
+                              check_orientation, d_matches12, nullptr, d_nmatches);
+}
+
+extern "C" int orbhip_match_and_triangulate_device(orbhip_ctx *ctx,
+        const int32_t *d_nid1, const uint8_t *d_has_mp1, const orbhip_keypoint *d_kp1, const uint8_t *d_desc1, const int32_t *d_n1,
+        const int32_t *d_node_ids2, const int32_t *d_node_start2, const int32_t *d_feat2, const int32_t *d_nnodes2,
+        const uint8_t *d_has_mp2, const orbhip_keypoint *d_kp2, const uint8_t *d_desc2, const int32_t *d_n2,
+        const orbhip_tri_pair_general *d_pair, const orbhip_tri_pair_poses *d_poses, int pairs, int max_nodes, int max_n, size_t frame_stride_kp,
+        const float *level_sigma2_1, const float *level_sigma2_2, int nlevels, int check_orientation,
+        int32_t *d_matches12, float *d_points12, int32_t *d_nmatches)
+{
+    if (!d_poses || !d_points12) return ORBHIP_E_BADARG;
+    return tri_general_launch(ctx, d_nid1, d_has_mp1, d_kp1, d_desc1, nullptr, d_n1, d_node_ids2, d_node_start2, d_feat2, d_nnodes2, d_has_mp2, d_kp2, d_desc2,
+                              nullptr, d_n2, d_pair, d_poses, pairs, max_nodes, max_n, frame_stride_kp, level_sigma2_1, level_sigma2_2, level_sigma2_2, nlevels,
+                              check_orientation, d_matches12, d_points12, d_nmatches);
 }

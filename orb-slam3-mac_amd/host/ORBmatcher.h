@@ -14,7 +14,7 @@
 //   SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th)                             src/LoopClosing.cc
 //   Fuse(pKF, vpMapPoints, th, bRight)                                                   src/LocalMapping.cc:787-788, 816-817
 //   Fuse(pKF, Scw, vpPoints, th, vpReplacePoint)                                         src/LoopClosing.cc
-// (SearchForTriangulation's second overload with vMatchedPoints, include/ORBmatcher.h:77, has no caller in the reference and is not mirrored.)
+// (SearchForTriangulation's second overload with vMatchedPoints, include/ORBmatcher.h:76-77, has no caller in the reference; it is mirrored all the same.)
 // The per-point host geometry in front of each search (projection, frustum record, radius, level range) is kept as the
 // reference writes it; the windowed best / second-best search with the claim rule, the ratio tests, the reprojection and epipolar gates
 // and the rotation histogram run on the device.
@@ -69,6 +69,9 @@ public:
     // Matching to triangulate new MapPoints. Check Epipolar Constraint.        include/ORBmatcher.h:74, src/ORBmatcher.cc:969-1210
     int SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12, std::vector<std::pair<size_t, size_t>> &vMatchedPairs,
                                const bool bOnlyStereo, const bool bCoarse = false);
+    // ... returning the triangulated points as well (GeometricCamera::matchAndtriangulate)   include/ORBmatcher.h:76-77, src/ORBmatcher.cc:1212-1402
+    int SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12, std::vector<std::pair<size_t, size_t>> &vMatchedPairs,
+                               const bool bOnlyStereo, std::vector<cv::Mat> &vMatchedPoints);
 
     // Search matches between MapPoints seen in KF1 and KF2 transforming by a Sim3 [s12*R12|t12]
     // In the stereo and RGB-D case, s12=1                                      include/ORBmatcher.h:82, src/ORBmatcher.cc:1739-1963

@@ -4,6 +4,7 @@
 //   SearchByProjection(KeyFrame*, Scw, vpPoints, vpPointsKFs, vpMatched, vpMatchedKF, th, ratioHamming)  :593-708 LoopClosing (place recognition)
 //   SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12)                                 :827-967                      LoopClosing
 //   SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo, bCoarse)   :969-1210                     LocalMapping::CreateNewMapPoints
+//   SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo, vMatchedPoints)   :1212-1402              (no caller)
 //   SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th)                       :1739-1963                    LoopClosing
 //   Fuse(pKF, vpMapPoints, th, bRight)                                             :1403-1613                    LocalMapping::SearchInNeighbors
 //   Fuse(pKF, Scw, vpPoints, th, vpReplacePoint)                                   :1615-1737                    LoopClosing
@@ -339,6 +340,60 @@ int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F
     for (int i = 0; i < n1; i++) {                                                    // :1196-1202
         if (m12[i] < 0) continue;
         vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)m12[i]));
+    }
+    return nmatches;
+}
+
+// The overload that returns the triangulated points (:1212-1402).  F12 and bOnlyStereo are not read by the reference's body either
+// (the epipole it computes at :1220-1224 is never used); the candidate test is pCamera1->matchAndtriangulate with the absolute
+// poses GetPose() / GetRightPose() of the cameras the two keypoints belong to.
+int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12, std::vector<std::pair<size_t, size_t>> &vMatchedPairs,
+                                       const bool bOnlyStereo, std::vector<cv::Mat> &vMatchedPoints)
+{
+    (void)F12; (void)bOnlyStereo;
+    orbhip_tri_pair_general g;
+    orbhip_tri_pair_poses P;
+    memset(&g, 0, sizeof(g)); memset(&P, 0, sizeof(P));
+    camera_params(pKF1->mpCamera, g.cam1[0], g.cam1_type[0]);
+    camera_params(pKF2->mpCamera, g.cam2[0], g.cam2_type[0]);
+    auto rows = [](const cv::Mat &T, float (&o)[12]) { for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) o[4 * i + j] = T.at<float>(i, j); };
+    rows(pKF1->GetPose(), P.Tcw1[0]); rows(pKF2->GetPose(), P.Tcw2[0]);                 // :1311, :1318
+    if (pKF1->NLeft != -1) { camera_params(pKF1->mpCamera2, g.cam1[1], g.cam1_type[1]); rows(pKF1->GetRightPose(), P.Tcw1[1]); }   // :1308-1309
+    if (pKF2->NLeft != -1) { camera_params(pKF2->mpCamera2, g.cam2[1], g.cam2_type[1]); rows(pKF2->GetRightPose(), P.Tcw2[1]); }   // :1315-1316
+    g.nleft1 = pKF1->NLeft; g.nleft2 = pKF2->NLeft;
+
+    const int n1 = pKF1->N, n2 = pKF2->N;
+    auto keys = [](KeyFrame *pKF) {                                                   // :1267-1269, :1300-1302
+        if (pKF->NLeft == -1) return pKF->mvKeysUn;
+        std::vector<cv::KeyPoint> k(pKF->mvKeys.begin(), pKF->mvKeys.begin() + pKF->NLeft);
+        k.insert(k.end(), pKF->mvKeysRight.begin(), pKF->mvKeysRight.end());
+        return k;
+    };
+    const std::vector<cv::KeyPoint> k1 = keys(pKF1), k2 = keys(pKF2);
+    std::vector<int32_t> nid1(n1 > 0 ? n1 : 1, -1);
+    for (const auto &kv : pKF1->mFeatVec) for (unsigned int i : kv.second) if ((int)i < n1) nid1[i] = (int32_t)kv.first;
+    std::vector<int32_t> i2, s2, f2;
+    flatten(pKF2->mFeatVec, i2, s2, f2);
+    std::vector<uint8_t> mp1(n1 > 0 ? n1 : 1, 0), mp2(n2 > 0 ? n2 : 1, 0);
+    for (int i = 0; i < n1; i++) mp1[i] = pKF1->GetMapPoint(i) ? 1 : 0;               // :1261-1265
+    for (int i = 0; i < n2; i++) mp2[i] = pKF2->GetMapPoint(i) ? 1 : 0;               // :1286-1290
+    std::vector<int32_t> m12(n1 > 0 ? n1 : 1, -1);
+    std::vector<float> pts(3 * (size_t)(n1 > 0 ? n1 : 1), 0.f);
+    int32_t nmatches = 0;
+    const int nlevels = (int)pKF2->mvLevelSigma2.size();
+    const int rc = orbhip_match_and_triangulate_host(thread_ctx(), nid1.data(), mp1.data(), (const orbhip_keypoint *)k1.data(), pKF1->mDescriptors.ptr<uint8_t>(), n1,
+                                                     i2.data(), s2.data(), f2.data(), (int)i2.size(), mp2.data(), (const orbhip_keypoint *)k2.data(),
+                                                     pKF2->mDescriptors.ptr<uint8_t>(), n2, &g, &P, pKF1->mvLevelSigma2.data(), pKF2->mvLevelSigma2.data(), nlevels,
+                                                     mbCheckOrientation ? 1 : 0, m12.data(), pts.data(), &nmatches);
+    vMatchedPairs.clear();
+    if (rc != ORBHIP_OK) { fprintf(stderr, "ORBmatcher (HIP): SearchForTriangulation (points): %d (%s)\n", rc, orbhip_last_error()); return 0; }
+    vMatchedPairs.reserve(nmatches);
+    for (int i = 0; i < n1; i++) {                                                    // :1391-1399 (vMatchedPoints is appended to, not cleared)
+        if (m12[i] < 0) continue;
+        vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)m12[i]));
+        cv::Mat x3D(3, 1, CV_32F);
+        for (int k = 0; k < 3; k++) x3D.at<float>(k) = pts[3 * (size_t)i + k];
+        vMatchedPoints.push_back(x3D);
     }
     return nmatches;
 }

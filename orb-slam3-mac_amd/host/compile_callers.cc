@@ -97,6 +97,9 @@ int local_mapping_calls(CallerState &S, KeyFrame *pKF2, cv::Mat F12, vector<KeyF
         bool bCoarse = false;
         matcher.SearchForTriangulation(mpCurrentKeyFrame, pKF2, F12, vMatchedIndices, false, bCoarse);
         total += vMatchedIndices.size();
+        vector<cv::Mat> vMatchedPoints;                        // the second overload (include/ORBmatcher.h:76-77): declared, never called in the reference
+        matcher.SearchForTriangulation(mpCurrentKeyFrame, pKF2, F12, vMatchedIndices, false, vMatchedPoints);
+        total += vMatchedPoints.size();
     }
     {   // LocalMapping::SearchInNeighbors, src/LocalMapping.cc:781-789, 816-817
         ORBmatcher matcher;

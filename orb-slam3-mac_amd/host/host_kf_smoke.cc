@@ -213,6 +213,20 @@ int kf_smoke(const char *in, const char *out)
         for (auto &p : vMatchedIndices) { pr.push_back((int32_t)p.first); pr.push_back((int32_t)p.second); }
         O.one("trio_n", n); O.ints("trio_pairs", pr);
     }
+    {   // ---- SearchForTriangulation(pKF1, pKF2, F12, vMatchedIndices, bOnlyStereo, vMatchedPoints): the overload that returns the points
+        for (int ori = 0; ori < 2; ori++) {
+            std::unique_ptr<World> W = build(S);
+            std::vector<std::pair<size_t, size_t>> vMatchedIndices;
+            std::vector<cv::Mat> vMatchedPoints;
+            ORBmatcher matcher(0.6, ori != 0);
+            const int n = matcher.SearchForTriangulation(W->kf[0].get(), W->kf[1].get(), mat_from(S.F("F12"), 3, 3), vMatchedIndices, true, vMatchedPoints);
+            std::vector<int32_t> pr;
+            std::vector<float> pt;
+            for (auto &p : vMatchedIndices) { pr.push_back((int32_t)p.first); pr.push_back((int32_t)p.second); }
+            for (auto &x : vMatchedPoints) for (int k = 0; k < 3; k++) pt.push_back(x.at<float>(k));
+            O.one(ori ? "trpo_n" : "trp_n", n); O.ints(ori ? "trpo_pairs" : "trp_pairs", pr); O.floats(ori ? "trpo_points" : "trp_points", pt);
+        }
+    }
     if (!rig) {   // ---- SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist): Tracking::Relocalization
         std::unique_ptr<World> W = build(S);
         Frame F;

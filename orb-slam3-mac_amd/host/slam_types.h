@@ -206,6 +206,13 @@ public:
         }
         return t;
     }
+    cv::Mat GetRightPose()                                  // Trw = [Rrw | trw], 3x4 (KeyFrame.cc:1176-1192: the same products)
+    {
+        const cv::Mat R = GetRightRotation(), t = GetRightTranslation();
+        cv::Mat T(3, 4, CV_32F);
+        for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) T.at<float>(i, j) = R.at<float>(i, j); T.at<float>(i, 3) = t.at<float>(i); }
+        return T;
+    }
     cv::Mat GetRightCameraCenter()                          // twr = Rwl * tlr + twl (KeyFrame.cc:1232-1241)
     {
         const cv::Mat Ow = GetCameraCenter();

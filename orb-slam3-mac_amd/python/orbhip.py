@@ -767,6 +767,21 @@ def search_for_triangulation_general_device(ctx, kf1, kf2, d_pair, pairs, max_no
          "orbhip_search_for_triangulation_general_device")
 
 
+TRI_POSES_DTYPE = np.dtype([("Tcw1", "<f4", (2, 12)), ("Tcw2", "<f4", (2, 12))])
+lib.orbhip_match_and_triangulate_device.argtypes = [vp] * 16 + [ci, ci, ci, sz, vp, vp, ci, ci, vp, vp, vp]
+
+
+def match_and_triangulate_device(ctx, kf1, kf2, d_pair, d_poses, pairs, max_nodes, max_n, kp_stride, level_sigma2_1, level_sigma2_2, check_ori,
+                                 d_matches12, d_points12, d_nmatches):
+    """ORBmatcher::SearchForTriangulation(..., vMatchedPoints) (ORBmatcher.cc:1212-1402), batched.  kf1 = [nid1, has_mp1, kp1, desc1, n1],
+    kf2 = [node_ids2, node_start2, feat2, nnodes2, has_mp2, kp2, desc2, n2] device pointers; d_poses: [pairs] TRI_POSES_DTYPE records."""
+    a = [np.ascontiguousarray(x, np.float32) for x in (level_sigma2_1, level_sigma2_2)]
+    assert len(a[0]) == len(a[1]) and len(kf1) == 5 and len(kf2) == 8
+    _chk(lib.orbhip_match_and_triangulate_device(ctx.h, *kf1, *kf2, d_pair, d_poses, pairs, max_nodes, max_n, kp_stride, a[0].ctypes.data,
+                                                 a[1].ctypes.data, len(a[0]), 1 if check_ori else 0, d_matches12, d_points12, d_nmatches),
+         "orbhip_match_and_triangulate_device")
+
+
 lib.orbhip_search_by_bow_device.argtypes = [vp] * 15 + [ci, ci, ci, sz, cf, ci, vp, vp]
 
 

@@ -374,6 +374,11 @@ TRI_GENERAL_DTYPE = np.dtype([("R12", "<f4", (4, 9)), ("t12", "<f4", (4, 3)), ("
                               ("only_stereo", "<i4"), ("coarse", "<i4")])
 lib.orc_search_for_triangulation_general.restype = ci
 lib.orc_search_for_triangulation_general.argtypes = [vp] * 5 + [ci] + [vp] * 3 + [ci] + [vp] * 4 + [vp, vp, vp, vp, ci, vp]
+TRI_POSES_DTYPE = np.dtype([("Tcw1", "<f4", (2, 12)), ("Tcw2", "<f4", (2, 12))])
+lib.orc_search_for_triangulation_points.restype = ci
+lib.orc_search_for_triangulation_points.argtypes = [vp] * 4 + [ci] + [vp] * 3 + [ci] + [vp] * 3 + [vp, vp, vp, vp, ci, vp, vp]
+lib.orc_kb8_match_and_triangulate.restype = ci
+lib.orc_kb8_match_and_triangulate.argtypes = [vp, ci, vp, cf, cf, cf, cf, vp, vp, cf, cf, vp]
 lib.orc_kb8_triangulate_matches.restype = cf
 lib.orc_kb8_triangulate_matches.argtypes = [ci, vp, ci, vp, cf, cf, cf, cf, vp, vp, cf, cf, vp]
 lib.orc_camera_project_f.argtypes = [ci, vp, vp, vp]
@@ -492,7 +497,39 @@ def make_tri_general_case(rng, n1, n2, mode, n_nodes=60, only_stereo=False, coar
     ur2 = np.where(rng.random(n2) < sf, kp2["x"] - 5, -1).astype(np.float32)
     return dict(kp1=kp1, d1=d1, nid1=nid1, mp1=(rng.random(n1) < 0.3).astype(np.uint8), ur1=ur1,
                 kp2=kp2, d2=d2, nid2=nid2, mp2=(rng.random(n2) < 0.2).astype(np.uint8), ur2=ur2, geom=g, scale=scale, sigma2=sigma2,
-                sigma2_1=(sigma2 * np.float32(1.0)).astype(np.float32), mode=mode)
+                sigma2_1=(sigma2 * np.float32(1.0)).astype(np.float32), mode=mode, rel=(Rll, tll, Rrl, trl))
+
+
+def tri_case_poses(c, seed=0):
+    """Absolute poses for a make_tri_general_case scene (the overload that returns the points works with GetPose() / GetRightPose(),
+    ORBmatcher.cc:1307-1321): KF2's left camera is placed at an arbitrary world pose, the others follow from the case's relative
+    poses.  Returns one TRI_POSES_DTYPE record (rows 0..2 of Tcw, row-major) -- [0] left, [1] right (zeros without a second camera)."""
+    Rll, tll, Rrl, trl = c["rel"]
+    rng = np.random.default_rng(4000 + seed)
+    R2w = _rot(rng.normal(size=3), rng.uniform(0.2, 1.0)); t2w = rng.uniform(-2, 2, 3)
+    R1w = Rll @ R2w; t1w = Rll @ t2w + tll                                    # X1l = Rll X2l + tll
+    P = np.zeros(1, TRI_POSES_DTYPE)[0]
+    rig = c["geom"]["nleft1"] != -1
+    for name, (R, t) in (("Tcw1", (R1w, t1w)), ("Tcw2", (R2w, t2w))):
+        P[name][0] = np.concatenate([R, t[:, None]], 1).astype(np.float32).reshape(12)
+        if rig:
+            P[name][1] = np.concatenate([Rrl @ R, (Rrl @ t + trl)[:, None]], 1).astype(np.float32).reshape(12)
+    return P
+
+
+def search_for_triangulation_points(c, poses, check_ori=True):
+    """ORBmatcher::SearchForTriangulation(..., vMatchedPoints) (ORBmatcher.cc:1212-1402) on a make_tri_general_case scene.
+    Returns (nmatches, matches12 [n1], points12 [n1][3])."""
+    i2, s2, f2 = feature_vector_csr(c["nid2"])
+    n1 = len(c["kp1"])
+    m = np.zeros(max(n1, 1), np.int32); pts = np.zeros((max(n1, 1), 3), np.float32)
+    a = {k: np.ascontiguousarray(c[k]) for k in ("nid1", "mp1", "kp1", "d1", "mp2", "kp2", "d2", "sigma2", "sigma2_1")}
+    g = np.ascontiguousarray(np.array([c["geom"]], TRI_GENERAL_DTYPE)); P = np.ascontiguousarray(np.array([poses], TRI_POSES_DTYPE))
+    n = lib.orc_search_for_triangulation_points(a["nid1"].ctypes.data, a["mp1"].ctypes.data, a["kp1"].ctypes.data, a["d1"].ctypes.data, n1,
+                                                i2.ctypes.data, s2.ctypes.data, f2.ctypes.data, len(i2), a["mp2"].ctypes.data, a["kp2"].ctypes.data,
+                                                a["d2"].ctypes.data, g.ctypes.data, P.ctypes.data, a["sigma2_1"].ctypes.data, a["sigma2"].ctypes.data,
+                                                1 if check_ori else 0, m.ctypes.data, pts.ctypes.data)
+    return n, m[:n1], pts[:n1]
 
 
 def search_for_triangulation_general(c, check_ori=True):

@@ -479,6 +479,9 @@ def test_keyframe_matchers_pinhole(tmp_path, seed, n1, n2, npts):
         pairs = np.stack([np.flatnonzero(m >= 0), m[m >= 0]], 1).reshape(-1).astype(np.int32)
         assert nm > 20 and out[key + "_n"][0] == nm, (key, nm, out[key + "_n"])
         np.testing.assert_array_equal(out[key + "_pairs"], pairs)
+    # the overload that returns the points: Pinhole::matchAndtriangulate is { return false; } (include/CameraModels/Pinhole.h:91-94)
+    for key in ("trp", "trpo"):
+        assert out[key + "_n"][0] == 0 and len(out[key + "_pairs"]) == 0 and len(out[key + "_points"]) == 0
 
     # ---- SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist)
     Rc, tc, Owc = kf_pose_parts(W["Tcw"][1])
@@ -558,6 +561,26 @@ def test_keyframe_matchers_fisheye_rig(tmp_path):
         np.testing.assert_array_equal(out[key + "_pairs"], pairs)
         i1 = np.flatnonzero(m >= 0)
         combos |= set((2 * (i1 >= kf1["nleft"]) + (m[i1] >= kf2["nleft"])).tolist())
+    assert combos == {0, 1, 2, 3}
+    # SearchForTriangulation(..., vMatchedPoints) (ORBmatcher.cc:1212-1402): absolute poses GetPose() / GetRightPose() per camera, bOnlyStereo (passed as
+    # true by the smoke) not read; pairs AND world points bit-exact
+    P = np.zeros(1, om.TRI_POSES_DTYPE)[0]
+    for k, name in enumerate(("Tcw1", "Tcw2")):
+        P[name][0] = W["Tcw"][k][:3, :].reshape(12)
+        P[name][1] = np.concatenate([Rr[k], tr[k].reshape(3, 1)], 1).reshape(12)
+    combos = set()
+    for key, ori in (("trp", False), ("trpo", True)):
+        nm, m, pts = om.search_for_triangulation_points(dict(base, geom=g), P, ori)
+        pairs = np.stack([np.flatnonzero(m >= 0), m[m >= 0]], 1).reshape(-1).astype(np.int32)
+        assert nm > 15 and out[key + "_n"][0] == nm, (key, nm, out[key + "_n"])
+        np.testing.assert_array_equal(out[key + "_pairs"], pairs)
+        np.testing.assert_array_equal(np.asarray(out[key + "_points"], F32).view(np.uint32), pts[m >= 0].reshape(-1).view(np.uint32))
+        i1 = np.flatnonzero(m >= 0)
+        combos |= set((2 * (i1 >= kf1["nleft"]) + (m[i1] >= kf2["nleft"])).tolist())
+        # the points are the world's: each lies within a few centimetres of a map point position or at least in front of both left cameras
+        for k in range(2):
+            Xc = pts[m >= 0].astype(np.float64) @ W["Tcw"][k][:3, :3].astype(np.float64).T + W["Tcw"][k][:3, 3].astype(np.float64)
+            assert (Xc[:, 2] > 0).all()
     assert combos == {0, 1, 2, 3}
 
 

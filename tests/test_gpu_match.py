@@ -613,6 +613,74 @@ def test_search_for_triangulation_parity(gpu_ctx, stereo_frac, only_stereo, coar
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode,check_ori,big", [("kb8", True, False), ("rig", True, False), ("rig", False, False), ("pinhole", True, False), ("rig", True, True)])
+def test_search_for_triangulation_points_parity(gpu_ctx, mode, check_ori, big):
+    """The SearchForTriangulation overload that returns the triangulated points (ORBmatcher.cc:1212-1402; KannalaBrandt8::matchAndtriangulate,
+    KannalaBrandt8.cpp:240-332): matches AND world points bit-exact vs the oracle on fisheye mono keyframes and fisheye rigs (all four camera
+    pairs); a Pinhole first camera matches nothing (Pinhole.h:91-94); has_mp / rotation-histogram gates as the first overload; the points
+    sit on the scene (they re-project into both keyframes).  big: keyframes above 4096 keypoints take the global-memory variant."""
+    import torch
+    import orbhip
+    import oracle_match_bind as om
+    rng = np.random.default_rng(1291)
+    sizes = ((0, 20, 10), (30, 0, 10), (200, 260, 40), (1000, 950, 100), (2000, 2048, 300), (600, 1500, 900)) if not big else ((5200, 4700, 800), (300, 5000, 100))
+    cases = [om.make_tri_general_case(rng, a, b, mode, nn, True, False) for a, b, nn in sizes]       # only_stereo set: must be ignored
+    poses = [om.tri_case_poses(c, i) for i, c in enumerate(cases)]
+    P, MN, MNODE = len(cases), (5248 if big else 2048), 2048
+    arr = dict(nid1=np.zeros((P, MN), np.int32), mp1=np.zeros((P, MN), np.uint8), kp1=np.zeros((P, MN), orbhip.KP_DTYPE),
+               d1=np.zeros((P, MN, 32), np.uint8), n1=np.zeros(P, np.int32),
+               i2=np.zeros((P, MNODE), np.int32), s2=np.zeros((P, MNODE + 1), np.int32), f2=np.zeros((P, MN), np.int32), nn2=np.zeros(P, np.int32),
+               mp2=np.zeros((P, MN), np.uint8), kp2=np.zeros((P, MN), orbhip.KP_DTYPE), d2=np.zeros((P, MN, 32), np.uint8),
+               n2=np.zeros(P, np.int32), geom=np.zeros(P, orbhip.TRI_GENERAL_DTYPE), poses=np.zeros(P, orbhip.TRI_POSES_DTYPE))
+    assert orbhip.TRI_POSES_DTYPE == om.TRI_POSES_DTYPE
+    for p, c in enumerate(cases):
+        a, b = len(c["kp1"]), len(c["kp2"])
+        i2, s2, f2 = om.feature_vector_csr(c["nid2"])
+        arr["nid1"][p, :a] = c["nid1"]; arr["mp1"][p, :a] = c["mp1"]; arr["kp1"][p, :a] = c["kp1"]; arr["d1"][p, :a] = c["d1"]; arr["n1"][p] = a
+        arr["i2"][p, :len(i2)] = i2; arr["s2"][p, :len(s2)] = s2; arr["f2"][p, :len(f2)] = f2; arr["nn2"][p] = len(i2)
+        arr["mp2"][p, :b] = c["mp2"]; arr["kp2"][p, :b] = c["kp2"]; arr["d2"][p, :b] = c["d2"]; arr["n2"][p] = b
+        arr["geom"][p] = c["geom"]; arr["poses"][p] = poses[p]
+    t = {k: torch.from_numpy(v.view(np.uint8) if v.dtype.fields else v).cuda() for k, v in arr.items()}
+    m12 = torch.full((P, MN), -9, dtype=torch.int32, device="cuda"); nm = torch.full((P,), -9, dtype=torch.int32, device="cuda")
+    pts = torch.full((P, MN, 3), -7.0, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    kf1 = [t["nid1"].data_ptr(), t["mp1"].data_ptr(), t["kp1"].data_ptr(), t["d1"].data_ptr(), t["n1"].data_ptr()]
+    kf2 = [t["i2"].data_ptr(), t["s2"].data_ptr(), t["f2"].data_ptr(), t["nn2"].data_ptr(), t["mp2"].data_ptr(), t["kp2"].data_ptr(), t["d2"].data_ptr(),
+           t["n2"].data_ptr()]
+    orbhip.match_and_triangulate_device(gpu_ctx, kf1, kf2, t["geom"].data_ptr(), t["poses"].data_ptr(), P, MNODE, MN, MN, cases[0]["sigma2_1"],
+                                        cases[0]["sigma2"], check_ori, m12.data_ptr(), pts.data_ptr(), nm.data_ptr())
+    gpu_ctx.check_status()
+    m12h, nmh, ptsh = m12.cpu().numpy(), nm.cpu().numpy(), pts.cpu().numpy()
+    tot = 0
+    for p, c in enumerate(cases):
+        n_ref, m_ref, p_ref = om.search_for_triangulation_points(c, poses[p], check_ori)
+        assert nmh[p] == n_ref, (p, nmh[p], n_ref)
+        np.testing.assert_array_equal(m12h[p, :len(m_ref)], m_ref)
+        np.testing.assert_array_equal(ptsh[p, :len(m_ref)].view(np.uint32), p_ref.view(np.uint32))
+        tot += n_ref
+        # the kept points are the scene's: in front of KF2's left camera and re-projecting onto the matched KF1 keypoint
+        keep = np.flatnonzero(m_ref >= 0)
+        if len(keep):
+            T1 = poses[p]["Tcw1"].reshape(2, 3, 4).astype(np.float64)
+            right1 = (c["geom"]["nleft1"] != -1) & (keep >= c["geom"]["nleft1"])
+            X = p_ref[keep].astype(np.float64)
+            Xc = np.einsum("kij,kj->ki", T1[right1.astype(int), :, :3], X) + T1[right1.astype(int), :, 3]
+            assert (Xc[:, 2] > 0).all()
+            cam = np.where(right1[:, None], c["geom"]["cam1"][1][None], c["geom"]["cam1"][0][None]).astype(np.float64)
+            uv = np.stack([om.kb8_project_np((1, cam[i]), Xc[i]) for i in range(len(keep))])
+            err2 = ((uv - np.stack([c["kp1"]["x"][keep], c["kp1"]["y"][keep]], 1)) ** 2).sum(1)
+            assert (err2 <= 5.991 * c["sigma2_1"][c["kp1"]["octave"][keep]] * 1.001 + 1e-3).all()
+    if mode == "pinhole":
+        assert tot == 0
+    else:
+        assert tot > 300
+    if mode == "rig" and not big:                             # all four camera pairs produced matches
+        c = cases[4]; m = m12h[4, :len(c["kp1"])]; i1 = np.flatnonzero(m >= 0)
+        combo = 2 * (i1 >= c["geom"]["nleft1"]) + (m[i1] >= c["geom"]["nleft2"])
+        assert set(combo.tolist()) == {0, 1, 2, 3}
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode,only_stereo,coarse,check_ori", [("pinhole", False, False, True), ("pinhole", True, False, False), ("kb8", False, False, True),
                                                                 ("kb8", False, True, True), ("rig", False, False, True), ("rig", False, False, False),
                                                                 ("rig", True, False, True)])

@@ -1226,6 +1226,67 @@ def test_search_for_triangulation_general_oracle_reduces_to_the_pinhole_form():
     assert om.search_for_triangulation_general(c, True)[0] == 0
 
 
+def test_search_for_triangulation_points_oracle_against_the_scene_and_the_first_overload():
+    """The overload that returns the points (ORBmatcher.cc:1212-1402), restated: (1) with Tcw1 = [I | 0] and Tcw2 = the inverse of the
+    first overload's (R12, t12), KannalaBrandt8::matchAndtriangulate is TriangulateMatches without the z1 > 1e-4 test -- same accept /
+    reject and the same x3D bit for bit; (2) on a scene with absolute poses the kept points are the scene's world points (a few cm off
+    at most: the keypoints carry sub-pixel jitter); (3) a Pinhole first camera matches nothing; bOnlyStereo / the epipole are not read."""
+    import oracle_match_bind as om
+    rng = np.random.default_rng(77)
+    c = om.make_tri_general_case(rng, 900, 1000, "kb8")
+    g = c["geom"]
+    R12 = g["R12"][0].reshape(3, 3); t12 = g["t12"][0]
+    R21 = np.ascontiguousarray(R12.T)
+    t21 = np.array([np.float32(-1.0 * (float(R21[i, 0]) * float(t12[0]) + float(R21[i, 1]) * float(t12[1]) + float(R21[i, 2]) * float(t12[2]))) for i in range(3)], np.float32)
+    T1 = np.concatenate([np.eye(3, dtype=np.float32), np.zeros((3, 1), np.float32)], 1).reshape(12)
+    T2 = np.concatenate([R21, t21[:, None]], 1).astype(np.float32).reshape(12)
+    cam = np.ascontiguousarray(g["cam1"][0]); x = np.zeros(3, np.float32)
+    acc = 0
+    for i2 in range(0, 1000):
+        i1 = int(rng.integers(0, 900))
+        p1 = (float(c["kp1"]["x"][i1]), float(c["kp1"]["y"][i1])); p2 = (float(c["kp2"]["x"][i2]), float(c["kp2"]["y"][i2]))
+        s1 = float(c["sigma2_1"][c["kp1"]["octave"][i1]]); s2 = float(c["sigma2"][c["kp2"]["octave"][i2]])
+        ok = om.lib.orc_kb8_match_and_triangulate(cam.ctypes.data, 1, cam.ctypes.data, p1[0], p1[1], p2[0], p2[1], T1.ctypes.data, T2.ctypes.data, s1, s2, x.ctypes.data)
+        z, x_ref = om.kb8_triangulate_matches(1, cam, 1, cam, p1, p2, R12, t12, s1, s2)
+        assert bool(ok) == (z > 0), (i1, i2, ok, z)
+        if ok:
+            assert np.array_equal(x.view(np.uint32), x_ref.view(np.uint32)); acc += 1
+    # matched reprojections among random pairs are rare: walk true pairs as well
+    n, m = om.search_for_triangulation_general(c, False)
+    for i1 in np.flatnonzero(m >= 0)[:200]:
+        i2 = int(m[i1])
+        p1 = (float(c["kp1"]["x"][i1]), float(c["kp1"]["y"][i1])); p2 = (float(c["kp2"]["x"][i2]), float(c["kp2"]["y"][i2]))
+        s1 = float(c["sigma2_1"][c["kp1"]["octave"][i1]]); s2 = float(c["sigma2"][c["kp2"]["octave"][i2]])
+        ok = om.lib.orc_kb8_match_and_triangulate(cam.ctypes.data, 1, cam.ctypes.data, p1[0], p1[1], p2[0], p2[1], T1.ctypes.data, T2.ctypes.data, s1, s2, x.ctypes.data)
+        z, x_ref = om.kb8_triangulate_matches(1, cam, 1, cam, p1, p2, R12, t12, s1, s2)
+        assert ok and z > 0 and np.array_equal(x.view(np.uint32), x_ref.view(np.uint32)); acc += 1
+    assert acc > 100
+    # (2) absolute poses: the kept points re-project onto the KF1 keypoint within the gate and lie in front of both cameras
+    for mode in ("kb8", "rig"):
+        c = om.make_tri_general_case(rng, 900, 1000, mode, only_stereo=True)
+        P = om.tri_case_poses(c, 3)
+        for ori in (True, False):
+            n, m, pts = om.search_for_triangulation_points(c, P, ori)
+            assert n == (m >= 0).sum() and n > 150
+            gm = c["geom"]
+            for i1 in np.flatnonzero(m >= 0):
+                b1 = int(gm["nleft1"] != -1 and i1 >= gm["nleft1"]); b2 = int(gm["nleft2"] != -1 and m[i1] >= gm["nleft2"])
+                for T, camp, kp, idx, sg in ((P["Tcw1"][b1], gm["cam1"][b1], c["kp1"], i1, c["sigma2_1"]), (P["Tcw2"][b2], gm["cam2"][b2], c["kp2"], m[i1], c["sigma2"])):
+                    T = T.reshape(3, 4).astype(np.float64)
+                    Xc = T[:, :3] @ pts[i1].astype(np.float64) + T[:, 3]
+                    assert Xc[2] > 0
+                    uv = om.kb8_project_np((1, camp.astype(np.float64)), Xc)
+                    assert ((uv - (kp["x"][idx], kp["y"][idx])) ** 2).sum() <= 5.991 * sg[kp["octave"][idx]] * 1.001 + 1e-3
+            assert (pts[m < 0] == 0).all() or ori            # only rotation-histogram rejects keep a point (vMatchesPoints12 is not cleared)
+        # the same walk with only_stereo cleared and the epipole moved: nothing changes
+        c2 = dict(c); g2 = c["geom"].copy(); g2["only_stereo"] = 0; g2["ep_x"] += 300; c2["geom"] = g2
+        assert np.array_equal(om.search_for_triangulation_points(c2, P, True)[1], om.search_for_triangulation_points(c, P, True)[1])
+    # (3)
+    c = om.make_tri_general_case(rng, 400, 400, "pinhole")
+    n, m, pts = om.search_for_triangulation_points(c, om.tri_case_poses(c, 4), True)
+    assert n == 0 and (m == -1).all() and (pts == 0).all()
+
+
 def _dense_numpy_ba_model(g, p, schedule):
     """Optimizer::LocalBundleAdjustment's optimisation (Optimizer.cc:2046-2122: optimize(5), then optimize(10) on the unchanged graph) on
     the vendored Levenberg-Marquardt (optimization_algorithm_levenberg.cpp:61-194), sharing no code with the oracle: numpy only, NUMERIC
