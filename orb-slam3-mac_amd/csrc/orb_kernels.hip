@@ -400,6 +400,21 @@ __device__ __forceinline__ void fc_issue_loads(const CELL &C, int lane, uint4 (&
     }
 }
 
+#ifdef FC_PROF
+// debug build only (make EXTRA=-DFC_PROF): wave-cycles of k_fast_cells by phase, summed over all waves -- stage (load wait, LDS writes, next cell's
+// geometry and loads) / sync / necessary test / arc scores / NMS + emission / tail; [6] cells, [7] whole kernel; [8] LDS writes of the stage,
+// [9] next cell's geometry, [10] issue of its loads (the three parts of [0], which is then only the rest)
+__device__ unsigned long long g_fc_prof[12];
+extern "C" int orbhip_debug_fc_prof(unsigned long long *out8, int reset)
+{
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_fc_prof), 96) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[12] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_fc_prof), z, 96) != hipSuccess) return -1; }
+    return 0;
+}
+#define FC_T(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); fc_acc[i] += t_ - fc_prev; fc_prev = t_; } while (0)
+#else
+#define FC_T(i) do { } while (0)
+#endif
 // One wave per workgroup, persistent over a contiguous range of cells (frame-major, then level, then row-major): the next
 // cell's staging loads are in flight while the current cell is processed.  LDS (private to the wave, no barriers): pair tile
 // PT [rows][PITCH = 8 NCH], score tile SC [srows + 2][SPITCH] (one guard row / pair all around), queue Q.
@@ -445,6 +460,10 @@ __global__ __launch_bounds__(64) void k_fast_cells(FastParams P)
     const int lo_th = min(ini_th, min_th);
 #define FC_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_s_waitcnt(0xc07f); \
                             __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#ifdef FC_PROF
+    unsigned long long fc_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, fc_prev = __builtin_readcyclecounter();
+    const unsigned long long fc_t0 = fc_prev;
+#endif
     for (bool more = true; more;) {
         const int dw = C.dw, dh = C.dh;
         const int npb = (dw + 1) >> 1;                             // band pixel pairs per row
@@ -472,6 +491,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(FastParams P)
             uint4 *scz = reinterpret_cast<uint4 *>(SC);
             for (int i = lane; i < ((dh + 2) * SPITCH + 7) / 8; i += 64) scz[i] = make_uint4(0u, 0u, 0u, 0u);
         }
+        FC_T(8);
         // ---- next cell (the next one of the chunk, or the first one of this wave's next chunk): its loads stay in flight while this one is processed
         FcCell N = C;
         g++;
@@ -486,14 +506,18 @@ __global__ __launch_bounds__(64) void k_fast_cells(FastParams P)
             more = ch < nchunks;
             if (more) { g = ch * chunk; g_end = min(g + chunk, total_cells); decode(g, N); }
         }
+        FC_T(9);
         if (more) fc_issue_loads<NCH, NLD>(N, lane, ld);
+        FC_T(10);
         if (dw <= 0) { if (lane == 0) *cnt_out = 0; C = N; continue; }
+        FC_T(0);
         FC_WAVE_SYNC();           // (also: the previous cell's LDS reads are done before this cell's writes -- same wave, program order)
         // Lane layout of the necessary test from the level's nominal cell width (clipped border cells leave lanes idle): tasks per row tpr,
         // rows per trip rpt, two adjacent pairs per lane
         const int tr0 = (int)(__umul24((uint32_t)lane, P.div_magic[tpr]) >> 16), tg = lane - tr0 * tpr;
         const bool lane_rows = tr0 < rptT && 2 * tg < npb, pair1 = 2 * tg + 1 < npb;
         int total = 0;
+        FC_T(1);
         for (int pass = 0; pass < 2; pass++) {
             // ---- (2) necessary test on every band pixel pair at this pass's threshold, rows in order (queue order = cv::FAST order).  No
             // per-pair state is kept: the rare second pass (nothing at iniThFAST, ORBextractor.cc:825-828) runs the test again at minThFAST
@@ -521,6 +545,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(FastParams P)
                 nq1 += __popcll(b0) + __popcll(b1);
             }
             FC_WAVE_SYNC();
+            FC_T(2);
             // ---- (3) dense arc score, one pair per lane
             for (int i0 = 0; i0 < nq1; i0 += 64) {
                 const int i = min(i0 + lane, nq1 - 1);
@@ -533,6 +558,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(FastParams P)
                 }
             }
             FC_WAVE_SYNC();
+            FC_T(3);
             // ---- (4) 3x3 strict NMS on raw scores + threshold gate + ordered emission
             for (int i0 = 0; i0 < nq1; i0 += 64) {
                 const int i = i0 + lane;
@@ -561,13 +587,22 @@ __global__ __launch_bounds__(64) void k_fast_cells(FastParams P)
                 if (keep & 2u) { if (offs < cell_cap) list[offs] = ORB_PACK_KEY(2 * bp + 1 + key_x0, by + key_y0, (sc >> 8) & 0xFFu); }
                 total += __builtin_amdgcn_readlane(inc, 63);
             }
+            FC_T(4);
             if (total > 0 || min_th == ini_th) break;              // vKeysCell not empty at iniThFAST: done
             FC_WAVE_SYNC();                                        // the second pass rewrites Q and SC
         }
         if (total > cell_cap) { if (lane == 0) atomicExch(P.status, ORBHIP_E_CAPACITY); total = cell_cap; }
         if (lane == 0) *cnt_out = (uint32_t)total;
         C = N;
+        FC_T(5);
+#ifdef FC_PROF
+        fc_acc[6]++;
+#endif
     }
+#ifdef FC_PROF
+    fc_acc[7] = __builtin_readcyclecounter() - fc_t0;
+    if (lane == 0) for (int i = 0; i < 12; i++) atomicAdd(&g_fc_prof[i], fc_acc[i]);
+#endif
 #undef FC_WAVE_SYNC
 }
 
