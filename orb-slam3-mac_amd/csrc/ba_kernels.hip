@@ -1723,6 +1723,84 @@ extern "C" void orbhip_ba_batch_destroy(orbhip_ba_batch *b)
 
 // pose_in_system[g] (optional): which poses take part in the reduced system even without an edge in THIS graph -- a sharded
 // batch sees only a slice of the edges but must number the free poses like every other rank.
+// ---------------------------------------------------------------------------------------------------------------- pair lists, built on the device
+// The lists k_ba_schur_big / k_ba_schur_rows walk -- per graph and pair of free poses (i <= j, row-major over the upper triangle) the Hpl
+// blocks of the points both see, in point order -- come from the pose-major edge lists that are uploaded anyway: a wave owns a pair, runs
+// over pose i's edges 64 at a time (they are in point order) and finds each point among pose j's by a lower bound (the first edge of a
+// (point, pose) chain is the one that carries the block).  Same entries in the same order as the host enumeration of round 3/4 -- every
+// summation order downstream is unchanged -- without the 0.5 ms the host spent per 50 x 2000 x 10 window and the 2 MB it uploaded.
+// FILL = 0: entries per pair into big_pair_start; k_ba_pair_scan turns them into starts; FILL = 1: the entries.
+template <int FILL>
+__global__ __launch_bounds__(256) void k_ba_pair_lists(BaBatch B)
+{
+    const BaGraphDev &G = B.gd[blockIdx.y];
+    const int nf = G.nf, npair = nf * (nf + 1) / 2;
+    const int lane = threadIdx.x & 63, pi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pi >= npair) return;
+    int i = 0, j = pi;
+    while (j >= nf - i) { j -= nf - i; i++; }
+    j += i;
+    const int *qs = B.pose_start + G.posestart_off, *pe = B.pose_edges + G.edge_off, *et = B.edge_task + G.edge_off, *ep = B.edge_point + G.edge_off;
+    const int a0 = qs[i], a1 = qs[i + 1], c0 = qs[j], c1 = qs[j + 1];
+    int *pstart = const_cast<int *>(B.big_pair_start) + G.pair_off;
+    int2 *ent = const_cast<int2 *>(B.big_pair_ent) + G.pent_off, *jr = const_cast<int2 *>(B.big_pair_jr) + G.pent_off;
+    int *ptl = const_cast<int *>(B.big_pair_pt) + G.pent_off;
+    int out = FILL ? pstart[pi] : 0, rank = 0;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int p0 = a0; p0 < a1; p0 += 64) {
+        const int p = p0 + lane;
+        int ta = -1, pt = -1;
+        if (p < a1) { const int ea = pe[p]; ta = et[ea]; pt = ep[ea]; }
+        const unsigned long long bb = __ballot(ta >= 0);
+        const int myrank = rank + __popcll(bb & lt);             // place of the block in pose i's own (diagonal) list
+        rank += __popcll(bb);
+        int tc = -1;
+        if (ta >= 0) {
+            if (i == j) tc = ta;
+            else {
+                int lo = c0, hi = c1;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (ep[pe[mid]] < pt) lo = mid + 1; else hi = mid; }
+                if (lo < c1) { const int ec = pe[lo]; if (ep[ec] == pt) tc = et[ec]; }
+            }
+        }
+        const unsigned long long hb = __ballot(tc >= 0);
+        if (FILL && tc >= 0) {
+            const int q = out + __popcll(hb & lt);
+            ent[q] = make_int2(ta, tc); ptl[q] = pt; jr[q] = make_int2(tc, myrank);
+        }
+        out += __popcll(hb);
+    }
+    if (!FILL && lane == 0) pstart[pi] = out;
+}
+// counts -> exclusive starts, one workgroup per graph; entry npair = the graph's total
+__global__ __launch_bounds__(256) void k_ba_pair_scan(BaBatch B)
+{
+    const BaGraphDev &G = B.gd[blockIdx.x];
+    const int npair = G.nf * (G.nf + 1) / 2;
+    int *ps = const_cast<int *>(B.big_pair_start) + G.pair_off;
+    __shared__ int part[256];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int k0 = 0; k0 <= npair; k0 += 256) {
+        const int k = k0 + threadIdx.x;
+        const int v = k < npair ? ps[k] : 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {
+            const int t = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+            __syncthreads();
+            part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const int base = carry;
+        if (k <= npair) ps[k] = base + part[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry = base + part[255];
+        __syncthreads();
+    }
+}
+
 static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_graphs, const double *const *poses, const double *const *points,
                           const std::vector<std::vector<uint8_t>> *pose_in_system, int rank, int world, orbhip_ba_batch **out, bool oneshot = false)
 {
@@ -1740,20 +1818,16 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
     // the host-side lists live in per-thread scratch vectors that keep their capacity from call to call: LocalMapping solves one window
     // per keyframe from the same thread, and fresh multi-megabyte vectors cost more in page faults than in arithmetic
     struct Scratch {
-        std::vector<int> x1off, x2off, hidx, epose, epoint, ptstart, posestart, poseedges, etask, pmpoint, pmtask, enext, pair_start, pair_pt;
+        std::vector<int> x1off, x2off, hidx, epose, epoint, ptstart, posestart, poseedges, etask, pmpoint, pmtask, enext;
         std::vector<uint32_t> ptmask;
         std::vector<int4> gtask, gstage;
         std::vector<uint8_t> pmtype, est, edup;
         std::vector<double> pmis2, pmobs, eobs, eis2;
-        std::vector<int2> pair_ent, pair_jr;
-        struct Tmp { int pi, ea, ec, ra, pt; };
-        std::vector<Tmp> tmp[4];
         void clear()
         {
             x1off.clear(); x2off.clear(); hidx.clear(); epose.clear(); epoint.clear(); ptstart.clear(); posestart.clear(); poseedges.clear(); etask.clear();
-            pmpoint.clear(); pmtask.clear(); enext.clear(); pair_start.clear(); pair_pt.clear(); ptmask.clear(); gtask.clear(); gstage.clear(); pmtype.clear();
-            est.clear(); edup.clear(); pmis2.clear(); pmobs.clear(); eobs.clear(); eis2.clear(); pair_ent.clear(); pair_jr.clear();
-            for (auto &t : tmp) t.clear();
+            pmpoint.clear(); pmtask.clear(); enext.clear(); ptmask.clear(); gtask.clear(); gstage.clear(); pmtype.clear();
+            est.clear(); edup.clear(); pmis2.clear(); pmobs.clear(); eobs.clear(); eis2.clear();
         }
     };
     static thread_local Scratch SC;
@@ -1973,12 +2047,13 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
     b->s_total = s; b->spart_total = sp;
     // big windows: every graph of the batch takes the global-memory path; per graph and pair of free poses (i <= j) the Hpl blocks
     // of the points both see, in point order (the summation order of k_ba_schur_big)
-    std::vector<int> &pair_start = SC.pair_start, &pair_pt = SC.pair_pt; std::vector<int2> &pair_ent = SC.pair_ent, &pair_jr = SC.pair_jr;
     b->max_row_blocks = 0;
     B.big = any_big ? 1 : 0;
     // Schur complement: per-block-pair lists (k_ba_schur_big) by default -- measured faster than the MFMA panel GEMM at every batch
     // size -- the GEMM on request (orbhip_ctx_set_ba_schur_mode(ctx, 2), a property of the context the batch is created on), in the landmark-sharded mode and never for big windows
     const bool pair_lists = any_big || (world == 1 && mode != 2);
+    size_t pair_total_start = 0, pair_total_ent = 0;
+    int max_npair = 0;
     if (dry) fprintf(stderr, "[orbhip ba] create (dry run): per-graph lists %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dry0).count());
     B.pair_schur = pair_lists ? 1 : 0;
     if (pair_lists) {
@@ -1988,82 +2063,21 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
             const orbhip_ba_graph &H = graphs[g];
             const std::vector<int> &lh = g_local_h[g];
             const int nf = D.nf, npair = nf * (nf + 1) / 2;
-            D.pair_off = pair_start.size(); D.pent_off = pair_ent.size();
-            std::vector<int> cnt(npair + 1, 0);
-            auto pidx = [&](int i, int j) { return i * nf - i * (i - 1) / 2 + (j - i); };
+            D.pair_off = pair_total_start; D.pent_off = pair_total_ent;
             const int *et = etask.data() + D.edge_off;
-            // rank of every Hpl block among its pose's blocks in point order = its place in that pose's diagonal list
-            std::vector<int> rank(H.n_edges, 0), seen(nf, 0);
-            for (int a = 0; a < H.n_edges; a++) if (et[a] >= 0) rank[a] = seen[lh[H.edge_pose[a]]]++;
+            // the lists themselves are built on the device (k_ba_pair_lists); the host only needs their sizes -- a point with nb blocks
+            // puts one entry into nb (nb + 1) / 2 lists -- and the longest row of blocks (the LDS the row-owner Schur kernel takes)
+            std::vector<int> seen(nf, 0);
+            size_t tot = 0;
+            for (int e0 = 0; e0 < H.n_edges;) {
+                int e1 = e0, nb = 0;
+                while (e1 < H.n_edges && H.edge_point[e1] == H.edge_point[e0]) { if (et[e1] >= 0) { nb++; seen[lh[H.edge_pose[e1]]]++; } e1++; }
+                tot += (size_t)nb * (nb + 1) / 2;
+                e0 = e1;
+            }
             for (int k = 0; k < nf; k++) b->max_row_blocks = std::max(b->max_row_blocks, seen[k]);
-            // every unordered pair of a point's Hpl blocks once, oriented by hessian index (i <= j; the diagonal pair is (a, a)): one
-            // enumeration into a temporary with a count per pair, a prefix, a scatter (round 3 enumerated every ORDERED pair twice).
-            // The code can cut the points into T contiguous ranges for T host threads (ORBHIP_BA_CREATE_THREADS; ranges are in point
-            // order, so a list's entries stay in point order whatever T) -- not the default, see below.
-            typedef Scratch::Tmp Tmp;
-            static const int t_env = getenv("ORBHIP_BA_CREATE_THREADS") ? atoi(getenv("ORBHIP_BA_CREATE_THREADS")) : 0;
-            const int T = t_env > 0 ? std::min(t_env, 4) : 1;     // measured on the GPU box (one 50 x 2000 x 10 window): create 0.90 ms on one thread, 1.44-1.60 ms on four -- the spawns cost more than the split returns
-            std::vector<Tmp> *tmp = SC.tmp;
-            for (int t = 0; t < 4; t++) tmp[t].clear();
-            std::vector<std::vector<int>> tcnt(T, std::vector<int>(npair, 0));
-            std::vector<int> cut(T + 1, H.n_edges);
-            cut[0] = 0;
-            for (int t = 1; t < T; t++) {                                                     // cut at point boundaries
-                int e = (int)((long long)H.n_edges * t / T);
-                while (e < H.n_edges && e > 0 && H.edge_point[e] == H.edge_point[e - 1]) e++;
-                cut[t] = std::max(e, cut[t - 1]);
-            }
-            auto enumerate = [&](int t) {
-                std::vector<Tmp> &out = tmp[t]; std::vector<int> &c_ = tcnt[t];
-                out.reserve((size_t)(cut[t + 1] - cut[t]) * 6);
-                int blk[1024], nb;
-                for (int e0 = cut[t]; e0 < cut[t + 1];) {
-                    int e1 = e0;
-                    nb = 0;
-                    while (e1 < H.n_edges && H.edge_point[e1] == H.edge_point[e0]) { if (et[e1] >= 0 && nb < 1024) blk[nb++] = e1; e1++; }
-                    for (int x = 0; x < nb; x++) {
-                        const int a = blk[x], i = lh[H.edge_pose[a]];
-                        for (int y = x; y < nb; y++) {
-                            const int c = blk[y], j = lh[H.edge_pose[c]];
-                            if (x != y && i == j) continue;                                  // (twin edges carry no block of their own: never here)
-                            const bool fw = i <= j;
-                            const int ea = fw ? a : c, ec = fw ? c : a, pi = fw ? pidx(i, j) : pidx(j, i);
-                            c_[pi]++;
-                            out.push_back({pi, et[ea], et[ec], rank[ea], H.edge_point[a]});
-                        }
-                    }
-                    e0 = e1;
-                }
-            };
-            {
-                std::vector<std::thread> th;
-                for (int t = 1; t < T; t++) th.emplace_back(enumerate, t);
-                enumerate(0);
-                for (std::thread &x : th) x.join();
-            }
-
-            std::vector<std::vector<int>> tfill(T, std::vector<int>(npair, 0));
-            {
-                int run = 0;
-                for (int k = 0; k < npair; k++) {
-                    cnt[k] = run;
-                    for (int t = 0; t < T; t++) { tfill[t][k] = run; run += tcnt[t][k]; }
-                }
-                cnt[npair] = run;
-            }
-            pair_ent.resize(D.pent_off + cnt[npair]); pair_pt.resize(D.pent_off + cnt[npair]); pair_jr.resize(D.pent_off + cnt[npair]);
-            auto scatter = [&](int t) {
-                std::vector<int> &fill = tfill[t];
-                for (const Tmp &e : tmp[t]) { const size_t q = D.pent_off + fill[e.pi]++; pair_ent[q] = make_int2(e.ea, e.ec); pair_pt[q] = e.pt; pair_jr[q] = make_int2(e.ec, e.ra); }
-            };
-            {
-                std::vector<std::thread> th;
-                for (int t = 1; t < T; t++) th.emplace_back(scatter, t);
-                scatter(0);
-                for (std::thread &x : th) x.join();
-            }
-
-            pair_start.insert(pair_start.end(), cnt.begin(), cnt.end());
+            pair_total_start += (size_t)npair + 1; pair_total_ent += tot;
+            max_npair = std::max(max_npair, npair);
         }
     }
     b->x_need = std::max(std::max(x1, x2), (size_t)3 * n_graphs);
@@ -2078,10 +2092,13 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
     UP(B.edge_is2, eis2); UP(B.edge_stereo, est); UP(B.edge_dup, edup); UP(B.edge_next, enext); UP(B.pt_start, ptstart); UP(B.pose_start, posestart); UP(B.pose_edges, poseedges);
     UP(B.ptmask, ptmask); UP(B.gemm_task, gtask); UP(B.gemm_stage, gstage); UP(B.edge_task, etask); UP(B.x1_off, x1off); UP(B.x2_off, x2off);
     UP(B.pm_point, pmpoint); UP(B.pm_task, pmtask); UP(B.pm_type, pmtype); UP(B.pm_is2, pmis2); UP(B.pm_obs, pmobs);
-    if (pair_lists) { UP(B.big_pair_start, pair_start); UP(B.big_pair_ent, pair_ent); UP(B.big_pair_pt, pair_pt); UP(B.big_pair_jr, pair_jr); }
     if (any_big) {
         AL(B.big_y, double, (size_t)sumF * 6); AL(B.big_d, double, (size_t)sumF * 6); AL(B.big_U, double, (size_t)n_graphs * LD_NB * LD_NB);
         AL(B.big_fail, int, n_graphs);
+    }
+    if (pair_lists) {
+        AL(B.big_pair_start, int, pair_total_start); AL(B.big_pair_ent, int2, std::max<size_t>(pair_total_ent, 1)); AL(B.big_pair_pt, int, std::max<size_t>(pair_total_ent, 1));
+        AL(B.big_pair_jr, int2, std::max<size_t>(pair_total_ent, 1));
     }
     AL(B.st, BaState, n_graphs);
     AL(B.poses, double, (size_t)2 * sumP * 7); AL(B.points, double, (size_t)2 * sumL * 3);
@@ -2112,7 +2129,15 @@ static int ba_create_impl(orbhip_ctx *ctx, const orbhip_ba_graph *graphs, int n_
             if (it.src && it.bytes) memcpy(stage + it.off, it.src, it.bytes);
         }
         // the staging area belongs to the context and the next host-pointer call may reuse it: the copy is waited for here
-        if (hipMemcpyAsync(arena, stage, plan.up_end, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        bool up_ok = hipMemcpyAsync(arena, stage, plan.up_end, hipMemcpyHostToDevice, st) == hipSuccess;
+        if (up_ok && pair_lists && max_npair > 0) {              // the pair lists, from the lists just uploaded (stream order)
+            const dim3 grid((unsigned)((max_npair + 3) / 4), (unsigned)n_graphs);
+            hipLaunchKernelGGL(k_ba_pair_lists<0>, grid, dim3(256), 0, st, B);
+            hipLaunchKernelGGL(k_ba_pair_scan, dim3((unsigned)n_graphs), dim3(256), 0, st, B);
+            hipLaunchKernelGGL(k_ba_pair_lists<1>, grid, dim3(256), 0, st, B);
+            up_ok = hipGetLastError() == hipSuccess;
+        }
+        if (!up_ok || hipStreamSynchronize(st) != hipSuccess) {
             orbhip_ba_batch_destroy(b); g_ba_error = "upload of the graph failed"; return ORBHIP_E_HIP;
         }
         if (oneshot && (b->h_n_active = orbhip_ctx_pinned_word_internal(ctx))) b->ctx_word = true;
