@@ -43,14 +43,25 @@ void orbhip_set_last_error_internal(const char *msg);
 
 #define IBA_KF ORBHIP_IBA_KF
 #define IBA_PRE ORBHIP_IBA_PREINT
-#define IBA_THREADS 1024
+#define IBA_THREADS 512
 #define IBA_WAVES (IBA_THREADS / 64)
-#define IBA_MAXG 16
+#define IBA_STAGE 544          // doubles of LDS a wave of workgroup 0 stages an inertial edge in (9 x 24 Jacobian, its Omega-weighted copy, Omega e at 432, the 9 x 9 information at 448)
+#define IBA_MAXG 32
 #define IBA_KF_CHUNK 256
 #define IBA_PAIR_CHUNK 256
 enum { K_R = 0, K_T = 9, K_V = 12, K_BG = 15, K_BA = 18 };
 enum { P_DT = 0, P_DR = 1, P_DV = 10, P_DP = 13, P_JRG = 16, P_JVG = 25, P_JVA = 34, P_JPG = 43, P_JPA = 52, P_BG = 61, P_BA = 64 };
 
+// Pointers into global memory carry their address space in the TYPE on the device side: the phase functions are not inlined (register
+// pressure) and reach IbaArgs through a pointer, where a plain `double *` loaded from memory is a generic pointer and every access
+// through it a FLAT instruction (1100 of them in the round-3 kernel: slower than global ones, and counted on BOTH wait counters, so that
+// they serialise with the LDS traffic).  gen() hands out the generic pointer the code computes with; the backend's address-space
+// inference sees the cast from the global space and emits global instructions.  Same layout on the host, which fills the struct.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GPTR(...) __attribute__((address_space(1))) __VA_ARGS__ *
+#else
+#define GPTR(...) __VA_ARGS__ *
+#endif
 struct IbaWin {
     int n_kf, L, E, M, n, nfree, ncolors, npairs, nktask, nptask;
     int kf_off, pt_off, e_off, m_off, x_off, free_off, ptstart_off, kfe_off, ktask_off, ktstart_off, ptask_off, ptstart2_off;
@@ -61,38 +72,46 @@ struct IbaWin {
 };
 
 struct IbaArgs {
-    const IbaWin *win;
-    const int *kf_xoff;                 // [sumKF] first unknown of the keyframe's block, -1 = fixed
-    const uint8_t *kf_imu;
-    const int *free_kf;                 // [sumFree] keyframe of free block f
-    const int *edge_kf, *edge_point;    // [sumE] window-local indices
-    const double *edge_obs, *edge_is2;
-    const uint8_t *edge_stereo, *edge_close;
-    const int *pt_start;                // per window L + 1 entries
-    const int *kf_edges;                // the visual edges of every free keyframe, keyframe by keyframe
-    const int4 *kf_task;                // {free block f, first, end (into kf_edges), 0}: chunks of <= IBA_KF_CHUNK edges
-    const int *kf_task_start;           // per window nfree + 1: the chunks of block f
-    const int2 *pair_ent;               // {edge of block i, edge of block j} of every landmark both see, pair by pair (i <= j, row-major)
-    const int4 *pair_task;              // {pair, first, end (into pair_ent), i == j}: chunks of <= IBA_PAIR_CHUNK entries
-    const int *pair_task_start;         // per window npairs + 1
-    const int *in_kf1, *in_kf2, *in_color; const uint8_t *in_robust;
-    const double *in_pre, *in_info, *in_info_g, *in_info_a;
-    double *kfs, *cam, *pts;            // estimates, two buffers each: [2][sumKF][21], [2][sumKF][2 cameras][12] (Rcw, tcw), [2][sumL][3]
+    GPTR(const IbaWin) win;
+    GPTR(const int) kf_xoff;                 // [sumKF] first unknown of the keyframe's block, -1 = fixed
+    GPTR(const uint8_t) kf_imu;
+    GPTR(const int) free_kf;                 // [sumFree] keyframe of free block f
+    GPTR(const int) edge_kf; GPTR(const int) edge_point;    // [sumE] window-local indices
+    GPTR(const double) edge_obs; GPTR(const double) edge_is2;
+    GPTR(const uint8_t) edge_stereo; GPTR(const uint8_t) edge_close;
+    GPTR(const int) pt_start;                // per window L + 1 entries
+    GPTR(const int) kf_edges;                // the visual edges of every free keyframe, keyframe by keyframe
+    GPTR(const int4) kf_task;                // {free block f, first, end (into kf_edges), 0}: chunks of <= IBA_KF_CHUNK edges
+    GPTR(const int) kf_task_start;           // per window nfree + 1: the chunks of block f
+    GPTR(const int2) pair_ent;               // {edge of block i, edge of block j} of every landmark both see, pair by pair (i <= j, row-major)
+    GPTR(const int4) pair_task;              // {pair, first, end (into pair_ent), i == j}: chunks of <= IBA_PAIR_CHUNK entries
+    GPTR(const int) pair_task_start;         // per window npairs + 1
+    GPTR(const int) in_kf1; GPTR(const int) in_kf2; GPTR(const int) in_color; GPTR(const uint8_t) in_robust;
+    GPTR(const double) in_pre; GPTR(const double) in_info; GPTR(const double) in_info_g; GPTR(const double) in_info_a;
+    GPTR(double) kfs; GPTR(double) cam; GPTR(double) pts;            // estimates, two buffers each: [2][sumKF][21], [2][sumKF][2 cameras][12] (Rcw, tcw), [2][sumL][3]
     long long kfs_stride, cam_stride, pts_stride;
-    double *err, *chi2, *W, *Hll, *bl, *Dinv, *db, *xl;
-    double *ierr, *ichi2, *Jb, *OJ, *Oe;
-    double *H, *S, *b, *bs, *x;
-    double *kpart, *ppart;              // [kf tasks][27], [pair tasks][42] partial sums
-    unsigned *counters; int *fail, *okflag;   // per window: team barrier counter, barrier time-out flag, LDL^T status
-    double *wpart;                      // per window [2][IBA_MAXG][2]
+    GPTR(double) err; GPTR(double) chi2; GPTR(double) W; GPTR(double) Hll; GPTR(double) bl; GPTR(double) Dinv; GPTR(double) db; GPTR(double) xl;
+    GPTR(double) ierr; GPTR(double) ichi2; GPTR(double) Jb; GPTR(double) OJ; GPTR(double) Oe;
+    GPTR(double) H; GPTR(double) S; GPTR(double) b; GPTR(double) bs; GPTR(double) x;
+    GPTR(double) kpart; GPTR(double) ppart;              // [kf tasks][27], [pair tasks][42] partial sums
+    GPTR(unsigned) counters; GPTR(int) fail; GPTR(int) okflag;   // per window: team barrier counter, barrier time-out flag, LDL^T status
+    GPTR(double) wpart;                      // per window [2][IBA_MAXG][2]
     int G, n_windows;                   // workgroups per window
-    uint8_t *outlier;
-    orbhip_iba_stats *stats;
+    GPTR(uint8_t) outlier;
+    GPTR(orbhip_iba_stats) stats;
     int iterations, max_trials, large, max_n;
     double lambda_init;
-    long long *prof;                    // optional [windows][16] shader-clock cycles per phase (ORBHIP_IBA_PROF=1): errors, build, prep+Schur, LDL^T, update
+    GPTR(long long) prof;                    // optional [windows][16] shader-clock cycles per phase (ORBHIP_IBA_PROF=1): errors, build, prep+Schur, LDL^T, update
 };
 
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class T>
+__device__ __forceinline__ T *gen(__attribute__((address_space(1))) T *p) { return (T *)p; }
+#else
+template <class T>
+__host__ __device__ inline T *gen(T *p) { return p; }      // (the host pass only parses the device functions)
+#endif
+#define GA(f) gen(A.f)
 // ------------------------------------------------------------------ small dense helpers (row-major 3x3)
 namespace {
 __device__ __forceinline__ void mm3(const double *A, const double *B, double *C)
@@ -388,8 +407,8 @@ __device__ __forceinline__ void team_sum2(Team &T, double &a, double &b, double 
 }
 
 struct IbaCtx {            // per-window views (all threads hold the same values)
-    const IbaWin *W;
-    const IbaArgs *A;
+    GPTR(const IbaWin) W;
+    GPTR(const IbaArgs) A;
     double delta_m, dsqr_m, delta_s, dsqr_s, delta_i, dsqr_i;
 };
 
@@ -397,19 +416,19 @@ struct IbaCtx {            // per-window views (all threads hold the same values
 // activeRobustChi2 (the caller sums over the team)
 __device__ __noinline__ double iba_errors(const IbaCtx &C, const Team &T, int buf)
 {
-    const IbaWin &W = *C.W; const IbaArgs &A = *C.A;
-    const double *cam = A.cam + buf * A.cam_stride + (size_t)W.kf_off * 24;
-    const double *pts = A.pts + buf * A.pts_stride + (size_t)W.pt_off * 3;
-    const double *kfs = A.kfs + buf * A.kfs_stride + (size_t)W.kf_off * IBA_KF;
+    const IbaWin &W = *gen(C.W); const IbaArgs &A = *gen(C.A);
+    const double *cam = GA(cam) + buf * A.cam_stride + (size_t)W.kf_off * 24;
+    const double *pts = GA(pts) + buf * A.pts_stride + (size_t)W.pt_off * 3;
+    const double *kfs = GA(kfs) + buf * A.kfs_stride + (size_t)W.kf_off * IBA_KF;
     double part = 0.0;
     for (int e = T.gtid; e < W.E; e += T.gsize) {
         const size_t ge = (size_t)W.e_off + e;
-        const int type = A.edge_stereo[ge], st = type == 1;
+        const int type = GA(edge_stereo)[ge], st = type == 1;
         double er[3], Xc[3];
-        visual_error(W, cam_view(W, type == 2), cam + 24 * A.edge_kf[ge] + 12 * (type == 2), pts + 3 * A.edge_point[ge], A.edge_obs + 3 * ge, type, er, Xc);
-        const double chi = (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * A.edge_is2[ge];
-        A.err[3 * ge] = er[0]; A.err[3 * ge + 1] = er[1]; A.err[3 * ge + 2] = er[2];
-        A.chi2[ge] = chi;
+        visual_error(W, cam_view(W, type == 2), cam + 24 * GA(edge_kf)[ge] + 12 * (type == 2), pts + 3 * GA(edge_point)[ge], GA(edge_obs) + 3 * ge, type, er, Xc);
+        const double chi = (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * GA(edge_is2)[ge];
+        GA(err)[3 * ge] = er[0]; GA(err)[3 * ge + 1] = er[1]; GA(err)[3 * ge + 2] = er[2];
+        GA(chi2)[ge] = chi;
         double r0, r1;
         huber(chi, st ? C.delta_s : C.delta_m, st ? C.dsqr_s : C.dsqr_m, r0, r1);
         part += r0;
@@ -418,11 +437,11 @@ __device__ __noinline__ double iba_errors(const IbaCtx &C, const Team &T, int bu
     const int m = T.gsize - 1 - T.gtid;
     if (m < W.M) {
         const size_t gm = (size_t)W.m_off + m;
-        const double *s1 = kfs + IBA_KF * A.in_kf1[gm], *s2 = kfs + IBA_KF * A.in_kf2[gm];
+        const double *s1 = kfs + IBA_KF * GA(in_kf1)[gm], *s2 = kfs + IBA_KF * GA(in_kf2)[gm];
         double er[15];
-        inertial_edge(s1, s2, A.in_pre + IBA_PRE * gm, er, nullptr);
+        inertial_edge(s1, s2, GA(in_pre) + IBA_PRE * gm, er, nullptr);
         for (int i = 0; i < 3; i++) { er[9 + i] = s2[K_BG + i] - s1[K_BG + i]; er[12 + i] = s2[K_BA + i] - s1[K_BA + i]; }
-        const double *I9 = A.in_info + 81 * gm, *Ig = A.in_info_g + 9 * gm, *Ia = A.in_info_a + 9 * gm;
+        const double *I9 = GA(in_info) + 81 * gm, *Ig = GA(in_info_g) + 9 * gm, *Ia = GA(in_info_a) + 9 * gm;
         double c9 = 0, cg = 0, ca = 0;
         for (int i = 0; i < 9; i++) { double r = 0; for (int j = 0; j < 9; j++) r += I9[9 * i + j] * er[j]; c9 += er[i] * r; }
         for (int i = 0; i < 3; i++) {
@@ -430,10 +449,10 @@ __device__ __noinline__ double iba_errors(const IbaCtx &C, const Team &T, int bu
             for (int j = 0; j < 3; j++) { r += Ig[3 * i + j] * er[9 + j]; q += Ia[3 * i + j] * er[12 + j]; }
             cg += er[9 + i] * r; ca += er[12 + i] * q;
         }
-        for (int i = 0; i < 15; i++) A.ierr[15 * gm + i] = er[i];
-        A.ichi2[3 * gm] = c9; A.ichi2[3 * gm + 1] = cg; A.ichi2[3 * gm + 2] = ca;
+        for (int i = 0; i < 15; i++) GA(ierr)[15 * gm + i] = er[i];
+        GA(ichi2)[3 * gm] = c9; GA(ichi2)[3 * gm + 1] = cg; GA(ichi2)[3 * gm + 2] = ca;
         double r0 = c9, r1;
-        if (A.in_robust[gm]) huber(c9, C.delta_i, C.dsqr_i, r0, r1);
+        if (GA(in_robust)[gm]) huber(c9, C.delta_i, C.dsqr_i, r0, r1);
         part += r0 + cg + ca;
     }
     return part;
@@ -445,24 +464,24 @@ __device__ __noinline__ double iba_errors(const IbaCtx &C, const Team &T, int bu
 template <int HALF>
 __device__ __forceinline__ void kf_block_task(const IbaCtx &C, const double *cam, const double *pts, int4 task, double *out)
 {
-    const IbaWin &W = *C.W; const IbaArgs &A = *C.A;
+    const IbaWin &W = *gen(C.W); const IbaArgs &A = *gen(C.A);
     constexpr int A0 = HALF ? 4 : 0, A1 = HALF ? 6 : 4, Q0 = HALF ? 10 : 0, NQ = HALF ? 11 : 10, NB = HALF ? 0 : 6;
     const int lane = threadIdx.x & 63;
-    const int k = A.free_kf[W.free_off + task.x];
-    const int *kf_edges = A.kf_edges + W.kfe_off;
+    const int k = GA(free_kf)[W.free_off + task.x];
+    const int *kf_edges = GA(kf_edges) + W.kfe_off;
     double acc[NQ + NB + 1];
 #pragma unroll
     for (int i = 0; i < NQ + NB; i++) acc[i] = 0.0;
     for (int j = task.y + lane; j < task.z; j += 64) {
         const size_t ge = (size_t)W.e_off + kf_edges[j];
-        const int type = A.edge_stereo[ge], st = type == 1;
+        const int type = GA(edge_stereo)[ge], st = type == 1;
         const double *c = cam + 24 * k + 12 * (type == 2);
-        const double *X = pts + 3 * A.edge_point[ge];
+        const double *X = pts + 3 * GA(edge_point)[ge];
         double Xc[3], Jx[9], Jp[18], r0, r1;
         mv3(c, X, Xc); Xc[0] += c[9]; Xc[1] += c[10]; Xc[2] += c[11];
         visual_jac(W, cam_view(W, type == 2), c, Xc, type, Jx, Jp);
-        huber(A.chi2[ge], st ? C.delta_s : C.delta_m, st ? C.dsqr_s : C.dsqr_m, r0, r1);
-        const double w = r1 * A.edge_is2[ge];
+        huber(GA(chi2)[ge], st ? C.delta_s : C.delta_m, st ? C.dsqr_s : C.dsqr_m, r0, r1);
+        const double w = r1 * GA(edge_is2)[ge];
         int q = 0;
 #pragma unroll
         for (int a = A0; a < A1; a++)
@@ -470,7 +489,7 @@ __device__ __forceinline__ void kf_block_task(const IbaCtx &C, const double *cam
             for (int cc = 0; cc <= a; cc++, q++)
                 acc[q] += Jp[a] * w * Jp[cc] + Jp[6 + a] * w * Jp[6 + cc] + Jp[12 + a] * w * Jp[12 + cc];      // row 2 of Jp is zero when mono
         if (!HALF) {
-            const double e0 = -w * A.err[3 * ge], e1 = -w * A.err[3 * ge + 1], e2 = st ? -w * A.err[3 * ge + 2] : 0.0;
+            const double e0 = -w * GA(err)[3 * ge], e1 = -w * GA(err)[3 * ge + 1], e2 = st ? -w * GA(err)[3 * ge + 2] : 0.0;
 #pragma unroll
             for (int a = 0; a < 6; a++) acc[NQ + a] += Jp[a] * e0 + Jp[6 + a] * e1 + Jp[12 + a] * e2;
         }
@@ -489,14 +508,14 @@ __device__ __forceinline__ void kf_block_task(const IbaCtx &C, const double *cam
 // pose blocks; the Omega-weighted inertial Jacobians.  Workgroup 0 then assembles H (dense, both triangles) and b.
 __device__ __noinline__ void iba_build(const IbaCtx &C, Team &T, int buf)
 {
-    const IbaWin &W = *C.W; const IbaArgs &A = *C.A;
+    const IbaWin &W = *gen(C.W); const IbaArgs &A = *gen(C.A);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = W.n;
-    const double *cam = A.cam + buf * A.cam_stride + (size_t)W.kf_off * 24;
-    const double *pts = A.pts + buf * A.pts_stride + (size_t)W.pt_off * 3;
-    const double *kfs = A.kfs + buf * A.kfs_stride + (size_t)W.kf_off * IBA_KF;
-    double *H = A.H + W.h_off, *b = A.b + W.x_off;
-    const bool bprof = A.prof && T.g == 0 && tid == 0;
-    long long *bpf = A.prof ? A.prof + 16 * T.w + 8 : nullptr;
+    const double *cam = GA(cam) + buf * A.cam_stride + (size_t)W.kf_off * 24;
+    const double *pts = GA(pts) + buf * A.pts_stride + (size_t)W.pt_off * 3;
+    const double *kfs = GA(kfs) + buf * A.kfs_stride + (size_t)W.kf_off * IBA_KF;
+    double *H = GA(H) + W.h_off, *b = GA(b) + W.x_off;
+    const bool bprof = GA(prof) && T.g == 0 && tid == 0;
+    long long *bpf = GA(prof) ? GA(prof) + 16 * T.w + 8 : nullptr;
     long long tb = bprof ? clock64() : 0;
 #define BPROF(k) do { if (bprof) { const long long t_ = clock64(); bpf[k] += t_ - tb; tb = t_; } } while (0)
     if (T.g == 0) {
@@ -509,12 +528,12 @@ __device__ __noinline__ void iba_build(const IbaCtx &C, Team &T, int buf)
         if (m < W.M) {
             const size_t gm = (size_t)W.m_off + m;
             double er[9];
-            inertial_edge(kfs + IBA_KF * A.in_kf1[gm], kfs + IBA_KF * A.in_kf2[gm], A.in_pre + IBA_PRE * gm, er, A.Jb + 216 * gm);
+            inertial_edge(kfs + IBA_KF * GA(in_kf1)[gm], kfs + IBA_KF * GA(in_kf2)[gm], GA(in_pre) + IBA_PRE * gm, er, GA(Jb) + 216 * gm);
         }
     }
     BPROF(0);
     // (2) landmarks: Hll, bl and the pose-landmark blocks; 8 lanes share a landmark's edges
-    const int *pt_start = A.pt_start + W.ptstart_off;
+    const int *pt_start = GA(pt_start) + W.ptstart_off;
     const int sub = tid & 7;
     for (int l0 = (T.gtid >> 3); l0 < ((W.L + 7) & ~7); l0 += (T.gsize >> 3)) {      // whole waves stay in the loop (DPP reductions)
         const int l = min(l0, W.L - 1);
@@ -523,14 +542,14 @@ __device__ __noinline__ void iba_build(const IbaCtx &C, Team &T, int buf)
         const int e_end = l0 < W.L ? pt_start[l + 1] : 0;
         for (int e = pt_start[l] + sub; e < e_end; e += 8) {
             const size_t ge = (size_t)W.e_off + e;
-            const int type = A.edge_stereo[ge], st = type == 1, k = A.edge_kf[ge];
+            const int type = GA(edge_stereo)[ge], st = type == 1, k = GA(edge_kf)[ge];
             const double *c = cam + 24 * k + 12 * (type == 2);
             double Xc[3], Jx[9], Jp[18], r0, r1;
             mv3(c, X, Xc); Xc[0] += c[9]; Xc[1] += c[10]; Xc[2] += c[11];
             visual_jac(W, cam_view(W, type == 2), c, Xc, type, Jx, Jp);
-            huber(A.chi2[ge], st ? C.delta_s : C.delta_m, st ? C.dsqr_s : C.dsqr_m, r0, r1);
-            const double w = r1 * A.edge_is2[ge];
-            const double es[3] = {-w * A.err[3 * ge], -w * A.err[3 * ge + 1], st ? -w * A.err[3 * ge + 2] : 0.0};
+            huber(GA(chi2)[ge], st ? C.delta_s : C.delta_m, st ? C.dsqr_s : C.dsqr_m, r0, r1);
+            const double w = r1 * GA(edge_is2)[ge];
+            const double es[3] = {-w * GA(err)[3 * ge], -w * GA(err)[3 * ge + 1], st ? -w * GA(err)[3 * ge + 2] : 0.0};
             int q = 0;
 #pragma unroll
             for (int a = 0; a < 3; a++) {
@@ -538,8 +557,8 @@ __device__ __noinline__ void iba_build(const IbaCtx &C, Team &T, int buf)
 #pragma unroll
                 for (int cc = 0; cc <= a; cc++, q++) h[q] += Jx[a] * w * Jx[cc] + Jx[3 + a] * w * Jx[3 + cc] + Jx[6 + a] * w * Jx[6 + cc];
             }
-            if (A.kf_xoff[W.kf_off + k] >= 0) {
-                double *Wd = A.W + 18 * ge;
+            if (GA(kf_xoff)[W.kf_off + k] >= 0) {
+                double *Wd = GA(W) + 18 * ge;
 #pragma unroll
                 for (int a = 0; a < 6; a++)
 #pragma unroll
@@ -551,7 +570,7 @@ __device__ __noinline__ void iba_build(const IbaCtx &C, Team &T, int buf)
 #pragma unroll
         for (int i = 0; i < 3; i++) bl[i] = oct_allreduce_f64(bl[i]);
         if (sub == 0 && l0 < W.L) {
-            double *Hl = A.Hll + 6 * ((size_t)W.pt_off + l), *Bl = A.bl + 3 * ((size_t)W.pt_off + l);
+            double *Hl = GA(Hll) + 6 * ((size_t)W.pt_off + l), *Bl = GA(bl) + 3 * ((size_t)W.pt_off + l);
             for (int i = 0; i < 6; i++) Hl[i] = h[i];
             for (int i = 0; i < 3; i++) Bl[i] = bl[i];
         }
@@ -559,8 +578,8 @@ __device__ __noinline__ void iba_build(const IbaCtx &C, Team &T, int buf)
     BPROF(1);
     // (3) per-chunk partial pose blocks, two waves per chunk
     {
-        const int4 *kf_task = A.kf_task + W.ktask_off;
-        double *kpart = A.kpart + 27 * (size_t)W.ktask_off;
+        const int4 *kf_task = GA(kf_task) + W.ktask_off;
+        double *kpart = GA(kpart) + 27 * (size_t)W.ktask_off;
         for (int t = T.gwave; t < 2 * W.nktask; t += T.gwaves) {
             const int4 task = kf_task[t >> 1];
             if (t & 1) kf_block_task<1>(C, cam, pts, task, kpart + 27 * (size_t)(t >> 1));
@@ -571,31 +590,14 @@ __device__ __noinline__ void iba_build(const IbaCtx &C, Team &T, int buf)
     team_sync(T);                      // Jb, kpart complete
     BPROF(3);
     if (T.g != 0) return;
-    // ---- workgroup 0: Omega-weighted inertial Jacobians / errors
-    for (int idx = tid; idx < W.M * 216; idx += IBA_THREADS) {
-        const int m = idx / 216, r = idx - m * 216, i = r / 24, c = r - i * 24;
-        const size_t gm = (size_t)W.m_off + m;
-        double r0, r1 = 1.0;
-        if (A.in_robust[gm]) huber(A.ichi2[3 * gm], C.delta_i, C.dsqr_i, r0, r1);
-        const double *I9 = A.in_info + 81 * gm + 9 * i, *J = A.Jb + 216 * gm + c;
-        double s = 0;
-        for (int k = 0; k < 9; k++) s += r1 * I9[k] * J[24 * k];
-        A.OJ[216 * gm + r] = s;
-        if (c == 0) {
-            const double *er = A.ierr + 15 * gm;
-            double q = 0;
-            for (int k = 0; k < 9; k++) q += I9[k] * er[k];
-            A.Oe[15 * gm + i] = -r1 * q;
-        }
-    }
     BPROF(4);
-    // pose blocks: the chunks of every keyframe summed in order
+    // ---- workgroup 0: pose blocks: the chunks of every keyframe summed in order
     {
-        const int *kts = A.kf_task_start + W.ktstart_off;
-        const double *kpart = A.kpart + 27 * (size_t)W.ktask_off;
+        const int *kts = GA(kf_task_start) + W.ktstart_off;
+        const double *kpart = GA(kpart) + 27 * (size_t)W.ktask_off;
         for (int idx = tid; idx < W.nfree * 27; idx += IBA_THREADS) {
             const int f = idx / 27, q = idx - 27 * f;
-            const int o = A.kf_xoff[W.kf_off + A.free_kf[W.free_off + f]];
+            const int o = GA(kf_xoff)[W.kf_off + GA(free_kf)[W.free_off + f]];
             double s = 0;
             for (int t = kts[f]; t < kts[f + 1]; t++) s += kpart[27 * (size_t)t + q];
             if (q >= 21) b[o + q - 21] = s;
@@ -606,51 +608,120 @@ __device__ __noinline__ void iba_build(const IbaCtx &C, Team &T, int buf)
             }
         }
     }
+    // what the colour loop needs to know about an edge, fetched for all edges at once (colour, first unknowns of its two keyframes or -1,
+    // robust flag): inside the loop these were four dependent L2 round trips per edge
+    extern __shared__ double iba_dyn_lds[];
+    typedef __attribute__((address_space(3))) int lds_i32;
+    lds_i32 *recs = (lds_i32 *)((lds_f64 *)iba_dyn_lds + (size_t)IBA_WAVES * IBA_STAGE);
+    for (int m = tid; m < W.M; m += IBA_THREADS) {
+        const size_t gm = (size_t)W.m_off + m;
+        const int *kx = GA(kf_xoff) + W.kf_off;
+        recs[4 * m] = GA(in_color)[gm]; recs[4 * m + 1] = kx[GA(in_kf1)[gm]]; recs[4 * m + 2] = kx[GA(in_kf2)[gm]]; recs[4 * m + 3] = GA(in_robust)[gm];
+    }
     __syncthreads();
     BPROF(5);
-    // inertial + random-walk edges into H / b: edges of one colour share no keyframe, colours run one after the other
-    const int *kf_xoff = A.kf_xoff + W.kf_off;
+    // inertial + random-walk edges into H / b: edges of one colour share no keyframe, colours run one after the other.  A wave takes an
+    // edge and keeps it in LDS (the solver's panel area is idle during the build): Jacobian, information and error are fetched in ONE
+    // round trip, the Omega-weighted copies (Huber weight x information x J, -weight x information x error) are formed in LDS -- round 3
+    // wrote them to global memory in a pass of its own, one L2 round trip per output -- and the 24 x 24 products read LDS only; the
+    // entries of H a lane updates are read together before and written together after.  Same expressions, same order of sums.
+    lds_f64 *sw = (lds_f64 *)iba_dyn_lds + (size_t)wave * IBA_STAGE;      // J [9][24] | Omega J [9][24] at 216 | Omega e [9] at 432 | information [9][9] at 448 | error [15] at 529
     for (int col = 0; col < W.ncolors; col++) {
-        for (int m = wave; m < W.M; m += IBA_WAVES) {
+        for (int m = 0; m < W.M; m++) {                             // (M is small: every wave scans the records, in LDS)
+            const int cr = recs[4 * m];
+            if ((cr & 255) != col || ((cr >> 8) % IBA_WAVES) != wave) continue;
             const size_t gm = (size_t)W.m_off + m;
-            if (A.in_color[gm] != col) continue;
-            const int o1 = kf_xoff[A.in_kf1[gm]], o2 = kf_xoff[A.in_kf2[gm]];
-            const double *J = A.Jb + 216 * gm, *OJ = A.OJ + 216 * gm, *Oe = A.Oe + 15 * gm;
-            for (int idx = lane; idx < 576; idx += 64) {
-                const int a = idx / 24, c = idx - a * 24;
-                const int ga = a < 15 ? (o1 < 0 ? -1 : o1 + a) : (o2 < 0 ? -1 : o2 + a - 15);
-                const int gc = c < 15 ? (o1 < 0 ? -1 : o1 + c) : (o2 < 0 ? -1 : o2 + c - 15);
-                if (ga < 0 || gc < 0) continue;
-                double s = 0;
-                for (int k = 0; k < 9; k++) s += J[24 * k + a] * OJ[24 * k + c];
-                H[(size_t)ga * n + gc] += s;
-            }
-            if (lane < 24) {
-                const int a = lane, ga = a < 15 ? (o1 < 0 ? -1 : o1 + a) : (o2 < 0 ? -1 : o2 + a - 15);
-                if (ga >= 0) {
-                    double s = 0;
-                    for (int k = 0; k < 9; k++) s += J[24 * k + a] * Oe[k];
-                    b[ga] += s;
-                }
-            }
-            // EdgeGyroRW / EdgeAccRW: J = [-I, I] (G2oTypes.h:648-651): lanes 32..49 = 2 edges x 3 x 3
-            if (lane >= 32 && lane < 50) {
-                const int t = lane - 32, which = t / 9, r = (t % 9) / 3, c = t % 3;
-                const double *If = (which ? A.in_info_a : A.in_info_g) + 9 * gm;
-                const int base = which ? 12 : 9;
-                const double v = If[3 * r + c];
-                if (o1 >= 0) H[(size_t)(o1 + base + r) * n + o1 + base + c] += v;
-                if (o2 >= 0) H[(size_t)(o2 + base + r) * n + o2 + base + c] += v;
-                if (o1 >= 0 && o2 >= 0) { H[(size_t)(o1 + base + r) * n + o2 + base + c] -= v; H[(size_t)(o2 + base + r) * n + o1 + base + c] -= v; }
-            }
+            const int o1 = recs[4 * m + 1], o2 = recs[4 * m + 2];
+            const double *Jg = GA(Jb) + 216 * gm, *Ig = GA(in_info) + 81 * gm, *erg = GA(ierr) + 15 * gm;
+            double jv[4], iv[2];
+#pragma unroll
+            for (int t = 0; t < 4; t++) jv[t] = lane + 64 * t < 216 ? Jg[lane + 64 * t] : 0.0;
+            iv[0] = Ig[lane]; iv[1] = lane + 64 < 81 ? Ig[lane + 64] : 0.0;
+            const double erv = lane < 15 ? erg[lane] : 0.0;
+            const double chi_i = GA(ichi2)[3 * gm];
+            // EdgeGyroRW / EdgeAccRW (G2oTypes.h:648-651, J = [-I, I]): lanes 32..49 = 2 edges x 3 x 3 of H, lanes 50..55 = 2 x 3 of b
+            double rwv = 0.0, rw0 = 0.0, rw1 = 0.0, rw2 = 0.0;
+            if (lane >= 32 && lane < 50) { const int t = lane - 32, which = t / 9; rwv = ((which ? GA(in_info_a) : GA(in_info_g)) + 9 * gm)[t % 9]; }
             if (lane >= 50 && lane < 56) {
                 const int t = lane - 50, which = t / 3, r = t % 3;
-                const double *If = (which ? A.in_info_a : A.in_info_g) + 9 * gm, *er = A.ierr + 15 * gm + (which ? 12 : 9);
-                const int base = which ? 12 : 9;
-                const double v = If[3 * r] * er[0] + If[3 * r + 1] * er[1] + If[3 * r + 2] * er[2];
-                if (o1 >= 0) b[o1 + base + r] += v;              // J1 = -I: b1 += -J1^T (-Omega e) = +Omega e
-                if (o2 >= 0) b[o2 + base + r] -= v;
+                const double *If = (which ? GA(in_info_a) : GA(in_info_g)) + 9 * gm;
+                rw0 = If[3 * r]; rw1 = If[3 * r + 1]; rw2 = If[3 * r + 2];
             }
+#pragma unroll
+            for (int t = 0; t < 4; t++) if (lane + 64 * t < 216) sw[lane + 64 * t] = jv[t];
+            sw[448 + lane] = iv[0];
+            if (lane + 64 < 81) sw[448 + 64 + lane] = iv[1];
+            if (lane < 15) sw[529 + lane] = erv;
+            double r0, r1 = 1.0;
+            if (recs[4 * m + 3]) huber(chi_i, C.delta_i, C.dsqr_i, r0, r1);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int idx = lane; idx < 216; idx += 64) {
+                const int i = idx / 24, c = idx - i * 24;
+                double s = 0;
+                for (int k = 0; k < 9; k++) s += r1 * sw[448 + 9 * i + k] * sw[24 * k + c];
+                sw[216 + idx] = s;
+            }
+            if (lane < 9) {
+                double q = 0;
+                for (int k = 0; k < 9; k++) q += sw[448 + 9 * lane + k] * sw[529 + k];
+                sw[432 + lane] = -r1 * q;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            {
+                double hv[9]; size_t ad[9];
+#pragma unroll
+                for (int j = 0; j < 9; j++) {
+                    const int idx = lane + 64 * j, a = idx / 24, c = idx - a * 24;
+                    const int ga = a < 15 ? (o1 < 0 ? -1 : o1 + a) : (o2 < 0 ? -1 : o2 + a - 15);
+                    const int gc = c < 15 ? (o1 < 0 ? -1 : o1 + c) : (o2 < 0 ? -1 : o2 + c - 15);
+                    ad[j] = (ga < 0 || gc < 0) ? (size_t)-1 : (size_t)ga * n + gc;
+                    hv[j] = ad[j] != (size_t)-1 ? H[ad[j]] : 0.0;
+                }
+                // the right-hand side entry of lanes 0..23 and the random-walk entries travel with the same round trip
+                const int ba_ = lane < 24 ? (lane < 15 ? (o1 < 0 ? -1 : o1 + lane) : (o2 < 0 ? -1 : o2 + lane - 15)) : -1;
+                double bv = ba_ >= 0 ? b[ba_] : 0.0;
+                size_t a11 = 0, a22 = 0, a12 = 0, a21 = 0;
+                int rb1 = -1, rb2 = -1;
+                if (lane >= 32 && lane < 50) {
+                    const int t = lane - 32, which = t / 9, r = (t % 9) / 3, c = t % 3, base = which ? 12 : 9;
+                    if (o1 >= 0) a11 = (size_t)(o1 + base + r) * n + o1 + base + c;
+                    if (o2 >= 0) a22 = (size_t)(o2 + base + r) * n + o2 + base + c;
+                    if (o1 >= 0 && o2 >= 0) { a12 = (size_t)(o1 + base + r) * n + o2 + base + c; a21 = (size_t)(o2 + base + r) * n + o1 + base + c; }
+                }
+                if (lane >= 50 && lane < 56) {
+                    const int t = lane - 50, which = t / 3, r = t % 3, base = which ? 12 : 9;
+                    if (o1 >= 0) rb1 = o1 + base + r;
+                    if (o2 >= 0) rb2 = o2 + base + r;
+                }
+#pragma unroll
+                for (int j = 0; j < 9; j++) {
+                    const int idx = lane + 64 * j, a = idx / 24, c = idx - a * 24;
+                    double s = 0;
+                    for (int k = 0; k < 9; k++) s += sw[24 * k + a] * sw[216 + 24 * k + c];
+                    if (ad[j] != (size_t)-1) H[ad[j]] = hv[j] + s;
+                }
+                if (ba_ >= 0) {
+                    double s = 0;
+                    for (int k = 0; k < 9; k++) s += sw[24 * k + lane] * sw[432 + k];
+                    b[ba_] = bv + s;
+                }
+                // the random-walk entries are addresses OTHER lanes have just written (blocks 9..14 of both keyframes): those stores are
+                // waited for before they are read back (the inertial sums go in first, as in round 3)
+                __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0)
+                __builtin_amdgcn_wave_barrier();
+                if (lane >= 32 && lane < 50) {
+                    if (o1 >= 0) H[a11] += rwv;
+                    if (o2 >= 0) H[a22] += rwv;
+                    if (o1 >= 0 && o2 >= 0) { H[a12] -= rwv; H[a21] -= rwv; }
+                }
+                if (lane >= 50 && lane < 56) {
+                    const int t = lane - 50, which = t / 3;
+                    const double v = rw0 * sw[529 + (which ? 12 : 9)] + rw1 * sw[529 + (which ? 12 : 9) + 1] + rw2 * sw[529 + (which ? 12 : 9) + 2];
+                    if (rb1 >= 0) b[rb1] += v;                   // J1 = -I: b1 += -J1^T (-Omega e) = +Omega e
+                    if (rb2 >= 0) b[rb2] -= v;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();                     // (the next edge of this wave restages sw)
         }
         __syncthreads();
     }
@@ -663,9 +734,9 @@ __device__ __noinline__ void iba_build(const IbaCtx &C, Team &T, int buf)
 template <int HALF>
 __device__ __forceinline__ void pair_task(const IbaCtx &C, int4 task, bool diag, double *out)
 {
-    const IbaWin &W = *C.W; const IbaArgs &A = *C.A;
+    const IbaWin &W = *gen(C.W); const IbaArgs &A = *gen(C.A);
     const int lane = threadIdx.x & 63;
-    const int2 *pair_ent = A.pair_ent + W.pent_off;
+    const int2 *pair_ent = GA(pair_ent) + W.pent_off;
     constexpr int NB = HALF ? 0 : 6;
     double acc[18 + NB + 1];
 #pragma unroll
@@ -673,8 +744,8 @@ __device__ __forceinline__ void pair_task(const IbaCtx &C, int4 task, bool diag,
     for (int t = task.y + lane; t < task.z; t += 64) {
         const int2 en = pair_ent[t];
         const size_t gi = (size_t)W.e_off + en.x, gj = (size_t)W.e_off + en.y;
-        const size_t gl = (size_t)W.pt_off + A.edge_point[gi];
-        const double *Wi = A.W + 18 * gi, *Wj = A.W + 18 * gj + 9 * HALF, *Di = A.Dinv + 6 * gl;
+        const size_t gl = (size_t)W.pt_off + GA(edge_point)[gi];
+        const double *Wi = GA(W) + 18 * gi, *Wj = GA(W) + 18 * gj + 9 * HALF, *Di = GA(Dinv) + 6 * gl;
         const double d00 = Di[0], d10 = Di[1], d11 = Di[2], d20 = Di[3], d21 = Di[4], d22 = Di[5];
         double wi[18];
 #pragma unroll
@@ -687,7 +758,7 @@ __device__ __forceinline__ void pair_task(const IbaCtx &C, int4 task, bool diag,
             for (int c = 0; c < 6; c++) acc[6 * a + c] += y0 * wi[3 * c] + y1 * wi[3 * c + 1] + y2 * wi[3 * c + 2];
         }
         if (!HALF && diag && en.x == en.y) {                  // W db once per edge (a keyframe's left / right twin edges also pair with each other)
-            const double *db = A.db + 3 * gl;
+            const double *db = GA(db) + 3 * gl;
 #pragma unroll
             for (int a = 0; a < 6; a++) acc[18 + a] += wi[3 * a] * db[0] + wi[3 * a + 1] * db[1] + wi[3 * a + 2] * db[2];
         }
@@ -707,16 +778,16 @@ __device__ __forceinline__ void pair_task(const IbaCtx &C, int4 task, bool diag,
 // (levenberg.cpp:187-194).
 __device__ __noinline__ bool iba_trial(const IbaCtx &C, Team &T, int buf, double lambda, double *scale_part)
 {
-    const IbaWin &W = *C.W; const IbaArgs &A = *C.A;
+    const IbaWin &W = *gen(C.W); const IbaArgs &A = *gen(C.A);
     const long long t_begin = clock64();
     const int tid = threadIdx.x, n = W.n;
-    double *H = A.H + W.h_off, *S = A.S + W.h_off, *b = A.b + W.x_off, *bs = A.bs + W.x_off, *x = A.x + W.x_off;
-    const int *pt_start = A.pt_start + W.ptstart_off;
+    double *H = GA(H) + W.h_off, *S = GA(S) + W.h_off, *b = GA(b) + W.x_off, *bs = GA(bs) + W.x_off, *x = GA(x) + W.x_off;
+    const int *pt_start = GA(pt_start) + W.ptstart_off;
     for (int l = (T.gtid >> 3); l < W.L && (tid & 7) == 0; l += (T.gsize >> 3)) {          // the lane that wrote Hll / bl in iba_build
         const size_t gl = (size_t)W.pt_off + l;
-        double *Di = A.Dinv + 6 * gl, *db = A.db + 3 * gl;
+        double *Di = GA(Dinv) + 6 * gl, *db = GA(db) + 3 * gl;
         if (pt_start[l + 1] == pt_start[l]) { for (int i = 0; i < 6; i++) Di[i] = 0.0; for (int i = 0; i < 3; i++) db[i] = 0.0; continue; }
-        const double *h = A.Hll + 6 * gl, *bl = A.bl + 3 * gl;
+        const double *h = GA(Hll) + 6 * gl, *bl = GA(bl) + 3 * gl;
         const double D[9] = {h[0] + lambda, h[1], h[3], h[1], h[2] + lambda, h[4], h[3], h[4], h[5] + lambda};
         double I[9];
         inv3(D, I);
@@ -730,8 +801,8 @@ __device__ __noinline__ bool iba_trial(const IbaCtx &C, Team &T, int buf, double
     team_sync(T);
     // Schur complement partials: (pair of free keyframes i <= j, chunk of the landmarks both see), two waves per chunk
     {
-        const int4 *ptask = A.pair_task + W.ptask_off;
-        double *ppart = A.ppart + 42 * (size_t)W.ptask_off;
+        const int4 *ptask = GA(pair_task) + W.ptask_off;
+        double *ppart = GA(ppart) + 42 * (size_t)W.ptask_off;
         const int nf = W.nfree;
         for (int t = T.gwave; t < 2 * W.nptask; t += T.gwaves) {
             const int4 task = ptask[t >> 1];
@@ -746,8 +817,8 @@ __device__ __noinline__ bool iba_trial(const IbaCtx &C, Team &T, int buf, double
     long long t_schur = 0, t_ldlt = 0;
     if (T.g == 0) {
         // combine: block (j, i) of the lower triangle -= sum of the pair's chunks, in order
-        const int *pts_ = A.pair_task_start + W.ptstart2_off;
-        const double *ppart = A.ppart + 42 * (size_t)W.ptask_off;
+        const int *pts_ = GA(pair_task_start) + W.ptstart2_off;
+        const double *ppart = GA(ppart) + 42 * (size_t)W.ptask_off;
         const int nf = W.nfree;
         for (int idx = tid; idx < W.npairs * 42; idx += IBA_THREADS) {
             const int p = idx / 42, q = idx - 42 * p;
@@ -758,33 +829,33 @@ __device__ __noinline__ bool iba_trial(const IbaCtx &C, Team &T, int buf, double
             if (q >= 36 && i != j) continue;
             double s = 0;
             for (int t = pts_[p]; t < pts_[p + 1]; t++) s += ppart[42 * (size_t)t + q];
-            const int oi = A.kf_xoff[W.kf_off + A.free_kf[W.free_off + i]], oj = A.kf_xoff[W.kf_off + A.free_kf[W.free_off + j]];
+            const int oi = GA(kf_xoff)[W.kf_off + GA(free_kf)[W.free_off + i]], oj = GA(kf_xoff)[W.kf_off + GA(free_kf)[W.free_off + j]];
             if (q >= 36) bs[oi + q - 36] -= s;
             else { const int a = q / 6, c = q - 6 * a; S[(size_t)(oj + a) * n + oi + c] -= s; }
         }
         __syncthreads();
         t_schur = clock64();
         ok = n > 0 ? ldlt_solve_wg(S, n, n, bs, x, A.max_n) : true;
-        if (tid == 0) A.okflag[T.w] = ok ? 1 : 0;
+        if (tid == 0) GA(okflag)[T.w] = ok ? 1 : 0;
         t_ldlt = clock64();
     }
     team_sync(T);
-    ok = A.okflag[T.w] != 0;
-    const double *cur_pts = A.pts + buf * A.pts_stride + (size_t)W.pt_off * 3;
-    double *new_pts = A.pts + (buf ^ 1) * A.pts_stride + (size_t)W.pt_off * 3;
+    ok = GA(okflag)[T.w] != 0;
+    const double *cur_pts = GA(pts) + buf * A.pts_stride + (size_t)W.pt_off * 3;
+    double *new_pts = GA(pts) + (buf ^ 1) * A.pts_stride + (size_t)W.pt_off * 3;
     double part = 0.0;
     for (int l0 = (T.gtid >> 3); l0 < ((W.L + 7) & ~7); l0 += (T.gsize >> 3)) {      // 8 lanes per landmark, whole waves stay in the loop
         const int l = min(l0, W.L - 1), sub = tid & 7;
         const size_t gl = (size_t)W.pt_off + l;
-        double *xl = A.xl + 3 * gl;
+        double *xl = GA(xl) + 3 * gl;
         const bool active = l0 < W.L && pt_start[l + 1] > pt_start[l];
         double cl[3] = {0, 0, 0};
         if (ok && active) {                                        // block_solver.hpp:461-481 (skipped when the pose solve failed: x stays stale)
             for (int e = pt_start[l] + sub; e < pt_start[l + 1]; e += 8) {
                 const size_t ge = (size_t)W.e_off + e;
-                const int o = A.kf_xoff[W.kf_off + A.edge_kf[ge]];
+                const int o = GA(kf_xoff)[W.kf_off + GA(edge_kf)[ge]];
                 if (o < 0) continue;
-                const double *We = A.W + 18 * ge, *xp = x + o;
+                const double *We = GA(W) + 18 * ge, *xp = x + o;
 #pragma unroll
                 for (int c = 0; c < 3; c++)
 #pragma unroll
@@ -795,7 +866,7 @@ __device__ __noinline__ bool iba_trial(const IbaCtx &C, Team &T, int buf, double
         for (int c = 0; c < 3; c++) cl[c] = oct_allreduce_f64(cl[c]);
         if (sub != 0 || l0 >= W.L) continue;
         if (ok && active) {
-            const double *bl = A.bl + 3 * gl, *Di = A.Dinv + 6 * gl;
+            const double *bl = GA(bl) + 3 * gl, *Di = GA(Dinv) + 6 * gl;
             cl[0] += bl[0]; cl[1] += bl[1]; cl[2] += bl[2];
             xl[0] = Di[0] * cl[0] + Di[1] * cl[1] + Di[3] * cl[2];
             xl[1] = Di[1] * cl[0] + Di[2] * cl[1] + Di[4] * cl[2];
@@ -804,18 +875,18 @@ __device__ __noinline__ bool iba_trial(const IbaCtx &C, Team &T, int buf, double
         for (int a = 0; a < 3; a++) {
             const double dx = active ? xl[a] : 0.0;
             new_pts[3 * l + a] = cur_pts[3 * l + a] + dx;
-            if (active) part += dx * (lambda * dx + A.bl[3 * gl + a]);
+            if (active) part += dx * (lambda * dx + GA(bl)[3 * gl + a]);
         }
     }
     if (T.g == 0) for (int i = tid; i < n; i += IBA_THREADS) part += x[i] * (lambda * x[i] + b[i]);
     // oplus on the keyframe vertices (ImuCamPose::Update, G2oTypes.cc:192-220; the velocity / bias vertices add)
-    const double *cur_kf = A.kfs + buf * A.kfs_stride + (size_t)W.kf_off * IBA_KF;
-    double *new_kf = A.kfs + (buf ^ 1) * A.kfs_stride + (size_t)W.kf_off * IBA_KF;
-    double *new_cam = A.cam + (buf ^ 1) * A.cam_stride + (size_t)W.kf_off * 24;
+    const double *cur_kf = GA(kfs) + buf * A.kfs_stride + (size_t)W.kf_off * IBA_KF;
+    double *new_kf = GA(kfs) + (buf ^ 1) * A.kfs_stride + (size_t)W.kf_off * IBA_KF;
+    double *new_cam = GA(cam) + (buf ^ 1) * A.cam_stride + (size_t)W.kf_off * 24;
     for (int k = T.gsize - 1 - T.gtid; k < W.n_kf; k += T.gsize) {
         double s[IBA_KF];
         for (int i = 0; i < IBA_KF; i++) s[i] = cur_kf[IBA_KF * k + i];
-        const int o = A.kf_xoff[W.kf_off + k];
+        const int o = GA(kf_xoff)[W.kf_off + k];
         if (o >= 0) {
             const double *dx = x + o;
             double t[3], E[9];
@@ -823,23 +894,24 @@ __device__ __noinline__ bool iba_trial(const IbaCtx &C, Team &T, int buf, double
             for (int i = 0; i < 3; i++) s[K_T + i] += t[i];
             exp_so3(dx, E, 1e-5, true);
             mm3(s + K_R, E, s + K_R);
-            if (A.kf_imu[W.kf_off + k]) for (int i = 0; i < 9; i++) s[K_V + i] += dx[6 + i];
+            if (GA(kf_imu)[W.kf_off + k]) for (int i = 0; i < 9; i++) s[K_V + i] += dx[6 + i];
         }
         for (int i = 0; i < IBA_KF; i++) new_kf[IBA_KF * k + i] = s[i];
         cam_pose(W, s, new_cam + 24 * k);
     }
     team_sync(T);                              // the new estimates are complete
     *scale_part = part;
-    if (A.prof && T.g == 0 && threadIdx.x == 0) {
-        long long *pf = A.prof + 16 * T.w;
+    if (GA(prof) && T.g == 0 && threadIdx.x == 0) {
+        long long *pf = GA(prof) + 16 * T.w;
         pf[2] += t_schur - t_begin; pf[3] += t_ldlt - t_schur; pf[4] += clock64() - t_ldlt;
     }
     return ok;
 }
 }  // namespace
 
-__global__ __launch_bounds__(IBA_THREADS) void k_iba_solve(IbaArgs A)
+__global__ __launch_bounds__(IBA_THREADS) void k_iba_solve(const IbaArgs *Ap)      // the argument block sits in global memory: the phase functions read it through a pointer
 {
+    const IbaArgs &A = *Ap;
     __shared__ double red[2 * IBA_WAVES];
     // blockIdx -> (window, member): with G > 1 the members of a team sit on ONE XCD (workgroups are dealt round-robin over the 8
     // XCDs), so that the team's scratch stays in that XCD's L2; correctness does not depend on it (agent-scope fences)
@@ -847,20 +919,20 @@ __global__ __launch_bounds__(IBA_THREADS) void k_iba_solve(IbaArgs A)
     if (A.G == 1) { w = blockIdx.x; g = 0; }
     else { const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3; w = xcd + 8 * (slot / A.G); g = slot % A.G; }
     if (w >= A.n_windows) return;
-    const IbaWin &W = A.win[w];
+    const IbaWin &W = GA(win)[w];
     const int tid = threadIdx.x;
     Team T;
     T.w = w; T.g = g; T.G = A.G; T.gtid = g * IBA_THREADS + tid; T.gsize = A.G * IBA_THREADS; T.gwave = g * IBA_WAVES + (tid >> 6); T.gwaves = A.G * IBA_WAVES;
-    T.counter = A.counters + w; T.epoch = 0; T.wpart = A.wpart + (size_t)w * 2 * IBA_MAXG * 2; T.slot = 0; T.fail = A.fail + w;
+    T.counter = GA(counters) + w; T.epoch = 0; T.wpart = GA(wpart) + (size_t)w * 2 * IBA_MAXG * 2; T.slot = 0; T.fail = GA(fail) + w;
     IbaCtx C;
-    C.W = &W; C.A = &A;
+    C.W = (GPTR(const IbaWin))&W; C.A = (GPTR(const IbaArgs))Ap;
     C.delta_m = (double)sqrtf(5.991f); C.dsqr_m = C.delta_m * C.delta_m;        // thHuberMono etc. are floats (Optimizer.cc:4893-4896)
     C.delta_s = (double)sqrtf(7.815f); C.dsqr_s = C.delta_s * C.delta_s;
     C.delta_i = sqrt(16.92); C.dsqr_i = C.delta_i * C.delta_i;                  // :4838
     int cur = 0;
     {
-        const double *kf0 = A.kfs + (size_t)W.kf_off * IBA_KF;
-        double *cam0 = A.cam + (size_t)W.kf_off * 24;
+        const double *kf0 = GA(kfs) + (size_t)W.kf_off * IBA_KF;
+        double *cam0 = GA(cam) + (size_t)W.kf_off * 24;
         for (int k = T.gtid; k < W.n_kf; k += T.gsize) cam_pose(W, kf0 + IBA_KF * k, cam0 + 24 * k);
     }
     team_sync(T);
@@ -914,34 +986,34 @@ __global__ __launch_bounds__(IBA_THREADS) void k_iba_solve(IbaArgs A)
         if (nbad >= 3) break;
     }
     // outlier gates on the stored chi2, depth of the final estimates (Optimizer.cc:5056-5088)
-    const double *cam = A.cam + cur * A.cam_stride + (size_t)W.kf_off * 24;
-    const double *pts = A.pts + cur * A.pts_stride + (size_t)W.pt_off * 3;
+    const double *cam = GA(cam) + cur * A.cam_stride + (size_t)W.kf_off * 24;
+    const double *pts = GA(pts) + cur * A.pts_stride + (size_t)W.pt_off * 3;
     double nout = 0.0;
     for (int e = T.gtid; e < W.E; e += T.gsize) {
         const size_t ge = (size_t)W.e_off + e;
-        const double c2 = A.chi2[ge];
+        const double c2 = GA(chi2)[ge];
         bool out;
-        if (A.edge_stereo[ge] == 1) out = c2 > (double)7.815f;
+        if (GA(edge_stereo)[ge] == 1) out = c2 > (double)7.815f;
         else {
-            const double *c = cam + 24 * A.edge_kf[ge] + 12 * (A.edge_stereo[ge] == 2), *X = pts + 3 * A.edge_point[ge];
+            const double *c = cam + 24 * GA(edge_kf)[ge] + 12 * (GA(edge_stereo)[ge] == 2), *X = pts + 3 * GA(edge_point)[ge];
             const bool depth_pos = (c[6] * X[0] + c[7] * X[1] + c[8] * X[2] + c[11]) > 0.0;
-            const bool close = A.edge_close[ge] != 0;
+            const bool close = GA(edge_close)[ge] != 0;
             out = (c2 > (double)5.991f && !close) || (c2 > (double)(1.5f * 5.991f) && close) || !depth_pos;
         }
-        A.outlier[ge] = out ? 1 : 0;
+        GA(outlier)[ge] = out ? 1 : 0;
         nout += out ? 1.0 : 0.0;
     }
     zero = 0.0;
     team_sum2(T, nout, zero, red);
     if (cur == 1) {                                         // results are read from buffer 0
-        double *k0 = A.kfs + (size_t)W.kf_off * IBA_KF, *p0 = A.pts + (size_t)W.pt_off * 3;
+        double *k0 = GA(kfs) + (size_t)W.kf_off * IBA_KF, *p0 = GA(pts) + (size_t)W.pt_off * 3;
         const double *k1 = k0 + A.kfs_stride, *p1 = p0 + A.pts_stride;
         for (int i = T.gtid; i < W.n_kf * IBA_KF; i += T.gsize) k0[i] = k1[i];
         for (int i = T.gtid; i < W.L * 3; i += T.gsize) p0[i] = p1[i];
     }
-    if (A.prof && g == 0 && tid == 0) { long long *pf = A.prof + 16 * w; pf[0] = t_err; pf[1] = t_build; pf[5] = clock64() - t_k0; }
+    if (GA(prof) && g == 0 && tid == 0) { long long *pf = GA(prof) + 16 * w; pf[0] = t_err; pf[1] = t_build; pf[5] = clock64() - t_k0; }
     if (g == 0 && tid == 0) {
-        orbhip_iba_stats &st = A.stats[w];
+        orbhip_iba_stats &st = GA(stats)[w];
         st.iterations_run = its; st.lm_trials = trials; st.n_outliers = (int)nout;
         st.err = err0; st.err_end = last_chi;
         const float fe = (float)err0, fl = (float)last_chi;
@@ -1167,6 +1239,7 @@ static int iba_pack_range(const orbhip_iba_window *wins, int w0, int w1, double 
         W.nptask = (int)pair_task.size() - W.ptask_off;
         // inertial edges + greedy colouring (edges of one colour share no keyframe)
         std::vector<std::vector<int>> used(g.n_kf);
+        std::vector<int> col_count;
         for (int m = 0; m < g.n_inertial; m++) {
             const int k1 = g.in_kf1[m], k2 = g.in_kf2[m];
             if (k1 < 0 || k1 >= g.n_kf || k2 < 0 || k2 >= g.n_kf || k1 == k2 || !g.kf_imu[k1] || !g.kf_imu[k2]) return ORBHIP_E_BADARG;
@@ -1175,7 +1248,10 @@ static int iba_pack_range(const orbhip_iba_window *wins, int w0, int w1, double 
             while (taken(c)) c++;
             used[k1].push_back(c); used[k2].push_back(c);
             W.ncolors = std::max(W.ncolors, c + 1);
-            in1.push_back(k1); in2.push_back(k2); in_color.push_back(c); in_robust.push_back(g.in_robust[m] ? 1 : 0);
+            if ((int)col_count.size() <= c) col_count.resize(c + 1, 0);
+            if (c > 255) return ORBHIP_E_CAPACITY;               // (a keyframe with more than 255 inertial edges)
+            // colour | rank inside the colour << 8: workgroup 0 deals the edges of a colour to its waves by rank
+            in1.push_back(k1); in2.push_back(k2); in_color.push_back(c | (col_count[c]++ << 8)); in_robust.push_back(g.in_robust[m] ? 1 : 0);
         }
         if (g.n_inertial) {
             in_pre.insert(in_pre.end(), g.in_preint, g.in_preint + (size_t)IBA_PRE * g.n_inertial);
@@ -1204,7 +1280,7 @@ struct orbhip_iba_batch {
     std::vector<double> kfs, pts;           // initial states, concatenated (host): a solve starts from them
     std::vector<uint8_t> blob;              // host image of the constant part while its upload may still be in flight (one-shot call)
     size_t sumKF, sumL, sumE, sumM, sumX, sumH;
-    size_t w_kfs, w_pts, w_xl, w_x, w_W, w_sync, w_stats, w_out, w_prof;
+    size_t w_kfs, w_pts, w_xl, w_x, w_W, w_sync, w_stats, w_out, w_prof, w_args;
     IbaArgs A;                              // kernel argument, iteration parameters filled per solve
     double pack_ms;
 };
@@ -1297,7 +1373,7 @@ static int iba_create_impl(orbhip_ctx *ctx, const orbhip_iba_window *wins, int n
                  w_H = take(8 * sumH), w_S = take(8 * sumH), w_b = take(8 * sumX), w_bs = take(8 * sumX), w_x = take(8 * sumX), w_out = take(sumE),
                  w_kpart = take(27 * 8 * n_kftask), w_ppart = take(42 * 8 * n_pairtask),
                  w_stats = take(sizeof(orbhip_iba_stats) * n_windows), w_prof = take(128 * (size_t)n_windows),
-                 w_sync = take((4 + 4 + 4) * (size_t)n_windows), w_wpart = take(8 * 2 * IBA_MAXG * 2 * (size_t)n_windows);
+                 w_sync = take((4 + 4 + 4) * (size_t)n_windows), w_wpart = take(8 * 2 * IBA_MAXG * 2 * (size_t)n_windows), w_args = take(sizeof(IbaArgs));
     ITRY(hipSetDevice(orbhip_ctx_device_internal(ctx)));
     hipStream_t s = orbhip_ctx_stream_internal(ctx);
     uint8_t *d = nullptr;
@@ -1307,7 +1383,7 @@ static int iba_create_impl(orbhip_ctx *ctx, const orbhip_iba_window *wins, int n
     orbhip_iba_batch *b = new orbhip_iba_batch();
     b->ctx = ctx; b->n_windows = n_windows; b->own = own; b->d = d; b->bytes = off; b->hw = std::move(hw); b->kfs = std::move(kfs); b->pts = std::move(pts);
     b->sumKF = sumKF; b->sumL = sumL; b->sumE = sumE; b->sumM = sumM; b->sumX = sumX; b->sumH = sumH;
-    b->w_kfs = w_kfs; b->w_pts = w_pts; b->w_xl = w_xl; b->w_x = w_x; b->w_W = w_W; b->w_sync = w_sync; b->w_stats = w_stats; b->w_out = w_out; b->w_prof = w_prof;
+    b->w_kfs = w_kfs; b->w_pts = w_pts; b->w_xl = w_xl; b->w_x = w_x; b->w_W = w_W; b->w_sync = w_sync; b->w_stats = w_stats; b->w_out = w_out; b->w_prof = w_prof; b->w_args = w_args;
     b->max_n = std::max(max_n, 32);
     b->blob = std::move(B.bytes);                                    // stays alive until the copy has been waited for
     if (hipMemcpyAsync(d, b->blob.data(), b->blob.size(), hipMemcpyHostToDevice, s) != hipSuccess || (own && hipStreamSynchronize(s) != hipSuccess)) {
@@ -1317,8 +1393,8 @@ static int iba_create_impl(orbhip_ctx *ctx, const orbhip_iba_window *wins, int n
     if (own) std::vector<uint8_t>().swap(b->blob);                   // a persistent batch keeps no host copy
     IbaArgs &A = b->A;
     memset(&A, 0, sizeof(A));
-#define CP(T, o) reinterpret_cast<const T *>(d + (o))
-#define WP(T, o) reinterpret_cast<T *>(d + (o))
+#define CP(T, o) (GPTR(const T))(d + (o))
+#define WP(T, o) (GPTR(T))(d + (o))
     A.win = CP(IbaWin, o_win); A.kf_xoff = CP(int, o_xoff); A.kf_imu = CP(uint8_t, o_imu); A.free_kf = CP(int, o_free);
     A.edge_kf = CP(int, o_ekf); A.edge_point = CP(int, o_ept); A.edge_obs = CP(double, o_obs); A.edge_is2 = CP(double, o_is2);
     A.edge_stereo = CP(uint8_t, o_est); A.edge_close = CP(uint8_t, o_ecl); A.pt_start = CP(int, o_pst);
@@ -1368,10 +1444,10 @@ static int iba_solve_impl(orbhip_iba_batch *b, const orbhip_iba_params *params)
     ITRY(hipMemsetAsync(d + b->w_W, 0, 144 * sumE + 8, s));
     ITRY(hipMemsetAsync(d + b->w_sync, 0, 12 * (size_t)n_windows, s));
     IbaArgs A = b->A;
-    if (want_prof) { ITRY(hipMemsetAsync(d + b->w_prof, 0, 128 * (size_t)n_windows, s)); A.prof = reinterpret_cast<long long *>(d + b->w_prof); }
+    if (want_prof) { ITRY(hipMemsetAsync(d + b->w_prof, 0, 128 * (size_t)n_windows, s)); A.prof = (GPTR(long long))(d + b->w_prof); }
     A.iterations = params->iterations; A.max_trials = params->max_trials; A.large = params->large; A.lambda_init = params->lambda_init;
     const int device = orbhip_ctx_device_internal(ctx);
-    const size_t lds = ba_ldlt_lds_bytes(A.max_n);
+    const size_t lds = std::max(ba_ldlt_lds_bytes(A.max_n), sizeof(double) * (size_t)IBA_WAVES * IBA_STAGE + 16 * (size_t)IBA_THREADS);      // the solver's panel area; the build stages inertial edges (and their records) in it
     if (orb_lds_optin((const void *)k_iba_solve, device, lds) != 0) return ORBHIP_E_HIP;
     // team size: every workgroup of a team must be resident (the barrier spins), so teams are only used while the whole grid fits
     // the device at one 1024-thread workgroup per CU; bigger batches run one workgroup per window
@@ -1388,15 +1464,19 @@ static int iba_solve_impl(orbhip_iba_batch *b, const orbhip_iba_params *params)
     if (G > 1 && !team_lock.try_acquire(device)) G = 1;              // another team grid is in flight on this device
     A.G = G;
     g_iba_last_team = G;
+    // the argument block goes to the device (the kernel's phase functions read it through a global pointer; a by-value kernel argument
+    // whose address is taken is copied to scratch by every thread)
+    const IbaArgs *d_args = reinterpret_cast<const IbaArgs *>(d + b->w_args);
+    ITRY(hipMemcpyAsync(d + b->w_args, &A, sizeof(IbaArgs), hipMemcpyHostToDevice, s));
     if (G == 1) {
-        hipLaunchKernelGGL(k_iba_solve, dim3(n_windows), dim3(IBA_THREADS), lds, s, A);
+        hipLaunchKernelGGL(k_iba_solve, dim3(n_windows), dim3(IBA_THREADS), lds, s, d_args);
         ITRY(hipGetLastError());
     } else {
         // the whole grid must be resident (the team barrier spins): a plain launch has the same residency as a cooperative one
         // (MI355X_MICROARCH.md), so the size rule is checked here instead of by hipLaunchCooperativeKernel (whose launches rocprofv3
         // cannot trace without crashing in the runtime's exit handler on this image: profiles/r03_iba_coop_exit_crash.txt)
         if (8 * G * win_per_xcd > cus * per_cu) { orbhip_set_last_error_internal("inertial BA: team grid larger than the device"); return ORBHIP_E_HIP; }
-        hipLaunchKernelGGL(k_iba_solve, dim3(8 * G * win_per_xcd), dim3(IBA_THREADS), lds, s, A);
+        hipLaunchKernelGGL(k_iba_solve, dim3(8 * G * win_per_xcd), dim3(IBA_THREADS), lds, s, d_args);
         ITRY(hipGetLastError());
     }
     std::vector<int> failv(n_windows);
