@@ -255,7 +255,9 @@ __device__ __forceinline__ bool ldlt_solve_wg(double *S, int ld, int n, const do
         //     still unscaled column jj (U[jj][r] = A[r][jj]) in LDS; every lane reads it back as wave-wide broadcasts.
         if (tid < nb) {
             // (measured alternatives: the column through LDS with look-ahead publishing of column jj + 1: 29.6 k cycles per 32 x 32 block
-            //  against 23.5 k for the register broadcasts below; straight-line FULL code: the scheduler hoists every step's broadcasts
+            //  against 23.5 k for the register broadcasts below; round 4: steps 0..23 reading the published column back as wave-wide
+            //  broadcast reads and only the last eight by v_readlane: 29.5 k -- the write -> read -> multiply-add turnaround of a step
+            //  outlasts its 2 x (31 - jj) v_readlane; straight-line FULL code: the scheduler hoists every step's broadcasts
             //  and spills ~700 SGPRs)
             ldlt_rows2<true, false>(P, U, dval + p0, y + p0, tid, nb, &s_ok);
             rdval[p0 + tid] = ldlt_rcp(dval[p0 + tid]);          // same lane wrote dval[p0 + tid]
