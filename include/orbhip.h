@@ -547,6 +547,12 @@ int orbhip_bow_transform_device(orbhip_ctx *ctx, const uint8_t *d_desc, const in
 int orbhip_compute_stereo_matches_device(orbhip_extractor *left, orbhip_extractor *right, float mb, float mbf,
                                          float *d_u_right, float *d_depth, int32_t *d_n_matches);
 
+/* One stereo frame, HOST outputs: the call behind Frame::ComputeStereoMatches() of host/Frame.cc (src/Frame.cc:802-980, called by the rectified-stereo
+ * constructor at :130).  u_right_out / depth_out [n] = mvuRight / mvDepth of frame 0 of the two extractors' latest extractions (n = the left
+ * frame's keypoint count); *n_matches_out (may be NULL) = matches kept.  Synchronous. */
+int orbhip_compute_stereo_matches_host(orbhip_extractor *left, orbhip_extractor *right, float mb, float mbf,
+                                       float *u_right_out, float *depth_out, int n, int32_t *n_matches_out);
+
 /* ------------------------------------------------------------------ local BA */
 /* One keyframe-window graph in SoA form: what Optimizer::LocalBundleAdjustment builds
  * between src/Optimizer.cc:1850 and :2034.  Poses world->camera as (qx,qy,qz,qw,tx,ty,tz)

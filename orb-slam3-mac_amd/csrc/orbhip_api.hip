@@ -674,6 +674,35 @@ extern "C" int orbhip_compute_stereo_matches_device(orbhip_extractor *left, orbh
     return ORBHIP_OK;
 }
 
+// Host-pointer form for ONE stereo frame: what Frame::ComputeStereoMatches() of host/Frame.cc calls after the two extractors have run
+// (src/Frame.cc:109-130).  mvuRight / mvDepth of frame 0 of the latest extractions, n = its left keypoint count.
+extern "C" int orbhip_compute_stereo_matches_host(orbhip_extractor *left, orbhip_extractor *right, float mb, float mbf,
+                                                  float *u_right_out, float *depth_out, int n, int32_t *n_matches_out)
+{
+    if (!left || !right || n < 0 || (n && (!u_right_out || !depth_out))) return ORBHIP_E_BADARG;
+    if (n_matches_out) *n_matches_out = 0;
+    for (int i = 0; i < n; i++) { u_right_out[i] = -1.0f; depth_out[i] = -1.0f; }      // Frame.cc:804-805
+    if (n == 0) return ORBHIP_OK;
+    if (left->last_batch <= 0 || n > left->P.max_kp) { g_last_error = "stereo: the left extractor holds no extraction of that many keypoints"; return ORBHIP_E_BADARG; }
+    const size_t slots = (size_t)left->max_batch * left->P.max_kp;
+    uint8_t *w = (uint8_t *)orbhip_ctx_work_internal(left->ctx, 8 * slots + 4 * (size_t)left->max_batch + 256);
+    if (!w) return ORBHIP_E_HIP;
+    float *d_ur = (float *)w, *d_dp = d_ur + slots;
+    int32_t *d_nk = (int32_t *)(d_dp + slots);
+    const int rc = orbhip_compute_stereo_matches_device(left, right, mb, mbf, d_ur, d_dp, d_nk);
+    if (rc) return rc;
+    uint8_t *h = (uint8_t *)orbhip_ctx_pinned_internal(left->ctx, 8 * (size_t)n + 16);
+    if (!h) return ORBHIP_E_HIP;
+    hipStream_t st = left->ctx->stream;
+    HIP_TRY(hipMemcpyAsync(h, d_ur, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h + 4 * (size_t)n, d_dp, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h + 8 * (size_t)n, d_nk, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    memcpy(u_right_out, h, 4 * (size_t)n); memcpy(depth_out, h + 4 * (size_t)n, 4 * (size_t)n);
+    if (n_matches_out) memcpy(n_matches_out, h + 8 * (size_t)n, 4);
+    return ORBHIP_OK;
+}
+
 extern "C" int orbhip_extractor_set_profiling(orbhip_extractor *e, int enable)
 {
     if (!e) return ORBHIP_E_BADARG;

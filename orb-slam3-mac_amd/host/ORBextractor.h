@@ -61,6 +61,9 @@ public:
     };
     ImagePyramid mvImagePyramid;
     void SetImagePyramidSync(bool on) { syncPyramid_ = on; }
+    // (not in the reference) the device-side extractor behind this object: Frame::ComputeStereoMatches (host/Frame.cc) pairs the two
+    // extractors' latest extractions where they lie, device pyramids included
+    orbhip_extractor *DeviceExtractor() const { return ext_; }
     void SyncImagePyramid();                       // materialise the host pyramid of the latest extraction now
 
 protected:

@@ -26,6 +26,16 @@ struct CallerState {                      // the members of Tracking / LocalMapp
     ORBextractor *mpORBextractorLeft;
 };
 
+// Frame::Frame(imLeft, imRight, ...) (rectified stereo), src/Frame.cc:109-130: the two ExtractORB threads, then ComputeStereoMatches()
+void frame_stereo_constructor_calls(Frame &F, const cv::Mat &imLeft, const cv::Mat &imRight)
+{
+    vector<int> vLapping = {0, 0};
+    (*F.mpORBextractorLeft)(imLeft, cv::Mat(), F.mvKeys, F.mDescriptors, vLapping);            // :412-413 (flag == 0)
+    (*F.mpORBextractorRight)(imRight, cv::Mat(), F.mvKeysRight, F.mDescriptorsRight, vLapping);  // :415-416
+    F.N = F.mvKeys.size();                                                                        // :121
+    F.ComputeStereoMatches();                                                                     // :130
+}
+
 int tracking_calls(CallerState &S, vector<KeyFrame *> &vpCandidateKFs, bool bMono)
 {
     Frame &mCurrentFrame = S.mCurrentFrame, &mLastFrame = S.mLastFrame;

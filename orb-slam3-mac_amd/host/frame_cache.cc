@@ -76,5 +76,25 @@ ResidentFrame FindResident(int device, const void *kp, const uint8_t *desc, int 
     return res;
 }
 
+ResidentFrame FindResidentIn(orbhip_extractor *ext, const void *kp, const uint8_t *desc, int n)
+{
+    ResidentFrame res;
+    if (!ext || !desc || n <= 0) return res;
+    ExtractorSlot *slot = nullptr;
+    {
+        std::lock_guard<std::mutex> g(g_reg_mu);
+        for (ExtractorSlot *s : registry()) if (s->ext == ext) { slot = s; break; }
+    }
+    if (!slot) return res;
+    std::shared_lock<std::shared_mutex> hold(slot->mu);              // (the caller owns the extractor object: the slot outlives this call)
+    const orbhip_keypoint *dk = nullptr, *hk = nullptr; const uint8_t *dd = nullptr, *hd = nullptr; int32_t cnt = 0;
+    if (orbhip_extractor_last_frame(ext, 0, &dk, &dd, &hk, &hd, &cnt, nullptr) != ORBHIP_OK) return res;
+    if (cnt != n || std::memcmp(hd, desc, (size_t)n * 32) != 0) return res;
+    res.d_desc = dd;
+    res.d_kp = (kp && std::memcmp(hk, kp, (size_t)n * sizeof(orbhip_keypoint)) == 0) ? dk : nullptr;
+    res.hold_ = std::move(hold);
+    return res;
+}
+
 }  // namespace hip
 }  // namespace ORB_SLAM3

@@ -36,6 +36,7 @@ public:
 private:
     std::shared_lock<std::shared_mutex> hold_;
     friend ResidentFrame FindResident(int, const void *, const uint8_t *, int);
+    friend ResidentFrame FindResidentIn(orbhip_extractor *, const void *, const uint8_t *, int);
 };
 
 ExtractorSlot *RegisterExtractor(orbhip_extractor *ext, int device);
@@ -43,6 +44,9 @@ void UnregisterExtractor(ExtractorSlot *slot);
 std::unique_lock<std::shared_mutex> LockForExtraction(ExtractorSlot *slot);
 // kp: n cv::KeyPoint records (28 bytes each) or nullptr, desc: n x 32 bytes.  ORBHIP_FRAME_CACHE=0 switches the lookup off.
 ResidentFrame FindResident(int device, const void *kp, const uint8_t *desc, int n);
+// The same test against ONE extractor's latest extraction (Frame::ComputeStereoMatches needs exactly the left and the right extractor's,
+// whatever else is resident; it has no upload path, so the ORBHIP_FRAME_CACHE switch does not apply).  Waits for a running extraction.
+ResidentFrame FindResidentIn(orbhip_extractor *ext, const void *kp, const uint8_t *desc, int n);
 void EnableFrameCache(bool on);          // run-time switch (measurements: host_latency.cc)
 
 }  // namespace hip

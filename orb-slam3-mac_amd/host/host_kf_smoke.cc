@@ -7,6 +7,8 @@
 #include <map>
 #include <memory>
 #include <set>
+#include <thread>
+#include "ORBextractor.h"
 #include "ORBmatcher.h"
 #include "Optimizer.h"
 #include "flatfile.h"
@@ -339,5 +341,52 @@ int mergeba_smoke(const char *in, const char *out)
     for (int e = 0; e < nE; e++) if (!mps[eMP[e]]->IsInKeyFrame(kfs[eKF[e]].get())) { erased.push_back(eKF[e]); erased.push_back(eMP[e]); }
     O.floats("Tcw", To); O.floats("X", Xo); O.ints("erased", erased); O.one("updates", updates); O.ints("bad", bad); O.one("change", map.mnMapChange);
     printf("HOST_MERGEBA_OK\n");
+    return 0;
+}
+
+// ---- Frame::ComputeStereoMatches through the class (host/Frame.cc): the rectified-stereo constructor's sequence (src/Frame.cc:96-130) --
+// two extractors on two threads with lapping {0, 0}, then ComputeStereoMatches().
+// in: "dims" i[3] (w, h, nfeatures), "left" / "right" u8 [h*w], "cal" f[2] (mb, mbf)
+// out: "n" / "nr", "kp" raw KeyPoint bytes of the left frame as floats-bit-pattern is not needed: "kpx" "kpy" f, "kpo" i; "uright", "depth" f;
+//      "stale": all -1 when the frame is no longer the extractors' latest extraction (must fail loudly, not match something else)
+int stereo_smoke(const char *in, const char *out)
+{
+    FlatFile S;
+    if (!S.load(in)) { fprintf(stderr, "cannot read %s\n", in); return 2; }
+    FlatWriter O(out);
+    const int W = S.I("dims")[0], H = S.I("dims")[1], nfeat = S.I("dims")[2];
+    cv::Mat imL(H, W, CV_8U), imR(H, W, CV_8U), mask;
+    memcpy(imL.data, S.U("left").data(), (size_t)W * H); memcpy(imR.data, S.U("right").data(), (size_t)W * H);
+    ORBextractor exL(nfeat, 1.2f, 8, 20, 7), exR(nfeat, 1.2f, 8, 20, 7);
+    Frame F;
+    F.mpORBextractorLeft = &exL; F.mpORBextractorRight = &exR;
+    F.mb = S.F("cal")[0]; F.mbf = S.F("cal")[1];
+    F.mvScaleFactors = exL.GetScaleFactors();
+    std::vector<int> lap = {0, 0};
+    // Frame::ExtractORB(0, imLeft, 0, 0) / (1, imRight, 0, 0) on two threads (:109-112, :410-417)
+    std::thread tl([&] { exL(imL, mask, F.mvKeys, F.mDescriptors, lap); });
+    std::thread tr([&] { exR(imR, mask, F.mvKeysRight, F.mDescriptorsRight, lap); });
+    tl.join(); tr.join();
+    F.N = (int)F.mvKeys.size();
+    F.ComputeStereoMatches();
+    std::vector<float> kx, ky; std::vector<int32_t> ko;
+    for (const cv::KeyPoint &k : F.mvKeys) { kx.push_back(k.pt.x); ky.push_back(k.pt.y); ko.push_back(k.octave); }
+    O.one("n", F.N); O.one("nr", (int32_t)F.mvKeysRight.size());
+    O.floats("kpx", kx); O.floats("kpy", ky); O.ints("kpo", ko);
+    O.floats("uright", F.mvuRight); O.floats("depth", F.mvDepth);
+    // a second call gives the same answer (nothing was consumed) ...
+    const std::vector<float> ur1 = F.mvuRight, dp1 = F.mvDepth;
+    F.ComputeStereoMatches();
+    int32_t same = F.mvuRight == ur1 && F.mvDepth == dp1;
+    O.one("same", same);
+    // ... and once the left extractor has moved on to another image the old frame is refused
+    std::vector<cv::KeyPoint> k2; cv::Mat d2;
+    exL(imR, mask, k2, d2, lap);
+    F.ComputeStereoMatches();
+    int32_t stale = 1;
+    for (float v : F.mvuRight) if (v != -1.0f) stale = 0;
+    for (float v : F.mvDepth) if (v != -1.0f) stale = 0;
+    O.one("stale", (F.N > 0 && (k2.size() != F.mvKeys.size() || memcmp(k2.data(), F.mvKeys.data(), sizeof(cv::KeyPoint) * k2.size()) != 0)) ? stale : -1);
+    printf("HOST_STEREO_OK\n");
     return 0;
 }

@@ -141,6 +141,30 @@ int latency_main(int reps)
         put(js, "extract_pyramid_first_read", stat(t_read), "first mvImagePyramid[0] access after operator() (Frame::ComputeStereoMatches): 8 levels device -> host + reflect-101 borders");
         put(js, "extract_one_frame_eager_pyramid", stat(t_eager), "operator() with SetImagePyramidSync(true): round 3's behaviour, the whole padded pyramid copied back inside every call");
     }
+    // ---- Frame::ComputeStereoMatches(): the two extractions stay on the device, mvuRight / mvDepth come back
+    {
+        cv::Mat imR(H, W, CV_8U);
+        const int disp = 9;                                                          // right view = left view moved by 9 px (rectified pair)
+        for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) imR.ptr(y)[x] = im1.ptr(y)[std::min(x + disp, W - 1)];
+        ORBextractor exR(1000, 1.2f, 8, 20, 7);
+        std::vector<int> lap0 = {0, 0};
+        Frame F;
+        F.mpORBextractorLeft = &ex; F.mpORBextractorRight = &exR; F.mb = 40.f / 458.f; F.mbf = 40.f;
+        ex(im1, mask, F.mvKeys, F.mDescriptors, lap0);
+        exR(imR, mask, F.mvKeysRight, F.mDescriptorsRight, lap0);
+        F.N = (int)F.mvKeys.size();
+        std::vector<double> t;
+        int nst = 0;
+        for (int r = 0; r < reps + 3; r++) {
+            const Clock::time_point t0 = Clock::now();
+            F.ComputeStereoMatches();
+            if (r >= 3) t.push_back(ms_since(t0));
+        }
+        for (float v : F.mvuRight) nst += v >= 0.f;
+        char b[256];
+        snprintf(b, sizeof(b), "Frame::ComputeStereoMatches(): %d left / %zu right keypoints on the device, mvuRight / mvDepth back on the host (%d matches)", F.N, F.mvKeysRight.size(), nst);
+        put(js, "compute_stereo_matches_one_frame", stat(t), b);
+    }
     // ---- Tracking::TrackWithMotionModel's matcher: the current frame is the one just extracted, the last frame holds map points
     ex(im0, mask, kps0, desc0, lap);
     const std::vector<cv::KeyPoint> k0 = kps0; cv::Mat d0 = desc0.clone();

@@ -319,6 +319,7 @@ int match_smoke(const char *in, const char *out);            // host_match_smoke
 int kf_smoke(const char *in, const char *out);
 int poseopt_smoke(const char *in, const char *out);
 int mergeba_smoke(const char *in, const char *out);
+int stereo_smoke(const char *in, const char *out);
 int latency_main(int reps);                                   // host_latency.cc
 int cachecheck_main();
 
@@ -333,5 +334,6 @@ int main(int argc, char **argv)
     if (argc == 4 && std::string(argv[1]) == "kfmatch") return kf_smoke(argv[2], argv[3]);
     if (argc == 4 && std::string(argv[1]) == "poseopt") return poseopt_smoke(argv[2], argv[3]);
     if (argc == 4 && std::string(argv[1]) == "mergeba") return mergeba_smoke(argv[2], argv[3]);
+    if (argc == 4 && std::string(argv[1]) == "stereo") return stereo_smoke(argv[2], argv[3]);
     return extractor_smoke();
 }

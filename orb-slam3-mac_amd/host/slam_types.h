@@ -346,11 +346,20 @@ public:
 };
 
 // include/Frame.h (the members ORBmatcher.cc:48-218, 710-825, 1965-2181 read or write)
+class ORBextractor;
 class Frame {
 public:
-    Frame() : mbf(0), mb(0), N(0), mpCamera(nullptr), mpCamera2(nullptr), Nleft(-1), Nright(-1), mnScaleLevels(8), mfLogScaleFactor(std::log(1.2f)) {}
+    Frame() : mbf(0), mb(0), N(0), mpORBextractorLeft(nullptr), mpORBextractorRight(nullptr), mpCamera(nullptr), mpCamera2(nullptr), Nleft(-1), Nright(-1),
+              mnScaleLevels(8), mfLogScaleFactor(std::log(1.2f)) {}
     float mbf, mb;
     int N;
+    // rectified stereo (include/Frame.h:153,239-248,296): the two extractors, the right image's features, and what ComputeStereoMatches fills
+    ORBextractor *mpORBextractorLeft, *mpORBextractorRight;
+    cv::Mat mDescriptorsRight;
+    std::vector<float> mvDepth;
+    // Search a match for each keypoint in the left image to a keypoint in the right image.  If there is a match, depth is computed and the
+    // right coordinate associated to the left keypoint is stored.  include/Frame.h:98-99, src/Frame.cc:802-980  (host/Frame.cc)
+    void ComputeStereoMatches();
     std::vector<cv::KeyPoint> mvKeys, mvKeysRight, mvKeysUn;
     std::vector<MapPoint *> mvpMapPoints;
     std::vector<float> mvuRight;

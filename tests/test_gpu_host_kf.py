@@ -748,3 +748,41 @@ def test_merge_local_bundle_adjustment_drop_in(tmp_path, marked):
         for i in np.flatnonzero(fixed == 0):
             assert np.abs(out["Tcw"].reshape(n_kf, 4, 4)[i] - T[i]).max() < 1e-6
         assert np.abs(out["X"].reshape(n_pts, 3) - X).max() > 1e-5
+
+
+# ------------------------------------------------------------------ Frame::ComputeStereoMatches()
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,disp,nfeat,mb,mbf,seed", [(640, 480, 12, 1000, 40.0 / 458.0, 40.0, 72), (640, 480, 3, 1000, 40.0 / 458.0, 40.0, 63),
+                                                        (752, 480, 8, 1500, 4.79, 47.9, 88), (640, 480, -1, 1000, 40.0 / 458.0, 40.0, 60)])
+def test_frame_compute_stereo_matches_drop_in(tmp_path, w, h, disp, nfeat, mb, mbf, seed):
+    """Frame::ComputeStereoMatches() (src/Frame.cc:802-980) through the class, in the rectified-stereo constructor's sequence (:109-130):
+    two ORBextractor objects run on two threads, then the member function fills mvuRight / mvDepth from the two device-resident
+    extractions -- bit-exact against the oracle's extraction + association of the same images; calling it again changes nothing; a frame
+    whose extractor has moved on is refused loudly (everything -1) instead of being matched against another image.  disp -1: a
+    featureless right image (no candidates)."""
+    import oracle_bind as ob
+    from test_oracle_orb import make_stereo_pair
+    left, right = make_stereo_pair(w, h, max(disp, 0), seed=seed)
+    if disp < 0:
+        right = np.full((h, w), 128, np.uint8)
+    out = run_smoke("stereo", tmp_path, dict(dims=np.array([w, h, nfeat], np.int32), left=left.reshape(-1), right=right.reshape(-1),
+                                             cal=np.array([mb, mbf], np.float32)), "HOST_STEREO_OK")
+    eL = ob.OracleExtractor(nfeat, 1.2, 8, 20, 7); eR = ob.OracleExtractor(nfeat, 1.2, 8, 20, 7)
+    kpL, dL, _ = eL.extract(left, (0, 0)); kpR, dR, _ = eR.extract(right, (0, 0))
+    assert out["n"][0] == len(kpL) and out["nr"][0] == len(kpR)
+    assert out["kpx"].tobytes() == kpL["x"].tobytes() and out["kpy"].tobytes() == kpL["y"].tobytes()
+    np.testing.assert_array_equal(out["kpo"], kpL["octave"])
+    if len(kpR):
+        kept, ur_ref, dp_ref, _ = ob.compute_stereo_matches(eL, eR, kpL, dL, kpR, dR, np.float32(mb), np.float32(mbf))
+    else:
+        kept, ur_ref, dp_ref = 0, np.full(len(kpL), -1, np.float32), np.full(len(kpL), -1, np.float32)
+    assert out["uright"].tobytes() == ur_ref.tobytes()
+    assert out["depth"].tobytes() == dp_ref.tobytes()
+    assert (out["uright"] >= 0).sum() == kept
+    if disp >= 0:
+        assert kept > (50 if mb > 1 else 300)
+    else:
+        assert kept == 0
+    assert out["same"][0] == 1
+    assert out["stale"][0] == 1, out["_log"][-800:]
+    assert "not the latest extractions" in out["_log"]
