@@ -45,6 +45,10 @@ const char *orbhip_last_error(void);
 int orbhip_ctx_create(int device, void *stream, orbhip_ctx **out);
 void orbhip_ctx_destroy(orbhip_ctx *ctx);
 int orbhip_ctx_synchronize(orbhip_ctx *ctx);
+/* Stream order across two contexts of one device, without a host synchronisation: everything submitted to `other` so far completes
+ * before anything submitted to `ctx` after this call starts (the reference runs its left / right extractors and its Tracking /
+ * LocalMapping / LoopClosing work on separate host threads, src/Frame.cc:109-112; contexts are this library's unit of concurrency). */
+int orbhip_ctx_wait_for(orbhip_ctx *ctx, orbhip_ctx *other);
 /* Synchronises, then returns and clears the context's sticky device-side error word
  * (ORBHIP_E_CAPACITY when a matcher kernel met more keypoints than it can hold). */
 int orbhip_ctx_check_status(orbhip_ctx *ctx);

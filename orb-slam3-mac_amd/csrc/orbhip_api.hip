@@ -181,6 +181,22 @@ extern "C" int orbhip_ctx_synchronize(orbhip_ctx *c)
     HIP_TRY(hipStreamSynchronize(c->stream));
     return ORBHIP_OK;
 }
+// Stream order across two contexts of one device: everything submitted to `other` so far completes before anything submitted to `c`
+// after this call starts.  What a caller needs to run, say, the two matchers of a frame pair side by side on two contexts and to keep the
+// next extraction from overwriting the arrays they still read.  No host synchronisation.
+extern "C" int orbhip_ctx_wait_for(orbhip_ctx *c, orbhip_ctx *other)
+{
+    if (!c || !other) return ORBHIP_E_BADARG;
+    if (c == other || c->stream == other->stream) return ORBHIP_OK;
+    if (c->device != other->device) { g_last_error = "orbhip_ctx_wait_for: contexts of two devices"; return ORBHIP_E_BADARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    hipEvent_t ev;
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ev, other->stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, ev, 0));
+    HIP_TRY(hipEventDestroy(ev));
+    return ORBHIP_OK;
+}
 extern "C" void *orbhip_ctx_stream(orbhip_ctx *c) { return c ? (void *)c->stream : nullptr; }
 hipStream_t orbhip_ctx_stream_internal(orbhip_ctx *c) { return c->stream; }
 int orbhip_ctx_device_internal(orbhip_ctx *c) { return c->device; }

@@ -68,6 +68,7 @@ lib.orbhip_match_bf2nn_device.argtypes = [vp, vp, vp, sz, vp, vp, sz, ci, ci, cd
 lib.orbhip_search_for_initialization_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, sz, cf, cf, cf, cf, ci, cf, ci,
                                                         vp, vp, vp]
 lib.orbhip_ctx_check_status.argtypes = [vp]
+lib.orbhip_ctx_wait_for.argtypes = [vp, vp]
 lib.orbhip_prev_matched_init_device.argtypes = [vp, vp, sz, ci, ci, vp]
 lib.orbhip_search_by_projection_device.argtypes = [vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, sz, ci, cf, cf, cf, cf, ci, ci, vp, vp]
 lib.orbhip_search_local_map_device.argtypes = [vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, sz, ci, cf, cf, cf, cf, ci, cf, vp, vp]
@@ -95,6 +96,10 @@ class Context:
 
     def check_status(self):
         _chk(lib.orbhip_ctx_check_status(self.h), "orbhip_ctx_check_status")
+
+    def wait_for(self, other):
+        """work submitted to this context from now on starts after everything submitted to `other` so far (no host synchronisation)"""
+        _chk(lib.orbhip_ctx_wait_for(self.h, other.h), "orbhip_ctx_wait_for")
 
     @property
     def stream(self):

@@ -1091,3 +1091,39 @@ def test_rig_assign_features_to_grid(gpu_ctx):
         np.testing.assert_array_equal(cs[f, 3072:], csr + csl[-1])
         np.testing.assert_array_equal(it[f, :csl[-1]], itl[:csl[-1]])
         np.testing.assert_array_equal(it[f, csl[-1]:csl[-1] + csr[-1]], itr[:csr[-1]])
+
+
+@pytest.mark.gpu
+def test_ctx_wait_for_orders_two_contexts(gpu_ctx):
+    """orbhip_ctx_wait_for: stream order across two contexts without a host synchronisation.  The extraction runs on one context, the
+    windowed matcher on another that waits for it, and the first context waits for the matcher before it extracts OTHER images into the
+    same result arrays: the matcher must have seen the first extraction (same matches as the one-context run), many times over."""
+    import torch
+    import orbhip
+    B, W, H = 16, 640, 480
+    imgs = orbhip.synth_frames(W, H, 2 * B, seed=991, first=0)
+    d = torch.from_numpy(imgs).cuda()
+    ctx2 = orbhip.Context(0)
+    ext = orbhip.Extractor(gpu_ctx, 1000, 1.2, 8, 20, 7); ext.reserve(W, H, B)
+    mk = ext.max_keypoints
+    kp, desc, cnt, _ = ext.results_device(); ds = mk * 32
+    prev = torch.zeros((B, mk, 2), dtype=torch.float32, device="cuda")
+    m12 = torch.full((B, mk), -7, dtype=torch.int32, device="cuda"); nm = torch.zeros((B,), dtype=torch.int32, device="cuda")
+
+    def match(c):
+        orbhip.prev_matched_init_device(c, kp, mk, B - 1, mk, prev.data_ptr())
+        orbhip.search_for_initialization_device(c, kp, desc, cnt, kp + mk * 28, desc + ds, cnt + 4, B - 1, mk, mk, (0.0, 0.0, float(W), float(H)), 100, 0.9, True,
+                                                prev.data_ptr(), m12.data_ptr(), nm.data_ptr())
+    ext.extract_device(d.data_ptr(), W, H, W, W * H, B, (0, 0)); match(gpu_ctx); gpu_ctx.synchronize()
+    ref = m12.clone(); ref_n = nm.clone()
+    assert int(ref_n.sum()) > 500
+    for it in range(6):
+        m12.fill_(-7); torch.cuda.synchronize()
+        ext.extract_device(d.data_ptr(), W, H, W, W * H, B, (0, 0))
+        ctx2.wait_for(gpu_ctx)
+        match(ctx2)
+        gpu_ctx.wait_for(ctx2)
+        ext.extract_device(d.data_ptr() + B * W * H, W, H, W, W * H, B, (0, 0))      # overwrites the arrays the matcher read
+        gpu_ctx.synchronize()                                                        # (covers ctx2's work: this context waited for it)
+        assert torch.equal(m12, ref) and torch.equal(nm, ref_n), it
+    ext.close(); ctx2.close()
