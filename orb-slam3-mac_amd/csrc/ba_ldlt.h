@@ -12,6 +12,9 @@
 #define BA_LDLT_MAXN 480
 #define LD_NB 32
 #define LD_PP 33
+#ifndef LDLT_DIAG_DPP
+#define LDLT_DIAG_DPP 1           // 0: the v_readlane form of the diagonal block for every panel (A/B)
+#endif
 static inline size_t ba_ldlt_lds_bytes(int max_n) { return sizeof(double) * ((size_t)max_n * LD_PP + 3 * (size_t)max_n + LD_NB + 32 * 32); }
 
 // One row of a panel through the nb elimination steps of its diagonal block (right-looking LDL^T without pivoting):
@@ -76,6 +79,69 @@ __device__ __forceinline__ void ldlt_rows2(lds_f64 *P, lds_f64 *U, lds_f64 *dv, 
     for (int c = 0; c < LD_NB; c++) if (!DIAG || c <= r) P[r * LD_PP + c] = a[c];
     if (!DIAG) yv[r] = yr;
 }
+// ---- the FULL 32 x 32 diagonal block with row-broadcast multiply-adds (round 4).  ldlt_rows2<true> fetches U[jj][kk] = lane kk's a[jj] with
+// two v_readlane per entry, and the v_readlane -> s_nop -> v_fma_f64 chain of an entry costs ~20 cycles on a wave that has its SIMD to
+// itself: 496 entries x 32 steps were 36 % of the whole solve.  gfx950 can do the broadcast inside the multiply-add: v_fmac_f64 with the DPP
+// control row_newbcast:k reads lane k of the lane's 16-lane ROW as its first operand, at the rate of a plain v_fma_f64
+// (tools/valu_rate.hip: 4.8 cycles per wave-instruction).  The 32 rows sit on two DPP rows (lanes 0..15, 16..31), so per step ONE
+// v_permlane16_swap per dword makes two registers of the pivot column: y0 = row 0's sixteen values in both rows, y1 = row 1's; the update of
+// column kk is then a single instruction on y0 (kk < 16) or y1.  Same operands, same fused multiply-add per entry: bit-identical results.
+template <int K>
+__device__ __forceinline__ void ldlt_fmac_bcast(double &a, double y, double nl)      // a += (lane K of this lane's row of y) * nl
+{
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(y), "v"(nl), "n"(K));
+}
+__device__ __forceinline__ void ldlt_row_pair(double c, double &y0, double &y1)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, c);
+    unsigned clo = (unsigned)u, chi = (unsigned)(u >> 32), tlo, thi;
+    // (the wait states around the swaps and in front of the DPP reads that follow are ours: the hazard recogniser does not look into inline asm)
+    asm volatile("v_mov_b32 %0, %2\n v_mov_b32 %1, %3\n s_nop 1\n v_permlane16_swap_b32 %0, %2\n v_permlane16_swap_b32 %1, %3\n s_nop 1"
+                 : "=&v"(tlo), "=&v"(thi), "+v"(clo), "+v"(chi));
+    y0 = __builtin_bit_cast(double, ((unsigned long long)thi << 32) | tlo);
+    y1 = __builtin_bit_cast(double, ((unsigned long long)chi << 32) | clo);
+}
+template <int KK>
+__device__ __forceinline__ void ldlt_diag_row_update(double (&a)[LD_NB], double y0, double y1, double nl)
+{
+    if constexpr (KK < LD_NB) {
+        ldlt_fmac_bcast<(KK & 15)>(a[KK], KK < 16 ? y0 : y1, nl);
+        ldlt_diag_row_update<KK + 1>(a, y0, y1, nl);
+    }
+}
+template <int JJ>
+__device__ __forceinline__ void ldlt_diag_step(double (&a)[LD_NB], double &yr, bool &ok, lds_f64 *U, lds_f64 *dv, lds_f64 *yv, int r)
+{
+#pragma clang fp contract(fast)
+    U[JJ * LD_NB + r] = a[JJ];                               // unscaled column JJ for the rows below the block (entry JJ = the pivot)
+    if (r == JJ) yv[JJ] = yr;                                // y_JJ is final
+    const double d = readlane_f64(a[JJ], JJ);
+    ok = ok && d != 0.0 && isfinite(d);
+    if (r == JJ) dv[JJ] = d;
+    const double yj = readlane_f64(yr, JJ);
+    double y0, y1;
+    ldlt_row_pair(a[JJ], y0, y1);
+    const double l = a[JJ] * ldlt_rcp(d);
+    yr -= l * yj;
+    ldlt_diag_row_update<JJ + 1>(a, y0, y1, -l);
+    if (r > JJ) a[JJ] = l;
+    if constexpr (JJ + 1 < LD_NB) ldlt_diag_step<JJ + 1>(a, yr, ok, U, dv, yv, r);
+}
+// all 32 lanes of rows 0..31 active (the caller's `tid < 32`), nb == LD_NB
+__device__ __forceinline__ void ldlt_diag_full(lds_f64 *P, lds_f64 *U, lds_f64 *dv, lds_f64 *yv, int r, int *s_ok)
+{
+    double a[LD_NB];
+    asm volatile("" : "+v"(U), "+v"(yv), "+v"(dv));
+#pragma unroll
+    for (int c = 0; c < LD_NB; c++) a[c] = P[r * LD_PP + c];
+    double yr = yv[r];
+    bool ok = true;
+    ldlt_diag_step<0>(a, yr, ok, U, dv, yv, r);
+    if (!ok && r == 0) *s_ok = 0;
+#pragma unroll
+    for (int c = 0; c < LD_NB; c++) if (c <= r) P[r * LD_PP + c] = a[c];
+}
+
 template <bool DIAG>
 __device__ __forceinline__ void ldlt_rows(lds_f64 *P, lds_f64 *U, lds_f64 *dv, lds_f64 *yv, int r, int nb, int *s_ok)
 {
@@ -259,7 +325,8 @@ __device__ __forceinline__ bool ldlt_solve_wg(double *S, int ld, int n, const do
             //  broadcast reads and only the last eight by v_readlane: 29.5 k -- the write -> read -> multiply-add turnaround of a step
             //  outlasts its 2 x (31 - jj) v_readlane; straight-line FULL code: the scheduler hoists every step's broadcasts
             //  and spills ~700 SGPRs)
-            ldlt_rows2<true, false>(P, U, dval + p0, y + p0, tid, nb, &s_ok);
+            if (nb == LD_NB && LDLT_DIAG_DPP) ldlt_diag_full(P, U, dval + p0, y + p0, tid, &s_ok);     // row-broadcast multiply-adds (full panels)
+            else ldlt_rows2<true, false>(P, U, dval + p0, y + p0, tid, nb, &s_ok);
             rdval[p0 + tid] = ldlt_rcp(dval[p0 + tid]);          // same lane wrote dval[p0 + tid]
         }
         __syncthreads();

@@ -79,6 +79,60 @@ __global__ __launch_bounds__(256) void k_mix_lds(uint32_t *out, uint32_t seed)
     out[blockIdx.x * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
 }
 
+// cross-lane probes (round 4): what a wave-wide broadcast costs.  v_readlane writes an SGPR: 8 of them, then one consumer each
+__global__ __launch_bounds__(256) void k_readlane(uint32_t *out, uint32_t seed)
+{
+    uint32_t a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19;
+    uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
+    for (int i = 0; i < ITER; i++) {
+        asm volatile("v_readlane_b32 %8, %0, 3\n v_readlane_b32 %9, %1, 5\n v_readlane_b32 %10, %2, 7\n v_readlane_b32 %11, %3, 9\n"
+                     "v_readlane_b32 %12, %4, 11\n v_readlane_b32 %13, %5, 13\n v_readlane_b32 %14, %6, 15\n v_readlane_b32 %15, %7, 17"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7),
+                       "=s"(s0), "=s"(s1), "=s"(s2), "=s"(s3), "=s"(s4), "=s"(s5), "=s"(s6), "=s"(s7));
+        a0 += s0; a1 += s1; a2 += s2; a3 += s3; a4 += s4; a5 += s5; a6 += s6; a7 += s7;          // 8 v_add_u32 with an SGPR operand
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+}
+#define I_DPPNB(r) "v_mov_b32_dpp " #r ", " #r " row_newbcast:5 row_mask:0xf bank_mask:0xf"
+#define I_DPPQP(r) "v_mov_b32_dpp " #r ", " #r " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+#define I_DPPSHR(r) "v_mov_b32_dpp " #r ", " #r " row_shr:1 row_mask:0xf bank_mask:0xf"
+DEF(k_dpp_newbcast, I_DPPNB) DEF(k_dpp_quadperm, I_DPPQP) DEF(k_dpp_rowshr, I_DPPSHR)
+__global__ __launch_bounds__(256) void k_fma64(uint32_t *out, uint32_t seed)
+{
+    double a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19;
+    const double b = 1.0000001, c = 1e-9;
+    for (int i = 0; i < ITER; i++) {
+        asm volatile("v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %1, %1, %8, %9\n v_fma_f64 %2, %2, %8, %9\n v_fma_f64 %3, %3, %8, %9\n"
+                     "v_fma_f64 %4, %4, %8, %9\n v_fma_f64 %5, %5, %8, %9\n v_fma_f64 %6, %6, %8, %9\n v_fma_f64 %7, %7, %8, %9"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = (uint32_t)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7);
+}
+__global__ __launch_bounds__(256) void k_fma64_dpp(uint32_t *out, uint32_t seed)
+{
+    double a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19;
+    const double b = 1.0000001, c = 1e-9;
+    for (int i = 0; i < ITER; i++) {
+        asm volatile("v_fmac_f64_dpp %0, %8, %9 row_newbcast:3 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %1, %8, %9 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+                     "v_fmac_f64_dpp %2, %8, %9 row_newbcast:5 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %3, %8, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+                     "v_fmac_f64_dpp %4, %8, %9 row_newbcast:7 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %5, %8, %9 row_newbcast:8 row_mask:0xf bank_mask:0xf\n"
+                     "v_fmac_f64_dpp %6, %8, %9 row_newbcast:9 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %7, %8, %9 row_newbcast:10 row_mask:0xf bank_mask:0xf"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = (uint32_t)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7);
+}
+__global__ __launch_bounds__(256) void k_bpermute(uint32_t *out, uint32_t seed)
+{
+    uint32_t a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19;
+    const uint32_t idx = 4 * 7;
+    for (int i = 0; i < ITER; i++) {
+        asm volatile("ds_bpermute_b32 %0, %8, %0\n ds_bpermute_b32 %1, %8, %1\n ds_bpermute_b32 %2, %8, %2\n ds_bpermute_b32 %3, %8, %3\n"
+                     "ds_bpermute_b32 %4, %8, %4\n ds_bpermute_b32 %5, %8, %5\n ds_bpermute_b32 %6, %8, %6\n ds_bpermute_b32 %7, %8, %7\n s_waitcnt lgkmcnt(0)"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(idx) : "memory");
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+}
+
 int main()
 {
     hipDeviceProp_t prop;
@@ -90,7 +144,7 @@ int main()
         {"v_pk_min_i16", k_pkmin}, {"v_pk_max_i16", k_pkmax}, {"v_pk_sub_i16", k_pksub}, {"v_pk_add_u16", k_pkaddu}, {"v_alignbit_b32", k_align},
         {"v_perm_b32", k_perm}, {"v_min_i32", k_min32}, {"v_add_u32", k_add32}, {"v_and_b32", k_and}, {"v_min3_i32", k_min3}, {"v_max3_i16", k_max3i16},
         {"v_min_i16", k_mini16}, {"v_sad_u8", k_sad}, {"v_lshlrev_b32", k_lshl}, {"v_dot4_u32_u8", k_dot4}, {"v_mad_u32_u24", k_mad24}, {"v_pk_mad_i16", k_pkmad},
-        {"v_bfe_u32", k_bfe}, {"8 v_pk_min + 8 SALU (per 8 vector)", k_mix_salu}, {"8 SALU only (per 8 scalar)", k_salu_only}, {"8 v_pk_min + 4 ds_read + 4 v_and/v_xor (per 8)", k_mix_lds}};
+        {"v_bfe_u32", k_bfe}, {"8 v_readlane + 8 v_add(sgpr) (per 16)", k_readlane}, {"v_mov_dpp row_newbcast", k_dpp_newbcast}, {"v_mov_dpp quad_perm", k_dpp_quadperm}, {"v_mov_dpp row_shr", k_dpp_rowshr}, {"v_fma_f64", k_fma64}, {"v_fmac_f64_dpp row_newbcast", k_fma64_dpp}, {"ds_bpermute_b32 (8 + wait)", k_bpermute}, {"8 v_pk_min + 8 SALU (per 8 vector)", k_mix_salu}, {"8 SALU only (per 8 scalar)", k_salu_only}, {"8 v_pk_min + 4 ds_read + 4 v_and/v_xor (per 8)", k_mix_lds}};
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     int clk_khz = 0;
