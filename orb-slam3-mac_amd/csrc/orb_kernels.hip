@@ -302,6 +302,22 @@ __device__ __forceinline__ s16x2 as_s16x2(uint32_t v) { return __builtin_bit_cas
 __device__ __forceinline__ uint32_t as_u32(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ s16x2 pkmin(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ s16x2 pkmax(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
+// Three-input packed min / max (round 4).  gfx950 has no v_pk_min3_i16, but v_pk_minimum3_f16 / v_pk_maximum3_f16 -- and a u16 pattern 0..255
+// read as an f16 is the subnormal k x 2^-24 (f16 denormals are not flushed), whose order is the integers' order: for pixel values the two
+// instructions ARE the integer min / max of three, exactly (all 2^24 triples checked on the device) and at the full rate (4.7 cycles per
+// wave-instruction).  Only for operands known to be pixel values (never -1 / NaN patterns).
+__device__ __forceinline__ s16x2 pkmin3(s16x2 a, s16x2 b, s16x2 c)
+{
+    uint32_t r;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(as_u32(a)), "v"(as_u32(b)), "v"(as_u32(c)));
+    return as_s16x2(r);
+}
+__device__ __forceinline__ s16x2 pkmax3(s16x2 a, s16x2 b, s16x2 c)
+{
+    uint32_t r;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(as_u32(a)), "v"(as_u32(b)), "v"(as_u32(c)));
+    return as_s16x2(r);
+}
 // pixel pair starting one pixel to the right of dword `lo`'s first pixel: (lo.hi, hi.lo)
 __device__ __forceinline__ s16x2 pair_odd(uint32_t hi, uint32_t lo) { return as_s16x2(__builtin_amdgcn_alignbit(hi, lo, 16)); }
 
@@ -315,8 +331,8 @@ __device__ __forceinline__ s16x2 fc_compass(const uint32_t *q)
     const s16x2 e = pair_odd(q[2], q[1]), w = pair_odd(q[-1], q[-2]);
     const s16x2 se = as_s16x2(q[2 * PITCH + 1]), nw = as_s16x2(q[-2 * PITCH - 1]);
     const s16x2 ne = as_s16x2(q[-2 * PITCH + 1]), sw = as_s16x2(q[2 * PITCH - 1]);
-    const s16x2 lo = pkmax(pkmax(pkmin(n, s), pkmin(e, w)), pkmax(pkmin(se, nw), pkmin(ne, sw)));
-    const s16x2 hi = pkmin(pkmin(pkmax(n, s), pkmax(e, w)), pkmin(pkmax(se, nw), pkmax(ne, sw)));
+    const s16x2 lo = pkmax(pkmax3(pkmin(n, s), pkmin(e, w), pkmin(se, nw)), pkmin(ne, sw));
+    const s16x2 hi = pkmin(pkmin3(pkmax(n, s), pkmax(e, w), pkmax(se, nw)), pkmax(ne, sw));
     return pkmax(v - lo, hi - v);
 }
 
@@ -344,13 +360,17 @@ __device__ __forceinline__ s16x2 fc_arc_score(const uint32_t *q)
     for (int m = 0; m < 8; m++) { lo2[m] = pkmin(p[2 * m + 1], p[(2 * m + 2) & 15]); hi2[m] = pkmax(p[2 * m + 1], p[(2 * m + 2) & 15]); }
 #pragma unroll
     for (int m = 0; m < 8; m++) { lo4[m] = pkmin(lo2[m], lo2[(m + 1) & 7]); hi4[m] = pkmax(hi2[m], hi2[(m + 1) & 7]); }
-    s16x2 Lo = (s16x2){-1, -1}, Hi = (s16x2){256, 256};
+    // per odd start m: the darkest pixel of the better of its two 9-arcs / the brightest one (three-input forms: one instruction each)
+    s16x2 xl[8], xh[8];
 #pragma unroll
     for (int m = 0; m < 8; m++) {
         const s16x2 e0 = p[2 * m], e1 = p[(2 * m + 9) & 15];
-        Lo = pkmax(Lo, pkmin(pkmin(lo4[m], lo4[(m + 2) & 7]), pkmax(e0, e1)));      // brightest "darkest pixel of an arc"
-        Hi = pkmin(Hi, pkmax(pkmax(hi4[m], hi4[(m + 2) & 7]), pkmin(e0, e1)));      // darkest "brightest pixel of an arc"
+        xl[m] = pkmin3(lo4[m], lo4[(m + 2) & 7], pkmax(e0, e1));
+        xh[m] = pkmax3(hi4[m], hi4[(m + 2) & 7], pkmin(e0, e1));
     }
+    // Lo = brightest "darkest pixel of an arc", Hi = darkest "brightest pixel of an arc"
+    const s16x2 Lo = pkmax(pkmax3(pkmax3(xl[0], xl[1], xl[2]), xl[3], xl[4]), pkmax3(xl[5], xl[6], xl[7]));
+    const s16x2 Hi = pkmin(pkmin3(pkmin3(xh[0], xh[1], xh[2]), xh[3], xh[4]), pkmin3(xh[5], xh[6], xh[7]));
     const s16x2 v = as_s16x2(q[0]);
     return pkmax(v - Hi, Lo - v);
 }
@@ -571,8 +591,8 @@ __global__ __launch_bounds__(64) void k_fast_cells(FastParams P)
 #define FC_U(v) as_s16x2(__builtin_amdgcn_perm(0u, (uint32_t)(v), 0x0c010c00u))                          /* left | right << 8  ->  packed halves */
                     sc = q[0];
                     const s16x2 V = pkmax(FC_U(q[-SPITCH]), FC_U(q[SPITCH]));                                  // above / below each pixel
-                    const s16x2 Lc = pkmax(pkmax(FC_U(q[-SPITCH - 1]), FC_U(q[-1])), FC_U(q[SPITCH - 1]));     // .y: column left of the pair
-                    const s16x2 Rc = pkmax(pkmax(FC_U(q[-SPITCH + 1]), FC_U(q[1])), FC_U(q[SPITCH + 1]));      // .x: column right of the pair
+                    const s16x2 Lc = pkmax3(FC_U(q[-SPITCH - 1]), FC_U(q[-1]), FC_U(q[SPITCH - 1]));     // .y: column left of the pair
+                    const s16x2 Rc = pkmax3(FC_U(q[-SPITCH + 1]), FC_U(q[1]), FC_U(q[SPITCH + 1]));      // .x: column right of the pair
 #undef FC_U
                     const int sl = (int)(sc & 0xFFu), sr = (int)(sc >> 8);
                     const int nbl = max(max((int)V.x, (int)V.y), max((int)Lc.y, sr));                // L: above, below, the R column (3 rows), left column
@@ -777,8 +797,8 @@ __global__ __launch_bounds__(64) void k_fast_runs(FastParams P)
                         const s16x2 e = pair_odd(cp2[i], rp[i + 3]), w = pair_odd(rm[i + 3], cm2[i]);
                         const s16x2 se = as_s16x2(rp[i + 5]), nw = as_s16x2(rm[i + 1]);
                         const s16x2 ne = as_s16x2(rp[i + 1]), sw = as_s16x2(rm[i + 5]);
-                        const s16x2 lo = pkmax(pkmax(pkmin(n, so), pkmin(e, w)), pkmax(pkmin(se, nw), pkmin(ne, sw)));
-                        const s16x2 hi = pkmin(pkmin(pkmax(n, so), pkmax(e, w)), pkmin(pkmax(se, nw), pkmax(ne, sw)));
+                        const s16x2 lo = pkmax(pkmax3(pkmin(n, so), pkmin(e, w), pkmin(se, nw)), pkmin(ne, sw));
+                        const s16x2 hi = pkmin(pkmin3(pkmax(n, so), pkmax(e, w), pkmax(se, nw)), pkmax(ne, sw));
                         const s16x2 M = pkmax(v - lo, hi - v);
                         f[i] = y0 + i < rows_on && (as_u32(M - thP) & SIGN) != SIGN;
                     }
@@ -822,8 +842,8 @@ __global__ __launch_bounds__(64) void k_fast_runs(FastParams P)
 #define FC_U(v) as_s16x2(__builtin_amdgcn_perm(0u, (uint32_t)(v), 0x0c010c00u))                          /* left | right << 8  ->  packed halves */
                     sc = q[0];
                     const s16x2 V = pkmax(FC_U(q[-SPITCH]), FC_U(q[SPITCH]));                                  // above / below each pixel
-                    const s16x2 Lc = pkmax(pkmax(FC_U(q[-SPITCH - 1]), FC_U(q[-1])), FC_U(q[SPITCH - 1]));     // .y: column left of the pair
-                    const s16x2 Rc = pkmax(pkmax(FC_U(q[-SPITCH + 1]), FC_U(q[1])), FC_U(q[SPITCH + 1]));      // .x: column right of the pair
+                    const s16x2 Lc = pkmax3(FC_U(q[-SPITCH - 1]), FC_U(q[-1]), FC_U(q[SPITCH - 1]));     // .y: column left of the pair
+                    const s16x2 Rc = pkmax3(FC_U(q[-SPITCH + 1]), FC_U(q[1]), FC_U(q[SPITCH + 1]));      // .x: column right of the pair
 #undef FC_U
                     const int xl = 2 * qp, xr = xl + 1;
                     const int sl = (int)(sc & 0xFFu), sr = (int)(sc >> 8);
