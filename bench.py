@@ -1029,7 +1029,7 @@ def main():
         ab = algorithmic_bytes(W, H, n_kp_avg, n_cand_avg)
         # the dominant kernel of the step: largest device time among ALL of its kernels (separate profiled pass).
         # one stage == one kernel (SURVEY's "FAST read S" = k_fast_cells, "blur read+write 2S" = k_blur)
-        kern = {"pyramid": "k_resize_rows", "blur": "k_blur_rows", "fast_cells": "k_fast_cells", "octree": "k_octree",
+        kern = {"pyramid": "k_resize_rows", "blur": ext.blur_kernel(B), "fast_cells": "k_fast_cells", "octree": "k_octree",
                 "desc": "k_orient_desc", "assemble": "k_assemble", "match_bf2nn": "k_bf2nn_mfma", "search_init": "k_search_init"}
 
         def profile_entry(table, name):                     # template instances are listed as "k_fast_cells<3, 24, 2>"

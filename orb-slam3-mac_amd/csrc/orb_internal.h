@@ -47,6 +47,7 @@ struct OrbParams {
     int max_kp;               // output row capacity per frame
     int oct_nc;               // k_octree: node capacity of its LDS arrays = max over levels of max(quota + 16, 4*nIni + 4)
     int rows_min_batch;       // the row-streaming pyramid / blur kernels are used from this batch size on (below it the tile kernels have the shorter latency)
+    int bm_min_batch;         // the matrix-core blur (k_blur_mfma) is used from this batch size on (its tables exist when bm_cols[nlevels] > 0)
     int br_blocks[ORB_MAX_LEVELS + 1];  // k_blur_rows: prefix of 256-lane workgroups per frame over the levels; [nlevels] == 0: k_blur (tiles) is used
     int bs_tiles[ORB_MAX_LEVELS + 1];   // k_blur: prefix of 64x32 tiles per frame over the levels (one launch for all levels)
     int lap0, lap1;

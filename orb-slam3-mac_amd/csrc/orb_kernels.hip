@@ -1684,7 +1684,7 @@ __global__ __launch_bounds__(256) void k_blur_mfma(OrbParams P, int frame0, int 
 
 void orb_launch_blur(const OrbParams &P, hipStream_t s, int wgs_per_cu, int frame0, int nframes)
 {
-    if (P.bm_cols[P.nlevels] > 0 && P.batch >= P.rows_min_batch) {
+    if (P.bm_cols[P.nlevels] > 0 && P.batch >= P.bm_min_batch) {
         if (nframes < 0) nframes = P.batch - frame0;
         const long waves = (long)P.bm_cols[P.nlevels] * nframes;
         if (nframes > 0) hipLaunchKernelGGL(k_blur_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, P, frame0, nframes);

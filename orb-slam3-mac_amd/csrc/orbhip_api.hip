@@ -560,9 +560,16 @@ extern "C" int orbhip_extractor_reserve(orbhip_extractor *e, int width, int heig
     {   // k_blur_mfma operand tables (orb_kernels.hip): horizontal band per (level, 32-column tile column, 16-column block) with the image
         // borders folded in and the kernel's chunk rule mirrored; vertical band per 16-row output block in the slot order the accumulator
         // layout of pass 1 dictates.  Not used (k_blur_rows stays) for levels narrower than 32 or shorter than 8.
-        // OPT-IN (ORBHIP_BLUR_MFMA=1 when the extractor is created): bit-exact, but measured no faster than k_blur_rows at VGA (3.72-3.76 vs
-        // 3.73-3.78 ms per step) and 10 % slower at 1080p -- kept as a tested alternative, not as the default.
-        bool ok = getenv("ORBHIP_BLUR_MFMA") && atoi(getenv("ORBHIP_BLUR_MFMA")) == 1 && P.br_blocks[e->nlevels] > 0;
+        // Round 4: the DEFAULT for images of up to half a megapixel in batches of 256 frames or more -- where the blur runs beside
+        // k_fast_cells and the pair is bound by the sum of their vector instructions, the matrix-core form needs ~6 per pixel against 14
+        // (measured after k_fast_cells lost 9 % of its own: 3.67 against 3.73 ms per 1024-frame VGA step, two A/B pairs; in round 3 the
+        // two were even).  Alone it is the slower kernel (0.93 against 0.75 ms), and at 1080p / 4K, where the blur is a smaller share of
+        // a step that is bound elsewhere, 12 % slower in the step: k_blur_rows stays for small batches and big images.
+        // ORBHIP_BLUR_MFMA=1: every batch that takes the row-streaming kernels, any size; =0: never.  Bit-exact either way.
+        const char *bm_env = getenv("ORBHIP_BLUR_MFMA");
+        const bool bm_force = bm_env && atoi(bm_env) == 1, bm_off = bm_env && atoi(bm_env) == 0;
+        bool ok = !bm_off && (bm_force || (size_t)width * height <= (size_t)512 * 1024) && P.br_blocks[e->nlevels] > 0;
+        P.bm_min_batch = bm_force ? P.rows_min_batch : 256;
         int S = 0;
         for (int i = 0; i < 7; i++) { S += e->gauss_q8[i]; if (e->gauss_q8[i] < 0 || e->gauss_q8[i] > 63) ok = false; }     // two folded taps must fit int8
         if (255 * S > 65535) ok = false;                                                                                  // row sums must fit 16 bits
@@ -717,6 +724,16 @@ extern "C" int orbhip_compute_stereo_matches_host(orbhip_extractor *left, orbhip
     memcpy(u_right_out, h, 4 * (size_t)n); memcpy(depth_out, h + 4 * (size_t)n, 4 * (size_t)n);
     if (n_matches_out) memcpy(n_matches_out, h + 8 * (size_t)n, 4);
     return ORBHIP_OK;
+}
+
+// which kernel blurs a batch of that many frames: 0 = the LDS tile kernel, 1 = k_blur_rows, 2 = k_blur_mfma (bench.py labels its stage with it)
+extern "C" int orbhip_extractor_blur_kernel(const orbhip_extractor *e, int batch)
+{
+    if (!e || !e->max_batch) return -1;
+    const OrbParams &P = e->P;
+    if (P.bm_cols[e->nlevels] > 0 && batch >= P.bm_min_batch) return 2;
+    if (P.br_blocks[e->nlevels] > 0 && batch >= P.rows_min_batch) return 1;
+    return 0;
 }
 
 extern "C" int orbhip_extractor_set_profiling(orbhip_extractor *e, int enable)

@@ -69,6 +69,8 @@ lib.orbhip_search_for_initialization_device.argtypes = [vp, vp, vp, vp, vp, vp, 
                                                         vp, vp, vp]
 lib.orbhip_ctx_check_status.argtypes = [vp]
 lib.orbhip_ctx_wait_for.argtypes = [vp, vp]
+lib.orbhip_extractor_blur_kernel.argtypes = [vp, ci]
+lib.orbhip_extractor_blur_kernel.restype = ci
 lib.orbhip_prev_matched_init_device.argtypes = [vp, vp, sz, ci, ci, vp]
 lib.orbhip_search_by_projection_device.argtypes = [vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, sz, ci, cf, cf, cf, cf, ci, ci, vp, vp]
 lib.orbhip_search_local_map_device.argtypes = [vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, sz, ci, cf, cf, cf, cf, ci, cf, vp, vp]
@@ -147,6 +149,10 @@ class Extractor:
     @property
     def max_keypoints(self):
         return lib.orbhip_extractor_max_keypoints(self.h)
+
+    def blur_kernel(self, batch):
+        """the kernel that blurs a batch of that many frames: 'k_blur' (LDS tiles), 'k_blur_rows' or 'k_blur_mfma'"""
+        return ("k_blur", "k_blur_rows", "k_blur_mfma")[lib.orbhip_extractor_blur_kernel(self.h, int(batch))]
 
     def set_graph_mode(self, on):
         _chk(lib.orbhip_extractor_set_graph_mode(self.h, 1 if on else 0), "orbhip_extractor_set_graph_mode")
