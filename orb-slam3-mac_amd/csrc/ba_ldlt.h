@@ -110,22 +110,24 @@ __device__ __forceinline__ void ldlt_diag_row_update(double (&a)[LD_NB], double 
     }
 }
 template <int JJ>
-__device__ __forceinline__ void ldlt_diag_step(double (&a)[LD_NB], double &yr, bool &ok, lds_f64 *U, lds_f64 *dv, lds_f64 *yv, int r)
+__device__ __forceinline__ void ldlt_diag_step(double (&a)[LD_NB], double &yr, bool &ok, lds_f64 *U, double &d_own, double &y_own, int r)
 {
 #pragma clang fp contract(fast)
     U[JJ * LD_NB + r] = a[JJ];                               // unscaled column JJ for the rows below the block (entry JJ = the pivot)
-    if (r == JJ) yv[JJ] = yr;                                // y_JJ is final
     const double d = readlane_f64(a[JJ], JJ);
     ok = ok && d != 0.0 && isfinite(d);
-    if (r == JJ) dv[JJ] = d;
     const double yj = readlane_f64(yr, JJ);
+    // lane JJ keeps its pivot and its (now final) right-hand side in registers; both go to LDS once, after the last step (a masked
+    // store per step meant an EXEC mask restored from a spilled SGPR pair by two v_readlane, twice per step)
+    d_own = r == JJ ? d : d_own;
+    y_own = r == JJ ? yr : y_own;
     double y0, y1;
     ldlt_row_pair(a[JJ], y0, y1);
     const double l = a[JJ] * ldlt_rcp(d);
     yr -= l * yj;
     ldlt_diag_row_update<JJ + 1>(a, y0, y1, -l);
     if (r > JJ) a[JJ] = l;
-    if constexpr (JJ + 1 < LD_NB) ldlt_diag_step<JJ + 1>(a, yr, ok, U, dv, yv, r);
+    if constexpr (JJ + 1 < LD_NB) ldlt_diag_step<JJ + 1>(a, yr, ok, U, d_own, y_own, r);
 }
 // all 32 lanes of rows 0..31 active (the caller's `tid < 32`), nb == LD_NB
 __device__ __forceinline__ void ldlt_diag_full(lds_f64 *P, lds_f64 *U, lds_f64 *dv, lds_f64 *yv, int r, int *s_ok)
@@ -136,7 +138,9 @@ __device__ __forceinline__ void ldlt_diag_full(lds_f64 *P, lds_f64 *U, lds_f64 *
     for (int c = 0; c < LD_NB; c++) a[c] = P[r * LD_PP + c];
     double yr = yv[r];
     bool ok = true;
-    ldlt_diag_step<0>(a, yr, ok, U, dv, yv, r);
+    double d_own = 0.0, y_own = 0.0;
+    ldlt_diag_step<0>(a, yr, ok, U, d_own, y_own, r);
+    dv[r] = d_own; yv[r] = y_own;
     if (!ok && r == 0) *s_ok = 0;
 #pragma unroll
     for (int c = 0; c < LD_NB; c++) if (c <= r) P[r * LD_PP + c] = a[c];
