@@ -790,7 +790,11 @@ static int run_pipeline(orbhip_extractor *e, int batch, int lap0, int lap1)
     for (int l = 0; l < e->nlevels; l++) { F.lv[l].img = P.lv[l].img; F.lv[l].frame_stride = P.lv[l].img_frame_stride; F.lv[l].img_pitch = P.lv[l].img_pitch; }
     F.batch = batch; F.n_cus = e->ctx->n_cus; F.cell_count = P.cell_count; F.cell_list = P.cell_list; F.cell_list_frame_stride = P.cell_list_frame_stride; F.status = P.status;
     const bool rows = P.br_blocks[e->nlevels] > 0 && batch >= P.rows_min_batch;      // the row-streaming blur needs no LDS: k_fast_cells keeps its full grid
-    const int fast_waves = fork ? tune_int("ORBHIP_TUNE_FAST_WAVES", rows ? 0 : 10) : 0;
+    // waves of k_fast_cells per CU while the blur runs beside it: 10 next to the LDS tile blur; 18 (of the 23 the LDS would hold) next to the
+    // row-streaming / matrix-core kernels, which need wave slots and registers, not LDS -- measured in one call on one box (round 4, 1024 VGA
+    // frames, matrix-core blur): 23 waves 3.79 ms per step, 22: 3.84, 20: 3.72, 18: 3.69, 16: 3.74, 14: 3.80; 1080p / 512 frames
+    // (row-streaming blur): 49.2 k -> 50.7 k frames/s; VGA with the row-streaming blur: 3.82 either way
+    const int fast_waves = fork ? tune_int("ORBHIP_TUNE_FAST_WAVES", rows ? 18 : 10) : 0;
     STAGE_MARK(ORBHIP_STAGE_PYRAMID);
     if (fork && e->nlevels > 1 && rows && tune_int("ORBHIP_TUNE_L0_EARLY", 0)) {
         // (off by default: measured 3.90 ms vs 3.84 ms per step)
