@@ -101,7 +101,7 @@ int orbhip_extract_batch_host_view(orbhip_extractor *ext, const uint8_t *h_image
                                    size_t frame_stride, int batch, int lap0, int lap1, const orbhip_keypoint **kp_view,
                                    const uint8_t **desc_view, int *row_capacity, const int32_t **count_view, const int32_t **mono_view);
 /* Which kernel blurs a batch of `batch` frames on this extractor's geometry: 0 the LDS tile kernel (small batches), 1 the row-streaming
- * kernel, 2 the matrix-core one (images of up to half a megapixel in batches of 256 frames or more; ORBHIP_BLUR_MFMA=0 / 1 overrides).
+ * kernel, 2 the matrix-core one (images of up to 320 K pixels (VGA) in batches of 128 frames or more; ORBHIP_BLUR_MFMA=0 / 1 overrides).
  * All three are bit-exact; the choice is a measured one. */
 int orbhip_extractor_blur_kernel(const orbhip_extractor *ext, int batch);
 

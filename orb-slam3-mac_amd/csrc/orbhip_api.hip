@@ -560,7 +560,7 @@ extern "C" int orbhip_extractor_reserve(orbhip_extractor *e, int width, int heig
     {   // k_blur_mfma operand tables (orb_kernels.hip): horizontal band per (level, 32-column tile column, 16-column block) with the image
         // borders folded in and the kernel's chunk rule mirrored; vertical band per 16-row output block in the slot order the accumulator
         // layout of pass 1 dictates.  Not used (k_blur_rows stays) for levels narrower than 32 or shorter than 8.
-        // Round 4: the DEFAULT for images of up to half a megapixel in batches of 256 frames or more -- where the blur runs beside
+        // Round 4: the DEFAULT for images of up to 320 K pixels (VGA) in batches of 128 frames or more -- where the blur runs beside
         // k_fast_cells and the pair is bound by the sum of their vector instructions, the matrix-core form needs ~6 per pixel against 14
         // (measured after k_fast_cells lost 9 % of its own: 3.67 against 3.73 ms per 1024-frame VGA step, two A/B pairs; in round 3 the
         // two were even).  Alone it is the slower kernel (0.93 against 0.75 ms), and at 1080p / 4K, where the blur is a smaller share of
@@ -568,8 +568,10 @@ extern "C" int orbhip_extractor_reserve(orbhip_extractor *e, int width, int heig
         // ORBHIP_BLUR_MFMA=1: every batch that takes the row-streaming kernels, any size; =0: never.  Bit-exact either way.
         const char *bm_env = getenv("ORBHIP_BLUR_MFMA");
         const bool bm_force = bm_env && atoi(bm_env) == 1, bm_off = bm_env && atoi(bm_env) == 0;
-        bool ok = !bm_off && (bm_force || (size_t)width * height <= (size_t)512 * 1024) && P.br_blocks[e->nlevels] > 0;
-        P.bm_min_batch = bm_force ? P.rows_min_batch : 256;
+        // (crossover measured in one call per pair, frames/s matrix cores / rows: 640x480 x 1024: 278 k / 270 k, x 128: 184.3 k / 181.4 k;
+        //  752x480 x 1024: 247.8 k / 249.7 k; 1280x720 x 512: 98.9 k / 104.0 k; 1920x1080 x 512: 44.2 k / 50.1 k)
+        bool ok = !bm_off && (bm_force || (size_t)width * height <= (size_t)320 * 1024) && P.br_blocks[e->nlevels] > 0;
+        P.bm_min_batch = bm_force ? P.rows_min_batch : 128;
         int S = 0;
         for (int i = 0; i < 7; i++) { S += e->gauss_q8[i]; if (e->gauss_q8[i] < 0 || e->gauss_q8[i] > 63) ok = false; }     // two folded taps must fit int8
         if (255 * S > 65535) ok = false;                                                                                  // row sums must fit 16 bits

@@ -126,7 +126,7 @@ def test_blur_on_the_matrix_cores_is_bit_exact(gpu_ctx, monkeypatch):
 
 def test_default_blur_kernel_by_size_and_batch(gpu_ctx, monkeypatch):
     """The blur kernel a batch takes is a measured choice (orbhip_extractor_blur_kernel): LDS tiles below 16 frames, the row-streaming
-    kernel from there, the matrix-core one for images of up to half a megapixel in batches of 256 frames or more -- and every choice
+    kernel from there, the matrix-core one for images of up to 320 K pixels in batches of 128 frames or more -- and every choice
     gives the same bytes: a 256-frame VGA batch (matrix cores by default) equals the same frames extracted 8 at a time (tiles) and with
     ORBHIP_BLUR_MFMA=0 (rows), frame by frame; the first frames also against the oracle."""
     import orbhip
@@ -134,7 +134,7 @@ def test_default_blur_kernel_by_size_and_batch(gpu_ctx, monkeypatch):
     imgs = orbhip.synth_frames(640, 480, 256, seed=77)
     ext, ora = _mk(gpu_ctx)
     ext.reserve(640, 480, 256)
-    assert (ext.blur_kernel(1), ext.blur_kernel(16), ext.blur_kernel(255), ext.blur_kernel(256)) == ("k_blur", "k_blur_rows", "k_blur_rows", "k_blur_mfma")
+    assert (ext.blur_kernel(1), ext.blur_kernel(16), ext.blur_kernel(127), ext.blur_kernel(128)) == ("k_blur", "k_blur_rows", "k_blur_rows", "k_blur_mfma")
     big = ext.extract_host(imgs)
     for f in range(2):
         _compare_frame(ext, ora, imgs, f, (0, 1000), big)          # (reads the levels of the extraction just made: before the small batches)
@@ -154,7 +154,7 @@ def test_default_blur_kernel_by_size_and_batch(gpu_ctx, monkeypatch):
     monkeypatch.delenv("ORBHIP_BLUR_MFMA", raising=False)
     exth, _ = _mk(gpu_ctx, nfeat=2000)
     exth.reserve(1920, 1080, 4)
-    assert exth.blur_kernel(512) == "k_blur_rows"           # above half a megapixel the row-streaming kernel stays
+    assert exth.blur_kernel(512) == "k_blur_rows"           # above VGA the row-streaming kernel stays
     exth.close()
 
 
