@@ -83,7 +83,7 @@ struct IbaArgs {
     GPTR(const int) kf_edges;                // the visual edges of every free keyframe, keyframe by keyframe
     GPTR(const int4) kf_task;                // {free block f, first, end (into kf_edges), 0}: chunks of <= IBA_KF_CHUNK edges
     GPTR(const int) kf_task_start;           // per window nfree + 1: the chunks of block f
-    GPTR(const int4) pair_ent;               // {edge of block i, edge of block j, the landmark, 0} of every landmark both see, pair by pair (i <= j, row-major)
+    GPTR(const int2) pair_ent;               // {edge of block i, edge of block j} of every landmark both see, pair by pair (i <= j, row-major)
     GPTR(const int4) pair_task;              // {pair, first, end (into pair_ent), i == j}: chunks of <= IBA_PAIR_CHUNK entries
     GPTR(const int) pair_task_start;         // per window npairs + 1
     GPTR(const int) in_kf1; GPTR(const int) in_kf2; GPTR(const int) in_color; GPTR(const uint8_t) in_robust;
@@ -736,17 +736,17 @@ __device__ __forceinline__ void pair_task(const IbaCtx &C, int4 task, bool diag,
 {
     const IbaWin &W = *gen(C.W); const IbaArgs &A = *gen(C.A);
     const int lane = threadIdx.x & 63;
-    const int4 *pair_ent = GA(pair_ent) + W.pent_off;
+    const int2 *pair_ent = GA(pair_ent) + W.pent_off;
     constexpr int NB = HALF ? 0 : 6;
     double acc[18 + NB + 1];
 #pragma unroll
     for (int q = 0; q < 18 + NB; q++) acc[q] = 0.0;
-    // an entry names its two edges AND its landmark: the blocks and D^-1 are fetched in ONE round trip after the entry (round 3 went
-    // entry -> edge -> landmark -> D^-1: three dependent L2 round trips per 64 entries of a chunk)
+    // (round 4: entries that also carry their landmark -- one dependent L2 round trip fewer per 64 entries -- took 0.4 % off the kernel and
+    // DOUBLED the host packing of a one-shot batch, whose scattered 16-byte stores are its hot loop: 5.2 -> 13.9 ms per 32 windows; undone)
     for (int t = task.y + lane; t < task.z; t += 64) {
-        const int4 en = pair_ent[t];
+        const int2 en = pair_ent[t];
         const size_t gi = (size_t)W.e_off + en.x, gj = (size_t)W.e_off + en.y;
-        const size_t gl = (size_t)W.pt_off + en.z;
+        const size_t gl = (size_t)W.pt_off + GA(edge_point)[gi];
         const double *Wi = GA(W) + 18 * gi, *Wj = GA(W) + 18 * gj + 9 * HALF, *Di = GA(Dinv) + 6 * gl;
         const double d00 = Di[0], d10 = Di[1], d11 = Di[2], d20 = Di[3], d21 = Di[4], d22 = Di[5];
         double wi[18];
@@ -1109,7 +1109,7 @@ struct IbaTeamLock {
 // (packing was 2.5x the device time of a batch) and rebases them when it lays the chunks out in the upload blob.
 struct IbaPack {
     std::vector<int> kf_xoff, free_kf, edge_kf, edge_point, pt_start, kf_edges, in1, in2, in_color, kf_task_start, pair_task_start;
-    std::vector<int4> pair_ent;
+    std::vector<int2> pair_ent;
     std::vector<int4> kf_task, pair_task;
     std::vector<uint8_t> kf_imu, edge_stereo, edge_close, in_robust;
     std::vector<double> edge_obs, edge_is2, in_pre, in_info, in_info_g, in_info_a, kfs, pts;
@@ -1232,8 +1232,8 @@ static int iba_pack_range(const orbhip_iba_window *wins, int w0, int w1, double 
                         const bool twin = b2 != a2 && i == j;
                         if (!pass) pcount[pair_id(i, j) + 1] += twin ? 2 : 1;
                         else {
-                            pair_ent[pbase + ppos[pair_id(i, j)]++] = make_int4(sw ? fe[b2].second : fe[a2].second, sw ? fe[a2].second : fe[b2].second, l, 0);
-                            if (twin) pair_ent[pbase + ppos[pair_id(i, j)]++] = make_int4(fe[b2].second, fe[a2].second, l, 0);
+                            pair_ent[pbase + ppos[pair_id(i, j)]++] = make_int2(sw ? fe[b2].second : fe[a2].second, sw ? fe[a2].second : fe[b2].second);
+                            if (twin) pair_ent[pbase + ppos[pair_id(i, j)]++] = make_int2(fe[b2].second, fe[a2].second);
                         }
                     }
             }
@@ -1358,7 +1358,7 @@ static int iba_create_impl(orbhip_ctx *ctx, const orbhip_iba_window *wins, int n
     const size_t o_win = B.alloc(sizeof(IbaWin) * (size_t)n_windows);
     const size_t o_xoff = lay(&IbaPack::kf_xoff, 4), o_imu = lay(&IbaPack::kf_imu, 1), o_free = lay(&IbaPack::free_kf, 4), o_ekf = lay(&IbaPack::edge_kf, 4),
                  o_ept = lay(&IbaPack::edge_point, 4), o_obs = lay(&IbaPack::edge_obs, 8), o_is2 = lay(&IbaPack::edge_is2, 8), o_est = lay(&IbaPack::edge_stereo, 1),
-                 o_ecl = lay(&IbaPack::edge_close, 1), o_pst = lay(&IbaPack::pt_start, 4), o_ked = lay(&IbaPack::kf_edges, 4), o_pre = lay(&IbaPack::pair_ent, 16),
+                 o_ecl = lay(&IbaPack::edge_close, 1), o_pst = lay(&IbaPack::pt_start, 4), o_ked = lay(&IbaPack::kf_edges, 4), o_pre = lay(&IbaPack::pair_ent, 8),
                  o_ktk = lay(&IbaPack::kf_task, 16), o_kts = lay(&IbaPack::kf_task_start, 4), o_ptk = lay(&IbaPack::pair_task, 16),
                  o_pts = lay(&IbaPack::pair_task_start, 4), o_in1 = lay(&IbaPack::in1, 4), o_in2 = lay(&IbaPack::in2, 4), o_col = lay(&IbaPack::in_color, 4),
                  o_rob = lay(&IbaPack::in_robust, 1), o_ipr = lay(&IbaPack::in_pre, 8), o_inf = lay(&IbaPack::in_info, 8), o_ig = lay(&IbaPack::in_info_g, 8),
@@ -1411,7 +1411,7 @@ static int iba_create_impl(orbhip_ctx *ctx, const orbhip_iba_window *wins, int n
     A.win = CP(IbaWin, o_win); A.kf_xoff = CP(int, o_xoff); A.kf_imu = CP(uint8_t, o_imu); A.free_kf = CP(int, o_free);
     A.edge_kf = CP(int, o_ekf); A.edge_point = CP(int, o_ept); A.edge_obs = CP(double, o_obs); A.edge_is2 = CP(double, o_is2);
     A.edge_stereo = CP(uint8_t, o_est); A.edge_close = CP(uint8_t, o_ecl); A.pt_start = CP(int, o_pst);
-    A.kf_edges = CP(int, o_ked); A.pair_ent = CP(int4, o_pre); A.kf_task = CP(int4, o_ktk); A.kf_task_start = CP(int, o_kts);
+    A.kf_edges = CP(int, o_ked); A.pair_ent = CP(int2, o_pre); A.kf_task = CP(int4, o_ktk); A.kf_task_start = CP(int, o_kts);
     A.pair_task = CP(int4, o_ptk); A.pair_task_start = CP(int, o_pts); A.in_kf1 = CP(int, o_in1); A.in_kf2 = CP(int, o_in2);
     A.in_color = CP(int, o_col); A.in_robust = CP(uint8_t, o_rob); A.in_pre = CP(double, o_ipr); A.in_info = CP(double, o_inf);
     A.in_info_g = CP(double, o_ig); A.in_info_a = CP(double, o_ia);
