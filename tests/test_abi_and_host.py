@@ -196,3 +196,18 @@ def test_reference_call_lines_compile_against_the_host_classes(tmp_path):
         defined += subprocess.run(["nm", "-C", "--defined-only", o], stdout=subprocess.PIPE, text=True).stdout
     missing = [w for w in wanted if w not in defined]
     assert not missing, missing
+
+
+def test_every_environment_variable_the_library_reads_is_documented():
+    """INTEGRATION.md section 5 lists every ORBHIP_* variable the sources read (getenv / the tune_int hook): a switch nobody can look up is
+    a behaviour nobody can reproduce."""
+    import glob
+    import re
+    names = set()
+    for f in glob.glob(os.path.join(ROOT, "orb-slam3-mac_amd", "csrc", "*")) + glob.glob(os.path.join(ROOT, "orb-slam3-mac_amd", "host", "*")):
+        if os.path.isfile(f):
+            names |= set(re.findall(r'(?:getenv|tune_int)\("(ORBHIP_[A-Z0-9_]+)"', open(f, errors="ignore").read()))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert len(names) > 20
+    missing = sorted(n for n in names if n not in doc)
+    assert not missing, missing
