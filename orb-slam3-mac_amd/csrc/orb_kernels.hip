@@ -1607,7 +1607,9 @@ __device__ __forceinline__ v4i bm_as_v4i(uint4 v) { v4i r; r[0] = (int)v.x; r[1]
 __global__ __launch_bounds__(256) void k_blur_mfma(OrbParams P, int frame0, int nframes)
 {
     const int per_frame = P.bm_cols[P.nlevels];
-    const unsigned wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // XCD-contiguous order: the four tile columns of a workgroup span 128 + 32 columns, so raw neighbours (dealt to different L2s) fetched
+    // the 128-byte lines at their seams twice or three times (2.5 GB read per 1024 VGA frames against 0.98 GB of pixels, profiles/r04_pmc_traffic)
+    const unsigned wid = xcd_logical_id(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
     const int fr = (int)(wid / (unsigned)per_frame), rem = (int)(wid - (unsigned)fr * (unsigned)per_frame);
     if (fr >= nframes) return;

@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB = os.path.join(ROOT, "oracle", "liborb_oracle.so")
+LIB = os.environ.get("ORB_ORACLE_LIB") or os.path.join(ROOT, "oracle", "liborb_oracle.so")      # (override: the sanitizer build, oracle/Makefile `asan`)
 lib = C.CDLL(LIB)
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
