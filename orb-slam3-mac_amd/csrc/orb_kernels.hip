@@ -917,10 +917,13 @@ void orb_launch_fast_cells(const FastParams &F_, hipStream_t s, int max_per_cu, 
     const long total = runs ? (long)F.batch * ((F.lvl_hi < F.nlevels ? F.lv[F.lvl_hi].run_base : F.runs_per_frame) - F.lv[F.lvl_lo].run_base)
                             : (long)F.batch * ((F.lvl_hi < F.nlevels ? F.lv[F.lvl_hi].cell_base : F.cells_per_frame) - F.lv[F.lvl_lo].cell_base);
     if (nblocks > total) nblocks = (total + 7) / 8 * 8;
-    // chunks of up to 16 consecutive cells (8 runs): they share aprons and level parameters; at least ~8 chunks per wave so that the shares even out
+    // chunks of up to 4 consecutive cells (8 runs): they share aprons and level parameters; at least ~8 chunks per wave so that the shares even out.
+    // (Round 4: 16 -> 4 cells.  The waves of an XCD work on neighbouring chunks at the same time, so the seam and apron lines of the k-th cells
+    // of neighbouring chunks are touched together, but the last cell of one chunk and the first of the next 15 cell times (~0.1 ms) apart --
+    // long after the line left the 4 MB L2.  1024 VGA frames: step 3.59 -> 3.55 ms at 4, 3.68 at 32; 1 and 2 lose to the per-chunk decode.)
     static const int chunk_env = getenv("ORBHIP_TUNE_FAST_CHUNK") ? atoi(getenv("ORBHIP_TUNE_FAST_CHUNK")) : 0;
     const long fair = total / (8 * nblocks);
-    const int cmax = runs ? 8 : 16;
+    const int cmax = runs ? 8 : 4;
     F.chunk = chunk_env > 0 ? chunk_env : (int)(fair < 1 ? 1 : fair > cmax ? cmax : fair);
     if (runs && nld == 4) hipLaunchKernelGGL(k_fast_runs<4>, dim3((unsigned)nblocks), dim3(64), lds, s, F);
     else if (runs) hipLaunchKernelGGL(k_fast_runs<6>, dim3((unsigned)nblocks), dim3(64), lds, s, F);
