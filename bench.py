@@ -263,6 +263,10 @@ def parse_args(argv=None):
                     help="1 = strictly serial steps (default).  > 1: the K steps alternate between this many independent pipelines (own "
                          "context, extractor, HIP streams and match buffers; every step is still one full pass over one resident batch); "
                          "paid +7 %% before the blur became an LDS-free kernel that fills k_fast_cells' idle slots, nothing since")
+    ap.add_argument("--serial-matchers", action="store_true",
+                    help="run the two matchers of a step one after the other on the extraction's stream (the default puts "
+                         "SearchForInitialization on a second context of the same GPU, ordered after the extraction by orbhip_ctx_wait_for: "
+                         "one latency-bound wave per pair beside the matrix-core 2-NN kernel -- 3.53 -> 3.38 ms per step)")
     ap.add_argument("--no-tracking", dest="tracking", action="store_false", help="skip the SearchByProjection legs")
     ap.add_argument("--inertial-windows", type=int, default=32, help="LocalInertialBA windows solved per call (0 = skip)")
     ap.add_argument("--stereo-pairs", type=int, default=None, help="rectified stereo pairs for the ComputeStereoMatches leg (0 = skip)")
@@ -411,16 +415,29 @@ def main():
                                   max_kp, 0.7, d_idx2.data_ptr() + (B - 1) * max_kp * 8,
                                   d_dist2.data_ptr() + (B - 1) * max_kp * 8, d_acc.data_ptr() + (B - 1) * max_kp)
 
-    def windowed():
+    # The two matchers of a step read the same extraction and are independent of each other: the windowed one (one latency-bound wave per
+    # frame pair) runs on a second context of the same GPU beside the matrix-core 2-NN kernel.  orbhip_ctx_wait_for orders the streams:
+    # the windowed matcher after this step's extraction, the next extraction after the windowed matcher (it overwrites what that reads).
+    ctx2 = None if args.serial_matchers else orbhip.Context(local_rank)
+
+    def windowed(c=None):
         # ORBmatcher::SearchForInitialization(frame i, frame i+1) (Tracking.cc:1506-1507: ORBmatcher(0.9,true),
         # windowSize 100) with vbPrevMatched = frame i's keypoint positions (Tracking.cc:1497-1499); B-1 pairs.
+        c = c or ctx
         if B > 1:
-            orbhip.prev_matched_init_device(ctx, kp_p, max_kp, B - 1, max_kp, d_prev.data_ptr())
-            orbhip.search_for_initialization_device(ctx, kp_p, desc_p, cnt_p, kp_p + max_kp * 28, desc_p + dstride, cnt_p + 4,
+            orbhip.prev_matched_init_device(c, kp_p, max_kp, B - 1, max_kp, d_prev.data_ptr())
+            orbhip.search_for_initialization_device(c, kp_p, desc_p, cnt_p, kp_p + max_kp * 28, desc_p + dstride, cnt_p + 4,
                                                     B - 1, max_kp, max_kp, (0.0, 0.0, float(W), float(H)), 100, 0.9, True,
                                                     d_prev.data_ptr(), d_m12.data_ptr(), d_nm.data_ptr())
 
     def step():
+        if ctx2 is not None:
+            ctx.wait_for(ctx2)
+            extract()
+            ctx2.wait_for(ctx)
+            windowed(ctx2)
+            bf_match()
+            return
         extract()
         bf_match()
         windowed()
@@ -508,6 +525,8 @@ def main():
     extract_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / n_prof
 
     ctx.check_status()                                   # loud failure on any device-side capacity overflow
+    if ctx2 is not None:
+        ctx2.check_status()
     res_chk = ext.extract_host(imgs[:min(B, 4)], (0, 0))  # host entry point re-check (raises on capacity errors)
     n_kp_avg = float(np.mean([len(r[0]) for r in res_chk]))
     n_cand_avg = float(np.mean([sum(len(ext.fast_candidates(f, l)[0]) for l in range(8)) for f in range(min(B, 4))]))
@@ -982,13 +1001,19 @@ def main():
         hk, hd_, hc, _ = exh.results_device()
         hs = mk * 32
 
+        cw = ctx2 or ctx                                          # the windowed matcher's context (as in the main line's step)
+
         def leg_step():
+            if ctx2 is not None:
+                ctx.wait_for(ctx2)
             exh.extract_device(dh.data_ptr(), HW, HH, HW, HW * HH, HB, (0, 0))
+            if ctx2 is not None:
+                ctx2.wait_for(ctx)
             orbhip.match_bf2nn_device(ctx, hd_, hc, hs, hd_ + hs, hc + 4, hs, HB - 1, mk, 0.7, h_idx2.data_ptr(), h_dist2.data_ptr(), h_acc.data_ptr())
             orbhip.match_bf2nn_device(ctx, hd_ + (HB - 1) * hs, hc + 4 * (HB - 1), hs, hd_, hc, hs, 1, mk, 0.7, h_idx2.data_ptr() + (HB - 1) * mk * 8,
                                       h_dist2.data_ptr() + (HB - 1) * mk * 8, h_acc.data_ptr() + (HB - 1) * mk)
-            orbhip.prev_matched_init_device(ctx, hk, mk, HB - 1, mk, h_prev.data_ptr())
-            orbhip.search_for_initialization_device(ctx, hk, hd_, hc, hk + mk * 28, hd_ + hs, hc + 4, HB - 1, mk, mk, (0.0, 0.0, float(HW), float(HH)), 100,
+            orbhip.prev_matched_init_device(cw, hk, mk, HB - 1, mk, h_prev.data_ptr())
+            orbhip.search_for_initialization_device(cw, hk, hd_, hc, hk + mk * 28, hd_ + hs, hc + 4, HB - 1, mk, mk, (0.0, 0.0, float(HW), float(HH)), 100,
                                                     0.9, True, h_prev.data_ptr(), h_m12.data_ptr(), h_nm.data_ptr())
         leg_step(); sync()
         t0 = time.perf_counter()
@@ -997,6 +1022,8 @@ def main():
         sync()
         dt_leg = time.perf_counter() - t0
         ctx.check_status()
+        if ctx2 is not None:
+            ctx2.check_status()
         # digest of sampled frames (keypoint records + descriptors as the C ABI returns them) and the oracle's digest of the same frames
         sample = sorted({0, HB // 2, HB - 1})
         got = exh.extract_host(h_imgs[sample], (0, 0))
@@ -1081,8 +1108,11 @@ def main():
                                    "ORB extract + Hamming 2-NN match (Frame.cc:1146) + SearchForInitialization "
                                    "(ORBmatcher.cc:710) vs successor frame" % (args.workload, W, H, B, args.nfeatures),
                        "pipelines": len(steppers),
-                       "pipelines_note": "1 = strictly serial steps; inside a step the blur runs beside k_fast_cells on a second HIP stream; "
-                                         "stage_ms and the roofline come from the separate profiled pass, one kernel at a time",
+                       "pipelines_note": "1 = strictly serial steps; inside a step the blur runs beside k_fast_cells on a second HIP stream"
+                                         + ("" if args.serial_matchers else " and SearchForInitialization beside the 2-NN matcher on a second context "
+                                            "(ordered after the extraction, the next extraction ordered after it)")
+                                         + "; stage_ms and the roofline come from the separate profiled pass, one kernel at a time",
+                       "matchers": "serial" if args.serial_matchers else "side by side (two contexts)",
                        "frames_total": world * B, "ranks_seen": ranks_seen, "collective_backend": backend if distributed else None,
                        "records_gathered": records_gathered,
                        "keypoints_per_frame": round(n_kp_avg, 1), "fast_candidates_per_frame": round(n_cand_avg, 1),

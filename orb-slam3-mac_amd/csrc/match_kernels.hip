@@ -108,8 +108,8 @@ __global__ __launch_bounds__(64 * BFM_WAVES) void k_bf2nn_mfma(const uint8_t *de
                                                     const uint8_t *descB, const int32_t *nB, size_t strideB,
                                                     int max_n, double ratio, int32_t *idx2, int32_t *dist2, uint8_t *accept)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t Bx[BFM_WAVES * 2 * 16 * 64 * 4];      // two tile buffers of 64 x BFM_ROWB bytes; at the end the merge area
-    static_assert(2 * 64 * BFM_ROWB <= BFM_WAVES * 2 * 16 * 64 * 4, "tile buffers fit");
+    __shared__ __attribute__((aligned(16))) uint8_t Bx[2 * 64 * BFM_ROWB];                 // two tile buffers of 64 x BFM_ROWB bytes (34 KB); at the end the merge area
+    static_assert(BFM_WAVES * 2 * 8 * 64 * 4 <= 2 * 64 * BFM_ROWB, "the merge area (half of the rows at a time) fits the tile buffers");
     const int pair = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int na = nA[pair], nb = nB[pair];
     const int q0 = blockIdx.x * (32 * BFM_WAVES);
@@ -180,27 +180,33 @@ __global__ __launch_bounds__(64 * BFM_WAVES) void k_bf2nn_mfma(const uint8_t *de
         if (more) widen(buf ^ 1, nw0);
         __syncthreads();
     }
-    // ---- merge the 32 columns (lanes of one half) of every row: through LDS (the tile buffers are free now), one thread per row
-    uint32_t (*kout)[2][16][64] = reinterpret_cast<uint32_t (*)[2][16][64]>(&Bx[0]);         // [wave][k1 | k2][reg][lane]
+    // ---- merge the 32 columns (lanes of one half) of every row: through LDS (the tile buffers are free now), one thread per row; rows
+    //      0..15 (accumulator registers 0..7) first, then rows 16..31, so that the area is 32 KB and the kernel's LDS stays at the 34 KB of its
+    //      tile buffers (64 KB until round 4: two workgroups filled 128 KB of a CU and no other kernel's workgroup could start beside them)
+    uint32_t (*kout)[2][8][64] = reinterpret_cast<uint32_t (*)[2][8][64]>(&Bx[0]);           // [wave][k1 | k2][reg & 7][lane]
 #pragma unroll
-    for (int g = 0; g < 16; g++) { kout[wave][0][g][lane] = k1[g]; kout[wave][1][g][lane] = k2[g]; }
-    __syncthreads();
-    if (lane < 32) {
-        const int row = lane, g = (row & 3) + 4 * (row >> 3), hh = (row >> 2) & 1;
-        uint32_t kb = 0xFFFFFFFFu, ks = 0xFFFFFFFFu;
-        for (int c = 0; c < 32; c++) {
-            const uint32_t a1 = kout[wave][0][g][32 * hh + c], a2 = kout[wave][1][g][32 * hh + c];
-            ks = min(min(ks, a2), max(kb, a1));                                    // two smallest of {kb, ks, a1, a2} (a1 <= a2, kb <= ks)
-            kb = min(kb, a1);
-        }
-        const int q = q0 + 32 * wave + row;
-        if (q < na) {
-            const bool hb = (kb >> 16) <= 256u, hs = (ks >> 16) <= 256u;            // a real descriptor distance (else: no such neighbour)
-            const int best = hb ? (int)(kb >> 16) : INT_MAX, second = hs ? (int)(ks >> 16) : INT_MAX;
-            const int bi = hb ? (int)(kb & 0xFFFFu) : -1, si = hs ? (int)(ks & 0xFFFFu) : -1;
-            const size_t o = ((size_t)pair * max_n + q) * 2;
-            idx2[o] = bi; idx2[o + 1] = si; dist2[o] = best; dist2[o + 1] = second;
-            accept[(size_t)pair * max_n + q] = (si >= 0 && (double)(float)best < (double)(float)second * ratio) ? 1 : 0;
+    for (int part = 0; part < 2; part++) {
+        if (part) __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 8; g++) { kout[wave][0][g][lane] = k1[8 * part + g]; kout[wave][1][g][lane] = k2[8 * part + g]; }
+        __syncthreads();
+        if (lane < 16) {
+            const int row = 16 * part + lane, g = (row & 3) + 4 * ((row >> 3) & 1), hh = (row >> 2) & 1;
+            uint32_t kb = 0xFFFFFFFFu, ks = 0xFFFFFFFFu;
+            for (int c = 0; c < 32; c++) {
+                const uint32_t a1 = kout[wave][0][g][32 * hh + c], a2 = kout[wave][1][g][32 * hh + c];
+                ks = min(min(ks, a2), max(kb, a1));                                    // two smallest of {kb, ks, a1, a2} (a1 <= a2, kb <= ks)
+                kb = min(kb, a1);
+            }
+            const int q = q0 + 32 * wave + row;
+            if (q < na) {
+                const bool hb = (kb >> 16) <= 256u, hs = (ks >> 16) <= 256u;            // a real descriptor distance (else: no such neighbour)
+                const int best = hb ? (int)(kb >> 16) : INT_MAX, second = hs ? (int)(ks >> 16) : INT_MAX;
+                const int bi = hb ? (int)(kb & 0xFFFFu) : -1, si = hs ? (int)(ks & 0xFFFFu) : -1;
+                const size_t o = ((size_t)pair * max_n + q) * 2;
+                idx2[o] = bi; idx2[o + 1] = si; dist2[o] = best; dist2[o + 1] = second;
+                accept[(size_t)pair * max_n + q] = (si >= 0 && (double)(float)best < (double)(float)second * ratio) ? 1 : 0;
+            }
         }
     }
 }
@@ -410,9 +416,12 @@ __global__ __launch_bounds__(64) void k_search_init(const orbhip_keypoint *kpA_,
                                                     const orbhip_keypoint *kpB_, const uint8_t *descB_, const int32_t *nB,
                                                     int max_n, size_t kp_stride, float min_x, float min_y, float max_x, float max_y,
                                                     int window, float nn_ratio, int check_ori, int cap0, int maxn,
-                                                    float *prev_, int32_t *m12_, int32_t *nmatches_, int32_t *status, const int32_t *redo_)
+                                                    float *prev_, int32_t *m12_, int32_t *nmatches_, int32_t *status, const int32_t *redo_,
+                                                    int32_t *redo_out)
 {
-    if (redo_ && !redo_[blockIdx.x]) return;                      // the replay form (k_si_replay) has done this pair
+    // redo_: only the flagged pairs are done (the others were finished by the replay form, or by the small-LDS launch of this kernel);
+    // redo_out: this launch carves its LDS for cap0 octave-0 points only -- a pair with more is flagged there and left to the next launch
+    if (redo_ && !redo_[blockIdx.x]) { if (redo_out && threadIdx.x == 0) redo_out[blockIdx.x] = 0; return; }
     // dynamic LDS, carved by the launcher's capacities: cap0 octave-0 entries per frame, maxn keypoints per frame
     extern __shared__ __attribute__((aligned(16))) uint8_t si_lds[];
     float *kx = reinterpret_cast<float *>(si_lds), *ky = kx + cap0;
@@ -470,6 +479,10 @@ __global__ __launch_bounds__(64) void k_search_init(const orbhip_keypoint *kpA_,
         if (in && li < cap0) aidx[li] = (uint16_t)i;
         na0 += __popcll(bal);
         if (i < n1) { m12[i] = -1; bin_of[i] = -1; bm[i] = 0xFFFFu; }
+    }
+    if (redo_out) {
+        if (lane == 0) redo_out[pair] = (n0 > cap0 || na0 > cap0) ? 1 : 0;
+        if (n0 > cap0 || na0 > cap0) return;                                    // (m12 was reset, prev is untouched: the next launch starts over)
     }
     if (n0 > cap0 || na0 > cap0) { if (lane == 0) { atomicExch(status, ORBHIP_E_CAPACITY); nmatches_[pair] = 0; } return; }
     __syncthreads();
@@ -833,6 +846,13 @@ extern "C" int orbhip_search_for_initialization_device(orbhip_ctx *ctx,
     // LDS is sized from the caller's row capacity: every keypoint of a frame may be octave 0
     const int maxn = max_n < SI_MAXN ? max_n : SI_MAXN, cap0 = max_n < SI_CAP0 ? max_n : SI_CAP0;
     const size_t lds = (size_t)cap0 * (4 * 4 + 7 * 2) + (size_t)maxn * 3;
+    // Only octave-0 keypoints take part (~0.22 x nFeatures), but any keypoint MAY be one, so the full carve is 33 bytes per keypoint of
+    // capacity: 36 KB per single-wave workgroup at 1100 -- four per CU, and no room beside another kernel's workgroups.  So the pairs are
+    // first tried with LDS for ORBHIP_SI_SMALL_CAP0 (default 512) octave-0 points per frame; a pair with more is flagged on the device and
+    // done by a second launch with the full carve, which returns at once for the others (0 switches the first launch off).
+    const int small_env = getenv("ORBHIP_SI_SMALL_CAP0") ? atoi(getenv("ORBHIP_SI_SMALL_CAP0")) : 512;
+    const int cap0_small = small_env > 0 && small_env < cap0 ? (small_env + 7) & ~7 : 0;
+    const size_t lds_small = (size_t)cap0_small * (4 * 4 + 7 * 2) + (size_t)maxn * 3;
     if (orb_lds_optin(reinterpret_cast<const void *>(k_search_init), orbhip_ctx_device_internal(ctx), lds)) return ORBHIP_E_HIP;
     hipStream_t st = orbhip_ctx_stream_internal(ctx);
     // Up to 512 pairs per call the replay form first (see k_si_replay); pairs it cannot finish are flagged on the device and done by the
@@ -842,6 +862,7 @@ extern "C" int orbhip_search_for_initialization_device(orbhip_ctx *ctx,
     // ORBHIP_SI_PARALLEL_MAX_PAIRS moves the switch (0: the sequential kernel alone; tests run both forms).
     const int par_max = getenv("ORBHIP_SI_PARALLEL_MAX_PAIRS") ? atoi(getenv("ORBHIP_SI_PARALLEL_MAX_PAIRS")) : 512;
     const int32_t *d_redo = nullptr;
+    int32_t *d_redo2 = nullptr;
     {
         SiWork W;
         W.cap0 = ((max_n < SIL_CAP ? max_n : SIL_CAP) + 7) & ~7; W.chunks = (W.cap0 + 63) / 64;
@@ -850,9 +871,14 @@ extern "C" int orbhip_search_for_initialization_device(orbhip_ctx *ctx,
         const size_t o_rec = 0, o_desc = o_rec + al(16 * P * W.cap0), o_aidx = o_desc + al(32 * P * W.cap0), o_n0 = o_aidx + al(2 * P * W.cap0),
                      o_na0 = o_n0 + al(4 * P), o_lkey = o_na0 + al(4 * P), o_lli = o_lkey + al(4 * P * W.chunks * SIL_K * 64),
                      o_count = o_lli + al(2 * P * W.chunks * SIL_K * 64), o_redo = o_count + al(4 * P * W.cap0), total = o_redo + al(4 * P);
-        if (pairs <= par_max && total <= ((size_t)1 << 30)) {
-            uint8_t *wb = (uint8_t *)orbhip_ctx_work_internal(ctx, total);
+        const bool replay = pairs <= par_max && total <= ((size_t)1 << 30);
+        uint8_t *wb = nullptr;
+        if (replay || cap0_small) {                                // (one request: the small launch's flags sit behind the replay form's work area)
+            wb = (uint8_t *)orbhip_ctx_work_internal(ctx, (replay ? total : 0) + (cap0_small ? al(4 * P) : 0));
             if (!wb) return ORBHIP_E_HIP;
+            if (cap0_small) d_redo2 = (int32_t *)(wb + (replay ? total : 0));
+        }
+        if (replay) {
             W.rec = (float4 *)(wb + o_rec); W.desc = (uint4 *)(wb + o_desc); W.aidx = (uint16_t *)(wb + o_aidx); W.n0 = (int32_t *)(wb + o_n0);
             W.na0 = (int32_t *)(wb + o_na0); W.lkey = (uint32_t *)(wb + o_lkey); W.lli = (uint16_t *)(wb + o_lli); W.count = (int32_t *)(wb + o_count);
             W.redo = (int32_t *)(wb + o_redo);
@@ -875,9 +901,15 @@ extern "C" int orbhip_search_for_initialization_device(orbhip_ctx *ctx,
             }
         }
     }
+    if (cap0_small) {
+        hipLaunchKernelGGL(k_search_init, dim3(pairs), dim3(64), lds_small, st, d_kpA, d_descA, d_nA,
+                           d_kpB, d_descB, d_nB, max_n, frame_stride_kp, min_x, min_y, max_x, max_y, window_size, nn_ratio,
+                           check_orientation, cap0_small, maxn, d_prev_matched, d_matches12, d_nmatches, d_status, d_redo, d_redo2);
+        d_redo = d_redo2;
+    }
     hipLaunchKernelGGL(k_search_init, dim3(pairs), dim3(64), lds, st, d_kpA, d_descA, d_nA,
                        d_kpB, d_descB, d_nB, max_n, frame_stride_kp, min_x, min_y, max_x, max_y, window_size, nn_ratio,
-                       check_orientation, cap0, maxn, d_prev_matched, d_matches12, d_nmatches, d_status, d_redo);
+                       check_orientation, cap0, maxn, d_prev_matched, d_matches12, d_nmatches, d_status, d_redo, (int32_t *)nullptr);
     return hipGetLastError() == hipSuccess ? ORBHIP_OK : ORBHIP_E_HIP;
 }
 

@@ -99,12 +99,21 @@ def test_bf2nn_on_extracted_frames(gpu_ctx):
 
 
 # ------------------------------------------------------------------ M3 + M4: SearchForInitialization
-@pytest.fixture(params=["replay", "sequential"])
+@pytest.fixture(params=["replay", "sequential", "sequential-small-lds-off", "sequential-small-lds-64"])
 def si_form(request, monkeypatch):
     """SearchForInitialization has two forms with identical results: candidate lists for all F1 points at once + a replay of the
     vMatchedDistance rule (k_si_prep / k_si_candidates / k_si_replay, the default; pairs it cannot finish fall back on the device) and
-    the sequential one-wave-per-pair loop (k_search_init).  ORBHIP_SI_PARALLEL_MAX_PAIRS=0 keeps the sequential kernel alone."""
+    the sequential one-wave-per-pair loop (k_search_init).  ORBHIP_SI_PARALLEL_MAX_PAIRS=0 keeps the sequential kernel alone.
+    The sequential kernel is launched twice (round 4): with LDS for ORBHIP_SI_SMALL_CAP0 (default 512) octave-0 points per frame first,
+    then with the full carve for the pairs the first launch flagged; 0 switches the first launch off, 64 sends most pairs of these
+    tests through the flag and the second launch."""
     monkeypatch.setenv("ORBHIP_SI_PARALLEL_MAX_PAIRS", "1048576" if request.param == "replay" else "0")
+    if request.param == "sequential-small-lds-off":
+        monkeypatch.setenv("ORBHIP_SI_SMALL_CAP0", "0")
+    elif request.param == "sequential-small-lds-64":
+        monkeypatch.setenv("ORBHIP_SI_SMALL_CAP0", "64")
+    else:
+        monkeypatch.delenv("ORBHIP_SI_SMALL_CAP0", raising=False)
     return request.param
 
 

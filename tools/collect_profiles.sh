@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): kernel trace + stats, and the PMC passes (FETCH_SIZE, WRITE_SIZE, SQ/GRBM) of the default
 # bench workload, each in its own rocprofv3 run (counters never share a run with a trace), then the per-(kernel, grid) summaries.
-# (--pipelines 1: strictly serial steps, so that a dispatch duration is that kernel's own; the default bench line alternates two pipelines)
+# (--pipelines 1 --serial-matchers: every kernel of a step alone on the chip apart from the blur beside FAST, so that a dispatch duration is that kernel's own)
 # usage: tools/collect_profiles.sh <tag> [bench args]   -> gpurun_out/prof_<tag>/ ; copy what should be judged into profiles/
 set -o pipefail
 tag=${1:-rXX}; shift
@@ -9,8 +9,8 @@ root=$PWD
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $root
-ORB="--no-cpu-baseline --ba-graphs 0 --pose-frames 0 --stereo-pairs 0 --inertial-windows 0 --pipelines 1 --no-tracking --no-latency --no-hd-leg --no-4k-leg"
-timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $out/trace -o run --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --stereo-pairs 0 --pipelines 1 --no-tracking --no-latency "$@" > $out/trace.log 2>&1 || { tail -5 $out/trace.log; exit 1; }
+ORB="--no-cpu-baseline --ba-graphs 0 --pose-frames 0 --stereo-pairs 0 --inertial-windows 0 --pipelines 1 --serial-matchers --no-tracking --no-latency --no-hd-leg --no-4k-leg"
+timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $out/trace -o run --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --stereo-pairs 0 --pipelines 1 --serial-matchers --no-tracking --no-latency "$@" > $out/trace.log 2>&1 || { tail -5 $out/trace.log; exit 1; }
 echo trace done
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE -d $out/fetch -o run --output-format csv -- python3 bench.py --steps 2 --warmup 1 $ORB "$@" > $out/fetch.log 2>&1 || { tail -5 $out/fetch.log; exit 1; }
 echo fetch done
