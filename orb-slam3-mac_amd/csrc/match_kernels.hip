@@ -851,7 +851,7 @@ extern "C" int orbhip_search_for_initialization_device(orbhip_ctx *ctx,
     // first tried with LDS for ORBHIP_SI_SMALL_CAP0 (default 512) octave-0 points per frame; a pair with more is flagged on the device and
     // done by a second launch with the full carve, which returns at once for the others (0 switches the first launch off).
     const int small_env = getenv("ORBHIP_SI_SMALL_CAP0") ? atoi(getenv("ORBHIP_SI_SMALL_CAP0")) : 512;
-    const int cap0_small = small_env > 0 && small_env < cap0 ? (small_env + 7) & ~7 : 0;
+    int cap0_small = small_env > 0 && small_env < cap0 ? (small_env + 7) & ~7 : 0;
     const size_t lds_small = (size_t)cap0_small * (4 * 4 + 7 * 2) + (size_t)maxn * 3;
     if (orb_lds_optin(reinterpret_cast<const void *>(k_search_init), orbhip_ctx_device_internal(ctx), lds)) return ORBHIP_E_HIP;
     hipStream_t st = orbhip_ctx_stream_internal(ctx);
@@ -872,6 +872,7 @@ extern "C" int orbhip_search_for_initialization_device(orbhip_ctx *ctx,
                      o_na0 = o_n0 + al(4 * P), o_lkey = o_na0 + al(4 * P), o_lli = o_lkey + al(4 * P * W.chunks * SIL_K * 64),
                      o_count = o_lli + al(2 * P * W.chunks * SIL_K * 64), o_redo = o_count + al(4 * P * W.cap0), total = o_redo + al(4 * P);
         const bool replay = pairs <= par_max && total <= ((size_t)1 << 30);
+        if (replay) cap0_small = 0;                                // behind the replay form the sequential kernel only sees the few pairs that one handed back: one launch
         uint8_t *wb = nullptr;
         if (replay || cap0_small) {                                // (one request: the small launch's flags sit behind the replay form's work area)
             wb = (uint8_t *)orbhip_ctx_work_internal(ctx, (replay ? total : 0) + (cap0_small ? al(4 * P) : 0));
