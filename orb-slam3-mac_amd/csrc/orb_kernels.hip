@@ -492,6 +492,10 @@ __global__ __launch_bounds__(64) void k_fast_cells(FastParams P)
         uint32_t *list = P.cell_list + (size_t)C.frame * P.cell_list_frame_stride + (size_t)cell * C.cell_cap;
         const int key_x0 = 3 + C.cj * C.wcell, key_y0 = 3 + C.ci * C.hcell;
         const int cell_cap = C.cell_cap, tpr = C.tpr, rptT = C.rpt;
+#ifdef FC_PROF
+        __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0): the wait for this cell's staging loads on its own counter
+        FC_T(11);
+#endif
         // ---- (1) stage: PT[r][p] = pixels (ini_x + 2p - 1, ini_x + 2p) of sub-image row r as u16 | u16 << 16
         if (dw > 0) {
             const int last = (dh + 6) * NCH - 1;

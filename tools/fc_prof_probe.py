@@ -35,10 +35,10 @@ ctx.synchronize()
 assert fn(out, 0) == 0
 v = [int(x) for x in out]
 names = ["stage rest", "sync", "necessary test", "arc scores", "nms+emit", "tail"]
-sub = {"stage: lds writes": 8, "stage: next geometry": 9, "stage: issue loads": 10}
+sub = {"stage: wait for the loads": 11, "stage: lds writes": 8, "stage: next geometry": 9, "stage: issue loads": 10}
 tot = v[7]
 res = {"frames": B, "launches": N, "cells": v[6] // N, "wave_cycles_per_launch": tot // N,
        "share": {n: round(v[i] / tot, 4) for i, n in enumerate(names)}, "cycles_per_cell": {n: round(v[i] / max(v[6], 1), 1) for i, n in enumerate(names)},
        "stage_parts_share": {n: round(v[i] / tot, 4) for n, i in sub.items()}, "stage_parts_cycles_per_cell": {n: round(v[i] / max(v[6], 1), 1) for n, i in sub.items()},
-       "unaccounted_share": round(1 - (sum(v[:6]) + sum(v[8:11])) / tot, 4)}
+       "unaccounted_share": round(1 - (sum(v[:6]) + sum(v[8:12])) / tot, 4)}
 print(json.dumps(res))
