@@ -1136,3 +1136,52 @@ def test_ctx_wait_for_orders_two_contexts(gpu_ctx):
         gpu_ctx.synchronize()                                                        # (covers ctx2's work: this context waited for it)
         assert torch.equal(m12, ref) and torch.equal(nm, ref_n), it
     ext.close(); ctx2.close()
+
+
+@pytest.mark.gpu
+def test_two_matchers_side_by_side_equal_the_serial_step(gpu_ctx, monkeypatch):
+    """bench.py's step since round 4: the 2-NN matcher on the extraction's context, SearchForInitialization (sequential form: small-LDS launch +
+    flagged second launch) on a second context beside it, ordered by orbhip_ctx_wait_for both ways.  Every output of both matchers must equal
+    the one-context step's, step after step."""
+    import torch
+    import orbhip
+    monkeypatch.setenv("ORBHIP_SI_PARALLEL_MAX_PAIRS", "0")
+    B, W, H = 48, 640, 480
+    imgs = orbhip.synth_frames(W, H, B, seed=1234, first=0)
+    d = torch.from_numpy(imgs).cuda()
+    ctx2 = orbhip.Context(0)
+    ext = orbhip.Extractor(gpu_ctx, 1000, 1.2, 8, 20, 7); ext.reserve(W, H, B)
+    mk = ext.max_keypoints
+    kp, desc, cnt, _ = ext.results_device(); ds = mk * 32
+    prev = torch.zeros((B, mk, 2), dtype=torch.float32, device="cuda")
+    m12 = torch.full((B, mk), -7, dtype=torch.int32, device="cuda"); nm = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    idx2 = torch.full((B, mk, 2), -9, dtype=torch.int32, device="cuda"); dist2 = torch.full((B, mk, 2), -9, dtype=torch.int32, device="cuda")
+    acc = torch.zeros((B, mk), dtype=torch.uint8, device="cuda")
+
+    def windowed(c):
+        orbhip.prev_matched_init_device(c, kp, mk, B - 1, mk, prev.data_ptr())
+        orbhip.search_for_initialization_device(c, kp, desc, cnt, kp + mk * 28, desc + ds, cnt + 4, B - 1, mk, mk, (0.0, 0.0, float(W), float(H)), 100, 0.9, True,
+                                                prev.data_ptr(), m12.data_ptr(), nm.data_ptr())
+
+    def bf(c):
+        orbhip.match_bf2nn_device(c, desc, cnt, ds, desc + ds, cnt + 4, ds, B - 1, mk, 0.7, idx2.data_ptr(), dist2.data_ptr(), acc.data_ptr())
+
+    ext.extract_device(d.data_ptr(), W, H, W, W * H, B, (0, 0)); bf(gpu_ctx); windowed(gpu_ctx); gpu_ctx.synchronize()
+    gpu_ctx.check_status()
+    ref = [t.clone() for t in (m12, nm, idx2, dist2, acc)]
+    assert int(ref[1].sum()) > 1000 and int(ref[4].sum()) > 1000
+    for it in range(4):
+        for t, v in ((m12, -7), (idx2, -9), (dist2, -9)):
+            t.fill_(v)
+        nm.zero_(); acc.zero_(); torch.cuda.synchronize()
+        for _ in range(3):                                       # three steps back to back, as the bench times them
+            gpu_ctx.wait_for(ctx2)
+            ext.extract_device(d.data_ptr(), W, H, W, W * H, B, (0, 0))
+            ctx2.wait_for(gpu_ctx)
+            windowed(ctx2)
+            bf(gpu_ctx)
+        gpu_ctx.synchronize(); ctx2.synchronize()
+        gpu_ctx.check_status(); ctx2.check_status()
+        for got, want in zip((m12, nm, idx2, dist2, acc), ref):
+            assert torch.equal(got[:B - 1], want[:B - 1]), it
+    ext.close(); ctx2.close()
